@@ -1,0 +1,304 @@
+/*
+ * oracle/df3d_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the integer/index algorithms on the 3D-Dual-Fusion
+ * hot path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product path (3d-dual-fusion_amd/) never does.
+ *
+ * Every function cites the reference file:line whose behaviour it restates
+ * (TF/ = /root/reference/TransFusion, CP/ = /root/reference/CenterPoint).
+ * The restatement is pinned against the reference's own compiled CPU code
+ * (oracle/_ref, see oracle/build_ref.py) and against the golden vectors in
+ * tests/golden/ (tests/test_oracle_*.py).
+ *
+ * Build: gcc -O2 -shared -fPIC -o oracle/libdf3d_oracle.so oracle/df3d_oracle.c -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------
+ * hard voxelisation.
+ * Restates TF/mmdet3d/ops/voxel/src/voxelization_cpu.cpp:7-41 (dynamic_voxelize_kernel:
+ * c = floor((p - min) / vs), reject c<0 || c>=grid, coords stored reversed -> (z,y,x))
+ * and :43-102 (hard_voxelize_kernel: dense coor_to_voxelidx grid, first-appearance
+ * voxel numbering, `break` when a NEW voxel would exceed max_voxels, at most
+ * max_points points per voxel kept in arrival order) and :105-141 (grid_size =
+ * round((max-min)/vs)).
+ * points [P,C] f32; voxels [max_voxels,max_points,C] (caller zero-filled);
+ * coors [max_voxels,3] i32 (z,y,x); num [max_voxels] i32 (caller zero-filled).
+ * Returns voxel_num.
+ * ---------------------------------------------------------------------- */
+int orc_hard_voxelize(const float *points, int P, int C, const float *voxel_size,
+                      const float *range, int max_points, int max_voxels,
+                      float *voxels, int32_t *coors, int32_t *num) {
+  int grid[3];
+  for (int i = 0; i < 3; ++i)
+    grid[i] = (int)roundf((range[3 + i] - range[i]) / voxel_size[i]);
+  size_t vol = (size_t)grid[0] * grid[1] * grid[2];
+  int32_t *c2v = (int32_t *)malloc(vol * sizeof(int32_t));
+  if (!c2v) return -1;
+  memset(c2v, 0xff, vol * sizeof(int32_t)); /* -1 */
+  int voxel_num = 0;
+  for (int i = 0; i < P; ++i) {
+    int coor[3];
+    int failed = 0;
+    for (int j = 0; j < 3; ++j) {
+      /* float arithmetic exactly as the reference: (float - float) / float, then floor */
+      int c = (int)floor((points[(size_t)i * C + j] - range[j]) / voxel_size[j]);
+      if (c < 0 || c >= grid[j]) { failed = 1; break; }
+      coor[2 - j] = c;
+    }
+    if (failed) continue;
+    size_t lin = ((size_t)coor[0] * grid[1] + coor[1]) * grid[0] + coor[2];
+    int vid = c2v[lin];
+    if (vid == -1) {
+      vid = voxel_num;
+      if (max_voxels != -1 && voxel_num >= max_voxels) break;
+      voxel_num += 1;
+      c2v[lin] = vid;
+      for (int k = 0; k < 3; ++k) coors[vid * 3 + k] = coor[k];
+    }
+    int n = num[vid];
+    if (max_points == -1 || n < max_points) {
+      memcpy(voxels + ((size_t)vid * max_points + n) * C, points + (size_t)i * C, sizeof(float) * C);
+      num[vid] += 1;
+    }
+  }
+  free(c2v);
+  return voxel_num;
+}
+
+/* numba variant: CP/det3d/ops/point_cloud/point_cloud_ops.py:7-55
+ * (_points_to_voxel_reverse_kernel).  Identical except that at the max_voxels cap
+ * it `continue`s (later points may still join EXISTING voxels) instead of
+ * breaking the loop, and grid_size is computed as round((max-min)/vs) in numpy. */
+int orc_points_to_voxel_numba(const float *points, int P, int C, const float *voxel_size,
+                              const float *range, int max_points, int max_voxels,
+                              float *voxels, int32_t *coors, int32_t *num) {
+  int grid[3];
+  for (int i = 0; i < 3; ++i)
+    grid[i] = (int)roundf((range[3 + i] - range[i]) / voxel_size[i]);
+  size_t vol = (size_t)grid[0] * grid[1] * grid[2];
+  int32_t *c2v = (int32_t *)malloc(vol * sizeof(int32_t));
+  if (!c2v) return -1;
+  memset(c2v, 0xff, vol * sizeof(int32_t));
+  int voxel_num = 0;
+  for (int i = 0; i < P; ++i) {
+    int coor[3];
+    int failed = 0;
+    for (int j = 0; j < 3; ++j) {
+      int c = (int)floor((points[(size_t)i * C + j] - range[j]) / voxel_size[j]);
+      if (c < 0 || c >= grid[j]) { failed = 1; break; }
+      coor[2 - j] = c;
+    }
+    if (failed) continue;
+    size_t lin = ((size_t)coor[0] * grid[1] + coor[1]) * grid[0] + coor[2];
+    int vid = c2v[lin];
+    if (vid == -1) {
+      vid = voxel_num;
+      if (voxel_num >= max_voxels) continue;
+      voxel_num += 1;
+      c2v[lin] = vid;
+      for (int k = 0; k < 3; ++k) coors[vid * 3 + k] = coor[k];
+    }
+    int n = num[vid];
+    if (n < max_points) {
+      memcpy(voxels + ((size_t)vid * max_points + n) * C, points + (size_t)i * C, sizeof(float) * C);
+      num[vid] += 1;
+    }
+  }
+  free(c2v);
+  return voxel_num;
+}
+
+/* ------------------------------------------------------------------------
+ * rulebook (indice pairs), NDim = 3.
+ * getValidOutPos restates TF/mmdet3d/ops/spconv/include/spconv/geometry.h:24-85:
+ * per axis lowers=(in-(k-1)d-1+s+p)/s, uppers=(in+p)/s (C integer division),
+ * enumerate val=uppers-counter*d with the LAST axis fastest, kernel offset
+ * = sum_j m_j*(in_j - val_j*s_j + p_j)/d_j with m row-major over (z,y,x).
+ * out: [<=K][4] = (z,y,x,offset) of the valid positions; returns their count.
+ * ---------------------------------------------------------------------- */
+static int get_valid_out_pos(const int *in, const int *ks, const int *st, const int *pad,
+                             const int *dil, const int *oshape, int *out) {
+  int lowers[3], uppers[3], counter[3], csize[3];
+  int npts = 1, cnt = 0;
+  for (int i = 0; i < 3; ++i) {
+    lowers[i] = (in[i] - (ks[i] - 1) * dil[i] - 1 + st[i] + pad[i]) / st[i];
+    uppers[i] = (in[i] + pad[i]) / st[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    csize[i] = (uppers[i] - lowers[i]) / dil[i] + 1;
+    npts *= csize[i];
+    counter[i] = 0;
+  }
+  for (int i = 0; i < npts; ++i) {
+    int valid = 1, m = 1, offset = 0;
+    for (int j = 2; j >= 0; --j) {
+      int val = uppers[j] - counter[j] * dil[j];
+      out[cnt * 4 + j] = val;
+      if (val < 0 || val > oshape[j] - 1) valid = 0;
+      offset += m * (in[j] - val * st[j] + pad[j]) / dil[j];
+      m *= ks[j];
+    }
+    out[cnt * 4 + 3] = offset;
+    if (valid) ++cnt;
+    counter[2] += 1;
+    for (int c = 2; c >= 0; --c) {
+      if (counter[c] == csize[c] && c > 0) {
+        counter[c - 1] += 1;
+        counter[c] = 0;
+      }
+    }
+  }
+  return cnt;
+}
+
+/* getIndicePairsSubM (geometry.h:247-297) / getIndicePairsConv (geometry.h:144-192),
+ * with the host-side conventions of getIndicePair<3> (spconv_ops.h:27-141):
+ * subM forces stride 1, pad k/2 (:76-79); indicePairs [K,2,N] prefilled -1,
+ * indiceNum [K] zero, dense grid [B*vol] prefilled -1.
+ * indices [N,4] = (b,z,y,x).  outids [N*K,4] (only written for !subm).
+ * Order = the reference CPU order: out voxels numbered by first touch, pairs per
+ * offset in input order.  Returns numActOut (N for subm). */
+int orc_get_indice_pairs(const int32_t *indices, int N, int batch, const int *out_shape,
+                         const int *ksize, const int *stride, const int *padding,
+                         const int *dilation, int subm, int32_t *outids, int32_t *pairs,
+                         int32_t *num) {
+  int K = ksize[0] * ksize[1] * ksize[2];
+  int st[3], pad[3], dil[3];
+  for (int i = 0; i < 3; ++i) {
+    st[i] = subm ? 1 : stride[i];
+    pad[i] = subm ? ksize[i] / 2 : padding[i];
+    dil[i] = dilation[i];
+  }
+  size_t vol = (size_t)out_shape[0] * out_shape[1] * out_shape[2];
+  int32_t *grid = (int32_t *)malloc(vol * batch * sizeof(int32_t));
+  if (!grid) return -1;
+  memset(grid, 0xff, vol * batch * sizeof(int32_t));
+  for (size_t i = 0; i < (size_t)K * 2 * N; ++i) pairs[i] = -1;
+  for (int k = 0; k < K; ++k) num[k] = 0;
+  int *vp = (int *)malloc(sizeof(int) * K * 4);
+  int numAct = 0;
+  if (subm) {
+    for (int j = 0; j < N; ++j) {
+      const int32_t *p = indices + (size_t)j * 4;
+      size_t idx = ((size_t)p[1] * out_shape[1] + p[2]) * out_shape[2] + p[3] + vol * p[0];
+      grid[idx] = j;
+    }
+    for (int j = 0; j < N; ++j) {
+      const int32_t *p = indices + (size_t)j * 4;
+      int nv = get_valid_out_pos(p + 1, ksize, st, pad, dil, out_shape, vp);
+      for (int i = 0; i < nv; ++i) {
+        const int *q = vp + i * 4;
+        int off = q[3];
+        size_t idx = ((size_t)q[0] * out_shape[1] + q[1]) * out_shape[2] + q[2] + vol * p[0];
+        if (grid[idx] > -1) {
+          pairs[((size_t)off * 2 + 0) * N + num[off]] = j;
+          pairs[((size_t)off * 2 + 1) * N + num[off]] = grid[idx];
+          num[off] += 1;
+        }
+      }
+    }
+    numAct = N;
+  } else {
+    for (int j = 0; j < N; ++j) {
+      const int32_t *p = indices + (size_t)j * 4;
+      int nv = get_valid_out_pos(p + 1, ksize, st, pad, dil, out_shape, vp);
+      for (int i = 0; i < nv; ++i) {
+        const int *q = vp + i * 4;
+        int off = q[3];
+        size_t idx = ((size_t)q[0] * out_shape[1] + q[1]) * out_shape[2] + q[2] + vol * p[0];
+        if (grid[idx] == -1) {
+          outids[(size_t)numAct * 4 + 0] = p[0];
+          outids[(size_t)numAct * 4 + 1] = q[0];
+          outids[(size_t)numAct * 4 + 2] = q[1];
+          outids[(size_t)numAct * 4 + 3] = q[2];
+          grid[idx] = numAct++;
+        }
+        pairs[((size_t)off * 2 + 0) * N + num[off]] = j;
+        pairs[((size_t)off * 2 + 1) * N + num[off]] = grid[idx];
+        num[off] += 1;
+      }
+    }
+  }
+  free(vp);
+  free(grid);
+  return numAct;
+}
+
+/* ------------------------------------------------------------------------
+ * point ops used by LocalTransformer (reference has CUDA only; restated from the
+ * kernels, see SURVEY.md §8c "LocalTransformer").
+ * ---------------------------------------------------------------------- */
+
+/* D-FPS.  CP/det3d/ops/furthest_point_sample/src/furthest_point_sample_cuda.cu:26-141
+ * (kernel) and :9-15,143-205 (block size = largest power of two <= N, capped at 1024,
+ * computed as int(log(N)/log(2)) in double).  Start at index 0; temp[k] (caller's 1e10
+ * fill, furthest_point_sample.py:31) = min(temp[k], d2(k,last)); next = argmax temp.
+ * Tie rule = what the block reduction yields deterministically: each thread keeps
+ * the LOWEST k of its strided sequence (strict '>', :66-67) and the tree reduction
+ * keeps the LOWER tid on ties (__update :17-24), i.e. among maxima the winner has
+ * the smallest (k mod block, k).  xyz [B,N,3]; idx out [B,m]. */
+int orc_fps_block(int n) {
+  int pow_2 = (int)(log((double)n) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > 1024) t = 1024;
+  if (t < 1) t = 1;
+  return t;
+}
+
+void orc_fps(const float *xyz, int B, int N, int m, int32_t *idx) {
+  float *temp = (float *)malloc(sizeof(float) * N);
+  int bs = orc_fps_block(N);
+  for (int b = 0; b < B; ++b) {
+    const float *p = xyz + (size_t)b * N * 3;
+    int32_t *o = idx + (size_t)b * m;
+    for (int k = 0; k < N; ++k) temp[k] = 1e10f;
+    int old = 0;
+    if (m > 0) o[0] = 0;
+    for (int j = 1; j < m; ++j) {
+      float x1 = p[old * 3], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+      float best = -1.f;
+      int besti = 0;
+      for (int k = 0; k < N; ++k) {
+        float x2 = p[k * 3], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+        float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+        float d2 = d < temp[k] ? d : temp[k];
+        temp[k] = d2;
+        if (d2 > best || (d2 == best && (k % bs) < (besti % bs))) { best = d2; besti = k; }
+      }
+      old = besti;
+      o[j] = old;
+    }
+  }
+  free(temp);
+}
+
+/* ball query.  CP/det3d/ops/ball_query/src/ball_query_cuda.cu:11-54: for each centre
+ * scan points in index order; accept if d2 == 0 || (d2 >= min_r2 && d2 < max_r2); on the first
+ * hit fill all nsample slots with it; stop after nsample hits.  idx [B,m,nsample]
+ * (zero-initialised by the caller, as the reference does). */
+void orc_ball_query(const float *new_xyz, const float *xyz, int B, int N, int m,
+                    float min_radius, float max_radius, int nsample, int32_t *idx) {
+  float max_r2 = max_radius * max_radius, min_r2 = min_radius * min_radius;
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < m; ++c) {
+      const float *q = new_xyz + ((size_t)b * m + c) * 3;
+      int32_t *o = idx + ((size_t)b * m + c) * nsample;
+      int cnt = 0;
+      for (int k = 0; k < N && cnt < nsample; ++k) {
+        const float *p = xyz + ((size_t)b * N + k) * 3;
+        float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+        float d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 == 0 || (d2 >= min_r2 && d2 < max_r2)) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) o[l] = k;
+          o[cnt] = k;
+          ++cnt;
+        }
+      }
+    }
+}

@@ -1,0 +1,240 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement (plain C via ctypes for the integer work, numpy for the fp32
+arithmetic) of the reference algorithms on the 3D-Dual-Fusion hot path.  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product package never does and fails loudly without its HIP library.
+
+Pinned (tests/test_oracle_*.py) against
+  * the reference's own compiled CPU code in oracle/_ref (oracle/build_ref.py) and
+  * the golden vectors committed under tests/golden/ (generated from the reference
+    by tests/golden/make_golden.py).
+
+Path shorthand in citations: TF/ = /root/reference/TransFusion, CP/ = /root/reference/CenterPoint.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """gcc-compile oracle/df3d_oracle.c -> oracle/libdf3d_oracle.so."""
+    src = os.path.join(_HERE, "df3d_oracle.c")
+    out = os.path.join(_HERE, "libdf3d_oracle.so")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-ffp-contract=off", "-o", out, src, "-lm"])
+    return out
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+_f32 = ctypes.c_float
+_i32 = ctypes.c_int32
+
+
+# --------------------------------------------------------------------- voxelize
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels, variant="cpp"):
+    """TF/mmdet3d/ops/voxel/src/voxelization_cpu.cpp:43-141 (variant='cpp') or
+    CP/det3d/ops/point_cloud/point_cloud_ops.py:7-55 (variant='numba').
+    Returns voxels [M,max_points,C] f32, coors [M,3] i32 (z,y,x), num [M] i32."""
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    P, C = points.shape
+    cap = max_voxels if max_voxels != -1 else P
+    voxels = np.zeros((cap, max_points, C), np.float32)
+    coors = np.zeros((cap, 3), np.int32)
+    num = np.zeros((cap,), np.int32)
+    vs = np.asarray(voxel_size, np.float32)
+    rg = np.asarray(coors_range, np.float32)
+    fn = lib().orc_hard_voxelize if variant == "cpp" else lib().orc_points_to_voxel_numba
+    n = fn(_p(points, _f32), P, C, _p(vs, _f32), _p(rg, _f32), int(max_points), int(max_voxels),
+           _p(voxels, _f32), _p(coors, _i32), _p(num, _i32))
+    assert n >= 0
+    return voxels[:n], coors[:n], num[:n]
+
+
+def mean_vfe(voxels, num, clamp_min=None):
+    """CP/det3d/models/readers/voxel_encoder.py:17-24 (sum over the padded point axis /
+    num_points); VR/pcdet/models/backbones_3d/vfe/mean_vfe.py:24-29 clamps num >= 1."""
+    n = num.astype(np.float32)
+    if clamp_min is not None:
+        n = np.maximum(n, np.float32(clamp_min))
+    return (voxels.sum(axis=1, dtype=np.float32) / n[:, None]).astype(np.float32)
+
+
+# --------------------------------------------------------------------- rulebook
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    """TF/mmdet3d/ops/spconv/ops.py:20-30."""
+    return [(input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+            for i in range(len(input_size))]
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm):
+    """TF/mmdet3d/ops/spconv/ops.py:46-94 -> spconv_ops.h:27-141 -> geometry.h:144-297 (CPU path).
+    Returns (outids [N_out,4], indice_pairs [K,2,N] (-1 padded), indice_num [K], out_shape),
+    in the reference CPU order (out voxels by first touch, pairs in input order)."""
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    N = indices.shape[0]
+    K = int(np.prod(ksize))
+    if subm:
+        out_shape = list(spatial_shape)
+    else:
+        out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
+    outids = np.zeros((max(N * K, 1), 4), np.int32)
+    pairs = np.empty((K, 2, max(N, 1)), np.int32)
+    num = np.zeros((K,), np.int32)
+    arr = lambda v: np.asarray(v, np.int32)
+    os_, ks_, st_, pd_, dl_ = arr(out_shape), arr(ksize), arr(stride), arr(padding), arr(dilation)
+    n_out = lib().orc_get_indice_pairs(_p(indices, _i32), N, int(batch_size), _p(os_, _i32), _p(ks_, _i32),
+                                       _p(st_, _i32), _p(pd_, _i32), _p(dl_, _i32), int(bool(subm)),
+                                       _p(outids, _i32), _p(pairs, _i32), _p(num, _i32))
+    assert n_out >= 0
+    pairs = pairs[:, :, :N]
+    if subm:
+        return indices, pairs, num, out_shape
+    return outids[:n_out].copy(), pairs, num, out_shape
+
+
+def canonical_rulebook(outids, pairs, num):
+    """Order-independent form of a rulebook (SURVEY.md §8c 'canonical order'): out voxels sorted
+    by (b,z,y,x); per offset the (in, relabelled-out) pairs sorted.  Returns
+    (outids_sorted, [K arrays of shape [n_k,2]])."""
+    outids = np.asarray(outids)
+    order = np.lexsort((outids[:, 3], outids[:, 2], outids[:, 1], outids[:, 0]))
+    relabel = np.empty(len(order), np.int64)
+    relabel[order] = np.arange(len(order))
+    lists = []
+    for k in range(pairs.shape[0]):
+        n = int(num[k])
+        i = pairs[k, 0, :n].astype(np.int64)
+        o = relabel[pairs[k, 1, :n].astype(np.int64)] if n else np.zeros(0, np.int64)
+        pr = np.stack([i, o], 1)
+        pr = pr[np.lexsort((pr[:, 1], pr[:, 0]))]
+        lists.append(pr)
+    return outids[order], lists
+
+
+# --------------------------------------------------------------------- sparse conv
+def indice_conv(features, filters, pairs, num, num_act_out, subm, inverse=False):
+    """TF/mmdet3d/ops/spconv/include/spconv/spconv_ops.h:260-361 (indiceConv<float>):
+    output = zeros; subM: output = features @ W[argmax num] first (:300-303); then for every
+    other non-empty offset: gather (src/reordering.cc:20-33) -> mm -> scatter-add (:35-50)."""
+    features = np.asarray(features, np.float32)
+    K = pairs.shape[0]
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    W = np.asarray(filters, np.float32).reshape(K, cin, cout)
+    out = np.zeros((num_act_out, cout), np.float32)
+    kmax = int(np.argmax(num))
+    if subm:
+        out[:] = features @ W[kmax]
+    a, b = (1, 0) if inverse else (0, 1)
+    for k in range(K):
+        n = int(num[k])
+        if n <= 0 or (subm and k == kmax):
+            continue
+        buf = features[pairs[k, a, :n]] @ W[k]
+        out[pairs[k, b, :n]] += buf  # out rows are unique within one offset
+    return out
+
+
+def batchnorm_eval(x, weight, bias, mean, var, eps):
+    """nn.BatchNorm1d in eval mode (eps 1e-3 everywhere on the path, CP/.../scn.py:108-109)."""
+    return ((x - mean) / np.sqrt(var + np.float32(eps)) * weight + bias).astype(np.float32)
+
+
+def dense(features, indices, spatial_shape, batch_size):
+    """TF/mmdet3d/ops/spconv/structure.py:5-18,55-64: zeros [B,*S,C] <- index_put, permute to [B,C,*S]."""
+    C = features.shape[1]
+    res = np.zeros([batch_size] + list(spatial_shape) + [C], np.float32)
+    ind = np.asarray(indices, np.int64)
+    res[ind[:, 0], ind[:, 1], ind[:, 2], ind[:, 3]] = features
+    return np.ascontiguousarray(res.transpose(0, 4, 1, 2, 3))
+
+
+# --------------------------------------------------------------------- MSDA
+def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights):
+    """Multi-scale deformable attention forward.  Restates the semantics of
+    CP/det3d/models/model_utils/ops/functions/ms_deform_attn_func.py:41-61
+    (grid_sample bilinear, align_corners=False, zero padding) == the CUDA kernel
+    ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299 (h_im = loc_h*H - 0.5, corners outside
+    contribute 0).  value [N,S,M,D]; shapes [(H,W)..]; loc [N,Lq,M,L,P,2] (x,y in [0,1]);
+    weights [N,Lq,M,L,P] -> out [N,Lq,M*D]."""
+    value = np.asarray(value, np.float32)
+    loc = np.asarray(sampling_locations, np.float32)
+    aw = np.asarray(attention_weights, np.float32)
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    out = np.zeros((N, Lq, M, D), np.float32)
+    start = 0
+    nn = np.arange(N)[:, None, None, None]
+    mm = np.arange(M)[None, None, :, None]
+    for l, (H, W) in enumerate(spatial_shapes):
+        H, W = int(H), int(W)
+        v = value[:, start:start + H * W].reshape(N, H, W, M, D)
+        start += H * W
+        w_im = loc[:, :, :, l, :, 0] * np.float32(W) - np.float32(0.5)  # [N,Lq,M,P]
+        h_im = loc[:, :, :, l, :, 1] * np.float32(H) - np.float32(0.5)
+        h0 = np.floor(h_im).astype(np.int64)
+        w0 = np.floor(w_im).astype(np.int64)
+        lh = (h_im - h0).astype(np.float32)
+        lw = (w_im - w0).astype(np.float32)
+        acc = np.zeros((N, Lq, M, P, D), np.float32)
+        for dh, dw, wt in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw),
+                           (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
+            hh, ww = h0 + dh, w0 + dw
+            ok = (hh >= 0) & (hh < H) & (ww >= 0) & (ww < W)
+            hc, wc = np.clip(hh, 0, H - 1), np.clip(ww, 0, W - 1)
+            g = v[nn, hc, wc, mm]  # [N,Lq,M,P,D]
+            acc += g * (wt * ok)[..., None].astype(np.float32)
+        out += (acc * aw[:, :, :, l, :, None]).sum(axis=3, dtype=np.float32)
+    return out.reshape(N, Lq, M * D)
+
+
+# --------------------------------------------------------------------- point ops
+def furthest_point_sample(xyz, m):
+    """CP/det3d/ops/furthest_point_sample/src/furthest_point_sample_cuda.cu:26-141."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    B, N, _ = xyz.shape
+    idx = np.zeros((B, m), np.int32)
+    lib().orc_fps(_p(xyz, _f32), B, N, int(m), _p(idx, _i32))
+    return idx
+
+
+def ball_query(min_radius, max_radius, nsample, xyz, new_xyz):
+    """CP/det3d/ops/ball_query/src/ball_query_cuda.cu:11-54 (idx zero-initialised by the
+    wrapper ball_query.py)."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    new_xyz = np.ascontiguousarray(new_xyz, np.float32)
+    B, N, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = np.zeros((B, m, nsample), np.int32)
+    lib().orc_ball_query.argtypes = [ctypes.POINTER(_f32), ctypes.POINTER(_f32), ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, _f32, _f32, ctypes.c_int, ctypes.POINTER(_i32)]
+    lib().orc_ball_query(_p(new_xyz, _f32), _p(xyz, _f32), B, N, m, float(min_radius), float(max_radius),
+                         int(nsample), _p(idx, _i32))
+    return idx
+
+
+def group_points(features, idx):
+    """CP/det3d/ops/group_points/src/group_points_cuda.cu:56-78: out[b,c,p,s] = feat[b,c,idx[b,p,s]]."""
+    B = features.shape[0]
+    return np.stack([features[b][:, idx[b]] for b in range(B)], 0)
+
+
+def gather_points(features, idx):
+    """CP/det3d/ops/gather_points/src/gather_points_cuda.cu:8-24: out[b,c,p] = feat[b,c,idx[b,p]]."""
+    B = features.shape[0]
+    return np.stack([features[b][:, idx[b]] for b in range(B)], 0)

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz FROM THE REFERENCE ITSELF.
+
+Runs only where /root/reference exists (this container).  Sources of truth:
+  * oracle/_ref/voxel_layer.so, sparse_conv_ext.so  = the reference's own C++ CPU code
+    (TF/mmdet3d/ops/voxel/src/voxelization_cpu.cpp, TF/mmdet3d/ops/spconv/src/*.cc),
+    compiled by oracle/build_ref.py;
+  * the reference's Python modules imported from /root/reference/CenterPoint/det3d with
+    dependency stubs in sys.modules (cv2 / torchvision / mmcv / the CUDA-only extension
+    modules are absent here; the stubs only satisfy `import`, no reference arithmetic is
+    replaced except MSDeformAttnFunction.apply -> the reference's OWN pure-torch
+    ms_deform_attn_core_pytorch, exactly what the reference's ops/test.py compares the
+    CUDA kernel with);
+  * literal expected values copied as DATA from the reference's tests
+    (TF/tests/test_models/test_voxel_encoder/test_voxel_generator.py:15-22).
+The fixtures are data: inputs (or the seeds that regenerate them, tests/golden/detgen.py)
+and expected outputs.  No reference source text is stored.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "3d-dual-fusion_amd"))
+sys.path.insert(0, HERE)
+
+import detgen  # noqa: E402
+from oracle import ref  # noqa: E402
+from dualfusion import synth  # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote %s (%.1f KB)" % (name, os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------ voxelize
+def gen_voxelize():
+    out = {}
+    # (a) the reference's own golden vector, test_voxel_generator.py:6-22
+    np.random.seed(0)
+    pts = np.random.rand(1000, 4).astype(np.float32)
+    v, c, n = ref.hard_voxelize(pts, [0.5, 0.5, 0.5], [0, -40, -3, 70.4, 40, 1], 1000, 20000)
+    out["tg_points"] = pts
+    out["tg_expected_coors"] = np.array([[7, 81, 1], [6, 81, 0], [7, 80, 1], [6, 81, 1],
+                                         [7, 81, 0], [6, 80, 1], [7, 80, 0], [6, 80, 0]], np.int32)
+    out["tg_expected_num"] = np.array([120, 121, 127, 134, 115, 127, 125, 131], np.int32)
+    out["tg_ref_coors"], out["tg_ref_num"] = c, n
+    out["tg_ref_voxel_sum"] = v.sum(1)
+    # (b) nuScenes-shaped sweep slice, no cap / cap hit / max_points hit
+    sw = synth.nusc_sweep(seed=7)[:6000]
+    out["sw_points"] = sw
+    for tag, maxp, maxv in (("nocap", 10, 20000), ("cap", 10, 3000), ("mp3", 3, 20000)):
+        v, c, n = ref.hard_voxelize(sw, synth.NUSC_VOXEL, synth.NUSC_RANGE, maxp, maxv)
+        out["sw_%s_coors" % tag], out["sw_%s_num" % tag] = c, n
+        out["sw_%s_voxel_sum" % tag] = v.sum(1)
+        out["sw_%s_first" % tag] = v[:, 0].copy()
+        out["sw_%s_params" % tag] = np.array([maxp, maxv], np.int64)
+    save("voxelize.npz", **out)
+
+
+# ------------------------------------------------------------------ rulebook + conv
+RB_CASES = {
+    # name: (ksize, stride, padding, dilation, subm, cin, cout)
+    "subm3": ([3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], 1, 16, 16),
+    "conv_s2p1": ([3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], 0, 16, 32),
+    "conv_s2p011": ([3, 3, 3], [2, 2, 2], [0, 1, 1], [1, 1, 1], 0, 8, 16),
+    "conv_k311": ([3, 1, 1], [2, 1, 1], [0, 0, 0], [1, 1, 1], 0, 16, 16),
+    "subm3_c5": ([3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], 1, 5, 16),
+}
+RB_SHAPE = [11, 40, 36]
+RB_BATCH = 2
+
+
+def rb_indices():
+    return detgen.clustered_voxels("rb", RB_BATCH, RB_SHAPE, n_seeds=6, walk=260)
+
+
+def gen_rulebook_conv():
+    ind = rb_indices()
+    out = {"indices": ind, "shape": np.array(RB_SHAPE), "batch": np.array(RB_BATCH)}
+    for name, (ks, st, pd, dl, subm, cin, cout) in RB_CASES.items():
+        outids, pairs, num, oshape = ref.get_indice_pairs(ind, RB_BATCH, RB_SHAPE, ks, st, pd, dl, subm)
+        feats = detgen.randn("feat_" + name, (len(ind), cin))
+        filt = detgen.randn("filt_" + name, (ks[0], ks[1], ks[2], cin, cout), 0.2)
+        y = ref.indice_conv(feats, filt, pairs, num, len(outids), subm)
+        out[name + "_outids"] = outids
+        out[name + "_pairs"] = pairs
+        out[name + "_num"] = num
+        out[name + "_oshape"] = np.array(oshape)
+        out[name + "_y"] = y
+    save("rulebook_conv.npz", **out)
+
+
+# ------------------------------------------------------------------ reference python import
+def _stub(n, **a):
+    m = types.ModuleType(n)
+    m.__dict__.update(a)
+    sys.modules[n] = m
+    return m
+
+
+def import_reference_actr():
+    R = "/root/reference/CenterPoint/det3d"
+    for pkg, path in [("det3d", R), ("det3d.models", R + "/models"),
+                      ("det3d.models.model_utils", R + "/models/model_utils"),
+                      ("det3d.models.model_utils.ops", R + "/models/model_utils/ops"), ("det3d.ops", R + "/ops")]:
+        _stub(pkg).__path__ = [path]
+    _stub("cv2")
+    tv = _stub("torchvision", __version__="0.25.0")
+    tv.ops = _stub("torchvision.ops")
+    tv.ops.misc = _stub("torchvision.ops.misc", _NewEmptyTensorOp=None)
+    _stub("MultiScaleDeformableAttention")
+
+    class ConvModule(torch.nn.Module):
+        def __init__(s, *a, **k):
+            super().__init__()
+
+    _stub("mmcv")
+    _stub("mmcv.cnn", ConvModule=ConvModule)
+    for n, a in [("det3d.ops.gather_points.gather_points", "gather_points"),
+                 ("det3d.ops.furthest_point_sample.points_sampler", "Points_Sampler"),
+                 ("det3d.ops.group_points.group_points", "QueryAndGroup")]:
+        _stub(n.rsplit(".", 1)[0])
+        _stub(n, **{a: None})
+    actr = importlib.import_module("det3d.models.model_utils.actr")
+    func = importlib.import_module("det3d.models.model_utils.ops.functions.ms_deform_attn_func")
+
+    class _F:
+        apply = staticmethod(lambda v, s, l, loc, w, step: func.ms_deform_attn_core_pytorch(v, s, loc, w))
+
+    importlib.import_module("det3d.models.model_utils.ops.modules.ms_deform_attn").MSDeformAttnFunction = _F
+    return actr, func
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def gen_msda(func):
+    out = {}
+    # (a) the reference's own self-check vector, ops/test.py:21-46 (manual_seed(3), fp32 leg)
+    N, M, D = 1, 2, 2
+    Lq, L, P = 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
+    S = int(sum(h * w for h, w in shapes.tolist()))
+    torch.manual_seed(3)
+    value = torch.rand(N, S, M, D) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2)
+    aw = torch.rand(N, Lq, M, L, P) + 1e-5
+    aw /= aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    y = func.ms_deform_attn_core_pytorch(value, shapes, loc, aw)
+    out.update(t_value=value.numpy(), t_shapes=shapes.numpy(), t_loc=loc.numpy(), t_aw=aw.numpy(), t_out=y.numpy())
+    # (b) hot shape: D=16, M=8, L=1, P=4; locations spill over the border
+    N, M, D, Lq, L, P, H, W = 2, 8, 16, 300, 1, 4, 30, 52
+    value = torch.from_numpy(detgen.randn("msda_h_value", (N, H * W, M, D)))
+    loc = torch.from_numpy(detgen.rand("msda_h_loc", (N, Lq, M, L, P, 2), -0.15, 1.15))
+    aw = torch.softmax(torch.from_numpy(detgen.randn("msda_h_aw", (N, Lq, M, L * P))), -1).view(N, Lq, M, L, P)
+    y = func.ms_deform_attn_core_pytorch(value, torch.as_tensor([(H, W)]), loc, aw)
+    out.update(h_dims=np.array([N, M, D, Lq, L, P, H, W]), h_out=y.numpy())
+    # (c) multi-level, odd head dim
+    N, M, D, Lq, L, P = 3, 4, 6, 50, 3, 2
+    shp = [(9, 13), (5, 7), (3, 4)]
+    S = sum(h * w for h, w in shp)
+    value = torch.from_numpy(detgen.randn("msda_m_value", (N, S, M, D)))
+    loc = torch.from_numpy(detgen.rand("msda_m_loc", (N, Lq, M, L, P, 2), -0.1, 1.1))
+    aw = torch.softmax(torch.from_numpy(detgen.randn("msda_m_aw", (N, Lq, M, L * P))), -1).view(N, Lq, M, L, P)
+    y = func.ms_deform_attn_core_pytorch(value, torch.as_tensor(shp), loc, aw)
+    out.update(m_dims=np.array([N, M, D, Lq, L, P]), m_shapes=np.array(shp), m_out=y.numpy())
+    save("msda.npz", **out)
+
+
+ACTR_CFG = dict(fusion_method="sum", feature_modal="hybrid",
+                hybrid_cfg=dict(attn_layer="BiGateSum1D_2", q_method="sum", q_rep_place=["weight"]),
+                num_bins=80, num_channels=[256], query_num_feat=128, num_enc_layers=2,
+                max_num_ne_voxel=26000, pos_encode_method="depth")
+ACTR_DIMS = dict(n=2, q=150, h=12, w=20)
+
+
+def actr_inputs():
+    d = ACTR_DIMS
+    n, q, h, w = d["n"], d["q"], d["h"], d["w"]
+    v_feat = detgen.randn("actr_v_feat", (n, q, 128))
+    grid = detgen.rand("actr_grid", (n, q, 2))
+    i_feat = detgen.randn("actr_i_feat", (n, 256, h, w))
+    lidar_grid = detgen.rand("actr_lidar", (n, q, 3), -50, 50)
+    v_i_feat = detgen.randn("actr_v_i_feat", (n, q, 256))
+    # zero-padded tail rows, like the per-camera padded batches the adapter builds
+    for a in (v_feat, grid, lidar_grid, v_i_feat):
+        a[1, q - 30:] = 0
+    return v_feat, grid, i_feat, lidar_grid, v_i_feat
+
+
+def gen_actr(actr):
+    model = actr.build(Cfg(ACTR_CFG), model_name="ACTR").eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = detgen.det_state_dict(shapes)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    v_feat, grid, i_feat, lidar_grid, v_i_feat = [torch.from_numpy(a) for a in actr_inputs()]
+    with torch.no_grad():
+        y = model(v_feat=v_feat, grid=grid, i_feats=[i_feat], lidar_grid=lidar_grid, v_i_feat=v_i_feat)
+    names = np.array(sorted(shapes))
+    save("actr.npz", out=y.numpy(), param_names=names,
+         param_shapes=np.array([str(shapes[k]) for k in names]), n_params=np.array(sum(int(np.prod(s)) for s in shapes.values())))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr"]
+    if "voxelize" in which:
+        gen_voxelize()
+    if "rulebook" in which:
+        gen_rulebook_conv()
+    if "msda" in which or "actr" in which:
+        actr, func = import_reference_actr()
+        if "msda" in which:
+            gen_msda(func)
+        if "actr" in which:
+            gen_actr(actr)

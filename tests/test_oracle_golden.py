@@ -1,0 +1,138 @@
+"""The oracle (oracle/oracle.py + oracle/df3d_oracle.c) against the golden vectors that
+tests/golden/make_golden.py generated from the reference's own code, and - when the
+reference build oracle/_ref is present - against that build directly on fresh inputs.
+CPU only."""
+import zlib
+
+import numpy as np
+import pytest
+
+import detgen
+from oracle import oracle as orc
+from oracle import ref
+from dualfusion import synth
+
+from make_golden import RB_CASES, RB_SHAPE, RB_BATCH  # constants only (no reference import at module load)
+
+
+def test_voxelize_reference_test_vector(golden):
+    g = golden("voxelize.npz")
+    v, c, n = orc.hard_voxelize(g["tg_points"], [0.5, 0.5, 0.5], [0, -40, -3, 70.4, 40, 1], 1000, 20000)
+    # literals of TF/tests/test_models/test_voxel_encoder/test_voxel_generator.py:15-22
+    assert np.array_equal(c, g["tg_expected_coors"])
+    assert np.array_equal(n, g["tg_expected_num"])
+    assert np.array_equal(c, g["tg_ref_coors"]) and np.array_equal(n, g["tg_ref_num"])
+    assert np.array_equal(v.sum(1), g["tg_ref_voxel_sum"])
+
+
+@pytest.mark.parametrize("tag", ["nocap", "cap", "mp3"])
+def test_voxelize_sweep(golden, tag):
+    g = golden("voxelize.npz")
+    maxp, maxv = [int(x) for x in g["sw_%s_params" % tag]]
+    v, c, n = orc.hard_voxelize(g["sw_points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, maxp, maxv)
+    assert np.array_equal(c, g["sw_%s_coors" % tag])
+    assert np.array_equal(n, g["sw_%s_num" % tag])
+    assert np.array_equal(v.sum(1), g["sw_%s_voxel_sum" % tag])
+    assert np.array_equal(v[:, 0], g["sw_%s_first" % tag])
+    if tag == "cap":
+        assert len(c) == maxv
+
+
+def test_voxelize_numba_variant_differs_only_at_cap(golden):
+    g = golden("voxelize.npz")
+    a = orc.hard_voxelize(g["sw_points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 20000, "cpp")
+    b = orc.hard_voxelize(g["sw_points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 20000, "numba")
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    a = orc.hard_voxelize(g["sw_points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 3000, "cpp")
+    b = orc.hard_voxelize(g["sw_points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 3000, "numba")
+    assert np.array_equal(a[1], b[1])          # same voxels...
+    assert (b[2] >= a[2]).all() and (b[2] > a[2]).any()   # ...numba keeps filling them after the cap
+
+
+@pytest.mark.parametrize("name", sorted(RB_CASES))
+def test_rulebook_and_conv(golden, name):
+    g = golden("rulebook_conv.npz")
+    ks, st, pd, dl, subm, cin, cout = RB_CASES[name]
+    ind = g["indices"]
+    outids, pairs, num, oshape = orc.get_indice_pairs(ind, RB_BATCH, RB_SHAPE, ks, st, pd, dl, subm)
+    # raw CPU order of the reference, bit-exact
+    assert list(oshape) == list(g[name + "_oshape"])
+    assert np.array_equal(outids, g[name + "_outids"])
+    assert np.array_equal(num, g[name + "_num"])
+    assert np.array_equal(pairs, g[name + "_pairs"])
+    feats = detgen.randn("feat_" + name, (len(ind), cin))
+    filt = detgen.randn("filt_" + name, (ks[0], ks[1], ks[2], cin, cout), 0.2)
+    y = orc.indice_conv(feats, filt, pairs, num, len(outids), subm)
+    np.testing.assert_allclose(y, g[name + "_y"], rtol=0, atol=2e-5)
+
+
+def test_conv_equals_dense_conv3d(golden):
+    """Independent pin of the arithmetic convention (cross-correlation, offset row-major kz,ky,kx)."""
+    import torch
+    g = golden("rulebook_conv.npz")
+    ind = g["indices"]
+    name = "subm3"
+    ks, st, pd, dl, subm, cin, cout = RB_CASES[name]
+    feats = detgen.randn("feat_" + name, (len(ind), cin))
+    filt = detgen.randn("filt_" + name, (3, 3, 3, cin, cout), 0.2)
+    d = torch.from_numpy(orc.dense(feats, ind, RB_SHAPE, RB_BATCH))
+    r = torch.nn.functional.conv3d(d, torch.from_numpy(filt).permute(4, 3, 0, 1, 2), padding=1)
+    r = r[ind[:, 0], :, ind[:, 1], ind[:, 2], ind[:, 3]].numpy()
+    np.testing.assert_allclose(g[name + "_y"], r, atol=2e-5)
+
+
+def test_msda_reference_test_vector(golden):
+    g = golden("msda.npz")
+    y = orc.ms_deform_attn(g["t_value"], g["t_shapes"], g["t_loc"], g["t_aw"])
+    np.testing.assert_allclose(y, g["t_out"], rtol=1e-5, atol=1e-7)
+
+
+def test_msda_hot_and_multilevel(golden):
+    g = golden("msda.npz")
+    N, M, D, Lq, L, P, H, W = [int(x) for x in g["h_dims"]]
+    value = detgen.randn("msda_h_value", (N, H * W, M, D))
+    loc = detgen.rand("msda_h_loc", (N, Lq, M, L, P, 2), -0.15, 1.15)
+    aw = _softmax(detgen.randn("msda_h_aw", (N, Lq, M, L * P))).reshape(N, Lq, M, L, P)
+    np.testing.assert_allclose(orc.ms_deform_attn(value, [(H, W)], loc, aw), g["h_out"], atol=2e-5)
+    N, M, D, Lq, L, P = [int(x) for x in g["m_dims"]]
+    shp = [tuple(int(v) for v in r) for r in g["m_shapes"]]
+    S = sum(h * w for h, w in shp)
+    value = detgen.randn("msda_m_value", (N, S, M, D))
+    loc = detgen.rand("msda_m_loc", (N, Lq, M, L, P, 2), -0.1, 1.1)
+    aw = _softmax(detgen.randn("msda_m_aw", (N, Lq, M, L * P))).reshape(N, Lq, M, L, P)
+    np.testing.assert_allclose(orc.ms_deform_attn(value, shp, loc, aw), g["m_out"], atol=2e-5)
+
+
+def _softmax(x):
+    import torch
+    return torch.softmax(torch.from_numpy(x), -1).numpy()
+
+
+# ---- direct comparison with the compiled reference on fresh inputs (skipped where oracle/_ref is absent)
+needs_ref = pytest.mark.skipif(not ref.available("sparse_conv_ext"), reason="oracle/_ref not built")
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", [0, 1])
+def test_oracle_vs_ref_build_fresh(seed):
+    ind = detgen.clustered_voxels("fresh%d" % seed, 3, [7, 24, 30], n_seeds=5, walk=150)
+    for ks, st, pd, subm in (([3, 3, 3], [1, 1, 1], [1, 1, 1], 1), ([3, 3, 3], [2, 2, 2], [1, 1, 1], 0),
+                             ([3, 1, 1], [2, 1, 1], [0, 0, 0], 0), ([1, 3, 3], [1, 2, 2], [0, 1, 1], 0)):
+        a = orc.get_indice_pairs(ind, 3, [7, 24, 30], ks, st, pd, [1, 1, 1], subm)
+        b = ref.get_indice_pairs(ind, 3, [7, 24, 30], ks, st, pd, [1, 1, 1], subm)
+        for x, y in zip(a[:3], b[:3]):
+            assert np.array_equal(x, y)
+        f = detgen.randn("ff%d" % seed, (len(ind), 12))
+        w = detgen.randn("fw%d" % seed, (ks[0], ks[1], ks[2], 12, 20), 0.2)
+        np.testing.assert_allclose(orc.indice_conv(f, w, a[1], a[2], len(a[0]), subm),
+                                   ref.indice_conv(f, w, b[1], b[2], len(b[0]), subm), atol=2e-5)
+
+
+@needs_ref
+def test_oracle_voxelize_vs_ref_build_fresh():
+    pts = synth.nusc_sweep(seed=11)[:20000]
+    a = orc.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 12000)
+    b = ref.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 12000)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
