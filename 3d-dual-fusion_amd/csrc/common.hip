@@ -1,0 +1,165 @@
+// Error reporting, device queries and the device-wide scan used by the rulebook / voxeliser.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace df3d {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------- scan
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+struct LoadU32 {
+  const uint32_t *p;
+  __device__ uint32_t operator()(size_t i) const { return p[i]; }
+};
+struct LoadPopc {
+  const unsigned long long *p;
+  __device__ uint32_t operator()(size_t i) const { return (uint32_t)__popcll(p[i]); }
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan inside one block of SCAN_TILE items; returns block total in *total (all threads)
+__device__ __forceinline__ void block_excl_scan(uint32_t (&x)[SCAN_ITEMS], uint32_t &total,
+                                                uint32_t *lds /*[SCAN_THREADS/64 + 1]*/) {
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) s += x[i];
+  uint32_t inc = wave_incl_scan(s, lane);
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+    uint32_t v = lds[w];
+    if (w < wave) woff += v;
+    tot += v;
+  }
+  uint32_t run = woff + inc - s;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint32_t v = x[i];
+    x[i] = run;
+    run += v;
+  }
+  total = tot;
+  __syncthreads();
+}
+
+template <typename Loader>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(Loader in, uint32_t *out, size_t n,
+                                                                  uint32_t *sums) {
+  __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t x[SCAN_ITEMS];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) x[i] = (base + i < n) ? in(base + i) : 0u;
+  uint32_t tot;
+  block_excl_scan(x, tot, lds);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i)
+    if (base + i < n) out[base + i] = x[i];
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint32_t *sums, size_t m, uint32_t *total) {
+  __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
+  uint32_t carry = 0;
+  for (size_t start = 0; start < m; start += SCAN_TILE) {
+    size_t base = start + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t x[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) x[i] = (base + i < m) ? sums[base + i] : 0u;
+    uint32_t tot;
+    block_excl_scan(x, tot, lds);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+      if (base + i < m) sums[base + i] = x[i] + carry;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(uint32_t *out, size_t n, const uint32_t *sums) {
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t add = sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i)
+    if (base + i < n) out[base + i] += add;
+}
+
+size_t scan_scratch_bytes(size_t n) { return align_up((n / SCAN_TILE + 2) * sizeof(uint32_t), 256); }
+
+template <typename Loader>
+static int scan_impl(Loader in, uint32_t *out, size_t n, uint32_t *total, void *scratch, size_t scratch_bytes,
+                     hipStream_t stream) {
+  if (n == 0) {
+    if (total) DF3D_HIP(hipMemsetAsync(total, 0, sizeof(uint32_t), stream));
+    return DF3D_OK;
+  }
+  if (scratch_bytes < scan_scratch_bytes(n)) {
+    set_error("scan scratch too small");
+    return DF3D_ENOMEM;
+  }
+  uint32_t *sums = (uint32_t *)scratch;
+  size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(scan_tiles_kernel<Loader>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out, n, sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, sums, nb, total);
+  if (nb > 1)
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, out, n, sums);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total, void *scratch,
+                       size_t scratch_bytes, hipStream_t stream) {
+  return scan_impl(LoadU32{in}, out, n, total, scratch, scratch_bytes, stream);
+}
+int exclusive_scan_popc64(const unsigned long long *words, uint32_t *out, size_t n, uint32_t *total,
+                          void *scratch, size_t scratch_bytes, hipStream_t stream) {
+  return scan_impl(LoadPopc{words}, out, n, total, scratch, scratch_bytes, stream);
+}
+
+}  // namespace df3d
+
+extern "C" {
+
+int df3d_version(void) { return 100; }
+const char *df3d_last_error(void) { return df3d::g_err; }
+
+int df3d_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int df3d_device_arch(char *buf, int buflen) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, 0) != hipSuccess) {
+    df3d::set_error("hipGetDeviceProperties failed");
+    return DF3D_EHIP;
+  }
+  snprintf(buf, buflen, "%s", p.gcnArchName);
+  return DF3D_OK;
+}
+}

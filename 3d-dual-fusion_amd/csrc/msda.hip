@@ -1,0 +1,162 @@
+// Multi-scale deformable attention forward for gfx950.
+//
+// Semantics = the reference kernel ms_deformable_im2col_gpu_kernel
+// (CP/det3d/models/model_utils/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299, bilinear
+// helper :33-84): h_im = loc_h*H - 0.5, w_im = loc_w*W - 0.5; a sample contributes iff
+// -1 < h_im < H and -1 < w_im < W; corners outside the map read 0;
+// out[b,q,m,:] = sum_{l,p} w[b,q,m,l,p] * bilinear(value[b, level l, m, :]).
+//
+// The reference runs one thread per output CHANNEL (16 lanes repeat the same index math and
+// share one 64-byte fetch) in 1024-thread blocks, chunked over the batch by im2col_step.
+// Here a lane owns VEC=4 channels (one 16-byte load per corner), so D=16 needs 4 lanes per
+// (query, head): a wave covers 16 (q, m) pairs = two whole queries of the 8-head layout, its
+// 64 x 16 B stores are one contiguous 1 KiB segment, and the four lanes of a (q, m) group
+// split the sampling points between them: each lane fetches one point's (x, y, w) and the
+// group exchanges them with wave shuffles instead of re-reading them 16 times.
+// Algorithmic bytes: min(N*S*M*D, N*Lq*M*L*P*4*D)*4 + N*Lq*M*L*P*3*4 +
+// N*Lq*M*D*4.  Bound: HBM/L2 gather bandwidth (10 flop per fetched element).
+#include "common.h"
+
+namespace df3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MsdaArgs {
+  const float *value;
+  const int64_t *shapes, *lstart;
+  const float *loc, *aw;
+  float *out;
+  int N, S, M, D, Lq, L, P;
+};
+
+// Fast path: D % 4 == 0 and (D/4) a power of two <= 16 (D = 4, 8, 16, 32, 64).
+template <int LPG /*lanes per (q,m) group = D/4*/>
+__global__ __launch_bounds__(256) void msda_vec4_kernel(MsdaArgs a) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over N*Lq*M*LPG
+  const long long total = (long long)a.N * a.Lq * a.M * LPG;
+  const bool live = gid < total;
+  const long long qm = live ? gid / LPG : (total - 1) / LPG;  // (b*Lq + q)*M + m
+  const int sub = (int)(gid % LPG);
+  const int m = (int)(qm % a.M);
+  const int b = (int)(qm / ((long long)a.M * a.Lq));
+  const int LP = a.L * a.P;
+  const float *loc = a.loc + (size_t)qm * LP * 2;
+  const float *aw = a.aw + (size_t)qm * LP;
+  const int lane = threadIdx.x & 63;
+  const int gbase = lane & ~(LPG - 1);
+  const int qstride = a.M * a.D;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int lp0 = 0; lp0 < LP; lp0 += LPG) {
+    // lane `sub` of the group fetches point lp0+sub
+    float mx = 0.f, my = 0.f, mw = 0.f;
+    int lp = lp0 + sub;
+    if (lp < LP) {
+      mx = loc[lp * 2];
+      my = loc[lp * 2 + 1];
+      mw = aw[lp];
+    }
+    const int cnt = (LP - lp0) < LPG ? (LP - lp0) : LPG;
+    for (int i = 0; i < cnt; ++i) {
+      float lx = __shfl(mx, gbase + i, 64);
+      float ly = __shfl(my, gbase + i, 64);
+      float w = __shfl(mw, gbase + i, 64);
+      int l = (lp0 + i) / a.P;
+      int H = (int)a.shapes[l * 2], W = (int)a.shapes[l * 2 + 1];
+      const float *vbase = a.value + ((size_t)b * a.S + (size_t)a.lstart[l]) * qstride + m * a.D + sub * 4;
+      float h_im = ly * (float)H - 0.5f;
+      float w_im = lx * (float)W - 0.5f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        int h_high = h_low + 1, w_high = w_low + 1;
+        float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        float hh = 1.f - lh, hw = 1.f - lw;
+        f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 v1 = z, v2 = z, v3 = z, v4 = z;
+        const size_t hs = (size_t)W * qstride;
+        if (h_low >= 0 && w_low >= 0) v1 = *(const f32x4 *)(vbase + h_low * hs + (size_t)w_low * qstride);
+        if (h_low >= 0 && w_high <= W - 1) v2 = *(const f32x4 *)(vbase + h_low * hs + (size_t)w_high * qstride);
+        if (h_high <= H - 1 && w_low >= 0) v3 = *(const f32x4 *)(vbase + h_high * hs + (size_t)w_low * qstride);
+        if (h_high <= H - 1 && w_high <= W - 1) v4 = *(const f32x4 *)(vbase + h_high * hs + (size_t)w_high * qstride);
+        float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * w;
+      }
+    }
+  }
+  if (live) *(f32x4 *)(a.out + (size_t)qm * a.D + sub * 4) = acc;
+}
+
+// General path: one thread per output channel (any D).
+__global__ __launch_bounds__(256) void msda_scalar_kernel(MsdaArgs a) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)a.N * a.Lq * a.M * a.D;
+  if (gid >= total) return;
+  const int c = (int)(gid % a.D);
+  const long long qm = gid / a.D;
+  const int m = (int)(qm % a.M);
+  const int b = (int)(qm / ((long long)a.M * a.Lq));
+  const int LP = a.L * a.P;
+  const float *loc = a.loc + (size_t)qm * LP * 2;
+  const float *aw = a.aw + (size_t)qm * LP;
+  const int qstride = a.M * a.D;
+  float acc = 0.f;
+  for (int l = 0; l < a.L; ++l) {
+    int H = (int)a.shapes[l * 2], W = (int)a.shapes[l * 2 + 1];
+    const float *vbase = a.value + ((size_t)b * a.S + (size_t)a.lstart[l]) * qstride + m * a.D + c;
+    for (int p = 0; p < a.P; ++p) {
+      float lx = loc[(l * a.P + p) * 2], ly = loc[(l * a.P + p) * 2 + 1], w = aw[l * a.P + p];
+      float h_im = ly * (float)H - 0.5f;
+      float w_im = lx * (float)W - 0.5f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        int h_high = h_low + 1, w_high = w_low + 1;
+        float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        float hh = 1.f - lh, hw = 1.f - lw;
+        float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        const size_t hs = (size_t)W * qstride;
+        if (h_low >= 0 && w_low >= 0) v1 = vbase[h_low * hs + (size_t)w_low * qstride];
+        if (h_low >= 0 && w_high <= W - 1) v2 = vbase[h_low * hs + (size_t)w_high * qstride];
+        if (h_high <= H - 1 && w_low >= 0) v3 = vbase[h_high * hs + (size_t)w_low * qstride];
+        if (h_high <= H - 1 && w_high <= W - 1) v4 = vbase[h_high * hs + (size_t)w_high * qstride];
+        float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * w;
+      }
+    }
+  }
+  a.out[gid] = acc;
+}
+
+}  // namespace df3d
+
+using namespace df3d;
+
+extern "C" int df3d_ms_deform_attn_forward(const float *value, const int64_t *spatial_shapes,
+                                           const int64_t *level_start_index, const float *sampling_loc,
+                                           const float *attn_weight, int N, int S, int M, int D, int Lq, int L, int P,
+                                           float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
+                 "ms_deform_attn_forward: null argument");
+  DF3D_CHECK_ARG(N >= 0 && S > 0 && M > 0 && D > 0 && Lq >= 0 && L > 0 && P > 0, "ms_deform_attn_forward: bad sizes");
+  if (N == 0 || Lq == 0) return DF3D_OK;
+  MsdaArgs a = {value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S, M, D, Lq, L, P};
+  int lpg = (D % 4 == 0) ? D / 4 : 0;
+  long long total;
+  switch (lpg) {
+#define DF3D_MSDA_CASE(G)                                                                                     \
+  case G:                                                                                                     \
+    total = (long long)N * Lq * M * G;                                                                        \
+    hipLaunchKernelGGL(msda_vec4_kernel<G>, dim3(cdiv(total, 256)), dim3(256), 0, stream, a);                 \
+    break;
+    DF3D_MSDA_CASE(1)
+    DF3D_MSDA_CASE(2)
+    DF3D_MSDA_CASE(4)
+    DF3D_MSDA_CASE(8)
+    DF3D_MSDA_CASE(16)
+#undef DF3D_MSDA_CASE
+    default:
+      total = (long long)N * Lq * M * D;
+      hipLaunchKernelGGL(msda_scalar_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a);
+  }
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}

@@ -1,0 +1,205 @@
+// Point ops of the 3D local self-attention (LocalTransformer) for gfx950:
+// D-FPS, ball query, grouping, gathering.  Semantics (including the FPS tie rule) follow
+// the reference CUDA kernels cited in include/df3d_hip.h; the oracle restates them in C.
+//
+// FPS is inherently sequential over m rounds.  The reference keeps min-distances in global
+// memory and does a 10-level LDS tree reduction (10 barriers) per round.  Here the running
+// min-distances live in REGISTERS (each thread owns points tid, tid+bs, ... exactly like the
+// reference, which makes its tie rule fall out naturally), the arg-max is a 6-step wave64
+// butterfly plus one LDS hop across <= 16 waves (2 barriers per round), and xyz (<= 312 KB at
+// 26 k points) is re-read from L2.  Bound: latency (m x ~1 us per batch element).
+#include <math.h>
+
+#include "common.h"
+
+namespace df3d {
+
+constexpr int FPS_MAXPT = 32;  // points per thread kept in registers (N <= 32 * 1024)
+
+struct Best {
+  float v;
+  int tid, k;
+};
+__device__ __forceinline__ Best better(Best a, Best b) {
+  // larger value wins; on ties the lower thread id (== k mod block) wins, as __update() does
+  bool takeb = (b.v > a.v) || (b.v == a.v && b.tid < a.tid);
+  return takeb ? b : a;
+}
+
+template <bool REG>
+__global__ void fps_kernel(const float *__restrict__ xyz, int N, int m, float *__restrict__ temp_g,
+                           int32_t *__restrict__ idx) {
+  __shared__ float s_v[16];
+  __shared__ int s_t[16], s_k[16];
+  __shared__ int s_old;
+  const int b = blockIdx.x, tid = threadIdx.x, bs = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = (bs + 63) >> 6;
+  const float *p = xyz + (size_t)b * N * 3;
+  float *tg = temp_g + (size_t)b * N;
+  int32_t *o = idx + (size_t)b * m;
+  float temp[FPS_MAXPT];
+#pragma unroll
+  for (int i = 0; i < FPS_MAXPT; ++i) temp[i] = 1e10f;
+  if (!REG)
+    for (int k = tid; k < N; k += bs) tg[k] = 1e10f;
+  int old = 0;
+  if (tid == 0 && m > 0) o[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    float x1 = p[old * 3], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+    Best me = {-1.f, tid, 0};
+    if (REG) {
+#pragma unroll
+      for (int i = 0; i < FPS_MAXPT; ++i) {
+        int k = tid + i * bs;
+        if (k < N) {
+          float x2 = p[k * 3], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+          float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+          float d2 = fminf(d, temp[i]);
+          temp[i] = d2;
+          if (d2 > me.v) {
+            me.v = d2;
+            me.k = k;
+          }
+        }
+      }
+    } else {
+      for (int k = tid; k < N; k += bs) {
+        float x2 = p[k * 3], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+        float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+        float d2 = fminf(d, tg[k]);
+        tg[k] = d2;
+        if (d2 > me.v) {
+          me.v = d2;
+          me.k = k;
+        }
+      }
+    }
+    // wave butterfly (inactive upper lanes of a partial wave hold v = -1 and never win)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      Best ot;
+      ot.v = __shfl_xor(me.v, off, 64);
+      ot.tid = __shfl_xor(me.tid, off, 64);
+      ot.k = __shfl_xor(me.k, off, 64);
+      me = better(me, ot);
+    }
+    if (lane == 0) {
+      s_v[wave] = me.v;
+      s_t[wave] = me.tid;
+      s_k[wave] = me.k;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      Best r = {s_v[0], s_t[0], s_k[0]};
+      for (int w = 1; w < nw; ++w) {
+        Best ot = {s_v[w], s_t[w], s_k[w]};
+        r = better(r, ot);
+      }
+      s_old = r.k;
+      o[j] = r.k;
+    }
+    __syncthreads();
+    old = s_old;
+  }
+}
+
+__global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ new_xyz,
+                                                         const float *__restrict__ xyz, int N, int m, float min_r2,
+                                                         float max_r2, int nsample, int32_t *__restrict__ idx) {
+  __shared__ float tile[1024 * 3];
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = c < m;
+  const float *q = new_xyz + ((size_t)b * m + (live ? c : 0)) * 3;
+  const float nx = q[0], ny = q[1], nz = q[2];
+  int32_t *o = idx + ((size_t)b * m + (live ? c : 0)) * nsample;
+  const float *pts = xyz + (size_t)b * N * 3;
+  int cnt = live ? 0 : nsample;
+  for (int t0 = 0; t0 < N; t0 += 1024) {
+    int tn = N - t0 < 1024 ? N - t0 : 1024;
+    __syncthreads();
+    for (int e = threadIdx.x; e < tn * 3; e += blockDim.x) tile[e] = pts[(size_t)t0 * 3 + e];
+    __syncthreads();
+    if (cnt < nsample) {
+      for (int k = 0; k < tn; ++k) {
+        float x = tile[k * 3], y = tile[k * 3 + 1], z = tile[k * 3 + 2];
+        float d2 = (nx - x) * (nx - x) + (ny - y) * (ny - y) + (nz - z) * (nz - z);
+        if (d2 == 0.f || (d2 >= min_r2 && d2 < max_r2)) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) o[l] = t0 + k;
+          o[cnt] = t0 + k;
+          ++cnt;
+          if (cnt >= nsample) break;
+        }
+      }
+    }
+  }
+}
+
+// out[b,c,p,s] = feat[b,c,idx[b,p,s]]  (gather_points: nsample == 1)
+__global__ __launch_bounds__(256) void group_points_kernel(const float *__restrict__ feat,
+                                                           const int32_t *__restrict__ idx, int C, int N, int np,
+                                                           int ns, float *__restrict__ out) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= np * ns) return;
+  int i = idx[(size_t)b * np * ns + t];
+  out[((size_t)b * C + c) * np * ns + t] = feat[((size_t)b * C + c) * N + i];
+}
+
+}  // namespace df3d
+
+using namespace df3d;
+
+static int fps_block(int n) {
+  // furthest_point_sample_cuda.cu:9-15 (opt_n_threads): largest power of two <= n, <= 1024
+  int pow_2 = (int)(log((double)n) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > 1024) t = 1024;
+  if (t < 1) t = 1;
+  return t;
+}
+
+extern "C" int df3d_furthest_point_sample(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
+                                          void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(xyz && idx && temp, "furthest_point_sample: null argument");
+  DF3D_CHECK_ARG(B >= 0 && N > 0 && m >= 0, "furthest_point_sample: bad sizes");
+  if (B == 0 || m == 0) return DF3D_OK;
+  int bs = fps_block(N);
+  if ((long long)N <= (long long)FPS_MAXPT * bs)
+    hipLaunchKernelGGL(fps_kernel<true>, dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
+  else
+    hipLaunchKernelGGL(fps_kernel<false>, dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_ball_query(const float *new_xyz, const float *xyz, int B, int N, int m, float min_radius,
+                               float max_radius, int nsample, int32_t *idx, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(new_xyz && xyz && idx && nsample > 0, "ball_query: bad arguments");
+  if (B == 0 || m == 0) return DF3D_OK;
+  DF3D_HIP(hipMemsetAsync(idx, 0, (size_t)B * m * nsample * 4, stream));  // ball_query.py zero-inits idx
+  hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(m, 256), B), dim3(256), 0, stream, new_xyz, xyz, N, m,
+                     min_radius * min_radius, max_radius * max_radius, nsample, idx);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_group_points(const float *features, const int32_t *idx, int B, int C, int N, int npoint,
+                                 int nsample, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(features && idx && out, "group_points: null argument");
+  if (B == 0 || C == 0 || npoint == 0 || nsample == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(C <= 65535 && B <= 65535, "group_points: B or C > 65535");
+  hipLaunchKernelGGL(group_points_kernel, dim3(cdiv((long long)npoint * nsample, 256), C, B), dim3(256), 0, stream,
+                     features, idx, C, N, npoint, nsample, out);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_gather_points(const float *features, const int32_t *idx, int B, int C, int N, int npoint,
+                                  float *out, void *stream_) {
+  return df3d_group_points(features, idx, B, C, N, npoint, 1, out, stream_);
+}

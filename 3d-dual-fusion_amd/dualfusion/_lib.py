@@ -1,0 +1,89 @@
+"""ctypes binding of libdf3d_hip.so (the C ABI declared in include/df3d_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or cannot be loaded
+every op raises.  (The CPU restatement in oracle/ is test infrastructure and is never
+imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libdf3d_hip.so")
+
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+c_float = ctypes.c_float
+c_void_p = ctypes.c_void_p
+c_char_p = ctypes.c_char_p
+
+# name -> (restype, argtypes); mirrors include/df3d_hip.h one to one
+SIGNATURES = {
+    "df3d_version": (c_int, []),
+    "df3d_last_error": (c_char_p, []),
+    "df3d_device_count": (c_int, []),
+    "df3d_device_arch": (c_int, [c_char_p, c_int]),
+    "df3d_hard_voxelize_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "df3d_hard_voxelize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_grid_bytes": (c_size_t, [c_int, c_void_p]),
+    "df3d_grid_build": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "df3d_subm_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "df3d_conv_out_indices": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p]),
+    "df3d_conv_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_nbr_to_pairs_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "df3d_nbr_to_pairs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_pairs_to_nbr": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_sparse_conv_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "df3d_sparse_to_dense": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_ms_deform_attn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_furthest_point_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_ball_query": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "df3d_group_points": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_gather_points": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class Df3dError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises loudly when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Df3dError(
+            "libdf3d_hip.so not found at %s: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback on the product path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().df3d_last_error()
+        raise Df3dError("%s failed (rc=%d): %s" % (what or "df3d call", rc, msg.decode() if msg else "?"))
+
+
+def int3(v):
+    """host int[3] argument"""
+    arr = (c_int * 3)(*[int(x) for x in v])
+    return ctypes.cast(arr, c_void_p), arr  # keep `arr` alive in the caller
+
+
+def float_arr(v):
+    arr = (c_float * len(v))(*[float(x) for x in v])
+    return ctypes.cast(arr, c_void_p), arr

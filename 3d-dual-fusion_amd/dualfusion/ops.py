@@ -1,0 +1,264 @@
+"""Tensor-level wrappers over the C ABI (include/df3d_hip.h).
+
+PyTorch supplies device memory and the current HIP stream; all arithmetic happens in
+libdf3d_hip.so.  Inputs must be contiguous tensors on one GPU, as the reference's bindings
+require (ms_deform_attn_cuda.cu:28-38).  Nothing here falls back to the CPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.Df3dError("%s must live on the GPU (got %s); the MI355X path has no CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise _lib.Df3dError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.Df3dError("%s must be contiguous" % name)
+    return t
+
+
+# ------------------------------------------------------------------------- voxelize
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels, break_at_cap=True,
+                  want_voxels=True, want_mean=True):
+    """-> (voxels [M,T,C] or None, coors [M,3] int32 (z,y,x), num [M] int32, mean [M,C] or None).
+    One D2H read of the voxel count (the reference op returns it as a Python int too)."""
+    lib = _lib.load()
+    _chk(points, torch.float32, "points")
+    P, C = points.shape
+    cap = P if (max_voxels < 0 or max_voxels > P) else int(max_voxels)
+    dev = points.device
+    voxels = torch.empty((cap, max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
+    coors = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    mean = torch.empty((cap, C), dtype=torch.float32, device=dev) if want_mean else None
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    wsb = lib.df3d_hard_voxelize_workspace_bytes(P, int(max_points), cap)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+    vs_p, vs_keep = _lib.float_arr(list(voxel_size))
+    rg_p, rg_keep = _lib.float_arr(list(coors_range))
+    rc = lib.df3d_hard_voxelize(_ptr(points), P, C, vs_p, rg_p, int(max_points), cap, int(bool(break_at_cap)),
+                                _ptr(voxels), _ptr(coors), _ptr(num), _ptr(mean), _ptr(count), _ptr(ws), wsb,
+                                _stream())
+    _lib.check(rc, "df3d_hard_voxelize")
+    n = int(count.item())
+    return (voxels[:n] if voxels is not None else None, coors[:n], num[:n], mean[:n] if mean is not None else None)
+
+
+# ------------------------------------------------------------------------- rulebook
+class GridDirectory(object):
+    """Occupancy directory of a voxel set (see csrc/rulebook.hip)."""
+
+    def __init__(self, blob, perm, batch, shape):
+        self.blob, self.perm, self.batch, self.shape = blob, perm, int(batch), [int(s) for s in shape]
+
+
+def grid_build(indices, batch, shape, rows_sorted=False):
+    lib = _lib.load()
+    _chk(indices, torch.int32, "indices")
+    shp_p, keep = _lib.int3(shape)
+    nbytes = lib.df3d_grid_bytes(int(batch), shp_p)
+    blob = torch.empty((nbytes,), dtype=torch.uint8, device=indices.device)
+    n = indices.shape[0]
+    perm = None if rows_sorted else torch.empty((max(n, 1),), dtype=torch.int32, device=indices.device)
+    rc = lib.df3d_grid_build(_ptr(indices), n, int(batch), shp_p, _ptr(blob), nbytes, _ptr(perm), _stream())
+    _lib.check(rc, "df3d_grid_build")
+    return GridDirectory(blob, perm, batch, shape)
+
+
+def subm_neighbors(grid, indices, ksize, dilation=(1, 1, 1)):
+    lib = _lib.load()
+    n = indices.shape[0]
+    K = int(ksize[0] * ksize[1] * ksize[2])
+    nbr = torch.empty((K, n), dtype=torch.int32, device=indices.device)
+    shp_p, k1 = _lib.int3(grid.shape)
+    ks_p, k2 = _lib.int3(ksize)
+    dl_p, k3 = _lib.int3(dilation)
+    rc = lib.df3d_subm_neighbors(_ptr(grid.blob), _ptr(grid.perm), _ptr(indices), n, grid.batch, shp_p, ks_p, dl_p,
+                                 _ptr(nbr), _stream())
+    _lib.check(rc, "df3d_subm_neighbors")
+    return nbr
+
+
+def conv_out_indices(indices, batch, in_shape, out_shape, ksize, stride, padding, dilation=(1, 1, 1)):
+    """-> (out_indices [n_out,4] sorted by flat index, GridDirectory of the outputs).  One D2H read (n_out)."""
+    lib = _lib.load()
+    _chk(indices, torch.int32, "indices")
+    n = indices.shape[0]
+    K = int(ksize[0] * ksize[1] * ksize[2])
+    vol_out = int(batch) * int(out_shape[0]) * int(out_shape[1]) * int(out_shape[2])
+    # per axis an input feeds at most ceil(k/s) outputs
+    fan = 1
+    for d in range(3):
+        fan *= -(-int(ksize[d]) // int(stride[d]))
+    cap = max(min(n * min(fan, K), vol_out), 1)
+    osh_p, k0 = _lib.int3(out_shape)
+    nbytes = lib.df3d_grid_bytes(int(batch), osh_p)
+    blob = torch.empty((nbytes,), dtype=torch.uint8, device=indices.device)
+    out_ind = torch.empty((cap, 4), dtype=torch.int32, device=indices.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=indices.device)
+    ish_p, k1 = _lib.int3(in_shape)
+    ks_p, k2 = _lib.int3(ksize)
+    st_p, k3 = _lib.int3(stride)
+    pd_p, k4 = _lib.int3(padding)
+    dl_p, k5 = _lib.int3(dilation)
+    rc = lib.df3d_conv_out_indices(_ptr(indices), n, int(batch), ish_p, osh_p, ks_p, st_p, pd_p, dl_p, _ptr(blob),
+                                   nbytes, _ptr(out_ind), cap, _ptr(count), _stream())
+    _lib.check(rc, "df3d_conv_out_indices")
+    n_out = int(count.item())
+    if n_out > cap:
+        raise _lib.Df3dError("conv_out_indices: %d outputs exceed the capacity bound %d" % (n_out, cap))
+    return out_ind[:n_out], GridDirectory(blob, None, batch, out_shape)
+
+
+def conv_neighbors(in_grid, out_indices, ksize, stride, padding, dilation=(1, 1, 1)):
+    lib = _lib.load()
+    n_out = out_indices.shape[0]
+    K = int(ksize[0] * ksize[1] * ksize[2])
+    nbr = torch.empty((K, n_out), dtype=torch.int32, device=out_indices.device)
+    ish_p, k1 = _lib.int3(in_grid.shape)
+    ks_p, k2 = _lib.int3(ksize)
+    st_p, k3 = _lib.int3(stride)
+    pd_p, k4 = _lib.int3(padding)
+    dl_p, k5 = _lib.int3(dilation)
+    rc = lib.df3d_conv_neighbors(_ptr(in_grid.blob), _ptr(in_grid.perm), _ptr(out_indices), n_out, in_grid.batch,
+                                 ish_p, ks_p, st_p, pd_p, dl_p, _ptr(nbr), _stream())
+    _lib.check(rc, "df3d_conv_neighbors")
+    return nbr
+
+
+def nbr_to_pairs(nbr, n_in):
+    """reference-format rulebook: (indice_pairs [K,2,n_in] int32 -1 padded, indice_num [K] int32)."""
+    lib = _lib.load()
+    K, n_out = nbr.shape
+    pairs = torch.empty((K, 2, max(n_in, 1)), dtype=torch.int32, device=nbr.device)
+    num = torch.empty((K,), dtype=torch.int32, device=nbr.device)
+    wsb = lib.df3d_nbr_to_pairs_workspace_bytes(K, n_out)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=nbr.device)
+    rc = lib.df3d_nbr_to_pairs(_ptr(nbr), K, n_out, max(n_in, 1), _ptr(pairs), _ptr(num), _ptr(ws), wsb, _stream())
+    _lib.check(rc, "df3d_nbr_to_pairs")
+    return pairs[:, :, :n_in], num
+
+
+def pairs_to_nbr(indice_pairs, indice_num, n_out):
+    lib = _lib.load()
+    _chk(indice_pairs, torch.int32, "indice_pairs")
+    K, _, n_in = indice_pairs.shape
+    num_host = indice_num.to("cpu", torch.int32).contiguous()
+    nbr = torch.empty((K, n_out), dtype=torch.int32, device=indice_pairs.device)
+    rc = lib.df3d_pairs_to_nbr(_ptr(indice_pairs), ctypes.c_void_p(num_host.data_ptr()), K, n_in, n_out, _ptr(nbr),
+                               _stream())
+    _lib.check(rc, "df3d_pairs_to_nbr")
+    return nbr
+
+
+# ------------------------------------------------------------------------- sparse conv
+def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shift=None, residual=None, relu=False):
+    """out[o] = act((sum_k features[nbr[k,o]] @ filters[k] + bias) * scale + shift + residual)."""
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    _chk(filters, torch.float32, "filters")
+    _chk(nbr, torch.int32, "nbr")
+    n_in, cin = features.shape
+    cout = filters.shape[-1]
+    K = nbr.shape[0]
+    if filters.numel() != K * cin * cout:
+        raise _lib.Df3dError("filters %s do not match K=%d cin=%d" % (tuple(filters.shape), K, cin))
+    for t, nm in ((bias, "bias"), (scale, "scale"), (shift, "shift"), (residual, "residual")):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
+    rc = lib.df3d_sparse_conv_fused(_ptr(features), n_in, cin, _ptr(filters), K, cout, _ptr(nbr), n_out, _ptr(bias),
+                                    _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out), _stream())
+    _lib.check(rc, "df3d_sparse_conv_fused")
+    return out
+
+
+def sparse_to_dense(features, indices, batch, shape):
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    _chk(indices, torch.int32, "indices")
+    n, C = features.shape
+    out = torch.empty([int(batch), C] + [int(s) for s in shape], dtype=torch.float32, device=features.device)
+    shp_p, keep = _lib.int3(shape)
+    rc = lib.df3d_sparse_to_dense(_ptr(features), _ptr(indices), n, C, int(batch), shp_p, _ptr(out), _stream())
+    _lib.check(rc, "df3d_sparse_to_dense")
+    return out
+
+
+# ------------------------------------------------------------------------- MSDA
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+    lib = _lib.load()
+    _chk(value, torch.float32, "value")
+    _chk(spatial_shapes, torch.int64, "spatial_shapes")
+    _chk(level_start_index, torch.int64, "level_start_index")
+    _chk(sampling_locations, torch.float32, "sampling_locations")
+    _chk(attention_weights, torch.float32, "attention_weights")
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
+    rc = lib.df3d_ms_deform_attn_forward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index),
+                                         _ptr(sampling_locations), _ptr(attention_weights), N, S, M, D, Lq, L, P,
+                                         _ptr(out), _stream())
+    _lib.check(rc, "df3d_ms_deform_attn_forward")
+    return out
+
+
+# ------------------------------------------------------------------------- point ops
+def furthest_point_sample(xyz, m):
+    lib = _lib.load()
+    _chk(xyz, torch.float32, "xyz")
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
+    temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device)
+    rc = lib.df3d_furthest_point_sample(_ptr(xyz), B, N, int(m), _ptr(temp), _ptr(idx), _stream())
+    _lib.check(rc, "df3d_furthest_point_sample")
+    return idx
+
+
+def ball_query(min_radius, max_radius, nsample, xyz, new_xyz):
+    lib = _lib.load()
+    _chk(xyz, torch.float32, "xyz")
+    _chk(new_xyz, torch.float32, "new_xyz")
+    B, N, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.empty((B, m, nsample), dtype=torch.int32, device=xyz.device)
+    rc = lib.df3d_ball_query(_ptr(new_xyz), _ptr(xyz), B, N, m, float(min_radius), float(max_radius), int(nsample),
+                             _ptr(idx), _stream())
+    _lib.check(rc, "df3d_ball_query")
+    return idx
+
+
+def group_points(features, idx):
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    _chk(idx, torch.int32, "idx")
+    B, C, N = features.shape
+    _, npoint, nsample = idx.shape
+    out = torch.empty((B, C, npoint, nsample), dtype=torch.float32, device=features.device)
+    rc = lib.df3d_group_points(_ptr(features), _ptr(idx), B, C, N, npoint, nsample, _ptr(out), _stream())
+    _lib.check(rc, "df3d_group_points")
+    return out
+
+
+def gather_points(features, idx):
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    _chk(idx, torch.int32, "idx")
+    B, C, N = features.shape
+    npoint = idx.shape[1]
+    out = torch.empty((B, C, npoint), dtype=torch.float32, device=features.device)
+    rc = lib.df3d_gather_points(_ptr(features), _ptr(idx), B, C, N, npoint, _ptr(out), _stream())
+    _lib.check(rc, "df3d_gather_points")
+    return out

@@ -1,0 +1,274 @@
+"""Parity tests proper: the HIP path (through the C ABI, libdf3d_hip.so) against the oracle on
+the same seeded inputs and against the golden fixtures generated from the reference.
+Bit-exact for voxel indices / rulebooks (canonical order); fp32 results within
+1e-3 (north_star), in practice ~1e-5.  Run with -m gpu on a MI355X."""
+import numpy as np
+import pytest
+
+import detgen
+from make_golden import RB_BATCH, RB_CASES, RB_SHAPE
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from dualfusion import _lib
+    lib = _lib.load()
+    buf = __import__("ctypes").create_string_buffer(64)
+    assert lib.df3d_device_arch(buf, 64) == 0
+    assert buf.value.decode().startswith("gfx950"), buf.value
+    return torch.device("cuda:0")
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+# ------------------------------------------------------------------------- voxelize
+@pytest.mark.parametrize("tag", ["nocap", "cap", "mp3"])
+def test_voxelize_golden(golden, dev, tag):
+    from dualfusion import ops, synth
+    g = golden("voxelize.npz")
+    maxp, maxv = [int(x) for x in g["sw_%s_params" % tag]]
+    v, c, n, mean = ops.hard_voxelize(T(g["sw_points"], dev), synth.NUSC_VOXEL, synth.NUSC_RANGE, maxp, maxv)
+    assert np.array_equal(c.cpu().numpy(), g["sw_%s_coors" % tag])
+    assert np.array_equal(n.cpu().numpy(), g["sw_%s_num" % tag])
+    assert np.array_equal(v[:, 0].cpu().numpy(), g["sw_%s_first" % tag])
+    ov, oc, on = orc.hard_voxelize(g["sw_points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, maxp, maxv)
+    assert np.array_equal(v.cpu().numpy(), ov)           # padded point tensor bit-exact
+    np.testing.assert_allclose(mean.cpu().numpy(), orc.mean_vfe(ov, on), rtol=1e-6, atol=1e-6)
+
+
+def test_voxelize_reference_test_vector(golden, dev):
+    from dualfusion import ops
+    g = golden("voxelize.npz")
+    v, c, n, mean = ops.hard_voxelize(T(g["tg_points"], dev), [0.5, 0.5, 0.5], [0, -40, -3, 70.4, 40, 1], 1000, 20000)
+    assert np.array_equal(c.cpu().numpy(), g["tg_expected_coors"])
+    assert np.array_equal(n.cpu().numpy(), g["tg_expected_num"])
+
+
+@pytest.mark.parametrize("break_at_cap", [True, False])
+def test_voxelize_full_sweep_vs_oracle(dev, break_at_cap):
+    from dualfusion import ops, synth
+    pts = synth.nusc_sweep(seed=3)
+    for maxv in (120000, 30000):
+        v, c, n, mean = ops.hard_voxelize(T(pts, dev), synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, maxv,
+                                          break_at_cap=break_at_cap)
+        ov, oc, on = orc.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, maxv,
+                                       "cpp" if break_at_cap else "numba")
+        assert np.array_equal(c.cpu().numpy(), oc)
+        assert np.array_equal(n.cpu().numpy(), on)
+        assert np.array_equal(v.cpu().numpy(), ov)
+
+
+def test_voxelize_edge_cases(dev):
+    from dualfusion import ops, synth
+    # no point in range
+    pts = np.full((100, 5), 1e4, np.float32)
+    v, c, n, mean = ops.hard_voxelize(T(pts, dev), synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 1000)
+    assert c.shape[0] == 0 and n.shape[0] == 0
+    # every point in ONE voxel, more points than max_points
+    pts = np.zeros((500, 5), np.float32)
+    pts[:, 3] = np.arange(500)
+    v, c, n, mean = ops.hard_voxelize(T(pts, dev), synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 1000)
+    assert c.shape[0] == 1 and int(n[0]) == 10
+    assert np.array_equal(v[0, :, 3].cpu().numpy(), np.arange(10, dtype=np.float32))   # arrival order
+    # points exactly on the upper range boundary are dropped, lower boundary kept
+    pts = np.array([[54.0, 0, 0, 1, 0], [-54.0, 0, 0, 2, 0], [0, 0, 3.0, 3, 0], [0, 0, -5.0, 4, 0]], np.float32)
+    v, c, n, mean = ops.hard_voxelize(T(pts, dev), synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 1000)
+    ov, oc, on = orc.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 1000)
+    assert np.array_equal(c.cpu().numpy(), oc) and np.array_equal(v.cpu().numpy(), ov)
+
+
+# ------------------------------------------------------------------------- rulebook
+def _hip_rulebook(ind_t, batch, shape, ks, st, pd, dl, subm):
+    from dualfusion import ops
+    if subm:
+        grid = ops.grid_build(ind_t, batch, shape)
+        nbr = ops.subm_neighbors(grid, ind_t, ks, dl)
+        return ind_t, nbr, list(shape)
+    oshape = orc.get_conv_output_size(shape, ks, st, pd, dl)
+    grid = ops.grid_build(ind_t, batch, shape)
+    outids, ogrid = ops.conv_out_indices(ind_t, batch, shape, oshape, ks, st, pd, dl)
+    nbr = ops.conv_neighbors(grid, outids, ks, st, pd, dl)
+    return outids, nbr, oshape
+
+
+@pytest.mark.parametrize("name", sorted(RB_CASES))
+def test_rulebook_and_conv_golden(golden, dev, name):
+    from dualfusion import ops
+    g = golden("rulebook_conv.npz")
+    ks, st, pd, dl, subm, cin, cout = RB_CASES[name]
+    ind = g["indices"]
+    ind_t = T(ind, dev)
+    outids, nbr, oshape = _hip_rulebook(ind_t, RB_BATCH, RB_SHAPE, ks, st, pd, dl, subm)
+    pairs, num = ops.nbr_to_pairs(nbr, len(ind))
+    # canonical-order comparison with the reference build's rulebook: bit-exact
+    ref_out, ref_lists = orc.canonical_rulebook(g[name + "_outids"], g[name + "_pairs"], g[name + "_num"])
+    my_out, my_lists = orc.canonical_rulebook(outids.cpu().numpy(), pairs.cpu().numpy(), num.cpu().numpy())
+    assert np.array_equal(my_out, ref_out)
+    assert np.array_equal(num.cpu().numpy(), g[name + "_num"])
+    for a, b in zip(my_lists, ref_lists):
+        assert np.array_equal(a, b)
+    if not subm:  # strided outputs come out sorted by flat index (the reference GPU path's order)
+        assert np.array_equal(outids.cpu().numpy(), ref_out)
+    # convolution values: rows follow OUR output order -> map to the reference's order
+    feats = detgen.randn("feat_" + name, (len(ind), cin))
+    filt = detgen.randn("filt_" + name, (ks[0], ks[1], ks[2], cin, cout), 0.2)
+    y = ops.sparse_conv_fused(T(feats, dev), T(filt, dev).reshape(-1, cin, cout), nbr, outids.shape[0]).cpu().numpy()
+    ref_y = g[name + "_y"]
+    if not subm:
+        key = lambda o: [tuple(r) for r in o]
+        pos = {k: i for i, k in enumerate(key(outids.cpu().numpy()))}
+        perm = np.array([pos[k] for k in key(g[name + "_outids"])])
+        y = y[perm]
+    np.testing.assert_allclose(y, ref_y, rtol=1e-3, atol=1e-4)
+    # the reference-format entry: rebuild nbr from pairs and convolve again
+    nbr2 = ops.pairs_to_nbr(pairs.contiguous(), num, outids.shape[0])
+    assert torch.equal(nbr2, nbr)
+
+
+CONV_SHAPES = [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (4, 16), (24, 40)]
+
+
+@pytest.mark.parametrize("cin,cout", CONV_SHAPES)
+@pytest.mark.parametrize("n_seeds", [4, 40])
+def test_sparse_conv_vs_oracle(dev, cin, cout, n_seeds):
+    """All tuned channel shapes + the generic fallback, small and multi-tile sizes, with the fused
+    epilogue (bias, folded BN, residual, ReLU)."""
+    from dualfusion import ops
+    shape, batch = [9, 48, 48], 2
+    ind = detgen.clustered_voxels("cv%d" % n_seeds, batch, shape, n_seeds=n_seeds, walk=200)
+    ind_t = T(ind, dev)
+    feats = detgen.randn("cvf%d_%d" % (cin, n_seeds), (len(ind), cin))
+    filt = detgen.randn("cvw%d_%d" % (cin, cout), (3, 3, 3, cin, cout), 0.5 / np.sqrt(cin))
+    bias = detgen.randn("cvb%d" % cout, (cout,), 0.1)
+    scale = 1 + detgen.randn("cvs%d" % cout, (cout,), 0.1)
+    shift = detgen.randn("cvh%d" % cout, (cout,), 0.1)
+    for subm in (1, 0):
+        ks, st, pd, dl = [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1]
+        o_out, o_pairs, o_num, oshape = orc.get_indice_pairs(ind, batch, shape, ks, st, pd, dl, subm)
+        outids, nbr, _ = _hip_rulebook(ind_t, batch, shape, ks, st, pd, dl, subm)
+        n_out = outids.shape[0]
+        assert n_out == len(o_out)
+        res = detgen.randn("cvr%d" % cout, (n_out, cout))
+        y = ops.sparse_conv_fused(T(feats, dev), T(filt, dev).reshape(-1, cin, cout), nbr, n_out, bias=T(bias, dev),
+                                  scale=T(scale, dev), shift=T(shift, dev), residual=T(res, dev), relu=True)
+        ref = orc.indice_conv(feats, filt, o_pairs, o_num, len(o_out), subm)
+        if not subm:  # oracle rows are in first-touch order; ours sorted
+            pos = {tuple(r): i for i, r in enumerate(o_out.tolist())}
+            ref = ref[[pos[tuple(r)] for r in outids.cpu().numpy().tolist()]]
+        ref = np.maximum((ref + bias) * scale + shift + res, 0)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-4)
+
+
+def test_rulebook_empty_and_single(dev):
+    from dualfusion import ops
+    shape, batch = [5, 8, 8], 1
+    ind = np.array([[0, 2, 3, 4]], np.int32)
+    outids, nbr, _ = _hip_rulebook(T(ind, dev), batch, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], 1)
+    nb = nbr.cpu().numpy()
+    assert nb[13, 0] == 0 and (np.delete(nb[:, 0], 13) == -1).all()
+    outids, nbr, _ = _hip_rulebook(T(ind, dev), batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], 0)
+    o = orc.get_indice_pairs(ind, batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], 0)
+    assert np.array_equal(np.sort(outids.cpu().numpy(), 0), np.sort(o[0], 0))
+
+
+def test_dense(dev):
+    from dualfusion import ops
+    shape, batch = [2, 30, 28], 3
+    ind = detgen.clustered_voxels("dn", batch, shape, n_seeds=5, walk=150)
+    f = detgen.randn("dnf", (len(ind), 128))
+    d = ops.sparse_to_dense(T(f, dev), T(ind, dev), batch, shape)
+    assert np.array_equal(d.cpu().numpy(), orc.dense(f, ind, shape, batch))
+
+
+# ------------------------------------------------------------------------- MSDA
+def _msda(dev, value, shapes, loc, aw):
+    from dualfusion import ops
+    shp = torch.as_tensor(np.asarray(shapes), dtype=torch.long, device=dev)
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    return ops.ms_deform_attn_forward(T(value, dev), shp, lsi, T(loc, dev), T(aw, dev)).cpu().numpy()
+
+
+def _softmax(x):
+    return torch.softmax(torch.from_numpy(x), -1).numpy()
+
+
+def test_msda_golden(golden, dev):
+    g = golden("msda.npz")
+    # the reference's own check tolerances for fp32 (ops/test.py:57): rtol 1e-2, atol 1e-3; we hold 1e-5
+    y = _msda(dev, g["t_value"], g["t_shapes"], g["t_loc"], g["t_aw"])
+    np.testing.assert_allclose(y, g["t_out"], rtol=1e-4, atol=1e-7)
+    N, M, D, Lq, L, P, H, W = [int(x) for x in g["h_dims"]]
+    value = detgen.randn("msda_h_value", (N, H * W, M, D))
+    loc = detgen.rand("msda_h_loc", (N, Lq, M, L, P, 2), -0.15, 1.15)
+    aw = _softmax(detgen.randn("msda_h_aw", (N, Lq, M, L * P))).reshape(N, Lq, M, L, P)
+    np.testing.assert_allclose(_msda(dev, value, [(H, W)], loc, aw), g["h_out"], rtol=1e-3, atol=2e-5)
+    N, M, D, Lq, L, P = [int(x) for x in g["m_dims"]]
+    shp = [tuple(int(v) for v in r) for r in g["m_shapes"]]
+    S = sum(h * w for h, w in shp)
+    value = detgen.randn("msda_m_value", (N, S, M, D))
+    loc = detgen.rand("msda_m_loc", (N, Lq, M, L, P, 2), -0.1, 1.1)
+    aw = _softmax(detgen.randn("msda_m_aw", (N, Lq, M, L * P))).reshape(N, Lq, M, L, P)
+    np.testing.assert_allclose(_msda(dev, value, shp, loc, aw), g["m_out"], rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 5])
+def test_msda_vs_oracle_shapes(dev, D):
+    N, M, Lq, L, P = 2, 8, 333, 2, 3
+    shp = [(17, 23), (9, 11)]
+    S = sum(h * w for h, w in shp)
+    value = detgen.randn("mo_v%d" % D, (N, S, M, D))
+    loc = detgen.rand("mo_l%d" % D, (N, Lq, M, L, P, 2), -0.2, 1.2)
+    aw = _softmax(detgen.randn("mo_a%d" % D, (N, Lq, M, L * P))).reshape(N, Lq, M, L, P)
+    np.testing.assert_allclose(_msda(dev, value, shp, loc, aw), orc.ms_deform_attn(value, shp, loc, aw),
+                               rtol=1e-3, atol=2e-5)
+
+
+def test_msda_linearity_at_full_size(dev):
+    """BASELINE config 2 size (6 cams, 150x267 map, Q=8000): linear in value and in the weights."""
+    from dualfusion import ops
+    N, M, D, Lq, L, P, H, W = 6, 8, 16, 8000, 1, 4, 150, 267
+    g = torch.Generator(device="cpu").manual_seed(0)
+    v1 = torch.randn(N, H * W, M, D, generator=g).to(dev)
+    v2 = torch.randn(N, H * W, M, D, generator=g).to(dev)
+    loc = (torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.2 - 0.1).to(dev)
+    aw = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P).to(dev)
+    shp = torch.as_tensor([(H, W)], dtype=torch.long, device=dev)
+    lsi = shp.new_zeros((1,))
+    f = lambda v, a: ops.ms_deform_attn_forward(v.contiguous(), shp, lsi, loc, a.contiguous())
+    torch.testing.assert_close(f(v1 + 2 * v2, aw), f(v1, aw) + 2 * f(v2, aw), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(f(v1, 0.5 * aw), 0.5 * f(v1, aw), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------- point ops
+def test_fps_ball_group_vs_oracle(dev):
+    from dualfusion import ops
+    B, N, m, ns = 3, 3000, 256, 16
+    xyz = detgen.rand("fps_xyz", (B, N, 3), -20, 20)
+    xyz[1, 2500:] = 0  # zero-padded tail rows (duplicates -> FPS ties), as the ACTR adapter pads
+    idx = ops.furthest_point_sample(T(xyz, dev), m).cpu().numpy()
+    assert np.array_equal(idx, orc.furthest_point_sample(xyz, m))
+    new_xyz = np.stack([xyz[b][idx[b]] for b in range(B)])
+    bq = ops.ball_query(0.0, 4.0, ns, T(xyz, dev), T(new_xyz, dev)).cpu().numpy()
+    assert np.array_equal(bq, orc.ball_query(0.0, 4.0, ns, xyz, new_xyz))
+    feat = detgen.randn("fps_feat", (B, 24, N))
+    gp = ops.group_points(T(feat, dev), T(bq, dev)).cpu().numpy()
+    assert np.array_equal(gp, orc.group_points(feat, bq))
+    ga = ops.gather_points(T(feat, dev), T(idx, dev)).cpu().numpy()
+    assert np.array_equal(ga, orc.gather_points(feat, idx))
+
+
+@pytest.mark.parametrize("N", [50, 64, 1000, 5000])
+def test_fps_block_sizes(dev, N):
+    from dualfusion import ops
+    xyz = detgen.rand("fpsb%d" % N, (2, N, 3), -5, 5)
+    m = min(N, 40)
+    assert np.array_equal(ops.furthest_point_sample(T(xyz, dev), m).cpu().numpy(), orc.furthest_point_sample(xyz, m))
