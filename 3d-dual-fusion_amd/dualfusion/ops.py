@@ -164,6 +164,23 @@ def pairs_to_nbr(indice_pairs, indice_num, n_out):
 
 
 # ------------------------------------------------------------------------- sparse conv
+class KernelTimer(object):
+    """Optional per-launch timing with HIP events recorded on the launching stream (bench.py's
+    roofline leg).  Off unless `ops.TIMER` is set; adds two event records per conv launch."""
+
+    def __init__(self):
+        self.records = []   # (key, start_event, end_event, meta)
+
+    def region(self, key, meta):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        self.records.append((key, a, b, meta))
+        return a, b
+
+
+TIMER = None
+
+
 def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shift=None, residual=None, relu=False):
     """out[o] = act((sum_k features[nbr[k,o]] @ filters[k] + bias) * scale + shift + residual)."""
     lib = _lib.load()
@@ -179,8 +196,13 @@ def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shif
         if t is not None:
             _chk(t, torch.float32, nm)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
+    ev = TIMER.region(("spconv", cin, cout, K), {"n_in": n_in, "n_out": n_out, "nbr": nbr}) if TIMER is not None else None
+    if ev:
+        ev[0].record()
     rc = lib.df3d_sparse_conv_fused(_ptr(features), n_in, cin, _ptr(filters), K, cout, _ptr(nbr), n_out, _ptr(bias),
                                     _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out), _stream())
+    if ev:
+        ev[1].record()
     _lib.check(rc, "df3d_sparse_conv_fused")
     return out
 

@@ -1,0 +1,49 @@
+"""The hot path assembled end to end, the way the reference detectors call it
+(CP/det3d/models/detectors/voxelnet.py:129-188: reader -> backbone(+fuse_func) -> dense BEV).
+
+`CenterPointHotPath` takes raw sweeps that are already resident in HBM and produces the dense
+BEV tensor the 2-D neck consumes.  The camera network is out of scope: its
+output feature maps are an *input* here."""
+import torch
+from torch import nn
+
+from . import synth
+from .backbones import SpMiddleResNetFHD, SpMiddleResNetFHDFusion
+from .voxel import Voxelization
+
+
+class CenterPointHotPath(nn.Module):
+    """voxelize + mean VFE (fused) -> SpMiddleResNetFHD[Fusion] -> dense [B, 256, 180, 180]."""
+
+    def __init__(self, fusion=None, voxel_size=synth.NUSC_VOXEL, pc_range=synth.NUSC_RANGE, max_points=10,
+                 max_voxels=(120000, 160000), num_input_features=5):
+        super(CenterPointHotPath, self).__init__()
+        self.voxel_layer = Voxelization(voxel_size, pc_range, max_points, max_voxels)
+        if fusion is None:
+            self.backbone = SpMiddleResNetFHD(num_input_features=num_input_features)
+        else:
+            self.backbone = SpMiddleResNetFHDFusion(num_input_features=num_input_features)
+        self.fusion = fusion
+        gs = self.voxel_layer.grid_size.tolist()
+        self.grid_size_xyz = [int(gs[0]), int(gs[1]), int(gs[2])]
+
+    @torch.no_grad()
+    def voxelize(self, points_list):
+        """list of [P_b, C] device tensors -> (features [M, C], coors [M, 4] (b,z,y,x) int32).
+        CenterPoint voxelises with the numba kernel's cap semantics (point_cloud_ops.py:46-47)."""
+        feats, coors = [], []
+        for b, pts in enumerate(points_list):
+            mean, c, _ = self.voxel_layer.voxelize_mean(pts, break_at_cap=False)
+            feats.append(mean)
+            coors.append(torch.cat([torch.full((c.shape[0], 1), b, dtype=torch.int32, device=c.device), c], 1))
+        if len(feats) == 1:
+            return feats[0], coors[0]
+        return torch.cat(feats), torch.cat(coors)
+
+    @torch.no_grad()
+    def forward(self, points_list, batch_dict=None, example=None):
+        feats, coors = self.voxelize(points_list)
+        B = len(points_list)
+        if self.fusion is None:
+            return self.backbone(feats, coors, B, self.grid_size_xyz)
+        return self.backbone(feats, batch_dict, coors, B, self.grid_size_xyz, example, fuse_func=self.fusion)

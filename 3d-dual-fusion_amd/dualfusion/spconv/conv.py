@@ -1,0 +1,167 @@
+"""Sparse convolution modules with the reference's constructor arguments, parameter names and
+shapes (weight [kD,kH,kW,Cin,Cout], bias [Cout]; TF/mmdet3d/ops/spconv/conv.py:48-204) so the
+reference's configs and checkpoints load unchanged.  forward() = rulebook (cached per
+indice_key, conv.py:146-172) + ONE fused kernel (csrc/spconv.hip)."""
+import math
+
+import numpy as np
+import torch
+from torch.nn import init
+from torch.nn.parameter import Parameter
+
+from .. import ops as _ops
+from .._lib import Df3dError
+from . import ops
+from .modules import SparseModule
+from .structure import Rulebook, SparseConvTensor
+
+
+def _calculate_fan_in_and_fan_out_hwio(tensor):
+    dimensions = tensor.ndimension()
+    if dimensions < 2:
+        raise ValueError('fan in and fan out can not be computed for tensor with fewer than 2 dimensions')
+    if dimensions == 2:
+        fan_in = tensor.size(-2)
+        fan_out = tensor.size(-1)
+    else:
+        num_input_fmaps = tensor.size(-2)
+        num_output_fmaps = tensor.size(-1)
+        receptive_field_size = 1
+        if tensor.dim() > 2:
+            receptive_field_size = tensor[..., 0, 0].numel()
+        fan_in = num_input_fmaps * receptive_field_size
+        fan_out = num_output_fmaps * receptive_field_size
+    return fan_in, fan_out
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 fused_bn=False):
+        super(SparseConvolution, self).__init__()
+        assert groups == 1
+        lst = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+        kernel_size, stride, padding, dilation = lst(kernel_size), lst(stride), lst(padding), lst(dilation)
+        output_padding = lst(output_padding)
+        for d, s in zip(dilation, stride):
+            assert any([s == 1, d == 1]), "don't support this."
+        self.ndim = ndim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.conv1x1 = np.prod(kernel_size) == 1
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.transposed = transposed
+        self.inverse = inverse
+        self.output_padding = output_padding
+        self.groups = groups
+        self.subm = subm
+        self.indice_key = indice_key
+        self.fused_bn = fused_bn
+        self.weight = Parameter(torch.Tensor(*kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = _calculate_fan_in_and_fan_out_hwio(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            init.uniform_(self.bias, -bound, bound)
+
+    # ------------------------------------------------------------------------------
+    def _rulebook(self, input):
+        """Reuse the rulebook of `indice_key` (conv.py:146-155) or build and register it."""
+        datas = input.find_indice_pair(self.indice_key)
+        if self.inverse:
+            raise Df3dError("SparseInverseConv is not used by the 3D-DF backbones and is not implemented")
+        if self.indice_key is not None and datas is not None:
+            return datas
+        if self.transposed:
+            raise Df3dError("transposed sparse convolution is not implemented on the MI355X path")
+        directory = input.directory()
+        outids, nbr, out_shape, out_dir = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape,
+                                                             self.kernel_size, self.stride, self.padding,
+                                                             self.dilation, self.subm, directory=directory)
+        rb = Rulebook(outids, input.indices, nbr, input.spatial_shape, out_shape, out_rows_sorted=not self.subm)
+        if out_dir is not None and not self.subm:
+            input._directories[(outids.data_ptr(), outids.shape[0])] = out_dir
+        input.indice_dict[self.indice_key] = rb
+        return rb
+
+    def forward_fused(self, input, scale=None, shift=None, relu=False, residual=None):
+        """out = act((conv(x) + bias) * scale + shift + residual): the conv kernel's epilogue."""
+        assert isinstance(input, SparseConvTensor)
+        if self.ndim != 3:
+            raise Df3dError("only SparseConv3d/SubMConv3d are implemented on the MI355X path")
+        if self.conv1x1:
+            feats = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
+            if self.bias is not None:
+                feats = feats + self.bias
+            if scale is not None:
+                feats = feats * scale + shift
+            if residual is not None:
+                feats = feats + residual
+            if relu:
+                feats = torch.relu(feats)
+            out = SparseConvTensor(feats, input.indices, input.spatial_shape, input.batch_size)
+            out.indice_dict, out.grid, out._directories = input.indice_dict, input.grid, input._directories
+            return out
+        rb = self._rulebook(input)
+        feats = input.features
+        if feats.dtype != torch.float32:
+            feats = feats.float()
+        w = self.weight.detach() if not self.weight.requires_grad or not torch.is_grad_enabled() else self.weight
+        if torch.is_grad_enabled() and (self.weight.requires_grad or feats.requires_grad):
+            raise Df3dError("the fused sparse conv is forward-only in this round; wrap inference in torch.no_grad()")
+        K = rb.nbr.shape[0]
+        out_features = _ops.sparse_conv_fused(feats.contiguous(), w.contiguous().view(K, self.in_channels,
+                                                                                      self.out_channels),
+                                              rb.nbr, rb.outids.shape[0],
+                                              bias=self.bias.detach() if self.bias is not None else None,
+                                              scale=scale, shift=shift, residual=residual, relu=relu)
+        out = SparseConvTensor(out_features, rb.outids, rb.out_spatial_shape, input.batch_size)
+        out.indice_dict, out.grid, out._directories = input.indice_dict, input.grid, input._directories
+        return out
+
+    def forward(self, input):
+        return self.forward_fused(input)
+
+
+class SparseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SparseConv2d, self).__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                           groups, bias, indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SparseConv3d, self).__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                           groups, bias, indice_key=indice_key)
+
+
+class SubMConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SubMConv2d, self).__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                                         bias, True, indice_key=indice_key)
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SubMConv3d, self).__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                                         bias, True, indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super(SparseInverseConv3d, self).__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                                                  indice_key=indice_key)

@@ -1,0 +1,101 @@
+"""SparseConvTensor: same container API as the reference's spconv
+(TF/mmdet3d/ops/spconv/structure.py:21-69; spconv 2.x `replace_feature` as probed by
+CP/det3d/models/backbones/scn.py:17-23), backed by the MI355X kernels."""
+import numpy as np
+import torch
+
+from .. import ops as _ops
+
+
+def scatter_nd(indices, updates, shape):
+    """TF/mmdet3d/ops/spconv/structure.py:5-18 (pure tensor op, kept for API parity)."""
+    ret = torch.zeros(*shape, dtype=updates.dtype, device=updates.device)
+    ndim = indices.shape[-1]
+    output_shape = list(indices.shape[:-1]) + shape[indices.shape[-1]:]
+    flatted_indices = indices.view(-1, ndim)
+    slices = [flatted_indices[:, i] for i in range(ndim)]
+    slices += [Ellipsis]
+    ret[slices] = updates.view(*output_shape)
+    return ret
+
+
+class Rulebook(object):
+    """What `indice_dict[key]` holds.  Unpacks like the reference's 5-tuple
+    (outids, indices, indice_pairs, indice_pair_num, spatial_shape) (conv.py:169-172); the
+    reference-format pairs are derived lazily from the neighbour table the kernels use."""
+
+    def __init__(self, outids, indices, nbr, spatial_shape, out_spatial_shape, out_rows_sorted):
+        self.outids, self.indices, self.nbr = outids, indices, nbr
+        self.spatial_shape, self.out_spatial_shape = spatial_shape, out_spatial_shape
+        self.out_rows_sorted = out_rows_sorted
+        self._pairs = None
+
+    def pairs(self):
+        if self._pairs is None:
+            self._pairs = _ops.nbr_to_pairs(self.nbr, self.indices.shape[0])
+        return self._pairs
+
+    def _tuple(self):
+        p, n = self.pairs()
+        return (self.outids, self.indices, p, n, self.spatial_shape)
+
+    def __iter__(self):
+        return iter(self._tuple())
+
+    def __getitem__(self, i):
+        return self._tuple()[i]
+
+    def __len__(self):
+        return 5
+
+
+class SparseConvTensor(object):
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices if indices.dtype == torch.int32 else indices.int()
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {}
+        self.grid = grid
+        # occupancy directories keyed by the identity of the indices tensor they index; shared by
+        # reference with derived tensors exactly like indice_dict
+        self._directories = {}
+
+    # ---- reference API ------------------------------------------------------------
+    @property
+    def spatial_size(self):
+        return np.prod(self.spatial_shape)
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key, None)
+
+    def dense(self, channels_first=True):
+        """[B, C, *spatial] (channels_first) like structure.py:55-64; one fused kernel."""
+        feats = self.features.contiguous()
+        out = _ops.sparse_to_dense(feats, self.indices.contiguous(), self.batch_size, self.spatial_shape)
+        if not channels_first:
+            nd = len(self.spatial_shape)
+            return out.permute(0, *range(2, nd + 2), 1).contiguous()
+        return out
+
+    @property
+    def sparity(self):
+        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+
+    def replace_feature(self, new_features):
+        """spconv 2.x style functional update (scn.py:17-23 probes for it)."""
+        out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self.grid)
+        out.indice_dict = self.indice_dict
+        out._directories = self._directories
+        return out
+
+    # ---- directory cache ----------------------------------------------------------
+    def directory(self, rows_sorted=False):
+        key = (self.indices.data_ptr(), self.indices.shape[0])
+        d = self._directories.get(key)
+        if d is None:
+            d = _ops.grid_build(self.indices.contiguous(), self.batch_size, self.spatial_shape, rows_sorted=rows_sorted)
+            self._directories[key] = d
+        return d

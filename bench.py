@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- sweeps/s of the 3D-Dual-Fusion hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic nuScenes-shaped sweeps that are
+already resident in HBM: voxelize + mean VFE -> sparse 3-D backbone (21 fused sparse convs, 8
+rulebooks) [-> dual-query deformable camera fusion] -> dense BEV [B,256,180,180].
+Frames are independent: ranks process different sweeps, no data-path collective (weak scaling).
+
+Besides the driver contract fields the JSON line carries
+  roofline     : dominant kernel, algorithmic flops or bytes per launch / HIP-event time per launch
+  cpu_baseline : the oracle (CPU restatement of the reference algorithm) timed on this box's host
+                 cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "3d-dual-fusion_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_FP32_MFMA_TF = 157.3   # dense fp32 MFMA (= vector) peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=os.environ.get("DF3D_WORKLOAD", "auto"),
+                    help="cp_fusion (BASELINE configs[1]) | cp_lidar (configs[0] shape) | auto")
+    ap.add_argument("--batch", type=int, default=1, help="sweeps per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(workload, dev):
+    from dualfusion.pipeline import CenterPointHotPath
+    torch.manual_seed(0)
+    fusion = None
+    if workload == "cp_fusion":
+        from dualfusion.fusion import build_centerpoint_fusion
+        fusion = build_centerpoint_fusion()
+    model = CenterPointHotPath(fusion=fusion).eval().to(dev)
+    # BatchNorm running statistics: mean 0 / var 1 defaults
+    return model
+
+
+def make_inputs(workload, batch, rank, dev):
+    from dualfusion import synth
+    pts = [torch.from_numpy(synth.nusc_sweep(seed=rank * 1000 + b)).to(dev) for b in range(batch)]
+    extra = None
+    if workload == "cp_fusion":
+        from dualfusion.fusion import synthetic_camera_inputs
+        extra = synthetic_camera_inputs(batch, dev, seed=1234 + rank)
+    return pts, extra
+
+
+def run_step(model, pts, extra):
+    if extra is None:
+        return model(pts)
+    return model(pts, batch_dict=extra[0], example=extra[1])
+
+
+def conv_algorithmic(meta, cin, cout, K):
+    """bytes = R*Cin*4 + N_out*Cout*4 + 8*R + K*Cin*Cout*4 ; flops = 2*R*Cin*Cout."""
+    R = int((meta["nbr"] >= 0).sum().item())
+    n_out = meta["n_out"]
+    by = R * cin * 4 + n_out * cout * 4 + 8 * R + K * cin * cout * 4
+    fl = 2 * R * cin * cout
+    return R, by, fl
+
+
+def roofline_from_timer(timer):
+    groups = {}
+    for key, a, b, meta in timer.records:
+        ms = a.elapsed_time(b)
+        g = groups.setdefault(key, {"ms": 0.0, "n": 0, "meta": []})
+        g["ms"] += ms
+        g["n"] += 1
+        g["meta"].append(meta)
+    if not groups:
+        return None, {}
+    key = max(groups, key=lambda k: groups[k]["ms"])
+    _, cin, cout, K = key
+    g = groups[key]
+    fl = by = 0
+    cache = {}
+    for m in g["meta"]:
+        ck = (m["nbr"].data_ptr(), m["n_out"])
+        if ck not in cache:
+            cache[ck] = conv_algorithmic(m, cin, cout, K)
+        _, b_, f_ = cache[ck]
+        by += b_
+        fl += f_
+    sec = g["ms"] * 1e-3
+    ai = fl / max(by, 1)
+    avg_us = g["ms"] * 1e3 / g["n"]
+    if ai >= PEAK_FP32_MFMA_TF * 1e12 / (PEAK_HBM_GBS * 1e9):
+        ach = fl / sec / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA_TF, 4)}
+    else:
+        ach = by / sec / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(ach / PEAK_HBM_GBS, 4)}
+    roof.update({"traffic": None, "kernel": "spconv_mfma_kernel<cin=%d,cout=%d,K=%d>" % (cin, cout, K),
+                 "launches": g["n"], "avg_launch_us": round(avg_us, 2),
+                 "algorithmic_flops_per_launch": fl // g["n"], "algorithmic_bytes_per_launch": by // g["n"]})
+    per_kernel = {"%dx%d_k%d" % (k[1], k[2], k[3]): {"ms_total": round(v["ms"], 3), "launches": v["n"]}
+                  for k, v in groups.items()}
+    return roof, per_kernel
+
+
+def cpu_baseline(workload, budget_s=30.0):
+    """The oracle composition (tests/oracle_models.py over oracle/oracle.py) on the SAME synthetic
+    sweep and weights, on this box's host cores.  Bounded: whole sweeps until ~budget_s elapsed."""
+    import detgen  # noqa: F401
+    import oracle_models as om
+    from oracle import oracle as orc
+    from dualfusion import synth
+    from dualfusion.backbones import SpMiddleResNetFHD
+    torch.manual_seed(0)
+    sd = {k: v.numpy() for k, v in SpMiddleResNetFHD(num_input_features=5).state_dict().items()}
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    n, t0 = 0, time.perf_counter()
+    while True:
+        pts = synth.nusc_sweep(seed=n)
+        t1 = time.perf_counter()
+        ov, oc, on = orc.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000, "numba")
+        feats = orc.mean_vfe(ov, on)
+        coors = np.concatenate([np.zeros((len(oc), 1), np.int32), oc], 1)
+        om.centerpoint_backbone(sd, feats, coors, 1, [1440, 1440, 40])
+        n += 1
+        dt = time.perf_counter() - t1
+        if n == 1:
+            first = dt
+        if time.perf_counter() - t0 + dt > budget_s or n >= 8:
+            break
+    total = time.perf_counter() - t0
+    return {"value": round(n / total, 4), "unit": "sweeps/s", "cores": int(cores), "kind": "port",
+            "sample": "%d whole synthetic sweeps (voxelize+VFE+sparse backbone+dense, LiDAR branch; "
+                      "C for index work, numpy/BLAS for fp32), %.1f s wall; host cpu_count=%d"
+                      % (n, total, os.cpu_count() or 0)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback on the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", init_method="env://")   # nccl == RCCL on ROCm
+    workload = args.workload
+    if workload == "auto":
+        try:
+            import dualfusion.fusion  # noqa: F401
+            workload = "cp_fusion"
+        except Exception:
+            workload = "cp_lidar"
+    from dualfusion import ops
+    model = build_model(workload, dev)
+    pts, extra = make_inputs(workload, args.batch, rank, dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step(model, pts, extra)
+    timer = None if args.no_kernel_timing else ops.KernelTimer()
+    barrier()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run_step(model, pts, extra)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dense = out[0]
+    assert tuple(dense.shape) == (args.batch, 256, 180, 180), dense.shape
+    if rank == 0:
+        sweeps = args.steps * args.batch * world
+        res = {
+            "metric": "nuScenes sweeps/sec (0.075 m voxel, ~60k pts)", "value": round(sweeps / elapsed, 3),
+            "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"cp_fusion": "CenterPoint + 3D-DF hot path (voxelize+VFE, SpMiddleResNetFHDFusion, "
+                                                 "ACTR dual-query fusion on 6 synthetic DeepLabV3-shaped cam feats, dense BEV), "
+                                                 "0.075 m voxel, fp32 [BASELINE configs[1]]",
+                                    "cp_lidar": "CenterPoint voxelnet 0.075 m hot path, LiDAR branch only (voxelize+VFE, "
+                                                "SpMiddleResNetFHD, dense BEV), fp32 [BASELINE configs[0] shape; camera fusion not in this line]"}[workload],
+                       "sweeps_per_gpu_per_step": args.batch, "points_per_sweep": int(pts[0].shape[0]),
+                       "global_batch": args.batch * world, "parallelism": "dp%d (frames sharded, no data-path collective)" % world},
+        }
+        if timer is not None:
+            roof, per_kernel = roofline_from_timer(timer)
+            res["roofline"] = roof
+            res["conv_kernel_ms"] = per_kernel
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(workload)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

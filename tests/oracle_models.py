@@ -1,0 +1,74 @@
+"""Oracle compositions (numpy, CPU) of the reference's backbone forward passes, driven by a
+module state_dict.  Test infrastructure only: used by the GPU parity tests, smoke() and
+bench.py's cpu_baseline leg.  Follows CP/det3d/models/backbones/scn.py:51-94,112-160,200-236."""
+import numpy as np
+
+from oracle import oracle as orc
+
+BN_EPS = 1e-3
+
+
+def _bn(sd, prefix, x):
+    return orc.batchnorm_eval(x, sd[prefix + ".weight"], sd[prefix + ".bias"], sd[prefix + ".running_mean"],
+                              sd[prefix + ".running_var"], BN_EPS)
+
+
+class SpTensor(object):
+    def __init__(self, features, indices, shape, batch, rulebooks=None):
+        self.features, self.indices, self.shape, self.batch = features, indices, list(shape), batch
+        self.rulebooks = rulebooks if rulebooks is not None else {}
+
+
+def _conv(sd, prefix, x, ks, stride, padding, subm, key=None):
+    w = sd[prefix + ".weight"]
+    rb = x.rulebooks.get(key) if key is not None else None
+    if rb is None:
+        rb = orc.get_indice_pairs(x.indices, x.batch, x.shape, ks, stride, padding, [1, 1, 1], subm)
+        if key is not None:
+            x.rulebooks[key] = rb
+    outids, pairs, num, oshape = rb
+    y = orc.indice_conv(x.features, w, pairs, num, len(outids), subm)
+    if prefix + ".bias" in sd:
+        y = y + sd[prefix + ".bias"]
+    return SpTensor(y.astype(np.float32), outids, oshape, x.batch, x.rulebooks)
+
+
+def _basic_block(sd, prefix, x, key):
+    out = _conv(sd, prefix + ".conv1", x, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, key)
+    out.features = np.maximum(_bn(sd, prefix + ".bn1", out.features), 0)
+    out = _conv(sd, prefix + ".conv2", out, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, key)
+    out.features = _bn(sd, prefix + ".bn2", out.features)
+    out.features = np.maximum(out.features + x.features, 0)
+    return out
+
+
+def _down(sd, prefix, x, ks, stride, padding):
+    out = _conv(sd, prefix + ".0", x, ks, stride, padding, 0)
+    out.features = np.maximum(_bn(sd, prefix + ".1", out.features), 0)
+    return out
+
+
+def centerpoint_backbone(sd, voxel_features, coors, batch_size, input_shape, fuse=None):
+    """SpMiddleResNetFHD(.Fusion).forward.  sd: numpy state_dict.  Returns (dense [B,256,H,W], convs dict)."""
+    shape = list(np.array(input_shape[::-1]) + [1, 0, 0])
+    x = SpTensor(np.asarray(voxel_features, np.float32), np.asarray(coors, np.int32), shape, batch_size)
+    x = _conv(sd, "conv_input.0", x, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, "res0")
+    x.features = np.maximum(_bn(sd, "conv_input.1", x.features), 0)
+    c1 = _basic_block(sd, "conv1.1", _basic_block(sd, "conv1.0", x, "res0"), "res0")
+    t = _down(sd, "conv2", c1, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    c2 = _basic_block(sd, "conv2.4", _basic_block(sd, "conv2.3", t, "res1"), "res1")
+    t = _down(sd, "conv3", c2, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    c3 = _basic_block(sd, "conv3.4", _basic_block(sd, "conv3.3", t, "res2"), "res2")
+    t = _down(sd, "conv4", c3, [3, 3, 3], [2, 2, 2], [0, 1, 1])
+    c4 = _basic_block(sd, "conv4.4", _basic_block(sd, "conv4.3", t, "res3"), "res3")
+    if fuse is not None:
+        c4 = fuse(c2, c3, c4)
+    e = _down(sd, "extra_conv", c4, [3, 1, 1], [2, 1, 1], [0, 0, 0])
+    d = orc.dense(e.features, e.indices, e.shape, batch_size)
+    B, C, D, H, W = d.shape
+    return d.reshape(B, C * D, H, W), {"conv1": c1, "conv2": c2, "conv3": c3, "conv4": c4}
+
+
+def sort_rows(indices, features):
+    o = np.lexsort((indices[:, 3], indices[:, 2], indices[:, 1], indices[:, 0]))
+    return indices[o], features[o]
