@@ -1,0 +1,409 @@
+"""ACTR: the dual-query deformable cross-attention encoder that fuses camera features into LiDAR
+voxel queries (reference: CP/det3d/models/model_utils/actr.py:40-187, build() :619-657;
+actr_transformer.py:22-141 (DeformableTransformerACTR), :276-336 (single-query layer), :338-426
+(dual-query fusion layer), :428-511 (encoder); attentions.py:34-117 (gates); position_encoding.py).
+
+Module tree and parameter names/shapes equal the reference's so its
+checkpoints load:  input_proj.0.{0,1}, i_input_proj.{0,1}, transformer.level_embed,
+transformer.encoder.layers.i.{self_attn.*, norm1-3, linear1-4, fusion_layer.{b,a}_conv1d},
+transformer.encoder.lidar_attns.i.* (ACTRv2).
+
+What differs is the execution plan (results identical in eval mode):
+  * the image-side sine position embedding and padding masks are never materialised: the
+    dual-query layer reads neither (value = value_proj(src) has no positional term,
+    actr_transformer.py:399-411), masks are all-False so valid_ratios == 1;
+  * query-side tensors stay [N, Q, C] row-major; 1x1 Conv1d layers run as GEMMs on that layout
+    instead of permute -> conv -> permute;
+  * multi-scale deformable sampling is the HIP kernel csrc/msda.hip.
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import normal_
+
+from .msda import MSDeformAttn
+
+
+# ----------------------------------------------------------------------------- gates
+class _Gate1D(nn.Module):
+    """Two 1x1 Conv1d(C -> 1) gates.  Parameter names b_conv1d / a_conv1d as in attentions.py."""
+
+    def __init__(self, g_channel, g_channel_):
+        super().__init__()
+        self.g_channel, self.g_channel_ = g_channel, g_channel_
+        self.b_conv1d = nn.Conv1d(g_channel, 1, kernel_size=1, stride=1, padding=0)
+        self.a_conv1d = nn.Conv1d(g_channel_, 1, kernel_size=1, stride=1, padding=0)
+
+    def _maps(self, x1, x2):
+        """sigmoid(conv1x1) on [N, Q, C] inputs without the permutes: one GEMV each."""
+        m1 = torch.sigmoid(F.linear(x1, self.b_conv1d.weight[:, :, 0], self.b_conv1d.bias))
+        m2 = torch.sigmoid(F.linear(x2, self.a_conv1d.weight[:, :, 0], self.a_conv1d.bias))
+        return m1, m2
+
+
+class BiGate1D(_Gate1D):
+    def forward(self, feat1, feat2):          # attentions.py:34-52
+        s1, s2 = self._maps(feat1, feat2)
+        return feat1 * s2, feat2 * s1
+
+
+class BiGate1D_2(_Gate1D):
+    def forward(self, feat1, feat2):          # attentions.py:54-74
+        fuse = feat1 + feat2
+        s1, s2 = self._maps(fuse, fuse)
+        return feat1 * s1, feat2 * s2
+
+
+class BiGateSum1D(_Gate1D):
+    def forward(self, feat1, feat2):          # attentions.py:76-94
+        s1, s2 = self._maps(feat1, feat2)
+        return feat1 + feat2 * s1, feat2 + feat1 * s2
+
+
+class BiGateSum1D_2(_Gate1D):
+    def forward(self, feat1, feat2):          # attentions.py:96-117
+        fuse = feat1 + feat2
+        s1, s2 = self._maps(fuse, fuse)
+        return feat1 + feat2 * s1, feat2 + feat1 * s2
+
+
+attn_dict = {'BiGate1D': BiGate1D, 'BiGate1D_2': BiGate1D_2, 'BiGateSum1D': BiGateSum1D,
+             'BiGateSum1D_2': BiGateSum1D_2}
+
+
+# ----------------------------------------------------------------------------- position encodings
+def _sine_table(x, num_pos_feats, temperature):
+    """x [..]: interleaved sin/cos over num_pos_feats channels (position_encoding.py:41-48)."""
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=x.device)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode='floor') / num_pos_feats)
+    p = x[..., None] / dim_t
+    return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
+
+
+class PositionEmbeddingSine(nn.Module):
+    """Image-plane sine embedding (position_encoding.py:17-53); input (tensor, mask)."""
+
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, x, mask):
+        not_mask = ~mask
+        y_embed = not_mask.cumsum(1, dtype=torch.float32)
+        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            eps = 1e-6
+            y_embed = (y_embed - 0.5) / (y_embed[:, -1:, :] + eps) * self.scale
+            x_embed = (x_embed - 0.5) / (x_embed[:, :, -1:] + eps) * self.scale
+        pos_x = _sine_table(x_embed, self.num_pos_feats, self.temperature)
+        pos_y = _sine_table(y_embed, self.num_pos_feats, self.temperature)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+class PositionEmbeddingSineSparse(PositionEmbeddingSine):
+    """position_encoding.py:56-89: normalised image coordinates of each query -> [N, C, Q]."""
+
+    def forward(self, coor, depth=None):
+        x_embed, y_embed = coor[..., 0], coor[..., 1]
+        if self.normalize:
+            y_embed = y_embed * self.scale
+            x_embed = x_embed * self.scale
+        pos_x = _sine_table(x_embed, self.num_pos_feats, self.temperature)
+        pos_y = _sine_table(y_embed, self.num_pos_feats, self.temperature)
+        return torch.cat((pos_y, pos_x), dim=2).permute(0, 2, 1)
+
+
+class PositionEmbeddingSineSparseDepth(PositionEmbeddingSine):
+    """position_encoding.py:91-120: "depth" = LiDAR-frame x of the voxel, / 60 * 2pi -> [N, C, Q]."""
+
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__(num_pos_feats, temperature, normalize, scale)
+        self.norm_param = 60.
+
+    def forward(self, depth):
+        d = depth / self.norm_param * self.scale if self.normalize else depth
+        return _sine_table(d, self.num_pos_feats, self.temperature).permute(0, 2, 1)
+
+
+class PositionEmbeddingLearnedDepth(nn.Module):
+    """position_encoding.py:122-141: learned table over num_bin depth bins (depth / 60 * num_bin).
+    (The reference's forward takes (feat, depth) although ACTR.forward calls it with one argument,
+    actr.py:163; 'depth_learn' is not used by any 3D-DF config.)"""
+
+    def __init__(self, num_pos_feats=256, num_bin=120):
+        super().__init__()
+        self.d_embed = nn.Embedding(num_bin, num_pos_feats)
+        self.num_bin = num_bin
+        nn.init.uniform_(self.d_embed.weight)
+
+    def forward(self, depth, feat=None):
+        d = (depth / 60. * self.num_bin).to(torch.long)
+        return self.d_embed(d).permute(0, 2, 1)
+
+
+# ----------------------------------------------------------------------------- encoder layers
+def _get_activation_fn(activation):
+    if activation == "relu":
+        return F.relu
+    if activation == "gelu":
+        return F.gelu
+    if activation == "glu":
+        return F.glu
+    raise RuntimeError("activation should be relu/gelu, not %s." % activation)
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    """Single-query layer (feature_modal 'lidar' / 'image'), actr_transformer.py:276-336."""
+
+    def __init__(self, d_model=256, q_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8,
+                 n_points=4, hybrid_cfg=None):
+        super().__init__()
+        self.d_model = d_model
+        self.self_attn = MSDeformAttn(d_model, q_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, q_pos=None,
+                q_feat=None, q_i_feat=None):
+        query = q_feat if q_pos is None else q_feat + q_pos
+        att = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+        q_feat = self.norm1(q_feat + self.dropout1(att))
+        ffn = self.linear2(self.dropout2(self.activation(self.linear1(q_feat))))
+        q_feat = self.norm2(q_feat + self.dropout3(ffn))
+        return q_feat, q_i_feat
+
+
+class DeformableTransformerFusionEncoderLayer(nn.Module):
+    """Dual-query layer, actr_transformer.py:338-426: sampling offsets from the LiDAR query,
+    attention weights from LiDAR+image queries, MSDA output added to the IMAGE query stream, one
+    FFN per stream, then a bidirectional gate."""
+
+    def __init__(self, d_model=256, q_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8,
+                 n_points=4, hybrid_cfg=None):
+        super().__init__()
+        self.attn_layer = hybrid_cfg['attn_layer']
+        self.q_method = hybrid_cfg.get('q_method', None)
+        self.q_rep_place = hybrid_cfg.get('q_rep_place', None)
+        self.d_model = d_model
+        self.self_attn = MSDeformAttn(d_model, q_model, n_levels, n_heads, n_points, q_method=self.q_method,
+                                      q_rep_place=self.q_rep_place)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)      # image-query FFN
+        self.activation = _get_activation_fn(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear3 = nn.Linear(d_model, d_ffn)      # LiDAR-query FFN
+        self.dropout4 = nn.Dropout(dropout)
+        self.linear4 = nn.Linear(d_ffn, d_model)
+        self.dropout5 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.fusion_layer = attn_dict[self.attn_layer](q_model, q_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, q_pos=None,
+                q_feat=None, q_i_feat=None):
+        lq = q_feat if q_pos is None else q_feat + q_pos
+        iq = q_i_feat if q_pos is None else q_i_feat + q_pos
+        att = self.self_attn(lq, reference_points, src, spatial_shapes, level_start_index, padding_mask, i_query=iq)
+        q_i_feat = self.norm1(q_i_feat + self.dropout1(att))
+        q_i_feat = self.norm2(q_i_feat + self.dropout3(
+            self.linear2(self.dropout2(self.activation(self.linear1(q_i_feat))))))
+        q_feat = self.norm3(q_feat + self.dropout5(
+            self.linear4(self.dropout4(self.activation(self.linear3(q_feat))))))
+        return self.fusion_layer(q_feat, q_i_feat)
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class DeformableTransformerEncoder(nn.Module):
+    """actr_transformer.py:428-511.  ACTRv2 runs a LocalTransformer (3-D local self-attention over
+    the LiDAR queries) before every deformable layer (:496-498)."""
+
+    def __init__(self, encoder_layer, num_layers, model_name='ACTR', lt_cfg=None):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.model_name = model_name
+        if model_name == 'ACTRv2':
+            from .pointformer import LocalTransformer
+            self.lidar_attns = _get_clones(
+                LocalTransformer(lt_cfg['npoint'], lt_cfg['radius'], lt_cfg['nsample'], encoder_layer.d_model,
+                                 encoder_layer.d_model, num_layers=lt_cfg['num_layers'],
+                                 attn_feat_agg_method=lt_cfg.get('attn_feat_agg_method', 'unique'),
+                                 feat_agg_method=lt_cfg.get('feat_agg_method', 'replace')), num_layers)
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, q_feat=None,
+                q_pos=None, q_reference_points=None, q_lidar_grid=None, q_i_feat=None):
+        if q_reference_points is None:
+            raise NotImplementedError("IACTR (image-grid queries) is not part of the 3D-DF configs")
+        reference_points = q_reference_points[:, :, None] * valid_ratios[:, None]
+        for idx, layer in enumerate(self.layers):
+            if self.model_name == 'ACTRv2':
+                q_feat = self.lidar_attns[idx](q_lidar_grid, q_feat.permute(0, 2, 1))
+            q_feat, q_i_feat = layer(src, pos, reference_points, spatial_shapes, level_start_index, padding_mask,
+                                     q_pos=q_pos, q_feat=q_feat, q_i_feat=q_i_feat)
+        return q_feat
+
+
+class DeformableTransformerACTR(nn.Module):
+    def __init__(self, d_model=256, query_num_feat=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024,
+                 dropout=0.1, activation="relu", return_intermediate_dec=False, num_feature_levels=4, enc_n_points=4,
+                 two_stage=False, two_stage_num_proposals=300, model_name='ACTR', lt_cfg=None, feature_modal='lidar',
+                 hybrid_cfg=None):
+        super().__init__()
+        self.d_model = d_model
+        self.q_model = query_num_feat
+        self.nhead = nhead
+        self.two_stage = two_stage
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.feature_modal = feature_modal
+        layer_cls = DeformableTransformerFusionEncoderLayer if feature_modal in ['hybrid'] \
+            else DeformableTransformerEncoderLayer
+        encoder_layer = layer_cls(self.d_model, self.q_model, dim_feedforward, dropout, activation,
+                                  num_feature_levels, nhead, enc_n_points, hybrid_cfg)
+        self.encoder = DeformableTransformerEncoder(encoder_layer, num_encoder_layers, model_name=model_name,
+                                                    lt_cfg=lt_cfg)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        normal_(self.level_embed)
+
+    def forward(self, srcs, masks, pos_embeds, q_feat_flatten, q_pos, q_ref_coors, q_lidar_grid=None,
+                q_i_feat_flatten=None):
+        """srcs: list of [N, C, H, W].  masks / pos_embeds may be None (all-valid maps): the ACTR
+        layers consume neither the masks' padding (all False) nor the level position embedding."""
+        dev = srcs[0].device
+        shapes = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
+        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=dev)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        N = src_flatten.shape[0]
+        if masks is None or all(m is None for m in masks):
+            valid_ratios = torch.ones((N, len(srcs), 2), dtype=torch.float32, device=dev)
+            mask_flatten = None
+        else:
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+            mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
+            if not bool(mask_flatten.any()):
+                mask_flatten = None
+        lvl_pos = None
+        if pos_embeds is not None:
+            lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
+                                 for l, p in enumerate(pos_embeds)], 1)
+        return self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, lvl_pos, mask_flatten,
+                            q_pos=q_pos, q_feat=q_feat_flatten, q_reference_points=q_ref_coors,
+                            q_lidar_grid=q_lidar_grid, q_i_feat=q_i_feat_flatten)
+
+    @staticmethod
+    def get_valid_ratio(mask):
+        _, H, W = mask.shape
+        valid_H = torch.sum(~mask[:, :, 0], 1)
+        valid_W = torch.sum(~mask[:, 0, :], 1)
+        return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
+
+
+class ACTR(nn.Module):
+    """actr.py:40-187.  forward(v_feat [N,Q,C], grid [N,Q,2] in [0,1], i_feats [[N,Cimg,H,W]..],
+    v_i_feat [N,Q,Cimg], lidar_grid [N,Q,3]) -> enhanced LiDAR queries [N,Q,C]."""
+
+    def __init__(self, transformer, num_channels, num_feature_levels, max_num_ne_voxel, p_num_channels=None,
+                 pos_encode_method="image_coor", feature_modal='lidar'):
+        super().__init__()
+        self.transformer = transformer
+        hidden_dim = transformer.d_model
+        self.num_feature_levels = num_feature_levels
+        self.num_backbone_outs = len(num_channels)
+        assert self.num_backbone_outs == num_feature_levels
+        self.input_proj = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(num_channels[l], hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim))
+            for l in range(max(num_feature_levels, 1))])
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        if feature_modal in ['image', 'hybrid']:
+            self.i_input_proj = nn.Sequential(nn.Conv1d(num_channels[0], hidden_dim, kernel_size=1),
+                                              nn.GroupNorm(32, hidden_dim))
+            nn.init.xavier_uniform_(self.i_input_proj[0].weight, gain=1)
+            nn.init.constant_(self.i_input_proj[0].bias, 0)
+        self.feature_modal = feature_modal
+        self.max_num_ne_voxel = max_num_ne_voxel
+        self.pos_encode_method = pos_encode_method
+        assert self.pos_encode_method in ["image_coor", "depth", "depth_learn"]
+        if pos_encode_method == "image_coor":
+            self.q_position_embedding = PositionEmbeddingSineSparse(num_pos_feats=transformer.q_model // 2,
+                                                                    normalize=True)
+        elif pos_encode_method == "depth":
+            self.q_position_embedding = PositionEmbeddingSineSparseDepth(num_pos_feats=transformer.q_model,
+                                                                         normalize=True)
+        else:
+            self.q_position_embedding = PositionEmbeddingLearnedDepth(num_pos_feats=transformer.q_model)
+        self.v_position_embedding = PositionEmbeddingSine(num_pos_feats=hidden_dim // 2, normalize=True)
+
+    def project_image_queries(self, v_i_feat):
+        """i_input_proj on [N, Q, Cimg]: the 1x1 Conv1d as a GEMM, GroupNorm over (group, Q)."""
+        conv, gn = self.i_input_proj[0], self.i_input_proj[1]
+        y = F.linear(v_i_feat, conv.weight[:, :, 0], conv.bias)            # [N, Q, C]
+        y = F.group_norm(y.transpose(1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)
+        return y.transpose(1, 2)
+
+    def forward(self, v_feat, grid, i_feats, v_i_feat=None, lidar_grid=None):
+        q_feat = v_feat
+        q_i_feat = None
+        if self.feature_modal in ['image', 'hybrid']:
+            assert v_i_feat is not None
+            q_i_feat = self.project_image_queries(v_i_feat)
+            if self.feature_modal == 'image':
+                q_feat = q_i_feat
+        if self.pos_encode_method == "image_coor":
+            q_pos = self.q_position_embedding(grid).transpose(1, 2)
+        else:
+            q_pos = self.q_position_embedding(lidar_grid[..., 0]).transpose(1, 2)
+        srcs = [self.input_proj[l](src) for l, src in enumerate(i_feats)]
+        return self.transformer(srcs, None, None, q_feat, q_pos, grid, q_lidar_grid=lidar_grid,
+                                q_i_feat_flatten=q_i_feat)
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def build(model_cfg, model_name='ACTR', lt_cfg=None):
+    """actr.py:619-657 with the argparse defaults it relies on (actr_utils.py:548-646): nheads 8,
+    enc_n_points 4, dim_feedforward 1024, dropout 0.1."""
+    if model_name not in ('ACTR', 'ACTRv2'):
+        raise NotImplementedError("%s: only ACTR / ACTRv2 are used by the 3D-DF configs" % model_name)
+    get = model_cfg.get if hasattr(model_cfg, "get") else (lambda k, d=None: getattr(model_cfg, k, d))
+    num_channels = model_cfg['num_channels'] if isinstance(model_cfg, dict) else model_cfg.num_channels
+    q = get('query_num_feat')
+    transformer = DeformableTransformerACTR(
+        d_model=q, query_num_feat=q, nhead=8, num_encoder_layers=get('num_enc_layers'), dim_feedforward=1024,
+        dropout=0.1, activation="relu", return_intermediate_dec=True, num_feature_levels=len(num_channels),
+        enc_n_points=4, two_stage=False, two_stage_num_proposals=300, model_name=model_name,
+        lt_cfg=_Cfg(lt_cfg) if lt_cfg is not None else None, feature_modal=get('feature_modal', 'lidar'),
+        hybrid_cfg=get('hybrid_cfg', None))
+    return ACTR(transformer, num_feature_levels=len(num_channels), p_num_channels=get('p_num_channels', None),
+                num_channels=num_channels, max_num_ne_voxel=get('max_num_ne_voxel'),
+                pos_encode_method=get('pos_encode_method'), feature_modal=get('feature_modal', 'lidar'))

@@ -168,6 +168,43 @@ int df3d_group_points(const float *features, const int32_t *idx, int B, int C, i
 int df3d_gather_points(const float *features, const int32_t *idx, int B, int C, int N, int npoint,
                        float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Camera-fusion glue of the CenterPoint adapter (rows a7-a9 of SURVEY.md §8a).  The reference has
+ * no native binding here: these replace the Python loops of
+ * CP/det3d/models/fusion/voxel_with_point_projection.py:131-385,
+ * point_to_image_projection.py:63-231 and model_utils/attention.py:422-468 (pts2img).
+ * Image index convention: img = b * ncam + cam (the order ACTR receives, :330-342).
+ *
+ * df3d_project_voxels: per (camera, voxel): voxel index * scale_xyz + pc_min -> lidar2cam
+ *   [B,ncam,4,4] -> intrinsic [B,ncam,3,3] -> pixel, truncated as the reference does (.long(),
+ *   * image_scale .long(), * feat_scale .long()); mask = 0<x<W_raw, 0<y<H_raw, depth > thres.
+ *   grid_xy [ncam,n,2] i32 (feature-map x,y; 0 where masked), mask [ncam,n] u8,
+ *   point_inv [n,3] f32 (LiDAR xyz), depth [ncam,n] f32 or NULL.
+ * df3d_scatter_to_image ("pts2img"): canvas [B*ncam, C+3, H, W] <- (features | xyz) of the
+ *   visible voxels, last writer wins (highest row); winner [B*ncam,H,W] i32 is scratch.
+ * df3d_assemble_queries: zero-padded per-camera query tensors for ACTR; pos [ncam,n] i32 = slot
+ *   of a visible voxel inside its (b, cam) list (exclusive count of visible rows before it).
+ * df3d_fusion_writeback: out[row] = features[row] + sum_cam enh[b*ncam+cam][pos] in camera order
+ *   (voxel_with_point_projection.py:368-377).
+ * ---------------------------------------------------------------------------------- */
+int df3d_project_voxels(const int32_t *indices, int n, int batch, int ncam,
+                        const float *scale_xyz_host, const float *pc_min_host,
+                        const float *lidar2cam, const float *intrinsic, const int32_t *raw_hw,
+                        const float *depth_thres, float image_scale, const float *feat_scale,
+                        int32_t *grid_xy, uint8_t *mask, float *point_inv, float *depth, void *stream);
+int df3d_scatter_to_image(const float *features, const float *point_inv, const int32_t *indices,
+                          const int32_t *grid_xy, const uint8_t *mask, int n, int channels,
+                          int batch, int ncam, int H, int W, int32_t *winner, float *canvas,
+                          void *stream);
+int df3d_assemble_queries(const float *features, const float *point_inv, const int32_t *indices,
+                          const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
+                          const float *img_feats, int n, int channels, int img_channels, int batch,
+                          int ncam, int H, int W, int max_ne, float *v_feat, float *v_i_feat,
+                          float *qgrid, float *qpts, void *stream);
+int df3d_fusion_writeback(const float *features, const float *enh, const int32_t *indices,
+                          const uint8_t *mask, const int32_t *pos, int n, int channels, int ncam,
+                          int max_ne, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,8 +211,142 @@ def gen_actr(actr):
          param_shapes=np.array([str(shapes[k]) for k in names]), n_params=np.array(sum(int(np.prod(s)) for s in shapes.values())))
 
 
+# ------------------------------------------------------------------ CenterPoint fusion adapter (a7-a9)
+FUS = dict(batch=2, pc_range=[-9.6, -9.6, -5.0, 9.6, 9.6, 3.0], voxel_size=[0.075, 0.075, 0.2],
+           raw_hw=(240, 320), image_scale=2.0 / 3.0, img_hw=(160, 213), feat_hw=(40, 54), focal=250.0,
+           depth_thres={'CAM_FRONT': 1, 'CAM_FRONT_LEFT': 0, 'CAM_FRONT_RIGHT': 0, 'CAM_BACK': 0.5,
+                        'CAM_BACK_LEFT': 0, 'CAM_BACK_RIGHT': 0})
+FUS_IFAT = dict(fusion_method='Basicgate_patch_iv_multivoxel', img_num_channel=256, pts_num_channel=128,
+                voxel_feat_channel=[32, 64, 128], voxel_idx=[0, 2])
+FUS_LT = dict(npoint=2048, radius=2.0, nsample=32, num_layers=2, attn_feat_agg_method='unique',
+              feat_agg_method='replace')
+
+
+def fusion_voxel_sets():
+    """Active voxel coordinates of x_conv2 / x_conv3 / x_conv4 for two synthetic sweeps on the reduced
+    grid (256 x 256 x 41 -> strides 2, 4, 8), through the oracle's rulebook chain."""
+    from oracle import oracle as orc
+    coors = []
+    for b in range(FUS["batch"]):
+        pts = synth.nusc_sweep(seed=40 + b)
+        _, c, _ = orc.hard_voxelize(pts, FUS["voxel_size"], FUS["pc_range"], 10, 120000)
+        coors.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+    ind = np.concatenate(coors)
+    shape = [41, 256, 256]
+    out = []
+    for pad in ([1, 1, 1], [1, 1, 1], [0, 1, 1]):
+        o, _, _, shape = orc.get_indice_pairs(ind, FUS["batch"], shape, [3, 3, 3], [2, 2, 2], pad, [1, 1, 1], 0)
+        order = np.lexsort((o[:, 3], o[:, 2], o[:, 1], o[:, 0]))   # (b,z,y,x)-sorted, as spconv's GPU path emits
+        ind = np.ascontiguousarray(o[order])
+        out.append(ind)
+    return out
+
+
+def fusion_inputs():
+    sets = fusion_voxel_sets()
+    feats = [detgen.randn("fus_feat%d" % i, (len(s), c)) for i, (s, c) in enumerate(zip(sets, [32, 64, 128]))]
+    cams = synth.nusc_cameras(image_hw=FUS["raw_hw"], focal=FUS["focal"])
+    B = FUS["batch"]
+    img = {name.lower(): detgen.randn("fus_img_" + name, (B, 256) + FUS["feat_hw"]) for name in synth.NUSC_CAMS}
+    return sets, feats, cams, img
+
+
+def gen_fusion():
+    """Reference VoxelWithPointProjection.forward (fuse_mode 'pfat', ACTR + ifat gate) on CPU.
+    Environment shims only: `.cuda()` -> identity, torch.tensor(device='cuda') -> cpu, and kornia
+    (absent, unpinned by the reference) restated from its published implementation
+    (kornia.geometry.linalg.transform_points / conversions.convert_points_{to,from}_homogeneous, 0.6.x)."""
+    import torch.nn.functional as F
+
+    def to_h(p):
+        return F.pad(p, [0, 1], "constant", 1.0)
+
+    def from_h(p, eps=1e-8):
+        z = p[..., -1:]
+        scale = torch.where(z.abs() > eps, 1.0 / (z + eps), torch.ones_like(z))
+        return scale * p[..., :-1]
+
+    def transform_points(trans_01, points_1):
+        shp = list(points_1.shape)
+        p = points_1.reshape(-1, shp[-2], shp[-1])
+        t = trans_01.reshape(-1, trans_01.shape[-2], trans_01.shape[-1])
+        t = torch.repeat_interleave(t, repeats=p.shape[0] // t.shape[0], dim=0)
+        o = from_h(torch.bmm(to_h(p), t.permute(0, 2, 1)))
+        shp[-2], shp[-1] = o.shape[-2], o.shape[-1]
+        return o.reshape(shp)
+
+    _stub("kornia")
+    _stub("kornia.utils")
+    _stub("kornia.utils.grid", create_meshgrid3d=None)
+    _stub("kornia.geometry")
+    _stub("kornia.geometry.linalg", transform_points=transform_points)
+    _stub("kornia.geometry.conversions", convert_points_to_homogeneous=to_h, convert_points_from_homogeneous=from_h)
+    R = "/root/reference/CenterPoint/det3d"
+    for pkg, path in [("det3d.models.fusion", R + "/models/fusion"), ("det3d.models.utils", R + "/models/utils"),
+                      ("det3d.models.losses", R + "/models/losses"), ("det3d.core", R + "/core"),
+                      ("det3d.datasets", R + "/datasets"), ("det3d.datasets.nuscenes", R + "/datasets/nuscenes")]:
+        _stub(pkg).__path__ = [path]
+
+    class _Reg:
+        def register_module(self, cls):
+            return cls
+
+    _stub("det3d.models.registry", FUSION=_Reg())
+    _stub("det3d.models.losses.auxseg_loss", SEGLOSS=None)
+    _stub("det3d.core.bbox", box_np_ops=None)
+    _stub("det3d.core.bbox.box_np_ops")
+    _stub("det3d.datasets.nuscenes.nusc_common", get_lidar2cam_matrix=None, view_points=None)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    _orig_tensor = torch.tensor
+    torch.tensor = lambda *a, **k: _orig_tensor(*a, **{kk: ("cpu" if kk == "device" and str(v).startswith("cuda") else v)
+                                                         for kk, v in k.items()})
+    try:
+        vwp = importlib.import_module("det3d.models.fusion.voxel_with_point_projection")
+        sets, feats, cams, img = fusion_inputs()
+        mod = vwp.VoxelWithPointProjection(
+            fuse_mode='pfat', interpolate=False, voxel_size=FUS["voxel_size"], pc_range=FUS["pc_range"],
+            image_list=synth.NUSC_CAMS, image_scale=FUS["image_scale"], depth_thres=FUS["depth_thres"],
+            pfat_cfg=Cfg(ACTR_CFG), lt_cfg=Cfg(FUS_LT), ifat_cfg=Cfg(FUS_IFAT), model_name='ACTR').eval()
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        sd = detgen.det_state_dict(shapes)
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        B = FUS["batch"]
+
+        class SpT:
+            def __init__(self, f, i):
+                self.features, self.indices = torch.from_numpy(f.copy()), torch.from_numpy(i.copy())
+
+        xs = [SpT(f, i) for f, i in zip(feats, sets)]
+        H, W = FUS["img_hw"]
+        batch_dict = {
+            'image_shape': {n.lower(): torch.tensor([[H, W, 3]] * B) for n in synth.NUSC_CAMS},
+            'img_feat': {'layer1_ori_feat2d': {k: torch.from_numpy(v) for k, v in img.items()}},
+            'calib': {},
+        }
+        for n in synth.NUSC_CAMS:
+            key = n.lower().lstrip('cam_')
+            T, K = cams[n]
+            batch_dict['calib']['lidar2cam_' + key] = torch.from_numpy(np.stack([T] * B))
+            batch_dict['calib']['cam_intrinsic_' + key] = torch.from_numpy(np.stack([K] * B))
+        with torch.no_grad():
+            out = mod(batch_dict, {}, encoded_voxel_list=xs, layer_name='layer1_ori', fuse_mode='pfat',
+                      d_factor_list=[2, 4, 8])
+        # per (b, cam) visible-voxel counts for diagnosis: recompute through the reference projector
+        counts = np.zeros((B, 6), np.int64)
+        for ci, n in enumerate(synth.NUSC_CAMS):
+            pd = mod.point_projector(voxel_coords=torch.from_numpy(sets[2]).float(), image_scale=FUS["image_scale"],
+                                     batch_dict=batch_dict, cam_key=n.lower(), d_factor=8)
+            counts[:, ci] = pd['point_mask'].sum(1).numpy()
+        names = np.array(sorted(shapes))
+        save("fusion_cp.npz", coords2=sets[0].astype(np.int16), coords3=sets[1].astype(np.int16),
+             coords4=sets[2].astype(np.int16), out=out.features.numpy(), counts=counts, param_names=names,
+             param_shapes=np.array([str(shapes[k]) for k in names]))
+    finally:
+        torch.tensor = _orig_tensor
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion"]
     if "voxelize" in which:
         gen_voxelize()
     if "rulebook" in which:
@@ -223,3 +357,7 @@ if __name__ == "__main__":
             gen_msda(func)
         if "actr" in which:
             gen_actr(actr)
+    if "fusion" in which:
+        if "det3d" not in sys.modules:
+            import_reference_actr()
+        gen_fusion()

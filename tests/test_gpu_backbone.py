@@ -62,3 +62,84 @@ def test_centerpoint_backbone_vs_oracle(batch):
         scale = np.abs(of).max()
         assert np.abs(mf - of).max() <= 1e-3 * max(scale, 1.0), (name, np.abs(mf - of).max(), scale)
     np.testing.assert_allclose(dense.cpu().numpy(), o_dense, rtol=1e-3, atol=1e-3 * max(np.abs(o_dense).max(), 1.0))
+
+
+# ------------------------------------------------------------------------- ACTR (dual-query fusion encoder)
+def test_actr_parameter_layout_matches_reference(golden):
+    from dualfusion import actr
+    from make_golden import ACTR_CFG
+    g = golden("actr.npz")
+    m = actr.build(dict(ACTR_CFG), model_name="ACTR")
+    sd = m.state_dict()
+    assert sorted(sd) == list(g["param_names"])
+    for k, s in zip(g["param_names"], g["param_shapes"]):
+        assert str(tuple(sd[str(k)].shape)) == str(s), k
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"]) == 1212484
+
+
+def test_actr_forward_vs_reference_golden(golden):
+    """Same weights (detgen), same inputs -> the reference ACTR.forward output stored by make_golden.py."""
+    from dualfusion import actr
+    from make_golden import ACTR_CFG, actr_inputs
+    dev = torch.device("cuda:0")
+    g = golden("actr.npz")
+    m = actr.build(dict(ACTR_CFG), model_name="ACTR").eval()
+    sd = detgen.det_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev)
+    v_feat, grid, i_feat, lidar_grid, v_i_feat = [torch.from_numpy(a).to(dev) for a in actr_inputs()]
+    with torch.no_grad():
+        y = m(v_feat=v_feat, grid=grid, i_feats=[i_feat], lidar_grid=lidar_grid, v_i_feat=v_i_feat)
+    ref = g["out"]
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err <= 1e-3 * max(1.0, np.abs(ref).max()), err
+
+
+# ------------------------------------------------------------------------- CenterPoint fusion adapter (a7-a9)
+def test_centerpoint_fusion_adapter_vs_reference_golden(golden):
+    """VoxelWithPointProjection (projection, image-side gate, per-camera query assembly, ACTR, write-back)
+    against the output of the REFERENCE module run by make_golden.py on the same inputs and weights."""
+    from dualfusion import fusion as fz, spconv, synth
+    from make_golden import ACTR_CFG, FUS, FUS_IFAT, FUS_LT
+    dev = torch.device("cuda:0")
+    g = golden("fusion_cp.npz")
+    sets = [g["coords2"].astype(np.int32), g["coords3"].astype(np.int32), g["coords4"].astype(np.int32)]
+    feats = [detgen.randn("fus_feat%d" % i, (len(s), c)) for i, (s, c) in enumerate(zip(sets, [32, 64, 128]))]
+    mod = fz.VoxelWithPointProjection(fuse_mode='pfat', interpolate=False, voxel_size=FUS["voxel_size"],
+                                      pc_range=FUS["pc_range"], image_list=synth.NUSC_CAMS,
+                                      image_scale=FUS["image_scale"], depth_thres=FUS["depth_thres"],
+                                      pfat_cfg=dict(ACTR_CFG), lt_cfg=dict(FUS_LT), ifat_cfg=dict(FUS_IFAT),
+                                      model_name='ACTR').eval()
+    sd_shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+    assert sorted(sd_shapes) == list(g["param_names"])          # fusion.pfat.* / fusion.ifat.* checkpoint layout
+    for k, s in zip(g["param_names"], g["param_shapes"]):
+        assert str(sd_shapes[str(k)]) == str(s), k
+    sd = detgen.det_state_dict(sd_shapes)
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    mod = mod.to(dev)
+    B = FUS["batch"]
+    cams = synth.nusc_cameras(image_hw=FUS["raw_hw"], focal=FUS["focal"])
+    H, W = FUS["img_hw"]
+    batch_dict = {'image_shape': {}, 'img_feat': {'layer1_ori_feat2d': {}}, 'calib': {}}
+    for n in synth.NUSC_CAMS:
+        key = n.lower()
+        batch_dict['image_shape'][key] = torch.tensor([[H, W, 3]] * B)
+        batch_dict['img_feat']['layer1_ori_feat2d'][key] = torch.from_numpy(
+            detgen.randn("fus_img_" + n, (B, 256) + tuple(FUS["feat_hw"]))).to(dev)
+        T, K = cams[n]
+        batch_dict['calib']['lidar2cam_' + key.lstrip('cam_')] = torch.from_numpy(np.stack([T] * B)).to(dev)
+        batch_dict['calib']['cam_intrinsic_' + key.lstrip('cam_')] = torch.from_numpy(np.stack([K] * B)).to(dev)
+    shapes = [[21, 128, 128], [11, 64, 64], [5, 32, 32]]
+    xs = [spconv.SparseConvTensor(torch.from_numpy(f).to(dev), torch.from_numpy(i).to(dev), shp, B)
+          for f, i, shp in zip(feats, sets, shapes)]
+    # visible-voxel counts per (sample, camera): integer parity of the projection + masks
+    inp = mod._gather_inputs(batch_dict, 'layer1_ori', dev)
+    grid, mask, pinv = mod._project(xs[2], 8, inp)
+    bcol = torch.from_numpy(sets[2][:, 0]).to(dev)
+    counts = np.array([[int((mask[c].bool() & (bcol == b)).sum()) for c in range(6)] for b in range(B)])
+    assert np.array_equal(counts, g["counts"]), (counts, g["counts"])
+    out = mod(batch_dict, {}, encoded_voxel_list=xs, layer_name='layer1_ori', fuse_mode='pfat',
+              d_factor_list=[2, 4, 8])
+    ref = g["out"]
+    err = np.abs(out.features.cpu().numpy() - ref).max()
+    assert err <= 1e-3 * max(1.0, np.abs(ref).max()), err
