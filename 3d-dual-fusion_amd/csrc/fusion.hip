@@ -34,6 +34,7 @@ struct ProjArgs {
 
 // k-ordered FMA chain, the accumulation a BLAS sgemm micro-kernel performs on the 4-vector
 __device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, const float *m) {
+#pragma clang fp contract(off)
   float acc = a0 * m[0];
   acc = fmaf(a1, m[1], acc);
   acc = fmaf(a2, m[2], acc);
@@ -42,16 +43,22 @@ __device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, co
 }
 
 __global__ __launch_bounds__(256) void project_voxels_kernel(ProjArgs a) {
+#pragma clang fp contract(off)  // (HIP's __fmul_rn/__fadd_rn are inline a*b / a+b and still fuse after inlining)
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)a.n * a.ncam) return;
   int cam = (int)(t / a.n);
   int i = (int)(t - (long long)cam * a.n);
   const int32_t *p = a.ind + (size_t)i * 4;
   int b = p[0];
-  // grid -> LiDAR (voxel corner): point_to_image_projection.py:82-103
-  float px = (float)p[3] * a.sx + a.minx;
-  float py = (float)p[2] * a.sy + a.miny;
-  float pz = (float)p[1] * a.sz + a.minz;
+  // grid -> LiDAR (voxel corner): point_to_image_projection.py:82-103.  The reference's 4x4 matmul
+  // rounds the product before adding the offset (k-ordered accumulation), so the compiler must
+  // not contract these into FMAs: a 1-ulp change here flips pixel truncations further down.
+  float px = (float)p[3] * a.sx;
+  px = px + a.minx;
+  float py = (float)p[2] * a.sy;
+  py = py + a.miny;
+  float pz = (float)p[1] * a.sz;
+  pz = pz + a.minz;
   if (cam == 0) {
     a.pinv[(size_t)i * 3 + 0] = px;
     a.pinv[(size_t)i * 3 + 1] = py;
@@ -63,10 +70,10 @@ __global__ __launch_bounds__(256) void project_voxels_kernel(ProjArgs a) {
   float cz = dot4(px, py, pz, 1.f, M + 8);
   const float *K = a.intr + ((size_t)b * a.ncam + cam) * 9;
   // camera_to_image (models/utils/transform_utils.py:39-60): [cx,cy,cz,1] @ pad4(K)^T, / z
-  float uh = fmaf(cz, K[2], fmaf(cy, K[1], cx * K[0]));
-  float vh = fmaf(cz, K[5], fmaf(cy, K[4], cx * K[3]));
-  float wh = fmaf(cz, K[8], fmaf(cy, K[7], cx * K[6]));
-  float u = (uh / wh), v = (vh / wh);
+  float uh = fmaf(cz, K[2], fmaf(cy, K[1], (cx * K[0])));
+  float vh = fmaf(cz, K[5], fmaf(cy, K[4], (cx * K[3])));
+  float wh = fmaf(cz, K[8], fmaf(cy, K[7], (cx * K[6])));
+  float u = uh / wh, v = vh / wh;
   bool ok = isfinite(u) && isfinite(v) && fabsf(u) < 1e9f && fabsf(v) < 1e9f;
   long long gx = 0, gy = 0;
   if (ok) {

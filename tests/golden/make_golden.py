@@ -296,6 +296,10 @@ def gen_fusion():
     _stub("det3d.core.bbox", box_np_ops=None)
     _stub("det3d.core.bbox.box_np_ops")
     _stub("det3d.datasets.nuscenes.nusc_common", get_lidar2cam_matrix=None, view_points=None)
+    # pts2img (attention.py:422-468) writes duplicate pixels with index_put_: the winner is order
+    # dependent (racy on the reference's GPU path and on a multi-threaded CPU).  The fixture is taken
+    # with ONE CPU thread = sequential execution = last writer wins.
+    torch.set_num_threads(1)
     torch.Tensor.cuda = lambda self, *a, **k: self
     _orig_tensor = torch.tensor
     torch.tensor = lambda *a, **k: _orig_tensor(*a, **{kk: ("cpu" if kk == "device" and str(v).startswith("cuda") else v)
