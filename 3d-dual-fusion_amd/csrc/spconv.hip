@@ -21,6 +21,8 @@
 // + K*CIN*COUT*4.  The reduction index order inside MFMA is a permutation
 // of cin (lane group g owns cin [g*KS, (g+1)*KS) of the slice); fp32 accumulate.
 // Roofline: HBM for C <= 32 (AI 3-14 flop/B), fp32 MFMA (157 TF) for C >= 64.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace df3d {
@@ -225,6 +227,209 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// v2 for the compute-bound layers (COUT >= 64): pair-compacted MFMA rows, LDS accumulators.
+//
+// The output-stationary kernel above issues MFMAs for every (row, offset) of its tile, also
+// where the neighbour is absent (42 % of the slots at conv4's occupancy).  Here a workgroup
+// still owns TM consecutive output rows, but
+//   * its accumulators live in LDS ([wave][TM][COUT/4] fp32), so MFMA rows need not be output
+//     rows: for each kernel offset the VALID (output row, input row) pairs of the tile are
+//     compacted (ballot + popcount into a per-wave scratch list) and processed 16 at a time;
+//     only the last chunk of an offset is partially filled;
+//   * each of the 4 waves owns a quarter of the output columns, keeps the matching
+//     [CIN x COUT/4] slice of W[k] in REGISTERS as MFMA B operands (loaded once per offset from
+//     L2, 8-byte loads) and accumulates its slice privately: there is NO barrier in the main loop;
+//   * A fragments (CIN/4 contiguous floats of the gathered input row per lane) are loaded
+//     straight from HBM/L2 with 16-byte loads, one chunk ahead of the MFMAs;
+//   * per chunk the 16 x COUT/4 product is added into the LDS accumulators (8-byte RMW, each
+//     output row appears at most once per offset, so no atomics);
+//   * epilogue from LDS: bias, folded BN, residual, ReLU, 16-byte stores.
+template <int CIN, int COUT, int TM>
+__global__ __launch_bounds__(256) void spconv_pair_kernel(ConvArgs a) {
+  constexpr int KS = CIN / 4;        // k-steps = floats of one input row held by a lane
+  constexpr int CS = COUT / 4;       // output columns per wave
+  constexpr int CT = CS / 16;        // 16-wide column tiles per wave (1 or 2)
+  constexpr int NCH = 2 / CT;        // chunks in flight -> always 2 independent accumulators
+  static_assert(CT == 1 || CT == 2, "COUT must be 64 or 128");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *accL = (float *)smem;                                  // [4][TM][CS]
+  int *nbrL = (int *)(smem + (size_t)4 * TM * CS * 4);          // [K][TM]
+  unsigned short *listL = (unsigned short *)(nbrL + a.K * TM);  // [4][TM]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  int nt = gridDim.x, bid = blockIdx.x, tile = bid;
+  if ((nt & 7) == 0) tile = (bid & 7) * (nt >> 3) + (bid >> 3);
+  const int row0 = tile * TM;
+  const int cs0 = wave * CS;
+
+  for (int e = tid; e < a.K * TM; e += 256) {
+    int k = e / TM, r = e - k * TM;
+    int row = row0 + r;
+    nbrL[e] = (row < a.n_out) ? a.nbr[(size_t)k * a.n_out + row] : -1;
+  }
+  float *myacc = accL + (size_t)wave * TM * CS;
+  for (int e = lane; e < TM * CS / 4; e += 64) ((f32x4 *)myacc)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  unsigned short *mylist = listL + wave * TM;
+  __syncthreads();
+
+  for (int k = 0; k < a.K; ++k) {
+    // ---- compact the valid rows of this offset (identical in every wave) ----
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < TM / 64; ++q) {
+      int r = q * 64 + lane;
+      bool valid = nbrL[k * TM + r] >= 0;
+      unsigned long long m = __ballot(valid);
+      int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+      if (valid) mylist[pos] = (unsigned short)r;
+      cnt += __popcll(m);
+    }
+    if (cnt == 0) continue;
+    __builtin_amdgcn_wave_barrier();
+    // ---- this wave's slice of W[k] as B operands ----
+    float b[KS][CT];
+    {
+      const float *wk = a.w + ((size_t)k * CIN + (size_t)g * KS) * COUT + cs0;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        if (CT == 2) {
+          float2 v = *(const float2 *)(wk + (size_t)j * COUT + 2 * n);
+          b[j][0] = v.x;
+          b[j][CT - 1] = v.y;
+        } else {
+          b[j][0] = wk[(size_t)j * COUT + n];
+        }
+      }
+    }
+    const int nchunk = (cnt + 15) >> 4;
+    const int ngroup = (nchunk + NCH - 1) / NCH;
+    float acur[NCH][KS], anext[NCH][KS];
+    auto load_a = [&](int grp, float (&dst)[NCH][KS]) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        int p = (grp * NCH + h) * 16 + n;
+        int idx = -1;
+        if (p < cnt) idx = nbrL[k * TM + mylist[p]];
+        const float *src = a.feat + (size_t)(idx < 0 ? 0 : idx) * CIN + g * KS;
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (idx >= 0) v = *(const f32x4 *)(src + q * 4);
+          dst[h][q * 4 + 0] = v[0];
+          dst[h][q * 4 + 1] = v[1];
+          dst[h][q * 4 + 2] = v[2];
+          dst[h][q * 4 + 3] = v[3];
+        }
+      }
+    };
+    load_a(0, anext);
+    for (int grp = 0; grp < ngroup; ++grp) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) acur[h][j] = anext[h][j];
+      if (grp + 1 < ngroup) load_a(grp + 1, anext);
+      f32x4 acc[NCH][CT];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[h][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int h = 0; h < NCH; ++h)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            acc[h][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[h][j], b[j][ct], acc[h][ct], 0, 0, 0);
+      // ---- add the 16 x CS products into the LDS accumulators (row = pair slot 4g + r) ----
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        int pbase = (grp * NCH + h) * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int p = pbase + r;
+          if (p < cnt) {
+            int rl = mylist[p];
+            if (CT == 2) {
+              float2 *dst = (float2 *)(myacc + (size_t)rl * CS + 2 * n);
+              float2 v = *dst;
+              v.x += acc[h][0][r];
+              v.y += acc[h][CT - 1][r];
+              *dst = v;
+            } else {
+              myacc[(size_t)rl * CS + n] += acc[h][0][r];
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- epilogue: this wave's CS columns of every row of the tile ----
+  constexpr int LPR = CS / 4;          // lanes per row (float4 each)
+  constexpr int RPI = 64 / LPR;        // rows per iteration
+  const int lr = lane / LPR, lc = (lane % LPR) * 4;
+  f32x4 bi = (f32x4){0.f, 0.f, 0.f, 0.f}, sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = bi;
+  if (a.bias) bi = *(const f32x4 *)(a.bias + cs0 + lc);
+  if (a.scale) sc = *(const f32x4 *)(a.scale + cs0 + lc);
+  if (a.shift) sh = *(const f32x4 *)(a.shift + cs0 + lc);
+  for (int r0 = 0; r0 < TM; r0 += RPI) {
+    int rl = r0 + lr;
+    int row = row0 + rl;
+    if (row < a.n_out) {
+      f32x4 v = *(const f32x4 *)(myacc + (size_t)rl * CS + lc);
+      v = (v + bi) * sc + sh;
+      size_t o = (size_t)row * COUT + cs0 + lc;
+      if (a.residual) v += *(const f32x4 *)(a.residual + o);
+      if (a.relu) {
+        v[0] = fmaxf(v[0], 0.f);
+        v[1] = fmaxf(v[1], 0.f);
+        v[2] = fmaxf(v[2], 0.f);
+        v[3] = fmaxf(v[3], 0.f);
+      }
+      *(f32x4 *)(a.out + o) = v;
+    }
+  }
+}
+
+template <int CIN, int COUT, int TM>
+static int launch_pair(const ConvArgs &a, hipStream_t stream) {
+  size_t lds = (size_t)4 * TM * (COUT / 4) * 4 + (size_t)a.K * TM * 4 + (size_t)4 * TM * 2;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void *)spconv_pair_kernel<CIN, COUT, TM>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+      return DF3D_EHIP;
+    }
+    configured = true;
+  }
+  int nt = cdiv(a.n_out, TM);
+  hipLaunchKernelGGL((spconv_pair_kernel<CIN, COUT, TM>), dim3(nt), dim3(256), lds, stream, a);
+  return DF3D_OK;
+}
+
+// returns 1 if handled, 0 if not applicable, <0 on error
+static int dispatch_pair(const ConvArgs &a, hipStream_t stream) {
+  int rc = 0;
+  if (a.cout == 128) {
+    if (a.cin == 128) rc = launch_pair<128, 128, 128>(a, stream);
+    else if (a.cin == 64) rc = launch_pair<64, 128, 128>(a, stream);
+    else return 0;
+  } else if (a.cout == 64) {
+    if (a.cin == 64) rc = launch_pair<64, 64, 256>(a, stream);
+    else if (a.cin == 32) rc = launch_pair<32, 64, 256>(a, stream);
+    else return 0;
+  } else {
+    return 0;
+  }
+  return rc < 0 ? rc : 1;
+}
+
 // Any-shape fallback (correctness path for channel counts outside the tuned table).
 __global__ __launch_bounds__(256) void spconv_generic_kernel(ConvArgs a) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,7 +506,15 @@ extern "C" int df3d_sparse_conv_fused(const float *features, int n_in, int cin, 
   a.cout = cout;
   a.relu = relu;
   bool done = false;
-  switch (cout) {
+  // v2 (pair-compacted rows) is correct but not yet faster than v1 at nuScenes sizes (too few,
+  // too large tiles for 256 CUs); opt-in until its tile scheduling is reworked.
+  static const bool use_v2 = getenv("DF3D_SPCONV_V2") != nullptr;
+  if (use_v2) {
+    int r = dispatch_pair(a, stream);
+    if (r < 0) return r;
+    done = r == 1;
+  }
+  if (!done) switch (cout) {
     case 16: done = dispatch_cin<16>(a, stream); break;
     case 32: done = dispatch_cin<32>(a, stream); break;
     case 64: done = dispatch_cin<64>(a, stream); break;
