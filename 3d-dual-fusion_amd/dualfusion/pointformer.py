@@ -1,0 +1,159 @@
+"""3-D local self-attention over the LiDAR queries (ACTRv2): `LocalTransformer`
+(reference: CP/det3d/models/model_utils/pointformer.py:250-380; pre-norm encoder layer :10-44;
+helpers CP/det3d/ops/furthest_point_sample/points_sampler.py:34-115,
+CP/det3d/ops/group_points/group_points.py:11-131).
+
+Pipeline: D-FPS of npoint centres -> ball query (radius, nsample) -> group features and ABSOLUTE
+xyz -> position-encoding MLP (1x1 conv + BN2d + ReLU, 1x1 conv) -> `num_layers` pre-norm MHA
+encoder layers over each group (sequence = nsample, batch = B*npoint) -> scatter the transformed
+group features back to the points.  Index ops are the HIP kernels of csrc/pointops.hip; the dense
+layers are plain library GEMMs.  Parameter names follow the reference (`pe.0.conv`, `pe.0.bn`,
+`pe.1.conv`, `chunk.layers.j.{self_attn,linear1,linear2,norm1,norm2}`), SURVEY.md Appendix B.
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops as _ops
+
+
+class ConvModule(nn.Module):
+    """The two mmcv.cnn.ConvModule configurations LocalTransformer uses (pointformer.py:287-290):
+    conv(bias = no norm) [-> BN2d] [-> ReLU], sub-module names `conv` / `bn` / `activate`."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, norm_cfg=None, act_cfg=dict(type='ReLU')):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, bias=norm_cfg is None)
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if self.with_norm:
+            self.bn = nn.BatchNorm2d(out_channels)
+        if self.with_activation:
+            self.activate = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.bn(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
+
+
+class TransformerEncoderLayerPreNorm(nn.Module):
+    """pointformer.py:10-44: x = LN1(x); x = x + MHA(x); x = LN2(x); x = x + FFN(x)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout, inplace=True)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout, inplace=True)
+        self.dropout2 = nn.Dropout(dropout, inplace=True)
+        self.activation = nn.ReLU(inplace=True)
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None):
+        src = self.norm1(src)
+        src2, _ = self.self_attn(src, src, src, attn_mask=src_mask, key_padding_mask=src_key_padding_mask,
+                                 need_weights=False)
+        src = src + self.dropout1(src2)
+        src = self.norm2(src)
+        src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
+        return src + self.dropout2(src2)
+
+
+class _EncoderStack(nn.Module):
+    """Holds `layers` like nn.TransformerEncoder (same state_dict keys `chunk.layers.j.*`) without
+    its fast-path machinery, which does not accept custom layers."""
+
+    def __init__(self, layer, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+class LocalTransformer(nn.Module):
+    def __init__(self, npoint, radius, nsample, dim_feature, dim_out, nhead=4, num_layers=2,
+                 norm_cfg=dict(type="BN2d"), ratio=1, drop=0.0, prenorm=True, attn_feat_agg_method="unique",
+                 feat_agg_method="replace"):
+        super().__init__()
+        if ratio != 1 or not prenorm:
+            raise NotImplementedError("only the pre-norm, ratio=1 configuration used by ACTRv2 is implemented")
+        self.npoint, self.nsample, self.radius = npoint, nsample, radius
+        self.nc_in, self.nc_out = dim_feature, dim_out
+        self.pe = nn.Sequential(ConvModule(3, self.nc_in // 2, 1, norm_cfg=norm_cfg),
+                                ConvModule(self.nc_in // 2, self.nc_in, 1, act_cfg=None, norm_cfg=None))
+        self.chunk = _EncoderStack(TransformerEncoderLayerPreNorm(d_model=self.nc_in, dim_feedforward=2 * self.nc_in,
+                                                                  dropout=drop, nhead=nhead), num_layers)
+        self.attn_feat_agg_method = attn_feat_agg_method
+        self.feat_agg_method = feat_agg_method
+
+    @staticmethod
+    def _winner(idx_flat, n_points):
+        """Per point id the flat group position whose feature is kept by the reference's
+        `unique_idx` (pointformer.py:320-328): scatter_ of flipped (inverse, perm) pairs keeps, for a
+        sequential scatter, the LOWEST flat position of each id.  -1 where a point is in no group."""
+        B, L = idx_flat.shape
+        pos = torch.arange(L, device=idx_flat.device, dtype=torch.int64).expand(B, L)
+        win = torch.full((B, n_points), L, dtype=torch.int64, device=idx_flat.device)
+        win.scatter_reduce_(1, idx_flat.long(), pos, reduce="amin", include_self=True)
+        return torch.where(win == L, torch.full_like(win, -1), win)
+
+    def scatter(self, attn_features, feats, idxs):
+        """attn_features [B,C,N] updated IN PLACE at the grouped point ids (pointformer.py:315-347)."""
+        B, C, np_, ns = feats.shape
+        N = attn_features.shape[2]
+        idx_f = idxs.reshape(B, -1)
+        feat_f = feats.reshape(B, C, -1)
+        if self.attn_feat_agg_method == "unique":
+            win = self._winner(idx_f, N)                                    # [B,N]
+            has = win >= 0
+            picked = torch.gather(feat_f, 2, win.clamp(min=0)[:, None, :].expand(B, C, N))
+            attn_features.copy_(torch.where(has[:, None, :], picked, attn_features))
+        elif self.attn_feat_agg_method == "sum":
+            summed = torch.zeros_like(attn_features).scatter_add_(2, idx_f.long()[:, None, :].expand(B, C, -1), feat_f)
+            cnt = torch.zeros((B, N), device=feats.device).scatter_add_(1, idx_f.long(),
+                                                                        torch.ones_like(idx_f, dtype=torch.float32))
+            attn_features.copy_(torch.where(cnt[:, None, :] > 0, (attn_features + summed) / cnt.clamp(min=1)[:, None, :],
+                                            attn_features))
+        else:
+            raise NotImplementedError(self.attn_feat_agg_method)
+
+    def forward(self, xyz, features):
+        """xyz [B,N,3], features [B,C,N] (may be a permuted view: 'replace' writes through it, as the
+        reference does) -> [B,N,C]."""
+        xyz = xyz.contiguous()
+        feats_c = features.contiguous()
+        fps_idx = _ops.furthest_point_sample(xyz, self.npoint)                          # [B,np]
+        xyz_t = xyz.transpose(1, 2).contiguous()
+        new_xyz = _ops.gather_points(xyz_t, fps_idx).transpose(1, 2).contiguous()       # [B,np,3]
+        group_idx = _ops.ball_query(0.0, self.radius, self.nsample, xyz, new_xyz)       # [B,np,ns]
+        group_xyz = _ops.group_points(xyz_t, group_idx)                                 # [B,3,np,ns] (absolute)
+        group_features = _ops.group_points(feats_c, group_idx)                          # [B,C,np,ns]
+        x = group_features + self.pe(group_xyz)
+        B, D, np_, ns = x.shape
+        x = x.permute(0, 2, 1, 3).reshape(-1, D, ns).permute(2, 0, 1)                   # [ns, B*np, D]
+        y = self.chunk(x).permute(1, 2, 0).reshape(B, np_, D, ns).transpose(1, 2)       # [B,D,np,ns]
+        if self.feat_agg_method == "replace":
+            out = feats_c
+            self.scatter(out, y, group_idx)
+            if out.data_ptr() != features.data_ptr():
+                features.copy_(out)          # the reference mutates its input in place (:371-372)
+            features = out
+        elif self.feat_agg_method == "sum":
+            attn = torch.zeros_like(feats_c)
+            self.scatter(attn, y, group_idx)
+            features = feats_c + attn
+        else:
+            raise NotImplementedError(self.feat_agg_method)
+        return features.permute(0, 2, 1)

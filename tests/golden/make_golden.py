@@ -349,8 +349,158 @@ def gen_fusion():
         torch.tensor = _orig_tensor
 
 
+# ------------------------------------------------------------------ LocalTransformer (a13)
+LT_DIMS = dict(B=2, N=300, C=32, npoint=64, radius=2.0, nsample=8, num_layers=2)
+
+
+def lt_inputs():
+    d = LT_DIMS
+    xyz = detgen.rand("lt_xyz", (d["B"], d["N"], 3), -6, 6)
+    feat = detgen.randn("lt_feat", (d["B"], d["C"], d["N"]))
+    xyz[1, 250:] = 0          # zero-padded tail, as the per-camera query batches have
+    feat[1, :, 250:] = 0
+    return xyz, feat
+
+
+def gen_local_transformer():
+    """Reference LocalTransformer.forward (pointformer.py:349-380) on CPU.  Its four CUDA-only index
+    ops have no CPU implementation in the reference; they are bound to the oracle, which gen_pointops()
+    pins to the reference's own unit-test literals.  mmcv.cnn.ConvModule (absent) is restated for the
+    two configurations used (conv [+BN2d] [+ReLU]; attribute names conv/bn/activate)."""
+    from oracle import oracle as orc
+    import_reference_actr()
+
+    class ConvModule(torch.nn.Module):
+        def __init__(self, cin, cout, k, norm_cfg=None, act_cfg=dict(type="ReLU")):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(cin, cout, k, bias=norm_cfg is None)
+            self.bn = torch.nn.BatchNorm2d(cout) if norm_cfg is not None else None
+            self.activate = torch.nn.ReLU(inplace=True) if act_cfg is not None else None
+            if self.bn is None:
+                del self.bn
+            if self.activate is None:
+                del self.activate
+
+        def forward(self, x):
+            x = self.conv(x)
+            if hasattr(self, "bn"):
+                x = self.bn(x)
+            if hasattr(self, "activate"):
+                x = self.activate(x)
+            return x
+
+    pf = importlib.import_module("det3d.models.model_utils.pointformer")
+    pf.ConvModule = ConvModule
+    pf.gather_points = lambda f, i: torch.from_numpy(orc.gather_points(f.numpy(), i.numpy()))
+
+    class Sampler(torch.nn.Module):
+        def __init__(self, num_point, mods):
+            super().__init__()
+            self.m = num_point[0]
+
+        def forward(self, xyz, feats):
+            return torch.from_numpy(orc.furthest_point_sample(xyz.numpy(), self.m))
+
+    class Grouper(torch.nn.Module):
+        def __init__(self, radius, nsample, **kw):
+            super().__init__()
+            self.r, self.ns = radius, nsample
+
+        def forward(self, xyz, new_xyz, feats):
+            idx = orc.ball_query(0.0, self.r, self.ns, xyz.numpy(), new_xyz.numpy())
+            gx = orc.group_points(xyz.transpose(1, 2).contiguous().numpy(), idx)
+            gf = orc.group_points(feats.numpy(), idx)
+            return torch.from_numpy(gf), torch.from_numpy(gx), torch.from_numpy(idx)
+
+    pf.Points_Sampler, pf.QueryAndGroup = Sampler, Grouper
+    # torch >= 2 passes is_causal to encoder layers; the reference layer (torch 1.x era) does not take it
+    _fw = pf.TransformerEncoderLayerPreNorm.forward
+    pf.TransformerEncoderLayerPreNorm.forward = lambda self, src, src_mask=None, src_key_padding_mask=None, **kw: \
+        _fw(self, src, src_mask, src_key_padding_mask)
+    d = LT_DIMS
+    torch.set_num_threads(1)
+    m = pf.LocalTransformer(d["npoint"], d["radius"], d["nsample"], d["C"], d["C"], num_layers=d["num_layers"],
+                            attn_feat_agg_method="unique", feat_agg_method="replace").eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = detgen.det_state_dict(shapes)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    xyz, feat = lt_inputs()
+    with torch.no_grad():
+        y = m(torch.from_numpy(xyz), torch.from_numpy(feat.copy()))
+    names = np.array(sorted(shapes))
+    save("local_transformer.npz", out=y.numpy(), param_names=names,
+         param_shapes=np.array([str(shapes[k]) for k in names]))
+
+
+# ------------------------------------------------------------------ point ops: the reference's own test vectors
+def gen_pointops():
+    """Run the reference's GPU-only unit tests for FPS / ball query / grouping / gathering
+    (TF/tests/test_models/test_common_modules/test_pointnet_ops.py:9-74,126-238) with `mmdet3d.ops`
+    bound to the ORACLE (so a wrong oracle fails right here) and record every (inputs, expected)
+    pair the tests hold as literals.  The recorded tensors are data; no test source is stored."""
+    from oracle import oracle as orc
+    rec = []
+
+    def wrap(name, fn):
+        def f(*a):
+            out = fn(*a)
+            rec.append([name, [np.asarray(x.numpy() if torch.is_tensor(x) else x) for x in a], None])
+            return out
+        return f
+
+    def fps(xyz, m):
+        return torch.from_numpy(orc.furthest_point_sample(xyz.numpy(), m))
+
+    def bq(min_r, max_r, ns, xyz, new_xyz):
+        return torch.from_numpy(orc.ball_query(min_r, max_r, ns, xyz.numpy(), new_xyz.numpy()))
+
+    def grp(feat, idx):
+        return torch.from_numpy(orc.group_points(feat.numpy(), idx.numpy()))
+
+    def gat(feat, idx):
+        return torch.from_numpy(orc.gather_points(feat.numpy(), idx.numpy()))
+
+    ops_mod = _stub("mmdet3d.ops", ball_query=wrap("ball_query", bq), furthest_point_sample=wrap("fps", fps),
+                    furthest_point_sample_with_dist=None, gather_points=wrap("gather_points", gat),
+                    grouping_operation=wrap("group_points", grp), knn=None, three_interpolate=None, three_nn=None)
+    _stub("mmdet3d").ops = ops_mod
+    src = open("/root/reference/TransFusion/tests/test_models/test_common_modules/test_pointnet_ops.py").read()
+    ns = {}
+    _cuda, _avail, _all, _allclose = torch.Tensor.cuda, torch.cuda.is_available, torch.all, torch.allclose
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.is_available = lambda: True
+
+    def rec_all(x):
+        return _all(x)
+
+    try:
+        exec(compile(src, "test_pointnet_ops", "exec"), ns)
+        out = {}
+        for tname in ("test_fps", "test_ball_query", "test_grouping_points", "test_gather_points"):
+            n0 = len(rec)
+            # capture `expected_*` locals by tracing the assert comparisons
+            import sys as _sys
+            captured = []
+
+            def tracer(frame, event, arg):
+                if event == "return" and frame.f_code.co_name == tname:
+                    captured.append({k: v for k, v in frame.f_locals.items() if torch.is_tensor(v)})
+                return tracer
+            _sys.settrace(tracer)
+            try:
+                ns[tname]()          # asserts inside: the oracle must reproduce the reference's literals
+            finally:
+                _sys.settrace(None)
+            loc = captured[-1]
+            for k, v in loc.items():
+                out["%s__%s" % (tname, k)] = v.numpy()
+        save("pointops_tests.npz", **out)
+    finally:
+        torch.Tensor.cuda, torch.cuda.is_available = _cuda, _avail
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt"]
     if "voxelize" in which:
         gen_voxelize()
     if "rulebook" in which:
@@ -361,6 +511,10 @@ if __name__ == "__main__":
             gen_msda(func)
         if "actr" in which:
             gen_actr(actr)
+    if "pointops" in which:
+        gen_pointops()
+    if "lt" in which:
+        gen_local_transformer()
     if "fusion" in which:
         if "det3d" not in sys.modules:
             import_reference_actr()

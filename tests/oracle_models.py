@@ -72,3 +72,47 @@ def centerpoint_backbone(sd, voxel_features, coors, batch_size, input_shape, fus
 def sort_rows(indices, features):
     o = np.lexsort((indices[:, 3], indices[:, 2], indices[:, 1], indices[:, 0]))
     return indices[o], features[o]
+
+
+# ------------------------------------------------------------------------- LocalTransformer (a13)
+def local_transformer(sd, xyz, feat, npoint, radius, nsample, nhead=4, num_layers=2, winner="first"):
+    """CP/det3d/models/model_utils/pointformer.py:349-380 restated on the CPU (oracle index ops +
+    torch-CPU fp32 for the dense layers).  sd: numpy state_dict of LocalTransformer.  xyz [B,N,3],
+    feat [B,C,N] -> [B,N,C].  `winner`: which duplicate the 'unique' scatter keeps (flat position)."""
+    import torch
+    import torch.nn.functional as F
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(sd[k]))
+    B, C, N = feat.shape
+    fps = orc.furthest_point_sample(xyz, npoint)
+    new_xyz = np.stack([xyz[b][fps[b]] for b in range(B)])
+    idx = orc.ball_query(0.0, radius, nsample, xyz, new_xyz)
+    gx = torch.from_numpy(orc.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx))
+    gf = torch.from_numpy(orc.group_points(feat, idx))
+    pe = F.conv2d(gx, t("pe.0.conv.weight"))
+    pe = F.batch_norm(pe, t("pe.0.bn.running_mean"), t("pe.0.bn.running_var"), t("pe.0.bn.weight"), t("pe.0.bn.bias"),
+                      False, 0.0, 1e-5)
+    pe = F.conv2d(F.relu(pe), t("pe.1.conv.weight"), t("pe.1.conv.bias"))
+    x = gf + pe
+    D, ns = C, nsample
+    x = x.permute(0, 2, 1, 3).reshape(-1, D, ns).permute(2, 0, 1)        # [ns, B*np, D]
+    for j in range(num_layers):
+        p = "chunk.layers.%d." % j
+        h = F.layer_norm(x, (D,), t(p + "norm1.weight"), t(p + "norm1.bias"))
+        a, _ = F.multi_head_attention_forward(h, h, h, D, nhead, t(p + "self_attn.in_proj_weight"),
+                                              t(p + "self_attn.in_proj_bias"), None, None, False, 0.0,
+                                              t(p + "self_attn.out_proj.weight"), t(p + "self_attn.out_proj.bias"),
+                                              training=False, need_weights=False)
+        h = h + a
+        h2 = F.layer_norm(h, (D,), t(p + "norm2.weight"), t(p + "norm2.bias"))
+        f = F.linear(F.relu(F.linear(h2, t(p + "linear1.weight"), t(p + "linear1.bias"))), t(p + "linear2.weight"),
+                     t(p + "linear2.bias"))
+        x = h2 + f
+    y = x.permute(1, 2, 0).reshape(B, npoint, D, ns).transpose(1, 2).numpy()   # [B,D,np,ns]
+    out = feat.copy()
+    for b in range(B):
+        idf = idx[b].reshape(-1)
+        ff = y[b].reshape(C, -1)
+        order = range(len(idf) - 1, -1, -1) if winner == "first" else range(len(idf))
+        for pos in order:               # later writes win
+            out[b][:, idf[pos]] = ff[:, pos]
+    return out.transpose(0, 2, 1)

@@ -143,3 +143,60 @@ def test_centerpoint_fusion_adapter_vs_reference_golden(golden):
     ref = g["out"]
     err = np.abs(out.features.cpu().numpy() - ref).max()
     assert err <= 1e-3 * max(1.0, np.abs(ref).max()), err
+
+
+# ------------------------------------------------------------------------- LocalTransformer (a13) / point ops
+def test_pointops_reference_test_vectors_on_gpu(golden):
+    from dualfusion import ops
+    dev = torch.device("cuda:0")
+    g = golden("pointops_tests.npz")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    assert np.array_equal(ops.furthest_point_sample(T(g["test_fps__xyz"]), 3).cpu().numpy(), g["test_fps__expected_idx"])
+    bq = ops.ball_query(0.2, 0.4, 5, T(g["test_ball_query__xyz"]), T(g["test_ball_query__new_xyz"]))
+    assert np.array_equal(bq.cpu().numpy(), g["test_ball_query__expected_idx"])
+    gp = ops.group_points(T(g["test_grouping_points__festures"]), T(g["test_grouping_points__idx"]))
+    np.testing.assert_allclose(gp.cpu().numpy(), g["test_grouping_points__expected_output"])
+    ga = ops.gather_points(T(g["test_gather_points__features"]), T(g["test_gather_points__idx"]))
+    np.testing.assert_allclose(ga.cpu().numpy(), g["test_gather_points__expected_output"])
+
+
+def test_local_transformer_vs_reference_golden(golden):
+    from dualfusion.pointformer import LocalTransformer
+    from make_golden import LT_DIMS, lt_inputs
+    dev = torch.device("cuda:0")
+    g = golden("local_transformer.npz")
+    d = LT_DIMS
+    m = LocalTransformer(d["npoint"], d["radius"], d["nsample"], d["C"], d["C"], num_layers=d["num_layers"],
+                         attn_feat_agg_method="unique", feat_agg_method="replace").eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert sorted(shapes) == list(g["param_names"])
+    sd = detgen.det_state_dict(shapes)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev)
+    xyz, feat = lt_inputs()
+    with torch.no_grad():
+        y = m(torch.from_numpy(xyz).to(dev), torch.from_numpy(feat.copy()).to(dev))
+    np.testing.assert_allclose(y.cpu().numpy(), g["out"], rtol=1e-3, atol=1e-4)
+
+
+def test_actrv2_builds_and_runs_with_local_transformer():
+    """ACTRv2 (CP `...pfatv2.py`, VR config 5): LocalTransformer before every deformable layer; parameter
+    names transformer.encoder.lidar_attns.i.* (SURVEY.md Appendix B)."""
+    from dualfusion import actr
+    from make_golden import ACTR_CFG
+    dev = torch.device("cuda:0")
+    lt = dict(npoint=128, radius=2.0, nsample=16, num_layers=2, attn_feat_agg_method='unique', feat_agg_method='replace')
+    m = actr.build(dict(ACTR_CFG), model_name="ACTRv2", lt_cfg=lt).eval().to(dev)
+    names = set(m.state_dict())
+    assert "transformer.encoder.lidar_attns.1.chunk.layers.0.self_attn.in_proj_weight" in names
+    assert "transformer.encoder.lidar_attns.0.pe.0.conv.weight" in names
+    N, Q = 2, 400
+    gen = torch.Generator().manual_seed(0)
+    v = torch.randn(N, Q, 128, generator=gen).to(dev)
+    grid = torch.rand(N, Q, 2, generator=gen).to(dev)
+    img = torch.randn(N, 256, 20, 30, generator=gen).to(dev)
+    lid = (torch.rand(N, Q, 3, generator=gen) * 40 - 20).to(dev)
+    vi = torch.randn(N, Q, 256, generator=gen).to(dev)
+    with torch.no_grad():
+        y = m(v_feat=v, grid=grid, i_feats=[img], lidar_grid=lid, v_i_feat=vi)
+    assert tuple(y.shape) == (N, Q, 128) and bool(torch.isfinite(y).all())

@@ -136,3 +136,30 @@ def test_oracle_voxelize_vs_ref_build_fresh():
     b = ref.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 12000)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+# ---- point ops: the reference's own (GPU-only) unit-test literals, recorded by make_golden.gen_pointops()
+def test_pointops_reference_test_vectors(golden):
+    g = golden("pointops_tests.npz")
+    assert np.array_equal(orc.furthest_point_sample(g["test_fps__xyz"], 3), g["test_fps__expected_idx"])
+    # the fixture holds the test's final (dilated, min_radius 0.2) ball query; the plain one is re-derived below
+    assert np.array_equal(orc.ball_query(0.2, 0.4, 5, g["test_ball_query__xyz"], g["test_ball_query__new_xyz"]),
+                          g["test_ball_query__expected_idx"])
+    plain = orc.ball_query(0, 0.2, 5, g["test_ball_query__xyz"], g["test_ball_query__new_xyz"])
+    assert np.array_equal(plain[0, 0], [0, 0, 0, 0, 0]) and np.array_equal(plain[0, 1], [6, 6, 6, 6, 6])
+    np.testing.assert_allclose(orc.group_points(g["test_grouping_points__festures"], g["test_grouping_points__idx"]),
+                               g["test_grouping_points__expected_output"])
+    np.testing.assert_allclose(orc.gather_points(g["test_gather_points__features"], g["test_gather_points__idx"]),
+                               g["test_gather_points__expected_output"])
+
+
+def test_local_transformer_oracle_vs_reference_golden(golden):
+    import oracle_models as om
+    from make_golden import LT_DIMS, lt_inputs
+    g = golden("local_transformer.npz")
+    shapes = {str(k): eval(str(s)) for k, s in zip(g["param_names"], g["param_shapes"])}
+    sd = detgen.det_state_dict(shapes)
+    xyz, feat = lt_inputs()
+    d = LT_DIMS
+    y = om.local_transformer(sd, xyz, feat, d["npoint"], d["radius"], d["nsample"], num_layers=d["num_layers"])
+    np.testing.assert_allclose(y, g["out"], atol=2e-5)
