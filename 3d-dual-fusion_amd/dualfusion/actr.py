@@ -390,8 +390,8 @@ class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
-def build(model_cfg, model_name='ACTR', lt_cfg=None):
-    """actr.py:619-657 with the argparse defaults it relies on (actr_utils.py:548-646): nheads 8,
+def build(model_cfg, model_name='ACTR', lt_cfg=None, hybrid_cfg=None):
+    """actr.py:619-657 (the Voxel-RCNN tree passes hybrid_cfg separately, VR/.../actr.py:619) with the argparse defaults it relies on (actr_utils.py:548-646): nheads 8,
     enc_n_points 4, dim_feedforward 1024, dropout 0.1."""
     if model_name not in ('ACTR', 'ACTRv2'):
         raise NotImplementedError("%s: only ACTR / ACTRv2 are used by the 3D-DF configs" % model_name)
@@ -403,7 +403,7 @@ def build(model_cfg, model_name='ACTR', lt_cfg=None):
         dropout=0.1, activation="relu", return_intermediate_dec=True, num_feature_levels=len(num_channels),
         enc_n_points=4, two_stage=False, two_stage_num_proposals=300, model_name=model_name,
         lt_cfg=_Cfg(lt_cfg) if lt_cfg is not None else None, feature_modal=get('feature_modal', 'lidar'),
-        hybrid_cfg=get('hybrid_cfg', None))
+        hybrid_cfg=hybrid_cfg if hybrid_cfg is not None else get('hybrid_cfg', None))
     return ACTR(transformer, num_feature_levels=len(num_channels), p_num_channels=get('p_num_channels', None),
                 num_channels=num_channels, max_num_ne_voxel=get('max_num_ne_voxel'),
                 pos_encode_method=get('pos_encode_method'), feature_modal=get('feature_modal', 'lidar'))

@@ -158,3 +158,384 @@ class SpMiddleResNetFHDFusion(SpMiddleResNetFHD):
             x_conv4 = fuse_func(batch_dict, example, encoded_voxel_list=[x_conv2, x_conv3, x_conv4],
                                 layer_name='layer1_ori', fuse_mode='pfat', d_factor_list=[2, 4, 8])
         return self._tail(x_conv1, x_conv2, x_conv3, x_conv4)
+
+
+# =======================================================================================
+# TransFusion tree (mmdet3d 0.11 fork)
+# =======================================================================================
+from .registry import CONV_LAYERS  # noqa: E402
+
+for _n, _c in (("SubMConv3d", spconv.SubMConv3d), ("SparseConv3d", spconv.SparseConv3d),
+               ("SubMConv2d", spconv.SubMConv2d), ("SparseConv2d", spconv.SparseConv2d),
+               ("SparseInverseConv3d", spconv.SparseInverseConv3d)):
+    if CONV_LAYERS.get(_n) is None:
+        CONV_LAYERS.register_module(_c, name=_n)
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    """mmcv.cnn.build_conv_layer for the sparse conv types (TF/mmdet3d/ops/spconv/conv.py:207-455 registers
+    them into mmcv's CONV_LAYERS)."""
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    cls = CONV_LAYERS.get(t)
+    if cls is None:
+        raise KeyError("Unrecognized conv type %s" % t)
+    return cls(*args, **kwargs, **cfg)
+
+
+class TFSparseBasicBlock(spconv.SparseModule):
+    """TF/mmdet3d/ops/sparse_block.py:67-120 over mmdet's BasicBlock: conv1/bn1/conv2/bn2 (convs
+    bias=False, no indice_key -> the rulebook of every conv is rebuilt; here the occupancy directory is
+    shared, so a rebuild is one neighbour-table kernel).  `norm1`/`norm2` alias bn1/bn2 like mmdet."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, conv_cfg=None, norm_cfg=None):
+        super().__init__()
+        conv_cfg = conv_cfg or dict(type='SubMConv3d')
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 3, stride=stride, padding=1, dilation=1, bias=False)
+        self.bn1 = build_norm_layer(norm_cfg, planes)[1]
+        self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3, padding=1, bias=False)
+        self.bn2 = build_norm_layer(norm_cfg, planes)[1]
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    @property
+    def norm1(self):
+        return self.bn1
+
+    @property
+    def norm2(self):
+        return self.bn2
+
+    def forward(self, x):
+        if not self.training and can_fold(self.bn1) and can_fold(self.bn2) and self.downsample is None:
+            return _fused_basic_block(x, self.conv1, self.bn1, self.conv2, self.bn2, None)
+        identity = x.features
+        out = self.conv1(x)
+        out.features = self.relu(self.bn1(out.features))
+        out = self.conv2(out)
+        out.features = self.bn2(out.features)
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out.features = self.relu(out.features + identity)
+        return out
+
+
+def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key, stride=1, padding=0,
+                           conv_type='SubMConv3d', norm_cfg=None, order=('conv', 'norm', 'act')):
+    """TF/mmdet3d/ops/sparse_block.py:123-185."""
+    assert isinstance(order, tuple) and len(order) <= 3
+    assert set(order) | {'conv', 'norm', 'act'} == {'conv', 'norm', 'act'}
+    conv_cfg = dict(type=conv_type, indice_key=indice_key)
+    layers = []
+    for layer in order:
+        if layer == 'conv':
+            if conv_type not in ['SparseInverseConv3d', 'SparseInverseConv2d', 'SparseInverseConv1d']:
+                layers.append(build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                               padding=padding, bias=False))
+            else:
+                layers.append(build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, bias=False))
+        elif layer == 'norm':
+            layers.append(build_norm_layer(norm_cfg, out_channels)[1])
+        elif layer == 'act':
+            layers.append(nn.ReLU(inplace=True))
+    return spconv.SparseSequential(*layers)
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseEncoder(nn.Module):
+    """TF/mmdet3d/models/middle_encoders/sparse_encoder.py:11-204 (and the fusion variant :207-448).
+    forward(voxel_features, coors, batch_size) -> [B, C*D, H, W]."""
+
+    def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
+                 encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type='conv_module'):
+        super().__init__()
+        assert block_type in ['conv_module', 'basicblock']
+        self.sparse_shape = sparse_shape
+        self.in_channels = in_channels
+        self.order = order
+        self.base_channels = base_channels
+        self.output_channels = output_channels
+        self.encoder_channels = encoder_channels
+        self.encoder_paddings = encoder_paddings
+        self.stage_num = len(self.encoder_channels)
+        self.fp16_enabled = False
+        assert isinstance(order, tuple) and len(order) == 3
+        assert set(order) == {'conv', 'norm', 'act'}
+        if self.order[0] != 'conv':
+            self.conv_input = make_sparse_convmodule(in_channels, self.base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                     indice_key='subm1', conv_type='SubMConv3d', order=('conv',))
+        else:
+            self.conv_input = make_sparse_convmodule(in_channels, self.base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                     indice_key='subm1', conv_type='SubMConv3d')
+        encoder_out_channels = self.make_encoder_layers(make_sparse_convmodule, norm_cfg, self.base_channels,
+                                                        block_type=block_type)
+        self.conv_out = make_sparse_convmodule(encoder_out_channels, self.output_channels, kernel_size=(3, 1, 1),
+                                               stride=(2, 1, 1), norm_cfg=norm_cfg, padding=0,
+                                               indice_key='spconv_down2', conv_type='SparseConv3d')
+
+    def make_encoder_layers(self, make_block, norm_cfg, in_channels, block_type='conv_module',
+                            conv_cfg=dict(type='SubMConv3d')):
+        self.encoder_layers = spconv.SparseSequential()
+        for i, blocks in enumerate(self.encoder_channels):
+            blocks_list = []
+            for j, out_channels in enumerate(tuple(blocks)):
+                padding = tuple(self.encoder_paddings[i])[j]
+                if i != 0 and j == 0 and block_type == 'conv_module':
+                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
+                                                  padding=padding, indice_key='spconv%d' % (i + 1),
+                                                  conv_type='SparseConv3d'))
+                elif block_type == 'basicblock':
+                    if j == len(blocks) - 1 and i != len(self.encoder_channels) - 1:
+                        blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
+                                                      padding=padding, indice_key='spconv%d' % (i + 1),
+                                                      conv_type='SparseConv3d'))
+                    else:
+                        blocks_list.append(TFSparseBasicBlock(out_channels, out_channels, norm_cfg=norm_cfg,
+                                                              conv_cfg=conv_cfg))
+                else:
+                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, padding=padding,
+                                                  indice_key='subm%d' % (i + 1), conv_type='SubMConv3d'))
+                in_channels = out_channels
+            self.encoder_layers.add_module('encoder_layer%d' % (i + 1), spconv.SparseSequential(*blocks_list))
+        return out_channels
+
+    def _dense_out(self, x):
+        out = self.conv_out(x)
+        spatial_features = out.dense()
+        N, C, D, H, W = spatial_features.shape
+        return spatial_features.view(N, C * D, H, W)
+
+    def forward(self, voxel_features, coors, batch_size):
+        coors = coors.int()
+        x = self.conv_input(spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size))
+        for encoder_layer in self.encoder_layers._modules.values():
+            x = encoder_layer(x)
+        return self._dense_out(x)
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseEncoderFusion(SparseEncoder):
+    """sparse_encoder.py:207-448: SparseEncoder + a fusion layer applied to the output of the stages
+    listed in `fusion_pos` (voxel centres via coor2pts, :309-319)."""
+
+    def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
+                 encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type='conv_module',
+                 fusion_layer=None, fusion_pos=None, voxel_size=None, point_cloud_range=None, ret_img_map=False):
+        super().__init__(in_channels, sparse_shape, order, norm_cfg, base_channels, output_channels, encoder_channels,
+                         encoder_paddings, block_type)
+        self.fusion_layer = None
+        self.fusion_pos = None
+        self.ret_img_map = ret_img_map
+        if fusion_layer is not None:
+            from .registry import FUSION_LAYERS, build_from_cfg
+            from . import fusion_tf  # noqa: F401  (registers 'ACTR' into FUSION_LAYERS)
+            self.fusion_layer = fusion_layer if isinstance(fusion_layer, nn.Module) else \
+                build_from_cfg(fusion_layer, FUSION_LAYERS)
+            self.fusion_pos = fusion_pos
+            self.voxel_size = voxel_size
+            self.point_cloud_range = point_cloud_range
+
+    def coor2pts(self, x, pad=0.0):
+        """:309-319: voxel index (+pad) -> metric (x, y, z); ratio taken from the y dimension."""
+        ratio = self.sparse_shape[1] / x.spatial_shape[1]
+        scale = torch.tensor((list(self.voxel_size) + [1])[::-1], dtype=torch.float32, device=x.indices.device)
+        pts = (x.indices.to(torch.float) + pad) * scale * ratio
+        pts[:, 0] = pts[:, 0] / ratio - pad
+        pts[:, 1:] += torch.tensor(self.point_cloud_range[:3][::-1], dtype=torch.float32, device=pts.device)
+        pts[:, 1:] = pts[:, [3, 2, 1]]
+        return pts            # [N, 4] (b, x, y, z); rows are batch-sorted
+
+    def forward(self, voxel_features, coors, batch_size, img_feats=None, img_metas=None, points=None,
+                ret_lidar_features=False, img=None):
+        coors = coors.int()
+        x = self.conv_input(spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size))
+        encode_features, lidar_features = [], []
+        for idx, encoder_layer in enumerate(self.encoder_layers._modules.values()):
+            x = encoder_layer(x)
+            if ret_lidar_features:
+                lidar_features.append(x)
+            if self.fusion_pos is not None and idx in self.fusion_pos:
+                c_pts = self.coor2pts(x, 0.5)
+                x = x.replace_feature(self.fusion_layer(img_feats, c_pts, x.features, img_metas, img))
+            encode_features.append(x)
+        spatial_features = self._dense_out(encode_features[-1])
+        if ret_lidar_features:
+            return (spatial_features, encode_features[-1], img_feats)
+        return spatial_features
+
+
+# =======================================================================================
+# Voxel-RCNN tree (OpenPCDet 0.5.2 fork)
+# =======================================================================================
+from functools import partial  # noqa: E402
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type="subm",
+                   norm_fn=None):
+    """VR/pcdet/models/backbones_3d/spconv_backbone.py:33-75."""
+    if conv_type == "subm":
+        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+    elif conv_type == "spconv":
+        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                                   indice_key=indice_key)
+    else:
+        raise NotImplementedError(conv_type)
+    return spconv.SparseSequential(conv, norm_fn(out_channels), nn.ReLU())
+
+
+class VoxelBackBone8x(nn.Module):
+    """VR/pcdet/models/backbones_3d/spconv_backbone.py:135-243: batch_dict in / out."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = [int(v) for v in (np.asarray(grid_size)[::-1] + [1, 0, 0])]
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key="subm1"), norm_fn(16), nn.ReLU())
+        block = post_act_block
+        self.conv1 = spconv.SparseSequential(block(16, 16, 3, norm_fn=norm_fn, padding=1, indice_key="subm1"))
+        self.conv2 = spconv.SparseSequential(
+            block(16, 32, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key="spconv2", conv_type="spconv"),
+            block(32, 32, 3, norm_fn=norm_fn, padding=1, indice_key="subm2"),
+            block(32, 32, 3, norm_fn=norm_fn, padding=1, indice_key="subm2"))
+        self.conv3 = spconv.SparseSequential(
+            block(32, 64, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key="spconv3", conv_type="spconv"),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key="subm3"),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key="subm3"))
+        self.conv4 = spconv.SparseSequential(
+            block(64, 64, 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key="spconv4", conv_type="spconv"),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key="subm4"),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key="subm4"))
+        last_pad = model_cfg.get("last_pad", 0) if hasattr(model_cfg, "get") else 0
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(64, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key="spconv_down2"), norm_fn(128), nn.ReLU())
+        self.num_point_features = 128
+        self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64}
+
+    def _fuse1(self, x_conv1, batch_dict):
+        return x_conv1
+
+    def _fuse4(self, x_conv2, x_conv3, x_conv4, batch_dict):
+        return x_conv4
+
+    def forward(self, batch_dict):
+        voxel_features, voxel_coords = batch_dict["voxel_features"], batch_dict["voxel_coords"]
+        batch_size = batch_dict["batch_size"]
+        x = self.conv_input(spconv.SparseConvTensor(voxel_features, voxel_coords.int(), self.sparse_shape, batch_size))
+        x_conv1 = self._fuse1(self.conv1(x), batch_dict)
+        x_conv2 = self.conv2(x_conv1)
+        x_conv3 = self.conv3(x_conv2)
+        x_conv4 = self._fuse4(x_conv2, x_conv3, self.conv4(x_conv3), batch_dict)
+        out = self.conv_out(x_conv4)
+        batch_dict.update({"encoded_spconv_tensor": out, "encoded_spconv_tensor_stride": 8})
+        batch_dict.update({"multi_scale_3d_features": {"x_conv1": x_conv1, "x_conv2": x_conv2, "x_conv3": x_conv3,
+                                                       "x_conv4": x_conv4}})
+        batch_dict.update({"multi_scale_3d_strides": {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}})
+        return batch_dict
+
+
+class VoxelBackBone8xFusion(VoxelBackBone8x):
+    """VR/pcdet/models/backbones_3d/spconv_backbone.py:436-928, camera branch reduced to the hot path:
+    MVX nearest-pixel sum at stride 1 (:733-756, FUSION_POS has 1) and ACTR(v2) dual-query fusion at
+    stride 8 (:760-814, FUSION_POS has 4), one camera.
+
+    Differences from the reference call protocol (documented in DESIGN.md): the 2-D network (`semseg`,
+    frozen DeepLabV3) is out of scope, so its outputs are read from `batch_dict['img_dict']`
+    ({'mvx_layer1_feat2d' | 'layer1_feat2d': [B,C,h,w]}); the KITTI calibration objects, whose
+    `lidar_to_img` runs in numpy on the CPU (:717-718), are replaced by `batch_dict['lidar2img']`
+    [B,3,4] = P2 @ R0 @ Tr on the device.  I_FUSION_METHOD (image gate) is not implemented for this tree:
+    the shipped `_ifat` yaml cannot be constructed by the reference itself."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__(model_cfg, input_channels, grid_size, **kwargs)
+        get = model_cfg.get
+        self.fusion_pos = get("FUSION_POS", [1])
+        self.fusion_method = get("FUSION_METHOD", "MVX")
+        self.feature_levels = get("FEATURE_LEVELS", [0])
+        self.register_buffer("voxel_size", torch.tensor([0.1, 0.05, 0.05]), persistent=False)          # z, y, x
+        self.register_buffer("point_cloud_range", torch.tensor([-3., -40., 0., 1., 40., 70.4]), persistent=False)
+        self.img_out_channel = 16 if 1 in self.fusion_pos else 64
+        if get("I_FUSION_METHOD", False):
+            raise NotImplementedError("I_FUSION_METHOD for the Voxel-RCNN tree")
+        if "ACTR" in self.fusion_method:
+            from .actr import build as build_actr
+            model_name = self.fusion_method if "MVX+" not in self.fusion_method else self.fusion_method[4:]
+            actr_cfg = get("ACTR_CFG", None)
+            assert actr_cfg is not None
+            self.actr = build_actr(actr_cfg, model_name=model_name, lt_cfg=get("LT_CFG", None),
+                                   hybrid_cfg=get("HYBRID_CFG", None))
+            self.max_num_nev = actr_cfg.get("max_num_ne_voxel", 26000)
+
+    # ------------------------------------------------------------------ geometry (device-side)
+    def _project(self, x, voxel_stride, batch_dict):
+        """voxel corner (z,y,x) -> LiDAR xyz -> image pixel (float) through lidar2img [B,3,4]."""
+        ind = x.indices
+        v3d = ind[:, 1:].float() * voxel_stride * self.voxel_size + self.point_cloud_range[:3]      # (z,y,x)
+        xyz = v3d[:, [2, 1, 0]]
+        for k in ("noise_scale", "noise_rot", "flip_x", "flip_y"):
+            if k in batch_dict:
+                raise NotImplementedError("inverse 3-D augmentation (%s) is a training-time row" % k)
+        P = batch_dict["lidar2img"].float()[ind[:, 0].long()]                                        # [N,3,4]
+        h = torch.einsum('nij,nj->ni', P, torch.cat([xyz, torch.ones_like(xyz[:, :1])], 1))
+        uv = h[:, :2] / h[:, 2:3]
+        return xyz, uv
+
+    def _sample_int(self, fmap, b, uv, hw):
+        """bilinear upsample to the image size, then nearest-integer (truncated) pixel gather (:682-731)."""
+        h, w = hw
+        up = nn.functional.interpolate(fmap, (h, w), mode="bilinear")
+        px = uv.long()                                      # torch.Tensor(voxels_2d).long(): truncation
+        ok = (px[:, 1] >= 0) & (px[:, 1] < h) & (px[:, 0] >= 0) & (px[:, 0] < w)
+        pxc = torch.stack([px[:, 0].clamp(0, w - 1), px[:, 1].clamp(0, h - 1)], 1)
+        feat = up[b, :, pxc[:, 1], pxc[:, 0]]
+        return torch.where(ok[:, None], feat, torch.zeros_like(feat))
+
+    def _fuse1(self, x_conv1, batch_dict):
+        if 1 not in self.fusion_pos:
+            return x_conv1
+        img_dict = batch_dict["img_dict"]
+        fmap = img_dict["mvx_layer1_feat2d"] if "mvx_layer1_feat2d" in img_dict else next(iter(img_dict.values()))
+        hw = tuple(batch_dict["images"].shape[2:]) if "images" in batch_dict else tuple(batch_dict["image_hw"])
+        _, uv = self._project(x_conv1, 1, batch_dict)
+        img_feat = self._sample_int(fmap, x_conv1.indices[:, 0].long(), uv, hw)
+        return x_conv1.replace_feature(x_conv1.features + img_feat)           # MVX, fuse_sum=True (:746-748)
+
+    def _fuse4(self, x_conv2, x_conv3, x_conv4, batch_dict):
+        if 4 not in self.fusion_pos or "ACTR" not in self.fusion_method:
+            return x_conv4
+        img_dict = batch_dict["img_dict"]
+        x_rgb = [v for k, v in img_dict.items() if k != "mvx_layer1_feat2d"]
+        hw = tuple(batch_dict["images"].shape[2:]) if "images" in batch_dict else tuple(batch_dict["image_hw"])
+        xyz, uv = self._project(x_conv4, 8, batch_dict)
+        ind = x_conv4.indices
+        b = ind[:, 0].long()
+        B = batch_dict["batch_size"]
+        feats = x_conv4.features
+        i_feat = self._sample_int(x_rgb[0], b, uv, hw)
+        counts = torch.bincount(b, minlength=B)
+        n_max = int(counts.max().item())                      # host sync (the reference pads to max_num_nev then slices)
+        starts = torch.cumsum(counts, 0) - counts
+        slot = torch.arange(ind.shape[0], device=ind.device) - starts[b]       # rows are batch-sorted
+        C = feats.shape[1]
+        v_feat = feats.new_zeros((B, n_max, C))
+        v_i = feats.new_zeros((B, n_max, i_feat.shape[1]))
+        grid = feats.new_zeros((B, n_max, 2))
+        pts = feats.new_zeros((B, n_max, 3))
+        v_feat[b, slot] = feats
+        v_i[b, slot] = i_feat
+        grid[b, slot] = uv / torch.tensor([hw[1], hw[0]], dtype=torch.float32, device=uv.device)
+        pts[b, slot] = xyz
+        enh = self.actr(v_feat=v_feat, v_i_feat=v_i, grid=grid, i_feats=x_rgb, lidar_grid=pts)
+        return x_conv4.replace_feature(enh[b, slot] + feats)                  # fuse_sum=True (:808-810)
+
+
+BACKBONES_3D.register_module(VoxelBackBone8x)
+BACKBONES_3D.register_module(VoxelBackBone8xFusion)

@@ -1,0 +1,125 @@
+"""TransFusion-tree camera fusion layer `ACTR` (registry FUSION_LAYERS; reference
+TF/mmdet3d/models/fusion_layers/point_fusion.py:315-643).
+
+The reference projects voxel centres with per-sample nuScenes-devkit DB lookups on the CPU
+(lidar -> ego -> global -> ego_cam -> cam, :551-643) and cannot run without the dataset on disk
+(SURVEY.md Appendix C item 12).  This layer takes the equivalent per-camera 4x4 `lidar2cam` and 3x3
+`cam_intrinsic` (or a 4x4 `lidar2img`) from `img_metas` and does everything on the device, batched:
+  visibility   depth > 1, 1 < u < W_ori-1, 1 < v < H_ori-1 on the ORIGINAL image (:612-617)
+  image coords u,v * scale_factor - crop_offset [flip]; normalised by the padded input shape (:519-540)
+  assignment   a voxel seen by several cameras goes to the LAST one; unseen voxels stay with camera 0
+               at (0, 0) and still form queries (:544-547, Appendix C item 6)
+  per-query image feature = level-0 map at (pixel // 4) (:375-378)
+  write-back   pts_feats + enh (fusion_method 'sum'), one contribution per voxel (:482-491)
+"""
+import torch
+from torch import nn
+
+from .actr import build as build_actr
+from .registry import FUSION_LAYERS
+
+
+@FUSION_LAYERS.register_module(name="ACTR")
+class ACTRFusionLayer(nn.Module):
+    def __init__(self, pfat_cfg, init_cfg=None, lt_cfg=None, coord_type='LIDAR', activate_out=False,
+                 data_version='v1.0-trainval', data_root='./data/nuscenes', model_name='ACTR', num_cams=6):
+        super().__init__()
+        self.fusion_method = pfat_cfg['fusion_method']
+        if self.fusion_method not in ('sum', 'replace', 'concat'):
+            raise NotImplementedError("fusion_method %r" % self.fusion_method)
+        self.actr = build_actr(pfat_cfg, lt_cfg=lt_cfg, model_name=model_name)
+        self.coord_type = coord_type
+        self.activate_out = activate_out
+        self.num_cams = num_cams
+
+    # ------------------------------------------------------------------ geometry
+    @staticmethod
+    def _calib(img_metas, dev):
+        l2c = torch.stack([torch.as_tensor(m['lidar2cam'], dtype=torch.float32) for m in img_metas]).to(dev)   # [B,6,4,4]
+        K = torch.stack([torch.as_tensor(m['cam_intrinsic'], dtype=torch.float32) for m in img_metas]).to(dev)  # [B,6,3,3]
+        return l2c, K
+
+    def project(self, pts, img_metas):
+        """pts [N,4] (b,x,y,z) batch-sorted -> cam_id [N] int64, coor_norm [N,2], coor_pix [N,2] (input-image px)."""
+        dev = pts.device
+        for m in img_metas:
+            if any(k in m for k in ('pcd_rotation', 'pcd_trans', 'pcd_scale_factor')) or m.get('pcd_horizontal_flip') \
+                    or m.get('pcd_vertical_flip'):
+                raise NotImplementedError("inverse 3-D augmentation is a training-time row (SURVEY.md §8f)")
+        l2c, K = self._calib(img_metas, dev)
+        b = pts[:, 0].long()
+        xyz1 = torch.cat([pts[:, 1:4], torch.ones_like(pts[:, :1])], 1)              # [N,4]
+        cam = torch.einsum('ncij,nj->nci', l2c[b], xyz1)[..., :3]                    # [N,6,3]
+        depth = cam[..., 2]
+        uvw = torch.einsum('ncij,ncj->nci', K[b], cam)
+        u = uvw[..., 0] / uvw[..., 2]
+        v = uvw[..., 1] / uvw[..., 2]
+        ori = torch.tensor([[m['ori_shape'][0], m['ori_shape'][1]] for m in img_metas], dtype=torch.float32, device=dev)
+        H = ori[b, 0][:, None]
+        W = ori[b, 1][:, None]
+        vis = (depth > 1.0) & (u > 1) & (u < W - 1) & (v > 1) & (v < H - 1)
+        sf = torch.tensor([list(m.get('scale_factor', [1.0, 1.0]))[:2] for m in img_metas], dtype=torch.float32, device=dev)
+        off = torch.tensor([list(m.get('img_crop_offset', [0.0, 0.0]))[:2] if not isinstance(m.get('img_crop_offset', 0), (int, float))
+                            else [float(m.get('img_crop_offset', 0))] * 2 for m in img_metas], dtype=torch.float32, device=dev)
+        x = u * sf[b, 0][:, None] - off[b, 0][:, None]
+        y = v * sf[b, 1][:, None] - off[b, 1][:, None]
+        flip = torch.tensor([bool(m.get('flip', False)) for m in img_metas], device=dev)
+        iw = torch.tensor([m['img_shape'][1] for m in img_metas], dtype=torch.float32, device=dev)
+        x = torch.where(flip[b][:, None], iw[b][:, None] - x, x)
+        pad = torch.tensor([[m['input_shape'][0], m['input_shape'][1]] for m in img_metas], dtype=torch.float32, device=dev)
+        # last visible camera wins; none -> camera 0 at (0,0)
+        ncam = vis.shape[1]
+        order = torch.arange(1, ncam + 1, device=dev)[None, :] * vis.long()
+        last = order.max(1)[0]                                                        # 0 = unseen
+        cam_id = (last - 1).clamp(min=0)
+        seen = last > 0
+        gx = torch.gather(x, 1, cam_id[:, None])[:, 0]
+        gy = torch.gather(y, 1, cam_id[:, None])[:, 0]
+        pix = torch.stack([torch.where(seen, gx, torch.zeros_like(gx)), torch.where(seen, gy, torch.zeros_like(gy))], 1)
+        norm = torch.stack([pix[:, 0] / pad[b, 1], pix[:, 1] / pad[b, 0]], 1)
+        return cam_id, norm, pix
+
+    def assemble(self, img_feats, pts, pts_feats, cam_id, norm, pix, batch_size):
+        """split_param (:342-382) without the Python double loop: per (b, cam) zero-padded query sets."""
+        dev = pts.device
+        N6 = batch_size * self.num_cams
+        b = pts[:, 0].long()
+        seg = b * self.num_cams + cam_id                                              # [N] image index
+        counts = torch.bincount(seg, minlength=N6)
+        max_pts = int(counts.max().item()) if seg.numel() else 0                      # host sync (the reference's too)
+        # slot = rank of the row among rows of the same segment, in row order
+        order = torch.argsort(seg, stable=True)
+        starts = torch.cumsum(counts, 0) - counts
+        slot = torch.empty_like(seg)
+        slot[order] = torch.arange(seg.numel(), device=dev) - starts[seg[order]]
+        C = pts_feats.shape[1]
+        IC = img_feats[0].shape[1]
+        v_feat = pts_feats.new_zeros((N6, max_pts, C))
+        v_i_feat = pts_feats.new_zeros((N6, max_pts, IC))
+        grid = pts_feats.new_zeros((N6, max_pts, 2))
+        qpts = pts_feats.new_zeros((N6, max_pts, 3))
+        v_feat[seg, slot] = pts_feats
+        grid[seg, slot] = norm
+        qpts[seg, slot] = pts[:, 1:4]
+        ic = (pix.to(torch.long) // 4)
+        v_i_feat[seg, slot] = img_feats[0][seg, :, ic[:, 1], ic[:, 0]]
+        return v_feat, v_i_feat, grid, qpts, seg, slot
+
+    def forward(self, img_feats, pts, pts_feats, img_metas, imgs=None):
+        """pts: [N,4] (b,x,y,z) tensor from SparseEncoderFusion.coor2pts (or the reference's list of
+        per-sample [n_b,3] tensors); pts_feats [N,C].  Returns fused [N,C]."""
+        if isinstance(pts, (list, tuple)):
+            pts = torch.cat([torch.cat([p.new_full((p.shape[0], 1), i), p[:, :3]], 1) for i, p in enumerate(pts)])
+        batch_size = len(img_metas)
+        img_feats = list(img_feats[:self.actr.num_backbone_outs])
+        cam_id, norm, pix = self.project(pts, img_metas)
+        v_feat, v_i_feat, grid, qpts, seg, slot = self.assemble(img_feats, pts, pts_feats, cam_id, norm, pix, batch_size)
+        enh = self.actr(v_feat=v_feat, grid=grid, i_feats=img_feats, lidar_grid=qpts, v_i_feat=v_i_feat)
+        enh_cat = enh[seg, slot]
+        if self.fusion_method == 'replace':
+            out = enh_cat
+        elif self.fusion_method == 'concat':
+            out = torch.cat((pts_feats, enh_cat), dim=1)
+        else:
+            out = pts_feats + enh_cat
+        return torch.relu(out) if self.activate_out else out

@@ -84,6 +84,16 @@ class SparseConvolution(SparseModule):
             return datas
         if self.transposed:
             raise Df3dError("transposed sparse convolution is not implemented on the MI355X path")
+        # SubM convs without an indice_key (every BasicBlock conv of the TransFusion encoder,
+        # sparse_block.py:85-100) rebuild an identical rulebook in the reference; the neighbour table
+        # only depends on the index set and the kernel geometry, so it is shared here.
+        auto_key = None
+        if self.subm and self.indice_key is None:
+            auto_key = ("__subm", tuple(self.kernel_size), tuple(self.dilation), input.indices.data_ptr(),
+                        input.indices.shape[0])
+            hit = input.indice_dict.get(auto_key)
+            if hit is not None:
+                return hit
         directory = input.directory()
         outids, nbr, out_shape, out_dir = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape,
                                                              self.kernel_size, self.stride, self.padding,
@@ -91,7 +101,7 @@ class SparseConvolution(SparseModule):
         rb = Rulebook(outids, input.indices, nbr, input.spatial_shape, out_shape, out_rows_sorted=not self.subm)
         if out_dir is not None and not self.subm:
             input._directories[(outids.data_ptr(), outids.shape[0])] = out_dir
-        input.indice_dict[self.indice_key] = rb
+        input.indice_dict[auto_key if auto_key is not None else self.indice_key] = rb
         return rb
 
     def forward_fused(self, input, scale=None, shift=None, relu=False, residual=None):

@@ -116,3 +116,55 @@ def local_transformer(sd, xyz, feat, npoint, radius, nsample, nhead=4, num_layer
         for pos in order:               # later writes win
             out[b][:, idf[pos]] = ff[:, pos]
     return out.transpose(0, 2, 1)
+
+
+# ------------------------------------------------------------------------- TransFusion / Voxel-RCNN encoders
+def _cbr(sd, pconv, pbn, x, ks, stride, padding, subm, key=None):
+    out = _conv(sd, pconv, x, ks, stride, padding, subm, key)
+    out.features = np.maximum(_bn(sd, pbn, out.features), 0)
+    return out
+
+
+def transfusion_encoder(sd, voxel_features, coors, batch_size, sparse_shape, encoder_channels, encoder_paddings,
+                        fuse=None, fusion_pos=None):
+    """TF/mmdet3d/models/middle_encoders/sparse_encoder.py:321-372 with block_type='basicblock'
+    (BasicBlock = TF/mmdet3d/ops/sparse_block.py:67-120: convs without bias, no indice_key)."""
+    x = SpTensor(np.asarray(voxel_features, np.float32), np.asarray(coors, np.int32), sparse_shape, batch_size)
+    x = _cbr(sd, "conv_input.0", "conv_input.1", x, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, "subm1")
+    for i, blocks in enumerate(encoder_channels):
+        for j, _ in enumerate(blocks):
+            p = "encoder_layers.encoder_layer%d.%d" % (i + 1, j)
+            if j == len(blocks) - 1 and i != len(encoder_channels) - 1:
+                pad = encoder_paddings[i][j]
+                pad = list(pad) if isinstance(pad, (list, tuple)) else [pad] * 3
+                x = _cbr(sd, p + ".0", p + ".1", x, [3, 3, 3], [2, 2, 2], pad, 0)
+            else:
+                idn = x.features
+                o = _conv(sd, p + ".conv1", x, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, ("s", i))
+                o.features = np.maximum(_bn(sd, p + ".bn1", o.features), 0)
+                o = _conv(sd, p + ".conv2", o, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, ("s", i))
+                o.features = np.maximum(_bn(sd, p + ".bn2", o.features) + idn, 0)
+                x = o
+        if fuse is not None and fusion_pos is not None and i in fusion_pos:
+            x = fuse(x)
+    e = _cbr(sd, "conv_out.0", "conv_out.1", x, [3, 1, 1], [2, 1, 1], [0, 0, 0], 0)
+    d = orc.dense(e.features, e.indices, e.shape, batch_size)
+    B, C, D, H, W = d.shape
+    return d.reshape(B, C * D, H, W), x
+
+
+def voxel_backbone8x(sd, voxel_features, coors, batch_size, sparse_shape):
+    """VR/pcdet/models/backbones_3d/spconv_backbone.py:135-243 (LiDAR branch)."""
+    x = SpTensor(np.asarray(voxel_features, np.float32), np.asarray(coors, np.int32), sparse_shape, batch_size)
+    x = _cbr(sd, "conv_input.0", "conv_input.1", x, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, "subm1")
+    c1 = _cbr(sd, "conv1.0.0", "conv1.0.1", x, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, "subm1")
+    outs = {"x_conv1": c1}
+    cur = c1
+    for s, pad in ((2, [1, 1, 1]), (3, [1, 1, 1]), (4, [0, 1, 1])):
+        cur = _cbr(sd, "conv%d.0.0" % s, "conv%d.0.1" % s, cur, [3, 3, 3], [2, 2, 2], pad, 0)
+        for j in (1, 2):
+            cur = _cbr(sd, "conv%d.%d.0" % (s, j), "conv%d.%d.1" % (s, j), cur, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1,
+                       "subm%d" % s)
+        outs["x_conv%d" % s] = cur
+    out = _cbr(sd, "conv_out.0", "conv_out.1", cur, [3, 1, 1], [2, 1, 1], [0, 0, 0], 0)
+    return out, outs

@@ -1,0 +1,200 @@
+"""TransFusion and Voxel-RCNN flavours of the hot path (BASELINE configs 3-5 shapes, reduced grids):
+sparse encoders vs the oracle compositions; fusion-layer glue vs loop restatements of the reference code."""
+import numpy as np
+import pytest
+
+import detgen
+import oracle_models as om
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TF_CH = ((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128))
+TF_PAD = ((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0))
+
+
+def _voxels(seed, rng, dev, feat_c=5, batch=1):
+    from dualfusion import ops, synth
+    feats, coors, of, oc_ = [], [], [], []
+    for b in range(batch):
+        pts = synth.nusc_sweep(seed=seed + b)[:, :feat_c].copy()
+        v, c, n, mean = ops.hard_voxelize(torch.from_numpy(pts).to(dev), synth.NUSC_VOXEL, rng, 10, 120000)
+        ov, oc, on = orc.hard_voxelize(pts, synth.NUSC_VOXEL, rng, 10, 120000)
+        feats.append(mean)
+        coors.append(torch.cat([torch.full((c.shape[0], 1), b, dtype=torch.int32, device=dev), c], 1))
+        of.append(orc.mean_vfe(ov, on))
+        oc_.append(np.concatenate([np.full((len(oc), 1), b, np.int32), oc], 1))
+    return torch.cat(feats), torch.cat(coors), np.concatenate(of), np.concatenate(oc_)
+
+
+def _load_det(model, dev):
+    sd = detgen.det_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return model.to(dev).eval(), sd
+
+
+def test_transfusion_sparse_encoder_vs_oracle():
+    from dualfusion.backbones import SparseEncoder
+    dev = torch.device("cuda:0")
+    shape = [41, 256, 256]
+    m = SparseEncoder(in_channels=5, sparse_shape=shape, output_channels=128, encoder_channels=TF_CH,
+                      encoder_paddings=TF_PAD, block_type='basicblock')
+    # checkpoint layout of SURVEY.md Appendix B
+    keys = set(m.state_dict())
+    assert {"conv_input.0.weight", "encoder_layers.encoder_layer1.0.conv1.weight", "encoder_layers.encoder_layer1.0.bn2.weight",
+            "encoder_layers.encoder_layer3.2.0.weight", "encoder_layers.encoder_layer4.1.conv2.weight",
+            "conv_out.0.weight"} <= keys
+    assert not any(k.endswith("conv1.bias") for k in keys)
+    m, sd = _load_det(m, dev)
+    f, c, of, oc = _voxels(60, [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0], dev, batch=2)
+    with torch.no_grad():
+        y = m(f, c, 2)
+    ref, _ = om.transfusion_encoder(sd, of, oc, 2, shape, TF_CH, TF_PAD)
+    assert tuple(y.shape) == ref.shape == (2, 256, 32, 32)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * max(1.0, np.abs(ref).max()))
+
+
+def _tf_metas(B, cams, ori_hw, in_hw):
+    sf = [in_hw[1] / ori_hw[1], in_hw[0] / ori_hw[0]]
+    from dualfusion import synth
+    return [dict(lidar2cam=np.stack([cams[n][0] for n in synth.NUSC_CAMS]),
+                 cam_intrinsic=np.stack([cams[n][1] for n in synth.NUSC_CAMS]),
+                 ori_shape=(ori_hw[0], ori_hw[1], 3), img_shape=(in_hw[0], in_hw[1], 3),
+                 input_shape=(in_hw[0], in_hw[1]), scale_factor=sf, flip=False) for _ in range(B)]
+
+
+def test_transfusion_fusion_layer_glue_and_encoder_fusion():
+    """ACTRFusionLayer.project/assemble vs a loop restatement of point_fusion.py:342-382,509-549,612-617
+    (projection through lidar2cam + intrinsics instead of the nuScenes DB)."""
+    from dualfusion import synth
+    from dualfusion.backbones import SparseEncoderFusion
+    from dualfusion.fusion_tf import ACTRFusionLayer
+    from make_golden import ACTR_CFG
+    dev = torch.device("cuda:0")
+    B, ori_hw, in_hw, fh, fw = 2, (225, 400), (112, 200), 28, 50
+    cams = synth.nusc_cameras(image_hw=ori_hw, focal=316.0)
+    metas = _tf_metas(B, cams, ori_hw, in_hw)
+    layer = ACTRFusionLayer(pfat_cfg=dict(ACTR_CFG)).to(dev).eval()
+    gen = np.random.RandomState(0)
+    n = 700
+    pts = np.concatenate([np.repeat(np.arange(B), n // B)[:, None].astype(np.float32),
+                          gen.uniform(-25, 25, (n, 2)).astype(np.float32), gen.uniform(-3, 1, (n, 1)).astype(np.float32)], 1)
+    feats = gen.standard_normal((n, 128)).astype(np.float32)
+    img = gen.standard_normal((B * 6, 256, fh, fw)).astype(np.float32)
+    cam_id, norm, pix = layer.project(torch.from_numpy(pts).to(dev), metas)
+    # ---- loop restatement
+    exp_cam = np.zeros(n, np.int64)
+    exp_pix = np.zeros((n, 2), np.float32)
+    for i in range(n):
+        b = int(pts[i, 0])
+        for ci, name in enumerate(synth.NUSC_CAMS):
+            T, K = cams[name]
+            pc = T[:3, :3].astype(np.float64) @ pts[i, 1:4].astype(np.float64) + T[:3, 3]
+            if pc[2] <= 1.0:
+                continue
+            u = (K[0, 0] * pc[0] + K[0, 2] * pc[2]) / pc[2]
+            v = (K[1, 1] * pc[1] + K[1, 2] * pc[2]) / pc[2]
+            if 1 < u < ori_hw[1] - 1 and 1 < v < ori_hw[0] - 1:
+                exp_cam[i] = ci
+                exp_pix[i] = [u * metas[b]['scale_factor'][0], v * metas[b]['scale_factor'][1]]
+    assert (cam_id.cpu().numpy() == exp_cam).mean() > 0.999          # fp32 vs fp64 borderline pixels
+    same = cam_id.cpu().numpy() == exp_cam
+    np.testing.assert_allclose(pix.cpu().numpy()[same], exp_pix[same], rtol=1e-3, atol=2e-2)
+    v_feat, v_i_feat, grid, qpts, seg, slot = layer.assemble([torch.from_numpy(img).to(dev)], torch.from_numpy(pts).to(dev),
+                                                             torch.from_numpy(feats).to(dev), cam_id, norm, pix, B)
+    cid, px = cam_id.cpu().numpy(), pix.cpu().numpy()
+    for b in range(B):
+        for c in range(6):
+            rows = [i for i in range(n) if int(pts[i, 0]) == b and cid[i] == c]
+            got = v_feat[b * 6 + c].cpu().numpy()
+            np.testing.assert_array_equal(got[:len(rows)], feats[rows])
+            assert not got[len(rows):].any()
+            if rows:
+                ic = px[rows].astype(np.int64) // 4
+                np.testing.assert_array_equal(v_i_feat[b * 6 + c, :len(rows)].cpu().numpy(),
+                                              img[b * 6 + c][:, ic[:, 1], ic[:, 0]].T)
+    # ---- the encoder with the fusion layer mounted (configs[2] module tree), reduced grid
+    enc = SparseEncoderFusion(in_channels=5, sparse_shape=[41, 256, 256], output_channels=128, encoder_channels=TF_CH,
+                              encoder_paddings=TF_PAD, block_type='basicblock', fusion_pos=[3],
+                              voxel_size=[0.075, 0.075, 0.2], point_cloud_range=[-9.6, -9.6, -5.0, 9.6, 9.6, 3.0],
+                              fusion_layer=dict(type='ACTR', pfat_cfg=dict(ACTR_CFG)))
+    assert "fusion_layer.actr.transformer.encoder.layers.1.linear3.weight" in enc.state_dict()
+    enc = enc.to(dev).eval()
+    f, c, _, _ = _voxels(70, [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0], dev, batch=B)
+    with torch.no_grad():
+        y = enc(f, c, B, img_feats=[torch.from_numpy(img).to(dev)], img_metas=metas)
+    assert tuple(y.shape) == (B, 256, 32, 32) and bool(torch.isfinite(y).all())
+
+
+VR_CFG = dict(NAME='VoxelBackBone8xFusion', USE_IMG=True, FUSION_POS=[1, 4], FUSION_METHOD='MVX+ACTRv2',
+              FEATURE_LEVELS=[0], LT_CFG=dict(npoint=256, radius=2.0, nsample=16, num_layers=2),
+              ACTR_CFG=dict(fusion_method='sum', feature_modal='hybrid', num_bins=80, num_channels=[256],
+                            query_num_feat=64, num_enc_layers=4, max_num_ne_voxel=20000, pos_encode_method='depth'),
+              HYBRID_CFG=dict(attn_layer='BiGateSum1D_2', q_method='sum', q_rep_place=['weight']))
+
+
+def _kitti_voxels(dev, batch):
+    from dualfusion import ops, synth
+    rng = [0.0, -12.8, -3.0, 25.6, 12.8, 1.0]         # reduced KITTI range: grid 512 x 512 x 40
+    feats, coors, of, oc_ = [], [], [], []
+    for b in range(batch):
+        pts = synth.kitti_sweep(seed=80 + b)
+        v, c, n, mean = ops.hard_voxelize(torch.from_numpy(pts).to(dev), synth.KITTI_VOXEL, rng, 5, 40000)
+        ov, oc, on = orc.hard_voxelize(pts, synth.KITTI_VOXEL, rng, 5, 40000)
+        assert np.array_equal(c.cpu().numpy(), oc)
+        feats.append(mean)
+        coors.append(torch.cat([torch.full((c.shape[0], 1), b, dtype=torch.int32, device=dev), c], 1))
+        of.append(orc.mean_vfe(ov, on, clamp_min=1.0))
+        oc_.append(np.concatenate([np.full((len(oc), 1), b, np.int32), oc], 1))
+    return torch.cat(feats), torch.cat(coors), np.concatenate(of), np.concatenate(oc_)
+
+
+def test_voxel_rcnn_backbone_vs_oracle_and_fusion_runs():
+    from dualfusion.backbones import VoxelBackBone8x, VoxelBackBone8xFusion
+    dev = torch.device("cuda:0")
+    B = 2
+    f, c, of, oc = _kitti_voxels(dev, B)
+    m = VoxelBackBone8x(dict(NAME='VoxelBackBone8x'), 4, [512, 512, 40])
+    assert {"conv_input.0.weight", "conv1.0.0.weight", "conv4.2.1.running_var", "conv_out.0.weight"} <= set(m.state_dict())
+    m, sd = _load_det(m, dev)
+    with torch.no_grad():
+        bd = m(dict(voxel_features=f, voxel_coords=c, batch_size=B))
+    o_out, o_ms = om.voxel_backbone8x(sd, of, oc, B, [41, 512, 512])
+    got = bd["encoded_spconv_tensor"]
+    assert got.spatial_shape == o_out.shape == [2, 64, 64] and bd["multi_scale_3d_strides"]["x_conv4"] == 8
+    gi, gf = om.sort_rows(got.indices.cpu().numpy(), got.features.cpu().numpy())
+    oi, of_ = om.sort_rows(o_out.indices, o_out.features)
+    assert np.array_equal(gi, oi)
+    np.testing.assert_allclose(gf, of_, rtol=1e-3, atol=1e-3 * max(1.0, np.abs(of_).max()))
+    # fusion variant (BASELINE config 5 module tree: MVX at stride 1 + ACTRv2 at stride 8, one camera)
+    mf = VoxelBackBone8xFusion(dict(VR_CFG), 4, [512, 512, 40]).to(dev).eval()
+    assert "actr.transformer.encoder.lidar_attns.3.chunk.layers.1.linear2.weight" in mf.state_dict()
+    H, W = 96, 320
+    K = np.array([[180., 0, W / 2, 0], [0, 180., H / 2, 0], [0, 0, 1, 0]], np.float32)
+    Tr = np.array([[0, -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27], [0, 0, 0, 1]], np.float32)   # velo -> cam
+    l2i = torch.from_numpy(np.stack([K @ Tr] * B)).to(dev)
+    gen = torch.Generator().manual_seed(0)
+    bd = dict(voxel_features=f, voxel_coords=c, batch_size=B, lidar2img=l2i, image_hw=(H, W),
+              img_dict={"mvx_layer1_feat2d": torch.randn(B, 16, H // 4, W // 4, generator=gen).to(dev),
+                        "layer1_feat2d": torch.randn(B, 256, H // 4, W // 4, generator=gen).to(dev)})
+    with torch.no_grad():
+        out = mf(bd)
+    x4 = out["multi_scale_3d_features"]["x_conv4"]
+    assert x4.features.shape[1] == 64 and bool(torch.isfinite(x4.features).all())
+    # MVX glue vs loop restatement (spconv_backbone.py:672-675,717-748)
+    x1 = out["multi_scale_3d_features"]["x_conv1"]
+    with torch.no_grad():
+        plain = mf.conv1(mf.conv_input(__import__("dualfusion").spconv.SparseConvTensor(f, c, mf.sparse_shape, B)))
+    up = torch.nn.functional.interpolate(bd["img_dict"]["mvx_layer1_feat2d"], (H, W), mode="bilinear").cpu().numpy()
+    ind = plain.indices.cpu().numpy()
+    vs, pr = np.array([0.1, 0.05, 0.05], np.float32), np.array([-3., -40., 0.], np.float32)
+    P = (K @ Tr).astype(np.float32)
+    exp = plain.features.cpu().numpy().copy()
+    for i in range(0, len(ind), 37):
+        zyx = ind[i, 1:].astype(np.float32) * vs + pr
+        hcoord = P @ np.array([zyx[2], zyx[1], zyx[0], 1.0], np.float32)
+        u, v = int(hcoord[0] / hcoord[2]), int(hcoord[1] / hcoord[2])
+        if 0 <= u < W and 0 <= v < H:
+            exp[i] += up[ind[i, 0], :, v, u]
+        np.testing.assert_allclose(x1.features[i].cpu().numpy(), exp[i], rtol=1e-3, atol=1e-3)
