@@ -160,17 +160,12 @@ def cpu_baseline(workload, budget_s=30.0):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback on the product path)"
+    from dualfusion import dist as D
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group("nccl", init_method="env://")   # nccl == RCCL on ROCm
+    rank, local, world = D.init_from_env("nccl")                # nccl == RCCL on ROCm (xGMI inside a node)
     workload = args.workload
     if workload == "auto":
         try:
@@ -183,9 +178,7 @@ def main():
     pts, extra = make_inputs(workload, args.batch, rank, dev)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        D.barrier(dev)
 
     for _ in range(args.warmup):
         run_step(model, pts, extra)
@@ -198,10 +191,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, dev)
     dense = out[0]
     assert tuple(dense.shape) == (args.batch, 256, 180, 180), dense.shape
     if rank == 0:
@@ -226,9 +216,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(workload)
         print(json.dumps(res))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if D.is_dist():
+        D.barrier(dev)
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

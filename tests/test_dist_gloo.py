@@ -1,0 +1,52 @@
+"""The N>1 path on CPU: two processes over gloo (127.0.0.1) exercise frame sharding, the
+barrier/max-over-ranks timing protocol of bench.py and the loss-scalar reductions."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, time, json
+    sys.path.insert(0, os.path.join(%r, "3d-dual-fusion_amd"))
+    import torch
+    from dualfusion import dist as D
+    rank, local, world = D.init_from_env("gloo")
+    assert world == 2 and D.is_dist()
+    frames = D.frame_shard(7, rank, world)
+    D.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))              # rank 1 is the slow one
+    D.barrier()
+    el = D.max_over_ranks(time.perf_counter() - t0)
+    losses = {"loss": torch.tensor(1.0 + rank), "hm_loss": torch.tensor(10.0 * (rank + 1))}
+    red = D.reduce_dict(losses)
+    allr = D.all_reduce_value(torch.tensor([float(rank + 1)]), "sum", average=True)
+    print("RESULT " + json.dumps({"rank": rank, "frames": frames, "elapsed": el,
+                                  "loss": float(red["loss"]), "hm": float(red["hm_loss"]), "avg": float(allr)}))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+""") % ROOT
+
+
+def test_two_rank_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = {}
+    for line in out.stdout.splitlines():
+        if line.startswith("RESULT "):
+            r = json.loads(line[7:])
+            res[r["rank"]] = r
+    assert set(res) == {0, 1}
+    assert res[0]["frames"] == [0, 2, 4, 6] and res[1]["frames"] == [1, 3, 5]      # disjoint, complete
+    assert abs(res[0]["elapsed"] - res[1]["elapsed"]) < 1e-9 and res[0]["elapsed"] >= 0.1   # MAX over ranks
+    assert abs(res[0]["loss"] - 1.5) < 1e-6 and abs(res[0]["hm"] - 15.0) < 1e-6    # rank 0 holds the average
+    assert abs(res[0]["avg"] - 1.5) < 1e-6 and abs(res[1]["avg"] - 1.5) < 1e-6
