@@ -228,145 +228,261 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// v2 for the compute-bound layers (COUT >= 64): pair-compacted MFMA rows, LDS accumulators.
+// v2 for the compute-bound layers (COUT >= 64): pair-compacted MFMA rows, LDS accumulators,
+// one workgroup per CU.
 //
 // The output-stationary kernel above issues MFMAs for every (row, offset) of its tile, also
-// where the neighbour is absent (42 % of the slots at conv4's occupancy).  Here a workgroup
-// still owns TM consecutive output rows, but
-//   * its accumulators live in LDS ([wave][TM][COUT/4] fp32), so MFMA rows need not be output
+// where the neighbour is absent (42 % of the slots at conv4's occupancy).  Here
+//   * the grid is sized to the machine: n_out rows are cut into 256*m equal tiles of TM rows
+//     (TM <= ~200-380, chosen at launch), one resident workgroup per CU, no tail wave;
+//   * accumulators live in LDS ([wave][TM][COUT/4] fp32), so MFMA rows need not be output
 //     rows: for each kernel offset the VALID (output row, input row) pairs of the tile are
-//     compacted (ballot + popcount into a per-wave scratch list) and processed 16 at a time;
-//     only the last chunk of an offset is partially filled;
-//   * each of the 4 waves owns a quarter of the output columns, keeps the matching
-//     [CIN x COUT/4] slice of W[k] in REGISTERS as MFMA B operands (loaded once per offset from
-//     L2, 8-byte loads) and accumulates its slice privately: there is NO barrier in the main loop;
-//   * A fragments (CIN/4 contiguous floats of the gathered input row per lane) are loaded
-//     straight from HBM/L2 with 16-byte loads, one chunk ahead of the MFMAs;
-//   * per chunk the 16 x COUT/4 product is added into the LDS accumulators (8-byte RMW, each
-//     output row appears at most once per offset, so no atomics);
+//     compacted (ballot + popcount into a per-wave list) and processed 16 at a time; only the
+//     last chunk of an offset is partially filled (~2-6 % waste instead of ~70 %);
+//   * each of the 4 waves owns a quarter of the output columns and keeps the matching
+//     [CIN x COUT/4] slice of W[k] in REGISTERS as MFMA B operands (8-byte loads from L2,
+//     double-buffered one offset ahead); waves never synchronise inside the main loop;
+//   * A fragments (CIN/4 contiguous floats of the gathered input row per lane) come straight
+//     from HBM/L2 with 16-byte loads, one chunk group ahead of the MFMAs;
+//   * per chunk the 16 x COUT/4 product is added into the LDS accumulators (8-byte RMW; an
+//     output row appears at most once per offset, so no atomics), one chunk behind the MFMAs;
 //   * epilogue from LDS: bias, folded BN, residual, ReLU, 16-byte stores.
-template <int CIN, int COUT, int TM>
-__global__ __launch_bounds__(256) void spconv_pair_kernel(ConvArgs a) {
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 1) void spconv_pair_kernel(ConvArgs a, int TM, const int32_t *__restrict__ tile_rows) {
   constexpr int KS = CIN / 4;        // k-steps = floats of one input row held by a lane
   constexpr int CS = COUT / 4;       // output columns per wave
   constexpr int CT = CS / 16;        // 16-wide column tiles per wave (1 or 2)
   constexpr int NCH = 2 / CT;        // chunks in flight -> always 2 independent accumulators
   static_assert(CT == 1 || CT == 2, "COUT must be 64 or 128");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *accL = (float *)smem;                                  // [4][TM][CS]
-  int *nbrL = (int *)(smem + (size_t)4 * TM * CS * 4);          // [K][TM]
-  unsigned short *listL = (unsigned short *)(nbrL + a.K * TM);  // [4][TM]
+  float *accL = (float *)smem;                                  // [4][TM+1][CS]; row TM = trash row
+  int *idxL = (int *)(smem + (size_t)4 * (TM + 1) * CS * 4);    // [K][TM]: nbr tile, compacted in place to input rows
+  unsigned short *listL = (unsigned short *)(idxL + a.K * TM);  // [K][TM]: matching output rows (tile-local)
+  __shared__ int cntL[DF3D_MAX_KVOL];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
-  int nt = gridDim.x, bid = blockIdx.x, tile = bid;
-  if ((nt & 7) == 0) tile = (bid & 7) * (nt >> 3) + (bid >> 3);
-  const int row0 = tile * TM;
   const int cs0 = wave * CS;
-
-  for (int e = tid; e < a.K * TM; e += 256) {
-    int k = e / TM, r = e - k * TM;
-    int row = row0 + r;
-    nbrL[e] = (row < a.n_out) ? a.nbr[(size_t)k * a.n_out + row] : -1;
-  }
-  float *myacc = accL + (size_t)wave * TM * CS;
-  for (int e = lane; e < TM * CS / 4; e += 64) ((f32x4 *)myacc)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  unsigned short *mylist = listL + wave * TM;
+  const int K = a.K;
+  // Row range of this workgroup: equal row counts, or - when the caller provides them - boundaries
+  // that balance the number of rulebook PAIRS per workgroup (df3d_conv_tiles; occupancy varies 1.4x
+  // between tiles of a LiDAR sweep and the slowest tile sets the kernel time).  Ranges longer than the
+  // LDS tile are walked in passes of TM rows.
+  const int range0 = tile_rows ? tile_rows[blockIdx.x] : blockIdx.x * TM;
+  const int range1 = tile_rows ? tile_rows[blockIdx.x + 1] : min(range0 + TM, a.n_out);
+  for (int row0 = range0; row0 < range1; row0 += TM) {
+  const int row_end = min(row0 + TM, range1);
   __syncthreads();
 
-  for (int k = 0; k < a.K; ++k) {
-    // ---- compact the valid rows of this offset (identical in every wave) ----
+  for (int e = tid; e < K * TM; e += 256) {
+    int k = e / TM, r = e - k * TM;
+    int row = row0 + r;
+    idxL[e] = (row < row_end) ? a.nbr[(size_t)k * a.n_out + row] : -1;
+  }
+  float *myacc = accL + (size_t)wave * (TM + 1) * CS;
+  for (int e = lane; e < TM * CS / 4; e += 64) ((f32x4 *)myacc)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  // ---- compact the valid pairs of every offset once per tile (offsets striped over the waves):
+  //      idxL[k][j] = input row, listL[k][j] = output row of the j-th valid pair (in place: j <= r) ----
+  for (int k = wave; k < K; k += 4) {
     int cnt = 0;
-#pragma unroll
-    for (int q = 0; q < TM / 64; ++q) {
-      int r = q * 64 + lane;
-      bool valid = nbrL[k * TM + r] >= 0;
+    for (int r0 = 0; r0 < TM; r0 += 64) {
+      int r = r0 + lane;
+      int v = r < TM ? idxL[k * TM + r] : -1;
+      bool valid = v >= 0;
       unsigned long long m = __ballot(valid);
       int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-      if (valid) mylist[pos] = (unsigned short)r;
+      __builtin_amdgcn_wave_barrier();
+      if (valid) {
+        idxL[k * TM + pos] = v;
+        listL[k * TM + pos] = (unsigned short)r;
+      }
       cnt += __popcll(m);
     }
-    if (cnt == 0) continue;
-    __builtin_amdgcn_wave_barrier();
-    // ---- this wave's slice of W[k] as B operands ----
-    float b[KS][CT];
-    {
-      const float *wk = a.w + ((size_t)k * CIN + (size_t)g * KS) * COUT + cs0;
+    if (lane == 0) cntL[k] = cnt;
+  }
+  __syncthreads();
+
+  // ---- item list: one entry per (offset, chunk group) in processing order: k | grp << 8 | cnt << 16 ----
+  int *itemL = (int *)(listL + (size_t)K * TM + (((size_t)K * TM) & 1));     // 4-byte aligned, [T+2]
+  __shared__ int segL[DF3D_MAX_KVOL + 1];                                     // first item of each offset; [K] = T
+  auto ngroups = [&](int cnt) { return (((cnt + 15) >> 4) + NCH - 1) / NCH; };
+  if (tid == 0) {
+    int t = 0;
+    for (int k = 0; k < K; ++k) {
+      segL[k] = t;
+      int cnt = cntL[k];
+      int ng = ngroups(cnt);
+      for (int gq = 0; gq < ng; ++gq) itemL[t++] = k | (gq << 8) | (cnt << 16);
+    }
+    segL[K] = t;
+    int last = t > 0 ? itemL[t - 1] : 0;
+    itemL[t] = last;          // two sentinels: the pipeline's look-ahead past the end re-reads the last item
+    itemL[t + 1] = last;
+  }
+  __syncthreads();
+  const int T = segL[K];
+
+  float bcur[KS][CT], bnext[KS][CT];
+  auto load_b = [&](int k, float (&dst)[KS][CT]) {
+    const float *wk = a.w + ((size_t)k * CIN + (size_t)g * KS) * COUT + cs0;
 #pragma unroll
-      for (int j = 0; j < KS; ++j) {
-        if (CT == 2) {
-          float2 v = *(const float2 *)(wk + (size_t)j * COUT + 2 * n);
-          b[j][0] = v.x;
-          b[j][CT - 1] = v.y;
-        } else {
-          b[j][0] = wk[(size_t)j * COUT + n];
-        }
+    for (int j = 0; j < KS; ++j) {
+      if (CT == 2) {
+        float2 v = *(const float2 *)(wk + (size_t)j * COUT + 2 * n);
+        dst[j][0] = v.x;
+        dst[j][CT - 1] = v.y;
+      } else {
+        dst[j][0] = wk[(size_t)j * COUT + n];
       }
     }
-    const int nchunk = (cnt + 15) >> 4;
-    const int ngroup = (nchunk + NCH - 1) / NCH;
-    float acur[NCH][KS], anext[NCH][KS];
-    auto load_a = [&](int grp, float (&dst)[NCH][KS]) {
+  };
+  // Branch-free gathers: slots past the end of an offset's pair list re-read its last pair; their
+  // products land in the trash row at flush time (MFMA rows are independent of each other).
+  auto read_idx = [&](int item, int (&idx)[NCH]) {
+    int k = item & 0xff, grp = (item >> 8) & 0xff, cnt = item >> 16;
 #pragma unroll
-      for (int h = 0; h < NCH; ++h) {
-        int p = (grp * NCH + h) * 16 + n;
-        int idx = -1;
-        if (p < cnt) idx = nbrL[k * TM + mylist[p]];
-        const float *src = a.feat + (size_t)(idx < 0 ? 0 : idx) * CIN + g * KS;
+    for (int h = 0; h < NCH; ++h) {
+      int p = (grp * NCH + h) * 16 + n;
+      p = p < cnt ? p : cnt - 1;
+      idx[h] = idxL[k * TM + p];
+    }
+  };
+  auto read_rows = [&](int item, int (&rl)[NCH][4]) {
+    int k = item & 0xff, grp = (item >> 8) & 0xff, cnt = item >> 16;
 #pragma unroll
-        for (int q = 0; q < KS / 4; ++q) {
-          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (idx >= 0) v = *(const f32x4 *)(src + q * 4);
-          dst[h][q * 4 + 0] = v[0];
-          dst[h][q * 4 + 1] = v[1];
-          dst[h][q * 4 + 2] = v[2];
-          dst[h][q * 4 + 3] = v[3];
+    for (int h = 0; h < NCH; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int p = (grp * NCH + h) * 16 + 4 * g + r;
+        int pp = p < cnt ? p : cnt - 1;
+        int t = listL[k * TM + pp];
+        rl[h][r] = p < cnt ? t : TM;              // invalid slots -> trash row
+      }
+  };
+  float a0[NCH][KS], a1[NCH][KS], a2[NCH][KS];     // A fragments of items t, t+1, t+2 (gathers run 2 items ahead)
+  auto load_a = [&](const int (&idx)[NCH], float (&dst)[NCH][KS]) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const float *src = a.feat + (size_t)idx[h] * CIN + g * KS;
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) {
+        f32x4 v = *(const f32x4 *)(src + q * 4);
+        dst[h][q * 4 + 0] = v[0];
+        dst[h][q * 4 + 1] = v[1];
+        dst[h][q * 4 + 2] = v[2];
+        dst[h][q * 4 + 3] = v[3];
+      }
+    }
+  };
+  f32x4 acc[NCH][CT], aprev[NCH][CT];
+  // LDS accumulate: plain read-add-write, the two halves in different MFMA shadows (LDS float atomics
+  // cost ~150 cycles per wave instruction on gfx950: measured 2x slower overall).  Rows of one group
+  // are distinct (trash-row duplicates do not matter).
+  float2 fo2[NCH][4];
+  float fo1[NCH][4];
+  auto flush_read = [&](const int (&rl)[NCH][4]) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (CT == 2) fo2[h][r] = *(const float2 *)(myacc + (size_t)rl[h][r] * CS + 2 * n);
+        else fo1[h][r] = myacc[(size_t)rl[h][r] * CS + n];
+      }
+  };
+  auto flush_write = [&](const int (&rl)[NCH][4], f32x4 (&v)[NCH][CT]) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (CT == 2) {
+          float2 o = fo2[h][r];
+          o.x += v[h][0][r];
+          o.y += v[h][CT - 1][r];
+          *(float2 *)(myacc + (size_t)rl[h][r] * CS + 2 * n) = o;
+        } else {
+          myacc[(size_t)rl[h][r] * CS + n] = fo1[h][r] + v[h][0][r];
         }
       }
-    };
-    load_a(0, anext);
-    for (int grp = 0; grp < ngroup; ++grp) {
+  };
+
+  int idxn[NCH], rl_cur[NCH][4], rl_prev[NCH][4];
 #pragma unroll
-      for (int h = 0; h < NCH; ++h)
+  for (int h = 0; h < NCH; ++h) {
 #pragma unroll
-        for (int j = 0; j < KS; ++j) acur[h][j] = anext[h][j];
-      if (grp + 1 < ngroup) load_a(grp + 1, anext);
-      f32x4 acc[NCH][CT];
+    for (int ct = 0; ct < CT; ++ct) aprev[h][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int h = 0; h < NCH; ++h)
+    for (int r = 0; r < 4; ++r) rl_prev[h][r] = TM;       // first flush goes to the trash row
+  }
+  if (T > 0) {
+    load_b(itemL[0] & 0xff, bnext);
+    read_idx(itemL[0], idxn);
+    load_a(idxn, a1);
+    read_idx(itemL[1], idxn);
+    load_a(idxn, a2);
+  }
+  for (int k = 0; k < K; ++k) {
+    const int t0 = segL[k], t1 = segL[k + 1];
+    if (t0 == t1) continue;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[h][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < KS; ++j)
 #pragma unroll
-      for (int j = 0; j < KS; ++j)
+      for (int ct = 0; ct < CT; ++ct) bcur[j][ct] = bnext[j][ct];
+    if (t1 < T) load_b(itemL[t1] & 0xff, bnext);          // next active offset's weights, one offset ahead
+    for (int t = t0; t < t1; ++t) {
+      // ---- one item = NCH chunks of 16 pairs.  Branch-free body, software-scheduled.  The A ring
+      //      (items t, t+1, t+2) rotates by NAME: three copies of the body selected by t % 3, so no
+      //      register moves are spent on it. ----
+      auto body = [&](float (&cur)[NCH][KS], float (&tgt)[NCH][KS]) {
+        const int it0 = itemL[t], it2 = itemL[t + 2];
+        read_idx(it2, idxn);
+        read_rows(it0, rl_cur);
+        flush_read(rl_prev);
 #pragma unroll
         for (int h = 0; h < NCH; ++h)
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
-            acc[h][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[h][j], b[j][ct], acc[h][ct], 0, 0, 0);
-      // ---- add the 16 x CS products into the LDS accumulators (row = pair slot 4g + r) ----
+          for (int ct = 0; ct < CT; ++ct) acc[h][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int h = 0; h < NCH; ++h) {
-        int pbase = (grp * NCH + h) * 16 + 4 * g;
+        for (int j = 0; j < KS; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int p = pbase + r;
-          if (p < cnt) {
-            int rl = mylist[p];
-            if (CT == 2) {
-              float2 *dst = (float2 *)(myacc + (size_t)rl * CS + 2 * n);
-              float2 v = *dst;
-              v.x += acc[h][0][r];
-              v.y += acc[h][CT - 1][r];
-              *dst = v;
-            } else {
-              myacc[(size_t)rl * CS + n] += acc[h][0][r];
-            }
-          }
+          for (int h = 0; h < NCH; ++h)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+              acc[h][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[h][j], bcur[j][ct], acc[h][ct], 0, 0, 0);
+        load_a(idxn, tgt);                                  // gathers of item t+2 (into the slot item t frees)
+        flush_write(rl_prev, aprev);                        // item t-1's LDS update
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) aprev[h][ct] = acc[h][ct];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rl_prev[h][r] = rl_cur[h][r];
         }
+        // The wave is alone on its SIMD and issue is in order: every non-MFMA instruction must sit in
+        // the 32-cycle shadow of an MFMA.  Ask the scheduler for "1 MFMA, then a few others" groups.
+#pragma unroll
+        for (int i = 0; i < KS * NCH * CT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
+          if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // LDS reads first (indices, rows, acc)
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);               // up to 3 VALU
+          if (i >= 8 && i < 8 + 2 * NCH * (KS / 4) && (i & 1) == 0)
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // one gather load every other MFMA
+          if (i >= KS * NCH * CT / 2 && i < KS * NCH * CT / 2 + 4 * NCH)
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);             // LDS writes of the flush
+        }
+      };
+      // NOTE: the MFMAs of item t cannot overwrite `cur` before they have read it: load_a(tgt == cur's
+      // successor slot) targets the slot of item t+2 == slot of item t-1, which is dead.
+      switch (t % 3) {
+        case 0: body(a1, a0); break;     // slots: t -> a1, t+1 -> a2, t+2 -> a0
+        case 1: body(a2, a1); break;
+        default: body(a0, a2); break;
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
+  flush_read(rl_prev);
+  flush_write(rl_prev, aprev);
+  __builtin_amdgcn_wave_barrier();
 
   // ---- epilogue: this wave's CS columns of every row of the tile ----
   constexpr int LPR = CS / 4;          // lanes per row (float4 each)
@@ -379,7 +495,7 @@ __global__ __launch_bounds__(256) void spconv_pair_kernel(ConvArgs a) {
   for (int r0 = 0; r0 < TM; r0 += RPI) {
     int rl = r0 + lr;
     int row = row0 + rl;
-    if (row < a.n_out) {
+    if (rl < TM && row < row_end) {
       f32x4 v = *(const f32x4 *)(myacc + (size_t)rl * CS + lc);
       v = (v + bi) * sc + sh;
       size_t o = (size_t)row * COUT + cs0 + lc;
@@ -393,15 +509,31 @@ __global__ __launch_bounds__(256) void spconv_pair_kernel(ConvArgs a) {
       *(f32x4 *)(a.out + o) = v;
     }
   }
+  }  // passes over the row range
 }
 
-template <int CIN, int COUT, int TM>
-static int launch_pair(const ConvArgs &a, hipStream_t stream) {
-  size_t lds = (size_t)4 * TM * (COUT / 4) * 4 + (size_t)a.K * TM * 4 + (size_t)4 * TM * 2;
+template <int CIN, int COUT>
+static int launch_pair(const ConvArgs &a, const int32_t *tile_rows, int ntiles, hipStream_t stream) {
+  // LDS per row: accumulators (COUT floats) + nbr tile (K ints) + 4 list entries
+  const size_t per_row = (size_t)COUT * 4 + (size_t)a.K * 4 + (size_t)a.K * 2;   // + one trash row below
+  int tm_max = (int)((144 * 1024) / per_row) & ~3;
+  static int num_cu = 0;
+  if (!num_cu) {
+    hipDeviceProp_t p;
+    num_cu = (hipGetDeviceProperties(&p, 0) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  static const int wgs_per_cu = getenv("DF3D_PAIR_WGS") ? atoi(getenv("DF3D_PAIR_WGS")) : 1;
+  if (wgs_per_cu > 1) tm_max = (int)((144 * 1024 / wgs_per_cu) / per_row) & ~3;
+  int slots = num_cu * wgs_per_cu;
+  int m = cdiv(a.n_out, (long long)slots * tm_max);
+  int TM = (cdiv(a.n_out, (long long)slots * m) + 3) & ~3;
+  if (TM < 16) TM = 16;
+  size_t items = (size_t)a.K * (TM / 16 + 2) + 8;   // upper bound on (offset, group) items
+  size_t lds = (size_t)TM * per_row + (size_t)COUT * 4 + items * 4 + 64;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)spconv_pair_kernel<CIN, COUT, TM>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)spconv_pair_kernel<CIN, COUT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
       return DF3D_EHIP;
@@ -409,20 +541,32 @@ static int launch_pair(const ConvArgs &a, hipStream_t stream) {
     configured = true;
   }
   int nt = cdiv(a.n_out, TM);
-  hipLaunchKernelGGL((spconv_pair_kernel<CIN, COUT, TM>), dim3(nt), dim3(256), lds, stream, a);
+  if (tile_rows && ntiles > 0) {
+    // pair-balanced ranges: sparse regions get more rows than the equal split, so give the LDS tile
+    // the full budget; longer ranges take extra passes
+    TM = tm_max;
+    lds = (size_t)TM * per_row + (size_t)COUT * 4 + ((size_t)a.K * (TM / 16 + 2) + 8) * 4 + 64;
+    nt = ntiles;
+  } else {
+    tile_rows = nullptr;
+  }
+  hipLaunchKernelGGL((spconv_pair_kernel<CIN, COUT>), dim3(nt), dim3(256), lds, stream, a, TM, tile_rows);
   return DF3D_OK;
 }
 
+static int pair_ntiles(int n_out, int cin, int cout);
+
 // returns 1 if handled, 0 if not applicable, <0 on error
-static int dispatch_pair(const ConvArgs &a, hipStream_t stream) {
+static int dispatch_pair(const ConvArgs &a, const int32_t *tile_rows, int ntiles, hipStream_t stream) {
   int rc = 0;
+  if (pair_ntiles(a.n_out, a.cin, a.cout) == 0) return 0;
   if (a.cout == 128) {
-    if (a.cin == 128) rc = launch_pair<128, 128, 128>(a, stream);
-    else if (a.cin == 64) rc = launch_pair<64, 128, 128>(a, stream);
+    if (a.cin == 128) rc = launch_pair<128, 128>(a, tile_rows, ntiles, stream);
+    else if (a.cin == 64) rc = launch_pair<64, 128>(a, tile_rows, ntiles, stream);
     else return 0;
   } else if (a.cout == 64) {
-    if (a.cin == 64) rc = launch_pair<64, 64, 256>(a, stream);
-    else if (a.cin == 32) rc = launch_pair<32, 64, 256>(a, stream);
+    if (a.cin == 64) rc = launch_pair<64, 64>(a, tile_rows, ntiles, stream);
+    else if (a.cin == 32) rc = launch_pair<32, 64>(a, tile_rows, ntiles, stream);
     else return 0;
   } else {
     return 0;
@@ -477,14 +621,115 @@ static bool dispatch_cin(const ConvArgs &a, hipStream_t stream) {
   }
 }
 
+
+// ---- pair-balanced row ranges for the pair kernel -------------------------------------------
+__global__ __launch_bounds__(256) void conv_rowcount_kernel(const int32_t *__restrict__ nbr, int K, int n_out,
+                                                            uint32_t *__restrict__ cnt) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_out) return;
+  uint32_t c = 0;
+  for (int k = 0; k < K; ++k) c += nbr[(size_t)k * n_out + r] >= 0 ? 1u : 0u;
+  cnt[r] = c + 1u;   // +1: a row costs something even without neighbours (epilogue), and keeps ranges non-empty
+}
+
+__global__ __launch_bounds__(256) void conv_tiles_kernel(const uint32_t *__restrict__ prefix,
+                                                         const uint32_t *__restrict__ total, int n_out, int ntiles,
+                                                         int32_t *__restrict__ tile_rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > ntiles) return;
+  if (i == ntiles) {
+    tile_rows[i] = n_out;
+    return;
+  }
+  unsigned long long target = (unsigned long long)(*total) * (unsigned long long)i / (unsigned long long)ntiles;
+  int lo = 0, hi = n_out;   // first row whose exclusive prefix >= target
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if ((unsigned long long)prefix[mid] < target) lo = mid + 1;
+    else hi = mid;
+  }
+  tile_rows[i] = lo;
+}
+
+static int pair_ntiles(int n_out, int cin, int cout) {
+  // measured on MI355X (tools/conv_probe.py): the pair kernel wins for COUT=128 (244 vs 306 us at conv4),
+  // the output-stationary kernel for COUT=64 (170 vs 218 us at conv3: items are only 32 MFMAs long there)
+  bool ok = cout == 128 && (cin == 128 || cin == 64);
+  if (getenv("DF3D_PAIR_ALL")) ok = ok || (cout == 64 && (cin == 64 || cin == 32));
+  if (!ok || n_out <= 0) return 0;
+  static int num_cu = 0;
+  if (!num_cu) {
+    hipDeviceProp_t p;
+    num_cu = (hipGetDeviceProperties(&p, 0) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return num_cu;   // one workgroup per CU
+}
+
 }  // namespace df3d
 
 using namespace df3d;
+
+extern "C" int df3d_conv_tile_count(int n_out, int cin, int cout, int kvol) {
+  (void)kvol;
+  static const bool use_v2 = getenv("DF3D_SPCONV_V1") == nullptr;
+  return use_v2 ? pair_ntiles(n_out, cin, cout) : 0;
+}
+
+extern "C" size_t df3d_conv_tiles_workspace_bytes(int n_out) {
+  size_t b = 0;
+  b = arena_need(b, (size_t)(n_out > 0 ? n_out : 1) * 4);
+  b = arena_need(b, 64);
+  b = arena_need(b, scan_scratch_bytes((size_t)(n_out > 0 ? n_out : 1)));
+  return b + 256;
+}
+
+extern "C" int df3d_conv_tiles(const int32_t *nbr, int kvol, int n_out, int ntiles, int32_t *tile_rows,
+                               void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(nbr && tile_rows && ntiles > 0 && n_out > 0 && kvol > 0, "conv_tiles: bad arguments");
+  Arena ar(workspace, workspace_bytes);
+  uint32_t *cnt = ar.take<uint32_t>(n_out);
+  uint32_t *total = ar.take<uint32_t>(16);
+  size_t ssz = scan_scratch_bytes((size_t)n_out);
+  void *sscr = ar.take<char>(ssz);
+  if (!sscr) {
+    set_error("conv_tiles: workspace too small");
+    return DF3D_ENOMEM;
+  }
+  hipLaunchKernelGGL(conv_rowcount_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, stream, nbr, kvol, n_out, cnt);
+  int rc = exclusive_scan_u32(cnt, cnt, (size_t)n_out, total, sscr, ssz, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(conv_tiles_kernel, dim3(cdiv(ntiles + 1, 256)), dim3(256), 0, stream, cnt, total, n_out, ntiles,
+                     tile_rows);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+static int sparse_conv_impl(const float *features, int n_in, int cin, const float *filters, int kvol, int cout,
+                            const int32_t *nbr, int n_out, const float *bias, const float *scale, const float *shift,
+                            const float *residual, int relu, float *out, const int32_t *tile_rows, int ntiles,
+                            void *stream_);
 
 extern "C" int df3d_sparse_conv_fused(const float *features, int n_in, int cin, const float *filters, int kvol,
                                       int cout, const int32_t *nbr, int n_out, const float *bias, const float *scale,
                                       const float *shift, const float *residual, int relu, float *out,
                                       void *stream_) {
+  return sparse_conv_impl(features, n_in, cin, filters, kvol, cout, nbr, n_out, bias, scale, shift, residual, relu, out,
+                          nullptr, 0, stream_);
+}
+
+extern "C" int df3d_sparse_conv_fused_tiled(const float *features, int n_in, int cin, const float *filters, int kvol,
+                                            int cout, const int32_t *nbr, int n_out, const float *bias,
+                                            const float *scale, const float *shift, const float *residual, int relu,
+                                            float *out, const int32_t *tile_rows, int ntiles, void *stream_) {
+  return sparse_conv_impl(features, n_in, cin, filters, kvol, cout, nbr, n_out, bias, scale, shift, residual, relu, out,
+                          tile_rows, ntiles, stream_);
+}
+
+static int sparse_conv_impl(const float *features, int n_in, int cin, const float *filters, int kvol, int cout,
+                            const int32_t *nbr, int n_out, const float *bias, const float *scale, const float *shift,
+                            const float *residual, int relu, float *out, const int32_t *tile_rows, int ntiles,
+                            void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(features && filters && nbr && out, "sparse_conv_fused: null argument");
   DF3D_CHECK_ARG(kvol > 0 && kvol <= DF3D_MAX_KVOL, "sparse_conv_fused: kernel volume %d unsupported", kvol);
@@ -506,11 +751,10 @@ extern "C" int df3d_sparse_conv_fused(const float *features, int n_in, int cin, 
   a.cout = cout;
   a.relu = relu;
   bool done = false;
-  // v2 (pair-compacted rows) is correct but not yet faster than v1 at nuScenes sizes (too few,
-  // too large tiles for 256 CUs); opt-in until its tile scheduling is reworked.
-  static const bool use_v2 = getenv("DF3D_SPCONV_V2") != nullptr;
+  // compute-bound shapes: pair-compacted kernel (DF3D_SPCONV_V1=1 forces the output-stationary kernel)
+  static const bool use_v2 = getenv("DF3D_SPCONV_V1") == nullptr;
   if (use_v2) {
-    int r = dispatch_pair(a, stream);
+    int r = dispatch_pair(a, tile_rows, ntiles, stream);
     if (r < 0) return r;
     done = r == 1;
   }

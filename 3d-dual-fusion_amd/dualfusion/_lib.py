@@ -38,6 +38,12 @@ SIGNATURES = {
     "df3d_pairs_to_nbr": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_sparse_conv_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "df3d_conv_tile_count": (c_int, [c_int, c_int, c_int, c_int]),
+    "df3d_conv_tiles_workspace_bytes": (c_size_t, [c_int]),
+    "df3d_conv_tiles": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_sparse_conv_fused_tiled": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                             c_void_p]),
     "df3d_sparse_to_dense": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_ms_deform_attn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

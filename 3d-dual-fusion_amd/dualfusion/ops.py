@@ -181,8 +181,25 @@ class KernelTimer(object):
 TIMER = None
 
 
-def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shift=None, residual=None, relu=False):
-    """out[o] = act((sum_k features[nbr[k,o]] @ filters[k] + bias) * scale + shift + residual)."""
+def conv_tiles(nbr, cin, cout):
+    """Pair-balanced row ranges for the compute-bound conv kernel (None when not applicable)."""
+    lib = _lib.load()
+    K, n_out = nbr.shape
+    nt = lib.df3d_conv_tile_count(int(n_out), int(cin), int(cout), int(K))
+    if nt <= 0 or n_out == 0:
+        return None
+    tiles = torch.empty((nt + 1,), dtype=torch.int32, device=nbr.device)
+    wsb = lib.df3d_conv_tiles_workspace_bytes(int(n_out))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=nbr.device)
+    rc = lib.df3d_conv_tiles(_ptr(nbr), K, n_out, nt, _ptr(tiles), _ptr(ws), wsb, _stream())
+    _lib.check(rc, "df3d_conv_tiles")
+    return tiles
+
+
+def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shift=None, residual=None, relu=False,
+                      tiles=None):
+    """out[o] = act((sum_k features[nbr[k,o]] @ filters[k] + bias) * scale + shift + residual).
+    `tiles`: optional pair-balanced row ranges from conv_tiles()."""
     lib = _lib.load()
     _chk(features, torch.float32, "features")
     _chk(filters, torch.float32, "filters")
@@ -199,8 +216,10 @@ def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shif
     ev = TIMER.region(("spconv", cin, cout, K), {"n_in": n_in, "n_out": n_out, "nbr": nbr}) if TIMER is not None else None
     if ev:
         ev[0].record()
-    rc = lib.df3d_sparse_conv_fused(_ptr(features), n_in, cin, _ptr(filters), K, cout, _ptr(nbr), n_out, _ptr(bias),
-                                    _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out), _stream())
+    rc = lib.df3d_sparse_conv_fused_tiled(_ptr(features), n_in, cin, _ptr(filters), K, cout, _ptr(nbr), n_out,
+                                          _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)),
+                                          _ptr(out), _ptr(tiles), (tiles.shape[0] - 1) if tiles is not None else 0,
+                                          _stream())
     if ev:
         ev[1].record()
     _lib.check(rc, "df3d_sparse_conv_fused")

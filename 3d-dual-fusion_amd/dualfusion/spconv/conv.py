@@ -134,7 +134,8 @@ class SparseConvolution(SparseModule):
                                                                                       self.out_channels),
                                               rb.nbr, rb.outids.shape[0],
                                               bias=self.bias.detach() if self.bias is not None else None,
-                                              scale=scale, shift=shift, residual=residual, relu=relu)
+                                              scale=scale, shift=shift, residual=residual, relu=relu,
+                                              tiles=rb.tiles(self.in_channels, self.out_channels))
         out = SparseConvTensor(out_features, rb.outids, rb.out_spatial_shape, input.batch_size)
         out.indice_dict, out.grid, out._directories = input.indice_dict, input.grid, input._directories
         return out

@@ -29,6 +29,15 @@ class Rulebook(object):
         self.spatial_shape, self.out_spatial_shape = spatial_shape, out_spatial_shape
         self.out_rows_sorted = out_rows_sorted
         self._pairs = None
+        self._tiles = {}
+
+    def tiles(self, cin, cout):
+        """Pair-balanced row ranges of this rulebook for a (cin, cout) layer; computed once, shared by
+        every conv that reuses the rulebook."""
+        key = (int(cin), int(cout))
+        if key not in self._tiles:
+            self._tiles[key] = _ops.conv_tiles(self.nbr, cin, cout)
+        return self._tiles[key]
 
     def pairs(self):
         if self._pairs is None:

@@ -114,7 +114,7 @@ def roofline_from_timer(timer):
         ach = by / sec / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(ach / PEAK_HBM_GBS, 4)}
-    roof.update({"traffic": None, "kernel": "spconv_mfma_kernel<cin=%d,cout=%d,K=%d>" % (cin, cout, K),
+    roof.update({"traffic": None, "kernel": "%s<cin=%d,cout=%d,K=%d>" % ("spconv_pair_kernel" if cout == 128 and cin >= 64 else "spconv_mfma_kernel", cin, cout, K),
                  "launches": g["n"], "avg_launch_us": round(avg_us, 2),
                  "algorithmic_flops_per_launch": fl // g["n"], "algorithmic_bytes_per_launch": by // g["n"]})
     per_kernel = {"%dx%d_k%d" % (k[1], k[2], k[3]): {"ms_total": round(v["ms"], 3), "launches": v["n"]}

@@ -128,6 +128,24 @@ int df3d_sparse_conv_fused(const float *features, int n_in, int cin,
                            const float *bias, const float *scale, const float *shift,
                            const float *residual, int relu, float *out, void *stream);
 
+/* Pair-balanced work split for the compute-bound layers.  The occupancy of a LiDAR sweep varies ~1.4x
+ * between equal-row tiles and the slowest workgroup sets the kernel time, so the pair-compacted kernel
+ * accepts row ranges that hold equal numbers of rulebook pairs.  They depend only on the neighbour table
+ * and are cached with it by the host side (one prefix scan per rulebook, not per conv).
+ *   df3d_conv_tile_count: recommended number of ranges for a (cin, cout) layer, 0 = not applicable.
+ *   df3d_conv_tiles: tile_rows [ntiles+1] i32, tile_rows[i]..tile_rows[i+1] = rows of range i.
+ *   df3d_sparse_conv_fused_tiled: as df3d_sparse_conv_fused, with the ranges (NULL/0 = equal rows). */
+int df3d_conv_tile_count(int n_out, int cin, int cout, int kvol);
+size_t df3d_conv_tiles_workspace_bytes(int n_out);
+int df3d_conv_tiles(const int32_t *nbr, int kvol, int n_out, int ntiles, int32_t *tile_rows,
+                    void *workspace, size_t workspace_bytes, void *stream);
+int df3d_sparse_conv_fused_tiled(const float *features, int n_in, int cin,
+                                 const float *filters, int kvol, int cout,
+                                 const int32_t *nbr, int n_out,
+                                 const float *bias, const float *scale, const float *shift,
+                                 const float *residual, int relu, float *out,
+                                 const int32_t *tile_rows, int ntiles, void *stream);
+
 /* SparseConvTensor.dense() (TF/mmdet3d/ops/spconv/structure.py:5-18,55-64): zero-fill +
  * scatter + permute fused; out [B, C, D, H, W] f32 (the backbones view it as [B, C*D, H, W]). */
 int df3d_sparse_to_dense(const float *features, const int32_t *indices, int n, int channels,
