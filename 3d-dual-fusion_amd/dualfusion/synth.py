@@ -68,10 +68,12 @@ def kitti_sweep(seed=0, n_beams=64, n_az=1900, pc_range=KITTI_RANGE):
     return np.ascontiguousarray(pts)
 
 
-def nusc_cameras(image_hw=(900, 1600), focal=1266.0):
+def nusc_cameras(image_hw=(900, 1600), focal=1266.0, yaw_offset_deg=0.0):
     """Six pinhole cameras at 60 deg yaw spacing around the LiDAR (z up, x forward).
     Returns {cam: (lidar2cam 4x4 f32, intrinsic 3x3 f32)} in nuScenes order
-    (front, front-left, front-right, back, back-left, back-right)."""
+    (front, front-left, front-right, back, back-left, back-right).  `yaw_offset_deg` turns the whole rig:
+    with 0 the front/back cameras are axis-aligned and voxel corners (a regular lattice) project exactly onto
+    pixel boundaries, where 1-ulp differences between implementations flip the reference's truncations."""
     H, W = image_hw
     yaws = {"CAM_FRONT": 0.0, "CAM_FRONT_LEFT": 60.0, "CAM_FRONT_RIGHT": -60.0,
             "CAM_BACK": 180.0, "CAM_BACK_LEFT": 120.0, "CAM_BACK_RIGHT": -120.0}
@@ -79,7 +81,7 @@ def nusc_cameras(image_hw=(900, 1600), focal=1266.0):
     # camera frame: x right, y down, z forward.  For yaw 0 the camera looks along lidar +x.
     base = np.array([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]])
     for name in NUSC_CAMS:
-        a = np.deg2rad(yaws[name])
+        a = np.deg2rad(yaws[name] + yaw_offset_deg)
         rz = np.array([[np.cos(a), np.sin(a), 0.0], [-np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])  # lidar->yawed
         R = base @ rz
         t_cam_in_lidar = np.array([0.3 * np.cos(a), 0.3 * np.sin(a), -0.3])

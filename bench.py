@@ -122,21 +122,23 @@ def roofline_from_timer(timer):
     return roof, per_kernel
 
 
-def cpu_baseline(workload, budget_s=30.0):
-    """The oracle composition (tests/oracle_models.py over oracle/oracle.py) on the SAME synthetic
-    sweep and weights, on this box's host cores.  Bounded: whole sweeps until ~budget_s elapsed."""
-    import detgen  # noqa: F401
+def cpu_baseline(workload, model, cam_np, budget_s=30.0):
+    """The oracle composition (tests/oracle_models.py over oracle/oracle.py) of the SAME workload with the
+    SAME weights on this box's host cores: voxelize -> VFE -> sparse backbone [-> projection, image gate,
+    ACTR, write-back] -> dense.  Bounded: whole sweeps until ~budget_s have elapsed (at least one)."""
     import oracle_models as om
     from oracle import oracle as orc
     from dualfusion import synth
-    from dualfusion.backbones import SpMiddleResNetFHD
-    torch.manual_seed(0)
-    sd = {k: v.numpy() for k, v in SpMiddleResNetFHD(num_input_features=5).state_dict().items()}
+    from dualfusion.fusion import CP_DEPTH_THRES
+    sd_all = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    sd = {k[len("backbone."):]: v for k, v in sd_all.items() if k.startswith("backbone.")}
+    sd_f = {k[len("fusion."):]: v for k, v in sd_all.items() if k.startswith("fusion.")}
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
+    cores = max(cores, torch.get_num_threads())
     n, t0 = 0, time.perf_counter()
     while True:
         pts = synth.nusc_sweep(seed=n)
@@ -144,18 +146,27 @@ def cpu_baseline(workload, budget_s=30.0):
         ov, oc, on = orc.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000, "numba")
         feats = orc.mean_vfe(ov, on)
         coors = np.concatenate([np.zeros((len(oc), 1), np.int32), oc], 1)
-        om.centerpoint_backbone(sd, feats, coors, 1, [1440, 1440, 40])
+        fuse = None
+        if workload == "cp_fusion":
+            img, calib, hw = cam_np
+
+            def fuse(c2, c3, c4):
+                out = om.centerpoint_fusion(sd_f, [(c.indices, c.features) for c in (c2, c3, c4)], img, calib, hw,
+                                            synth.NUSC_CAMS, synth.NUSC_VOXEL, synth.NUSC_RANGE, 2.0 / 3.0,
+                                            CP_DEPTH_THRES)
+                c4.features = out
+                return c4
+        om.centerpoint_backbone(sd, feats, coors, 1, [1440, 1440, 40], fuse=fuse)
         n += 1
         dt = time.perf_counter() - t1
-        if n == 1:
-            first = dt
         if time.perf_counter() - t0 + dt > budget_s or n >= 8:
             break
     total = time.perf_counter() - t0
+    what = "voxelize+VFE+sparse backbone+camera fusion (projection, gate, ACTR)+dense" if workload == "cp_fusion" \
+        else "voxelize+VFE+sparse backbone+dense, LiDAR branch"
     return {"value": round(n / total, 4), "unit": "sweeps/s", "cores": int(cores), "kind": "port",
-            "sample": "%d whole synthetic sweeps (voxelize+VFE+sparse backbone+dense, LiDAR branch; "
-                      "C for index work, numpy/BLAS for fp32), %.1f s wall; host cpu_count=%d"
-                      % (n, total, os.cpu_count() or 0)}
+            "sample": "%d whole synthetic sweeps (%s; C for index work, numpy/BLAS + torch-CPU fp32 for the dense "
+                      "layers), %.1f s wall; host cpu_count=%d" % (n, what, total, os.cpu_count() or 0)}
 
 
 def main():
@@ -214,7 +225,17 @@ def main():
             res["roofline"] = roof
             res["conv_kernel_ms"] = per_kernel
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(workload)
+            cam_np = None
+            if workload == "cp_fusion":
+                bd = extra[0]
+                from dualfusion import synth
+                img = {n: bd['img_feat']['layer1_ori_feat2d'][n.lower()].cpu().numpy() for n in synth.NUSC_CAMS}
+                calib = {n: (bd['calib']['lidar2cam_' + n.lower().lstrip('cam_')].cpu().numpy(),
+                             bd['calib']['cam_intrinsic_' + n.lower().lstrip('cam_')].cpu().numpy())
+                         for n in synth.NUSC_CAMS}
+                hw = tuple(int(v) for v in bd['image_shape']['cam_front'][0][:2])
+                cam_np = (img, calib, hw)
+            res["cpu_baseline"] = cpu_baseline(workload, model, cam_np)
         print(json.dumps(res))
     if D.is_dist():
         D.barrier(dev)

@@ -168,3 +168,159 @@ def voxel_backbone8x(sd, voxel_features, coors, batch_size, sparse_shape):
         outs["x_conv%d" % s] = cur
     out = _cbr(sd, "conv_out.0", "conv_out.1", cur, [3, 1, 1], [2, 1, 1], [0, 0, 0], 0)
     return out, outs
+
+
+# ------------------------------------------------------------------------- ACTR + CenterPoint fusion adapter (a7-a12)
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def actr_forward(sd, v_feat, grid, i_feat, lidar_grid, v_i_feat, num_layers=2, n_heads=8, n_points=4, prefix=""):
+    """ACTR.forward with feature_modal='hybrid', pos_encode_method='depth', q_method 'sum' / rep_place
+    ['weight'], BiGateSum1D_2 (CP/det3d/models/model_utils/actr.py:131-187, actr_transformer.py:399-426,
+    473-511, ops/modules/ms_deform_attn.py:98-190, attentions.py:96-117, position_encoding.py:107-120).
+    Dense layers in torch-CPU fp32, deformable sampling by the numpy oracle."""
+    import torch
+    import torch.nn.functional as F
+    P = lambda k: _t(sd[prefix + k])
+    v_feat, grid, i_feat, lidar_grid, v_i_feat = [_t(np.asarray(a, np.float32)) for a in
+                                                  (v_feat, grid, i_feat, lidar_grid, v_i_feat)]
+    N, Q, C = v_feat.shape
+    H, W = i_feat.shape[2:]
+    qi = F.conv1d(v_i_feat.transpose(1, 2), P("i_input_proj.0.weight"), P("i_input_proj.0.bias"))
+    qi = F.group_norm(qi, 32, P("i_input_proj.1.weight"), P("i_input_proj.1.bias"), 1e-5).transpose(1, 2)
+    d = lidar_grid[..., 0] / 60.0 * (2 * np.pi)
+    dim_t = torch.arange(C, dtype=torch.float32)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / C)
+    pd = d[:, :, None] / dim_t
+    q_pos = torch.stack((pd[:, :, 0::2].sin(), pd[:, :, 1::2].cos()), dim=3).flatten(2)
+    src = F.group_norm(F.conv2d(i_feat, P("input_proj.0.0.weight"), P("input_proj.0.0.bias")), 32,
+                       P("input_proj.0.1.weight"), P("input_proj.0.1.bias"), 1e-5)
+    src = src.flatten(2).transpose(1, 2)                                   # [N, HW, C]
+    q = v_feat
+    D = C // n_heads
+    for i in range(num_layers):
+        L = "transformer.encoder.layers.%d." % i
+        value = F.linear(src, P(L + "self_attn.value_proj.weight"), P(L + "self_attn.value_proj.bias"))
+        query, iq = q + q_pos, qi + q_pos
+        off = F.linear(query, P(L + "self_attn.sampling_offsets.weight"), P(L + "self_attn.sampling_offsets.bias"))
+        aw = F.linear(query + iq, P(L + "self_attn.attention_weights.weight"), P(L + "self_attn.attention_weights.bias"))
+        aw = torch.softmax(aw.view(N, Q, n_heads, n_points), -1).view(N, Q, n_heads, 1, n_points)
+        off = off.view(N, Q, n_heads, 1, n_points, 2)
+        loc = grid[:, :, None, None, None, :] + off / torch.tensor([W, H], dtype=torch.float32)
+        att = orc.ms_deform_attn(value.view(N, H * W, n_heads, D).numpy(), [(H, W)], loc.numpy(), aw.numpy())
+        att = F.linear(_t(att), P(L + "self_attn.output_proj.weight"), P(L + "self_attn.output_proj.bias"))
+        qi = F.layer_norm(qi + att, (C,), P(L + "norm1.weight"), P(L + "norm1.bias"))
+        qi = F.layer_norm(qi + F.linear(F.relu(F.linear(qi, P(L + "linear1.weight"), P(L + "linear1.bias"))),
+                                        P(L + "linear2.weight"), P(L + "linear2.bias")), (C,),
+                          P(L + "norm2.weight"), P(L + "norm2.bias"))
+        q = F.layer_norm(q + F.linear(F.relu(F.linear(q, P(L + "linear3.weight"), P(L + "linear3.bias"))),
+                                      P(L + "linear4.weight"), P(L + "linear4.bias")), (C,),
+                         P(L + "norm3.weight"), P(L + "norm3.bias"))
+        fuse = (q + qi).transpose(1, 2)
+        s1 = torch.sigmoid(F.conv1d(fuse, P(L + "fusion_layer.b_conv1d.weight"), P(L + "fusion_layer.b_conv1d.bias"))).transpose(1, 2)
+        s2 = torch.sigmoid(F.conv1d(fuse, P(L + "fusion_layer.a_conv1d.weight"), P(L + "fusion_layer.a_conv1d.bias"))).transpose(1, 2)
+        q, qi = q + qi * s1, qi + q * s2
+    return q.numpy()
+
+
+def centerpoint_fusion(sd, levels, img_feats, calib, image_hw, cams, voxel_size, pc_range, image_scale, depth_thres,
+                       d_factors=(2, 4, 8), ifat_idx=(0, 2), debug=None):
+    """VoxelWithPointProjection.forward, fuse_mode 'pfat' + ifat gate (CP/det3d/models/fusion/
+    voxel_with_point_projection.py:131-385, point_to_image_projection.py:63-231,
+    model_utils/attention.py:31-61,422-468) restated with explicit loops.
+    levels: [(indices [n,4], features [n,C])] for x_conv2..4 (rows batch-sorted); img_feats {cam: [B,256,h,w]};
+    calib {cam: (lidar2cam [B,4,4], intrinsic [B,3,3])}; image_hw (H, W) of the network input image.
+    Returns the fused features of the last level."""
+    import torch
+    import torch.nn.functional as F
+    P = lambda k: _t(sd[k])
+    B = next(iter(img_feats.values())).shape[0]
+    H, W = image_hw
+    pc_min = torch.tensor(pc_range[:3], dtype=torch.float32)
+    vs = torch.tensor(voxel_size, dtype=torch.float32)
+    n_last = len(levels) - 1
+    per = {}                    # (b, cam) -> dict
+    img_gated = {}
+    for ci, cam in enumerate(cams):
+        l2c, K = [_t(np.asarray(x, np.float32)) for x in calib[cam]]
+        proj = []
+        for (ind, _), dfac in zip(levels, d_factors):
+            ind_t = _t(ind).float()
+            xyz = ind_t[:, [3, 2, 1]] * (vs * dfac) + pc_min                       # voxel corner
+            out = []
+            for b in range(B):
+                sel = ind[:, 0] == b
+                p = xyz[sel]
+                ph = torch.cat([p, torch.ones(len(p), 1)], 1)
+                pc = torch.bmm(ph[None], l2c[b].t()[None])[0][:, :3]              # transform_points
+                depth = pc[:, 2].clone()
+                K4 = torch.eye(4)
+                K4[:3, :3] = K[b]
+                uvw = torch.bmm(torch.cat([pc, torch.ones(len(pc), 1)], 1)[None], K4.t()[None])[0][:, :3]
+                uv = (uvw / uvw[:, 2:3])[:, :2]
+                g = uv.long()
+                g = (image_scale * g.float()).long()
+                m = (g[:, 0] > 0) & (g[:, 0] < W) & (g[:, 1] > 0) & (g[:, 1] < H) & (depth > depth_thres[cam])
+                h_, w_ = img_feats[cam].shape[2:]
+                gf = g.float()
+                gf[:, 0] *= (w_ / W)
+                gf[:, 1] *= (h_ / H)
+                out.append((gf.long(), m, p))
+            proj.append(out)
+        for b in range(B):
+            img = _t(img_feats[cam][b])
+            h_, w_ = img.shape[1:]
+            # ---- image-side gate
+            pt_img = None
+            for li in ifat_idx:
+                ind, feat = levels[li]
+                sel = ind[:, 0] == b
+                g, m, p = proj[li][b]
+                vf = torch.cat([_t(feat[sel])[m], p[m]], 1)
+                canvas = torch.zeros(h_ + 1, w_ + 1, vf.shape[1])
+                gy, gx = g[m][:, 1], g[m][:, 0]
+                for j in range(len(vf)):                                          # sequential: last writer wins
+                    canvas[gy[j], gx[j]] = vf[j]
+                canvas = canvas[:-1, :-1].permute(2, 0, 1)[None]
+                if li != ifat_idx[-1]:
+                    canvas = F.conv2d(canvas, P("ifat.reduced_dim.%d.weight" % li), P("ifat.reduced_dim.%d.bias" % li))
+                pt_img = canvas if pt_img is None else pt_img + canvas
+            pt_img = F.conv2d(pt_img, P("ifat.reduced_dim2.weight"), P("ifat.reduced_dim2.bias"))
+            gate = F.conv2d(img[None], P("ifat.reduced_dim3.weight"), P("ifat.reduced_dim3.bias"))
+            att = torch.sigmoid(F.conv2d(gate + pt_img, P("ifat.spatial_basic.weight"), P("ifat.spatial_basic.bias"), padding=1))
+            img = (img[None] * att)[0]
+            img_gated[(b, ci)] = img
+            ind, feat = levels[n_last]
+            sel = ind[:, 0] == b
+            g, m, p = proj[n_last][b]
+            per[(b, ci)] = dict(grid=g[m], pts=p[m], feat=_t(feat[sel])[m], mask=m,
+                                ifeat=img[:, g[m][:, 1], g[m][:, 0]].t())
+    if debug is not None:
+        debug.update(per=per)
+    ncam = len(cams)
+    max_ne = max(len(v["grid"]) for v in per.values())
+    C = levels[n_last][1].shape[1]
+    h_, w_ = next(iter(img_feats.values())).shape[2:]
+    v_feat = np.zeros((B * ncam, max_ne, C), np.float32)
+    v_i = np.zeros((B * ncam, max_ne, 256), np.float32)
+    grid = np.zeros((B * ncam, max_ne, 2), np.float32)
+    pts = np.zeros((B * ncam, max_ne, 3), np.float32)
+    imgs = np.zeros((B * ncam, 256, h_, w_), np.float32)
+    for (b, ci), v in per.items():
+        n = len(v["grid"])
+        i = b * ncam + ci
+        v_feat[i, :n], v_i[i, :n], pts[i, :n] = v["feat"].numpy(), v["ifeat"].numpy(), v["pts"].numpy()
+        grid[i, :n] = v["grid"].float().numpy()
+        imgs[i] = img_gated[(b, ci)].numpy()
+    grid = (_t(grid) / torch.tensor([w_, h_], dtype=torch.float32)).numpy()
+    enh = actr_forward(sd, v_feat, grid, imgs, pts, v_i, prefix="pfat.")
+    ind, feat = levels[n_last]
+    out = np.array(feat, np.float32, copy=True)
+    for b in range(B):
+        rows = np.nonzero(ind[:, 0] == b)[0]
+        for ci in range(ncam):
+            m = per[(b, ci)]["mask"].numpy()
+            out[rows[m]] += enh[b * ncam + ci][:int(m.sum())]
+    return out

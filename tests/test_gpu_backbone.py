@@ -200,3 +200,79 @@ def test_actrv2_builds_and_runs_with_local_transformer():
     with torch.no_grad():
         y = m(v_feat=v, grid=grid, i_feats=[img], lidar_grid=lid, v_i_feat=vi)
     assert tuple(y.shape) == (N, Q, 128) and bool(torch.isfinite(y).all())
+
+
+def test_centerpoint_hot_path_end_to_end_vs_oracle():
+    """BASELINE configs[1] module tree end to end on a reduced grid: voxelize + mean VFE ->
+    SpMiddleResNetFHDFusion -> VoxelWithPointProjection (projection, image gate, ACTR, write-back) -> dense
+    BEV, against the oracle composition with the same weights and inputs."""
+    from dualfusion import fusion as fz, synth
+    from dualfusion.pipeline import CenterPointHotPath
+    from make_golden import FUS
+    dev = torch.device("cuda:0")
+    rng = FUS["pc_range"]
+    fus = fz.build_centerpoint_fusion(pc_range=rng, image_scale=FUS["image_scale"])
+    fus.depth_thres = FUS["depth_thres"]
+    model = CenterPointHotPath(fusion=fus, pc_range=rng).eval()
+    sd = detgen.det_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    B = 2
+    pts_np = [synth.nusc_sweep(seed=90 + b) for b in range(B)]
+    cams = synth.nusc_cameras(image_hw=FUS["raw_hw"], focal=FUS["focal"], yaw_offset_deg=1.37)   # no lattice ties
+    H, W = FUS["img_hw"]
+    img = {n: detgen.randn("e2e_img_" + n, (B, 256) + tuple(FUS["feat_hw"])) for n in synth.NUSC_CAMS}
+    bd = {'image_shape': {}, 'img_feat': {'layer1_ori_feat2d': {}}, 'calib': {}}
+    for n in synth.NUSC_CAMS:
+        key = n.lower()
+        bd['image_shape'][key] = torch.tensor([[H, W, 3]] * B)
+        bd['img_feat']['layer1_ori_feat2d'][key] = torch.from_numpy(img[n]).to(dev)
+        bd['calib']['lidar2cam_' + key.lstrip('cam_')] = torch.from_numpy(np.stack([cams[n][0]] * B)).to(dev)
+        bd['calib']['cam_intrinsic_' + key.lstrip('cam_')] = torch.from_numpy(np.stack([cams[n][1]] * B)).to(dev)
+    dense, ms = model([torch.from_numpy(p).to(dev) for p in pts_np], batch_dict=bd, example={})
+    # ---- oracle
+    feats, coors = [], []
+    for b, p in enumerate(pts_np):
+        ov, oc, on = orc.hard_voxelize(p, synth.NUSC_VOXEL, rng, 10, 160000, "numba")
+        feats.append(orc.mean_vfe(ov, on))
+        coors.append(np.concatenate([np.full((len(oc), 1), b, np.int32), oc], 1))
+    sd_b = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    sd_f = {k[len("fusion."):]: v for k, v in sd.items() if k.startswith("fusion.")}
+    calib = {n: (np.stack([cams[n][0]] * B), np.stack([cams[n][1]] * B)) for n in synth.NUSC_CAMS}
+
+    def srt(c):
+        i, f = om.sort_rows(c.indices, c.features)
+        return np.ascontiguousarray(i), np.ascontiguousarray(f)
+
+    dbg = {}
+
+    def fuse(c2, c3, c4):
+        lv = [srt(c) for c in (c2, c3, c4)]        # the adapter needs batch-sorted rows (spconv's GPU order)
+        out = om.centerpoint_fusion(sd_f, lv, img, calib, FUS["img_hw"], synth.NUSC_CAMS, synth.NUSC_VOXEL, rng,
+                                    FUS["image_scale"], FUS["depth_thres"], debug=dbg)
+        c4.indices, c4.features = lv[2][0], out
+        c4.rulebooks = {}
+        return c4
+    o_dense, o_ms = om.centerpoint_backbone(sd_b, np.concatenate(feats), np.concatenate(coors), B, [256, 256, 40],
+                                            fuse=fuse)
+    mi, mf = om.sort_rows(ms["conv4"].indices.cpu().numpy(), ms["conv4"].features.cpu().numpy())
+    oi, of = om.sort_rows(o_ms["conv4"].indices, o_ms["conv4"].features)
+    assert np.array_equal(mi, oi)
+    # Voxel -> pixel projection truncates three times (.long()); the oracle projects with torch-CPU matmuls,
+    # the kernel with an explicit k-ordered FMA chain (bit-identical on the reference golden,
+    # test_centerpoint_fusion_adapter_vs_reference_golden).  A voxel that projects exactly onto a pixel
+    # boundary can fall on either side; the rig is turned by 1.37 deg so the voxel lattice has no such ties,
+    # and the visible sets must then agree exactly.
+    tol = 1e-3 * max(1.0, np.abs(of).max())
+    row_err = np.abs(mf - of).max(1)
+    inp = fus._gather_inputs(bd, 'layer1_ori', dev)
+    _, m_, _ = fus._project(ms["conv4"], 8, inp)
+    ind4 = ms["conv4"].indices.cpu().numpy()
+    order = np.lexsort((ind4[:, 3], ind4[:, 2], ind4[:, 1], ind4[:, 0]))
+    mm = m_.cpu().numpy()[:, order].astype(bool)
+    for ci in range(6):
+        for b in range(B):
+            assert np.array_equal(dbg["per"][(b, ci)]["mask"].numpy(), mm[ci][mi[:, 0] == b]), (ci, b)
+    assert row_err.max() <= tol, (row_err.max(), int((row_err > tol).sum()))
+    d_err = np.abs(dense.cpu().numpy() - o_dense)
+    assert (d_err > 1e-3 * max(1.0, np.abs(o_dense).max())).mean() < 0.01

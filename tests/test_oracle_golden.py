@@ -163,3 +163,31 @@ def test_local_transformer_oracle_vs_reference_golden(golden):
     d = LT_DIMS
     y = om.local_transformer(sd, xyz, feat, d["npoint"], d["radius"], d["nsample"], num_layers=d["num_layers"])
     np.testing.assert_allclose(y, g["out"], atol=2e-5)
+
+
+def test_actr_oracle_vs_reference_golden(golden):
+    import oracle_models as om
+    from make_golden import actr_inputs
+    g = golden("actr.npz")
+    shapes = {str(k): eval(str(s)) for k, s in zip(g["param_names"], g["param_shapes"])}
+    sd = detgen.det_state_dict(shapes)
+    v_feat, grid, i_feat, lidar_grid, v_i_feat = actr_inputs()
+    y = om.actr_forward(sd, v_feat, grid, i_feat, lidar_grid, v_i_feat)
+    np.testing.assert_allclose(y, g["out"], atol=5e-5)
+
+
+def test_centerpoint_fusion_oracle_vs_reference_golden(golden):
+    import oracle_models as om
+    from make_golden import FUS
+    g = golden("fusion_cp.npz")
+    shapes = {str(k): eval(str(s)) for k, s in zip(g["param_names"], g["param_shapes"])}
+    sd = detgen.det_state_dict(shapes)
+    sets = [g["coords2"].astype(np.int32), g["coords3"].astype(np.int32), g["coords4"].astype(np.int32)]
+    feats = [detgen.randn("fus_feat%d" % i, (len(s), c)) for i, (s, c) in enumerate(zip(sets, [32, 64, 128]))]
+    cams = synth.nusc_cameras(image_hw=FUS["raw_hw"], focal=FUS["focal"])
+    B = FUS["batch"]
+    img = {n: detgen.randn("fus_img_" + n, (B, 256) + tuple(FUS["feat_hw"])) for n in synth.NUSC_CAMS}
+    calib = {n: (np.stack([cams[n][0]] * B), np.stack([cams[n][1]] * B)) for n in synth.NUSC_CAMS}
+    out = om.centerpoint_fusion(sd, list(zip(sets, feats)), img, calib, FUS["img_hw"], synth.NUSC_CAMS,
+                                FUS["voxel_size"], FUS["pc_range"], FUS["image_scale"], FUS["depth_thres"])
+    np.testing.assert_allclose(out, g["out"], atol=1e-4)
