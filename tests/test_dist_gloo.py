@@ -23,8 +23,9 @@ WORKER = textwrap.dedent("""
     losses = {"loss": torch.tensor(1.0 + rank), "hm_loss": torch.tensor(10.0 * (rank + 1))}
     red = D.reduce_dict(losses)
     allr = D.all_reduce_value(torch.tensor([float(rank + 1)]), "sum", average=True)
-    print("RESULT " + json.dumps({"rank": rank, "frames": frames, "elapsed": el,
-                                  "loss": float(red["loss"]), "hm": float(red["hm_loss"]), "avg": float(allr)}))
+    with open(os.path.join(os.environ["DF3D_TEST_OUT"], "rank%d.json" % rank), "w") as f:
+        json.dump({"rank": rank, "frames": frames, "elapsed": el, "loss": float(red["loss"]),
+                   "hm": float(red["hm_loss"]), "avg": float(allr)}, f)
     D.barrier()
     torch.distributed.destroy_process_group()
 """) % ROOT
@@ -36,15 +37,14 @@ def test_two_rank_gloo(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), str(script)]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", DF3D_TEST_OUT=str(tmp_path))
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     res = {}
-    for line in out.stdout.splitlines():
-        if line.startswith("RESULT "):
-            r = json.loads(line[7:])
-            res[r["rank"]] = r
+    for r in (0, 1):       # one file per rank: stdout of the two processes can interleave
+        with open(os.path.join(str(tmp_path), "rank%d.json" % r)) as f:
+            res[r] = json.load(f)
     assert set(res) == {0, 1}
     assert res[0]["frames"] == [0, 2, 4, 6] and res[1]["frames"] == [1, 3, 5]      # disjoint, complete
     assert abs(res[0]["elapsed"] - res[1]["elapsed"]) < 1e-9 and res[0]["elapsed"] >= 0.1   # MAX over ranks
