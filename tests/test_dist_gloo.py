@@ -23,7 +23,7 @@ WORKER = textwrap.dedent("""
     losses = {"loss": torch.tensor(1.0 + rank), "hm_loss": torch.tensor(10.0 * (rank + 1))}
     red = D.reduce_dict(losses)
     allr = D.all_reduce_value(torch.tensor([float(rank + 1)]), "sum", average=True)
-    with open(os.path.join(os.environ["DF3D_TEST_OUT"], "rank%d.json" % rank), "w") as f:
+    with open(os.path.join(os.environ["DF3D_TEST_OUT"], "rank%%d.json" %% rank), "w") as f:
         json.dump({"rank": rank, "frames": frames, "elapsed": el, "loss": float(red["loss"]),
                    "hm": float(red["hm_loss"]), "avg": float(allr)}, f)
     D.barrier()
