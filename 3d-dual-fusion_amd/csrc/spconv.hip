@@ -23,6 +23,8 @@
 // Roofline: HBM for C <= 32 (AI 3-14 flop/B), fp32 MFMA (157 TF) for C >= 64.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace df3d {
@@ -651,6 +653,28 @@ __global__ __launch_bounds__(256) void conv_tiles_kernel(const uint32_t *__restr
   tile_rows[i] = lo;
 }
 
+
+// ---- optional per-launch timing with HIP events recorded right around the launch (bench.py's roofline
+//      leg; hipEventRecord on the launching stream, microseconds apart on the host) ----------------------
+struct TimingRec {
+  hipEvent_t e0, e1;
+  int cin, cout, kvol, n_out;
+};
+static bool g_timing_on = false;
+static std::vector<TimingRec> g_timing;
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t timing_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
 static int pair_ntiles(int n_out, int cin, int cout) {
   // measured on MI355X (tools/conv_probe.py): the pair kernel wins for COUT=128 (244 vs 306 us at conv4),
   // the output-stationary kernel for COUT=64 (170 vs 218 us at conv3: items are only 32 MFMAs long there)
@@ -750,6 +774,12 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
   a.cin = cin;
   a.cout = cout;
   a.relu = relu;
+  TimingRec trec;
+  const bool timed = g_timing_on;
+  if (timed) {
+    trec = {timing_event(), timing_event(), cin, cout, kvol, n_out};
+    if (trec.e0 && trec.e1) (void)hipEventRecord(trec.e0, stream);
+  }
   bool done = false;
   // compute-bound shapes: pair-compacted kernel (DF3D_SPCONV_V1=1 forces the output-stationary kernel)
   static const bool use_v2 = getenv("DF3D_SPCONV_V1") == nullptr;
@@ -769,6 +799,37 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
     size_t tot = (size_t)n_out * cout;
     hipLaunchKernelGGL(spconv_generic_kernel, dim3(cdiv((long long)tot, 256)), dim3(256), 0, stream, a);
   }
+  if (timed && trec.e0 && trec.e1) {
+    (void)hipEventRecord(trec.e1, stream);
+    g_timing.push_back(trec);
+  }
   DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_timing_begin(void) {
+  for (auto &r : g_timing) {
+    g_event_pool.push_back(r.e0);
+    g_event_pool.push_back(r.e1);
+  }
+  g_timing.clear();
+  g_timing_on = true;
+  return DF3D_OK;
+}
+
+extern "C" int df3d_timing_end(void) {
+  g_timing_on = false;
+  return (int)g_timing.size();
+}
+
+extern "C" int df3d_timing_get(int i, int *shape4, float *ms) {
+  DF3D_CHECK_ARG(i >= 0 && i < (int)g_timing.size() && shape4 && ms, "timing_get: bad index");
+  const TimingRec &r = g_timing[i];
+  DF3D_HIP(hipEventSynchronize(r.e1));
+  DF3D_HIP(hipEventElapsedTime(ms, r.e0, r.e1));
+  shape4[0] = r.cin;
+  shape4[1] = r.cout;
+  shape4[2] = r.kvol;
+  shape4[3] = r.n_out;
   return DF3D_OK;
 }

@@ -44,6 +44,9 @@ SIGNATURES = {
     "df3d_sparse_conv_fused_tiled": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                              c_void_p]),
+    "df3d_timing_begin": (c_int, []),
+    "df3d_timing_end": (c_int, []),
+    "df3d_timing_get": (c_int, [c_int, c_void_p, c_void_p]),
     "df3d_sparse_to_dense": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_ms_deform_attn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

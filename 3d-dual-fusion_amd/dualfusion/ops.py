@@ -165,17 +165,33 @@ def pairs_to_nbr(indice_pairs, indice_num, n_out):
 
 # ------------------------------------------------------------------------- sparse conv
 class KernelTimer(object):
-    """Optional per-launch timing with HIP events recorded on the launching stream (bench.py's
-    roofline leg).  Off unless `ops.TIMER` is set; adds two event records per conv launch."""
+    """Per-launch timing of the sparse-conv kernels for bench.py's roofline leg.  The HIP events are
+    recorded inside libdf3d_hip.so right around the kernel launch on the launching stream
+    (df3d_timing_*); this object keeps the matching per-call metadata (neighbour table, sizes)."""
 
     def __init__(self):
-        self.records = []   # (key, start_event, end_event, meta)
+        self.meta = []
+        self.records = []   # (key, ms, meta) after stop()
 
-    def region(self, key, meta):
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
-        self.records.append((key, a, b, meta))
-        return a, b
+    def start(self):
+        _lib.load().df3d_timing_begin()
+
+    def note(self, key, meta):
+        self.meta.append((key, meta))
+
+    def stop(self):
+        lib = _lib.load()
+        n = lib.df3d_timing_end()
+        shape = (ctypes.c_int * 4)()
+        ms = ctypes.c_float()
+        assert n == len(self.meta), (n, len(self.meta))
+        for i in range(n):
+            _lib.check(lib.df3d_timing_get(i, ctypes.cast(shape, ctypes.c_void_p),
+                                           ctypes.cast(ctypes.pointer(ms), ctypes.c_void_p)), "df3d_timing_get")
+            key, meta = self.meta[i]
+            assert (shape[0], shape[1], shape[2]) == key[1:], (tuple(shape), key)
+            self.records.append((key, float(ms.value), meta))
+        return self.records
 
 
 TIMER = None
@@ -213,15 +229,12 @@ def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shif
         if t is not None:
             _chk(t, torch.float32, nm)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
-    ev = TIMER.region(("spconv", cin, cout, K), {"n_in": n_in, "n_out": n_out, "nbr": nbr}) if TIMER is not None else None
-    if ev:
-        ev[0].record()
+    if TIMER is not None:
+        TIMER.note(("spconv", cin, cout, K), {"n_in": n_in, "n_out": n_out, "nbr": nbr})
     rc = lib.df3d_sparse_conv_fused_tiled(_ptr(features), n_in, cin, _ptr(filters), K, cout, _ptr(nbr), n_out,
                                           _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)),
                                           _ptr(out), _ptr(tiles), (tiles.shape[0] - 1) if tiles is not None else 0,
                                           _stream())
-    if ev:
-        ev[1].record()
     _lib.check(rc, "df3d_sparse_conv_fused")
     return out
 

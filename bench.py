@@ -83,8 +83,7 @@ def conv_algorithmic(meta, cin, cout, K):
 
 def roofline_from_timer(timer):
     groups = {}
-    for key, a, b, meta in timer.records:
-        ms = a.elapsed_time(b)
+    for key, ms, meta in timer.records:
         g = groups.setdefault(key, {"ms": 0.0, "n": 0, "meta": []})
         g["ms"] += ms
         g["n"] += 1
@@ -117,6 +116,16 @@ def roofline_from_timer(timer):
     roof.update({"traffic": None, "kernel": "%s<cin=%d,cout=%d,K=%d>" % ("spconv_pair_kernel" if cout == 128 and cin >= 64 else "spconv_mfma_kernel", cin, cout, K),
                  "launches": g["n"], "avg_launch_us": round(avg_us, 2),
                  "algorithmic_flops_per_launch": fl // g["n"], "algorithmic_bytes_per_launch": by // g["n"]})
+    # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; PMC
+    # cannot be read from inside the process).  The committed summary of the last such run is attached
+    # when it belongs to the same kernel; otherwise null.
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_spconv_pair.json")))
+        if (cin, cout, K) == (128, 128, 27):
+            roof["traffic"] = pm["traffic_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r01_pmc_spconv_pair.json (rocprofv3 --pmc, separate passes)"
+    except Exception:
+        pass
     per_kernel = {"%dx%d_k%d" % (k[1], k[2], k[3]): {"ms_total": round(v["ms"], 3), "launches": v["n"]}
                   for k, v in groups.items()}
     return roof, per_kernel
@@ -196,12 +205,16 @@ def main():
     timer = None if args.no_kernel_timing else ops.KernelTimer()
     barrier()
     ops.TIMER = timer
+    if timer is not None:
+        timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = run_step(model, pts, extra)
     barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    if timer is not None:
+        timer.stop()
     elapsed = D.max_over_ranks(elapsed, dev)
     dense = out[0]
     assert tuple(dense.shape) == (args.batch, 256, 180, 180), dense.shape

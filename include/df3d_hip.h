@@ -146,6 +146,14 @@ int df3d_sparse_conv_fused_tiled(const float *features, int n_in, int cin,
                                  const float *residual, int relu, float *out,
                                  const int32_t *tile_rows, int ntiles, void *stream);
 
+/* Per-launch timing of the sparse-conv kernels with HIP events recorded on the launching stream, adjacent
+ * to the launch (measurement aid for bench.py's roofline leg; off by default, not thread-safe).
+ * begin: reset + enable.  end: disable, returns the number of records.  get: shape4 = (cin, cout, kvol,
+ * n_out) of record i and its duration in ms (synchronises on the record's stop event). */
+int df3d_timing_begin(void);
+int df3d_timing_end(void);
+int df3d_timing_get(int i, int *shape4_host, float *ms_host);
+
 /* SparseConvTensor.dense() (TF/mmdet3d/ops/spconv/structure.py:5-18,55-64): zero-fill +
  * scatter + permute fused; out [B, C, D, H, W] f32 (the backbones view it as [B, C*D, H, W]). */
 int df3d_sparse_to_dense(const float *features, const int32_t *indices, int n, int channels,
