@@ -266,3 +266,172 @@ extern "C" int df3d_fusion_writeback(const float *features, const float *enh, co
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }
+
+// =========================================================================================
+// Image-side gate without dense canvases.
+//
+// The reference gate (attention.py:31-61) builds two dense canvases [C+3, H, W] per image, runs 1x1
+// convs over them, adds a 1-channel image summary, runs a 3x3 conv to ONE channel and a sigmoid.
+// Every step before the sigmoid is linear, and the canvases are non-zero only at the few thousand
+// pixels hit by a voxel, so the same map is
+//     y[p] = b + sum_t inside(p+t) * (k_t + g_t * gate[p+t]) + sum_t S[t][p+t]
+// where t runs over the 3x3 taps, k_t / g_t are scalars derived from the weights, gate is the
+// 1-channel image summary and S[t] holds, at each voxel pixel, the tap-t response of that voxel's
+// (already projected) feature row.  S is filled by scattering 9 scalars per winning voxel row.
+// =========================================================================================
+namespace df3d {
+
+// S[img][t][gy][gx] += s[row][t] for the winner rows of one scale (winner map from scatter_winner_kernel)
+__global__ __launch_bounds__(256) void gate_scatter_kernel(const float *__restrict__ s9, const int32_t *__restrict__ ind,
+                                                           const int32_t *__restrict__ grid,
+                                                           const uint8_t *__restrict__ mask,
+                                                           const int32_t *__restrict__ winner, int n, int ncam, int H,
+                                                           int W, float *__restrict__ S) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * ncam) return;
+  int cam = (int)(t / n), i = (int)(t - (long long)cam * n);
+  if (!mask[(size_t)cam * n + i]) return;
+  int gx = grid[((size_t)cam * n + i) * 2], gy = grid[((size_t)cam * n + i) * 2 + 1];
+  if (gx < 0 || gx >= W || gy < 0 || gy >= H) return;
+  int img = ind[(size_t)i * 4] * ncam + cam;
+  size_t pix = (size_t)gy * W + gx;
+  if (winner[(size_t)img * H * W + pix] != i) return;
+  size_t hw = (size_t)H * W;
+  float *dst = S + (size_t)img * 9 * hw + pix;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dst[(size_t)k * hw] += s9[(size_t)i * 9 + k];   // row response is camera independent
+}
+
+// att[img][p] = sigmoid(bias + sum_t inside * (k[t] + g[t]*gate[p+t] + S[t][p+t]))
+__global__ __launch_bounds__(256) void gate_finish_kernel(const float *__restrict__ gate, const float *__restrict__ S,
+                                                          const float *__restrict__ kg /* [9] k_t, [9] g_t, bias */,
+                                                          int nimg, int H, int W, float *__restrict__ att) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t hw = (size_t)H * W;
+  if (t >= (long long)nimg * hw) return;
+  int img = (int)(t / hw);
+  int p = (int)(t - (long long)img * hw);
+  int y = p / W, x = p - y * W;
+  float acc = kg[18];
+#pragma unroll
+  for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      int yy = y + ty - 1, xx = x + tx - 1;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;   // zero padding of the 3x3 conv
+      int k = ty * 3 + tx;
+      size_t q = (size_t)yy * W + xx;
+      acc += kg[k] + kg[9 + k] * gate[(size_t)img * hw + q] + S[((size_t)img * 9 + k) * hw + q];
+    }
+  att[t] = 1.f / (1.f + __expf(-acc));
+}
+
+struct AsmArgs2 {
+  const float *feat, *pinv;
+  const int32_t *ind, *grid;
+  const uint8_t *mask;
+  const int32_t *pos;
+  const float *img;       // UNGATED image features [B*ncam, Ci, H, W]
+  const float *att;       // [B*ncam, H, W] or null
+  int n, C, Ci, ncam, H, W, max_ne;
+  float *v_feat, *v_i_feat, *qgrid, *qpts, *qpos;   // qpos [B*ncam, max_ne, C] depth sine embedding or null
+};
+
+// assemble_queries with (a) the gate applied on the fly to the sampled image feature and (b) the depth
+// sine position embedding (position_encoding.py:107-120: x / 60 * 2pi over temperature^(2*(i//2)/C),
+// sin on even / cos on odd channels) written directly, so neither a gated image nor a trig pass exists.
+__global__ __launch_bounds__(256) void assemble_queries2_kernel(AsmArgs2 a) {
+  long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (w >= (long long)a.n * a.ncam) return;
+  int cam = (int)(w / a.n), i = (int)(w - (long long)cam * a.n);
+  if (!a.mask[(size_t)cam * a.n + i]) return;
+  int slot = a.pos[(size_t)cam * a.n + i];
+  if (slot >= a.max_ne) return;
+  int img = a.ind[(size_t)i * 4] * a.ncam + cam;
+  size_t q = (size_t)img * a.max_ne + slot;
+  int gx = a.grid[((size_t)cam * a.n + i) * 2], gy = a.grid[((size_t)cam * a.n + i) * 2 + 1];
+  for (int c = lane; c < a.C; c += 64) a.v_feat[q * a.C + c] = a.feat[(size_t)i * a.C + c];
+  size_t hw = (size_t)a.H * a.W;
+  size_t pix = (size_t)gy * a.W + gx;
+  float g = a.att ? a.att[(size_t)img * hw + pix] : 1.f;
+  const float *src = a.img + (size_t)img * a.Ci * hw + pix;
+  for (int c = lane; c < a.Ci; c += 64) a.v_i_feat[q * a.Ci + c] = src[(size_t)c * hw] * g;
+  if (lane == 0) {
+    a.qgrid[q * 2 + 0] = (float)gx / (float)a.W;
+    a.qgrid[q * 2 + 1] = (float)gy / (float)a.H;
+  }
+  if (lane < 3) a.qpts[q * 3 + lane] = a.pinv[(size_t)i * 3 + lane];
+  if (a.qpos) {
+    float d = a.pinv[(size_t)i * 3] / 60.f * 6.283185307179586f;
+    for (int c = lane; c < a.C; c += 64) {
+      float dim_t = powf(10000.f, (float)(2 * (c / 2)) / (float)a.C);
+      float v = d / dim_t;
+      a.qpos[q * a.C + c] = (c & 1) ? cosf(v) : sinf(v);
+    }
+  }
+}
+
+// position embedding of a padded (all-zero) query: sin(0) = 0 on even, cos(0) = 1 on odd channels
+__global__ __launch_bounds__(256) void qpos_pad_kernel(float *__restrict__ qpos, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) qpos[i] = (i & 1) ? 1.f : 0.f;      // channel count is even, so parity of the flat index = channel parity
+}
+
+}  // namespace df3d
+
+extern "C" int df3d_gate_scatter(const float *s9, const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask,
+                                 int n, int batch, int ncam, int H, int W, int32_t *winner, float *S, int clear,
+                                 void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(winner && S, "gate_scatter: null output");
+  size_t nimg = (size_t)batch * ncam;
+  if (clear) DF3D_HIP(hipMemsetAsync(S, 0, nimg * 9 * (size_t)H * W * sizeof(float), stream));
+  DF3D_HIP(hipMemsetAsync(winner, 0xff, nimg * H * W * sizeof(int32_t), stream));
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(s9 && indices && grid_xy && mask, "gate_scatter: null input");
+  ScatArgs a = {nullptr, nullptr, indices, grid_xy, mask, n, 0, ncam, H, W, winner, nullptr};
+  dim3 g(cdiv((long long)n * ncam, 256));
+  hipLaunchKernelGGL(scatter_winner_kernel, g, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(gate_scatter_kernel, g, dim3(256), 0, stream, s9, indices, grid_xy, mask, winner, n, ncam, H, W, S);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_gate_finish(const float *gate, const float *S, const float *kg, int nimg, int H, int W, float *att,
+                                void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(gate && S && kg && att, "gate_finish: null argument");
+  long long tot = (long long)nimg * H * W;
+  if (tot == 0) return DF3D_OK;
+  hipLaunchKernelGGL(gate_finish_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, gate, S, kg, nimg, H, W, att);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_assemble_queries2(const float *features, const float *point_inv, const int32_t *indices,
+                                      const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
+                                      const float *img_feats, const float *att, int n, int channels, int img_channels,
+                                      int batch, int ncam, int H, int W, int max_ne, float *v_feat, float *v_i_feat,
+                                      float *qgrid, float *qpts, float *qpos, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(v_feat && v_i_feat && qgrid && qpts, "assemble_queries2: null output");
+  size_t nq = (size_t)batch * ncam * max_ne;
+  DF3D_HIP(hipMemsetAsync(v_feat, 0, nq * channels * sizeof(float), stream));
+  DF3D_HIP(hipMemsetAsync(v_i_feat, 0, nq * img_channels * sizeof(float), stream));
+  DF3D_HIP(hipMemsetAsync(qgrid, 0, nq * 2 * sizeof(float), stream));
+  DF3D_HIP(hipMemsetAsync(qpts, 0, nq * 3 * sizeof(float), stream));
+  if (qpos && nq) {
+    DF3D_CHECK_ARG(channels % 2 == 0, "assemble_queries2: odd channel count");
+    size_t tot = nq * channels;
+    hipLaunchKernelGGL(qpos_pad_kernel, dim3(cdiv((long long)tot, 256)), dim3(256), 0, stream, qpos, tot);
+  }
+  if (n == 0 || max_ne == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(features && point_inv && indices && grid_xy && mask && pos && img_feats,
+                 "assemble_queries2: null input");
+  AsmArgs2 a = {features, point_inv, indices, grid_xy, mask, pos, img_feats, att, n, channels, img_channels, ncam, H, W,
+                max_ne, v_feat, v_i_feat, qgrid, qpts, qpos};
+  hipLaunchKernelGGL(assemble_queries2_kernel, dim3(cdiv((long long)n * ncam * 64, 256)), dim3(256), 0, stream, a);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}

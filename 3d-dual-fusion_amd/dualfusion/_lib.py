@@ -61,6 +61,12 @@ SIGNATURES = {
     "df3d_assemble_queries": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_gate_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p, c_void_p, c_int, c_void_p]),
+    "df3d_gate_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_assemble_queries2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_fusion_writeback": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p]),
 }

@@ -369,6 +369,26 @@ class ACTR(nn.Module):
         y = F.group_norm(y.transpose(1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)
         return y.transpose(1, 2)
 
+    def forward_projected(self, v_feat, grid, src_conv, v_i_feat, lidar_grid, q_pos=None):
+        """forward() for callers that already hold the 1x1 input projection of the (single-level) image,
+        `src_conv` [N, C, H, W] = input_proj[0][0](image) before its GroupNorm, and optionally the query
+        position embedding [N, Q, C].  Used by the CenterPoint adapter, which folds its image gate into
+        that projection (dualfusion/fusion.py)."""
+        q_feat = v_feat
+        q_i_feat = None
+        if self.feature_modal in ['image', 'hybrid']:
+            q_i_feat = self.project_image_queries(v_i_feat)
+            if self.feature_modal == 'image':
+                q_feat = q_i_feat
+        if q_pos is None:
+            if self.pos_encode_method == "image_coor":
+                q_pos = self.q_position_embedding(grid).transpose(1, 2)
+            else:
+                q_pos = self.q_position_embedding(lidar_grid[..., 0]).transpose(1, 2)
+        srcs = [self.input_proj[0][1](src_conv)]
+        return self.transformer(srcs, None, None, q_feat, q_pos, grid, q_lidar_grid=lidar_grid,
+                                q_i_feat_flatten=q_i_feat)
+
     def forward(self, v_feat, grid, i_feats, v_i_feat=None, lidar_grid=None):
         q_feat = v_feat
         q_i_feat = None

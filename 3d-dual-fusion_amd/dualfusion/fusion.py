@@ -50,6 +50,27 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
             nn.Conv2d(self.voxel_feat_channel[i] + 3, last, kernel_size=1, stride=1, padding=0)
             for i in range(self.voxel_idx[-1])])
 
+    def folded(self):
+        """The gate is linear up to its sigmoid, so it collapses to a few small matrices (see
+        csrc/fusion.hip "Image-side gate without dense canvases"):
+          T[idx] [9, C_idx+3]: tap responses of a voxel row of scale idx;  kg [19] = k_t, g_t, bias;
+          w3 [1, Cimg], b3: the 1-channel image summary (reduced_dim3)."""
+        with torch.no_grad():
+            last = self.voxel_idx[-1]
+            R2 = self.reduced_dim2.weight[:, :, 0, 0].float()
+            Wsb = self.spatial_basic.weight[0].float().permute(1, 2, 0).reshape(9, -1)     # [tap, channel]
+            const = self.reduced_dim2.bias.float().clone()
+            T = {}
+            for idx in self.voxel_idx:
+                if len(self.voxel_idx) > 1 and idx != last:
+                    Ri = self.reduced_dim[idx].weight[:, :, 0, 0].float()
+                    T[idx] = (Wsb @ (R2 @ Ri)).contiguous()
+                    const = const + R2 @ self.reduced_dim[idx].bias.float()
+                else:
+                    T[idx] = (Wsb @ R2).contiguous()
+            kg = torch.cat([Wsb @ const, Wsb.sum(1), self.spatial_basic.bias.float().view(1)]).contiguous()
+            return T, kg, self.reduced_dim3.weight[:, :, 0, 0].float(), self.reduced_dim3.bias.float()
+
     def forward_batched(self, img_feat, canvases):
         """img_feat [NI, Cimg, H, W]; canvases {scale idx: [NI, C_s+3, H, W]} -> gated img_feat."""
         pt_img = None
@@ -155,34 +176,10 @@ class VoxelWithPointProjection(nn.Module):
         return canvas
 
     # ------------------------------------------------------------------ forward
-    @torch.no_grad()
-    def forward(self, batch_dict, example, encoded_voxel_list=None, layer_name=None, img_conv_func=None,
-                fuse_mode=None, d_factor_list=None):
-        if fuse_mode != 'pfat':
-            raise NotImplementedError("fuse_mode %r" % (fuse_mode,))
-        lib = _lib.load()
-        x_last = encoded_voxel_list[-1]
-        dev = x_last.features.device
-        inp = self._gather_inputs(batch_dict, layer_name, dev)
-        B, ncam = inp['B'], inp['ncam']
-        img = inp['img']
-        if img_conv_func is not None:
-            img = img_conv_func(img)
-        # (a7) projection of every scale the gate or the queries need
-        need = set([len(encoded_voxel_list) - 1])
-        if self.ifat_cfg is not None:
-            need |= set(self.ifat.voxel_idx)
-        proj = {s: self._project(encoded_voxel_list[s], d_factor_list[s], inp) for s in sorted(need)}
-        # (a9) image-side gate
-        if self.ifat_cfg is not None:
-            canv = {s: self._canvas(encoded_voxel_list[s], *proj[s], inp) for s in self.ifat.voxel_idx}
-            img = self.ifat.forward_batched(img, canv)
-        img = img.contiguous()
-        # (a8) per-camera query sets from the LAST scale (Appendix C item 4)
-        grid, mask, pinv = proj[len(encoded_voxel_list) - 1]
-        feats = x_last.features.contiguous()
-        ind = x_last.indices.contiguous()
-        n, C = feats.shape
+    def _query_slots(self, ind, mask, B):
+        """slot of every visible voxel inside its (sample, camera) list + max list length (one host sync)."""
+        n = ind.shape[0]
+        dev = ind.device
         m32 = mask.to(torch.int32)
         incl = torch.cumsum(m32, 1, dtype=torch.int32)
         excl = incl - m32
@@ -196,18 +193,77 @@ class VoxelWithPointProjection(nn.Module):
         pos = (excl - base[:, bcol.long()]).contiguous()
         counts = (incl[:, (ends - 1).clamp(min=0)] - base) * nonempty[None, :].to(torch.int32)
         max_ne = int(counts.max().item()) if n > 0 else 0                                     # the one host sync
+        return pos, max_ne
+
+    @torch.no_grad()
+    def forward(self, batch_dict, example, encoded_voxel_list=None, layer_name=None, img_conv_func=None,
+                fuse_mode=None, d_factor_list=None):
+        if fuse_mode != 'pfat':
+            raise NotImplementedError("fuse_mode %r" % (fuse_mode,))
+        lib = _lib.load()
+        x_last = encoded_voxel_list[-1]
+        dev = x_last.features.device
+        inp = self._gather_inputs(batch_dict, layer_name, dev)
+        B, ncam = inp['B'], inp['ncam']
         NI = B * ncam
+        H, W = inp['h'], inp['w']
+        img = inp['img']
+        if img_conv_func is not None:
+            img = img_conv_func(img)
+        last = len(encoded_voxel_list) - 1
+        # (a7) projection of every scale the gate or the queries need
+        need = set([last])
+        if self.ifat_cfg is not None:
+            need |= set(self.ifat.voxel_idx)
+        proj = {s: self._project(encoded_voxel_list[s], d_factor_list[s], inp) for s in sorted(need)}
+        in_conv = self.pfat.input_proj[0][0]
+        att = None
+        if self.ifat_cfg is not None:
+            # (a9) image-side gate, canvas-free: one pass over the image gives the ACTR input projection AND the
+            # gate's 1-channel summary; the voxel side is 9 scalars per visible voxel
+            T, kg, w3, b3 = self.ifat.folded()
+            wcat = torch.cat([in_conv.weight[:, :, 0, 0], w3], 0)[:, :, None, None]
+            both = torch.nn.functional.conv2d(img, wcat)                        # [NI, C+1, H, W], no bias
+            src_conv = both[:, :-1]
+            gate = (both[:, -1] + b3).contiguous()
+            S = torch.empty((NI, 9, H, W), dtype=torch.float32, device=dev)
+            winner = torch.empty((NI, H, W), dtype=torch.int32, device=dev)
+            first = True
+            for sidx in self.ifat.voxel_idx:
+                x = encoded_voxel_list[sidx]
+                grid_s, mask_s, pinv_s = proj[sidx]
+                rows = torch.cat([x.features, pinv_s], 1)
+                s9 = (rows @ T[sidx].t()).contiguous()                          # [n, 9]
+                rc = lib.df3d_gate_scatter(_p(s9), _p(x.indices.contiguous()), _p(grid_s), _p(mask_s), rows.shape[0],
+                                           B, ncam, H, W, _p(winner), _p(S), int(first), _ops._stream())
+                _lib.check(rc, "df3d_gate_scatter")
+                first = False
+            att = torch.empty((NI, H, W), dtype=torch.float32, device=dev)
+            rc = lib.df3d_gate_finish(_p(gate), _p(S), _p(kg), NI, H, W, _p(att), _ops._stream())
+            _lib.check(rc, "df3d_gate_finish")
+            # input_proj(img * att) = att * (W img) + b   (att is a per-pixel scalar)
+            src_conv = src_conv * att[:, None] + in_conv.bias[None, :, None, None]
+        else:
+            src_conv = in_conv(img)
+        # (a8) per-camera query sets from the LAST scale (Appendix C item 4)
+        grid, mask, pinv = proj[last]
+        feats = x_last.features.contiguous()
+        ind = x_last.indices.contiguous()
+        n, C = feats.shape
+        pos, max_ne = self._query_slots(ind, mask, B)
         Ci = img.shape[1]
         v_feat = torch.empty((NI, max_ne, C), dtype=torch.float32, device=dev)
         v_i_feat = torch.empty((NI, max_ne, Ci), dtype=torch.float32, device=dev)
         qgrid = torch.empty((NI, max_ne, 2), dtype=torch.float32, device=dev)
         qpts = torch.empty((NI, max_ne, 3), dtype=torch.float32, device=dev)
-        rc = lib.df3d_assemble_queries(_p(feats), _p(pinv), _p(ind), _p(grid), _p(mask), _p(pos), _p(img), n, C, Ci, B,
-                                       ncam, inp['h'], inp['w'], max_ne, _p(v_feat), _p(v_i_feat), _p(qgrid), _p(qpts),
-                                       _ops._stream())
-        _lib.check(rc, "df3d_assemble_queries")
+        depth_pos = self.pfat.pos_encode_method == "depth"
+        qpos = torch.empty((NI, max_ne, C), dtype=torch.float32, device=dev) if depth_pos else None
+        rc = lib.df3d_assemble_queries2(_p(feats), _p(pinv), _p(ind), _p(grid), _p(mask), _p(pos), _p(img), _p(att), n,
+                                        C, Ci, B, ncam, H, W, max_ne, _p(v_feat), _p(v_i_feat), _p(qgrid), _p(qpts),
+                                        _p(qpos), _ops._stream())
+        _lib.check(rc, "df3d_assemble_queries2")
         # (a10-a12) ACTR
-        enh = self.pfat(v_feat=v_feat, grid=qgrid, i_feats=[img], lidar_grid=qpts, v_i_feat=v_i_feat).contiguous()
+        enh = self.pfat.forward_projected(v_feat, qgrid, src_conv, v_i_feat, qpts, q_pos=qpos).contiguous()
         # write-back, additive, camera order (Appendix C item 8)
         out = torch.empty_like(feats)
         rc = lib.df3d_fusion_writeback(_p(feats), _p(enh), _p(ind), _p(mask), _p(pos), n, C, ncam, max_ne, _p(out),

@@ -231,6 +231,23 @@ int df3d_fusion_writeback(const float *features, const float *enh, const int32_t
                           const uint8_t *mask, const int32_t *pos, int n, int channels, int ncam,
                           int max_ne, float *out, void *stream);
 
+/* Canvas-free image gate (attention.py:31-61 refactored by linearity, see csrc/fusion.hip):
+ * df3d_gate_scatter: S [B*ncam, 9, H, W] += s9 [n, 9] at the winning voxel pixel of each (image, pixel)
+ *   (last writer = highest row, as pts2img); clear != 0 zero-fills S first; winner is scratch [B*ncam,H,W].
+ * df3d_gate_finish: att [nimg,H,W] = sigmoid(kg[18] + sum_taps inside*(kg[t] + kg[9+t]*gate[p+t] + S[t][p+t])).
+ * df3d_assemble_queries2: df3d_assemble_queries that samples the UNGATED image and multiplies by att at the
+ *   query pixel, and also writes the depth sine position embedding qpos [B*ncam, max_ne, C]
+ *   (position_encoding.py:107-120); att / qpos may be NULL. */
+int df3d_gate_scatter(const float *s9, const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask,
+                      int n, int batch, int ncam, int H, int W, int32_t *winner, float *S, int clear, void *stream);
+int df3d_gate_finish(const float *gate, const float *S, const float *kg, int nimg, int H, int W, float *att,
+                     void *stream);
+int df3d_assemble_queries2(const float *features, const float *point_inv, const int32_t *indices,
+                           const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
+                           const float *img_feats, const float *att, int n, int channels, int img_channels,
+                           int batch, int ncam, int H, int W, int max_ne, float *v_feat, float *v_i_feat,
+                           float *qgrid, float *qpts, float *qpos, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
