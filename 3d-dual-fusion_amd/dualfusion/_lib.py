@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libdf3d_hip.so")
 
 c_int = ctypes.c_int
+c_longlong = ctypes.c_longlong
 c_size_t = ctypes.c_size_t
 c_float = ctypes.c_float
 c_void_p = ctypes.c_void_p
@@ -67,6 +68,13 @@ SIGNATURES = {
     "df3d_assemble_queries2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,
+                                   c_void_p]),
+    "df3d_bigate_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int,
+                                c_void_p, c_void_p, c_void_p]),
+    "df3d_ms_deform_attn_fused": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_fusion_writeback": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p]),
 }

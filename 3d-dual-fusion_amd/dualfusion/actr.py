@@ -216,6 +216,9 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, q_pos=None,
                 q_feat=None, q_i_feat=None):
+        if self._fusable(src, reference_points, padding_mask, q_pos, q_feat, q_i_feat):
+            return self._forward_fused(src, reference_points, spatial_shapes, level_start_index, q_pos, q_feat,
+                                       q_i_feat)
         lq = q_feat if q_pos is None else q_feat + q_pos
         iq = q_i_feat if q_pos is None else q_i_feat + q_pos
         att = self.self_attn(lq, reference_points, src, spatial_shapes, level_start_index, padding_mask, i_query=iq)
@@ -225,6 +228,42 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         q_feat = self.norm3(q_feat + self.dropout5(
             self.linear4(self.dropout4(self.activation(self.linear3(q_feat))))))
         return self.fusion_layer(q_feat, q_i_feat)
+
+
+    # ---- inference fast path: the ~25 element-wise launches of one layer as 4 HIP kernels (csrc/actr.hip)
+    def _fusable(self, src, reference_points, padding_mask, q_pos, q_feat, q_i_feat):
+        return (not self.training and not torch.is_grad_enabled() and q_feat.is_cuda and q_pos is not None
+                and q_i_feat is not None and padding_mask is None and q_feat.dtype == torch.float32
+                and self.q_method == 'sum' and list(self.q_rep_place) == ['weight']
+                and self.attn_layer == 'BiGateSum1D_2' and self.activation is F.relu
+                and reference_points.shape[-1] == 2 and q_feat.shape[-1] % 4 == 0)
+
+    @staticmethod
+    def _linear_relu(lin, x):
+        return F.relu(lin(x), inplace=True)
+
+    def _forward_fused(self, src, reference_points, spatial_shapes, level_start_index, q_pos, q_feat, q_i_feat,
+                       value=None):
+        """Same arithmetic as forward(); `reference_points` [N,Q,L,2] carries the same (x, y) for every level when
+        the valid ratios are 1 (ACTR feeds unpadded maps), which is what the fused sampler assumes."""
+        from . import ops as _ops
+        sa = self.self_attn
+        q_feat, q_i_feat, q_pos = q_feat.contiguous(), q_i_feat.contiguous(), q_pos.contiguous()
+        if value is None:
+            value = sa.project_value(src)
+        ref_xy = reference_points[:, :, 0, :].contiguous()
+        A, Bw = _ops.actr_prep(q_feat, q_i_feat, q_pos)
+        out = _ops.ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, sa.sampling_offsets(A),
+                                        sa.attention_weights(Bw), sa.n_levels, sa.n_points)
+        att = sa.output_proj(out)
+        qi = _ops.add_layernorm(q_i_feat, att, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qi = _ops.add_layernorm(qi, self.linear2(self._linear_relu(self.linear1, qi)), self.norm2.weight,
+                                self.norm2.bias, self.norm2.eps)
+        q = _ops.add_layernorm(q_feat, self.linear4(self._linear_relu(self.linear3, q_feat)), self.norm3.weight,
+                               self.norm3.bias, self.norm3.eps)
+        g = self.fusion_layer
+        return _ops.bigate_sum(q, qi, g.b_conv1d.weight.view(-1), g.b_conv1d.bias, g.a_conv1d.weight.view(-1),
+                               g.a_conv1d.bias)
 
 
 def _get_clones(module, N):

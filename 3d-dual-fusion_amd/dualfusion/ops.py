@@ -269,6 +269,69 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+def ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, offsets, logits, n_levels, n_points,
+                         n_heads=None):
+    """Sampling with in-kernel softmax and location arithmetic (csrc/actr.hip).  value [N,S,M,D] may be a
+    channel slice of a wider buffer (pixel stride = value.stride(1)); ref_xy [N,Lq,2]; offsets [N,Lq,M*L*P*2] and
+    logits [N,Lq,M*L*P] are the raw outputs of the two query linears."""
+    lib = _lib.load()
+    for t, name in ((ref_xy, "ref_xy"), (offsets, "offsets"), (logits, "logits")):
+        _chk(t, torch.float32, name)
+    _chk(spatial_shapes, torch.int64, "spatial_shapes")
+    _chk(level_start_index, torch.int64, "level_start_index")
+    if not value.is_cuda or value.dtype != torch.float32:
+        raise _lib.Df3dError("value must be a float32 GPU tensor")
+    N, S, M, D = value.shape
+    if value.stride(3) != 1 or value.stride(2) != D or value.stride(0) != S * value.stride(1):
+        raise _lib.Df3dError("value must be [N,S,M,D] with contiguous heads and a uniform pixel stride")
+    Lq = ref_xy.shape[1]
+    out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
+    rc = lib.df3d_ms_deform_attn_fused(_ptr(value), int(value.stride(1)), _ptr(spatial_shapes),
+                                       _ptr(level_start_index), _ptr(ref_xy), _ptr(offsets), _ptr(logits), N, S, M, D,
+                                       Lq, int(n_levels), int(n_points), _ptr(out), _stream())
+    _lib.check(rc, "df3d_ms_deform_attn_fused")
+    return out
+
+
+def actr_prep(q, qi, pos):
+    """A = q + pos, Bw = (q + pos) + (qi + pos) in one pass."""
+    lib = _lib.load()
+    for t, name in ((q, "q"), (qi, "qi"), (pos, "pos")):
+        _chk(t, torch.float32, name)
+    A, Bw = torch.empty_like(q), torch.empty_like(q)
+    C = q.shape[-1]
+    rc = lib.df3d_actr_prep(_ptr(q), _ptr(qi), _ptr(pos), q.numel() // C, C, _ptr(A), _ptr(Bw), _stream())
+    _lib.check(rc, "df3d_actr_prep")
+    return A, Bw
+
+
+def add_layernorm(x, y, weight, bias, eps):
+    """LayerNorm(x + y) over the last dimension (y may be None)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    if y is not None:
+        _chk(y, torch.float32, "y")
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    rc = lib.df3d_add_layernorm(_ptr(x), _ptr(y), _ptr(weight), _ptr(bias), float(eps), x.numel() // C, C, _ptr(out),
+                                _stream())
+    _lib.check(rc, "df3d_add_layernorm")
+    return out
+
+
+def bigate_sum(q, qi, wb, bb, wa, ba):
+    """BiGateSum1D_2 on [.., C] rows: returns (q + qi*s1, qi + q*s2)."""
+    lib = _lib.load()
+    _chk(q, torch.float32, "q")
+    _chk(qi, torch.float32, "qi")
+    C = q.shape[-1]
+    qo, qio = torch.empty_like(q), torch.empty_like(qi)
+    rc = lib.df3d_bigate_sum(_ptr(q), _ptr(qi), _ptr(wb), _ptr(bb), _ptr(wa), _ptr(ba), q.numel() // C, C, _ptr(qo),
+                             _ptr(qio), _stream())
+    _lib.check(rc, "df3d_bigate_sum")
+    return qo, qio
+
+
 # ------------------------------------------------------------------------- point ops
 def furthest_point_sample(xyz, m):
     lib = _lib.load()

@@ -248,6 +248,29 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
                            int batch, int ncam, int H, int W, int max_ne, float *v_feat, float *v_i_feat,
                            float *qgrid, float *qpts, float *qpos, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused element-wise stages of the dual-query encoder layer (csrc/actr.hip); the reference runs them as
+ * separate torch ops (actr_transformer.py:399-426, ms_deform_attn.py:129-166, attentions.py:111-117).
+ * Rows = B*ncam*Q query rows of C channels, fp32, contiguous.
+ *   df3d_actr_prep:      A = q + pos, Bw = (q + pos) + (qi + pos)
+ *   df3d_add_layernorm:  out = LayerNorm(x + y) (y may be NULL), eps as nn.LayerNorm
+ *   df3d_bigate_sum:     BiGateSum1D_2: g = q + qi; q' = q + qi*sigmoid(g.wb+bb); qi' = qi + q*sigmoid(g.wa+ba)
+ *   df3d_ms_deform_attn_fused: df3d_ms_deform_attn_forward taking the RAW outputs of the sampling_offsets
+ *     and attention_weights linears plus the 2-D reference points [N,Lq,2]: softmax over L*P and
+ *     loc = ref + off / (W_l, H_l) happen in the kernel.  value_stride = floats between consecutive pixels
+ *     of `value` (M*D when contiguous; larger when several layers' value projections share one buffer).
+ * ---------------------------------------------------------------------------------- */
+int df3d_actr_prep(const float *q, const float *qi, const float *pos, long long rows, int C, float *A, float *Bw,
+                   void *stream);
+int df3d_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, float eps,
+                       long long rows, int C, float *out, void *stream);
+int df3d_bigate_sum(const float *q, const float *qi, const float *wb, const float *bb, const float *wa,
+                    const float *ba, long long rows, int C, float *q_out, float *qi_out, void *stream);
+int df3d_ms_deform_attn_fused(const float *value, long long value_stride, const int64_t *spatial_shapes,
+                              const int64_t *level_start_index, const float *ref_xy, const float *offsets,
+                              const float *logits, int N, int S, int M, int D, int Lq, int L, int P,
+                              float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

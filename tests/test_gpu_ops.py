@@ -232,6 +232,59 @@ def test_msda_vs_oracle_shapes(dev, D):
                                rtol=1e-3, atol=2e-5)
 
 
+@pytest.mark.parametrize("D,L,P,wide", [(16, 1, 4, False), (16, 1, 4, True), (8, 2, 3, False), (32, 3, 5, False),
+                                        (4, 1, 1, False)])
+def test_msda_fused_vs_oracle(dev, D, L, P, wide):
+    """Raw offsets/logits + 2-D reference points in, softmax and location arithmetic in the kernel
+    (ms_deform_attn.py:149-166); `wide` samples a channel slice of a 2x wider value buffer."""
+    from dualfusion import ops
+    N, M, Lq = 2, 8, 257
+    shp = [(17, 23), (9, 11), (5, 4)][:L]
+    S = sum(h * w for h, w in shp)
+    tag = "mf%d_%d_%d" % (D, L, P)
+    value = detgen.randn(tag + "v", (N, S, M, D))
+    ref = detgen.rand(tag + "r", (N, Lq, 2), -0.05, 1.05)
+    off = detgen.randn(tag + "o", (N, Lq, M, L, P, 2)) * 2.0
+    lg = detgen.randn(tag + "l", (N, Lq, M, L * P)) * 3.0
+    norm = np.array([[w, h] for h, w in shp], np.float32)
+    loc = (ref[:, :, None, None, None, :] + off / norm[None, None, None, :, None, :]).astype(np.float32)
+    aw = _softmax(lg).reshape(N, Lq, M, L, P)
+    want = orc.ms_deform_attn(value, shp, loc, aw)
+    shapes = torch.as_tensor(shp, dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    v = T(value, dev)
+    if wide:
+        buf = torch.full((N, S, 2, M, D), 7.0, device=dev)
+        buf[:, :, 1] = v
+        v = buf[:, :, 1]
+    y = ops.ms_deform_attn_fused(v, shapes, lsi, T(ref, dev), T(off.reshape(N, Lq, -1), dev), T(lg, dev), L, P)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("C,rows", [(128, 1000), (64, 77), (256, 3), (1024, 5), (16, 130)])
+def test_actr_rowwise_kernels(dev, C, rows):
+    """actr_prep / add_layernorm / bigate_sum against the torch expressions the reference layer runs
+    (actr_transformer.py:399-426, attentions.py:96-117), fp32 within 1e-5."""
+    from dualfusion import ops
+    g = torch.Generator(device="cpu").manual_seed(C * 1000 + rows)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    q, qi, pos = r(2, rows, C), r(2, rows, C), r(2, rows, C)
+    A, Bw = ops.actr_prep(q, qi, pos)
+    assert torch.equal(A, q + pos) and torch.equal(Bw, (q + pos) + (qi + pos))
+    w, b = r(C), r(C)
+    want = torch.nn.functional.layer_norm(q + qi, (C,), w, b, 1e-5)
+    torch.testing.assert_close(ops.add_layernorm(q, qi, w, b, 1e-5), want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ops.add_layernorm(q, None, w, b, 1e-5),
+                               torch.nn.functional.layer_norm(q, (C,), w, b, 1e-5), rtol=1e-5, atol=1e-5)
+    wb, wa, bb, ba = r(C) * 0.2, r(C) * 0.2, r(1), r(1)
+    fuse = q + qi
+    s1 = torch.sigmoid(fuse @ wb + bb)[..., None]
+    s2 = torch.sigmoid(fuse @ wa + ba)[..., None]
+    qo, qio = ops.bigate_sum(q, qi, wb, bb, wa, ba)
+    torch.testing.assert_close(qo, q + qi * s1, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(qio, qi + q * s2, rtol=1e-5, atol=1e-5)
+
+
 def test_msda_linearity_at_full_size(dev):
     """BASELINE config 2 size (6 cams, 150x267 map, Q=8000): linear in value and in the weights."""
     from dualfusion import ops
