@@ -122,6 +122,9 @@ struct MsdaFusedArgs {
   float *out;
   int N, S, M, D, Lq, L, P;
   long long vstride;     // floats between consecutive pixels of `value` (>= M*D)
+  const float *pscale;   // optional [N, S]: value(p) = pscale[p] * value[p] + ibias[n]
+  const float *ibias;    // optional [N, M*D] rows, `bstride` floats apart
+  long long bstride;
 };
 
 // msda_vec4_kernel + in-kernel softmax over the L*P logits of a (query, head) and
@@ -153,6 +156,8 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs a) {
   for (int o = LPG >> 1; o >= 1; o >>= 1) sm += __shfl_xor(sm, o, 64);
   const float inv = 1.f / sm;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 cb = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (a.ibias) cb = *(const f32x4 *)(a.ibias + (size_t)b * a.bstride + m * a.D + sub * 4);
   for (int lp0 = 0; lp0 < LP; lp0 += LPG) {
     float mxo = 0.f, myo = 0.f, mw = 0.f;
     int lp = lp0 + sub;
@@ -170,7 +175,9 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs a) {
       int H = (int)a.shapes[l * 2], W = (int)a.shapes[l * 2 + 1];
       float lx = rx + ox / (float)W;
       float ly = ry + oy / (float)H;
-      const float *vbase = a.value + ((size_t)b * a.S + (size_t)a.lstart[l]) * a.vstride + m * a.D + sub * 4;
+      const size_t pix0 = (size_t)b * a.S + (size_t)a.lstart[l];
+      const float *vbase = a.value + pix0 * a.vstride + m * a.D + sub * 4;
+      const float *sbase = a.pscale ? a.pscale + pix0 : nullptr;
       float h_im = ly * (float)H - 0.5f;
       float w_im = lx * (float)W - 0.5f;
       if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
@@ -180,17 +187,115 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs a) {
         float hh = 1.f - lh, hw = 1.f - lw;
         f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 v1 = z, v2 = z, v3 = z, v4 = z;
-        const size_t hs = (size_t)W * a.vstride;
-        if (h_low >= 0 && w_low >= 0) v1 = *(const f32x4 *)(vbase + h_low * hs + (size_t)w_low * a.vstride);
-        if (h_low >= 0 && w_high <= W - 1) v2 = *(const f32x4 *)(vbase + h_low * hs + (size_t)w_high * a.vstride);
-        if (h_high <= H - 1 && w_low >= 0) v3 = *(const f32x4 *)(vbase + h_high * hs + (size_t)w_low * a.vstride);
-        if (h_high <= H - 1 && w_high <= W - 1) v4 = *(const f32x4 *)(vbase + h_high * hs + (size_t)w_high * a.vstride);
         float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * w;
+        const bool in1 = h_low >= 0 && w_low >= 0, in2 = h_low >= 0 && w_high <= W - 1;
+        const bool in3 = h_high <= H - 1 && w_low >= 0, in4 = h_high <= H - 1 && w_high <= W - 1;
+        const size_t p1 = (size_t)h_low * W + w_low, p2 = (size_t)h_low * W + w_high;
+        const size_t p3 = (size_t)h_high * W + w_low, p4 = (size_t)h_high * W + w_high;
+        if (in1) v1 = *(const f32x4 *)(vbase + p1 * a.vstride);
+        if (in2) v2 = *(const f32x4 *)(vbase + p2 * a.vstride);
+        if (in3) v3 = *(const f32x4 *)(vbase + p3 * a.vstride);
+        if (in4) v4 = *(const f32x4 *)(vbase + p4 * a.vstride);
+        if (sbase) {
+          // value(p) = s_p * raw_p + c: the scale rides on the corner weight, the constant on the in-bounds weight sum
+          float ws = (in1 ? w1 : 0.f) + (in2 ? w2 : 0.f) + (in3 ? w3 : 0.f) + (in4 ? w4 : 0.f);
+          w1 *= in1 ? sbase[p1] : 0.f;
+          w2 *= in2 ? sbase[p2] : 0.f;
+          w3 *= in3 ? sbase[p3] : 0.f;
+          w4 *= in4 ? sbase[p4] : 0.f;
+          acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4 + ws * cb) * w;
+        } else if (a.ibias) {
+          float ws = (in1 ? w1 : 0.f) + (in2 ? w2 : 0.f) + (in3 ? w3 : 0.f) + (in4 ? w4 : 0.f);
+          acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4 + ws * cb) * w;
+        } else {
+          acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * w;
+        }
       }
     }
   }
   if (live) *(f32x4 *)(a.out + (size_t)qm * a.D + sub * 4) = acc;
+}
+
+// Per (image, channel) sums over pixels of a_p * u_cp and (a_p * u_cp)^2 for channel-first u [N, C(+), S]
+// (`cstride` floats between channels, `nstride` between images); a may be NULL (a_p = 1).
+// One block per (channel, image): the GroupNorm statistics of x = a*u + b follow in closed form.
+__global__ __launch_bounds__(256) void scaled_moments_kernel(const float *__restrict__ u, long long nstride,
+                                                             long long cstride, const float *__restrict__ a, int S,
+                                                             int C, double *__restrict__ out) {
+  const int c = blockIdx.x, n = blockIdx.y;
+  const float *row = u + (size_t)n * nstride + (size_t)c * cstride;
+  const float *ar = a ? a + (size_t)n * S : nullptr;
+  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0.0, d2 = 0.0;
+  int it = 0;
+  for (int p = threadIdx.x; p < S; p += 256) {
+    float v = row[p] * (ar ? ar[p] : 1.f);
+    s1 += v;
+    s2 += v * v;
+    if (++it == 32) {      // fold the fp32 partials into doubles every 32 terms
+      d1 += s1; d2 += s2; s1 = s2 = 0.f; it = 0;
+    }
+  }
+  d1 += s1; d2 += s2;
+  __shared__ double sh[2][256];
+  sh[0][threadIdx.x] = d1;
+  sh[1][threadIdx.x] = d2;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[((size_t)n * C + c) * 2] = sh[0][0];
+    out[((size_t)n * C + c) * 2 + 1] = sh[1][0];
+  }
+}
+
+// GroupNorm(x = a*u + b) followed by O linear outputs, folded per image:
+//   y_c = a*u_c*s_c + t_c, s_c = rstd_g*gamma_c, t_c = (b_c - mean_g)*rstd_g*gamma_c + beta_c
+//   out = a * (Wf u) + cf, Wf[o,c] = W[o,c]*s_c, cf[o] = sum_c W[o,c]*t_c + wb[o]
+// One block per image, 256 threads; C <= 256.
+__global__ __launch_bounds__(256) void gn_fold_kernel(const double *__restrict__ mom, const float *__restrict__ b,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                      float eps, int S, int C, int groups,
+                                                      const float *__restrict__ W, const float *__restrict__ wb, int O,
+                                                      float *__restrict__ Wf, float *__restrict__ cf) {
+  const int n = blockIdx.x, tid = threadIdx.x;
+  __shared__ double m1[256], m2[256];
+  __shared__ float sc[256], tc[256];
+  if (tid < C) {
+    double su = mom[((size_t)n * C + tid) * 2], sq = mom[((size_t)n * C + tid) * 2 + 1];
+    double bc = b ? (double)b[tid] : 0.0;
+    m1[tid] = su + S * bc;                                // sum_p x_c
+    m2[tid] = sq + 2.0 * bc * su + S * bc * bc;           // sum_p x_c^2
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  if (tid < C) {
+    int g = tid / cpg;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < cpg; ++k) { s += m1[g * cpg + k]; q += m2[g * cpg + k]; }
+    double cnt = (double)cpg * S;
+    double mean = s / cnt, var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float bc = b ? b[tid] : 0.f;
+    sc[tid] = rstd * gamma[tid];
+    tc[tid] = (bc - (float)mean) * rstd * gamma[tid] + beta[tid];
+  }
+  __syncthreads();
+  for (int o = tid; o < O; o += 256) {
+    float acc = wb ? wb[o] : 0.f;
+    for (int c = 0; c < C; ++c) {
+      float w = W[(size_t)o * C + c];
+      Wf[((size_t)n * O + o) * C + c] = w * sc[c];
+      acc += w * tc[c];
+    }
+    cf[(size_t)n * O + o] = acc;
+  }
 }
 
 }  // namespace df3d
@@ -234,16 +339,19 @@ extern "C" int df3d_bigate_sum(const float *q, const float *qi, const float *wb,
 
 extern "C" int df3d_ms_deform_attn_fused(const float *value, long long value_stride, const int64_t *spatial_shapes,
                                          const int64_t *level_start_index, const float *ref_xy,
-                                         const float *offsets, const float *logits, int N, int S, int M, int D, int Lq,
-                                         int L, int P, float *out, void *stream_) {
+                                         const float *offsets, const float *logits, const float *pixel_scale,
+                                         const float *image_bias, long long bias_stride, int N, int S, int M, int D,
+                                         int Lq, int L, int P, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(value && spatial_shapes && level_start_index && ref_xy && offsets && logits && out,
                  "ms_deform_attn_fused: null argument");
   DF3D_CHECK_ARG(D % 4 == 0 && value_stride >= (long long)M * D && value_stride % 4 == 0,
                  "ms_deform_attn_fused: D %% 4 != 0 or bad value stride");
   if (N == 0 || Lq == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(!pixel_scale || image_bias, "ms_deform_attn_fused: pixel_scale needs image_bias");
+  DF3D_CHECK_ARG(!image_bias || bias_stride % 4 == 0, "ms_deform_attn_fused: bias stride must be a multiple of 4");
   MsdaFusedArgs a = {value, spatial_shapes, level_start_index, ref_xy, offsets, logits, out, N, S, M, D, Lq, L, P,
-                     value_stride};
+                     value_stride, pixel_scale, image_bias, bias_stride};
   long long total;
   switch (D / 4) {
 #define DF3D_CASE(G)                                                                                \
@@ -261,6 +369,30 @@ extern "C" int df3d_ms_deform_attn_fused(const float *value, long long value_str
       set_error("ms_deform_attn_fused: head dim %d unsupported (need D/4 in {1,2,4,8,16})", D);
       return DF3D_EINVAL;
   }
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_scaled_moments(const float *u, long long image_stride, long long channel_stride, const float *a,
+                                   int N, int S, int C, double *moments, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(u && moments, "scaled_moments: null argument");
+  if (N == 0 || C == 0) return DF3D_OK;
+  hipLaunchKernelGGL(scaled_moments_kernel, dim3(C, N), dim3(256), 0, stream, u, image_stride, channel_stride, a, S, C,
+                     moments);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_groupnorm_fold(const double *moments, const float *b, const float *gamma, const float *beta,
+                                   float eps, int N, int S, int C, int groups, const float *W, const float *wb, int O,
+                                   float *Wf, float *cf, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(moments && gamma && beta && W && Wf && cf, "groupnorm_fold: null argument");
+  DF3D_CHECK_ARG(C <= 256 && groups > 0 && C % groups == 0, "groupnorm_fold: need C <= 256 and C %% groups == 0");
+  if (N == 0) return DF3D_OK;
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(N), dim3(256), 0, stream, moments, b, gamma, beta, eps, S, C, groups, W, wb,
+                     O, Wf, cf);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

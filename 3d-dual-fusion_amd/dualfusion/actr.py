@@ -240,7 +240,13 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
 
     @staticmethod
     def _linear_relu(lin, x):
-        return F.relu(lin(x), inplace=True)
+        """relu(x W^T + b) with the ReLU in the GEMM epilogue (hipBLASLt) instead of a second pass."""
+        return torch._addmm_activation(lin.bias, x.reshape(-1, x.shape[-1]), lin.weight.t()).view(
+            x.shape[:-1] + (lin.out_features,))
+
+    def fusable_config(self):
+        return (not self.training and self.q_method == 'sum' and list(self.q_rep_place) == ['weight']
+                and self.attn_layer == 'BiGateSum1D_2' and self.activation is F.relu and self.d_model % 4 == 0)
 
     def _forward_fused(self, src, reference_points, spatial_shapes, level_start_index, q_pos, q_feat, q_i_feat,
                        value=None):
@@ -249,12 +255,15 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         from . import ops as _ops
         sa = self.self_attn
         q_feat, q_i_feat, q_pos = q_feat.contiguous(), q_i_feat.contiguous(), q_pos.contiguous()
+        pixel_scale = image_bias = None
         if value is None:
             value = sa.project_value(src)
+        elif isinstance(value, tuple):
+            value, pixel_scale, image_bias = value
         ref_xy = reference_points[:, :, 0, :].contiguous()
         A, Bw = _ops.actr_prep(q_feat, q_i_feat, q_pos)
         out = _ops.ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, sa.sampling_offsets(A),
-                                        sa.attention_weights(Bw), sa.n_levels, sa.n_points)
+                                        sa.attention_weights(Bw), sa.n_levels, sa.n_points, pixel_scale, image_bias)
         att = sa.output_proj(out)
         qi = _ops.add_layernorm(q_i_feat, att, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         qi = _ops.add_layernorm(qi, self.linear2(self._linear_relu(self.linear1, qi)), self.norm2.weight,
@@ -288,15 +297,24 @@ class DeformableTransformerEncoder(nn.Module):
                                  feat_agg_method=lt_cfg.get('feat_agg_method', 'replace')), num_layers)
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, q_feat=None,
-                q_pos=None, q_reference_points=None, q_lidar_grid=None, q_i_feat=None):
+                q_pos=None, q_reference_points=None, q_lidar_grid=None, q_i_feat=None, layer_values=None):
+        """`layer_values` (inference fast path): per layer (value [N,S,M,D], pixel_scale, image_bias) already
+        projected by ACTR.forward_folded; `src` is then unused and valid_ratios are 1."""
         if q_reference_points is None:
             raise NotImplementedError("IACTR (image-grid queries) is not part of the 3D-DF configs")
-        reference_points = q_reference_points[:, :, None] * valid_ratios[:, None]
+        if layer_values is not None:
+            reference_points = q_reference_points[:, :, None]
+        else:
+            reference_points = q_reference_points[:, :, None] * valid_ratios[:, None]
         for idx, layer in enumerate(self.layers):
             if self.model_name == 'ACTRv2':
                 q_feat = self.lidar_attns[idx](q_lidar_grid, q_feat.permute(0, 2, 1))
-            q_feat, q_i_feat = layer(src, pos, reference_points, spatial_shapes, level_start_index, padding_mask,
-                                     q_pos=q_pos, q_feat=q_feat, q_i_feat=q_i_feat)
+            if layer_values is not None:
+                q_feat, q_i_feat = layer._forward_fused(None, reference_points, spatial_shapes, level_start_index,
+                                                        q_pos, q_feat, q_i_feat, value=layer_values[idx])
+            else:
+                q_feat, q_i_feat = layer(src, pos, reference_points, spatial_shapes, level_start_index, padding_mask,
+                                         q_pos=q_pos, q_feat=q_feat, q_i_feat=q_i_feat)
         return q_feat
 
 
@@ -427,6 +445,43 @@ class ACTR(nn.Module):
         srcs = [self.input_proj[0][1](src_conv)]
         return self.transformer(srcs, None, None, q_feat, q_pos, grid, q_lidar_grid=lidar_grid,
                                 q_i_feat_flatten=q_i_feat)
+
+    def can_fold(self):
+        """True when forward_folded() applies: inference, one image level, dual-query layers of the 3D-DF config."""
+        layers = self.transformer.encoder.layers
+        return (not self.training and not torch.is_grad_enabled() and self.feature_modal == 'hybrid'
+                and self.num_feature_levels == 1 and self.input_proj[0][1].num_channels <= 256
+                and all(isinstance(l, DeformableTransformerFusionEncoderLayer) and l.fusable_config()
+                        for l in layers))
+
+    def forward_folded(self, v_feat, grid, u, gate, hw, v_i_feat, lidar_grid, q_pos=None):
+        """Inference path that never materialises the normalised image map.  `u` [N, >=C, H*W] channel-first is
+        input_proj[0][0] WITHOUT its bias applied to the (un-gated) image, `gate` [N, H*W] the adapter's per-pixel
+        image gate (or None).  input_proj's GroupNorm and every layer's value_proj are folded into one per-image
+        GEMM (csrc/actr.hip gn_fold_kernel); the gate and the folded constant are applied inside the sampler."""
+        from . import ops as _ops
+        conv, gn = self.input_proj[0][0], self.input_proj[0][1]
+        layers = self.transformer.encoder.layers
+        C = gn.num_channels
+        N, _, S = u.shape
+        W = torch.cat([l.self_attn.value_proj.weight for l in layers], 0)
+        wb = torch.cat([l.self_attn.value_proj.bias for l in layers], 0)
+        Wf, cf = _ops.groupnorm_fold(u, gate, conv.bias, gn, W, wb)
+        value = torch.bmm(u[:, :C].transpose(1, 2), Wf.transpose(1, 2))             # [N, S, nlayers*C]
+        M = layers[0].self_attn.n_heads
+        layer_values = [(value[:, :, i * C:(i + 1) * C].unflatten(-1, (M, C // M)), gate, cf[:, i * C:(i + 1) * C])
+                        for i in range(len(layers))]
+        q_i_feat = self.project_image_queries(v_i_feat)
+        if q_pos is None:
+            if self.pos_encode_method == "image_coor":
+                q_pos = self.q_position_embedding(grid).transpose(1, 2)
+            else:
+                q_pos = self.q_position_embedding(lidar_grid[..., 0]).transpose(1, 2)
+        spatial_shapes = torch.as_tensor([hw], dtype=torch.long, device=u.device)
+        level_start_index = spatial_shapes.new_zeros((1,))
+        return self.transformer.encoder(None, spatial_shapes, level_start_index, None, q_feat=v_feat, q_pos=q_pos,
+                                        q_reference_points=grid, q_lidar_grid=lidar_grid, q_i_feat=q_i_feat,
+                                        layer_values=layer_values)
 
     def forward(self, v_feat, grid, i_feats, v_i_feat=None, lidar_grid=None):
         q_feat = v_feat

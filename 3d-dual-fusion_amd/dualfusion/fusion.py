@@ -218,14 +218,16 @@ class VoxelWithPointProjection(nn.Module):
         proj = {s: self._project(encoded_voxel_list[s], d_factor_list[s], inp) for s in sorted(need)}
         in_conv = self.pfat.input_proj[0][0]
         att = None
+        S_pix = H * W
+        imgf = img.flatten(2)                                                    # [NI, Cimg, H*W]
+        w_ip = in_conv.weight[:, :, 0, 0]
         if self.ifat_cfg is not None:
             # (a9) image-side gate, canvas-free: one pass over the image gives the ACTR input projection AND the
-            # gate's 1-channel summary; the voxel side is 9 scalars per visible voxel
+            # gate's 1-channel summary (a plain batched GEMM, no layout change); the voxel side is 9 scalars per
+            # visible voxel
             T, kg, w3, b3 = self.ifat.folded()
-            wcat = torch.cat([in_conv.weight[:, :, 0, 0], w3], 0)[:, :, None, None]
-            both = torch.nn.functional.conv2d(img, wcat)                        # [NI, C+1, H, W], no bias
-            src_conv = both[:, :-1]
-            gate = (both[:, -1] + b3).contiguous()
+            both = torch.matmul(torch.cat([w_ip, w3], 0), imgf)                  # [NI, C+1, H*W], no bias
+            gate = both[:, -1] + b3                                              # [NI, H*W]
             S = torch.empty((NI, 9, H, W), dtype=torch.float32, device=dev)
             winner = torch.empty((NI, H, W), dtype=torch.int32, device=dev)
             first = True
@@ -241,10 +243,15 @@ class VoxelWithPointProjection(nn.Module):
             att = torch.empty((NI, H, W), dtype=torch.float32, device=dev)
             rc = lib.df3d_gate_finish(_p(gate), _p(S), _p(kg), NI, H, W, _p(att), _ops._stream())
             _lib.check(rc, "df3d_gate_finish")
-            # input_proj(img * att) = att * (W img) + b   (att is a per-pixel scalar)
-            src_conv = src_conv * att[:, None] + in_conv.bias[None, :, None, None]
         else:
-            src_conv = in_conv(img)
+            both = torch.matmul(w_ip, imgf)
+        fold = self.pfat.can_fold()
+        if not fold:
+            # input_proj(img * att) = att * (W img) + b   (att is a per-pixel scalar)
+            src_conv = both[:, :w_ip.shape[0]]
+            if att is not None:
+                src_conv = src_conv * att.view(NI, 1, S_pix)
+            src_conv = (src_conv + in_conv.bias[None, :, None]).view(NI, -1, H, W)
         # (a8) per-camera query sets from the LAST scale (Appendix C item 4)
         grid, mask, pinv = proj[last]
         feats = x_last.features.contiguous()
@@ -263,7 +270,11 @@ class VoxelWithPointProjection(nn.Module):
                                         _p(qpos), _ops._stream())
         _lib.check(rc, "df3d_assemble_queries2")
         # (a10-a12) ACTR
-        enh = self.pfat.forward_projected(v_feat, qgrid, src_conv, v_i_feat, qpts, q_pos=qpos).contiguous()
+        if fold:
+            enh = self.pfat.forward_folded(v_feat, qgrid, both, None if att is None else att.view(NI, S_pix), (H, W),
+                                           v_i_feat, qpts, q_pos=qpos).contiguous()
+        else:
+            enh = self.pfat.forward_projected(v_feat, qgrid, src_conv, v_i_feat, qpts, q_pos=qpos).contiguous()
         # write-back, additive, camera order (Appendix C item 8)
         out = torch.empty_like(feats)
         rc = lib.df3d_fusion_writeback(_p(feats), _p(enh), _p(ind), _p(mask), _p(pos), n, C, ncam, max_ne, _p(out),

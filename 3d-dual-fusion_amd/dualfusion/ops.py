@@ -270,7 +270,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 
 def ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, offsets, logits, n_levels, n_points,
-                         n_heads=None):
+                         pixel_scale=None, image_bias=None):
     """Sampling with in-kernel softmax and location arithmetic (csrc/actr.hip).  value [N,S,M,D] may be a
     channel slice of a wider buffer (pixel stride = value.stride(1)); ref_xy [N,Lq,2]; offsets [N,Lq,M*L*P*2] and
     logits [N,Lq,M*L*P] are the raw outputs of the two query linears."""
@@ -285,12 +285,44 @@ def ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, offse
     if value.stride(3) != 1 or value.stride(2) != D or value.stride(0) != S * value.stride(1):
         raise _lib.Df3dError("value must be [N,S,M,D] with contiguous heads and a uniform pixel stride")
     Lq = ref_xy.shape[1]
+    bstride = 0
+    if pixel_scale is not None:
+        _chk(pixel_scale, torch.float32, "pixel_scale")
+    if image_bias is not None:
+        if image_bias.dtype != torch.float32 or image_bias.stride(-1) != 1 or image_bias.shape != (N, M * D):
+            raise _lib.Df3dError("image_bias must be float32 [N, M*D] with unit channel stride")
+        bstride = int(image_bias.stride(0))
     out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
     rc = lib.df3d_ms_deform_attn_fused(_ptr(value), int(value.stride(1)), _ptr(spatial_shapes),
-                                       _ptr(level_start_index), _ptr(ref_xy), _ptr(offsets), _ptr(logits), N, S, M, D,
+                                       _ptr(level_start_index), _ptr(ref_xy), _ptr(offsets), _ptr(logits),
+                                       _ptr(pixel_scale), _ptr(image_bias), bstride, N, S, M, D,
                                        Lq, int(n_levels), int(n_points), _ptr(out), _stream())
     _lib.check(rc, "df3d_ms_deform_attn_fused")
     return out
+
+
+def groupnorm_fold(u, gate, conv_bias, gn, weight, bias):
+    """u [N, C(+extra), S] channel-first = 1x1 projection without bias, gate [N, S] or None.  Returns
+    (Wf [N,O,C], cf [N,O]) with weight @ GroupNorm(gate*u + conv_bias) + bias = gate * (Wf u) + cf."""
+    lib = _lib.load()
+    if not u.is_cuda or u.dtype != torch.float32 or u.stride(2) != 1:
+        raise _lib.Df3dError("u must be a float32 GPU tensor [N, C, S] with unit pixel stride")
+    N, _, S = u.shape
+    C = gn.num_channels
+    O = weight.shape[0]
+    if gate is not None:
+        _chk(gate, torch.float32, "gate")
+    mom = torch.empty((N, C, 2), dtype=torch.float64, device=u.device)
+    rc = lib.df3d_scaled_moments(_ptr(u), int(u.stride(0)), int(u.stride(1)), _ptr(gate), N, S, C, _ptr(mom),
+                                 _stream())
+    _lib.check(rc, "df3d_scaled_moments")
+    Wf = torch.empty((N, O, C), dtype=torch.float32, device=u.device)
+    cf = torch.empty((N, O), dtype=torch.float32, device=u.device)
+    rc = lib.df3d_groupnorm_fold(_ptr(mom), _ptr(conv_bias), _ptr(gn.weight), _ptr(gn.bias), float(gn.eps), N, S, C,
+                                 int(gn.num_groups), _ptr(weight.contiguous()), _ptr(bias), O, _ptr(Wf), _ptr(cf),
+                                 _stream())
+    _lib.check(rc, "df3d_groupnorm_fold")
+    return Wf, cf
 
 
 def actr_prep(q, qi, pos):

@@ -259,6 +259,7 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
  *     and attention_weights linears plus the 2-D reference points [N,Lq,2]: softmax over L*P and
  *     loc = ref + off / (W_l, H_l) happen in the kernel.  value_stride = floats between consecutive pixels
  *     of `value` (M*D when contiguous; larger when several layers' value projections share one buffer).
+ *     Optional pixel_scale [N,S] / image_bias (rows bias_stride floats apart): value(p) = scale_p*value[p] + bias_n.
  * ---------------------------------------------------------------------------------- */
 int df3d_actr_prep(const float *q, const float *qi, const float *pos, long long rows, int C, float *A, float *Bw,
                    void *stream);
@@ -268,8 +269,23 @@ int df3d_bigate_sum(const float *q, const float *qi, const float *wb, const floa
                     const float *ba, long long rows, int C, float *q_out, float *qi_out, void *stream);
 int df3d_ms_deform_attn_fused(const float *value, long long value_stride, const int64_t *spatial_shapes,
                               const int64_t *level_start_index, const float *ref_xy, const float *offsets,
-                              const float *logits, int N, int S, int M, int D, int Lq, int L, int P,
+                              const float *logits, const float *pixel_scale, const float *image_bias,
+                              long long bias_stride, int N, int S, int M, int D, int Lq, int L, int P,
                               float *out, void *stream);
+
+/* GroupNorm of the gated input projection folded into the value projection (actr.py:139-149 input_proj[l] =
+ * Conv2d 1x1 + GroupNorm, ms_deform_attn.py:139 value_proj).  With x = a_p*u + b (u = W_ip*img without bias,
+ * a_p the per-pixel image gate, a = NULL -> 1):
+ *   df3d_scaled_moments: moments[n][c] = (sum_p a_p u_cp, sum_p (a_p u_cp)^2), u channel-first with the given
+ *     image / channel strides (floats);
+ *   df3d_groupnorm_fold: per image, Wf[n][o][c] = W[o][c]*rstd_g*gamma_c and cf[n][o] so that
+ *     W*GroupNorm(x)+wb = a_p * (Wf[n] u_p) + cf[n].  The sampler applies a_p and cf through
+ *     pixel_scale / image_bias, so neither x, GroupNorm(x) nor its transpose is ever materialised. */
+int df3d_scaled_moments(const float *u, long long image_stride, long long channel_stride, const float *a, int N,
+                        int S, int C, double *moments, void *stream);
+int df3d_groupnorm_fold(const double *moments, const float *b, const float *gamma, const float *beta, float eps,
+                        int N, int S, int C, int groups, const float *W, const float *wb, int O, float *Wf,
+                        float *cf, void *stream);
 
 #ifdef __cplusplus
 }

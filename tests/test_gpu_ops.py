@@ -285,6 +285,44 @@ def test_actr_rowwise_kernels(dev, C, rows):
     torch.testing.assert_close(qio, qi + q * s2, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("gated", [True, False])
+def test_groupnorm_fold(dev, gated):
+    """value_proj(GroupNorm(gate * u + b)) == gate * (Wf u) + cf  (actr.py:139-149 + ms_deform_attn.py:139),
+    and the sampler's pixel_scale / image_bias inputs reproduce sampling the materialised map."""
+    from dualfusion import ops
+    g = torch.Generator(device="cpu").manual_seed(5 + gated)
+    N, C, H, W, O = 3, 128, 13, 17, 256
+    S = H * W
+    u = (torch.randn(N, C + 1, S, generator=g) * 1.7 + 0.3).to(dev)
+    gate = torch.rand(N, S, generator=g).to(dev) if gated else None
+    gn = torch.nn.GroupNorm(32, C).to(dev)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+    b = torch.randn(C, generator=g).to(dev)
+    Wv = (torch.randn(O, C, generator=g) * 0.1).to(dev)
+    wb = torch.randn(O, generator=g).to(dev)
+    with torch.no_grad():
+        Wf, cf = ops.groupnorm_fold(u, gate, b, gn, Wv, wb)
+        x = u[:, :C] * (gate[:, None] if gated else 1.0) + b[None, :, None]
+        want = torch.einsum('oc,ncs->nso', Wv.double(), gn(x).double()) + wb.double()
+        raw = torch.bmm(u[:, :C].transpose(1, 2), Wf.transpose(1, 2))
+        got = raw * (gate[..., None] if gated else 1.0) + cf[:, None]
+    torch.testing.assert_close(got, want.float(), rtol=1e-4, atol=1e-4)
+    # sampler with the scale / constant applied on the fly == sampler on the materialised value (layer 1 slice)
+    M, D, Lq, L, P = 8, 16, 301, 1, 4
+    shapes = torch.as_tensor([(H, W)], dtype=torch.long, device=dev)
+    lsi = shapes.new_zeros((1,))
+    ref = (torch.rand(N, Lq, 2, generator=g) * 1.1 - 0.05).to(dev)
+    off = (torch.randn(N, Lq, M * L * P * 2, generator=g) * 2).to(dev)
+    lg = torch.randn(N, Lq, M * L * P, generator=g).to(dev)
+    v_mat = got[:, :, 128:].contiguous().view(N, S, M, D)
+    y0 = ops.ms_deform_attn_fused(v_mat, shapes, lsi, ref, off, lg, L, P)
+    y1 = ops.ms_deform_attn_fused(raw[:, :, 128:].unflatten(-1, (M, D)), shapes, lsi, ref, off, lg, L, P,
+                                  gate, cf[:, 128:])
+    torch.testing.assert_close(y1, y0, rtol=1e-4, atol=1e-5)
+
+
 def test_msda_linearity_at_full_size(dev):
     """BASELINE config 2 size (6 cams, 150x267 map, Q=8000): linear in value and in the weights."""
     from dualfusion import ops
