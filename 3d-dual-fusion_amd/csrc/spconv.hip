@@ -675,6 +675,19 @@ static hipEvent_t timing_event() {
   return e;
 }
 
+int timing_rec_begin(int cin, int cout, int kvol, int n_out, hipStream_t stream) {
+  if (!g_timing_on) return -1;
+  TimingRec r = {timing_event(), timing_event(), cin, cout, kvol, n_out};
+  if (!r.e0 || !r.e1) return -1;
+  (void)hipEventRecord(r.e0, stream);
+  g_timing.push_back(r);
+  return (int)g_timing.size() - 1;
+}
+
+void timing_rec_end(int rec, hipStream_t stream) {
+  if (rec >= 0 && rec < (int)g_timing.size()) (void)hipEventRecord(g_timing[rec].e1, stream);
+}
+
 static int pair_ntiles(int n_out, int cin, int cout) {
   // measured on MI355X (tools/conv_probe.py): the pair kernel wins for COUT=128 (244 vs 306 us at conv4),
   // the output-stationary kernel for COUT=64 (170 vs 218 us at conv3: items are only 32 MFMAs long there)
@@ -695,8 +708,10 @@ using namespace df3d;
 
 extern "C" int df3d_conv_tile_count(int n_out, int cin, int cout, int kvol) {
   (void)kvol;
-  static const bool use_v2 = getenv("DF3D_SPCONV_V1") == nullptr;
-  return use_v2 ? pair_ntiles(n_out, cin, cout) : 0;
+  // shapes served by the one-workgroup-per-CU kernels (spconv_pair_kernel / spconv_split_kernel)
+  bool ok = (cout == 128 && (cin == 128 || cin == 64)) || (cout == 64 && (cin == 64 || cin == 32));
+  if (!ok || n_out <= 0) return 0;
+  return pair_ntiles(n_out, 128, 128);
 }
 
 extern "C" size_t df3d_conv_tiles_workspace_bytes(int n_out) {
@@ -774,12 +789,7 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
   a.cin = cin;
   a.cout = cout;
   a.relu = relu;
-  TimingRec trec;
-  const bool timed = g_timing_on;
-  if (timed) {
-    trec = {timing_event(), timing_event(), cin, cout, kvol, n_out};
-    if (trec.e0 && trec.e1) (void)hipEventRecord(trec.e0, stream);
-  }
+  const int trec = timing_rec_begin(cin, cout, kvol, n_out, stream);
   bool done = false;
   // compute-bound shapes: pair-compacted kernel (DF3D_SPCONV_V1=1 forces the output-stationary kernel)
   static const bool use_v2 = getenv("DF3D_SPCONV_V1") == nullptr;
@@ -799,10 +809,7 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
     size_t tot = (size_t)n_out * cout;
     hipLaunchKernelGGL(spconv_generic_kernel, dim3(cdiv((long long)tot, 256)), dim3(256), 0, stream, a);
   }
-  if (timed && trec.e0 && trec.e1) {
-    (void)hipEventRecord(trec.e1, stream);
-    g_timing.push_back(trec);
-  }
+  timing_rec_end(trec, stream);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -1,0 +1,694 @@
+// Sparse convolution on the bf16 matrix cores with fp32-grade accuracy ("split" path) for gfx950.
+//
+// fp32 MFMA on gfx950 runs at 1/16 of the bf16 rate (157 vs 2500 TFLOP/s).  An fp32 value x is split
+// exactly once, where it is PRODUCED, into two bf16 numbers
+//     hi = bf16(x),  lo = bf16(x - hi)            (x = hi + lo up to 2^-17 |x|)
+// and the contraction is evaluated as  A_hi*W_hi + A_lo*W_hi + A_hi*W_lo  with v_mfma_f32_16x16x32_bf16
+// (bf16 x bf16 products are exact in fp32; accumulation is fp32).  The dropped lo*lo term and the split
+// residuals are <= 2^-16 relative per product, i.e. the result carries ~1e-5 relative error against the exact
+// fp32 contraction -- two orders inside the 1e-3 parity bar, the same size as fp32 summation-order noise --
+// at 3/16 of the fp32-MFMA time.  That moves the C >= 64 layers from the MFMA roof onto the gather (L1/L2/HBM)
+// roof, which is where BASELINE.json's north_star measures them.
+//
+// Data formats (both produced by kernels in this file or by the conv epilogue):
+//   split rows   [n][C/8][ hi 8 x bf16 | lo 8 x bf16 ]   32 B per 8 channels, same bytes as fp32
+//   packed W     [K][wave 4][kb][ct][hi|lo][lane 64][8 x bf16]: exactly the B operand of every lane, so the
+//                per-offset weight fetch is 16 B per lane, coalesced
+//
+// Kernel structure = spconv_pair_kernel (spconv.hip): one workgroup per CU, rulebook pairs of a row tile
+// compacted per kernel offset, 16-pair MFMA chunks, per-wave column slice of W in registers, LDS
+// accumulators, fused epilogue.  Differences: 16x16x32 bf16 MFMAs (3 per fp32 product block), gathers run
+// 3 items ahead (items are ~5x shorter than in the fp32 kernel), weights rotate between two register sets by
+// name, the item list is built by 32 lanes instead of one, and the epilogue can emit the split rows of its
+// output for the next convolution.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace df3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+int timing_rec_begin(int cin, int cout, int kvol, int n_out, hipStream_t stream);   // spconv.hip
+void timing_rec_end(int rec, hipStream_t stream);
+
+__device__ __forceinline__ unsigned bf16_bits(float x) {   // round to nearest even; finite inputs
+  unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split2(float x, unsigned &hi, unsigned &lo) {
+  hi = bf16_bits(x);
+  lo = bf16_bits(x - __uint_as_float(hi << 16));
+}
+
+// ---- fp32 rows -> split rows ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ x, size_t nblk,
+                                                         u32x4 *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblk) return;
+  f32x4 a = ((const f32x4 *)x)[2 * i], b = ((const f32x4 *)x)[2 * i + 1];
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    split2(a[e], h[e], l[e]);
+    split2(b[e], h[4 + e], l[4 + e]);
+  }
+  u32x4 ho, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ho[e] = h[2 * e] | (h[2 * e + 1] << 16);
+    lo[e] = l[2 * e] | (l[2 * e + 1] << 16);
+  }
+  out[2 * i] = ho;
+  out[2 * i + 1] = lo;
+}
+
+// ---- W[K][CIN][COUT] fp32 -> packed B operands -----------------------------------------------------------
+// layout 0 (spconv_split_kernel, pair-compacted):   [k][wave 4][kb][ct][hi|lo][lane], lane (n,g) -> column
+//          wave*COUT/4 + CT*n + ct, channels g*CIN/4 + kb*8 + e
+// layout 1 (spconv_os_split_kernel, output-stationary): [k][kb][ct][hi|lo][lane], lane (n,g) -> column ct*16 + n,
+//          channels kb*32 + g*8 + e
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, int K, int cin, int cout,
+                                                           int layout, u32x4 *__restrict__ out) {
+  const int KB = cin / 32;
+  size_t total = (size_t)K * cin * cout / 4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lane = (int)(i & 63);
+  size_t r = i >> 6;
+  int part = (int)(r & 1); r >>= 1;
+  int n = lane & 15, g = lane >> 4;
+  int k, kb, col, ch0;
+  if (layout == 0) {
+    const int CS = cout / 4, CT = CS / 16;
+    int ct = (int)(r % CT); r /= CT;
+    kb = (int)(r % KB); r /= KB;
+    int wave = (int)(r & 3);
+    k = (int)(r >> 2);
+    col = wave * CS + CT * n + ct;
+    ch0 = g * (cin / 4) + kb * 8;
+  } else {
+    const int CT = cout / 16;
+    int ct = (int)(r % CT); r /= CT;
+    kb = (int)(r % KB);
+    k = (int)(r / KB);
+    col = ct * 16 + n;
+    ch0 = kb * 32 + g * 8;
+  }
+  unsigned v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int ch = ch0 + e;
+    unsigned hi, lo;
+    split2(w[((size_t)k * cin + ch) * cout + col], hi, lo);
+    v[e] = part ? lo : hi;
+  }
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = v[2 * e] | (v[2 * e + 1] << 16);
+  out[i] = o;
+}
+
+struct SplitConvArgs {
+  const u32x4 *feat;     // split rows of the input
+  const u32x4 *w;        // packed weights
+  const int32_t *nbr;
+  const float *bias, *scale, *shift, *residual;
+  float *out;
+  u32x4 *out_split;      // optional split rows of the output
+  int n_in, n_out, K, relu;
+};
+
+#define DF3D_MFMA_BF16(A, B, C) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 1) void spconv_split_kernel(SplitConvArgs a, int TM,
+                                                               const int32_t *__restrict__ tile_rows) {
+  constexpr int KB = CIN / 32;       // 32-deep MFMA k-blocks; lane group g owns channels [g*CIN/4, (g+1)*CIN/4)
+  constexpr int CS = COUT / 4;       // output columns per wave
+  constexpr int CT = CS / 16;        // 16-wide column tiles per wave (1 or 2)
+  constexpr int NCH = 2 / CT;        // chunks per item -> always 2 independent accumulators
+  constexpr int RQ = CIN / 4;        // u32x4 per split row
+  static_assert(CT == 1 || CT == 2, "COUT must be 64 or 128");
+  static_assert(CIN % 32 == 0, "CIN must be a multiple of 32");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *accL = (float *)smem;                                  // [4][TM+1][CS]; row TM = trash row
+  int *idxL = (int *)(smem + (size_t)4 * (TM + 1) * CS * 4);    // [K][TM]: nbr tile, compacted in place to input rows
+  unsigned short *listL = (unsigned short *)(idxL + a.K * TM);  // [K][TM]: matching output rows (tile-local)
+  __shared__ int cntL[DF3D_MAX_KVOL];
+  __shared__ int segL[DF3D_MAX_KVOL + 1];                       // first item of each ACTIVE offset; [nact] = T
+  __shared__ int actL[DF3D_MAX_KVOL + 1];                       // active offsets in order
+  __shared__ int nactL;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int cs0 = wave * CS;
+  const int K = a.K;
+  const int range0 = tile_rows ? tile_rows[blockIdx.x] : blockIdx.x * TM;
+  const int range1 = tile_rows ? tile_rows[blockIdx.x + 1] : min(range0 + TM, a.n_out);
+  for (int row0 = range0; row0 < range1; row0 += TM) {
+    const int row_end = min(row0 + TM, range1);
+    __syncthreads();
+
+    for (int e = tid; e < K * TM; e += 256) {
+      int k = e / TM, r = e - k * TM;
+      int row = row0 + r;
+      idxL[e] = (row < row_end) ? a.nbr[(size_t)k * a.n_out + row] : -1;
+    }
+    float *myacc = accL + (size_t)wave * (TM + 1) * CS;
+    for (int e = lane; e < TM * CS / 4; e += 64) ((f32x4 *)myacc)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    // ---- compact the valid pairs of every offset (offsets striped over the waves) ----
+    for (int k = wave; k < K; k += 4) {
+      int cnt = 0;
+      for (int r0 = 0; r0 < TM; r0 += 64) {
+        int r = r0 + lane;
+        int v = r < TM ? idxL[k * TM + r] : -1;
+        bool valid = v >= 0;
+        unsigned long long m = __ballot(valid);
+        int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+          idxL[k * TM + pos] = v;
+          listL[k * TM + pos] = (unsigned short)r;
+        }
+        cnt += __popcll(m);
+      }
+      if (lane == 0) cntL[k] = cnt;
+    }
+    __syncthreads();
+
+    // ---- item list: one entry per (offset, chunk group): k | grp << 8 | cnt << 16, built by one lane per offset ----
+    int *itemL = (int *)(listL + (size_t)K * TM + (((size_t)K * TM) & 1));     // 4-byte aligned, [T+3]
+    auto ngroups = [&](int cnt) { return (((cnt + 15) >> 4) + NCH - 1) / NCH; };
+    if (tid < 32) {
+      int cnt = tid < K ? cntL[tid] : 0;
+      int ng = ngroups(cnt);
+      int start = 0, rank = 0, tot = 0, nact = 0;
+      for (int j = 0; j < K; ++j) {                // K <= 32: every lane scans the counts once
+        int c = cntL[j];
+        int gj = ngroups(c);
+        if (j < tid) { start += gj; rank += gj > 0; }
+        tot += gj;
+        nact += gj > 0;
+      }
+      if (tid < K && ng > 0) {
+        segL[rank] = start;
+        actL[rank] = tid;
+        for (int gq = 0; gq < ng; ++gq) itemL[start + gq] = tid | (gq << 8) | (cnt << 16);
+      }
+      if (tid == 0) {
+        segL[nact] = tot;
+        actL[nact] = 0;
+        nactL = nact;
+      }
+    }
+    __syncthreads();
+    const int nact = nactL;
+    const int T = segL[nact];
+    if (tid < 3 && T > 0) itemL[T + tid] = itemL[T - 1];   // sentinels: the look-ahead re-reads the last item
+    __syncthreads();
+
+    u32x4 bc[KB][CT][2], bn[KB][CT][2];
+    auto load_b = [&](int k, u32x4 (&dst)[KB][CT][2]) {
+      const u32x4 *wk = a.w + ((size_t)(k * 4 + wave) * (KB * CT * 2)) * 64 + lane;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) dst[kb][ct][p] = wk[((kb * CT + ct) * 2 + p) * 64];
+    };
+    auto read_idx = [&](int item, int (&idx)[NCH]) {
+      int k = item & 0xff, grp = (item >> 8) & 0xff, cnt = item >> 16;
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        int p = (grp * NCH + h) * 16 + n;
+        p = p < cnt ? p : cnt - 1;
+        idx[h] = idxL[k * TM + p];
+      }
+    };
+    auto read_rows = [&](int item, int (&rl)[NCH][4]) {
+      int k = item & 0xff, grp = (item >> 8) & 0xff, cnt = item >> 16;
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int p = (grp * NCH + h) * 16 + 4 * g + r;
+          int pp = p < cnt ? p : cnt - 1;
+          int t = listL[k * TM + pp];
+          rl[h][r] = p < cnt ? t : TM;              // invalid slots -> trash row
+        }
+    };
+    // A fragments of items t .. t+3 (the gathers run 3 items ahead): [slot][chunk][k-block][hi|lo]
+    u32x4 s0[NCH][KB][2], s1[NCH][KB][2], s2[NCH][KB][2], s3[NCH][KB][2];
+    auto load_a = [&](const int (&idx)[NCH], u32x4 (&dst)[NCH][KB][2]) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        const u32x4 *src = a.feat + (size_t)idx[h] * RQ + (size_t)g * KB * 2;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          dst[h][kb][0] = src[kb * 2];
+          dst[h][kb][1] = src[kb * 2 + 1];
+        }
+      }
+    };
+    f32x4 acc[NCH][CT], aprev[NCH][CT];
+    float2 fo2[NCH][4];
+    float fo1[NCH][4];
+    auto flush_read = [&](const int (&rl)[NCH][4]) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (CT == 2) fo2[h][r] = *(const float2 *)(myacc + (size_t)rl[h][r] * CS + 2 * n);
+          else fo1[h][r] = myacc[(size_t)rl[h][r] * CS + n];
+        }
+    };
+    auto flush_write = [&](const int (&rl)[NCH][4], f32x4 (&v)[NCH][CT]) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (CT == 2) {
+            float2 o = fo2[h][r];
+            o.x += v[h][0][r];
+            o.y += v[h][CT - 1][r];
+            *(float2 *)(myacc + (size_t)rl[h][r] * CS + 2 * n) = o;
+          } else {
+            myacc[(size_t)rl[h][r] * CS + n] = fo1[h][r] + v[h][0][r];
+          }
+        }
+    };
+
+    int idxn[NCH], rl_cur[NCH][4], rl_prev[NCH][4];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) aprev[h][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rl_prev[h][r] = TM;       // first flush goes to the trash row
+    }
+    if (T > 0) {
+      load_b(actL[0], bn);
+      read_idx(itemL[0], idxn);
+      load_a(idxn, s0);
+      read_idx(itemL[1], idxn);
+      load_a(idxn, s1);
+      read_idx(itemL[2], idxn);
+      load_a(idxn, s2);
+    }
+    // One item = NCH chunks of 16 pairs = 3*KB*NCH*CT MFMAs.  The items of the whole tile form ONE software
+    // pipeline (no bubble at offset boundaries), unrolled four times so that the A ring slots are fixed
+    // registers.  When the offset changes, the prefetched weights move bn -> bc (once per ~T/K items) and the
+    // fetch of the following offset's weights starts.
+    int kcur = -1, ai = -1;
+    auto step = [&](int t, u32x4 (&cur)[NCH][KB][2], u32x4 (&tgt)[NCH][KB][2]) {
+      const int it0 = __builtin_amdgcn_readfirstlane(itemL[t]);
+      const int it3 = __builtin_amdgcn_readfirstlane(itemL[t + 3]);
+      if ((it0 & 0xff) != kcur) {
+        kcur = it0 & 0xff;
+        ++ai;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bc[kb][ct][p] = bn[kb][ct][p];
+        if (ai + 1 < nact) load_b(actL[ai + 1], bn);
+      }
+      read_idx(it3, idxn);
+      read_rows(it0, rl_cur);
+      flush_read(rl_prev);
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[h][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)          // lo*hi, hi*lo first (small), hi*hi last
+#pragma unroll
+          for (int h = 0; h < NCH; ++h)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+              acc[h][ct] = DF3D_MFMA_BF16(cur[h][kb][pa], bc[kb][ct][pb], acc[h][ct]);
+            }
+      load_a(idxn, tgt);                                  // gathers of item t+3 (into the slot item t-1 freed)
+      flush_write(rl_prev, aprev);                        // item t-1's LDS update
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) aprev[h][ct] = acc[h][ct];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rl_prev[h][r] = rl_cur[h][r];
+      }
+    };
+    for (int t = 0; t < T; t += 4) {
+      step(t, s0, s3);
+      if (t + 1 < T) step(t + 1, s1, s0);
+      if (t + 2 < T) step(t + 2, s2, s1);
+      if (t + 3 < T) step(t + 3, s3, s2);
+    }
+    flush_read(rl_prev);
+    flush_write(rl_prev, aprev);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- epilogue: this wave's CS columns of every row of the tile.  LDS column c of the wave's slice holds
+    //      output column cs0 + c (the packed weights put tile ct of lane n at column CT*n + ct) ----
+    constexpr int LPR = CS / 4;          // lanes per row (float4 each)
+    constexpr int RPI = 64 / LPR;        // rows per iteration
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
+    f32x4 bi = (f32x4){0.f, 0.f, 0.f, 0.f}, sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = bi;
+    if (a.bias) bi = *(const f32x4 *)(a.bias + cs0 + lc);
+    if (a.scale) sc = *(const f32x4 *)(a.scale + cs0 + lc);
+    if (a.shift) sh = *(const f32x4 *)(a.shift + cs0 + lc);
+    for (int r0 = 0; r0 < TM; r0 += RPI) {
+      int rl = r0 + lr;
+      int row = row0 + rl;
+      if (rl < TM && row < row_end) {
+        f32x4 v = *(const f32x4 *)(myacc + (size_t)rl * CS + lc);
+        v = (v + bi) * sc + sh;
+        size_t o = (size_t)row * COUT + cs0 + lc;
+        if (a.residual) v += *(const f32x4 *)(a.residual + o);
+        if (a.relu) {
+          v[0] = fmaxf(v[0], 0.f);
+          v[1] = fmaxf(v[1], 0.f);
+          v[2] = fmaxf(v[2], 0.f);
+          v[3] = fmaxf(v[3], 0.f);
+        }
+        *(f32x4 *)(a.out + o) = v;
+        if (a.out_split) {
+          unsigned h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2(v[e], h[e], l[e]);
+          // 8-channel block = [hi 16 B | lo 16 B]; this lane owns 4 of the 8 channels
+          char *blk = (char *)a.out_split + (o >> 3) * 32 + ((o >> 2) & 1) * 8;
+          *(u32x2 *)blk = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+          *(u32x2 *)(blk + 16) = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+        }
+      }
+    }
+  }  // passes over the row range
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Output-stationary variant: a wave owns 16*RT output rows and all COUT columns, accumulators in registers,
+// the packed B operands of one (offset, 32-channel block) step staged through LDS (double buffered, one
+// barrier per step), A fragments (32 B of split row per lane) straight from L2/HBM one step ahead.  MFMAs are
+// also issued for rows without a neighbour at an offset (zero operands) -- at 3/16 of the fp32 cost that waste
+// is cheaper than the pair compaction -- and several workgroups per CU hide the gather latency.
+template <int CIN, int COUT, int RT, int NW>
+__global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs a) {
+  constexpr int KB = CIN / 32, CT = COUT / 16, TM = 16 * RT * NW, WROWS = 16 * RT, RQ = CIN / 4;
+  constexpr int WQ = CT * 2 * 64;                 // u32x4 per W step tile
+  constexpr int NT = NW * 64;
+  constexpr int WPT = (WQ + NT - 1) / NT;
+  __shared__ u32x4 Wl[2][WQ];
+  __shared__ int nbrL[DF3D_MAX_KVOL][TM];
+  __shared__ unsigned wg_mask;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  int nt = gridDim.x, bid = blockIdx.x, tile = bid;
+  if ((nt & 7) == 0) tile = (bid & 7) * (nt >> 3) + (bid >> 3);     // consecutive tiles stay on one XCD / L2
+  const int row0 = tile * TM;
+
+  if (tid == 0) wg_mask = 0u;
+  for (int e = tid; e < a.K * TM; e += NT) {
+    int k = e / TM, r = e - k * TM;
+    int row = row0 + r;
+    nbrL[k][r] = (row < a.n_out) ? a.nbr[(size_t)k * a.n_out + row] : -1;
+  }
+  __syncthreads();
+  unsigned wmask = 0u;
+  for (int k = 0; k < a.K; ++k) {
+    int r = lane;
+    int v = (r < WROWS) ? nbrL[k][wave * WROWS + r] : -1;
+    if (__ballot(v >= 0) != 0ull) wmask |= (1u << k);
+  }
+  if (lane == 0 && wmask) atomicOr(&wg_mask, wmask);
+  __syncthreads();
+  const unsigned gmask = wg_mask;
+  const int steps = __popc(gmask) * KB;
+
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto kth_active = [&](int ai) -> int {
+    unsigned m = gmask;
+    for (int i = 0; i < ai; ++i) m &= m - 1;
+    return __ffs((int)m) - 1;
+  };
+  u32x4 wreg[WPT];
+  auto load_w = [&](int k, int kb) {
+    const u32x4 *src = a.w + (size_t)(k * KB + kb) * WQ;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      int e = tid + NT * i;
+      if (WQ % NT == 0 || e < WQ) wreg[i] = src[e];
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      int e = tid + NT * i;
+      if (WQ % NT == 0 || e < WQ) Wl[buf][e] = wreg[i];
+    }
+  };
+  u32x4 anext[RT][2], acur[RT][2];
+  auto load_a = [&](int k, int kb) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      int idx = nbrL[k][wave * WROWS + rt * 16 + n];
+      u32x4 h = (u32x4){0u, 0u, 0u, 0u}, l = h;
+      if (idx >= 0) {
+        const u32x4 *p = a.feat + (size_t)idx * RQ + (kb * 4 + g) * 2;
+        h = p[0];
+        l = p[1];
+      }
+      anext[rt][0] = h;
+      anext[rt][1] = l;
+    }
+  };
+
+  int k_next = 0;
+  if (steps > 0) {
+    k_next = kth_active(0);
+    load_w(k_next, 0);
+    store_w(0);
+    if ((wmask >> k_next) & 1u) load_a(k_next, 0);
+  }
+  for (int s = 0; s < steps; ++s) {
+    const int k_cur = k_next;
+    const bool wave_on = (wmask >> k_cur) & 1u;
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      acur[rt][0] = anext[rt][0];
+      acur[rt][1] = anext[rt][1];
+    }
+    const bool more = s + 1 < steps;
+    if (more) {
+      int s1 = s + 1;
+      int ai = s1 / KB;
+      int kb_n = s1 - ai * KB;
+      k_next = (kb_n == 0) ? kth_active(ai) : k_cur;
+      load_w(k_next, kb_n);
+      if ((wmask >> k_next) & 1u) load_a(k_next, kb_n);
+    }
+    if (wave_on) {
+      const u32x4 *wb = Wl[s & 1];
+#pragma unroll
+      for (int c2 = 0; c2 < CT; c2 += 2) {
+        u32x4 bh0 = wb[(c2 * 2 + 0) * 64 + lane], bl0 = wb[(c2 * 2 + 1) * 64 + lane];
+        u32x4 bh1 = wb[(c2 * 2 + 2) * 64 + lane], bl1 = wb[(c2 * 2 + 3) * 64 + lane];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc[rt][c2] = DF3D_MFMA_BF16(acur[rt][1], bh0, acc[rt][c2]);
+          acc[rt][c2 + 1] = DF3D_MFMA_BF16(acur[rt][1], bh1, acc[rt][c2 + 1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc[rt][c2] = DF3D_MFMA_BF16(acur[rt][0], bl0, acc[rt][c2]);
+          acc[rt][c2 + 1] = DF3D_MFMA_BF16(acur[rt][0], bl1, acc[rt][c2 + 1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc[rt][c2] = DF3D_MFMA_BF16(acur[rt][0], bh0, acc[rt][c2]);
+          acc[rt][c2 + 1] = DF3D_MFMA_BF16(acur[rt][0], bh1, acc[rt][c2 + 1]);
+        }
+      }
+    }
+    if (more) store_w((s + 1) & 1);
+  }
+
+  // ---- epilogue: bias, folded BN, residual, ReLU; optional split rows of the result ----
+  unsigned short *osplit = (unsigned short *)a.out_split;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    int col = ct * 16 + n;
+    float bi = a.bias ? a.bias[col] : 0.f;
+    float sc = a.scale ? a.scale[col] : 1.f;
+    float sh = a.shift ? a.shift[col] : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
+        if (row < a.n_out) {
+          float v = (acc[rt][ct][r] + bi) * sc + sh;
+          if (a.residual) v += a.residual[(size_t)row * COUT + col];
+          if (a.relu) v = fmaxf(v, 0.f);
+          a.out[(size_t)row * COUT + col] = v;
+          if (osplit) {
+            unsigned hi, lo;
+            split2(v, hi, lo);
+            size_t blk = ((size_t)row * COUT + col) >> 3;          // 8-channel block: 8 hi then 8 lo (u16)
+            osplit[blk * 16 + (col & 7)] = (unsigned short)hi;
+            osplit[blk * 16 + 8 + (col & 7)] = (unsigned short)lo;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int CIN, int COUT>
+static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
+  // enough workgroups to cover the 256 CUs a few times; two row tiles per wave when the layer is large
+  if (a.n_out >= 96 * 1024) {
+    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 2, 4>), dim3(cdiv(a.n_out, 128)), dim3(256), 0, stream, a);
+  } else if (a.n_out >= 48 * 1024) {
+    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 4>), dim3(cdiv(a.n_out, 64)), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 2>), dim3(cdiv(a.n_out, 32)), dim3(128), 0, stream, a);
+  }
+  return DF3D_OK;
+}
+
+static int g_num_cu = 0;
+static int num_cu() {
+  if (!g_num_cu) {
+    hipDeviceProp_t p;
+    g_num_cu = (hipGetDeviceProperties(&p, 0) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return g_num_cu;
+}
+
+template <int CIN, int COUT>
+static int launch_split(const SplitConvArgs &a, const int32_t *tile_rows, int ntiles, hipStream_t stream) {
+  const size_t per_row = (size_t)COUT * 4 + (size_t)a.K * 4 + (size_t)a.K * 2;
+  int tm_max = (int)((144 * 1024) / per_row) & ~3;
+  if (tm_max > 4095) tm_max = 4092;                    // chunk-group index has 8 bits: (TM/16) < 256
+  int slots = num_cu();
+  int m = cdiv(a.n_out, (long long)slots * tm_max);
+  int TM = (cdiv(a.n_out, (long long)slots * m) + 3) & ~3;
+  if (TM < 16) TM = 16;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void *)spconv_split_kernel<CIN, COUT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+      return DF3D_EHIP;
+    }
+    configured = true;
+  }
+  int nt = cdiv(a.n_out, TM);
+  if (tile_rows && ntiles > 0) {
+    TM = tm_max;
+    nt = ntiles;
+  } else {
+    tile_rows = nullptr;
+  }
+  size_t lds = (size_t)(TM + 1) * COUT * 4 + (size_t)TM * a.K * 6 + ((size_t)a.K * (TM / 16 + 2) + 8) * 4 + 64;
+  hipLaunchKernelGGL((spconv_split_kernel<CIN, COUT>), dim3(nt), dim3(256), lds, stream, a, TM, tile_rows);
+  return DF3D_OK;
+}
+
+static bool split_shape_ok(int cin, int cout) {
+  return (cout == 128 && (cin == 128 || cin == 64)) || (cout == 64 && (cin == 64 || cin == 32));
+}
+
+}  // namespace df3d
+
+using namespace df3d;
+
+extern "C" size_t df3d_conv_packed_weight_bytes(int kvol, int cin, int cout) {
+  if (!split_shape_ok(cin, cout) || kvol <= 0 || kvol > DF3D_MAX_KVOL) return 0;
+  return (size_t)kvol * cin * cout * 4;
+}
+
+// which kernel serves a shape: 1 = output-stationary (layout 1), 0 = pair-compacted (layout 0)
+static int split_layout(int cin, int cout) {
+  static const char *force = getenv("DF3D_SPLIT_KERNEL");
+  if (force && force[0] == 'p') return 0;
+  if (force && force[0] == 'o') return 1;
+  (void)cin;
+  (void)cout;
+  return 1;
+}
+
+extern "C" int df3d_conv_pack_weights(const float *filters, int kvol, int cin, int cout, void *packed, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(filters && packed, "conv_pack_weights: null argument");
+  DF3D_CHECK_ARG(df3d_conv_packed_weight_bytes(kvol, cin, cout) != 0,
+                 "conv_pack_weights: shape K=%d cin=%d cout=%d has no split-precision kernel", kvol, cin, cout);
+  size_t total = (size_t)kvol * cin * cout / 4;     // 16-byte groups
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, stream, filters, kvol, cin,
+                     cout, split_layout(cin, cout), (u32x4 *)packed);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_split_rows(const float *features, long long n, int c, void *split, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(features && split, "split_rows: null argument");
+  DF3D_CHECK_ARG(c > 0 && c % 8 == 0 && n >= 0, "split_rows: channels must be a multiple of 8 (got %d)", c);
+  size_t nblk = (size_t)n * c / 8;
+  if (nblk == 0) return DF3D_OK;
+  hipLaunchKernelGGL(split_rows_kernel, dim3(cdiv((long long)nblk, 256)), dim3(256), 0, stream, features, nblk,
+                     (u32x4 *)split);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int cin, const void *packed_filters,
+                                      int kvol, int cout, const int32_t *nbr, int n_out, const float *bias,
+                                      const float *scale, const float *shift, const float *residual, int relu,
+                                      float *out, void *out_split, const int32_t *tile_rows, int ntiles,
+                                      void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(features_split && packed_filters && nbr && out, "sparse_conv_split: null argument");
+  DF3D_CHECK_ARG(kvol > 0 && kvol <= DF3D_MAX_KVOL, "sparse_conv_split: kernel volume %d unsupported", kvol);
+  DF3D_CHECK_ARG(split_shape_ok(cin, cout), "sparse_conv_split: cin=%d cout=%d has no split-precision kernel", cin,
+                 cout);
+  if (n_out == 0) return DF3D_OK;
+  SplitConvArgs a = {(const u32x4 *)features_split, (const u32x4 *)packed_filters, nbr, bias, scale, shift, residual,
+                     out, (u32x4 *)out_split, n_in, n_out, kvol, relu};
+  int rec = timing_rec_begin(cin, cout, kvol, n_out, stream);
+  int rc;
+  if (split_layout(cin, cout) == 1) {
+    if (cout == 128) rc = cin == 128 ? launch_os_split<128, 128>(a, stream) : launch_os_split<64, 128>(a, stream);
+    else rc = cin == 64 ? launch_os_split<64, 64>(a, stream) : launch_os_split<32, 64>(a, stream);
+  } else if (cout == 128) {
+    rc = cin == 128 ? launch_split<128, 128>(a, tile_rows, ntiles, stream)
+                    : launch_split<64, 128>(a, tile_rows, ntiles, stream);
+  } else {
+    rc = cin == 64 ? launch_split<64, 64>(a, tile_rows, ntiles, stream)
+                   : launch_split<32, 64>(a, tile_rows, ntiles, stream);
+  }
+  if (rc) return rc;
+  timing_rec_end(rec, stream);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}

@@ -5,6 +5,7 @@ libdf3d_hip.so.  Inputs must be contiguous tensors on one GPU, as the reference'
 require (ms_deform_attn_cuda.cu:28-38).  Nothing here falls back to the CPU.
 """
 import ctypes
+import os
 
 import torch
 
@@ -237,6 +238,69 @@ def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shif
                                           _stream())
     _lib.check(rc, "df3d_sparse_conv_fused")
     return out
+
+
+# ---- split-precision convolution (csrc/spconv_split.hip) --------------------------------------------------
+# "split": C >= 64 layers run on the bf16 matrix cores with hi/lo-split fp32 operands (~1e-5 relative error);
+# "fp32":  every layer on the exact fp32 MFMA kernels (csrc/spconv.hip).  DF3D_CONV_PRECISION overrides.
+CONV_PRECISION = os.environ.get("DF3D_CONV_PRECISION", "split")
+
+
+def conv_split_supported(kvol, cin, cout):
+    if CONV_PRECISION != "split":
+        return False
+    return _lib.load().df3d_conv_packed_weight_bytes(int(kvol), int(cin), int(cout)) > 0
+
+
+def conv_pack_weights(filters):
+    """filters [K, cin, cout] fp32 -> packed hi/lo bf16 MFMA operands (uint8 buffer)."""
+    lib = _lib.load()
+    _chk(filters, torch.float32, "filters")
+    K, cin, cout = filters.shape
+    nbytes = lib.df3d_conv_packed_weight_bytes(K, cin, cout)
+    if nbytes == 0:
+        raise _lib.Df3dError("no split-precision kernel for K=%d cin=%d cout=%d" % (K, cin, cout))
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=filters.device)
+    rc = lib.df3d_conv_pack_weights(_ptr(filters), K, cin, cout, _ptr(packed), _stream())
+    _lib.check(rc, "df3d_conv_pack_weights")
+    return packed
+
+
+def split_rows(features):
+    """features [n, c] fp32 -> split rows (uint8 [n, 4c]: per 8 channels 16 B of bf16 hi, 16 B of bf16 lo)."""
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    n, c = features.shape
+    out = torch.empty((n, 4 * c), dtype=torch.uint8, device=features.device)
+    rc = lib.df3d_split_rows(_ptr(features), n, c, _ptr(out), _stream())
+    _lib.check(rc, "df3d_split_rows")
+    return out
+
+
+def sparse_conv_split(features_split, packed, nbr, n_out, cin, cout, bias=None, scale=None, shift=None,
+                      residual=None, relu=False, tiles=None, emit_split=True):
+    """Split-precision twin of sparse_conv_fused.  Returns (out fp32 [n_out, cout], split rows of out or None)."""
+    lib = _lib.load()
+    _chk(features_split, torch.uint8, "features_split")
+    _chk(packed, torch.uint8, "packed")
+    _chk(nbr, torch.int32, "nbr")
+    n_in = features_split.shape[0]
+    K = nbr.shape[0]
+    if features_split.shape[1] != 4 * cin or packed.numel() != K * cin * cout * 4:
+        raise _lib.Df3dError("split operands do not match K=%d cin=%d cout=%d" % (K, cin, cout))
+    for t, nm in ((bias, "bias"), (scale, "scale"), (shift, "shift"), (residual, "residual")):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=nbr.device)
+    out_split = torch.empty((n_out, 4 * cout), dtype=torch.uint8, device=nbr.device) if emit_split else None
+    if TIMER is not None:
+        TIMER.note(("spconv", cin, cout, K), {"n_in": n_in, "n_out": n_out, "nbr": nbr})
+    rc = lib.df3d_sparse_conv_split(_ptr(features_split), n_in, cin, _ptr(packed), K, cout, _ptr(nbr), n_out,
+                                    _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out),
+                                    _ptr(out_split), _ptr(tiles), (tiles.shape[0] - 1) if tiles is not None else 0,
+                                    _stream())
+    _lib.check(rc, "df3d_sparse_conv_split")
+    return out, out_split
 
 
 def sparse_to_dense(features, indices, batch, shape):

@@ -130,15 +130,35 @@ class SparseConvolution(SparseModule):
         if torch.is_grad_enabled() and (self.weight.requires_grad or feats.requires_grad):
             raise Df3dError("the fused sparse conv is forward-only in this round; wrap inference in torch.no_grad()")
         K = rb.nbr.shape[0]
-        out_features = _ops.sparse_conv_fused(feats.contiguous(), w.contiguous().view(K, self.in_channels,
-                                                                                      self.out_channels),
-                                              rb.nbr, rb.outids.shape[0],
-                                              bias=self.bias.detach() if self.bias is not None else None,
-                                              scale=scale, shift=shift, residual=residual, relu=relu,
-                                              tiles=rb.tiles(self.in_channels, self.out_channels))
+        n_out = rb.outids.shape[0]
+        bias = self.bias.detach() if self.bias is not None else None
+        tiles = rb.tiles(self.in_channels, self.out_channels)
+        out_split = None
+        if _ops.conv_split_supported(K, self.in_channels, self.out_channels):
+            if input.features is not feats:
+                input = input.replace_feature(feats)
+            out_features, out_split = _ops.sparse_conv_split(
+                input.split_features(), self._packed_weight(w, K), rb.nbr, n_out, self.in_channels,
+                self.out_channels, bias=bias, scale=scale, shift=shift, residual=residual, relu=relu, tiles=tiles)
+        else:
+            out_features = _ops.sparse_conv_fused(feats.contiguous(),
+                                                  w.contiguous().view(K, self.in_channels, self.out_channels),
+                                                  rb.nbr, n_out, bias=bias, scale=scale, shift=shift,
+                                                  residual=residual, relu=relu, tiles=tiles)
         out = SparseConvTensor(out_features, rb.outids, rb.out_spatial_shape, input.batch_size)
         out.indice_dict, out.grid, out._directories = input.indice_dict, input.grid, input._directories
+        if out_split is not None:
+            out._split = (out_features, out_split)
         return out
+
+    def _packed_weight(self, w, K):
+        """hi/lo bf16 MFMA operands of the filter bank, rebuilt only when the parameter changes."""
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = getattr(self, "_packed", None)
+        if hit is None or hit[0] != key:
+            hit = (key, _ops.conv_pack_weights(w.contiguous().view(K, self.in_channels, self.out_channels)))
+            self._packed = hit
+        return hit[1]
 
     def forward(self, input):
         return self.forward_fused(input)

@@ -69,6 +69,16 @@ class SparseConvTensor(object):
         # occupancy directories keyed by the identity of the indices tensor they index; shared by
         # reference with derived tensors exactly like indice_dict
         self._directories = {}
+        # (features tensor, its split rows) when a split-precision conv produced or consumed these features
+        self._split = None
+
+    def split_features(self):
+        """Split rows (bf16 hi | lo) of `features` for the split-precision conv kernels; emitted by the producing
+        conv's epilogue when there is one, otherwise computed here once."""
+        if self._split is None or self._split[0] is not self.features:
+            feats = self.features.contiguous()
+            self._split = (self.features, _ops.split_rows(feats))
+        return self._split[1]
 
     # ---- reference API ------------------------------------------------------------
     @property

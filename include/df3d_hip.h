@@ -249,6 +249,27 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
                            float *qgrid, float *qpts, float *qpos, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Split-precision sparse convolution (csrc/spconv_split.hip): same contract as df3d_sparse_conv_fused
+ * (replaces the same reference entry points, spconv_ops.h:260-361 + the BN/ReLU/residual passes), evaluated
+ * on the bf16 matrix cores.  Every fp32 operand x is split once into hi = bf16(x), lo = bf16(x - hi) and the
+ * contraction is A_hi*W_hi + A_lo*W_hi + A_hi*W_lo with fp32 accumulation: ~1e-5 relative error against the
+ * exact fp32 result (parity bar 1e-3), 16/3 of the fp32 MFMA rate.
+ *   df3d_conv_packed_weight_bytes: bytes of the packed filter bank, 0 when (cin, cout) has no split kernel
+ *                                  (served: 32->64, 64->64, 64->128, 128->128)
+ *   df3d_conv_pack_weights:  filters [kvol][cin][cout] fp32 -> packed MFMA B operands (once per weight)
+ *   df3d_split_rows:         features [n][c] fp32 -> split rows [n][c/8][hi 8 x bf16 | lo 8 x bf16], c % 8 == 0
+ *   df3d_sparse_conv_split:  out fp32 [n_out][cout]; out_split (optional) receives the split rows of `out`
+ *                            so that the next convolution needs no df3d_split_rows pass.
+ * ---------------------------------------------------------------------------------- */
+size_t df3d_conv_packed_weight_bytes(int kvol, int cin, int cout);
+int df3d_conv_pack_weights(const float *filters, int kvol, int cin, int cout, void *packed, void *stream);
+int df3d_split_rows(const float *features, long long n, int c, void *split, void *stream);
+int df3d_sparse_conv_split(const void *features_split, int n_in, int cin, const void *packed_filters, int kvol,
+                           int cout, const int32_t *nbr, int n_out, const float *bias, const float *scale,
+                           const float *shift, const float *residual, int relu, float *out, void *out_split,
+                           const int32_t *tile_rows, int ntiles, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused element-wise stages of the dual-query encoder layer (csrc/actr.hip); the reference runs them as
  * separate torch ops (actr_transformer.py:399-426, ms_deform_attn.py:129-166, attentions.py:111-117).
  * Rows = B*ncam*Q query rows of C channels, fp32, contiguous.

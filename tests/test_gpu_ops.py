@@ -168,6 +168,71 @@ def test_sparse_conv_vs_oracle(dev, cin, cout, n_seeds):
         np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-4)
 
 
+def _np_split(x):
+    """hi = bf16_rne(x), lo = bf16_rne(x - hi) as uint16 bit patterns (csrc/spconv_split.hip split2)."""
+    def rne(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) & 0xffff).astype(np.uint32)
+    hi = rne(x)
+    hif = (hi << 16).astype(np.uint32).view(np.float32)
+    lo = rne((x.astype(np.float32) - hif).astype(np.float32))
+    return hi.astype(np.uint16), lo.astype(np.uint16)
+
+
+def test_split_rows_bit_exact(dev):
+    from dualfusion import ops
+    x = detgen.randn("splitrows", (1000, 64)) * np.exp(detgen.randn("splitrows_s", (1000, 1)) * 3).astype(np.float32)
+    x[0, :8] = [0.0, -0.0, 1.0, -1.0, 3.0e-39, 1.0e30, -65504.0, 0.333333343]
+    got = ops.split_rows(T(x, dev)).cpu().numpy().view(np.uint16).reshape(1000, 8, 2, 8)
+    hi, lo = _np_split(x)
+    assert np.array_equal(got[:, :, 0], hi.reshape(1000, 8, 8))
+    assert np.array_equal(got[:, :, 1], lo.reshape(1000, 8, 8))
+    # the pair reproduces x to 2^-16 relative
+    rec = (hi.astype(np.uint32) << 16).view(np.float32) + (lo.astype(np.uint32) << 16).view(np.float32)
+    big = np.abs(x) > 1e-30
+    assert np.max(np.abs(rec - x)[big] / np.abs(x)[big]) < 2.0 ** -16
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 64), (64, 128), (128, 128)])
+@pytest.mark.parametrize("n_seeds", [4, 60])
+def test_sparse_conv_split_precision(dev, cin, cout, n_seeds):
+    """Split-precision kernel (bf16 hi/lo operands, 3 MFMA products, fp32 accumulate) against the float64
+    contraction: <= 5e-5 of the output scale (parity bar 1e-3; the exact-fp32 kernel sits at ~1e-6), fused
+    epilogue included, and its emitted split rows equal split_rows(out) bit for bit."""
+    from dualfusion import ops
+    shape, batch = [9, 48, 48], 2
+    ind = detgen.clustered_voxels("cs%d" % n_seeds, batch, shape, n_seeds=n_seeds, walk=200)
+    ind_t = T(ind, dev)
+    feats = detgen.randn("csf%d_%d" % (cin, n_seeds), (len(ind), cin))
+    filt = detgen.randn("csw%d_%d" % (cin, cout), (27, cin, cout), 0.5 / np.sqrt(cin))
+    bias = detgen.randn("csb%d" % cout, (cout,), 0.1)
+    scale = 1 + detgen.randn("css%d" % cout, (cout,), 0.1)
+    shift = detgen.randn("csh%d" % cout, (cout,), 0.1)
+    packed = ops.conv_pack_weights(T(filt, dev))
+    fsplit = ops.split_rows(T(feats, dev))
+    for subm in (1, 0):
+        ks, st, pd, dl = [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1]
+        outids, nbr, _ = _hip_rulebook(ind_t, batch, shape, ks, st, pd, dl, subm)
+        n_out = outids.shape[0]
+        res = detgen.randn("csr%d" % cout, (n_out, cout))
+        for tiles in (None, ops.conv_tiles(nbr, cin, cout)):
+            y, ys = ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, bias=T(bias, dev),
+                                          scale=T(scale, dev), shift=T(shift, dev), residual=T(res, dev), relu=True,
+                                          tiles=tiles)
+            nb = nbr.cpu().numpy()
+            acc = np.zeros((n_out, cout), np.float64)
+            for k in range(27):
+                m = nb[k] >= 0
+                acc[m] += feats[nb[k][m]].astype(np.float64) @ filt[k].astype(np.float64)
+            ref = np.maximum((acc + bias) * scale + shift + res, 0)
+            err = np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max()
+            assert err < 5e-5, err
+            assert torch.equal(ys, ops.split_rows(y))
+        y32 = ops.sparse_conv_fused(T(feats, dev), T(filt, dev), nbr, n_out, bias=T(bias, dev), scale=T(scale, dev),
+                                    shift=T(shift, dev), residual=T(res, dev), relu=True)
+        assert np.abs(y32.cpu().numpy() - ref).max() / np.abs(ref).max() < 5e-6
+
+
 def test_rulebook_empty_and_single(dev):
     from dualfusion import ops
     shape, batch = [5, 8, 8], 1

@@ -30,20 +30,36 @@ f = x.features.contiguous()
 R = int((rb.nbr >= 0).sum())
 n = f.shape[0]
 tiles = rb.tiles(C, C) if os.environ.get('DF3D_BALANCE', '1') == '1' else None
-for _ in range(3):
-    y = ops.sparse_conv_fused(f, w, rb.nbr, n, relu=True, tiles=tiles)
-torch.cuda.synchronize()
-a = torch.cuda.Event(enable_timing=True)
-b = torch.cuda.Event(enable_timing=True)
-a.record()
-for _ in range(iters):
-    y = ops.sparse_conv_fused(f, w, rb.nbr, n, relu=True, tiles=tiles)
-b.record()
-torch.cuda.synchronize()
-us = a.elapsed_time(b) * 1e3 / iters
+def timeit(fn):
+    for _ in range(3):
+        y = fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        y = fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters, y
+
+
 fl = 2.0 * R * C * C
-print("stage %s N=%d C=%d R=%d pairs/row=%.1f : %.1f us/launch, %.1f TF useful (%.1f%% of 157.3), v2=%s" % (
-    stage, n, C, R, R / n, us, fl / us / 1e6, fl / us / 1e6 / 157.3 * 100, bool(os.environ.get("DF3D_SPCONV_V2"))))
+abytes = R * C * 4 + n * C * 4 + rb.nbr.numel() * 4 + w.numel() * 4
+us, y32 = timeit(lambda: ops.sparse_conv_fused(f, w, rb.nbr, n, relu=True, tiles=tiles))
+print("stage %s N=%d C=%d R=%d pairs/row=%.1f : fp32 kernel %.1f us/launch, %.1f TF useful (%.1f%% of 157.3 fp32 MFMA)"
+      % (stage, n, C, R, R / n, us, fl / us / 1e6, fl / us / 1e6 / 157.3 * 100))
+if ops.conv_split_supported(rb.nbr.shape[0], C, C):
+    packed = ops.conv_pack_weights(w)
+    fs = ops.split_rows(f)
+    us, (ys, _) = timeit(lambda: ops.sparse_conv_split(fs, packed, rb.nbr, n, C, C, relu=True, tiles=tiles))
+    err = float((ys - y32).abs().max() / y32.abs().max())
+    print("  split-precision kernel (%s) %.1f us/launch, %.1f TF useful, %.2f TB/s algorithmic (%.1f%% of 8 TB/s HBM), "
+          "max |diff| vs fp32 kernel %.2e of scale" % (os.environ.get("DF3D_SPLIT_KERNEL", "default"), us,
+                                                      fl / us / 1e6, abytes / us / 1e6, abytes / us / 1e6 / 8 * 100,
+                                                      err))
+    us, _ = timeit(lambda: ops.split_rows(f))
+    print("  split_rows pass %.1f us" % us)
 # ---- tile balance statistics (rows cut into 256 equal tiles, as the pair kernel does)
 import math
 cnt_row = (rb.nbr >= 0).sum(0).float()
