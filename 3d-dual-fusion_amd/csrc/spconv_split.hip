@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
 // ---- W[K][CIN][COUT] fp32 -> packed B operands -----------------------------------------------------------
 // layout 0 (spconv_split_kernel, pair-compacted):   [k][wave 4][kb][ct][hi|lo][lane], lane (n,g) -> column
 //          wave*COUT/4 + CT*n + ct, channels g*CIN/4 + kb*8 + e
-// layout 1 (spconv_os_split_kernel, output-stationary): [k][kb][ct][hi|lo][lane], lane (n,g) -> column ct*16 + n,
+// layout 1 (spconv_os_split_kernel, output-stationary): [k][kb][ct][hi|lo][lane], lane (n,g) -> column n*CT + ct,
 //          channels kb*32 + g*8 + e
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, int K, int cin, int cout,
                                                            int layout, u32x4 *__restrict__ out) {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
     int ct = (int)(r % CT); r /= CT;
     kb = (int)(r % KB);
     k = (int)(r / KB);
-    col = ct * 16 + n;
+    col = n * CT + ct;                 // lane n owns CT consecutive output columns -> vector epilogue
     ch0 = kb * 32 + g * 8;
   }
   unsigned v[8];
@@ -120,6 +120,7 @@ struct SplitConvArgs {
   float *out;
   u32x4 *out_split;      // optional split rows of the output
   int n_in, n_out, K, relu;
+  int dbg;               // tuning experiments (DF3D_OS_DBG): 1 = no gathers, 2 = no W staging, 4 = no MFMAs
 };
 
 #define DF3D_MFMA_BF16(A, B, C) \
@@ -397,21 +398,27 @@ __global__ __launch_bounds__(256, 1) void spconv_split_kernel(SplitConvArgs a, i
   }  // passes over the row range
 }
 
+// rows without a neighbour gather this all-zero split row (keeps the gathers branch-free, so that the
+// compiler can count its vmcnt waits instead of draining the whole load queue at every step)
+__device__ u32x4 g_zero_row[64];
+
 // ---------------------------------------------------------------------------------------------------------
 // Output-stationary variant: a wave owns 16*RT output rows and all COUT columns, accumulators in registers,
 // the packed B operands of one (offset, 32-channel block) step staged through LDS (double buffered, one
 // barrier per step), A fragments (32 B of split row per lane) straight from L2/HBM one step ahead.  MFMAs are
 // also issued for rows without a neighbour at an offset (zero operands) -- at 3/16 of the fp32 cost that waste
 // is cheaper than the pair compaction -- and several workgroups per CU hide the gather latency.
-template <int CIN, int COUT, int RT, int NW>
+template <int CIN, int COUT, int RT, int NW, int KPS>
 __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs a) {
-  constexpr int KB = CIN / 32, CT = COUT / 16, TM = 16 * RT * NW, WROWS = 16 * RT, RQ = CIN / 4;
-  constexpr int WQ = CT * 2 * 64;                 // u32x4 per W step tile
+  // KPS = 32-channel blocks per step (one barrier per step)
+  constexpr int KB = CIN / 32 / KPS, CT = COUT / 16, TM = 16 * RT * NW, WROWS = 16 * RT, RQ = CIN / 4;
+  constexpr int WQ = KPS * CT * 2 * 64;           // u32x4 per W step tile
   constexpr int NT = NW * 64;
   constexpr int WPT = (WQ + NT - 1) / NT;
   __shared__ u32x4 Wl[2][WQ];
   __shared__ int nbrL[DF3D_MAX_KVOL][TM];
   __shared__ unsigned wg_mask;
+  __shared__ int actL[DF3D_MAX_KVOL + 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
@@ -420,22 +427,42 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   const int row0 = tile * TM;
 
   if (tid == 0) wg_mask = 0u;
-  for (int e = tid; e < a.K * TM; e += NT) {
-    int k = e / TM, r = e - k * TM;
-    int row = row0 + r;
-    nbrL[k][r] = (row < a.n_out) ? a.nbr[(size_t)k * a.n_out + row] : -1;
-  }
   __syncthreads();
-  unsigned wmask = 0u;
-  for (int k = 0; k < a.K; ++k) {
-    int r = lane;
-    int v = (r < WROWS) ? nbrL[k][wave * WROWS + r] : -1;
-    if (__ballot(v >= 0) != 0ull) wmask |= (1u << k);
+  // neighbour tile -> LDS; a wave covers 64 rows (or TM) of one offset per pass, so the set of offsets with at
+  // least one neighbour in the tile falls out of the same pass (one ballot per load)
+  {
+    constexpr int KSTEP = NT / TM;               // offsets covered per pass (NT = 4*TM/RT... >= 1)
+    static_assert(NT % TM == 0 && KSTEP >= 1, "tile shape");
+    const int r = tid % TM, k0 = tid / TM;
+    const int row = row0 + r;
+    unsigned mine = 0u;
+    int v[(DF3D_MAX_KVOL + KSTEP - 1) / KSTEP];
+#pragma unroll
+    for (int i = 0; i < (DF3D_MAX_KVOL + KSTEP - 1) / KSTEP; ++i) {
+      int k = k0 + i * KSTEP;
+      v[i] = (k < a.K && row < a.n_out) ? a.nbr[(size_t)k * a.n_out + row] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < (DF3D_MAX_KVOL + KSTEP - 1) / KSTEP; ++i) {
+      int k = k0 + i * KSTEP;
+      if (k < a.K) nbrL[k][r] = v[i];
+      if (TM >= 64) {                            // the whole wave looks at one offset
+        if (__ballot(v[i] >= 0) != 0ull) mine |= 1u << (k & 31);
+      } else if (v[i] >= 0) {
+        atomicOr(&wg_mask, 1u << k);
+      }
+    }
+    if (TM >= 64 && lane == 0 && mine) atomicOr(&wg_mask, mine);
   }
-  if (lane == 0 && wmask) atomicOr(&wg_mask, wmask);
   __syncthreads();
   const unsigned gmask = wg_mask;
-  const int steps = __popc(gmask) * KB;
+  const int nact = __popc(gmask);
+  if (tid < 32) {
+    if ((gmask >> tid) & 1u) actL[__popc(gmask & ((1u << tid) - 1u))] = tid;
+    if (tid == 0) actL[nact] = 0;
+  }
+  __syncthreads();
+  const int steps = nact * KB;
 
   f32x4 acc[RT][CT];
 #pragma unroll
@@ -443,18 +470,18 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto kth_active = [&](int ai) -> int {
-    unsigned m = gmask;
-    for (int i = 0; i < ai; ++i) m &= m - 1;
-    return __ffs((int)m) - 1;
-  };
+  // Every step issues the same loads, unconditionally: W tile of step min(s+2, last) and the A fragments of step
+  // s+3 (the zero row past the end or where a row has no neighbour).  Steps are padded to a multiple of 3
+  // (the A ring rotates by name); padding steps multiply zeros.
   u32x4 wreg[WPT];
-  auto load_w = [&](int k, int kb) {
-    const u32x4 *src = a.w + (size_t)(k * KB + kb) * WQ;
+  auto load_w = [&](int s) {
+    s = s < steps ? s : steps - 1;
+    const int k = __builtin_amdgcn_readfirstlane(actL[s / KB]);
+    const u32x4 *src = a.w + (size_t)(k * KB + s % KB) * WQ;     // KPS consecutive [kb] tiles
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       int e = tid + NT * i;
-      if (WQ % NT == 0 || e < WQ) wreg[i] = src[e];
+      wreg[i] = src[(WQ % NT == 0 || e < WQ) ? e : 0];
     }
   };
   auto store_w = [&](int buf) {
@@ -464,98 +491,122 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       if (WQ % NT == 0 || e < WQ) Wl[buf][e] = wreg[i];
     }
   };
-  u32x4 anext[RT][2], acur[RT][2];
-  auto load_a = [&](int k, int kb) {
+  u32x4 a0[RT][KPS][2], a1[RT][KPS][2], a2[RT][KPS][2];
+  auto load_a = [&](int s, u32x4 (&dst)[RT][KPS][2]) {
+    const bool live = s < steps;
+    const int sc = live ? s : 0;
+    const int k = __builtin_amdgcn_readfirstlane(actL[sc / KB]), kb = (sc % KB) * KPS;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       int idx = nbrL[k][wave * WROWS + rt * 16 + n];
-      u32x4 h = (u32x4){0u, 0u, 0u, 0u}, l = h;
-      if (idx >= 0) {
-        const u32x4 *p = a.feat + (size_t)idx * RQ + (kb * 4 + g) * 2;
-        h = p[0];
-        l = p[1];
+      const u32x4 *p = (live && idx >= 0 && !(a.dbg & 1)) ? a.feat + (size_t)idx * RQ : g_zero_row;
+      p += (kb * 4 + g) * 2;
+#pragma unroll
+      for (int j = 0; j < KPS; ++j) {
+        dst[rt][j][0] = p[j * 8];
+        dst[rt][j][1] = p[j * 8 + 1];
       }
-      anext[rt][0] = h;
-      anext[rt][1] = l;
     }
   };
-
-  int k_next = 0;
-  if (steps > 0) {
-    k_next = kth_active(0);
-    load_w(k_next, 0);
-    store_w(0);
-    if ((wmask >> k_next) & 1u) load_a(k_next, 0);
-  }
-  for (int s = 0; s < steps; ++s) {
-    const int k_cur = k_next;
-    const bool wave_on = (wmask >> k_cur) & 1u;
+  // Step s: barrier; W(s+1) (fetched during step s-1) -> LDS; fetch W(s+2); MFMAs of step s; fetch A(s+3).
+  auto step = [&](int s, u32x4 (&cur)[RT][KPS][2]) {
     __syncthreads();
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      acur[rt][0] = anext[rt][0];
-      acur[rt][1] = anext[rt][1];
+    if (!(a.dbg & 2)) {
+      store_w((s + 1) & 1);
+      load_w(s + 2);
     }
-    const bool more = s + 1 < steps;
-    if (more) {
-      int s1 = s + 1;
-      int ai = s1 / KB;
-      int kb_n = s1 - ai * KB;
-      k_next = (kb_n == 0) ? kth_active(ai) : k_cur;
-      load_w(k_next, kb_n);
-      if ((wmask >> k_next) & 1u) load_a(k_next, kb_n);
-    }
-    if (wave_on) {
-      const u32x4 *wb = Wl[s & 1];
+    const u32x4 *wb = Wl[s & 1] + lane;
+    // B fragments of the next column pair are fetched from LDS while the MFMAs of the current pair run
+    constexpr int NBATCH = KPS * CT / 2;
+    u32x4 bq[2][4];
 #pragma unroll
-      for (int c2 = 0; c2 < CT; c2 += 2) {
-        u32x4 bh0 = wb[(c2 * 2 + 0) * 64 + lane], bl0 = wb[(c2 * 2 + 1) * 64 + lane];
-        u32x4 bh1 = wb[(c2 * 2 + 2) * 64 + lane], bl1 = wb[(c2 * 2 + 3) * 64 + lane];
+    for (int q = 0; q < 4; ++q) bq[0][q] = wb[q * 64];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          acc[rt][c2] = DF3D_MFMA_BF16(acur[rt][1], bh0, acc[rt][c2]);
-          acc[rt][c2 + 1] = DF3D_MFMA_BF16(acur[rt][1], bh1, acc[rt][c2 + 1]);
-        }
+    for (int i = 0; i < NBATCH; ++i) {
+      const int j = i / (CT / 2), c2 = (i % (CT / 2)) * 2;
+      if (i + 1 < NBATCH) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          acc[rt][c2] = DF3D_MFMA_BF16(acur[rt][0], bl0, acc[rt][c2]);
-          acc[rt][c2 + 1] = DF3D_MFMA_BF16(acur[rt][0], bl1, acc[rt][c2 + 1]);
-        }
+        for (int q = 0; q < 4; ++q) bq[(i + 1) & 1][q] = wb[((i + 1) * 4 + q) * 64];
+      }
+      const u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][1], bh1 = bq[i & 1][2], bl1 = bq[i & 1][3];
+      if (a.dbg & 4) continue;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          acc[rt][c2] = DF3D_MFMA_BF16(acur[rt][0], bh0, acc[rt][c2]);
-          acc[rt][c2 + 1] = DF3D_MFMA_BF16(acur[rt][0], bh1, acc[rt][c2 + 1]);
-        }
+      for (int rt = 0; rt < RT; ++rt) {
+        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][1], bh0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][1], bh1, acc[rt][c2 + 1]);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][0], bl0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][0], bl1, acc[rt][c2 + 1]);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][0], bh0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][0], bh1, acc[rt][c2 + 1]);
       }
     }
-    if (more) store_w((s + 1) & 1);
+    load_a(s + 3, cur);
+  };
+
+  if (steps > 0) {
+    load_w(0);
+    store_w(0);
+    load_w(1);
+    load_a(0, a0);
+    load_a(1, a1);
+    load_a(2, a2);
+    for (int s = 0; s < steps; s += 3) {
+      step(s, a0);
+      step(s + 1, a1);
+      step(s + 2, a2);
+    }
   }
 
-  // ---- epilogue: bias, folded BN, residual, ReLU; optional split rows of the result ----
-  unsigned short *osplit = (unsigned short *)a.out_split;
+  // ---- epilogue: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the CT
+  //      consecutive columns n*CT .. n*CT+CT-1 of its rows (packed-weight layout 1): 16-byte stores ----
+  static_assert(CT == 4 || CT == 8, "COUT must be 64 or 128");
+  f32x4 bi[CT / 4], sc[CT / 4], sh[CT / 4];
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) {
-    int col = ct * 16 + n;
-    float bi = a.bias ? a.bias[col] : 0.f;
-    float sc = a.scale ? a.scale[col] : 1.f;
-    float sh = a.shift ? a.shift[col] : 0.f;
+  for (int q = 0; q < CT / 4; ++q) {
+    const int col = n * CT + q * 4;
+    bi[q] = a.bias ? *(const f32x4 *)(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    sc[q] = a.scale ? *(const f32x4 *)(a.scale + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    sh[q] = a.shift ? *(const f32x4 *)(a.shift + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
-        if (row < a.n_out) {
-          float v = (acc[rt][ct][r] + bi) * sc + sh;
-          if (a.residual) v += a.residual[(size_t)row * COUT + col];
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.out[(size_t)row * COUT + col] = v;
-          if (osplit) {
-            unsigned hi, lo;
-            split2(v, hi, lo);
-            size_t blk = ((size_t)row * COUT + col) >> 3;          // 8-channel block: 8 hi then 8 lo (u16)
-            osplit[blk * 16 + (col & 7)] = (unsigned short)hi;
-            osplit[blk * 16 + 8 + (col & 7)] = (unsigned short)lo;
-          }
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
+      if (row >= a.n_out) continue;
+      const size_t o = (size_t)row * COUT + n * CT;
+      unsigned h[CT], l[CT];
+#pragma unroll
+      for (int q = 0; q < CT / 4; ++q) {
+        f32x4 v = (f32x4){acc[rt][q * 4][r], acc[rt][q * 4 + 1][r], acc[rt][q * 4 + 2][r], acc[rt][q * 4 + 3][r]};
+        v = (v + bi[q]) * sc[q] + sh[q];
+        if (a.residual) v += *(const f32x4 *)(a.residual + o + q * 4);
+        if (a.relu) {
+          v[0] = fmaxf(v[0], 0.f);
+          v[1] = fmaxf(v[1], 0.f);
+          v[2] = fmaxf(v[2], 0.f);
+          v[3] = fmaxf(v[3], 0.f);
+        }
+        *(f32x4 *)(a.out + o + q * 4) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2(v[e], h[q * 4 + e], l[q * 4 + e]);
+      }
+      if (a.out_split) {
+        char *blk = (char *)a.out_split + (o >> 3) * 32;             // 8-channel block = [hi 16 B | lo 16 B]
+        if (CT == 8) {
+          *(u32x4 *)blk = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+          *(u32x4 *)(blk + 16) =
+              (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+        } else {
+          blk += (n & 1) * 8;                                        // two lanes share a block
+          *(u32x2 *)blk = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+          *(u32x2 *)(blk + 16) = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
         }
       }
     }
@@ -564,14 +615,32 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 
 template <int CIN, int COUT>
 static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
-  // enough workgroups to cover the 256 CUs a few times; two row tiles per wave when the layer is large
-  if (a.n_out >= 96 * 1024) {
-    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 2, 4>), dim3(cdiv(a.n_out, 128)), dim3(256), 0, stream, a);
-  } else if (a.n_out >= 48 * 1024) {
-    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 4>), dim3(cdiv(a.n_out, 64)), dim3(256), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 2>), dim3(cdiv(a.n_out, 32)), dim3(128), 0, stream, a);
+  // measured on MI355X (tools/conv_probe.py, DF3D_OS_CFG sweep): 8 waves x 1 row tile wins at the nuScenes layer
+  // sizes (30k-70k rows).  The W step tiles are re-read from L2 by every workgroup (n_out/TM x 4*K*CIN*COUT
+  // bytes per launch, more than the gathers), so more rows per workgroup = less L2 traffic; bigger register
+  // tiles (RT 2) leave too few waves on the 256 CUs at these row counts.
+  int rt = 1, nw = a.n_out >= 16 * 1024 ? 8 : 2, kps = 1;
+  static const char *cfg = getenv("DF3D_OS_CFG");       // tuning aid: "RT,NW[,KPS]"
+  if (cfg && cfg[0] && cfg[1] == ',') {
+    rt = cfg[0] - '0';
+    nw = cfg[2] - '0';
+    if (cfg[3] == ',') kps = cfg[4] - '0';
   }
+  constexpr int KMAX = CIN >= 64 ? 2 : 1;
+  if (kps > KMAX) kps = KMAX;
+#define DF3D_OS_LAUNCH(RT, NW, KPS)                                                                      \
+  hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, RT, NW, KPS>), dim3(cdiv(a.n_out, 16 * RT * NW)), \
+                     dim3(NW * 64), 0, stream, a)
+  if (kps == 2) {
+    if (rt == 2) DF3D_OS_LAUNCH(2, 4, KMAX);
+    else if (nw == 2) DF3D_OS_LAUNCH(1, 2, KMAX);
+    else DF3D_OS_LAUNCH(1, 4, KMAX);
+  } else if (nw == 8) DF3D_OS_LAUNCH(1, 8, 1);
+  else if (rt == 2 && nw == 4) DF3D_OS_LAUNCH(2, 4, 1);
+  else if (rt == 2 && nw == 2) DF3D_OS_LAUNCH(2, 2, 1);
+  else if (rt == 1 && nw == 4) DF3D_OS_LAUNCH(1, 4, 1);
+  else DF3D_OS_LAUNCH(1, 2, 1);
+#undef DF3D_OS_LAUNCH
   return DF3D_OK;
 }
 
@@ -674,7 +743,8 @@ extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int 
                  cout);
   if (n_out == 0) return DF3D_OK;
   SplitConvArgs a = {(const u32x4 *)features_split, (const u32x4 *)packed_filters, nbr, bias, scale, shift, residual,
-                     out, (u32x4 *)out_split, n_in, n_out, kvol, relu};
+                     out, (u32x4 *)out_split, n_in, n_out, kvol, relu,
+                     getenv("DF3D_OS_DBG") ? atoi(getenv("DF3D_OS_DBG")) : 0};
   int rec = timing_rec_begin(cin, cout, kvol, n_out, stream);
   int rc;
   if (split_layout(cin, cout) == 1) {

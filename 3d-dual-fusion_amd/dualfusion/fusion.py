@@ -226,8 +226,11 @@ class VoxelWithPointProjection(nn.Module):
             # gate's 1-channel summary (a plain batched GEMM, no layout change); the voxel side is 9 scalars per
             # visible voxel
             T, kg, w3, b3 = self.ifat.folded()
-            both = torch.matmul(torch.cat([w_ip, w3], 0), imgf)                  # [NI, C+1, H*W], no bias
-            gate = both[:, -1] + b3                                              # [NI, H*W]
+            # rows padded to a multiple of 16: hipBLASLt picks a 2x slower macro-tile for a 129-row operand
+            npad = (-(w_ip.shape[0] + 1)) % 16
+            wcat = torch.cat([w_ip, w3, w3.new_zeros((npad, w3.shape[1]))], 0)
+            both = torch.matmul(wcat, imgf)                                      # [NI, C+1(+pad), H*W], no bias
+            gate = both[:, w_ip.shape[0]] + b3                                   # [NI, H*W]
             S = torch.empty((NI, 9, H, W), dtype=torch.float32, device=dev)
             winner = torch.empty((NI, H, W), dtype=torch.int32, device=dev)
             first = True
