@@ -1,0 +1,287 @@
+// Fused feed-forward block of the encoder layer for gfx950:
+//     out = LayerNorm(x + W2 relu(W1 x + b1) + b2)          (actr_transformer.py:413-424, d_model 128, d_ffn 1024)
+// as ONE kernel on the bf16 matrix cores with split-precision operands (see spconv_split.hip: x = hi + lo in
+// bf16, products hi*hi + lo*hi + hi*lo, fp32 accumulate, ~1e-5 relative error).  The reference (and the
+// hipBLASLt path) runs two fp32 GEMMs at ~90-110 TFLOP/s plus ReLU, residual add and LayerNorm passes, and moves
+// the [rows, 1024] hidden activation through HBM twice; here the hidden activation never leaves registers.
+//
+// A wave owns 16 rows.  The hidden layer is processed in chunks of 128 units:
+//   phase 1 (4 steps, one per 32 input channels):   H^T chunk = W1_c x^T   -- W1 is the MFMA A operand, the
+//            rows' x fragments the B operand, so the result lands as  lane (row, g) -> hidden 16t + 4g + {0..3}
+//   that register layout IS an MFMA A operand (lane (row, g) holds 8 k-values) once two 16-unit tiles are paired,
+//   so after bias + ReLU + hi/lo split the chunk feeds
+//   phase 2 (4 steps, one per 32 hidden units):     Y += H_c W2_c^T        -- no shuffle, no LDS round trip.
+// The packed weight stream [chunk][8 steps][16 KB] holds exactly the operand images of those steps in order
+// (pack_ffn_kernel), staged through LDS by the whole workgroup (double buffered, one barrier per step) as in
+// spconv_os_split_kernel.  Lane n owns output columns 8n..8n+7 (permuted W2 columns), so residual add,
+// LayerNorm (16-lane reductions) and the 16-byte stores happen in registers.
+//
+// Algorithmic bytes: rows*128*4 read + rows*128*4 written + 1 MB of weights per workgroup from L2;
+// 2*rows*128*1024*2 flops.  Bound: bf16 MFMA at 3 products per fp32 product.
+#include "common.h"
+
+namespace df3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define DF3D_MFMA_BF16(A, B, C) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
+__device__ __forceinline__ unsigned ffn_bf16_bits(float x) {
+  unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void ffn_split2(float x, unsigned &hi, unsigned &lo) {
+  hi = ffn_bf16_bits(x);
+  lo = ffn_bf16_bits(x - __uint_as_float(hi << 16));
+}
+
+constexpr int FFN_C = 128;            // model width
+constexpr int FFN_WQ = 8 * 2 * 64;    // u32x4 per step tile (8 operand tiles x hi/lo x 64 lanes) = 16 KB
+
+// stream tile (chunk c, step j): j < 4 -> W1 rows 128c..128c+127, input channels 32j..32j+31 (A operands);
+//                                j >= 4 -> W2 columns of hidden units 128c + 32(j-4) .. +31 (B operands)
+__global__ __launch_bounds__(256) void pack_ffn_kernel(const float *__restrict__ w1, const float *__restrict__ w2,
+                                                       int H, u32x4 *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)(H / 128) * 8 * FFN_WQ;
+  if (i >= total) return;
+  int lane = (int)(i & 63);
+  int part = (int)((i >> 6) & 1);
+  int t = (int)((i >> 7) & 7);
+  int j = (int)((i >> 10) & 7);
+  int c = (int)(i >> 13);
+  int n = lane & 15, g = lane >> 4;
+  unsigned v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float w;
+    if (j < 4) {
+      int hid = c * 128 + t * 16 + n;            // A operand row m = n
+      int ch = j * 32 + g * 8 + e;
+      w = w1[(size_t)hid * FFN_C + ch];
+    } else {
+      int q = j - 4;
+      int col = n * 8 + t;                       // lane n owns 8 consecutive output columns
+      int hid = c * 128 + (2 * q + (e >> 2)) * 16 + 4 * g + (e & 3);
+      w = w2[(size_t)col * H + hid];
+    }
+    unsigned hi, lo;
+    ffn_split2(w, hi, lo);
+    v[e] = part ? lo : hi;
+  }
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = v[2 * e] | (v[2 * e + 1] << 16);
+  out[i] = o;
+}
+
+struct FfnArgs {
+  const float *x;          // [rows, 128]
+  const u32x4 *w;          // packed stream
+  const float *b1, *b2;    // [H], [128]
+  const float *res;        // residual added before the LayerNorm (usually x), or NULL
+  const float *ln_g, *ln_b;  // LayerNorm affine, or NULL (no normalisation)
+  float eps;
+  float *out;
+  long long rows;
+  int H;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
+  constexpr int NT = NW * 64, TM = NW * 16;
+  constexpr int WPT = FFN_WQ / NT;
+  static_assert(FFN_WQ % NT == 0, "tile must divide over the workgroup");
+  __shared__ u32x4 Wl[2][FFN_WQ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const long long row_n = (long long)blockIdx.x * TM + wave * 16 + n;        // the row this lane feeds as operand
+  const long long row_ld = row_n < a.rows ? row_n : a.rows - 1;
+  const int nchunks = a.H / 128;
+  const int steps = nchunks * 8;
+
+  // x fragments of the wave's 16 rows: lane (row n, g) holds channels 32kb + 8g .. +7, split hi/lo
+  u32x4 xh[4], xl[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const float *p = a.x + row_ld * FFN_C + kb * 32 + g * 8;
+    f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ffn_split2(v0[e], h[e], l[e]);
+      ffn_split2(v1[e], h[4 + e], l[4 + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xh[kb][e] = h[2 * e] | (h[2 * e + 1] << 16);
+      xl[kb][e] = l[2 * e] | (l[2 * e + 1] << 16);
+    }
+  }
+
+  u32x4 wreg[WPT];
+  auto load_w = [&](int s) {
+    s = s < steps ? s : steps - 1;
+    const u32x4 *src = a.w + (size_t)s * FFN_WQ;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) wreg[i] = src[tid + NT * i];
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) Wl[buf][tid + NT * i] = wreg[i];
+  };
+
+  f32x4 acc2[8];
+#pragma unroll
+  for (int ct = 0; ct < 8; ++ct) acc2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_w(0);
+  store_w(0);
+  load_w(1);
+  for (int c = 0; c < nchunks; ++c) {
+    f32x4 acc1[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- phase 1: H^T chunk = W1_c x^T ----
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int s = c * 8 + kb;
+      __syncthreads();
+      store_w((s + 1) & 1);
+      load_w(s + 2);
+      const u32x4 *wb = Wl[s & 1] + lane;
+#pragma unroll
+      for (int t = 0; t < 8; t += 2) {
+        const u32x4 ah0 = wb[(t * 2 + 0) * 64], al0 = wb[(t * 2 + 1) * 64];
+        const u32x4 ah1 = wb[(t * 2 + 2) * 64], al1 = wb[(t * 2 + 3) * 64];
+        acc1[t] = DF3D_MFMA_BF16(ah0, xl[kb], acc1[t]);
+        acc1[t + 1] = DF3D_MFMA_BF16(ah1, xl[kb], acc1[t + 1]);
+        acc1[t] = DF3D_MFMA_BF16(al0, xh[kb], acc1[t]);
+        acc1[t + 1] = DF3D_MFMA_BF16(al1, xh[kb], acc1[t + 1]);
+        acc1[t] = DF3D_MFMA_BF16(ah0, xh[kb], acc1[t]);
+        acc1[t + 1] = DF3D_MFMA_BF16(ah1, xh[kb], acc1[t + 1]);
+      }
+    }
+    // ---- bias + ReLU + split: lane (row n, g) holds hidden 128c + 16t + 4g + {0..3} -> phase-2 A operands ----
+    u32x4 hh[4], hl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned h[8], l[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * q + half;
+        const f32x4 b = *(const f32x4 *)(a.b1 + c * 128 + t * 16 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ffn_split2(fmaxf(acc1[t][e] + b[e], 0.f), h[half * 4 + e], l[half * 4 + e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hh[q][e] = h[2 * e] | (h[2 * e + 1] << 16);
+        hl[q][e] = l[2 * e] | (l[2 * e + 1] << 16);
+      }
+    }
+    // ---- phase 2: Y += H_c W2_c^T ----
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s = c * 8 + 4 + q;
+      __syncthreads();
+      store_w((s + 1) & 1);
+      load_w(s + 2);
+      const u32x4 *wb = Wl[s & 1] + lane;
+#pragma unroll
+      for (int ct = 0; ct < 8; ct += 2) {
+        const u32x4 bh0 = wb[(ct * 2 + 0) * 64], bl0 = wb[(ct * 2 + 1) * 64];
+        const u32x4 bh1 = wb[(ct * 2 + 2) * 64], bl1 = wb[(ct * 2 + 3) * 64];
+        acc2[ct] = DF3D_MFMA_BF16(hl[q], bh0, acc2[ct]);
+        acc2[ct + 1] = DF3D_MFMA_BF16(hl[q], bh1, acc2[ct + 1]);
+        acc2[ct] = DF3D_MFMA_BF16(hh[q], bl0, acc2[ct]);
+        acc2[ct + 1] = DF3D_MFMA_BF16(hh[q], bl1, acc2[ct + 1]);
+        acc2[ct] = DF3D_MFMA_BF16(hh[q], bh0, acc2[ct]);
+        acc2[ct + 1] = DF3D_MFMA_BF16(hh[q], bh1, acc2[ct + 1]);
+      }
+    }
+  }
+
+  // ---- epilogue: lane (n, g) holds rows 4g+r, columns 8n..8n+7: + b2, + residual, LayerNorm over the row ----
+  const f32x4 bA = *(const f32x4 *)(a.b2 + n * 8), bB = *(const f32x4 *)(a.b2 + n * 8 + 4);
+  f32x4 gA = (f32x4){1.f, 1.f, 1.f, 1.f}, gB = gA, zA = (f32x4){0.f, 0.f, 0.f, 0.f}, zB = zA;
+  if (a.ln_g) {
+    gA = *(const f32x4 *)(a.ln_g + n * 8);
+    gB = *(const f32x4 *)(a.ln_g + n * 8 + 4);
+    zA = *(const f32x4 *)(a.ln_b + n * 8);
+    zB = *(const f32x4 *)(a.ln_b + n * 8 + 4);
+  }
+  const long long rbase = (long long)blockIdx.x * TM + wave * 16 + 4 * g;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long row = rbase + r;
+    const bool live = row < a.rows;
+    const long long rr = live ? row : a.rows - 1;
+    f32x4 vA = (f32x4){acc2[0][r], acc2[1][r], acc2[2][r], acc2[3][r]} + bA;
+    f32x4 vB = (f32x4){acc2[4][r], acc2[5][r], acc2[6][r], acc2[7][r]} + bB;
+    if (a.res) {
+      vA += *(const f32x4 *)(a.res + rr * FFN_C + n * 8);
+      vB += *(const f32x4 *)(a.res + rr * FFN_C + n * 8 + 4);
+    }
+    if (a.ln_g) {
+      float s = vA[0] + vA[1] + vA[2] + vA[3] + vB[0] + vB[1] + vB[2] + vB[3];
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);      // the 16 lanes of this row group
+      const float mean = s * (1.f / FFN_C);
+      f32x4 dA = vA - mean, dB = vB - mean;
+      float ss = dA[0] * dA[0] + dA[1] * dA[1] + dA[2] * dA[2] + dA[3] * dA[3] + dB[0] * dB[0] + dB[1] * dB[1] +
+                 dB[2] * dB[2] + dB[3] * dB[3];
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      const float rstd = rsqrtf(ss * (1.f / FFN_C) + a.eps);
+      vA = dA * rstd * gA + zA;
+      vB = dB * rstd * gB + zB;
+    }
+    if (live) {
+      *(f32x4 *)(a.out + row * FFN_C + n * 8) = vA;
+      *(f32x4 *)(a.out + row * FFN_C + n * 8 + 4) = vB;
+    }
+  }
+}
+
+}  // namespace df3d
+
+using namespace df3d;
+
+extern "C" size_t df3d_ffn_packed_bytes(int d_model, int d_ffn) {
+  if (d_model != FFN_C || d_ffn <= 0 || d_ffn % 128 != 0) return 0;
+  return (size_t)(d_ffn / 128) * 8 * FFN_WQ * 16;
+}
+
+extern "C" int df3d_ffn_pack(const float *w1, const float *w2, int d_model, int d_ffn, void *packed, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(w1 && w2 && packed, "ffn_pack: null argument");
+  DF3D_CHECK_ARG(df3d_ffn_packed_bytes(d_model, d_ffn) != 0,
+                 "ffn_pack: the fused feed-forward kernel serves d_model 128 and d_ffn %% 128 == 0 (got %d, %d)",
+                 d_model, d_ffn);
+  size_t total = (size_t)(d_ffn / 128) * 8 * FFN_WQ;
+  hipLaunchKernelGGL(pack_ffn_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, stream, w1, w2, d_ffn,
+                     (u32x4 *)packed);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_ffn_fused(const float *x, long long rows, int d_model, int d_ffn, const void *packed,
+                              const float *b1, const float *b2, const float *residual, const float *ln_weight,
+                              const float *ln_bias, float eps, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(x && packed && b1 && b2 && out, "ffn_fused: null argument");
+  DF3D_CHECK_ARG(df3d_ffn_packed_bytes(d_model, d_ffn) != 0, "ffn_fused: unsupported sizes d_model=%d d_ffn=%d",
+                 d_model, d_ffn);
+  DF3D_CHECK_ARG((ln_weight == nullptr) == (ln_bias == nullptr), "ffn_fused: LayerNorm needs weight and bias");
+  if (rows <= 0) return DF3D_OK;
+  FfnArgs a = {x, (const u32x4 *)packed, b1, b2, residual, ln_weight, ln_bias, eps, out, rows, d_ffn};
+  constexpr int NW = 8;
+  hipLaunchKernelGGL((ffn_split_kernel<NW>), dim3(cdiv(rows, NW * 16)), dim3(NW * 64), 0, stream, a);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}

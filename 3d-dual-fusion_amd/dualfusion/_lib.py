@@ -74,6 +74,10 @@ SIGNATURES = {
     "df3d_sparse_conv_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p]),
+    "df3d_ffn_packed_bytes": (c_size_t, [c_int, c_int]),
+    "df3d_ffn_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_ffn_fused": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_float, c_void_p, c_void_p]),
     "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,
                                    c_void_p]),

@@ -248,6 +248,19 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         return (not self.training and self.q_method == 'sum' and list(self.q_rep_place) == ['weight']
                 and self.attn_layer == 'BiGateSum1D_2' and self.activation is F.relu and self.d_model % 4 == 0)
 
+    def _ffn(self, x, lin_a, lin_b, norm, slot):
+        """norm(x + lin_b(relu(lin_a(x)))): one fused kernel (csrc/ffn.hip) when the sizes fit it."""
+        from . import ops as _ops
+        if not _ops.ffn_supported(lin_a.in_features, lin_a.out_features):
+            return _ops.add_layernorm(x, lin_b(self._linear_relu(lin_a, x)), norm.weight, norm.bias, norm.eps)
+        key = (lin_a.weight.data_ptr(), lin_a.weight._version, lin_b.weight.data_ptr(), lin_b.weight._version)
+        hit = getattr(self, slot, None)
+        if hit is None or hit[0] != key:
+            hit = (key, _ops.ffn_pack(lin_a.weight.detach().contiguous(), lin_b.weight.detach().contiguous()))
+            object.__setattr__(self, slot, hit)
+        return _ops.ffn_fused(x, hit[1], lin_a.bias, lin_b.bias, lin_a.out_features, residual=x,
+                              ln_weight=norm.weight, ln_bias=norm.bias, eps=norm.eps)
+
     def _forward_fused(self, src, reference_points, spatial_shapes, level_start_index, q_pos, q_feat, q_i_feat,
                        value=None):
         """Same arithmetic as forward(); `reference_points` [N,Q,L,2] carries the same (x, y) for every level when
@@ -266,10 +279,8 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
                                         sa.attention_weights(Bw), sa.n_levels, sa.n_points, pixel_scale, image_bias)
         att = sa.output_proj(out)
         qi = _ops.add_layernorm(q_i_feat, att, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qi = _ops.add_layernorm(qi, self.linear2(self._linear_relu(self.linear1, qi)), self.norm2.weight,
-                                self.norm2.bias, self.norm2.eps)
-        q = _ops.add_layernorm(q_feat, self.linear4(self._linear_relu(self.linear3, q_feat)), self.norm3.weight,
-                               self.norm3.bias, self.norm3.eps)
+        qi = self._ffn(qi, self.linear1, self.linear2, self.norm2, "_ffn_i")
+        q = self._ffn(q_feat, self.linear3, self.linear4, self.norm3, "_ffn_p")
         g = self.fusion_layer
         return _ops.bigate_sum(q, qi, g.b_conv1d.weight.view(-1), g.b_conv1d.bias, g.a_conv1d.weight.view(-1),
                                g.a_conv1d.bias)

@@ -389,6 +389,40 @@ def groupnorm_fold(u, gate, conv_bias, gn, weight, bias):
     return Wf, cf
 
 
+def ffn_supported(d_model, d_ffn):
+    return _lib.load().df3d_ffn_packed_bytes(int(d_model), int(d_ffn)) > 0
+
+
+def ffn_pack(w1, w2):
+    """nn.Linear weights W1 [d_ffn, d_model], W2 [d_model, d_ffn] -> packed operand stream of csrc/ffn.hip."""
+    lib = _lib.load()
+    _chk(w1, torch.float32, "w1")
+    _chk(w2, torch.float32, "w2")
+    d_ffn, d_model = w1.shape
+    nbytes = lib.df3d_ffn_packed_bytes(d_model, d_ffn)
+    if nbytes == 0 or tuple(w2.shape) != (d_model, d_ffn):
+        raise _lib.Df3dError("fused FFN serves d_model 128, d_ffn %% 128 == 0 (got %s, %s)" % (tuple(w1.shape),
+                                                                                              tuple(w2.shape)))
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=w1.device)
+    rc = lib.df3d_ffn_pack(_ptr(w1), _ptr(w2), d_model, d_ffn, _ptr(packed), _stream())
+    _lib.check(rc, "df3d_ffn_pack")
+    return packed
+
+
+def ffn_fused(x, packed, b1, b2, d_ffn, residual=None, ln_weight=None, ln_bias=None, eps=1e-5):
+    """LayerNorm(residual + W2 relu(W1 x + b1) + b2) on [.., 128] rows in one kernel."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    if residual is not None:
+        _chk(residual, torch.float32, "residual")
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    rc = lib.df3d_ffn_fused(_ptr(x), x.numel() // C, C, int(d_ffn), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(residual),
+                            _ptr(ln_weight), _ptr(ln_bias), float(eps), _ptr(out), _stream())
+    _lib.check(rc, "df3d_ffn_fused")
+    return out
+
+
 def actr_prep(q, qi, pos):
     """A = q + pos, Bw = (q + pos) + (qi + pos) in one pass."""
     lib = _lib.load()

@@ -308,6 +308,20 @@ int df3d_groupnorm_fold(const double *moments, const float *b, const float *gamm
                         int N, int S, int C, int groups, const float *W, const float *wb, int O, float *Wf,
                         float *cf, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused feed-forward block of the encoder layer (csrc/ffn.hip):
+ *   out = LayerNorm(residual + W2 relu(W1 x + b1) + b2)     (actr_transformer.py:413-424: linear1/activation/
+ *   linear2/dropout/norm of either query stream; nn.Linear weights W1 [d_ffn, d_model], W2 [d_model, d_ffn])
+ * in one kernel on the bf16 matrix cores with split-precision operands (~1e-5 relative error); the hidden
+ * activation stays in registers.  Serves d_model == 128, d_ffn % 128 == 0 (df3d_ffn_packed_bytes returns 0
+ * otherwise).  residual / ln_weight+ln_bias may be NULL (no residual / no normalisation).
+ * ---------------------------------------------------------------------------------- */
+size_t df3d_ffn_packed_bytes(int d_model, int d_ffn);
+int df3d_ffn_pack(const float *w1, const float *w2, int d_model, int d_ffn, void *packed, void *stream);
+int df3d_ffn_fused(const float *x, long long rows, int d_model, int d_ffn, const void *packed, const float *b1,
+                   const float *b2, const float *residual, const float *ln_weight, const float *ln_bias, float eps,
+                   float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -388,6 +388,32 @@ def test_groupnorm_fold(dev, gated):
     torch.testing.assert_close(y1, y0, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("rows,H,ln,res", [(1000, 1024, True, True), (37, 256, True, False), (130, 128, False, True),
+                                            (31000, 1024, True, True)])
+def test_ffn_fused(dev, rows, H, ln, res):
+    """LayerNorm(x + W2 relu(W1 x + b1) + b2) in one split-precision kernel against the float64 composition
+    (actr_transformer.py:413-424); 5e-5 of the output scale (parity bar 1e-3)."""
+    from dualfusion import ops
+    g = torch.Generator(device="cpu").manual_seed(rows + H)
+    C = 128
+    x = (torch.randn(rows, C, generator=g) * 1.3).to(dev)
+    w1 = (torch.randn(H, C, generator=g) / C ** 0.5).to(dev)
+    w2 = (torch.randn(C, H, generator=g) / H ** 0.5).to(dev)
+    b1, b2 = torch.randn(H, generator=g).to(dev) * 0.3, torch.randn(C, generator=g).to(dev) * 0.3
+    lw, lb = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    packed = ops.ffn_pack(w1, w2)
+    y = ops.ffn_fused(x, packed, b1, b2, H, residual=x if res else None, ln_weight=lw if ln else None,
+                      ln_bias=lb if ln else None, eps=1e-5)
+    xd = x.double()
+    ref = torch.relu(xd @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    if res:
+        ref = ref + xd
+    if ln:
+        ref = torch.nn.functional.layer_norm(ref, (C,), lw.double(), lb.double(), 1e-5)
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err < 5e-5, err
+
+
 def test_msda_linearity_at_full_size(dev):
     """BASELINE config 2 size (6 cams, 150x267 map, Q=8000): linear in value and in the weights."""
     from dualfusion import ops

@@ -53,3 +53,16 @@ try:
 except Exception as e:  # noqa
     print("no _addmm_activation:", e)
 bench("FFN linear2 31000x1024 -> 128", lambda: torch.nn.functional.linear(h, W2, b2), 2.0 * 31000 * 128 * 1024)
+
+# ---- fused split-precision FFN (csrc/ffn.hip) vs the two hipBLASLt GEMMs + ReLU + add + LayerNorm
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-dual-fusion_amd")]
+from dualfusion import ops  # noqa: E402
+lw, lb = torch.randn(128, device=dev), torch.randn(128, device=dev)
+packed = ops.ffn_pack(W1, W2)
+fl = 4.0 * 31000 * 128 * 1024
+bench("FFN fused kernel (split precision)", lambda: ops.ffn_fused(x, packed, b1, b2, 1024, residual=x, ln_weight=lw,
+                                                                  ln_bias=lb), fl)
+bench("FFN torch: addmm_act + linear + add + LN", lambda: torch.nn.functional.layer_norm(
+    x + torch.nn.functional.linear(torch._addmm_activation(b1, x, W1.t()), W2, b2), (128,), lw, lb), fl)
