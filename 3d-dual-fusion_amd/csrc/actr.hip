@@ -225,15 +225,38 @@ __global__ __launch_bounds__(256) void scaled_moments_kernel(const float *__rest
   const int c = blockIdx.x, n = blockIdx.y;
   const float *row = u + (size_t)n * nstride + (size_t)c * cstride;
   const float *ar = a ? a + (size_t)n * S : nullptr;
-  float s1 = 0.f, s2 = 0.f;
+  // 16-byte loads of u over the aligned body of the row (rows start at arbitrary 4-byte offsets), scalar
+  // head/tail; fp32 partials are folded into doubles every 8 vectors
+  const size_t off = ((size_t)(uintptr_t)row >> 2) & 3;     // dwords past a 16-byte boundary
+  const int head = (int)((4 - off) & 3) < S ? (int)((4 - off) & 3) : S;
+  const int nb = (S - head) / 4;
   double d1 = 0.0, d2 = 0.0;
+  float s1 = 0.f, s2 = 0.f;
   int it = 0;
-  for (int p = threadIdx.x; p < S; p += 256) {
-    float v = row[p] * (ar ? ar[p] : 1.f);
-    s1 += v;
-    s2 += v * v;
-    if (++it == 32) {      // fold the fp32 partials into doubles every 32 terms
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    const int p = head + 4 * i;
+    f32x4 v = *(const f32x4 *)(row + p);
+    if (ar) {
+      v[0] *= ar[p];
+      v[1] *= ar[p + 1];
+      v[2] *= ar[p + 2];
+      v[3] *= ar[p + 3];
+    }
+    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    if (++it == 8) {
       d1 += s1; d2 += s2; s1 = s2 = 0.f; it = 0;
+    }
+  }
+  {                                                      // scalar head (< 4 elements) and tail (< 4 elements)
+    const int tail0 = head + 4 * nb;
+    int p = -1;
+    if ((int)threadIdx.x < head) p = threadIdx.x;
+    else if ((int)threadIdx.x - head < S - tail0) p = tail0 + (int)threadIdx.x - head;
+    if (p >= 0) {
+      float v = row[p] * (ar ? ar[p] : 1.f);
+      s1 += v;
+      s2 += v * v;
     }
   }
   d1 += s1; d2 += s2;

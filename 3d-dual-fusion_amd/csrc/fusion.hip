@@ -331,7 +331,8 @@ struct AsmArgs2 {
   const int32_t *ind, *grid;
   const uint8_t *mask;
   const int32_t *pos;
-  const float *img;       // UNGATED image features [B*ncam, Ci, H, W]
+  const float *img;       // UNGATED image features [B*ncam, Ci, H, W] ...
+  const float *const *img_ptrs;   // ... or one [Ci, H, W] map per image (b*ncam + cam), when img is null
   const float *att;       // [B*ncam, H, W] or null
   int n, C, Ci, ncam, H, W, max_ne;
   float *v_feat, *v_i_feat, *qgrid, *qpts, *qpos;   // qpos [B*ncam, max_ne, C] depth sine embedding or null
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void assemble_queries2_kernel(AsmArgs2 a) {
   size_t hw = (size_t)a.H * a.W;
   size_t pix = (size_t)gy * a.W + gx;
   float g = a.att ? a.att[(size_t)img * hw + pix] : 1.f;
-  const float *src = a.img + (size_t)img * a.Ci * hw + pix;
+  const float *src = (a.img ? a.img + (size_t)img * a.Ci * hw : a.img_ptrs[img]) + pix;
   for (int c = lane; c < a.Ci; c += 64) a.v_i_feat[q * a.Ci + c] = src[(size_t)c * hw] * g;
   if (lane == 0) {
     a.qgrid[q * 2 + 0] = (float)gx / (float)a.W;
@@ -376,6 +377,51 @@ __global__ __launch_bounds__(256) void assemble_queries2_kernel(AsmArgs2 a) {
 __global__ __launch_bounds__(256) void qpos_pad_kernel(float *__restrict__ qpos, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) qpos[i] = (i & 1) ? 1.f : 0.f;      // channel count is even, so parity of the flat index = channel parity
+}
+
+// Slot of every voxel inside its (sample, camera) query list = number of visible voxels of the same sample and
+// camera before it; one block per (camera, sample) walks the sample's rows (indices are batch-sorted, as every
+// strided-conv output is) with a ballot/popcount block scan.  counts[b*ncam + cam] = list length.
+__global__ __launch_bounds__(1024) void query_slots_kernel(const uint8_t *__restrict__ mask,
+                                                           const int32_t *__restrict__ ind, int n, int ncam,
+                                                           int32_t *__restrict__ pos, int32_t *__restrict__ counts) {
+  const int cam = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int range[2];
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  if (tid < 2) {          // first row with batch >= b (tid 0) / >= b+1 (tid 1)
+    int key = b + tid, lo = 0, hi = n;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (ind[(size_t)mid * 4] < key) lo = mid + 1;
+      else hi = mid;
+    }
+    range[tid] = lo;
+  }
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  const int r0 = range[0], r1 = range[1];
+  const uint8_t *m = mask + (size_t)cam * n;
+  for (int base = r0; base < r1; base += 1024) {
+    int r = base + tid;
+    bool v = r < r1 && m[r] != 0;
+    unsigned long long bal = __ballot(v);
+    int within = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (r < r1) pos[(size_t)cam * n + r] = off + within;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      carry += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) counts[b * ncam + cam] = carry;
 }
 
 }  // namespace df3d
@@ -411,9 +457,10 @@ extern "C" int df3d_gate_finish(const float *gate, const float *S, const float *
 
 extern "C" int df3d_assemble_queries2(const float *features, const float *point_inv, const int32_t *indices,
                                       const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
-                                      const float *img_feats, const float *att, int n, int channels, int img_channels,
-                                      int batch, int ncam, int H, int W, int max_ne, float *v_feat, float *v_i_feat,
-                                      float *qgrid, float *qpts, float *qpos, void *stream_) {
+                                      const float *img_feats, const float *const *img_ptrs, const float *att, int n,
+                                      int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
+                                      float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
+                                      void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(v_feat && v_i_feat && qgrid && qpts, "assemble_queries2: null output");
   size_t nq = (size_t)batch * ncam * max_ne;
@@ -427,11 +474,25 @@ extern "C" int df3d_assemble_queries2(const float *features, const float *point_
     hipLaunchKernelGGL(qpos_pad_kernel, dim3(cdiv((long long)tot, 256)), dim3(256), 0, stream, qpos, tot);
   }
   if (n == 0 || max_ne == 0) return DF3D_OK;
-  DF3D_CHECK_ARG(features && point_inv && indices && grid_xy && mask && pos && img_feats,
+  DF3D_CHECK_ARG(features && point_inv && indices && grid_xy && mask && pos && (img_feats || img_ptrs),
                  "assemble_queries2: null input");
-  AsmArgs2 a = {features, point_inv, indices, grid_xy, mask, pos, img_feats, att, n, channels, img_channels, ncam, H, W,
+  AsmArgs2 a = {features, point_inv, indices, grid_xy, mask, pos, img_feats, img_ptrs, att, n, channels, img_channels, ncam, H, W,
                 max_ne, v_feat, v_i_feat, qgrid, qpts, qpos};
   hipLaunchKernelGGL(assemble_queries2_kernel, dim3(cdiv((long long)n * ncam * 64, 256)), dim3(256), 0, stream, a);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_query_slots(const uint8_t *mask, const int32_t *indices, int n, int batch, int ncam, int32_t *pos,
+                                int32_t *counts, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(counts && batch > 0 && ncam > 0, "query_slots: bad arguments");
+  if (n == 0) {
+    DF3D_HIP(hipMemsetAsync(counts, 0, (size_t)batch * ncam * sizeof(int32_t), stream));
+    return DF3D_OK;
+  }
+  DF3D_CHECK_ARG(mask && indices && pos, "query_slots: null argument");
+  hipLaunchKernelGGL(query_slots_kernel, dim3(ncam, batch), dim3(1024), 0, stream, mask, indices, n, ncam, pos, counts);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -708,7 +708,8 @@ using namespace df3d;
 
 extern "C" int df3d_conv_tile_count(int n_out, int cin, int cout, int kvol) {
   (void)kvol;
-  // shapes served by the one-workgroup-per-CU kernels (spconv_pair_kernel / spconv_split_kernel)
+  // shapes served by the one-workgroup-per-CU pair-compacted kernels (spconv_pair_kernel, spconv_split_kernel);
+  // the output-stationary kernels cut equal tiles and need no ranges
   bool ok = (cout == 128 && (cin == 128 || cin == 64)) || (cout == 64 && (cin == 64 || cin == 32));
   if (!ok || n_out <= 0) return 0;
   return pair_ntiles(n_out, 128, 128);

@@ -202,6 +202,13 @@ def conv_tiles(nbr, cin, cout):
     """Pair-balanced row ranges for the compute-bound conv kernel (None when not applicable)."""
     lib = _lib.load()
     K, n_out = nbr.shape
+    # only the pair-compacted kernels consume the ranges: the fp32 kernel for cout 128, or the split-precision
+    # pair kernel when DF3D_SPLIT_KERNEL=pair selects it; the output-stationary split kernel cuts equal tiles
+    if conv_split_supported(K, cin, cout):
+        if not os.environ.get("DF3D_SPLIT_KERNEL", "").startswith("p"):
+            return None
+    elif not (int(cout) == 128 and int(cin) in (64, 128)):
+        return None
     nt = lib.df3d_conv_tile_count(int(n_out), int(cin), int(cout), int(K))
     if nt <= 0 or n_out == 0:
         return None
