@@ -475,8 +475,14 @@ class ACTR(nn.Module):
         layers = self.transformer.encoder.layers
         C = gn.num_channels
         N, _, S = u.shape
-        W = torch.cat([l.self_attn.value_proj.weight for l in layers], 0)
-        wb = torch.cat([l.self_attn.value_proj.bias for l in layers], 0)
+        vkey = tuple((l.self_attn.value_proj.weight.data_ptr(), l.self_attn.value_proj.weight._version,
+                      l.self_attn.value_proj.bias._version) for l in layers)
+        hit = getattr(self, "_vcat", None)
+        if hit is None or hit[0] != vkey:
+            hit = (vkey, torch.cat([l.self_attn.value_proj.weight for l in layers], 0).contiguous(),
+                   torch.cat([l.self_attn.value_proj.bias for l in layers], 0).contiguous())
+            object.__setattr__(self, "_vcat", hit)
+        W, wb = hit[1], hit[2]
         Wf, cf = _ops.groupnorm_fold(u, gate, conv.bias, gn, W, wb)
         value = torch.bmm(u[:, :C].transpose(1, 2), Wf.transpose(1, 2))             # [N, S, nlayers*C]
         M = layers[0].self_attn.n_heads
@@ -488,8 +494,13 @@ class ACTR(nn.Module):
                 q_pos = self.q_position_embedding(grid).transpose(1, 2)
             else:
                 q_pos = self.q_position_embedding(lidar_grid[..., 0]).transpose(1, 2)
-        spatial_shapes = torch.as_tensor([hw], dtype=torch.long, device=u.device)
-        level_start_index = spatial_shapes.new_zeros((1,))
+        skey = (int(hw[0]), int(hw[1]), str(u.device))
+        shp = getattr(self, "_shape_cache", None)
+        if shp is None or shp[0] != skey:
+            spatial_shapes = torch.as_tensor([hw], dtype=torch.long, device=u.device)
+            shp = (skey, spatial_shapes, spatial_shapes.new_zeros((1,)))
+            object.__setattr__(self, "_shape_cache", shp)
+        spatial_shapes, level_start_index = shp[1], shp[2]
         return self.transformer.encoder(None, spatial_shapes, level_start_index, None, q_feat=v_feat, q_pos=q_pos,
                                         q_reference_points=grid, q_lidar_grid=lidar_grid, q_i_feat=q_i_feat,
                                         layer_values=layer_values)

@@ -12,7 +12,14 @@ import torch
 from . import _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw hipStream_t of torch's current stream (the C accessor is ~20x cheaper than torch.cuda.current_stream(),
+    which showed up as 15 % of the host time of a step)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
