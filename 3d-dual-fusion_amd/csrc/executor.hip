@@ -1,0 +1,232 @@
+// Native executor for a chain of fused sparse-convolution layers (the sparse 3-D backbones).
+//
+// The reference walks its backbone layer by layer from Python: per layer a rulebook lookup / build, a D2H read
+// of the output count for strided layers, gather/GEMM/scatter launches and separate BN / ReLU / residual passes
+// (CP/det3d/models/backbones/scn.py:97-201, TF/mmdet3d/ops/spconv/conv.py:124-204).  With the fused kernels of
+// this library a layer is one or two launches of 20-90 us, and the HOST became the bottleneck: ~40 us of
+// interpreter work per layer against ~20 us of GPU work (tools/cpu_profile.py).  This executor runs the whole
+// chain from one C call: the layer table is built once from the module tree, every intermediate (features,
+// split rows, neighbour tables, occupancy directories) comes from one caller-provided arena (bump allocation,
+// nothing is freed inside a run), and the only host round trips left are the output counts of the strided
+// layers.  The kernels are exactly the ones the per-layer API launches (the extern "C" entry points below call
+// the same functions), so results are bit-identical to the module path.
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+using namespace df3d;
+
+namespace {
+
+struct IndexSet {
+  const int32_t *indices = nullptr;
+  int n = 0;
+  int shape[3] = {0, 0, 0};
+  void *grid = nullptr;        // occupancy directory (built lazily)
+  size_t grid_bytes = 0;
+  int32_t *perm = nullptr;     // rank -> row (NULL when the rows are sorted by flat index)
+  bool sorted = false;
+};
+
+struct LayerOut {
+  float *features = nullptr;
+  void *split = nullptr;
+  int set = -1;
+  int channels = 0;
+};
+
+struct Bump {
+  char *base;
+  size_t cap, used = 0;
+  bool overflow = false;
+  Bump(void *p, size_t bytes) : base((char *)p), cap(bytes) {}
+  void *take(size_t bytes) {
+    size_t off = align_up(used, 256);
+    used = off + bytes;
+    if (used > cap) {
+      overflow = true;
+      return nullptr;
+    }
+    return base + off;
+  }
+};
+
+int kvol_of(const int *k) { return k[0] * k[1] * k[2]; }
+
+}  // namespace
+
+extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *features, const int32_t *indices,
+                                 int n, int in_channels, int batch, const int *shape, void *arena,
+                                 size_t arena_bytes, df3d_layer_view *views, size_t *arena_used, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(layers && nlayers > 0 && features && indices && shape && arena && views,
+                 "backbone_run: null argument");
+  DF3D_CHECK_ARG(n > 0 && batch > 0, "backbone_run: empty input (n=%d, batch=%d)", n, batch);
+  Bump mem(arena, arena_bytes);
+  std::vector<IndexSet> sets;
+  std::vector<LayerOut> outs(nlayers);
+  std::vector<std::pair<int, const int32_t *>> rulebooks;     // (rulebook id, nbr table)
+  std::vector<int> rulebook_set;                              // index set of the rulebook's outputs
+  IndexSet s0;
+  s0.indices = indices;
+  s0.n = n;
+  memcpy(s0.shape, shape, sizeof(s0.shape));
+  sets.push_back(s0);
+  void *split0 = nullptr;      // split rows of the network input, built on demand
+#define DF3D_ARENA_CHECK(ok)                                                                                   \
+  do {                                                                                                          \
+    if (!(ok)) {                                                                                                \
+      if (arena_used) *arena_used = mem.used;                                                                   \
+      set_error("backbone_run: arena of %zu bytes is too small (needed more than %zu)", arena_bytes, mem.used); \
+      return DF3D_ENOMEM;                                                                                       \
+    }                                                                                                           \
+  } while (0)
+  int32_t *count_dev = (int32_t *)mem.take(256);
+  DF3D_ARENA_CHECK(count_dev);
+
+  for (int li = 0; li < nlayers; ++li) {
+    const df3d_layer &L = layers[li];
+    DF3D_CHECK_ARG(L.input >= -1 && L.input < li && L.residual >= -1 && L.residual < li,
+                   "backbone_run: layer %d reads a later layer", li);
+    const float *in_feat = L.input < 0 ? features : outs[L.input].features;
+    const int in_set = L.input < 0 ? 0 : outs[L.input].set;
+    const int cin = L.input < 0 ? in_channels : outs[L.input].channels;
+    DF3D_CHECK_ARG(cin == L.cin, "backbone_run: layer %d expects %d input channels, gets %d", li, L.cin, cin);
+    const int K = kvol_of(L.ksize);
+    DF3D_CHECK_ARG(K > 0 && K <= DF3D_MAX_KVOL, "backbone_run: layer %d kernel volume %d unsupported", li, K);
+
+    // ---- neighbour table: shared through the rulebook id, or built here ----
+    const int32_t *nbr = nullptr;
+    int out_set = -1, n_out = 0;
+    if (L.rulebook >= 0)
+      for (size_t r = 0; r < rulebooks.size(); ++r)
+        if (rulebooks[r].first == L.rulebook) {
+          nbr = rulebooks[r].second;
+          out_set = rulebook_set[r];
+          DF3D_CHECK_ARG(L.kind != 0 || out_set == in_set,
+                         "backbone_run: layer %d shares rulebook %d but reads another index set", li, L.rulebook);
+        }
+    if (!nbr) {
+      auto ensure_grid = [&](int si) -> int {
+        IndexSet &S = sets[si];
+        if (S.grid) return DF3D_OK;
+        S.grid_bytes = df3d_grid_bytes(batch, S.shape);
+        S.grid = mem.take(S.grid_bytes);
+        if (!S.sorted) S.perm = (int32_t *)mem.take((size_t)S.n * 4);
+        if (!S.grid || (!S.sorted && !S.perm)) return DF3D_ENOMEM;
+        return df3d_grid_build(S.indices, S.n, batch, S.shape, S.grid, S.grid_bytes, S.perm, stream_);
+      };
+      if (L.kind == 0) {                       // submanifold: outputs = inputs
+        int rc = ensure_grid(in_set);
+        DF3D_ARENA_CHECK(rc != DF3D_ENOMEM);
+        if (rc) return rc;
+        const IndexSet &S = sets[in_set];
+        int32_t *t = (int32_t *)mem.take((size_t)K * S.n * 4);
+        DF3D_ARENA_CHECK(t);
+        rc = df3d_subm_neighbors(S.grid, S.perm, S.indices, S.n, batch, S.shape, L.ksize, L.dilation, t, stream_);
+        if (rc) return rc;
+        nbr = t;
+        out_set = in_set;
+      } else {                                 // strided: enumerate the active outputs (one host round trip)
+        const IndexSet S = sets[in_set];
+        IndexSet O;
+        for (int d = 0; d < 3; ++d)
+          O.shape[d] = (S.shape[d] + 2 * L.padding[d] - L.dilation[d] * (L.ksize[d] - 1) - 1) / L.stride[d] + 1;
+        long long fan = 1;
+        for (int d = 0; d < 3; ++d) fan *= (L.ksize[d] + L.stride[d] - 1) / L.stride[d];
+        long long vol = (long long)batch * O.shape[0] * O.shape[1] * O.shape[2];
+        long long cap = (long long)S.n * (fan < K ? fan : K);
+        if (cap > vol) cap = vol;
+        if (cap < 1) cap = 1;
+        O.grid_bytes = df3d_grid_bytes(batch, O.shape);
+        O.grid = mem.take(O.grid_bytes);
+        int32_t *oi = (int32_t *)mem.take((size_t)cap * 16);
+        DF3D_ARENA_CHECK(O.grid && oi);
+        int rc = df3d_conv_out_indices(S.indices, S.n, batch, S.shape, O.shape, L.ksize, L.stride, L.padding,
+                                       L.dilation, O.grid, O.grid_bytes, oi, (int)cap, count_dev, stream_);
+        if (rc) return rc;
+        int32_t cnt = 0;
+        DF3D_HIP(hipMemcpyAsync(&cnt, count_dev, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+        DF3D_HIP(hipStreamSynchronize(stream));
+        if (cnt > cap) {
+          set_error("backbone_run: layer %d produced %d outputs, capacity bound %lld", li, cnt, cap);
+          return DF3D_EINVAL;
+        }
+        if (cnt <= 0) {
+          set_error("backbone_run: layer %d has no active outputs", li);
+          return DF3D_EINVAL;
+        }
+        O.indices = oi;
+        O.n = cnt;
+        O.sorted = true;
+        sets.push_back(O);
+        out_set = (int)sets.size() - 1;
+        rc = ensure_grid(in_set);
+        DF3D_ARENA_CHECK(rc != DF3D_ENOMEM);
+        if (rc) return rc;
+        const IndexSet &Sg = sets[in_set];
+        int32_t *t = (int32_t *)mem.take((size_t)K * cnt * 4);
+        DF3D_ARENA_CHECK(t);
+        rc = df3d_conv_neighbors(Sg.grid, Sg.perm, oi, cnt, batch, Sg.shape, L.ksize, L.stride, L.padding, L.dilation,
+                                 t, stream_);
+        if (rc) return rc;
+        nbr = t;
+      }
+      rulebooks.push_back(std::make_pair(L.rulebook, nbr));
+      rulebook_set.push_back(out_set);
+    }
+    n_out = sets[out_set].n;
+    const int n_in = sets[in_set].n;
+
+    // ---- the fused convolution ----
+    LayerOut &o = outs[li];
+    o.set = out_set;
+    o.channels = L.cout;
+    o.features = (float *)mem.take((size_t)n_out * L.cout * 4);
+    DF3D_ARENA_CHECK(o.features);
+    const float *res = L.residual < 0 ? nullptr : outs[L.residual].features;
+    if (L.residual >= 0)
+      DF3D_CHECK_ARG(outs[L.residual].set == out_set && outs[L.residual].channels == L.cout,
+                     "backbone_run: residual of layer %d lives on another index set", li);
+    if (L.packed && df3d_conv_packed_weight_bytes(K, L.cin, L.cout) != 0) {
+      void **in_split = L.input < 0 ? &split0 : &outs[L.input].split;
+      if (!*in_split) {
+        *in_split = mem.take((size_t)n_in * L.cin * 4);
+        DF3D_ARENA_CHECK(*in_split);
+        int rc = df3d_split_rows(in_feat, n_in, L.cin, *in_split, stream_);
+        if (rc) return rc;
+      }
+      o.split = mem.take((size_t)n_out * L.cout * 4);
+      DF3D_ARENA_CHECK(o.split);
+      int rc = df3d_sparse_conv_split(*in_split, n_in, L.cin, L.packed, K, L.cout, nbr, n_out, L.bias, L.scale, L.shift,
+                                      res, L.relu, o.features, o.split, nullptr, 0, stream_);
+      if (rc) return rc;
+    } else {
+      int rc = df3d_sparse_conv_fused(in_feat, n_in, L.cin, L.weight, K, L.cout, nbr, n_out, L.bias, L.scale, L.shift,
+                                      res, L.relu, o.features, stream_);
+      if (rc) return rc;
+    }
+    df3d_layer_view &v = views[li];
+    const IndexSet &OS = sets[out_set];
+    v.features = o.features;
+    v.split = o.split;
+    v.indices = OS.indices;
+    v.grid = OS.grid;          // may still be NULL: directories are built when a later layer needs them
+    v.grid_bytes = OS.grid_bytes;
+    v.n = OS.n;
+    v.channels = L.cout;
+    v.rows_sorted = OS.sorted ? 1 : 0;
+    memcpy(v.shape, OS.shape, sizeof(v.shape));
+  }
+  // directories may have been built after a view was written: refresh
+  for (int li = 0; li < nlayers; ++li) {
+    const IndexSet &OS = sets[outs[li].set];
+    views[li].grid = OS.grid;
+    views[li].grid_bytes = OS.grid_bytes;
+  }
+  if (arena_used) *arena_used = mem.used;
+  return DF3D_OK;
+#undef DF3D_ARENA_CHECK
+}

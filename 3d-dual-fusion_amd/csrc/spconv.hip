@@ -659,7 +659,19 @@ __global__ __launch_bounds__(256) void conv_tiles_kernel(const uint32_t *__restr
 struct TimingRec {
   hipEvent_t e0, e1;
   int cin, cout, kvol, n_out;
+  long long pairs;       // valid rulebook entries, counted only in pair-count mode (df3d_timing_count_pairs)
+  int split;             // 1 = split-precision kernel
 };
+static bool g_timing_pairs = false;
+static unsigned long long *g_pair_counter = nullptr;
+
+__global__ __launch_bounds__(256) void count_valid_kernel(const int32_t *__restrict__ nbr, size_t n,
+                                                          unsigned long long *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool v = i < n && nbr[i] >= 0;
+  unsigned long long b = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
+}
 static bool g_timing_on = false;
 static std::vector<TimingRec> g_timing;
 static std::vector<hipEvent_t> g_event_pool;
@@ -675,10 +687,24 @@ static hipEvent_t timing_event() {
   return e;
 }
 
-int timing_rec_begin(int cin, int cout, int kvol, int n_out, hipStream_t stream) {
+int timing_rec_begin(int cin, int cout, int kvol, int n_out, const int32_t *nbr, int split, hipStream_t stream) {
   if (!g_timing_on) return -1;
-  TimingRec r = {timing_event(), timing_event(), cin, cout, kvol, n_out};
+  TimingRec r = {timing_event(), timing_event(), cin, cout, kvol, n_out, -1, split};
   if (!r.e0 || !r.e1) return -1;
+  if (g_timing_pairs && nbr) {
+    // metadata pass (never inside a timed region): count the valid (output, offset) pairs of this launch
+    if (!g_pair_counter && hipMalloc((void **)&g_pair_counter, 8) != hipSuccess) g_pair_counter = nullptr;
+    if (g_pair_counter) {
+      size_t tot = (size_t)kvol * n_out;
+      unsigned long long h = 0;
+      (void)hipMemsetAsync(g_pair_counter, 0, 8, stream);
+      hipLaunchKernelGGL(count_valid_kernel, dim3(cdiv((long long)tot, 256)), dim3(256), 0, stream, nbr, tot,
+                         g_pair_counter);
+      (void)hipMemcpyAsync(&h, g_pair_counter, 8, hipMemcpyDeviceToHost, stream);
+      (void)hipStreamSynchronize(stream);
+      r.pairs = (long long)h;
+    }
+  }
   (void)hipEventRecord(r.e0, stream);
   g_timing.push_back(r);
   return (int)g_timing.size() - 1;
@@ -790,7 +816,7 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
   a.cin = cin;
   a.cout = cout;
   a.relu = relu;
-  const int trec = timing_rec_begin(cin, cout, kvol, n_out, stream);
+  const int trec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 0, stream);
   bool done = false;
   // compute-bound shapes: pair-compacted kernel (DF3D_SPCONV_V1=1 forces the output-stationary kernel)
   static const bool use_v2 = getenv("DF3D_SPCONV_V1") == nullptr;
@@ -822,6 +848,25 @@ extern "C" int df3d_timing_begin(void) {
   }
   g_timing.clear();
   g_timing_on = true;
+  return DF3D_OK;
+}
+
+extern "C" int df3d_timing_count_pairs(int on) {
+  g_timing_pairs = on != 0;
+  return DF3D_OK;
+}
+
+extern "C" int df3d_timing_get2(int i, int *shape4, float *ms, long long *pairs, int *split) {
+  DF3D_CHECK_ARG(i >= 0 && i < (int)g_timing.size() && shape4 && ms && pairs && split, "timing_get2: bad index");
+  const TimingRec &r = g_timing[i];
+  DF3D_HIP(hipEventSynchronize(r.e1));
+  DF3D_HIP(hipEventElapsedTime(ms, r.e0, r.e1));
+  shape4[0] = r.cin;
+  shape4[1] = r.cout;
+  shape4[2] = r.kvol;
+  shape4[3] = r.n_out;
+  *pairs = r.pairs;
+  *split = r.split;
   return DF3D_OK;
 }
 

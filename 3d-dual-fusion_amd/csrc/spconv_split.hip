@@ -32,7 +32,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-int timing_rec_begin(int cin, int cout, int kvol, int n_out, hipStream_t stream);   // spconv.hip
+int timing_rec_begin(int cin, int cout, int kvol, int n_out, const int32_t *nbr, int split,
+                     hipStream_t stream);   // spconv.hip
 void timing_rec_end(int rec, hipStream_t stream);
 
 __device__ __forceinline__ unsigned bf16_bits(float x) {   // round to nearest even; finite inputs
@@ -745,7 +746,7 @@ extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int 
   SplitConvArgs a = {(const u32x4 *)features_split, (const u32x4 *)packed_filters, nbr, bias, scale, shift, residual,
                      out, (u32x4 *)out_split, n_in, n_out, kvol, relu,
                      getenv("DF3D_OS_DBG") ? atoi(getenv("DF3D_OS_DBG")) : 0};
-  int rec = timing_rec_begin(cin, cout, kvol, n_out, stream);
+  int rec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 1, stream);
   int rc;
   if (split_layout(cin, cout) == 1) {
     if (cout == 128) rc = cin == 128 ? launch_os_split<128, 128>(a, stream) : launch_os_split<64, 128>(a, stream);

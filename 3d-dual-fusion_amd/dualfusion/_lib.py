@@ -79,6 +79,10 @@ SIGNATURES = {
     "df3d_ffn_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "df3d_ffn_fused": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_float, c_void_p, c_void_p]),
+    "df3d_timing_count_pairs": (c_int, [c_int]),
+    "df3d_timing_get2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_backbone_run": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_size_t, c_void_p, c_void_p, c_void_p]),
     "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,
                                    c_void_p]),
@@ -96,6 +100,9 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+DF3D_OK, DF3D_EINVAL, DF3D_ENOMEM, DF3D_EHIP = 0, -1, -2, -3      # include/df3d_hip.h
 
 
 class Df3dError(RuntimeError):

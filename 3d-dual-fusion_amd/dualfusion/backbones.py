@@ -6,6 +6,8 @@ CenterPoint:  SpMiddleResNetFHD / SpMiddleResNetFHDFusion  (CP/det3d/models/back
 TransFusion:  SparseEncoder / SparseEncoderFusion          (TF/mmdet3d/models/middle_encoders/sparse_encoder.py)
 Voxel-RCNN:   VoxelBackBone8x / VoxelBackBone8xFusion      (VR/pcdet/models/backbones_3d/spconv_backbone.py)
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -125,9 +127,29 @@ class SpMiddleResNetFHD(nn.Module):
             build_norm_layer(norm_cfg, 128)[1],
             nn.ReLU())
 
+    def _plan(self):
+        """Native executor plan of the conv chain (dualfusion/executor.py) for inference; None -> module path."""
+        if self.training or os.environ.get("DF3D_EXECUTOR", "1") != "1":
+            return None
+        plan = getattr(self, "_exec_plan", False)
+        if plan is False:
+            from .executor import compile_stages
+            plan = compile_stages([("conv_input", self.conv_input), ("conv1", self.conv1), ("conv2", self.conv2),
+                                   ("conv3", self.conv3), ("conv4", self.conv4)])
+            object.__setattr__(self, "_exec_plan", plan)
+        return plan
+
+    def train(self, mode=True):
+        object.__setattr__(self, "_exec_plan", False)
+        return super(SpMiddleResNetFHD, self).train(mode)
+
     def _stem(self, voxel_features, coors, batch_size, input_shape):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
         coors = coors.int()
+        plan = self._plan() if voxel_features.is_cuda and not torch.is_grad_enabled() else None
+        if plan is not None and voxel_features.shape[0] > 0:
+            out = plan.run(voxel_features, coors, batch_size, [int(v) for v in sparse_shape])
+            return out["conv1"], out["conv2"], out["conv3"], out["conv4"]
         ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape, batch_size)
         x = self.conv_input(ret)
         x_conv1 = self.conv1(x)

@@ -1,0 +1,222 @@
+"""Native execution of a sparse backbone's convolution chain (csrc/executor.hip, df3d_backbone_run).
+
+The module tree stays the API (same classes, parameter names and checkpoints as the reference); for inference the
+chain of SparseSequential / SubMConv3d / SparseConv3d / BatchNorm1d / ReLU / basic-block modules is flattened once
+into a layer table and every forward is ONE native call instead of ~40 us of interpreter work per layer.  Anything
+the table cannot express (training mode, 1x1 convs, down-sampled residuals, unknown modules) makes `compile`
+return None and the caller keeps the per-module path; both paths launch the same kernels, so the outputs are
+bit-identical."""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from . import ops as _ops
+from .spconv.conv import SparseConvolution
+from .spconv.modules import SparseSequential, can_fold, fold_batchnorm
+from .spconv.structure import SparseConvTensor
+
+
+class _Layer(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("input", ctypes.c_int), ("residual", ctypes.c_int),
+                ("rulebook", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int),
+                ("ksize", ctypes.c_int * 3), ("stride", ctypes.c_int * 3), ("padding", ctypes.c_int * 3),
+                ("dilation", ctypes.c_int * 3), ("relu", ctypes.c_int), ("reserved", ctypes.c_int),
+                ("weight", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p)]
+
+
+class _View(ctypes.Structure):
+    _fields_ = [("features", ctypes.c_void_p), ("split", ctypes.c_void_p), ("indices", ctypes.c_void_p),
+                ("grid", ctypes.c_void_p), ("grid_bytes", ctypes.c_size_t), ("n", ctypes.c_int),
+                ("channels", ctypes.c_int), ("rows_sorted", ctypes.c_int), ("shape", ctypes.c_int * 3)]
+
+
+class Unsupported(Exception):
+    pass
+
+
+class _Spec(object):
+    """One fused layer: conv + optional folded BN + optional residual + optional ReLU."""
+
+    def __init__(self, conv, bn, relu, inp, residual, rulebook):
+        self.conv, self.bn, self.relu, self.input, self.residual, self.rulebook = conv, bn, relu, inp, residual, rulebook
+
+
+def _is_basic_block(m):
+    return all(hasattr(m, a) for a in ("conv1", "bn1", "conv2", "bn2")) and hasattr(m, "downsample")
+
+
+class BackbonePlan(object):
+    def __init__(self, stages):
+        """stages: list of (name, module); the output of every stage is exported under its name."""
+        self.specs = []
+        self.exports = {}
+        self._keys = {}
+        self._set = 0              # index-set counter (changes at every strided conv)
+        cur = -1
+        for name, module in stages:
+            cur = self._walk(module, cur)
+            self.exports[name] = cur
+        self._table = None
+        self._sig = None
+        self._keep = None
+        self._arena_bytes = 256 << 20
+
+    # ---------------------------------------------------------------- module tree -> layer specs
+    def _rulebook_id(self, conv):
+        if conv.subm:
+            key = ("subm", conv.indice_key if conv.indice_key is not None else ("auto", self._set),
+                   tuple(conv.kernel_size), tuple(conv.dilation))
+        else:
+            if conv.indice_key is None:
+                return -1
+            key = ("sparse", conv.indice_key)
+        return self._keys.setdefault(key, len(self._keys))
+
+    def _add(self, conv, bn, relu, inp, residual):
+        if not isinstance(conv, SparseConvolution) or conv.ndim != 3 or conv.conv1x1 or conv.inverse \
+                or conv.transposed or conv.training:
+            raise Unsupported("conv %r" % (conv,))
+        if bn is not None and not can_fold(bn):
+            raise Unsupported("BatchNorm in training mode")
+        rb = self._rulebook_id(conv)
+        self.specs.append(_Spec(conv, bn, relu, inp, residual, rb))
+        if not conv.subm:
+            self._set += 1
+        return len(self.specs) - 1
+
+    def _walk(self, m, cur):
+        if isinstance(m, SparseSequential):
+            mods = list(m._modules.values())
+            i = 0
+            while i < len(mods):
+                c = mods[i]
+                if isinstance(c, SparseConvolution):
+                    bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+                    j = i + (2 if bn is not None else 1)
+                    relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+                    cur = self._add(c, bn, relu, cur, -1)
+                    i = j + (1 if relu else 0)
+                elif isinstance(c, (nn.Identity, nn.Dropout)):
+                    i += 1
+                else:
+                    cur = self._walk(c, cur)
+                    i += 1
+            return cur
+        if _is_basic_block(m):
+            if m.downsample is not None:
+                raise Unsupported("basic block with a downsample branch")
+            a = self._add(m.conv1, m.bn1, True, cur, -1)
+            if cur < 0:
+                raise Unsupported("basic block on the network input")
+            return self._add(m.conv2, m.bn2, True, a, cur)
+        if isinstance(m, SparseConvolution):
+            return self._add(m, None, False, cur, -1)
+        raise Unsupported("module %s" % type(m).__name__)
+
+    # ---------------------------------------------------------------- layer specs -> C table
+    def _signature(self):
+        sig = []
+        for s in self.specs:
+            sig.append((s.conv.weight.data_ptr(), s.conv.weight._version))
+            if s.bn is not None:
+                sig.append((s.bn.running_var.data_ptr(), s.bn.running_var._version, s.bn.weight._version))
+        return tuple(sig), _ops.CONV_PRECISION
+
+    def _build_table(self):
+        n = len(self.specs)
+        table = (_Layer * n)()
+        keep = []
+        for i, s in enumerate(self.specs):
+            c = s.conv
+            L = table[i]
+            L.kind = 0 if c.subm else 1
+            L.input, L.residual, L.rulebook = s.input, s.residual, s.rulebook
+            L.cin, L.cout = c.in_channels, c.out_channels
+            for d in range(3):
+                L.ksize[d], L.stride[d] = int(c.kernel_size[d]), int(c.stride[d])
+                L.padding[d], L.dilation[d] = int(c.padding[d]), int(c.dilation[d])
+            if c.subm:                       # SubM geometry: stride 1, pad = k/2 whatever the module was given
+                for d in range(3):
+                    L.stride[d], L.padding[d] = 1, int(c.kernel_size[d]) // 2
+            L.relu = int(bool(s.relu))
+            K = int(c.kernel_size[0] * c.kernel_size[1] * c.kernel_size[2])
+            w = c.weight.detach().contiguous().view(K, c.in_channels, c.out_channels)
+            if w.dtype != torch.float32:
+                raise Unsupported("non-fp32 weights")
+            keep.append(w)
+            L.weight = w.data_ptr()
+            L.packed = None
+            if _ops.conv_split_supported(K, c.in_channels, c.out_channels):
+                p = c._packed_weight(c.weight.detach(), K)
+                keep.append(p)
+                L.packed = p.data_ptr()
+            if c.bias is not None:
+                L.bias = c.bias.detach().data_ptr()
+            if s.bn is not None:
+                scale, shift = fold_batchnorm(s.bn)
+                keep += [scale, shift]
+                L.scale, L.shift = scale.data_ptr(), shift.data_ptr()
+        self._table, self._keep = table, keep
+
+    # ---------------------------------------------------------------- run
+    def run(self, features, coors, batch_size, spatial_shape):
+        """-> {stage name: SparseConvTensor} whose tensors are views into one arena."""
+        lib = _lib.load()
+        sig = self._signature()
+        if self._table is None or sig != self._sig:
+            self._build_table()
+            self._sig = sig
+        feats = features.contiguous()
+        if feats.dtype != torch.float32:
+            feats = feats.float()
+        coors = coors.contiguous()
+        n = feats.shape[0]
+        nl = len(self.specs)
+        views = (_View * nl)()
+        used = ctypes.c_size_t(0)
+        shp = (ctypes.c_int * 3)(*[int(v) for v in spatial_shape])
+        while True:
+            arena = torch.empty((self._arena_bytes,), dtype=torch.uint8, device=feats.device)
+            rc = lib.df3d_backbone_run(self._table, nl, _ops._ptr(feats), _ops._ptr(coors), n, feats.shape[1],
+                                       int(batch_size), shp, _ops._ptr(arena), self._arena_bytes, views,
+                                       ctypes.byref(used), _ops._stream())
+            if rc == _lib.DF3D_ENOMEM and self._arena_bytes < (64 << 30):
+                self._arena_bytes *= 2
+                continue
+            _lib.check(rc, "df3d_backbone_run")
+            break
+        base = arena.data_ptr()
+
+        def view(ptr, nbytes, dtype, shape):
+            off = ptr - base
+            return arena[off:off + nbytes].view(dtype).view(shape)
+
+        out, idict, dirs = {}, {}, {}
+        for name, li in self.exports.items():
+            v = views[li]
+            f = view(v.features, v.n * v.channels * 4, torch.float32, (v.n, v.channels))
+            # SubM stages of the first index set keep the caller's index tensor
+            ind = coors if v.indices == coors.data_ptr() else view(v.indices, v.n * 16, torch.int32, (v.n, 4))
+            t = SparseConvTensor(f, ind, [v.shape[0], v.shape[1], v.shape[2]], batch_size)
+            t.indice_dict, t._directories = idict, dirs
+            if v.split:
+                t._split = (f, view(v.split, v.n * v.channels * 4, torch.uint8, (v.n, v.channels * 4)))
+            if v.grid and v.rows_sorted:
+                # the occupancy directory the executor built is handed to the module path (e.g. a conv that runs
+                # after a fusion step): SparseConvTensor.directory() finds it by the identity of `indices`
+                blob = view(v.grid, v.grid_bytes, torch.uint8, (v.grid_bytes,))
+                dirs[(ind.data_ptr(), ind.shape[0])] = _ops.GridDirectory(blob, None, batch_size,
+                                                                          list(t.spatial_shape))
+            out[name] = t
+        return out
+
+
+def compile_stages(stages):
+    """BackbonePlan for [(name, module), ...] or None when the chain cannot be expressed."""
+    try:
+        return BackbonePlan(stages)
+    except Unsupported:
+        return None

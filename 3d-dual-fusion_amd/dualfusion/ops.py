@@ -173,32 +173,36 @@ def pairs_to_nbr(indice_pairs, indice_num, n_out):
 
 # ------------------------------------------------------------------------- sparse conv
 class KernelTimer(object):
-    """Per-launch timing of the sparse-conv kernels for bench.py's roofline leg.  The HIP events are
-    recorded inside libdf3d_hip.so right around the kernel launch on the launching stream
-    (df3d_timing_*); this object keeps the matching per-call metadata (neighbour table, sizes)."""
+    """Per-launch timing of the sparse-conv kernels for bench.py's roofline leg.  The HIP events are recorded
+    inside libdf3d_hip.so right around the kernel launch on the launching stream (df3d_timing_*), whether the
+    launch comes from the per-layer API or from the native executor.  `count_pairs=True` is the metadata mode for
+    an extra pass OUTSIDE the timed region: each launch also reports its valid rulebook pairs."""
 
-    def __init__(self):
-        self.meta = []
-        self.records = []   # (key, ms, meta) after stop()
+    def __init__(self, count_pairs=False):
+        self.count_pairs = count_pairs
+        self.records = []   # dicts: cin, cout, kvol, n_out, ms, pairs, split
 
     def start(self):
-        _lib.load().df3d_timing_begin()
+        lib = _lib.load()
+        lib.df3d_timing_count_pairs(1 if self.count_pairs else 0)
+        lib.df3d_timing_begin()
 
-    def note(self, key, meta):
-        self.meta.append((key, meta))
+    def note(self, key, meta):      # kept for callers of the older interface
+        pass
 
     def stop(self):
         lib = _lib.load()
         n = lib.df3d_timing_end()
+        lib.df3d_timing_count_pairs(0)
         shape = (ctypes.c_int * 4)()
         ms = ctypes.c_float()
-        assert n == len(self.meta), (n, len(self.meta))
+        pairs = ctypes.c_longlong()
+        split = ctypes.c_int()
         for i in range(n):
-            _lib.check(lib.df3d_timing_get(i, ctypes.cast(shape, ctypes.c_void_p),
-                                           ctypes.cast(ctypes.pointer(ms), ctypes.c_void_p)), "df3d_timing_get")
-            key, meta = self.meta[i]
-            assert (shape[0], shape[1], shape[2]) == key[1:], (tuple(shape), key)
-            self.records.append((key, float(ms.value), meta))
+            _lib.check(lib.df3d_timing_get2(i, ctypes.cast(shape, ctypes.c_void_p), ctypes.addressof(ms),
+                                            ctypes.addressof(pairs), ctypes.addressof(split)), "df3d_timing_get2")
+            self.records.append(dict(cin=shape[0], cout=shape[1], kvol=shape[2], n_out=shape[3], ms=float(ms.value),
+                                     pairs=int(pairs.value), split=int(split.value)))
         return self.records
 
 

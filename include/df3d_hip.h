@@ -153,6 +153,12 @@ int df3d_sparse_conv_fused_tiled(const float *features, int n_in, int cin,
 int df3d_timing_begin(void);
 int df3d_timing_end(void);
 int df3d_timing_get(int i, int *shape4_host, float *ms_host);
+/* df3d_timing_count_pairs(1): metadata mode for a pass OUTSIDE any timed region -- every recorded launch also
+ * counts its valid (output row, offset) pairs R (one extra kernel + a D2H read per launch), which is what the
+ * algorithmic bytes / flops of SURVEY.md section 8(d) are stated in.  df3d_timing_get2 returns R (-1 when it was
+ * not counted) and whether the split-precision kernel served the launch. */
+int df3d_timing_count_pairs(int on);
+int df3d_timing_get2(int i, int *shape4, float *ms, long long *pairs, int *split);
 
 /* SparseConvTensor.dense() (TF/mmdet3d/ops/spconv/structure.py:5-18,55-64): zero-fill +
  * scatter + permute fused; out [B, C, D, H, W] f32 (the backbones view it as [B, C*D, H, W]). */
@@ -328,6 +334,45 @@ int df3d_ffn_pack(const float *w1, const float *w2, int d_model, int d_ffn, void
 int df3d_ffn_fused(const float *x, long long rows, int d_model, int d_ffn, const void *packed, const float *b1,
                    const float *b2, const float *residual, const float *ln_weight, const float *ln_bias, float eps,
                    float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Native executor for a chain of fused sparse-convolution layers (csrc/executor.hip): the sparse backbones'
+ * forward (CP/det3d/models/backbones/scn.py:97-201; TF/mmdet3d/models/middle_encoders/sparse_encoder.py;
+ * VR/pcdet/models/backbones_3d/spconv_backbone.py) as one call.  Rulebooks, occupancy directories, features
+ * and split rows of every layer are bump-allocated from `arena`; DF3D_ENOMEM (with *arena_used = bytes needed
+ * so far) asks for a larger one.  Each layer is conv -> (+bias)*scale+shift -> +residual -> ReLU, i.e. the
+ * reference's conv / BatchNorm(eval) / residual add / ReLU group.
+ *   kind      0 = SubMConv3d (outputs = inputs), 1 = SparseConv3d (strided; one D2H read of the output count)
+ *   input     index of the producing layer, -1 = the network input
+ *   residual  layer whose output features are added in the epilogue, -1 = none
+ *   rulebook  layers with the same id >= 0 share one neighbour table (the reference's indice_key); -1 = private
+ *   packed    split-precision filter bank (df3d_conv_pack_weights) or NULL for the exact fp32 kernels
+ * views[i] describes layer i's output inside the arena (grid = its occupancy directory when one was built).
+ * ---------------------------------------------------------------------------------- */
+typedef struct df3d_layer {
+  int kind, input, residual, rulebook;
+  int cin, cout;
+  int ksize[3], stride[3], padding[3], dilation[3];
+  int relu;
+  int reserved;
+  const float *weight;   /* [kvol][cin][cout] fp32 */
+  const void *packed;
+  const float *bias, *scale, *shift;
+} df3d_layer;
+
+typedef struct df3d_layer_view {
+  float *features;
+  void *split;
+  const int32_t *indices;
+  void *grid;
+  size_t grid_bytes;
+  int n, channels, rows_sorted;
+  int shape[3];
+} df3d_layer_view;
+
+int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *features, const int32_t *indices, int n,
+                      int in_channels, int batch, const int *shape_host, void *arena, size_t arena_bytes,
+                      df3d_layer_view *views, size_t *arena_used, void *stream);
 
 #ifdef __cplusplus
 }
