@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256) void conv_mark_kernel(const int32_t *__restric
     if (o[d] >= cg.out_shape[d]) return;
   }
   long long flat = (long long)p[0] * out_vol + ((long long)o[0] * cg.out_shape[1] + o[1]) * cg.out_shape[2] + o[2];
-  atomicOr(&bits[flat >> 6], 1ull << (flat & 63));
+  // an output is marked by ~4 inputs on average: look before the (same-address, serialised) atomic
+  const unsigned long long m = 1ull << (flat & 63);
+  if (!(__builtin_nontemporal_load(&bits[flat >> 6]) & m)) atomicOr(&bits[flat >> 6], m);
 }
 
 // one thread per 64-cell word: emit the coordinates of its set bits at prefix[word]...
@@ -129,24 +131,32 @@ __global__ __launch_bounds__(256) void grid_enumerate_kernel(GridView g, unsigne
   unsigned long long bits = g.bits[w];
   if (!bits) return;
   uint32_t r = g.prefix[w];
-  long long yx = (long long)g.shape[1] * g.shape[2];
+  // decode the word's first cell once (the only divisions), then walk the set bits with carries
+  const long long flat0 = (long long)(w << 6);
+  const long long yx = (long long)g.shape[1] * g.shape[2];
+  int bb = (int)(flat0 / g.vol);
+  long long rem = flat0 - (long long)bb * g.vol;
+  int z = (int)(rem / yx);
+  rem -= (long long)z * yx;
+  int y = (int)(rem / g.shape[2]);
+  int x = (int)(rem - (long long)y * g.shape[2]);
+  int prev = 0;
   while (bits) {
     int b = __ffsll((long long)bits) - 1;
     bits &= bits - 1;
-    long long flat = (long long)(w << 6) + b;
-    if ((int)r < cap) {
-      int bb = (int)(flat / g.vol);
-      long long rem = flat - (long long)bb * g.vol;
-      int z = (int)(rem / yx);
-      rem -= (long long)z * yx;
-      int y = (int)(rem / g.shape[2]);
-      int x = (int)(rem - (long long)y * g.shape[2]);
-      int32_t *q = out_ind + (size_t)r * 4;
-      q[0] = bb;
-      q[1] = z;
-      q[2] = y;
-      q[3] = x;
+    x += b - prev;
+    prev = b;
+    while (x >= g.shape[2]) {
+      x -= g.shape[2];
+      if (++y == g.shape[1]) {
+        y = 0;
+        if (++z == g.shape[0]) {
+          z = 0;
+          ++bb;
+        }
+      }
     }
+    if ((int)r < cap) *(int4 *)(out_ind + (size_t)r * 4) = make_int4(bb, z, y, x);
     ++r;
   }
 }

@@ -200,9 +200,21 @@ class VoxelWithPointProjection(nn.Module):
         else:
             wcat = w_ip
         S_pix = inp['h'] * inp['w']
+        # The camera network runs the cameras as one batch, so the per-camera dict entries are normally views of one
+        # tensor at a uniform stride: then the projection is a single batched GEMM over that storage (still no copy).
+        # Unrelated buffers get one GEMM per map.
+        Ci = imgs[0].shape[0]
+        p0 = imgs[0].data_ptr()
+        step = (imgs[1].data_ptr() - p0) if len(imgs) > 1 else Ci * S_pix * 4
+        store = imgs[0].untyped_storage().data_ptr()
+        if step >= Ci * S_pix * 4 and step % 4 == 0 and all(
+                f.untyped_storage().data_ptr() == store and f.data_ptr() == p0 + i * step
+                for i, f in enumerate(imgs)):
+            stacked = torch.as_strided(imgs[0], (len(imgs), Ci, S_pix), (step // 4, S_pix, 1))
+            return torch.matmul(wcat, stacked)
         both = torch.empty((len(imgs), wcat.shape[0], S_pix), dtype=torch.float32, device=imgs[0].device)
         for i, f in enumerate(imgs):
-            torch.matmul(wcat, f.view(f.shape[0], S_pix), out=both[i])
+            torch.matmul(wcat, f.view(Ci, S_pix), out=both[i])
         return both
 
     def prefetch(self, batch_dict, layer_name='layer1_ori', img_conv_func=None):
@@ -384,11 +396,14 @@ def synthetic_camera_inputs(batch, dev, seed=1234, raw_hw=(900, 1600), image_sca
     cams = synth.nusc_cameras(image_hw=raw_hw)
     H, W = int(round(raw_hw[0] * image_scale)), int(round(raw_hw[1] * image_scale))
     feats = synth.camera_features(batch * 6, 256, feat_hw, seed).reshape(batch, 6, 256, feat_hw[0], feat_hw[1])
+    # the camera network's output for the B*6 images is one tensor; the reference hands it on as a dict of
+    # per-camera slices (CP/det3d/models/detectors/voxelnet.py) -- same here: views, not copies
+    feats_dev = torch.from_numpy(np.ascontiguousarray(feats)).to(dev)
     batch_dict = {'image_shape': {}, 'img_feat': {'layer1_ori_feat2d': {}}, 'calib': {}}
     for i, name in enumerate(synth.NUSC_CAMS):
         key = name.lower()
         batch_dict['image_shape'][key] = torch.tensor([[H, W, 3]] * batch)
-        batch_dict['img_feat']['layer1_ori_feat2d'][key] = torch.from_numpy(np.ascontiguousarray(feats[:, i])).to(dev)
+        batch_dict['img_feat']['layer1_ori_feat2d'][key] = feats_dev[:, i]
         T, K = cams[name]
         ck = key.lstrip('cam_')
         batch_dict['calib']['lidar2cam_' + ck] = torch.from_numpy(np.stack([T] * batch)).to(dev)
