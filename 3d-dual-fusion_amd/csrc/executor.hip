@@ -86,11 +86,14 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
   int32_t *count_dev = (int32_t *)mem.take(256);
   DF3D_ARENA_CHECK(count_dev);
 
+  // ---- phase 1, geometry: every rulebook of the chain.  Index sets and neighbour tables depend on the voxel
+  //      coordinates only, so all host round trips (output counts of the strided layers) happen here, while the
+  //      GPU has nothing else to do; phase 2 then enqueues all convolutions back to back and returns. ----
+  std::vector<const int32_t *> layer_nbr(nlayers, nullptr);
   for (int li = 0; li < nlayers; ++li) {
     const df3d_layer &L = layers[li];
     DF3D_CHECK_ARG(L.input >= -1 && L.input < li && L.residual >= -1 && L.residual < li,
                    "backbone_run: layer %d reads a later layer", li);
-    const float *in_feat = L.input < 0 ? features : outs[L.input].features;
     const int in_set = L.input < 0 ? 0 : outs[L.input].set;
     const int cin = L.input < 0 ? in_channels : outs[L.input].channels;
     DF3D_CHECK_ARG(cin == L.cin, "backbone_run: layer %d expects %d input channels, gets %d", li, L.cin, cin);
@@ -177,13 +180,40 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
       rulebooks.push_back(std::make_pair(L.rulebook, nbr));
       rulebook_set.push_back(out_set);
     }
-    n_out = sets[out_set].n;
-    const int n_in = sets[in_set].n;
+    (void)n_out;
+    layer_nbr[li] = nbr;
+    outs[li].set = out_set;
+    outs[li].channels = L.cout;
+  }
 
-    // ---- the fused convolution ----
+  // ---- phase 2, features: one fused convolution per layer, no host synchronisation ----
+  for (int li = 0; li < nlayers; ++li) {
+    const df3d_layer &L = layers[li];
+    const float *in_feat = L.input < 0 ? features : outs[L.input].features;
+    const int in_set = L.input < 0 ? 0 : outs[L.input].set;
+    const int K = kvol_of(L.ksize);
+    const int32_t *nbr = layer_nbr[li];
+    const int out_set = outs[li].set;
+    const int n_out = sets[out_set].n;
+    const int n_in = sets[in_set].n;
     LayerOut &o = outs[li];
-    o.set = out_set;
-    o.channels = L.cout;
+    df3d_layer_view &v = views[li];
+    v.nbr = nbr;
+    v.kvol = K;
+    if (L.reserved & 1) {                      // geometry-only layer: the caller runs this convolution itself
+      const IndexSet &GS = sets[out_set];
+      v.features = nullptr;
+      v.split = nullptr;
+      v.indices = GS.indices;
+      v.grid = GS.grid;
+      v.grid_bytes = GS.grid_bytes;
+      v.n = GS.n;
+      v.channels = L.cout;
+      v.rows_sorted = GS.sorted ? 1 : 0;
+      memcpy(v.shape, GS.shape, sizeof(v.shape));
+      continue;
+    }
+    DF3D_CHECK_ARG(L.input < 0 || outs[L.input].features, "backbone_run: layer %d reads a geometry-only layer", li);
     o.features = (float *)mem.take((size_t)n_out * L.cout * 4);
     DF3D_ARENA_CHECK(o.features);
     const float *res = L.residual < 0 ? nullptr : outs[L.residual].features;
@@ -208,7 +238,6 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
                                       res, L.relu, o.features, stream_);
       if (rc) return rc;
     }
-    df3d_layer_view &v = views[li];
     const IndexSet &OS = sets[out_set];
     v.features = o.features;
     v.split = o.split;

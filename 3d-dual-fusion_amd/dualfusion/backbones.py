@@ -135,7 +135,8 @@ class SpMiddleResNetFHD(nn.Module):
         if plan is False:
             from .executor import compile_stages
             plan = compile_stages([("conv_input", self.conv_input), ("conv1", self.conv1), ("conv2", self.conv2),
-                                   ("conv3", self.conv3), ("conv4", self.conv4)])
+                                   ("conv3", self.conv3), ("conv4", self.conv4)],
+                                  geometry_stages=[("conv4", self.extra_conv)])
             object.__setattr__(self, "_exec_plan", plan)
         return plan
 

@@ -30,7 +30,8 @@ class _Layer(ctypes.Structure):
 class _View(ctypes.Structure):
     _fields_ = [("features", ctypes.c_void_p), ("split", ctypes.c_void_p), ("indices", ctypes.c_void_p),
                 ("grid", ctypes.c_void_p), ("grid_bytes", ctypes.c_size_t), ("n", ctypes.c_int),
-                ("channels", ctypes.c_int), ("rows_sorted", ctypes.c_int), ("shape", ctypes.c_int * 3)]
+                ("channels", ctypes.c_int), ("rows_sorted", ctypes.c_int), ("shape", ctypes.c_int * 3),
+                ("nbr", ctypes.c_void_p), ("kvol", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
 class Unsupported(Exception):
@@ -42,6 +43,7 @@ class _Spec(object):
 
     def __init__(self, conv, bn, relu, inp, residual, rulebook):
         self.conv, self.bn, self.relu, self.input, self.residual, self.rulebook = conv, bn, relu, inp, residual, rulebook
+        self.geometry_only = False
 
 
 def _is_basic_block(m):
@@ -49,16 +51,27 @@ def _is_basic_block(m):
 
 
 class BackbonePlan(object):
-    def __init__(self, stages):
-        """stages: list of (name, module); the output of every stage is exported under its name."""
+    def __init__(self, stages, geometry_stages=()):
+        """stages: list of (name, module); the output of every stage is exported under its name.
+        geometry_stages: [(name of the stage it reads, module)]: modules that run AFTER the caller has modified that
+        stage's features (a fusion step): only their rulebooks are built here (geometry depends on the coordinates
+        alone) and handed to the module path, which then needs no host round trip."""
         self.specs = []
         self.exports = {}
+        self.geometry = []         # (input stage name, layer index)
         self._keys = {}
         self._set = 0              # index-set counter (changes at every strided conv)
         cur = -1
         for name, module in stages:
             cur = self._walk(module, cur)
             self.exports[name] = cur
+        for src, module in geometry_stages:
+            first = len(self.specs)
+            self._walk(module, self.exports[src])
+            if len(self.specs) != first + 1:
+                raise Unsupported("geometry stage must be a single convolution group")
+            self.specs[first].geometry_only = True
+            self.geometry.append((src, first))
         self._table = None
         self._sig = None
         self._keep = None
@@ -142,6 +155,7 @@ class BackbonePlan(object):
                 for d in range(3):
                     L.stride[d], L.padding[d] = 1, int(c.kernel_size[d]) // 2
             L.relu = int(bool(s.relu))
+            L.reserved = 1 if s.geometry_only else 0
             K = int(c.kernel_size[0] * c.kernel_size[1] * c.kernel_size[2])
             w = c.weight.detach().contiguous().view(K, c.in_channels, c.out_channels)
             if w.dtype != torch.float32:
@@ -211,12 +225,21 @@ class BackbonePlan(object):
                 dirs[(ind.data_ptr(), ind.shape[0])] = _ops.GridDirectory(blob, None, batch_size,
                                                                           list(t.spatial_shape))
             out[name] = t
+        for src, li in self.geometry:
+            v = views[li]
+            from .spconv.structure import Rulebook
+            x = out[src]
+            outids = view(v.indices, v.n * 16, torch.int32, (v.n, 4))
+            nbr = view(v.nbr, v.kvol * v.n * 4, torch.int32, (v.kvol, v.n))
+            rb = Rulebook(outids, x.indices, nbr, list(x.spatial_shape), [v.shape[0], v.shape[1], v.shape[2]],
+                          out_rows_sorted=True)
+            x._prebuilt[id(self.specs[li].conv)] = rb
         return out
 
 
-def compile_stages(stages):
+def compile_stages(stages, geometry_stages=()):
     """BackbonePlan for [(name, module), ...] or None when the chain cannot be expressed."""
     try:
-        return BackbonePlan(stages)
+        return BackbonePlan(stages, geometry_stages)
     except Unsupported:
         return None

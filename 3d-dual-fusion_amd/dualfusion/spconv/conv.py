@@ -77,6 +77,9 @@ class SparseConvolution(SparseModule):
     # ------------------------------------------------------------------------------
     def _rulebook(self, input):
         """Reuse the rulebook of `indice_key` (conv.py:146-155) or build and register it."""
+        pre = input._prebuilt.get(id(self)) if input._prebuilt else None
+        if pre is not None and pre.indices is input.indices:
+            return pre
         datas = input.find_indice_pair(self.indice_key)
         if self.inverse:
             raise Df3dError("SparseInverseConv is not used by the 3D-DF backbones and is not implemented")

@@ -71,6 +71,8 @@ class SparseConvTensor(object):
         self._directories = {}
         # (features tensor, its split rows) when a split-precision conv produced or consumed these features
         self._split = None
+        # rulebooks built ahead of time for specific conv modules (dualfusion/executor.py), keyed by id(module)
+        self._prebuilt = {}
 
     def split_features(self):
         """Split rows (bf16 hi | lo) of `features` for the split-precision conv kernels; emitted by the producing
@@ -108,6 +110,7 @@ class SparseConvTensor(object):
         out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self.grid)
         out.indice_dict = self.indice_dict
         out._directories = self._directories
+        out._prebuilt = self._prebuilt
         return out
 
     # ---- directory cache ----------------------------------------------------------

@@ -348,13 +348,15 @@ int df3d_ffn_fused(const float *x, long long rows, int d_model, int d_ffn, const
  *   rulebook  layers with the same id >= 0 share one neighbour table (the reference's indice_key); -1 = private
  *   packed    split-precision filter bank (df3d_conv_pack_weights) or NULL for the exact fp32 kernels
  * views[i] describes layer i's output inside the arena (grid = its occupancy directory when one was built).
+ * The call first builds EVERY rulebook (geometry depends on the coordinates only; all host round trips happen
+ * there), then enqueues the convolutions back to back and returns without waiting for them.
  * ---------------------------------------------------------------------------------- */
 typedef struct df3d_layer {
   int kind, input, residual, rulebook;
   int cin, cout;
   int ksize[3], stride[3], padding[3], dilation[3];
   int relu;
-  int reserved;
+  int reserved;          /* flags: bit 0 = geometry only (build the rulebook, export it, do not run the conv) */
   const float *weight;   /* [kvol][cin][cout] fp32 */
   const void *packed;
   const float *bias, *scale, *shift;
@@ -368,6 +370,9 @@ typedef struct df3d_layer_view {
   size_t grid_bytes;
   int n, channels, rows_sorted;
   int shape[3];
+  const int32_t *nbr;    /* the layer's neighbour table [kvol][n] */
+  int kvol;
+  int reserved;
 } df3d_layer_view;
 
 int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *features, const int32_t *indices, int n,
