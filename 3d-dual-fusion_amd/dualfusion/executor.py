@@ -216,6 +216,7 @@ class BackbonePlan(object):
             ind = coors if v.indices == coors.data_ptr() else view(v.indices, v.n * 16, torch.int32, (v.n, 4))
             t = SparseConvTensor(f, ind, [v.shape[0], v.shape[1], v.shape[2]], batch_size)
             t.indice_dict, t._directories = idict, dirs
+            t._indices_synced = True      # the host has waited for these coordinates (count round trip)
             if v.split:
                 t._split = (f, view(v.split, v.n * v.channels * 4, torch.uint8, (v.n, v.channels * 4)))
             if v.grid and v.rows_sorted:

@@ -15,6 +15,8 @@ Semantics kept bug-for-bug.
 """
 import ctypes
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -304,7 +306,25 @@ class VoxelWithPointProjection(nn.Module):
         need = set([last])
         if self.ifat_cfg is not None:
             need |= set(self.ifat.voxel_idx)
-        proj = {s: self._project(encoded_voxel_list[s], d_factor_list[s], inp) for s in sorted(need)}
+        proj = {}
+        early = None
+        if getattr(x_last, "_indices_synced", False) and os.environ.get("DF3D_EARLY_SLOTS", "1") == "1":
+            # The query lists depend on the voxel COORDINATES only, and those are complete (the host has read their
+            # count).  Project + count on a side stream now: the one host round trip of this adapter (max list
+            # length) then does not wait for the convolutions still queued on the main stream, and the host can
+            # enqueue the rest of the adapter while they run.
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(self._side):
+                proj[last] = self._project(x_last, d_factor_list[last], inp)
+                early = self._query_slots(x_last.indices.contiguous(), proj[last][1], B)
+            main.wait_stream(self._side)
+            for t in proj[last] + (early[0],):
+                t.record_stream(main)
+        for s_ in sorted(need):
+            if s_ not in proj:
+                proj[s_] = self._project(encoded_voxel_list[s_], d_factor_list[s_], inp)
         in_conv = self.pfat.input_proj[0][0]
         att = None
         S_pix = H * W
@@ -341,7 +361,7 @@ class VoxelWithPointProjection(nn.Module):
         feats = x_last.features.contiguous()
         ind = x_last.indices.contiguous()
         n, C = feats.shape
-        pos, max_ne = self._query_slots(ind, mask, B)
+        pos, max_ne = early if early is not None else self._query_slots(ind, mask, B)
         Ci = inp['Ci']
         v_feat = torch.empty((NI, max_ne, C), dtype=torch.float32, device=dev)
         v_i_feat = torch.empty((NI, max_ne, Ci), dtype=torch.float32, device=dev)

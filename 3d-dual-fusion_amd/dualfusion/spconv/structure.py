@@ -111,6 +111,7 @@ class SparseConvTensor(object):
         out.indice_dict = self.indice_dict
         out._directories = self._directories
         out._prebuilt = self._prebuilt
+        out._indices_synced = getattr(self, "_indices_synced", False)
         return out
 
     # ---- directory cache ----------------------------------------------------------
