@@ -99,28 +99,40 @@ __global__ __launch_bounds__(256) void neighbors_kernel(GridView g, const int32_
 // mark every output cell touched by an input voxel: out = (in + pad - k*dil) / stride when divisible
 __global__ __launch_bounds__(256) void conv_mark_kernel(const int32_t *__restrict__ ind, int n, ConvGeom cg,
                                                         long long out_vol, unsigned long long *__restrict__ bits) {
+  // one thread per (voxel, kz, ky): the kx taps land in the same or the next 64-cell word, so they are merged
+  // into one mask before the (same-address, serialising) atomic
+  const int KZY = cg.ks[0] * cg.ks[1];
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)n * cg.K) return;
-  int i = (int)(t / cg.K);
-  int k = (int)(t - (long long)i * cg.K);
+  if (t >= (long long)n * KZY) return;
+  int i = (int)(t / KZY);
+  int kzy = (int)(t - (long long)i * KZY);
   const int32_t *p = ind + (size_t)i * 4;
-  int kk[3];
-  kk[2] = k % cg.ks[2];
-  int kt = k / cg.ks[2];
-  kk[1] = kt % cg.ks[1];
-  kk[0] = kt / cg.ks[1];
-  int o[3];
+  int kk[2] = {kzy / cg.ks[1], kzy % cg.ks[1]};
+  int o[2];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
+  for (int d = 0; d < 2; ++d) {
     int num = p[1 + d] + cg.pad[d] - kk[d] * cg.dil[d];
     if (num < 0 || (num % cg.st[d]) != 0) return;
     o[d] = num / cg.st[d];
     if (o[d] >= cg.out_shape[d]) return;
   }
-  long long flat = (long long)p[0] * out_vol + ((long long)o[0] * cg.out_shape[1] + o[1]) * cg.out_shape[2] + o[2];
-  // an output is marked by ~4 inputs on average: look before the (same-address, serialised) atomic
-  const unsigned long long m = 1ull << (flat & 63);
-  if (!(__builtin_nontemporal_load(&bits[flat >> 6]) & m)) atomicOr(&bits[flat >> 6], m);
+  const long long row = (long long)p[0] * out_vol + ((long long)o[0] * cg.out_shape[1] + o[1]) * cg.out_shape[2];
+  long long cur = -1;
+  unsigned long long mask = 0ull;
+  for (int kx = 0; kx < cg.ks[2]; ++kx) {
+    int num = p[3] + cg.pad[2] - kx * cg.dil[2];
+    if (num < 0 || (num % cg.st[2]) != 0) continue;
+    int ox = num / cg.st[2];
+    if (ox >= cg.out_shape[2]) continue;
+    long long flat = row + ox;
+    if ((flat >> 6) != cur) {
+      if (mask) atomicOr(&bits[cur], mask);
+      cur = flat >> 6;
+      mask = 0ull;
+    }
+    mask |= 1ull << (flat & 63);
+  }
+  if (mask) atomicOr(&bits[cur], mask);
 }
 
 // one thread per 64-cell word: emit the coordinates of its set bits at prefix[word]...
@@ -308,7 +320,7 @@ extern "C" int df3d_conv_out_indices(const int32_t *indices, int n, int batch, c
   DF3D_HIP(hipMemsetAsync(bits, 0, (size_t)h.nwords * 8, stream));
   long long out_vol = (long long)out_shape[0] * out_shape[1] * out_shape[2];
   if (n > 0) {
-    long long total = (long long)n * K;
+    long long total = (long long)n * cg.ks[0] * cg.ks[1];
     hipLaunchKernelGGL(conv_mark_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, indices, n, cg, out_vol, bits);
   }
   int rc = grid_finish(out_grid, h, stream);
