@@ -321,6 +321,61 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(const double *__restrict__
   }
 }
 
+// GroupNorm over [N, Q, C] rows (the reference normalises the Conv1d output [N, C, Q], actr.py:150-158: statistics per
+// image n and group over Q x C/groups values) without the two transposes: pass 1 accumulates per-(n, group) sums
+// with one 16-byte quad of channels per lane (a row is read as one contiguous 4C-byte segment), pass 2 normalises.
+__global__ __launch_bounds__(256) void rows_gn_stats_kernel(const float *__restrict__ x, int Q, int C, int cpg,
+                                                            int rows_per_block, double *__restrict__ stats) {
+  const int n = blockIdx.y;
+  const int nq = C / 4;                      // quads per row
+  const int q4 = threadIdx.x % nq, rsub = threadIdx.x / nq, rstep = blockDim.x / nq;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(r0 + rows_per_block, Q);
+  float s1 = 0.f, s2 = 0.f;
+  if (rsub < rstep)
+    for (int r = r0 + rsub; r < r1; r += rstep) {
+      f32x4 v = *(const f32x4 *)(x + ((size_t)n * Q + r) * C + q4 * 4);
+      s1 += (v[0] + v[1]) + (v[2] + v[3]);
+      s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+  __shared__ float sh1[256], sh2[256];
+  sh1[threadIdx.x] = s1;
+  sh2[threadIdx.x] = s2;
+  __syncthreads();
+  const int groups = C / cpg, qpg = cpg / 4;  // quads per group
+  if ((int)threadIdx.x < groups) {
+    double a = 0.0, b = 0.0;
+    for (int rs = 0; rs < rstep; ++rs)
+      for (int k = 0; k < qpg; ++k) {
+        a += sh1[rs * nq + threadIdx.x * qpg + k];
+        b += sh2[rs * nq + threadIdx.x * qpg + k];
+      }
+    atomicAdd(&stats[((size_t)n * groups + threadIdx.x) * 2], a);
+    atomicAdd(&stats[((size_t)n * groups + threadIdx.x) * 2 + 1], b);
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ stats,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float eps, int Q, int C,
+                                                            int cpg, size_t n4, float *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int nq = C / 4;
+  const int q4 = (int)(i % nq);
+  const size_t row = i / nq;
+  const int n = (int)(row / Q);
+  const int g = q4 * 4 / cpg, groups = C / cpg;
+  const double cnt = (double)Q * cpg;
+  const double m = stats[((size_t)n * groups + g) * 2] / cnt;
+  double var = stats[((size_t)n * groups + g) * 2 + 1] / cnt - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  f32x4 v = ((const f32x4 *)x)[i];
+  f32x4 ga = ((const f32x4 *)gamma)[q4], be = ((const f32x4 *)beta)[q4];
+  ((f32x4 *)out)[i] = (v - mean) * rstd * ga + be;
+}
+
 }  // namespace df3d
 
 using namespace df3d;
@@ -416,6 +471,25 @@ extern "C" int df3d_groupnorm_fold(const double *moments, const float *b, const 
   if (N == 0) return DF3D_OK;
   hipLaunchKernelGGL(gn_fold_kernel, dim3(N), dim3(256), 0, stream, moments, b, gamma, beta, eps, S, C, groups, W, wb,
                      O, Wf, cf);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_rows_groupnorm(const float *x, int N, int Q, int C, int groups, const float *gamma,
+                                   const float *beta, float eps, double *stats, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(x && gamma && beta && stats && out, "rows_groupnorm: null argument");
+  DF3D_CHECK_ARG(groups > 0 && C % groups == 0 && (C / groups) % 4 == 0 && C <= 1024 && groups <= 256,
+                 "rows_groupnorm: needs C %% groups == 0 and a group width that is a multiple of 4 (C=%d, groups=%d)",
+                 C, groups);
+  if (N == 0 || Q == 0) return DF3D_OK;
+  DF3D_HIP(hipMemsetAsync(stats, 0, (size_t)N * groups * 2 * sizeof(double), stream));
+  const int rows_per_block = 256;
+  hipLaunchKernelGGL(rows_gn_stats_kernel, dim3(cdiv(Q, rows_per_block), N), dim3(256), 0, stream, x, Q, C, C / groups,
+                     rows_per_block, stats);
+  size_t n4 = (size_t)N * Q * C / 4;
+  hipLaunchKernelGGL(rows_gn_apply_kernel, dim3(cdiv((long long)n4, 256)), dim3(256), 0, stream, x, stats, gamma, beta,
+                     eps, Q, C, C / groups, n4, out);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -91,6 +91,8 @@ SIGNATURES = {
     "df3d_ms_deform_attn_fused": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_longlong,
                                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_rows_groupnorm": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
+                                    c_void_p, c_void_p]),
     "df3d_scaled_moments": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_void_p,
                                     c_void_p]),
     "df3d_groupnorm_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,

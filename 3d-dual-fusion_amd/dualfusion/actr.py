@@ -434,6 +434,10 @@ class ACTR(nn.Module):
         """i_input_proj on [N, Q, Cimg]: the 1x1 Conv1d as a GEMM, GroupNorm over (group, Q)."""
         conv, gn = self.i_input_proj[0], self.i_input_proj[1]
         y = F.linear(v_i_feat, conv.weight[:, :, 0], conv.bias)            # [N, Q, C]
+        if y.is_cuda and y.dtype == torch.float32 and not torch.is_grad_enabled() \
+                and (gn.num_channels // gn.num_groups) % 4 == 0 and y.shape[1] > 0:
+            from . import ops as _ops
+            return _ops.rows_groupnorm(y.contiguous(), gn)
         y = F.group_norm(y.transpose(1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)
         return y.transpose(1, 2)
 

@@ -441,6 +441,19 @@ def ffn_fused(x, packed, b1, b2, d_ffn, residual=None, ln_weight=None, ln_bias=N
     return out
 
 
+def rows_groupnorm(x, gn):
+    """GroupNorm of [N, Q, C] rows == gn(x.transpose(1, 2)).transpose(1, 2), without the transposes."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    N, Q, C = x.shape
+    stats = torch.empty((N, gn.num_groups, 2), dtype=torch.float64, device=x.device)
+    out = torch.empty_like(x)
+    rc = lib.df3d_rows_groupnorm(_ptr(x), N, Q, C, int(gn.num_groups), _ptr(gn.weight), _ptr(gn.bias), float(gn.eps),
+                                 _ptr(stats), _ptr(out), _stream())
+    _lib.check(rc, "df3d_rows_groupnorm")
+    return out
+
+
 def actr_prep(q, qi, pos):
     """A = q + pos, Bw = (q + pos) + (qi + pos) in one pass."""
     lib = _lib.load()

@@ -315,6 +315,11 @@ int df3d_ms_deform_attn_fused(const float *value, long long value_stride, const 
  *   df3d_groupnorm_fold: per image, Wf[n][o][c] = W[o][c]*rstd_g*gamma_c and cf[n][o] so that
  *     W*GroupNorm(x)+wb = a_p * (Wf[n] u_p) + cf[n].  The sampler applies a_p and cf through
  *     pixel_scale / image_bias, so neither x, GroupNorm(x) nor its transpose is ever materialised. */
+/* df3d_rows_groupnorm: GroupNorm of [N, Q, C] rows with statistics per (n, group) over Q x C/groups values -- what
+ * i_input_proj's GroupNorm computes on the Conv1d layout [N, C, Q] (actr.py:150-158) -- without transposing;
+ * stats = scratch of N*groups*2 doubles. */
+int df3d_rows_groupnorm(const float *x, int N, int Q, int C, int groups, const float *gamma, const float *beta,
+                        float eps, double *stats, float *out, void *stream);
 int df3d_scaled_moments(const float *u, long long image_stride, long long channel_stride, const float *a, int N,
                         int S, int C, double *moments, void *stream);
 int df3d_groupnorm_fold(const double *moments, const float *b, const float *gamma, const float *beta, float eps,

@@ -414,6 +414,21 @@ def test_ffn_fused(dev, rows, H, ln, res):
     assert err < 5e-5, err
 
 
+@pytest.mark.parametrize("N,Q,C,G", [(6, 5189, 128, 32), (2, 77, 256, 32), (1, 1, 64, 16), (3, 300, 128, 8)])
+def test_rows_groupnorm(dev, N, Q, C, G):
+    """GroupNorm on the [N, Q, C] layout == the reference's GroupNorm on the Conv1d layout [N, C, Q]."""
+    from dualfusion import ops
+    g = torch.Generator(device="cpu").manual_seed(N * 1000 + Q)
+    x = (torch.randn(N, Q, C, generator=g) * 2.0 + 0.7).to(dev)
+    gn = torch.nn.GroupNorm(G, C).to(dev)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+        want = gn(x.transpose(1, 2)).transpose(1, 2)
+        got = ops.rows_groupnorm(x, gn)
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+
+
 def test_msda_linearity_at_full_size(dev):
     """BASELINE config 2 size (6 cams, 150x267 map, Q=8000): linear in value and in the weights."""
     from dualfusion import ops
