@@ -18,6 +18,8 @@
 //
 // Algorithmic bytes: rows*128*4 read + rows*128*4 written + 1 MB of weights per workgroup from L2;
 // 2*rows*128*1024*2 flops.  Bound: bf16 MFMA at 3 products per fp32 product.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace df3d {
@@ -154,10 +156,18 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
       store_w((s + 1) & 1);
       load_w(s + 2);
       const u32x4 *wb = Wl[s & 1] + lane;
+      // operand fragments of the next tile pair come from LDS while the MFMAs of the current pair run
+      u32x4 fq[2][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fq[0][q] = wb[q * 64];
 #pragma unroll
       for (int t = 0; t < 8; t += 2) {
-        const u32x4 ah0 = wb[(t * 2 + 0) * 64], al0 = wb[(t * 2 + 1) * 64];
-        const u32x4 ah1 = wb[(t * 2 + 2) * 64], al1 = wb[(t * 2 + 3) * 64];
+        const int cur = (t >> 1) & 1;
+        if (t + 2 < 8) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fq[cur ^ 1][q] = wb[((t + 2) * 2 + q) * 64];
+        }
+        const u32x4 ah0 = fq[cur][0], al0 = fq[cur][1], ah1 = fq[cur][2], al1 = fq[cur][3];
         acc1[t] = DF3D_MFMA_BF16(ah0, xl[kb], acc1[t]);
         acc1[t + 1] = DF3D_MFMA_BF16(ah1, xl[kb], acc1[t + 1]);
         acc1[t] = DF3D_MFMA_BF16(al0, xh[kb], acc1[t]);
@@ -192,10 +202,17 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
       store_w((s + 1) & 1);
       load_w(s + 2);
       const u32x4 *wb = Wl[s & 1] + lane;
+      u32x4 fq[2][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fq[0][k] = wb[k * 64];
 #pragma unroll
       for (int ct = 0; ct < 8; ct += 2) {
-        const u32x4 bh0 = wb[(ct * 2 + 0) * 64], bl0 = wb[(ct * 2 + 1) * 64];
-        const u32x4 bh1 = wb[(ct * 2 + 2) * 64], bl1 = wb[(ct * 2 + 3) * 64];
+        const int cur = (ct >> 1) & 1;
+        if (ct + 2 < 8) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) fq[cur ^ 1][k] = wb[((ct + 2) * 2 + k) * 64];
+        }
+        const u32x4 bh0 = fq[cur][0], bl0 = fq[cur][1], bh1 = fq[cur][2], bl1 = fq[cur][3];
         acc2[ct] = DF3D_MFMA_BF16(hl[q], bh0, acc2[ct]);
         acc2[ct + 1] = DF3D_MFMA_BF16(hl[q], bh1, acc2[ct + 1]);
         acc2[ct] = DF3D_MFMA_BF16(hh[q], bl0, acc2[ct]);
@@ -280,8 +297,10 @@ extern "C" int df3d_ffn_fused(const float *x, long long rows, int d_model, int d
   DF3D_CHECK_ARG((ln_weight == nullptr) == (ln_bias == nullptr), "ffn_fused: LayerNorm needs weight and bias");
   if (rows <= 0) return DF3D_OK;
   FfnArgs a = {x, (const u32x4 *)packed, b1, b2, residual, ln_weight, ln_bias, eps, out, rows, d_ffn};
-  constexpr int NW = 8;
-  hipLaunchKernelGGL((ffn_split_kernel<NW>), dim3(cdiv(rows, NW * 16)), dim3(NW * 64), 0, stream, a);
+  static const int nw = getenv("DF3D_FFN_NW") ? atoi(getenv("DF3D_FFN_NW")) : 8;      // tuning aid
+  if (nw == 4) hipLaunchKernelGGL((ffn_split_kernel<4>), dim3(cdiv(rows, 64)), dim3(256), 0, stream, a);
+  else if (nw == 16) hipLaunchKernelGGL((ffn_split_kernel<16>), dim3(cdiv(rows, 256)), dim3(1024), 0, stream, a);
+  else hipLaunchKernelGGL((ffn_split_kernel<8>), dim3(cdiv(rows, 128)), dim3(512), 0, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -566,7 +566,43 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 
   // ---- epilogue: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the CT
   //      consecutive columns n*CT .. n*CT+CT-1 of its rows (packed-weight layout 1): 16-byte stores ----
-  static_assert(CT == 4 || CT == 8, "COUT must be 64 or 128");
+  static_assert(CT == 2 || CT == 4 || CT == 8, "COUT must be 32, 64 or 128");
+  if constexpr (CT == 2) {
+    // COUT = 32: lane n owns columns 2n, 2n+1 (8-byte stores; four lanes share a split block)
+    const int col = n * 2;
+    const float2 bi = a.bias ? *(const float2 *)(a.bias + col) : make_float2(0.f, 0.f);
+    const float2 sc = a.scale ? *(const float2 *)(a.scale + col) : make_float2(1.f, 1.f);
+    const float2 sh = a.shift ? *(const float2 *)(a.shift + col) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
+        if (row >= a.n_out) continue;
+        const size_t o = (size_t)row * COUT + col;
+        float2 v = make_float2((acc[rt][0][r] + bi.x) * sc.x + sh.x, (acc[rt][1][r] + bi.y) * sc.y + sh.y);
+        if (a.residual) {
+          const float2 rr = *(const float2 *)(a.residual + o);
+          v.x += rr.x;
+          v.y += rr.y;
+        }
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+        }
+        *(float2 *)(a.out + o) = v;
+        if (a.out_split) {
+          unsigned h0, l0, h1, l1;
+          split2(v.x, h0, l0);
+          split2(v.y, h1, l1);
+          char *blk = (char *)a.out_split + (o >> 3) * 32 + (n & 3) * 4;     // 8-channel block = [hi 16 B | lo 16 B]
+          *(unsigned *)blk = h0 | (h1 << 16);
+          *(unsigned *)(blk + 16) = l0 | (l1 << 16);
+        }
+      }
+    }
+    return;
+  } else {
   f32x4 bi[CT / 4], sc[CT / 4], sh[CT / 4];
 #pragma unroll
   for (int q = 0; q < CT / 4; ++q) {
@@ -611,6 +647,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         }
       }
     }
+  }
   }
 }
 
@@ -685,8 +722,19 @@ static int launch_split(const SplitConvArgs &a, const int32_t *tile_rows, int nt
   return DF3D_OK;
 }
 
+// which kernel serves a shape: 1 = output-stationary (layout 1), 0 = pair-compacted (layout 0)
+static int split_layout(int cin, int cout) {
+  static const char *force = getenv("DF3D_SPLIT_KERNEL");
+  if (force && force[0] == 'p') return 0;
+  if (force && force[0] == 'o') return 1;
+  (void)cin;
+  (void)cout;
+  return 1;
+}
+
 static bool split_shape_ok(int cin, int cout) {
-  return (cout == 128 && (cin == 128 || cin == 64)) || (cout == 64 && (cin == 64 || cin == 32));
+  return (cout == 128 && (cin == 128 || cin == 64)) || (cout == 64 && (cin == 64 || cin == 32)) ||
+         (cout == 32 && cin == 32 && split_layout(cin, cout) == 1);      // 32 -> 32: output-stationary kernel only
 }
 
 }  // namespace df3d
@@ -696,16 +744,6 @@ using namespace df3d;
 extern "C" size_t df3d_conv_packed_weight_bytes(int kvol, int cin, int cout) {
   if (!split_shape_ok(cin, cout) || kvol <= 0 || kvol > DF3D_MAX_KVOL) return 0;
   return (size_t)kvol * cin * cout * 4;
-}
-
-// which kernel serves a shape: 1 = output-stationary (layout 1), 0 = pair-compacted (layout 0)
-static int split_layout(int cin, int cout) {
-  static const char *force = getenv("DF3D_SPLIT_KERNEL");
-  if (force && force[0] == 'p') return 0;
-  if (force && force[0] == 'o') return 1;
-  (void)cin;
-  (void)cout;
-  return 1;
 }
 
 extern "C" int df3d_conv_pack_weights(const float *filters, int kvol, int cin, int cout, void *packed, void *stream_) {
@@ -750,6 +788,7 @@ extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int 
   int rc;
   if (split_layout(cin, cout) == 1) {
     if (cout == 128) rc = cin == 128 ? launch_os_split<128, 128>(a, stream) : launch_os_split<64, 128>(a, stream);
+    else if (cout == 32) rc = launch_os_split<32, 32>(a, stream);
     else rc = cin == 64 ? launch_os_split<64, 64>(a, stream) : launch_os_split<32, 64>(a, stream);
   } else if (cout == 128) {
     rc = cin == 128 ? launch_split<128, 128>(a, tile_rows, ntiles, stream)

@@ -268,7 +268,7 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
  * contraction is A_hi*W_hi + A_lo*W_hi + A_hi*W_lo with fp32 accumulation: ~1e-5 relative error against the
  * exact fp32 result (parity bar 1e-3), 16/3 of the fp32 MFMA rate.
  *   df3d_conv_packed_weight_bytes: bytes of the packed filter bank, 0 when (cin, cout) has no split kernel
- *                                  (served: 32->64, 64->64, 64->128, 128->128)
+ *                                  (served: 32->32, 32->64, 64->64, 64->128, 128->128)
  *   df3d_conv_pack_weights:  filters [kvol][cin][cout] fp32 -> packed MFMA B operands (once per weight)
  *   df3d_split_rows:         features [n][c] fp32 -> split rows [n][c/8][hi 8 x bf16 | lo 8 x bf16], c % 8 == 0
  *   df3d_sparse_conv_split:  out fp32 [n_out][cout]; out_split (optional) receives the split rows of `out`

@@ -193,7 +193,7 @@ def test_split_rows_bit_exact(dev):
     assert np.max(np.abs(rec - x)[big] / np.abs(x)[big]) < 2.0 ** -16
 
 
-@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 64), (64, 128), (128, 128)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
 @pytest.mark.parametrize("n_seeds", [4, 60])
 def test_sparse_conv_split_precision(dev, cin, cout, n_seeds):
     """Split-precision kernel (bf16 hi/lo operands, 3 MFMA products, fp32 accumulate) against the float64

@@ -5,6 +5,8 @@ import os
 import sys
 import time
 
+os.environ["DF3D_EXECUTOR"] = "0"      # the probe needs the per-module rulebooks (indice_dict)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-dual-fusion_amd")]
 import torch  # noqa: E402
