@@ -424,6 +424,27 @@ __global__ __launch_bounds__(1024) void query_slots_kernel(const uint8_t *__rest
   if (tid == 0) counts[b * ncam + cam] = carry;
 }
 
+// zero rows of the padded query tensors: slots >= counts[image] (one wave per padding row); the position
+// embedding of an all-zero query is sin(0) = 0 on even, cos(0) = 1 on odd channels
+__global__ __launch_bounds__(256) void pad_queries_kernel(const int32_t *__restrict__ counts, int nimg, int max_ne, int C,
+                                                          int Ci, float *__restrict__ v_feat,
+                                                          float *__restrict__ v_i_feat, float *__restrict__ qgrid,
+                                                          float *__restrict__ qpts, float *__restrict__ qpos) {
+  long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (w >= (long long)nimg * max_ne) return;
+  int img = (int)(w / max_ne), slot = (int)(w - (long long)img * max_ne);
+  if (slot < counts[img]) return;
+  size_t q = (size_t)w;
+  for (int c = lane; c < C; c += 64) {
+    v_feat[q * C + c] = 0.f;
+    if (qpos) qpos[q * C + c] = (c & 1) ? 1.f : 0.f;
+  }
+  for (int c = lane; c < Ci; c += 64) v_i_feat[q * Ci + c] = 0.f;
+  if (lane < 2) qgrid[q * 2 + lane] = 0.f;
+  if (lane < 3) qpts[q * 3 + lane] = 0.f;
+}
+
 }  // namespace df3d
 
 extern "C" int df3d_gate_scatter(const float *s9, const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask,
@@ -460,18 +481,24 @@ extern "C" int df3d_assemble_queries2(const float *features, const float *point_
                                       const float *img_feats, const float *const *img_ptrs, const float *att, int n,
                                       int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
                                       float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
-                                      void *stream_) {
+                                      const int32_t *counts, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(v_feat && v_i_feat && qgrid && qpts, "assemble_queries2: null output");
   size_t nq = (size_t)batch * ncam * max_ne;
-  DF3D_HIP(hipMemsetAsync(v_feat, 0, nq * channels * sizeof(float), stream));
-  DF3D_HIP(hipMemsetAsync(v_i_feat, 0, nq * img_channels * sizeof(float), stream));
-  DF3D_HIP(hipMemsetAsync(qgrid, 0, nq * 2 * sizeof(float), stream));
-  DF3D_HIP(hipMemsetAsync(qpts, 0, nq * 3 * sizeof(float), stream));
-  if (qpos && nq) {
-    DF3D_CHECK_ARG(channels % 2 == 0, "assemble_queries2: odd channel count");
-    size_t tot = nq * channels;
-    hipLaunchKernelGGL(qpos_pad_kernel, dim3(cdiv((long long)tot, 256)), dim3(256), 0, stream, qpos, tot);
+  if (qpos) DF3D_CHECK_ARG(channels % 2 == 0, "assemble_queries2: odd channel count");
+  if (counts && nq) {
+    // only the padding rows (slot >= list length) are cleared; every other row is written by the gather below
+    hipLaunchKernelGGL(pad_queries_kernel, dim3(cdiv((long long)nq * 64, 256)), dim3(256), 0, stream, counts,
+                       batch * ncam, max_ne, channels, img_channels, v_feat, v_i_feat, qgrid, qpts, qpos);
+  } else {
+    DF3D_HIP(hipMemsetAsync(v_feat, 0, nq * channels * sizeof(float), stream));
+    DF3D_HIP(hipMemsetAsync(v_i_feat, 0, nq * img_channels * sizeof(float), stream));
+    DF3D_HIP(hipMemsetAsync(qgrid, 0, nq * 2 * sizeof(float), stream));
+    DF3D_HIP(hipMemsetAsync(qpts, 0, nq * 3 * sizeof(float), stream));
+    if (qpos && nq) {
+      size_t tot = nq * channels;
+      hipLaunchKernelGGL(qpos_pad_kernel, dim3(cdiv((long long)tot, 256)), dim3(256), 0, stream, qpos, tot);
+    }
   }
   if (n == 0 || max_ne == 0) return DF3D_OK;
   DF3D_CHECK_ARG(features && point_inv && indices && grid_xy && mask && pos && (img_feats || img_ptrs),

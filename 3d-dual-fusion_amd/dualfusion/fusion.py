@@ -279,7 +279,7 @@ class VoxelWithPointProjection(nn.Module):
         rc = _lib.load().df3d_query_slots(_p(mask), _p(ind), n, B, ncam, _p(pos), _p(counts), _ops._stream())
         _lib.check(rc, "df3d_query_slots")
         max_ne = int(counts.max().item()) if n > 0 else 0                                     # the one host sync
-        return pos, max_ne
+        return pos, max_ne, counts
 
     @torch.no_grad()
     def forward(self, batch_dict, example, encoded_voxel_list=None, layer_name=None, img_conv_func=None,
@@ -320,7 +320,7 @@ class VoxelWithPointProjection(nn.Module):
                 proj[last] = self._project(x_last, d_factor_list[last], inp)
                 early = self._query_slots(x_last.indices.contiguous(), proj[last][1], B)
             main.wait_stream(self._side)
-            for t in proj[last] + (early[0],):
+            for t in proj[last] + (early[0], early[2]):
                 t.record_stream(main)
         for s_ in sorted(need):
             if s_ not in proj:
@@ -361,7 +361,7 @@ class VoxelWithPointProjection(nn.Module):
         feats = x_last.features.contiguous()
         ind = x_last.indices.contiguous()
         n, C = feats.shape
-        pos, max_ne = early if early is not None else self._query_slots(ind, mask, B)
+        pos, max_ne, counts = early if early is not None else self._query_slots(ind, mask, B)
         Ci = inp['Ci']
         v_feat = torch.empty((NI, max_ne, C), dtype=torch.float32, device=dev)
         v_i_feat = torch.empty((NI, max_ne, Ci), dtype=torch.float32, device=dev)
@@ -371,7 +371,7 @@ class VoxelWithPointProjection(nn.Module):
         qpos = torch.empty((NI, max_ne, C), dtype=torch.float32, device=dev) if depth_pos else None
         rc = lib.df3d_assemble_queries2(_p(feats), _p(pinv), _p(ind), _p(grid), _p(mask), _p(pos), None, _p(inp['img_ptrs']), _p(att), n,
                                         C, Ci, B, ncam, H, W, max_ne, _p(v_feat), _p(v_i_feat), _p(qgrid), _p(qpts),
-                                        _p(qpos), _ops._stream())
+                                        _p(qpos), _p(counts), _ops._stream())
         _lib.check(rc, "df3d_assemble_queries2")
         # (a10-a12) ACTR
         if fold:

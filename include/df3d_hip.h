@@ -245,7 +245,9 @@ int df3d_fusion_writeback(const float *features, const float *enh, const int32_t
  *   query pixel, and also writes the depth sine position embedding qpos [B*ncam, max_ne, C]
  *   (position_encoding.py:107-120); att / qpos may be NULL.  The image is either one tensor img_feats
  *   [B*ncam, Ci, H, W] or (img_feats NULL) a device table img_ptrs of B*ncam pointers to [Ci, H, W] maps, which is
- *   how the reference holds them (one dict entry per camera) -- no stacking copy. */
+ *   how the reference holds them (one dict entry per camera) -- no stacking copy.  counts (optional, from
+ *   df3d_query_slots): when given, only the padding rows (slot >= counts[image]) are zeroed instead of the whole
+ *   padded tensors. */
 int df3d_gate_scatter(const float *s9, const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask,
                       int n, int batch, int ncam, int H, int W, int32_t *winner, float *S, int clear, void *stream);
 int df3d_gate_finish(const float *gate, const float *S, const float *kg, int nimg, int H, int W, float *att,
@@ -259,7 +261,8 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
                            const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
                            const float *img_feats, const float *const *img_ptrs, const float *att, int n,
                            int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
-                           float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos, void *stream);
+                           float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
+                           const int32_t *counts, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Split-precision sparse convolution (csrc/spconv_split.hip): same contract as df3d_sparse_conv_fused
