@@ -1,0 +1,388 @@
+// Image side of the dual-query fusion on the bf16 matrix cores (split precision, see spconv_split.hip).
+//
+// The reference runs, per sample, over six [256, 150, 267] camera maps: the image gate's 1x1 summary
+// (attention.py:456), ACTR's input_proj 1x1 conv + GroupNorm (actr.py:139-149) and, per encoder layer, value_proj
+// over every pixel (ms_deform_attn.py:139).  dualfusion/fusion.py collapses that to two GEMMs (DESIGN.md section 3
+// "image side"); hipBLASLt runs them in fp32 at ~90-100 TFLOP/s (173 + 175 us).  Here they are
+//
+//   img_proj_split_kernel   u[p][0:144] = Wcat[144x256] . img[:, p]   from the channel-first fp32 maps in place:
+//                           a [32 k][128 pixel] tile is staged coalesced through LDS and read back transposed
+//                           (8 k-values per lane = one MFMA B operand after the hi/lo split), Wcat is the packed A
+//                           operand, so the accumulators hold u TRANSPOSED: lane (pixel, g) -> 4 consecutive
+//                           channels per 16-channel tile, i.e. pixel-major rows.  Output: split rows of the 128
+//                           projection channels (the A operand of the next GEMM) + the fp32 gate column.
+//   split_moments_kernel    per (image, channel) sum_p a_p u_cp and sum_p (a_p u_cp)^2 from the split rows
+//   gn_fold_pack_kernel     GroupNorm statistics -> per-image folded value weights, written directly as packed
+//                           B operands
+//   rows_gemm_split_kernel  value[p][0:256] = u_p . Wf[n]^T  (both encoder layers at once), rows contiguous
+//
+// Bytes: img 246 MB read once, u 123 MB written + read twice, value 246 MB written; 2*(17.7 + 15.7) GFLOP.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace df3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define DF3D_MFMA_BF16(A, B, C) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
+__device__ __forceinline__ unsigned ip_bf16_bits(float x) {
+  unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void ip_split2(float x, unsigned &hi, unsigned &lo) {
+  hi = ip_bf16_bits(x);
+  lo = ip_bf16_bits(x - __uint_as_float(hi << 16));
+}
+__device__ __forceinline__ float ip_bf16_to_float(unsigned bits16) { return __uint_as_float(bits16 << 16); }
+
+constexpr int IP_CIN = 256;          // camera feature channels
+constexpr int IP_MT = 9;             // 16-row tiles of Wcat: 128 projection rows + gate row + padding = 144
+constexpr int IP_C = 128;            // projection channels
+constexpr int IP_TP = 128;           // pixels per workgroup (8 waves x 16)
+constexpr int IP_LD = 130;           // LDS row pitch of the image tile (floats): 8*LD = 16 (mod 32) -> the four
+                                     // k-groups of a ds_read_b32 hit different banks
+constexpr int IP_WQ = IP_MT * 2 * 64;  // u32x4 per packed Wcat step tile
+
+// Wcat [144][256] fp32 -> [kb 8][t 9][hi|lo][lane 64] u32x4: lane (m, g) = row 16t+m, channels 32kb + 8g + e
+__global__ __launch_bounds__(256) void pack_proj_kernel(const float *__restrict__ w, int rows, u32x4 *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 8 * IP_WQ) return;
+  int lane = i & 63, part = (i >> 6) & 1;
+  int t = (i >> 7) % IP_MT, kb = (i >> 7) / IP_MT;
+  int m = lane & 15, g = lane >> 4;
+  int row = 16 * t + m;
+  unsigned v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float x = row < rows ? w[(size_t)row * IP_CIN + kb * 32 + g * 8 + e] : 0.f;
+    unsigned hi, lo;
+    ip_split2(x, hi, lo);
+    v[e] = part ? lo : hi;
+  }
+  out[i] = (u32x4){v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+}
+
+struct ProjArgs2 {
+  const float *const *img;   // NI pointers to [256][S] fp32
+  const u32x4 *w;            // packed Wcat
+  u32x4 *usplit;             // [NI][S][128] split rows
+  float *gate;               // [NI][S] row 128 of Wcat . img (no bias)
+  int S;
+};
+
+__global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
+  __shared__ u32x4 Wl[2][IP_WQ];                 // 2 x 18 KB
+  __shared__ float Xl[2][32 * IP_LD];            // 2 x 16.25 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int p0 = blockIdx.x * IP_TP;
+  const float *img = a.img[blockIdx.y];
+  const int S = a.S;
+  const bool pair_ok = (S & 1) == 0;             // rows of an even-length map are 8-byte aligned
+
+  // register staging of the next step's tiles: image tile 32 x 128 floats = 2048 float2, 4 per thread
+  float2 xr[4];
+  u32x4 wr[3];
+  auto load_tiles = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + 512 * i;                     // float2 index: k = e / 64, pixel pair = e % 64
+      int k = e >> 6, p = p0 + 2 * (e & 63);
+      const float *src = img + (size_t)(kb * 32 + k) * S + p;
+      float2 v = make_float2(0.f, 0.f);
+      if (pair_ok && p + 1 < S) v = *(const float2 *)src;
+      else {
+        if (p < S) v.x = src[0];
+        if (p + 1 < S) v.y = src[1];
+      }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int e = tid + 512 * i;
+      wr[i] = a.w[(size_t)kb * IP_WQ + (e < IP_WQ ? e : 0)];
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + 512 * i;
+      int k = e >> 6, pp = 2 * (e & 63);
+      *(float2 *)(&Xl[buf][k * IP_LD + pp]) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int e = tid + 512 * i;
+      if (e < IP_WQ) Wl[buf][e] = wr[i];
+    }
+  };
+
+  f32x4 acc[IP_MT];
+#pragma unroll
+  for (int t = 0; t < IP_MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_tiles(0);
+  store_tiles(0);
+  load_tiles(1);
+  for (int kb = 0; kb < 8; ++kb) {
+    __syncthreads();
+    if (kb + 1 < 8) store_tiles((kb + 1) & 1);
+    if (kb + 2 < 8) load_tiles(kb + 2);
+    // B operand: the 8 k-values of this lane's pixel, read transposed from the staged tile, split hi/lo
+    const float *xb = &Xl[kb & 1][(g * 8) * IP_LD + wave * 16 + n];
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ip_split2(xb[e * IP_LD], h[e], l[e]);
+    const u32x4 bh = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    const u32x4 bl = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    const u32x4 *wb = Wl[kb & 1] + lane;
+#pragma unroll
+    for (int t = 0; t < IP_MT; ++t) {
+      const u32x4 ah = wb[(t * 2) * 64], al = wb[(t * 2 + 1) * 64];
+      acc[t] = DF3D_MFMA_BF16(ah, bl, acc[t]);
+      acc[t] = DF3D_MFMA_BF16(al, bh, acc[t]);
+      acc[t] = DF3D_MFMA_BF16(ah, bh, acc[t]);
+    }
+  }
+
+  // epilogue: lane (pixel n, g) holds channels 16t + 4g + {0..3}: pixel-major split rows + the gate column
+  const int p = p0 + wave * 16 + n;
+  if (p >= S) return;
+  const size_t row = (size_t)blockIdx.y * S + p;
+  char *urow = (char *)a.usplit + row * (IP_C * 4);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ip_split2(acc[t][e], h[e], l[e]);
+    char *blk = urow + (2 * t + (g >> 1)) * 32 + (g & 1) * 8;      // 8-channel block = [hi 16 B | lo 16 B]
+    *(u32x2 *)blk = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+    *(u32x2 *)(blk + 16) = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+  }
+  if (g == 0) a.gate[row] = acc[8][0];
+}
+
+// mom[n][c] = (sum_p a_p u_cp, sum_p (a_p u_cp)^2) from split rows; a may be NULL (a_p = 1)
+__global__ __launch_bounds__(256) void split_moments_kernel(const u32x4 *__restrict__ us, const float *__restrict__ a,
+                                                            int S, int rows_per_block, double *__restrict__ mom) {
+  const int nimg = blockIdx.y;
+  const int blk = threadIdx.x & 15, rsub = threadIdx.x >> 4;     // 16 blocks of 8 channels per row, 16 rows in flight
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, S);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  for (int r = r0 + rsub; r < r1; r += 16) {
+    const size_t row = (size_t)nimg * S + r;
+    const u32x4 hi = us[row * 32 + blk * 2], lo = us[row * 32 + blk * 2 + 1];
+    const float ar = a ? a[row] : 1.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v0 = (ip_bf16_to_float(hi[e] & 0xffffu) + ip_bf16_to_float(lo[e] & 0xffffu)) * ar;
+      float v1 = (ip_bf16_to_float(hi[e] >> 16) + ip_bf16_to_float(lo[e] >> 16)) * ar;
+      s1[2 * e] += v0;
+      s2[2 * e] += v0 * v0;
+      s1[2 * e + 1] += v1;
+      s2[2 * e + 1] += v1 * v1;
+    }
+  }
+  __shared__ float sh[2][16][IP_C + 1];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sh[0][rsub][blk * 8 + e] = s1[e];
+    sh[1][rsub][blk * 8 + e] = s2[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < IP_C) {
+    double d1 = 0.0, d2 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      d1 += sh[0][k][threadIdx.x];
+      d2 += sh[1][k][threadIdx.x];
+    }
+    atomicAdd(&mom[((size_t)nimg * IP_C + threadIdx.x) * 2], d1);
+    atomicAdd(&mom[((size_t)nimg * IP_C + threadIdx.x) * 2 + 1], d2);
+  }
+}
+
+constexpr int RG_COUT = 256;                      // both layers' value projections
+constexpr int RG_CT = RG_COUT / 16;
+constexpr int RG_WQ = RG_CT * 2 * 64;             // u32x4 per step tile = 32 KB
+
+// GroupNorm fold (see gn_fold_kernel in actr.hip) with the folded weights written as packed B operands
+//   Wp[n][kb 4][ct 16][hi|lo][lane]: lane (col_n, g) -> output column col_n*16 + ct, channels 32kb + 8g + e
+__global__ __launch_bounds__(256) void gn_fold_pack_kernel(const double *__restrict__ mom, const float *__restrict__ b,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float eps, int S, int groups,
+                                                           const float *__restrict__ W, const float *__restrict__ wb,
+                                                           u32x4 *__restrict__ Wp, float *__restrict__ cf) {
+  const int n = blockIdx.x, tid = threadIdx.x;
+  constexpr int C = IP_C, O = RG_COUT;
+  __shared__ double m1[C], m2[C];
+  __shared__ float sc[C], tc[C];
+  if (tid < C) {
+    double su = mom[((size_t)n * C + tid) * 2], sq = mom[((size_t)n * C + tid) * 2 + 1];
+    double bc = b ? (double)b[tid] : 0.0;
+    m1[tid] = su + S * bc;
+    m2[tid] = sq + 2.0 * bc * su + S * bc * bc;
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  if (tid < C) {
+    int gi = tid / cpg;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < cpg; ++k) { s += m1[gi * cpg + k]; q += m2[gi * cpg + k]; }
+    double cnt = (double)cpg * S;
+    double mean = s / cnt, var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float bc = b ? b[tid] : 0.f;
+    sc[tid] = rstd * gamma[tid];
+    tc[tid] = (bc - (float)mean) * rstd * gamma[tid] + beta[tid];
+  }
+  __syncthreads();
+  for (int o = tid; o < O; o += 256) {
+    float acc = wb ? wb[o] : 0.f;
+    for (int c = 0; c < C; ++c) acc += W[(size_t)o * C + c] * tc[c];
+    cf[(size_t)n * O + o] = acc;
+  }
+  for (int i = tid; i < 4 * RG_WQ; i += 256) {
+    int lane = i & 63, part = (i >> 6) & 1, ct = (i >> 7) & 15, kb = i >> 11;
+    int col = (lane & 15) * 16 + ct, gq = lane >> 4;
+    unsigned v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = kb * 32 + gq * 8 + e;
+      unsigned hi, lo;
+      ip_split2(W[(size_t)col * C + c] * sc[c], hi, lo);
+      v[e] = part ? lo : hi;
+    }
+    Wp[(size_t)n * 4 * RG_WQ + i] = (u32x4){v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+  }
+}
+
+// value[n][p][0:256] = u[n][p][0:128] . Wf[n]^T: rows contiguous, weights per image (blockIdx.y)
+__global__ __launch_bounds__(512) void rows_gemm_split_kernel(const u32x4 *__restrict__ us, const u32x4 *__restrict__ Wp,
+                                                              int S, float *__restrict__ out) {
+  __shared__ u32x4 Wl[2][RG_WQ];                 // 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int nimg = blockIdx.y;
+  const int p0 = blockIdx.x * 128 + wave * 16;
+  const int pr = min(p0 + n, S - 1);
+  const u32x4 *w = Wp + (size_t)nimg * 4 * RG_WQ;
+  // A operands of the wave's 16 rows, all four 32-channel blocks
+  u32x4 ah[4], al[4];
+  const u32x4 *urow = us + ((size_t)nimg * S + pr) * 32;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    ah[kb] = urow[(kb * 4 + g) * 2];
+    al[kb] = urow[(kb * 4 + g) * 2 + 1];
+  }
+  u32x4 wr[4];
+  auto load_w = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[i] = w[(size_t)kb * RG_WQ + tid + 512 * i];
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Wl[buf][tid + 512 * i] = wr[i];
+  };
+  f32x4 acc[RG_CT];
+#pragma unroll
+  for (int ct = 0; ct < RG_CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  load_w(0);
+  store_w(0);
+  load_w(1);
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    __syncthreads();
+    if (kb + 1 < 4) store_w((kb + 1) & 1);
+    if (kb + 2 < 4) load_w(kb + 2);
+    const u32x4 *wb = Wl[kb & 1] + lane;
+    u32x4 fq[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fq[0][k] = wb[k * 64];
+#pragma unroll
+    for (int ct = 0; ct < RG_CT; ct += 2) {
+      const int cur = (ct >> 1) & 1;
+      if (ct + 2 < RG_CT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fq[cur ^ 1][k] = wb[((ct + 2) * 2 + k) * 64];
+      }
+      const u32x4 bh0 = fq[cur][0], bl0 = fq[cur][1], bh1 = fq[cur][2], bl1 = fq[cur][3];
+      acc[ct] = DF3D_MFMA_BF16(al[kb], bh0, acc[ct]);
+      acc[ct + 1] = DF3D_MFMA_BF16(al[kb], bh1, acc[ct + 1]);
+      acc[ct] = DF3D_MFMA_BF16(ah[kb], bl0, acc[ct]);
+      acc[ct + 1] = DF3D_MFMA_BF16(ah[kb], bl1, acc[ct + 1]);
+      acc[ct] = DF3D_MFMA_BF16(ah[kb], bh0, acc[ct]);
+      acc[ct + 1] = DF3D_MFMA_BF16(ah[kb], bh1, acc[ct + 1]);
+    }
+  }
+  // lane (col_n, g) holds rows 4g+r, columns 16 col_n .. +15
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int p = blockIdx.x * 128 + wave * 16 + 4 * g + r;
+    if (p >= S) continue;
+    float *o = out + ((size_t)nimg * S + p) * RG_COUT + n * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(f32x4 *)(o + q * 4) = (f32x4){acc[q * 4][r], acc[q * 4 + 1][r], acc[q * 4 + 2][r], acc[q * 4 + 3][r]};
+  }
+}
+
+}  // namespace df3d
+
+using namespace df3d;
+
+extern "C" size_t df3d_imgproj_packed_bytes(int rows, int cin) {
+  if (cin != IP_CIN || rows <= 0 || rows > IP_MT * 16) return 0;
+  return (size_t)8 * IP_WQ * 16;
+}
+
+extern "C" int df3d_imgproj_pack(const float *wcat, int rows, int cin, void *packed, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(wcat && packed, "imgproj_pack: null argument");
+  DF3D_CHECK_ARG(df3d_imgproj_packed_bytes(rows, cin) != 0,
+                 "imgproj_pack: serves cin == 256 and at most 144 output rows (got %d x %d)", rows, cin);
+  hipLaunchKernelGGL(pack_proj_kernel, dim3(cdiv(8 * IP_WQ, 256)), dim3(256), 0, stream, wcat, rows, (u32x4 *)packed);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_imgproj_split(const float *const *img_ptrs, int nimg, int cin, int S, const void *packed,
+                                  void *u_split, float *gate, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(img_ptrs && packed && u_split && gate, "imgproj_split: null argument");
+  DF3D_CHECK_ARG(cin == IP_CIN, "imgproj_split: serves 256 input channels (got %d)", cin);
+  if (nimg == 0 || S == 0) return DF3D_OK;
+  ProjArgs2 a = {img_ptrs, (const u32x4 *)packed, (u32x4 *)u_split, gate, S};
+  hipLaunchKernelGGL(img_proj_split_kernel, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_value_fold_gemm(const void *u_split, const float *att, int nimg, int S, const float *conv_bias,
+                                    const float *gn_weight, const float *gn_bias, float eps, int groups,
+                                    const float *W, const float *wb, double *moments, void *packed_w, float *cf,
+                                    float *value, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(u_split && gn_weight && gn_bias && W && moments && packed_w && cf && value,
+                 "value_fold_gemm: null argument");
+  DF3D_CHECK_ARG(groups > 0 && IP_C % groups == 0, "value_fold_gemm: bad group count %d", groups);
+  if (nimg == 0 || S == 0) return DF3D_OK;
+  DF3D_HIP(hipMemsetAsync(moments, 0, (size_t)nimg * IP_C * 2 * sizeof(double), stream));
+  const int rpb = 1024;
+  hipLaunchKernelGGL(split_moments_kernel, dim3(cdiv(S, rpb), nimg), dim3(256), 0, stream, (const u32x4 *)u_split, att,
+                     S, rpb, moments);
+  hipLaunchKernelGGL(gn_fold_pack_kernel, dim3(nimg), dim3(256), 0, stream, moments, conv_bias, gn_weight, gn_bias, eps,
+                     S, groups, W, wb, (u32x4 *)packed_w, cf);
+  hipLaunchKernelGGL(rows_gemm_split_kernel, dim3(cdiv(S, 128), nimg), dim3(512), 0, stream, (const u32x4 *)u_split,
+                     (const u32x4 *)packed_w, S, value);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}

@@ -81,6 +81,11 @@ SIGNATURES = {
                                c_void_p, c_float, c_void_p, c_void_p]),
     "df3d_timing_count_pairs": (c_int, [c_int]),
     "df3d_timing_get2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_imgproj_packed_bytes": (c_size_t, [c_int, c_int]),
+    "df3d_imgproj_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_imgproj_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_value_fold_gemm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_backbone_run": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_size_t, c_void_p, c_void_p, c_void_p]),
     "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),

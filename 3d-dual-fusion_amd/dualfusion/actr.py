@@ -478,7 +478,6 @@ class ACTR(nn.Module):
         conv, gn = self.input_proj[0][0], self.input_proj[0][1]
         layers = self.transformer.encoder.layers
         C = gn.num_channels
-        N, _, S = u.shape
         vkey = tuple((l.self_attn.value_proj.weight.data_ptr(), l.self_attn.value_proj.weight._version,
                       l.self_attn.value_proj.bias._version) for l in layers)
         hit = getattr(self, "_vcat", None)
@@ -487,8 +486,13 @@ class ACTR(nn.Module):
                    torch.cat([l.self_attn.value_proj.bias for l in layers], 0).contiguous())
             object.__setattr__(self, "_vcat", hit)
         W, wb = hit[1], hit[2]
-        Wf, cf = _ops.groupnorm_fold(u, gate, conv.bias, gn, W, wb)
-        value = torch.bmm(u[:, :C].transpose(1, 2), Wf.transpose(1, 2))             # [N, S, nlayers*C]
+        if u.dtype == torch.uint8:
+            # u arrives as pixel-major split rows (csrc/imgproj.hip): moments, fold and the value GEMM of all
+            # layers in one native call on the bf16 matrix cores
+            value, cf = _ops.value_fold_gemm(u, gate, conv.bias, gn, W, wb)
+        else:
+            Wf, cf = _ops.groupnorm_fold(u, gate, conv.bias, gn, W, wb)
+            value = torch.bmm(u[:, :C].transpose(1, 2), Wf.transpose(1, 2))         # [N, S, nlayers*C]
         M = layers[0].self_attn.n_heads
         layer_values = [(value[:, :, i * C:(i + 1) * C].unflatten(-1, (M, C // M)), gate, cf[:, i * C:(i + 1) * C])
                         for i in range(len(layers))]

@@ -125,6 +125,7 @@ class VoxelWithPointProjection(nn.Module):
         self._prefetched = None
         self._ptr_tables = {}
         self._wcat = None
+        self._wpack = None
 
     # ------------------------------------------------------------------ inputs
     def _gather_inputs(self, batch_dict, layer_name, dev):
@@ -202,6 +203,15 @@ class VoxelWithPointProjection(nn.Module):
         else:
             wcat = w_ip
         S_pix = inp['h'] * inp['w']
+        if (img_conv_func is None and self.pfat.can_fold() and len(self.pfat.transformer.encoder.layers) == 2
+                and _ops.imgproj_supported(wcat.shape[0], imgs[0].shape[0], w_ip.shape[0])
+                and os.environ.get("DF3D_IMGPROJ", "1") == "1"):
+            # native split-precision projection straight from the channel-first maps (csrc/imgproj.hip): returns
+            # (pixel-major split rows of the 128 projection channels, fp32 gate row)
+            key = (wcat.data_ptr(), wcat._version)
+            if self._wpack is None or self._wpack[0] != key:
+                self._wpack = (key, _ops.imgproj_pack(wcat.contiguous()))
+            return _ops.imgproj_split(inp['img_ptrs'], len(imgs), imgs[0].shape[0], S_pix, self._wpack[1])
         # The camera network runs the cameras as one batch, so the per-camera dict entries are normally views of one
         # tensor at a uniform stride: then the projection is a single batched GEMM over that storage (still no copy).
         # Unrelated buffers get one GEMM per map.
@@ -294,7 +304,8 @@ class VoxelWithPointProjection(nn.Module):
             inp, both, ev = pre[2], pre[3], pre[4]
             main = torch.cuda.current_stream(dev)
             main.wait_event(ev)
-            both.record_stream(main)
+            for t_ in (both if isinstance(both, tuple) else (both,)):
+                t_.record_stream(main)
         else:
             inp = self._gather_inputs(batch_dict, layer_name, dev)
             both = self._image_projection(inp, img_conv_func)
@@ -333,7 +344,7 @@ class VoxelWithPointProjection(nn.Module):
             # (a9) image-side gate, canvas-free: the projection above also produced the gate's 1-channel image
             # summary (extra GEMM row); the voxel side is 9 scalars per visible voxel
             T, kg, w3, b3 = self.ifat.folded()
-            gate = both[:, w_ip.shape[0]] + b3                                   # [NI, H*W]
+            gate = (both[1] if isinstance(both, tuple) else both[:, w_ip.shape[0]]) + b3     # [NI, H*W]
             S = torch.empty((NI, 9, H, W), dtype=torch.float32, device=dev)
             winner = torch.empty((NI, H, W), dtype=torch.int32, device=dev)
             first = True
@@ -375,7 +386,8 @@ class VoxelWithPointProjection(nn.Module):
         _lib.check(rc, "df3d_assemble_queries2")
         # (a10-a12) ACTR
         if fold:
-            enh = self.pfat.forward_folded(v_feat, qgrid, both, None if att is None else att.view(NI, S_pix), (H, W),
+            enh = self.pfat.forward_folded(v_feat, qgrid, both[0] if isinstance(both, tuple) else both,
+                                           None if att is None else att.view(NI, S_pix), (H, W),
                                            v_i_feat, qpts, q_pos=qpos).contiguous()
         else:
             enh = self.pfat.forward_projected(v_feat, qgrid, src_conv, v_i_feat, qpts, q_pos=qpos).contiguous()

@@ -441,6 +441,56 @@ def ffn_fused(x, packed, b1, b2, d_ffn, residual=None, ln_weight=None, ln_bias=N
     return out
 
 
+def imgproj_supported(rows, cin, c_model):
+    return c_model == 128 and _lib.load().df3d_imgproj_packed_bytes(int(rows), int(cin)) > 0
+
+
+def imgproj_pack(wcat):
+    """Wcat [rows <= 144, 256] fp32 -> packed MFMA operands of csrc/imgproj.hip."""
+    lib = _lib.load()
+    _chk(wcat, torch.float32, "wcat")
+    rows, cin = wcat.shape
+    nbytes = lib.df3d_imgproj_packed_bytes(rows, cin)
+    if nbytes == 0:
+        raise _lib.Df3dError("image projection kernel serves 256 input channels and <= 144 rows (got %s)" %
+                             (tuple(wcat.shape),))
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=wcat.device)
+    rc = lib.df3d_imgproj_pack(_ptr(wcat), rows, cin, _ptr(packed), _stream())
+    _lib.check(rc, "df3d_imgproj_pack")
+    return packed
+
+
+def imgproj_split(img_ptrs, nimg, cin, S, packed):
+    """-> (u_split uint8 [nimg, S, 512], gate fp32 [nimg, S]) from the camera maps behind the pointer table."""
+    lib = _lib.load()
+    u = torch.empty((nimg, S, 512), dtype=torch.uint8, device=packed.device)
+    gate = torch.empty((nimg, S), dtype=torch.float32, device=packed.device)
+    rc = lib.df3d_imgproj_split(_ptr(img_ptrs), nimg, cin, S, _ptr(packed), _ptr(u), _ptr(gate), _stream())
+    _lib.check(rc, "df3d_imgproj_split")
+    return u, gate
+
+
+def value_fold_gemm(u_split, att, conv_bias, gn, W, wb):
+    """-> (value fp32 [nimg, S, 256], cf [nimg, 256]): W GroupNorm(att*u + conv_bias) + wb = att_p * value_p + cf."""
+    lib = _lib.load()
+    _chk(u_split, torch.uint8, "u_split")
+    nimg, S = u_split.shape[0], u_split.shape[1]
+    if att is not None:
+        _chk(att, torch.float32, "att")
+    if tuple(W.shape) != (256, 128):
+        raise _lib.Df3dError("value_fold_gemm: stacked value projections must be [256, 128] (got %s)" % (tuple(W.shape),))
+    dev = u_split.device
+    mom = torch.empty((nimg, 128, 2), dtype=torch.float64, device=dev)
+    pw = torch.empty((nimg, 128 * 1024), dtype=torch.uint8, device=dev)
+    cf = torch.empty((nimg, 256), dtype=torch.float32, device=dev)
+    value = torch.empty((nimg, S, 256), dtype=torch.float32, device=dev)
+    rc = lib.df3d_value_fold_gemm(_ptr(u_split), _ptr(att), nimg, S, _ptr(conv_bias), _ptr(gn.weight), _ptr(gn.bias),
+                                  float(gn.eps), int(gn.num_groups), _ptr(W), _ptr(wb), _ptr(mom), _ptr(pw), _ptr(cf),
+                                  _ptr(value), _stream())
+    _lib.check(rc, "df3d_value_fold_gemm")
+    return value, cf
+
+
 def rows_groupnorm(x, gn):
     """GroupNorm of [N, Q, C] rows == gn(x.transpose(1, 2)).transpose(1, 2), without the transposes."""
     lib = _lib.load()

@@ -344,6 +344,27 @@ int df3d_ffn_fused(const float *x, long long rows, int d_model, int d_ffn, const
                    float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Image side of the fusion on the bf16 matrix cores, split precision (csrc/imgproj.hip).  Replaces the 1x1
+ * convolutions over the camera maps: the image gate's summary (attention.py:456), ACTR's input_proj conv +
+ * GroupNorm (actr.py:139-149) and every layer's value_proj (ms_deform_attn.py:139), for 256-channel maps and a
+ * 128-channel model.
+ *   df3d_imgproj_pack:    Wcat [rows <= 144][256] fp32 (input_proj weight rows, then the gate's row) -> packed
+ *   df3d_imgproj_split:   u = Wcat . img per pixel, from the nimg channel-first maps [256][S] behind img_ptrs:
+ *                         u_split [nimg][S][128] split rows (hi|lo bf16, 512 B per pixel) and gate [nimg][S] = row 128
+ *   df3d_value_fold_gemm: GroupNorm statistics of x = att*u + conv_bias (att may be NULL), their fold into the
+ *                         stacked value projections W [256][128] / wb [256] and value [nimg][S][256] = u . Wf[n]^T;
+ *                         cf [nimg][256] is the folded constant: W*GroupNorm(x)+wb = att_p * value_p + cf[n].
+ *                         Scratch: moments nimg*128*2 doubles, packed_w nimg*128 KiB.
+ * ---------------------------------------------------------------------------------- */
+size_t df3d_imgproj_packed_bytes(int rows, int cin);
+int df3d_imgproj_pack(const float *wcat, int rows, int cin, void *packed, void *stream);
+int df3d_imgproj_split(const float *const *img_ptrs, int nimg, int cin, int S, const void *packed, void *u_split,
+                       float *gate, void *stream);
+int df3d_value_fold_gemm(const void *u_split, const float *att, int nimg, int S, const float *conv_bias,
+                         const float *gn_weight, const float *gn_bias, float eps, int groups, const float *W,
+                         const float *wb, double *moments, void *packed_w, float *cf, float *value, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Native executor for a chain of fused sparse-convolution layers (csrc/executor.hip): the sparse backbones'
  * forward (CP/det3d/models/backbones/scn.py:97-201; TF/mmdet3d/models/middle_encoders/sparse_encoder.py;
  * VR/pcdet/models/backbones_3d/spconv_backbone.py) as one call.  Rulebooks, occupancy directories, features

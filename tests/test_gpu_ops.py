@@ -429,6 +429,40 @@ def test_rows_groupnorm(dev, N, Q, C, G):
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("S,gated", [(40050, True), (1000, False), (77, True)])
+def test_image_projection_split_path(dev, S, gated):
+    """csrc/imgproj.hip: u = Wcat.img from channel-first maps (split rows + gate row) and the folded value GEMM
+    against float64: W GroupNorm(att*u + b) + wb == att * value + cf, 5e-5 of the output scale."""
+    from dualfusion import ops
+    g = torch.Generator(device="cpu").manual_seed(S)
+    NI, Cin, C = 3, 256, 128
+    maps = [(torch.randn(Cin, S, generator=g) * 1.5).to(dev) for _ in range(NI)]
+    wcat = (torch.randn(129, Cin, generator=g) / Cin ** 0.5).to(dev)
+    ptrs = torch.tensor([m.data_ptr() for m in maps], dtype=torch.int64, device=dev)
+    us, gate = ops.imgproj_split(ptrs, NI, Cin, S, ops.imgproj_pack(wcat))
+    ref_u = torch.stack([wcat.double() @ m.double() for m in maps])             # [NI, 129, S]
+    # split rows -> floats
+    w16 = us.view(torch.int16).view(NI, S, 16, 2, 8).to(torch.int32) & 0xffff
+    u_got = ((w16[:, :, :, 0] << 16).view(torch.float32) + (w16[:, :, :, 1] << 16).view(torch.float32)).reshape(NI, S, C)
+    scale = ref_u.abs().max()
+    assert float((u_got.double() - ref_u[:, :C].transpose(1, 2)).abs().max() / scale) < 2e-5
+    assert float((gate.double() - ref_u[:, C]).abs().max() / scale) < 2e-5
+    att = torch.rand(NI, S, generator=g).to(dev) if gated else None
+    gn = torch.nn.GroupNorm(32, C).to(dev)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+    b = torch.randn(C, generator=g).to(dev)
+    Wv = (torch.randn(256, C, generator=g) * 0.1).to(dev)
+    wb = torch.randn(256, generator=g).to(dev)
+    with torch.no_grad():
+        value, cf = ops.value_fold_gemm(us, att, b, gn, Wv, wb)
+        x = ref_u[:, :C].float() * (att[:, None] if gated else 1.0) + b[None, :, None]
+        want = torch.einsum('oc,ncs->nso', Wv.double(), gn(x).double()) + wb.double()
+        got = value.double() * (att[..., None].double() if gated else 1.0) + cf[:, None].double()
+    assert float((got - want).abs().max() / want.abs().max()) < 5e-5
+
+
 def test_msda_linearity_at_full_size(dev):
     """BASELINE config 2 size (6 cams, 150x267 map, Q=8000): linear in value and in the weights."""
     from dualfusion import ops
