@@ -39,6 +39,29 @@ void set_error(const char *fmt, ...);
   } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+#ifdef __HIPCC__
+// hi/lo bf16 split of two fp32 values with the hardware converter (v_cvt_pk_bf16_f32, round to nearest even):
+// hi = bf16(x), lo = bf16(x - hi); each result packs the pair (x0 in the low 16 bits).  5 VALU per pair.
+typedef __bf16 df3d_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float df3d_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_ref(float x0, float x1, unsigned &hi, unsigned &lo) {
+  df3d_f32x2 v = {x0, x1};
+  df3d_bf16x2 h = __builtin_convertvector(v, df3d_bf16x2);
+  df3d_f32x2 r = v - __builtin_convertvector(h, df3d_f32x2);
+  df3d_bf16x2 l = __builtin_convertvector(r, df3d_bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// outputs may be vector elements (which cannot bind to references)
+#define split_pair(x0, x1, HI, LO)                 \
+  do {                                             \
+    unsigned sp_h__, sp_l__;                       \
+    df3d::split_pair_ref(x0, x1, sp_h__, sp_l__);  \
+    (HI) = sp_h__;                                 \
+    (LO) = sp_l__;                                 \
+  } while (0)
+#endif
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Bump allocator over a caller-provided workspace.

@@ -112,17 +112,10 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
   for (int kb = 0; kb < 4; ++kb) {
     const float *p = a.x + row_ld * FFN_C + kb * 32 + g * 8;
     f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
-    unsigned h[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ffn_split2(v0[e], h[e], l[e]);
-      ffn_split2(v1[e], h[4 + e], l[4 + e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      xh[kb][e] = h[2 * e] | (h[2 * e + 1] << 16);
-      xl[kb][e] = l[2 * e] | (l[2 * e + 1] << 16);
-    }
+    split_pair(v0[0], v0[1], xh[kb][0], xl[kb][0]);
+    split_pair(v0[2], v0[3], xh[kb][1], xl[kb][1]);
+    split_pair(v1[0], v1[1], xh[kb][2], xl[kb][2]);
+    split_pair(v1[2], v1[3], xh[kb][3], xl[kb][3]);
   }
 
   u32x4 wreg[WPT];
@@ -180,18 +173,13 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
     u32x4 hh[4], hl[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      unsigned h[8], l[8];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int t = 2 * q + half;
         const f32x4 b = *(const f32x4 *)(a.b1 + c * 128 + t * 16 + 4 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ffn_split2(fmaxf(acc1[t][e] + b[e], 0.f), h[half * 4 + e], l[half * 4 + e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        hh[q][e] = h[2 * e] | (h[2 * e + 1] << 16);
-        hl[q][e] = l[2 * e] | (l[2 * e + 1] << 16);
+        split_pair(fmaxf(acc1[t][0] + b[0], 0.f), fmaxf(acc1[t][1] + b[1], 0.f), hh[q][half * 2], hl[q][half * 2]);
+        split_pair(fmaxf(acc1[t][2] + b[2], 0.f), fmaxf(acc1[t][3] + b[3], 0.f), hh[q][half * 2 + 1],
+                   hl[q][half * 2 + 1]);
       }
     }
     // ---- phase 2: Y += H_c W2_c^T ----

@@ -74,11 +74,18 @@ struct ProjArgs2 {
   u32x4 *usplit;             // [NI][S][128] split rows
   float *gate;               // [NI][S] row 128 of Wcat . img (no bias)
   int S;
+  int dbg;                   // tuning experiments (DF3D_IP_DBG): 1 = no image loads, 2 = no MFMAs, 4 = no W loads, 8 = no stores
 };
 
 __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
-  __shared__ u32x4 Wl[2][IP_WQ];                 // 2 x 18 KB
-  __shared__ float Xl[2][32 * IP_LD];            // 2 x 16.25 KB
+  // one raw LDS buffer: packed Wcat tiles (2 x 18 KB) + image tiles (2 x 16.25 KB); the epilogue reuses all of it
+  // to turn the accumulators into whole 512-byte rows
+  constexpr int W_BYTES = 2 * IP_WQ * 16, X_BYTES = 2 * 32 * IP_LD * 4;
+  constexpr int ROW_PITCH = 528;                  // 512 B row + 16 B: rows start 4 banks apart
+  static_assert(8 * 16 * ROW_PITCH <= W_BYTES + X_BYTES, "epilogue tile must fit");
+  __shared__ __attribute__((aligned(16))) char smem[W_BYTES + X_BYTES];
+  u32x4 (*Wl)[IP_WQ] = (u32x4(*)[IP_WQ])smem;
+  float (*Xl)[32 * IP_LD] = (float(*)[32 * IP_LD])(smem + W_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
   const int p0 = blockIdx.x * IP_TP;
@@ -96,7 +103,8 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
       int k = e >> 6, p = p0 + 2 * (e & 63);
       const float *src = img + (size_t)(kb * 32 + k) * S + p;
       float2 v = make_float2(0.f, 0.f);
-      if (pair_ok && p + 1 < S) v = *(const float2 *)src;
+      if (a.dbg & 1) {
+      } else if (pair_ok && p + 1 < S) v = *(const float2 *)src;
       else {
         if (p < S) v.x = src[0];
         if (p + 1 < S) v.y = src[1];
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       int e = tid + 512 * i;
-      wr[i] = a.w[(size_t)kb * IP_WQ + (e < IP_WQ ? e : 0)];
+      wr[i] = a.w[(a.dbg & 4) ? (size_t)(e < IP_WQ ? e : 0) & 63 : (size_t)kb * IP_WQ + (e < IP_WQ ? e : 0)];
     }
   };
   auto store_tiles = [&](int buf) {
@@ -136,36 +144,57 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
     if (kb + 2 < 8) load_tiles(kb + 2);
     // B operand: the 8 k-values of this lane's pixel, read transposed from the staged tile, split hi/lo
     const float *xb = &Xl[kb & 1][(g * 8) * IP_LD + wave * 16 + n];
-    unsigned h[8], l[8];
+    u32x4 bh, bl;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ip_split2(xb[e * IP_LD], h[e], l[e]);
-    const u32x4 bh = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-    const u32x4 bl = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    for (int e = 0; e < 4; ++e) split_pair(xb[(2 * e) * IP_LD], xb[(2 * e + 1) * IP_LD], bh[e], bl[e]);
     const u32x4 *wb = Wl[kb & 1] + lane;
+    if (a.dbg & 2) continue;
+    // three row tiles at a time: their 9 MFMAs are interleaved (no back-to-back dependent pair) and the next
+    // group's A fragments come from LDS meanwhile
+    u32x4 fq[2][6];
 #pragma unroll
-    for (int t = 0; t < IP_MT; ++t) {
-      const u32x4 ah = wb[(t * 2) * 64], al = wb[(t * 2 + 1) * 64];
-      acc[t] = DF3D_MFMA_BF16(ah, bl, acc[t]);
-      acc[t] = DF3D_MFMA_BF16(al, bh, acc[t]);
-      acc[t] = DF3D_MFMA_BF16(ah, bh, acc[t]);
+    for (int q = 0; q < 6; ++q) fq[0][q] = wb[q * 64];
+#pragma unroll
+    for (int tg = 0; tg < IP_MT / 3; ++tg) {
+      const int cur = tg & 1;
+      if (tg + 1 < IP_MT / 3) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) fq[cur ^ 1][q] = wb[((tg + 1) * 6 + q) * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[cur][2 * j], bl, acc[tg * 3 + j]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[cur][2 * j + 1], bh, acc[tg * 3 + j]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[cur][2 * j], bh, acc[tg * 3 + j]);
     }
   }
 
-  // epilogue: lane (pixel n, g) holds channels 16t + 4g + {0..3}: pixel-major split rows + the gate column
-  const int p = p0 + wave * 16 + n;
-  if (p >= S) return;
-  const size_t row = (size_t)blockIdx.y * S + p;
-  char *urow = (char *)a.usplit + row * (IP_C * 4);
+  // epilogue: lane (pixel n, g) holds channels 16t + 4g + {0..3}.  The wave's 16 split rows (8 KB) are assembled
+  // in LDS and stored as whole 512-byte rows (scattered 8-byte global stores cost 50 us of 135)
+  __syncthreads();
+  char *wt = smem + wave * 16 * ROW_PITCH;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) ip_split2(acc[t][e], h[e], l[e]);
-    char *blk = urow + (2 * t + (g >> 1)) * 32 + (g & 1) * 8;      // 8-channel block = [hi 16 B | lo 16 B]
-    *(u32x2 *)blk = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-    *(u32x2 *)(blk + 16) = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    unsigned h[2], l[2];
+    split_pair(acc[t][0], acc[t][1], h[0], l[0]);
+    split_pair(acc[t][2], acc[t][3], h[1], l[1]);
+    char *blk = wt + n * ROW_PITCH + (2 * t + (g >> 1)) * 32 + (g & 1) * 8;   // 8-channel block = [hi 16 B | lo 16 B]
+    *(u32x2 *)blk = (u32x2){h[0], h[1]};
+    *(u32x2 *)(blk + 16) = (u32x2){l[0], l[1]};
   }
-  if (g == 0) a.gate[row] = acc[8][0];
+  const int pw = p0 + wave * 16;
+  if (g == 0 && pw + n < S && !(a.dbg & 8)) a.gate[(size_t)blockIdx.y * S + pw + n] = acc[8][0];
+  __builtin_amdgcn_wave_barrier();
+  if (a.dbg & 8) return;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = it * 2 + (lane >> 5), c16 = lane & 31;
+    if (pw + r < S) {
+      const u32x4 v = *(const u32x4 *)(wt + r * ROW_PITCH + c16 * 16);
+      a.usplit[((size_t)blockIdx.y * S + pw + r) * 32 + c16] = v;
+    }
+  }
 }
 
 // mom[n][c] = (sum_p a_p u_cp, sum_p (a_p u_cp)^2) from split rows; a may be NULL (a_p = 1)
@@ -214,7 +243,7 @@ constexpr int RG_CT = RG_COUT / 16;
 constexpr int RG_WQ = RG_CT * 2 * 64;             // u32x4 per step tile = 32 KB
 
 // GroupNorm fold (see gn_fold_kernel in actr.hip) with the folded weights written as packed B operands
-//   Wp[n][kb 4][ct 16][hi|lo][lane]: lane (col_n, g) -> output column col_n*16 + ct, channels 32kb + 8g + e
+//   Wp[n][kb 4][ct 16][hi|lo][lane]: lane (col_n, g) -> output column (ct/4)*64 + col_n*4 + ct%4, channels 32kb+8g+e
 __global__ __launch_bounds__(256) void gn_fold_pack_kernel(const double *__restrict__ mom, const float *__restrict__ b,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, float eps, int S, int groups,
@@ -252,7 +281,7 @@ __global__ __launch_bounds__(256) void gn_fold_pack_kernel(const double *__restr
   }
   for (int i = tid; i < 4 * RG_WQ; i += 256) {
     int lane = i & 63, part = (i >> 6) & 1, ct = (i >> 7) & 15, kb = i >> 11;
-    int col = (lane & 15) * 16 + ct, gq = lane >> 4;
+    int col = (ct >> 2) * 64 + (lane & 15) * 4 + (ct & 3), gq = lane >> 4;   // store q = ct/4 writes 256 B runs
     unsigned v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -323,15 +352,16 @@ __global__ __launch_bounds__(512) void rows_gemm_split_kernel(const u32x4 *__res
       acc[ct + 1] = DF3D_MFMA_BF16(ah[kb], bh1, acc[ct + 1]);
     }
   }
-  // lane (col_n, g) holds rows 4g+r, columns 16 col_n .. +15
+  // lane (col_n, g) holds rows 4g+r, columns 64q + 4 col_n + {0..3} of column tile 4q+j: one store instruction
+  // covers 256 contiguous bytes of a row
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int p = blockIdx.x * 128 + wave * 16 + 4 * g + r;
     if (p >= S) continue;
-    float *o = out + ((size_t)nimg * S + p) * RG_COUT + n * 16;
+    float *o = out + ((size_t)nimg * S + p) * RG_COUT + n * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      *(f32x4 *)(o + q * 4) = (f32x4){acc[q * 4][r], acc[q * 4 + 1][r], acc[q * 4 + 2][r], acc[q * 4 + 3][r]};
+      *(f32x4 *)(o + q * 64) = (f32x4){acc[q * 4][r], acc[q * 4 + 1][r], acc[q * 4 + 2][r], acc[q * 4 + 3][r]};
   }
 }
 
@@ -360,7 +390,8 @@ extern "C" int df3d_imgproj_split(const float *const *img_ptrs, int nimg, int ci
   DF3D_CHECK_ARG(img_ptrs && packed && u_split && gate, "imgproj_split: null argument");
   DF3D_CHECK_ARG(cin == IP_CIN, "imgproj_split: serves 256 input channels (got %d)", cin);
   if (nimg == 0 || S == 0) return DF3D_OK;
-  ProjArgs2 a = {img_ptrs, (const u32x4 *)packed, (u32x4 *)u_split, gate, S};
+  ProjArgs2 a = {img_ptrs, (const u32x4 *)packed, (u32x4 *)u_split, gate, S,
+                 getenv("DF3D_IP_DBG") ? atoi(getenv("DF3D_IP_DBG")) : 0};
   hipLaunchKernelGGL(img_proj_split_kernel, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
@@ -376,7 +407,7 @@ extern "C" int df3d_value_fold_gemm(const void *u_split, const float *att, int n
   DF3D_CHECK_ARG(groups > 0 && IP_C % groups == 0, "value_fold_gemm: bad group count %d", groups);
   if (nimg == 0 || S == 0) return DF3D_OK;
   DF3D_HIP(hipMemsetAsync(moments, 0, (size_t)nimg * IP_C * 2 * sizeof(double), stream));
-  const int rpb = 1024;
+  const int rpb = 160;          // ~1500 blocks at nuScenes size: enough waves to stream at HBM rate
   hipLaunchKernelGGL(split_moments_kernel, dim3(cdiv(S, rpb), nimg), dim3(256), 0, stream, (const u32x4 *)u_split, att,
                      S, rpb, moments);
   hipLaunchKernelGGL(gn_fold_pack_kernel, dim3(nimg), dim3(256), 0, stream, moments, conv_bias, gn_weight, gn_bias, eps,

@@ -51,18 +51,11 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nblk) return;
   f32x4 a = ((const f32x4 *)x)[2 * i], b = ((const f32x4 *)x)[2 * i + 1];
-  unsigned h[8], l[8];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    split2(a[e], h[e], l[e]);
-    split2(b[e], h[4 + e], l[4 + e]);
-  }
   u32x4 ho, lo;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    ho[e] = h[2 * e] | (h[2 * e + 1] << 16);
-    lo[e] = l[2 * e] | (l[2 * e + 1] << 16);
-  }
+  split_pair(a[0], a[1], ho[0], lo[0]);
+  split_pair(a[2], a[3], ho[1], lo[1]);
+  split_pair(b[0], b[1], ho[2], lo[2]);
+  split_pair(b[2], b[3], ho[3], lo[3]);
   out[2 * i] = ho;
   out[2 * i + 1] = lo;
 }
@@ -386,13 +379,13 @@ __global__ __launch_bounds__(256, 1) void spconv_split_kernel(SplitConvArgs a, i
         }
         *(f32x4 *)(a.out + o) = v;
         if (a.out_split) {
-          unsigned h[4], l[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) split2(v[e], h[e], l[e]);
+          unsigned h[2], l[2];
+          split_pair(v[0], v[1], h[0], l[0]);
+          split_pair(v[2], v[3], h[1], l[1]);
           // 8-channel block = [hi 16 B | lo 16 B]; this lane owns 4 of the 8 channels
           char *blk = (char *)a.out_split + (o >> 3) * 32 + ((o >> 2) & 1) * 8;
-          *(u32x2 *)blk = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-          *(u32x2 *)(blk + 16) = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+          *(u32x2 *)blk = (u32x2){h[0], h[1]};
+          *(u32x2 *)(blk + 16) = (u32x2){l[0], l[1]};
         }
       }
     }
@@ -592,12 +585,11 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         }
         *(float2 *)(a.out + o) = v;
         if (a.out_split) {
-          unsigned h0, l0, h1, l1;
-          split2(v.x, h0, l0);
-          split2(v.y, h1, l1);
+          unsigned hp, lp;
+          split_pair(v.x, v.y, hp, lp);
           char *blk = (char *)a.out_split + (o >> 3) * 32 + (n & 3) * 4;     // 8-channel block = [hi 16 B | lo 16 B]
-          *(unsigned *)blk = h0 | (h1 << 16);
-          *(unsigned *)(blk + 16) = l0 | (l1 << 16);
+          *(unsigned *)blk = hp;
+          *(unsigned *)(blk + 16) = lp;
         }
       }
     }
@@ -618,7 +610,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       const int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
       if (row >= a.n_out) continue;
       const size_t o = (size_t)row * COUT + n * CT;
-      unsigned h[CT], l[CT];
+      unsigned h[CT / 2], l[CT / 2];         // packed pairs
 #pragma unroll
       for (int q = 0; q < CT / 4; ++q) {
         f32x4 v = (f32x4){acc[rt][q * 4][r], acc[rt][q * 4 + 1][r], acc[rt][q * 4 + 2][r], acc[rt][q * 4 + 3][r]};
@@ -631,19 +623,20 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
           v[3] = fmaxf(v[3], 0.f);
         }
         *(f32x4 *)(a.out + o + q * 4) = v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2(v[e], h[q * 4 + e], l[q * 4 + e]);
+        if (a.out_split) {
+          split_pair(v[0], v[1], h[q * 2], l[q * 2]);
+          split_pair(v[2], v[3], h[q * 2 + 1], l[q * 2 + 1]);
+        }
       }
       if (a.out_split) {
         char *blk = (char *)a.out_split + (o >> 3) * 32;             // 8-channel block = [hi 16 B | lo 16 B]
-        if (CT == 8) {
-          *(u32x4 *)blk = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-          *(u32x4 *)(blk + 16) =
-              (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+        if constexpr (CT == 8) {
+          *(u32x4 *)blk = (u32x4){h[0], h[1], h[2], h[3]};
+          *(u32x4 *)(blk + 16) = (u32x4){l[0], l[1], l[2], l[3]};
         } else {
           blk += (n & 1) * 8;                                        // two lanes share a block
-          *(u32x2 *)blk = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-          *(u32x2 *)(blk + 16) = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+          *(u32x2 *)blk = (u32x2){h[0], h[1]};
+          *(u32x2 *)(blk + 16) = (u32x2){l[0], l[1]};
         }
       }
     }
