@@ -10,6 +10,7 @@
 // nothing is freed inside a run), and the only host round trips left are the output counts of the strided
 // layers.  The kernels are exactly the ones the per-layer API launches (the extern "C" entry points below call
 // the same functions), so results are bit-identical to the module path.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -55,6 +56,18 @@ struct Bump {
 
 int kvol_of(const int *k) { return k[0] * k[1] * k[2]; }
 
+// Second stream for the geometry work + a small pool of ordering events (created once per process).
+hipStream_t g_geo_stream = nullptr;
+std::vector<hipEvent_t> g_events;
+hipEvent_t order_event(size_t i) {
+  while (g_events.size() <= i) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    g_events.push_back(e);
+  }
+  return g_events[i];
+}
+
 }  // namespace
 
 extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *features, const int32_t *indices,
@@ -64,6 +77,22 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
   DF3D_CHECK_ARG(layers && nlayers > 0 && features && indices && shape && arena && views,
                  "backbone_run: null argument");
   DF3D_CHECK_ARG(n > 0 && batch > 0, "backbone_run: empty input (n=%d, batch=%d)", n, batch);
+  // Geometry (rulebooks, directories, the host round trips for the output counts) runs on its own stream and only
+  // ever waits for itself; the convolutions run on the caller's stream and wait, per rulebook, for the event that
+  // marks its neighbour table complete.  Index sets depend on coordinates alone, so the geometry of later stages
+  // proceeds while the convolutions of earlier stages keep the GPU busy.  DF3D_EXEC_STREAMS=0: one stream.
+  static const bool two_streams = !(getenv("DF3D_EXEC_STREAMS") && getenv("DF3D_EXEC_STREAMS")[0] == '0');
+  hipStream_t gstream = stream;
+  size_t next_event = 0;
+  if (two_streams) {
+    if (!g_geo_stream) DF3D_HIP(hipStreamCreateWithFlags(&g_geo_stream, hipStreamNonBlocking));
+    gstream = g_geo_stream;
+    hipEvent_t e = order_event(next_event++);
+    DF3D_CHECK_ARG(e != nullptr, "backbone_run: cannot create an event");
+    DF3D_HIP(hipEventRecord(e, stream));               // inputs (voxel features / coordinates) are ready
+    DF3D_HIP(hipStreamWaitEvent(gstream, e, 0));
+  }
+  void *gs_ = (void *)gstream;
   Bump mem(arena, arena_bytes);
   std::vector<IndexSet> sets;
   std::vector<LayerOut> outs(nlayers);
@@ -86,9 +115,8 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
   int32_t *count_dev = (int32_t *)mem.take(256);
   DF3D_ARENA_CHECK(count_dev);
 
-  // ---- phase 1, geometry: every rulebook of the chain.  Index sets and neighbour tables depend on the voxel
-  //      coordinates only, so all host round trips (output counts of the strided layers) happen here, while the
-  //      GPU has nothing else to do; phase 2 then enqueues all convolutions back to back and returns. ----
+  // ---- per layer: geometry (neighbour table; for strided layers the output index set, with the one host round
+  //      trip for its size) on the geometry stream, then the fused convolution on the caller's stream ----
   std::vector<const int32_t *> layer_nbr(nlayers, nullptr);
   for (int li = 0; li < nlayers; ++li) {
     const df3d_layer &L = layers[li];
@@ -119,7 +147,7 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
         S.grid = mem.take(S.grid_bytes);
         if (!S.sorted) S.perm = (int32_t *)mem.take((size_t)S.n * 4);
         if (!S.grid || (!S.sorted && !S.perm)) return DF3D_ENOMEM;
-        return df3d_grid_build(S.indices, S.n, batch, S.shape, S.grid, S.grid_bytes, S.perm, stream_);
+        return df3d_grid_build(S.indices, S.n, batch, S.shape, S.grid, S.grid_bytes, S.perm, gs_);
       };
       if (L.kind == 0) {                       // submanifold: outputs = inputs
         int rc = ensure_grid(in_set);
@@ -128,7 +156,7 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
         const IndexSet &S = sets[in_set];
         int32_t *t = (int32_t *)mem.take((size_t)K * S.n * 4);
         DF3D_ARENA_CHECK(t);
-        rc = df3d_subm_neighbors(S.grid, S.perm, S.indices, S.n, batch, S.shape, L.ksize, L.dilation, t, stream_);
+        rc = df3d_subm_neighbors(S.grid, S.perm, S.indices, S.n, batch, S.shape, L.ksize, L.dilation, t, gs_);
         if (rc) return rc;
         nbr = t;
         out_set = in_set;
@@ -148,11 +176,11 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
         int32_t *oi = (int32_t *)mem.take((size_t)cap * 16);
         DF3D_ARENA_CHECK(O.grid && oi);
         int rc = df3d_conv_out_indices(S.indices, S.n, batch, S.shape, O.shape, L.ksize, L.stride, L.padding,
-                                       L.dilation, O.grid, O.grid_bytes, oi, (int)cap, count_dev, stream_);
+                                       L.dilation, O.grid, O.grid_bytes, oi, (int)cap, count_dev, gs_);
         if (rc) return rc;
         int32_t cnt = 0;
-        DF3D_HIP(hipMemcpyAsync(&cnt, count_dev, sizeof(cnt), hipMemcpyDeviceToHost, stream));
-        DF3D_HIP(hipStreamSynchronize(stream));
+        DF3D_HIP(hipMemcpyAsync(&cnt, count_dev, sizeof(cnt), hipMemcpyDeviceToHost, gstream));
+        DF3D_HIP(hipStreamSynchronize(gstream));
         if (cnt > cap) {
           set_error("backbone_run: layer %d produced %d outputs, capacity bound %lld", li, cnt, cap);
           return DF3D_EINVAL;
@@ -173,28 +201,26 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
         int32_t *t = (int32_t *)mem.take((size_t)K * cnt * 4);
         DF3D_ARENA_CHECK(t);
         rc = df3d_conv_neighbors(Sg.grid, Sg.perm, oi, cnt, batch, Sg.shape, L.ksize, L.stride, L.padding, L.dilation,
-                                 t, stream_);
+                                 t, gs_);
         if (rc) return rc;
         nbr = t;
+      }
+      if (two_streams) {                       // the convolutions that use this table wait for it
+        hipEvent_t e = order_event(next_event++);
+        DF3D_CHECK_ARG(e != nullptr, "backbone_run: cannot create an event");
+        DF3D_HIP(hipEventRecord(e, gstream));
+        DF3D_HIP(hipStreamWaitEvent(stream, e, 0));
       }
       rulebooks.push_back(std::make_pair(L.rulebook, nbr));
       rulebook_set.push_back(out_set);
     }
-    (void)n_out;
     layer_nbr[li] = nbr;
     outs[li].set = out_set;
     outs[li].channels = L.cout;
-  }
 
-  // ---- phase 2, features: one fused convolution per layer, no host synchronisation ----
-  for (int li = 0; li < nlayers; ++li) {
-    const df3d_layer &L = layers[li];
+    // ---- features: the fused convolution of this layer, enqueued on the caller's stream (no host wait) ----
     const float *in_feat = L.input < 0 ? features : outs[L.input].features;
-    const int in_set = L.input < 0 ? 0 : outs[L.input].set;
-    const int K = kvol_of(L.ksize);
-    const int32_t *nbr = layer_nbr[li];
-    const int out_set = outs[li].set;
-    const int n_out = sets[out_set].n;
+    n_out = sets[out_set].n;
     const int n_in = sets[in_set].n;
     LayerOut &o = outs[li];
     df3d_layer_view &v = views[li];
@@ -248,6 +274,12 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
     v.channels = L.cout;
     v.rows_sorted = OS.sorted ? 1 : 0;
     memcpy(v.shape, OS.shape, sizeof(v.shape));
+  }
+  if (two_streams) {                           // exported index sets / directories were written on the geometry stream
+    hipEvent_t e = order_event(next_event++);
+    DF3D_CHECK_ARG(e != nullptr, "backbone_run: cannot create an event");
+    DF3D_HIP(hipEventRecord(e, gstream));
+    DF3D_HIP(hipStreamWaitEvent(stream, e, 0));
   }
   // directories may have been built after a view was written: refresh
   for (int li = 0; li < nlayers; ++li) {
