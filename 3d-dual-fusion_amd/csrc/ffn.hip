@@ -92,30 +92,36 @@ struct FfnArgs {
   int H;
 };
 
-template <int NW>
+// NW waves per workgroup, RT 16-row tiles per wave.  RT = 2 halves the LDS fragment reads per MFMA (every operand
+// fragment read from LDS feeds two row tiles) at the price of one resident wave per SIMD.
+template <int NW, int RT>
 __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
-  constexpr int NT = NW * 64, TM = NW * 16;
+  constexpr int NT = NW * 64, WR = 16 * RT, TM = NW * WR;
   constexpr int WPT = FFN_WQ / NT;
   static_assert(FFN_WQ % NT == 0, "tile must divide over the workgroup");
   __shared__ u32x4 Wl[2][FFN_WQ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
-  const long long row_n = (long long)blockIdx.x * TM + wave * 16 + n;        // the row this lane feeds as operand
-  const long long row_ld = row_n < a.rows ? row_n : a.rows - 1;
+  const long long wrow0 = (long long)blockIdx.x * TM + wave * WR;
   const int nchunks = a.H / 128;
   const int steps = nchunks * 8;
 
-  // x fragments of the wave's 16 rows: lane (row n, g) holds channels 32kb + 8g .. +7, split hi/lo
-  u32x4 xh[4], xl[4];
+  // x fragments of the wave's rows: lane (row n of tile rt, g) holds channels 32kb + 8g .. +7, split hi/lo
+  u32x4 xh[RT][4], xl[RT][4];
 #pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
-    const float *p = a.x + row_ld * FFN_C + kb * 32 + g * 8;
-    f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
-    split_pair(v0[0], v0[1], xh[kb][0], xl[kb][0]);
-    split_pair(v0[2], v0[3], xh[kb][1], xl[kb][1]);
-    split_pair(v1[0], v1[1], xh[kb][2], xl[kb][2]);
-    split_pair(v1[2], v1[3], xh[kb][3], xl[kb][3]);
+  for (int rt = 0; rt < RT; ++rt) {
+    const long long row_n = wrow0 + rt * 16 + n;
+    const long long row_ld = row_n < a.rows ? row_n : a.rows - 1;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float *p = a.x + row_ld * FFN_C + kb * 32 + g * 8;
+      f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
+      split_pair(v0[0], v0[1], xh[rt][kb][0], xl[rt][kb][0]);
+      split_pair(v0[2], v0[3], xh[rt][kb][1], xl[rt][kb][1]);
+      split_pair(v1[0], v1[1], xh[rt][kb][2], xl[rt][kb][2]);
+      split_pair(v1[2], v1[3], xh[rt][kb][3], xl[rt][kb][3]);
+    }
   }
 
   u32x4 wreg[WPT];
@@ -130,17 +136,21 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
     for (int i = 0; i < WPT; ++i) Wl[buf][tid + NT * i] = wreg[i];
   };
 
-  f32x4 acc2[8];
+  f32x4 acc2[RT][8];
 #pragma unroll
-  for (int ct = 0; ct < 8; ++ct) acc2[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) acc2[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   load_w(0);
   store_w(0);
   load_w(1);
   for (int c = 0; c < nchunks; ++c) {
-    f32x4 acc1[8];
+    f32x4 acc1[RT][8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc1[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // ---- phase 1: H^T chunk = W1_c x^T ----
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -161,25 +171,38 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
           for (int q = 0; q < 4; ++q) fq[cur ^ 1][q] = wb[((t + 2) * 2 + q) * 64];
         }
         const u32x4 ah0 = fq[cur][0], al0 = fq[cur][1], ah1 = fq[cur][2], al1 = fq[cur][3];
-        acc1[t] = DF3D_MFMA_BF16(ah0, xl[kb], acc1[t]);
-        acc1[t + 1] = DF3D_MFMA_BF16(ah1, xl[kb], acc1[t + 1]);
-        acc1[t] = DF3D_MFMA_BF16(al0, xh[kb], acc1[t]);
-        acc1[t + 1] = DF3D_MFMA_BF16(al1, xh[kb], acc1[t + 1]);
-        acc1[t] = DF3D_MFMA_BF16(ah0, xh[kb], acc1[t]);
-        acc1[t + 1] = DF3D_MFMA_BF16(ah1, xh[kb], acc1[t + 1]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc1[rt][t] = DF3D_MFMA_BF16(ah0, xl[rt][kb], acc1[rt][t]);
+          acc1[rt][t + 1] = DF3D_MFMA_BF16(ah1, xl[rt][kb], acc1[rt][t + 1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc1[rt][t] = DF3D_MFMA_BF16(al0, xh[rt][kb], acc1[rt][t]);
+          acc1[rt][t + 1] = DF3D_MFMA_BF16(al1, xh[rt][kb], acc1[rt][t + 1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc1[rt][t] = DF3D_MFMA_BF16(ah0, xh[rt][kb], acc1[rt][t]);
+          acc1[rt][t + 1] = DF3D_MFMA_BF16(ah1, xh[rt][kb], acc1[rt][t + 1]);
+        }
       }
     }
     // ---- bias + ReLU + split: lane (row n, g) holds hidden 128c + 16t + 4g + {0..3} -> phase-2 A operands ----
-    u32x4 hh[4], hl[4];
+    u32x4 hh[RT][4], hl[RT][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int t = 2 * q + half;
         const f32x4 b = *(const f32x4 *)(a.b1 + c * 128 + t * 16 + 4 * g);
-        split_pair(fmaxf(acc1[t][0] + b[0], 0.f), fmaxf(acc1[t][1] + b[1], 0.f), hh[q][half * 2], hl[q][half * 2]);
-        split_pair(fmaxf(acc1[t][2] + b[2], 0.f), fmaxf(acc1[t][3] + b[3], 0.f), hh[q][half * 2 + 1],
-                   hl[q][half * 2 + 1]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          split_pair(fmaxf(acc1[rt][t][0] + b[0], 0.f), fmaxf(acc1[rt][t][1] + b[1], 0.f), hh[rt][q][half * 2],
+                     hl[rt][q][half * 2]);
+          split_pair(fmaxf(acc1[rt][t][2] + b[2], 0.f), fmaxf(acc1[rt][t][3] + b[3], 0.f), hh[rt][q][half * 2 + 1],
+                     hl[rt][q][half * 2 + 1]);
+        }
       }
     }
     // ---- phase 2: Y += H_c W2_c^T ----
@@ -201,12 +224,21 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
           for (int k = 0; k < 4; ++k) fq[cur ^ 1][k] = wb[((ct + 2) * 2 + k) * 64];
         }
         const u32x4 bh0 = fq[cur][0], bl0 = fq[cur][1], bh1 = fq[cur][2], bl1 = fq[cur][3];
-        acc2[ct] = DF3D_MFMA_BF16(hl[q], bh0, acc2[ct]);
-        acc2[ct + 1] = DF3D_MFMA_BF16(hl[q], bh1, acc2[ct + 1]);
-        acc2[ct] = DF3D_MFMA_BF16(hh[q], bl0, acc2[ct]);
-        acc2[ct + 1] = DF3D_MFMA_BF16(hh[q], bl1, acc2[ct + 1]);
-        acc2[ct] = DF3D_MFMA_BF16(hh[q], bh0, acc2[ct]);
-        acc2[ct + 1] = DF3D_MFMA_BF16(hh[q], bh1, acc2[ct + 1]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc2[rt][ct] = DF3D_MFMA_BF16(hl[rt][q], bh0, acc2[rt][ct]);
+          acc2[rt][ct + 1] = DF3D_MFMA_BF16(hl[rt][q], bh1, acc2[rt][ct + 1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc2[rt][ct] = DF3D_MFMA_BF16(hh[rt][q], bl0, acc2[rt][ct]);
+          acc2[rt][ct + 1] = DF3D_MFMA_BF16(hh[rt][q], bl1, acc2[rt][ct + 1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc2[rt][ct] = DF3D_MFMA_BF16(hh[rt][q], bh0, acc2[rt][ct]);
+          acc2[rt][ct + 1] = DF3D_MFMA_BF16(hh[rt][q], bh1, acc2[rt][ct + 1]);
+        }
       }
     }
   }
@@ -220,35 +252,38 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
     zA = *(const f32x4 *)(a.ln_b + n * 8);
     zB = *(const f32x4 *)(a.ln_b + n * 8 + 4);
   }
-  const long long rbase = (long long)blockIdx.x * TM + wave * 16 + 4 * g;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long long row = rbase + r;
-    const bool live = row < a.rows;
-    const long long rr = live ? row : a.rows - 1;
-    f32x4 vA = (f32x4){acc2[0][r], acc2[1][r], acc2[2][r], acc2[3][r]} + bA;
-    f32x4 vB = (f32x4){acc2[4][r], acc2[5][r], acc2[6][r], acc2[7][r]} + bB;
-    if (a.res) {
-      vA += *(const f32x4 *)(a.res + rr * FFN_C + n * 8);
-      vB += *(const f32x4 *)(a.res + rr * FFN_C + n * 8 + 4);
-    }
-    if (a.ln_g) {
-      float s = vA[0] + vA[1] + vA[2] + vA[3] + vB[0] + vB[1] + vB[2] + vB[3];
+  for (int rt = 0; rt < RT; ++rt) {
+    const long long rbase = wrow0 + rt * 16 + 4 * g;
 #pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);      // the 16 lanes of this row group
-      const float mean = s * (1.f / FFN_C);
-      f32x4 dA = vA - mean, dB = vB - mean;
-      float ss = dA[0] * dA[0] + dA[1] * dA[1] + dA[2] * dA[2] + dA[3] * dA[3] + dB[0] * dB[0] + dB[1] * dB[1] +
-                 dB[2] * dB[2] + dB[3] * dB[3];
+    for (int r = 0; r < 4; ++r) {
+      const long long row = rbase + r;
+      const bool live = row < a.rows;
+      const long long rr = live ? row : a.rows - 1;
+      f32x4 vA = (f32x4){acc2[rt][0][r], acc2[rt][1][r], acc2[rt][2][r], acc2[rt][3][r]} + bA;
+      f32x4 vB = (f32x4){acc2[rt][4][r], acc2[rt][5][r], acc2[rt][6][r], acc2[rt][7][r]} + bB;
+      if (a.res) {
+        vA += *(const f32x4 *)(a.res + rr * FFN_C + n * 8);
+        vB += *(const f32x4 *)(a.res + rr * FFN_C + n * 8 + 4);
+      }
+      if (a.ln_g) {
+        float s = vA[0] + vA[1] + vA[2] + vA[3] + vB[0] + vB[1] + vB[2] + vB[3];
 #pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-      const float rstd = rsqrtf(ss * (1.f / FFN_C) + a.eps);
-      vA = dA * rstd * gA + zA;
-      vB = dB * rstd * gB + zB;
-    }
-    if (live) {
-      *(f32x4 *)(a.out + row * FFN_C + n * 8) = vA;
-      *(f32x4 *)(a.out + row * FFN_C + n * 8 + 4) = vB;
+        for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);      // the 16 lanes of this row group
+        const float mean = s * (1.f / FFN_C);
+        f32x4 dA = vA - mean, dB = vB - mean;
+        float ss = dA[0] * dA[0] + dA[1] * dA[1] + dA[2] * dA[2] + dA[3] * dA[3] + dB[0] * dB[0] + dB[1] * dB[1] +
+                   dB[2] * dB[2] + dB[3] * dB[3];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = rsqrtf(ss * (1.f / FFN_C) + a.eps);
+        vA = dA * rstd * gA + zA;
+        vB = dB * rstd * gB + zB;
+      }
+      if (live) {
+        *(f32x4 *)(a.out + row * FFN_C + n * 8) = vA;
+        *(f32x4 *)(a.out + row * FFN_C + n * 8 + 4) = vB;
+      }
     }
   }
 }
@@ -285,10 +320,11 @@ extern "C" int df3d_ffn_fused(const float *x, long long rows, int d_model, int d
   DF3D_CHECK_ARG((ln_weight == nullptr) == (ln_bias == nullptr), "ffn_fused: LayerNorm needs weight and bias");
   if (rows <= 0) return DF3D_OK;
   FfnArgs a = {x, (const u32x4 *)packed, b1, b2, residual, ln_weight, ln_bias, eps, out, rows, d_ffn};
-  static const int nw = getenv("DF3D_FFN_NW") ? atoi(getenv("DF3D_FFN_NW")) : 8;      // tuning aid
-  if (nw == 4) hipLaunchKernelGGL((ffn_split_kernel<4>), dim3(cdiv(rows, 64)), dim3(256), 0, stream, a);
-  else if (nw == 16) hipLaunchKernelGGL((ffn_split_kernel<16>), dim3(cdiv(rows, 256)), dim3(1024), 0, stream, a);
-  else hipLaunchKernelGGL((ffn_split_kernel<8>), dim3(cdiv(rows, 128)), dim3(512), 0, stream, a);
+  static const int cfg = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 81;      // tuning aid: NW*10 + RT
+  if (cfg == 42) hipLaunchKernelGGL((ffn_split_kernel<4, 2>), dim3(cdiv(rows, 128)), dim3(256), 0, stream, a);
+  else if (cfg == 82) hipLaunchKernelGGL((ffn_split_kernel<8, 2>), dim3(cdiv(rows, 256)), dim3(512), 0, stream, a);
+  else if (cfg == 41) hipLaunchKernelGGL((ffn_split_kernel<4, 1>), dim3(cdiv(rows, 64)), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((ffn_split_kernel<8, 1>), dim3(cdiv(rows, 128)), dim3(512), 0, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }
