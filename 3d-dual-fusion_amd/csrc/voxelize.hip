@@ -24,6 +24,7 @@ struct VoxParams {
   float min[3], vs[3];
   int grid[3];  // x, y, z
   int P, C, T, maxV, cap_mask;
+  int batch_index;   // >= 0: coors rows are (batch, z, y, x); < 0: (z, y, x)
 };
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t k) {
@@ -100,9 +101,13 @@ __global__ __launch_bounds__(256) void vox_number_kernel(VoxParams p, const int 
     int t = key / p.grid[0];
     int y = t % p.grid[1];
     int z = t / p.grid[1];
-    coors[r * 3 + 0] = z;
-    coors[r * 3 + 1] = y;
-    coors[r * 3 + 2] = x;
+    if (p.batch_index >= 0) {
+      *(int4 *)(coors + (size_t)r * 4) = make_int4(p.batch_index, z, y, x);
+    } else {
+      coors[r * 3 + 0] = z;
+      coors[r * 3 + 1] = y;
+      coors[r * 3 + 2] = x;
+    }
   }
 }
 
@@ -176,11 +181,38 @@ extern "C" size_t df3d_hard_voxelize_workspace_bytes(int num_points, int max_poi
   return b + 256;
 }
 
+static int hard_voxelize_impl(const float *points, int num_points, int num_features, const float *voxel_size,
+                              const float *coors_range, int max_points, int max_voxels, int break_at_cap,
+                              float *voxels, int32_t *coors, int batch_index, int32_t *num_points_per_voxel,
+                              float *mean, int32_t *voxel_num, void *workspace, size_t workspace_bytes,
+                              void *stream_);
+
 extern "C" int df3d_hard_voxelize(const float *points, int num_points, int num_features,
                                   const float *voxel_size, const float *coors_range, int max_points,
                                   int max_voxels, int break_at_cap, float *voxels, int32_t *coors,
                                   int32_t *num_points_per_voxel, float *mean, int32_t *voxel_num,
                                   void *workspace, size_t workspace_bytes, void *stream_) {
+  return hard_voxelize_impl(points, num_points, num_features, voxel_size, coors_range, max_points, max_voxels,
+                            break_at_cap, voxels, coors, -1, num_points_per_voxel, mean, voxel_num, workspace,
+                            workspace_bytes, stream_);
+}
+
+extern "C" int df3d_hard_voxelize_batched(const float *points, int num_points, int num_features,
+                                          const float *voxel_size, const float *coors_range, int max_points,
+                                          int max_voxels, int break_at_cap, int batch_index, float *voxels,
+                                          int32_t *coors4, int32_t *num_points_per_voxel, float *mean,
+                                          int32_t *voxel_num, void *workspace, size_t workspace_bytes, void *stream_) {
+  DF3D_CHECK_ARG(batch_index >= 0, "hard_voxelize_batched: negative batch index");
+  return hard_voxelize_impl(points, num_points, num_features, voxel_size, coors_range, max_points, max_voxels,
+                            break_at_cap, voxels, coors4, batch_index, num_points_per_voxel, mean, voxel_num, workspace,
+                            workspace_bytes, stream_);
+}
+
+static int hard_voxelize_impl(const float *points, int num_points, int num_features, const float *voxel_size,
+                              const float *coors_range, int max_points, int max_voxels, int break_at_cap,
+                              float *voxels, int32_t *coors, int batch_index, int32_t *num_points_per_voxel,
+                              float *mean, int32_t *voxel_num, void *workspace, size_t workspace_bytes,
+                              void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(num_points >= 0 && num_features >= 3, "hard_voxelize: need points [P,C>=3]");
   DF3D_CHECK_ARG(max_points > 0, "hard_voxelize: max_points must be > 0 (got %d)", max_points);
@@ -201,6 +233,7 @@ extern "C" int df3d_hard_voxelize(const float *points, int num_points, int num_f
   p.C = num_features;
   p.T = max_points;
   p.maxV = max_voxels;
+  p.batch_index = batch_index;
   if (num_points == 0) {
     DF3D_HIP(hipMemsetAsync(voxel_num, 0, sizeof(int32_t), stream));
     return DF3D_OK;

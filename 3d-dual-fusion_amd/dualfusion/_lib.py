@@ -26,6 +26,9 @@ SIGNATURES = {
     "df3d_hard_voxelize_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "df3d_hard_voxelize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_hard_voxelize_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                           c_void_p]),
     "df3d_grid_bytes": (c_size_t, [c_int, c_void_p]),
     "df3d_grid_build": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "df3d_subm_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -131,12 +131,14 @@ class BackbonePlan(object):
 
     # ---------------------------------------------------------------- layer specs -> C table
     def _signature(self):
-        sig = []
+        """Cheap change detector for the cached table: parameter version counters (bumped by every in-place
+        update, e.g. load_state_dict / optimizer steps) + storage addresses of the first and last filter bank."""
+        v = 0
         for s in self.specs:
-            sig.append((s.conv.weight.data_ptr(), s.conv.weight._version))
+            v += s.conv.weight._version
             if s.bn is not None:
-                sig.append((s.bn.running_var.data_ptr(), s.bn.running_var._version, s.bn.weight._version))
-        return tuple(sig), _ops.CONV_PRECISION
+                v += s.bn.running_var._version + s.bn.weight._version
+        return (v, self.specs[0].conv.weight.data_ptr(), self.specs[-1].conv.weight.data_ptr(), _ops.CONV_PRECISION)
 
     def _build_table(self):
         n = len(self.specs)

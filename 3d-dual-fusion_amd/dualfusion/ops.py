@@ -39,26 +39,32 @@ def _chk(t, dtype, name):
 
 # ------------------------------------------------------------------------- voxelize
 def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels, break_at_cap=True,
-                  want_voxels=True, want_mean=True):
+                  want_voxels=True, want_mean=True, batch_index=None):
     """-> (voxels [M,T,C] or None, coors [M,3] int32 (z,y,x), num [M] int32, mean [M,C] or None).
-    One D2H read of the voxel count (the reference op returns it as a Python int too)."""
+    One D2H read of the voxel count (the reference op returns it as a Python int too).
+    batch_index: when given, coors comes back as [M,4] rows (batch_index, z, y, x), the sparse-tensor layout."""
     lib = _lib.load()
     _chk(points, torch.float32, "points")
     P, C = points.shape
     cap = P if (max_voxels < 0 or max_voxels > P) else int(max_voxels)
     dev = points.device
     voxels = torch.empty((cap, max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
-    coors = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+    coors = torch.empty((cap, 3 if batch_index is None else 4), dtype=torch.int32, device=dev)
     num = torch.empty((cap,), dtype=torch.int32, device=dev)
     mean = torch.empty((cap, C), dtype=torch.float32, device=dev) if want_mean else None
-    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)          # always written by the kernel
     wsb = lib.df3d_hard_voxelize_workspace_bytes(P, int(max_points), cap)
     ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
     vs_p, vs_keep = _lib.float_arr(list(voxel_size))
     rg_p, rg_keep = _lib.float_arr(list(coors_range))
-    rc = lib.df3d_hard_voxelize(_ptr(points), P, C, vs_p, rg_p, int(max_points), cap, int(bool(break_at_cap)),
-                                _ptr(voxels), _ptr(coors), _ptr(num), _ptr(mean), _ptr(count), _ptr(ws), wsb,
-                                _stream())
+    if batch_index is None:
+        rc = lib.df3d_hard_voxelize(_ptr(points), P, C, vs_p, rg_p, int(max_points), cap, int(bool(break_at_cap)),
+                                    _ptr(voxels), _ptr(coors), _ptr(num), _ptr(mean), _ptr(count), _ptr(ws), wsb,
+                                    _stream())
+    else:
+        rc = lib.df3d_hard_voxelize_batched(_ptr(points), P, C, vs_p, rg_p, int(max_points), cap,
+                                            int(bool(break_at_cap)), int(batch_index), _ptr(voxels), _ptr(coors),
+                                            _ptr(num), _ptr(mean), _ptr(count), _ptr(ws), wsb, _stream())
     _lib.check(rc, "df3d_hard_voxelize")
     n = int(count.item())
     return (voxels[:n] if voxels is not None else None, coors[:n], num[:n], mean[:n] if mean is not None else None)

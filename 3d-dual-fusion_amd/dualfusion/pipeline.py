@@ -35,9 +35,9 @@ class CenterPointHotPath(nn.Module):
         CenterPoint voxelises with the numba kernel's cap semantics (point_cloud_ops.py:46-47)."""
         feats, coors = [], []
         for b, pts in enumerate(points_list):
-            mean, c, _ = self.voxel_layer.voxelize_mean(pts, break_at_cap=False)
+            mean, c, _ = self.voxel_layer.voxelize_mean(pts, break_at_cap=False, batch_index=b)
             feats.append(mean)
-            coors.append(torch.cat([torch.full((c.shape[0], 1), b, dtype=torch.int32, device=c.device), c], 1))
+            coors.append(c)
         if len(feats) == 1:
             return feats[0], coors[0]
         return torch.cat(feats), torch.cat(coors)

@@ -51,11 +51,12 @@ class Voxelization(nn.Module):
     def forward(self, input):
         return voxelization(input, self.voxel_size, self.point_cloud_range, self.max_num_points, self._cap())
 
-    def voxelize_mean(self, points, break_at_cap=True):
-        """fused voxelise + mean VFE: (mean [M,C], coors [M,3] (z,y,x), num [M])."""
+    def voxelize_mean(self, points, break_at_cap=True, batch_index=None):
+        """fused voxelise + mean VFE: (mean [M,C], coors [M,3] (z,y,x) -- or [M,4] (b,z,y,x) when `batch_index`
+        is given --, num [M])."""
         _, coors, num, mean = _ops.hard_voxelize(points.contiguous().float(), self.voxel_size, self.point_cloud_range,
                                                  self.max_num_points, self._cap(), break_at_cap=break_at_cap,
-                                                 want_voxels=False, want_mean=True)
+                                                 want_voxels=False, want_mean=True, batch_index=batch_index)
         return mean, coors, num
 
     def __repr__(self):

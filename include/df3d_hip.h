@@ -65,6 +65,14 @@ int df3d_hard_voxelize(const float *points, int num_points, int num_features,
                        float *voxels, int32_t *coors, int32_t *num_points_per_voxel,
                        float *mean, int32_t *voxel_num,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* same, writing coors4 [max_voxels, 4] rows (batch_index, z, y, x): the layout the sparse tensors take
+ * (the reference prepends the batch column on the host, CP/det3d/torchie/parallel/collate.py) */
+int df3d_hard_voxelize_batched(const float *points, int num_points, int num_features,
+                               const float *voxel_size_host, const float *coors_range_host,
+                               int max_points, int max_voxels, int break_at_cap, int batch_index,
+                               float *voxels, int32_t *coors4, int32_t *num_points_per_voxel,
+                               float *mean, int32_t *voxel_num,
+                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Rulebook.  Replaces sparse_conv_ext.get_indice_pairs_3d
