@@ -22,6 +22,7 @@
 // name, the item list is built by 32 lanes instead of one, and the epilogue can emit the split rows of its
 // output for the next convolution.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -654,8 +655,9 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
   static const char *cfg = getenv("DF3D_OS_CFG");       // tuning aid: "RT,NW[,KPS]"
   if (cfg && cfg[0] && cfg[1] == ',') {
     rt = cfg[0] - '0';
-    nw = cfg[2] - '0';
-    if (cfg[3] == ',') kps = cfg[4] - '0';
+    nw = atoi(cfg + 2);
+    const char *c2 = strchr(cfg + 2, ',');
+    if (c2) kps = atoi(c2 + 1);
   }
   constexpr int KMAX = CIN >= 64 ? 2 : 1;
   if (kps > KMAX) kps = KMAX;
@@ -666,7 +668,8 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
     if (rt == 2) DF3D_OS_LAUNCH(2, 4, KMAX);
     else if (nw == 2) DF3D_OS_LAUNCH(1, 2, KMAX);
     else DF3D_OS_LAUNCH(1, 4, KMAX);
-  } else if (nw == 8) DF3D_OS_LAUNCH(1, 8, 1);
+  } else if (nw == 16) DF3D_OS_LAUNCH(1, 16, 1);
+  else if (nw == 8) DF3D_OS_LAUNCH(1, 8, 1);
   else if (rt == 2 && nw == 4) DF3D_OS_LAUNCH(2, 4, 1);
   else if (rt == 2 && nw == 2) DF3D_OS_LAUNCH(2, 2, 1);
   else if (rt == 1 && nw == 4) DF3D_OS_LAUNCH(1, 4, 1);
