@@ -26,8 +26,10 @@ __device__ __forceinline__ Best better(Best a, Best b) {
   return takeb ? b : a;
 }
 
-template <bool REG>
-__global__ void fps_kernel(const float *__restrict__ xyz, int N, int m, float *__restrict__ temp_g,
+// REG: running min-distances in registers; PT points per thread; XYZ: the thread's coordinates in registers too
+// (PT <= 24: 4*PT live registers fit the 128-VGPR budget of a 1024-thread block)
+template <bool REG, int PT, bool XYZ>
+__global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz, int N, int m, float *__restrict__ temp_g,
                            int32_t *__restrict__ idx) {
   __shared__ float s_v[16];
   __shared__ int s_t[16], s_k[16];
@@ -37,22 +39,32 @@ __global__ void fps_kernel(const float *__restrict__ xyz, int N, int m, float *_
   const float *p = xyz + (size_t)b * N * 3;
   float *tg = temp_g + (size_t)b * N;
   int32_t *o = idx + (size_t)b * m;
-  float temp[FPS_MAXPT];
+  float temp[PT];
+  float px[XYZ ? PT : 1], py[XYZ ? PT : 1], pz[XYZ ? PT : 1];   // the thread's points, loaded once
 #pragma unroll
-  for (int i = 0; i < FPS_MAXPT; ++i) temp[i] = 1e10f;
+  for (int i = 0; i < PT; ++i) temp[i] = 1e10f;
+  if (XYZ) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      int k = tid + i * bs;
+      int kk = k < N ? k : N - 1;
+      px[i] = p[kk * 3];
+      py[i] = p[kk * 3 + 1];
+      pz[i] = p[kk * 3 + 2];
+    }
+  }
   if (!REG)
     for (int k = tid; k < N; k += bs) tg[k] = 1e10f;
-  int old = 0;
   if (tid == 0 && m > 0) o[0] = 0;
+  float x1 = p[0], y1 = p[1], z1 = p[2];
   for (int j = 1; j < m; ++j) {
-    float x1 = p[old * 3], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
     Best me = {-1.f, tid, 0};
     if (REG) {
 #pragma unroll
-      for (int i = 0; i < FPS_MAXPT; ++i) {
+      for (int i = 0; i < PT; ++i) {
         int k = tid + i * bs;
         if (k < N) {
-          float x2 = p[k * 3], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+          float x2 = XYZ ? px[i] : p[k * 3], y2 = XYZ ? py[i] : p[k * 3 + 1], z2 = XYZ ? pz[i] : p[k * 3 + 2];
           float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
           float d2 = fminf(d, temp[i]);
           temp[i] = d2;
@@ -99,7 +111,10 @@ __global__ void fps_kernel(const float *__restrict__ xyz, int N, int m, float *_
       o[j] = r.k;
     }
     __syncthreads();
-    old = s_old;
+    const int old = s_old;
+    x1 = p[old * 3];
+    y1 = p[old * 3 + 1];
+    z1 = p[old * 3 + 2];
   }
 }
 
@@ -167,10 +182,17 @@ extern "C" int df3d_furthest_point_sample(const float *xyz, int B, int N, int m,
   DF3D_CHECK_ARG(B >= 0 && N > 0 && m >= 0, "furthest_point_sample: bad sizes");
   if (B == 0 || m == 0) return DF3D_OK;
   int bs = fps_block(N);
-  if ((long long)N <= (long long)FPS_MAXPT * bs)
-    hipLaunchKernelGGL(fps_kernel<true>, dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
+  const long long ppt = ((long long)N + bs - 1) / bs;      // points per thread
+  if (ppt <= 8)
+    hipLaunchKernelGGL((fps_kernel<true, 8, true>), dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
+  else if (ppt <= 16)
+    hipLaunchKernelGGL((fps_kernel<true, 16, true>), dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
+  else if (ppt <= 24)
+    hipLaunchKernelGGL((fps_kernel<true, 24, true>), dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
+  else if (ppt <= FPS_MAXPT)
+    hipLaunchKernelGGL((fps_kernel<true, FPS_MAXPT, false>), dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
   else
-    hipLaunchKernelGGL(fps_kernel<false>, dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
+    hipLaunchKernelGGL((fps_kernel<false, 1, false>), dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -430,6 +430,18 @@ class ACTR(nn.Module):
             self.q_position_embedding = PositionEmbeddingLearnedDepth(num_pos_feats=transformer.q_model)
         self.v_position_embedding = PositionEmbeddingSine(num_pos_feats=hidden_dim // 2, normalize=True)
 
+    def _input_proj(self, l, src):
+        """input_proj[l] = Conv2d 1x1 + GroupNorm.  The 1x1 conv runs as one batched GEMM: MIOpen without a tuning
+        database falls back to its naive fp32 kernel for this shape (6.7 ms per call at KITTI size)."""
+        conv, gn = self.input_proj[l][0], self.input_proj[l][1]
+        if src.is_cuda and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1) and conv.groups == 1:
+            N, C, H, W = src.shape
+            y = torch.matmul(conv.weight[:, :, 0, 0], src.reshape(N, C, H * W))
+            if conv.bias is not None:
+                y = y + conv.bias[None, :, None]
+            return gn(y.view(N, -1, H, W))
+        return self.input_proj[l](src)
+
     def project_image_queries(self, v_i_feat):
         """i_input_proj on [N, Q, Cimg]: the 1x1 Conv1d as a GEMM, GroupNorm over (group, Q)."""
         conv, gn = self.i_input_proj[0], self.i_input_proj[1]
@@ -525,7 +537,7 @@ class ACTR(nn.Module):
             q_pos = self.q_position_embedding(grid).transpose(1, 2)
         else:
             q_pos = self.q_position_embedding(lidar_grid[..., 0]).transpose(1, 2)
-        srcs = [self.input_proj[l](src) for l, src in enumerate(i_feats)]
+        srcs = [self._input_proj(l, src) for l, src in enumerate(i_feats)]
         return self.transformer(srcs, None, None, q_feat, q_pos, grid, q_lidar_grid=lidar_grid,
                                 q_i_feat_flatten=q_i_feat)
 

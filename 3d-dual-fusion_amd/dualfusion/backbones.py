@@ -332,9 +332,32 @@ class SparseEncoder(nn.Module):
         N, C, D, H, W = spatial_features.shape
         return spatial_features.view(N, C * D, H, W)
 
+    # ---- native executor (dualfusion/executor.py): the conv chain as one call per uninterrupted segment
+    def _stage_list(self):
+        return [("conv_input", self.conv_input)] + list(self.encoder_layers._modules.items())
+
+    def _runner(self, cuts=()):
+        if self.training or torch.is_grad_enabled() or os.environ.get("DF3D_EXECUTOR", "1") != "1":
+            return None
+        key = tuple(cuts)
+        cache = self.__dict__.setdefault("_exec_runners", {})
+        if key not in cache:
+            from .executor import build_runner
+            cache[key] = build_runner(self._stage_list(), cuts=cuts, geometry_module=self.conv_out)
+        return cache[key]
+
+    def train(self, mode=True):
+        self.__dict__.pop("_exec_runners", None)
+        return super(SparseEncoder, self).train(mode)
+
     def forward(self, voxel_features, coors, batch_size):
         coors = coors.int()
-        x = self.conv_input(spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size))
+        x = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        runner = self._runner() if voxel_features.is_cuda and voxel_features.shape[0] > 0 else None
+        if runner is not None:
+            outs = runner.run(x)
+            return self._dense_out(outs[self._stage_list()[-1][0]])
+        x = self.conv_input(x)
         for encoder_layer in self.encoder_layers._modules.values():
             x = encoder_layer(x)
         return self._dense_out(x)
@@ -377,16 +400,27 @@ class SparseEncoderFusion(SparseEncoder):
     def forward(self, voxel_features, coors, batch_size, img_feats=None, img_metas=None, points=None,
                 ret_lidar_features=False, img=None):
         coors = coors.int()
-        x = self.conv_input(spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size))
+        x0 = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
         encode_features, lidar_features = [], []
-        for idx, encoder_layer in enumerate(self.encoder_layers._modules.values()):
-            x = encoder_layer(x)
+
+        def fuse(idx, x):
             if ret_lidar_features:
                 lidar_features.append(x)
             if self.fusion_pos is not None and idx in self.fusion_pos:
                 c_pts = self.coor2pts(x, 0.5)
                 x = x.replace_feature(self.fusion_layer(img_feats, c_pts, x.features, img_metas, img))
             encode_features.append(x)
+            return x
+
+        # the fusion layer modifies the features after encoder layer idx = stage idx + 1: cut the chain there
+        cuts = [p + 1 for p in (self.fusion_pos or [])]
+        runner = self._runner(cuts) if voxel_features.is_cuda and voxel_features.shape[0] > 0 else None
+        if runner is not None:
+            runner.run(x0, hook=lambda i, name, t: t if i == 0 else fuse(i - 1, t))
+        else:
+            x = self.conv_input(x0)
+            for idx, encoder_layer in enumerate(self.encoder_layers._modules.values()):
+                x = fuse(idx, encoder_layer(x))
         spatial_features = self._dense_out(encode_features[-1])
         if ret_lidar_features:
             return (spatial_features, encode_features[-1], img_feats)
@@ -443,6 +477,22 @@ class VoxelBackBone8x(nn.Module):
         self.num_point_features = 128
         self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64}
 
+    def _runner(self):
+        """Native executor for the conv chain, cut after conv1 when a subclass fuses there (dualfusion/executor.py)."""
+        if self.training or torch.is_grad_enabled() or os.environ.get("DF3D_EXECUTOR", "1") != "1":
+            return None
+        if "_exec_runner" not in self.__dict__:
+            from .executor import build_runner
+            stages = [("conv_input", self.conv_input), ("conv1", self.conv1), ("conv2", self.conv2),
+                      ("conv3", self.conv3), ("conv4", self.conv4)]
+            cuts = [1] if type(self)._fuse1 is not VoxelBackBone8x._fuse1 else []
+            self.__dict__["_exec_runner"] = build_runner(stages, cuts=cuts, geometry_module=self.conv_out)
+        return self.__dict__["_exec_runner"]
+
+    def train(self, mode=True):
+        self.__dict__.pop("_exec_runner", None)
+        return super(VoxelBackBone8x, self).train(mode)
+
     def _fuse1(self, x_conv1, batch_dict):
         return x_conv1
 
@@ -452,11 +502,27 @@ class VoxelBackBone8x(nn.Module):
     def forward(self, batch_dict):
         voxel_features, voxel_coords = batch_dict["voxel_features"], batch_dict["voxel_coords"]
         batch_size = batch_dict["batch_size"]
-        x = self.conv_input(spconv.SparseConvTensor(voxel_features, voxel_coords.int(), self.sparse_shape, batch_size))
-        x_conv1 = self._fuse1(self.conv1(x), batch_dict)
-        x_conv2 = self.conv2(x_conv1)
-        x_conv3 = self.conv3(x_conv2)
-        x_conv4 = self._fuse4(x_conv2, x_conv3, self.conv4(x_conv3), batch_dict)
+        x0 = spconv.SparseConvTensor(voxel_features, voxel_coords.int(), self.sparse_shape, batch_size)
+        runner = self._runner() if voxel_features.is_cuda and voxel_features.shape[0] > 0 else None
+        if runner is not None:
+            keep = {}
+
+            def hook(i, name, t):
+                if name == "conv1":
+                    t = self._fuse1(t, batch_dict)
+                elif name == "conv4":
+                    t = self._fuse4(keep["conv2"], keep["conv3"], t, batch_dict)
+                keep[name] = t
+                return t
+
+            runner.run(x0, hook=hook)
+            x_conv1, x_conv2, x_conv3, x_conv4 = keep["conv1"], keep["conv2"], keep["conv3"], keep["conv4"]
+        else:
+            x = self.conv_input(x0)
+            x_conv1 = self._fuse1(self.conv1(x), batch_dict)
+            x_conv2 = self.conv2(x_conv1)
+            x_conv3 = self.conv3(x_conv2)
+            x_conv4 = self._fuse4(x_conv2, x_conv3, self.conv4(x_conv3), batch_dict)
         out = self.conv_out(x_conv4)
         batch_dict.update({"encoded_spconv_tensor": out, "encoded_spconv_tensor_stride": 8})
         batch_dict.update({"multi_scale_3d_features": {"x_conv1": x_conv1, "x_conv2": x_conv2, "x_conv3": x_conv3,

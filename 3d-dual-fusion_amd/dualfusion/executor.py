@@ -246,3 +246,47 @@ def compile_stages(stages, geometry_stages=()):
         return BackbonePlan(stages, geometry_stages)
     except Unsupported:
         return None
+
+
+class SegmentedRunner(object):
+    """Executor plans for a backbone whose conv chain is interrupted by feature-modifying hooks (fusion layers):
+    the stages are cut into contiguous segments, each one native call; the hooks run between them on the module
+    path.  `cuts` = indices i such that a hook runs AFTER stage i."""
+
+    def __init__(self, stages, cuts=(), geometry_module=None):
+        self.stages = list(stages)
+        bounds = sorted(set(int(c) for c in cuts if 0 <= int(c) < len(self.stages) - 1))
+        starts = [0] + [c + 1 for c in bounds]
+        ends = [c + 1 for c in bounds] + [len(self.stages)]
+        self.segments = []
+        for k, (a, b) in enumerate(zip(starts, ends)):
+            seg = self.stages[a:b]
+            geo = [(seg[-1][0], geometry_module)] if (geometry_module is not None and b == len(self.stages)) else ()
+            plan = compile_stages(seg, geometry_stages=geo)
+            if plan is None:
+                raise Unsupported("segment %d" % k)
+            self.segments.append((a, b, plan))
+
+    def run(self, x, hook=None):
+        """x: SparseConvTensor (network input).  hook(stage_index, name, tensor) -> tensor is called after every
+        stage in order (identity when None) -- stages inside a segment see their output after the segment ran,
+        which is fine for hooks that only READ; hooks that MODIFY features must sit at a cut.
+        Returns {stage name: tensor}."""
+        outs = {}
+        for a, b, plan in self.segments:
+            res = plan.run(x.features, x.indices, x.batch_size, x.spatial_shape)
+            for i in range(a, b):
+                name = self.stages[i][0]
+                t = res[name]
+                if hook is not None:
+                    t = hook(i, name, t)
+                outs[name] = t
+            x = outs[self.stages[b - 1][0]]
+        return outs
+
+
+def build_runner(stages, cuts=(), geometry_module=None):
+    try:
+        return SegmentedRunner(stages, cuts, geometry_module)
+    except Unsupported:
+        return None

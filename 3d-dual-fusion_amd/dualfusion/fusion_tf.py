@@ -112,6 +112,13 @@ class ACTRFusionLayer(nn.Module):
             pts = torch.cat([torch.cat([p.new_full((p.shape[0], 1), i), p[:, :3]], 1) for i, p in enumerate(pts)])
         batch_size = len(img_metas)
         img_feats = list(img_feats[:self.actr.num_backbone_outs])
+        # the image coordinates index the level-0 map at stride 4 (point_fusion.py:366): a map of another stride
+        # would be read out of bounds
+        fh, fw = img_feats[0].shape[-2:]
+        ih, iw = img_metas[0]['input_shape'][:2]
+        if fh * 4 < ih or fw * 4 < iw:
+            raise ValueError("ACTRFusionLayer expects the stride-4 camera feature map: input %dx%d needs at least "
+                             "%dx%d, got %dx%d" % (ih, iw, -(-ih // 4), -(-iw // 4), fh, fw))
         cam_id, norm, pix = self.project(pts, img_metas)
         v_feat, v_i_feat, grid, qpts, seg, slot = self.assemble(img_feats, pts, pts_feats, cam_id, norm, pix, batch_size)
         enh = self.actr(v_feat=v_feat, grid=grid, i_feats=img_feats, lidar_grid=qpts, v_i_feat=v_i_feat)

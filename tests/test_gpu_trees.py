@@ -49,6 +49,7 @@ def test_transfusion_sparse_encoder_vs_oracle():
     m, sd = _load_det(m, dev)
     f, c, of, oc = _voxels(60, [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0], dev, batch=2)
     with torch.no_grad():
+        assert m._runner() is not None, "the native executor must serve this module tree"
         y = m(f, c, 2)
     ref, _ = om.transfusion_encoder(sd, of, oc, 2, shape, TF_CH, TF_PAD)
     assert tuple(y.shape) == ref.shape == (2, 256, 32, 32)
@@ -123,8 +124,17 @@ def test_transfusion_fusion_layer_glue_and_encoder_fusion():
     enc = enc.to(dev).eval()
     f, c, _, _ = _voxels(70, [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0], dev, batch=B)
     with torch.no_grad():
+        assert enc._runner([4]) is not None          # fusion after the LAST encoder layer: one segment, hook at its end
         y = enc(f, c, B, img_feats=[torch.from_numpy(img).to(dev)], img_metas=metas)
+        # the executor segments launch the same kernels as the per-module path
+        import os
+        os.environ["DF3D_EXECUTOR"] = "0"
+        try:
+            y_slow = enc(f, c, B, img_feats=[torch.from_numpy(img).to(dev)], img_metas=metas)
+        finally:
+            os.environ["DF3D_EXECUTOR"] = "1"
     assert tuple(y.shape) == (B, 256, 32, 32) and bool(torch.isfinite(y).all())
+    torch.testing.assert_close(y, y_slow, rtol=1e-4, atol=1e-4)
 
 
 VR_CFG = dict(NAME='VoxelBackBone8xFusion', USE_IMG=True, FUSION_POS=[1, 4], FUSION_METHOD='MVX+ACTRv2',
@@ -159,6 +169,7 @@ def test_voxel_rcnn_backbone_vs_oracle_and_fusion_runs():
     assert {"conv_input.0.weight", "conv1.0.0.weight", "conv4.2.1.running_var", "conv_out.0.weight"} <= set(m.state_dict())
     m, sd = _load_det(m, dev)
     with torch.no_grad():
+        assert m._runner() is not None and len(m._runner().segments) == 1
         bd = m(dict(voxel_features=f, voxel_coords=c, batch_size=B))
     o_out, o_ms = om.voxel_backbone8x(sd, of, oc, B, [41, 512, 512])
     got = bd["encoded_spconv_tensor"]
@@ -179,6 +190,7 @@ def test_voxel_rcnn_backbone_vs_oracle_and_fusion_runs():
               img_dict={"mvx_layer1_feat2d": torch.randn(B, 16, H // 4, W // 4, generator=gen).to(dev),
                         "layer1_feat2d": torch.randn(B, 256, H // 4, W // 4, generator=gen).to(dev)})
     with torch.no_grad():
+        assert mf._runner() is not None and len(mf._runner().segments) == 2          # cut after conv1 (MVX fusion)
         out = mf(bd)
     x4 = out["multi_scale_3d_features"]["x_conv4"]
     assert x4.features.shape[1] == 64 and bool(torch.isfinite(x4.features).all())

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Timing of the other two module trees at their BASELINE config shapes (not the driver's bench line):
+  tf : TransFusion-L SparseEncoderFusion + ACTR fusion layer, 0.075 m nuScenes grid, bs=4, 6 cameras (configs[2] shape, fp32)
+  vr : Voxel-RCNN VoxelBackBone8xFusion (MVX + ACTRv2), KITTI 0.05 m grid, bs=8, one camera (configs[4] shape)
+usage: bench_trees.py [tf|vr] [steps]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-dual-fusion_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from dualfusion import ops, synth  # noqa: E402
+
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "tf"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+torch.manual_seed(0)
+
+
+def voxels(batch, sweep, vs, rng, maxp, maxv, feat_c):
+    feats, coors = [], []
+    for b in range(batch):
+        pts = torch.from_numpy(sweep(seed=b)[:, :feat_c].copy()).to(dev)
+        _, c, _, mean = ops.hard_voxelize(pts, vs, rng, maxp, maxv, want_voxels=False, batch_index=b)
+        feats.append(mean)
+        coors.append(c)
+    return torch.cat(feats), torch.cat(coors)
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+if which == "tf":
+    from dualfusion.backbones import SparseEncoderFusion
+    from make_golden import ACTR_CFG
+    B = 4
+    TF_CH = ((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128))
+    TF_PAD = ((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0))
+    enc = SparseEncoderFusion(in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128, encoder_channels=TF_CH,
+                              encoder_paddings=TF_PAD, block_type='basicblock', fusion_pos=[3],
+                              voxel_size=synth.NUSC_VOXEL, point_cloud_range=synth.NUSC_RANGE,
+                              fusion_layer=dict(type='ACTR', pfat_cfg=dict(ACTR_CFG))).to(dev).eval()
+    f, c = voxels(B, synth.nusc_sweep, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000, 5)
+    ori_hw, in_hw, fh, fw = (900, 1600), (448, 800), 112, 200          # stride-4 level (the layer indexes pix // 4)
+    cams = synth.nusc_cameras(image_hw=ori_hw)
+    sf = [in_hw[1] / ori_hw[1], in_hw[0] / ori_hw[0]]
+    metas = [dict(lidar2cam=np.stack([cams[n][0] for n in synth.NUSC_CAMS]),
+                  cam_intrinsic=np.stack([cams[n][1] for n in synth.NUSC_CAMS]), ori_shape=ori_hw + (3,),
+                  img_shape=in_hw + (3,), input_shape=in_hw, scale_factor=sf, flip=False) for _ in range(B)]
+    img = torch.randn(B * 6, 256, fh, fw, device=dev)
+
+    def step():
+        with torch.no_grad():
+            return enc(f, c, B, img_feats=[img], img_metas=metas)
+    ms = timeit(step)
+    print("tf  SparseEncoderFusion+ACTR bs=%d (%d voxels): %.2f ms/step = %.1f sweeps/s  [DF3D_EXECUTOR=%s]" % (
+        B, f.shape[0], ms, B / ms * 1e3, os.environ.get("DF3D_EXECUTOR", "1")))
+else:
+    from dualfusion.backbones import VoxelBackBone8xFusion
+    B = 8
+    cfg = dict(NAME='VoxelBackBone8xFusion', USE_IMG=True, FUSION_POS=[1, 4], FUSION_METHOD='MVX+ACTRv2',
+               FEATURE_LEVELS=[0], LT_CFG=dict(npoint=2048, radius=2.0, nsample=32, num_layers=2),
+               ACTR_CFG=dict(fusion_method='sum', feature_modal='hybrid', num_bins=80, num_channels=[256],
+                             query_num_feat=64, num_enc_layers=4, max_num_ne_voxel=20000, pos_encode_method='depth'),
+               HYBRID_CFG=dict(attn_layer='BiGateSum1D_2', q_method='sum', q_rep_place=['weight']))
+    mf = VoxelBackBone8xFusion(cfg, 4, [1408, 1600, 40]).to(dev).eval()
+    f, c = voxels(B, synth.kitti_sweep, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 40000, 4)
+    H, W = 384, 1280
+    K = np.array([[720., 0, W / 2, 0], [0, 720., H / 2, 0], [0, 0, 1, 0]], np.float32)
+    Tr = np.array([[0, -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27], [0, 0, 0, 1]], np.float32)
+    l2i = torch.from_numpy(np.stack([K @ Tr] * B)).to(dev)
+    bd0 = dict(voxel_features=f, voxel_coords=c, batch_size=B, lidar2img=l2i, image_hw=(H, W),
+               img_dict={"mvx_layer1_feat2d": torch.randn(B, 16, H // 4, W // 4, device=dev),
+                         "layer1_feat2d": torch.randn(B, 256, H // 4, W // 4, device=dev)})
+
+    def step():
+        with torch.no_grad():
+            return mf(dict(bd0))
+    ms = timeit(step)
+    print("vr  VoxelBackBone8xFusion (MVX+ACTRv2) bs=%d (%d voxels): %.2f ms/step = %.1f frames/s  [DF3D_EXECUTOR=%s]" % (
+        B, f.shape[0], ms, B / ms * 1e3, os.environ.get("DF3D_EXECUTOR", "1")))
