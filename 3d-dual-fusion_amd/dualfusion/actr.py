@@ -365,7 +365,8 @@ class DeformableTransformerACTR(nn.Module):
         layers consume neither the masks' padding (all False) nor the level position embedding."""
         dev = srcs[0].device
         shapes = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
-        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        # contiguous [N, sum HW, C]: value_proj on a transposed view makes hipBLASLt pick a 25x slower kernel
+        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1).contiguous()
         spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=dev)
         level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
         N = src_flatten.shape[0]

@@ -49,9 +49,11 @@ class ACTRFusionLayer(nn.Module):
         l2c, K = self._calib(img_metas, dev)
         b = pts[:, 0].long()
         xyz1 = torch.cat([pts[:, 1:4], torch.ones_like(pts[:, :1])], 1)              # [N,4]
-        cam = torch.einsum('ncij,nj->nci', l2c[b], xyz1)[..., :3]                    # [N,6,3]
+        # broadcast multiply-sum instead of einsum: einsum lowers to a batched GEMM over N*6 tiny 3x4 matrices
+        # (9 ms at nuScenes size); this is two element-wise passes
+        cam = (l2c[b][:, :, :3, :] * xyz1[:, None, None, :]).sum(-1)                 # [N,6,3]
         depth = cam[..., 2]
-        uvw = torch.einsum('ncij,ncj->nci', K[b], cam)
+        uvw = (K[b] * cam[:, :, None, :]).sum(-1)
         u = uvw[..., 0] / uvw[..., 2]
         v = uvw[..., 1] / uvw[..., 2]
         ori = torch.tensor([[m['ori_shape'][0], m['ori_shape'][1]] for m in img_metas], dtype=torch.float32, device=dev)

@@ -34,6 +34,13 @@ def timeit(fn):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get("DF3D_TORCH_PROFILE") == "1":       # one profiled step: top ops by GPU time, with shapes
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            fn()
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=10,
+                                                                  max_name_column_width=36, max_shapes_column_width=80))
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
