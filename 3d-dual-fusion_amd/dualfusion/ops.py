@@ -193,9 +193,6 @@ class KernelTimer(object):
         lib.df3d_timing_count_pairs(1 if self.count_pairs else 0)
         lib.df3d_timing_begin()
 
-    def note(self, key, meta):      # kept for callers of the older interface
-        pass
-
     def stop(self):
         lib = _lib.load()
         n = lib.df3d_timing_end()
@@ -211,8 +208,6 @@ class KernelTimer(object):
                                      pairs=int(pairs.value), split=int(split.value)))
         return self.records
 
-
-TIMER = None
 
 
 def conv_tiles(nbr, cin, cout):
@@ -254,8 +249,6 @@ def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shif
         if t is not None:
             _chk(t, torch.float32, nm)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
-    if TIMER is not None:
-        TIMER.note(("spconv", cin, cout, K), {"n_in": n_in, "n_out": n_out, "nbr": nbr})
     rc = lib.df3d_sparse_conv_fused_tiled(_ptr(features), n_in, cin, _ptr(filters), K, cout, _ptr(nbr), n_out,
                                           _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)),
                                           _ptr(out), _ptr(tiles), (tiles.shape[0] - 1) if tiles is not None else 0,
@@ -317,8 +310,6 @@ def sparse_conv_split(features_split, packed, nbr, n_out, cin, cout, bias=None, 
             _chk(t, torch.float32, nm)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=nbr.device)
     out_split = torch.empty((n_out, 4 * cout), dtype=torch.uint8, device=nbr.device) if emit_split else None
-    if TIMER is not None:
-        TIMER.note(("spconv", cin, cout, K), {"n_in": n_in, "n_out": n_out, "nbr": nbr})
     rc = lib.df3d_sparse_conv_split(_ptr(features_split), n_in, cin, _ptr(packed), K, cout, _ptr(nbr), n_out,
                                     _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out),
                                     _ptr(out_split), _ptr(tiles), (tiles.shape[0] - 1) if tiles is not None else 0,
