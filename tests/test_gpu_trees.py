@@ -56,6 +56,23 @@ def test_transfusion_sparse_encoder_vs_oracle():
     np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * max(1.0, np.abs(ref).max()))
 
 
+def test_transfusion_encoder_accepts_bf16_features():
+    """BASELINE configs[2] feeds bf16 activations: the encoder takes them (computing in fp32 / split precision) and
+    stays within bf16 input rounding (2^-8 relative per feature) of the fp32-input result."""
+    from dualfusion.backbones import SparseEncoder
+    dev = torch.device("cuda:0")
+    m = SparseEncoder(in_channels=5, sparse_shape=[41, 256, 256], output_channels=128, encoder_channels=TF_CH,
+                      encoder_paddings=TF_PAD, block_type='basicblock')
+    m, _ = _load_det(m, dev)
+    f, c, _, _ = _voxels(61, [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0], dev, batch=2)
+    with torch.no_grad():
+        y32 = m(f, c, 2)
+        y16 = m(f.to(torch.bfloat16), c, 2)
+    assert y16.dtype == torch.float32 and tuple(y16.shape) == tuple(y32.shape)
+    err = float((y16 - y32).abs().max() / y32.abs().max())
+    assert err < 3e-2, err
+
+
 def _tf_metas(B, cams, ori_hw, in_hw):
     sf = [in_hw[1] / ori_hw[1], in_hw[0] / ori_hw[0]]
     from dualfusion import synth
