@@ -90,6 +90,7 @@ struct FfnArgs {
   float *out;
   long long rows;
   int H;
+  int dbg;     // tuning experiments (DF3D_FFN_DBG): 1 = no MFMAs, 2 = no weight staging
 };
 
 // NW waves per workgroup, RT 16-row tiles per wave.  RT = 2 halves the LDS fragment reads per MFMA (every operand
@@ -156,9 +157,12 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
     for (int kb = 0; kb < 4; ++kb) {
       const int s = c * 8 + kb;
       __syncthreads();
-      store_w((s + 1) & 1);
-      load_w(s + 2);
+      if (!(a.dbg & 2)) {
+        store_w((s + 1) & 1);
+        load_w(s + 2);
+      }
       const u32x4 *wb = Wl[s & 1] + lane;
+      if (a.dbg & 1) continue;
       // operand fragments of the next tile pair come from LDS while the MFMAs of the current pair run
       u32x4 fq[2][4];
 #pragma unroll
@@ -210,9 +214,12 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int s = c * 8 + 4 + q;
       __syncthreads();
-      store_w((s + 1) & 1);
-      load_w(s + 2);
+      if (!(a.dbg & 2)) {
+        store_w((s + 1) & 1);
+        load_w(s + 2);
+      }
       const u32x4 *wb = Wl[s & 1] + lane;
+      if (a.dbg & 1) continue;
       u32x4 fq[2][4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) fq[0][k] = wb[k * 64];
@@ -319,7 +326,8 @@ extern "C" int df3d_ffn_fused(const float *x, long long rows, int d_model, int d
                  d_model, d_ffn);
   DF3D_CHECK_ARG((ln_weight == nullptr) == (ln_bias == nullptr), "ffn_fused: LayerNorm needs weight and bias");
   if (rows <= 0) return DF3D_OK;
-  FfnArgs a = {x, (const u32x4 *)packed, b1, b2, residual, ln_weight, ln_bias, eps, out, rows, d_ffn};
+  FfnArgs a = {x, (const u32x4 *)packed, b1, b2, residual, ln_weight, ln_bias, eps, out, rows, d_ffn,
+               getenv("DF3D_FFN_DBG") ? atoi(getenv("DF3D_FFN_DBG")) : 0};
   static const int cfg = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 81;      // tuning aid: NW*10 + RT
   if (cfg == 42) hipLaunchKernelGGL((ffn_split_kernel<4, 2>), dim3(cdiv(rows, 128)), dim3(256), 0, stream, a);
   else if (cfg == 82) hipLaunchKernelGGL((ffn_split_kernel<8, 2>), dim3(cdiv(rows, 256)), dim3(512), 0, stream, a);

@@ -151,6 +151,83 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
   }
 }
 
+// Half-size block for 16k < N <= 24k points: 512 threads x PT points each keep distances AND coordinates in
+// registers without spilling (the 1024-thread kernel has 128 VGPRs per thread).  The reference's result depends on
+// its block size through the tie rule ("equal distance: lower thread id wins", thread id = k mod 1024); every
+// physical thread therefore plays two virtual threads and the reduction compares VIRTUAL ids (k & (VT - 1)).
+template <int PT>
+__global__ __launch_bounds__(512) void fps_kernel_half(const float *__restrict__ xyz, int N, int m, int VT,
+                                                       int32_t *__restrict__ idx) {
+  __shared__ float s_v[8];
+  __shared__ int s_t[8], s_k[8];
+  __shared__ int s_old;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const float *p = xyz + (size_t)b * N * 3;
+  int32_t *o = idx + (size_t)b * m;
+  float temp[PT], px[PT], py[PT], pz[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    int k = tid + i * 512;
+    int kk = k < N ? k : N - 1;
+    temp[i] = 1e10f;
+    px[i] = p[kk * 3];
+    py[i] = p[kk * 3 + 1];
+    pz[i] = p[kk * 3 + 2];
+  }
+  if (tid == 0 && m > 0) o[0] = 0;
+  float x1 = p[0], y1 = p[1], z1 = p[2];
+  const int vmask = VT - 1;
+  for (int j = 1; j < m; ++j) {
+    Best me = {-1.f, 0x7fffffff, 0};
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      int k = tid + i * 512;
+      if (k < N) {
+        float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+        float d = dx * dx + dy * dy + dz * dz;
+        float d2 = fminf(d, temp[i]);
+        temp[i] = d2;
+        int vt = k & vmask;
+        // same virtual thread: the first (lowest k) of equal values stays; other virtual thread: lower id wins ties
+        if (d2 > me.v || (d2 == me.v && vt < me.tid)) {
+          me.v = d2;
+          me.tid = vt;
+          me.k = k;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      Best ot;
+      ot.v = __shfl_xor(me.v, off, 64);
+      ot.tid = __shfl_xor(me.tid, off, 64);
+      ot.k = __shfl_xor(me.k, off, 64);
+      me = better(me, ot);
+    }
+    if (lane == 0) {
+      s_v[wave] = me.v;
+      s_t[wave] = me.tid;
+      s_k[wave] = me.k;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      Best r = {s_v[0], s_t[0], s_k[0]};
+      for (int w = 1; w < 8; ++w) {
+        Best ot = {s_v[w], s_t[w], s_k[w]};
+        r = better(r, ot);
+      }
+      s_old = r.k;
+      o[j] = r.k;
+    }
+    __syncthreads();
+    const int old = s_old;
+    x1 = p[old * 3];
+    y1 = p[old * 3 + 1];
+    z1 = p[old * 3 + 2];
+  }
+}
+
 // out[b,c,p,s] = feat[b,c,idx[b,p,s]]  (gather_points: nsample == 1)
 __global__ __launch_bounds__(256) void group_points_kernel(const float *__restrict__ feat,
                                                            const int32_t *__restrict__ idx, int C, int N, int np,
@@ -187,6 +264,8 @@ extern "C" int df3d_furthest_point_sample(const float *xyz, int B, int N, int m,
     hipLaunchKernelGGL((fps_kernel<true, 8, true>), dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
   else if (ppt <= 16)
     hipLaunchKernelGGL((fps_kernel<true, 16, true>), dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
+  else if (ppt <= 24 && bs == 1024)
+    hipLaunchKernelGGL((fps_kernel_half<48>), dim3(B), dim3(512), 0, stream, xyz, N, m, bs, idx);
   else if (ppt <= 24)
     hipLaunchKernelGGL((fps_kernel<true, 24, true>), dim3(B), dim3(bs), 0, stream, xyz, N, m, temp, idx);
   else if (ppt <= FPS_MAXPT)

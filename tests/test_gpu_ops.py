@@ -497,9 +497,14 @@ def test_fps_ball_group_vs_oracle(dev):
     assert np.array_equal(ga, orc.gather_points(feat, idx))
 
 
-@pytest.mark.parametrize("N", [50, 64, 1000, 5000])
+@pytest.mark.parametrize("N", [50, 64, 1000, 5000, 12000, 17000, 20001, 24576, 26000])
 def test_fps_block_sizes(dev, N):
+    """every kernel variant (points per thread 8/16/24-as-half-block/32, global fallback) against the oracle,
+    with a zero-padded tail (exact distance ties, resolved by the reference's thread-id rule)"""
     from dualfusion import ops
     xyz = detgen.rand("fpsb%d" % N, (2, N, 3), -5, 5)
+    if N >= 1000:
+        xyz[1, N - N // 5:] = 0
+        xyz[0, ::7] = xyz[0, 3]          # duplicated points spread over many threads
     m = min(N, 40)
     assert np.array_equal(ops.furthest_point_sample(T(xyz, dev), m).cpu().numpy(), orc.furthest_point_sample(xyz, m))
