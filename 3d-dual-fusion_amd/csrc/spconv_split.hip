@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
 // layout 0 (spconv_split_kernel, pair-compacted):   [k][wave 4][kb][ct][hi|lo][lane], lane (n,g) -> column
 //          wave*COUT/4 + CT*n + ct, channels g*CIN/4 + kb*8 + e
 // layout 1 (spconv_os_split_kernel, output-stationary): [k][kb][ct][hi|lo][lane], lane (n,g) -> column n*CT + ct,
-//          channels kb*32 + g*8 + e
+//          channels kb*32 + g*8 + e.  256-column filters are two such 128-column halves back to back
+//          ([half][k][kb][ct 8][hi|lo][lane], column half*128 + n*8 + ct): a workgroup computes one half.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, int K, int cin, int cout,
                                                            int layout, u32x4 *__restrict__ out) {
   const int KB = cin / 32;
@@ -86,11 +87,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
     col = wave * CS + CT * n + ct;
     ch0 = g * (cin / 4) + kb * 8;
   } else {
-    const int CT = cout / 16;
+    const int CW = cout > 128 ? 128 : cout, CT = CW / 16;
     int ct = (int)(r % CT); r /= CT;
-    kb = (int)(r % KB);
-    k = (int)(r / KB);
-    col = n * CT + ct;                 // lane n owns CT consecutive output columns -> vector epilogue
+    kb = (int)(r % KB); r /= KB;
+    k = (int)(r % K);
+    col = (int)(r / K) * CW + n * CT + ct;     // lane n owns CT consecutive output columns -> vector epilogue
     ch0 = kb * 32 + g * 8;
   }
   unsigned v[8];
@@ -406,7 +407,10 @@ __device__ u32x4 g_zero_row[64];
 template <int CIN, int COUT, int RT, int NW, int KPS>
 __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs a) {
   // KPS = 32-channel blocks per step (one barrier per step)
-  constexpr int KB = CIN / 32 / KPS, CT = COUT / 16, TM = 16 * RT * NW, WROWS = 16 * RT, RQ = CIN / 4;
+  // COUT = 256 is computed as two 128-column halves by different workgroups (blockIdx.y): twice the workgroups for
+  // the small dense maps of the BEV neck and half the accumulator registers; the gathers of the second half hit L2
+  constexpr int CW = COUT > 128 ? 128 : COUT;
+  constexpr int KB = CIN / 32 / KPS, CT = CW / 16, TM = 16 * RT * NW, WROWS = 16 * RT, RQ = CIN / 4;
   constexpr int WQ = KPS * CT * 2 * 64;           // u32x4 per W step tile
   constexpr int NT = NW * 64;
   constexpr int WPT = (WQ + NT - 1) / NT;
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   int nt = gridDim.x, bid = blockIdx.x, tile = bid;
   if ((nt & 7) == 0) tile = (bid & 7) * (nt >> 3) + (bid >> 3);     // consecutive tiles stay on one XCD / L2
   const int row0 = tile * TM;
+  const int col0 = blockIdx.y * CW;
 
   if (tid == 0) wg_mask = 0u;
   __syncthreads();
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   auto load_w = [&](int s) {
     s = s < steps ? s : steps - 1;
     const int k = __builtin_amdgcn_readfirstlane(actL[s / KB]);
-    const u32x4 *src = a.w + (size_t)(k * KB + s % KB) * WQ;     // KPS consecutive [kb] tiles
+    const u32x4 *src = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)(k * KB + s % KB)) * WQ;   // KPS consecutive [kb] tiles
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       int e = tid + NT * i;
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 
   // ---- epilogue: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the CT
   //      consecutive columns n*CT .. n*CT+CT-1 of its rows (packed-weight layout 1): 16-byte stores ----
-  static_assert(CT == 2 || CT == 4 || CT == 8, "COUT must be 32, 64 or 128");
+  static_assert(CT == 2 || CT == 4 || CT == 8, "COUT must be 32, 64, 128 or 256");
   if constexpr (CT == 2) {
     // COUT = 32: lane n owns columns 2n, 2n+1 (8-byte stores; four lanes share a split block)
     const int col = n * 2;
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   f32x4 bi[CT / 4], sc[CT / 4], sh[CT / 4];
 #pragma unroll
   for (int q = 0; q < CT / 4; ++q) {
-    const int col = n * CT + q * 4;
+    const int col = col0 + n * CT + q * 4;
     bi[q] = a.bias ? *(const f32x4 *)(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
     sc[q] = a.scale ? *(const f32x4 *)(a.scale + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
     sh[q] = a.shift ? *(const f32x4 *)(a.shift + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
       if (row >= a.n_out) continue;
-      const size_t o = (size_t)row * COUT + n * CT;
+      const size_t o = (size_t)row * COUT + col0 + n * CT;
       unsigned h[CT / 2], l[CT / 2];         // packed pairs
 #pragma unroll
       for (int q = 0; q < CT / 4; ++q) {
@@ -678,6 +683,29 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
   return DF3D_OK;
 }
 
+// 256-channel shapes (dense BEV neck).  Workgroup rows by map size so that the small (90 x 90) maps still fill the
+// 256 CUs; DF3D_OS_WIDE="RT,NW" overrides (tuning aid).
+template <int CIN, int COUT>
+static int launch_os_split_wide(const SplitConvArgs &a, hipStream_t stream) {
+  constexpr int CS = COUT > 128 ? 2 : 1;
+  int rt = 1, nw = (long long)a.n_out * CS >= 128 * 384 ? 8 : (long long)a.n_out * CS >= 64 * 192 ? 4 : 2;
+  static const char *cfg = getenv("DF3D_OS_WIDE");
+  if (cfg && cfg[0] && cfg[1] == ',') {
+    rt = cfg[0] - '0';
+    nw = atoi(cfg + 2);
+  }
+#define DF3D_OS_LAUNCH(RT, NW)                                                                                  \
+  hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, RT, NW, 1>), dim3(cdiv(a.n_out, 16 * RT * NW), CS), \
+                     dim3(NW * 64), 0, stream, a)
+  if (rt == 2 && nw == 4) DF3D_OS_LAUNCH(2, 4);
+  else if (rt == 2) DF3D_OS_LAUNCH(2, 2);
+  else if (nw == 8) DF3D_OS_LAUNCH(1, 8);
+  else if (nw == 4) DF3D_OS_LAUNCH(1, 4);
+  else DF3D_OS_LAUNCH(1, 2);
+#undef DF3D_OS_LAUNCH
+  return DF3D_OK;
+}
+
 static int g_num_cu = 0;
 static int num_cu() {
   if (!g_num_cu) {
@@ -728,9 +756,13 @@ static int split_layout(int cin, int cout) {
   return 1;
 }
 
+static bool split_shape_wide(int cin, int cout) {      // served by the output-stationary kernel only
+  return (cin == 256 && (cout == 128 || cout == 256)) || (cin == 128 && cout == 256);
+}
+
 static bool split_shape_ok(int cin, int cout) {
   return (cout == 128 && (cin == 128 || cin == 64)) || (cout == 64 && (cin == 64 || cin == 32)) ||
-         (cout == 32 && cin == 32 && split_layout(cin, cout) == 1);      // 32 -> 32: output-stationary kernel only
+         ((split_shape_wide(cin, cout) || (cout == 32 && cin == 32)) && split_layout(cin, cout) == 1);
 }
 
 }  // namespace df3d
@@ -783,7 +815,10 @@ extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int 
   int rec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 1, stream);
   int rc;
   if (split_layout(cin, cout) == 1) {
-    if (cout == 128) rc = cin == 128 ? launch_os_split<128, 128>(a, stream) : launch_os_split<64, 128>(a, stream);
+    if (cin == 256 && cout == 256) rc = launch_os_split_wide<256, 256>(a, stream);
+    else if (cin == 256) rc = launch_os_split_wide<256, 128>(a, stream);
+    else if (cout == 256) rc = launch_os_split_wide<128, 256>(a, stream);
+    else if (cout == 128) rc = cin == 128 ? launch_os_split<128, 128>(a, stream) : launch_os_split<64, 128>(a, stream);
     else if (cout == 32) rc = launch_os_split<32, 32>(a, stream);
     else rc = cin == 64 ? launch_os_split<64, 64>(a, stream) : launch_os_split<32, 64>(a, stream);
   } else if (cout == 128) {

@@ -84,6 +84,8 @@ SIGNATURES = {
                                c_void_p, c_float, c_void_p, c_void_p]),
     "df3d_timing_count_pairs": (c_int, [c_int]),
     "df3d_timing_get2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_sparse_to_dense_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_conv2d_neighbors": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_imgproj_packed_bytes": (c_size_t, [c_int, c_int]),
     "df3d_imgproj_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "df3d_imgproj_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -161,9 +161,15 @@ class SpMiddleResNetFHD(nn.Module):
 
     def _tail(self, x_conv1, x_conv2, x_conv3, x_conv4):
         ret = self.extra_conv(x_conv4)
-        ret = ret.dense()
-        N, C, D, H, W = ret.shape
-        ret = ret.view(N, C * D, H, W)
+        if getattr(self, "dense_layout", "nchw") == "rows" and ret.features.is_cuda:
+            # channels-last pixel rows for the row-kernel neck (necks.RPN.forward_rows): same values as
+            # dense().view(N, C*D, H, W), laid out [N*H*W, C*D]
+            D, H, W = [int(v) for v in ret.spatial_shape]
+            ret = (ret.dense_rows(), (ret.batch_size, ret.features.shape[1] * D, H, W))
+        else:
+            ret = ret.dense()
+            N, C, D, H, W = ret.shape
+            ret = ret.view(N, C * D, H, W)
         return ret, {'conv1': x_conv1, 'conv2': x_conv2, 'conv3': x_conv3, 'conv4': x_conv4}
 
     def forward(self, voxel_features, coors, batch_size, input_shape):

@@ -1,0 +1,199 @@
+"""BEV neck: `RPN` with the reference's constructor arguments and parameter layout
+(CP/det3d/models/necks/rpn.py:22-163: blocks.<i> = ZeroPad2d, Conv2d 3x3, BN, ReLU, then n x (Conv2d 3x3 pad 1, BN,
+ReLU); deblocks.<i> = ConvTranspose2d(k = s) | Conv2d, BN, ReLU), so the README checkpoints load.
+
+`forward(x)` takes / returns NCHW like the reference.  In eval mode on the GPU the layers do not go through MIOpen:
+a dense 3x3 convolution over channels-last pixel rows IS the sparse convolution with a full neighbour table, so
+every layer (conv + folded BatchNorm + ReLU) is one launch of the split-precision kernel of csrc/spconv_split.hip
+(`forward_rows`; 126 GFLOP per nuScenes sweep).  `SparseConvTensor.dense()` can feed it rows directly
+(`ops.sparse_to_dense_rows`), which removes the NCHW volume and its permute."""
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops as _ops
+from .registry import NECKS
+
+
+def _bn(norm_cfg, planes):
+    cfg = dict(norm_cfg or dict(type="BN", eps=1e-3, momentum=0.01))
+    t = cfg.pop("type", "BN")
+    if t not in ("BN", "BN2d"):
+        raise KeyError("unsupported norm type for the BEV neck: %s" % t)
+    cfg.pop("requires_grad", None)
+    return nn.BatchNorm2d(planes, **cfg)
+
+
+class _Layer(object):
+    """One conv/deconv + BN(eval) + ReLU group prepared for the row kernels."""
+
+    def __init__(self, conv, bn, relu):
+        self.conv, self.bn, self.relu = conv, bn, relu
+        self.transposed = isinstance(conv, nn.ConvTranspose2d)
+        self._key = None
+
+    def prepare(self, pad):
+        c = self.conv
+        key = (c.weight.data_ptr(), c.weight._version, self.bn.running_var._version, self.bn.weight._version,
+               _ops.CONV_PRECISION)
+        if key == self._key:
+            return
+        w = c.weight.detach().float()
+        if self.transposed:                  # [cin, cout, s, s] -> [s*s, cin, cout]
+            self.filters = w.permute(2, 3, 0, 1).reshape(-1, w.shape[0], w.shape[1]).contiguous()
+        else:                                # [cout, cin, kh, kw] -> [kh*kw, cin, cout]
+            self.filters = w.permute(2, 3, 1, 0).reshape(-1, w.shape[1], w.shape[0]).contiguous()
+        K, cin, cout = self.filters.shape
+        self.packed = _ops.conv_pack_weights(self.filters) if _ops.conv_split_supported(K, cin, cout) else None
+        inv = torch.rsqrt(self.bn.running_var.float() + self.bn.eps)
+        self.scale = (self.bn.weight.float() * inv).contiguous()
+        self.shift = (self.bn.bias.float() - self.bn.running_mean.float() * self.scale).contiguous()
+        self.bias = c.bias.detach().float().contiguous() if c.bias is not None else None
+        self.kh, self.kw = int(c.kernel_size[0]), int(c.kernel_size[1])
+        self.stride = int(c.stride[0])
+        self.pad = pad
+        self._key = key
+
+
+@NECKS.register_module
+class RPN(nn.Module):
+    def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
+                 num_input_features, norm_cfg=None, name="rpn", logger=None, **kwargs):
+        super(RPN, self).__init__()
+        self._layer_strides = list(ds_layer_strides)
+        self._num_filters = list(ds_num_filters)
+        self._layer_nums = list(layer_nums)
+        self._upsample_strides = list(us_layer_strides)
+        self._num_upsample_filters = list(us_num_filters)
+        self._num_input_features = num_input_features
+        self._norm_cfg = norm_cfg if norm_cfg is not None else dict(type="BN", eps=1e-3, momentum=0.01)
+        assert len(self._layer_strides) == len(self._layer_nums) == len(self._num_filters)
+        assert len(self._num_upsample_filters) == len(self._upsample_strides)
+        self._upsample_start_idx = len(self._layer_nums) - len(self._upsample_strides)
+        ratios = [self._upsample_strides[i] / np.prod(self._layer_strides[:i + self._upsample_start_idx + 1])
+                  for i in range(len(self._upsample_strides))]
+        assert all(r == ratios[0] for r in ratios)
+        in_filters = [self._num_input_features] + self._num_filters[:-1]
+        blocks, deblocks = [], []
+        for i, layer_num in enumerate(self._layer_nums):
+            planes = self._num_filters[i]
+            mods = [nn.ZeroPad2d(1), nn.Conv2d(in_filters[i], planes, 3, stride=self._layer_strides[i], bias=False),
+                    _bn(self._norm_cfg, planes), nn.ReLU()]
+            for _ in range(layer_num):
+                mods += [nn.Conv2d(planes, planes, 3, padding=1, bias=False), _bn(self._norm_cfg, planes), nn.ReLU()]
+            blocks.append(nn.Sequential(*mods))
+            j = i - self._upsample_start_idx
+            if j >= 0:
+                stride = self._upsample_strides[j]
+                up = self._num_upsample_filters[j]
+                if stride > 1:
+                    conv = nn.ConvTranspose2d(planes, up, int(stride), stride=int(stride), bias=False)
+                else:
+                    st = int(np.round(1 / stride))
+                    conv = nn.Conv2d(planes, up, st, stride=st, bias=False)
+                deblocks.append(nn.Sequential(conv, _bn(self._norm_cfg, up), nn.ReLU()))
+        self.blocks = nn.ModuleList(blocks)
+        self.deblocks = nn.ModuleList(deblocks)
+
+    @property
+    def downsample_factor(self):
+        factor = np.prod(self._layer_strides)
+        if len(self._upsample_strides) > 0:
+            factor /= self._upsample_strides[-1]
+        return factor
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+
+    # ------------------------------------------------------------------ reference composition (NCHW, torch ops)
+    def forward_reference(self, x):
+        ups = []
+        for i in range(len(self.blocks)):
+            x = self.blocks[i](x)
+            if i - self._upsample_start_idx >= 0:
+                ups.append(self.deblocks[i - self._upsample_start_idx](x))
+        return torch.cat(ups, dim=1) if ups else x
+
+    # ------------------------------------------------------------------ row kernels
+    def _groups(self, seq):
+        """[(conv, bn, relu, pad)] of a block / deblock Sequential."""
+        mods = list(seq)
+        out, pad, i = [], 0, 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.ZeroPad2d):
+                pad = int(m.padding[0])
+                i += 1
+                continue
+            assert isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and isinstance(mods[i + 1], nn.BatchNorm2d)
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            out.append((m, mods[i + 1], relu, pad + int(m.padding[0])))
+            pad = 0
+            i += 3 if relu else 2
+        return out
+
+    def _plan(self):
+        plan = self.__dict__.get("_row_plan")
+        if plan is None:
+            plan = {"blocks": [[(_Layer(c, b, r), p) for c, b, r, p in self._groups(blk)] for blk in self.blocks],
+                    "deblocks": [[(_Layer(c, b, r), p) for c, b, r, p in self._groups(d)] for d in self.deblocks],
+                    "nbr": {}}
+            self.__dict__["_row_plan"] = plan
+        return plan
+
+    def train(self, mode=True):
+        self.__dict__.pop("_row_plan", None)
+        return super(RPN, self).train(mode)
+
+    @staticmethod
+    def _run(layer, pad, rows, split, B, H, W, tables):
+        layer.prepare(pad)
+        key = (B, H, W, layer.kh, layer.kw, layer.stride, layer.pad, layer.transposed)
+        if key not in tables:
+            tables[key] = _ops.conv2d_neighbors(B, H, W, layer.kh, layer.kw, layer.stride, layer.pad, layer.transposed,
+                                                rows.device)
+        nbr, Ho, Wo = tables[key]
+        K, cin, cout = layer.filters.shape
+        n_out = nbr.shape[1]
+        if layer.packed is not None:
+            if split is None:
+                split = _ops.split_rows(rows)
+            out, osplit = _ops.sparse_conv_split(split, layer.packed, nbr, n_out, cin, cout, bias=layer.bias,
+                                                 scale=layer.scale, shift=layer.shift, relu=layer.relu)
+        else:
+            out = _ops.sparse_conv_fused(rows, layer.filters, nbr, n_out, bias=layer.bias, scale=layer.scale,
+                                         shift=layer.shift, relu=layer.relu)
+            osplit = None
+        return out, osplit, Ho, Wo
+
+    @torch.no_grad()
+    def forward_rows(self, rows, B, H, W):
+        """rows [B*H*W, C] fp32 channels-last (row = (b, y, x)) -> NCHW-shaped, channels-last-strided output."""
+        plan = self._plan()
+        tables = plan["nbr"]
+        x, xs = rows.contiguous(), None
+        ups = []
+        for i, blk in enumerate(plan["blocks"]):
+            for layer, pad in blk:
+                x, xs, H, W = self._run(layer, pad, x, xs, B, H, W, tables)
+            j = i - self._upsample_start_idx
+            if j >= 0:
+                u, us, uh, uw = x, xs, H, W
+                for layer, pad in plan["deblocks"][j]:
+                    u, us, uh, uw = self._run(layer, pad, u, us, B, uh, uw, tables)
+                ups.append((u, uh, uw))
+        if not ups:
+            return x.view(B, H, W, -1).permute(0, 3, 1, 2)
+        uh, uw = ups[0][1], ups[0][2]
+        assert all(h == uh and w == uw for _, h, w in ups)
+        out = torch.cat([u for u, _, _ in ups], 1) if len(ups) > 1 else ups[0][0]
+        return out.view(B, uh, uw, -1).permute(0, 3, 1, 2)
+
+    def forward(self, x):
+        if self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32:
+            return self.forward_reference(x)
+        B, C, H, W = x.shape
+        rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        return self.forward_rows(rows, B, H, W)

@@ -331,6 +331,34 @@ def sparse_to_dense(features, indices, batch, shape):
 
 
 # ------------------------------------------------------------------------- MSDA
+def sparse_to_dense_rows(features, indices, batch, shape):
+    """dense().view(N, C*D, H, W) as channels-last rows [B*H*W, C*D] (row = (b, y, x), column = c*D + d)."""
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    _chk(indices, torch.int32, "indices")
+    n, C = features.shape
+    D, H, W = [int(v) for v in shape]
+    out = torch.empty((int(batch) * H * W, C * D), dtype=torch.float32, device=features.device)
+    shp_p, keep = _lib.int3(shape)
+    rc = lib.df3d_sparse_to_dense_rows(_ptr(features), _ptr(indices), n, C, int(batch), shp_p, _ptr(out), _stream())
+    _lib.check(rc, "df3d_sparse_to_dense_rows")
+    return out
+
+
+def conv2d_neighbors(batch, H, W, kh, kw, stride, pad, transposed, device):
+    """Neighbour table [kh*kw, B*Ho*Wo] int32 of a dense (transposed) convolution over row-major pixel rows."""
+    lib = _lib.load()
+    if transposed:
+        Ho, Wo = H * stride, W * stride
+    else:
+        Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    nbr = torch.empty((kh * kw, int(batch) * Ho * Wo), dtype=torch.int32, device=device)
+    rc = lib.df3d_conv2d_neighbors(int(batch), int(H), int(W), int(kh), int(kw), int(stride), int(pad),
+                                   int(bool(transposed)), _ptr(nbr), _stream())
+    _lib.check(rc, "df3d_conv2d_neighbors")
+    return nbr, Ho, Wo
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
     lib = _lib.load()
     _chk(value, torch.float32, "value")

@@ -18,7 +18,7 @@ class CenterPointHotPath(nn.Module):
     """voxelize + mean VFE (fused) -> SpMiddleResNetFHD[Fusion] -> dense [B, 256, 180, 180]."""
 
     def __init__(self, fusion=None, voxel_size=synth.NUSC_VOXEL, pc_range=synth.NUSC_RANGE, max_points=10,
-                 max_voxels=(120000, 160000), num_input_features=5):
+                 max_voxels=(120000, 160000), num_input_features=5, neck=None):
         super(CenterPointHotPath, self).__init__()
         self.voxel_layer = Voxelization(voxel_size, pc_range, max_points, max_voxels)
         if fusion is None:
@@ -26,6 +26,11 @@ class CenterPointHotPath(nn.Module):
         else:
             self.backbone = SpMiddleResNetFHDFusion(num_input_features=num_input_features)
         self.fusion = fusion
+        # optional BEV neck (necks.RPN): the backbone then hands over channels-last pixel
+        # rows and forward returns the neck's [B, 512, 180, 180] map instead of the dense BEV tensor
+        self.neck = neck
+        if neck is not None:
+            self.backbone.dense_layout = "rows"
         gs = self.voxel_layer.grid_size.tolist()
         self.grid_size_xyz = [int(gs[0]), int(gs[1]), int(gs[2])]
 
@@ -53,5 +58,10 @@ class CenterPointHotPath(nn.Module):
         feats, coors = self.voxelize(points_list)
         B = len(points_list)
         if self.fusion is None:
-            return self.backbone(feats, coors, B, self.grid_size_xyz)
-        return self.backbone(feats, batch_dict, coors, B, self.grid_size_xyz, example, fuse_func=self.fusion)
+            bev, multi = self.backbone(feats, coors, B, self.grid_size_xyz)
+        else:
+            bev, multi = self.backbone(feats, batch_dict, coors, B, self.grid_size_xyz, example, fuse_func=self.fusion)
+        if self.neck is not None:
+            rows, (nb, _, h, w) = bev
+            bev = self.neck.forward_rows(rows, nb, h, w)
+        return bev, multi

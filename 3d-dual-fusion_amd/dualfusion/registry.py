@@ -71,6 +71,7 @@ def build_from_cfg(cfg, registry, default_args=None):
 READERS = Registry("reader")
 BACKBONES = Registry("backbone")
 FUSION = Registry("fusion")
+NECKS = Registry("neck")
 MIDDLE_ENCODERS = Registry("middle_encoder")
 VOXEL_ENCODERS = Registry("voxel_encoder")
 FUSION_LAYERS = Registry("fusion_layer")
@@ -99,7 +100,7 @@ def late_register():
         pass
     try:
         from det3d.models import registry as d3
-        for src, dst in ((READERS, d3.READERS), (BACKBONES, d3.BACKBONES), (FUSION, d3.FUSION)):
+        for src, dst in ((READERS, d3.READERS), (BACKBONES, d3.BACKBONES), (FUSION, d3.FUSION), (NECKS, d3.NECKS)):
             for k, v in src.module_dict.items():
                 dst._module_dict[k] = v
         done.append("det3d")

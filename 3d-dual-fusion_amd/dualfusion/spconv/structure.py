@@ -101,6 +101,11 @@ class SparseConvTensor(object):
             return out.permute(0, *range(2, nd + 2), 1).contiguous()
         return out
 
+    def dense_rows(self):
+        """dense().view(B, C*D, H, W) as channels-last pixel rows [B*H*W, C*D] (3-D tensors only)."""
+        return _ops.sparse_to_dense_rows(self.features.contiguous(), self.indices.contiguous(), self.batch_size,
+                                         self.spatial_shape)
+
     @property
     def sparity(self):
         return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size

@@ -173,6 +173,19 @@ int df3d_timing_get2(int i, int *shape4, float *ms, long long *pairs, int *split
 int df3d_sparse_to_dense(const float *features, const int32_t *indices, int n, int channels,
                          int batch, const int *shape_host, float *out, void *stream);
 
+/* Dense BEV neck on the sparse-convolution kernels (CP/det3d/models/necks/rpn.py,
+ * dense 3x3 / strided / transposed conv2d + BatchNorm + ReLU on [B,256,180,180]).
+ *   df3d_sparse_to_dense_rows: SparseConvTensor.dense().view(N, C*D, H, W) emitted channels-last as rows
+ *       [(b,y,x)][c*D + d] fp32 -- the layout the conv kernels gather from (no NCHW volume, no permute);
+ *   df3d_conv2d_neighbors: neighbour table nbr[kh*kw][B*Ho*Wo] of a dense Conv2d (cross-correlation, tap k =
+ *       ky*kw + kx) or, with transposed != 0, of a ConvTranspose2d with kernel == stride (tap k = (oy%s)*s + ox%s).
+ * A dense layer is then df3d_sparse_conv_split / df3d_sparse_conv_fused on those rows with filters
+ * [kh*kw][Cin][Cout] (Conv2d weight.permute(2,3,1,0); ConvTranspose2d weight.permute(2,3,0,1)). */
+int df3d_sparse_to_dense_rows(const float *features, const int32_t *indices, int n, int channels, int batch,
+                              const int *shape_host, float *out_rows, void *stream);
+int df3d_conv2d_neighbors(int batch, int H, int W, int kh, int kw, int stride, int pad, int transposed,
+                          int32_t *nbr, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Multi-scale deformable attention, forward.  Replaces
  * MultiScaleDeformableAttention.ms_deform_attn_forward (CP/det3d/models/model_utils/ops/src/
@@ -279,7 +292,7 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
  * contraction is A_hi*W_hi + A_lo*W_hi + A_hi*W_lo with fp32 accumulation: ~1e-5 relative error against the
  * exact fp32 result (parity bar 1e-3), 16/3 of the fp32 MFMA rate.
  *   df3d_conv_packed_weight_bytes: bytes of the packed filter bank, 0 when (cin, cout) has no split kernel
- *                                  (served: 32->32, 32->64, 64->64, 64->128, 128->128)
+ *                                  (served: 32->32, 32->64, 64->64, 64->128, 128->128, 128->256, 256->128, 256->256)
  *   df3d_conv_pack_weights:  filters [kvol][cin][cout] fp32 -> packed MFMA B operands (once per weight)
  *   df3d_split_rows:         features [n][c] fp32 -> split rows [n][c/8][hi 8 x bf16 | lo 8 x bf16], c % 8 == 0
  *   df3d_sparse_conv_split:  out fp32 [n_out][cout]; out_split (optional) receives the split rows of `out`

@@ -1,0 +1,92 @@
+"""BEV neck on the sparse-convolution kernels: the RPN module's row path against the
+torch fp32 CPU composition of the same module (Conv2d / ConvTranspose2d / BatchNorm2d / ReLU), and the channels-last
+dense() against SparseConvTensor.dense()."""
+import numpy as np
+import pytest
+
+import detgen
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _det_module(m):
+    sd = detgen.det_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.eval()
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 44, 36), (1, 180, 180)])
+def test_rpn_rows_vs_torch_cpu(B, H, W):
+    from dualfusion.necks import RPN
+    dev = torch.device("cuda:0")
+    m = _det_module(RPN([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256))
+    x = torch.from_numpy(detgen.randn("neck_x_%d_%d" % (H, W), (B, 256, H, W)))
+    x = x * (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(1)) < 0.3)     # BEV maps are mostly empty
+    with torch.no_grad():
+        ref = m.forward_reference(x)                       # torch CPU fp32 = the oracle for this floating-point row
+        md = m.to(dev)
+        y = md(x.to(dev))
+        y_lib = md.forward_reference(x.to(dev))            # MIOpen / hipBLASLt composition, for reference only
+    assert tuple(y.shape) == tuple(ref.shape) == (B, 512, H, W)
+    err = float((y.cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-3, err                                 # north_star tolerance; measured ~1e-5
+    assert float((y_lib.cpu() - ref).abs().max() / ref.abs().max()) < 1e-3
+
+
+def test_rpn_parameter_layout_and_exact_path():
+    """state_dict keys of the reference checkpoint layout; DF3D_CONV_PRECISION=fp32 path through the same module."""
+    from dualfusion import ops
+    from dualfusion.necks import RPN
+    dev = torch.device("cuda:0")
+    m = RPN([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256)
+    keys = set(m.state_dict())
+    assert {"blocks.0.1.weight", "blocks.0.2.running_var", "blocks.0.4.weight", "blocks.1.16.weight",
+            "deblocks.0.0.weight", "deblocks.1.0.weight", "deblocks.1.1.bias"} <= keys
+    assert tuple(m.state_dict()["deblocks.1.0.weight"].shape) == (256, 256, 2, 2)
+    m = _det_module(m)
+    x = torch.from_numpy(detgen.randn("neck_exact", (1, 256, 20, 24)))
+    with torch.no_grad():
+        ref = m.forward_reference(x)
+        old = ops.CONV_PRECISION
+        ops.CONV_PRECISION = "fp32"
+        try:
+            y = m.to(dev)(x.to(dev))
+        finally:
+            ops.CONV_PRECISION = old
+    assert float((y.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
+
+
+def test_dense_rows_equals_dense_view():
+    from dualfusion import ops
+    dev = torch.device("cuda:0")
+    shape, batch, C = [2, 30, 28], 3, 128
+    ind = detgen.clustered_voxels("dnr", batch, shape, n_seeds=5, walk=150)
+    f = detgen.randn("dnrf", (len(ind), C))
+    ft, it = torch.from_numpy(f).to(dev), torch.from_numpy(ind).to(dev)
+    rows = ops.sparse_to_dense_rows(ft, it, batch, shape)
+    dense = ops.sparse_to_dense(ft, it, batch, shape)                      # [B, C, D, H, W]
+    want = dense.view(batch, C * shape[0], shape[1], shape[2]).permute(0, 2, 3, 1).reshape(-1, C * shape[0])
+    assert torch.equal(rows, want)
+
+
+def test_pipeline_with_neck_equals_dense_then_neck():
+    """CenterPointHotPath(neck=RPN): backbone hands over pixel rows (no NCHW volume); same values as dense() -> RPN."""
+    from dualfusion import synth
+    from dualfusion.necks import RPN
+    from dualfusion.pipeline import CenterPointHotPath
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    neck = _det_module(RPN([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256)).to(dev)
+    model = CenterPointHotPath().eval().to(dev)
+    pts = [torch.from_numpy(synth.nusc_sweep(seed=s)).to(dev) for s in (0, 1)]
+    with torch.no_grad():
+        bev, _ = model(pts)
+        want = neck(bev)
+        want_ref = neck.forward_reference(bev)
+        with_neck = CenterPointHotPath(neck=neck).eval().to(dev)
+        with_neck.backbone.load_state_dict(model.backbone.state_dict())
+        got, multi = with_neck(pts)
+    assert tuple(got.shape) == (2, 512, 180, 180) and set(multi) == {"conv1", "conv2", "conv3", "conv4"}
+    assert torch.equal(got, want)
+    assert float((got - want_ref).abs().max() / want_ref.abs().max()) < 1e-3

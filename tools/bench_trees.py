@@ -2,7 +2,8 @@
 """Timing of the other two module trees at their BASELINE config shapes (not the driver's bench line):
   tf : TransFusion-L SparseEncoderFusion + ACTR fusion layer, 0.075 m nuScenes grid, bs=4, 6 cameras (configs[2] shape, fp32)
   vr : Voxel-RCNN VoxelBackBone8xFusion (MVX + ACTRv2), KITTI 0.05 m grid, bs=8, one camera (configs[4] shape)
-usage: bench_trees.py [tf|vr] [steps]"""
+  neck : CenterPoint RPN BEV neck on [B, 256, 180, 180] (0.1 m nuScenes grid), row kernels vs the torch/MIOpen composition
+usage: bench_trees.py [tf|vr|neck] [steps]"""
 import os
 import sys
 import time
@@ -73,6 +74,36 @@ if which == "tf":
     ms = timeit(step)
     print("tf  SparseEncoderFusion+ACTR bs=%d (%d voxels): %.2f ms/step = %.1f sweeps/s  [DF3D_EXECUTOR=%s]" % (
         B, f.shape[0], ms, B / ms * 1e3, os.environ.get("DF3D_EXECUTOR", "1")))
+elif which == "neck":
+    from dualfusion.necks import RPN
+    B = int(os.environ.get("DF3D_NECK_BATCH", "1"))
+    neck = RPN([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256).to(dev).eval()
+    for m in neck.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+    x = torch.randn(B, 256, 180, 180, device=dev) * (torch.rand(B, 1, 180, 180, device=dev) < 0.3)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, 256).contiguous()
+    with torch.no_grad():
+        ms_rows = timeit(lambda: neck.forward_rows(rows, B, 180, 180))
+        ms_nchw = timeit(lambda: neck(x))
+        ms_lib = timeit(lambda: neck.forward_reference(x))
+        xcl = x.contiguous(memory_format=torch.channels_last)
+        neck_cl = neck.to(memory_format=torch.channels_last)
+        ms_lib_cl = timeit(lambda: neck_cl.forward_reference(xcl))
+        err = float((neck(x) - neck.forward_reference(x)).abs().max())
+    gf = 125.8 * B
+    if B == 1:                                       # whole LiDAR path + neck, one sweep per step (bench.py's workload)
+        from dualfusion import synth as _s
+        from dualfusion.pipeline import CenterPointHotPath
+        hp = CenterPointHotPath(neck=neck).eval().to(dev)
+        hp0 = CenterPointHotPath().eval().to(dev)
+        pts = [torch.from_numpy(_s.nusc_sweep(seed=0)).to(dev)]
+        ms_hp0 = timeit(lambda: hp0(pts))
+        ms_hp = timeit(lambda: hp(pts))
+        print("LiDAR hot path %.3f ms/sweep; with the row-kernel neck %.3f ms/sweep" % (ms_hp0, ms_hp))
+    print("neck RPN bs=%d: rows %.3f ms (%.0f TFLOP/s), NCHW in %.3f ms | torch/MIOpen NCHW %.3f ms, channels_last %.3f ms"
+          " | max abs diff %.2e" % (B, ms_rows, gf / ms_rows, ms_nchw, ms_lib, ms_lib_cl, err))
 else:
     from dualfusion.backbones import VoxelBackBone8xFusion
     B = 8
