@@ -1,6 +1,9 @@
-"""BEV neck: `RPN` with the reference's constructor arguments and parameter layout
-(CP/det3d/models/necks/rpn.py:22-163: blocks.<i> = ZeroPad2d, Conv2d 3x3, BN, ReLU, then n x (Conv2d 3x3 pad 1, BN,
-ReLU); deblocks.<i> = ConvTranspose2d(k = s) | Conv2d, BN, ReLU), so the README checkpoints load.
+"""BEV neck with the reference's constructor arguments and parameter layouts, so the
+README checkpoints load:
+  `RPN`                 CP/det3d/models/necks/rpn.py:22-163 (blocks.<i> = ZeroPad2d, Conv2d 3x3, BN, ReLU, then n x (Conv2d
+                        3x3 pad 1, BN, ReLU); deblocks.<i> = ConvTranspose2d(k = s) | Conv2d, BN, ReLU)
+  `SECOND`, `SECONDFPN` TF/mmdet3d/models/backbones/second.py:9-88, TF/mmdet3d/models/necks/second_fpn.py:12-91
+                        (pts_backbone / pts_neck of TF/configs/transfusion_nusc_voxel_LC.py:168-183)
 
 `forward(x)` takes / returns NCHW like the reference.  In eval mode on the GPU the layers do not go through MIOpen:
 a dense 3x3 convolution over channels-last pixel rows IS the sparse convolution with a full neighbour table, so
@@ -12,7 +15,7 @@ import torch
 from torch import nn
 
 from . import ops as _ops
-from .registry import NECKS
+from .registry import MM_BACKBONES, MM_NECKS, NECKS
 
 
 def _bn(norm_cfg, planes):
@@ -117,7 +120,8 @@ class RPN(nn.Module):
         return torch.cat(ups, dim=1) if ups else x
 
     # ------------------------------------------------------------------ row kernels
-    def _groups(self, seq):
+    @staticmethod
+    def _groups(seq):
         """[(conv, bn, relu, pad)] of a block / deblock Sequential."""
         mods = list(seq)
         out, pad, i = [], 0, 0
@@ -197,3 +201,156 @@ class RPN(nn.Module):
         B, C, H, W = x.shape
         rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
         return self.forward_rows(rows, B, H, W)
+
+
+# ---------------------------------------------------------------------------------------------- TransFusion tree
+def _norm2d(norm_cfg, planes):
+    cfg = dict(norm_cfg or dict(type="BN", eps=1e-3, momentum=0.01))
+    t = cfg.pop("type", "BN")
+    if t not in ("BN", "BN2d"):
+        raise KeyError("unsupported norm type for the BEV neck: %s" % t)
+    cfg.pop("requires_grad", None)
+    return nn.BatchNorm2d(planes, **cfg)
+
+
+def _conv2d(conv_cfg, cin, cout, k, **kw):
+    cfg = dict(conv_cfg or dict(type="Conv2d", bias=False))
+    t = cfg.pop("type", "Conv2d")
+    if t not in ("Conv2d", "Conv"):
+        raise KeyError("unsupported conv type for the BEV neck: %s" % t)
+    kw.update(cfg)
+    return nn.Conv2d(cin, cout, k, **kw)
+
+
+def _rows_of(x):
+    """NCHW tensor -> (rows [B*H*W, C], split rows or None); free for the channels-last views this module returns."""
+    cached = getattr(x, "_df3d_rows", None)
+    if cached is not None and cached[2] == x._version:       # views share the version counter: in-place edits void it
+        return cached[0], cached[1]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C), None
+
+
+def _as_nchw(rows, split, B, H, W):
+    out = rows.view(B, H, W, -1).permute(0, 3, 1, 2)
+    out._df3d_rows = (rows, split, out._version)   # lets the next module skip the layout change and the operand split
+    return out
+
+
+class _RowStacks(nn.Module):
+    """Shared machinery: per-Sequential row plans, invalidated by train()."""
+
+    def _stacks(self, name, seqs):
+        plan = self.__dict__.get("_row_plan")
+        if plan is None:
+            plan = self.__dict__["_row_plan"] = {"nbr": {}}
+        if name not in plan:
+            plan[name] = [[(_Layer(c, b, r), p) for c, b, r, p in RPN._groups(s)] for s in seqs]
+        return plan[name], plan["nbr"]
+
+    def train(self, mode=True):
+        self.__dict__.pop("_row_plan", None)
+        return super(_RowStacks, self).train(mode)
+
+    @staticmethod
+    def _fast(x):
+        return x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+
+
+@MM_BACKBONES.register_module()
+class SECOND(_RowStacks):
+    def __init__(self, in_channels=128, out_channels=[128, 128, 256], layer_nums=[3, 5, 5], layer_strides=[2, 2, 2],
+                 norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), conv_cfg=dict(type="Conv2d", bias=False)):
+        super(SECOND, self).__init__()
+        assert len(layer_strides) == len(layer_nums) == len(out_channels)
+        in_filters = [in_channels] + list(out_channels[:-1])
+        blocks = []
+        for i, layer_num in enumerate(layer_nums):
+            mods = [_conv2d(conv_cfg, in_filters[i], out_channels[i], 3, stride=layer_strides[i], padding=1),
+                    _norm2d(norm_cfg, out_channels[i]), nn.ReLU(inplace=True)]
+            for _ in range(layer_num):
+                mods += [_conv2d(conv_cfg, out_channels[i], out_channels[i], 3, padding=1),
+                         _norm2d(norm_cfg, out_channels[i]), nn.ReLU(inplace=True)]
+            blocks.append(nn.Sequential(*mods))
+        self.blocks = nn.ModuleList(blocks)
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):
+            self.load_state_dict(torch.load(pretrained, map_location="cpu").get("state_dict", {}), strict=False)
+
+    def forward_reference(self, x):
+        outs = []
+        for blk in self.blocks:
+            x = blk(x)
+            outs.append(x)
+        return tuple(outs)
+
+    def forward(self, x):
+        if self.training or not self._fast(x):
+            return self.forward_reference(x)
+        stacks, tables = self._stacks("blocks", self.blocks)
+        B, _, H, W = x.shape
+        rows, split = _rows_of(x)
+        rows = rows.contiguous()
+        outs = []
+        for stack in stacks:
+            for layer, pad in stack:
+                rows, split, H, W = RPN._run(layer, pad, rows, split, B, H, W, tables)
+            outs.append(_as_nchw(rows, split, B, H, W))
+        return tuple(outs)
+
+
+@MM_NECKS.register_module()
+class SECONDFPN(_RowStacks):
+    def __init__(self, in_channels=[128, 128, 256], out_channels=[256, 256, 256], upsample_strides=[1, 2, 4],
+                 norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), upsample_cfg=dict(type="deconv", bias=False),
+                 conv_cfg=dict(type="Conv2d", bias=False), use_conv_for_no_stride=False):
+        super(SECONDFPN, self).__init__()
+        assert len(out_channels) == len(upsample_strides) == len(in_channels)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.fp16_enabled = False
+        deblocks = []
+        for i, out_channel in enumerate(out_channels):
+            stride = upsample_strides[i]
+            if stride > 1 or (stride == 1 and not use_conv_for_no_stride):
+                cfg = dict(upsample_cfg)
+                if cfg.pop("type", "deconv") != "deconv":
+                    raise KeyError("the BEV neck serves upsample_cfg type 'deconv'")
+                up = nn.ConvTranspose2d(in_channels[i], out_channel, int(stride), stride=int(stride), **cfg)
+            else:
+                st = int(np.round(1 / stride))
+                up = _conv2d(conv_cfg, in_channels[i], out_channel, st, stride=st)
+            deblocks.append(nn.Sequential(up, _norm2d(norm_cfg, out_channel), nn.ReLU(inplace=True)))
+        self.deblocks = nn.ModuleList(deblocks)
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward_reference(self, x):
+        assert len(x) == len(self.in_channels)
+        ups = [d(x[i]) for i, d in enumerate(self.deblocks)]
+        return [torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]]
+
+    def forward(self, x):
+        assert len(x) == len(self.in_channels)
+        if self.training or not all(self._fast(t) for t in x):
+            return self.forward_reference(x)
+        stacks, tables = self._stacks("deblocks", self.deblocks)
+        ups = []
+        for t, stack in zip(x, stacks):
+            B, _, H, W = t.shape
+            rows, split = _rows_of(t)
+            rows = rows.contiguous()
+            for layer, pad in stack:
+                rows, split, H, W = RPN._run(layer, pad, rows, split, B, H, W, tables)
+            ups.append((rows, H, W))
+        H, W = ups[0][1], ups[0][2]
+        assert all(h == H and w == W for _, h, w in ups)
+        rows = torch.cat([u for u, _, _ in ups], 1) if len(ups) > 1 else ups[0][0]
+        return [_as_nchw(rows, None, B, H, W)]

@@ -76,6 +76,8 @@ MIDDLE_ENCODERS = Registry("middle_encoder")
 VOXEL_ENCODERS = Registry("voxel_encoder")
 FUSION_LAYERS = Registry("fusion_layer")
 CONV_LAYERS = Registry("conv layer")
+MM_BACKBONES = Registry("mmdet backbone")      # 2-D BEV backbone / neck of the TransFusion tree (SECOND, SECONDFPN)
+MM_NECKS = Registry("mmdet neck")
 BACKBONES_3D = Registry("pcdet backbone_3d")   # pcdet uses a plain dict `__all__`; same lookup by NAME
 
 
@@ -96,6 +98,14 @@ def late_register():
             for k, v in src.module_dict.items():
                 dst.register_module(name=k, module=v, force=True)
         done.append("mmdet3d")
+    except Exception:
+        pass
+    try:
+        from mmdet.models import BACKBONES as MB, NECKS as MN
+        for src, dst in ((MM_BACKBONES, MB), (MM_NECKS, MN)):
+            for k, v in src.module_dict.items():
+                dst.register_module(name=k, module=v, force=True)
+        done.append("mmdet")
     except Exception:
         pass
     try:

@@ -90,3 +90,40 @@ def test_pipeline_with_neck_equals_dense_then_neck():
     assert tuple(got.shape) == (2, 512, 180, 180) and set(multi) == {"conv1", "conv2", "conv3", "conv4"}
     assert torch.equal(got, want)
     assert float((got - want_ref).abs().max() / want_ref.abs().max()) < 1e-3
+
+
+def test_second_fpn_rows_vs_torch_cpu():
+    """TransFusion tree: SECOND -> SECONDFPN (transfusion_nusc_voxel_LC.py:168-183) on the row kernels."""
+    from dualfusion.necks import SECOND, SECONDFPN
+    from dualfusion.registry import MM_BACKBONES, MM_NECKS, build_from_cfg
+    dev = torch.device("cuda:0")
+    bb = build_from_cfg(dict(type="SECOND", in_channels=256, out_channels=[128, 256], layer_nums=[5, 5],
+                             layer_strides=[1, 2], norm_cfg=dict(type="BN", eps=0.001, momentum=0.01),
+                             conv_cfg=dict(type="Conv2d", bias=False)), MM_BACKBONES)
+    fpn = build_from_cfg(dict(type="SECONDFPN", in_channels=[128, 256], out_channels=[256, 256],
+                              upsample_strides=[1, 2], norm_cfg=dict(type="BN", eps=0.001, momentum=0.01),
+                              upsample_cfg=dict(type="deconv", bias=False), use_conv_for_no_stride=True), MM_NECKS)
+    assert isinstance(bb, SECOND) and isinstance(fpn, SECONDFPN)
+    assert {"blocks.0.0.weight", "blocks.1.15.weight", "blocks.1.16.running_mean"} <= set(bb.state_dict())
+    assert tuple(fpn.state_dict()["deblocks.0.0.weight"].shape) == (256, 128, 1, 1)      # conv for stride 1
+    assert tuple(fpn.state_dict()["deblocks.1.0.weight"].shape) == (256, 256, 2, 2)      # deconv [cin, cout, s, s]
+    bb, fpn = _det_module(bb), _det_module(fpn)
+    x = torch.from_numpy(detgen.randn("second_x", (2, 256, 40, 52)))
+    x = x * (torch.rand(2, 1, 40, 52, generator=torch.Generator().manual_seed(2)) < 0.3)
+    with torch.no_grad():
+        ref_ms = bb.forward_reference(x)
+        ref = fpn.forward_reference(ref_ms)[0]
+        bb, fpn = bb.to(dev), fpn.to(dev)
+        ms = bb(x.to(dev))
+        out = fpn(ms)[0]
+        assert getattr(ms[1], "_df3d_rows", None) is not None          # stayed on rows between the two modules
+        # default deconv for stride 1 (use_conv_for_no_stride=False) is a 1x1 ConvTranspose2d
+        fpn2 = _det_module(SECONDFPN(in_channels=[128, 256], out_channels=[256, 256], upsample_strides=[1, 2]))
+        ref2 = fpn2.forward_reference(ref_ms)[0]
+        out2 = fpn2.to(dev)(ms)[0]
+    for a, b in zip(ms, ref_ms):
+        assert tuple(a.shape) == tuple(b.shape)
+        assert float((a.cpu() - b).abs().max() / b.abs().max()) < 1e-3
+    assert tuple(out.shape) == tuple(ref.shape) == (2, 512, 40, 52)
+    assert float((out.cpu() - ref).abs().max() / ref.abs().max()) < 1e-3
+    assert float((out2.cpu() - ref2).abs().max() / ref2.abs().max()) < 1e-3
