@@ -359,6 +359,47 @@ def conv2d_neighbors(batch, H, W, kh, kw, stride, pad, transposed, device):
     return nbr, Ho, Wo
 
 
+# ------------------------------------------------------------------------- detection tail
+NMS_NORMAL, NMS_ROTATED, NMS_CIRCLE = 0, 1, 2
+
+
+def boxes_bev_pairwise(boxes_a, boxes_b, iou=True):
+    """[N,7] x [M,7] -> [N,M] rotated BEV IoU (or overlap area)."""
+    lib = _lib.load()
+    _chk(boxes_a, torch.float32, "boxes_a")
+    _chk(boxes_b, torch.float32, "boxes_b")
+    if boxes_a.dim() != 2 or boxes_b.dim() != 2 or boxes_a.shape[1] != 7 or boxes_b.shape[1] != 7:
+        raise ValueError("boxes must be [N, 7] (x, y, z, dx, dy, dz, heading)")
+    out = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
+    rc = lib.df3d_boxes_bev_pairwise(_ptr(boxes_a), boxes_a.shape[0], _ptr(boxes_b), boxes_b.shape[0], int(bool(iou)),
+                                     _ptr(out), _stream())
+    _lib.check(rc, "df3d_boxes_bev_pairwise")
+    return out
+
+
+def nms_bev(boxes, thresh, mode=NMS_ROTATED, counts=None, max_keep=0):
+    """Greedy NMS of score-sorted lists boxes [S, cap, 7] (or [cap, 7]) -> (keep [S, cap] int32, num_keep [S] int32),
+    all on the device."""
+    lib = _lib.load()
+    _chk(boxes, torch.float32, "boxes")
+    single = boxes.dim() == 2
+    if single:
+        boxes = boxes.unsqueeze(0)
+    if boxes.dim() != 3 or boxes.shape[2] != 7:
+        raise ValueError("boxes must be [lists, cap, 7]")
+    S, cap = int(boxes.shape[0]), int(boxes.shape[1])
+    if counts is not None:
+        _chk(counts, torch.int32, "counts")
+    keep = torch.empty((S, cap), dtype=torch.int32, device=boxes.device)
+    num = torch.zeros((S,), dtype=torch.int32, device=boxes.device)
+    nbytes = lib.df3d_nms_bev_workspace_bytes(S, cap)
+    ws = torch.empty((max(int(nbytes), 8),), dtype=torch.uint8, device=boxes.device)
+    rc = lib.df3d_nms_bev(_ptr(boxes), _ptr(counts) if counts is not None else None, S, cap, float(thresh), int(mode),
+                          int(max_keep), _ptr(keep), _ptr(num), _ptr(ws), int(nbytes), _stream())
+    _lib.check(rc, "df3d_nms_bev")
+    return (keep[0], num[0]) if single else (keep, num)
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
     lib = _lib.load()
     _chk(value, torch.float32, "value")

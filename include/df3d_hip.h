@@ -187,6 +187,27 @@ int df3d_conv2d_neighbors(int batch, int H, int W, int kh, int kw, int stride, i
                           int32_t *nbr, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Detection tail: rotated BEV overlap / IoU / NMS.  Replace the pybind module
+ * `iou3d_nms_cuda` (CP/det3d/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17): boxes_overlap_bev_gpu / boxes_iou_bev_gpu
+ * (iou3d_nms.cpp:38-85) and nms_gpu / nms_normal_gpu (iou3d_nms.cpp:88-188), plus the numba circle NMS
+ * (CP/det3d/core/utils/circle_nms_jit.py:4-27).  Boxes are rows [x, y, z, dx, dy, dz, heading] f32.
+ *   df3d_boxes_bev_pairwise: out[na][nb] = overlap area (mode 0) or rotated IoU (mode 1).
+ *   df3d_nms_bev: greedy NMS of `lists` independent lists boxes[lists][cap][7], each already sorted by descending
+ *       score, counts[lists] valid boxes (device i32; NULL = cap each).  keep[lists][cap] receives the kept indices
+ *       in ascending order, num_keep[lists] their number, clipped to max_keep when max_keep > 0 (the reference's
+ *       `selected[:post_max_size]`).  thresh = IoU threshold, or the squared centre distance for DF3D_NMS_CIRCLE.
+ *       The bit matrix AND its greedy reduction stay on the device (the reference copies the matrix to the host,
+ *       iou3d_nms.cpp:108-133).  cap <= 4096.  workspace: df3d_nms_bev_workspace_bytes(lists, cap). */
+#define DF3D_NMS_NORMAL 0
+#define DF3D_NMS_ROTATED 1
+#define DF3D_NMS_CIRCLE 2
+int df3d_boxes_bev_pairwise(const float *boxes_a, int na, const float *boxes_b, int nb, int mode, float *out,
+                            void *stream);
+size_t df3d_nms_bev_workspace_bytes(int lists, int cap);
+int df3d_nms_bev(const float *boxes, const int32_t *counts, int lists, int cap, float thresh, int mode, int max_keep,
+                 int32_t *keep, int32_t *num_keep, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Multi-scale deformable attention, forward.  Replaces
  * MultiScaleDeformableAttention.ms_deform_attn_forward (CP/det3d/models/model_utils/ops/src/
  * vision.cpp:13-16, ms_deform_attn.h:21-40, cuda/ms_deform_attn_cuda.cu:20-84, kernel

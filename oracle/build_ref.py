@@ -19,6 +19,12 @@ Built here:
   oracle/_ref/voxel_layer.so      <- TF/mmdet3d/ops/voxel/src/{voxelization.cpp,
                                      voxelization_cpu.cpp, scatter_points_cpu.cpp} (CPU only)
 
+  oracle/_ref/iou3d_nms_cuda.so  <- CP/det3d/ops/iou3d_nms/src/{iou3d_cpu.cpp, iou3d_nms.cpp, iou3d_nms_api.cpp,
+                                     iou3d_nms_kernel.cu} (rotated BEV IoU / NMS: the CPU path `boxes_iou_bev_cpu`
+                                     and, through torch's own hipify step, the reference's GPU kernels
+                                     `boxes_overlap_bev_gpu / boxes_iou_bev_gpu / nms_gpu / nms_normal_gpu`, which
+                                     the -m gpu tests run beside ours on the MI355X)
+
 Nothing outside tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
 may load these libraries.
 """
@@ -28,6 +34,7 @@ import sys
 import tempfile
 
 REF = "/root/reference/TransFusion/mmdet3d/ops"
+REF_CP = "/root/reference/CenterPoint/det3d/ops"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref")
 
@@ -41,7 +48,8 @@ def build(verbose=False):
         print("[oracle/_ref] /root/reference absent: keeping prebuilt files", file=sys.stderr)
         return False
     os.makedirs(OUT, exist_ok=True)
-    want = [os.path.join(OUT, "sparse_conv_ext.so"), os.path.join(OUT, "voxel_layer.so")]
+    want = [os.path.join(OUT, "sparse_conv_ext.so"), os.path.join(OUT, "voxel_layer.so"),
+            os.path.join(OUT, "iou3d_nms_cuda.so")]
     if all(os.path.exists(w) for w in want) and not os.environ.get("DF3D_REBUILD_REF"):
         return True
     os.environ.setdefault("PYTORCH_ROCM_ARCH", "gfx950")
@@ -80,6 +88,18 @@ def build(verbose=False):
                                          ("voxelization.cpp", "voxelization_cpu.cpp", "scatter_points_cpu.cpp")],
              extra_cflags=["-w"], build_directory=bdir, verbose=verbose)
         shutil.copy(os.path.join(bdir, "voxel_layer.so"), want[1])
+
+        # ---- iou3d_nms (CPU IoU + hipified GPU kernels) -----------------
+        io = os.path.join(stage, "iou3d_nms")
+        shutil.copytree(os.path.join(REF_CP, "iou3d_nms", "src"), io)
+        os.system("chmod -R u+w %s" % io)
+        bdir = os.path.join(io, "out")
+        os.makedirs(bdir)
+        load(name="iou3d_nms_cuda", sources=[os.path.join(io, f) for f in
+                                            ("iou3d_cpu.cpp", "iou3d_nms.cpp", "iou3d_nms_api.cpp", "iou3d_nms_kernel.cu")],
+             extra_include_paths=[io], extra_cflags=["-w"], extra_cuda_cflags=["-w"], build_directory=bdir,
+             with_cuda=True, verbose=verbose)
+        shutil.copy(os.path.join(bdir, "iou3d_nms_cuda.so"), want[2])
     finally:
         shutil.rmtree(stage, ignore_errors=True)
     return True

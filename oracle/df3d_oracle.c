@@ -302,3 +302,148 @@ void orc_ball_query(const float *new_xyz, const float *xyz, int B, int N, int m,
       }
     }
 }
+
+/* ------------------------------------------------------------------------
+ * rotated BEV overlap / IoU / NMS (detection tail).
+ * Restates CP/det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:58-221 (the reference's CPU path; its GPU kernel
+ * iou3d_nms_kernel.cu:36-245 is the same arithmetic): boxes are [x, y, z, dx, dy, dz, heading]; the overlap polygon
+ * is assembled from (i) the proper crossings of the 4x4 edge pairs (bounding-rectangle rejection, strict
+ * cross-product sign test, line intersection with the EPS = 1e-8 fallback formula), (ii) the corners of either
+ * box inside the other with a 1e-2 margin (corner of b tested before corner of a for each k), ordered by a bubble
+ * sort on atan2 around the vertex mean, and its area is the fan of cross products around vertex 0.
+ * All arithmetic in float like the reference (cosf/sinf/atan2f are what the C++ float overloads resolve to). */
+typedef struct { float x, y; } orc_pt;
+
+static float orc_cross3(orc_pt p1, orc_pt p2, orc_pt p0) {
+  return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+
+static int orc_rect_cross(orc_pt p1, orc_pt p2, orc_pt q1, orc_pt q2) {
+  return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
+         fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
+}
+
+static int orc_in_box2d(const float *box, orc_pt p) { /* iou3d_cpu.cpp:73-83 */
+  const float margin = 1e-2f;
+  float ca = cosf(-box[6]), sa = sinf(-box[6]);
+  float rx = (p.x - box[0]) * ca + (p.y - box[1]) * (-sa);
+  float ry = (p.x - box[0]) * sa + (p.y - box[1]) * ca;
+  return fabsf(rx) < box[3] / 2 + margin && fabsf(ry) < box[4] / 2 + margin;
+}
+
+static int orc_intersection(orc_pt p1, orc_pt p0, orc_pt q1, orc_pt q0, orc_pt *ans) { /* :85-115 */
+  if (!orc_rect_cross(p0, p1, q0, q1)) return 0;
+  float s1 = orc_cross3(q0, p1, p0), s2 = orc_cross3(p1, q1, p0);
+  float s3 = orc_cross3(p0, q1, q0), s4 = orc_cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+  float s5 = orc_cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > 1e-8f) {
+    ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    float D = a0 * b1 - a1 * b0;
+    ans->x = (b0 * c1 - b1 * c0) / D;
+    ans->y = (a1 * c0 - a0 * c1) / D;
+  }
+  return 1;
+}
+
+static void orc_corners(const float *box, orc_pt *c) { /* :131-163 */
+  float hx = box[3] / 2, hy = box[4] / 2, ca = cosf(box[6]), sa = sinf(box[6]);
+  float x1 = box[0] - hx, y1 = box[1] - hy, x2 = box[0] + hx, y2 = box[1] + hy;
+  float px[4] = {x1, x2, x2, x1}, py[4] = {y1, y1, y2, y2};
+  for (int k = 0; k < 4; ++k) {
+    c[k].x = (px[k] - box[0]) * ca + (py[k] - box[1]) * (-sa) + box[0];
+    c[k].y = (px[k] - box[0]) * sa + (py[k] - box[1]) * ca + box[1];
+  }
+  c[4] = c[0];
+}
+
+float orc_box_overlap(const float *a, const float *b) { /* :125-212 */
+  orc_pt ca[5], cb[5], pts[16], ctr = {0.f, 0.f};
+  int cnt = 0;
+  orc_corners(a, ca);
+  orc_corners(b, cb);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (orc_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], &pts[cnt])) {
+        ctr.x += pts[cnt].x;
+        ctr.y += pts[cnt].y;
+        cnt++;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (orc_in_box2d(a, cb[k])) {
+      ctr.x += cb[k].x;
+      ctr.y += cb[k].y;
+      pts[cnt++] = cb[k];
+    }
+    if (orc_in_box2d(b, ca[k])) {
+      ctr.x += ca[k].x;
+      ctr.y += ca[k].y;
+      pts[cnt++] = ca[k];
+    }
+  }
+  ctr.x /= cnt;
+  ctr.y /= cnt;
+  for (int j = 0; j < cnt - 1; ++j)
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (atan2f(pts[i].y - ctr.y, pts[i].x - ctr.x) > atan2f(pts[i + 1].y - ctr.y, pts[i + 1].x - ctr.x)) {
+        orc_pt t = pts[i];
+        pts[i] = pts[i + 1];
+        pts[i + 1] = t;
+      }
+  float area = 0;
+  for (int k = 0; k < cnt - 1; ++k) {
+    float ax = pts[k].x - pts[0].x, ay = pts[k].y - pts[0].y;
+    float bx = pts[k + 1].x - pts[0].x, by = pts[k + 1].y - pts[0].y;
+    area += ax * by - ay * bx;
+  }
+  return fabsf(area) / 2.0f;
+}
+
+float orc_iou_bev(const float *a, const float *b) { /* :214-221 */
+  float sa = a[3] * a[4], sb = b[3] * b[4], so = orc_box_overlap(a, b);
+  return so / fmaxf(sa + sb - so, 1e-8f);
+}
+
+static float orc_iou_normal(const float *a, const float *b) { /* iou3d_nms_kernel.cu:309-320 */
+  float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+  float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+  float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f), inter = w * h;
+  return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, 1e-8f);
+}
+
+/* mode 0: overlap area, 1: rotated IoU (boxes_overlap_bev_gpu / boxes_iou_bev_gpu, iou3d_nms.cpp:38-85) */
+void orc_boxes_pairwise(const float *a, int na, const float *b, int nb, int mode, float *out) {
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j)
+      out[(size_t)i * nb + j] = mode ? orc_iou_bev(a + i * 7, b + j * 7) : orc_box_overlap(a + i * 7, b + j * 7);
+}
+
+/* nms_gpu / nms_normal_gpu (iou3d_nms.cpp:88-139,142-188 + nms_kernel iou3d_nms_kernel.cu:262-306): boxes are
+ * already sorted by descending score; box i is kept unless an earlier kept box j < i has IoU(j, i) > thresh
+ * (the bit matrix is evaluated as iou(row, col) with col > row).  Returns the number kept; keep[] = indices. */
+int orc_nms_bev(const float *boxes, int n, float thresh, int rotated, int64_t *keep, float margin,
+                int *n_close) {
+  unsigned char *removed = (unsigned char *)calloc((size_t)n > 0 ? n : 1, 1);
+  int nk = 0, close = 0;
+  for (int i = 0; i < n; ++i) {
+    if (removed[i]) continue;
+    keep[nk++] = i;
+    for (int j = i + 1; j < n; ++j) {
+      if (rotated == 2) { /* circle NMS, CP/det3d/core/utils/circle_nms_jit.py:4-27: squared centre distance <= thresh */
+        float dx = boxes[i * 7] - boxes[j * 7], dy = boxes[i * 7 + 1] - boxes[j * 7 + 1];
+        if (dx * dx + dy * dy <= thresh) removed[j] = 1;
+        continue;
+      }
+      float v = rotated ? orc_iou_bev(boxes + i * 7, boxes + j * 7) : orc_iou_normal(boxes + i * 7, boxes + j * 7);
+      if (fabsf(v - thresh) < margin) close++;     /* decisions a last-ulp difference of cos/sin/atan2 could flip */
+      if (v > thresh) removed[j] = 1;
+    }
+  }
+  free(removed);
+  if (n_close) *n_close = close;
+  return nk;
+}

@@ -238,3 +238,46 @@ def gather_points(features, idx):
     """CP/det3d/ops/gather_points/src/gather_points_cuda.cu:8-24: out[b,c,p] = feat[b,c,idx[b,p]]."""
     B = features.shape[0]
     return np.stack([features[b][:, idx[b]] for b in range(B)], 0)
+
+
+# --------------------------------------------------------------------- rotated BEV IoU / NMS (detection tail)
+def boxes_pairwise_bev(boxes_a, boxes_b, mode="iou"):
+    """CP/det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:125-252: [N,7] x [M,7] -> overlap area ('overlap') or rotated IoU."""
+    a = np.ascontiguousarray(boxes_a, np.float32)
+    b = np.ascontiguousarray(boxes_b, np.float32)
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    lib().orc_boxes_pairwise(_p(a, _f32), a.shape[0], _p(b, _f32), b.shape[0], 1 if mode == "iou" else 0, _p(out, _f32))
+    return out
+
+
+def nms_bev(boxes_sorted, thresh, rotated=True, margin=0.0):
+    """iou3d_nms.cpp:88-139 (nms_gpu) / :142-188 (nms_normal_gpu) on boxes already sorted by descending score.
+    Returns (keep indices int64, number of evaluated IoUs within `margin` of the threshold)."""
+    b = np.ascontiguousarray(boxes_sorted, np.float32)
+    keep = np.zeros((max(b.shape[0], 1),), np.int64)
+    close = ctypes.c_int(0)
+    f = lib().orc_nms_bev
+    f.argtypes = [ctypes.POINTER(_f32), ctypes.c_int, _f32, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), _f32,
+                  ctypes.POINTER(ctypes.c_int)]
+    f.restype = ctypes.c_int
+    mode = 2 if rotated == "circle" else int(bool(rotated))
+    n = f(_p(b, _f32), b.shape[0], float(thresh), mode, _p(keep, ctypes.c_int64), float(margin),
+          ctypes.byref(close))
+    return keep[:n].copy(), int(close.value)
+
+
+def rotate_nms_pcdet(boxes, scores, thresh, pre_maxsize=None, post_max_size=None, margin=0.0):
+    """CP/det3d/core/bbox/box_torch_ops.py:248-279: column swap + heading flip into pcdet's frame, stable sort by
+    descending score (ties: lower index first -- the reference's torch sort leaves ties unspecified), rotated NMS."""
+    boxes = np.asarray(boxes, np.float32)[:, [0, 1, 2, 4, 3, 5, -1]].copy()
+    boxes[:, -1] = -boxes[:, -1] - np.float32(np.pi / 2)
+    order = np.argsort(-np.asarray(scores, np.float32), kind="stable")
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    if len(order) == 0:
+        return order.astype(np.int64), 0
+    keep, close = nms_bev(boxes[order], thresh, True, margin)
+    sel = order[keep]
+    if post_max_size is not None:
+        sel = sel[:post_max_size]
+    return sel.astype(np.int64), close

@@ -20,7 +20,7 @@ def available(name="sparse_conv_ext"):
 
 
 def load(name):
-    """name in {'sparse_conv_ext', 'voxel_layer'} -> the reference's pybind module."""
+    """name in {'sparse_conv_ext', 'voxel_layer', 'iou3d_nms_cuda'} -> the reference's pybind module."""
     if name in _mods:
         return _mods[name]
     import torch  # noqa: F401  (libtorch must be loaded first)
@@ -78,3 +78,15 @@ def indice_conv(features, filters, pairs, num, num_act_out, subm):
     t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a, dtype=d))
     return m.indice_conv_fp32(t(features, np.float32), t(filters, np.float32), t(pairs, np.int32),
                               t(num, np.int32), int(num_act_out), 0, int(bool(subm))).numpy()
+
+
+def boxes_iou_bev_cpu(boxes_a, boxes_b):
+    """iou3d_nms_cuda.boxes_iou_bev_cpu (CP/det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:224-252): the reference's CPU path."""
+    import numpy as np
+    import torch
+    m = load("iou3d_nms_cuda")
+    a = torch.from_numpy(np.ascontiguousarray(boxes_a, dtype=np.float32))
+    b = torch.from_numpy(np.ascontiguousarray(boxes_b, dtype=np.float32))
+    out = torch.zeros(a.shape[0], b.shape[0])
+    m.boxes_iou_bev_cpu(a, b, out)
+    return out.numpy()

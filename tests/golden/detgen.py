@@ -73,3 +73,26 @@ def clustered_voxels(name, batch, shape, n_seeds, walk):
     arr = np.array(out, np.int32)
     rs.shuffle(arr)
     return arr
+
+
+def bev_boxes(name, n, spread=10.0, special=True):
+    """[n, 7] (x, y, z, dx, dy, dz, heading) boxes clustered enough to overlap; the first rows are special cases
+    (identical, axis-aligned touching / nested, 90-degree and 45-degree rotations, a tiny and a huge box)."""
+    rs = np.random.RandomState(_seed(name))
+    b = np.zeros((n, 7), np.float32)
+    b[:, 0:2] = rs.uniform(-spread, spread, (n, 2))
+    b[:, 2] = rs.uniform(-2, 1, n)
+    b[:, 3] = rs.uniform(0.5, 5.0, n)
+    b[:, 4] = rs.uniform(0.5, 2.5, n)
+    b[:, 5] = rs.uniform(1.0, 2.0, n)
+    b[:, 6] = rs.uniform(-np.pi, np.pi, n)
+    if special and n >= 8:
+        b[0] = [0, 0, 0, 2, 2, 1, 0]
+        b[1] = [0, 0, 0, 2, 2, 1, 0]
+        b[2] = [2, 0, 0, 2, 2, 1, 0]
+        b[3] = [0.5, 0.5, 0, 2, 2, 1, np.pi / 2]
+        b[4] = [0, 0, 0, 2, 2, 1, np.pi / 4]
+        b[5] = [0.2, -0.1, 0, 0.05, 0.05, 1, 1.0]
+        b[6] = [0, 0, 0, 30, 30, 1, 0.3]
+        b[7] = [0, 0, 0, 1, 1, 1, 0]
+    return b

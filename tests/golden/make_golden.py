@@ -499,8 +499,33 @@ def gen_pointops():
         torch.Tensor.cuda, torch.cuda.is_available = _cuda, _avail
 
 
+def gen_iou3d():
+    """Rotated BEV IoU from the reference's own CPU path (oracle/_ref/iou3d_nms_cuda.so: boxes_iou_bev_cpu,
+    CP/det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:224-252) on detgen boxes, and the greedy keep list that the reference's
+    host reduction (iou3d_nms.cpp:118-133) yields on THAT matrix for score-sorted boxes."""
+    out = {}
+    for tag, n, spread in (("dense", 192, 6.0), ("sparse", 300, 25.0)):
+        a = detgen.bev_boxes("iou_a_" + tag, n, spread)
+        b = detgen.bev_boxes("iou_b_" + tag, n - 17, spread, special=False)
+        out["iou_" + tag] = ref.boxes_iou_bev_cpu(a, b)
+        self_iou = ref.boxes_iou_bev_cpu(a, a)
+        for thr in (0.2, 0.7):
+            removed = np.zeros(n, bool)
+            keep = []
+            for i in range(n):
+                if removed[i]:
+                    continue
+                keep.append(i)
+                removed[i + 1:] |= self_iou[i, i + 1:] > thr
+            out["keep_%s_%d" % (tag, int(thr * 100))] = np.asarray(keep, np.int64)
+        out["self_iou_" + tag] = self_iou
+    save("iou3d.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d"]
+    if "iou3d" in which:
+        gen_iou3d()
     if "voxelize" in which:
         gen_voxelize()
     if "rulebook" in which:

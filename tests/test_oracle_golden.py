@@ -191,3 +191,54 @@ def test_centerpoint_fusion_oracle_vs_reference_golden(golden):
     out = om.centerpoint_fusion(sd, list(zip(sets, feats)), img, calib, FUS["img_hw"], synth.NUSC_CAMS,
                                 FUS["voxel_size"], FUS["pc_range"], FUS["image_scale"], FUS["depth_thres"])
     np.testing.assert_allclose(out, g["out"], atol=1e-4)
+
+
+# ---- detection tail: rotated BEV IoU / NMS
+@pytest.mark.parametrize("tag,n,spread", [("dense", 192, 6.0), ("sparse", 300, 25.0)])
+def test_iou_bev_oracle_vs_reference_golden(golden, tag, n, spread):
+    g = golden("iou3d.npz")
+    a = detgen.bev_boxes("iou_a_" + tag, n, spread)
+    b = detgen.bev_boxes("iou_b_" + tag, n - 17, spread, special=False)
+    assert np.array_equal(orc.boxes_pairwise_bev(a, b), g["iou_" + tag])          # bit-exact with the reference CPU path
+    assert np.array_equal(orc.boxes_pairwise_bev(a, a), g["self_iou_" + tag])
+    for thr in (0.2, 0.7):
+        keep, _ = orc.nms_bev(a, thr, True)
+        assert np.array_equal(keep, g["keep_%s_%d" % (tag, int(thr * 100))])
+    ov = orc.boxes_pairwise_bev(a[:8], a[:8], mode="overlap")
+    assert ov[0, 1] == 4.0 and ov[0, 2] == 0.0 and abs(ov[0, 7] - 1.0) < 1e-6     # identical / touching / nested
+
+
+def test_nms_variants_oracle():
+    b = detgen.bev_boxes("nmsv", 120, 5.0)
+    keep_n, _ = orc.nms_bev(b, 0.3, False)
+    # axis-aligned greedy NMS restated with numpy (iou3d_nms_kernel.cu:309-320)
+    x1, x2 = b[:, 0] - b[:, 3] / 2, b[:, 0] + b[:, 3] / 2
+    y1, y2 = b[:, 1] - b[:, 4] / 2, b[:, 1] + b[:, 4] / 2
+    removed, want = np.zeros(len(b), bool), []
+    for i in range(len(b)):
+        if removed[i]:
+            continue
+        want.append(i)
+        w = np.maximum(np.minimum(x2[i], x2) - np.maximum(x1[i], x1), 0)
+        h = np.maximum(np.minimum(y2[i], y2) - np.maximum(y1[i], y1), 0)
+        iou = w * h / np.maximum(b[i, 3] * b[i, 4] + b[:, 3] * b[:, 4] - w * h, 1e-8)
+        removed[i + 1:] |= iou[i + 1:] > 0.3
+    assert keep_n.tolist() == want
+    keep_c, _ = orc.nms_bev(b, 4.0, "circle")
+    removed, want = np.zeros(len(b), bool), []
+    for i in range(len(b)):
+        if removed[i]:
+            continue
+        want.append(i)
+        d = (b[i, 0] - b[:, 0]) ** 2 + (b[i, 1] - b[:, 1]) ** 2
+        removed[i + 1:] |= d[i + 1:] <= 4.0
+    assert keep_c.tolist() == want
+    sel, _ = orc.rotate_nms_pcdet(b, detgen.rand("nmsv_s", (120,)), 0.2, pre_maxsize=100, post_max_size=10)
+    assert len(sel) == 10 and len(set(sel.tolist())) == 10
+
+
+@pytest.mark.skipif(not ref.available("iou3d_nms_cuda"), reason="oracle/_ref not built")
+def test_iou_bev_oracle_vs_ref_build_fresh():
+    a = detgen.bev_boxes("fresh_iou_a", 257, 9.0)
+    b = detgen.bev_boxes("fresh_iou_b", 131, 9.0, special=False)
+    assert np.array_equal(orc.boxes_pairwise_bev(a, b), ref.boxes_iou_bev_cpu(a, b))
