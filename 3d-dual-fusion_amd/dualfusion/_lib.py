@@ -90,6 +90,9 @@ SIGNATURES = {
     "df3d_nms_bev_workspace_bytes": (c_size_t, [c_int, c_int]),
     "df3d_nms_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
                              c_size_t, c_void_p]),
+    "df3d_centerhead_predict_workspace_bytes": (c_size_t, [c_int, c_void_p]),
+    "df3d_centerhead_predict": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_size_t, c_void_p]),
     "df3d_imgproj_packed_bytes": (c_size_t, [c_int, c_int]),
     "df3d_imgproj_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "df3d_imgproj_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -400,6 +400,71 @@ def nms_bev(boxes, thresh, mode=NMS_ROTATED, counts=None, max_keep=0):
     return (keep[0], num[0]) if single else (keep, num)
 
 
+class _HeadTask(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("hm", "reg", "height", "dim", "rot", "vel")] + \
+               [(n, ctypes.c_int) for n in ("ld_hm", "ld_reg", "ld_height", "ld_dim", "ld_rot", "ld_vel", "num_classes",
+                                            "label_base")]
+
+
+class _HeadCfg(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("out_size_factor", ctypes.c_float),
+                ("voxel_size", ctypes.c_float * 2), ("pc_range", ctypes.c_float * 2),
+                ("has_post_center_range", ctypes.c_int), ("post_center_range", ctypes.c_float * 6),
+                ("score_threshold", ctypes.c_float), ("nms_mode", ctypes.c_int), ("nms_threshold", ctypes.c_float),
+                ("pre_max", ctypes.c_int), ("post_max", ctypes.c_int)]
+
+
+def centerhead_predict(tasks, batch, H, W, out_size_factor, voxel_size, pc_range, post_center_range, score_threshold,
+                       nms_mode, nms_threshold, pre_max, post_max):
+    """tasks: list of dicts {'hm','reg','height','dim','rot'[,'vel']: 2-D fp32 views [B*H*W, C] (any row stride, unit
+    column stride), 'label_base': int}.  Returns (boxes [S, post_max, 9|7], scores [S, post_max], labels [S, post_max]
+    int32, counts [S] int32) with S = len(tasks) * batch, segment = task * batch + sample; everything stays on device."""
+    lib = _lib.load()
+    n = len(tasks)
+    arr = (_HeadTask * n)()
+    dev = tasks[0]["hm"].device
+    has_vel = "vel" in tasks[0] and tasks[0]["vel"] is not None
+    for i, t in enumerate(tasks):
+        for k in ("hm", "reg", "height", "dim", "rot", "vel"):
+            v = t.get(k)
+            if v is None:
+                setattr(arr[i], k, None)
+                setattr(arr[i], "ld_" + k, 0)
+                continue
+            if v.dtype != torch.float32 or not v.is_cuda or v.dim() != 2 or (v.shape[1] > 1 and v.stride(1) != 1) or v.shape[0] != batch * H * W:
+                raise ValueError("head map '%s' must be a CUDA fp32 [B*H*W, C] view with unit column stride" % k)
+            setattr(arr[i], k, v.data_ptr())
+            setattr(arr[i], "ld_" + k, int(v.stride(0)))
+        arr[i].num_classes = int(t["hm"].shape[1])
+        arr[i].label_base = int(t.get("label_base", 0))
+    cfg = _HeadCfg()
+    cfg.batch, cfg.H, cfg.W = int(batch), int(H), int(W)
+    cfg.out_size_factor = float(out_size_factor)
+    cfg.voxel_size[0], cfg.voxel_size[1] = float(voxel_size[0]), float(voxel_size[1])
+    cfg.pc_range[0], cfg.pc_range[1] = float(pc_range[0]), float(pc_range[1])
+    cfg.has_post_center_range = int(post_center_range is not None and len(post_center_range) == 6)
+    if cfg.has_post_center_range:
+        for e in range(6):
+            cfg.post_center_range[e] = float(post_center_range[e])
+    cfg.score_threshold = float(score_threshold)
+    cfg.nms_mode, cfg.nms_threshold = int(nms_mode), float(nms_threshold)
+    cfg.pre_max, cfg.post_max = int(pre_max), int(post_max)
+    S = n * int(batch)
+    bd = 9 if has_vel else 7
+    boxes = torch.empty((S, cfg.post_max, bd), dtype=torch.float32, device=dev)
+    scores = torch.empty((S, cfg.post_max), dtype=torch.float32, device=dev)
+    labels = torch.empty((S, cfg.post_max), dtype=torch.int32, device=dev)
+    counts = torch.empty((S,), dtype=torch.int32, device=dev)
+    nbytes = lib.df3d_centerhead_predict_workspace_bytes(n, ctypes.byref(cfg))
+    if nbytes == 0:
+        raise ValueError("df3d_centerhead_predict: unsupported configuration")
+    ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=dev)
+    rc = lib.df3d_centerhead_predict(ctypes.byref(arr), n, ctypes.byref(cfg), _ptr(boxes), _ptr(scores), _ptr(labels),
+                                     _ptr(counts), _ptr(ws), int(nbytes), _stream())
+    _lib.check(rc, "df3d_centerhead_predict")
+    return boxes, scores, labels, counts
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
     lib = _lib.load()
     _chk(value, torch.float32, "value")

@@ -72,6 +72,7 @@ READERS = Registry("reader")
 BACKBONES = Registry("backbone")
 FUSION = Registry("fusion")
 NECKS = Registry("neck")
+HEADS = Registry("head")
 MIDDLE_ENCODERS = Registry("middle_encoder")
 VOXEL_ENCODERS = Registry("voxel_encoder")
 FUSION_LAYERS = Registry("fusion_layer")
@@ -110,7 +111,8 @@ def late_register():
         pass
     try:
         from det3d.models import registry as d3
-        for src, dst in ((READERS, d3.READERS), (BACKBONES, d3.BACKBONES), (FUSION, d3.FUSION), (NECKS, d3.NECKS)):
+        for src, dst in ((READERS, d3.READERS), (BACKBONES, d3.BACKBONES), (FUSION, d3.FUSION), (NECKS, d3.NECKS),
+                         (HEADS, d3.HEADS)):
             for k, v in src.module_dict.items():
                 dst._module_dict[k] = v
         done.append("det3d")

@@ -207,6 +207,38 @@ size_t df3d_nms_bev_workspace_bytes(int lists, int cap);
 int df3d_nms_bev(const float *boxes, const int32_t *counts, int lists, int cap, float thresh, int mode, int max_keep,
                  int32_t *keep, int32_t *num_keep, void *workspace, size_t workspace_bytes, void *stream);
 
+/* CenterHead.predict + post_processing (CP/det3d/models/bbox_heads/center_head.py:302-501) for all tasks and samples in
+ * one call, no host round trip: score = max_c sigmoid(hm), box = [(x + reg_x) * out_size_factor * voxel_size_x +
+ * pc_range_x, ..y.., height, exp(dim) x3, vel x2, atan2(rot_0, rot_1)], mask = score > score_threshold and the centre
+ * inside post_center_range (inclusive); candidates sorted by descending score (ties: lower pixel index), the first
+ * pre_max go through rotate_nms_pcdet (box_torch_ops.py:248-279; nms_mode as for df3d_nms_bev, the circle variant
+ * takes nms_threshold = min_radius), the first post_max kept boxes are returned.
+ *   Head maps are channels-last rows [(b, y, x)][channels] with row strides ld_* in floats (the layout the row
+ *   kernels of the neck / head produce; NCHW maps need the reference's own permute(0, 2, 3, 1) first).
+ *   A segment is (task t, sample b) -> index t * batch + b.  Outputs: out_boxes [segments][post_max][9 or 7 without
+ *   vel], out_scores / out_labels (label + label_base; -1 = empty slot) [segments][post_max], out_counts [segments].
+ *   Limits: <= DF3D_MAX_HEAD_TASKS tasks, tasks * batch <= 255, H*W < 2^24, pre_max <= 4096. */
+#define DF3D_MAX_HEAD_TASKS 8
+typedef struct df3d_head_task {
+  const float *hm, *reg, *height, *dim, *rot, *vel; /* vel NULL = 7-value boxes */
+  int ld_hm, ld_reg, ld_height, ld_dim, ld_rot, ld_vel;
+  int num_classes, label_base;
+} df3d_head_task;
+typedef struct df3d_head_decode_cfg {
+  int batch, H, W;
+  float out_size_factor, voxel_size[2], pc_range[2];
+  int has_post_center_range;
+  float post_center_range[6];
+  float score_threshold;
+  int nms_mode;
+  float nms_threshold;
+  int pre_max, post_max;
+} df3d_head_decode_cfg;
+size_t df3d_centerhead_predict_workspace_bytes(int ntasks, const df3d_head_decode_cfg *cfg);
+int df3d_centerhead_predict(const df3d_head_task *tasks, int ntasks, const df3d_head_decode_cfg *cfg, float *out_boxes,
+                            float *out_scores, int32_t *out_labels, int32_t *out_counts, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Multi-scale deformable attention, forward.  Replaces
  * MultiScaleDeformableAttention.ms_deform_attn_forward (CP/det3d/models/model_utils/ops/src/

@@ -281,3 +281,72 @@ def rotate_nms_pcdet(boxes, scores, thresh, pre_maxsize=None, post_max_size=None
     if post_max_size is not None:
         sel = sel[:post_max_size]
     return sel.astype(np.int64), close
+
+
+def centerhead_predict(preds_dicts, test_cfg, num_classes, margin_out=None):
+    """CenterHead.predict + post_processing (CP/det3d/models/bbox_heads/center_head.py:302-501, no double flip,
+    rotate NMS or circular NMS) restated with numpy float32 arithmetic in the reference's evaluation order.
+    preds_dicts: per task {'hm','reg','height','dim','rot'[,'vel']: [B, C, H, W] float32}.
+    test_cfg keys: post_center_limit_range, score_threshold, pc_range, out_size_factor, voxel_size,
+    nms{nms_pre_max_size, nms_post_max_size, nms_iou_threshold} [, circular_nms, min_radius].
+    Returns per sample {'box3d_lidar','scores','label_preds'}; margin_out (dict) collects how close the decisive
+    comparisons came to flipping ('score_gap', 'thr_gap', 'range_gap', 'iou_close')."""
+    f32 = np.float32
+    rng = np.asarray(test_cfg["post_center_limit_range"], f32)
+    stats = dict(score_gap=np.inf, thr_gap=np.inf, range_gap=np.inf, iou_close=0)
+    rets = []
+    for task_id, pd in enumerate(preds_dicts):
+        pd = {k: np.ascontiguousarray(np.transpose(np.asarray(v, f32), (0, 2, 3, 1))) for k, v in pd.items()}
+        B, H, W, ncls = pd["hm"].shape
+        hm = (f32(1) / (f32(1) + np.exp(-pd["hm"]))).astype(f32)
+        dim = np.exp(pd["dim"]).astype(f32)
+        rot = np.arctan2(pd["rot"][..., 0:1], pd["rot"][..., 1:2]).astype(f32)
+        ys, xs = np.meshgrid(np.arange(H, dtype=f32), np.arange(W, dtype=f32), indexing="ij")
+        xs = xs.reshape(1, -1, 1) + pd["reg"].reshape(B, H * W, 2)[:, :, 0:1]
+        ys = ys.reshape(1, -1, 1) + pd["reg"].reshape(B, H * W, 2)[:, :, 1:2]
+        xs = xs * f32(test_cfg["out_size_factor"]) * f32(test_cfg["voxel_size"][0]) + f32(test_cfg["pc_range"][0])
+        ys = ys * f32(test_cfg["out_size_factor"]) * f32(test_cfg["voxel_size"][1]) + f32(test_cfg["pc_range"][1])
+        parts = [xs, ys, pd["height"].reshape(B, H * W, 1), dim.reshape(B, H * W, 3)]
+        if "vel" in pd:
+            parts.append(pd["vel"].reshape(B, H * W, 2))
+        parts.append(rot.reshape(B, H * W, 1))
+        boxes_all = np.concatenate(parts, axis=2).astype(f32)
+        hm = hm.reshape(B, H * W, ncls)
+        per_sample = []
+        for i in range(B):
+            box_preds, hm_preds = boxes_all[i], hm[i]
+            labels = np.argmax(hm_preds, axis=-1)                  # first maximum, like torch.max
+            scores = hm_preds[np.arange(len(labels)), labels]
+            smask = scores > f32(test_cfg["score_threshold"])
+            dmask = (box_preds[:, :3] >= rng[:3]).all(1) & (box_preds[:, :3] <= rng[3:]).all(1)
+            stats["thr_gap"] = min(stats["thr_gap"], float(np.abs(scores - f32(test_cfg["score_threshold"])).min()))
+            stats["range_gap"] = min(stats["range_gap"], float(np.minimum(np.abs(box_preds[:, :3] - rng[:3]),
+                                                                         np.abs(box_preds[:, :3] - rng[3:])).min()))
+            mask = smask & dmask
+            box_preds, scores, labels = box_preds[mask], scores[mask], labels[mask]
+            if len(scores) > 1:
+                stats["score_gap"] = min(stats["score_gap"], float(np.diff(np.sort(scores)).min()))
+            nms = test_cfg["nms"]
+            if test_cfg.get("circular_nms", False):
+                order = np.argsort(-scores, kind="stable")
+                b7 = np.zeros((len(order), 7), f32)
+                b7[:, :2] = box_preds[order][:, :2]
+                keep, _ = nms_bev(b7, test_cfg["min_radius"][task_id], "circle")
+                sel = order[keep][:nms["nms_post_max_size"]]
+            else:
+                sel, close = rotate_nms_pcdet(box_preds[:, [0, 1, 2, 3, 4, 5, -1]], scores, nms["nms_iou_threshold"],
+                                              nms["nms_pre_max_size"], nms["nms_post_max_size"], margin=1e-4)
+                stats["iou_close"] += close
+            per_sample.append(dict(box3d_lidar=box_preds[sel], scores=scores[sel], label_preds=labels[sel].astype(np.int64)))
+        rets.append(per_sample)
+    out = []
+    for i in range(len(rets[0])):
+        flag, lab = 0, []
+        for j, nc in enumerate(num_classes):
+            lab.append(rets[j][i]["label_preds"] + flag)
+            flag += nc
+        out.append(dict(box3d_lidar=np.concatenate([r[i]["box3d_lidar"] for r in rets]),
+                        scores=np.concatenate([r[i]["scores"] for r in rets]), label_preds=np.concatenate(lab)))
+    if margin_out is not None:
+        margin_out.update(stats)
+    return out

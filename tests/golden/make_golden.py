@@ -499,6 +499,124 @@ def gen_pointops():
         torch.Tensor.cuda, torch.cuda.is_available = _cuda, _avail
 
 
+HEAD_TASKS = [dict(num_class=1, class_names=["car"]), dict(num_class=2, class_names=["truck", "construction_vehicle"]),
+              dict(num_class=2, class_names=["bus", "trailer"]), dict(num_class=1, class_names=["barrier"]),
+              dict(num_class=2, class_names=["motorcycle", "bicycle"]),
+              dict(num_class=2, class_names=["pedestrian", "traffic_cone"])]
+HEAD_COMMON = {'reg': (2, 2), 'height': (1, 2), 'dim': (3, 2), 'rot': (2, 2), 'vel': (2, 2)}
+HEAD_SHAPE = (2, 512, 12, 14)
+# nuScenes test_cfg of the 3D-DF config (nusc_centerpoint_voxelnet_0075voxel_fix_bn_z_multimodal_pfat_hybrid7_ifat.py:
+# 145-159) with a smaller pre_max (so that the 168-pixel test map exercises the truncation) and a z range that masks
+HEAD_TEST_CFG = dict(post_center_limit_range=[-61.2, -61.2, -0.6, 61.2, 61.2, 0.7], max_per_img=500,
+                     nms=dict(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=60,
+                              nms_post_max_size=83, nms_iou_threshold=0.2),
+                     score_threshold=0.1, pc_range=[-54, -54], out_size_factor=8, voxel_size=[0.075, 0.075])
+
+
+def head_bias_shift(sd):
+    """Liven the detgen weights up: larger final convolutions (spread-out scores, heights, sizes) and lower heat-map
+    logits, so that the score threshold, the z range and the NMS all have something to decide."""
+    for k in sd:
+        if k.endswith(".3.weight"):
+            sd[k] = sd[k] * (12.0 if ".hm." in k else 6.0)
+        if ".hm.3.bias" in k:
+            sd[k] = sd[k] - 1.5
+    return sd
+
+
+def import_reference_centerhead():
+    """CP/det3d/models/bbox_heads/center_head.py with import stubs (registry, Sequential and box_torch_ops are the
+    reference's own files; numba.jit -> identity; kaiming_init -> no-op, the weights are overwritten)."""
+    import importlib.util
+    R = "/root/reference/CenterPoint/det3d"
+
+    def load_file(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+    for pkg, path in [("det3d", R), ("det3d.models", R + "/models"), ("det3d.models.bbox_heads", R + "/models/bbox_heads"),
+                      ("det3d.models.losses", R + "/models/losses"), ("det3d.models.utils", R + "/models/utils"),
+                      ("det3d.core", R + "/core"), ("det3d.core.utils", R + "/core/utils"),
+                      ("det3d.core.bbox", R + "/core/bbox"), ("det3d.utils", R + "/utils"),
+                      ("det3d.torchie", R + "/torchie"), ("det3d.ops", R + "/ops")]:
+        _stub(pkg).__path__ = [path]
+    _stub("numba", jit=lambda *a, **k: (lambda f: f))
+    reg = load_file("det3d.utils.registry", R + "/utils/registry.py")
+    sys.modules["det3d.utils"].Registry = reg.Registry
+    sys.modules["det3d.utils"].build_from_cfg = reg.build_from_cfg
+    _stub("det3d.torchie.cnn", kaiming_init=lambda m, **k: None)
+    misc = load_file("det3d.models.utils.misc", R + "/models/utils/misc.py")
+    sys.modules["det3d.models.utils"].Sequential = misc.Sequential
+    bto = load_file("det3d.core.bbox.box_torch_ops", R + "/core/bbox/box_torch_ops.py")
+    sys.modules["det3d.core"].box_torch_ops = bto
+    ch = importlib.import_module("det3d.models.bbox_heads.center_head")
+
+    class _Nms:                                   # the CUDA extension's entry point on the reference's CPU IoU
+        @staticmethod
+        def nms_gpu(boxes, keep, thresh):
+            b = boxes.numpy()
+            iou = ref.boxes_iou_bev_cpu(b, b)
+            removed = np.zeros(len(b), bool)
+            n = 0
+            for i in range(len(b)):               # iou3d_nms.cpp:118-133
+                if removed[i]:
+                    continue
+                keep[n] = i
+                n += 1
+                removed[i + 1:] |= iou[i, i + 1:] > thresh
+            return n
+    bto.iou3d_nms_cuda = _Nms
+    return ch, bto
+
+
+def gen_centerhead():
+    """Reference CenterHead forward + predict (center_head.py:237-247,302-501) on a small BEV map."""
+    from oracle import oracle as orc
+    ch, _ = import_reference_centerhead()
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        head = ch.CenterHead(in_channels=512, tasks=HEAD_TASKS, dataset='nuscenes', weight=0.25,
+                             code_weights=[1.0] * 10, common_heads=dict(HEAD_COMMON), share_conv_channel=64,
+                             dcn_head=False)
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    sd = head_bias_shift(detgen.det_state_dict(shapes))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    head.eval()
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for k in range(400):
+            x = torch.from_numpy(detgen.randn("head_x_%d" % k, HEAD_SHAPE))
+            with torch.no_grad():
+                preds = head(x)
+            stats = {}
+            pn = [{kk: vv.numpy().copy() for kk, vv in p.items()} for p in preds]
+            orc.centerhead_predict(pn, HEAD_TEST_CFG, [1, 2, 2, 1, 2, 2], margin_out=stats)
+            if stats["score_gap"] > 2e-6 and stats["thr_gap"] > 1e-5 and stats["range_gap"] > 1e-4 and stats["iou_close"] == 0:
+                break
+        else:
+            raise RuntimeError("no tie-free head input found")
+        with torch.no_grad():
+            dets = head.predict({}, [{kk: vv.clone() for kk, vv in p.items()} for p in preds],
+                                Cfg(HEAD_TEST_CFG, nms=Cfg(HEAD_TEST_CFG["nms"])))
+    finally:
+        torch.Tensor.cuda = _cuda
+    out = dict(seed=np.int64(k), keys=np.array(sorted(shapes)), margins=np.array([stats["score_gap"], stats["thr_gap"],
+                                                                                 stats["range_gap"]]))
+    for t, p in enumerate(pn):
+        for name, v in p.items():
+            out["chk_%d_%s" % (t, name)] = np.array([v.sum(dtype=np.float64), np.abs(v).sum(dtype=np.float64)])
+    for i, d in enumerate(dets):
+        out["boxes_%d" % i] = d["box3d_lidar"].numpy()
+        out["scores_%d" % i] = d["scores"].numpy()
+        out["labels_%d" % i] = d["label_preds"].numpy()
+    print("seed", k, stats, [len(d["scores"]) for d in dets])
+    save("centerhead.npz", **out)
+
+
 def gen_iou3d():
     """Rotated BEV IoU from the reference's own CPU path (oracle/_ref/iou3d_nms_cuda.so: boxes_iou_bev_cpu,
     CP/det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:224-252) on detgen boxes, and the greedy keep list that the reference's
@@ -523,9 +641,11 @@ def gen_iou3d():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead"]
     if "iou3d" in which:
         gen_iou3d()
+    if "centerhead" in which:
+        gen_centerhead()
     if "voxelize" in which:
         gen_voxelize()
     if "rulebook" in which:

@@ -242,3 +242,41 @@ def test_iou_bev_oracle_vs_ref_build_fresh():
     a = detgen.bev_boxes("fresh_iou_a", 257, 9.0)
     b = detgen.bev_boxes("fresh_iou_b", 131, 9.0, special=False)
     assert np.array_equal(orc.boxes_pairwise_bev(a, b), ref.boxes_iou_bev_cpu(a, b))
+
+
+def _mirror_head():
+    """dualfusion.heads.CenterHead (plain torch modules on the CPU) with the golden's deterministic weights."""
+    import torch
+    from dualfusion.heads import CenterHead
+    from make_golden import HEAD_COMMON, HEAD_TASKS, head_bias_shift
+    head = CenterHead(in_channels=512, tasks=HEAD_TASKS, dataset='nuscenes', weight=0.25, code_weights=[1.0] * 10,
+                      common_heads=dict(HEAD_COMMON), share_conv_channel=64, dcn_head=False)
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    sd = head_bias_shift(detgen.det_state_dict(shapes))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return head.eval(), shapes
+
+
+def test_centerhead_oracle_vs_reference_golden(golden):
+    """Reference CenterHead.forward + predict (imported from /root/reference when the fixture was made): the mirror
+    module has the same parameter names and the same forward values; the oracle's predict restatement returns the
+    reference's detections (same boxes in the same order)."""
+    import torch
+    from make_golden import HEAD_SHAPE, HEAD_TEST_CFG
+    g = golden("centerhead.npz")
+    head, shapes = _mirror_head()
+    assert sorted(shapes) == g["keys"].tolist()
+    x = torch.from_numpy(detgen.randn("head_x_%d" % int(g["seed"]), HEAD_SHAPE))
+    with torch.no_grad():
+        preds = head(x)
+    pn = [{k: v.numpy() for k, v in p.items()} for p in preds]
+    for t, p in enumerate(pn):
+        for name, v in p.items():
+            chk = np.array([v.sum(dtype=np.float64), np.abs(v).sum(dtype=np.float64)])
+            np.testing.assert_allclose(chk, g["chk_%d_%s" % (t, name)], rtol=1e-6, atol=1e-6)
+    dets = orc.centerhead_predict(pn, HEAD_TEST_CFG, [1, 2, 2, 1, 2, 2])
+    for i, d in enumerate(dets):
+        assert np.array_equal(d["label_preds"], g["labels_%d" % i])
+        np.testing.assert_allclose(d["scores"], g["scores_%d" % i], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(d["box3d_lidar"], g["boxes_%d" % i], rtol=1e-5, atol=2e-6)
+    assert len(dets[0]["scores"]) > 100 and len(set(dets[0]["label_preds"].tolist())) >= 8
