@@ -117,6 +117,12 @@ struct SplitConvArgs {
   u32x4 *out_split;      // optional split rows of the output
   int n_in, n_out, K, relu;
   int dbg;               // tuning experiments (DF3D_OS_DBG): 1 = no gathers, 2 = no W staging, 4 = no MFMAs
+  // grouped / strided rows (output-stationary kernel only; blockIdx.y = column block or group):
+  int ldi;               // u32x4 per split input row
+  int in_goff;           // u32x4 added to the input row per blockIdx.y (0: every block reads the same channels)
+  int ldo;               // floats per output row
+  int gy;                // gridDim.y
+  const int32_t *cols;   // optional [gy][2] = (first output column, valid columns) of a block: compact fp32 stores
 };
 
 #define DF3D_MFMA_BF16(A, B, C) \
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void spconv_split_kernel(SplitConvArgs a, i
 
 // rows without a neighbour gather this all-zero split row (keeps the gathers branch-free, so that the
 // compiler can count its vmcnt waits instead of draining the whole load queue at every step)
-__device__ u32x4 g_zero_row[64];
+__device__ u32x4 g_zero_row[128];          // up to 512 input channels
 
 // ---------------------------------------------------------------------------------------------------------
 // Output-stationary variant: a wave owns 16*RT output rows and all COUT columns, accumulators in registers,
@@ -499,7 +505,8 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       int idx = nbrL[k][wave * WROWS + rt * 16 + n];
-      const u32x4 *p = (live && idx >= 0 && !(a.dbg & 1)) ? a.feat + (size_t)idx * RQ : g_zero_row;
+      const u32x4 *p = (live && idx >= 0 && !(a.dbg & 1)) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff
+                                                          : g_zero_row;
       p += (kb * 4 + g) * 2;
 #pragma unroll
       for (int j = 0; j < KPS; ++j) {
@@ -567,19 +574,30 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   //      consecutive columns n*CT .. n*CT+CT-1 of its rows (packed-weight layout 1): 16-byte stores ----
   static_assert(CT == 2 || CT == 4 || CT == 8, "COUT must be 32, 64, 128 or 256");
   if constexpr (CT == 2) {
-    // COUT = 32: lane n owns columns 2n, 2n+1 (8-byte stores; four lanes share a split block)
-    const int col = n * 2;
+    // 32 columns per block: lane n owns columns 2n, 2n+1 (8-byte stores; four lanes share a split block)
+    const int col = col0 + n * 2;
     const float2 bi = a.bias ? *(const float2 *)(a.bias + col) : make_float2(0.f, 0.f);
     const float2 sc = a.scale ? *(const float2 *)(a.scale + col) : make_float2(1.f, 1.f);
     const float2 sh = a.shift ? *(const float2 *)(a.shift + col) : make_float2(0.f, 0.f);
+    const int oc0 = a.cols ? a.cols[2 * blockIdx.y] : 0, ocnt = a.cols ? a.cols[2 * blockIdx.y + 1] : 0;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
         if (row >= a.n_out) continue;
-        const size_t o = (size_t)row * COUT + col;
         float2 v = make_float2((acc[rt][0][r] + bi.x) * sc.x + sh.x, (acc[rt][1][r] + bi.y) * sc.y + sh.y);
+        if (a.cols) {                        // compact layout: only the block's valid columns exist in the output
+          if (a.relu) {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+          }
+          float *dst = a.out + (size_t)row * a.ldo + oc0 + n * 2;
+          if (n * 2 < ocnt) dst[0] = v.x;
+          if (n * 2 + 1 < ocnt) dst[1] = v.y;
+          continue;
+        }
+        const size_t o = (size_t)row * a.ldo + col;
         if (a.residual) {
           const float2 rr = *(const float2 *)(a.residual + o);
           v.x += rr.x;
@@ -589,7 +607,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
           v.x = fmaxf(v.x, 0.f);
           v.y = fmaxf(v.y, 0.f);
         }
-        *(float2 *)(a.out + o) = v;
+        if (a.out) *(float2 *)(a.out + o) = v;
         if (a.out_split) {
           unsigned hp, lp;
           split_pair(v.x, v.y, hp, lp);
@@ -615,7 +633,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
       if (row >= a.n_out) continue;
-      const size_t o = (size_t)row * COUT + col0 + n * CT;
+      const size_t o = (size_t)row * a.ldo + col0 + n * CT;
       unsigned h[CT / 2], l[CT / 2];         // packed pairs
 #pragma unroll
       for (int q = 0; q < CT / 4; ++q) {
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
           v[2] = fmaxf(v[2], 0.f);
           v[3] = fmaxf(v[3], 0.f);
         }
-        *(f32x4 *)(a.out + o + q * 4) = v;
+        if (a.out) *(f32x4 *)(a.out + o + q * 4) = v;
         if (a.out_split) {
           split_pair(v[0], v[1], h[q * 2], l[q * 2]);
           split_pair(v[2], v[3], h[q * 2 + 1], l[q * 2 + 1]);
@@ -667,7 +685,7 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
   constexpr int KMAX = CIN >= 64 ? 2 : 1;
   if (kps > KMAX) kps = KMAX;
 #define DF3D_OS_LAUNCH(RT, NW, KPS)                                                                      \
-  hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, RT, NW, KPS>), dim3(cdiv(a.n_out, 16 * RT * NW)), \
+  hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, RT, NW, KPS>), dim3(cdiv(a.n_out, 16 * RT * NW), a.gy), \
                      dim3(NW * 64), 0, stream, a)
   if (kps == 2) {
     if (rt == 2) DF3D_OS_LAUNCH(2, 4, KMAX);
@@ -687,7 +705,7 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
 // 256 CUs; DF3D_OS_WIDE="RT,NW" overrides (tuning aid).
 template <int CIN, int COUT>
 static int launch_os_split_wide(const SplitConvArgs &a, hipStream_t stream) {
-  constexpr int CS = COUT > 128 ? 2 : 1;
+  const int CS = a.gy;
   int rt = 1, nw = (long long)a.n_out * CS >= 128 * 384 ? 8 : (long long)a.n_out * CS >= 64 * 192 ? 4 : 2;
   static const char *cfg = getenv("DF3D_OS_WIDE");
   if (cfg && cfg[0] && cfg[1] == ',') {
@@ -760,9 +778,32 @@ static bool split_shape_wide(int cin, int cout) {      // served by the output-s
   return (cin == 256 && (cout == 128 || cout == 256)) || (cin == 128 && cout == 256);
 }
 
+static bool split_shape_head(int cin, int cout) {      // detection head: shared conv 512 -> 64, final convs 64 -> <= 32
+  return (cin == 512 && cout == 64) || (cin == 64 && cout == 32);
+}
+
+// output-stationary launch of any served (cin, cout per column block) pair
+static int launch_os_any(int cin, int cout, const SplitConvArgs &a, hipStream_t stream);
+
 static bool split_shape_ok(int cin, int cout) {
   return (cout == 128 && (cin == 128 || cin == 64)) || (cout == 64 && (cin == 64 || cin == 32)) ||
-         ((split_shape_wide(cin, cout) || (cout == 32 && cin == 32)) && split_layout(cin, cout) == 1);
+         ((split_shape_wide(cin, cout) || split_shape_head(cin, cout) || (cout == 32 && cin == 32)) &&
+          split_layout(cin, cout) == 1);
+}
+
+static int launch_os_any(int cin, int cout, const SplitConvArgs &a, hipStream_t stream) {
+  if (cin == 256 && cout == 256) return launch_os_split_wide<256, 256>(a, stream);
+  if (cin == 256 && cout == 128) return launch_os_split_wide<256, 128>(a, stream);
+  if (cin == 128 && cout == 256) return launch_os_split_wide<128, 256>(a, stream);
+  if (cin == 512 && cout == 64) return launch_os_split_wide<512, 64>(a, stream);
+  if (cin == 128 && cout == 128) return launch_os_split<128, 128>(a, stream);
+  if (cin == 64 && cout == 128) return launch_os_split<64, 128>(a, stream);
+  if (cin == 64 && cout == 64) return launch_os_split<64, 64>(a, stream);
+  if (cin == 32 && cout == 64) return launch_os_split<32, 64>(a, stream);
+  if (cin == 64 && cout == 32) return launch_os_split<64, 32>(a, stream);
+  if (cin == 32 && cout == 32) return launch_os_split<32, 32>(a, stream);
+  set_error("no output-stationary split kernel for cin=%d cout=%d", cin, cout);
+  return DF3D_EINVAL;
 }
 
 }  // namespace df3d
@@ -811,16 +852,12 @@ extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int 
   if (n_out == 0) return DF3D_OK;
   SplitConvArgs a = {(const u32x4 *)features_split, (const u32x4 *)packed_filters, nbr, bias, scale, shift, residual,
                      out, (u32x4 *)out_split, n_in, n_out, kvol, relu,
-                     getenv("DF3D_OS_DBG") ? atoi(getenv("DF3D_OS_DBG")) : 0};
+                     getenv("DF3D_OS_DBG") ? atoi(getenv("DF3D_OS_DBG")) : 0,
+                     cin / 4, 0, cout, cout > 128 ? cout / 128 : 1, nullptr};
   int rec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 1, stream);
   int rc;
   if (split_layout(cin, cout) == 1) {
-    if (cin == 256 && cout == 256) rc = launch_os_split_wide<256, 256>(a, stream);
-    else if (cin == 256) rc = launch_os_split_wide<256, 128>(a, stream);
-    else if (cout == 256) rc = launch_os_split_wide<128, 256>(a, stream);
-    else if (cout == 128) rc = cin == 128 ? launch_os_split<128, 128>(a, stream) : launch_os_split<64, 128>(a, stream);
-    else if (cout == 32) rc = launch_os_split<32, 32>(a, stream);
-    else rc = cin == 64 ? launch_os_split<64, 64>(a, stream) : launch_os_split<32, 64>(a, stream);
+    rc = launch_os_any(cin, cout, a, stream);
   } else if (cout == 128) {
     rc = cin == 128 ? launch_split<128, 128>(a, tile_rows, ntiles, stream)
                     : launch_split<64, 128>(a, tile_rows, ntiles, stream);
@@ -828,6 +865,40 @@ extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int 
     rc = cin == 64 ? launch_split<64, 64>(a, tile_rows, ntiles, stream)
                    : launch_split<32, 64>(a, tile_rows, ntiles, stream);
   }
+  if (rc) return rc;
+  timing_rec_end(rec, stream);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_conv_rows_split(const void *in_split, int n_in, int in_channels, int cin, int in_group_stride,
+                                    const void *packed_filters, int kvol, int cout, int groups, const int32_t *nbr,
+                                    int n_out, const float *bias, const float *scale, const float *shift, int relu,
+                                    float *out, int out_channels, const int32_t *out_cols, void *out_split,
+                                    void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(in_split && packed_filters && nbr && (out || out_split), "conv_rows_split: null argument");
+  DF3D_CHECK_ARG(kvol > 0 && kvol <= DF3D_MAX_KVOL, "conv_rows_split: kernel volume %d unsupported", kvol);
+  DF3D_CHECK_ARG(split_shape_ok(cin, cout) && split_layout(cin, cout) == 1,
+                 "conv_rows_split: cin=%d cout=%d has no output-stationary split kernel", cin, cout);
+  DF3D_CHECK_ARG(groups >= 1 && groups <= 65535, "conv_rows_split: groups");
+  DF3D_CHECK_ARG(in_channels % 8 == 0 && in_group_stride % 8 == 0 && in_group_stride >= 0 &&
+                     (long long)(groups - 1) * in_group_stride + cin <= in_channels,
+                 "conv_rows_split: input columns [g*%d, g*%d+%d) must lie inside the %d-channel rows", in_group_stride,
+                 in_group_stride, cin, in_channels);
+  const int blocks = groups * (cout > 128 ? cout / 128 : 1);
+  if (out_cols) {
+    DF3D_CHECK_ARG(cout == 32 && !out_split, "conv_rows_split: compact output columns need cout = 32 and no split output");
+  } else {
+    DF3D_CHECK_ARG(out_channels % 8 == 0 && (long long)groups * cout <= out_channels,
+                   "conv_rows_split: %d x %d output columns do not fit %d-channel rows", groups, cout, out_channels);
+  }
+  if (n_out == 0) return DF3D_OK;
+  SplitConvArgs a = {(const u32x4 *)in_split, (const u32x4 *)packed_filters, nbr, bias, scale, shift, nullptr,
+                     out, (u32x4 *)out_split, n_in, n_out, kvol, relu, 0,
+                     in_channels / 4, in_group_stride / 4, out_channels, blocks, out_cols};
+  int rec = timing_rec_begin(cin, cout * groups, kvol, n_out, nbr, 1, stream);
+  int rc = launch_os_any(cin, cout, a, stream);
   if (rc) return rc;
   timing_rec_end(rec, stream);
   DF3D_LAUNCH_CHECK();

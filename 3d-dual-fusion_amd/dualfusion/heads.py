@@ -68,9 +68,107 @@ class CenterHead(nn.Module):
             heads.update(dict(hm=(num_cls, num_hm_conv)))
             self.tasks.append(SepHead(share_conv_channel, heads, bn=True, init_bias=init_bias, final_kernel=3))
 
-    def forward(self, x, *kwargs):
+    def forward_reference(self, x):
         x = self.shared_conv(x)
         return [task(x) for task in self.tasks]
+
+    def forward(self, x, *kwargs):
+        if (self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32
+                or _ops.CONV_PRECISION != "split" or not self._row_kernels_fit(x)):
+            return self.forward_reference(x)
+        return self.forward_rows(x)
+
+    # ------------------------------------------------------------------ the three conv depths as three launches
+    def train(self, mode=True):
+        self.__dict__.pop("_row_plan", None)
+        return super(CenterHead, self).train(mode)
+
+    def _row_kernels_fit(self, x):
+        sc = self.shared_conv[0]
+        ok = sc.in_channels == 512 and sc.out_channels == 64 and sc.kernel_size == (3, 3)
+        for task in self.tasks:
+            for head in task.heads:
+                fc = getattr(task, head)
+                ok = ok and len(fc) == 4 and isinstance(fc[1], nn.BatchNorm2d) and fc[0].kernel_size == (3, 3) \
+                    and fc[0].out_channels == 64 and fc[3].out_channels <= 32
+        return ok
+
+    @staticmethod
+    def _filters(conv, pad_to=None):
+        w = conv.weight.detach().float().permute(2, 3, 1, 0).reshape(9, conv.in_channels, conv.out_channels)
+        if pad_to is not None and pad_to > conv.out_channels:
+            w = torch.cat([w, w.new_zeros(9, conv.in_channels, pad_to - conv.out_channels)], 2)
+        return w.contiguous()
+
+    @staticmethod
+    def _fold(bn):
+        scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+        return scale, bn.bias.float() - bn.running_mean.float() * scale
+
+    def _plan(self):
+        params = [p for p in self.parameters()] + [b for b in self.buffers()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        plan = self.__dict__.get("_row_plan")
+        if plan is not None and plan["key"] == key:
+            return plan
+        sc, sbn = self.shared_conv[0], self.shared_conv[1]
+        s_scale, s_shift = self._fold(sbn)
+        dev = sc.weight.device
+        mid_packed, mid_bias, mid_scale, mid_shift, fin_packed, fin_bias, cols, layout = [], [], [], [], [], [], [], []
+        c0 = 0
+        for t, task in enumerate(self.tasks):
+            for head in task.heads:
+                fc = getattr(task, head)
+                mid_packed.append(_ops.conv_pack_weights(self._filters(fc[0])))
+                mid_bias.append(fc[0].bias.detach().float())
+                a, b = self._fold(fc[1])
+                mid_scale.append(a)
+                mid_shift.append(b)
+                k = fc[3].out_channels
+                fin_packed.append(_ops.conv_pack_weights(self._filters(fc[3], 32)))
+                fin_bias.append(torch.cat([fc[3].bias.detach().float(), torch.zeros(32 - k, device=dev)]))
+                cols.append((c0, k))
+                layout.append((t, head, c0, k))
+                c0 += k
+        plan = dict(key=key, shared=_ops.conv_pack_weights(self._filters(sc)), s_bias=sc.bias.detach().float().contiguous(),
+                    s_scale=s_scale.contiguous(), s_shift=s_shift.contiguous(),
+                    mid=torch.cat(mid_packed), mid_bias=torch.cat(mid_bias).contiguous(),
+                    mid_scale=torch.cat(mid_scale).contiguous(), mid_shift=torch.cat(mid_shift).contiguous(),
+                    fin=torch.cat(fin_packed), fin_bias=torch.cat(fin_bias).contiguous(),
+                    cols=torch.tensor(cols, dtype=torch.int32, device=dev).contiguous(), layout=layout,
+                    groups=len(cols), width=(c0 + 7) // 8 * 8, nbr={})
+        self.__dict__["_row_plan"] = plan
+        return plan
+
+    @torch.no_grad()
+    def forward_rows(self, x):
+        """shared 3x3 conv (512 -> 64), the 36 first convs of all heads (64 -> 36 x 64) and their 36 final convs
+        (block-diagonal 64 -> classes) as three launches of the split-precision conv kernel over pixel rows; every
+        head map is a column slice of one [B*H*W, 72] buffer, which `predict` reads in place."""
+        from .necks import _rows_of
+        plan = self._plan()
+        B, _, H, W = x.shape
+        rows, split = _rows_of(x)
+        if split is None:
+            split = _ops.split_rows(rows.contiguous())
+        if (B, H, W) not in plan["nbr"]:
+            plan["nbr"][(B, H, W)] = _ops.conv2d_neighbors(B, H, W, 3, 3, 1, 1, False, x.device)[0]
+        nbr = plan["nbr"][(B, H, W)]
+        n = B * H * W
+        G = plan["groups"]
+        _, s1 = _ops.conv_rows_split(split, 512, 0, plan["shared"], 64, 1, nbr, n, plan["s_bias"], plan["s_scale"],
+                                     plan["s_shift"], relu=True, want_out=False, want_split=True)
+        _, s2 = _ops.conv_rows_split(s1, 64, 0, plan["mid"], 64, G, nbr, n, plan["mid_bias"], plan["mid_scale"],
+                                     plan["mid_shift"], relu=True, want_out=False, want_split=True)
+        out, _ = _ops.conv_rows_split(s2, 64, 64, plan["fin"], 32, G, nbr, n, plan["fin_bias"], None, None, relu=False,
+                                      out_channels=plan["width"], out_cols=plan["cols"])
+        rets = [dict() for _ in self.tasks]
+        for t, head, c0, k in plan["layout"]:
+            r = out[:, c0:c0 + k]
+            v = r.view(B, H, W, k).permute(0, 3, 1, 2)
+            v._df3d_rows = (r, None, v._version)
+            rets[t][head] = v
+        return rets
 
     def loss(self, example, preds_dicts, batch_dict=None, **kwargs):
         raise NotImplementedError("training rows are out of this build's scope (SURVEY.md section 8f row 4)")
@@ -80,8 +178,11 @@ class CenterHead(nn.Module):
     def _rows(v):
         """NCHW head map -> [B*H*W, C] rows (the reference's own permute(0, 2, 3, 1), center_head.py:321-323); maps that
         are already channels-last views of rows are taken in place."""
+        cached = getattr(v, "_df3d_rows", None)
+        if cached is not None and cached[2] == v._version and cached[0].dtype == torch.float32:
+            return cached[0]
         B, C, H, W = v.shape
-        return v.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        return v.float().permute(0, 2, 3, 1).reshape(B * H * W, C)
 
     @torch.no_grad()
     def predict_device(self, preds_dicts, test_cfg):
@@ -97,9 +198,9 @@ class CenterHead(nn.Module):
         B, _, H, W = preds_dicts[0]['hm'].shape
         tasks, base = [], 0
         for t, pd in enumerate(preds_dicts):
-            d = {k: self._rows(pd[k].float()) for k in ('hm', 'reg', 'height', 'dim', 'rot')}
+            d = {k: self._rows(pd[k]) for k in ('hm', 'reg', 'height', 'dim', 'rot')}
             if 'vel' in pd:
-                d['vel'] = self._rows(pd['vel'].float())
+                d['vel'] = self._rows(pd['vel'])
             d['label_base'] = base
             base += self.num_classes[t]
             tasks.append(d)

@@ -318,6 +318,36 @@ def sparse_conv_split(features_split, packed, nbr, n_out, cin, cout, bias=None, 
     return out, out_split
 
 
+def conv_rows_split(in_split, cin, in_group_stride, packed, cout, groups, nbr, n_out, bias=None, scale=None, shift=None,
+                    relu=False, out_channels=None, out_cols=None, want_out=True, want_split=False):
+    """Grouped / multi-head convolution over split rows (df3d_conv_rows_split).  in_split [n_in, 4*in_channels] uint8.
+    Returns (out fp32 [n_out, out_channels] or None, split rows of it or None)."""
+    lib = _lib.load()
+    _chk(in_split, torch.uint8, "in_split")
+    _chk(packed, torch.uint8, "packed")
+    _chk(nbr, torch.int32, "nbr")
+    n_in, in_channels = in_split.shape[0], in_split.shape[1] // 4
+    K = nbr.shape[0]
+    if packed.numel() != groups * K * cin * cout * 4:
+        raise _lib.Df3dError("packed filters do not match groups=%d K=%d cin=%d cout=%d" % (groups, K, cin, cout))
+    for t, nm in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+            if t.numel() != groups * cout:
+                raise _lib.Df3dError("%s must have groups * cout = %d entries" % (nm, groups * cout))
+    if out_cols is not None:
+        _chk(out_cols, torch.int32, "out_cols")
+    oc = int(out_channels if out_channels is not None else groups * cout)
+    dev = nbr.device
+    out = torch.empty((n_out, oc), dtype=torch.float32, device=dev) if want_out else None
+    osp = torch.empty((n_out, 4 * oc), dtype=torch.uint8, device=dev) if want_split else None
+    rc = lib.df3d_conv_rows_split(_ptr(in_split), n_in, in_channels, int(cin), int(in_group_stride), _ptr(packed), K,
+                                  int(cout), int(groups), _ptr(nbr), int(n_out), _ptr(bias), _ptr(scale), _ptr(shift),
+                                  int(bool(relu)), _ptr(out), oc, _ptr(out_cols), _ptr(osp), _stream())
+    _lib.check(rc, "df3d_conv_rows_split")
+    return out, osp
+
+
 def sparse_to_dense(features, indices, batch, shape):
     lib = _lib.load()
     _chk(features, torch.float32, "features")

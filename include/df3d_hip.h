@@ -186,6 +186,23 @@ int df3d_sparse_to_dense_rows(const float *features, const int32_t *indices, int
 int df3d_conv2d_neighbors(int batch, int H, int W, int kh, int kw, int stride, int pad, int transposed,
                           int32_t *nbr, void *stream);
 
+/* Grouped / multi-head convolution over pixel (or voxel) rows on the split-precision kernel -- the detection head's
+ * stacks (CP/det3d/models/bbox_heads/center_head.py:66-110: per task and per head Conv2d 3x3 64 -> 64 + BN + ReLU
+ * + Conv2d 3x3 64 -> classes) as ONE launch per depth instead of one cuDNN call per head.
+ *   Group g reads the input columns [g * in_group_stride, + cin) of the split rows `in_split` ([n_in][in_channels],
+ *   df3d_split_rows layout; in_group_stride = 0: every group reads the same columns), uses the g-th of `groups`
+ *   consecutive packed filters (each df3d_conv_pack_weights(kvol, cin, cout)) and writes the output columns
+ *   [g * cout, + cout) of `out` ([n_out][out_channels] f32, and of `out_split` when given).  With out_cols
+ *   ([groups][2] i32 on the device: first output column, number of valid columns <= 32; needs cout = 32) only the
+ *   valid columns are stored, anywhere in the row -- the heads' 1..3-channel outputs next to each other.
+ *   `out` may be NULL when only the split rows are wanted (an intermediate layer).
+ *   bias / scale / shift are indexed g * cout + c.  Served (cin, cout): those of df3d_conv_packed_weight_bytes
+ *   != 0 on the output-stationary kernel (64->64, 64->32, 512->64, 128->128, ...). */
+int df3d_conv_rows_split(const void *in_split, int n_in, int in_channels, int cin, int in_group_stride,
+                         const void *packed_filters, int kvol, int cout, int groups, const int32_t *nbr, int n_out,
+                         const float *bias, const float *scale, const float *shift, int relu, float *out,
+                         int out_channels, const int32_t *out_cols, void *out_split, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Detection tail: rotated BEV overlap / IoU / NMS.  Replace the pybind module
  * `iou3d_nms_cuda` (CP/det3d/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17): boxes_overlap_bev_gpu / boxes_iou_bev_gpu

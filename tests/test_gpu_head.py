@@ -24,7 +24,7 @@ def test_predict_equals_reference_golden(golden):
     head = _head().to(DEV)
     x = torch.from_numpy(detgen.randn("head_x_%d" % int(g["seed"]), HEAD_SHAPE)).to(DEV)
     with torch.no_grad():
-        preds = head(x)
+        preds = head.forward_reference(x)          # library convolutions: this test isolates the decode / NMS tail
         dets = head.predict({}, preds, HEAD_TEST_CFG)
     assert len(dets) == 2
     for i, d in enumerate(dets):
@@ -153,4 +153,31 @@ def test_predict_properties_at_nuscenes_size():
         # and the whole kept list agrees wherever no tie interferes: at least 90 % identical rows
         k = min(counts[b], len(want[b]["scores"]))
         same = np.isclose(boxes[b, :k].cpu().numpy(), want[b]["box3d_lidar"][:k], rtol=1e-4, atol=1e-4).all(1)
+        assert same.mean() > 0.9
+
+
+def test_forward_rows_vs_torch_cpu_and_end_to_end():
+    """CenterHead.forward on the row kernels (3 launches) against the torch fp32 CPU composition of the same module,
+    then neck -> head -> predict chained on the device."""
+    from make_golden import HEAD_TEST_CFG
+    head = _head()
+    x = torch.from_numpy(detgen.randn("head_fw_x", (2, 512, 20, 24)))
+    with torch.no_grad():
+        ref = head.forward_reference(x)
+        hd = head.to(DEV)
+        got = hd(x.to(DEV))
+    assert len(got) == 6
+    for t in range(6):
+        assert set(got[t]) == set(ref[t])
+        for k in ref[t]:
+            assert tuple(got[t][k].shape) == tuple(ref[t][k].shape)
+            err = float((got[t][k].cpu() - ref[t][k]).abs().max() / ref[t][k].abs().max())
+            assert err < 1e-3, (t, k, err)                                   # measured ~1e-5
+    assert getattr(got[0]["hm"], "_df3d_rows", None) is not None
+    dets = hd.predict({}, got, HEAD_TEST_CFG)
+    dets_ref = hd.predict({}, [{k: v.to(DEV) for k, v in p.items()} for p in ref], HEAD_TEST_CFG)
+    for a, b in zip(dets, dets_ref):
+        k = min(len(a["scores"]), len(b["scores"]))
+        assert k > 50
+        same = np.isclose(a["box3d_lidar"][:k].cpu().numpy(), b["box3d_lidar"][:k].cpu().numpy(), rtol=1e-3, atol=1e-3).all(1)
         assert same.mean() > 0.9

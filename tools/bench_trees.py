@@ -3,7 +3,9 @@
   tf : TransFusion-L SparseEncoderFusion + ACTR fusion layer, 0.075 m nuScenes grid, bs=4, 6 cameras (configs[2] shape, fp32)
   vr : Voxel-RCNN VoxelBackBone8xFusion (MVX + ACTRv2), KITTI 0.05 m grid, bs=8, one camera (configs[4] shape)
   neck : CenterPoint RPN BEV neck on [B, 256, 180, 180] (0.1 m nuScenes grid), row kernels vs the torch/MIOpen composition
-usage: bench_trees.py [tf|vr|neck] [steps]"""
+  head : CenterPoint CenterHead (6 tasks) forward + predict on the neck's [B, 512, 180, 180] map, row kernels + device tail
+         vs the torch/MIOpen forward; then sweep -> boxes end to end (LiDAR hot path + neck + head + predict)
+usage: bench_trees.py [tf|vr|neck|head] [steps]"""
 import os
 import sys
 import time
@@ -104,6 +106,40 @@ elif which == "neck":
         print("LiDAR hot path %.3f ms/sweep; with the row-kernel neck %.3f ms/sweep" % (ms_hp0, ms_hp))
     print("neck RPN bs=%d: rows %.3f ms (%.0f TFLOP/s), NCHW in %.3f ms | torch/MIOpen NCHW %.3f ms, channels_last %.3f ms"
           " | max abs diff %.2e" % (B, ms_rows, gf / ms_rows, ms_nchw, ms_lib, ms_lib_cl, err))
+elif which == "head":
+    from dualfusion.heads import CenterHead
+    from dualfusion.necks import RPN
+    TASKS = [dict(num_class=1, class_names=["car"]), dict(num_class=2, class_names=["truck", "construction_vehicle"]),
+             dict(num_class=2, class_names=["bus", "trailer"]), dict(num_class=1, class_names=["barrier"]),
+             dict(num_class=2, class_names=["motorcycle", "bicycle"]), dict(num_class=2, class_names=["pedestrian", "traffic_cone"])]
+    TEST_CFG = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                    nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=0.2), score_threshold=0.1,
+                    pc_range=[-54, -54], out_size_factor=8, voxel_size=[0.075, 0.075])
+    B = int(os.environ.get("DF3D_NECK_BATCH", "1"))
+    head = CenterHead(in_channels=512, tasks=TASKS, common_heads={'reg': (2, 2), 'height': (1, 2), 'dim': (3, 2),
+                                                                  'rot': (2, 2), 'vel': (2, 2)}, share_conv_channel=64).to(dev).eval()
+    x = torch.randn(B, 512, 180, 180, device=dev).relu()
+    with torch.no_grad():
+        ms_fw = timeit(lambda: head(x))
+        ms_fw_lib = timeit(lambda: head.forward_reference(x))
+        preds = head(x)
+        ms_pred = timeit(lambda: head.predict_device(preds, TEST_CFG))
+        ms_pred_host = timeit(lambda: head.predict({}, preds, TEST_CFG))
+        n_det = sum(len(d["scores"]) for d in head.predict({}, preds, TEST_CFG))
+    print("head bs=%d: forward rows %.3f ms (%.0f TFLOP/s) | torch/MIOpen %.3f ms | predict (device, no sync) %.3f ms, with result "
+          "lists on the host side %.3f ms (%d boxes)" % (B, ms_fw, 108.0 * B / ms_fw, ms_fw_lib, ms_pred, ms_pred_host, n_det))
+    if B == 1:
+        from dualfusion import synth as _s
+        from dualfusion.pipeline import CenterPointHotPath
+        neck = RPN([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256).to(dev).eval()
+        hp = CenterPointHotPath(neck=neck).eval().to(dev)
+        pts = [torch.from_numpy(_s.nusc_sweep(seed=0)).to(dev)]
+
+        def e2e():
+            with torch.no_grad():
+                bev, _ = hp(pts)
+                return head.predict_device(head(bev), TEST_CFG)
+        print("sweep -> boxes (LiDAR hot path + neck + head + predict): %.3f ms/sweep" % timeit(e2e))
 else:
     from dualfusion.backbones import VoxelBackBone8xFusion
     B = 8
