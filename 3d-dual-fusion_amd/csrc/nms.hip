@@ -156,7 +156,11 @@ __global__ __launch_bounds__(256) void boxes_pairwise_kernel(const float *__rest
   out[(size_t)i * nb + j] = v;
 }
 
-// bit (i, j) = IoU(box i, box j) > thresh, j > i, 64 x 64 tiles; grid (col tile, row tile, list)
+// bit (i, j) = IoU(box i, box j) > thresh, j > i, 64 x 64 tiles; grid (col tile, row tile, list).
+// Rotated mode in two phases, because the polygon clipping is ~100x the cost of the rejection test and only a few
+// pairs of a tile need it: (1) every lane scans its row with the centre-distance test and records the surviving
+// columns as a bit word; (2) the surviving (row, column) pairs of the whole tile are listed in LDS and clipped one
+// pair per lane -- all 64 lanes busy, instead of the whole wave waiting whenever one lane met a close pair.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ counts,
                                                       int cap, int cbmax, float thresh, int mode,
                                                       unsigned long long *__restrict__ mask) {
@@ -166,32 +170,59 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
   n = n < cap ? n : cap;
   if (rb * 64 >= n || cb * 64 >= n) return;
   const float *bx = boxes + (size_t)s * cap * 7;
-  __shared__ float colb[64 * 7];
+  __shared__ float colb[64 * 7], rowb[64 * 7];
+  __shared__ unsigned short pairs[64 * 64];
+  __shared__ unsigned long long bitsL[64];
   const int t = threadIdx.x;
-  const int csize = min(n - cb * 64, 64);
+  const int csize = min(n - cb * 64, 64), rsize = min(n - rb * 64, 64);
   for (int e = t; e < csize * 7; e += 64) colb[e] = bx[(size_t)cb * 64 * 7 + e];
+  for (int e = t; e < rsize * 7; e += 64) rowb[e] = bx[(size_t)rb * 64 * 7 + e];
+  bitsL[t] = 0ull;
   __syncthreads();
   const int i = rb * 64 + t;
-  if (i >= n) return;
-  float a[7];
-#pragma unroll
-  for (int e = 0; e < 7; ++e) a[e] = bx[(size_t)i * 7 + e];
-  unsigned long long bits = 0ull;
+  const bool live = t < rsize;
+  const float *a = rowb + t * 7;
+  unsigned long long bits = 0ull, near = 0ull;
   const int start = rb == cb ? t + 1 : 0;
-  for (int j = start; j < csize; ++j) {
-    const float *b = colb + j * 7;
-    bool sup;
-    if (mode == DF3D_NMS_CIRCLE) {               // centre distance (CP/det3d/core/utils/circle_nms_jit.py:21-26)
-      const float dx = a[0] - b[0], dy = a[1] - b[1];
-      sup = dx * dx + dy * dy <= thresh;
-    } else if (mode == DF3D_NMS_NORMAL) {
-      sup = iou_normal(a, b) > thresh;
-    } else {
-      sup = (thresh < 0.f || !far_apart(a, b)) && iou_rotated(a, b) > thresh;
+  if (live) {
+    for (int j = start; j < csize; ++j) {
+      const float *b = colb + j * 7;
+      if (mode == DF3D_NMS_CIRCLE) {               // centre distance (CP/det3d/core/utils/circle_nms_jit.py:21-26)
+        const float dx = a[0] - b[0], dy = a[1] - b[1];
+        if (dx * dx + dy * dy <= thresh) bits |= 1ull << j;
+      } else if (mode == DF3D_NMS_NORMAL) {
+        if (iou_normal(a, b) > thresh) bits |= 1ull << j;
+      } else if (thresh < 0.f || !far_apart(a, b)) {
+        near |= 1ull << j;
+      }
     }
-    if (sup) bits |= 1ull << j;
   }
-  mask[((size_t)s * cap + i) * cbmax + cb] = bits;
+  if (mode == DF3D_NMS_ROTATED) {
+    // exclusive prefix of the per-lane pair counts (wave64 scan by shuffles)
+    const int mine = __popcll(near);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      if (t >= d) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    int pos = incl - mine;
+    unsigned long long m = near;
+    while (m) {
+      const int j = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      pairs[pos++] = (unsigned short)((t << 6) | j);
+    }
+    __syncthreads();
+    for (int p = t; p < total; p += 64) {
+      const int r = pairs[p] >> 6, j = pairs[p] & 63;
+      if (iou_rotated(rowb + r * 7, colb + j * 7) > thresh) atomicOr(&bitsL[r], 1ull << j);
+    }
+    __syncthreads();
+    bits = bitsL[t];
+  }
+  if (live) mask[((size_t)s * cap + i) * cbmax + cb] = bits;
 }
 
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {

@@ -118,6 +118,10 @@ elif which == "head":
     B = int(os.environ.get("DF3D_NECK_BATCH", "1"))
     head = CenterHead(in_channels=512, tasks=TASKS, common_heads={'reg': (2, 2), 'height': (1, 2), 'dim': (3, 2),
                                                                   'rot': (2, 2), 'vel': (2, 2)}, share_conv_channel=64).to(dev).eval()
+    with torch.no_grad():                      # car-sized boxes (a random-init 'dim' head gives 50 m boxes: every pair overlaps)
+        for task in head.tasks:
+            task.dim[3].weight.mul_(0.05)
+            task.dim[3].bias.fill_(0.5)
     x = torch.randn(B, 512, 180, 180, device=dev).relu()
     with torch.no_grad():
         ms_fw = timeit(lambda: head(x))
