@@ -17,7 +17,8 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT] + srcs
+    extra = os.environ.get("DF3D_HIPCC_FLAGS", "").split()          # e.g. -DDF3D_OS_EXPERIMENTS for the tuning flags
+    cmd = [hipcc] + FLAGS + extra + ["-o", OUT] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -125,6 +125,16 @@ struct SplitConvArgs {
   const int32_t *cols;   // optional [gy][2] = (first output column, valid columns) of a block: compact fp32 stores
 };
 
+// tuning experiments of the output-stationary kernel (DF3D_OS_DBG bits: 1 no gathers, 2 no W staging, 4 no MFMAs,
+// 8 raised wave priority around the MFMAs, 16 MFMAs without B-operand LDS reads, 32 no output stores) exist only in
+// builds with -DDF3D_OS_EXPERIMENTS: as run-time flags they cost the production kernel ~20 % (uniform branches
+// inside the MFMA batches)
+#ifdef DF3D_OS_EXPERIMENTS
+#define OS_DBG(bit) ((a.dbg & (bit)) != 0)
+#else
+#define OS_DBG(bit) false
+#endif
+
 #define DF3D_MFMA_BF16(A, B, C) \
   __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       int idx = nbrL[k][wave * WROWS + rt * 16 + n];
-      const u32x4 *p = (live && idx >= 0 && !(a.dbg & 1)) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff
+      const u32x4 *p = (live && idx >= 0 && !OS_DBG(1)) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff
                                                           : g_zero_row;
       p += (kb * 4 + g) * 2;
 #pragma unroll
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   // Step s: barrier; W(s+1) (fetched during step s-1) -> LDS; fetch W(s+2); MFMAs of step s; fetch A(s+3).
   auto step = [&](int s, u32x4 (&cur)[RT][KPS][2]) {
     __syncthreads();
-    if (!(a.dbg & 2)) {
+    if (!OS_DBG(2)) {
       store_w((s + 1) & 1);
       load_w(s + 2);
     }
@@ -526,17 +536,26 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     // B fragments of the next column pair are fetched from LDS while the MFMAs of the current pair run
     constexpr int NBATCH = KPS * CT / 2;
     u32x4 bq[2][4];
+    if (!OS_DBG(16)) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bq[0][q] = wb[q * 64];
+      for (int q = 0; q < 4; ++q) bq[0][q] = wb[q * 64];
+    }
 #pragma unroll
     for (int i = 0; i < NBATCH; ++i) {
       const int j = i / (CT / 2), c2 = (i % (CT / 2)) * 2;
-      if (i + 1 < NBATCH) {
+      if (i + 1 < NBATCH && !OS_DBG(16)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[(i + 1) & 1][q] = wb[((i + 1) * 4 + q) * 64];
       }
-      const u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][1], bh1 = bq[i & 1][2], bl1 = bq[i & 1][3];
-      if (a.dbg & 4) continue;
+      u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][1], bh1 = bq[i & 1][2], bl1 = bq[i & 1][3];
+      if (OS_DBG(16)) {                    // experiment: MFMAs without the LDS reads of their B operands
+        bh0 = cur[0][j][0];
+        bl0 = cur[0][j][1];
+        bh1 = cur[0][j][0];
+        bl1 = cur[0][j][1];
+      }
+      if (OS_DBG(4)) continue;
+      if (OS_DBG(8)) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][1], bh0, acc[rt][c2]);
@@ -552,6 +571,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][0], bh0, acc[rt][c2]);
         acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][0], bh1, acc[rt][c2 + 1]);
       }
+      if (OS_DBG(8)) __builtin_amdgcn_s_setprio(0);
     }
     load_a(s + 3, cur);
   };
@@ -633,6 +653,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
       if (row >= a.n_out) continue;
+      if (OS_DBG(32) && acc[rt][0][r] != 1234.567f) continue;      // experiment: no output stores
       const size_t o = (size_t)row * a.ldo + col0 + n * CT;
       unsigned h[CT / 2], l[CT / 2];         // packed pairs
 #pragma unroll
@@ -690,6 +711,7 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
   if (kps == 2) {
     if (rt == 2) DF3D_OS_LAUNCH(2, 4, KMAX);
     else if (nw == 2) DF3D_OS_LAUNCH(1, 2, KMAX);
+    else if (nw == 8) DF3D_OS_LAUNCH(1, 8, KMAX);
     else DF3D_OS_LAUNCH(1, 4, KMAX);
   } else if (nw == 16) DF3D_OS_LAUNCH(1, 16, 1);
   else if (nw == 8) DF3D_OS_LAUNCH(1, 8, 1);
@@ -895,8 +917,8 @@ extern "C" int df3d_conv_rows_split(const void *in_split, int n_in, int in_chann
   }
   if (n_out == 0) return DF3D_OK;
   SplitConvArgs a = {(const u32x4 *)in_split, (const u32x4 *)packed_filters, nbr, bias, scale, shift, nullptr,
-                     out, (u32x4 *)out_split, n_in, n_out, kvol, relu, 0,
-                     in_channels / 4, in_group_stride / 4, out_channels, blocks, out_cols};
+                     out, (u32x4 *)out_split, n_in, n_out, kvol, relu,
+                     getenv("DF3D_OS_DBG") ? atoi(getenv("DF3D_OS_DBG")) : 0, in_channels / 4, in_group_stride / 4, out_channels, blocks, out_cols};
   int rec = timing_rec_begin(cin, cout * groups, kvol, n_out, nbr, 1, stream);
   int rc = launch_os_any(cin, cout, a, stream);
   if (rc) return rc;
