@@ -16,20 +16,27 @@ from ._lib import Df3dError
 
 class MSDeformAttnFunction(Function):
     """forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
-    im2col_step) -> [N, Lq, M*D].  im2col_step is accepted for signature parity; the HIP kernel
-    needs no batch chunking.  Backward (col2im) is a later row of SURVEY.md §8(f)."""
+    im2col_step) -> [N, Lq, M*D].  im2col_step is accepted for signature parity; the HIP kernels
+    need no batch chunking.  backward -> (grad_value, None, None, grad_sampling_loc, grad_attn_weight, None) like
+    ms_deform_attn_func.py:31-38 (csrc/msda.hip, df3d_ms_deform_attn_backward)."""
 
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
                 im2col_step):
         ctx.im2col_step = im2col_step
-        return _ops.ms_deform_attn_forward(value.contiguous(), value_spatial_shapes.contiguous(),
-                                           value_level_start_index.contiguous(), sampling_locations.contiguous(),
-                                           attention_weights.contiguous())
+        value, sampling_locations = value.contiguous(), sampling_locations.contiguous()
+        value_spatial_shapes, value_level_start_index = value_spatial_shapes.contiguous(), value_level_start_index.contiguous()
+        attention_weights = attention_weights.contiguous()
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        return _ops.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                           attention_weights)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
-        raise Df3dError("MSDeformAttnFunction.backward is not implemented in this round (forward/inference path)")
+        value, shapes, lstart, loc, aw = ctx.saved_tensors
+        gv, gl, ga = _ops.ms_deform_attn_backward(value, shapes, lstart, loc, aw, grad_output.contiguous())
+        return gv, None, None, gl, ga, None
 
 
 def _is_power_of_2(n):

@@ -512,6 +512,28 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, grad_output):
+    """-> (grad_value [N,S,M,D], grad_sampling_loc [N,Lq,M,L,P,2], grad_attn_weight [N,Lq,M,L,P])."""
+    lib = _lib.load()
+    for t, name in ((value, "value"), (sampling_locations, "sampling_locations"), (attention_weights, "attention_weights"),
+                    (grad_output, "grad_output")):
+        _chk(t, torch.float32, name)
+    _chk(spatial_shapes, torch.int64, "spatial_shapes")
+    _chk(level_start_index, torch.int64, "level_start_index")
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    if tuple(grad_output.shape) != (N, Lq, M * D):
+        raise ValueError("grad_output must be [N, Lq, M*D]")
+    gv = torch.empty_like(value)
+    gl = torch.empty_like(sampling_locations)
+    ga = torch.empty_like(attention_weights)
+    rc = lib.df3d_ms_deform_attn_backward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index),
+                                          _ptr(sampling_locations), _ptr(attention_weights), _ptr(grad_output), N, S, M,
+                                          D, Lq, L, P, _ptr(gv), _ptr(gl), _ptr(ga), _stream())
+    _lib.check(rc, "df3d_ms_deform_attn_backward")
+    return gv, gl, ga
+
+
 def ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, offsets, logits, n_levels, n_points,
                          pixel_scale=None, image_bias=None):
     """Sampling with in-kernel softmax and location arithmetic (csrc/actr.hip).  value [N,S,M,D] may be a

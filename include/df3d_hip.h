@@ -271,6 +271,16 @@ int df3d_ms_deform_attn_forward(const float *value, const int64_t *spatial_shape
                                 const float *attn_weight, int N, int S, int M, int D, int Lq,
                                 int L, int P, float *out, void *stream);
 
+/* Backward of the above.  Replaces MultiScaleDeformableAttention.ms_deform_attn_backward
+ * (vision.cpp:13-16, ms_deform_attn.h:42-62, cuda/ms_deform_attn_cuda.cu:87-153, kernels
+ * ms_deform_im2col_cuda.cuh:87-232,301-921).  grad_output [N,Lq,M*D]; grad_value [N,S,M,D] (zero-filled here, then
+ * accumulated with fp32 atomics -- summation order varies between runs, as in the reference), grad_sampling_loc
+ * [N,Lq,M,L,P,2], grad_attn_weight [N,Lq,M,L,P] (plain stores). */
+int df3d_ms_deform_attn_backward(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                 const float *sampling_loc, const float *attn_weight, const float *grad_output, int N,
+                                 int S, int M, int D, int Lq, int L, int P, float *grad_value,
+                                 float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Point ops of LocalTransformer (CP/det3d/models/model_utils/pointformer.py:349-380).
  * furthest_point_sampling_wrapper (CP/det3d/ops/furthest_point_sample/src/

@@ -203,6 +203,58 @@ def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights)
     return out.reshape(N, Lq, M * D)
 
 
+def ms_deform_attn_backward(value, spatial_shapes, sampling_locations, attention_weights, grad_output):
+    """Backward of ms_deform_attn.  Restates ms_deformable_col2im_gpu_kernel* + ms_deform_attn_col2im_bilinear
+    (CP/det3d/models/model_utils/ops/src/cuda/ms_deform_im2col_cuda.cuh:87-232,301-921) in float64 accumulation:
+    grad_value[corner] += w_corner * attn * g; grad_attn = sum_c g * bilinear; grad_loc = (W * dval/dw, H * dval/dh)
+    * attn * g summed over channels; samples with h_im / w_im outside (-1, H) / (-1, W) contribute nothing.
+    -> (grad_value [N,S,M,D], grad_loc [N,Lq,M,L,P,2], grad_attn [N,Lq,M,L,P]) float32."""
+    value = np.asarray(value, np.float64)
+    loc = np.asarray(sampling_locations, np.float32)
+    aw = np.asarray(attention_weights, np.float64)
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    g = np.asarray(grad_output, np.float64).reshape(N, Lq, M, 1, D)
+    gv = np.zeros((N, S, M, D), np.float64)
+    gl = np.zeros((N, Lq, M, L, P, 2), np.float64)
+    ga = np.zeros((N, Lq, M, L, P), np.float64)
+    nn = np.broadcast_to(np.arange(N)[:, None, None, None], (N, Lq, M, P))
+    mm = np.broadcast_to(np.arange(M)[None, None, :, None], (N, Lq, M, P))
+    start = 0
+    for l, (H, W) in enumerate(spatial_shapes):
+        H, W = int(H), int(W)
+        v = value[:, start:start + H * W].reshape(N, H, W, M, D)
+        gvl = np.zeros((N, H, W, M, D), np.float64)
+        w_im = loc[:, :, :, l, :, 0] * np.float32(W) - np.float32(0.5)
+        h_im = loc[:, :, :, l, :, 1] * np.float32(H) - np.float32(0.5)
+        inside = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
+        h0 = np.floor(h_im).astype(np.int64)
+        w0 = np.floor(w_im).astype(np.int64)
+        lh = (h_im - h0).astype(np.float32).astype(np.float64)
+        lw = (w_im - w0).astype(np.float32).astype(np.float64)
+        hh, hw = 1 - lh, 1 - lw
+        corner = []
+        for dh, dw, wt in ((0, 0, hh * hw), (0, 1, hh * lw), (1, 0, lh * hw), (1, 1, lh * lw)):
+            y, x = h0 + dh, w0 + dw
+            ok = inside & (y >= 0) & (y < H) & (x >= 0) & (x < W)
+            yc, xc = np.clip(y, 0, H - 1), np.clip(x, 0, W - 1)
+            vals = v[nn, yc, xc, mm] * ok[..., None]                                 # [N,Lq,M,P,D]
+            corner.append(vals)
+            contrib = (wt * ok * aw[:, :, :, l, :])[..., None] * g                   # [N,Lq,M,P,D]
+            np.add.at(gvl, (nn, yc, xc, mm), contrib)
+        v1, v2, v3, v4 = corner
+        val = (hh * hw)[..., None] * v1 + (hh * lw)[..., None] * v2 + (lh * hw)[..., None] * v3 + (lh * lw)[..., None] * v4
+        dh_ = hw[..., None] * (v3 - v1) + lw[..., None] * (v4 - v2)
+        dw_ = hh[..., None] * (v2 - v1) + lh[..., None] * (v4 - v3)
+        tg = g * aw[:, :, :, l, :, None]
+        ga[:, :, :, l, :] = (g * val).sum(-1) * inside
+        gl[:, :, :, l, :, 0] = W * (dw_ * tg).sum(-1) * inside
+        gl[:, :, :, l, :, 1] = H * (dh_ * tg).sum(-1) * inside
+        gv[:, start:start + H * W] = gvl.reshape(N, H * W, M, D)
+        start += H * W
+    return gv.astype(np.float32), gl.astype(np.float32), ga.astype(np.float32)
+
+
 # --------------------------------------------------------------------- point ops
 def furthest_point_sample(xyz, m):
     """CP/det3d/ops/furthest_point_sample/src/furthest_point_sample_cuda.cu:26-141."""

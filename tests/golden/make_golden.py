@@ -177,6 +177,37 @@ def gen_msda(func):
     save("msda.npz", **out)
 
 
+MSDA_BWD_CASES = dict(hot=dict(N=1, M=8, D=16, Lq=40, P=4, shapes=[(8, 10)]),
+                      multi=dict(N=2, M=4, D=6, Lq=20, P=2, shapes=[(5, 7), (3, 4), (2, 3)]))
+
+
+def msda_bwd_inputs(tag):
+    c = MSDA_BWD_CASES[tag]
+    N, M, D, Lq, P, shp = c["N"], c["M"], c["D"], c["Lq"], c["P"], c["shapes"]
+    L, S = len(shp), sum(h * w for h, w in shp)
+    value = detgen.randn("msdab_%s_value" % tag, (N, S, M, D))
+    loc = detgen.rand("msdab_%s_loc" % tag, (N, Lq, M, L, P, 2), -0.15, 1.15)
+    aw = detgen.rand("msdab_%s_aw" % tag, (N, Lq, M, L, P), 0.05, 1.0)
+    gout = detgen.randn("msdab_%s_gout" % tag, (N, Lq, M * D))
+    return value, shp, loc, aw, gout
+
+
+def gen_msda_bwd(func):
+    """Gradients of the reference's own pure-torch core (ms_deform_attn_func.py:41-61) by autograd in float64 --
+    what the reference's ops/test.py:49-86 checks its CUDA backward against."""
+    out = {}
+    for tag in MSDA_BWD_CASES:
+        value, shp, loc, aw, gout = msda_bwd_inputs(tag)
+        v = torch.from_numpy(value).double().requires_grad_(True)
+        lo = torch.from_numpy(loc).double().requires_grad_(True)
+        a = torch.from_numpy(aw).double().requires_grad_(True)
+        y = func.ms_deform_attn_core_pytorch(v, torch.as_tensor(shp), lo, a)
+        y.backward(torch.from_numpy(gout).double())
+        out.update({tag + "_gv": v.grad.float().numpy(), tag + "_gl": lo.grad.float().numpy(),
+                    tag + "_ga": a.grad.float().numpy()})
+    save("msda_bwd.npz", **out)
+
+
 ACTR_CFG = dict(fusion_method="sum", feature_modal="hybrid",
                 hybrid_cfg=dict(attn_layer="BiGateSum1D_2", q_method="sum", q_rep_place=["weight"]),
                 num_bins=80, num_channels=[256], query_num_feat=128, num_enc_layers=2,
@@ -654,6 +685,7 @@ if __name__ == "__main__":
         actr, func = import_reference_actr()
         if "msda" in which:
             gen_msda(func)
+            gen_msda_bwd(func)
         if "actr" in which:
             gen_actr(actr)
     if "pointops" in which:

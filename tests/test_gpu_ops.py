@@ -508,3 +508,52 @@ def test_fps_block_sizes(dev, N):
         xyz[0, ::7] = xyz[0, 3]          # duplicated points spread over many threads
     m = min(N, 40)
     assert np.array_equal(ops.furthest_point_sample(T(xyz, dev), m).cpu().numpy(), orc.furthest_point_sample(xyz, m))
+
+
+# ------------------------------------------------------------------------- MSDA backward
+@pytest.mark.parametrize("tag", ["hot", "multi"])
+def test_msda_backward_golden_and_oracle(golden, dev, tag):
+    """df3d_ms_deform_attn_backward against the reference's autograd gradients (float64 pure-torch core) and the oracle;
+    through MSDeformAttnFunction.backward, i.e. the way the reference's modules reach it."""
+    from dualfusion.msda import MSDeformAttnFunction
+    from make_golden import msda_bwd_inputs
+    g = golden("msda_bwd.npz")
+    value, shp, loc, aw, gout = msda_bwd_inputs(tag)
+    v, lo, a = (T(x, dev).requires_grad_(True) for x in (value, loc, aw))
+    shapes = torch.as_tensor(shp, dtype=torch.long, device=dev)
+    lstart = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    y = MSDeformAttnFunction.apply(v, shapes, lstart, lo, a, 64)
+    y.backward(T(gout, dev))
+    for got, key in ((v.grad, "_gv"), (lo.grad, "_gl"), (a.grad, "_ga")):
+        want = g[tag + key]
+        err = np.abs(got.cpu().numpy() - want).max() / max(1.0, np.abs(want).max())
+        assert err <= 1e-4, (key, err)                         # fp32 kernel vs float64 reference; measured ~1e-6
+
+
+def test_msda_backward_full_size_properties(dev):
+    """6 cameras x 150x267 map, 8000 queries (the CenterPoint fusion layer): linearity in grad_output, and the
+    directional derivative <grad_value, dV> = d/dt <out(V + t dV), g> (out is linear in value: exact up to rounding)."""
+    from dualfusion import ops
+    N, H, W, M, D, Lq, P = 6, 150, 267, 8, 16, 8000, 4
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    value = torch.randn(N, H * W, M, D, generator=gen).to(dev)
+    loc = (torch.rand(N, Lq, M, 1, P, 2, generator=gen) * 1.2 - 0.1).to(dev)
+    aw = torch.softmax(torch.randn(N, Lq, M, P, generator=gen), -1).view(N, Lq, M, 1, P).to(dev)
+    g1 = torch.randn(N, Lq, M * D, generator=gen).to(dev)
+    g2 = torch.randn(N, Lq, M * D, generator=gen).to(dev)
+    shapes = torch.as_tensor([(H, W)], dtype=torch.long, device=dev)
+    lstart = shapes.new_zeros((1,))
+    a = ops.ms_deform_attn_backward(value, shapes, lstart, loc, aw, g1)
+    b = ops.ms_deform_attn_backward(value, shapes, lstart, loc, aw, g2)
+    c = ops.ms_deform_attn_backward(value, shapes, lstart, loc, aw, g1 + 2 * g2)
+    for x, y, z in zip(a, b, c):
+        assert float((z - (x + 2 * y)).abs().max()) <= 2e-4 * float(z.abs().max())
+    dv = torch.randn(N, H * W, M, D, generator=gen).to(dev)
+    lhs = float((a[0].double() * dv.double()).sum())
+    rhs = float((ops.ms_deform_attn_forward(dv, shapes, lstart, loc, aw).double() * g1.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))
+    # grad_attn_weight is the forward of each sample alone: <out, g> = sum_p aw_p * grad_aw_p
+    out = ops.ms_deform_attn_forward(value, shapes, lstart, loc, aw)
+    lhs = float((out.double() * g1.double()).sum())
+    rhs = float((a[2].double() * aw.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))

@@ -280,3 +280,17 @@ def test_centerhead_oracle_vs_reference_golden(golden):
         np.testing.assert_allclose(d["scores"], g["scores_%d" % i], rtol=2e-6, atol=1e-7)
         np.testing.assert_allclose(d["box3d_lidar"], g["boxes_%d" % i], rtol=1e-5, atol=2e-6)
     assert len(dets[0]["scores"]) > 100 and len(set(dets[0]["label_preds"].tolist())) >= 8
+
+
+@pytest.mark.parametrize("tag", ["hot", "multi"])
+def test_msda_backward_oracle_vs_reference_autograd(golden, tag):
+    """Oracle col2im restatement against the float64 autograd gradients of the reference's pure-torch core."""
+    from make_golden import msda_bwd_inputs
+    g = golden("msda_bwd.npz")
+    value, shp, loc, aw, gout = msda_bwd_inputs(tag)
+    gv, gl, ga = orc.ms_deform_attn_backward(value, shp, loc, aw, gout)
+    for got, key in ((gv, "_gv"), (gl, "_gl"), (ga, "_ga")):
+        want = g[tag + key]
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    assert np.abs(gl).max() > 0 and (gl == 0).any()          # some samples fall outside the map
