@@ -88,6 +88,9 @@ SIGNATURES = {
     "df3d_timing_get2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_sparse_to_dense_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_conv2d_neighbors": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_invert_neighbors": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_sparse_conv_grad_filters": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                              c_void_p]),
     "df3d_conv_rows_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_boxes_bev_pairwise": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -318,6 +318,47 @@ def sparse_conv_split(features_split, packed, nbr, n_out, cin, cout, bias=None, 
     return out, out_split
 
 
+def invert_neighbors(nbr, n_in):
+    """nbr [K, n_out] (input row of output o at offset k, -1 = none) -> inv [K, n_in] (output row fed by input i)."""
+    lib = _lib.load()
+    _chk(nbr, torch.int32, "nbr")
+    K, n_out = nbr.shape
+    inv = torch.empty((K, int(n_in)), dtype=torch.int32, device=nbr.device)
+    rc = lib.df3d_invert_neighbors(_ptr(nbr), K, n_out, int(n_in), _ptr(inv), _stream())
+    _lib.check(rc, "df3d_invert_neighbors")
+    return inv
+
+
+def sparse_conv_grad_filters(features, grad_out, nbr):
+    """-> grad_filters [K, cin, cout] = sum over rulebook pairs of features[in]^T grad_out[out]."""
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    _chk(grad_out, torch.float32, "grad_out")
+    _chk(nbr, torch.int32, "nbr")
+    K, n_out = nbr.shape
+    if grad_out.shape[0] != n_out:
+        raise ValueError("grad_out rows do not match the neighbour table")
+    cin, cout = features.shape[1], grad_out.shape[1]
+    gw = torch.empty((K, cin, cout), dtype=torch.float32, device=features.device)
+    rc = lib.df3d_sparse_conv_grad_filters(_ptr(features), features.shape[0], cin, _ptr(grad_out), n_out, cout, _ptr(nbr),
+                                           K, _ptr(gw), _stream())
+    _lib.check(rc, "df3d_sparse_conv_grad_filters")
+    return gw
+
+
+def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None):
+    """indice_conv backward from the kernel-facing rulebook: -> (grad_features [n_in, cin], grad_filters [K, cin, cout]).
+    filters [K, cin, cout]."""
+    K = nbr.shape[0]
+    n_in = features.shape[0]
+    grad_out = grad_out.contiguous()
+    if inv is None:
+        inv = nbr.flip(0).contiguous() if subm else invert_neighbors(nbr, n_in)
+    wt = filters.transpose(1, 2).contiguous()                     # [K, cout, cin]
+    g_in = sparse_conv_fused(grad_out, wt, inv, n_in)
+    return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr)
+
+
 def conv_rows_split(in_split, cin, in_group_stride, packed, cout, groups, nbr, n_out, bias=None, scale=None, shift=None,
                     relu=False, out_channels=None, out_cols=None, want_out=True, want_split=False):
     """Grouped / multi-head convolution over split rows (df3d_conv_rows_split).  in_split [n_in, 4*in_channels] uint8.

@@ -34,6 +34,33 @@ def _calculate_fan_in_and_fan_out_hwio(tensor):
     return fan_in, fan_out
 
 
+class SparseConvFunction(torch.autograd.Function):
+    """indice_conv + its backward (TF/mmdet3d/ops/spconv/functional.py:20-75 -> ops.indice_conv /
+    ops.indice_conv_backward) on the kernel-facing rulebook: forward = the exact-fp32 fused kernel (conv + bias),
+    backward = input gradient by the same kernel on the inverse table, filter gradient by
+    df3d_sparse_conv_grad_filters, bias gradient = column sums."""
+
+    @staticmethod
+    def forward(ctx, features, filters, bias, nbr, n_out, mirror):
+        K = nbr.shape[0]
+        cin, cout = features.shape[1], filters.shape[-1]
+        ctx.save_for_backward(features, filters, nbr)
+        ctx.mirror, ctx.has_bias = mirror, bias is not None
+        return _ops.sparse_conv_fused(features, filters.detach().contiguous().view(K, cin, cout), nbr, n_out,
+                                      bias=bias.detach() if bias is not None else None)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        features, filters, nbr = ctx.saved_tensors
+        K = nbr.shape[0]
+        cin, cout = features.shape[1], filters.shape[-1]
+        g_in, g_w = _ops.sparse_conv_backward(features, filters.detach().contiguous().view(K, cin, cout),
+                                              grad_out.contiguous().float(), nbr, ctx.mirror)
+        g_b = grad_out.sum(0) if ctx.has_bias else None
+        return g_in, g_w.view_as(filters), g_b, None, None, None
+
+
 class SparseConvolution(SparseModule):
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
@@ -129,11 +156,20 @@ class SparseConvolution(SparseModule):
         feats = input.features
         if feats.dtype != torch.float32:
             feats = feats.float()
-        w = self.weight.detach() if not self.weight.requires_grad or not torch.is_grad_enabled() else self.weight
-        if torch.is_grad_enabled() and (self.weight.requires_grad or feats.requires_grad):
-            raise Df3dError("the fused sparse conv is forward-only in this round; wrap inference in torch.no_grad()")
         K = rb.nbr.shape[0]
         n_out = rb.outids.shape[0]
+        if torch.is_grad_enabled() and (self.weight.requires_grad or feats.requires_grad):
+            # training: plain convolution (+ bias) through the autograd Function; BatchNorm / ReLU / residual stay
+            # separate modules exactly as in the reference (conv.py:179-204, functional.py:20-75)
+            if scale is not None or shift is not None or residual is not None or relu:
+                raise Df3dError("the fused BatchNorm / ReLU / residual epilogue is inference-only; call the conv alone "
+                                "when gradients are required")
+            out_features = SparseConvFunction.apply(feats.contiguous(), self.weight, self.bias, rb.nbr, n_out,
+                                                    bool(self.subm and all(k % 2 == 1 for k in self.kernel_size)))
+            out = SparseConvTensor(out_features, rb.outids, rb.out_spatial_shape, input.batch_size)
+            out.indice_dict, out.grid, out._directories = input.indice_dict, input.grid, input._directories
+            return out
+        w = self.weight.detach()
         bias = self.bias.detach() if self.bias is not None else None
         tiles = rb.tiles(self.in_channels, self.out_channels)
         out_split = None

@@ -78,6 +78,22 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
                                   int(num_activate_out))
 
 
+def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
+    """sparse_conv_ext.indice_conv_backward_fp32 (spconv_ops.h:363-456) from a reference-format rulebook:
+    -> [input_grad [N_in, Cin], filters_grad (shape of `filters`)]."""
+    if features.dtype != torch.float32:
+        raise Df3dError("indice_conv_backward: fp32 only (got %s)" % features.dtype)
+    pairs = indice_pairs.contiguous()
+    if inverse:
+        pairs = pairs.flip(1).contiguous()
+    n_out = out_bp.shape[0]
+    nbr = _ops.pairs_to_nbr(pairs, indice_pair_num, int(n_out))
+    cin, cout = features.shape[1], filters.shape[-1]
+    g_in, g_w = _ops.sparse_conv_backward(features.contiguous(), filters.contiguous().view(-1, cin, cout),
+                                          out_bp.contiguous(), nbr, False)
+    return [g_in, g_w.view_as(filters)]
+
+
 def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, num_activate_out, inverse, subm):
     """sparse_conv_ext.fused_indice_conv_fp32 (fused_spconv_ops.h:28-132): conv + bias."""
     pairs = indice_pairs.contiguous()

@@ -186,6 +186,19 @@ int df3d_sparse_to_dense_rows(const float *features, const int32_t *indices, int
 int df3d_conv2d_neighbors(int batch, int H, int W, int kh, int kw, int stride, int pad, int transposed,
                           int32_t *nbr, void *stream);
 
+/* Sparse convolution backward.  Replace sparse_conv_ext.indice_conv_backward_fp32
+ * (TF/mmdet3d/ops/spconv/src/all.cc:21-51, include/spconv/spconv_ops.h:363-456):
+ *   input gradient  = df3d_sparse_conv_fused(grad_out, filters^T per offset [K][Cout][Cin], inverse table, n_in) -- the
+ *       forward kernel, output-stationary in the input rows (no scatter-add).  df3d_invert_neighbors builds the
+ *       inverse table inv[k][i] = o of nbr[k][o] = i ([K][n_in], -1 = none); a submanifold convolution needs none:
+ *       inv[k] = nbr[K-1-k].
+ *   filter gradient = df3d_sparse_conv_grad_filters: grad_filters[k][ci][co] = sum_o features[nbr[k][o]][ci] *
+ *       grad_out[o][co] ([K][Cin][Cout], zero-filled here; fp32 MFMA partial tiles are added with fp32 atomics, so
+ *       the summation order varies between runs like the reference's cuBLAS split-K).  Cout <= 128. */
+int df3d_invert_neighbors(const int32_t *nbr, int kvol, int n_out, int n_in, int32_t *inv, void *stream);
+int df3d_sparse_conv_grad_filters(const float *features, int n_in, int cin, const float *grad_out, int n_out, int cout,
+                                  const int32_t *nbr, int kvol, float *grad_filters, void *stream);
+
 /* Grouped / multi-head convolution over pixel (or voxel) rows on the split-precision kernel -- the detection head's
  * stacks (CP/det3d/models/bbox_heads/center_head.py:66-110: per task and per head Conv2d 3x3 64 -> 64 + BN + ReLU
  * + Conv2d 3x3 64 -> classes) as ONE launch per depth instead of one cuDNN call per head.

@@ -150,6 +150,33 @@ def indice_conv(features, filters, pairs, num, num_act_out, subm, inverse=False)
     return out
 
 
+def indice_conv_backward(features, filters, out_grad, pairs, num, subm, inverse=False):
+    """TF/mmdet3d/ops/spconv/include/spconv/spconv_ops.h:363-456 (indiceConvBackward<float>): per non-empty offset
+    filtersGrad[k] = gather(features)^T @ gather(outGrad), inputGrad[in rows] += gather(outGrad) @ W[k]^T; subM handles
+    the offset with the most pairs (the centre) with two dense GEMMs first (:398-402).  float64 accumulation.
+    -> (input_grad [N_in, Cin], filters_grad (shape of filters))."""
+    features = np.asarray(features, np.float64)
+    og = np.asarray(out_grad, np.float64)
+    K = pairs.shape[0]
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    W = np.asarray(filters, np.float64).reshape(K, cin, cout)
+    gin = np.zeros_like(features)
+    gw = np.zeros_like(W)
+    kmax = int(np.argmax(num))
+    if subm:
+        gw[kmax] = features.T @ og
+        gin[:] = og @ W[kmax].T
+    a, b = (1, 0) if inverse else (0, 1)
+    for k in range(K):
+        n = int(num[k])
+        if n <= 0 or (subm and k == kmax):
+            continue
+        ib, ob = features[pairs[k, a, :n]], og[pairs[k, b, :n]]
+        gw[k] = ib.T @ ob
+        np.add.at(gin, pairs[k, a, :n], ob @ W[k].T)
+    return gin.astype(np.float32), gw.reshape(np.shape(filters)).astype(np.float32)
+
+
 def batchnorm_eval(x, weight, bias, mean, var, eps):
     """nn.BatchNorm1d in eval mode (eps 1e-3 everywhere on the path, CP/.../scn.py:108-109)."""
     return ((x - mean) / np.sqrt(var + np.float32(eps)) * weight + bias).astype(np.float32)

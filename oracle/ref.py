@@ -80,6 +80,17 @@ def indice_conv(features, filters, pairs, num, num_act_out, subm):
                               t(num, np.int32), int(num_act_out), 0, int(bool(subm))).numpy()
 
 
+def indice_conv_backward(features, filters, out_grad, pairs, num, subm):
+    """sparse_conv_ext.indice_conv_backward_fp32 (TF/.../spconv_ops.h:363-456) -> (input_grad, filters_grad)."""
+    import numpy as np
+    import torch
+    m = load("sparse_conv_ext")
+    t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a, dtype=d))
+    gi, gw = m.indice_conv_backward_fp32(t(features, np.float32), t(filters, np.float32), t(out_grad, np.float32),
+                                         t(pairs, np.int32), t(num, np.int32), 0, int(bool(subm)))
+    return gi.numpy(), gw.numpy()
+
+
 def boxes_iou_bev_cpu(boxes_a, boxes_b):
     """iou3d_nms_cuda.boxes_iou_bev_cpu (CP/det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:224-252): the reference's CPU path."""
     import numpy as np

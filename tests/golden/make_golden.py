@@ -648,6 +648,31 @@ def gen_centerhead():
     save("centerhead.npz", **out)
 
 
+CONV_BWD_SHAPE, CONV_BWD_BATCH = [7, 20, 22], 2
+
+
+def conv_bwd_case(subm):
+    ind = detgen.clustered_voxels("bwd%d" % subm, CONV_BWD_BATCH, CONV_BWD_SHAPE, n_seeds=4, walk=120)
+    ks, st, pd = ([3, 3, 3], [1, 1, 1], [1, 1, 1]) if subm else ([3, 3, 3], [2, 2, 2], [1, 1, 1])
+    f = detgen.randn("bwd_f%d" % subm, (len(ind), 12))
+    w = detgen.randn("bwd_w%d" % subm, (3, 3, 3, 12, 20), 0.2)
+    return ind, ks, st, pd, f, w
+
+
+def gen_conv_bwd():
+    """indice_conv_backward_fp32 of the reference's compiled CPU code (oracle/_ref/sparse_conv_ext.so)."""
+    out = {}
+    for subm in (1, 0):
+        ind, ks, st, pd, f, w = conv_bwd_case(subm)
+        outids, pairs, num, _ = ref.get_indice_pairs(ind, CONV_BWD_BATCH, CONV_BWD_SHAPE, ks, st, pd, [1, 1, 1], subm)
+        go = detgen.randn("bwd_g%d" % subm, (len(outids), 20))
+        gi, gw = ref.indice_conv_backward(f, w, go, pairs, num, subm)
+        order = np.lexsort(outids.T[::-1])                      # canonical out-voxel order (SURVEY section 8c)
+        out.update({"outids_%d" % subm: outids[order], "gi_%d" % subm: gi, "gw_%d" % subm: gw,
+                    "order_%d" % subm: order.astype(np.int64)})
+    save("conv_bwd.npz", **out)
+
+
 def gen_iou3d():
     """Rotated BEV IoU from the reference's own CPU path (oracle/_ref/iou3d_nms_cuda.so: boxes_iou_bev_cpu,
     CP/det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:224-252) on detgen boxes, and the greedy keep list that the reference's
@@ -672,9 +697,11 @@ def gen_iou3d():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "conv_bwd"]
     if "iou3d" in which:
         gen_iou3d()
+    if "conv_bwd" in which:
+        gen_conv_bwd()
     if "centerhead" in which:
         gen_centerhead()
     if "voxelize" in which:

@@ -294,3 +294,20 @@ def test_msda_backward_oracle_vs_reference_autograd(golden, tag):
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
     assert np.abs(gl).max() > 0 and (gl == 0).any()          # some samples fall outside the map
+
+
+@needs_ref
+@pytest.mark.parametrize("subm", [1, 0])
+def test_conv_backward_oracle_vs_ref_build(subm):
+    """Oracle indiceConvBackward restatement against the reference's own compiled CPU code (oracle/_ref)."""
+    ind = detgen.clustered_voxels("bwd%d" % subm, 2, [7, 20, 22], n_seeds=4, walk=120)
+    ks, st, pd = ([3, 3, 3], [1, 1, 1], [1, 1, 1]) if subm else ([3, 3, 3], [2, 2, 2], [1, 1, 1])
+    outids, pairs, num, _ = ref.get_indice_pairs(ind, 2, [7, 20, 22], ks, st, pd, [1, 1, 1], subm)
+    f = detgen.randn("bwd_f%d" % subm, (len(ind), 12))
+    w = detgen.randn("bwd_w%d" % subm, (3, 3, 3, 12, 20), 0.2)
+    go = detgen.randn("bwd_g%d" % subm, (len(outids), 20))
+    a = orc.indice_conv_backward(f, w, go, pairs, num, subm)
+    b = ref.indice_conv_backward(f, w, go, pairs, num, subm)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape
+        np.testing.assert_allclose(x, y, rtol=1e-4, atol=2e-4)
