@@ -58,6 +58,22 @@ class Rulebook(object):
         return 5
 
 
+class _DenseFunction(torch.autograd.Function):
+    """dense() with a backward (structure.py:5-18 scatter_nd: the gradient is the gather at the active sites)."""
+
+    @staticmethod
+    def forward(ctx, features, indices, batch_size, spatial_shape):
+        ctx.save_for_backward(indices)
+        return _ops.sparse_to_dense(features, indices, batch_size, list(spatial_shape))
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        idx = indices.long()
+        g = grad[(idx[:, 0], slice(None)) + tuple(idx[:, i + 1] for i in range(idx.shape[1] - 1))]
+        return g.contiguous(), None, None, None
+
+
 class SparseConvTensor(object):
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
         self.features = features
@@ -95,7 +111,10 @@ class SparseConvTensor(object):
     def dense(self, channels_first=True):
         """[B, C, *spatial] (channels_first) like structure.py:55-64; one fused kernel."""
         feats = self.features.contiguous()
-        out = _ops.sparse_to_dense(feats, self.indices.contiguous(), self.batch_size, self.spatial_shape)
+        if feats.requires_grad and torch.is_grad_enabled():
+            out = _DenseFunction.apply(feats, self.indices.contiguous(), self.batch_size, tuple(self.spatial_shape))
+        else:
+            out = _ops.sparse_to_dense(feats, self.indices.contiguous(), self.batch_size, self.spatial_shape)
         if not channels_first:
             nd = len(self.spatial_shape)
             return out.permute(0, *range(2, nd + 2), 1).contiguous()

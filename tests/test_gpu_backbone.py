@@ -382,3 +382,59 @@ def test_conv_backward_inverse_table_and_full_size():
     lhs = float((gw.double() * dw.double()).sum())
     rhs = float((ops.sparse_conv_fused(f, dw, rb.nbr, n).double() * g.double()).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))
+
+
+def test_training_step_gradients_vs_dense_torch():
+    """A training step through the spconv mirror (SubM conv -> BN(train) -> ReLU -> strided conv -> BN -> ReLU -> dense ->
+    loss.backward()) against the same network written with dense torch ops in float64 on the CPU (conv3d on the
+    densified tensor, masked to the active sites; BatchNorm over the active rows)."""
+    from dualfusion import spconv
+    F = torch.nn.functional
+    dev = torch.device("cuda:0")
+    shape, B, C0 = [6, 10, 12], 2, 8
+    ind = detgen.clustered_voxels("train", B, shape, n_seeds=3, walk=60)
+    f = detgen.randn("train_f", (len(ind), C0))
+    w1 = detgen.randn("train_w1", (3, 3, 3, C0, 16), 0.3)
+    w2 = detgen.randn("train_w2", (3, 3, 3, 16, 32), 0.2)
+    seq = spconv.SparseSequential(spconv.SubMConv3d(C0, 16, 3, bias=False, indice_key="a"), torch.nn.BatchNorm1d(16),
+                                  torch.nn.ReLU(), spconv.SparseConv3d(16, 32, 3, 2, padding=1, bias=False),
+                                  torch.nn.BatchNorm1d(32), torch.nn.ReLU()).to(dev).train()
+    with torch.no_grad():
+        seq[0].weight.copy_(torch.from_numpy(w1))
+        seq[3].weight.copy_(torch.from_numpy(w2))
+    feats = torch.from_numpy(f).to(dev).requires_grad_(True)
+    out = seq(spconv.SparseConvTensor(feats, torch.from_numpy(ind).to(dev), shape, B)).dense()
+    G = torch.from_numpy(detgen.randn("train_G", tuple(out.shape)))
+    (out * G.to(dev)).sum().backward()
+
+    # ---- dense float64 reference
+    idx = torch.from_numpy(ind).long()
+    fr = torch.from_numpy(f).double().requires_grad_(True)
+    W1 = torch.from_numpy(w1).double().requires_grad_(True)
+    W2 = torch.from_numpy(w2).double().requires_grad_(True)
+    g1, b1 = torch.ones(16, dtype=torch.float64, requires_grad=True), torch.zeros(16, dtype=torch.float64, requires_grad=True)
+    def densify(rows, where, dims, C):
+        cl = torch.zeros(B, *dims, C, dtype=torch.float64).index_put((where[:, 0], where[:, 1], where[:, 2], where[:, 3]), rows)
+        return cl.permute(0, 4, 1, 2, 3)
+    X = densify(fr, idx, shape, C0)
+    m0 = torch.zeros(B, 1, *shape, dtype=torch.float64)
+    m0[idx[:, 0], 0, idx[:, 1], idx[:, 2], idx[:, 3]] = 1
+    y1 = F.conv3d(X, W1.permute(4, 3, 0, 1, 2), padding=1)
+    r1 = y1[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]]
+    r1 = torch.relu(F.batch_norm(r1, None, None, g1, b1, training=True, eps=1e-5))
+    Y1 = densify(r1, idx, shape, 16)
+    m1 = F.conv3d(m0, torch.ones(1, 1, 3, 3, 3, dtype=torch.float64), stride=2, padding=1) > 0
+    oid = torch.nonzero(m1[:, 0])
+    y2 = F.conv3d(Y1, W2.permute(4, 3, 0, 1, 2), stride=2, padding=1)
+    r2 = y2[oid[:, 0], :, oid[:, 1], oid[:, 2], oid[:, 3]]
+    r2 = torch.relu(F.batch_norm(r2, None, None, torch.ones(32, dtype=torch.float64), torch.zeros(32, dtype=torch.float64),
+                                 training=True, eps=1e-5))
+    ref = densify(r2, oid, list(y2.shape[2:]), 32)
+    assert tuple(ref.shape) == tuple(out.shape)
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-4
+    (ref * G.double()).sum().backward()
+    for got, want, name in ((feats.grad, fr.grad, "features"), (seq[0].weight.grad, W1.grad, "w1"),
+                            (seq[3].weight.grad, W2.grad, "w2"), (seq[1].weight.grad, g1.grad, "bn1.weight"),
+                            (seq[1].bias.grad, b1.grad, "bn1.bias")):
+        err = float((got.cpu().double() - want).abs().max() / max(1.0, float(want.abs().max())))
+        assert err <= 2e-4, (name, err)

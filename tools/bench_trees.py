@@ -5,7 +5,9 @@
   neck : CenterPoint RPN BEV neck on [B, 256, 180, 180] (0.1 m nuScenes grid), row kernels vs the torch/MIOpen composition
   head : CenterPoint CenterHead (6 tasks) forward + predict on the neck's [B, 512, 180, 180] map, row kernels + device tail
          vs the torch/MIOpen forward; then sweep -> boxes end to end (LiDAR hot path + neck + head + predict)
-usage: bench_trees.py [tf|vr|neck|head] [steps]"""
+  train : CenterPoint SpMiddleResNetFHD in train() mode, one sweep: forward + dense + loss + backward through the sparse
+          conv backward kernels (training row of SURVEY section 8f; LiDAR-only, no optimizer)
+usage: bench_trees.py [tf|vr|neck|head|train] [steps]"""
 import os
 import sys
 import time
@@ -106,6 +108,31 @@ elif which == "neck":
         print("LiDAR hot path %.3f ms/sweep; with the row-kernel neck %.3f ms/sweep" % (ms_hp0, ms_hp))
     print("neck RPN bs=%d: rows %.3f ms (%.0f TFLOP/s), NCHW in %.3f ms | torch/MIOpen NCHW %.3f ms, channels_last %.3f ms"
           " | max abs diff %.2e" % (B, ms_rows, gf / ms_rows, ms_nchw, ms_lib, ms_lib_cl, err))
+elif which == "train":
+    from dualfusion import synth as _s
+    from dualfusion.pipeline import CenterPointHotPath
+    hp = CenterPointHotPath().to(dev)
+    pts = [torch.from_numpy(_s.nusc_sweep(seed=0)).to(dev)]
+    with torch.no_grad():
+        feats, coors = hp.voxelize(pts)
+    hp.backbone.train()
+    params = [p for p in hp.backbone.parameters() if p.requires_grad]
+
+    def fwd():
+        bev, _ = hp.backbone(feats, coors, 1, hp.grid_size_xyz)
+        return bev
+
+    def step():
+        for p in params:
+            p.grad = None
+        fwd().square().mean().backward()
+    ms_f = timeit(lambda: fwd())
+    ms = timeit(step)
+    hp.backbone.eval()
+    with torch.no_grad():
+        ms_inf = timeit(lambda: hp.backbone(feats, coors, 1, hp.grid_size_xyz))
+    print("train SpMiddleResNetFHD, 1 sweep (%d voxels): forward (train mode, unfused BN) %.2f ms, forward + backward %.2f ms "
+          "| inference forward %.2f ms" % (feats.shape[0], ms_f, ms, ms_inf))
 elif which == "head":
     from dualfusion.heads import CenterHead
     from dualfusion.necks import RPN
