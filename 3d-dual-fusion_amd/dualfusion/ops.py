@@ -355,7 +355,11 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None):
     if inv is None:
         inv = nbr.flip(0).contiguous() if subm else invert_neighbors(nbr, n_in)
     wt = filters.transpose(1, 2).contiguous()                     # [K, cout, cin]
-    g_in = sparse_conv_fused(grad_out, wt, inv, n_in)
+    cout, cin = wt.shape[1], wt.shape[2]
+    if conv_split_supported(K, cout, cin):
+        g_in, _ = sparse_conv_split(split_rows(grad_out), conv_pack_weights(wt), inv, n_in, cout, cin, emit_split=False)
+    else:
+        g_in = sparse_conv_fused(grad_out, wt, inv, n_in)
     return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr)
 
 

@@ -46,8 +46,12 @@ class SparseConvFunction(torch.autograd.Function):
         cin, cout = features.shape[1], filters.shape[-1]
         ctx.save_for_backward(features, filters, nbr)
         ctx.mirror, ctx.has_bias = mirror, bias is not None
-        return _ops.sparse_conv_fused(features, filters.detach().contiguous().view(K, cin, cout), nbr, n_out,
-                                      bias=bias.detach() if bias is not None else None)
+        w = filters.detach().contiguous().view(K, cin, cout)
+        b = bias.detach() if bias is not None else None
+        if _ops.conv_split_supported(K, cin, cout):            # same split-precision kernel as inference (~1e-5 rel.)
+            return _ops.sparse_conv_split(_ops.split_rows(features), _ops.conv_pack_weights(w), nbr, n_out, cin, cout,
+                                          bias=b, emit_split=False)[0]
+        return _ops.sparse_conv_fused(features, w, nbr, n_out, bias=b)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
