@@ -489,8 +489,12 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   // Every step issues the same loads, unconditionally: W tile of step min(s+2, last) and the A fragments of step
   // s+3 (the zero row past the end or where a row has no neighbour).  Steps are padded to a multiple of 3
   // (the A ring rotates by name); padding steps multiply zeros.
-  u32x4 wreg[WPT];
-  auto load_w = [&](int s) {
+  // The W tile of step s+4 is fetched at step s and parked in one of three register sets until step s+3 stores it
+  // to LDS: three whole steps cover the L2 / HBM latency (with a single set the store waited for a load issued one
+  // step earlier, which made every step at least one memory round trip long).  WD = 1 where a set is too large.
+  constexpr int WD = WPT <= 4 ? 3 : 1;
+  u32x4 w0[WPT], w1[WPT], w2[WPT];
+  auto load_w = [&](int s, u32x4 (&wreg)[WPT]) {
     s = s < steps ? s : steps - 1;
     const int k = __builtin_amdgcn_readfirstlane(actL[s / KB]);
     const u32x4 *src = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)(k * KB + s % KB)) * WQ;   // KPS consecutive [kb] tiles
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       wreg[i] = src[(WQ % NT == 0 || e < WQ) ? e : 0];
     }
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](int buf, u32x4 (&wreg)[WPT]) {
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       int e = tid + NT * i;
@@ -526,11 +530,16 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     }
   };
   // Step s: barrier; W(s+1) (fetched during step s-1) -> LDS; fetch W(s+2); MFMAs of step s; fetch A(s+3).
-  auto step = [&](int s, u32x4 (&cur)[RT][KPS][2]) {
+  auto step = [&](int s, u32x4 (&cur)[RT][KPS][2], u32x4 (&wset)[WPT]) {
     __syncthreads();
     if (!OS_DBG(2)) {
-      store_w((s + 1) & 1);
-      load_w(s + 2);
+      if constexpr (WD == 3) {
+        store_w((s + 1) & 1, wset);
+        load_w(s + 4, wset);
+      } else {
+        store_w((s + 1) & 1, w0);
+        load_w(s + 2, w0);
+      }
     }
     const u32x4 *wb = Wl[s & 1] + lane;
     // B fragments of the next column pair are fetched from LDS while the MFMAs of the current pair run
@@ -577,16 +586,22 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   };
 
   if (steps > 0) {
-    load_w(0);
-    store_w(0);
-    load_w(1);
+    load_w(0, w0);
+    store_w(0, w0);
+    if constexpr (WD == 3) {
+      load_w(1, w1);
+      load_w(2, w2);
+      load_w(3, w0);
+    } else {
+      load_w(1, w0);
+    }
     load_a(0, a0);
     load_a(1, a1);
     load_a(2, a2);
     for (int s = 0; s < steps; s += 3) {
-      step(s, a0);
-      step(s + 1, a1);
-      step(s + 2, a2);
+      step(s, a0, w1);
+      step(s + 1, a1, w2);
+      step(s + 2, a2, w0);
     }
   }
 
