@@ -15,6 +15,8 @@
 
 #include <vector>
 
+#include <mutex>
+
 #include "common.h"
 
 using namespace df3d;
@@ -56,9 +58,10 @@ struct Bump {
 
 int kvol_of(const int *k) { return k[0] * k[1] * k[2]; }
 
-// Second stream for the geometry work + a small pool of ordering events (created once per process).
-hipStream_t g_geo_stream = nullptr;
-std::vector<hipEvent_t> g_events;
+// Second stream for the geometry work + a small pool of ordering events, created once per HOST THREAD: frames are
+// independent, and a caller that keeps several frames in flight drives each from its own thread and stream.
+thread_local hipStream_t g_geo_stream = nullptr;
+thread_local std::vector<hipEvent_t> g_events;
 hipEvent_t order_event(size_t i) {
   while (g_events.size() <= i) {
     hipEvent_t e = nullptr;

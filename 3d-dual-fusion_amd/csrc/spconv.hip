@@ -25,6 +25,8 @@
 
 #include <vector>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace df3d {
@@ -673,6 +675,7 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const int32_t *__restr
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
 }
 static bool g_timing_on = false;
+static std::mutex g_timing_mu;          // several host threads (frames in flight) launch convolutions concurrently
 static std::vector<TimingRec> g_timing;
 static std::vector<hipEvent_t> g_event_pool;
 
@@ -689,6 +692,7 @@ static hipEvent_t timing_event() {
 
 int timing_rec_begin(int cin, int cout, int kvol, int n_out, const int32_t *nbr, int split, hipStream_t stream) {
   if (!g_timing_on) return -1;
+  std::lock_guard<std::mutex> lock(g_timing_mu);
   TimingRec r = {timing_event(), timing_event(), cin, cout, kvol, n_out, -1, split};
   if (!r.e0 || !r.e1) return -1;
   if (g_timing_pairs && nbr) {
@@ -711,7 +715,9 @@ int timing_rec_begin(int cin, int cout, int kvol, int n_out, const int32_t *nbr,
 }
 
 void timing_rec_end(int rec, hipStream_t stream) {
-  if (rec >= 0 && rec < (int)g_timing.size()) (void)hipEventRecord(g_timing[rec].e1, stream);
+  if (rec < 0) return;
+  std::lock_guard<std::mutex> lock(g_timing_mu);
+  if (rec < (int)g_timing.size()) (void)hipEventRecord(g_timing[rec].e1, stream);
 }
 
 static int pair_ntiles(int n_out, int cin, int cout) {
@@ -842,6 +848,7 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
 }
 
 extern "C" int df3d_timing_begin(void) {
+  std::lock_guard<std::mutex> lock(g_timing_mu);
   for (auto &r : g_timing) {
     g_event_pool.push_back(r.e0);
     g_event_pool.push_back(r.e1);

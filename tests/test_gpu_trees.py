@@ -227,3 +227,41 @@ def test_voxel_rcnn_backbone_vs_oracle_and_fusion_runs():
         if 0 <= u < W and 0 <= v < H:
             exp[i] += up[ind[i, 0], :, v, u]
         np.testing.assert_allclose(x1.features[i].cpu().numpy(), exp[i], rtol=1e-3, atol=1e-3)
+
+
+def test_two_frames_in_flight_equal_sequential():
+    """bench.py keeps two frames in flight per GPU (one host thread + HIP stream + model replica each).  Frames are
+    independent: concurrent execution must give every frame exactly the result of a sequential run (per-thread
+    geometry stream / ordering events in the native executor, no shared scratch)."""
+    import threading
+    import bench
+    dev = torch.device("cuda:0")
+    slots = []
+    for i in range(2):
+        m = bench.build_model("cp_fusion", dev)
+        pts, extra = bench.make_inputs("cp_fusion", 1, i, dev)            # different sweeps / cameras per slot
+        slots.append((m, pts, extra, torch.cuda.Stream()))
+    want = []
+    for m, pts, extra, _ in slots:
+        dense, multi = bench.run_step(m, pts, extra)
+        want.append((dense.clone(), [multi[k].indices.clone() for k in ("conv1", "conv2", "conv3", "conv4")]))
+    torch.cuda.synchronize()
+    got = [[], []]
+
+    def work(i):
+        m, pts, extra, st = slots[i]
+        with torch.cuda.stream(st):
+            for _ in range(6):
+                dense, multi = bench.run_step(m, pts, extra)
+                got[i].append((dense.clone(), [multi[k].indices.clone() for k in ("conv1", "conv2", "conv3", "conv4")]))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    for i in range(2):
+        for dense, idx in got[i]:
+            for a, b in zip(idx, want[i][1]):
+                assert torch.equal(a, b)
+            assert float((dense - want[i][0]).abs().max()) <= 1e-5 * float(want[i][0].abs().max())
