@@ -729,6 +729,7 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
     else if (nw == 8) DF3D_OS_LAUNCH(1, 8, KMAX);
     else DF3D_OS_LAUNCH(1, 4, KMAX);
   } else if (nw == 16) DF3D_OS_LAUNCH(1, 16, 1);
+  else if (rt == 2 && nw == 8) DF3D_OS_LAUNCH(2, 8, 1);
   else if (nw == 8) DF3D_OS_LAUNCH(1, 8, 1);
   else if (rt == 2 && nw == 4) DF3D_OS_LAUNCH(2, 4, 1);
   else if (rt == 2 && nw == 2) DF3D_OS_LAUNCH(2, 2, 1);

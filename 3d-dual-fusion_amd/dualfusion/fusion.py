@@ -246,6 +246,14 @@ class VoxelWithPointProjection(nn.Module):
             ev.record(self._side)
         self._prefetched = (id(batch_dict), layer_name, inp, both, ev)
 
+    def prefetch_inline(self, batch_dict, layer_name='layer1_ori', img_conv_func=None):
+        """The image-side projection issued early on the CURRENT stream (no co-running, just earlier in the frame)."""
+        feats = batch_dict['img_feat'][layer_name + '_feat2d']
+        dev = next(iter(feats.values())).device
+        inp = self._gather_inputs(batch_dict, layer_name, dev)
+        both = self._image_projection(inp, img_conv_func)
+        self._prefetched = (id(batch_dict), layer_name, inp, both, None)
+
     def _project(self, x, d_factor, inp):
         lib = _lib.load()
         ind = x.indices.contiguous()
@@ -302,10 +310,11 @@ class VoxelWithPointProjection(nn.Module):
         pre, self._prefetched = self._prefetched, None
         if pre is not None and pre[0] == id(batch_dict) and pre[1] == layer_name:
             inp, both, ev = pre[2], pre[3], pre[4]
-            main = torch.cuda.current_stream(dev)
-            main.wait_event(ev)
-            for t_ in (both if isinstance(both, tuple) else (both,)):
-                t_.record_stream(main)
+            if ev is not None:                       # produced on the side stream
+                main = torch.cuda.current_stream(dev)
+                main.wait_event(ev)
+                for t_ in (both if isinstance(both, tuple) else (both,)):
+                    t_.record_stream(main)
         else:
             inp = self._gather_inputs(batch_dict, layer_name, dev)
             both = self._image_projection(inp, img_conv_func)

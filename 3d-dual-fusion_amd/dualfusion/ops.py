@@ -38,8 +38,30 @@ def _chk(t, dtype, name):
 
 
 # ------------------------------------------------------------------------- voxelize
+_PINNED_COUNTS = {}
+
+
+def _read_count(count, while_waiting=None):
+    """Value of a 1-element device int32.  With `while_waiting` the copy goes to pinned memory asynchronously, the
+    callback enqueues independent work behind it on the same stream, and only then the host waits for the COPY (an
+    event), not for the work it just queued -- the GPU keeps running while the host learns the count."""
+    if while_waiting is None:
+        return int(count.item())
+    import threading
+    key = (threading.get_ident(), count.device.index)
+    slot = _PINNED_COUNTS.get(key)
+    if slot is None:
+        slot = _PINNED_COUNTS[key] = (torch.empty((1,), dtype=torch.int32).pin_memory(), torch.cuda.Event())
+    host, ev = slot
+    host.copy_(count, non_blocking=True)
+    ev.record()
+    while_waiting()
+    ev.synchronize()
+    return int(host[0])
+
+
 def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels, break_at_cap=True,
-                  want_voxels=True, want_mean=True, batch_index=None):
+                  want_voxels=True, want_mean=True, batch_index=None, while_waiting=None):
     """-> (voxels [M,T,C] or None, coors [M,3] int32 (z,y,x), num [M] int32, mean [M,C] or None).
     One D2H read of the voxel count (the reference op returns it as a Python int too).
     batch_index: when given, coors comes back as [M,4] rows (batch_index, z, y, x), the sparse-tensor layout."""
@@ -66,7 +88,7 @@ def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels, break
                                             int(bool(break_at_cap)), int(batch_index), _ptr(voxels), _ptr(coors),
                                             _ptr(num), _ptr(mean), _ptr(count), _ptr(ws), wsb, _stream())
     _lib.check(rc, "df3d_hard_voxelize")
-    n = int(count.item())
+    n = _read_count(count, while_waiting)
     return (voxels[:n] if voxels is not None else None, coors[:n], num[:n], mean[:n] if mean is not None else None)
 
 

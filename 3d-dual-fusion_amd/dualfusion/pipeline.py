@@ -35,12 +35,14 @@ class CenterPointHotPath(nn.Module):
         self.grid_size_xyz = [int(gs[0]), int(gs[1]), int(gs[2])]
 
     @torch.no_grad()
-    def voxelize(self, points_list):
+    def voxelize(self, points_list, while_waiting=None):
         """list of [P_b, C] device tensors -> (features [M, C], coors [M, 4] (b,z,y,x) int32).
-        CenterPoint voxelises with the numba kernel's cap semantics (point_cloud_ops.py:46-47)."""
+        CenterPoint voxelises with the numba kernel's cap semantics (point_cloud_ops.py:46-47).
+        `while_waiting`: enqueued behind the first sweep's voxelizer while the host waits for its voxel count."""
         feats, coors = [], []
         for b, pts in enumerate(points_list):
-            mean, c, _ = self.voxel_layer.voxelize_mean(pts, break_at_cap=False, batch_index=b)
+            mean, c, _ = self.voxel_layer.voxelize_mean(pts, break_at_cap=False, batch_index=b,
+                                                        while_waiting=while_waiting if b == 0 else None)
             feats.append(mean)
             coors.append(c)
         if len(feats) == 1:
@@ -55,7 +57,13 @@ class CenterPointHotPath(nn.Module):
             # Measured on MI355X it LOSES 3-9 % (the GPU is ~85 % busy already; co-running GEMMs slow the conv
             # kernels more than the filled gaps gain), so it is off by default.
             self.fusion.prefetch(batch_dict, 'layer1_ori')
-        feats, coors = self.voxelize(points_list)
+        early = None
+        if (self.fusion is not None and batch_dict is not None and hasattr(self.fusion, "prefetch_inline")
+                and os.environ.get("DF3D_EARLY_IMGPROJ", "1") == "1" and os.environ.get("DF3D_PREFETCH", "0") != "1"):
+            # the image-side projection depends on the camera maps only: queue it right behind the voxelizer, on the
+            # same stream, so that the GPU has ~250 us of work while the host waits for the voxel count
+            early = lambda: self.fusion.prefetch_inline(batch_dict, 'layer1_ori')   # noqa: E731
+        feats, coors = self.voxelize(points_list, while_waiting=early)
         B = len(points_list)
         if self.fusion is None:
             bev, multi = self.backbone(feats, coors, B, self.grid_size_xyz)

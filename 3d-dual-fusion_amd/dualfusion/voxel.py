@@ -51,12 +51,13 @@ class Voxelization(nn.Module):
     def forward(self, input):
         return voxelization(input, self.voxel_size, self.point_cloud_range, self.max_num_points, self._cap())
 
-    def voxelize_mean(self, points, break_at_cap=True, batch_index=None):
+    def voxelize_mean(self, points, break_at_cap=True, batch_index=None, while_waiting=None):
         """fused voxelise + mean VFE: (mean [M,C], coors [M,3] (z,y,x) -- or [M,4] (b,z,y,x) when `batch_index`
         is given --, num [M])."""
         _, coors, num, mean = _ops.hard_voxelize(points.contiguous().float(), self.voxel_size, self.point_cloud_range,
                                                  self.max_num_points, self._cap(), break_at_cap=break_at_cap,
-                                                 want_voxels=False, want_mean=True, batch_index=batch_index)
+                                                 want_voxels=False, want_mean=True, batch_index=batch_index,
+                                                 while_waiting=while_waiting)
         return mean, coors, num
 
     def __repr__(self):
