@@ -532,15 +532,22 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   // Step s: barrier; W(s+1) (fetched during step s-1) -> LDS; fetch W(s+2); MFMAs of step s; fetch A(s+3).
   auto step = [&](int s, u32x4 (&cur)[RT][KPS][2], u32x4 (&wset)[WPT]) {
     __syncthreads();
-    if (!OS_DBG(2)) {
-      if constexpr (WD == 3) {
-        store_w((s + 1) & 1, wset);
-        load_w(s + 4, wset);
-      } else {
-        store_w((s + 1) & 1, w0);
-        load_w(s + 2, w0);
+    // the next step's weight tile goes to LDS (and the one after the ring is fetched) in the shadow of the first MFMA
+    // batch instead of in front of it: right after the barrier a wave should do nothing but fetch B fragments and issue
+    // matrix instructions (the other buffer is not read by anybody during this step)
+    auto stage_w = [&]() {
+      if (!OS_DBG(2)) {
+        if constexpr (WD == 3) {
+          store_w((s + 1) & 1, wset);
+          load_w(s + 4, wset);
+        } else {
+          store_w((s + 1) & 1, w0);
+          load_w(s + 2, w0);
+        }
       }
-    }
+    };
+    constexpr int WPOS = (KPS * CT / 2) > 1 ? 1 : 0;
+    if (WPOS == 0) stage_w();
     const u32x4 *wb = Wl[s & 1] + lane;
     // B fragments of the next column pair are fetched from LDS while the MFMAs of the current pair run
     constexpr int NBATCH = KPS * CT / 2;
@@ -552,6 +559,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 #pragma unroll
     for (int i = 0; i < NBATCH; ++i) {
       const int j = i / (CT / 2), c2 = (i % (CT / 2)) * 2;
+      if (WPOS > 0 && i == WPOS) stage_w();
       if (i + 1 < NBATCH && !OS_DBG(16)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[(i + 1) & 1][q] = wb[((i + 1) * 4 + q) * 64];
