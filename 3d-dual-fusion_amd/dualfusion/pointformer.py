@@ -12,11 +12,17 @@ layers are plain library GEMMs.  Parameter names follow the reference (`pe.0.con
 """
 import copy
 
+import threading
+import weakref
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from . import ops as _ops
+
+
+_GEO = threading.local()          # last LocalTransformer geometry of this host thread (see LocalTransformer._geometry)
 
 
 class ConvModule(nn.Module):
@@ -129,16 +135,30 @@ class LocalTransformer(nn.Module):
         else:
             raise NotImplementedError(self.attn_feat_agg_method)
 
-    def forward(self, xyz, features):
-        """xyz [B,N,3], features [B,C,N] (may be a permuted view: 'replace' writes through it, as the
-        reference does) -> [B,N,C]."""
-        xyz = xyz.contiguous()
-        feats_c = features.contiguous()
+    def _geometry(self, xyz_in):
+        """FPS centres, ball-query neighbourhoods and grouped coordinates.  They depend on the point coordinates and on
+        (npoint, radius, nsample) only, and the ACTRv2 encoder hands the SAME coordinate tensor to the LocalTransformer
+        of every layer (actr_transformer.py:482-486): the result of the first layer is reused by the others (the
+        reference recomputes it -- 2048 serial FPS iterations -- once per layer)."""
+        key = (self.npoint, float(self.radius), self.nsample, xyz_in._version, tuple(xyz_in.shape))
+        hit = getattr(_GEO, "entry", None)
+        if hit is not None and hit[0]() is xyz_in and hit[1] == key and not torch.is_grad_enabled():
+            return hit[2], hit[3]
+        xyz = xyz_in.contiguous()
         fps_idx = _ops.furthest_point_sample(xyz, self.npoint)                          # [B,np]
         xyz_t = xyz.transpose(1, 2).contiguous()
         new_xyz = _ops.gather_points(xyz_t, fps_idx).transpose(1, 2).contiguous()       # [B,np,3]
         group_idx = _ops.ball_query(0.0, self.radius, self.nsample, xyz, new_xyz)       # [B,np,ns]
         group_xyz = _ops.group_points(xyz_t, group_idx)                                 # [B,3,np,ns] (absolute)
+        if not torch.is_grad_enabled():
+            _GEO.entry = (weakref.ref(xyz_in), key, group_idx, group_xyz)
+        return group_idx, group_xyz
+
+    def forward(self, xyz, features):
+        """xyz [B,N,3], features [B,C,N] (may be a permuted view: 'replace' writes through it, as the
+        reference does) -> [B,N,C]."""
+        feats_c = features.contiguous()
+        group_idx, group_xyz = self._geometry(xyz)
         group_features = _ops.group_points(feats_c, group_idx)                          # [B,C,np,ns]
         x = group_features + self.pe(group_xyz)
         B, D, np_, ns = x.shape
