@@ -12,6 +12,8 @@ The reference projects voxel centres with per-sample nuScenes-devkit DB lookups 
   per-query image feature = level-0 map at (pixel // 4) (:375-378)
   write-back   pts_feats + enh (fusion_method 'sum'), one contribution per voxel (:482-491)
 """
+import os
+
 import torch
 from torch import nn
 
@@ -107,6 +109,32 @@ class ACTRFusionLayer(nn.Module):
         v_i_feat[seg, slot] = img_feats[0][seg, :, ic[:, 1], ic[:, 0]]
         return v_feat, v_i_feat, grid, qpts, seg, slot
 
+    def _actr(self, v_feat, grid, img_feats, qpts, v_i_feat):
+        """ACTR on the assembled queries.  Inference with the 3D-DF configuration (one 256-channel level, two dual-query
+        layers) takes the fold-through path of the CenterPoint adapter: the input projection runs on the matrix cores
+        straight from the channel-first camera maps (csrc/imgproj.hip) and GroupNorm + both value projections are
+        one folded GEMM -- no [B*6, 256, H, W] permute / copy, no normalised image map (the module composition made
+        five 550 MB copies per step at bs = 4)."""
+        from . import ops as _ops
+        f0 = img_feats[0]
+        actr = self.actr
+        if (len(img_feats) == 1 and f0.is_cuda and f0.dtype == torch.float32 and f0.is_contiguous() and actr.can_fold()
+                and len(actr.transformer.encoder.layers) == 2 and f0.shape[1] == 256
+                and _ops.imgproj_supported(actr.input_proj[0][0].weight.shape[0], 256, actr.input_proj[0][1].num_channels)
+                and os.environ.get("DF3D_IMGPROJ", "1") == "1"):
+            NI, Ci, H, W = f0.shape
+            w = actr.input_proj[0][0].weight
+            key = (w.data_ptr(), w._version)
+            if getattr(self, "_wpack", None) is None or self._wpack[0] != key:
+                self._wpack = (key, _ops.imgproj_pack(w[:, :, 0, 0].contiguous()))
+            pkey = (f0.data_ptr(), NI, Ci * H * W)
+            if getattr(self, "_ptrs", None) is None or self._ptrs[0] != pkey:
+                base, step = f0.data_ptr(), Ci * H * W * 4
+                self._ptrs = (pkey, torch.tensor([base + i * step for i in range(NI)], dtype=torch.int64, device=f0.device))
+            u, _ = _ops.imgproj_split(self._ptrs[1], NI, Ci, H * W, self._wpack[1])
+            return actr.forward_folded(v_feat, grid, u, None, (H, W), v_i_feat, qpts)
+        return actr(v_feat=v_feat, grid=grid, i_feats=img_feats, lidar_grid=qpts, v_i_feat=v_i_feat)
+
     def forward(self, img_feats, pts, pts_feats, img_metas, imgs=None):
         """pts: [N,4] (b,x,y,z) tensor from SparseEncoderFusion.coor2pts (or the reference's list of
         per-sample [n_b,3] tensors); pts_feats [N,C].  Returns fused [N,C]."""
@@ -123,7 +151,7 @@ class ACTRFusionLayer(nn.Module):
                              "%dx%d, got %dx%d" % (ih, iw, -(-ih // 4), -(-iw // 4), fh, fw))
         cam_id, norm, pix = self.project(pts, img_metas)
         v_feat, v_i_feat, grid, qpts, seg, slot = self.assemble(img_feats, pts, pts_feats, cam_id, norm, pix, batch_size)
-        enh = self.actr(v_feat=v_feat, grid=grid, i_feats=img_feats, lidar_grid=qpts, v_i_feat=v_i_feat)
+        enh = self._actr(v_feat, grid, img_feats, qpts, v_i_feat)
         enh_cat = enh[seg, slot]
         if self.fusion_method == 'replace':
             out = enh_cat
