@@ -47,6 +47,10 @@ def dense(cin, cout, H, W, k=3, stride=1, groups=1, tag=""):
         tag, cin, cout, groups, n_out, k * k, us, fl / us / 1e6, fl / us / 1e6 / 833 * 100))
 
 
+if os.environ.get("DF3D_PROBE_K1", "0") == "1":
+    dense(128, 128, 180, 180, k=1, tag="1x1 (fixed cost probe)")
+    dense(128, 128, 90, 90, k=1, tag="1x1 quarter rows")
+    dense(128, 128, 90, 90, k=3, tag="3x3 quarter rows")
 dense(128, 128, 180, 180, tag="neck block 1")
 dense(256, 256, 90, 90, tag="neck block 2")
 dense(256, 128, 180, 180, tag="neck first")
