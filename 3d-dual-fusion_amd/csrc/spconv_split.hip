@@ -46,6 +46,59 @@ __device__ __forceinline__ void split2(float x, unsigned &hi, unsigned &lo) {
   lo = bf16_bits(x - __uint_as_float(hi << 16));
 }
 
+__device__ __forceinline__ float bf16lo_to_f32(unsigned packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(unsigned packed) { return __uint_as_float(packed & 0xffff0000u); }
+
+// ---- fp32 rows -> bf16 rows (round to nearest even; the `hi` half of the split) --------------------------
+__global__ __launch_bounds__(256) void bf16_rows_kernel(const float *__restrict__ x, size_t nblk, u32x4 *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblk) return;
+  f32x4 a = ((const f32x4 *)x)[2 * i], b = ((const f32x4 *)x)[2 * i + 1];
+  u32x4 ho;
+  unsigned lo;
+  split_pair(a[0], a[1], ho[0], lo);
+  split_pair(a[2], a[3], ho[1], lo);
+  split_pair(b[0], b[1], ho[2], lo);
+  split_pair(b[2], b[3], ho[3], lo);
+  out[i] = ho;
+}
+
+// bf16 rows -> fp32 rows
+__global__ __launch_bounds__(256) void bf16_rows_to_f32_kernel(const u32x4 *__restrict__ x, size_t nblk, float *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblk) return;
+  const u32x4 v = x[i];
+  ((f32x4 *)out)[2 * i] = (f32x4){bf16lo_to_f32(v[0]), bf16hi_to_f32(v[0]), bf16lo_to_f32(v[1]), bf16hi_to_f32(v[1])};
+  ((f32x4 *)out)[2 * i + 1] = (f32x4){bf16lo_to_f32(v[2]), bf16hi_to_f32(v[2]), bf16lo_to_f32(v[3]), bf16hi_to_f32(v[3])};
+}
+
+// W[K][CIN][COUT] fp32 -> bf16 B operands of the output-stationary kernel (NP = 1): [k][kb][ct][lane], same lane ->
+// (column, channel) map as layout 1 of pack_weights_kernel, hi parts only
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float *__restrict__ w, int K, int cin, int cout,
+                                                                u32x4 *__restrict__ out) {
+  const int KB = cin / 32;
+  size_t total = (size_t)K * cin * cout / 8;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  size_t r = i >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int CW = cout > 128 ? 128 : cout, CT = CW / 16;
+  const int ct = (int)(r % CT); r /= CT;
+  const int kb = (int)(r % KB); r /= KB;
+  const int k = (int)(r % K);
+  const int col = (int)(r / K) * CW + n * CT + ct;
+  const int ch0 = kb * 32 + g * 8;
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned h, l;
+    split_pair(w[((size_t)k * cin + ch0 + 2 * e) * cout + col], w[((size_t)k * cin + ch0 + 2 * e + 1) * cout + col], h, l);
+    o[e] = h;
+  }
+  out[i] = o;
+}
+
 // ---- fp32 rows -> split rows ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ x, size_t nblk,
                                                          u32x4 *__restrict__ out) {
@@ -420,14 +473,17 @@ __device__ u32x4 g_zero_row[128];          // up to 512 input channels
 // barrier per step), A fragments (32 B of split row per lane) straight from L2/HBM one step ahead.  MFMAs are
 // also issued for rows without a neighbour at an offset (zero operands) -- at 3/16 of the fp32 cost that waste
 // is cheaper than the pair compaction -- and several workgroups per CU hide the gather latency.
-template <int CIN, int COUT, int RT, int NW, int KPS>
+// NP = precision parts of the operands: 2 = fp32 rows split into bf16 hi + lo (three MFMA products per pair, fp32-grade
+// result), 1 = plain bf16 rows and bf16 weights (one product, fp32 accumulate; rows are [N][C] bf16, the packed filter
+// bank holds the hi parts only, `out_split` receives bf16 rows and `residual` is read as bf16 rows).
+template <int CIN, int COUT, int RT, int NW, int KPS, int NP = 2>
 __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs a) {
   // KPS = 32-channel blocks per step (one barrier per step)
   // COUT = 256 is computed as two 128-column halves by different workgroups (blockIdx.y): twice the workgroups for
   // the small dense maps of the BEV neck and half the accumulator registers; the gathers of the second half hit L2
   constexpr int CW = COUT > 128 ? 128 : COUT;
   constexpr int KB = CIN / 32 / KPS, CT = CW / 16, TM = 16 * RT * NW, WROWS = 16 * RT, RQ = CIN / 4;
-  constexpr int WQ = KPS * CT * 2 * 64;           // u32x4 per W step tile
+  constexpr int WQ = KPS * CT * NP * 64;          // u32x4 per W step tile
   constexpr int NT = NW * 64;
   constexpr int WPT = (WQ + NT - 1) / NT;
   __shared__ u32x4 Wl[2][WQ];
@@ -511,8 +567,8 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       if (WQ % NT == 0 || e < WQ) Wl[buf][e] = wreg[i];
     }
   };
-  u32x4 a0[RT][KPS][2], a1[RT][KPS][2], a2[RT][KPS][2];
-  auto load_a = [&](int s, u32x4 (&dst)[RT][KPS][2]) {
+  u32x4 a0[RT][KPS][NP], a1[RT][KPS][NP], a2[RT][KPS][NP];
+  auto load_a = [&](int s, u32x4 (&dst)[RT][KPS][NP]) {
     const bool live = s < steps;
     const int sc = live ? s : 0;
     const int k = __builtin_amdgcn_readfirstlane(actL[sc / KB]), kb = (sc % KB) * KPS;
@@ -521,16 +577,16 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       int idx = nbrL[k][wave * WROWS + rt * 16 + n];
       const u32x4 *p = (live && idx >= 0 && !OS_DBG(1)) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff
                                                           : g_zero_row;
-      p += (kb * 4 + g) * 2;
+      p += (kb * 4 + g) * NP;
 #pragma unroll
       for (int j = 0; j < KPS; ++j) {
-        dst[rt][j][0] = p[j * 8];
-        dst[rt][j][1] = p[j * 8 + 1];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dst[rt][j][q] = p[j * 4 * NP + q];
       }
     }
   };
   // Step s: barrier; W(s+1) (fetched during step s-1) -> LDS; fetch W(s+2); MFMAs of step s; fetch A(s+3).
-  auto step = [&](int s, u32x4 (&cur)[RT][KPS][2], u32x4 (&wset)[WPT]) {
+  auto step = [&](int s, u32x4 (&cur)[RT][KPS][NP], u32x4 (&wset)[WPT]) {
     __syncthreads();
     // the next step's weight tile goes to LDS (and the one after the ring is fetched) in the shadow of the first MFMA
     // batch instead of in front of it: right after the barrier a wave should do nothing but fetch B fragments and issue
@@ -551,10 +607,10 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     const u32x4 *wb = Wl[s & 1] + lane;
     // B fragments of the next column pair are fetched from LDS while the MFMAs of the current pair run
     constexpr int NBATCH = KPS * CT / 2;
-    u32x4 bq[2][4];
+    u32x4 bq[2][2 * NP];
     if (!OS_DBG(16)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bq[0][q] = wb[q * 64];
+      for (int q = 0; q < 2 * NP; ++q) bq[0][q] = wb[q * 64];
     }
 #pragma unroll
     for (int i = 0; i < NBATCH; ++i) {
@@ -562,21 +618,30 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       if (WPOS > 0 && i == WPOS) stage_w();
       if (i + 1 < NBATCH && !OS_DBG(16)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[(i + 1) & 1][q] = wb[((i + 1) * 4 + q) * 64];
+        for (int q = 0; q < 2 * NP; ++q) bq[(i + 1) & 1][q] = wb[((i + 1) * 2 * NP + q) * 64];
       }
-      u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][1], bh1 = bq[i & 1][2], bl1 = bq[i & 1][3];
+      if constexpr (NP == 1) {
+        const u32x4 b0 = bq[i & 1][0], b1 = bq[i & 1][1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][0], b0, acc[rt][c2]);
+          acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][0], b1, acc[rt][c2 + 1]);
+        }
+        continue;
+      }
+      u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][NP == 2 ? 1 : 0], bh1 = bq[i & 1][NP == 2 ? 2 : 0], bl1 = bq[i & 1][NP == 2 ? 3 : 0];
       if (OS_DBG(16)) {                    // experiment: MFMAs without the LDS reads of their B operands
         bh0 = cur[0][j][0];
-        bl0 = cur[0][j][1];
+        bl0 = cur[0][j][NP - 1];
         bh1 = cur[0][j][0];
-        bl1 = cur[0][j][1];
+        bl1 = cur[0][j][NP - 1];
       }
       if (OS_DBG(4)) continue;
       if (OS_DBG(8)) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][1], bh0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][1], bh1, acc[rt][c2 + 1]);
+        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][NP - 1], bh0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][NP - 1], bh1, acc[rt][c2 + 1]);
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
@@ -642,9 +707,15 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         }
         const size_t o = (size_t)row * a.ldo + col;
         if (a.residual) {
-          const float2 rr = *(const float2 *)(a.residual + o);
-          v.x += rr.x;
-          v.y += rr.y;
+          if constexpr (NP == 1) {
+            const unsigned rr = *(const unsigned *)((const char *)a.residual + o * 2);
+            v.x += bf16lo_to_f32(rr);
+            v.y += bf16hi_to_f32(rr);
+          } else {
+            const float2 rr = *(const float2 *)(a.residual + o);
+            v.x += rr.x;
+            v.y += rr.y;
+          }
         }
         if (a.relu) {
           v.x = fmaxf(v.x, 0.f);
@@ -654,6 +725,10 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         if (a.out_split) {
           unsigned hp, lp;
           split_pair(v.x, v.y, hp, lp);
+          if constexpr (NP == 1) {
+            *(unsigned *)((char *)a.out_split + o * 2) = hp;
+            continue;
+          }
           char *blk = (char *)a.out_split + (o >> 3) * 32 + (n & 3) * 4;     // 8-channel block = [hi 16 B | lo 16 B]
           *(unsigned *)blk = hp;
           *(unsigned *)(blk + 16) = lp;
@@ -683,7 +758,14 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       for (int q = 0; q < CT / 4; ++q) {
         f32x4 v = (f32x4){acc[rt][q * 4][r], acc[rt][q * 4 + 1][r], acc[rt][q * 4 + 2][r], acc[rt][q * 4 + 3][r]};
         v = (v + bi[q]) * sc[q] + sh[q];
-        if (a.residual) v += *(const f32x4 *)(a.residual + o + q * 4);
+        if (a.residual) {
+          if constexpr (NP == 1) {
+            const u32x2 rr = *(const u32x2 *)((const char *)a.residual + (o + q * 4) * 2);
+            v += (f32x4){bf16lo_to_f32(rr[0]), bf16hi_to_f32(rr[0]), bf16lo_to_f32(rr[1]), bf16hi_to_f32(rr[1])};
+          } else {
+            v += *(const f32x4 *)(a.residual + o + q * 4);
+          }
+        }
         if (a.relu) {
           v[0] = fmaxf(v[0], 0.f);
           v[1] = fmaxf(v[1], 0.f);
@@ -696,7 +778,11 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
           split_pair(v[2], v[3], h[q * 2 + 1], l[q * 2 + 1]);
         }
       }
-      if (a.out_split) {
+      if (a.out_split && NP == 1) {                                   // bf16 rows: this lane's CT columns
+        char *dst = (char *)a.out_split + o * 2;
+        if constexpr (CT == 8) *(u32x4 *)dst = (u32x4){h[0], h[1], h[2], h[3]};
+        else *(u32x2 *)dst = (u32x2){h[0], h[1]};
+      } else if (a.out_split) {
         char *blk = (char *)a.out_split + (o >> 3) * 32;             // 8-channel block = [hi 16 B | lo 16 B]
         if constexpr (CT == 8) {
           *(u32x4 *)blk = (u32x4){h[0], h[1], h[2], h[3]};
@@ -837,6 +923,34 @@ static bool split_shape_ok(int cin, int cout) {
           split_layout(cin, cout) == 1);
 }
 
+// bf16 rows / bf16 weights (NP = 1): one configuration per shape (8 waves, or 2 for small row counts)
+template <int CIN, int COUT>
+static int launch_os_bf16(const SplitConvArgs &a, hipStream_t stream) {
+  if ((long long)a.n_out * a.gy >= 16 * 1024)
+    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 8, 1, 1>), dim3(cdiv(a.n_out, 128), a.gy), dim3(512), 0, stream, a);
+  else
+    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 2, 1, 1>), dim3(cdiv(a.n_out, 32), a.gy), dim3(128), 0, stream, a);
+  return DF3D_OK;
+}
+
+static bool bf16_shape_ok(int cin, int cout) {
+  return (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 64 || cout == 128)) ||
+         (cin == 128 && (cout == 128 || cout == 256)) || (cin == 256 && (cout == 128 || cout == 256));
+}
+
+static int launch_os_bf16_any(int cin, int cout, const SplitConvArgs &a, hipStream_t stream) {
+  if (cin == 32 && cout == 32) return launch_os_bf16<32, 32>(a, stream);
+  if (cin == 32 && cout == 64) return launch_os_bf16<32, 64>(a, stream);
+  if (cin == 64 && cout == 64) return launch_os_bf16<64, 64>(a, stream);
+  if (cin == 64 && cout == 128) return launch_os_bf16<64, 128>(a, stream);
+  if (cin == 128 && cout == 128) return launch_os_bf16<128, 128>(a, stream);
+  if (cin == 128 && cout == 256) return launch_os_bf16<128, 256>(a, stream);
+  if (cin == 256 && cout == 128) return launch_os_bf16<256, 128>(a, stream);
+  if (cin == 256 && cout == 256) return launch_os_bf16<256, 256>(a, stream);
+  set_error("no bf16 kernel for cin=%d cout=%d", cin, cout);
+  return DF3D_EINVAL;
+}
+
 static int launch_os_any(int cin, int cout, const SplitConvArgs &a, hipStream_t stream) {
   if (cin == 256 && cout == 256) return launch_os_split_wide<256, 256>(a, stream);
   if (cin == 256 && cout == 128) return launch_os_split_wide<256, 128>(a, stream);
@@ -945,6 +1059,69 @@ extern "C" int df3d_conv_rows_split(const void *in_split, int n_in, int in_chann
                      getenv("DF3D_OS_DBG") ? atoi(getenv("DF3D_OS_DBG")) : 0, in_channels / 4, in_group_stride / 4, out_channels, blocks, out_cols};
   int rec = timing_rec_begin(cin, cout * groups, kvol, n_out, nbr, 1, stream);
   int rc = launch_os_any(cin, cout, a, stream);
+  if (rc) return rc;
+  timing_rec_end(rec, stream);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+// ---- bf16 rows / bf16 weights, fp32 accumulate (BASELINE configs[2]: "bf16, fp32 accumulate") -------------------
+extern "C" int df3d_rows_to_bf16(const float *features, long long n, int c, void *rows_bf16, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(c > 0 && c % 8 == 0 && n >= 0, "rows_to_bf16: channels must be a multiple of 8 (got %d)", c);
+  size_t nblk = (size_t)n * c / 8;
+  if (nblk == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(features && rows_bf16, "rows_to_bf16: null argument");
+  hipLaunchKernelGGL(bf16_rows_kernel, dim3(cdiv((long long)nblk, 256)), dim3(256), 0, stream, features, nblk,
+                     (u32x4 *)rows_bf16);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_rows_from_bf16(const void *rows_bf16, long long n, int c, float *features, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(c > 0 && c % 8 == 0 && n >= 0, "rows_from_bf16: channels must be a multiple of 8 (got %d)", c);
+  size_t nblk = (size_t)n * c / 8;
+  if (nblk == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(features && rows_bf16, "rows_from_bf16: null argument");
+  hipLaunchKernelGGL(bf16_rows_to_f32_kernel, dim3(cdiv((long long)nblk, 256)), dim3(256), 0, stream,
+                     (const u32x4 *)rows_bf16, nblk, features);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" size_t df3d_conv_packed_weight_bytes_bf16(int kvol, int cin, int cout) {
+  if (!bf16_shape_ok(cin, cout) || kvol <= 0 || kvol > DF3D_MAX_KVOL) return 0;
+  return (size_t)kvol * cin * cout * 2;
+}
+
+extern "C" int df3d_conv_pack_weights_bf16(const float *filters, int kvol, int cin, int cout, void *packed,
+                                           void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(filters && packed, "conv_pack_weights_bf16: null argument");
+  DF3D_CHECK_ARG(df3d_conv_packed_weight_bytes_bf16(kvol, cin, cout) != 0,
+                 "conv_pack_weights_bf16: shape K=%d cin=%d cout=%d has no bf16 kernel", kvol, cin, cout);
+  size_t total = (size_t)kvol * cin * cout / 8;
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, stream, filters, kvol,
+                     cin, cout, (u32x4 *)packed);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_sparse_conv_bf16(const void *features_bf16, int n_in, int cin, const void *packed_filters, int kvol,
+                                     int cout, const int32_t *nbr, int n_out, const float *bias, const float *scale,
+                                     const float *shift, const void *residual_bf16, int relu, float *out,
+                                     void *out_bf16, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(features_bf16 && packed_filters && nbr && (out || out_bf16), "sparse_conv_bf16: null argument");
+  DF3D_CHECK_ARG(kvol > 0 && kvol <= DF3D_MAX_KVOL, "sparse_conv_bf16: kernel volume %d unsupported", kvol);
+  DF3D_CHECK_ARG(bf16_shape_ok(cin, cout), "sparse_conv_bf16: cin=%d cout=%d has no bf16 kernel", cin, cout);
+  if (n_out == 0) return DF3D_OK;
+  SplitConvArgs a = {(const u32x4 *)features_bf16, (const u32x4 *)packed_filters, nbr, bias, scale, shift,
+                     (const float *)residual_bf16, out, (u32x4 *)out_bf16, n_in, n_out, kvol, relu, 0,
+                     cin / 8, 0, cout, cout > 128 ? cout / 128 : 1, nullptr};
+  int rec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 2, stream);
+  int rc = launch_os_bf16_any(cin, cout, a, stream);
   if (rc) return rc;
   timing_rec_end(rec, stream);
   DF3D_LAUNCH_CHECK();

@@ -88,6 +88,12 @@ SIGNATURES = {
     "df3d_timing_get2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_sparse_to_dense_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_conv2d_neighbors": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_rows_to_bf16": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
+    "df3d_rows_from_bf16": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
+    "df3d_conv_packed_weight_bytes_bf16": (c_size_t, [c_int, c_int, c_int]),
+    "df3d_conv_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_sparse_conv_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_invert_neighbors": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_sparse_conv_grad_filters": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                               c_void_p]),

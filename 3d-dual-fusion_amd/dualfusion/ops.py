@@ -340,6 +340,69 @@ def sparse_conv_split(features_split, packed, nbr, n_out, cin, cout, bias=None, 
     return out, out_split
 
 
+# ---- bf16 rows / bf16 weights (BASELINE configs[2]: bf16 with fp32 accumulate) ------------------------------------
+def conv_bf16_supported(kvol, cin, cout):
+    return _lib.load().df3d_conv_packed_weight_bytes_bf16(int(kvol), int(cin), int(cout)) > 0
+
+
+def rows_to_bf16(features):
+    """fp32 [n, c] -> torch.bfloat16 [n, c] (round to nearest even)."""
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    n, c = features.shape
+    out = torch.empty((n, c), dtype=torch.bfloat16, device=features.device)
+    _lib.check(lib.df3d_rows_to_bf16(_ptr(features), n, c, _ptr(out), _stream()), "df3d_rows_to_bf16")
+    return out
+
+
+def rows_from_bf16(rows):
+    lib = _lib.load()
+    _chk(rows, torch.bfloat16, "rows")
+    n, c = rows.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=rows.device)
+    _lib.check(lib.df3d_rows_from_bf16(_ptr(rows), n, c, _ptr(out), _stream()), "df3d_rows_from_bf16")
+    return out
+
+
+def conv_pack_weights_bf16(filters):
+    """filters [K, cin, cout] fp32 -> packed bf16 MFMA operands (uint8 buffer)."""
+    lib = _lib.load()
+    _chk(filters, torch.float32, "filters")
+    K, cin, cout = filters.shape
+    nbytes = lib.df3d_conv_packed_weight_bytes_bf16(K, cin, cout)
+    if nbytes == 0:
+        raise _lib.Df3dError("no bf16 conv kernel for K=%d cin=%d cout=%d" % (K, cin, cout))
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=filters.device)
+    _lib.check(lib.df3d_conv_pack_weights_bf16(_ptr(filters), K, cin, cout, _ptr(packed), _stream()),
+               "df3d_conv_pack_weights_bf16")
+    return packed
+
+
+def sparse_conv_bf16(rows, packed, nbr, n_out, cin, cout, bias=None, scale=None, shift=None, residual=None, relu=False,
+                     want_f32=False, want_bf16=True):
+    """bf16 twin of sparse_conv_fused: rows / residual torch.bfloat16 [n, c]; -> (out fp32 or None, out bf16 or None)."""
+    lib = _lib.load()
+    _chk(rows, torch.bfloat16, "rows")
+    _chk(packed, torch.uint8, "packed")
+    _chk(nbr, torch.int32, "nbr")
+    K = nbr.shape[0]
+    if rows.shape[1] != cin or packed.numel() != K * cin * cout * 2:
+        raise _lib.Df3dError("bf16 operands do not match K=%d cin=%d cout=%d" % (K, cin, cout))
+    for t, nm in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+    if residual is not None:
+        _chk(residual, torch.bfloat16, "residual")
+    dev = nbr.device
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev) if want_f32 else None
+    ob = torch.empty((n_out, cout), dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    rc = lib.df3d_sparse_conv_bf16(_ptr(rows), rows.shape[0], cin, _ptr(packed), K, cout, _ptr(nbr), int(n_out),
+                                   _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out),
+                                   _ptr(ob), _stream())
+    _lib.check(rc, "df3d_sparse_conv_bf16")
+    return out, ob
+
+
 def invert_neighbors(nbr, n_in):
     """nbr [K, n_out] (input row of output o at offset k, -1 = none) -> inv [K, n_in] (output row fed by input i)."""
     lib = _lib.load()

@@ -186,6 +186,20 @@ int df3d_sparse_to_dense_rows(const float *features, const int32_t *indices, int
 int df3d_conv2d_neighbors(int batch, int H, int W, int kh, int kw, int stride, int pad, int transposed,
                           int32_t *nbr, void *stream);
 
+/* bf16 variant of the fused sparse convolution (BASELINE configs[2]/[3]: "bf16, fp32 accumulate"): feature rows are
+ * [N][C] bf16 (C % 8 == 0), the packed filter bank holds bf16 weights, one MFMA product per operand pair, fp32
+ * accumulation and fp32 epilogue (bias, folded BN, residual -- read as bf16 rows --, ReLU), output as bf16 rows
+ * (out_bf16) and / or fp32 rows (out); either may be NULL.  Half the gather / store bytes and a third of the matrix
+ * instructions of df3d_sparse_conv_split.  Served (cin, cout): 32->32/64, 64->64/128, 128->128/256, 256->128/256.
+ *   df3d_rows_to_bf16 / df3d_rows_from_bf16: fp32 rows <-> bf16 rows (round to nearest even). */
+int df3d_rows_to_bf16(const float *features, long long n, int c, void *rows_bf16, void *stream);
+int df3d_rows_from_bf16(const void *rows_bf16, long long n, int c, float *features, void *stream);
+size_t df3d_conv_packed_weight_bytes_bf16(int kvol, int cin, int cout);
+int df3d_conv_pack_weights_bf16(const float *filters, int kvol, int cin, int cout, void *packed, void *stream);
+int df3d_sparse_conv_bf16(const void *features_bf16, int n_in, int cin, const void *packed_filters, int kvol, int cout,
+                          const int32_t *nbr, int n_out, const float *bias, const float *scale, const float *shift,
+                          const void *residual_bf16, int relu, float *out, void *out_bf16, void *stream);
+
 /* Sparse convolution backward.  Replace sparse_conv_ext.indice_conv_backward_fp32
  * (TF/mmdet3d/ops/spconv/src/all.cc:21-51, include/spconv/spconv_ops.h:363-456):
  *   input gradient  = df3d_sparse_conv_fused(grad_out, filters^T per offset [K][Cout][Cin], inverse table, n_in) -- the

@@ -557,3 +557,41 @@ def test_msda_backward_full_size_properties(dev):
     lhs = float((out.double() * g1.double()).sum())
     rhs = float((a[2].double() * aw.double()).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))
+
+
+# ------------------------------------------------------------------------- bf16 convolution (BASELINE configs[2])
+@pytest.mark.parametrize("cin,cout,n_seeds,ks,st,subm", [(128, 128, 14, 3, 1, 1), (64, 64, 9, 3, 1, 1), (32, 64, 9, 3, 2, 0),
+                                                        (64, 128, 6, 3, 2, 0), (32, 32, 4, 3, 1, 1)])
+def test_conv_bf16_equals_fp32_kernel_on_rounded_operands(dev, cin, cout, n_seeds, ks, st, subm):
+    """df3d_sparse_conv_bf16 (bf16 rows, bf16 weights, fp32 accumulate, fused BN / residual / ReLU) against the exact
+    fp32 kernel fed the SAME bf16-rounded operands: products of bf16 numbers are exact in fp32, so only the
+    accumulation order differs (<= 2e-5 of the output scale); the bf16 output rows are the RNE rounding of it."""
+    from dualfusion import ops
+    from dualfusion.spconv import ops as sops
+    shape, batch = [9, 40, 44], 2
+    ind = detgen.clustered_voxels("bfc%d" % n_seeds, batch, shape, n_seeds=n_seeds, walk=220)
+    it = T(ind, dev)
+    outids, nbr, _, _ = sops.build_rulebook(it, batch, shape, [ks] * 3, [st] * 3, [1] * 3, [1] * 3, bool(subm))
+    n_out = outids.shape[0]
+    f = T(detgen.randn("bfc_f%d_%d" % (cin, n_seeds), (len(ind), cin)), dev)
+    w = T(detgen.randn("bfc_w%d_%d" % (cin, cout), (ks ** 3, cin, cout), 0.1), dev)
+    bias, scale, shift = (T(detgen.randn("bfc_%s%d" % (nm, cout), (cout,), 0.3), dev) for nm in "bsh")
+    scale = scale + 1.0
+    res = T(detgen.randn("bfc_r%d_%d" % (cout, n_seeds), (n_out, cout)), dev)
+    fb, rb = ops.rows_to_bf16(f), ops.rows_to_bf16(res)
+    assert torch.equal(fb, f.to(torch.bfloat16)) and torch.equal(ops.rows_from_bf16(fb), fb.float())
+    wb = w.to(torch.bfloat16).float()
+    want = ops.sparse_conv_fused(fb.float(), wb, nbr, n_out, bias=bias, scale=scale, shift=shift, residual=rb.float(),
+                                 relu=True)
+    got32, got16 = ops.sparse_conv_bf16(fb, ops.conv_pack_weights_bf16(w), nbr, n_out, cin, cout, bias=bias, scale=scale,
+                                        shift=shift, residual=rb, relu=True, want_f32=True, want_bf16=True)
+    err = float((got32 - want).abs().max() / want.abs().max())
+    assert err <= 2e-5, err
+    assert torch.equal(got16, got32.to(torch.bfloat16))
+    # bf16-only output (no fp32 copy) and no epilogue operands
+    _, only16 = ops.sparse_conv_bf16(fb, ops.conv_pack_weights_bf16(w), nbr, n_out, cin, cout)
+    plain = ops.sparse_conv_fused(fb.float(), wb, nbr, n_out)
+    assert float((only16.float() - plain).abs().max() / plain.abs().max()) <= 5e-3      # bf16 rounding of the result
+    # vs the fp32 operands: the bf16 path's error is the operand rounding (~2^-9 per term, averaging out)
+    full = ops.sparse_conv_fused(f, w, nbr, n_out)
+    assert float((plain - full).abs().max() / full.abs().max()) <= 2e-2

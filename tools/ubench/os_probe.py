@@ -43,8 +43,13 @@ def dense(cin, cout, H, W, k=3, stride=1, groups=1, tag=""):
         us = timeit(lambda: ops.conv_rows_split(fs, cin, 0, packed, cout, groups, nbr, n_out, relu=True, want_out=False,
                                                 want_split=True))
     fl = 2.0 * n_out * k * k * cin * cout * groups
-    print("%-28s %4d->%4dx%-2d rows %6d K=%2d : %7.1f us  %6.1f TF fp32-eq (%4.1f%% of the bf16/3 roof)" % (
-        tag, cin, cout, groups, n_out, k * k, us, fl / us / 1e6, fl / us / 1e6 / 833 * 100))
+    extra = ""
+    if groups == 1 and ops.conv_bf16_supported(k * k, cin, cout):
+        fb, pb = ops.rows_to_bf16(f), ops.conv_pack_weights_bf16(w)
+        usb = timeit(lambda: ops.sparse_conv_bf16(fb, pb, nbr, n_out, cin, cout, relu=True))
+        extra = " | bf16 %6.1f us (%5.1f TF)" % (usb, fl / usb / 1e6)
+    print("%-28s %4d->%4dx%-2d rows %6d K=%2d : %7.1f us  %6.1f TF fp32-eq (%4.1f%% of the bf16/3 roof)%s" % (
+        tag, cin, cout, groups, n_out, k * k, us, fl / us / 1e6, fl / us / 1e6 / 833 * 100, extra))
 
 
 if os.environ.get("DF3D_PROBE_K1", "0") == "1":
@@ -76,5 +81,7 @@ if os.environ.get("DF3D_PROBE_SPARSE", "1") == "1":
         packed = ops.conv_pack_weights(w)
         us = timeit(lambda: ops.sparse_conv_split(fs, packed, rb.nbr, n, C, C, relu=True))
         ab = R * C * 4 + 2 * n * C * 4 + rb.nbr.numel() * 4 + w.numel() * 4
-        print("%-28s %4d->%4d    rows %6d K=27 pairs/row %.1f : %7.1f us  %6.1f TF useful, %.2f TB/s algorithmic" % (
-            "backbone " + stage, C, C, n, R / n, us, 2.0 * R * C * C / us / 1e6, ab / us / 1e6))
+        fb, pb = ops.rows_to_bf16(x.features.contiguous()), ops.conv_pack_weights_bf16(w)
+        usb = timeit(lambda: ops.sparse_conv_bf16(fb, pb, rb.nbr, n, C, C, relu=True))
+        print("%-28s %4d->%4d    rows %6d K=27 pairs/row %.1f : %7.1f us  %6.1f TF useful, %.2f TB/s algorithmic | bf16 %6.1f us" % (
+            "backbone " + stage, C, C, n, R / n, us, 2.0 * R * C * C / us / 1e6, ab / us / 1e6, usb))
