@@ -139,8 +139,12 @@ class SparseConvolution(SparseModule):
         return rb
 
     def forward_fused(self, input, scale=None, shift=None, relu=False, residual=None):
-        """out = act((conv(x) + bias) * scale + shift + residual): the conv kernel's epilogue."""
+        """out = act((conv(x) + bias) * scale + shift + residual): the conv kernel's epilogue.  `residual`: fp32 rows
+        or the SparseConvTensor that holds them (lets the bf16 mode reuse its bf16 rows)."""
         assert isinstance(input, SparseConvTensor)
+        res_sct = residual if isinstance(residual, SparseConvTensor) else None
+        if res_sct is not None:
+            residual = res_sct.features.contiguous()
         if self.ndim != 3:
             raise Df3dError("only SparseConv3d/SubMConv3d are implemented on the MI355X path")
         if self.conv1x1:
@@ -177,6 +181,25 @@ class SparseConvolution(SparseModule):
         bias = self.bias.detach() if self.bias is not None else None
         tiles = rb.tiles(self.in_channels, self.out_channels)
         out_split = None
+        if _ops.CONV_PRECISION == "bf16" and _ops.conv_bf16_supported(K, self.in_channels, self.out_channels):
+            # BASELINE configs[2]: bf16 rows and weights, fp32 accumulate; the fp32 copy of the result serves the
+            # layers without a bf16 kernel (C <= 16) and the fusion adapter
+            if input.features is not feats:
+                input = input.replace_feature(feats)
+            if residual is None:
+                res16 = None
+            elif res_sct is not None:
+                res16 = res_sct.bf16_features()
+            else:
+                res16 = _ops.rows_to_bf16(residual.contiguous().float())
+            out_features, out16 = _ops.sparse_conv_bf16(input.bf16_features(), self._packed_weight_bf16(w, K), rb.nbr,
+                                                        n_out, self.in_channels, self.out_channels, bias=bias,
+                                                        scale=scale, shift=shift, residual=res16, relu=relu,
+                                                        want_f32=True, want_bf16=True)
+            out = SparseConvTensor(out_features, rb.outids, rb.out_spatial_shape, input.batch_size)
+            out.indice_dict, out.grid, out._directories = input.indice_dict, input.grid, input._directories
+            out._bf16 = (out_features, out16)
+            return out
         if _ops.conv_split_supported(K, self.in_channels, self.out_channels):
             if input.features is not feats:
                 input = input.replace_feature(feats)
@@ -193,6 +216,14 @@ class SparseConvolution(SparseModule):
         if out_split is not None:
             out._split = (out_features, out_split)
         return out
+
+    def _packed_weight_bf16(self, w, K):
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = getattr(self, "_packed16", None)
+        if hit is None or hit[0] != key:
+            hit = (key, _ops.conv_pack_weights_bf16(w.contiguous().float().view(K, self.in_channels, self.out_channels)))
+            self._packed16 = hit
+        return hit[1]
 
     def _packed_weight(self, w, K):
         """hi/lo bf16 MFMA operands of the filter bank, rebuilt only when the parameter changes."""

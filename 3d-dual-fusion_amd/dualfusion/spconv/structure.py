@@ -98,6 +98,15 @@ class SparseConvTensor(object):
             self._split = (self.features, _ops.split_rows(feats))
         return self._split[1]
 
+    def bf16_features(self):
+        """`features` as bf16 rows for the bf16 conv kernels (DF3D_CONV_PRECISION=bf16); emitted by the producing
+        conv's epilogue when there is one, otherwise converted here once."""
+        hit = getattr(self, "_bf16", None)
+        if hit is None or hit[0] is not self.features:
+            hit = (self.features, _ops.rows_to_bf16(self.features.contiguous().float()))
+            self._bf16 = hit
+        return hit[1]
+
     # ---- reference API ------------------------------------------------------------
     @property
     def spatial_size(self):

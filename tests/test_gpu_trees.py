@@ -73,6 +73,41 @@ def test_transfusion_encoder_accepts_bf16_features():
     assert err < 3e-2, err
 
 
+def test_bf16_conv_mode_encoder_and_centerpoint_backbone():
+    """DF3D_CONV_PRECISION=bf16 (BASELINE configs[2]: bf16, fp32 accumulate): every C >= 32 sparse conv runs on the bf16
+    kernel (bf16 rows handed from layer to layer, fp32 epilogue); results stay within accumulated bf16 rounding of the
+    split-precision path, index sets are identical."""
+    from dualfusion import ops
+    from dualfusion.backbones import SparseEncoder
+    from dualfusion.pipeline import CenterPointHotPath
+    from dualfusion import synth
+    dev = torch.device("cuda:0")
+    m = SparseEncoder(in_channels=5, sparse_shape=[41, 256, 256], output_channels=128, encoder_channels=TF_CH,
+                      encoder_paddings=TF_PAD, block_type='basicblock')
+    m, _ = _load_det(m, dev)
+    f, c, _, _ = _voxels(61, [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0], dev, batch=2)
+    hp = CenterPointHotPath().eval().to(dev)
+    pts = [torch.from_numpy(synth.nusc_sweep(seed=4)).to(dev)]
+    with torch.no_grad():
+        y32 = m(f, c, 2)
+        d32, multi32 = hp(pts)
+        old = ops.CONV_PRECISION
+        ops.CONV_PRECISION = "bf16"
+        try:
+            y16 = m(f, c, 2)
+            d16, multi16 = hp(pts)
+        finally:
+            ops.CONV_PRECISION = old
+    assert y16.dtype == torch.float32 and tuple(y16.shape) == tuple(y32.shape)
+    assert float((y16 - y32).abs().max() / y32.abs().max()) < 5e-2
+    assert float((y16 - y32).abs().mean() / y32.abs().mean()) < 1e-2
+    for k in ("conv1", "conv2", "conv3", "conv4"):
+        assert torch.equal(multi16[k].indices, multi32[k].indices)
+    assert getattr(multi16["conv4"], "_bf16", None) is not None          # the bf16 kernel served the 128-channel stage
+    assert float((d16 - d32).abs().max() / d32.abs().max()) < 5e-2
+    assert float((d16 - d32).abs().mean() / d32.abs().mean()) < 1e-2
+
+
 def _tf_metas(B, cams, ori_hw, in_hw):
     sf = [in_hw[1] / ori_hw[1], in_hw[0] / ori_hw[0]]
     from dualfusion import synth
