@@ -48,6 +48,8 @@ class _Layer(object):
             self.filters = w.permute(2, 3, 1, 0).reshape(-1, w.shape[1], w.shape[0]).contiguous()
         K, cin, cout = self.filters.shape
         self.packed = _ops.conv_pack_weights(self.filters) if _ops.conv_split_supported(K, cin, cout) else None
+        self.packed16 = (_ops.conv_pack_weights_bf16(self.filters)
+                         if _ops.CONV_PRECISION == "bf16" and _ops.conv_bf16_supported(K, cin, cout) else None)
         inv = torch.rsqrt(self.bn.running_var.float() + self.bn.eps)
         self.scale = (self.bn.weight.float() * inv).contiguous()
         self.shift = (self.bn.bias.float() - self.bn.running_mean.float() * self.scale).contiguous()
@@ -161,6 +163,13 @@ class RPN(nn.Module):
         nbr, Ho, Wo = tables[key]
         K, cin, cout = layer.filters.shape
         n_out = nbr.shape[1]
+        if layer.packed16 is not None:                       # DF3D_CONV_PRECISION=bf16: bf16 rows from layer to layer
+            r16 = split if (split is not None and split.dtype == torch.bfloat16) else _ops.rows_to_bf16(rows)
+            out, o16 = _ops.sparse_conv_bf16(r16, layer.packed16, nbr, n_out, cin, cout, bias=layer.bias,
+                                             scale=layer.scale, shift=layer.shift, relu=layer.relu, want_f32=True)
+            return out, o16, Ho, Wo
+        if split is not None and split.dtype == torch.bfloat16:
+            split = None
         if layer.packed is not None:
             if split is None:
                 split = _ops.split_rows(rows)

@@ -127,3 +127,24 @@ def test_second_fpn_rows_vs_torch_cpu():
     assert tuple(out.shape) == tuple(ref.shape) == (2, 512, 40, 52)
     assert float((out.cpu() - ref).abs().max() / ref.abs().max()) < 1e-3
     assert float((out2.cpu() - ref2).abs().max() / ref2.abs().max()) < 1e-3
+
+
+def test_rpn_bf16_mode():
+    """DF3D_CONV_PRECISION=bf16: the neck's 13 layers on the bf16 kernel, within bf16 rounding of the fp32 module."""
+    from dualfusion import ops
+    from dualfusion.necks import RPN
+    dev = torch.device("cuda:0")
+    m = _det_module(RPN([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256))
+    x = torch.from_numpy(detgen.randn("neck_bf16", (1, 256, 40, 48)))
+    with torch.no_grad():
+        ref = m.forward_reference(x)
+        md = m.to(dev)
+        old = ops.CONV_PRECISION
+        ops.CONV_PRECISION = "bf16"
+        try:
+            y = md(x.to(dev))
+        finally:
+            ops.CONV_PRECISION = old
+            md.train(False)                       # drops the plan that holds the bf16 filter banks
+    assert float((y.cpu() - ref).abs().max() / ref.abs().max()) < 5e-2
+    assert float((y.cpu() - ref).abs().mean() / ref.abs().mean()) < 1e-2
