@@ -68,7 +68,7 @@ __device__ __forceinline__ void block_excl_scan(uint32_t (&x)[SCAN_ITEMS], uint3
 
 template <typename Loader>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(Loader in, uint32_t *out, size_t n,
-                                                                  uint32_t *sums) {
+                                                                  uint32_t *sums, uint32_t *total_if_single) {
   __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
   size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint32_t x[SCAN_ITEMS];
@@ -79,30 +79,51 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(Loader in, uin
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i)
     if (base + i < n) out[base + i] = x[i];
-  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint32_t *sums, size_t m, uint32_t *total) {
-  __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
-  uint32_t carry = 0;
-  for (size_t start = 0; start < m; start += SCAN_TILE) {
-    size_t base = start + (size_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t x[SCAN_ITEMS];
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) x[i] = (base + i < m) ? sums[base + i] : 0u;
-    uint32_t tot;
-    block_excl_scan(x, tot, lds);
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i)
-      if (base + i < m) sums[base + i] = x[i] + carry;
-    carry += tot;
+  if (threadIdx.x == 0) {
+    sums[blockIdx.x] = tot;
+    if (total_if_single) *total_if_single = tot;      // one tile: the scan is complete after this launch
   }
-  if (threadIdx.x == 0 && total) *total = carry;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(uint32_t *out, size_t n, const uint32_t *sums) {
+// second (and last) launch of a multi-tile scan: every block sums the totals of the tiles in front of it (at most a
+// few thousand values out of L2) and adds the offset to its tile -- no separate launch for the scan of the tile sums
+__global__ __launch_bounds__(SCAN_THREADS) void scan_offset_kernel(uint32_t *out, size_t n, const uint32_t *sums, size_t nb,
+                                                                   uint32_t *total) {
+  __shared__ uint32_t lds[SCAN_THREADS / 64];
+  __shared__ uint32_t s_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool last = blockIdx.x + 1 == nb;
+  const size_t upto = last ? nb : blockIdx.x;          // the last block also produces the grand total
+  uint32_t s = 0, mine = 0;
+  for (size_t i = tid; i < upto; i += SCAN_THREADS) {
+    const uint32_t v = sums[i];
+    if (i < blockIdx.x) mine += v;
+    s += v;
+  }
+  // two reductions (offset of this tile, grand total) share the shuffles
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    mine += __shfl_xor(mine, d, 64);
+    s += __shfl_xor(s, d, 64);
+  }
+  __shared__ uint32_t lds2[SCAN_THREADS / 64];
+  if (lane == 0) {
+    lds[wave] = mine;
+    lds2[wave] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t a = 0, b = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+      a += lds[w];
+      b += lds2[w];
+    }
+    s_off = a;
+    if (last && total) *total = b;
+  }
+  __syncthreads();
+  const uint32_t add = s_off;
   size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-  uint32_t add = sums[blockIdx.x];
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i)
     if (base + i < n) out[base + i] += add;
@@ -123,10 +144,10 @@ static int scan_impl(Loader in, uint32_t *out, size_t n, uint32_t *total, void *
   }
   uint32_t *sums = (uint32_t *)scratch;
   size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(scan_tiles_kernel<Loader>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out, n, sums);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, sums, nb, total);
+  hipLaunchKernelGGL(scan_tiles_kernel<Loader>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out, n, sums,
+                     nb == 1 ? total : (uint32_t *)nullptr);
   if (nb > 1)
-    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, out, n, sums);
+    hipLaunchKernelGGL(scan_offset_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, out, n, sums, nb, total);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }
