@@ -35,7 +35,8 @@ struct IndexSet {
 
 struct LayerOut {
   float *features = nullptr;
-  void *split = nullptr;
+  void *split = nullptr;       // split rows (bf16 hi | lo) of `features`, or its bf16 rows when the layer ran in bf16
+  void *rows16 = nullptr;      // bf16 rows of `features` (bf16 layers; converted on demand for fp32 producers)
   int set = -1;
   int channels = 0;
 };
@@ -107,6 +108,7 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
   memcpy(s0.shape, shape, sizeof(s0.shape));
   sets.push_back(s0);
   void *split0 = nullptr;      // split rows of the network input, built on demand
+  void *rows16_0 = nullptr;    // its bf16 rows (bf16 layers)
 #define DF3D_ARENA_CHECK(ok)                                                                                   \
   do {                                                                                                          \
     if (!(ok)) {                                                                                                \
@@ -249,7 +251,33 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
     if (L.residual >= 0)
       DF3D_CHECK_ARG(outs[L.residual].set == out_set && outs[L.residual].channels == L.cout,
                      "backbone_run: residual of layer %d lives on another index set", li);
-    if (L.packed && df3d_conv_packed_weight_bytes(K, L.cin, L.cout) != 0) {
+    if (L.packed && (L.reserved & 2)) {          // bf16 rows / bf16 weights (DF3D_CONV_PRECISION=bf16)
+      DF3D_CHECK_ARG(df3d_conv_packed_weight_bytes_bf16(K, L.cin, L.cout) != 0,
+                     "backbone_run: layer %d has no bf16 kernel (K=%d cin=%d cout=%d)", li, K, L.cin, L.cout);
+      void **in16 = L.input < 0 ? &rows16_0 : &outs[L.input].rows16;
+      if (!*in16) {
+        *in16 = mem.take((size_t)n_in * L.cin * 2);
+        DF3D_ARENA_CHECK(*in16);
+        int rc = df3d_rows_to_bf16(in_feat, n_in, L.cin, *in16, stream_);
+        if (rc) return rc;
+      }
+      const void *res16 = nullptr;
+      if (L.residual >= 0) {
+        LayerOut &R = outs[L.residual];
+        if (!R.rows16) {
+          R.rows16 = mem.take((size_t)n_out * L.cout * 2);
+          DF3D_ARENA_CHECK(R.rows16);
+          int rc = df3d_rows_to_bf16(R.features, n_out, L.cout, R.rows16, stream_);
+          if (rc) return rc;
+        }
+        res16 = R.rows16;
+      }
+      o.rows16 = mem.take((size_t)n_out * L.cout * 2);
+      DF3D_ARENA_CHECK(o.rows16);
+      int rc = df3d_sparse_conv_bf16(*in16, n_in, L.cin, L.packed, K, L.cout, nbr, n_out, L.bias, L.scale, L.shift, res16,
+                                     L.relu, o.features, o.rows16, stream_);
+      if (rc) return rc;
+    } else if (L.packed && df3d_conv_packed_weight_bytes(K, L.cin, L.cout) != 0) {
       void **in_split = L.input < 0 ? &split0 : &outs[L.input].split;
       if (!*in_split) {
         *in_split = mem.take((size_t)n_in * L.cin * 4);
@@ -269,7 +297,8 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
     }
     const IndexSet &OS = sets[out_set];
     v.features = o.features;
-    v.split = o.split;
+    v.split = o.split ? o.split : o.rows16;      // reserved bit 1 tells the caller which format this is
+    v.reserved = o.rows16 && !o.split ? 2 : 0;
     v.indices = OS.indices;
     v.grid = OS.grid;          // may still be NULL: directories are built when a later layer needs them
     v.grid_bytes = OS.grid_bytes;

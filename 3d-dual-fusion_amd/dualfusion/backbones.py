@@ -44,13 +44,6 @@ def conv1x1(in_planes, out_planes, stride=1, indice_key=None, bias=True):
                              indice_key=indice_key)
 
 
-def _bf16_mode():
-    """DF3D_CONV_PRECISION=bf16: the layer table of the native executor speaks fp32 / split rows only, so the chain
-    runs through the modules (each conv hands its bf16 rows to the next through the tensor's cache)."""
-    from . import ops as _o
-    return _o.CONV_PRECISION == "bf16"
-
-
 def _fused_basic_block(x, conv1, bn1, conv2, bn2, downsample):
     """conv1-bn1-relu-conv2-bn2-(+identity)-relu as two fused kernels (eval mode)."""
     s1, h1 = fold_batchnorm(bn1)
@@ -136,7 +129,7 @@ class SpMiddleResNetFHD(nn.Module):
 
     def _plan(self):
         """Native executor plan of the conv chain (dualfusion/executor.py) for inference; None -> module path."""
-        if self.training or os.environ.get("DF3D_EXECUTOR", "1") != "1" or _bf16_mode():
+        if self.training or os.environ.get("DF3D_EXECUTOR", "1") != "1":
             return None
         plan = getattr(self, "_exec_plan", False)
         if plan is False:
@@ -350,7 +343,7 @@ class SparseEncoder(nn.Module):
         return [("conv_input", self.conv_input)] + list(self.encoder_layers._modules.items())
 
     def _runner(self, cuts=()):
-        if self.training or torch.is_grad_enabled() or os.environ.get("DF3D_EXECUTOR", "1") != "1" or _bf16_mode():
+        if self.training or torch.is_grad_enabled() or os.environ.get("DF3D_EXECUTOR", "1") != "1":
             return None
         key = tuple(cuts)
         cache = self.__dict__.setdefault("_exec_runners", {})
@@ -492,7 +485,7 @@ class VoxelBackBone8x(nn.Module):
 
     def _runner(self):
         """Native executor for the conv chain, cut after conv1 when a subclass fuses there (dualfusion/executor.py)."""
-        if self.training or torch.is_grad_enabled() or os.environ.get("DF3D_EXECUTOR", "1") != "1" or _bf16_mode():
+        if self.training or torch.is_grad_enabled() or os.environ.get("DF3D_EXECUTOR", "1") != "1":
             return None
         if "_exec_runner" not in self.__dict__:
             from .executor import build_runner

@@ -165,7 +165,12 @@ class BackbonePlan(object):
             keep.append(w)
             L.weight = w.data_ptr()
             L.packed = None
-            if _ops.conv_split_supported(K, c.in_channels, c.out_channels):
+            if _ops.CONV_PRECISION == "bf16" and _ops.conv_bf16_supported(K, c.in_channels, c.out_channels):
+                p = c._packed_weight_bf16(c.weight.detach(), K)
+                keep.append(p)
+                L.packed = p.data_ptr()
+                L.reserved |= 2                      # bf16 rows / weights for this layer
+            elif _ops.conv_split_supported(K, c.in_channels, c.out_channels):
                 p = c._packed_weight(c.weight.detach(), K)
                 keep.append(p)
                 L.packed = p.data_ptr()
@@ -219,7 +224,9 @@ class BackbonePlan(object):
             t = SparseConvTensor(f, ind, [v.shape[0], v.shape[1], v.shape[2]], batch_size)
             t.indice_dict, t._directories = idict, dirs
             t._indices_synced = True      # the host has waited for these coordinates (count round trip)
-            if v.split:
+            if v.split and (v.reserved & 2):
+                t._bf16 = (f, view(v.split, v.n * v.channels * 2, torch.bfloat16, (v.n, v.channels)))
+            elif v.split:
                 t._split = (f, view(v.split, v.n * v.channels * 4, torch.uint8, (v.n, v.channels * 4)))
             if v.grid and v.rows_sorted:
                 # the occupancy directory the executor built is handed to the module path (e.g. a conv that runs

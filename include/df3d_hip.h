@@ -513,7 +513,9 @@ typedef struct df3d_layer {
   int cin, cout;
   int ksize[3], stride[3], padding[3], dilation[3];
   int relu;
-  int reserved;          /* flags: bit 0 = geometry only (build the rulebook, export it, do not run the conv) */
+  int reserved;          /* flags: bit 0 = geometry only (build the rulebook, export it, do not run the conv);
+                          *        bit 1 = `packed` holds bf16 weights (df3d_conv_pack_weights_bf16): the layer runs on
+                          *                df3d_sparse_conv_bf16 with bf16 rows */
   const float *weight;   /* [kvol][cin][cout] fp32 */
   const void *packed;
   const float *bias, *scale, *shift;
@@ -529,7 +531,7 @@ typedef struct df3d_layer_view {
   int shape[3];
   const int32_t *nbr;    /* the layer's neighbour table [kvol][n] */
   int kvol;
-  int reserved;
+  int reserved;          /* bit 1: `split` holds bf16 rows [n][channels] instead of split rows */
 } df3d_layer_view;
 
 int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *features, const int32_t *indices, int n,
