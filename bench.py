@@ -42,6 +42,11 @@ def parse():
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("DF3D_INFLIGHT", "2")),
                     help="frames in flight per GPU: each slot is a host thread + HIP stream + model replica; the K "
                          "timed steps are dealt to the slots (frames are independent).  1 = strictly sequential")
+    ap.add_argument("--conv-precision", default=os.environ.get("DF3D_CONV_PRECISION", "split"),
+                    choices=["split", "fp32", "bf16"],
+                    help="sparse-conv arithmetic: split (default, fp32-grade: bf16 hi+lo operands, 3 MFMA products), fp32 "
+                         "(exact fp32 MFMA), bf16 (bf16 rows / weights, fp32 accumulate: BASELINE configs[2]-style, NOT the "
+                         "fp32 configs[1] line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -84,7 +89,10 @@ def conv_algorithmic(rec, pairs):
     neighbour table and the filter bank:
         bytes = R*Cin*4 + N_out*Cout*4*(1 or 2) + K*N_out*4 + K*Cin*Cout*4 ;  flops = 2*R*Cin*Cout."""
     cin, cout, K, n_out = rec["cin"], rec["cout"], rec["kvol"], rec["n_out"]
-    by = pairs * cin * 4 + n_out * cout * 4 * (2 if rec["split"] else 1) + K * n_out * 4 + K * cin * cout * 4
+    if rec["split"] == 2:      # bf16 kernel: 2-byte rows and weights; it writes bf16 rows and an fp32 copy of the result
+        by = pairs * cin * 2 + n_out * cout * (2 + 4) + K * n_out * 4 + K * cin * cout * 2
+    else:
+        by = pairs * cin * 4 + n_out * cout * 4 * (2 if rec["split"] else 1) + K * n_out * 4 + K * cin * cout * 4
     return by, 2 * pairs * cin * cout
 
 
@@ -119,7 +127,7 @@ def roofline_from_timer(timer, meta_timer):
     sec = g["ms"] * 1e-3
     counted = max(g["n"] - g["miss"], 1)
     by, fl = g["by"] * g["n"] // counted, g["fl"] * g["n"] // counted
-    mfma_peak = PEAK_BF16_MFMA_TF / 3.0 if split else PEAK_FP32_MFMA_TF
+    mfma_peak = PEAK_BF16_MFMA_TF if split == 2 else (PEAK_BF16_MFMA_TF / 3.0 if split else PEAK_FP32_MFMA_TF)
     ai = fl / max(by, 1)
     if ai >= mfma_peak * 1e12 / (PEAK_HBM_GBS * 1e9):
         ach = fl / sec / 1e12
@@ -132,7 +140,8 @@ def roofline_from_timer(timer, meta_timer):
     kname = ("spconv_os_split_kernel" if split else ("spconv_pair_kernel" if cout == 128 and cin >= 64
                                                      else "spconv_mfma_kernel"))
     roof.update({"traffic": None, "kernel": "%s<cin=%d,cout=%d,K=%d>" % (kname, cin, cout, K),
-                 "precision": "split bf16 hi/lo operands, 3 MFMA products, fp32 accumulate" if split else "fp32 MFMA",
+                 "precision": ("bf16 rows and weights, fp32 accumulate" if split == 2 else
+                               "split bf16 hi/lo operands, 3 MFMA products, fp32 accumulate" if split else "fp32 MFMA"),
                  "launches": g["n"], "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),
                  "algorithmic_flops_per_launch": fl // g["n"], "algorithmic_bytes_per_launch": by // g["n"],
                  "arithmetic_intensity_flop_per_byte": round(ai, 1)})
@@ -214,6 +223,7 @@ def main():
         except Exception:
             workload = "cp_lidar"
     from dualfusion import ops
+    ops.CONV_PRECISION = args.conv_precision
     nslots = max(1, min(args.inflight, args.steps))
     # one slot = model replica (same seed -> same weights) + the same synthetic frame + its own HIP stream
     slots = []
@@ -291,8 +301,12 @@ def main():
             "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (C>=64 sparse convs and the FFN: operands split into bf16 hi+lo, 3 MFMA products, fp32 "
-                     "accumulate, ~1e-5 rel. error; everything else exact fp32)", "data": "synthetic",
+            "dtype": {"split": "f32 (C>=64 sparse convs and the FFN: operands split into bf16 hi+lo, 3 MFMA products, fp32 "
+                               "accumulate, ~1e-5 rel. error; everything else exact fp32)",
+                      "fp32": "f32 (exact fp32 MFMA convolutions; FFN split precision)",
+                      "bf16": "bf16 sparse convs (bf16 rows and weights, fp32 accumulate and epilogue); fusion adapter, "
+                              "ACTR and C<=16 layers f32 -- NOT the fp32 configs[1] line"}[args.conv_precision],
+            "data": "synthetic",
             "config": {"workload": {"cp_fusion": "CenterPoint + 3D-DF hot path (voxelize+VFE, SpMiddleResNetFHDFusion, "
                                                  "ACTR dual-query fusion on 6 synthetic DeepLabV3-shaped cam feats, dense BEV), "
                                                  "0.075 m voxel, fp32 [BASELINE configs[1]]",
