@@ -173,7 +173,9 @@ def test_forward_rows_vs_torch_cpu_and_end_to_end():
             assert tuple(got[t][k].shape) == tuple(ref[t][k].shape)
             err = float((got[t][k].cpu() - ref[t][k]).abs().max() / ref[t][k].abs().max())
             assert err < 1e-3, (t, k, err)                                   # measured ~1e-5
-    assert getattr(got[0]["hm"], "_df3d_rows", None) is not None
+    from dualfusion import ops
+    if ops.CONV_PRECISION == "split":                       # other precisions take the library composition
+        assert getattr(got[0]["hm"], "_df3d_rows", None) is not None
     dets = hd.predict({}, got, HEAD_TEST_CFG)
     dets_ref = hd.predict({}, [{k: v.to(DEV) for k, v in p.items()} for p in ref], HEAD_TEST_CFG)
     for a, b in zip(dets, dets_ref):
