@@ -675,6 +675,7 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const int32_t *__restr
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
 }
 static bool g_timing_on = false;
+static int g_timing_filter[3] = {0, 0, 0};   // (cin, cout, kvol) of the only launches to time; 0 = any
 static std::mutex g_timing_mu;          // several host threads (frames in flight) launch convolutions concurrently
 static std::vector<TimingRec> g_timing;
 static std::vector<hipEvent_t> g_event_pool;
@@ -692,6 +693,9 @@ static hipEvent_t timing_event() {
 
 int timing_rec_begin(int cin, int cout, int kvol, int n_out, const int32_t *nbr, int split, hipStream_t stream) {
   if (!g_timing_on) return -1;
+  if ((g_timing_filter[0] && g_timing_filter[0] != cin) || (g_timing_filter[1] && g_timing_filter[1] != cout) ||
+      (g_timing_filter[2] && g_timing_filter[2] != kvol))
+    return -1;
   std::lock_guard<std::mutex> lock(g_timing_mu);
   TimingRec r = {timing_event(), timing_event(), cin, cout, kvol, n_out, -1, split};
   if (!r.e0 || !r.e1) return -1;
@@ -855,6 +859,13 @@ extern "C" int df3d_timing_begin(void) {
   }
   g_timing.clear();
   g_timing_on = true;
+  return DF3D_OK;
+}
+
+extern "C" int df3d_timing_filter(int cin, int cout, int kvol) {
+  g_timing_filter[0] = cin;
+  g_timing_filter[1] = cout;
+  g_timing_filter[2] = kvol;
   return DF3D_OK;
 }
 

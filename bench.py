@@ -39,9 +39,10 @@ def parse():
     ap.add_argument("--workload", default=os.environ.get("DF3D_WORKLOAD", "auto"),
                     help="cp_fusion (BASELINE configs[1]) | cp_lidar (configs[0] shape) | auto")
     ap.add_argument("--batch", type=int, default=1, help="sweeps per GPU per step")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DF3D_INFLIGHT", "2")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DF3D_INFLIGHT", "1")),
                     help="frames in flight per GPU: each slot is a host thread + HIP stream + model replica; the K "
-                         "timed steps are dealt to the slots (frames are independent).  1 = strictly sequential")
+                         "timed steps are dealt to the slots (frames are independent).  1 (default) = strictly "
+                         "sequential; 2 gains ~10 %% from K >= 40 steps on, nothing at K = 20")
     ap.add_argument("--conv-precision", default=os.environ.get("DF3D_CONV_PRECISION", "split"),
                     choices=["split", "fp32", "bf16"],
                     help="sparse-conv arithmetic: split (default, fp32-grade: bf16 hi+lo operands, 3 MFMA products), fp32 "
@@ -256,7 +257,21 @@ def main():
     # a launch also times whatever the other frame's stream co-runs, and the event packets serialise the queues
     # (measured: 580 -> 436 sweeps/s).  With frames in flight the roofline is therefore measured in a second pass of
     # the same K steps, sequentially, right after the timed region (reported with its own ms_per_step).
-    timer = None if args.no_kernel_timing else ops.KernelTimer()
+    # Events around EVERY conv launch cost the timed region ~6 % (30 launches per frame).  The roofline needs the
+    # dominant kernel only: one untimed probe step with all events finds it (and yields the per-kernel table), the
+    # timed region then records events around its launches alone.
+    timer, probe = None, None
+    if not args.no_kernel_timing:
+        probe = ops.KernelTimer()
+        probe.start()
+        run_step(model, pts, extra)
+        torch.cuda.synchronize()
+        probe.stop()
+        tot = {}
+        for r in probe.records:
+            k = (r["cin"], r["cout"], r["kvol"])
+            tot[k] = tot.get(k, 0.0) + r["ms"]
+        timer = ops.KernelTimer(only=max(tot, key=tot.get)) if tot else ops.KernelTimer()
     if nslots > 1:
         import threading
         threads = [threading.Thread(target=work, args=(i, share[i])) for i in range(nslots)]
@@ -316,7 +331,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d (frames sharded, no data-path collective)" % world},
         }
         if timer is not None:
-            roof, per_kernel = roofline_from_timer(timer, meta_timer)
+            roof, _ = roofline_from_timer(timer, meta_timer)
+            _, per_kernel = roofline_from_timer(probe, meta_timer)        # all conv kernels, from the untimed probe step
             if roof is not None and seq_elapsed is not None:
                 roof["measured_over"] = ("second pass of the same %d steps with ONE frame in flight (HIP events around "
                                          "every conv launch), %.4f ms/step; the timed region above keeps %d frames in "
@@ -324,9 +340,10 @@ def main():
                                                                                nslots))
                 res["sequential_ms_per_step"] = round(seq_elapsed / args.steps * 1e3, 4)
             elif roof is not None:
-                roof["measured_over"] = "the timed region (one frame in flight)"
+                roof["measured_over"] = ("the timed region (one frame in flight; HIP events around the launches of this "
+                                         "kernel only -- it was picked by an untimed probe step with events on every launch)")
             res["roofline"] = roof
-            res["conv_kernel_ms"] = per_kernel
+            res["conv_kernel_ms_probe_step"] = per_kernel
         if world == 1 and not args.no_cpu_baseline:
             cam_np = None
             if workload == "cp_fusion":

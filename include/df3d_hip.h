@@ -166,6 +166,9 @@ int df3d_timing_get(int i, int *shape4_host, float *ms_host);
  * algorithmic bytes / flops of SURVEY.md section 8(d) are stated in.  df3d_timing_get2 returns R (-1 when it was
  * not counted) and whether the split-precision kernel served the launch. */
 int df3d_timing_count_pairs(int on);
+/* Only launches of this (cin, cout, kernel volume) are timed (0 = any): event pairs around EVERY conv launch cost the
+ * timed region ~6 %; the roofline needs the dominant kernel only. */
+int df3d_timing_filter(int cin, int cout, int kvol);
 int df3d_timing_get2(int i, int *shape4, float *ms, long long *pairs, int *split);
 
 /* SparseConvTensor.dense() (TF/mmdet3d/ops/spconv/structure.py:5-18,55-64): zero-fill +
