@@ -20,6 +20,8 @@
 // 2*rows*128*1024*2 flops.  Bound: bf16 MFMA at 3 products per fp32 product.
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "common.h"
 
 namespace df3d {
@@ -95,8 +97,17 @@ struct FfnArgs {
 
 // NW waves per workgroup, RT 16-row tiles per wave.  RT = 2 halves the LDS fragment reads per MFMA (every operand
 // fragment read from LDS feeds two row tiles) at the price of one resident wave per SIMD.
+// up to four independent FFN jobs (same sizes, different weights / rows) in one launch: blockIdx.y picks the job.  The
+// dual-query layer runs its image-query and LiDAR-query FFNs this way: twice the workgroups per launch fill the 256
+// CUs better than two launches of ~1.2 waves each.
+struct FfnJobs {
+  FfnArgs s[4];
+};
+
 template <int NW, int RT>
-__global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnArgs a) {
+__global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
+  const FfnArgs &a = jobs.s[blockIdx.y];
+  if ((long long)blockIdx.x * (16 * RT * NW) >= a.rows) return;
   constexpr int NT = NW * 64, WR = 16 * RT, TM = NW * WR;
   constexpr int WPT = FFN_WQ / NT;
   static_assert(FFN_WQ % NT == 0, "tile must divide over the workgroup");
@@ -317,6 +328,16 @@ extern "C" int df3d_ffn_pack(const float *w1, const float *w2, int d_model, int 
   return DF3D_OK;
 }
 
+static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, hipStream_t stream) {
+  static const int cfg = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 81;      // tuning aid: NW*10 + RT
+  if (cfg == 42) hipLaunchKernelGGL((ffn_split_kernel<4, 2>), dim3(cdiv(max_rows, 128), njobs), dim3(256), 0, stream, jobs);
+  else if (cfg == 82) hipLaunchKernelGGL((ffn_split_kernel<8, 2>), dim3(cdiv(max_rows, 256), njobs), dim3(512), 0, stream, jobs);
+  else if (cfg == 41) hipLaunchKernelGGL((ffn_split_kernel<4, 1>), dim3(cdiv(max_rows, 64), njobs), dim3(256), 0, stream, jobs);
+  else hipLaunchKernelGGL((ffn_split_kernel<8, 1>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
 extern "C" int df3d_ffn_fused(const float *x, long long rows, int d_model, int d_ffn, const void *packed,
                               const float *b1, const float *b2, const float *residual, const float *ln_weight,
                               const float *ln_bias, float eps, float *out, void *stream_) {
@@ -326,13 +347,30 @@ extern "C" int df3d_ffn_fused(const float *x, long long rows, int d_model, int d
                  d_model, d_ffn);
   DF3D_CHECK_ARG((ln_weight == nullptr) == (ln_bias == nullptr), "ffn_fused: LayerNorm needs weight and bias");
   if (rows <= 0) return DF3D_OK;
-  FfnArgs a = {x, (const u32x4 *)packed, b1, b2, residual, ln_weight, ln_bias, eps, out, rows, d_ffn,
+  FfnJobs jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  jobs.s[0] = {x, (const u32x4 *)packed, b1, b2, residual, ln_weight, ln_bias, eps, out, rows, d_ffn,
                getenv("DF3D_FFN_DBG") ? atoi(getenv("DF3D_FFN_DBG")) : 0};
-  static const int cfg = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 81;      // tuning aid: NW*10 + RT
-  if (cfg == 42) hipLaunchKernelGGL((ffn_split_kernel<4, 2>), dim3(cdiv(rows, 128)), dim3(256), 0, stream, a);
-  else if (cfg == 82) hipLaunchKernelGGL((ffn_split_kernel<8, 2>), dim3(cdiv(rows, 256)), dim3(512), 0, stream, a);
-  else if (cfg == 41) hipLaunchKernelGGL((ffn_split_kernel<4, 1>), dim3(cdiv(rows, 64)), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((ffn_split_kernel<8, 1>), dim3(cdiv(rows, 128)), dim3(512), 0, stream, a);
-  DF3D_LAUNCH_CHECK();
-  return DF3D_OK;
+  return ffn_launch(jobs, 1, rows, stream);
+}
+
+extern "C" int df3d_ffn_fused_jobs(const df3d_ffn_job *j, int njobs, int d_model, int d_ffn, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(j && njobs >= 1 && njobs <= 4, "ffn_fused_jobs: 1..4 jobs");
+  DF3D_CHECK_ARG(df3d_ffn_packed_bytes(d_model, d_ffn) != 0, "ffn_fused_jobs: unsupported sizes d_model=%d d_ffn=%d",
+                 d_model, d_ffn);
+  FfnJobs jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  long long max_rows = 0;
+  for (int i = 0; i < njobs; ++i) {
+    DF3D_CHECK_ARG(j[i].rows <= 0 || (j[i].x && j[i].packed && j[i].b1 && j[i].b2 && j[i].out),
+                   "ffn_fused_jobs: job %d has a null argument", i);
+    DF3D_CHECK_ARG((j[i].ln_weight == nullptr) == (j[i].ln_bias == nullptr),
+                   "ffn_fused_jobs: LayerNorm needs weight and bias");
+    jobs.s[i] = {j[i].x, (const u32x4 *)j[i].packed, j[i].b1, j[i].b2, j[i].residual, j[i].ln_weight, j[i].ln_bias,
+                 j[i].eps, j[i].out, j[i].rows > 0 ? j[i].rows : 0, d_ffn, 0};
+    if (j[i].rows > max_rows) max_rows = j[i].rows;
+  }
+  if (max_rows <= 0) return DF3D_OK;
+  return ffn_launch(jobs, njobs, max_rows, stream);
 }

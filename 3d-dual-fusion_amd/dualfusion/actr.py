@@ -261,6 +261,25 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         return _ops.ffn_fused(x, hit[1], lin_a.bias, lin_b.bias, lin_a.out_features, residual=x,
                               ln_weight=norm.weight, ln_bias=norm.bias, eps=norm.eps)
 
+    def _ffn_pair(self, qi, q):
+        """The image-query FFN (linear1/2, norm2) and the LiDAR-query FFN (linear3/4, norm3) as ONE launch."""
+        from . import ops as _ops
+        if not _ops.ffn_supported(self.linear1.in_features, self.linear1.out_features) or \
+                self.linear1.out_features != self.linear3.out_features:
+            return (self._ffn(qi, self.linear1, self.linear2, self.norm2, "_ffn_i"),
+                    self._ffn(q, self.linear3, self.linear4, self.norm3, "_ffn_p"))
+        jobs = []
+        for x, la, lb, norm, slot in ((qi, self.linear1, self.linear2, self.norm2, "_ffn_i"),
+                                      (q, self.linear3, self.linear4, self.norm3, "_ffn_p")):
+            key = (la.weight.data_ptr(), la.weight._version, lb.weight.data_ptr(), lb.weight._version)
+            hit = getattr(self, slot, None)
+            if hit is None or hit[0] != key:
+                hit = (key, _ops.ffn_pack(la.weight.detach().contiguous(), lb.weight.detach().contiguous()))
+                object.__setattr__(self, slot, hit)
+            jobs.append(dict(x=x.contiguous(), packed=hit[1], b1=la.bias, b2=lb.bias, residual=x.contiguous(),
+                             ln_weight=norm.weight, ln_bias=norm.bias, eps=norm.eps))
+        return tuple(_ops.ffn_fused_jobs(jobs, self.linear1.out_features))
+
     def _forward_fused(self, src, reference_points, spatial_shapes, level_start_index, q_pos, q_feat, q_i_feat,
                        value=None):
         """Same arithmetic as forward(); `reference_points` [N,Q,L,2] carries the same (x, y) for every level when
@@ -279,8 +298,7 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
                                         sa.attention_weights(Bw), sa.n_levels, sa.n_points, pixel_scale, image_bias)
         att = sa.output_proj(out)
         qi = _ops.add_layernorm(q_i_feat, att, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qi = self._ffn(qi, self.linear1, self.linear2, self.norm2, "_ffn_i")
-        q = self._ffn(q_feat, self.linear3, self.linear4, self.norm3, "_ffn_p")
+        qi, q = self._ffn_pair(qi, q_feat)
         g = self.fusion_layer
         return _ops.bigate_sum(q, qi, g.b_conv1d.weight.view(-1), g.b_conv1d.bias, g.a_conv1d.weight.view(-1),
                                g.a_conv1d.bias)

@@ -758,6 +758,34 @@ def ffn_fused(x, packed, b1, b2, d_ffn, residual=None, ln_weight=None, ln_bias=N
     return out
 
 
+class _FfnJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("rows", ctypes.c_longlong), ("packed", ctypes.c_void_p), ("b1", ctypes.c_void_p),
+                ("b2", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("ln_weight", ctypes.c_void_p),
+                ("ln_bias", ctypes.c_void_p), ("eps", ctypes.c_float), ("out", ctypes.c_void_p)]
+
+
+def ffn_fused_jobs(jobs, d_ffn):
+    """jobs: list of dicts (x, packed, b1, b2, residual, ln_weight, ln_bias, eps) -> list of outputs; one launch."""
+    lib = _lib.load()
+    arr = (_FfnJob * len(jobs))()
+    outs = []
+    C = jobs[0]["x"].shape[-1]
+    for i, j in enumerate(jobs):
+        x = _chk(j["x"], torch.float32, "x")
+        out = torch.empty_like(x)
+        outs.append(out)
+        arr[i].x, arr[i].rows, arr[i].packed = x.data_ptr(), x.numel() // C, j["packed"].data_ptr()
+        arr[i].b1, arr[i].b2 = j["b1"].data_ptr(), j["b2"].data_ptr()
+        arr[i].residual = j["residual"].data_ptr() if j.get("residual") is not None else None
+        arr[i].ln_weight = j["ln_weight"].data_ptr() if j.get("ln_weight") is not None else None
+        arr[i].ln_bias = j["ln_bias"].data_ptr() if j.get("ln_bias") is not None else None
+        arr[i].eps = float(j.get("eps", 1e-5))
+        arr[i].out = out.data_ptr()
+    rc = lib.df3d_ffn_fused_jobs(ctypes.byref(arr), len(jobs), int(C), int(d_ffn), _stream())
+    _lib.check(rc, "df3d_ffn_fused_jobs")
+    return outs
+
+
 def imgproj_supported(rows, cin, c_model):
     return c_model == 128 and _lib.load().df3d_imgproj_packed_bytes(int(rows), int(cin)) > 0
 

@@ -473,6 +473,17 @@ int df3d_ffn_pack(const float *w1, const float *w2, int d_model, int d_ffn, void
 int df3d_ffn_fused(const float *x, long long rows, int d_model, int d_ffn, const void *packed, const float *b1,
                    const float *b2, const float *residual, const float *ln_weight, const float *ln_bias, float eps,
                    float *out, void *stream);
+/* Up to four independent FFN jobs of the same sizes in ONE launch (the dual-query layer's image-query and LiDAR-query
+ * FFNs, actr_transformer.py:413-424): rows < 0 / 0 skips a job. */
+typedef struct df3d_ffn_job {
+  const float *x;
+  long long rows;
+  const void *packed;
+  const float *b1, *b2, *residual, *ln_weight, *ln_bias;
+  float eps;
+  float *out;
+} df3d_ffn_job;
+int df3d_ffn_fused_jobs(const df3d_ffn_job *jobs, int njobs, int d_model, int d_ffn, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Image side of the fusion on the bf16 matrix cores, split precision (csrc/imgproj.hip).  Replaces the 1x1
