@@ -158,6 +158,8 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
 template <int PT>
 __global__ __launch_bounds__(512) void fps_kernel_half(const float *__restrict__ xyz, int N, int m, int VT,
                                                        int32_t *__restrict__ idx) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  static_assert(PT % 4 == 0, "points are processed in same-parity pairs");
   __shared__ float s_v[8];
   __shared__ int s_t[8], s_k[8];
   __shared__ int s_old;
@@ -165,38 +167,50 @@ __global__ __launch_bounds__(512) void fps_kernel_half(const float *__restrict__
   const int lane = tid & 63, wave = tid >> 6;
   const float *p = xyz + (size_t)b * N * 3;
   int32_t *o = idx + (size_t)b * m;
-  float temp[PT], px[PT], py[PT], pz[PT];
+  // point i of this thread is k = tid + 512 i; its virtual thread (the reference's 1024-thread block) is tid for even i
+  // and tid + 512 for odd i.  Pairs (i, i + 2) share the parity: [parity e][pair q] <-> i = 4q + e, 4q + e + 2.
+  // Two points per packed instruction (v_pk_add / v_pk_mul / v_pk_fma_f32).
+  f2 temp[2][PT / 4], px[2][PT / 4], py[2][PT / 4], pz[2][PT / 4];
 #pragma unroll
-  for (int i = 0; i < PT; ++i) {
-    int k = tid + i * 512;
-    int kk = k < N ? k : N - 1;
-    temp[i] = 1e10f;
-    px[i] = p[kk * 3];
-    py[i] = p[kk * 3 + 1];
-    pz[i] = p[kk * 3 + 2];
-  }
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int q = 0; q < PT / 4; ++q)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = tid + (4 * q + e + 2 * h) * 512;
+        const int kk = k < N ? k : N - 1;
+        temp[e][q][h] = 1e10f;
+        px[e][q][h] = p[kk * 3];
+        py[e][q][h] = p[kk * 3 + 1];
+        pz[e][q][h] = p[kk * 3 + 2];
+      }
   if (tid == 0 && m > 0) o[0] = 0;
   float x1 = p[0], y1 = p[1], z1 = p[2];
   const int vmask = VT - 1;
   for (int j = 1; j < m; ++j) {
-    Best me = {-1.f, 0x7fffffff, 0};
+    // The reference's thread scans its points in increasing k with a strict '>' (the first maximum stays); the block
+    // reduction breaks ties towards the lower thread id.  For a physical thread playing two virtual threads that is:
+    // all even-i points first (virtual thread tid), then the odd ones (tid + 512), strict '>' throughout.
+    float bv = -1.f;
+    int bk = 0;
 #pragma unroll
-    for (int i = 0; i < PT; ++i) {
-      int k = tid + i * 512;
-      if (k < N) {
-        float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-        float d = dx * dx + dy * dy + dz * dz;
-        float d2 = fminf(d, temp[i]);
-        temp[i] = d2;
-        int vt = k & vmask;
-        // same virtual thread: the first (lowest k) of equal values stays; other virtual thread: lower id wins ties
-        if (d2 > me.v || (d2 == me.v && vt < me.tid)) {
-          me.v = d2;
-          me.tid = vt;
-          me.k = k;
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int q = 0; q < PT / 4; ++q) {
+        const f2 dx = px[e][q] - x1, dy = py[e][q] - y1, dz = pz[e][q] - z1;
+        const f2 d = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = tid + (4 * q + e + 2 * h) * 512;
+          const float d2 = fminf(d[h], temp[e][q][h]);
+          temp[e][q][h] = d2;
+          if (k < N && d2 > bv) {
+            bv = d2;
+            bk = k;
+          }
         }
       }
-    }
+    Best me = {bv, bv < 0.f ? 0x7fffffff : (bk & vmask), bk};
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       Best ot;
