@@ -64,6 +64,16 @@ class TransformerEncoderLayerPreNorm(nn.Module):
         self.activation = nn.ReLU(inplace=True)
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None):
+        if (src.is_cuda and src.dtype == torch.float32 and not self.training and not torch.is_grad_enabled()
+                and src.shape[-1] % 4 == 0):
+            # the row kernel of csrc/actr.hip (one wave per row, residual add fused): torch's LayerNorm runs at
+            # ~0.5 TB/s on these [32 * B * npoint, 64] rows (9 ms per step in the Voxel-RCNN tree)
+            src = _ops.add_layernorm(src.contiguous(), None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            src2, _ = self.self_attn(src, src, src, attn_mask=src_mask, key_padding_mask=src_key_padding_mask,
+                                     need_weights=False)
+            src = _ops.add_layernorm(src, src2.contiguous(), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            src2 = self.linear2(self.activation(self.linear1(src)))
+            return src + src2
         src = self.norm1(src)
         src2, _ = self.self_attn(src, src, src, attn_mask=src_mask, key_padding_mask=src_key_padding_mask,
                                  need_weights=False)
