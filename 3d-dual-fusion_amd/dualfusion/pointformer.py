@@ -164,9 +164,62 @@ class LocalTransformer(nn.Module):
             _GEO.entry = (weakref.ref(xyz_in), key, group_idx, group_xyz)
         return group_idx, group_xyz
 
+    def _row_plan(self, xyz_in, group_idx, group_xyz):
+        """Index tensors of the row-layout path, functions of the geometry alone (cached with it): gather rows of the
+        grouped points in [ns, B*np] order, the grouped coordinates as rows, and for every point the row of the
+        'unique' winner (lowest flat group position, pointformer.py:320-328) or -1."""
+        hit = getattr(_GEO, "rows", None)
+        if hit is not None and hit[0] is group_idx:
+            return hit[1]
+        B, np_, ns = group_idx.shape
+        N = xyz_in.shape[1]
+        base = (torch.arange(B, device=group_idx.device, dtype=torch.int64) * N)[:, None, None]
+        sel = (group_idx.long() + base).permute(2, 0, 1).reshape(-1)                    # [ns*B*np] rows of [B*N, C]
+        gx = group_xyz.permute(3, 0, 2, 1).reshape(ns * B * np_, 3).contiguous()        # [ns*B*np, 3]
+        win = self._winner(group_idx.reshape(B, -1), N)                                 # [B,N] flat (p, s) position
+        has = win >= 0
+        w = win.clamp(min=0)
+        p_w, s_w = w // ns, w % ns
+        src = s_w * (B * np_) + torch.arange(B, device=w.device)[:, None] * np_ + p_w   # row of y [ns*B*np, C]
+        plan = (sel, gx, src.reshape(-1), has.reshape(-1, 1))
+        _GEO.rows = (group_idx, plan)
+        return plan
+
+    def _pe_rows(self, gx):
+        """self.pe (two 1x1 ConvModules, the first with BatchNorm2d + ReLU) on coordinate rows [R, 3] -> [R, C]."""
+        c0, c1 = self.pe[0], self.pe[1]
+        w0, b0 = c0.conv.weight[:, :, 0, 0], c0.conv.bias
+        if c0.with_norm:
+            inv = torch.rsqrt(c0.bn.running_var + c0.bn.eps) * c0.bn.weight
+            w0 = w0 * inv[:, None]
+            b0 = c0.bn.bias - c0.bn.running_mean * inv + (b0 * inv if b0 is not None else 0)
+        h = F.linear(gx, w0, b0)
+        if c0.with_activation:
+            h = torch.relu_(h)
+        return F.linear(h, c1.conv.weight[:, :, 0, 0], c1.conv.bias)
+
+    def _forward_rows(self, xyz, rows):
+        """Inference path without a single transpose: `rows` [B,N,C] is the caller's query tensor (updated in place,
+        'replace' semantics); grouped features are row gathers, the positional MLP runs on coordinate rows, the
+        encoder sees [ns, B*np, C] directly and the winners are gathered back by row."""
+        B, N, C = rows.shape
+        group_idx, group_xyz = self._geometry(xyz)
+        sel, gx, src, has = self._row_plan(xyz, group_idx, group_xyz)
+        ns, np_ = group_idx.shape[2], group_idx.shape[1]
+        flat = rows.reshape(B * N, C)
+        x = flat.index_select(0, sel) + self._pe_rows(gx)
+        y = self.chunk(x.view(ns, B * np_, C)).reshape(ns * B * np_, C)
+        flat.copy_(torch.where(has, y.index_select(0, src), flat))
+        return rows
+
     def forward(self, xyz, features):
         """xyz [B,N,3], features [B,C,N] (may be a permuted view: 'replace' writes through it, as the
         reference does) -> [B,N,C]."""
+        if (features.is_cuda and not torch.is_grad_enabled() and not self.training and features.dtype == torch.float32
+                and self.attn_feat_agg_method == "unique" and self.feat_agg_method == "replace"
+                and features.permute(0, 2, 1).is_contiguous() and not (self.pe[0].with_norm and self.pe[0].bn.training)
+                and self.pe[1].with_norm is False and self.pe[1].with_activation is False):
+            return self._forward_rows(xyz, features.permute(0, 2, 1))
         feats_c = features.contiguous()
         group_idx, group_xyz = self._geometry(xyz)
         group_features = _ops.group_points(feats_c, group_idx)                          # [B,C,np,ns]

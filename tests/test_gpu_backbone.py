@@ -177,6 +177,13 @@ def test_local_transformer_vs_reference_golden(golden):
     with torch.no_grad():
         y = m(torch.from_numpy(xyz).to(dev), torch.from_numpy(feat.copy()).to(dev))
     np.testing.assert_allclose(y.cpu().numpy(), g["out"], rtol=1e-3, atol=1e-4)
+    # the encoder hands the LocalTransformer a permuted VIEW of its [B, N, C] query rows: that takes the row-layout
+    # path (no transposes, in-place 'replace' update) and must give the reference result too
+    rows = torch.from_numpy(np.ascontiguousarray(feat.transpose(0, 2, 1))).to(dev)            # [B, N, C]
+    with torch.no_grad():
+        y2 = m(torch.from_numpy(xyz).to(dev), rows.permute(0, 2, 1))
+    assert y2.data_ptr() == rows.data_ptr()                                                    # updated in place
+    np.testing.assert_allclose(y2.cpu().numpy(), g["out"], rtol=1e-3, atol=1e-4)
 
 
 def test_actrv2_builds_and_runs_with_local_transformer():
