@@ -910,8 +910,8 @@ static bool split_shape_wide(int cin, int cout) {      // served by the output-s
   return (cin == 256 && (cout == 128 || cout == 256)) || (cin == 128 && cout == 256);
 }
 
-static bool split_shape_head(int cin, int cout) {      // detection head: shared conv 512 -> 64, final convs 64 -> <= 32
-  return (cin == 512 && cout == 64) || (cin == 64 && cout == 32);
+static bool split_shape_head(int cin, int cout) {      // detection heads: shared conv 512 -> 64 | 128, final convs -> <= 32
+  return (cin == 512 && (cout == 64 || cout == 128)) || ((cin == 64 || cin == 128) && cout == 32);
 }
 
 // output-stationary launch of any served (cin, cout per column block) pair
@@ -956,6 +956,8 @@ static int launch_os_any(int cin, int cout, const SplitConvArgs &a, hipStream_t 
   if (cin == 256 && cout == 128) return launch_os_split_wide<256, 128>(a, stream);
   if (cin == 128 && cout == 256) return launch_os_split_wide<128, 256>(a, stream);
   if (cin == 512 && cout == 64) return launch_os_split_wide<512, 64>(a, stream);
+  if (cin == 512 && cout == 128) return launch_os_split_wide<512, 128>(a, stream);
+  if (cin == 128 && cout == 32) return launch_os_split<128, 32>(a, stream);
   if (cin == 128 && cout == 128) return launch_os_split<128, 128>(a, stream);
   if (cin == 64 && cout == 128) return launch_os_split<64, 128>(a, stream);
   if (cin == 64 && cout == 64) return launch_os_split<64, 64>(a, stream);

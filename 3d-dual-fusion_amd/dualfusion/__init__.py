@@ -6,7 +6,7 @@ is missing (there is no CPU fallback)."""
 from ._lib import Df3dError, LIB_PATH, load as require  # noqa: F401
 
 __all__ = ["require", "Df3dError", "LIB_PATH", "spconv", "ops", "voxel", "msda", "actr", "fusion", "backbones",
-           "pipeline", "registry", "synth", "necks", "executor", "fusion_tf", "iou3d_nms", "heads"]
+           "pipeline", "registry", "synth", "necks", "executor", "fusion_tf", "iou3d_nms", "heads", "transfusion_head"]
 
 
 def __getattr__(name):

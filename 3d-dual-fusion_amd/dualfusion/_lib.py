@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libdf3d_hip.so")
 
 c_int = ctypes.c_int
+c_uint = ctypes.c_uint
 c_longlong = ctypes.c_longlong
 c_size_t = ctypes.c_size_t
 c_float = ctypes.c_float
@@ -108,6 +109,12 @@ SIGNATURES = {
     "df3d_centerhead_predict_workspace_bytes": (c_size_t, [c_int, c_void_p]),
     "df3d_centerhead_predict": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),
+    "df3d_heatmap_proposals_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "df3d_heatmap_proposals": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_int, c_void_p, c_int,
+                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
+    "df3d_transfusion_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
     "df3d_imgproj_packed_bytes": (c_size_t, [c_int, c_int]),
     "df3d_imgproj_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "df3d_imgproj_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -629,6 +629,99 @@ def centerhead_predict(tasks, batch, H, W, out_size_factor, voxel_size, pc_range
     return boxes, scores, labels, counts
 
 
+class _QueryHeads(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("heatmap", "center", "height", "dim", "rot", "vel")] + \
+               [(n, ctypes.c_int) for n in ("ld_heatmap", "ld_center", "ld_height", "ld_dim", "ld_rot", "ld_vel")]
+
+
+def _row_view(v, rows, name):
+    if v.dtype != torch.float32 or not v.is_cuda or v.dim() != 2 or (v.shape[1] > 1 and v.stride(1) != 1) or v.shape[0] != rows:
+        raise ValueError("'%s' must be a CUDA fp32 [%d, C] view with unit column stride" % (name, rows))
+    return v
+
+
+def heatmap_proposals(heat_rows, batch, num_classes, H, W, nms_kernel_size, exempt_classes, num_proposals,
+                      feat_rows=None, class_weight=None, class_bias=None):
+    """df3d_heatmap_proposals.  heat_rows: fp32 [B*H*W, >= C] view of the dense heat-map logits; feat_rows: fp32
+    [B*H*W, channels] view.  Returns (top_class [B,K] i32, top_pixel [B,K] i32, query_score [B,C,K], query_pos [B,K,2],
+    query_feat [B,K,channels] or None)."""
+    lib = _lib.load()
+    n = int(batch) * int(H) * int(W)
+    _row_view(heat_rows, n, "heat_rows")
+    dev = heat_rows.device
+    K, C = int(num_proposals), int(num_classes)
+    top_class = torch.empty((batch, K), dtype=torch.int32, device=dev)
+    top_pixel = torch.empty((batch, K), dtype=torch.int32, device=dev)
+    qscore = torch.empty((batch, C, K), dtype=torch.float32, device=dev)
+    qpos = torch.empty((batch, K, 2), dtype=torch.float32, device=dev)
+    qfeat, ch = None, 0
+    if feat_rows is not None:
+        _row_view(feat_rows, n, "feat_rows")
+        ch = int(feat_rows.shape[1])
+        qfeat = torch.empty((batch, K, ch), dtype=torch.float32, device=dev)
+        for t, nm, shape in ((class_weight, "class_weight", (ch, C)), (class_bias, "class_bias", (ch,))):
+            if t is not None:
+                _chk(t, torch.float32, nm)
+                if tuple(t.shape) != shape:
+                    raise ValueError("%s must have shape %s" % (nm, (shape,)))
+    mask = 0
+    for c in exempt_classes:
+        mask |= 1 << int(c)
+    nbytes = lib.df3d_heatmap_proposals_workspace_bytes(int(batch), C, int(H), int(W))
+    if nbytes == 0:
+        raise ValueError("df3d_heatmap_proposals: unsupported map size")
+    ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=dev)
+    rc = lib.df3d_heatmap_proposals(_ptr(heat_rows), int(heat_rows.stride(0)), int(batch), C, int(H), int(W),
+                                    int(nms_kernel_size), mask, K, _ptr(feat_rows),
+                                    int(feat_rows.stride(0)) if feat_rows is not None else 0, ch, _ptr(class_weight),
+                                    _ptr(class_bias), _ptr(top_class), _ptr(top_pixel), _ptr(qscore), _ptr(qpos),
+                                    _ptr(qfeat), _ptr(ws), int(nbytes), _stream())
+    _lib.check(rc, "df3d_heatmap_proposals")
+    return top_class, top_pixel, qscore, qpos, qfeat
+
+
+def transfusion_decode(heads, query_score, query_label, batch, num_proposals, num_classes, out_size_factor, voxel_size,
+                       pc_range, post_center_range, score_threshold):
+    """df3d_transfusion_decode.  heads: {'heatmap','center','height','dim','rot'[,'vel']: fp32 [B*K, C] row views}.
+    Returns (boxes [B,K,7|9], scores [B,K], labels [B,K] i32, counts [B] i32); entries past counts[b] are undefined."""
+    lib = _lib.load()
+    B, K = int(batch), int(num_proposals)
+    qh = _QueryHeads()
+    for k in ("heatmap", "center", "height", "dim", "rot", "vel"):
+        v = heads.get(k)
+        if v is None:
+            setattr(qh, k, None)
+            setattr(qh, "ld_" + k, 0)
+            continue
+        _row_view(v, B * K, k)
+        setattr(qh, k, v.data_ptr())
+        setattr(qh, "ld_" + k, int(v.stride(0)))
+    _chk(query_score, torch.float32, "query_score")
+    _chk(query_label, torch.int32, "query_label")
+    if tuple(query_score.shape) != (B, int(num_classes), K) or tuple(query_label.shape) != (B, K):
+        raise ValueError("query_score must be [B, C, K] and query_label [B, K]")
+    cfg = _HeadCfg()
+    cfg.batch, cfg.H, cfg.W = B, 1, 1
+    cfg.out_size_factor = float(out_size_factor)
+    cfg.voxel_size[0], cfg.voxel_size[1] = float(voxel_size[0]), float(voxel_size[1])
+    cfg.pc_range[0], cfg.pc_range[1] = float(pc_range[0]), float(pc_range[1])
+    cfg.has_post_center_range = int(post_center_range is not None and len(post_center_range) == 6)
+    if cfg.has_post_center_range:
+        for e in range(6):
+            cfg.post_center_range[e] = float(post_center_range[e])
+    cfg.score_threshold = float(score_threshold or 0.0)
+    dev = query_score.device
+    bd = 9 if heads.get("vel") is not None else 7
+    boxes = torch.empty((B, K, bd), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, K), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, K), dtype=torch.int32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    rc = lib.df3d_transfusion_decode(ctypes.byref(qh), _ptr(query_score), _ptr(query_label), B, K, int(num_classes),
+                                     ctypes.byref(cfg), _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), _stream())
+    _lib.check(rc, "df3d_transfusion_decode")
+    return boxes, scores, labels, counts
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
     lib = _lib.load()
     _chk(value, torch.float32, "value")

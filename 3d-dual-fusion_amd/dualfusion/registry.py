@@ -79,6 +79,7 @@ FUSION_LAYERS = Registry("fusion_layer")
 CONV_LAYERS = Registry("conv layer")
 MM_BACKBONES = Registry("mmdet backbone")      # 2-D BEV backbone / neck of the TransFusion tree (SECOND, SECONDFPN)
 MM_NECKS = Registry("mmdet neck")
+MM_HEADS = Registry("mmdet head")              # TransFusionHead (mmdet3d HEADS is mmdet's HEADS registry)
 BACKBONES_3D = Registry("pcdet backbone_3d")   # pcdet uses a plain dict `__all__`; same lookup by NAME
 
 
@@ -102,8 +103,8 @@ def late_register():
     except Exception:
         pass
     try:
-        from mmdet.models import BACKBONES as MB, NECKS as MN
-        for src, dst in ((MM_BACKBONES, MB), (MM_NECKS, MN)):
+        from mmdet.models import BACKBONES as MB, HEADS as MH, NECKS as MN
+        for src, dst in ((MM_BACKBONES, MB), (MM_NECKS, MN), (MM_HEADS, MH)):
             for k, v in src.module_dict.items():
                 dst.register_module(name=k, module=v, force=True)
         done.append("mmdet")

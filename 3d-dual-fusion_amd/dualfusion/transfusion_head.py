@@ -1,0 +1,532 @@
+"""Detection head of the TransFusion tree: `TransFusionHead`, LiDAR-only branch
+(`fuse_img=False`, as in TF/configs/transfusion_nusc_voxel_F.py:244-300), with the reference's constructor arguments,
+parameter names (so its checkpoints load) and output structure (TF/mmdet3d/models/dense_heads/transfusion_head.py:
+594-1045, 1285-1376; TransFusionBBoxCoder: core/bbox/coders/transfusion_bbox_coder.py).
+
+Device path in eval mode:
+  * shared 3x3 conv (512 -> 128) and the two heat-map convs (128 -> 128 + BN + ReLU, 128 -> classes) = three launches
+    of the split-precision row kernel on the neck's pixel rows (no NCHW round trip);
+  * sigmoid + local-maximum suppression + top-k + query feature / position gather = `df3d_heatmap_proposals`
+    (keys -> radix sort -> gather) instead of ~25 launches and four map-sized temporaries;
+  * decoder layer: key / value projection of the 32 400 BEV pixels as ONE GEMM on the pixel rows (the learned position
+    embedding of the fixed BEV grid is input-independent in eval mode and folded into a cached additive term), fused
+    attention, all prediction heads as two GEMMs (BN folded, block-diagonal second layer);
+  * `get_bboxes` = `df3d_transfusion_decode` (one launch).
+Training-mode forward runs the plain torch modules (autograd); `loss` / target assignment are out of scope."""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops as _ops
+from .registry import HEADS, MM_HEADS
+
+
+class _ConvModule(nn.Module):
+    """mmcv.cnn.ConvModule as the head uses it: conv [+ norm] + ReLU, attributes `conv` / `bn` / `activate`,
+    bias='auto' = no conv bias when a norm layer follows."""
+
+    def __init__(self, cin, cout, kernel_size, padding=0, bias='auto', conv_cfg=None, norm_cfg=None):
+        super(_ConvModule, self).__init__()
+        conv = {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d}[(conv_cfg or dict(type='Conv2d'))['type']]
+        self.conv = conv(cin, cout, kernel_size, stride=1, padding=padding,
+                         bias=(norm_cfg is None) if bias == 'auto' else bool(bias))
+        if norm_cfg is not None:
+            self.bn = {'BN1d': nn.BatchNorm1d, 'BN2d': nn.BatchNorm2d, 'BN': nn.BatchNorm2d}[norm_cfg['type']](cout)
+        self.activate = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if hasattr(self, "bn"):
+            x = self.bn(x)
+        return self.activate(x)
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """transfusion_head.py:25-41."""
+
+    def __init__(self, input_channel, num_pos_feats=288):
+        super(PositionEmbeddingLearned, self).__init__()
+        self.position_embedding_head = nn.Sequential(nn.Conv1d(input_channel, num_pos_feats, kernel_size=1),
+                                                     nn.BatchNorm1d(num_pos_feats), nn.ReLU(inplace=True),
+                                                     nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+
+    def forward(self, xyz):
+        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+
+
+class MultiheadAttention(nn.Module):
+    """transfusion_head.py:125-253 for kdim = vdim = embed_dim, no key bias / zero attention / masks: parameters
+    `in_proj_weight`, `in_proj_bias`, `out_proj`.  Operands are batch-first [N, L, E] here."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0., bias=True):
+        super(MultiheadAttention, self).__init__()
+        assert embed_dim % num_heads == 0, "embed_dim must be divisible by num_heads"
+        self.embed_dim, self.num_heads, self.dropout, self.head_dim = embed_dim, num_heads, dropout, embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        if bias:
+            self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        else:
+            self.register_parameter('in_proj_bias', None)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        if bias:
+            nn.init.constant_(self.in_proj_bias, 0.)
+            nn.init.constant_(self.out_proj.bias, 0.)
+
+    def _heads(self, t):
+        return t.view(t.shape[0], t.shape[1], self.num_heads, self.head_dim).transpose(1, 2)
+
+    def attend(self, q, k, v):
+        """q [N, L, E], k / v [N, S, E] already projected -> out_proj(softmax(q k^T / sqrt(d)) v)."""
+        o = F.scaled_dot_product_attention(self._heads(q), self._heads(k), self._heads(v),
+                                           dropout_p=self.dropout if self.training else 0.0)
+        return self.out_proj(o.transpose(1, 2).reshape(q.shape[0], q.shape[1], self.embed_dim))
+
+    def forward(self, query, key, value):
+        E = self.embed_dim
+        w, b = self.in_proj_weight, self.in_proj_bias
+        bs = (None, None, None) if b is None else (b[:E], b[E:2 * E], b[2 * E:])
+        return self.attend(F.linear(query, w[:E], bs[0]), F.linear(key, w[E:2 * E], bs[1]), F.linear(value, w[2 * E:], bs[2]))
+
+
+class TransformerDecoderLayer(nn.Module):
+    """transfusion_head.py:44-122 (post-norm decoder layer with learned position embeddings on query and key)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", self_posembed=None,
+                 cross_posembed=None, cross_only=False):
+        super(TransformerDecoderLayer, self).__init__()
+        self.cross_only = cross_only
+        if not cross_only:
+            self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
+        if activation not in ("relu", "gelu"):
+            raise RuntimeError("activation should be relu/gelu, not %s." % activation)
+        self.activation = F.relu if activation == "relu" else F.gelu
+        self.self_posembed, self.cross_posembed = self_posembed, cross_posembed
+
+    def forward(self, query, key, query_pos, key_pos):
+        """query [B, C, Pq], key [B, C, Pk], query_pos [B, Pq, 2], key_pos [B, Pk, 2] -> [B, C, Pq]."""
+        qpe = self.self_posembed(query_pos).transpose(1, 2) if self.self_posembed is not None else 0
+        kpe = self.cross_posembed(key_pos).transpose(1, 2) if self.cross_posembed is not None else 0
+        q = query.transpose(1, 2)
+        k = key.transpose(1, 2) + kpe
+        return self.finish(q, qpe, lambda qq: self.multihead_attn(qq, k, k)).transpose(1, 2)
+
+    def finish(self, q, qpe, cross):
+        """q [B, Pq, C]; cross(q + qpe) -> the cross-attention output."""
+        if not self.cross_only:
+            s = q + qpe
+            q = self.norm1(q + self.dropout1(self.self_attn(s, s, s)))
+        q = self.norm2(q + self.dropout2(cross(q + qpe)))
+        q2 = self.linear2(self.dropout(self.activation(self.linear1(q))))
+        return self.norm3(q + self.dropout3(q2))
+
+
+class FFN(nn.Module):
+    """Prediction heads of one decoder layer (transfusion_head.py:507-591): per head (ConvModule 1x1 + BN1d + ReLU)
+    x (num_conv - 1), then Conv1d -> classes."""
+
+    def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, init_bias=-2.19, conv_cfg=dict(type='Conv1d'),
+                 norm_cfg=dict(type='BN1d'), bias='auto', **kwargs):
+        super(FFN, self).__init__()
+        self.heads = heads
+        self.init_bias = init_bias
+        for head in self.heads:
+            classes, num_conv = self.heads[head]
+            layers, c_in = [], in_channels
+            for _ in range(num_conv - 1):
+                layers.append(_ConvModule(c_in, head_conv, final_kernel, padding=final_kernel // 2, bias=bias,
+                                          conv_cfg=conv_cfg, norm_cfg=norm_cfg))
+                c_in = head_conv
+            layers.append({'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d}[conv_cfg['type']](
+                c_in, classes, kernel_size=final_kernel, stride=1, padding=final_kernel // 2, bias=True))
+            self.__setattr__(head, nn.Sequential(*layers))
+
+    def init_weights(self):
+        for head in self.heads:
+            if head == 'heatmap':
+                self.__getattr__(head)[-1].bias.data.fill_(self.init_bias)
+
+    def forward(self, x):
+        return {head: self.__getattr__(head)(x) for head in self.heads}
+
+
+class TransFusionBBoxCoder(object):
+    """core/bbox/coders/transfusion_bbox_coder.py:8-128."""
+
+    def __init__(self, pc_range, out_size_factor, voxel_size, post_center_range=None, score_threshold=None, code_size=8):
+        self.pc_range, self.out_size_factor, self.voxel_size = pc_range, out_size_factor, voxel_size
+        self.post_center_range, self.score_threshold, self.code_size = post_center_range, score_threshold, code_size
+
+    def encode(self, dst_boxes):
+        t = torch.zeros([dst_boxes.shape[0], self.code_size]).to(dst_boxes.device)
+        t[:, 0] = (dst_boxes[:, 0] - self.pc_range[0]) / (self.out_size_factor * self.voxel_size[0])
+        t[:, 1] = (dst_boxes[:, 1] - self.pc_range[1]) / (self.out_size_factor * self.voxel_size[1])
+        t[:, 3:6] = dst_boxes[:, 3:6].log()
+        t[:, 2] = dst_boxes[:, 2] + dst_boxes[:, 5] * 0.5
+        t[:, 6], t[:, 7] = torch.sin(dst_boxes[:, 6]), torch.cos(dst_boxes[:, 6])
+        if self.code_size == 10:
+            t[:, 8:10] = dst_boxes[:, 7:]
+        return t
+
+    def decode(self, heatmap, rot, dim, center, height, vel, filter=False):
+        """Plain torch decode (any device); the head's `get_bboxes` uses df3d_transfusion_decode instead."""
+        final_scores, final_preds = heatmap.max(1)
+        center = torch.stack([center[:, 0] * self.out_size_factor * self.voxel_size[0] + self.pc_range[0],
+                              center[:, 1] * self.out_size_factor * self.voxel_size[1] + self.pc_range[1]], 1)
+        dim = dim.exp()
+        height = height - dim[:, 2:3, :] * 0.5
+        rot = torch.atan2(rot[:, 0:1, :], rot[:, 1:2, :])
+        parts = [center, height, dim, rot] + ([vel] if vel is not None else [])
+        boxes = torch.cat(parts, dim=1).permute(0, 2, 1)
+        B = heatmap.shape[0]
+        if filter is False:
+            return [dict(bboxes=boxes[i], scores=final_scores[i], labels=final_preds[i]) for i in range(B)]
+        if self.post_center_range is None:
+            raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range is not None for now!')
+        rng = torch.tensor(self.post_center_range, device=heatmap.device, dtype=boxes.dtype)
+        mask = (boxes[..., :3] >= rng[:3]).all(2) & (boxes[..., :3] <= rng[3:]).all(2)
+        if self.score_threshold:
+            mask &= final_scores > self.score_threshold
+        return [dict(bboxes=boxes[i, mask[i]], scores=final_scores[i, mask[i]], labels=final_preds[i, mask[i]])
+                for i in range(B)]
+
+
+_EXEMPT = {'nuScenes': (8, 9), 'Waymo': (1, 2)}        # transfusion_head.py:856-861
+
+
+@HEADS.register_module
+@MM_HEADS.register_module
+class TransFusionHead(nn.Module):
+    def __init__(self, fuse_img=False, num_views=0, in_channels_img=64, out_size_factor_img=4, num_proposals=128,
+                 auxiliary=True, in_channels=128 * 3, hidden_channel=128, num_classes=4, num_decoder_layers=3, num_heads=8,
+                 learnable_query_pos=False, initialize_by_heatmap=False, nms_kernel_size=1, ffn_channel=256, dropout=0.1,
+                 bn_momentum=0.1, activation='relu', common_heads=dict(), num_heatmap_convs=2,
+                 conv_cfg=dict(type='Conv1d'), norm_cfg=dict(type='BN1d'), bias='auto', loss_cls=None, loss_iou=None,
+                 loss_bbox=None, loss_heatmap=None, train_cfg=None, test_cfg=None, bbox_coder=None):
+        super(TransFusionHead, self).__init__()
+        if fuse_img:
+            raise NotImplementedError("fuse_img=True (the camera decoder of TransFusion-LC) is not part of the "
+                                      "3D-Dual-Fusion configs, which use the LiDAR-only head")
+        self.num_classes = num_classes
+        self.num_proposals = num_proposals
+        self.auxiliary = auxiliary
+        self.in_channels = in_channels
+        self.num_heads = num_heads
+        self.num_decoder_layers = num_decoder_layers
+        self.bn_momentum = bn_momentum
+        self.learnable_query_pos = learnable_query_pos
+        self.initialize_by_heatmap = initialize_by_heatmap
+        self.nms_kernel_size = nms_kernel_size
+        if initialize_by_heatmap:
+            assert learnable_query_pos is False, "initialized by heatmap is conflicting with learnable query position"
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.use_sigmoid_cls = (loss_cls or {}).get('use_sigmoid', False)
+        if not self.use_sigmoid_cls:
+            self.num_classes += 1
+        coder = dict(bbox_coder or {})
+        coder.pop('type', None)
+        self.bbox_coder = TransFusionBBoxCoder(**coder) if coder else None
+        self.fuse_img = False
+        self.shared_conv = nn.Conv2d(in_channels, hidden_channel, kernel_size=3, padding=1, bias=bool(bias))
+        if initialize_by_heatmap:
+            self.heatmap_head = nn.Sequential(
+                _ConvModule(hidden_channel, hidden_channel, 3, padding=1, bias=bias, conv_cfg=dict(type='Conv2d'),
+                            norm_cfg=dict(type='BN2d')),
+                nn.Conv2d(hidden_channel, num_classes, kernel_size=3, padding=1, bias=bool(bias)))
+            self.class_encoding = nn.Conv1d(num_classes, hidden_channel, 1)
+        else:
+            self.query_feat = nn.Parameter(torch.randn(1, hidden_channel, num_proposals))
+            self.query_pos = nn.Parameter(torch.rand([1, num_proposals, 2]), requires_grad=learnable_query_pos)
+        self.decoder = nn.ModuleList([
+            TransformerDecoderLayer(hidden_channel, num_heads, ffn_channel, dropout, activation,
+                                    self_posembed=PositionEmbeddingLearned(2, hidden_channel),
+                                    cross_posembed=PositionEmbeddingLearned(2, hidden_channel))
+            for _ in range(num_decoder_layers)])
+        self.prediction_heads = nn.ModuleList()
+        for _ in range(num_decoder_layers):
+            heads = copy.deepcopy(common_heads)
+            heads.update(dict(heatmap=(self.num_classes, num_heatmap_convs)))
+            self.prediction_heads.append(FFN(hidden_channel, heads, conv_cfg=conv_cfg, norm_cfg=norm_cfg, bias=bias))
+        self.init_weights()
+        x_size = self.test_cfg['grid_size'][0] // self.test_cfg['out_size_factor']
+        y_size = self.test_cfg['grid_size'][1] // self.test_cfg['out_size_factor']
+        self.bev_pos = self.create_2D_grid(x_size, y_size)
+        self.query_labels = None
+
+    def create_2D_grid(self, x_size, y_size):
+        """[1, x_size * y_size, 2]: entry i * y_size + j = (j + 0.5, i + 0.5) (transfusion_head.py:758-765)."""
+        by, bx = torch.meshgrid(torch.linspace(0, x_size - 1, x_size), torch.linspace(0, y_size - 1, y_size), indexing="ij")
+        return torch.stack([bx + 0.5, by + 0.5], 0).view(1, 2, -1).permute(0, 2, 1).contiguous()
+
+    def init_weights(self):
+        for m in self.decoder.parameters():
+            if m.dim() > 1:
+                nn.init.xavier_uniform_(m)
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.momentum = self.bn_momentum
+
+    def train(self, mode=True):
+        self.__dict__.pop("_row_plan", None)
+        return super(TransFusionHead, self).train(mode)
+
+    # ------------------------------------------------------------------ plain torch path (training / CPU)
+    def forward_reference(self, inputs):
+        """forward_single (transfusion_head.py:797-1030), LiDAR-only statements."""
+        B = inputs.shape[0]
+        lidar_feat = self.shared_conv(inputs)
+        flat = lidar_feat.view(B, lidar_feat.shape[1], -1)
+        bev_pos = self.bev_pos.repeat(B, 1, 1).to(lidar_feat.device)
+        if self.initialize_by_heatmap:
+            dense_heatmap = self.heatmap_head(lidar_feat)
+            heatmap = dense_heatmap.detach().sigmoid()
+            pad = self.nms_kernel_size // 2
+            local_max = torch.zeros_like(heatmap)
+            inner = F.max_pool2d(heatmap, kernel_size=self.nms_kernel_size, stride=1, padding=0)
+            local_max[:, :, pad:heatmap.shape[2] - pad, pad:heatmap.shape[3] - pad] = inner
+            for c in _EXEMPT.get(self.test_cfg['dataset'], ()):
+                local_max[:, c] = heatmap[:, c]
+            heatmap = (heatmap * (heatmap == local_max)).view(B, heatmap.shape[1], -1)
+            top = heatmap.view(B, -1).argsort(dim=-1, descending=True, stable=True)[..., :self.num_proposals]
+            top_class = top // heatmap.shape[-1]
+            top_index = top % heatmap.shape[-1]
+            query_feat = flat.gather(index=top_index[:, None, :].expand(-1, flat.shape[1], -1), dim=-1)
+            self.query_labels = top_class
+            one_hot = F.one_hot(top_class, num_classes=self.num_classes).permute(0, 2, 1)
+            query_feat = query_feat + self.class_encoding(one_hot.float())
+            query_pos = bev_pos.gather(index=top_index[:, :, None].expand(-1, -1, 2), dim=1)
+        else:
+            query_feat = self.query_feat.repeat(B, 1, 1)
+            query_pos = self.query_pos.repeat(B, 1, 1).to(lidar_feat.device)
+        ret_dicts = []
+        for i in range(self.num_decoder_layers):
+            query_feat = self.decoder[i](query_feat, flat, query_pos, bev_pos)
+            res = self.prediction_heads[i](query_feat)
+            res['center'] = res['center'] + query_pos.permute(0, 2, 1)
+            ret_dicts.append(res)
+            query_pos = res['center'].detach().clone().permute(0, 2, 1)
+        if self.initialize_by_heatmap:
+            ret_dicts[0]['query_heatmap_score'] = heatmap.gather(
+                index=top_index[:, None, :].expand(-1, self.num_classes, -1), dim=-1)
+            ret_dicts[0]['dense_heatmap'] = dense_heatmap
+        return self._collect(ret_dicts)
+
+    def _collect(self, ret_dicts):
+        if self.auxiliary is False:
+            return [ret_dicts[-1]]
+        new_res = {}
+        for key in ret_dicts[0].keys():
+            if key not in ('dense_heatmap', 'dense_heatmap_old', 'query_heatmap_score'):
+                new_res[key] = torch.cat([r[key] for r in ret_dicts], dim=-1) if len(ret_dicts) > 1 else ret_dicts[0][key]
+            else:
+                new_res[key] = ret_dicts[0][key]
+        return [new_res]
+
+    def forward_single(self, inputs, img_inputs=None, img_metas=None):
+        if (self.training or torch.is_grad_enabled() or not inputs.is_cuda or inputs.dtype != torch.float32
+                or _ops.CONV_PRECISION != "split" or not self._row_kernels_fit(inputs)):
+            return self.forward_reference(inputs)
+        return self.forward_rows(inputs)
+
+    def forward(self, feats, img_feats=None, img_metas=None):
+        """feats: list with ONE BEV map [B, C, H, W] (or the tensor).  Returns ([dict],) like the reference's
+        multi_apply over levels (transfusion_head.py:1032-1046)."""
+        if torch.is_tensor(feats):
+            feats = [feats]
+        assert len(feats) == 1, "only support one level features."
+        return ([self.forward_single(feats[0], None, img_metas)[0]],)
+
+    # ------------------------------------------------------------------ device path
+    def _row_kernels_fit(self, x):
+        hm = getattr(self, "heatmap_head", None)
+        return (self.initialize_by_heatmap and self.shared_conv.in_channels == 512 and self.shared_conv.out_channels == 128
+                and self.shared_conv.bias is not None and self.num_classes <= 32 and self.nms_kernel_size >= 3
+                and self.nms_kernel_size % 2 == 1 and x.shape[2] * x.shape[3] == self.bev_pos.shape[1]
+                and hm is not None and hm[1].bias is not None and hasattr(hm[0], "bn"))
+
+    @staticmethod
+    def _filters(conv, pad_to=None):
+        w = conv.weight.detach().float().permute(2, 3, 1, 0).reshape(9, conv.in_channels, conv.out_channels)
+        if pad_to is not None and pad_to > conv.out_channels:
+            w = torch.cat([w, w.new_zeros(9, conv.in_channels, pad_to - conv.out_channels)], 2)
+        return w.contiguous()
+
+    @staticmethod
+    def _fold(bn):
+        scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+        return scale.contiguous(), (bn.bias.detach().float() - bn.running_mean.float() * scale).contiguous()
+
+    def _plan(self):
+        params = [p for p in self.parameters()] + [b for b in self.buffers()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        plan = self.__dict__.get("_row_plan")
+        if plan is not None and plan["key"] == key:
+            return plan
+        dev = self.shared_conv.weight.device
+        hm0, hm1 = self.heatmap_head[0], self.heatmap_head[1]
+        C = self.num_classes
+        m_scale, m_shift = self._fold(hm0.bn)
+        plan = dict(key=key, nbr={}, kv_const={},
+                    shared=_ops.conv_pack_weights(self._filters(self.shared_conv)),
+                    s_bias=self.shared_conv.bias.detach().float().contiguous(),
+                    mid=_ops.conv_pack_weights(self._filters(hm0.conv)),
+                    m_bias=hm0.conv.bias.detach().float().contiguous() if hm0.conv.bias is not None else None,
+                    m_scale=m_scale, m_shift=m_shift,
+                    fin=_ops.conv_pack_weights(self._filters(hm1, 32)),
+                    f_bias=torch.cat([hm1.bias.detach().float(), torch.zeros(32 - C, device=dev)]).contiguous(),
+                    cols=torch.tensor([[0, C]], dtype=torch.int32, device=dev), width=(C + 7) // 8 * 8,
+                    cls_w=self.class_encoding.weight.detach().float().reshape(-1, C).contiguous(),
+                    cls_b=self.class_encoding.bias.detach().float().contiguous(), layers=[])
+        for i in range(self.num_decoder_layers):
+            dec, ffn = self.decoder[i], self.prediction_heads[i]
+            E = dec.multihead_attn.embed_dim
+            w, b = dec.multihead_attn.in_proj_weight.detach().float(), dec.multihead_attn.in_proj_bias.detach().float()
+            w1, b1, blocks, b2, layout, c0 = [], [], [], [], [], 0
+            for head in ffn.heads:
+                fc = getattr(ffn, head)
+                if len(fc) != 2:
+                    raise NotImplementedError("prediction heads with num_conv != 2")
+                a, s = self._fold(fc[0].bn) if hasattr(fc[0], "bn") else (None, None)
+                cw = fc[0].conv.weight.detach().float().reshape(fc[0].conv.out_channels, -1)
+                cb = fc[0].conv.bias.detach().float() if fc[0].conv.bias is not None else cw.new_zeros(cw.shape[0])
+                w1.append(cw * a[:, None] if a is not None else cw)
+                b1.append(cb * a + s if a is not None else cb)
+                blocks.append(fc[1].weight.detach().float().reshape(fc[1].out_channels, -1))
+                b2.append(fc[1].bias.detach().float())
+                layout.append((head, c0, fc[1].out_channels))
+                c0 += fc[1].out_channels
+            plan["layers"].append(dict(wq=w[:E].contiguous(), bq=b[:E].contiguous(), wkv_t=w[E:].t().contiguous(),
+                                       bkv=b[E:].contiguous(), w1=torch.cat(w1).contiguous(), b1=torch.cat(b1).contiguous(),
+                                       w2=torch.block_diag(*blocks).contiguous(), b2=torch.cat(b2).contiguous(),
+                                       layout=layout))
+        self.__dict__["_row_plan"] = plan
+        return plan
+
+    def _kv_const(self, plan, i, B, dev):
+        """rows of  cross_posembed(bev_pos) @ W_kv^T + b_kv  [B*H*W, 2E]: the additive term of the key / value GEMM."""
+        if (i, B) not in plan["kv_const"]:
+            L = plan["layers"][i]
+            kpe = self.decoder[i].cross_posembed(self.bev_pos.to(dev))[0].t()               # [HW, E]
+            plan["kv_const"][(i, B)] = torch.addmm(L["bkv"], kpe, L["wkv_t"]).repeat(B, 1).contiguous()
+        return plan["kv_const"][(i, B)]
+
+    @torch.no_grad()
+    def forward_rows(self, x):
+        from .necks import _rows_of
+        plan = self._plan()
+        B, _, H, W = x.shape
+        n, C, K, dev = B * H * W, self.num_classes, self.num_proposals, x.device
+        rows, split = _rows_of(x)
+        if split is None:
+            split = _ops.split_rows(rows.contiguous())
+        if (B, H, W) not in plan["nbr"]:
+            plan["nbr"][(B, H, W)] = _ops.conv2d_neighbors(B, H, W, 3, 3, 1, 1, False, dev)[0]
+        nbr = plan["nbr"][(B, H, W)]
+        feat, s1 = _ops.conv_rows_split(split, 512, 0, plan["shared"], 128, 1, nbr, n, plan["s_bias"], None, None,
+                                        relu=False, want_out=True, want_split=True)
+        _, s2 = _ops.conv_rows_split(s1, 128, 0, plan["mid"], 128, 1, nbr, n, plan["m_bias"], plan["m_scale"],
+                                     plan["m_shift"], relu=True, want_out=False, want_split=True)
+        heat, _ = _ops.conv_rows_split(s2, 128, 0, plan["fin"], 32, 1, nbr, n, plan["f_bias"], None, None, relu=False,
+                                       out_channels=plan["width"], out_cols=plan["cols"])
+        top_class, top_pixel, qscore, query_pos, qf = _ops.heatmap_proposals(
+            heat[:, :C], B, C, H, W, self.nms_kernel_size, _EXEMPT.get(self.test_cfg['dataset'], ()), K, feat,
+            plan["cls_w"], plan["cls_b"])
+        self.query_labels = top_class.long()
+        E = feat.shape[1]
+        ret_dicts = []
+        for i in range(self.num_decoder_layers):
+            dec, L = self.decoder[i], plan["layers"][i]
+            qpe = dec.self_posembed(query_pos).transpose(1, 2)                              # [B, K, E]
+            kv = torch.addmm(self._kv_const(plan, i, B, dev), feat, L["wkv_t"]).view(B, H * W, 2 * E)
+
+            def cross(qq, dec=dec, L=L, kv=kv):
+                return dec.multihead_attn.attend(F.linear(qq, L["wq"], L["bq"]), kv[..., :E], kv[..., E:])
+            qf = dec.finish(qf, qpe, cross)
+            out = torch.addmm(L["b2"], torch.relu_(torch.addmm(L["b1"], qf.reshape(B * K, E), L["w1"].t())), L["w2"].t())
+            out = out.view(B, K, -1)
+            res = {}
+            for head, c0, k in L["layout"]:
+                if head == 'center':
+                    out[..., c0:c0 + k] += query_pos
+                res[head] = out[..., c0:c0 + k].permute(0, 2, 1)
+            ret_dicts.append(res)
+            query_pos = res['center'].permute(0, 2, 1).clone()
+        ret_dicts[0]['query_heatmap_score'] = qscore
+        ret_dicts[0]['dense_heatmap'] = heat[:, :C].view(B, H, W, C).permute(0, 3, 1, 2)
+        return self._collect(ret_dicts)
+
+    # ------------------------------------------------------------------ boxes
+    def loss(self, *args, **kwargs):
+        raise NotImplementedError("target assignment and losses are training rows outside this build's scope "
+                                  "(SURVEY.md section 8f row 4)")
+
+    def get_bboxes_device(self, preds_dicts):
+        """Device-resident result of get_bboxes with nms_type=None: (boxes [B, K, 7|9], scores [B, K], labels [B, K] i32,
+        counts [B] i32); the first counts[b] entries of sample b are valid, in proposal order."""
+        p = preds_dicts[0][0]
+        K, C = self.num_proposals, self.num_classes
+        B = p['heatmap'].shape[0]
+        heads = {}
+        for k in ('heatmap', 'center', 'height', 'dim', 'rot', 'vel'):
+            if k in p:
+                heads[k] = p[k][..., -K:].permute(0, 2, 1).reshape(B * K, -1).float()
+        c = self.bbox_coder
+        return _ops.transfusion_decode(heads, p['query_heatmap_score'].float().contiguous(),
+                                       self.query_labels.to(torch.int32).contiguous(), B, K, C, c.out_size_factor,
+                                       c.voxel_size, c.pc_range, c.post_center_range, c.score_threshold)
+
+    @torch.no_grad()
+    def get_bboxes(self, preds_dicts, img_metas=None, img=None, rescale=False, for_roi=False):
+        """transfusion_head.py:1285-1376.  Returns one [boxes, scores, labels] triple per sample (the reference
+        asserts a single sample and returns the one-element list)."""
+        p = preds_dicts[0][0]
+        nms_type = (self.test_cfg or {}).get('nms_type')
+        if self.bbox_coder.post_center_range is None:
+            raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range is not None for now!')
+        if p['heatmap'].is_cuda:
+            boxes, scores, labels, counts = self.get_bboxes_device(preds_dicts)
+            counts = counts.tolist()
+            dets = [(boxes[b, :n], scores[b, :n], labels[b, :n].long()) for b, n in enumerate(counts)]
+        else:
+            K = self.num_proposals
+            one_hot = F.one_hot(self.query_labels, num_classes=self.num_classes).permute(0, 2, 1)
+            score = p['heatmap'][..., -K:].sigmoid() * p['query_heatmap_score'] * one_hot
+            t = self.bbox_coder.decode(score, p['rot'][..., -K:], p['dim'][..., -K:], p['center'][..., -K:],
+                                       p['height'][..., -K:], p['vel'][..., -K:] if 'vel' in p else None, filter=True)
+            dets = [(d['bboxes'], d['scores'], d['labels']) for d in t]
+        if nms_type is not None:
+            dets = [self._task_nms(*d, nms_type) for d in dets]
+        wrap = None
+        if img_metas and isinstance(img_metas[0], dict) and callable(img_metas[0].get('box_type_3d')):
+            wrap = img_metas[0]['box_type_3d']
+        return [[wrap(b, box_dim=b.shape[-1]) if wrap else b, s, l.int()] for b, s, l in dets]
+
+    def _task_nms(self, boxes3d, scores, labels, nms_type):
+        """Per-task NMS of transfusion_head.py:1313-1357 (circle NMS on the device; task radii of the reference)."""
+        from .iou3d_nms import circle_nms
+        if nms_type != 'circle':
+            raise NotImplementedError("nms_type=%r needs mmdet3d's box classes; the 3D-DF config uses None" % (nms_type,))
+        if self.test_cfg['dataset'] == 'nuScenes':
+            tasks = [(list(range(8)), -1), ([8], 0.175), ([9], 0.175)]
+        elif self.test_cfg['dataset'] == 'Waymo':
+            tasks = [([0], 0.7), ([1], 0.7), ([2], 0.7)]
+        else:
+            tasks = []
+        keep = torch.zeros_like(scores, dtype=torch.bool)
+        for classes, radius in tasks:
+            m = torch.zeros_like(keep)
+            for c in classes:
+                m |= labels == c
+            idx = torch.where(m)[0]
+            if radius > 0 and idx.numel():
+                idx = idx[circle_nms(torch.cat([boxes3d[idx][:, :2], scores[idx, None]], 1), radius).long()]
+            keep[idx] = True
+        return boxes3d[keep], scores[keep], labels[keep]

@@ -287,6 +287,42 @@ int df3d_centerhead_predict(const df3d_head_task *tasks, int ntasks, const df3d_
                             size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * TransFusionHead (LiDAR-only branch), the index and decode steps.
+ *
+ * df3d_heatmap_proposals replaces transfusion_head.py:843-878 (TF/mmdet3d/models/dense_heads/): sigmoid of the
+ * dense heat map, 3x3 (nms_kernel_size) local-maximum suppression on interior pixels, classes of `exempt_classes`
+ * (bit c) keep every pixel (:856-861, nuScenes 8 and 9 / Waymo 1 and 2), top num_proposals of the [C*H*W] scores of
+ * each sample (descending; equal scores by ascending flat index, which the reference's unstable argsort leaves open),
+ * query features  feat[pixel] + class_weight[:, class] + class_bias  (class_encoding Conv1d on the one-hot, :872-875)
+ * and query positions (x + 0.5, y + 0.5) (:758-765,878).
+ *   heat_rows [B*H*W, ld_heat] f32 logits (channels-last pixel rows), feat_rows [B*H*W, ld_feat] f32,
+ *   class_weight [channels, C] f32 (Conv1d weight [channels, C, 1]), class_bias [channels];
+ *   out: top_class, top_pixel [B, K] i32; query_score [B, C, K] f32 (= 'query_heatmap_score', :1013);
+ *   query_pos [B, K, 2] f32; query_feat [B, K, channels] f32 (either may be NULL).
+ *
+ * df3d_transfusion_decode replaces get_bboxes with nms_type=None (:1285-1312) over TransFusionBBoxCoder.decode
+ * (core/bbox/coders/transfusion_bbox_coder.py:41-128, filter=True): score = sigmoid(heatmap)[label] *
+ * query_score[label], boxes [x, y, z, dx, dy, dz, rot, (vx, vy)], post_center_range mask and score threshold
+ * (applied only when non-zero, like `if self.score_threshold:`), order-preserving compaction per sample.
+ *   heads: rows [B*K, ld_*] of the LAST decoder layer; cfg: out_size_factor, voxel_size, pc_range,
+ *   has_post_center_range / post_center_range, score_threshold (batch, H, W, nms_*, pre/post_max unused);
+ *   out_boxes [B, K, 7|9], out_scores / out_labels [B, K], out_counts [B].
+ */
+typedef struct df3d_query_heads {
+  const float *heatmap, *center, *height, *dim, *rot, *vel; /* vel may be NULL */
+  int ld_heatmap, ld_center, ld_height, ld_dim, ld_rot, ld_vel;
+} df3d_query_heads;
+size_t df3d_heatmap_proposals_workspace_bytes(int batch, int num_classes, int H, int W);
+int df3d_heatmap_proposals(const float *heat_rows, int ld_heat, int batch, int num_classes, int H, int W,
+                           int nms_kernel_size, unsigned exempt_classes, int num_proposals, const float *feat_rows,
+                           int ld_feat, int channels, const float *class_weight, const float *class_bias,
+                           int32_t *top_class, int32_t *top_pixel, float *query_score, float *query_pos,
+                           float *query_feat, void *workspace, size_t workspace_bytes, void *stream);
+int df3d_transfusion_decode(const df3d_query_heads *heads, const float *query_score, const int32_t *query_label,
+                            int batch, int num_proposals, int num_classes, const df3d_head_decode_cfg *cfg,
+                            float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *out_counts, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Multi-scale deformable attention, forward.  Replaces
  * MultiScaleDeformableAttention.ms_deform_attn_forward (CP/det3d/models/model_utils/ops/src/
  * vision.cpp:13-16, ms_deform_attn.h:21-40, cuda/ms_deform_attn_cuda.cu:20-84, kernel

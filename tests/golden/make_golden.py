@@ -648,6 +648,151 @@ def gen_centerhead():
     save("centerhead.npz", **out)
 
 
+TFH_SHAPE = (2, 512, 20, 22)                       # [B, 2 x 256 neck channels, H, W]
+TFH_KW = dict(num_proposals=24, auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10,
+              num_decoder_layers=1, num_heads=8, learnable_query_pos=False, initialize_by_heatmap=True,
+              nms_kernel_size=3, ffn_channel=256, dropout=0.1, bn_momentum=0.1, activation='relu',
+              common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)))
+# transfusion_nusc_voxel_F.py:244-300 on a small map: grid_size / out_size_factor give the 20 x 22 BEV grid
+# (grid_size[0] sizes the first mesh axis = rows), and the centre range is narrowed so that the range mask decides.
+TFH_CODER = dict(pc_range=[-6.0, -6.6], voxel_size=[0.075, 0.075], out_size_factor=8,
+                 post_center_range=[-5.2, -5.9, -10.0, 5.0, 5.6, 10.0], score_threshold=0.0, code_size=10)
+TFH_TEST_CFG = dict(dataset='nuScenes', grid_size=[160, 176, 40], out_size_factor=8, pc_range=[-6.0, -6.6],
+                    voxel_size=[0.075, 0.075], nms_type=None)
+
+
+def tfh_weight_shift(sd):
+    """detgen weights with a wider heat map (final 3x3 conv) and wider box regressions."""
+    for k in sd:
+        if k == "heatmap_head.1.weight":
+            sd[k] = sd[k] * 10.0
+        if k.startswith("prediction_heads.") and k.endswith(".1.weight"):
+            sd[k] = sd[k] * 4.0
+    return sd
+
+
+def import_reference_transfusion_head():
+    """TF/mmdet3d/models/dense_heads/transfusion_head.py and core/bbox/coders/transfusion_bbox_coder.py (the
+    reference's own files) under import stubs for the absent mmcv / mmdet packages: ConvModule is restated for the
+    two configurations the head uses (Conv1d/2d [+ BN] + ReLU, attribute names conv / bn / activate, bias = no norm),
+    build_conv_layer maps the cfg type onto torch.nn, multi_apply is mmdet's map-and-transpose."""
+    import importlib.util
+    R = "/root/reference/TransFusion/mmdet3d"
+
+    class ConvModule(torch.nn.Module):
+        def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias='auto', conv_cfg=None, norm_cfg=None):
+            super().__init__()
+            conv = getattr(torch.nn, (conv_cfg or dict(type='Conv2d'))['type'])
+            self.conv = conv(cin, cout, kernel_size, stride=stride, padding=padding,
+                             bias=(norm_cfg is None) if bias == 'auto' else bias)
+            if norm_cfg is not None:
+                self.bn = {'BN1d': torch.nn.BatchNorm1d, 'BN2d': torch.nn.BatchNorm2d}[norm_cfg['type']](cout)
+            self.activate = torch.nn.ReLU(inplace=True)
+
+        def forward(self, x):
+            x = self.conv(x)
+            if hasattr(self, "bn"):
+                x = self.bn(x)
+            return self.activate(x)
+
+    def build_conv_layer(cfg, *a, **k):
+        return getattr(torch.nn, cfg['type'])(*a, **k)
+
+    class Reg:
+        def __init__(self):
+            self.d = {}
+
+        def register_module(self, *a, **k):
+            def deco(c):
+                self.d[c.__name__] = c
+                return c
+            return deco
+    heads, coders = Reg(), Reg()
+    _stub("mmcv")
+    _stub("mmcv.cnn", ConvModule=ConvModule, build_conv_layer=build_conv_layer, kaiming_init=lambda m, **k: None)
+    _stub("mmcv.runner", force_fp32=lambda *a, **k: (lambda f: f))
+    _stub("mmdet")
+    _stub("mmdet.core.bbox", BaseBBoxCoder=object)
+    _stub("mmdet.core.bbox.builder", BBOX_CODERS=coders)
+    spec = importlib.util.spec_from_file_location("tf_coder", R + "/core/bbox/coders/transfusion_bbox_coder.py")
+    cm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cm)
+
+    def multi_apply(func, *args):
+        return tuple(map(list, zip(*map(func, *args))))
+
+    def build_bbox_coder(cfg):
+        cfg = dict(cfg)
+        return coders.d[cfg.pop('type')](**cfg)
+    _stub("mmdet.core", build_bbox_coder=build_bbox_coder, multi_apply=multi_apply, build_assigner=None,
+          build_sampler=None, AssignResult=None)
+    _stub("mmdet3d")
+    _stub("mmdet3d.core", circle_nms=None, draw_heatmap_gaussian=None, gaussian_radius=None, xywhr2xyxyr=None,
+          limit_period=None, PseudoSampler=None, Box3DMode=None, LiDARInstance3DBoxes=None)
+    _stub("mmdet3d.core.bbox")
+    _stub("mmdet3d.core.bbox.structures", rotation_3d_in_axis=None)
+    mb = _stub("mmdet3d.models.builder", HEADS=heads, build_loss=lambda cfg: None)
+    _stub("mmdet3d.models", builder=mb)
+    _stub("mmdet3d.models.utils", clip_sigmoid=None)
+    _stub("mmdet3d.models.fusion_layers", apply_3d_transformation=None)
+    _stub("mmdet3d.ops")
+    _stub("mmdet3d.ops.iou3d")
+    _stub("mmdet3d.ops.iou3d.iou3d_utils", nms_gpu=None)
+    _stub("mmdet3d.ops.roiaware_pool3d", points_in_boxes_batch=None)
+    spec = importlib.util.spec_from_file_location("tf_head", R + "/models/dense_heads/transfusion_head.py")
+    hm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hm)
+    return hm
+
+
+def gen_transfusion_head():
+    """Reference TransFusionHead.forward + get_bboxes (transfusion_head.py:797-1045,1285-1376), LiDAR-only branch
+    (fuse_img=False, as in transfusion_nusc_voxel_F.py:244-300), eval mode, CPU.  The input seed is searched until the
+    proposal selection survives a 1e-5 relative perturbation of the input (the top-k / local-maximum decisions have
+    margins), so that an fp32 implementation with a different summation order picks the same proposals."""
+    hm = import_reference_transfusion_head()
+    head = hm.TransFusionHead(loss_cls=dict(use_sigmoid=True), loss_iou=dict(), loss_bbox=dict(), loss_heatmap=dict(),
+                              train_cfg=None, test_cfg=dict(TFH_TEST_CFG),
+                              bbox_coder=dict(type='TransFusionBBoxCoder', **TFH_CODER), **TFH_KW)
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    sd = tfh_weight_shift(detgen.det_state_dict(shapes))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    head.eval()
+    for k in range(200):
+        x = torch.from_numpy(detgen.randn("tfh_x_%d" % k, TFH_SHAPE))
+        with torch.no_grad():
+            res = head([x], None, [{}])
+            labels = head.query_labels.clone()
+            picks = []
+            for j in range(3):
+                noise = torch.from_numpy(detgen.randn("tfh_n_%d_%d" % (k, j), TFH_SHAPE))
+                r2 = head([x * (1 + 1e-5 * noise)], None, [{}])
+                picks.append((r2[0][0]['center'] - res[0][0]['center']).abs().max().item() < 1e-2 and
+                             torch.equal(head.query_labels, labels))
+        if all(picks):
+            break
+    else:
+        raise RuntimeError("no stable TransFusionHead input found")
+    with torch.no_grad():
+        res = head([x], None, [{}])
+        labels = head.query_labels.clone()
+        # get_bboxes asserts batch size 1 at its end (transfusion_head.py:1366-1367); the per-sample part is taken
+        # sample by sample exactly as a batch-1 call would see it
+        dets = []
+        for b in range(TFH_SHAPE[0]):
+            head.query_labels = labels[b:b + 1]
+            one = ([{kk: vv[b:b + 1].clone() for kk, vv in res[0][0].items()}],)
+            box, score, lab = head.get_bboxes(one, [dict(box_type_3d=lambda t, box_dim: t)])[0]
+            dets.append((box.numpy(), score.numpy(), lab.numpy()))
+    out = dict(seed=np.int64(k), keys=np.array(sorted(shapes)), query_labels=labels.numpy())
+    for name, v in res[0][0].items():
+        out["pred_" + name] = v.numpy()
+    for b, (box, score, lab) in enumerate(dets):
+        out["boxes_%d" % b], out["scores_%d" % b], out["labels_%d" % b] = box, score, lab
+    print("seed", k, {n: tuple(v.shape) for n, v in res[0][0].items()}, [len(d[1]) for d in dets])
+    save("transfusion_head.npz", **out)
+
+
 CONV_BWD_SHAPE, CONV_BWD_BATCH = [7, 20, 22], 2
 
 
@@ -697,13 +842,15 @@ def gen_iou3d():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "conv_bwd"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "conv_bwd"]
     if "iou3d" in which:
         gen_iou3d()
     if "conv_bwd" in which:
         gen_conv_bwd()
     if "centerhead" in which:
         gen_centerhead()
+    if "tfhead" in which:
+        gen_transfusion_head()
     if "voxelize" in which:
         gen_voxelize()
     if "rulebook" in which:

@@ -324,3 +324,117 @@ def centerpoint_fusion(sd, levels, img_feats, calib, image_hw, cams, voxel_size,
             m = per[(b, ci)]["mask"].numpy()
             out[rows[m]] += enh[b * ncam + ci][:int(m.sum())]
     return out
+
+
+# ------------------------------------------------------------------------- TransFusion head (section 8f row 3)
+def transfusion_head(sd, x, num_proposals, num_classes=10, num_heads=8, nms_kernel_size=3, dataset="nuScenes",
+                     num_decoder_layers=1, heads=("center", "height", "dim", "rot", "vel", "heatmap"), bn_eps=1e-5):
+    """TransFusionHead.forward_single, LiDAR-only branch (fuse_img=False, initialize_by_heatmap=True), eval mode
+    (TF/mmdet3d/models/dense_heads/transfusion_head.py:797-1030; decoder layer :82-122, attention :255-505,
+    position embedding :30-41, prediction FFN :507-591).  torch-CPU fp32, one statement per reference statement.
+    Returns (dict of numpy arrays with the reference's keys, query_labels)."""
+    import torch
+    import torch.nn.functional as F
+    P = lambda k: _t(sd[k])
+    x = _t(np.asarray(x, np.float32))
+    B, _, H, W = x.shape
+
+    def bn(prefix, v):
+        return F.batch_norm(v, P(prefix + ".running_mean"), P(prefix + ".running_var"), P(prefix + ".weight"),
+                            P(prefix + ".bias"), False, 0.0, bn_eps)
+
+    def posembed(prefix, xy):                                   # :38-41 on [B, P, 2]
+        v = F.conv1d(xy.transpose(1, 2), P(prefix + ".position_embedding_head.0.weight"),
+                     P(prefix + ".position_embedding_head.0.bias"))
+        v = F.relu(bn(prefix + ".position_embedding_head.1", v))
+        return F.conv1d(v, P(prefix + ".position_embedding_head.3.weight"), P(prefix + ".position_embedding_head.3.bias"))
+
+    def mha(prefix, q, k, v):                                   # :255-505, [L, N, E] operands, no masks, eval
+        E = q.shape[-1]
+        w, b = P(prefix + ".in_proj_weight"), P(prefix + ".in_proj_bias")
+        hd = E // num_heads
+        qq = F.linear(q, w[:E], b[:E]) * (float(hd) ** -0.5)
+        kk = F.linear(k, w[E:2 * E], b[E:2 * E])
+        vv = F.linear(v, w[2 * E:], b[2 * E:])
+        L, N = q.shape[0], q.shape[1]
+        qq = qq.contiguous().view(L, N * num_heads, hd).transpose(0, 1)
+        kk = kk.contiguous().view(-1, N * num_heads, hd).transpose(0, 1)
+        vv = vv.contiguous().view(-1, N * num_heads, hd).transpose(0, 1)
+        a = torch.softmax(torch.bmm(qq, kk.transpose(1, 2)), -1)
+        o = torch.bmm(a, vv).transpose(0, 1).contiguous().view(L, N, E)
+        return F.linear(o, P(prefix + ".out_proj.weight"), P(prefix + ".out_proj.bias"))
+
+    lidar_feat = F.conv2d(x, P("shared_conv.weight"), P("shared_conv.bias"), padding=1)                  # :808
+    flat = lidar_feat.view(B, lidar_feat.shape[1], -1)
+    ys, xs = torch.meshgrid(torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W), indexing="ij")    # :758-765
+    bev_pos = torch.stack([xs + 0.5, ys + 0.5], 0).view(1, 2, -1).permute(0, 2, 1).repeat(B, 1, 1)
+    hmid = F.relu(bn("heatmap_head.0.bn", F.conv2d(lidar_feat, P("heatmap_head.0.conv.weight"), None, padding=1)))
+    dense_heatmap = F.conv2d(hmid, P("heatmap_head.1.weight"), P("heatmap_head.1.bias"), padding=1)      # :843
+    heatmap = dense_heatmap.sigmoid()
+    pad = nms_kernel_size // 2
+    local_max = torch.zeros_like(heatmap)
+    inner = F.max_pool2d(heatmap, kernel_size=nms_kernel_size, stride=1, padding=0)
+    local_max[:, :, pad:H - pad, pad:W - pad] = inner                                                    # :851-854
+    exempt = {"nuScenes": (8, 9), "Waymo": (1, 2)}.get(dataset, ())
+    for c in exempt:                                                                                     # :856-861
+        local_max[:, c] = heatmap[:, c]
+    heatmap = (heatmap * (heatmap == local_max)).view(B, num_classes, -1)
+    top = heatmap.view(B, -1).argsort(dim=-1, descending=True, stable=True)[..., :num_proposals]          # :866
+    top_class = top // heatmap.shape[-1]
+    top_index = top % heatmap.shape[-1]
+    query_feat = flat.gather(index=top_index[:, None, :].expand(-1, flat.shape[1], -1), dim=-1)
+    one_hot = F.one_hot(top_class, num_classes=num_classes).permute(0, 2, 1)
+    query_feat = query_feat + F.conv1d(one_hot.float(), P("class_encoding.weight"), P("class_encoding.bias"))
+    query_pos = bev_pos.gather(index=top_index[:, :, None].expand(-1, -1, 2), dim=1)                     # :878
+    rets = []
+    for i in range(num_decoder_layers):
+        D = "decoder.%d" % i
+        qpe = posembed(D + ".self_posembed", query_pos).permute(2, 0, 1)                                  # :92-99
+        kpe = posembed(D + ".cross_posembed", bev_pos).permute(2, 0, 1)
+        q = query_feat.permute(2, 0, 1)
+        k = flat.permute(2, 0, 1)
+        q = F.layer_norm(q + mha(D + ".self_attn", q + qpe, q + qpe, q + qpe), (q.shape[-1],),
+                         P(D + ".norm1.weight"), P(D + ".norm1.bias"))                                    # :104-108
+        q = F.layer_norm(q + mha(D + ".multihead_attn", q + qpe, k + kpe, k + kpe), (q.shape[-1],),
+                         P(D + ".norm2.weight"), P(D + ".norm2.bias"))                                    # :110-114
+        f = F.linear(F.relu(F.linear(q, P(D + ".linear1.weight"), P(D + ".linear1.bias"))),
+                     P(D + ".linear2.weight"), P(D + ".linear2.bias"))
+        q = F.layer_norm(q + f, (q.shape[-1],), P(D + ".norm3.weight"), P(D + ".norm3.bias"))            # :116-118
+        query_feat = q.permute(1, 2, 0)
+        res = {}
+        for h in heads:                                                                                   # :585-589
+            pre = "prediction_heads.%d.%s" % (i, h)
+            v = F.relu(bn(pre + ".0.bn", F.conv1d(query_feat, P(pre + ".0.conv.weight"), None)))
+            res[h] = F.conv1d(v, P(pre + ".1.weight"), P(pre + ".1.bias"))
+        res["center"] = res["center"] + query_pos.permute(0, 2, 1)                                        # :899
+        rets.append(res)
+        query_pos = res["center"].clone().permute(0, 2, 1)
+    out = {k: torch.cat([r[k] for r in rets], -1) for k in rets[0]}                                       # :1022-1028
+    out["query_heatmap_score"] = heatmap.gather(index=top_index[:, None, :].expand(-1, num_classes, -1), dim=-1)
+    out["dense_heatmap"] = dense_heatmap
+    return {k: v.numpy() for k, v in out.items()}, top_class.numpy()
+
+
+def transfusion_get_bboxes(preds, query_labels, num_proposals, coder, num_classes=10):
+    """TransFusionHead.get_bboxes with nms_type=None (transfusion_head.py:1285-1312,1326-1376) over
+    TransFusionBBoxCoder.decode(filter=True) (core/bbox/coders/transfusion_bbox_coder.py:41-128), per sample.
+    Returns a list of (boxes [n, 7 or 9], scores [n], labels [n])."""
+    K = num_proposals
+    score = 1.0 / (1.0 + np.exp(-preds["heatmap"][..., -K:].astype(np.float32)))
+    one_hot = np.eye(num_classes, dtype=np.float32)[query_labels].transpose(0, 2, 1)
+    score = (score * preds["query_heatmap_score"] * one_hot).astype(np.float32)
+    labels, scores = score.argmax(1), score.max(1)
+    center = preds["center"][..., -K:].astype(np.float32).copy()
+    f32 = np.float32
+    center[:, 0] = center[:, 0] * f32(coder["out_size_factor"]) * f32(coder["voxel_size"][0]) + f32(coder["pc_range"][0])
+    center[:, 1] = center[:, 1] * f32(coder["out_size_factor"]) * f32(coder["voxel_size"][1]) + f32(coder["pc_range"][1])
+    dim = np.exp(preds["dim"][..., -K:].astype(np.float32))
+    height = preds["height"][..., -K:] - dim[:, 2:3] * f32(0.5)
+    rot = np.arctan2(preds["rot"][..., -K:][:, 0:1], preds["rot"][..., -K:][:, 1:2])
+    parts = [center, height, dim, rot] + ([preds["vel"][..., -K:]] if "vel" in preds else [])
+    boxes = np.concatenate(parts, 1).transpose(0, 2, 1).astype(np.float32)
+    rng = np.asarray(coder["post_center_range"], np.float32)
+    mask = (boxes[..., :3] >= rng[:3]).all(2) & (boxes[..., :3] <= rng[3:]).all(2)
+    if coder.get("score_threshold"):
+        mask &= scores > coder["score_threshold"]
+    return [(boxes[b][mask[b]], scores[b][mask[b]], labels[b][mask[b]]) for b in range(len(boxes))]

@@ -282,6 +282,54 @@ def test_centerhead_oracle_vs_reference_golden(golden):
     assert len(dets[0]["scores"]) > 100 and len(set(dets[0]["label_preds"].tolist())) >= 8
 
 
+def _mirror_tf_head():
+    """dualfusion.transfusion_head.TransFusionHead (plain torch modules on the CPU) with the golden's weights."""
+    import torch
+    from dualfusion.transfusion_head import TransFusionHead
+    from make_golden import TFH_CODER, TFH_KW, TFH_TEST_CFG, tfh_weight_shift
+    head = TransFusionHead(loss_cls=dict(use_sigmoid=True), test_cfg=dict(TFH_TEST_CFG),
+                           bbox_coder=dict(type='TransFusionBBoxCoder', **TFH_CODER), **TFH_KW)
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    sd = tfh_weight_shift(detgen.det_state_dict(shapes))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return head.eval(), shapes, sd
+
+
+def test_transfusion_head_oracle_and_mirror_vs_reference_golden(golden):
+    """Reference TransFusionHead.forward + get_bboxes (imported from /root/reference when the fixture was made): the
+    mirror module has the reference's parameter names, and both its torch path and the oracle restatement return the
+    reference's predictions (same proposals, same values) and detections."""
+    import torch
+    import oracle_models as om
+    from make_golden import TFH_CODER, TFH_KW, TFH_SHAPE
+    g = golden("transfusion_head.npz")
+    head, shapes, sd = _mirror_tf_head()
+    assert sorted(shapes) == g["keys"].tolist()
+    x = detgen.randn("tfh_x_%d" % int(g["seed"]), TFH_SHAPE)
+    K = TFH_KW["num_proposals"]
+    preds, labels = om.transfusion_head(sd, x, K)
+    with torch.no_grad():
+        res = head([torch.from_numpy(x)], None, [{}])
+    assert np.array_equal(labels, g["query_labels"]) and np.array_equal(head.query_labels.numpy(), g["query_labels"])
+    names = ["center", "height", "dim", "rot", "vel", "heatmap", "query_heatmap_score", "dense_heatmap"]
+    assert sorted(res[0][0]) == sorted(names)
+    for name in names:
+        want = g["pred_" + name]
+        for got in (preds[name], res[0][0][name].numpy()):
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), name
+    dets_o = om.transfusion_get_bboxes(preds, labels, K, TFH_CODER)
+    dets_m = head.get_bboxes(res)
+    n = 0
+    for b in range(TFH_SHAPE[0]):
+        for box, score, lab in (dets_o[b], [t.numpy() for t in dets_m[b]]):
+            assert np.array_equal(lab, g["labels_%d" % b])
+            np.testing.assert_allclose(score, g["scores_%d" % b], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(box, g["boxes_%d" % b], rtol=1e-5, atol=2e-5)
+        n += len(g["labels_%d" % b])
+    assert 0 < n < TFH_SHAPE[0] * K                       # the centre-range mask removed some proposals, not all
+
+
 @pytest.mark.parametrize("tag", ["hot", "multi"])
 def test_msda_backward_oracle_vs_reference_autograd(golden, tag):
     """Oracle col2im restatement against the float64 autograd gradients of the reference's pure-torch core."""

@@ -3,11 +3,12 @@
   tf : TransFusion-L SparseEncoderFusion + ACTR fusion layer, 0.075 m nuScenes grid, bs=4, 6 cameras (configs[2] shape, fp32)
   vr : Voxel-RCNN VoxelBackBone8xFusion (MVX + ACTRv2), KITTI 0.05 m grid, bs=8, one camera (configs[4] shape)
   neck : CenterPoint RPN BEV neck on [B, 256, 180, 180] (0.1 m nuScenes grid), row kernels vs the torch/MIOpen composition
+  tfhead : TransFusionHead (LiDAR-only, 200 proposals) forward + get_bboxes on [B, 512, 180, 180], device path vs plain torch
   head : CenterPoint CenterHead (6 tasks) forward + predict on the neck's [B, 512, 180, 180] map, row kernels + device tail
          vs the torch/MIOpen forward; then sweep -> boxes end to end (LiDAR hot path + neck + head + predict)
   train : CenterPoint SpMiddleResNetFHD in train() mode, one sweep: forward + dense + loss + backward through the sparse
           conv backward kernels (training row of SURVEY section 8f; LiDAR-only, no optimizer)
-usage: bench_trees.py [tf|vr|neck|head|train] [steps]"""
+usage: bench_trees.py [tf|vr|neck|head|tfhead|train] [steps]"""
 import os
 import sys
 import time
@@ -171,6 +172,31 @@ elif which == "head":
                 bev, _ = hp(pts)
                 return head.predict_device(head(bev), TEST_CFG)
         print("sweep -> boxes (LiDAR hot path + neck + head + predict): %.3f ms/sweep" % timeit(e2e))
+elif which == "tfhead":
+    from dualfusion.transfusion_head import TransFusionHead
+    B = int(os.environ.get("DF3D_NECK_BATCH", "1"))
+    head = TransFusionHead(num_proposals=200, auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10,
+                           num_decoder_layers=1, num_heads=8, initialize_by_heatmap=True, nms_kernel_size=3, ffn_channel=256,
+                           common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)),
+                           bbox_coder=dict(type='TransFusionBBoxCoder', pc_range=[-54.0, -54.0], voxel_size=[0.075, 0.075],
+                                           out_size_factor=8, post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                                           score_threshold=0.0, code_size=10), loss_cls=dict(use_sigmoid=True),
+                           test_cfg=dict(dataset='nuScenes', grid_size=[1440, 1440, 40], out_size_factor=8,
+                                         pc_range=[-54.0, -54.0], voxel_size=[0.075, 0.075], nms_type=None)).to(dev).eval()
+    x = torch.randn(B, 512, 180, 180, device=dev).relu()
+    with torch.no_grad():
+        ms_fw = timeit(lambda: head([x]))
+        ms_fw_lib = timeit(lambda: head.forward_reference(x))
+        preds = head([x])
+        ms_box = timeit(lambda: head.get_bboxes_device(preds))
+        ms_box_host = timeit(lambda: head.get_bboxes(preds))
+        ref = head.forward_reference(x)
+        ms_box_torch = timeit(lambda: head.bbox_coder.decode(
+            ref[0]['heatmap'].sigmoid() * ref[0]['query_heatmap_score'], ref[0]['rot'], ref[0]['dim'], ref[0]['center'],
+            ref[0]['height'], ref[0]['vel'], filter=True))
+    print("TransFusionHead bs=%d (200 proposals): forward, device path %.3f ms | plain torch/MIOpen path %.3f ms | get_bboxes: "
+          "device call %.3f ms, with per-sample lists %.3f ms, torch decode %.3f ms" % (B, ms_fw, ms_fw_lib, ms_box, ms_box_host,
+                                                                                     ms_box_torch))
 else:
     from dualfusion.backbones import VoxelBackBone8xFusion
     B = 8
