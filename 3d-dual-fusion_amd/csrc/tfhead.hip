@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void proposal_keys_kernel(ProposalArgs a, unsi
   keys[i] = ((unsigned long long)b << 56) | ((unsigned long long)inv << 24) | (unsigned)(c * hw + pix);
 }
 
-// grid (B), 256 threads; thread r < K takes the r-th key of the sample
+// grid (ceil(K / 16), B), 256 threads: 16 proposals per workgroup -- thread (q, c) evaluates class c at proposal q's
+// pixel, then the 256 threads copy the 16 feature rows
 __global__ __launch_bounds__(256) void proposal_gather_kernel(ProposalArgs a, const unsigned long long *__restrict__ keys,
                                                               int K, const float *__restrict__ feat, int ld_feat,
                                                               int channels, const float *__restrict__ cls_w,
@@ -70,36 +71,37 @@ __global__ __launch_bounds__(256) void proposal_gather_kernel(ProposalArgs a, co
                                                               int32_t *__restrict__ top_class, int32_t *__restrict__ top_pixel,
                                                               float *__restrict__ query_score, float *__restrict__ query_pos,
                                                               float *__restrict__ query_feat) {
-  const int b = blockIdx.x, hw = a.H * a.W;
+  const int b = blockIdx.y, r0 = blockIdx.x * 16, hw = a.H * a.W;
   const unsigned long long *seg = keys + (size_t)b * hw * a.C;         // every sample owns exactly C*H*W keys
-  __shared__ int s_cls[256], s_pix[256];
-  for (int r0 = 0; r0 < K; r0 += 256) {
+  __shared__ int s_cls[16], s_pix[16];
+  const int n = min(16, K - r0);
+  if (threadIdx.x < n) {
     const int r = r0 + threadIdx.x;
-    __syncthreads();
-    if (r < K) {
-      const unsigned idx = (unsigned)(seg[r] & 0xFFFFFFu);
-      const int c = idx / hw, pix = idx - c * hw;
-      s_cls[threadIdx.x] = c;
-      s_pix[threadIdx.x] = pix;
-      top_class[(size_t)b * K + r] = c;
-      top_pixel[(size_t)b * K + r] = pix;
+    const unsigned idx = (unsigned)(seg[r] & 0xFFFFFFu);
+    const int c = idx / hw, pix = idx - c * hw;
+    s_cls[threadIdx.x] = c;
+    s_pix[threadIdx.x] = pix;
+    top_class[(size_t)b * K + r] = c;
+    top_pixel[(size_t)b * K + r] = pix;
+    if (query_pos) {
       const int y = pix / a.W, x = pix - y * a.W;
-      if (query_pos) {
-        query_pos[((size_t)b * K + r) * 2] = (float)x + 0.5f;
-        query_pos[((size_t)b * K + r) * 2 + 1] = (float)y + 0.5f;
-      }
-      for (int cc = 0; cc < a.C; ++cc) query_score[((size_t)b * a.C + cc) * K + r] = suppressed_score(a, b, cc, y, x);
+      query_pos[((size_t)b * K + r) * 2] = (float)x + 0.5f;
+      query_pos[((size_t)b * K + r) * 2 + 1] = (float)y + 0.5f;
     }
-    __syncthreads();
-    if (query_feat) {
-      const int n = min(256, K - r0);
-      for (int e = threadIdx.x; e < n * channels; e += 256) {
-        const int q = e / channels, ch = e - q * channels;
-        float v = feat[((size_t)b * hw + s_pix[q]) * ld_feat + ch];
-        if (cls_w) v += cls_w[(size_t)ch * a.C + s_cls[q]];
-        if (cls_b) v += cls_b[ch];
-        query_feat[((size_t)b * K + r0 + q) * channels + ch] = v;
-      }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n * a.C; e += 256) {
+    const int q = e / a.C, cc = e - q * a.C;
+    const int y = s_pix[q] / a.W, x = s_pix[q] - y * a.W;
+    query_score[((size_t)b * a.C + cc) * K + r0 + q] = suppressed_score(a, b, cc, y, x);
+  }
+  if (query_feat) {
+    for (int e = threadIdx.x; e < n * channels; e += 256) {
+      const int q = e / channels, ch = e - q * channels;
+      float v = feat[((size_t)b * hw + s_pix[q]) * ld_feat + ch];
+      if (cls_w) v += cls_w[(size_t)ch * a.C + s_cls[q]];
+      if (cls_b) v += cls_b[ch];
+      query_feat[((size_t)b * K + r0 + q) * channels + ch] = v;
     }
   }
 }
@@ -233,7 +235,7 @@ extern "C" int df3d_heatmap_proposals(const float *heat_rows, int ld_heat, int b
   hipLaunchKernelGGL(proposal_keys_kernel, dim3(cdiv(nkeys, 256)), dim3(256), 0, stream, a, kin);
   size_t tmp = p.sort_tmp_bytes;
   DF3D_HIP(rocprim::radix_sort_keys(ws + p.sort_tmp, tmp, kin, kout, (size_t)nkeys, 0, 64, stream));
-  hipLaunchKernelGGL(proposal_gather_kernel, dim3(batch), dim3(256), 0, stream, a, kout, num_proposals, feat_rows, ld_feat,
+  hipLaunchKernelGGL(proposal_gather_kernel, dim3(cdiv(num_proposals, 16), batch), dim3(256), 0, stream, a, kout, num_proposals, feat_rows, ld_feat,
                      channels, class_weight, class_bias, top_class, top_pixel, query_score, query_pos, query_feat);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;

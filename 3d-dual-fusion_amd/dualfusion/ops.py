@@ -722,6 +722,29 @@ def transfusion_decode(heads, query_score, query_label, batch, num_proposals, nu
     return boxes, scores, labels, counts
 
 
+def cross_attention(q, k, v, batch, heads, scale=None):
+    """df3d_cross_attention.  q: fp32 [B*nq, heads*16] row view, k / v: fp32 [B*nk, heads*16] row views (unit column
+    stride, any row stride).  Returns out [B*nq, heads*16]."""
+    lib = _lib.load()
+    E = int(heads) * 16
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.shape[1] != E or t.stride(1) != 1 or t.shape[0] % batch:
+            raise ValueError("'%s' must be a CUDA fp32 [B*n, %d] view with unit column stride" % (nm, E))
+    nq, nk = q.shape[0] // batch, k.shape[0] // batch
+    if v.shape[0] != k.shape[0]:
+        raise ValueError("k and v must have the same number of rows")
+    out = torch.empty((q.shape[0], E), dtype=torch.float32, device=q.device)
+    nbytes = lib.df3d_cross_attention_workspace_bytes(int(batch), int(heads), nq, nk)
+    if nbytes == 0:
+        raise ValueError("df3d_cross_attention: unsupported sizes")
+    ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=q.device)
+    rc = lib.df3d_cross_attention(_ptr(q), int(q.stride(0)), _ptr(k), int(k.stride(0)), _ptr(v), int(v.stride(0)), int(batch),
+                                  nq, nk, int(heads), 16, float(scale if scale is not None else 0.25), _ptr(out), E, _ptr(ws),
+                                  int(nbytes), _stream())
+    _lib.check(rc, "df3d_cross_attention")
+    return out
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
     lib = _lib.load()
     _chk(value, torch.float32, "value")

@@ -9,8 +9,9 @@ Device path in eval mode:
   * sigmoid + local-maximum suppression + top-k + query feature / position gather = `df3d_heatmap_proposals`
     (keys -> radix sort -> gather) instead of ~25 launches and four map-sized temporaries;
   * decoder layer: key / value projection of the 32 400 BEV pixels as ONE GEMM on the pixel rows (the learned position
-    embedding of the fixed BEV grid is input-independent in eval mode and folded into a cached additive term), fused
-    attention, all prediction heads as two GEMMs (BN folded, block-diagonal second layer);
+    embedding of the fixed BEV grid is input-independent in eval mode and folded into a cached additive term), the
+    200 x 32 400 cross-attention as `df3d_cross_attention` (keys split over workgroups, log-sum-exp merge), all
+    prediction heads as two GEMMs (BN folded, block-diagonal second layer);
   * `get_bboxes` = `df3d_transfusion_decode` (one launch).
 Training-mode forward runs the plain torch modules (autograd); `loss` / target assignment are out of scope."""
 import copy
@@ -448,7 +449,13 @@ class TransFusionHead(nn.Module):
             kv = torch.addmm(self._kv_const(plan, i, B, dev), feat, L["wkv_t"]).view(B, H * W, 2 * E)
 
             def cross(qq, dec=dec, L=L, kv=kv):
-                return dec.multihead_attn.attend(F.linear(qq, L["wq"], L["bq"]), kv[..., :E], kv[..., E:])
+                mha = dec.multihead_attn
+                qp = F.linear(qq, L["wq"], L["bq"])
+                if mha.head_dim != 16:
+                    return mha.attend(qp, kv[..., :E], kv[..., E:])
+                kvr = kv.view(B * H * W, 2 * E)
+                o = _ops.cross_attention(qp.view(B * K, E), kvr[:, :E], kvr[:, E:], B, mha.num_heads, mha.head_dim ** -0.5)
+                return mha.out_proj(o.view(B, K, E))
             qf = dec.finish(qf, qpe, cross)
             out = torch.addmm(L["b2"], torch.relu_(torch.addmm(L["b1"], qf.reshape(B * K, E), L["w1"].t())), L["w2"].t())
             out = out.view(B, K, -1)

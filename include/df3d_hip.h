@@ -323,6 +323,19 @@ int df3d_transfusion_decode(const df3d_query_heads *heads, const float *query_sc
                             float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *out_counts, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Cross-attention of object queries over the BEV map (TransFusionHead decoder layer, transfusion_head.py:110-113 ->
+ * multi_head_attention_forward :255-505, the bmm / softmax / bmm of :478-495):
+ *   out[b, q, h*16 + d] = sum_k softmax_k(scale * <Q[b,q,h,:], K[b,k,h,:]>) * V[b,k,h,d]
+ * q [B*nq, ld_q], k / v [B*nk, ld_k / ld_v], out [B*nq, ld_out] f32 row views whose first heads*16 columns are the
+ * projected operands (head h in columns h*16 .. h*16+15); head_dim must be 16.  Keys are split over workgroups and
+ * merged by log-sum-exp; the [B*heads, nq, nk] score tensor is never materialised.
+ */
+size_t df3d_cross_attention_workspace_bytes(int batch, int heads, int nq, int nk);
+int df3d_cross_attention(const float *q, int ld_q, const float *k, int ld_k, const float *v, int ld_v, int batch, int nq,
+                         int nk, int heads, int head_dim, float scale, float *out, int ld_out, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Multi-scale deformable attention, forward.  Replaces
  * MultiScaleDeformableAttention.ms_deform_attn_forward (CP/det3d/models/model_utils/ops/src/
  * vision.cpp:13-16, ms_deform_attn.h:21-40, cuda/ms_deform_attn_cuda.cu:20-84, kernel

@@ -210,3 +210,36 @@ def test_training_mode_uses_autograd_path():
     (res["heatmap"].sum() + res["center"].sum() + res["dense_heatmap"].sum()).backward()
     assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0
     assert head.shared_conv.weight.grad is not None and head.decoder[0].multihead_attn.in_proj_weight.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("B,nq,nk,heads", [(1, 200, 32400, 8), (2, 24, 440, 8), (3, 300, 1000, 4), (1, 1, 17, 2),
+                                           (2, 16, 16, 8)])
+def test_cross_attention_vs_float64(B, nq, nk, heads):
+    """df3d_cross_attention (keys split over workgroups + log-sum-exp merge) against softmax(q k^T / sqrt(d)) v in
+    float64; k and v are column slices of one [B*nk, 2E] projection buffer, as the head passes them."""
+    from dualfusion import ops
+    E = heads * 16
+    q = detgen.randn("xa_q_%d_%d" % (nq, nk), (B * nq, E))
+    kv = detgen.randn("xa_kv_%d_%d" % (nq, nk), (B * nk, 2 * E))
+    kv[:, :E] *= 1.5                                                       # scores of a few units: a peaked softmax
+    qd, kvd = torch.from_numpy(q).to(DEV), torch.from_numpy(kv).to(DEV)
+    out = ops.cross_attention(qd, kvd[:, :E], kvd[:, E:], B, heads, 0.25).cpu().numpy()
+    q64 = q.astype(np.float64).reshape(B, nq, heads, 16).transpose(0, 2, 1, 3)
+    k64 = kv[:, :E].astype(np.float64).reshape(B, nk, heads, 16).transpose(0, 2, 1, 3)
+    v64 = kv[:, E:].astype(np.float64).reshape(B, nk, heads, 16).transpose(0, 2, 1, 3)
+    s = np.einsum("bhqd,bhkd->bhqk", q64, k64) * 0.25
+    p = np.exp(s - s.max(-1, keepdims=True))
+    want = np.einsum("bhqk,bhkd->bhqd", p / p.sum(-1, keepdims=True), v64).transpose(0, 2, 1, 3).reshape(B * nq, E)
+    assert np.abs(out - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_cross_attention_rejects_bad_arguments():
+    from dualfusion import Df3dError, ops
+    q, kv = torch.zeros((8, 96), device=DEV), torch.zeros((64, 96), device=DEV)
+    with pytest.raises(ValueError):
+        ops.cross_attention(q, kv, kv, 1, 8)                               # 96 columns are not 8 heads x 16
+    with pytest.raises(ValueError):
+        ops.cross_attention(q.cpu(), kv.cpu(), kv.cpu(), 1, 6)
+    flat = torch.zeros((8 * 80 + 1,), device=DEV)
+    with pytest.raises(Df3dError):
+        ops.cross_attention(flat[1:].view(8, 80), kv[:, :80].contiguous(), kv[:, :80].contiguous(), 1, 5)   # q not 16-byte aligned
