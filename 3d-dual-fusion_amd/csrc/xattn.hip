@@ -34,22 +34,35 @@ struct XAttnArgs {
 
 constexpr int XQ = 4;        // query tiles per wave
 
-__global__ __launch_bounds__(256) void xattn_partial_kernel(XAttnArgs a) {
-  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z / a.qblocks, qb = blockIdx.z - b * a.qblocks;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, g = lane >> 4;
-  const int ntiles = (a.nk + 15) >> 4;
-  const int t0 = chunk * a.tiles_per_chunk, t1 = min(t0 + a.tiles_per_chunk, ntiles);
-  const int nqt = (a.nq + 15) >> 4;
-  f32x4 qf[XQ], o[XQ];
-  float m[XQ], ls[XQ];
-  int qtile[XQ];
+struct KVTile {
+  float4 kf;
+  float vf[4];
+};
+
+__device__ __forceinline__ KVTile load_kv(const float *kb, const float *vb, int ld_k, int ld_v, int kt, int nk, int j, int g) {
+  KVTile t;
+  const int key0 = kt * 16;
+  const int krow = min(key0 + j, nk - 1);                       // clamped rows are masked by the caller
+  t.kf = *(const float4 *)(kb + (size_t)krow * ld_k + 4 * g);
 #pragma unroll
-  for (int t = 0; t < XQ; ++t) {
-    qtile[t] = qb * (4 * XQ) + wave + 4 * t;
-    const int q = qtile[t] * 16 + j;
+  for (int r = 0; r < 4; ++r) {
+    const int key = key0 + 4 * g + r;
+    t.vf[r] = key < nk ? vb[(size_t)key * ld_v + j] : 0.f;
+  }
+  return t;
+}
+
+// NT query tiles of this wave, fully unrolled: NT independent MFMA chains per stage
+template <int NT>
+__device__ __forceinline__ void xattn_wave(const XAttnArgs &a, int b, int h, int chunk, int tile0, int t0, int t1, int j,
+                                           int g) {
+  f32x4 qf[NT], o[NT];
+  float m[NT], ls[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int q = (tile0 + 4 * t) * 16 + j;
     qf[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (qtile[t] < nqt && q < a.nq) {
+    if (q < a.nq) {
       const float4 x = *(const float4 *)(a.q + ((size_t)b * a.nq + q) * a.ld_q + h * 16 + 4 * g);
       qf[t] = (f32x4){x.x * a.qscale, x.y * a.qscale, x.z * a.qscale, x.w * a.qscale};
     }
@@ -57,54 +70,49 @@ __global__ __launch_bounds__(256) void xattn_partial_kernel(XAttnArgs a) {
     m[t] = -INFINITY;
     ls[t] = 0.f;
   }
-  if (qtile[0] >= nqt) return;                                  // whole wave idle (qtile grows with t)
   const float *kb = a.k + (size_t)b * a.nk * a.ld_k + h * 16, *vb = a.v + (size_t)b * a.nk * a.ld_v + h * 16;
+  KVTile cur = load_kv(kb, vb, a.ld_k, a.ld_v, t0, a.nk, j, g);
   for (int kt = t0; kt < t1; ++kt) {
-    const int key0 = kt * 16;
-    const int krow = min(key0 + j, a.nk - 1);                   // clamped rows are masked below
-    const float4 kf = *(const float4 *)(kb + (size_t)krow * a.ld_k + 4 * g);
-    float vf[4];
-    bool valid[4];
+    const KVTile nxt = load_kv(kb, vb, a.ld_k, a.ld_v, min(kt + 1, t1 - 1), a.nk, j, g);     // in flight during the MFMAs
+    const float kc[4] = {cur.kf.x, cur.kf.y, cur.kf.z, cur.kf.w};
+    f32x4 s[NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = key0 + 4 * g + r;
-      valid[r] = key < a.nk;
-      vf[r] = valid[r] ? vb[(size_t)key * a.ld_v + j] : 0.f;
-    }
+    for (int t = 0; t < NT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < XQ; ++t) {
-      if (qtile[t] >= nqt) break;                               // wave-uniform
-      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[t][0], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[t][1], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[t][2], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[t][3], s, 0, 0, 0);
-      // lane (query j, keys 4g + r)
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[c], qf[t][c], s[t], 0, 0, 0);
+    // lane (query j of tile t, keys 4g + r)
+    const int key0 = kt * 16 + 4 * g;
+    float p[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (!valid[r]) s[r] = -INFINITY;
-      float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        if (key0 + r >= a.nk) s[t][r] = -INFINITY;
+      float mx = fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3]));
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mnew = fmaxf(m[t], mx);                       // finite: key 0 of every tile exists
       const float alpha = __builtin_amdgcn_exp2f(m[t] - mnew);
-      float p[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] - mnew);
-      ls[t] = ls[t] * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
+      for (int r = 0; r < 4; ++r) p[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mnew);
+      ls[t] = ls[t] * alpha + ((p[t][0] + p[t][1]) + (p[t][2] + p[t][3]));
       o[t] *= alpha;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], p[r], o[t], 0, 0, 0);
       m[t] = mnew;
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.vf[r], p[t][r], o[t], 0, 0, 0);
+    cur = nxt;
   }
 #pragma unroll
-  for (int t = 0; t < XQ; ++t) {
-    if (qtile[t] >= nqt) break;
+  for (int t = 0; t < NT; ++t) {
     float l = ls[t];
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
-    const int q = qtile[t] * 16 + j;                            // < nq_pad
+    const int q = (tile0 + 4 * t) * 16 + j;                     // < nq_pad
     const size_t slot = (((size_t)b * a.heads + h) * a.nchunks + chunk) * a.nq_pad + q;
     *(f32x4 *)(a.po + slot * 16 + 4 * g) = o[t];               // lane (query j, head-dim rows 4g + r)
     if (g == 0) {
@@ -114,25 +122,54 @@ __global__ __launch_bounds__(256) void xattn_partial_kernel(XAttnArgs a) {
   }
 }
 
-// thread = (b, q, h, d)
+__global__ __launch_bounds__(256) void xattn_partial_kernel(XAttnArgs a) {
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z / a.qblocks, qb = blockIdx.z - b * a.qblocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntiles = (a.nk + 15) >> 4;
+  const int t0 = chunk * a.tiles_per_chunk, t1 = min(t0 + a.tiles_per_chunk, ntiles);
+  const int nqt = (a.nq + 15) >> 4;
+  const int tile0 = qb * (4 * XQ) + wave;                       // this wave's tiles: tile0 + 4 t
+  if (tile0 >= nqt) return;
+  const int mine = min(XQ, (nqt - tile0 + 3) / 4);              // wave-uniform
+  const int j = lane & 15, g = lane >> 4;
+  if (mine == 4) xattn_wave<4>(a, b, h, chunk, tile0, t0, t1, j, g);
+  else if (mine == 3) xattn_wave<3>(a, b, h, chunk, tile0, t0, t1, j, g);
+  else if (mine == 2) xattn_wave<2>(a, b, h, chunk, tile0, t0, t1, j, g);
+  else xattn_wave<1>(a, b, h, chunk, tile0, t0, t1, j, g);
+}
+
+// one wave per (b, h, q): lane = (chunk phase cg = lane >> 4, head-dim d = lane & 15); every lane merges the chunks
+// c = cg (mod 4) with a running (M, L, O), then the four phases are merged across the lane groups
 __global__ __launch_bounds__(256) void xattn_combine_kernel(XAttnArgs a, float *__restrict__ out, int ld_out) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)a.batch * a.nq * a.heads * 16;
-  if (i >= total) return;
-  const int d = (int)(i & 15), h = (int)((i >> 4) % a.heads);
-  const long long bq = (i >> 4) / a.heads;
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (long long)a.batch * a.nq * a.heads) return;
+  const int lane = threadIdx.x & 63, d = lane & 15, cg = lane >> 4;
+  const int h = (int)(w % a.heads);
+  const long long bq = w / a.heads;
   const int b = (int)(bq / a.nq), q = (int)(bq - (long long)b * a.nq);
   const size_t base = ((size_t)b * a.heads + h) * a.nchunks;
-  float M = -INFINITY;
-  for (int c = 0; c < a.nchunks; ++c) M = fmaxf(M, a.pml[((base + c) * a.nq_pad + q) * 2]);
-  float L = 0.f, O = 0.f;
-  for (int c = 0; c < a.nchunks; ++c) {
+  float M = -INFINITY, L = 0.f, O = 0.f;
+  for (int c = cg; c < a.nchunks; c += 4) {
     const size_t slot = (base + c) * a.nq_pad + q;
-    const float w = __builtin_amdgcn_exp2f(a.pml[slot * 2] - M);
-    L += a.pml[slot * 2 + 1] * w;
-    O += a.po[slot * 16 + d] * w;
+    const float2 ml = *(const float2 *)(a.pml + slot * 2);
+    const float o = a.po[slot * 16 + d];
+    const float Mn = fmaxf(M, ml.x);
+    const float w0 = __builtin_amdgcn_exp2f(M - Mn), w1 = __builtin_amdgcn_exp2f(ml.x - Mn);
+    L = L * w0 + ml.y * w1;
+    O = O * w0 + o * w1;
+    M = Mn;
   }
-  out[((size_t)b * a.nq + q) * ld_out + h * 16 + d] = O / L;
+#pragma unroll
+  for (int s = 16; s <= 32; s <<= 1) {
+    const float M2 = __shfl_xor(M, s), L2 = __shfl_xor(L, s), O2 = __shfl_xor(O, s);
+    const float Mn = fmaxf(M, M2);
+    const bool none = Mn == -INFINITY;                           // both phases empty (fewer than 4 chunks)
+    const float w0 = none ? 0.f : __builtin_amdgcn_exp2f(M - Mn), w1 = none ? 0.f : __builtin_amdgcn_exp2f(M2 - Mn);
+    L = L * w0 + L2 * w1;
+    O = O * w0 + O2 * w1;
+    M = Mn;
+  }
+  if (cg == 0) out[((size_t)b * a.nq + q) * ld_out + h * 16 + d] = O / L;
 }
 
 static void xattn_plan(int batch, int heads, int nq, int nk, XAttnArgs &a) {
@@ -193,8 +230,7 @@ extern "C" int df3d_cross_attention(const float *q, int ld_q, const float *k, in
   a.po = (float *)workspace;
   a.pml = a.po + (size_t)batch * heads * a.nchunks * a.nq_pad * 16;
   hipLaunchKernelGGL(xattn_partial_kernel, dim3(a.nchunks, heads, batch * a.qblocks), dim3(256), 0, stream, a);
-  const long long total = (long long)batch * nq * heads * 16;
-  hipLaunchKernelGGL(xattn_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, out, ld_out);
+  hipLaunchKernelGGL(xattn_combine_kernel, dim3(cdiv((long long)batch * nq * heads, 4)), dim3(256), 0, stream, a, out, ld_out);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -79,6 +79,35 @@ if which == "tf":
     ms = timeit(step)
     print("tf  SparseEncoderFusion+ACTR bs=%d (%d voxels): %.2f ms/step = %.1f sweeps/s  [DF3D_EXECUTOR=%s]" % (
         B, f.shape[0], ms, B / ms * 1e3, os.environ.get("DF3D_EXECUTOR", "1")))
+    if os.environ.get("DF3D_TF_DETECTOR", "1") == "1":     # ... + SECOND + SECONDFPN + TransFusionHead -> boxes
+        from dualfusion.necks import SECOND, SECONDFPN
+        from dualfusion.transfusion_head import TransFusionHead
+        bb = SECOND(in_channels=256, out_channels=[128, 256], layer_nums=[5, 5], layer_strides=[1, 2]).to(dev).eval()
+        fpn = SECONDFPN(in_channels=[128, 256], out_channels=[256, 256], upsample_strides=[1, 2],
+                        use_conv_for_no_stride=True).to(dev).eval()
+        head = TransFusionHead(num_proposals=200, auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10,
+                               num_decoder_layers=1, num_heads=8, initialize_by_heatmap=True, nms_kernel_size=3,
+                               ffn_channel=256, common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2),
+                                                                  vel=(2, 2)),
+                               bbox_coder=dict(type='TransFusionBBoxCoder', pc_range=[-54.0, -54.0],
+                                               voxel_size=[0.075, 0.075], out_size_factor=8,
+                                               post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                                               score_threshold=0.0, code_size=10), loss_cls=dict(use_sigmoid=True),
+                               test_cfg=dict(dataset='nuScenes', grid_size=[1440, 1440, 40], out_size_factor=8,
+                                             pc_range=[-54.0, -54.0], voxel_size=[0.075, 0.075], nms_type=None)).to(dev).eval()
+
+        def detect():
+            with torch.no_grad():
+                x = enc(f, c, B, img_feats=[img], img_metas=metas)
+                x = fpn(bb(x))
+                return head.get_bboxes_device(head(x))
+        ms_det = timeit(detect)
+        with torch.no_grad():
+            x = fpn(bb(enc(f, c, B, img_feats=[img], img_metas=metas)))
+            ms_neck = timeit(lambda: fpn(bb(enc(f, c, B, img_feats=[img], img_metas=metas)))) - ms
+            ms_head = timeit(lambda: head.get_bboxes_device(head(x)))
+        print("tf  voxel features -> boxes (encoder + ACTR + SECOND + SECONDFPN + TransFusionHead + decode) bs=%d: %.2f ms/step"
+              " = %.1f sweeps/s  (neck %.2f ms, head + decode %.2f ms)" % (B, ms_det, B / ms_det * 1e3, ms_neck, ms_head))
 elif which == "neck":
     from dualfusion.necks import RPN
     B = int(os.environ.get("DF3D_NECK_BATCH", "1"))

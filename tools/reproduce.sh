@@ -12,6 +12,8 @@ DF3D_CONV_PRECISION=bf16 python tools/bench_trees.py tf 8    # ... with the bf16
 python tools/bench_trees.py vr 5                  # Voxel-RCNN backbone (MVX + ACTRv2), bs=8 (configs[4] shape)
 python tools/bench_trees.py neck 20               # BEV neck (RPN) on the row kernels vs torch/MIOpen
 python tools/bench_trees.py head 20               # CenterHead forward + predict; sweep -> boxes
+python tools/bench_trees.py tfhead 20             # TransFusionHead forward + get_bboxes (device path vs plain torch)
 python tools/bench_trees.py train 10              # backbone training step (forward + backward)
+python tools/ubench/xattn_probe.py                # the split-key cross-attention kernel alone
 python tools/ubench/os_probe.py                   # per-layer conv kernel timings (split precision and bf16)
 # profiles/: rocprofv3 --kernel-trace --stats and --pmc FETCH_SIZE / WRITE_SIZE passes, distilled by tools/make_profiles.py
