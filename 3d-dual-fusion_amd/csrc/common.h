@@ -124,4 +124,10 @@ __device__ __forceinline__ int grid_rank(const GridView &g, long long flat) {
   return (int)(g.prefix[flat >> 6] + __popcll(w & ((1ull << b) - 1ull)));
 }
 
+// topk.hip: the K smallest 64-bit keys of each of S equally long segments, ascending (K <= 4096); out_count[s] (optional)
+// = how many of them are not the all-ones key
+size_t topk_keys_workspace(int S, long long n, int K);
+int topk_keys(const unsigned long long *keys, int S, long long n, int K, unsigned long long *out, int32_t *out_count,
+              void *ws, size_t ws_bytes, hipStream_t stream);
+
 }  // namespace df3d

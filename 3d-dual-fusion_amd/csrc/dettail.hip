@@ -8,7 +8,7 @@
 // Here the whole tail of all tasks and samples is five launches and no host round trip:
 //   head_keys      one 64-bit key per (task, sample, pixel): [segment | 0x3F800000 - score bits | pixel]; pixels that
 //                  fail the score / range mask get the all-ones key.  No atomics, no compaction pass.
-//   radix sort     (rocPRIM) -- candidates of a segment become contiguous, by descending score, ties by pixel.
+//   top-k select   (topk.hip) -- the pre_max smallest keys of every (task, sample) segment: descending score, ties by pixel.
 //   head_gather    segment bounds by binary search; the first pre_max candidates are decoded again from the maps
 //                  (boxes [x, y, z, dx, dy, dz, vx, vy, rot]) together with their NMS boxes in pcdet's frame
 //                  (box_torch_ops.py:255-257: dx <-> dy, heading -> -heading - pi/2).
@@ -17,8 +17,6 @@
 // Head maps are read as channels-last rows with a row stride, i.e. straight from the row kernels of the neck / head
 // (NCHW maps go through one permute on the caller's side, as the reference does).
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -79,33 +77,15 @@ __global__ __launch_bounds__(256) void head_keys_kernel(TailArgs a, unsigned lon
   keys[i] = key;
 }
 
-__device__ __forceinline__ long long lower_bound(const unsigned long long *k, long long n, unsigned long long v) {
-  long long lo = 0, hi = n;
-  while (lo < hi) {
-    const long long mid = (lo + hi) >> 1;
-    if (k[mid] < v) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
-}
-
 // grid (ceil(pre_max / 256), segments)
 __global__ __launch_bounds__(256) void head_gather_kernel(TailArgs a, const unsigned long long *__restrict__ keys,
-                                                          long long nkeys, int pre_max, float *__restrict__ cand_boxes,
+                                                          int pre_max, float *__restrict__ cand_boxes,
                                                           float *__restrict__ cand_scores, int32_t *__restrict__ cand_labels,
-                                                          float *__restrict__ nms_boxes, int32_t *__restrict__ counts) {
+                                                          float *__restrict__ nms_boxes, const int32_t *__restrict__ counts) {
   const int seg = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
-  __shared__ long long s_lo, s_hi;
-  if (threadIdx.x == 0) {
-    s_lo = lower_bound(keys, nkeys, (unsigned long long)seg << 56);
-    s_hi = lower_bound(keys, nkeys, (unsigned long long)(seg + 1) << 56);
-  }
-  __syncthreads();
-  const long long lo = s_lo;
-  const int n = (int)min((long long)pre_max, s_hi - lo);
-  if (r == 0) counts[seg] = n;
+  const int n = counts[seg];                     // valid keys among the segment's pre_max best (written by the select)
   if (r >= n) return;
-  const unsigned long long key = keys[lo + r];
+  const unsigned long long key = keys[(size_t)seg * pre_max + r];
   const int t = seg / a.batch, b = seg - t * a.batch;
   const int pix = (int)(key & 0xFFFFFFull);
   const float score = __uint_as_float(0x3F800000u - (unsigned)((key >> 24) & 0xFFFFFFFFull));
@@ -173,16 +153,12 @@ __global__ __launch_bounds__(128) void head_select_kernel(const float *__restric
 }
 
 struct TailPlan {
-  size_t keys_in, keys_out, sort_tmp, sort_tmp_bytes, cand_boxes, cand_scores, cand_labels, nms_boxes, counts, keep, mask,
+  size_t keys_in, keys_out, select, select_bytes, cand_boxes, cand_scores, cand_labels, nms_boxes, counts, keep, mask,
       mask_bytes, total;
 };
 
 static int tail_plan(int ntasks, int batch, int H, int W, int pre_max, TailPlan &p) {
   const size_t nkeys = (size_t)ntasks * batch * H * W, S = (size_t)ntasks * batch;
-  size_t tmp = 0;
-  if (rocprim::radix_sort_keys(nullptr, tmp, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, nkeys, 0,
-                               64, (hipStream_t)0) != hipSuccess)
-    return DF3D_EHIP;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = align_up(off, 256);
@@ -190,9 +166,9 @@ static int tail_plan(int ntasks, int batch, int H, int W, int pre_max, TailPlan 
     return o;
   };
   p.keys_in = take(nkeys * 8);
-  p.keys_out = take(nkeys * 8);
-  p.sort_tmp_bytes = tmp;
-  p.sort_tmp = take(tmp);
+  p.keys_out = take(S * pre_max * 8);
+  p.select_bytes = topk_keys_workspace((int)S, (long long)H * W, pre_max);
+  p.select = take(p.select_bytes);
   p.cand_boxes = take(S * pre_max * 9 * 4);
   p.cand_scores = take(S * pre_max * 4);
   p.cand_labels = take(S * pre_max * 4);
@@ -271,12 +247,12 @@ extern "C" int df3d_centerhead_predict(const df3d_head_task *tasks, int ntasks, 
   const int S = ntasks * cfg->batch;
   unsigned long long *kin = (unsigned long long *)(ws + p.keys_in), *kout = (unsigned long long *)(ws + p.keys_out);
   hipLaunchKernelGGL(head_keys_kernel, dim3(cdiv(nkeys, 256)), dim3(256), 0, stream, a, kin);
-  size_t tmp = p.sort_tmp_bytes;
-  DF3D_HIP(rocprim::radix_sort_keys(ws + p.sort_tmp, tmp, kin, kout, (size_t)nkeys, 0, 64, stream));
   float *cb = (float *)(ws + p.cand_boxes), *cs = (float *)(ws + p.cand_scores), *nb = (float *)(ws + p.nms_boxes);
   int32_t *cl = (int32_t *)(ws + p.cand_labels), *cnt = (int32_t *)(ws + p.counts), *keep = (int32_t *)(ws + p.keep);
-  hipLaunchKernelGGL(head_gather_kernel, dim3(cdiv(cfg->pre_max, 256), S), dim3(256), 0, stream, a, kout, nkeys,
-                     cfg->pre_max, cb, cs, cl, nb, cnt);
+  rc = topk_keys(kin, S, (long long)cfg->H * cfg->W, cfg->pre_max, kout, cnt, ws + p.select, p.select_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(head_gather_kernel, dim3(cdiv(cfg->pre_max, 256), S), dim3(256), 0, stream, a, kout, cfg->pre_max, cb,
+                     cs, cl, nb, cnt);
   DF3D_LAUNCH_CHECK();
   rc = df3d_nms_bev(nb, cnt, S, cfg->pre_max, cfg->nms_threshold, cfg->nms_mode, cfg->post_max, keep, out_counts,
                     ws + p.mask, p.mask_bytes, stream_);

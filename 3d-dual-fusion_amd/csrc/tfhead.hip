@@ -11,14 +11,12 @@
 //   proposal_keys     one 64-bit key per (sample, class, pixel): [sample | 0x3F800000 - score bits | class*HW + pixel]
 //                     where score = sigmoid(logit) if it is the maximum of its window (interior pixels only) or its
 //                     class is exempt, else 0.  Reads the heat map as channels-last rows straight from the conv kernel.
-//   radix sort        (rocPRIM): per sample by descending score, equal scores by ascending flat index (= a stable
-//                     descending argsort; the reference's argsort leaves the order of equal scores open).
+//   top-k select      (topk.hip): the K smallest keys per sample = descending score, equal scores by ascending flat
+//                     index (= a stable descending argsort; the reference's argsort leaves the order of equal scores open).
 //   proposal_gather   class / pixel / position of the first K keys, the suppressed scores of ALL classes at those
 //                     pixels (query_heatmap_score) and the query feature rows  feat[pixel] + W_cls[:, class] + b_cls.
 //   decode            one workgroup per sample: score, label, box, masks and the order-preserving compaction.
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -72,7 +70,7 @@ __global__ __launch_bounds__(256) void proposal_gather_kernel(ProposalArgs a, co
                                                               float *__restrict__ query_score, float *__restrict__ query_pos,
                                                               float *__restrict__ query_feat) {
   const int b = blockIdx.y, r0 = blockIdx.x * 16, hw = a.H * a.W;
-  const unsigned long long *seg = keys + (size_t)b * hw * a.C;         // every sample owns exactly C*H*W keys
+  const unsigned long long *seg = keys + (size_t)b * K;                  // the K best keys of sample b, ascending
   __shared__ int s_cls[16], s_pix[16];
   const int n = min(16, K - r0);
   if (threadIdx.x < n) {
@@ -168,27 +166,25 @@ __global__ __launch_bounds__(256) void tf_decode_kernel(DecodeArgs a, float *__r
 }
 
 struct TopkPlan {
-  size_t keys_in, keys_out, sort_tmp, sort_tmp_bytes, total;
+  size_t keys, top, select, select_bytes, total;
 };
 
+constexpr int TF_MAX_PROPOSALS = 4096;
+
 static int topk_plan(int batch, int C, int H, int W, TopkPlan &p) {
-  const size_t nkeys = (size_t)batch * C * H * W;
-  size_t tmp = 0;
-  if (rocprim::radix_sort_keys(nullptr, tmp, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, nkeys, 0,
-                               64, (hipStream_t)0) != hipSuccess)
-    return DF3D_EHIP;
+  const size_t n = (size_t)C * H * W;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = align_up(off, 256);
     off = o + bytes;
     return o;
   };
-  p.keys_in = take(nkeys * 8);
-  p.keys_out = take(nkeys * 8);
-  p.sort_tmp_bytes = tmp;
-  p.sort_tmp = take(tmp);
+  p.keys = take((size_t)batch * n * 8);
+  p.top = take((size_t)batch * TF_MAX_PROPOSALS * 8);
+  p.select_bytes = topk_keys_workspace(batch, (long long)n, TF_MAX_PROPOSALS);
+  p.select = take(p.select_bytes);
   p.total = align_up(off, 256);
-  return DF3D_OK;
+  return p.select_bytes ? DF3D_OK : DF3D_EINVAL;
 }
 
 }  // namespace df3d
@@ -217,24 +213,22 @@ extern "C" int df3d_heatmap_proposals(const float *heat_rows, int ld_heat, int b
                  "heatmap_proposals: need 1..255 samples, 1..32 classes and fewer than 2^24 (class, pixel) pairs");
   DF3D_CHECK_ARG(nms_kernel_size >= 3 && (nms_kernel_size & 1) && nms_kernel_size <= 2 * (H < W ? H : W),
                  "heatmap_proposals: nms_kernel_size must be odd and >= 3 (got %d)", nms_kernel_size);
-  DF3D_CHECK_ARG(num_proposals > 0 && (long long)num_proposals <= (long long)num_classes * H * W,
-                 "heatmap_proposals: num_proposals %d out of range", num_proposals);
+  DF3D_CHECK_ARG(num_proposals > 0 && num_proposals <= TF_MAX_PROPOSALS &&
+                     (long long)num_proposals <= (long long)num_classes * H * W,
+                 "heatmap_proposals: num_proposals %d out of range (1..min(%d, C*H*W))", num_proposals, TF_MAX_PROPOSALS);
   DF3D_CHECK_ARG(heat_rows && ld_heat >= num_classes, "heatmap_proposals: heat map rows");
   DF3D_CHECK_ARG(top_class && top_pixel && query_score && workspace, "heatmap_proposals: null output");
   DF3D_CHECK_ARG(!query_feat || (feat_rows && channels > 0 && ld_feat >= channels), "heatmap_proposals: feature rows");
   TopkPlan p;
-  if (topk_plan(batch, num_classes, H, W, p)) {
-    set_error("heatmap_proposals: rocPRIM temp-storage query failed");
-    return DF3D_EHIP;
-  }
+  DF3D_CHECK_ARG(topk_plan(batch, num_classes, H, W, p) == DF3D_OK, "heatmap_proposals: unsupported map size");
   DF3D_CHECK_ARG(workspace_bytes >= p.total, "heatmap_proposals: workspace %zu < %zu bytes", workspace_bytes, p.total);
   ProposalArgs a = {heat_rows, ld_heat, batch, num_classes, H, W, nms_kernel_size / 2, exempt_classes};
   char *ws = (char *)workspace;
-  const long long nkeys = (long long)batch * num_classes * H * W;
-  unsigned long long *kin = (unsigned long long *)(ws + p.keys_in), *kout = (unsigned long long *)(ws + p.keys_out);
+  const long long per_sample = (long long)num_classes * H * W, nkeys = (long long)batch * per_sample;
+  unsigned long long *kin = (unsigned long long *)(ws + p.keys), *kout = (unsigned long long *)(ws + p.top);
   hipLaunchKernelGGL(proposal_keys_kernel, dim3(cdiv(nkeys, 256)), dim3(256), 0, stream, a, kin);
-  size_t tmp = p.sort_tmp_bytes;
-  DF3D_HIP(rocprim::radix_sort_keys(ws + p.sort_tmp, tmp, kin, kout, (size_t)nkeys, 0, 64, stream));
+  int rc = topk_keys(kin, batch, per_sample, num_proposals, kout, nullptr, ws + p.select, p.select_bytes, stream);
+  if (rc) return rc;
   hipLaunchKernelGGL(proposal_gather_kernel, dim3(cdiv(num_proposals, 16), batch), dim3(256), 0, stream, a, kout, num_proposals, feat_rows, ld_feat,
                      channels, class_weight, class_bias, top_class, top_pixel, query_score, query_pos, query_feat);
   DF3D_LAUNCH_CHECK();

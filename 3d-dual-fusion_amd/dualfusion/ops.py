@@ -722,6 +722,25 @@ def transfusion_decode(heads, query_score, query_label, batch, num_proposals, nu
     return boxes, scores, labels, counts
 
 
+def topk_keys(keys, k):
+    """df3d_topk_keys.  keys: int64 [segments, n] (the 64-bit keys reinterpreted; they compare as UNSIGNED).  Returns
+    (out int64 [segments, k] ascending as unsigned, count int32 [segments] of keys below the all-ones key)."""
+    lib = _lib.load()
+    _chk(keys, torch.int64, "keys")
+    if keys.dim() != 2:
+        raise ValueError("keys must be [segments, n]")
+    S, n = keys.shape
+    out = torch.empty((S, int(k)), dtype=torch.int64, device=keys.device)
+    cnt = torch.empty((S,), dtype=torch.int32, device=keys.device)
+    nbytes = lib.df3d_topk_keys_workspace_bytes(S, n, int(k))
+    if nbytes == 0:
+        raise _lib.Df3dError("df3d_topk_keys: unsupported sizes (1 <= k <= 4096)")
+    ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=keys.device)
+    rc = lib.df3d_topk_keys(_ptr(keys), S, n, int(k), _ptr(out), _ptr(cnt), _ptr(ws), int(nbytes), _stream())
+    _lib.check(rc, "df3d_topk_keys")
+    return out, cnt
+
+
 def cross_attention(q, k, v, batch, heads, scale=None):
     """df3d_cross_attention.  q: fp32 [B*nq, heads*16] row view, k / v: fp32 [B*nk, heads*16] row views (unit column
     stride, any row stride).  Returns out [B*nq, heads*16]."""

@@ -323,6 +323,21 @@ int df3d_transfusion_decode(const df3d_query_heads *heads, const float *query_sc
                             float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *out_counts, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * The k smallest 64-bit keys of each of `segments` equally long key arrays, in ascending order: the selection step
+ * of both detection heads (keys = [segment | 0x3F800000 - score bits | index], so ascending key = descending score,
+ * ties by ascending index).  Replaces the full sorts of the reference -- the per-(task, sample) score sort before
+ * rotate_nms_pcdet (CP/det3d/models/bbox_heads/center_head.py:470-478, box_torch_ops.py:248-279) and the argsort of
+ * all C*H*W scores (TF/mmdet3d/models/dense_heads/transfusion_head.py:866) -- by a two-level radix select
+ * (histogram, histogram, compaction, one-workgroup sort); exact for any input.
+ *   keys [segments, n] u64 (bits 63:56 equal within a segment; the all-ones key is "masked"), out [segments, k] u64
+ *   (padded with all-ones keys when n < k), out_count [segments] i32 or NULL = keys of out below the all-ones key.
+ *   1 <= k <= 4096.
+ */
+size_t df3d_topk_keys_workspace_bytes(int segments, long long n, int k);
+int df3d_topk_keys(const unsigned long long *keys, int segments, long long n, int k, unsigned long long *out,
+                   int32_t *out_count, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Cross-attention of object queries over the BEV map (TransFusionHead decoder layer, transfusion_head.py:110-113 ->
  * multi_head_attention_forward :255-505, the bmm / softmax / bmm of :478-495):
  *   out[b, q, h*16 + d] = sum_k softmax_k(scale * <Q[b,q,h,:], K[b,k,h,:]>) * V[b,k,h,d]

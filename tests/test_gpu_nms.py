@@ -122,3 +122,48 @@ def test_against_reference_gpu_kernels_on_this_device():
         keep, num = ops.nms_bev(at, thr, ops.NMS_NORMAL if normal else ops.NMS_ROTATED)
         if normal or not bool(((iou_ref - thr).abs() < 1e-4).any()):
             assert int(num) == n_ref and keep[:n_ref].cpu().tolist() == keep_ref[:n_ref].tolist()
+
+
+# ---- df3d_topk_keys: the selection step of both heads, against a full numpy sort
+def _score_keys(rs, S, n, kind):
+    """[segment | 0x3F800000 - score bits | index] keys like the heads build them."""
+    if kind == "uniform":
+        score = rs.uniform(0.0, 1.0, size=(S, n)).astype(np.float32)
+    elif kind == "peaked":                                  # sigmoid of wide logits: many scores next to 1.0
+        score = (1.0 / (1.0 + np.exp(-rs.normal(4.0, 3.0, size=(S, n))))).astype(np.float32)
+    elif kind == "saturated":                               # thousands of exactly equal top scores: ties by index
+        score = np.where(rs.uniform(size=(S, n)) < 0.5, np.float32(1.0), rs.uniform(0, 1, size=(S, n)).astype(np.float32))
+    elif kind == "clustered":                               # a near-constant heat map: thousands of scores within 1e-6
+        score = (0.1006 + rs.uniform(0, 1e-6, size=(S, n))).astype(np.float32)
+    elif kind == "zeros":                                   # fewer positive scores than k
+        score = np.where(rs.uniform(size=(S, n)) < 0.002, rs.uniform(0, 1, size=(S, n)), 0.0).astype(np.float32)
+    inv = (np.uint64(0x3F800000) - score.view(np.uint32).astype(np.uint64))
+    idx = np.broadcast_to(rs.permutation(n).astype(np.uint64), (S, n))
+    keys = (np.arange(S, dtype=np.uint64)[:, None] << np.uint64(56)) | (inv << np.uint64(24)) | idx
+    if kind == "uniform":
+        keys = np.where(rs.uniform(size=(S, n)) < 0.3, np.uint64(0xFFFFFFFFFFFFFFFF), keys)      # masked entries
+    return keys
+
+
+@pytest.mark.parametrize("S,n,k,kind", [(3, 32400, 1000, "uniform"), (2, 324000, 200, "peaked"), (2, 50000, 500, "saturated"),
+                                        (2, 40000, 300, "zeros"), (6, 32400, 1000, "clustered"), (5, 168, 60, "uniform"), (1, 100, 4096, "uniform"),
+                                        (2, 20000, 4096, "saturated"), (1, 7, 1, "peaked")])
+def test_topk_keys_equals_full_sort(S, n, k, kind):
+    from dualfusion import ops
+    rs = np.random.RandomState(S * 1000 + k)
+    keys = _score_keys(rs, S, n, kind)
+    out, cnt = ops.topk_keys(torch.from_numpy(keys.view(np.int64)).to(DEV), k)
+    want = np.sort(keys, axis=1)[:, :k]
+    if n < k:
+        want = np.concatenate([want, np.full((S, k - n), 0xFFFFFFFFFFFFFFFF, np.uint64)], 1)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    assert cnt.cpu().numpy().tolist() == (want != np.uint64(0xFFFFFFFFFFFFFFFF)).sum(1).tolist()
+
+
+def test_topk_keys_rejects_bad_arguments():
+    from dualfusion import Df3dError, ops
+    keys = torch.zeros((2, 100), dtype=torch.int64, device=DEV)
+    with pytest.raises(Df3dError):
+        ops.topk_keys(keys, 4097)
+    with pytest.raises(Df3dError):
+        ops.topk_keys(keys.cpu(), 10)
