@@ -15,5 +15,6 @@ python tools/bench_trees.py head 20               # CenterHead forward + predict
 python tools/bench_trees.py tfhead 20             # TransFusionHead forward + get_bboxes (device path vs plain torch)
 python tools/bench_trees.py train 10              # backbone training step (forward + backward)
 python tools/ubench/xattn_probe.py                # the split-key cross-attention kernel alone
+python tools/ubench/topk_probe.py                 # the top-k select of both heads alone
 python tools/ubench/os_probe.py                   # per-layer conv kernel timings (split precision and bf16)
 # profiles/: rocprofv3 --kernel-trace --stats and --pmc FETCH_SIZE / WRITE_SIZE passes, distilled by tools/make_profiles.py
