@@ -243,3 +243,42 @@ def test_cross_attention_rejects_bad_arguments():
     flat = torch.zeros((8 * 80 + 1,), device=DEV)
     with pytest.raises(Df3dError):
         ops.cross_attention(flat[1:].view(8, 80), kv[:, :80].contiguous(), kv[:, :80].contiguous(), 1, 5)   # q not 16-byte aligned
+
+
+@pytest.mark.parametrize("layers,aux", [(2, True), (3, False)])
+def test_multi_layer_decoder_device_path_vs_torch_path(layers, aux):
+    """num_decoder_layers > 1 (the reference's default is 3): query positions move to the predicted centres between
+    layers, auxiliary=True concatenates the per-layer predictions along the proposal axis (transfusion_head.py:
+    886-905,1016-1028).  Device path vs the same module's plain-torch path on a small map."""
+    from dualfusion.transfusion_head import TransFusionHead
+    from make_golden import TFH_CODER, TFH_KW, TFH_SHAPE, TFH_TEST_CFG, tfh_weight_shift
+    kw = dict(TFH_KW, num_decoder_layers=layers, auxiliary=aux)
+    head = TransFusionHead(loss_cls=dict(use_sigmoid=True), test_cfg=dict(TFH_TEST_CFG),
+                           bbox_coder=dict(type='TransFusionBBoxCoder', **TFH_CODER), **kw)
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    sd = tfh_weight_shift(detgen.det_state_dict(shapes))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    head = head.eval().to(DEV)
+    x = torch.from_numpy(detgen.randn("tfh_x_0", TFH_SHAPE)).to(DEV)         # the golden's tie-free input
+    with torch.no_grad():
+        got = head([x])[0][0]
+        lab = head.query_labels.clone()
+        want = head.forward_reference(x)[0]
+    K = TFH_KW["num_proposals"]
+    assert torch.equal(lab, head.query_labels)
+    assert got["heatmap"].shape[-1] == (K * layers if aux else K)
+    assert sorted(got) == sorted(want)
+    for name in got:
+        _close(got[name].cpu().numpy(), want[name].cpu().numpy(), 1e-3, name)
+    if not aux:
+        # like the reference, only the FIRST layer's dict carries 'query_heatmap_score' (transfusion_head.py:1013-1020),
+        # so get_bboxes needs auxiliary=True (or one layer) -- same KeyError as the reference otherwise
+        assert "query_heatmap_score" not in got
+        return
+    with torch.no_grad():
+        boxes = head.get_bboxes(([got],))
+        boxes_ref = head.get_bboxes(([{k: v.clone() for k, v in want.items()}],))
+    for (b0, s0, l0), (b1, s1, l1) in zip(boxes, boxes_ref):
+        assert l0.cpu().numpy().tolist() == l1.cpu().numpy().tolist()
+        np.testing.assert_allclose(s0.cpu().numpy(), s1.cpu().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(b0.cpu().numpy(), b1.cpu().numpy(), rtol=1e-3, atol=1e-3)
