@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["common.hip", "voxelize.hip", "rulebook.hip", "spconv.hip", "spconv_split.hip", "dense.hip", "msda.hip", "pointops.hip",
-           "fusion.hip", "actr.hip", "ffn.hip", "imgproj.hip", "executor.hip", "nms.hip", "dettail.hip", "topk.hip", "tfhead.hip", "xattn.hip",
+           "fusion.hip", "actr.hip", "ffn.hip", "imgproj.hip", "executor.hip", "nms.hip", "dettail.hip", "topk.hip", "pool.hip", "tfhead.hip", "xattn.hip",
            "spconv_bwd.hip"]
 OUT = os.path.join(HERE, "libdf3d_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]

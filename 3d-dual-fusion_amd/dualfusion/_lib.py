@@ -115,6 +115,9 @@ SIGNATURES = {
                                        c_void_p, c_size_t, c_void_p]),
     "df3d_transfusion_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
+    "df3d_sparse_maxpool": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_sparse_maxpool_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "df3d_dynamic_voxelize": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_topk_keys_workspace_bytes": (c_size_t, [c_int, c_longlong, c_int]),
     "df3d_topk_keys": (c_int, [c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_cross_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

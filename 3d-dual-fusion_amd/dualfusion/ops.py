@@ -722,6 +722,46 @@ def transfusion_decode(heads, query_score, query_label, batch, num_proposals, nu
     return boxes, scores, labels, counts
 
 
+def sparse_maxpool(features, nbr, n_out):
+    """df3d_sparse_maxpool: out[o] = max(0, max_k features[nbr[k][o]])."""
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    _chk(nbr, torch.int32, "nbr")
+    n_in, C = features.shape
+    out = torch.empty((int(n_out), C), dtype=torch.float32, device=features.device)
+    rc = lib.df3d_sparse_maxpool(_ptr(features), n_in, C, _ptr(nbr), nbr.shape[0], int(n_out), _ptr(out), _stream())
+    _lib.check(rc, "df3d_sparse_maxpool")
+    return out
+
+
+def sparse_maxpool_backward(features, out_features, grad_out, inv):
+    """df3d_sparse_maxpool_backward; inv = invert_neighbors(nbr, n_in)."""
+    lib = _lib.load()
+    for t, nm in ((features, "features"), (out_features, "out_features"), (grad_out, "grad_out")):
+        _chk(t, torch.float32, nm)
+    _chk(inv, torch.int32, "inv")
+    n_in, C = features.shape
+    gin = torch.empty_like(features)
+    rc = lib.df3d_sparse_maxpool_backward(_ptr(features), _ptr(out_features), _ptr(grad_out), n_in, C, _ptr(inv),
+                                          inv.shape[0], _ptr(gin), _stream())
+    _lib.check(rc, "df3d_sparse_maxpool_backward")
+    return gin
+
+
+def dynamic_voxelize(points, voxel_size, coors_range):
+    """df3d_dynamic_voxelize: coors [P, 3] int32 (z, y, x), -1 rows for points outside the grid."""
+    lib = _lib.load()
+    _chk(points, torch.float32, "points")
+    P, F = points.shape
+    coors = torch.empty((P, 3), dtype=torch.int32, device=points.device)
+    vs = (ctypes.c_float * 3)(*[float(v) for v in voxel_size])
+    rng = (ctypes.c_float * 6)(*[float(v) for v in coors_range])
+    rc = lib.df3d_dynamic_voxelize(_ptr(points), P, F, ctypes.cast(vs, ctypes.c_void_p), ctypes.cast(rng, ctypes.c_void_p),
+                                   _ptr(coors), _stream())
+    _lib.check(rc, "df3d_dynamic_voxelize")
+    return coors
+
+
 def topk_keys(keys, k):
     """df3d_topk_keys.  keys: int64 [segments, n] (the 64-bit keys reinterpreted; they compare as UNSIGNED).  Returns
     (out int64 [segments, k] ascending as unsigned, count int32 [segments] of keys below the all-ones key)."""

@@ -113,7 +113,18 @@ class SparseConvolution(SparseModule):
             return pre
         datas = input.find_indice_pair(self.indice_key)
         if self.inverse:
-            raise Df3dError("SparseInverseConv is not used by the 3D-DF backbones and is not implemented")
+            # conv.py:146-151: the rulebook of the forward conv registered under `indice_key`, read backwards -- the
+            # outputs are that conv's INPUT sites, every pair (i, o) of offset k contributes in[o] . W[k] to out[i]
+            if datas is None or self.indice_key is None:
+                raise Df3dError("SparseInverseConv needs the rulebook of a previous convolution with the same indice_key")
+            if datas.nbr.shape[0] != int(np.prod(self.kernel_size)):
+                raise Df3dError("SparseInverseConv: kernel size differs from the convolution registered as %r" % (self.indice_key,))
+            inv = getattr(datas, "_inverse", None)
+            if inv is None:
+                inv = Rulebook(datas.indices, datas.outids, _ops.invert_neighbors(datas.nbr, datas.indices.shape[0]),
+                               datas.out_spatial_shape, datas.spatial_shape, out_rows_sorted=False)
+                datas._inverse = inv
+            return inv
         if self.indice_key is not None and datas is not None:
             return datas
         if self.transposed:

@@ -104,3 +104,20 @@ def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, nu
     cout = filters.shape[-1]
     return _ops.sparse_conv_fused(features.contiguous(), filters.contiguous().view(-1, cin, cout), nbr,
                                   int(num_activate_out), bias=bias.contiguous())
+
+
+def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
+    """sparse_conv_ext.indice_maxpool_fp32 (pool_ops.h:26-58) from a reference-format rulebook."""
+    if features.dtype != torch.float32:
+        raise Df3dError("indice_maxpool: fp32 only (got %s)" % features.dtype)
+    nbr = _ops.pairs_to_nbr(indice_pairs.contiguous(), indice_pair_num, int(num_activate_out))
+    return _ops.sparse_maxpool(features.contiguous(), nbr, int(num_activate_out))
+
+
+def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num):
+    """sparse_conv_ext.indice_maxpool_backward_fp32 (pool_ops.h:60-94)."""
+    if features.dtype != torch.float32:
+        raise Df3dError("indice_maxpool_backward: fp32 only (got %s)" % features.dtype)
+    nbr = _ops.pairs_to_nbr(indice_pairs.contiguous(), indice_pair_num, int(out_features.shape[0]))
+    inv = _ops.invert_neighbors(nbr, features.shape[0])
+    return _ops.sparse_maxpool_backward(features.contiguous(), out_features.contiguous(), out_bp.contiguous(), inv)

@@ -16,10 +16,10 @@ from .registry import READERS, VOXEL_ENCODERS
 class _Voxelization(object):
     @staticmethod
     def apply(points, voxel_size, coors_range, max_points=35, max_voxels=20000):
-        """voxelize.py:13-58.  max_points == -1 or max_voxels == -1 selects dynamic voxelisation in
-        the reference (returns per-point coords); only hard voxelisation is on the 3D-DF path."""
+        """voxelize.py:13-58.  max_points == -1 or max_voxels == -1 selects dynamic voxelisation
+        (per-point (z, y, x) coordinates, -1 outside the grid)."""
         if max_points == -1 or max_voxels == -1:
-            raise NotImplementedError("dynamic voxelisation is not used by the 3D-DF configs")
+            return _ops.dynamic_voxelize(points.contiguous().float(), voxel_size, coors_range)
         voxels, coors, num, _ = _ops.hard_voxelize(points.contiguous().float(), voxel_size, coors_range, max_points,
                                                    max_voxels, break_at_cap=True, want_voxels=True, want_mean=False)
         return voxels, coors, num

@@ -323,6 +323,29 @@ int df3d_transfusion_decode(const df3d_query_heads *heads, const float *query_sc
                             float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *out_counts, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Sparse max pooling.  Replaces sparse_conv_ext.indice_maxpool_fp32 / indice_maxpool_backward_fp32
+ * (TF/mmdet3d/ops/spconv/src/all.cc:21-51 -> include/spconv/pool_ops.h:26-94, src/maxpool.cc:22-66, maxpool_cuda.cu):
+ *   forward   out[o, c] = max(0, max over offsets k with nbr[k][o] >= 0 of features[nbr[k][o], c])
+ *             (the reference starts from a ZERO output and only raises it; kept bug for bug)
+ *   backward  grad_in[i, c] = sum over offsets k (ascending, like the reference's loop) with o = inv[k][i] >= 0 and
+ *             out_features[o, c] == features[i, c] of grad_out[o, c];  inv = df3d_invert_neighbors(nbr).
+ * One launch each over the neighbour table instead of one launch per kernel offset; channels % 4 == 0.
+ */
+int df3d_sparse_maxpool(const float *features, int n_in, int channels, const int32_t *nbr, int kvol, int n_out, float *out,
+                        void *stream);
+int df3d_sparse_maxpool_backward(const float *features, const float *out_features, const float *grad_out, int n_in,
+                                 int channels, const int32_t *inv, int kvol, float *grad_in, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Dynamic voxelisation.  Replaces voxel_layer.dynamic_voxelize (TF/mmdet3d/ops/voxel/src/voxelization.h:71-86,
+ * voxelization_cpu.cpp:8-41,147-171, voxelization_cuda.cu:11-45,328-373): coors[i] = (z, y, x) voxel of point i,
+ * c = floor((p - range_min) / voxel_size) per axis in fp32, grid = round((max - min) / voxel_size); all three -1 when
+ * the point lies outside the grid.  points [P, F >= 3] f32, voxel_size [3], coors_range [6] (host), coors [P, 3] i32.
+ */
+int df3d_dynamic_voxelize(const float *points, long long num_points, int num_features, const float *voxel_size,
+                          const float *coors_range, int32_t *coors, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * The k smallest 64-bit keys of each of `segments` equally long key arrays, in ascending order: the selection step
  * of both detection heads (keys = [segment | 0x3F800000 - score bits | index], so ascending key = descending score,
  * ties by ascending index).  Replaces the full sorts of the reference -- the per-(task, sample) score sort before

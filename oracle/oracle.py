@@ -429,3 +429,43 @@ def centerhead_predict(preds_dicts, test_cfg, num_classes, margin_out=None):
     if margin_out is not None:
         margin_out.update(stats)
     return out
+
+
+def indice_maxpool(features, pairs, num, num_act_out):
+    """TF/mmdet3d/ops/spconv/include/spconv/pool_ops.h:26-58 + src/maxpool.cc:22-41: output = ZEROS, then per offset and
+    pair out[o] = in[i] where out[o] < in[i]."""
+    features = np.asarray(features, np.float32)
+    out = np.zeros((num_act_out, features.shape[1]), np.float32)
+    for k in range(pairs.shape[0]):
+        n = int(num[k])
+        if n > 0:
+            np.maximum.at(out, pairs[k, 1, :n], features[pairs[k, 0, :n]])
+    return out
+
+
+def indice_maxpool_backward(features, out_features, out_grad, pairs, num):
+    """pool_ops.h:60-94 + src/maxpool.cc:43-66: din[i] += dout[o] for every pair with out[o] == in[i], offsets in
+    ascending order (an input row occurs at most once per offset, so the order of the fp32 additions is fixed)."""
+    features = np.asarray(features, np.float32)
+    gin = np.zeros_like(features)
+    for k in range(pairs.shape[0]):
+        n = int(num[k])
+        if n > 0:
+            i, o = pairs[k, 0, :n], pairs[k, 1, :n]
+            gin[i] = (gin[i] + np.where(out_features[o] == features[i], out_grad[o], np.float32(0))).astype(np.float32)
+    return gin
+
+
+def dynamic_voxelize(points, voxel_size, coors_range):
+    """TF/mmdet3d/ops/voxel/src/voxelization_cpu.cpp:8-41,147-171: c = floor((p - min) / size) in fp32 per axis,
+    (z, y, x) order, all -1 when any axis falls outside grid = round((max - min) / size)."""
+    pts = np.asarray(points, np.float32)[:, :3]
+    vs = np.asarray(voxel_size, np.float32)
+    rng = np.asarray(coors_range, np.float32)
+    grid = np.round((rng[3:] - rng[:3]) / vs).astype(np.int64)
+    with np.errstate(invalid="ignore"):
+        c = np.floor((pts - rng[:3]) / vs)
+        ok = ((c >= 0) & (c < grid)).all(1)
+    out = np.full((len(pts), 3), -1, np.int32)
+    out[ok] = c[ok][:, ::-1].astype(np.int32)
+    return out

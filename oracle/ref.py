@@ -70,14 +70,44 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding,
     return outids.numpy(), pairs.numpy(), num.numpy(), out_shape
 
 
-def indice_conv(features, filters, pairs, num, num_act_out, subm):
+def indice_conv(features, filters, pairs, num, num_act_out, subm, inverse=False):
     """sparse_conv_ext.indice_conv_fp32 (TF/.../spconv_ops.h:260-361)."""
     import numpy as np
     import torch
     m = load("sparse_conv_ext")
     t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a, dtype=d))
     return m.indice_conv_fp32(t(features, np.float32), t(filters, np.float32), t(pairs, np.int32),
-                              t(num, np.int32), int(num_act_out), 0, int(bool(subm))).numpy()
+                              t(num, np.int32), int(num_act_out), int(bool(inverse)), int(bool(subm))).numpy()
+
+
+def indice_maxpool(features, pairs, num, num_act_out):
+    """sparse_conv_ext.indice_maxpool_fp32 (TF/.../pool_ops.h:26-58)."""
+    import numpy as np
+    import torch
+    m = load("sparse_conv_ext")
+    t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a, dtype=d))
+    return m.indice_maxpool_fp32(t(features, np.float32), t(pairs, np.int32), t(num, np.int32), int(num_act_out)).numpy()
+
+
+def indice_maxpool_backward(features, out_features, out_grad, pairs, num):
+    """sparse_conv_ext.indice_maxpool_backward_fp32 (TF/.../pool_ops.h:60-94)."""
+    import numpy as np
+    import torch
+    m = load("sparse_conv_ext")
+    t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a, dtype=d))
+    return m.indice_maxpool_backward_fp32(t(features, np.float32), t(out_features, np.float32), t(out_grad, np.float32),
+                                          t(pairs, np.int32), t(num, np.int32)).numpy()
+
+
+def dynamic_voxelize(points, voxel_size, coors_range):
+    """voxel_layer.dynamic_voxelize (TF/mmdet3d/ops/voxel/src/voxelization.h:71-86), called as voxelize.py:41-44 does."""
+    import numpy as np
+    import torch
+    m = load("voxel_layer")
+    pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32))
+    coors = pts.new_zeros(size=(pts.size(0), 3), dtype=torch.int)
+    m.dynamic_voxelize(pts, coors, [float(v) for v in voxel_size], [float(v) for v in coors_range], 3)
+    return coors.numpy()
 
 
 def indice_conv_backward(features, filters, out_grad, pairs, num, subm):

@@ -818,6 +818,37 @@ def gen_conv_bwd():
     save("conv_bwd.npz", **out)
 
 
+def pool_points(name="dynvox"):
+    """Points around a small grid: inside, outside, on the faces."""
+    pts = detgen.rand(name, (4000, 4), -1.0, 1.0) * np.array([12.0, 9.0, 3.0, 1.0], np.float32)
+    pts[:8, :3] = [[-10, -8, -2], [10, 8, 2], [9.999999, 0, 0], [0, 7.9999995, 0], [-10.000001, 0, 0], [0, 0, 1.9999999],
+                   [0, -8, -2], [5, 5, 2.0000002]]
+    return pts.astype(np.float32)
+
+
+POOL_VS, POOL_RANGE = [0.25, 0.2, 0.5], [-10.0, -8.0, -2.0, 10.0, 8.0, 2.0]
+
+
+def gen_pool():
+    """indice_maxpool_fp32 / indice_maxpool_backward_fp32 / indice_conv_fp32(inverse) / dynamic_voxelize of the
+    reference's compiled CPU code (oracle/_ref)."""
+    out = {}
+    ind, ks, st, pd, f, w = conv_bwd_case(0)                    # strided 3x3x3 geometry, 12 channels
+    outids, pairs, num, _ = ref.get_indice_pairs(ind, CONV_BWD_BATCH, CONV_BWD_SHAPE, ks, st, pd, [1, 1, 1], 0)
+    order = np.lexsort(outids.T[::-1])
+    y = ref.indice_maxpool(f, pairs, num, len(outids))
+    go = detgen.randn("pool_g", y.shape)
+    fq = np.round(f * 2) / 2                                     # quantised copy: equal values inside one window
+    yq = ref.indice_maxpool(fq, pairs, num, len(outids))
+    out.update(outids=outids[order], order=order.astype(np.int64), y=y, gin=ref.indice_maxpool_backward(f, y, go, pairs, num),
+               yq=yq, ginq=ref.indice_maxpool_backward(fq, yq, go, pairs, num))
+    fo = detgen.randn("inv_f", (len(outids), 20))               # features on the strided conv's OUTPUT sites
+    wi = detgen.randn("inv_w", (3, 3, 3, 20, 12), 0.2)
+    out["inv"] = ref.indice_conv(fo, wi, pairs, num, len(ind), 0, inverse=True)
+    out["dyn"] = ref.dynamic_voxelize(pool_points(), POOL_VS, POOL_RANGE)
+    save("pool.npz", **out)
+
+
 def gen_iou3d():
     """Rotated BEV IoU from the reference's own CPU path (oracle/_ref/iou3d_nms_cuda.so: boxes_iou_bev_cpu,
     CP/det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:224-252) on detgen boxes, and the greedy keep list that the reference's
@@ -842,11 +873,13 @@ def gen_iou3d():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "conv_bwd"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "conv_bwd", "pool"]
     if "iou3d" in which:
         gen_iou3d()
     if "conv_bwd" in which:
         gen_conv_bwd()
+    if "pool" in which:
+        gen_pool()
     if "centerhead" in which:
         gen_centerhead()
     if "tfhead" in which:

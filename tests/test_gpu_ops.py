@@ -595,3 +595,95 @@ def test_conv_bf16_equals_fp32_kernel_on_rounded_operands(dev, cin, cout, n_seed
     # vs the fp32 operands: the bf16 path's error is the operand rounding (~2^-9 per term, averaging out)
     full = ops.sparse_conv_fused(f, w, nbr, n_out)
     assert float((plain - full).abs().max() / full.abs().max()) <= 2e-2
+
+
+# ------------------------------------------------------------------------- sparse max pool, inverse conv, dynamic voxelize
+def _canon(ids):
+    return np.lexsort(np.asarray(ids).T[::-1])
+
+
+def test_sparse_maxpool_module_golden_and_oracle(golden, dev):
+    """SparseMaxPool3d forward / backward (one launch each over the neighbour table) against the reference's compiled
+    CPU outputs (tests/golden/pool.npz) and the oracle -- bit for bit, incl. the zero-initialised output and the
+    fan-out of the gradient over equal values."""
+    from dualfusion import spconv
+    from make_golden import CONV_BWD_BATCH, CONV_BWD_SHAPE, conv_bwd_case
+    g = golden("pool.npz")
+    ind, ks, st, pd, f, _ = conv_bwd_case(0)
+    pool = spconv.SparseMaxPool3d(ks, st, pd)
+    for feats, ykey, gkey in ((f, "y", "gin"), (np.round(f * 2) / 2, "yq", "ginq")):
+        x = T(feats, dev).requires_grad_(True)
+        out = pool(spconv.SparseConvTensor(x, T(ind, dev), CONV_BWD_SHAPE, CONV_BWD_BATCH))
+        o = _canon(out.indices.cpu().numpy())
+        assert np.array_equal(out.indices.cpu().numpy()[o], g["outids"]) and out.spatial_shape == [4, 10, 11]
+        assert np.array_equal(out.features.detach().cpu().numpy()[o], g[ykey][g["order"]])
+        go = np.empty(out.features.shape, np.float32)
+        go[o] = detgen.randn("pool_g", out.features.shape)[g["order"]]
+        out.features.backward(T(go, dev))
+        assert np.array_equal(x.grad.cpu().numpy(), g[gkey])
+    # function-level entry points on a reference-format rulebook (ops.py:161-183)
+    outids, pairs, num, _ = orc.get_indice_pairs(ind, CONV_BWD_BATCH, CONV_BWD_SHAPE, ks, st, pd, [1, 1, 1], 0)
+    y = spconv.ops.indice_maxpool(T(f, dev), T(pairs, dev), T(num, dev), len(outids))
+    assert np.array_equal(y.cpu().numpy(), orc.indice_maxpool(f, pairs, num, len(outids)))
+    go = detgen.randn("pool_g2", tuple(y.shape))
+    gin = spconv.ops.indice_maxpool_backward(T(f, dev), y, T(go, dev), T(pairs, dev), T(num, dev))
+    assert np.array_equal(gin.cpu().numpy(), orc.indice_maxpool_backward(f, y.cpu().numpy(), go, pairs, num))
+
+
+def test_sparse_maxpool_full_size_vs_oracle(dev):
+    from dualfusion import ops, synth
+    pts = torch.from_numpy(synth.nusc_sweep(seed=3)).to(dev)
+    _, coors, _, mean = ops.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000, want_voxels=False, batch_index=0)
+    from dualfusion import spconv
+    feats = torch.cat([mean, mean[:, :3]], 1).contiguous()                  # 8 channels
+    x = spconv.SparseConvTensor(feats, coors, [41, 1440, 1440], 1)
+    out = spconv.SparseMaxPool3d(3, 2, 1)(x)
+    outids, pairs, num, _ = orc.get_indice_pairs(coors.cpu().numpy(), 1, [41, 1440, 1440], [3] * 3, [2] * 3, [1] * 3, [1] * 3, 0)
+    want = orc.indice_maxpool(feats.cpu().numpy(), pairs, num, len(outids))
+    a, b = _canon(out.indices.cpu().numpy()), _canon(outids)
+    assert np.array_equal(out.indices.cpu().numpy()[a], outids[b])
+    assert np.array_equal(out.features.cpu().numpy()[a], want[b])
+
+
+def test_sparse_inverse_conv_golden_and_autograd(golden, dev):
+    """SparseConv3d(indice_key) -> SparseInverseConv3d(same key): the inverse reads the registered rulebook backwards
+    (conv.py:146-151,188-192); values against indice_conv_fp32(inverse=1) of the reference's compiled CPU code."""
+    from dualfusion import spconv
+    from make_golden import CONV_BWD_BATCH, CONV_BWD_SHAPE, conv_bwd_case
+    g = golden("pool.npz")
+    ind, ks, st, pd, f, w = conv_bwd_case(0)
+    down = spconv.SparseConv3d(12, 20, 3, 2, 1, bias=False, indice_key="d").to(dev)
+    up = spconv.SparseInverseConv3d(20, 12, 3, indice_key="d", bias=False).to(dev)
+    wi = detgen.randn("inv_w", (3, 3, 3, 20, 12), 0.2)
+    with torch.no_grad():
+        down.weight.copy_(T(w, dev))
+        up.weight.copy_(T(wi, dev))
+        x = spconv.SparseConvTensor(T(f, dev), T(ind, dev), CONV_BWD_SHAPE, CONV_BWD_BATCH)
+        mid = down(x)
+        o = _canon(mid.indices.cpu().numpy())
+        fo = np.empty((len(o), 20), np.float32)
+        fo[o] = detgen.randn("inv_f", (len(o), 20))[g["order"]]
+        y = up(mid.replace_feature(T(fo, dev)))
+    assert torch.equal(y.indices, x.indices) and y.spatial_shape == CONV_BWD_SHAPE
+    assert np.abs(y.features.cpu().numpy() - g["inv"]).max() <= 2e-5 * np.abs(g["inv"]).max()
+    with pytest.raises(Exception):
+        spconv.SparseInverseConv3d(20, 12, 3, indice_key="missing", bias=False).to(dev)(mid)
+    # training path: gradients flow through both convolutions
+    xg = spconv.SparseConvTensor(T(f, dev).requires_grad_(True), T(ind, dev), CONV_BWD_SHAPE, CONV_BWD_BATCH)
+    up(down(xg)).features.square().sum().backward()
+    assert xg.features.grad.abs().sum() > 0 and up.weight.grad.abs().sum() > 0 and down.weight.grad.abs().sum() > 0
+
+
+def test_dynamic_voxelize_golden_and_oracle(golden, dev):
+    from dualfusion import ops, synth, voxel
+    from make_golden import POOL_RANGE, POOL_VS, pool_points
+    g = golden("pool.npz")
+    pts = pool_points()
+    got = voxel.voxelization(T(pts, dev), POOL_VS, POOL_RANGE, -1, 20000)
+    assert got.dtype == torch.int32 and np.array_equal(got.cpu().numpy(), g["dyn"])
+    sweep = synth.nusc_sweep(seed=1)
+    sweep[:5, 0] = [np.nan, np.inf, -np.inf, 53.999996, -54.0]
+    want = orc.dynamic_voxelize(sweep, synth.NUSC_VOXEL, synth.NUSC_RANGE)
+    got = ops.dynamic_voxelize(T(sweep, dev), synth.NUSC_VOXEL, synth.NUSC_RANGE).cpu().numpy()
+    assert np.array_equal(got, want) and (got[:3] == -1).all()
+    assert ops.dynamic_voxelize(torch.zeros((0, 4), device=dev), POOL_VS, POOL_RANGE).shape == (0, 3)

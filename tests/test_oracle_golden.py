@@ -359,3 +359,54 @@ def test_conv_backward_oracle_vs_ref_build(subm):
     for x, y in zip(a, b):
         assert x.shape == y.shape
         np.testing.assert_allclose(x, y, rtol=1e-4, atol=2e-4)
+
+
+# ---- sparse max pool, inverse convolution, dynamic voxelisation (boundary rows of SURVEY section 8b)
+def _pool_case():
+    from make_golden import CONV_BWD_BATCH, CONV_BWD_SHAPE, conv_bwd_case
+    ind, ks, st, pd, f, w = conv_bwd_case(0)
+    outids, pairs, num, _ = orc.get_indice_pairs(ind, CONV_BWD_BATCH, CONV_BWD_SHAPE, ks, st, pd, [1, 1, 1], 0)
+    return ind, f, outids, pairs, num
+
+
+def test_maxpool_inverse_conv_dynamic_voxelize_oracle_vs_reference_golden(golden):
+    """Outputs of the reference's compiled CPU code (oracle/_ref when the fixture was made).  The oracle's rulebook
+    emits the out-voxels in the reference CPU path's order for this geometry (pinned by the rulebook fixtures), the
+    fixture also stores the canonical order."""
+    from make_golden import POOL_RANGE, POOL_VS, pool_points
+    g = golden("pool.npz")
+    ind, f, outids, pairs, num = _pool_case()
+    order = np.lexsort(outids.T[::-1])
+    assert np.array_equal(outids[order], g["outids"])
+    y = orc.indice_maxpool(f, pairs, num, len(outids))
+    assert np.array_equal(y[order], g["y"][g["order"]])
+    assert (y >= 0).all() and (y == 0).any()                      # zero-initialised output: negatives never survive
+    go = np.empty_like(y)
+    go[order] = detgen.randn("pool_g", y.shape)[g["order"]]      # the same gradient per out-voxel
+    assert np.array_equal(orc.indice_maxpool_backward(f, y, go, pairs, num), g["gin"])
+    fq = np.round(f * 2) / 2
+    yq = orc.indice_maxpool(fq, pairs, num, len(outids))
+    assert np.array_equal(yq[order], g["yq"][g["order"]])
+    ginq = orc.indice_maxpool_backward(fq, yq, go, pairs, num)
+    assert np.array_equal(ginq, g["ginq"]) and (np.abs(ginq) > 0).sum() > (np.abs(g["gin"]) > 0).sum()   # ties fan out
+    fo = np.empty((len(outids), 20), np.float32)
+    fo[order] = detgen.randn("inv_f", (len(outids), 20))[g["order"]]
+    wi = detgen.randn("inv_w", (3, 3, 3, 20, 12), 0.2)
+    inv = orc.indice_conv(fo, wi, pairs, num, len(ind), 0, inverse=True)
+    assert inv.shape == g["inv"].shape and np.abs(inv - g["inv"]).max() <= 2e-5 * np.abs(g["inv"]).max()
+    dyn = orc.dynamic_voxelize(pool_points(), POOL_VS, POOL_RANGE)
+    assert np.array_equal(dyn, g["dyn"]) and (dyn[:, 0] == -1).sum() > 100 and (dyn[:, 0] >= 0).sum() > 1000
+
+
+@needs_ref
+def test_maxpool_dynamic_voxelize_oracle_vs_ref_build_fresh():
+    ind = detgen.clustered_voxels("pool_fresh", 2, [9, 18, 16], n_seeds=5, walk=150)
+    outids, pairs, num, _ = ref.get_indice_pairs(ind, 2, [9, 18, 16], [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], 0)
+    f = np.round(detgen.randn("pool_fresh_f", (len(ind), 8)) * 4) / 4
+    y = ref.indice_maxpool(f, pairs, num, len(outids))
+    assert np.array_equal(orc.indice_maxpool(f, pairs, num, len(outids)), y)
+    go = detgen.randn("pool_fresh_g", y.shape)
+    assert np.array_equal(orc.indice_maxpool_backward(f, y, go, pairs, num), ref.indice_maxpool_backward(f, y, go, pairs, num))
+    pts = detgen.rand("dyn_fresh", (3000, 5), -60.0, 60.0)
+    rng, vs = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], [0.075, 0.075, 0.2]
+    assert np.array_equal(orc.dynamic_voxelize(pts, vs, rng), ref.dynamic_voxelize(pts, vs, rng))
