@@ -404,10 +404,27 @@ class TransFusionHead(nn.Module):
                 b2.append(fc[1].bias.detach().float())
                 layout.append((head, c0, fc[1].out_channels))
                 c0 += fc[1].out_channels
-            plan["layers"].append(dict(wq=w[:E].contiguous(), bq=b[:E].contiguous(), wkv_t=w[E:].t().contiguous(),
-                                       bkv=b[E:].contiguous(), w1=torch.cat(w1).contiguous(), b1=torch.cat(b1).contiguous(),
-                                       w2=torch.block_diag(*blocks).contiguous(), b2=torch.cat(b2).contiguous(),
-                                       layout=layout))
+            L = dict(wq=w[:E].contiguous(), bq=b[:E].contiguous(), wkv_t=w[E:].t().contiguous(),
+                     bkv=b[E:].contiguous(), w1=torch.cat(w1).contiguous(), b1=torch.cat(b1).contiguous(),
+                     w2=torch.block_diag(*blocks).contiguous(), b2=torch.cat(b2).contiguous(), layout=layout)
+            # row form of the layer's small operators (200 x 128 activations): transposed weights for addmm, the
+            # query position embedding's BatchNorm folded into its first 1x1 convolution
+            t = lambda m: m.detach().float().t().contiguous()
+            v = lambda m: m.detach().float().contiguous()
+            pe = dec.self_posembed.position_embedding_head
+            a, sft = self._fold(pe[1])
+            sa = getattr(dec, "self_attn", None)
+            L.update(wq_t=t(w[:E]), pe_w1t=(pe[0].weight.detach().float().reshape(E, -1) * a[:, None]).t().contiguous(),
+                     pe_b1=(pe[0].bias.detach().float() * a + sft).contiguous(),
+                     pe_w2t=t(pe[3].weight.reshape(pe[3].out_channels, -1)), pe_b2=v(pe[3].bias),
+                     sa_wt=t(sa.in_proj_weight) if sa is not None else None,
+                     sa_b=v(sa.in_proj_bias) if sa is not None else None,
+                     sa_owt=t(sa.out_proj.weight) if sa is not None else None,
+                     sa_ob=v(sa.out_proj.bias) if sa is not None else None,
+                     ca_owt=t(dec.multihead_attn.out_proj.weight), ca_ob=v(dec.multihead_attn.out_proj.bias),
+                     l1_wt=t(dec.linear1.weight), l1_b=v(dec.linear1.bias), l2_wt=t(dec.linear2.weight),
+                     l2_b=v(dec.linear2.bias))
+            plan["layers"].append(L)
         self.__dict__["_row_plan"] = plan
         return plan
 
@@ -418,6 +435,29 @@ class TransFusionHead(nn.Module):
             kpe = self.decoder[i].cross_posembed(self.bev_pos.to(dev))[0].t()               # [HW, E]
             plan["kv_const"][(i, B)] = torch.addmm(L["bkv"], kpe, L["wkv_t"]).repeat(B, 1).contiguous()
         return plan["kv_const"][(i, B)]
+
+    def _decoder_rows(self, dec, L, q, qpos, kv, B):
+        """TransformerDecoderLayer.forward (transfusion_head.py:82-122) in eval mode on [B*K, E] rows: the same
+        operators as `TransformerDecoderLayer.finish`, with fused-bias GEMMs, one add + LayerNorm launch per residual
+        and both attentions through df3d_cross_attention."""
+        E, mha = q.shape[1], dec.multihead_attn
+        if mha.head_dim != 16 or E != mha.embed_dim:
+            K = q.shape[0] // B
+            qpe = dec.self_posembed(qpos.view(B, K, 2)).transpose(1, 2)
+            kv3 = kv.view(B, -1, 2 * E)
+            return dec.finish(q.view(B, K, E), qpe, lambda qq: mha.attend(F.linear(qq, L["wq"], L["bq"]), kv3[..., :E],
+                                                                          kv3[..., E:])).reshape(B * K, E)
+        scale = mha.head_dim ** -0.5
+        qpe = torch.addmm(L["pe_b2"], torch.relu_(torch.addmm(L["pe_b1"], qpos, L["pe_w1t"])), L["pe_w2t"])
+        if not dec.cross_only:
+            qkv = torch.addmm(L["sa_b"], q + qpe, L["sa_wt"])                              # [B*K, 3E]
+            o = _ops.cross_attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, mha.num_heads, scale)
+            q = _ops.add_layernorm(q, torch.addmm(L["sa_ob"], o, L["sa_owt"]), dec.norm1.weight, dec.norm1.bias, dec.norm1.eps)
+        qp = torch.addmm(L["bq"], q + qpe, L["wq_t"])
+        o = _ops.cross_attention(qp, kv[:, :E], kv[:, E:], B, mha.num_heads, scale)
+        q = _ops.add_layernorm(q, torch.addmm(L["ca_ob"], o, L["ca_owt"]), dec.norm2.weight, dec.norm2.bias, dec.norm2.eps)
+        f = torch.addmm(L["l2_b"], dec.activation(torch.addmm(L["l1_b"], q, L["l1_wt"])), L["l2_wt"])
+        return _ops.add_layernorm(q, f, dec.norm3.weight, dec.norm3.bias, dec.norm3.eps)
 
     @torch.no_grad()
     def forward_rows(self, x):
@@ -445,18 +485,8 @@ class TransFusionHead(nn.Module):
         ret_dicts = []
         for i in range(self.num_decoder_layers):
             dec, L = self.decoder[i], plan["layers"][i]
-            qpe = dec.self_posembed(query_pos).transpose(1, 2)                              # [B, K, E]
-            kv = torch.addmm(self._kv_const(plan, i, B, dev), feat, L["wkv_t"]).view(B, H * W, 2 * E)
-
-            def cross(qq, dec=dec, L=L, kv=kv):
-                mha = dec.multihead_attn
-                qp = F.linear(qq, L["wq"], L["bq"])
-                if mha.head_dim != 16:
-                    return mha.attend(qp, kv[..., :E], kv[..., E:])
-                kvr = kv.view(B * H * W, 2 * E)
-                o = _ops.cross_attention(qp.view(B * K, E), kvr[:, :E], kvr[:, E:], B, mha.num_heads, mha.head_dim ** -0.5)
-                return mha.out_proj(o.view(B, K, E))
-            qf = dec.finish(qf, qpe, cross)
+            kv = torch.addmm(self._kv_const(plan, i, B, dev), feat, L["wkv_t"])             # [B*H*W, 2E]
+            qf = self._decoder_rows(dec, L, qf.reshape(B * K, E), query_pos.reshape(B * K, 2), kv, B).view(B, K, E)
             out = torch.addmm(L["b2"], torch.relu_(torch.addmm(L["b1"], qf.reshape(B * K, E), L["w1"].t())), L["w2"].t())
             out = out.view(B, K, -1)
             res = {}
