@@ -8,7 +8,8 @@
 //   xattn_partial   grid (key chunks, heads, samples x query blocks); a wave owns up to 4 tiles of 16 queries (Q in
 //                   registers) and walks the chunk in tiles of 16 keys:  S^T = K.Q^T (4 x v_mfma_f32_16x16x4_f32, the
 //                   head dimension 16 is the contraction), running maximum per query (two cross-lane steps: with the
-//                   transposed scores a lane holds 4 keys of ONE query), P^T = exp2(S^T - m), O^T += V^T.P^T (4 MFMA).
+//                   transposed scores a lane holds 4 keys of ONE query), P^T = exp2(S^T - m), O^T += V^T.P^T (4 MFMA);
+//                   two key tiles share one softmax step (one max / rescale per 32 keys).
 //                   K / V rows are read once per wave straight from the [pixels, 2E] projection rows (64 B per head).
 //                   Writes (m, l, O) per (chunk, query).
 //   xattn_combine   log-sum-exp merge of the chunks.
@@ -71,41 +72,61 @@ __device__ __forceinline__ void xattn_wave(const XAttnArgs &a, int b, int h, int
     ls[t] = 0.f;
   }
   const float *kb = a.k + (size_t)b * a.nk * a.ld_k + h * 16, *vb = a.v + (size_t)b * a.nk * a.ld_v + h * 16;
-  KVTile cur = load_kv(kb, vb, a.ld_k, a.ld_v, t0, a.nk, j, g);
-  for (int kt = t0; kt < t1; ++kt) {
-    const KVTile nxt = load_kv(kb, vb, a.ld_k, a.ld_v, min(kt + 1, t1 - 1), a.nk, j, g);     // in flight during the MFMAs
-    const float kc[4] = {cur.kf.x, cur.kf.y, cur.kf.z, cur.kf.w};
-    f32x4 s[NT];
+  // two key tiles (32 keys) per softmax step: one running-max update, one rescale and two cross-lane steps per 32 keys
+  KVTile c0 = load_kv(kb, vb, a.ld_k, a.ld_v, t0, a.nk, j, g);
+  KVTile c1 = load_kv(kb, vb, a.ld_k, a.ld_v, min(t0 + 1, t1 - 1), a.nk, j, g);
+  for (int kt = t0; kt < t1; kt += 2) {
+    const KVTile n0 = load_kv(kb, vb, a.ld_k, a.ld_v, min(kt + 2, t1 - 1), a.nk, j, g);      // in flight during the MFMAs
+    const KVTile n1 = load_kv(kb, vb, a.ld_k, a.ld_v, min(kt + 3, t1 - 1), a.nk, j, g);
+    const bool two = kt + 1 < t1;                               // wave-uniform: the second tile exists
+    const bool full = two && (kt + 2) * 16 <= a.nk;             // no key of the pair is beyond nk
+    const float k0[4] = {c0.kf.x, c0.kf.y, c0.kf.z, c0.kf.w}, k1[4] = {c1.kf.x, c1.kf.y, c1.kf.z, c1.kf.w};
+    f32x4 s0[NT], s1[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) s0[t] = s1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[c], qf[t][c], s[t], 0, 0, 0);
-    // lane (query j of tile t, keys 4g + r)
+      for (int t = 0; t < NT; ++t) {
+        s0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[c], qf[t][c], s0[t], 0, 0, 0);
+        s1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[c], qf[t][c], s1[t], 0, 0, 0);
+      }
+    // lane (query j of tile t, keys 4g + r of either key tile)
     const int key0 = kt * 16 + 4 * g;
-    float p[NT][4];
+    float p0[NT][4], p1[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      if (!full) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (key0 + r >= a.nk) s[t][r] = -INFINITY;
-      float mx = fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3]));
+        for (int r = 0; r < 4; ++r) {
+          if (key0 + r >= a.nk) s0[t][r] = -INFINITY;
+          if (!two || key0 + 16 + r >= a.nk) s1[t][r] = -INFINITY;
+        }
+      }
+      float mx = fmaxf(fmaxf(fmaxf(s0[t][0], s0[t][1]), fmaxf(s0[t][2], s0[t][3])),
+                       fmaxf(fmaxf(s1[t][0], s1[t][1]), fmaxf(s1[t][2], s1[t][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mnew = fmaxf(m[t], mx);                       // finite: key 0 of every tile exists
+      const float mnew = fmaxf(m[t], mx);                       // finite: key 0 of the first tile exists
       const float alpha = __builtin_amdgcn_exp2f(m[t] - mnew);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mnew);
-      ls[t] = ls[t] * alpha + ((p[t][0] + p[t][1]) + (p[t][2] + p[t][3]));
+      for (int r = 0; r < 4; ++r) {
+        p0[t][r] = __builtin_amdgcn_exp2f(s0[t][r] - mnew);
+        p1[t][r] = __builtin_amdgcn_exp2f(s1[t][r] - mnew);
+      }
+      ls[t] = ls[t] * alpha + (((p0[t][0] + p0[t][1]) + (p0[t][2] + p0[t][3])) + ((p1[t][0] + p1[t][1]) + (p1[t][2] + p1[t][3])));
       o[t] *= alpha;
       m[t] = mnew;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {                               // consecutive MFMAs hit different accumulators
 #pragma unroll
-      for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.vf[r], p[t][r], o[t], 0, 0, 0);
-    cur = nxt;
+      for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.vf[r], p0[t][r], o[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.vf[r], p1[t][r], o[t], 0, 0, 0);
+    }
+    c0 = n0;
+    c1 = n1;
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
