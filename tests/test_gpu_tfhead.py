@@ -39,7 +39,9 @@ def test_forward_and_boxes_equal_reference_golden(golden):
         res = head([x], None, [{}])
         dets = head.get_bboxes(res)
     torch.cuda.synchronize()
-    assert sorted((r["cin"], r["cout"]) for r in kt.stop()) == [(128, 32), (128, 128), (512, 128)]   # row kernels, not torch convs
+    recs = sorted((r["cin"], r["cout"]) for r in kt.stop())
+    if ops.CONV_PRECISION == "split":                       # (DF3D_CONV_PRECISION=fp32 / bf16 select the module's torch path)
+        assert recs == [(128, 32), (128, 128), (512, 128)]   # row kernels, not torch convs
     assert head.query_labels.cpu().numpy().tolist() == g["query_labels"].tolist()
     for name in NAMES:
         _close(res[0][0][name].cpu().numpy(), g["pred_" + name], 1e-3, name)
