@@ -2,8 +2,8 @@
 constructor arguments and parameter names (CP/det3d/models/bbox_heads/center_head.py:66-110,165-243), and
 `predict` = the reference's decode + per-sample post-processing (center_head.py:302-501) as ONE device call
 (`df3d_centerhead_predict`: keys -> radix sort -> gather -> NMS bit matrix -> on-device greedy reduction -> select)
-instead of ~30 launches and three host round trips per (task, sample).  Forward-only: `loss` is a training row
-(SURVEY.md section 8f row 4)."""
+instead of ~30 launches and three host round trips per (task, sample).  `loss` (center_head.py:250-298) is the
+reference's torch composition (training row)."""
 import copy
 
 import torch
@@ -11,6 +11,41 @@ from torch import nn
 
 from . import ops as _ops
 from .registry import HEADS
+
+
+def _clamped_sigmoid(x):
+    """center_head.py:246-248."""
+    return torch.clamp(x.sigmoid_(), min=1e-4, max=1 - 1e-4)
+
+
+def _transpose_and_gather_feat(feat, ind):
+    """CP/det3d/core/utils/center_utils.py: [B, C, H, W] -> rows at the flat pixel indices ind [B, M] -> [B, M, C]."""
+    feat = feat.permute(0, 2, 3, 1).contiguous()
+    feat = feat.view(feat.size(0), -1, feat.size(3))
+    return feat.gather(1, ind.unsqueeze(2).expand(ind.size(0), ind.size(1), feat.size(2)))
+
+
+def reg_loss(output, mask, ind, target):
+    """RegLoss (CP/det3d/models/losses/centernet_loss.py:6-27) -> one value per box code."""
+    pred = _transpose_and_gather_feat(output, ind)
+    mask = mask.float().unsqueeze(2)
+    loss = torch.nn.functional.l1_loss(pred * mask, target * mask, reduction='none')
+    loss = loss / (mask.sum() + 1e-4)
+    return loss.transpose(2, 0).sum(dim=2).sum(dim=1)
+
+
+def fast_focal_loss(out, target, ind, mask, cat):
+    """FastFocalLoss (centernet_loss.py:29-58)."""
+    mask = mask.float()
+    gt = torch.pow(1 - target, 4)
+    neg_loss = (torch.log(1 - out) * torch.pow(out, 2) * gt).sum()
+    pos_pred_pix = _transpose_and_gather_feat(out, ind)
+    pos_pred = pos_pred_pix.gather(2, cat.unsqueeze(2))
+    num_pos = mask.sum()
+    pos_loss = (torch.log(pos_pred) * torch.pow(1 - pos_pred, 2) * mask.unsqueeze(2)).sum()
+    if num_pos == 0:
+        return -neg_loss
+    return -(pos_loss + neg_loss) / num_pos
 
 
 class SepHead(nn.Module):
@@ -171,7 +206,43 @@ class CenterHead(nn.Module):
         return rets
 
     def loss(self, example, preds_dicts, batch_dict=None, **kwargs):
-        raise NotImplementedError("training rows are out of this build's scope (SURVEY.md section 8f row 4)")
+        """center_head.py:250-298: per task the CornerNet focal loss on the clamped sigmoid heat map
+        (losses/centernet_loss.py:29-58) + `weight` x the code-weighted L1 loss of the gathered box regressions
+        (:6-27); plain torch (autograd), the targets `hm / ind / mask / cat / anno_box` come with `example` exactly as
+        the reference's assigner provides them.  Like the reference it replaces preds_dict['hm'] by its sigmoid in
+        place and returns {key: [per-task values]}."""
+        from collections import defaultdict
+        rets = []
+        for task_id, preds_dict in enumerate(preds_dicts):
+            preds_dict['hm'] = _clamped_sigmoid(preds_dict['hm'])
+            hm_loss = fast_focal_loss(preds_dict['hm'], example['hm'][task_id], example['ind'][task_id],
+                                      example['mask'][task_id], example['cat'][task_id])
+            target_box = example['anno_box'][task_id]
+            if self.dataset not in ('waymo', 'nuscenes'):
+                raise NotImplementedError()
+            if 'vel' in preds_dict:
+                preds_dict['anno_box'] = torch.cat((preds_dict['reg'], preds_dict['height'], preds_dict['dim'],
+                                                    preds_dict['vel'], preds_dict['rot']), dim=1)
+            else:
+                preds_dict['anno_box'] = torch.cat((preds_dict['reg'], preds_dict['height'], preds_dict['dim'],
+                                                    preds_dict['rot']), dim=1)
+                target_box = target_box[..., [0, 1, 2, 3, 4, 5, -2, -1]]
+            box_loss = reg_loss(preds_dict['anno_box'], example['mask'][task_id], example['ind'][task_id], target_box)
+            loc_loss = (box_loss * box_loss.new_tensor(self.code_weights)).sum()
+            loss = hm_loss + self.weight * loc_loss
+            ret = {}
+            if batch_dict is not None and "auxseg_loss" in batch_dict:
+                auxseg_loss = sum(a[task_id] for a in batch_dict['auxseg_loss'])
+                ret['auxseg_loss'] = auxseg_loss
+                loss = loss + auxseg_loss
+            ret.update({'loss': loss, 'hm_loss': hm_loss.detach().cpu(), 'loc_loss': loc_loss,
+                        'loc_loss_elem': box_loss.detach().cpu(), 'num_positive': example['mask'][task_id].float().sum()})
+            rets.append(ret)
+        merged = defaultdict(list)
+        for ret in rets:
+            for k, v in ret.items():
+                merged[k].append(v)
+        return merged
 
     # ------------------------------------------------------------------ decode + NMS on the device
     @staticmethod

@@ -793,6 +793,57 @@ def gen_transfusion_head():
     save("transfusion_head.npz", **out)
 
 
+def head_loss_example():
+    """Assigner outputs for CenterHead.loss on the golden map (HEAD_SHAPE): per task a heat-map target with a few unit
+    peaks, flat pixel indices, mask, category id and box codes of M = 6 object slots."""
+    B, _, H, W = HEAD_SHAPE
+    M, ex = 6, dict(hm=[], ind=[], mask=[], cat=[], anno_box=[])
+    for t, task in enumerate(HEAD_TASKS):
+        nc = task["num_class"]
+        rs = np.random.RandomState(100 + t)
+        hm = (rs.uniform(0, 1, size=(B, nc, H, W)) ** 6).astype(np.float32)
+        ind = rs.randint(0, H * W, size=(B, M)).astype(np.int64)
+        mask = (rs.uniform(size=(B, M)) < 0.7).astype(np.uint8)
+        mask[0, 0] = 1
+        cat = rs.randint(0, nc, size=(B, M)).astype(np.int64)
+        for b in range(B):
+            for m in range(M):
+                if mask[b, m]:
+                    hm[b, cat[b, m], ind[b, m] // W, ind[b, m] % W] = 1.0
+        ex["hm"].append(hm), ex["ind"].append(ind), ex["mask"].append(mask), ex["cat"].append(cat)
+        ex["anno_box"].append(rs.normal(size=(B, M, 10)).astype(np.float32))
+    return ex
+
+
+def gen_centerhead_loss():
+    """Reference CenterHead.forward (train mode) + loss (center_head.py:237-298) and the gradient it sends back."""
+    ch, _ = import_reference_centerhead()
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        head = ch.CenterHead(in_channels=512, tasks=HEAD_TASKS, dataset='nuscenes', weight=0.25,
+                             code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 1.0, 1.0], common_heads=dict(HEAD_COMMON),
+                             share_conv_channel=64, dcn_head=False)
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    sd = head_bias_shift(detgen.det_state_dict(shapes))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    head.eval()                                               # running BN statistics: the forward is deterministic
+    x = torch.from_numpy(detgen.randn("head_loss_x", HEAD_SHAPE)).requires_grad_(True)
+    ex = {k: [torch.from_numpy(a) for a in v] for k, v in head_loss_example().items()}
+    rets = head.loss(ex, head(x), {})
+    total = sum(rets["loss"])
+    total.backward()
+    out = dict(loss=np.array([v.item() for v in rets["loss"]]), hm_loss=np.array([v.item() for v in rets["hm_loss"]]),
+               loc_loss=np.array([v.item() for v in rets["loc_loss"]]),
+               loc_loss_elem=np.stack([v.numpy() for v in rets["loc_loss_elem"]]),
+               num_positive=np.array([v.item() for v in rets["num_positive"]]),
+               gx=np.array([x.grad.sum(dtype=torch.float64).item(), x.grad.abs().sum(dtype=torch.float64).item()]),
+               gw=np.array([head.shared_conv[0].weight.grad.abs().sum(dtype=torch.float64).item(),
+                            head.tasks[1].hm[3].bias.grad.abs().sum(dtype=torch.float64).item()]))
+    print({k: v.tolist() if v.size < 8 else v.shape for k, v in out.items()})
+    save("centerhead_loss.npz", **out)
+
+
 CONV_BWD_SHAPE, CONV_BWD_BATCH = [7, 20, 22], 2
 
 
@@ -873,7 +924,7 @@ def gen_iou3d():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "conv_bwd", "pool"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "headloss", "conv_bwd", "pool"]
     if "iou3d" in which:
         gen_iou3d()
     if "conv_bwd" in which:
@@ -884,6 +935,8 @@ if __name__ == "__main__":
         gen_centerhead()
     if "tfhead" in which:
         gen_transfusion_head()
+    if "headloss" in which:
+        gen_centerhead_loss()
     if "voxelize" in which:
         gen_voxelize()
     if "rulebook" in which:

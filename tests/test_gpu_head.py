@@ -183,3 +183,27 @@ def test_forward_rows_vs_torch_cpu_and_end_to_end():
         assert k > 50
         same = np.isclose(a["box3d_lidar"][:k].cpu().numpy(), b["box3d_lidar"][:k].cpu().numpy(), rtol=1e-3, atol=1e-3).all(1)
         assert same.mean() > 0.9
+
+
+def test_loss_on_device_equals_cpu():
+    """CenterHead forward (training path: autograd through the torch modules) + loss + backward on the MI355X against the
+    same computation on the CPU (which tests/test_oracle_golden.py pins to the reference's own loss)."""
+    from dualfusion.heads import CenterHead
+    from make_golden import HEAD_COMMON, HEAD_SHAPE, HEAD_TASKS, head_bias_shift, head_loss_example
+
+    def run(dev):
+        head = CenterHead(in_channels=512, tasks=HEAD_TASKS, dataset='nuscenes', weight=0.25,
+                          code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 1.0, 1.0], common_heads=dict(HEAD_COMMON),
+                          share_conv_channel=64, dcn_head=False)
+        shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+        head.load_state_dict({k: torch.from_numpy(v) for k, v in head_bias_shift(detgen.det_state_dict(shapes)).items()})
+        head = head.to(dev).eval()
+        x = torch.from_numpy(detgen.randn("head_loss_x", HEAD_SHAPE)).to(dev).requires_grad_(True)
+        ex = {k: [torch.from_numpy(a).to(dev) for a in v] for k, v in head_loss_example().items()}
+        rets = head.loss(ex, head(x), {})
+        sum(rets["loss"]).backward()
+        return [v.item() for v in rets["loss"]], x.grad.cpu().numpy(), head.shared_conv[0].weight.grad.cpu().numpy()
+    lg, xg, wg = run(DEV)
+    lc, xc, wc = run("cpu")
+    np.testing.assert_allclose(lg, lc, rtol=1e-4)
+    assert np.abs(xg - xc).max() <= 1e-3 * np.abs(xc).max() and np.abs(wg - wc).max() <= 1e-3 * np.abs(wc).max()

@@ -410,3 +410,30 @@ def test_maxpool_dynamic_voxelize_oracle_vs_ref_build_fresh():
     pts = detgen.rand("dyn_fresh", (3000, 5), -60.0, 60.0)
     rng, vs = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], [0.075, 0.075, 0.2]
     assert np.array_equal(orc.dynamic_voxelize(pts, vs, rng), ref.dynamic_voxelize(pts, vs, rng))
+
+
+def test_centerhead_loss_vs_reference_golden(golden):
+    """CenterHead.loss (focal heat-map loss + code-weighted L1 box loss) and its gradient against the reference's own
+    `loss` on the same weights, input and assigner outputs (center_head.py:250-298, losses/centernet_loss.py)."""
+    import torch
+    from dualfusion.heads import CenterHead
+    from make_golden import HEAD_COMMON, HEAD_SHAPE, HEAD_TASKS, head_bias_shift, head_loss_example
+    g = golden("centerhead_loss.npz")
+    head = CenterHead(in_channels=512, tasks=HEAD_TASKS, dataset='nuscenes', weight=0.25,
+                      code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 1.0, 1.0], common_heads=dict(HEAD_COMMON),
+                      share_conv_channel=64, dcn_head=False)
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in head_bias_shift(detgen.det_state_dict(shapes)).items()})
+    head.eval()
+    x = torch.from_numpy(detgen.randn("head_loss_x", HEAD_SHAPE)).requires_grad_(True)
+    ex = {k: [torch.from_numpy(a) for a in v] for k, v in head_loss_example().items()}
+    rets = head.loss(ex, head(x), {})
+    sum(rets["loss"]).backward()
+    for key in ("loss", "hm_loss", "loc_loss", "num_positive"):
+        np.testing.assert_allclose([v.item() for v in rets[key]], g[key], rtol=2e-5)
+    np.testing.assert_allclose(np.stack([v.numpy() for v in rets["loc_loss_elem"]]), g["loc_loss_elem"], rtol=2e-5, atol=1e-6)
+    gx = [x.grad.sum(dtype=torch.float64).item(), x.grad.abs().sum(dtype=torch.float64).item()]
+    np.testing.assert_allclose(gx, g["gx"], rtol=1e-4)
+    gw = [head.shared_conv[0].weight.grad.abs().sum(dtype=torch.float64).item(),
+          head.tasks[1].hm[3].bias.grad.abs().sum(dtype=torch.float64).item()]
+    np.testing.assert_allclose(gw, g["gw"], rtol=1e-4)
