@@ -59,8 +59,8 @@ def test_centerhead_layout_and_cpu_forward():
     assert tuple(preds[1]["hm"].shape) == (1, 2, 6, 7)
     with pytest.raises(NotImplementedError):
         CenterHead(in_channels=512, tasks=TASKS, common_heads=dict(COMMON), dcn_head=True)
-    with pytest.raises(NotImplementedError):
-        h.loss({}, preds)
+    with pytest.raises(KeyError):                                   # loss needs the assigner's targets in `example`
+        h.loss({}, [dict(p) for p in preds])
     # the decode / NMS tail is device-only: CPU maps are refused, nothing falls back
     cfg = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.1, pc_range=[-54, -54],
                out_size_factor=8, voxel_size=[0.075, 0.075],
