@@ -163,6 +163,32 @@ elif which == "train":
         ms_inf = timeit(lambda: hp.backbone(feats, coors, 1, hp.grid_size_xyz))
     print("train SpMiddleResNetFHD, 1 sweep (%d voxels): forward (train mode, unfused BN) %.2f ms, forward + backward %.2f ms "
           "| inference forward %.2f ms" % (feats.shape[0], ms_f, ms, ms_inf))
+    # whole CenterPoint detector: backbone -> RPN neck -> CenterHead -> loss -> backward (targets as the assigner gives them)
+    from dualfusion.heads import CenterHead
+    from dualfusion.necks import RPN
+    TASKS = [dict(num_class=1, class_names=["car"]), dict(num_class=2, class_names=["truck", "construction_vehicle"]),
+             dict(num_class=2, class_names=["bus", "trailer"]), dict(num_class=1, class_names=["barrier"]),
+             dict(num_class=2, class_names=["motorcycle", "bicycle"]), dict(num_class=2, class_names=["pedestrian", "traffic_cone"])]
+    neck = RPN([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256).to(dev).train()
+    head = CenterHead(in_channels=512, tasks=TASKS, weight=0.25, code_weights=[1.0] * 8 + [0.2, 0.2],
+                      common_heads={'reg': (2, 2), 'height': (1, 2), 'dim': (3, 2), 'rot': (2, 2), 'vel': (2, 2)},
+                      share_conv_channel=64).to(dev).train()
+    M, HW = 500, 180 * 180
+    ex = dict(hm=[torch.rand(1, t["num_class"], 180, 180, device=dev) ** 8 for t in TASKS],
+              ind=[torch.randint(0, HW, (1, M), device=dev) for _ in TASKS],
+              mask=[(torch.rand(1, M, device=dev) < 0.1).to(torch.uint8) for _ in TASKS],
+              cat=[torch.randint(0, t["num_class"], (1, M), device=dev) for t in TASKS],
+              anno_box=[torch.randn(1, M, 10, device=dev) for _ in TASKS])
+    hp.backbone.train()
+    all_params = params + [p for m in (neck, head) for p in m.parameters()]
+
+    def det_step():
+        for p in all_params:
+            p.grad = None
+        rets = head.loss(ex, head(neck(fwd())), {})
+        sum(rets["loss"]).backward()
+    ms_det = timeit(det_step)
+    print("train CenterPoint detector, 1 sweep: backbone + RPN neck + CenterHead + loss, forward + backward %.2f ms" % ms_det)
 elif which == "head":
     from dualfusion.heads import CenterHead
     from dualfusion.necks import RPN
