@@ -156,8 +156,11 @@ class SparseConvolution(SparseModule):
         res_sct = residual if isinstance(residual, SparseConvTensor) else None
         if res_sct is not None:
             residual = res_sct.features.contiguous()
+        if self.ndim == 2:
+            # SparseConv2d / SubMConv2d: the same kernels on a one-slice volume, kernel (1, kh, kw)
+            return SparseConvolution.forward_fused(self._twin3d(), input.lift3d(), scale, shift, relu, residual).drop_z()
         if self.ndim != 3:
-            raise Df3dError("only SparseConv3d/SubMConv3d are implemented on the MI355X path")
+            raise Df3dError("only 2-D and 3-D sparse convolutions are implemented on the MI355X path")
         if self.conv1x1:
             feats = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
             if self.bias is not None:
@@ -227,6 +230,20 @@ class SparseConvolution(SparseModule):
         if out_split is not None:
             out._split = (out_features, out_split)
         return out
+
+    def _twin3d(self):
+        """This 2-D module as a 3-D one (kernel (1, kh, kw), ...) sharing its parameters."""
+        twin = self.__dict__.get("_twin")
+        if twin is None:
+            import copy
+            twin = copy.copy(self)
+            twin.__dict__.pop("_twin", None)
+            twin.ndim = 3
+            twin.kernel_size, twin.stride = [1] + list(self.kernel_size), [1] + list(self.stride)
+            twin.padding, twin.dilation = [0] + list(self.padding), [1] + list(self.dilation)
+            twin.output_padding = [0] + list(self.output_padding) if isinstance(self.output_padding, (list, tuple)) else self.output_padding
+            self.__dict__["_twin"] = twin
+        return twin
 
     def _packed_weight_bf16(self, w, K):
         key = (w.data_ptr(), w._version, str(w.device))

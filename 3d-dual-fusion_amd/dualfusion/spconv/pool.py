@@ -35,8 +35,14 @@ class SparseMaxPool(SparseModule):
 
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
+        if self.ndim == 2:                                  # one-slice volume, kernel (1, kh, kw)
+            twin = self.__dict__.get("_twin")
+            if twin is None:
+                twin = self.__dict__["_twin"] = SparseMaxPool(3, [1] + self.kernel_size, [1] + self.stride,
+                                                              [0] + self.padding, [1] + self.dilation, self.subm)
+            return twin(input.lift3d()).drop_z()
         if self.ndim != 3:
-            raise Df3dError("only SparseMaxPool3d is implemented on the MI355X path")
+            raise Df3dError("only 2-D and 3-D sparse max pooling is implemented on the MI355X path")
         feats = input.features
         if feats.dtype != torch.float32:
             raise Df3dError("SparseMaxPool: fp32 only (got %s)" % feats.dtype)

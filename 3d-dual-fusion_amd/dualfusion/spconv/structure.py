@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 from .. import ops as _ops
+from .._lib import Df3dError
 
 
 def scatter_nd(indices, updates, shape):
@@ -107,6 +108,31 @@ class SparseConvTensor(object):
             self._bf16 = hit
         return hit[1]
 
+    # ---- 2-D tensors run on the 3-D kernels as a one-slice volume ------------------------------------------------
+    def lift3d(self):
+        """[N, 3] (b, y, x) indices on [H, W] -> the same tensor as (b, 0, y, x) on [1, H, W]; cached, and shares the
+        rulebook / directory dictionaries like every derived tensor."""
+        hit = self.__dict__.get("_lift")
+        if hit is None or hit[0] is not self.indices:
+            ind = self.indices
+            ind3 = torch.cat([ind[:, :1], torch.zeros_like(ind[:, :1]), ind[:, 1:]], 1).contiguous()
+            t = SparseConvTensor(self.features, ind3, [1] + self.spatial_shape, self.batch_size, self.grid)
+            t.indice_dict, t._directories = self.indice_dict, self._directories
+            hit = (self.indices, t)
+            self.__dict__["_lift"] = hit
+        t = hit[1]
+        if t.features is not self.features:
+            t.features, t._split = self.features, self._split
+        return t
+
+    def drop_z(self):
+        """inverse of lift3d for a tensor produced by a (1, kh, kw) kernel."""
+        ind2 = self.indices[:, [0, 2, 3]].contiguous()
+        t = SparseConvTensor(self.features, ind2, self.spatial_shape[1:], self.batch_size, self.grid)
+        t.indice_dict, t._directories, t._split = self.indice_dict, self._directories, self._split
+        t.__dict__["_lift"] = (ind2, self)
+        return t
+
     # ---- reference API ------------------------------------------------------------
     @property
     def spatial_size(self):
@@ -119,6 +145,10 @@ class SparseConvTensor(object):
 
     def dense(self, channels_first=True):
         """[B, C, *spatial] (channels_first) like structure.py:55-64; one fused kernel."""
+        if len(self.spatial_shape) == 2:                     # one-slice volume, z dropped again
+            return self.lift3d().dense(channels_first).squeeze(2 if channels_first else 1)
+        if len(self.spatial_shape) != 3 or self.indices.shape[1] != 4:
+            raise Df3dError("dense(): 2-D or 3-D tensors with [N, 1 + ndim] indices only")
         feats = self.features.contiguous()
         if feats.requires_grad and torch.is_grad_enabled():
             out = _DenseFunction.apply(feats, self.indices.contiguous(), self.batch_size, tuple(self.spatial_shape))

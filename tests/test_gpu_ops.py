@@ -687,3 +687,34 @@ def test_dynamic_voxelize_golden_and_oracle(golden, dev):
     got = ops.dynamic_voxelize(T(sweep, dev), synth.NUSC_VOXEL, synth.NUSC_RANGE).cpu().numpy()
     assert np.array_equal(got, want) and (got[:3] == -1).all()
     assert ops.dynamic_voxelize(torch.zeros((0, 4), device=dev), POOL_VS, POOL_RANGE).shape == (0, 3)
+
+
+def test_sparse_conv2d_and_pool2d_vs_dense_torch(dev):
+    """SparseConv2d / SubMConv2d / SparseMaxPool2d (TF/mmdet3d/ops/spconv/conv.py:207-260, pool.py:73-78) run on the
+    3-D kernels as a one-slice volume; values against torch's dense conv2d / max_pool2d at the active sites."""
+    import torch.nn.functional as F
+    from dualfusion import spconv
+    B, H, W, C = 2, 33, 40, 16
+    rs = np.random.RandomState(5)
+    flat = rs.choice(B * H * W, size=700, replace=False)
+    ind = np.stack([flat // (H * W), (flat % (H * W)) // W, flat % W], 1).astype(np.int32)
+    f = detgen.randn("c2d_f", (len(ind), C))
+    dense = torch.zeros(B, C, H, W, device=dev)
+    dense[ind[:, 0], :, ind[:, 1], ind[:, 2]] = T(f, dev)
+    x = spconv.SparseConvTensor(T(f, dev), T(ind, dev), [H, W], B)
+    subm = spconv.SubMConv2d(C, 32, 3, padding=1, bias=True, indice_key="s").to(dev)
+    down = spconv.SparseConv2d(32, 32, 3, stride=2, padding=1, bias=False).to(dev)
+    with torch.no_grad():
+        y = subm(x)
+        assert y.indices.shape[1] == 3 and torch.equal(y.indices, x.indices) and y.spatial_shape == [H, W]
+        want = F.conv2d(dense, subm.weight.permute(3, 2, 0, 1), subm.bias, padding=1)
+        got = y.dense()
+        act = (dense.abs().sum(1, keepdim=True) > 0).float()
+        assert (got - want * act).abs().max() <= 1e-4 * want.abs().max()
+        z = down(y)
+        assert z.spatial_shape == [17, 20] and z.indices.shape[1] == 3
+        want2 = F.conv2d(got, down.weight.permute(3, 2, 0, 1), None, stride=2, padding=1)
+        assert (z.dense() - want2).abs().max() <= 1e-4 * want2.abs().max()
+        p = spconv.SparseMaxPool2d(3, 2, 1)(y)
+        wantp = F.max_pool2d(got.clamp_min(0), 3, 2, 1)                    # the reference's pool starts from zero
+        assert torch.equal(p.indices, z.indices) and (p.dense() - wantp).abs().max() <= 1e-6
