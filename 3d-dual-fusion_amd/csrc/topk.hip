@@ -76,13 +76,15 @@ __device__ void tk_find_threshold(const unsigned *hist, unsigned need, unsigned 
     }
   }
   __syncthreads();
-  if (s_T == 0xFFFFFFFFu) {                        // fewer than `need` keys in total
-    if (t == 255) {
-      s_T = TK_BINS - 1;
-      s_A = incl - mine[15];
-    }
-    __syncthreads();
+  // every thread snapshots the flag BEFORE anyone may overwrite it (a wave that read it after thread 255's store
+  // would skip the barrier below and leave the workgroup's barriers skewed)
+  const bool none = (s_T == 0xFFFFFFFFu);          // fewer than `need` keys in total
+  __syncthreads();
+  if (none && t == 255) {
+    s_T = TK_BINS - 1;
+    s_A = incl - mine[15];
   }
+  __syncthreads();
   T = s_T;
   A = s_A;
 }

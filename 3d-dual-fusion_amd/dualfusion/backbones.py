@@ -15,7 +15,7 @@ from torch import nn
 from . import spconv
 from .registry import BACKBONES, BACKBONES_3D, MIDDLE_ENCODERS
 from .spconv import SparseConv3d, SubMConv3d
-from .spconv.modules import can_fold, fold_batchnorm
+from .spconv.modules import can_fold, fold_batchnorm, wants_grad
 
 
 def build_norm_layer(cfg, num_features, postfix=""):
@@ -73,7 +73,7 @@ class SparseBasicBlock(spconv.SparseModule):
         self.stride = stride
 
     def forward(self, x):
-        if not self.training and can_fold(self.bn1) and can_fold(self.bn2):
+        if not self.training and can_fold(self.bn1) and can_fold(self.bn2) and not wants_grad(x, self):
             return _fused_basic_block(x, self.conv1, self.bn1, self.conv2, self.bn2, self.downsample)
         identity = x
         out = self.conv1(x)
@@ -238,7 +238,8 @@ class TFSparseBasicBlock(spconv.SparseModule):
         return self.bn2
 
     def forward(self, x):
-        if not self.training and can_fold(self.bn1) and can_fold(self.bn2) and self.downsample is None:
+        if not self.training and can_fold(self.bn1) and can_fold(self.bn2) and self.downsample is None \
+                and not wants_grad(x, self):
             return _fused_basic_block(x, self.conv1, self.bn1, self.conv2, self.bn2, None)
         identity = x.features
         out = self.conv1(x)

@@ -7,9 +7,33 @@ VR/pcdet/utils/commu_utils.py:148-162) and the timing/barrier protocol of the be
 "nccl" is RCCL on ROCm (xGMI inside a node); "gloo" is used by the CPU tests.
 """
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(nprocs, script, argv, master_port=None, env=None, timeout=None):
+    """Run `script argv...` as `nprocs` ranks of ONE node, one process per GPU, the way the reference launches its
+    trainers (`python -m torch.distributed.launch --nproc_per_node=N tools/train.py`, CP/docs/GETTING_START.md;
+    the worker side is CP/det3d/torchie/apis/train.py:289-295): torch.distributed.run with a 127.0.0.1 rendezvous
+    exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* to every rank, which `init_from_env` reads.  Returns the exit
+    code of the launcher (0 only when every rank exited cleanly)."""
+    port = int(master_port) if master_port else free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nprocs)),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, int(nprocs)))))
+    return subprocess.call(cmd, env=e, timeout=timeout)
 
 
 def init_from_env(backend=None):
@@ -51,18 +75,25 @@ def max_over_ranks(value, device="cpu"):
 
 
 def reduce_dict(input_dict, average=True):
-    """CP/det3d/torchie/trainer/utils.py:157-183: stack the (sorted-key) scalar tensors, reduce to
-    rank 0, average there.  Other ranks get the un-divided partial result back, like the reference."""
+    """CP/det3d/torchie/trainer/utils.py:157-183: the values of the (sorted-key) dict go through ONE reduce to
+    rank 0, which averages them; the other ranks get the un-divided partial result back, like the reference.
+    The reference stacks scalars; here the values are flattened into one buffer, so per-task vectors (`CenterHead`
+    returns one value per task) and entries of different shapes travel in the same single collective."""
     if not is_dist():
         return input_dict
     world = dist.get_world_size()
     with torch.no_grad():
         names = sorted(input_dict.keys())
-        values = torch.stack([input_dict[k] for k in names], dim=0)
+        parts = [input_dict[k].reshape(-1) for k in names]
+        values = torch.cat(parts) if len(parts) > 1 else parts[0].clone()
         dist.reduce(values, dst=0)
         if dist.get_rank() == 0 and average:
             values /= world
-        return {k: v for k, v in zip(names, values)}
+        out, pos = {}, 0
+        for k, p in zip(names, parts):
+            out[k] = values[pos:pos + p.numel()].view(input_dict[k].shape)
+            pos += p.numel()
+        return out
 
 
 def all_reduce_value(data, op="sum", average=False):

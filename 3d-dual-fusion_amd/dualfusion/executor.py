@@ -15,7 +15,7 @@ from . import _lib
 from . import ops as _ops
 from .spconv.conv import SparseConvolution
 from .spconv.modules import SparseSequential, can_fold, fold_batchnorm
-from .spconv.structure import SparseConvTensor
+from .spconv.structure import DirectoryCache, SparseConvTensor
 
 
 class _Layer(ctypes.Structure):
@@ -215,7 +215,7 @@ class BackbonePlan(object):
             off = ptr - base
             return arena[off:off + nbytes].view(dtype).view(shape)
 
-        out, idict, dirs = {}, {}, {}
+        out, idict, dirs = {}, {}, DirectoryCache()
         for name, li in self.exports.items():
             v = views[li]
             f = view(v.features, v.n * v.channels * 4, torch.float32, (v.n, v.channels))
@@ -232,8 +232,7 @@ class BackbonePlan(object):
                 # the occupancy directory the executor built is handed to the module path (e.g. a conv that runs
                 # after a fusion step): SparseConvTensor.directory() finds it by the identity of `indices`
                 blob = view(v.grid, v.grid_bytes, torch.uint8, (v.grid_bytes,))
-                dirs[(ind.data_ptr(), ind.shape[0])] = _ops.GridDirectory(blob, None, batch_size,
-                                                                          list(t.spatial_shape))
+                dirs.put(ind, _ops.GridDirectory(blob, None, batch_size, list(t.spatial_shape)))
             out[name] = t
         for src, li in self.geometry:
             v = views[li]

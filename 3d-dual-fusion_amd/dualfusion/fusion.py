@@ -121,6 +121,7 @@ class VoxelWithPointProjection(nn.Module):
             self.ifat_cfg = ifat_cfg
             self.ifat = ifat_all[ifat_cfg['fusion_method']](**ifat_cfg)
         self._calib_cache = None
+        self._shape_cache = None
         self._side = None
         self._prefetched = None
         self._ptr_tables = {}
@@ -145,26 +146,34 @@ class VoxelWithPointProjection(nn.Module):
                 imgs.append(f)
         Ci, h, w = imgs[0].shape
         img_ptrs = self._pointer_table(imgs, dev)
-        key = (id(batch_dict.get('calib')), id(batch_dict.get('image_shape')), h, w)
-        if self._calib_cache is None or self._calib_cache[0] != key:
-            calib = batch_dict['calib']
-            l2c = torch.stack([calib['lidar2cam_' + c.lstrip('cam_')].float() for c in cams], 1).contiguous().to(dev)
-            intr = torch.stack([calib['cam_intrinsic_' + c.lstrip('cam_')].float() for c in cams],
-                               1).contiguous().to(dev)
-            shp = torch.stack([torch.as_tensor(batch_dict['image_shape'][c])[:, :2] for c in cams], 1)  # [B,ncam,2]
-            shp_cpu = shp.cpu()
-            raw_hw = shp_cpu.to(torch.int32).contiguous().to(dev)
-            fs = np.empty((B, ncam, 2), np.float32)
+        # Calibration differs per sample (nuScenes lidar2cam changes every frame), so nothing here is keyed on object
+        # identity: the image-shape derived tensors are cached by VALUE (the shapes are a handful of host integers),
+        # the calibration matrices are re-stacked unless the very same tensors (held by reference, same version
+        # counters) come again.
+        calib = batch_dict['calib']
+        shp_cpu = torch.stack([torch.as_tensor(batch_dict['image_shape'][c])[:, :2] for c in cams], 1).cpu()  # [B,ncam,2]
+        skey = (tuple(shp_cpu.reshape(-1).tolist()), h, w, str(dev))
+        if self._shape_cache is None or self._shape_cache[0] != skey:
             shp_np = shp_cpu.numpy()
+            fs = np.empty((B, ncam, 2), np.float32)
             for b in range(B):
                 for c in range(ncam):
                     fs[b, c, 0] = np.float32(w / float(shp_np[b, c, 1]))          # :265-266 (python float -> fp32)
                     fs[b, c, 1] = np.float32(h / float(shp_np[b, c, 0]))
-            feat_scale = torch.from_numpy(fs).to(dev)
             thres = torch.tensor([float(self.depth_thres[c.upper()]) if isinstance(self.depth_thres, dict)
                                   else float(self.depth_thres) for c in cams], dtype=torch.float32, device=dev)
-            self._calib_cache = (key, dict(l2c=l2c, intr=intr, raw_hw=raw_hw, feat_scale=feat_scale, thres=thres))
-        out = dict(self._calib_cache[1])
+            self._shape_cache = (skey, dict(raw_hw=shp_cpu.to(torch.int32).contiguous().to(dev),
+                                            feat_scale=torch.from_numpy(fs).to(dev), thres=thres))
+        mats = [calib['lidar2cam_' + c.lstrip('cam_')] for c in cams] + \
+               [calib['cam_intrinsic_' + c.lstrip('cam_')] for c in cams]
+        hit = self._calib_cache
+        if hit is None or len(hit[0]) != len(mats) or any(a is not b or a._version != v
+                                                          for a, b, v in zip(mats, hit[0], hit[1])):
+            l2c = torch.stack([m.float() for m in mats[:ncam]], 1).contiguous().to(dev)
+            intr = torch.stack([m.float() for m in mats[ncam:]], 1).contiguous().to(dev)
+            self._calib_cache = hit = (mats, [m._version for m in mats], dict(l2c=l2c, intr=intr))
+        self._calib_cache = (hit[0], hit[1], dict(hit[2], **self._shape_cache[1]))
+        out = dict(self._calib_cache[2])
         out.update(imgs=imgs, img_ptrs=img_ptrs, B=B, ncam=ncam, Ci=Ci, h=h, w=w)
         return out
 
@@ -304,6 +313,12 @@ class VoxelWithPointProjection(nn.Module):
                 fuse_mode=None, d_factor_list=None):
         if fuse_mode != 'pfat':
             raise NotImplementedError("fuse_mode %r" % (fuse_mode,))
+        if self.training and any(p.requires_grad for p in self.parameters()):
+            # this adapter is the inference formulation (folded gate matrices, fused ACTR layers, no autograd graph):
+            # a training step through it would run and silently stop fusion.pfat.* / fusion.ifat.* from learning
+            raise NotImplementedError("VoxelWithPointProjection.forward is inference-only on the MI355X path: call "
+                                      ".eval() (or freeze the fusion parameters) -- the fused adapter records no "
+                                      "gradients for fusion.pfat.* / fusion.ifat.* or the voxel features")
         lib = _lib.load()
         x_last = encoded_voxel_list[-1]
         dev = x_last.features.device

@@ -244,6 +244,31 @@ class CenterHead(nn.Module):
                 merged[k].append(v)
         return merged
 
+    @torch.no_grad()
+    def loss_device(self, example, preds_dicts):
+        """The same loss values as `loss` for a no-grad evaluation (validation loss, the loss scalars a data-parallel
+        step reduces over the ranks), computed by ONE device call for all tasks and samples (csrc/loss.hip) with no host
+        round trip; `loss` itself stays the reference's autograd composition for training.  Returns
+        {'loss', 'hm_loss', 'loc_loss', 'num_positive': [T] device tensors, 'loc_loss_elem': [T, codes]} -- views
+        of one [T, 14] buffer.  Unlike the reference it leaves preds_dict['hm'] untouched (no in-place sigmoid)."""
+        if self.dataset not in ('waymo', 'nuscenes'):
+            raise NotImplementedError()
+        B, _, H, W = preds_dicts[0]['hm'].shape
+        tasks = []
+        for pd in preds_dicts:
+            d = {k: self._rows(pd[k]) for k in ('hm', 'reg', 'height', 'dim', 'rot')}
+            if 'vel' in pd:
+                d['vel'] = self._rows(pd['vel'])
+            tasks.append(d)
+        targets = [dict(hm=example['hm'][t], ind=example['ind'][t], mask=example['mask'][t], cat=example['cat'][t],
+                        anno_box=example['anno_box'][t]) for t in range(len(preds_dicts))]
+        ncodes = 10 if 'vel' in preds_dicts[0] else 8
+        if len(self.code_weights) != ncodes:
+            raise ValueError("code_weights has %d entries, the head regresses %d codes" % (len(self.code_weights), ncodes))
+        out = _ops.centerhead_loss(tasks, targets, B, H, W, self.code_weights, self.weight)
+        return {'loss': out[:, 0], 'hm_loss': out[:, 1], 'loc_loss': out[:, 2], 'num_positive': out[:, 3],
+                'loc_loss_elem': out[:, 4:4 + ncodes]}
+
     # ------------------------------------------------------------------ decode + NMS on the device
     @staticmethod
     def _rows(v):

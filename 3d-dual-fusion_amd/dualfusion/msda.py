@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 from torch.autograd import Function
-from torch.nn.init import constant_, xavier_uniform_
+from torch.nn.init import xavier_uniform_
 
 from . import ops as _ops
 from ._lib import Df3dError
@@ -70,21 +70,23 @@ class MSDeformAttn(nn.Module):
         self._reset_parameters()
 
     def _reset_parameters(self):
-        constant_(self.sampling_offsets.weight.data, 0.0)
-        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
-        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
-        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2).repeat(
-            1, self.n_levels, self.n_points, 1)
-        for i in range(self.n_points):
-            grid_init[:, :, i, :] *= i + 1
+        """Initial state of ms_deform_attn.py:76-90: zero offset / weight matrices; the offset bias of head m points
+        along direction 2*pi*m/n_heads (scaled so its larger component is 1) and grows linearly with the point index;
+        Xavier projections with zero bias."""
+        H, L, P = self.n_heads, self.n_levels, self.n_points
         with torch.no_grad():
-            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
-        constant_(self.attention_weights.weight.data, 0.0)
-        constant_(self.attention_weights.bias.data, 0.0)
-        xavier_uniform_(self.value_proj.weight.data)
-        constant_(self.value_proj.bias.data, 0.0)
-        xavier_uniform_(self.output_proj.weight.data)
-        constant_(self.output_proj.bias.data, 0.0)
+            ang = torch.arange(H, dtype=torch.float32) * (2.0 * math.pi / H)
+            ray = torch.stack((ang.cos(), ang.sin()), dim=-1)                      # [H, 2]
+            ray = ray / ray.abs().amax(dim=-1, keepdim=True)
+            reach = torch.arange(1, P + 1, dtype=torch.float32).view(1, 1, P, 1)   # point p sits p+1 steps out
+            bias = ray.view(H, 1, 1, 2).repeat(1, L, P, 1) * reach
+            self.sampling_offsets.bias = nn.Parameter(bias.reshape(-1))
+            for lin in (self.sampling_offsets, self.attention_weights):
+                lin.weight.zero_()
+            self.attention_weights.bias.zero_()
+            for lin in (self.value_proj, self.output_proj):
+                xavier_uniform_(lin.weight)
+                lin.bias.zero_()
 
     def project_value(self, input_flatten, input_padding_mask=None):
         N, Len_in, _ = input_flatten.shape
@@ -93,44 +95,45 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         return value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
 
+    def _queries(self, query, i_query):
+        """(query driving the offsets, query driving the weights) after the dual-query mixing rule `q_method`
+        (ms_deform_attn.py:129-147): the LiDAR query is replaced by the mixed one in the places `q_rep_place` names."""
+        if self.q_method is None:
+            return query, query
+        assert i_query is not None and self.q_rep_place is not None
+        if self.q_method == 'sum':
+            mixed = query + i_query
+        elif self.q_method == 'image':
+            mixed = i_query
+        elif self.q_method == 'gating':
+            gq, gi = self.q_gating(query, i_query)
+            mixed = gq + gi - query - i_query
+        else:
+            raise NotImplementedError('q_method must be among ["gating", "sum", "image"]')
+        return (mixed if 'offset' in self.q_rep_place else query), (mixed if 'weight' in self.q_rep_place else query)
+
+    def _locations(self, reference_points, offsets, spatial_shapes):
+        """Normalised sampling locations [N, Lq, M, L, P, 2]: 2-d reference points move by offset / (W_l, H_l);
+        4-d ones (cx, cy, w, h) by offset / P * (w, h) / 2."""
+        last = reference_points.shape[-1]
+        ref = reference_points[:, :, None, :, None, :]
+        if last == 2:
+            wh = spatial_shapes.flip(-1)                                            # (H, W) -> (W, H)
+            return ref + offsets / wh[None, None, None, :, None, :]
+        if last == 4:
+            return ref[..., :2] + offsets / self.n_points * ref[..., 2:] * 0.5
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(last))
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None, i_query=None):
         N, Len_q, _ = query.shape
-        N, Len_in, _ = input_flatten.shape
-        assert input_spatial_shapes.shape[0] == self.n_levels
+        H, L, P = self.n_heads, self.n_levels, self.n_points
+        assert input_spatial_shapes.shape[0] == L
         value = self.project_value(input_flatten, input_padding_mask)
-        weight_query = query
-        if self.q_method is not None:
-            assert i_query is not None
-            assert self.q_rep_place is not None
-            if self.q_method == 'gating':
-                g_query, g_i_query = self.q_gating(query, i_query)
-                new_query = g_query + g_i_query - query - i_query
-            elif self.q_method == 'sum':
-                new_query = query + i_query
-            elif self.q_method == 'image':
-                new_query = i_query
-            else:
-                raise NotImplementedError('q_method must be among ["gating", "sum", "image"]')
-            if 'offset' in self.q_rep_place:
-                query = new_query
-            if 'weight' in self.q_rep_place:
-                weight_query = new_query
-        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = self.attention_weights(weight_query).view(N, Len_q, self.n_heads,
-                                                                      self.n_levels * self.n_points)
-        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, self.n_heads, self.n_levels,
-                                                                  self.n_points)
-        if reference_points.shape[-1] == 2:
-            offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
-            sampling_locations = reference_points[:, :, None, :, None, :] \
-                + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            sampling_locations = reference_points[:, :, None, :, None, :2] \
-                + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
-        else:
-            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
-                reference_points.shape[-1]))
-        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                            sampling_locations, attention_weights, self.im2col_step)
+        q_off, q_w = self._queries(query, i_query)
+        offsets = self.sampling_offsets(q_off).view(N, Len_q, H, L, P, 2)
+        weights = F.softmax(self.attention_weights(q_w).view(N, Len_q, H, L * P), -1).view(N, Len_q, H, L, P)
+        locations = self._locations(reference_points, offsets, input_spatial_shapes)
+        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, locations, weights,
+                                            self.im2col_step)
         return self.output_proj(output)

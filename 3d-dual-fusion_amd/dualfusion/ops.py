@@ -629,6 +629,71 @@ def centerhead_predict(tasks, batch, H, W, out_size_factor, voxel_size, pc_range
     return boxes, scores, labels, counts
 
 
+class _HeadTargets(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("hm", "ind", "mask", "cat", "box")]
+
+
+LOSS_FIELDS = 14        # DF3D_LOSS_FIELDS: loss, hm_loss, loc_loss, num_positive, loc_loss_elem[10]
+
+
+def _fill_head_tasks(arr, tasks, rows):
+    for i, t in enumerate(tasks):
+        for k in ("hm", "reg", "height", "dim", "rot", "vel"):
+            v = t.get(k)
+            if v is None:
+                setattr(arr[i], k, None)
+                setattr(arr[i], "ld_" + k, 0)
+                continue
+            if v.dtype != torch.float32 or not v.is_cuda or v.dim() != 2 or (v.shape[1] > 1 and v.stride(1) != 1) or v.shape[0] != rows:
+                raise ValueError("head map '%s' must be a CUDA fp32 [B*H*W, C] view with unit column stride" % k)
+            setattr(arr[i], k, v.data_ptr())
+            setattr(arr[i], "ld_" + k, int(v.stride(0)))
+        arr[i].num_classes = int(t["hm"].shape[1])
+        arr[i].label_base = int(t.get("label_base", 0))
+
+
+def centerhead_loss(tasks, targets, batch, H, W, code_weights, weight):
+    """Detection losses of all tasks in two launches (csrc/loss.hip).  tasks: as for centerhead_predict; targets: list of
+    dicts {'hm' [B, C, H, W] f32, 'ind' [B, M] i64, 'mask' [B, M] u8, 'cat' [B, M] i64, 'anno_box' [B, M, D] f32} on
+    the device.  Returns [T, LOSS_FIELDS] f32 on the device: loss, hm_loss, loc_loss, num_positive, loc_loss_elem[10]."""
+    lib = _lib.load()
+    n = len(tasks)
+    dev = tasks[0]["hm"].device
+    arr = (_HeadTask * n)()
+    _fill_head_tasks(arr, tasks, batch * H * W)
+    tg = (_HeadTargets * n)()
+    M = int(targets[0]["ind"].shape[1])
+    D = int(targets[0]["anno_box"].shape[2])
+    keep = []
+    for i, t in enumerate(targets):
+        hm, ind, mask, cat, box = t["hm"], t["ind"], t["mask"], t["cat"], t["anno_box"]
+        if tuple(hm.shape) != (batch, arr[i].num_classes, H, W) or hm.dtype != torch.float32:
+            raise ValueError("target hm of task %d must be f32 [%d, %d, %d, %d]" % (i, batch, arr[i].num_classes, H, W))
+        if ind.dtype != torch.int64 or cat.dtype != torch.int64 or tuple(ind.shape) != (batch, M) or tuple(cat.shape) != (batch, M):
+            raise ValueError("targets ind / cat of task %d must be int64 [%d, %d]" % (i, batch, M))
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        if mask.dtype != torch.uint8 or tuple(mask.shape) != (batch, M):
+            raise ValueError("target mask of task %d must be uint8 / bool [%d, %d]" % (i, batch, M))
+        if box.dtype != torch.float32 or tuple(box.shape) != (batch, M, D):
+            raise ValueError("target anno_box of task %d must be f32 [%d, %d, %d]" % (i, batch, M, D))
+        ts = [x if x.is_contiguous() else x.contiguous() for x in (hm, ind, mask, cat, box)]
+        for x in ts:
+            if not x.is_cuda:
+                raise _lib.Df3dError("centerhead_loss: targets must live on the GPU (no CPU fallback)")
+        keep.append(ts)
+        tg[i].hm, tg[i].ind, tg[i].mask, tg[i].cat, tg[i].box = [x.data_ptr() for x in ts]
+    cw = (ctypes.c_float * len(code_weights))(*[float(v) for v in code_weights])
+    out = torch.empty((n, LOSS_FIELDS), dtype=torch.float32, device=dev)
+    nbytes = int(lib.df3d_centerhead_loss_workspace_bytes(n, int(batch), int(H), int(W)))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    rc = lib.df3d_centerhead_loss(ctypes.byref(arr), ctypes.byref(tg), n, int(batch), int(H), int(W), M, D,
+                                  ctypes.cast(cw, ctypes.c_void_p), len(code_weights), float(weight), _ptr(out), _ptr(ws),
+                                  nbytes, _stream())
+    _lib.check(rc, "df3d_centerhead_loss")
+    return out
+
+
 class _QueryHeads(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("heatmap", "center", "height", "dim", "rot", "vel")] + \
                [(n, ctypes.c_int) for n in ("ld_heatmap", "ld_center", "ld_height", "ld_dim", "ld_rot", "ld_vel")]

@@ -73,3 +73,51 @@ class CenterPointHotPath(nn.Module):
             rows, (nb, _, h, w) = bev
             bev = self.neck.forward_rows(rows, nb, h, w)
         return bev, multi
+
+
+# nuScenes head of the 3D-DF CenterPoint config
+# (CP/configs/nusc/voxelnet/nusc_centerpoint_voxelnet_0075voxel_fix_bn_z_multimodal_pfat_hybrid7_ifat.py:7-14,110-133)
+NUSC_TASKS = [dict(num_class=1, class_names=["car"]), dict(num_class=2, class_names=["truck", "construction_vehicle"]),
+              dict(num_class=2, class_names=["bus", "trailer"]), dict(num_class=1, class_names=["barrier"]),
+              dict(num_class=2, class_names=["motorcycle", "bicycle"]),
+              dict(num_class=2, class_names=["pedestrian", "traffic_cone"])]
+NUSC_COMMON_HEADS = {'reg': (2, 2), 'height': (1, 2), 'dim': (3, 2), 'rot': (2, 2), 'vel': (2, 2)}
+NUSC_CODE_WEIGHTS = [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 1.0, 1.0]
+NUSC_TEST_CFG = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], max_per_img=500,
+                     nms=dict(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=1000,
+                              nms_post_max_size=83, nms_iou_threshold=0.2),
+                     score_threshold=0.1, pc_range=[-54, -54], out_size_factor=8, voxel_size=[0.075, 0.075])
+
+
+class CenterPointDetector(nn.Module):
+    """The detector the way the reference composes it (`VoxelNet` / `VoxelNetFusion.forward`,
+    CP/det3d/models/detectors/voxelnet.py:150-188): reader -> backbone (+ fuse_func) -> neck -> bbox_head ->
+    `loss` (return_loss=True) or `predict`.  Inference-mode composition on the MI355X kernels: the hot path hands the
+    neck channels-last pixel rows, the head reads the neck's rows, the losses / detections are computed on the device
+    (`CenterHead.loss_device` / `predict_device`); the camera network's feature maps are an input (`batch_dict`)."""
+
+    def __init__(self, fusion=None, neck=None, bbox_head=None, test_cfg=None, **hot_path_kwargs):
+        super(CenterPointDetector, self).__init__()
+        from .heads import CenterHead
+        from .necks import RPN
+        if neck is None:
+            neck = RPN([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256)
+        if bbox_head is None:
+            bbox_head = CenterHead(in_channels=512, tasks=NUSC_TASKS, dataset='nuscenes', weight=0.25,
+                                   code_weights=NUSC_CODE_WEIGHTS, common_heads=dict(NUSC_COMMON_HEADS),
+                                   share_conv_channel=64, dcn_head=False)
+        self.hot_path = CenterPointHotPath(fusion=fusion, neck=neck, **hot_path_kwargs)
+        self.bbox_head = bbox_head
+        self.test_cfg = dict(NUSC_TEST_CFG) if test_cfg is None else test_cfg
+
+    @property
+    def neck(self):
+        return self.hot_path.neck
+
+    @torch.no_grad()
+    def forward(self, points_list, batch_dict=None, example=None, return_loss=True):
+        x, _ = self.hot_path(points_list, batch_dict=batch_dict, example=example)
+        preds = self.bbox_head(x)
+        if return_loss:
+            return self.bbox_head.loss_device(example, preds)
+        return self.bbox_head.predict_device(preds, self.test_cfg)

@@ -16,22 +16,12 @@ from .modules import SparseModule
 from .structure import Rulebook, SparseConvTensor
 
 
-def _calculate_fan_in_and_fan_out_hwio(tensor):
-    dimensions = tensor.ndimension()
-    if dimensions < 2:
+def _fan_in_hwio(weight):
+    """fan-in of a filter bank stored [*kernel, Cin, Cout] (the reference keeps the channels LAST, so torch's own
+    fan computation -- which assumes [Cout, Cin, *kernel] -- would be wrong): taps x input channels."""
+    if weight.dim() < 2:
         raise ValueError('fan in and fan out can not be computed for tensor with fewer than 2 dimensions')
-    if dimensions == 2:
-        fan_in = tensor.size(-2)
-        fan_out = tensor.size(-1)
-    else:
-        num_input_fmaps = tensor.size(-2)
-        num_output_fmaps = tensor.size(-1)
-        receptive_field_size = 1
-        if tensor.dim() > 2:
-            receptive_field_size = tensor[..., 0, 0].numel()
-        fan_in = num_input_fmaps * receptive_field_size
-        fan_out = num_output_fmaps * receptive_field_size
-    return fan_in, fan_out
+    return int(np.prod(weight.shape[:-1]))
 
 
 class SparseConvFunction(torch.autograd.Function):
@@ -99,11 +89,14 @@ class SparseConvolution(SparseModule):
         self.reset_parameters()
 
     def reset_parameters(self):
+        """Same distributions as the reference's initialiser (conv.py:106-112): Kaiming-uniform filters with
+        a = sqrt(5) (fan counted by torch on the stored layout, as the reference does) and a bias uniform in
+        +-1/sqrt(taps * Cin)."""
         init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         if self.bias is not None:
-            fan_in, _ = _calculate_fan_in_and_fan_out_hwio(self.weight)
-            bound = 1 / math.sqrt(fan_in)
-            init.uniform_(self.bias, -bound, bound)
+            lim = 1.0 / math.sqrt(_fan_in_hwio(self.weight))
+            with torch.no_grad():
+                self.bias.uniform_(-lim, lim)
 
     # ------------------------------------------------------------------------------
     def _rulebook(self, input):
@@ -145,7 +138,7 @@ class SparseConvolution(SparseModule):
                                                              self.dilation, self.subm, directory=directory)
         rb = Rulebook(outids, input.indices, nbr, input.spatial_shape, out_shape, out_rows_sorted=not self.subm)
         if out_dir is not None and not self.subm:
-            input._directories[(outids.data_ptr(), outids.shape[0])] = out_dir
+            input._directories.put(outids, out_dir)
         input.indice_dict[auto_key if auto_key is not None else self.indice_key] = rb
         return rb
 

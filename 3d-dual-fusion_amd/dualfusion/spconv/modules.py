@@ -2,7 +2,6 @@
 (TF/mmdet3d/ops/spconv/modules.py:43-137).  In eval mode the container folds
 conv -> BatchNorm1d -> ReLU runs into the conv kernel's epilogue (the reference anticipates
 this with `fused()` / fused_indice_conv, modules.py:139-187, but never enables it)."""
-import sys
 from collections import OrderedDict
 
 import torch
@@ -25,16 +24,13 @@ class SparseModule(nn.Module):
     pass
 
 
-_FOLD_CACHE = {}
-
-
 def fold_batchnorm(bn):
-    """(scale, shift) of an eval-mode BatchNorm1d: y = x * scale + shift.  Cached on the
-    parameter versions so a steady-state forward launches nothing for it."""
-    key = id(bn)
-    ver = (bn.weight._version if bn.weight is not None else -1, bn.bias._version if bn.bias is not None else -1,
-           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.eps)
-    hit = _FOLD_CACHE.get(key)
+    """(scale, shift) of an eval-mode BatchNorm1d: y = x * scale + shift.  The folded pair lives ON the module
+    (so it dies with it and can never be handed to another module) and is rebuilt when any parameter / buffer
+    changes version, storage or device -- a steady-state forward launches nothing for it."""
+    tensors = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    ver = tuple((-1, 0) if t is None else (t._version, t.data_ptr()) for t in tensors) + (bn.eps,)
+    hit = bn.__dict__.get("_df3d_fold")
     if hit is not None and hit[0] == ver:
         return hit[1], hit[2]
     with torch.no_grad():
@@ -43,7 +39,7 @@ def fold_batchnorm(bn):
         b = bn.bias.float() if bn.bias is not None else torch.zeros_like(inv)
         scale = (w * inv).contiguous()
         shift = (b - bn.running_mean.float() * scale).contiguous()
-    _FOLD_CACHE[key] = (ver, scale, shift)
+    bn.__dict__["_df3d_fold"] = (ver, scale, shift)
     return scale, shift
 
 
@@ -52,43 +48,55 @@ def can_fold(bn):
         and bn.running_mean is not None
 
 
+def wants_grad(x, *modules):
+    """True when autograd would have to record this call: grad mode on and the input rows or any parameter of
+    `modules` require grad.  The fused conv + BatchNorm + ReLU epilogue is inference-only, so callers take the
+    unfused module sequence (the reference's composition) in that case -- e.g. `model.eval()` without
+    `torch.no_grad()`, frozen-BN fine-tuning, gradient-based analysis."""
+    if not torch.is_grad_enabled():
+        return False
+    feats = getattr(x, "features", x)
+    if isinstance(feats, torch.Tensor) and feats.requires_grad:
+        return True
+    return any(p.requires_grad for m in modules if m is not None for p in m.parameters())
+
+
 class SparseSequential(SparseModule):
+    """Ordered container of sparse / dense modules.  Construction forms of the reference
+    (TF/mmdet3d/ops/spconv/modules.py:43-137): positional modules (named "0", "1", ...), one OrderedDict, and
+    keyword modules appended after either; `seq[i]`, `len(seq)`, `seq.add(module, name)`, `seq.sparity_dict`."""
+
     def __init__(self, *args, **kwargs):
         super(SparseSequential, self).__init__()
+        self._sparity_dict = {}
         if len(args) == 1 and isinstance(args[0], OrderedDict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
+            entries = list(args[0].items())
         else:
-            for idx, module in enumerate(args):
-                self.add_module(str(idx), module)
-        for name, module in kwargs.items():
-            if sys.version_info < (3, 6):
-                raise ValueError('kwargs only supported in py36+')
+            entries = [(str(pos), mod) for pos, mod in enumerate(args)]
+        for name, mod in entries:
+            self.add_module(name, mod)
+        for name, mod in kwargs.items():
             if name in self._modules:
                 raise ValueError('name exists.')
-            self.add_module(name, module)
-        self._sparity_dict = {}
-
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError('index {} is out of range'.format(idx))
-        if idx < 0:
-            idx += len(self)
-        it = iter(self._modules.values())
-        for i in range(idx):
-            next(it)
-        return next(it)
+            self.add_module(name, mod)
 
     def __len__(self):
         return len(self._modules)
+
+    def __getitem__(self, idx):
+        members = tuple(self._modules.values())
+        if idx < -len(members) or idx >= len(members):
+            raise IndexError('index {} is out of range'.format(idx))
+        return members[idx]
 
     @property
     def sparity_dict(self):
         return self._sparity_dict
 
     def add(self, module, name=None):
+        """Append `module`; unnamed modules take their position as name."""
         if name is None:
-            name = str(len(self._modules))
+            name = str(len(self))
             if name in self._modules:
                 raise KeyError('name exists')
         self.add_module(name, module)
@@ -99,7 +107,8 @@ class SparseSequential(SparseModule):
         while i < len(mods):
             k, module = mods[i]
             if is_sparse_conv(module) and isinstance(input, SparseConvTensor) and not module.training \
-                    and i + 1 < len(mods) and can_fold(mods[i + 1][1]) and not module.conv1x1:
+                    and i + 1 < len(mods) and can_fold(mods[i + 1][1]) and not module.conv1x1 \
+                    and not wants_grad(input, module, mods[i + 1][1]):
                 # conv -> BN(eval) [-> ReLU] in one kernel
                 scale, shift = fold_batchnorm(mods[i + 1][1])
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2][1], nn.ReLU)

@@ -52,7 +52,7 @@ class SparseMaxPool(SparseModule):
         out = SparseConvTensor(SparseMaxPoolFunction.apply(feats, nbr, outids.shape[0]), outids, out_shape, input.batch_size)
         out.indice_dict, out.grid, out._directories = input.indice_dict, input.grid, input._directories
         if out_dir is not None and not self.subm:
-            input._directories[(outids.data_ptr(), outids.shape[0])] = out_dir
+            input._directories.put(outids, out_dir)
         return out
 
 

@@ -75,6 +75,28 @@ class _DenseFunction(torch.autograd.Function):
         return g.contiguous(), None, None, None
 
 
+class DirectoryCache(object):
+    """Occupancy directories of the index sets of one frame, found again by the index tensor they belong to.
+    An entry PINS its index tensor (strong reference): the storage cannot be recycled for another tensor while the
+    entry exists, so the (address, rows) key is unambiguous, and the tensor's version counter catches in-place
+    edits of the coordinates."""
+
+    def __init__(self):
+        self._entries = {}
+
+    def get(self, indices):
+        hit = self._entries.get((indices.data_ptr(), indices.shape[0]))
+        if hit is not None and hit[1] == hit[0]._version == indices._version:
+            return hit[2]
+        return None
+
+    def put(self, indices, directory):
+        self._entries[(indices.data_ptr(), indices.shape[0])] = (indices, indices._version, directory)
+
+    def __len__(self):
+        return len(self._entries)
+
+
 class SparseConvTensor(object):
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
         self.features = features
@@ -85,7 +107,7 @@ class SparseConvTensor(object):
         self.grid = grid
         # occupancy directories keyed by the identity of the indices tensor they index; shared by
         # reference with derived tensors exactly like indice_dict
-        self._directories = {}
+        self._directories = DirectoryCache()
         # (features tensor, its split rows) when a split-precision conv produced or consumed these features
         self._split = None
         # rulebooks built ahead of time for specific conv modules (dualfusion/executor.py), keyed by id(module)
@@ -179,9 +201,8 @@ class SparseConvTensor(object):
 
     # ---- directory cache ----------------------------------------------------------
     def directory(self, rows_sorted=False):
-        key = (self.indices.data_ptr(), self.indices.shape[0])
-        d = self._directories.get(key)
+        d = self._directories.get(self.indices)
         if d is None:
             d = _ops.grid_build(self.indices.contiguous(), self.batch_size, self.spatial_shape, rows_sorted=rows_sorted)
-            self._directories[key] = d
+            self._directories.put(self.indices, d)
         return d

@@ -97,3 +97,37 @@ def camera_features(n_img, channels=256, hw=(150, 267), seed=1234):
     """Stand-in for the frozen 2D backbone output: N(0,1) fp32 [n_img, C, h, w]."""
     rs = np.random.RandomState(seed)
     return rs.standard_normal((n_img, channels, hw[0], hw[1])).astype(np.float32)
+
+
+def centerhead_targets(batch, num_classes, hw=(180, 180), max_objs=500, seed=0, objs_per_task=(5, 40)):
+    """Assigner outputs for `CenterHead.loss` in the reference's layout (CP/det3d/datasets/pipelines/preprocess.py
+    `AssignLabel`): per task hm [B, C, H, W] f32 with one Gaussian (radius 2, peak 1) per object, ind [B, M] i64 flat
+    centre pixel, mask [B, M] u8, cat [B, M] i64, anno_box [B, M, 10] f32 (sub-pixel offset 2, height 1, log size 3,
+    velocity 2, sin / cos of the yaw 2).  Object positions, classes and boxes are random; numpy only."""
+    H, W = hw
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[-2:3, -2:3]
+    blob = np.exp(-(xx * xx + yy * yy) / (2.0 * (5.0 / 6.0) ** 2)).astype(np.float32)      # sigma = diameter / 6
+    ex = dict(hm=[], ind=[], mask=[], cat=[], anno_box=[])
+    for nc in num_classes:
+        hm = np.zeros((batch, nc, H, W), np.float32)
+        ind = np.zeros((batch, max_objs), np.int64)
+        mask = np.zeros((batch, max_objs), np.uint8)
+        cat = np.zeros((batch, max_objs), np.int64)
+        box = np.zeros((batch, max_objs, 10), np.float32)
+        for b in range(batch):
+            n = int(rs.randint(objs_per_task[0], objs_per_task[1] + 1))
+            cx, cy = rs.uniform(2, W - 3, n), rs.uniform(2, H - 3, n)
+            ix, iy = cx.astype(np.int64), cy.astype(np.int64)
+            cls = rs.randint(0, nc, n)
+            for m in range(n):
+                win = hm[b, cls[m], iy[m] - 2:iy[m] + 3, ix[m] - 2:ix[m] + 3]
+                np.maximum(win, blob, out=win)
+            yaw = rs.uniform(-np.pi, np.pi, n)
+            ind[b, :n], mask[b, :n], cat[b, :n] = iy * W + ix, 1, cls
+            box[b, :n] = np.stack([cx - ix, cy - iy, rs.uniform(-2, 1, n), np.log(rs.uniform(0.5, 5, n)),
+                                   np.log(rs.uniform(0.5, 12, n)), np.log(rs.uniform(0.5, 4, n)), rs.normal(0, 2, n),
+                                   rs.normal(0, 2, n), np.sin(yaw), np.cos(yaw)], 1).astype(np.float32)
+        ex["hm"].append(hm), ex["ind"].append(ind), ex["mask"].append(mask), ex["cat"].append(cat)
+        ex["anno_box"].append(box)
+    return ex

@@ -1,0 +1,147 @@
+"""The other two module trees at their BASELINE config shapes, as bench.py workloads (`--workload tf_fusion|vr_fusion`).
+
+  tf_fusion : BASELINE configs[2] -- TransFusion-L + 3D-DF: `SparseEncoderFusion` + ACTR fusion layer on the full
+              0.075 m nuScenes grid, bs = 4 sweeps x 6 cameras (ResNet50-stride-4-shaped feature maps [24, 256, 112, 200]),
+              then SECOND + SECONDFPN + TransFusionHead (LiDAR-only decoder, 200 proposals) -> boxes
+              (TF/configs/transfusion_nusc_voxel_F.py:181-243 shapes).
+  vr_fusion : BASELINE configs[4] -- Voxel-RCNN + 3D-DF: `VoxelBackBone8xFusion` (MVX + ACTRv2 with the 3-D local
+              self-attention), KITTI 0.05 m grid, bs = 8 frames x 1 camera (small-grid / high-sparsity rulebook stress).
+
+Inputs are synthetic and resident in HBM; every step takes the next of `--frames` distinct frames.  Voxelisation of the
+batch is part of the step.  These trees have no loss on the device path, so their steps carry no collective: with N > 1
+ranks they run as independent replicas behind bench.py's barrier (frames sharded by rank seed)."""
+import numpy as np
+import torch
+
+from . import ops, synth
+
+TF_ACTR_CFG = dict(fusion_method="sum", feature_modal="hybrid",
+                   hybrid_cfg=dict(attn_layer="BiGateSum1D_2", q_method="sum", q_rep_place=["weight"]),
+                   num_bins=80, num_channels=[256], query_num_feat=128, num_enc_layers=2, max_num_ne_voxel=26000,
+                   pos_encode_method="depth")
+
+
+def _voxelize_batch(points, vs, rng, max_points, max_voxels):
+    feats, coors = [], []
+    for b, pts in enumerate(points):
+        _, c, _, mean = ops.hard_voxelize(pts, vs, rng, max_points, max_voxels, want_voxels=False, batch_index=b)
+        feats.append(mean)
+        coors.append(c)
+    return torch.cat(feats), torch.cat(coors)
+
+
+class TransFusionWorkload(object):
+    name, unit_name = "tf_fusion", "sweeps"
+
+    def __init__(self, args, rank, world, dev):
+        from .backbones import SparseEncoderFusion
+        from .necks import SECOND, SECONDFPN
+        from .transfusion_head import TransFusionHead
+        self.batch = B = args.batch or 4
+        self.dev = dev
+        torch.manual_seed(0)
+        ch = ((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128))
+        pad = ((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0))
+        self.enc = SparseEncoderFusion(in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
+                                       encoder_channels=ch, encoder_paddings=pad, block_type='basicblock', fusion_pos=[3],
+                                       voxel_size=synth.NUSC_VOXEL, point_cloud_range=synth.NUSC_RANGE,
+                                       fusion_layer=dict(type='ACTR', pfat_cfg=dict(TF_ACTR_CFG))).to(dev).eval()
+        self.second = SECOND(in_channels=256, out_channels=[128, 256], layer_nums=[5, 5], layer_strides=[1, 2]).to(dev).eval()
+        self.fpn = SECONDFPN(in_channels=[128, 256], out_channels=[256, 256], upsample_strides=[1, 2],
+                             use_conv_for_no_stride=True).to(dev).eval()
+        self.head = TransFusionHead(
+            num_proposals=200, auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10, num_decoder_layers=1,
+            num_heads=8, initialize_by_heatmap=True, nms_kernel_size=3, ffn_channel=256,
+            common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)),
+            bbox_coder=dict(type='TransFusionBBoxCoder', pc_range=[-54.0, -54.0], voxel_size=[0.075, 0.075],
+                            out_size_factor=8, post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                            score_threshold=0.0, code_size=10), loss_cls=dict(use_sigmoid=True),
+            test_cfg=dict(dataset='nuScenes', grid_size=[1440, 1440, 40], out_size_factor=8, pc_range=[-54.0, -54.0],
+                          voxel_size=[0.075, 0.075], nms_type=None)).to(dev).eval()
+        ori_hw, in_hw, fh, fw = (900, 1600), (448, 800), 112, 200          # stride-4 level (the layer indexes pix // 4)
+        sf = [in_hw[1] / ori_hw[1], in_hw[0] / ori_hw[0]]
+        self.frames = []
+        for f in range(max(1, args.frames)):
+            seed = rank * 1000 + f
+            cams = synth.nusc_cameras(image_hw=ori_hw, yaw_offset_deg=0.37 * (seed % 97))
+            metas = [dict(lidar2cam=np.stack([cams[n][0] for n in synth.NUSC_CAMS]),
+                          cam_intrinsic=np.stack([cams[n][1] for n in synth.NUSC_CAMS]), ori_shape=ori_hw + (3,),
+                          img_shape=in_hw + (3,), input_shape=in_hw, scale_factor=sf, flip=False) for _ in range(B)]
+            self.frames.append(dict(
+                points=[torch.from_numpy(synth.nusc_sweep(seed=seed * 16 + b)).to(dev) for b in range(B)],
+                img=torch.from_numpy(synth.camera_features(B * 6, 256, (fh, fw), 1234 + seed)).to(dev), metas=metas))
+
+    def describe(self):
+        return ("TransFusion-L + 3D-DF (voxelize+VFE, SparseEncoderFusion + ACTR fusion layer on %d x 6 synthetic "
+                "ResNet50-stride-4-shaped cam feats [256,112,200], SECOND + SECONDFPN, TransFusionHead 200 proposals -> "
+                "boxes), 0.075 m voxel, bs=%d [BASELINE configs[2]]" % (self.batch, self.batch))
+
+    @torch.no_grad()
+    def step(self, i, stage):
+        fr = self.frames[i % len(self.frames)]
+        f, c = _voxelize_batch(fr["points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000)
+        metas = [dict(m) for m in fr["metas"]]                    # fresh meta dicts per iteration
+        x = self.enc(f, c, self.batch, img_feats=[fr["img"]], img_metas=metas)
+        if stage == "hot_path":
+            return x
+        return self.head.get_bboxes_device(self.head(self.fpn(self.second(x))))
+
+    def check(self, out, stage):
+        if stage == "hot_path":
+            assert out.shape[0] == self.batch and out.shape[-2:] == (180, 180), out.shape
+        else:
+            assert out[0].shape[0] == self.batch and bool(torch.isfinite(out[1]).all())
+
+
+class VoxelRCNNWorkload(object):
+    name, unit_name = "vr_fusion", "frames"
+    metric = "KITTI frames/sec (0.05 m voxel, ~19k pts, 1 camera)"
+
+    def __init__(self, args, rank, world, dev):
+        from .backbones import VoxelBackBone8xFusion
+        self.batch = B = args.batch or 8
+        self.dev = dev
+        torch.manual_seed(0)
+        cfg = dict(NAME='VoxelBackBone8xFusion', USE_IMG=True, FUSION_POS=[1, 4], FUSION_METHOD='MVX+ACTRv2',
+                   FEATURE_LEVELS=[0], LT_CFG=dict(npoint=2048, radius=2.0, nsample=32, num_layers=2),
+                   ACTR_CFG=dict(fusion_method='sum', feature_modal='hybrid', num_bins=80, num_channels=[256],
+                                 query_num_feat=64, num_enc_layers=4, max_num_ne_voxel=20000, pos_encode_method='depth'),
+                   HYBRID_CFG=dict(attn_layer='BiGateSum1D_2', q_method='sum', q_rep_place=['weight']))
+        self.model = VoxelBackBone8xFusion(cfg, 4, [1408, 1600, 40]).to(dev).eval()
+        H, W = 384, 1280
+        self.hw = (H, W)
+        K = np.array([[720., 0, W / 2, 0], [0, 720., H / 2, 0], [0, 0, 1, 0]], np.float32)
+        self.frames = []
+        for f in range(max(1, args.frames)):
+            seed = rank * 1000 + f
+            rs = np.random.RandomState(seed)
+            l2i = []
+            for b in range(B):
+                Tr = np.array([[0, -1, 0, 0.01 * rs.randn()], [0, 0, -1, -0.08], [1, 0, 0, -0.27], [0, 0, 0, 1]], np.float32)
+                l2i.append(K @ Tr)
+            g = torch.Generator().manual_seed(seed)
+            self.frames.append(dict(
+                points=[torch.from_numpy(synth.kitti_sweep(seed=seed * 16 + b)[:, :4].copy()).to(dev) for b in range(B)],
+                l2i=torch.from_numpy(np.stack(l2i)).to(dev),
+                mvx=torch.randn(B, 16, H // 4, W // 4, generator=g).to(dev),
+                img=torch.randn(B, 256, H // 4, W // 4, generator=g).to(dev)))
+
+    def describe(self):
+        return ("Voxel-RCNN + 3D-DF (voxelize+VFE, VoxelBackBone8xFusion: MVX point fusion + ACTRv2 with 3-D local "
+                "self-attention, d_model 64, 4 encoder layers), KITTI 0.05 m voxel, bs=%d, 1 camera [BASELINE configs[4]]"
+                % self.batch)
+
+    @torch.no_grad()
+    def step(self, i, stage):
+        fr = self.frames[i % len(self.frames)]
+        f, c = _voxelize_batch(fr["points"], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 40000)
+        bd = dict(voxel_features=f, voxel_coords=c, batch_size=self.batch, lidar2img=fr["l2i"], image_hw=self.hw,
+                  img_dict={"mvx_layer1_feat2d": fr["mvx"], "layer1_feat2d": fr["img"]})
+        return self.model(bd)
+
+    def check(self, out, stage):
+        assert "encoded_spconv_tensor" in out and bool(torch.isfinite(out["encoded_spconv_tensor"].features).all())
+
+
+def make(args, rank, world, dev):
+    return {"tf_fusion": TransFusionWorkload, "vr_fusion": VoxelRCNNWorkload}[args.workload](args, rank, world, dev)

@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- sweeps/s of the 3D-Dual-Fusion hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic nuScenes-shaped sweeps that are
-already resident in HBM: voxelize + mean VFE -> sparse 3-D backbone (21 fused sparse convs, 8
-rulebooks) [-> dual-query deformable camera fusion] -> dense BEV [B,256,180,180].
-Frames are independent: ranks process different sweeps, no data-path collective (weak scaling).
+With N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks (one process per GPU,
+torch.distributed.run, 127.0.0.1 rendezvous, backend nccl = RCCL over xGMI); launched BY torch.distributed.run it
+reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.  Either way rank 0 prints ONE JSON line.
 
-Besides the driver contract fields the JSON line carries
-  roofline     : dominant kernel, algorithmic flops or bytes per launch / HIP-event time per launch
-  cpu_baseline : the oracle (CPU restatement of the reference algorithm) timed on this box's host
-                 cores on a bounded sample of the same workload (rank 0, N=1 only).
+A "step" (default workload cp_fusion = BASELINE configs[1]) is one pass of the detector's forward over one batch of
+synthetic nuScenes-shaped sweeps resident in HBM, the same at every N:
+    points -> voxelize + mean VFE -> sparse 3-D backbone (21 fused sparse convs, 8 rulebooks) -> dual-query deformable
+    camera fusion (ACTR) -> dense BEV -> RPN neck -> CenterHead -> detection losses (device) -> reduce_dict over the
+    ranks (RCCL reduce of the loss scalars; a no-op at N = 1).
+Frames are independent: ranks process different sweeps (weak scaling); the loss reduction is the path's only
+collective.  Every step takes the NEXT of >= 8 distinct frames (sweep, camera feature maps, calibration, targets) and
+fresh batch_dict / example objects, as a data loader would hand them over.
+
+Besides the driver contract the JSON line carries
+  hot_path      the same K steps ending at the dense BEV tensor (round-1's step), timed in a second pass
+  fp32          both of the above with every sparse conv on the exact-fp32 MFMA kernels (--conv-precision fp32)
+  roofline      dominant sparse-conv kernel: SURVEY 8(d) algorithmic bytes / HIP-event time, measured in the timed region
+  cpu_baseline  the reference's own compiled CPU ops (oracle/_ref) on this box's host cores (rank 0, N = 1 only)
 """
 import argparse
 import json
@@ -29,6 +38,8 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_MFMA_TF = 157.3   # dense fp32 MFMA (= vector) peak
+PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 MFMA peak; the split-precision kernels spend 3 bf16 products per fp32 product
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_spconv_split.json")
 
 
 def parse():
@@ -36,90 +47,184 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=os.environ.get("DF3D_WORKLOAD", "auto"),
-                    help="cp_fusion (BASELINE configs[1]) | cp_lidar (configs[0] shape) | auto")
-    ap.add_argument("--batch", type=int, default=1, help="sweeps per GPU per step")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("DF3D_INFLIGHT", "1")),
-                    help="frames in flight per GPU: each slot is a host thread + HIP stream + model replica; the K "
-                         "timed steps are dealt to the slots (frames are independent).  1 (default) = strictly "
-                         "sequential; 2 gains ~10 %% from K >= 40 steps on, nothing at K = 20")
-    ap.add_argument("--conv-precision", default=os.environ.get("DF3D_CONV_PRECISION", "split"),
-                    choices=["split", "fp32", "bf16"],
-                    help="sparse-conv arithmetic: split (default, fp32-grade: bf16 hi+lo operands, 3 MFMA products), fp32 "
-                         "(exact fp32 MFMA), bf16 (bf16 rows / weights, fp32 accumulate: BASELINE configs[2]-style, NOT the "
-                         "fp32 configs[1] line)")
+    ap.add_argument("--workload", default=os.environ.get("DF3D_WORKLOAD", "cp_fusion"),
+                    choices=["cp_fusion", "cp_lidar", "tf_fusion", "vr_fusion", "protocol"],
+                    help="cp_fusion = BASELINE configs[1] (default, the headline); cp_lidar = configs[0] shape; tf_fusion = "
+                         "configs[2] (TransFusion-L + 3D-DF, bs=4, bf16 convs); vr_fusion = configs[4] (Voxel-RCNN + 3D-DF, "
+                         "KITTI, bs=8); protocol = launcher / barrier / reduce protocol only, no GPU work (CPU tests)")
+    ap.add_argument("--stage", default="detect", choices=["detect", "hot_path"],
+                    help="detect (default): ... -> neck -> head -> losses -> reduce_dict; hot_path: stop at the dense BEV")
+    ap.add_argument("--batch", type=int, default=0, help="sweeps per GPU per step (0 = the workload's BASELINE batch)")
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames the steps rotate through")
+    ap.add_argument("--conv-precision", default=os.environ.get("DF3D_CONV_PRECISION", ""),
+                    choices=["", "split", "fp32", "bf16"],
+                    help="sparse-conv arithmetic: split (fp32-grade: bf16 hi+lo operands, 3 MFMA products), fp32 (exact fp32 "
+                         "MFMA), bf16 (bf16 rows / weights, fp32 accumulate).  Default: split for the fp32 configs, bf16 "
+                         "for tf_fusion (configs[2] is a bf16 config)")
+    ap.add_argument("--backend", default="", help="torch.distributed backend (default nccl = RCCL; gloo for the CPU tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extra-passes", action="store_true", help="skip the hot_path / fp32 passes after the timed region")
+    ap.add_argument("--cpu-sweeps", type=int, default=5, help="sweeps of the CPU baseline at all threads (after 1 warm-up)")
     return ap.parse_args()
 
 
-def build_model(workload, dev):
-    from dualfusion.pipeline import CenterPointHotPath
-    torch.manual_seed(0)
-    fusion = None
-    if workload == "cp_fusion":
-        from dualfusion.fusion import build_centerpoint_fusion
-        fusion = build_centerpoint_fusion()
-    model = CenterPointHotPath(fusion=fusion).eval().to(dev)
-    # BatchNorm running statistics: mean 0 / var 1 defaults
-    return model
+# ------------------------------------------------------------------------------------------------ workloads
+class ProtocolWorkload(object):
+    """No GPU work: exercises exactly the launcher, the barrier / max-over-ranks timing and the loss reduction of this
+    script with any backend (tests/test_dist_gloo.py drives it with gloo on CPU)."""
+    name, unit_name, batch = "protocol", "sweeps", 1
+
+    def __init__(self, args, rank, world, dev):
+        self.rank, self.dev = rank, dev
+
+    def describe(self):
+        return "protocol check: no device work, loss scalars = f(rank) reduced over the ranks"
+
+    def step(self, i, stage):
+        time.sleep(0.002)
+        return {"loss": torch.tensor([1.0 + self.rank], device=self.dev),
+                "hm_loss": torch.tensor([10.0 * (1 + self.rank)], device=self.dev)}
+
+    def check(self, out, stage):
+        pass
 
 
-def make_inputs(workload, batch, rank, dev):
-    from dualfusion import synth
-    pts = [torch.from_numpy(synth.nusc_sweep(seed=rank * 1000 + b)).to(dev) for b in range(batch)]
-    extra = None
-    if workload == "cp_fusion":
-        from dualfusion.fusion import synthetic_camera_inputs
-        extra = synthetic_camera_inputs(batch, dev, seed=1234 + rank)
-    return pts, extra
+class CenterPointWorkload(object):
+    """BASELINE configs[1] (cp_fusion) / configs[0] shape (cp_lidar): CenterPoint voxelnet 0.075 m [+ 3D-DF fusion on six
+    DeepLabV3-shaped camera feature maps], RPN neck, 6-task CenterHead, device losses."""
+    unit_name = "sweeps"
+
+    def __init__(self, args, rank, world, dev):
+        from dualfusion import synth
+        from dualfusion.pipeline import NUSC_TASKS, CenterPointDetector
+        self.name = args.workload
+        self.batch = args.batch or 1
+        self.dev, self.rank = dev, rank
+        torch.manual_seed(0)                          # every rank holds the same replica (BN: mean 0 / var 1 defaults)
+        fusion = None
+        if self.name == "cp_fusion":
+            from dualfusion.fusion import build_centerpoint_fusion
+            fusion = build_centerpoint_fusion()
+        self.model = CenterPointDetector(fusion=fusion).eval().to(dev)
+        self.num_classes = [t["num_class"] for t in NUSC_TASKS]
+        self.frames = []
+        for f in range(max(1, args.frames)):
+            seed = rank * 1000 + f
+            fr = {"points": [torch.from_numpy(synth.nusc_sweep(seed=seed * 16 + b)).to(dev) for b in range(self.batch)]}
+            tg = synth.centerhead_targets(self.batch, self.num_classes, seed=seed)
+            fr["targets"] = {k: [torch.from_numpy(a).to(dev) for a in v] for k, v in tg.items()}
+            if fusion is not None:
+                fr["cam"] = self._camera_frame(seed)
+            self.frames.append(fr)
+
+    def _camera_frame(self, seed, raw_hw=(900, 1600), image_scale=2.0 / 3.0, feat_hw=(150, 267)):
+        """Camera-side inputs of ONE frame: the 2-D network's output for its B*6 images as one tensor, the per-sample
+        calibration (the rig yaw differs from frame to frame, as nuScenes' lidar2cam does) and the image shapes."""
+        from dualfusion import synth
+        B = self.batch
+        feats = torch.from_numpy(synth.camera_features(B * 6, 256, feat_hw, 1234 + seed).reshape(
+            B, 6, 256, feat_hw[0], feat_hw[1])).to(self.dev)
+        cams = synth.nusc_cameras(image_hw=raw_hw, yaw_offset_deg=0.37 * (seed % 97))
+        H, W = int(round(raw_hw[0] * image_scale)), int(round(raw_hw[1] * image_scale))
+        calib = {}
+        for name in synth.NUSC_CAMS:
+            T, K = cams[name]
+            ck = name.lower().lstrip('cam_')
+            calib['lidar2cam_' + ck] = torch.from_numpy(np.stack([T] * B)).to(self.dev)
+            calib['cam_intrinsic_' + ck] = torch.from_numpy(np.stack([K] * B)).to(self.dev)
+        return {"feats": feats, "calib": calib, "shape": [H, W, 3]}
+
+    def fresh_inputs(self, fr):
+        """New batch_dict / example OBJECTS around the frame's resident tensors -- what a data loader hands over per
+        iteration (nothing downstream may key a cache on the identity of these dicts)."""
+        from dualfusion import synth
+        example = {k: list(v) for k, v in fr["targets"].items()}
+        if "cam" not in fr:
+            return None, example
+        cam = fr["cam"]
+        bd = {'image_shape': {}, 'img_feat': {'layer1_ori_feat2d': {}}, 'calib': dict(cam["calib"])}
+        for i, name in enumerate(synth.NUSC_CAMS):
+            key = name.lower()
+            bd['image_shape'][key] = torch.tensor([cam["shape"]] * self.batch)
+            bd['img_feat']['layer1_ori_feat2d'][key] = cam["feats"][:, i]
+        return bd, example
+
+    def describe(self):
+        return {"cp_fusion": "CenterPoint + 3D-DF detector forward (voxelize+VFE, SpMiddleResNetFHDFusion, ACTR dual-query "
+                             "fusion on 6 synthetic DeepLabV3-shaped cam feats, dense BEV, RPN neck, CenterHead, detection "
+                             "losses), 0.075 m voxel, fp32 [BASELINE configs[1]]",
+                "cp_lidar": "CenterPoint voxelnet 0.075 m detector forward, LiDAR branch only (voxelize+VFE, "
+                            "SpMiddleResNetFHD, dense BEV, RPN neck, CenterHead, detection losses), fp32 [BASELINE "
+                            "configs[0] shape; camera fusion not in this line]"}[self.name]
+
+    def step(self, i, stage):
+        fr = self.frames[i % len(self.frames)]
+        bd, example = self.fresh_inputs(fr)
+        if stage == "hot_path":
+            hp = self.model.hot_path
+            neck, hp.neck, hp.backbone.dense_layout = hp.neck, None, "nchw"
+            try:
+                return hp(fr["points"], batch_dict=bd, example=example)[0]
+            finally:
+                hp.neck, hp.backbone.dense_layout = neck, "rows"
+        return self.model(fr["points"], batch_dict=bd, example=example, return_loss=True)
+
+    def check(self, out, stage):
+        if stage == "hot_path":
+            assert tuple(out.shape) == (self.batch, 256, 180, 180), out.shape
+        else:
+            v = out["loss"].float().cpu()
+            assert v.shape == (6,) and bool(torch.isfinite(v).all()), v
 
 
-def run_step(model, pts, extra):
-    if extra is None:
-        return model(pts)
-    return model(pts, batch_dict=extra[0], example=extra[1])
+def make_workload(args, rank, world, dev):
+    if args.workload == "protocol":
+        return ProtocolWorkload(args, rank, world, dev)
+    if args.workload in ("cp_fusion", "cp_lidar"):
+        return CenterPointWorkload(args, rank, world, dev)
+    from dualfusion.workloads import make as make_tree_workload      # tf_fusion / vr_fusion (configs[2] / [4])
+    return make_tree_workload(args, rank, world, dev)
 
 
-PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 MFMA peak; the split-precision kernels spend 3 bf16 products per fp32 product
-
-
+# ------------------------------------------------------------------------------------------------ roofline
 def conv_algorithmic(rec, pairs):
-    """SURVEY.md section 8(d) per launch: every valid (output, offset) pair reads one input row, every output row
-    is written once (twice when the epilogue also emits the split rows the next layer gathers), plus the
-    neighbour table and the filter bank:
-        bytes = R*Cin*4 + N_out*Cout*4*(1 or 2) + K*N_out*4 + K*Cin*Cout*4 ;  flops = 2*R*Cin*Cout."""
+    """SURVEY.md section 8(d), per launch:  bytes = R*Cin*s + N_out*Cout*s + 8*R + K*Cin*Cout*s ;  flops = 2*R*Cin*Cout
+    (R = valid rulebook pairs, s = bytes per element of the rows: 4, or 2 for the bf16 kernels).  Every output row is
+    counted ONCE: the second copy the split-precision epilogue writes for the next layer (hi/lo bf16 rows) is an
+    implementation choice, reported separately as `extra_written_bytes_per_launch`."""
     cin, cout, K, n_out = rec["cin"], rec["cout"], rec["kvol"], rec["n_out"]
-    if rec["split"] == 2:      # bf16 kernel: 2-byte rows and weights; it writes bf16 rows and an fp32 copy of the result
-        by = pairs * cin * 2 + n_out * cout * (2 + 4) + K * n_out * 4 + K * cin * cout * 2
-    else:
-        by = pairs * cin * 4 + n_out * cout * 4 * (2 if rec["split"] else 1) + K * n_out * 4 + K * cin * cout * 4
-    return by, 2 * pairs * cin * cout
+    s = 2 if rec["split"] == 2 else 4
+    by = pairs * cin * s + n_out * cout * s + 8 * pairs + K * cin * cout * s
+    extra = n_out * cout * 4 if rec["split"] else 0
+    return by, 2 * pairs * cin * cout, extra
 
 
 def roofline_from_timer(timer, meta_timer):
-    """Dominant sparse-conv kernel of the timed region: HIP-event time per launch (timer) against the algorithmic
-    bytes / flops of the same launches (pair counts from `meta_timer`, an extra untimed step with identical
-    inputs).  Bound = whichever roof the kernel's arithmetic intensity puts it under: fp32 MFMA (157 TF) for the
-    exact-fp32 kernels, bf16 MFMA / 3 for the split-precision kernels, HBM otherwise."""
+    """Dominant sparse-conv kernel of the timed region: HIP-event time per launch (`timer`) against the algorithmic
+    bytes / flops of the same launches (pair counts from `meta_timer`: one extra untimed pass over every frame).
+    Bound = whichever roof the kernel's arithmetic intensity puts it under: fp32 MFMA (157 TF) for the exact-fp32
+    kernels, bf16 MFMA / 3 for the split-precision kernels, HBM otherwise."""
     pairs_of = {}
     for r in meta_timer.records:
         pairs_of.setdefault((r["cin"], r["cout"], r["kvol"], r["n_out"]), []).append(r["pairs"])
     groups = {}
     for r in timer.records:
         key = (r["cin"], r["cout"], r["kvol"], r["split"])
-        g = groups.setdefault(key, {"ms": 0.0, "n": 0, "by": 0, "fl": 0, "miss": 0})
+        g = groups.setdefault(key, {"ms": 0.0, "n": 0, "by": 0, "fl": 0, "extra": 0, "miss": 0, "n_out": 0})
         g["ms"] += r["ms"]
         g["n"] += 1
+        g["n_out"] += r["n_out"]
         cand = pairs_of.get((r["cin"], r["cout"], r["kvol"], r["n_out"]))
         if not cand:
             g["miss"] += 1
             continue
         # layers of one stage share the rulebook (same n_out -> same R); distinct tables of equal n_out average
         R = sum(cand) // len(cand)
-        by, fl = conv_algorithmic(r, R)
+        by, fl, extra = conv_algorithmic(r, R)
         g["by"] += by
         g["fl"] += fl
+        g["extra"] += extra
     if not groups:
         return None, {}
     key = max(groups, key=lambda k: groups[k]["ms"])
@@ -127,7 +232,7 @@ def roofline_from_timer(timer, meta_timer):
     g = groups[key]
     sec = g["ms"] * 1e-3
     counted = max(g["n"] - g["miss"], 1)
-    by, fl = g["by"] * g["n"] // counted, g["fl"] * g["n"] // counted
+    by, fl, extra = (g[k] * g["n"] // counted for k in ("by", "fl", "extra"))
     mfma_peak = PEAK_BF16_MFMA_TF if split == 2 else (PEAK_BF16_MFMA_TF / 3.0 if split else PEAK_FP32_MFMA_TF)
     ai = fl / max(by, 1)
     if ai >= mfma_peak * 1e12 / (PEAK_HBM_GBS * 1e9):
@@ -140,20 +245,30 @@ def roofline_from_timer(timer, meta_timer):
                 "frac": round(ach / PEAK_HBM_GBS, 4)}
     kname = ("spconv_os_split_kernel" if split else ("spconv_pair_kernel" if cout == 128 and cin >= 64
                                                      else "spconv_mfma_kernel"))
+    n_out_avg = g["n_out"] // g["n"]
+    s = 2 if split == 2 else 4
     roof.update({"traffic": None, "kernel": "%s<cin=%d,cout=%d,K=%d>" % (kname, cin, cout, K),
                  "precision": ("bf16 rows and weights, fp32 accumulate" if split == 2 else
                                "split bf16 hi/lo operands, 3 MFMA products, fp32 accumulate" if split else "fp32 MFMA"),
                  "launches": g["n"], "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),
                  "algorithmic_flops_per_launch": fl // g["n"], "algorithmic_bytes_per_launch": by // g["n"],
+                 "extra_written_bytes_per_launch": extra // g["n"],
                  "arithmetic_intensity_flop_per_byte": round(ai, 1)})
+    if K == 27:
+        # SubM layer (n_in = n_out): every input row once, every output row once, the neighbour table, the filter bank
+        roof["compulsory_bytes"] = n_out_avg * cin * s + n_out_avg * cout * s + 4 * K * n_out_avg + K * cin * cout * s
     # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; PMC cannot be
-    # read from inside the process).  The committed summary of the last such run is attached when it belongs to
-    # the same kernel; otherwise null.
+    # read from inside the process).  The committed summary of the last such run is attached when it belongs to the
+    # same kernel; otherwise null.
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_spconv_split.json")))
+        pm = json.load(open(PMC_SUMMARY))
         if pm.get("kernel_key") == [cin, cout, K, split]:
             roof["traffic"] = pm["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_pmc_spconv_split.json (rocprofv3 --pmc, separate passes)"
+            roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, separate passes, same command)" % os.path.basename(PMC_SUMMARY)
+            # what the HBM interface really moved during this kernel, against the 8 TB/s peak
+            roof["hbm_measured_frac"] = round(pm["traffic_bytes_per_launch"] / (g["ms"] * 1e-3 / g["n"]) / (PEAK_HBM_GBS * 1e9), 4)
+            if "fetch_calibration" in pm:
+                roof["fetch_calibration"] = pm["fetch_calibration"]
     except Exception:
         pass
     per_kernel = {"%dx%d_k%d%s" % (k[0], k[1], k[2], "_split" if k[3] else ""):
@@ -161,204 +276,260 @@ def roofline_from_timer(timer, meta_timer):
     return roof, per_kernel
 
 
-def cpu_baseline(workload, model, cam_np, budget_s=30.0):
-    """The oracle composition (tests/oracle_models.py over oracle/oracle.py) of the SAME workload with the
-    SAME weights on this box's host cores: voxelize -> VFE -> sparse backbone [-> projection, image gate,
-    ACTR, write-back] -> dense.  Bounded: whole sweeps until ~budget_s have elapsed (at least one)."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, n_sweeps=5):
+    """The reference's CPU path on this box's host cores, same workload, same weights, one sweep at a time:
+      voxelize        oracle/_ref/voxel_layer.so `hard_voxelize` (TF/mmdet3d/ops/voxel/src/voxelization_cpu.cpp)
+      sparse backbone oracle/_ref/sparse_conv_ext.so `get_indice_pairs_3d` + `indice_conv_fp32` (the reference's own
+                      compiled CPU rulebook + gather/GEMM/scatter, spconv_ops.h:27-141,260-361), BN / ReLU in numpy
+      camera fusion   the oracle port (tests/oracle_models.py: projection, gate, ACTR through torch-CPU fp32) -- the
+                      reference has no CPU build of its MSDA op
+      neck+head+loss  the mirror modules' torch composition on the CPU (= the reference's own torch layers)
+    1 warm-up sweep, then `n_sweeps` timed sweeps with all threads (median), 2 with one thread."""
     import oracle_models as om
     from oracle import oracle as orc
+    from oracle import ref
     from dualfusion import synth
-    from dualfusion.fusion import CP_DEPTH_THRES
+    if not (ref.available("sparse_conv_ext") and ref.available("voxel_layer")):
+        return {"value": None, "unit": "sweeps/s", "cores": 0, "kind": "reference",
+                "sample": "oracle/_ref/*.so missing on this box (built where /root/reference exists)"}
+    model = wl.model
     sd_all = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    sd = {k[len("backbone."):]: v for k, v in sd_all.items() if k.startswith("backbone.")}
-    sd_f = {k[len("fusion."):]: v for k, v in sd_all.items() if k.startswith("fusion.")}
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    cores = max(cores, torch.get_num_threads())
-    n, t0 = 0, time.perf_counter()
-    while True:
-        pts = synth.nusc_sweep(seed=n)
-        t1 = time.perf_counter()
-        ov, oc, on = orc.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000, "numba")
+    sd = {k[len("hot_path.backbone."):]: v for k, v in sd_all.items() if k.startswith("hot_path.backbone.")}
+    sd_f = {k[len("hot_path.fusion."):]: v for k, v in sd_all.items() if k.startswith("hot_path.fusion.")}
+    import copy
+    neck_cpu = copy.deepcopy(model.neck).cpu().eval()
+    head_cpu = copy.deepcopy(model.bbox_head).cpu().eval()
+    all_threads = torch.get_num_threads()
+    fusion_on = wl.name == "cp_fusion"
+
+    def one_sweep(seed, fr):
+        st = {}
+        pts = synth.nusc_sweep(seed=seed)
+        t0 = time.perf_counter()
+        ov, oc, on = ref.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000)
         feats = orc.mean_vfe(ov, on)
+        st["voxelize"] = time.perf_counter() - t0
         coors = np.concatenate([np.zeros((len(oc), 1), np.int32), oc], 1)
         fuse = None
-        if workload == "cp_fusion":
-            img, calib, hw = cam_np
+        if fusion_on:
+            from dualfusion.fusion import CP_DEPTH_THRES
+            cam = fr["cam"]
+            img = {n: cam["feats"][:, i].cpu().numpy() for i, n in enumerate(synth.NUSC_CAMS)}
+            calib = {n: (cam["calib"]['lidar2cam_' + n.lower().lstrip('cam_')].cpu().numpy(),
+                         cam["calib"]['cam_intrinsic_' + n.lower().lstrip('cam_')].cpu().numpy()) for n in synth.NUSC_CAMS}
+            hw = tuple(cam["shape"][:2])
 
             def fuse(c2, c3, c4):
-                out = om.centerpoint_fusion(sd_f, [(c.indices, c.features) for c in (c2, c3, c4)], img, calib, hw,
-                                            synth.NUSC_CAMS, synth.NUSC_VOXEL, synth.NUSC_RANGE, 2.0 / 3.0,
-                                            CP_DEPTH_THRES)
+                t1 = time.perf_counter()
+                with om.using(orc):
+                    out = om.centerpoint_fusion(sd_f, [(c.indices, c.features) for c in (c2, c3, c4)], img, calib, hw,
+                                                synth.NUSC_CAMS, synth.NUSC_VOXEL, synth.NUSC_RANGE, 2.0 / 3.0,
+                                                CP_DEPTH_THRES)
+                st["fusion_port"] = time.perf_counter() - t1
                 c4.features = out
                 return c4
-        om.centerpoint_backbone(sd, feats, coors, 1, [1440, 1440, 40], fuse=fuse)
-        n += 1
-        dt = time.perf_counter() - t1
-        if time.perf_counter() - t0 + dt > budget_s or n >= 8:
-            break
-    total = time.perf_counter() - t0
-    what = "voxelize+VFE+sparse backbone+camera fusion (projection, gate, ACTR)+dense" if workload == "cp_fusion" \
-        else "voxelize+VFE+sparse backbone+dense, LiDAR branch"
-    return {"value": round(n / total, 4), "unit": "sweeps/s", "cores": int(cores), "kind": "port",
-            "sample": "%d whole synthetic sweeps (%s; C for index work, numpy/BLAS + torch-CPU fp32 for the dense "
-                      "layers), %.1f s wall; host cpu_count=%d" % (n, what, total, os.cpu_count() or 0)}
+        om.STAGE_SECONDS.clear()
+        t0 = time.perf_counter()
+        with om.using(ref):
+            bev, _ = om.centerpoint_backbone(sd, feats, coors, 1, [1440, 1440, 40], fuse=fuse)
+        st["backbone"] = time.perf_counter() - t0 - st.get("fusion_port", 0.0)
+        st["backbone_rulebook"] = om.STAGE_SECONDS.get("rulebook", 0.0)
+        st["backbone_conv"] = om.STAGE_SECONDS.get("conv", 0.0)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            x = neck_cpu.forward_reference(torch.from_numpy(np.ascontiguousarray(bev)))
+            preds = head_cpu.forward_reference(x)
+            ex = {k: [a[:1].cpu() for a in v] for k, v in fr["targets"].items()}
+            head_cpu.loss(ex, preds, {})
+        st["neck_head_loss"] = time.perf_counter() - t0
+        st["total"] = sum(v for k, v in st.items() if k in ("voxelize", "backbone", "fusion_port", "neck_head_loss"))
+        return st
+
+    runs = {}
+    t_all = time.perf_counter()
+    for threads, n in ((all_threads, n_sweeps + 1), (1, 2)):
+        torch.set_num_threads(threads)
+        rs = [one_sweep(i, wl.frames[i % len(wl.frames)]) for i in range(n)]
+        runs[threads] = rs[1:] if threads == all_threads else rs        # first all-thread sweep = warm-up
+    torch.set_num_threads(all_threads)
+    wall = time.perf_counter() - t_all
+
+    def med(rs, k):
+        return float(np.median([r.get(k, 0.0) for r in rs]))
+    stages = ("voxelize", "backbone", "backbone_rulebook", "backbone_conv", "fusion_port", "neck_head_loss", "total")
+    per = {str(t): {k: round(med(rs, k), 4) for k in stages} for t, rs in runs.items()}
+    total = med(runs[all_threads], "total")
+    return {"value": round(1.0 / total, 4), "unit": "sweeps/s", "cores": int(all_threads), "kind": "reference",
+            "cpu_model": cpu_model_string(), "host_cpu_count": os.cpu_count() or 0,
+            "seconds_per_sweep_median_by_threads": per,
+            "value_one_thread": round(1.0 / med(runs[1], "total"), 4),
+            "sample": "%d whole synthetic sweeps after 1 warm-up at %d threads (median) + 2 at 1 thread; voxelize and the "
+                      "sparse backbone on the reference's compiled CPU ops (oracle/_ref: hard_voxelize, get_indice_pairs_3d, "
+                      "indice_conv_fp32)%s, neck + head + loss on torch CPU fp32; %.0f s wall" % (
+                          len(runs[all_threads]), all_threads,
+                          ", camera fusion through the oracle port (kind 'port' for that stage)" if fusion_on else "", wall)}
+
+
+# ------------------------------------------------------------------------------------------------ main
+def timed_steps(wl, stage, steps, first, barrier, reduce_losses):
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for k in range(steps):
+        out = wl.step(first + k, stage)
+        if isinstance(out, dict) and stage == "detect":
+            out = reduce_losses(out)
+    barrier()                                  # synchronises the device (all streams) and the ranks
+    return time.perf_counter() - t0, out
 
 
 def main():
     args = parse()
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback on the product path)"
     from dualfusion import dist as D
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(D.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    protocol = args.workload == "protocol"
+    if not protocol:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback on the product path)"
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    rank, local, world = D.init_from_env("nccl")                # nccl == RCCL on ROCm (xGMI inside a node)
-    workload = args.workload
-    if workload == "auto":
-        try:
-            import dualfusion.fusion  # noqa: F401
-            workload = "cp_fusion"
-        except Exception:
-            workload = "cp_lidar"
-    from dualfusion import ops
-    ops.CONV_PRECISION = args.conv_precision
-    nslots = max(1, min(args.inflight, args.steps))
-    # one slot = model replica (same seed -> same weights) + the same synthetic frame + its own HIP stream
-    slots = []
-    for _ in range(nslots):
-        m = build_model(workload, dev)
-        p, e = make_inputs(workload, args.batch, rank, dev)
-        slots.append((m, p, e, torch.cuda.Stream(device=dev) if nslots > 1 else None))
-    model, pts, extra, _ = slots[0]
-    outs = [None] * nslots
+    use_gpu = torch.cuda.is_available() and args.backend != "gloo"
+    if use_gpu:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    rank, local, world = D.init_from_env(args.backend or ("nccl" if use_gpu else "gloo"))   # nccl == RCCL on ROCm
+    assert world == max(1, args.gpus), "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    precision = args.conv_precision or ("bf16" if args.workload == "tf_fusion" else "split")
+    if not protocol:
+        from dualfusion import ops
+        ops.CONV_PRECISION = precision
+    wl = make_workload(args, rank, world, dev)
+    stage = args.stage
 
     def barrier():
-        D.barrier(dev)
+        D.barrier(dev if use_gpu else None)
 
-    def work(i, n):
-        m, p, e, st = slots[i]
-        if st is None:
-            for _ in range(n):
-                outs[i] = run_step(m, p, e)
-            return
-        torch.cuda.set_device(dev)
-        with torch.cuda.stream(st):
-            for _ in range(n):
-                outs[i] = run_step(m, p, e)
+    def reduce_losses(losses):
+        return D.reduce_dict(losses)            # CP/det3d/torchie/trainer/utils.py:157-183: rank 0 holds the average
 
-    for i in range(nslots):
-        work(i, max(args.warmup, 1) if nslots > 1 else args.warmup)
-    torch.cuda.synchronize()
-    share = [args.steps // nslots + (1 if i < args.steps % nslots else 0) for i in range(nslots)]
-    # Per-kernel HIP events live in the timed region only when one frame is in flight: with two, an event pair around
-    # a launch also times whatever the other frame's stream co-runs, and the event packets serialise the queues
-    # (measured: 580 -> 436 sweeps/s).  With frames in flight the roofline is therefore measured in a second pass of
-    # the same K steps, sequentially, right after the timed region (reported with its own ms_per_step).
-    # Events around EVERY conv launch cost the timed region ~6 % (30 launches per frame).  The roofline needs the
-    # dominant kernel only: one untimed probe step with all events finds it (and yields the per-kernel table), the
-    # timed region then records events around its launches alone.
-    timer, probe = None, None
-    if not args.no_kernel_timing:
+    for k in range(args.warmup):
+        out = wl.step(k, stage)
+        if isinstance(out, dict) and stage == "detect":
+            out = reduce_losses(out)
+    barrier()
+    # Roofline: HIP events around EVERY conv launch cost the timed region ~6 % (30 launches per frame).  The roofline
+    # needs the dominant kernel only: one untimed probe step with all events finds it (and yields the per-kernel
+    # table), the timed region then records events around its launches alone.
+    timer = probe = meta_timer = None
+    kernel_timing = not (args.no_kernel_timing or protocol)
+    if kernel_timing:
         probe = ops.KernelTimer()
         probe.start()
-        run_step(model, pts, extra)
+        wl.step(0, stage)
         torch.cuda.synchronize()
         probe.stop()
         tot = {}
         for r in probe.records:
-            k = (r["cin"], r["cout"], r["kvol"])
-            tot[k] = tot.get(k, 0.0) + r["ms"]
+            if r["kvol"] == 27:                  # the 3-D sparse convolutions (the neck / head reuse the kernel with K = 9)
+                k = (r["cin"], r["cout"], r["kvol"])
+                tot[k] = tot.get(k, 0.0) + r["ms"]
         timer = ops.KernelTimer(only=max(tot, key=tot.get)) if tot else ops.KernelTimer()
-    if nslots > 1:
-        import threading
-        threads = [threading.Thread(target=work, args=(i, share[i])) for i in range(nslots)]
-    barrier()
-    if timer is not None and nslots == 1:
         timer.start()
-    t0 = time.perf_counter()
-    if nslots == 1:
-        work(0, args.steps)
-    else:
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-    barrier()                                  # synchronises the device (all streams) and the ranks
-    elapsed = time.perf_counter() - t0
-    out = outs[0]
-    seq_elapsed = None
-    if timer is not None and nslots > 1:
-        timer.start()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            run_step(model, pts, extra)
-        barrier()
-        seq_elapsed = time.perf_counter() - t1
+    elapsed, out = timed_steps(wl, stage, args.steps, args.warmup, barrier, reduce_losses)
     if timer is not None:
         timer.stop()
-        # metadata pass, outside the timed region: one more step with the same inputs that counts the valid
-        # rulebook pairs of every conv launch (the unit the algorithmic bytes are stated in)
+    elapsed = D.max_over_ranks(elapsed, dev)
+    wl.check(out, stage)
+    extra = {}
+    if not (args.no_extra_passes or protocol):
+        # the same K steps ending at the dense BEV tensor (round 1's step), and both stages on the exact-fp32 kernels
+        if stage == "detect":
+            wl.step(0, "hot_path")
+            e, o = timed_steps(wl, "hot_path", args.steps, args.warmup, barrier, reduce_losses)
+            wl.check(o, "hot_path")
+            extra["hot_path"] = D.max_over_ranks(e, dev)
+        if precision == "split" and args.workload in ("cp_fusion", "cp_lidar"):
+            ops.CONV_PRECISION = "fp32"
+            try:
+                for st in (["detect", "hot_path"] if stage == "detect" else ["hot_path"]):
+                    for k in range(3):
+                        o = wl.step(k, st)
+                        if isinstance(o, dict) and st == "detect":
+                            reduce_losses(o)
+                    e, o = timed_steps(wl, st, args.steps, args.warmup, barrier, reduce_losses)
+                    wl.check(o, st)
+                    extra["fp32_" + st] = D.max_over_ranks(e, dev)
+            finally:
+                ops.CONV_PRECISION = precision
+    if kernel_timing:
+        # metadata pass, outside the timed region: every frame once more, counting the valid rulebook pairs of every
+        # conv launch (the unit the algorithmic bytes are stated in)
         meta_timer = ops.KernelTimer(count_pairs=True)
         meta_timer.start()
-        run_step(model, pts, extra)
+        for k in range(len(getattr(wl, "frames", [0]))):
+            wl.step(k, stage)
         torch.cuda.synchronize()
         meta_timer.stop()
-    elapsed = D.max_over_ranks(elapsed, dev)
-    dense = out[0]
-    assert tuple(dense.shape) == (args.batch, 256, 180, 180), dense.shape
     if rank == 0:
-        sweeps = args.steps * args.batch * world
+        units = args.steps * wl.batch * world
+        per_step = lambda e: round(e / args.steps * 1e3, 4)      # noqa: E731
         res = {
-            "metric": "nuScenes sweeps/sec (0.075 m voxel, ~60k pts)", "value": round(sweeps / elapsed, 3),
-            "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "metric": getattr(wl, "metric", "nuScenes sweeps/sec (0.075 m voxel, ~60k pts)"), "value": round(units / elapsed, 3),
+            "unit": wl.unit_name + "/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": per_step(elapsed), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"split": "f32 (C>=64 sparse convs and the FFN: operands split into bf16 hi+lo, 3 MFMA products, fp32 "
-                               "accumulate, ~1e-5 rel. error; everything else exact fp32)",
+            "dtype": {"split": "f32 (C>=32 sparse convs, neck / head convs and the FFN: operands split into bf16 hi+lo, 3 MFMA "
+                               "products, fp32 accumulate, ~1e-5 rel. error; everything else exact fp32)",
                       "fp32": "f32 (exact fp32 MFMA convolutions; FFN split precision)",
                       "bf16": "bf16 sparse convs (bf16 rows and weights, fp32 accumulate and epilogue); fusion adapter, "
-                              "ACTR and C<=16 layers f32 -- NOT the fp32 configs[1] line"}[args.conv_precision],
+                              "ACTR and C<=16 layers f32"}[precision] if not protocol else "none",
             "data": "synthetic",
-            "config": {"workload": {"cp_fusion": "CenterPoint + 3D-DF hot path (voxelize+VFE, SpMiddleResNetFHDFusion, "
-                                                 "ACTR dual-query fusion on 6 synthetic DeepLabV3-shaped cam feats, dense BEV), "
-                                                 "0.075 m voxel, fp32 [BASELINE configs[1]]",
-                                    "cp_lidar": "CenterPoint voxelnet 0.075 m hot path, LiDAR branch only (voxelize+VFE, "
-                                                "SpMiddleResNetFHD, dense BEV), fp32 [BASELINE configs[0] shape; camera fusion not in this line]"}[workload],
-                       "frames_in_flight_per_gpu": nslots, "sweeps_per_gpu_per_step": args.batch, "points_per_sweep": int(pts[0].shape[0]),
-                       "global_batch": args.batch * world, "parallelism": "dp%d (frames sharded, no data-path collective)" % world},
+            "config": {"workload": wl.describe(), "stage": stage, "sweeps_per_gpu_per_step": wl.batch,
+                       "distinct_frames_per_rank": len(getattr(wl, "frames", [0])),
+                       "global_batch": wl.batch * world,
+                       "parallelism": "dp%d (frames sharded over the ranks; the only collective is the reduce of the loss "
+                                      "scalars%s)" % (world, ", RCCL" if use_gpu and world > 1 else "")},
+            "collective_backend": (torch.distributed.get_backend() if D.is_dist() else None), "world_size": world,
         }
-        if timer is not None:
+        if stage == "detect" and isinstance(out, dict) and "encoded_spconv_tensor" not in out:
+            res["reduced_losses"] = {k: [round(float(x), 5) for x in v.reshape(-1).float().cpu()] for k, v in out.items()
+                                     if k in ("loss", "hm_loss", "loc_loss")}
+        if "hot_path" in extra:
+            res["hot_path"] = {"ms_per_step": per_step(extra["hot_path"]), "value": round(units / extra["hot_path"], 3),
+                               "unit": "sweeps/s", "what": "the same K steps ending at the dense BEV tensor [B,256,180,180] "
+                                                           "(no neck / head / losses / reduce): round 1's step"}
+        if "fp32_detect" in extra or "fp32_hot_path" in extra:
+            res["fp32"] = {"what": "every sparse conv on the exact-fp32 MFMA kernels (--conv-precision fp32; neck / head "
+                                   "through torch / MIOpen fp32)"}
+            if "fp32_detect" in extra:
+                res["fp32"]["ms_per_step"] = per_step(extra["fp32_detect"])
+                res["ms_per_step_fp32"] = per_step(extra["fp32_detect"])
+            if "fp32_hot_path" in extra:
+                res["fp32"]["hot_path_ms_per_step"] = per_step(extra["fp32_hot_path"])
+        if kernel_timing:
             roof, _ = roofline_from_timer(timer, meta_timer)
             _, per_kernel = roofline_from_timer(probe, meta_timer)        # all conv kernels, from the untimed probe step
-            if roof is not None and seq_elapsed is not None:
-                roof["measured_over"] = ("second pass of the same %d steps with ONE frame in flight (HIP events around "
-                                         "every conv launch), %.4f ms/step; the timed region above keeps %d frames in "
-                                         "flight without per-kernel events" % (args.steps, seq_elapsed / args.steps * 1e3,
-                                                                               nslots))
-                res["sequential_ms_per_step"] = round(seq_elapsed / args.steps * 1e3, 4)
-            elif roof is not None:
-                roof["measured_over"] = ("the timed region (one frame in flight; HIP events around the launches of this "
-                                         "kernel only -- it was picked by an untimed probe step with events on every launch)")
+            if roof is not None:
+                roof["measured_over"] = ("the timed region (HIP events around the launches of this kernel only -- it was "
+                                         "picked by an untimed probe step with events on every launch)")
             res["roofline"] = roof
             res["conv_kernel_ms_probe_step"] = per_kernel
-        if world == 1 and not args.no_cpu_baseline:
-            cam_np = None
-            if workload == "cp_fusion":
-                bd = extra[0]
-                from dualfusion import synth
-                img = {n: bd['img_feat']['layer1_ori_feat2d'][n.lower()].cpu().numpy() for n in synth.NUSC_CAMS}
-                calib = {n: (bd['calib']['lidar2cam_' + n.lower().lstrip('cam_')].cpu().numpy(),
-                             bd['calib']['cam_intrinsic_' + n.lower().lstrip('cam_')].cpu().numpy())
-                         for n in synth.NUSC_CAMS}
-                hw = tuple(int(v) for v in bd['image_shape']['cam_front'][0][:2])
-                cam_np = (img, calib, hw)
-            res["cpu_baseline"] = cpu_baseline(workload, model, cam_np)
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("cp_fusion", "cp_lidar"):
+            res["cpu_baseline"] = cpu_baseline(wl, args.cpu_sweeps)
         print(json.dumps(res))
+        sys.stdout.flush()
     if D.is_dist():
-        D.barrier(dev)
+        barrier()
         torch.distributed.destroy_process_group()
 
 

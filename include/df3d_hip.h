@@ -286,6 +286,32 @@ int df3d_centerhead_predict(const df3d_head_task *tasks, int ntasks, const df3d_
                             float *out_scores, int32_t *out_labels, int32_t *out_counts, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* df3d_centerhead_loss replaces CenterHead.loss for a no-grad evaluation of the detection losses
+ * (CP/det3d/models/bbox_heads/center_head.py:250-298 over FastFocalLoss / RegLoss,
+ * CP/det3d/models/losses/centernet_loss.py:6-58): per task the CornerNet focal loss of the clamped sigmoid heat map
+ * and the code-weighted L1 loss of the box regressions gathered at the object slots -- the scalars the data-parallel
+ * step reduces over the ranks (`reduce_dict`, CP/det3d/torchie/trainer/utils.py:157-183).  Two launches for all tasks
+ * and samples, no host round trip (the reference: ~25 launches and two `.cpu()` per task).
+ *   tasks: head maps as channels-last pixel rows (as for df3d_centerhead_predict; label_base unused);
+ *   targets (per task, what the reference's assigner puts into `example`): hm [B, classes, H, W] f32,
+ *   ind [B, max_objs] i64 (flat pixel), mask [B, max_objs] u8, cat [B, max_objs] i64, box = anno_box
+ *   [B, max_objs, box_dim] f32 (10 codes: reg 2, height 1, dim 3, vel 2, rot 2; heads without vel compare columns
+ *   [0..5, -2, -1], center_head.py:229); code_weights: HOST array [ncodes] (10 with vel, 8 without).
+ *   out [ntasks][DF3D_LOSS_FIELDS] f32: loss, hm_loss, loc_loss, num_positive, loc_loss_elem[DF3D_LOSS_MAX_CODES]. */
+#define DF3D_LOSS_MAX_CODES 10
+#define DF3D_LOSS_FIELDS (4 + DF3D_LOSS_MAX_CODES)
+typedef struct df3d_head_targets {
+  const float *hm;
+  const long long *ind;
+  const unsigned char *mask;
+  const long long *cat;
+  const float *box;
+} df3d_head_targets;
+size_t df3d_centerhead_loss_workspace_bytes(int ntasks, int batch, int H, int W);
+int df3d_centerhead_loss(const df3d_head_task *tasks, const df3d_head_targets *targets, int ntasks, int batch, int H, int W,
+                         int max_objs, int box_dim, const float *code_weights, int ncodes, float weight, float *out,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * TransFusionHead (LiDAR-only branch), the index and decode steps.
  *

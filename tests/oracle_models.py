@@ -19,15 +19,43 @@ class SpTensor(object):
         self.rulebooks = rulebooks if rulebooks is not None else {}
 
 
+# the two index / convolution providers a composition can run on: the restatement (`oracle.oracle`) or the
+# reference's own compiled CPU code (`oracle.ref`, oracle/_ref/*.so); both expose get_indice_pairs / indice_conv
+_IMPL = [orc]
+
+
+class using(object):
+    """with using(ref): ... -- run the compositions below on another provider (e.g. the reference's compiled CPU ops)."""
+
+    def __init__(self, impl):
+        self.impl = impl
+
+    def __enter__(self):
+        _IMPL.append(self.impl)
+
+    def __exit__(self, *exc):
+        _IMPL.pop()
+
+
+STAGE_SECONDS = {}      # filled when timing is on: {'rulebook': s, 'conv': s}
+
+
 def _conv(sd, prefix, x, ks, stride, padding, subm, key=None):
+    import time
+    impl = _IMPL[-1]
     w = sd[prefix + ".weight"]
     rb = x.rulebooks.get(key) if key is not None else None
+    t0 = time.perf_counter()
     if rb is None:
-        rb = orc.get_indice_pairs(x.indices, x.batch, x.shape, ks, stride, padding, [1, 1, 1], subm)
+        rb = impl.get_indice_pairs(x.indices, x.batch, x.shape, ks, stride, padding, [1, 1, 1], subm)
         if key is not None:
             x.rulebooks[key] = rb
     outids, pairs, num, oshape = rb
-    y = orc.indice_conv(x.features, w, pairs, num, len(outids), subm)
+    t1 = time.perf_counter()
+    y = impl.indice_conv(x.features, w, pairs, num, len(outids), subm)
+    t2 = time.perf_counter()
+    STAGE_SECONDS["rulebook"] = STAGE_SECONDS.get("rulebook", 0.0) + (t1 - t0)
+    STAGE_SECONDS["conv"] = STAGE_SECONDS.get("conv", 0.0) + (t2 - t1)
     if prefix + ".bias" in sd:
         y = y + sd[prefix + ".bias"]
     return SpTensor(y.astype(np.float32), outids, oshape, x.batch, x.rulebooks)

@@ -50,3 +50,53 @@ def test_two_rank_gloo(tmp_path):
     assert abs(res[0]["elapsed"] - res[1]["elapsed"]) < 1e-9 and res[0]["elapsed"] >= 0.1   # MAX over ranks
     assert abs(res[0]["loss"] - 1.5) < 1e-6 and abs(res[0]["hm"] - 15.0) < 1e-6    # rank 0 holds the average
     assert abs(res[0]["avg"] - 1.5) < 1e-6 and abs(res[1]["avg"] - 1.5) < 1e-6
+
+
+def test_bench_self_spawn_two_ranks_gloo():
+    """`python bench.py --gpus 2` ALONE (no torch.distributed.run around it) starts its own two ranks through
+    dualfusion.dist.launch_ranks -- the same spawn code the GPU run uses -- and rank 0 prints one JSON line with
+    n_gpus = 2 and the rank-averaged loss scalars (protocol workload: no device work, gloo instead of RCCL)."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "protocol",
+                          "--backend", "gloo", "--steps", "4", "--warmup", "1"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["world_size"] == 2 and res["collective_backend"] == "gloo"
+    assert res["steps"] == 4 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["config"]["global_batch"] == 2
+    assert abs(res["reduced_losses"]["loss"][0] - 1.5) < 1e-6 and abs(res["reduced_losses"]["hm_loss"][0] - 15.0) < 1e-6
+    assert res["ms_per_step"] >= 2.0 and abs(res["value"] - 2 * 1e3 / res["ms_per_step"]) < 0.5
+
+
+def test_reduce_dict_mixed_shapes_two_ranks(tmp_path):
+    """reduce_dict with per-task vectors and a matrix in one dict (CenterHead.loss_device's layout): one collective."""
+    worker = textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, os.path.join(%r, "3d-dual-fusion_amd"))
+        import torch
+        from dualfusion import dist as D
+        rank, local, world = D.init_from_env("gloo")
+        d = {"loss": torch.arange(6.0) + rank, "elem": torch.ones(6, 10) * (rank + 1), "n": torch.tensor(4.0 * rank)}
+        r = D.reduce_dict(d)
+        if rank == 0:
+            json.dump({"loss": r["loss"].tolist(), "elem": float(r["elem"].mean()), "shape": list(r["elem"].shape),
+                       "n": float(r["n"])}, open(os.path.join(os.environ["DF3D_TEST_OUT"], "r.json"), "w"))
+        D.barrier()
+        torch.distributed.destroy_process_group()
+    """) % ROOT
+    script = tmp_path / "w.py"
+    script.write_text(worker)
+    sys.path.insert(0, os.path.join(ROOT, "3d-dual-fusion_amd"))
+    from dualfusion import dist as D
+    rc = D.launch_ranks(2, str(script), [], env=dict(os.environ, OMP_NUM_THREADS="1", DF3D_TEST_OUT=str(tmp_path)),
+                        timeout=300)
+    assert rc == 0
+    import json
+    r = json.load(open(os.path.join(str(tmp_path), "r.json")))
+    assert r["loss"] == [0.5, 1.5, 2.5, 3.5, 4.5, 5.5] and abs(r["elem"] - 1.5) < 1e-6 and r["shape"] == [6, 10]
+    assert abs(r["n"] - 2.0) < 1e-6
