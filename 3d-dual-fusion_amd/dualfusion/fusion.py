@@ -445,11 +445,12 @@ def build_centerpoint_fusion(voxel_size=synth.NUSC_VOXEL, pc_range=synth.NUSC_RA
                                     model_name='ACTR')
 
 
-def synthetic_camera_inputs(batch, dev, seed=1234, raw_hw=(900, 1600), image_scale=2.0 / 3.0, feat_hw=(150, 267)):
+def synthetic_camera_inputs(batch, dev, seed=1234, raw_hw=(900, 1600), image_scale=2.0 / 3.0, feat_hw=(150, 267),
+                            yaw_offset_deg=0.0):
     """batch_dict / example with the keys the adapter reads: six synthetic
     DeepLabV3-layer1-shaped feature maps [B,256,150,267] (N(0,1)), calibration of six pinhole cameras
     at 60 deg spacing, scaled image shape (600, 1067)."""
-    cams = synth.nusc_cameras(image_hw=raw_hw)
+    cams = synth.nusc_cameras(image_hw=raw_hw, yaw_offset_deg=yaw_offset_deg)
     H, W = int(round(raw_hw[0] * image_scale)), int(round(raw_hw[1] * image_scale))
     feats = synth.camera_features(batch * 6, 256, feat_hw, seed).reshape(batch, 6, 256, feat_hw[0], feat_hw[1])
     # the camera network's output for the B*6 images is one tensor; the reference hands it on as a dict of

@@ -66,7 +66,9 @@ def test_full_grid_voxelize_and_hot_path_vs_oracle(sweep):
                 m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
                 m.weight.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
                 m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
-    bd, ex = synthetic_camera_inputs(1, DEV, seed=77)
+    # rig turned off the axes: with axis-aligned cameras the voxel lattice projects exactly onto pixel boundaries, where
+    # a 1-ulp difference between two correct implementations flips the reference's truncations (synth.nusc_cameras)
+    bd, ex = synthetic_camera_inputs(1, DEV, seed=77, yaw_offset_deg=7.3)
     pts = T(sweep["points"])
     with torch.no_grad():
         feats, coors = model.voxelize([pts])
@@ -83,8 +85,13 @@ def test_full_grid_voxelize_and_hot_path_vs_oracle(sweep):
     hw = tuple(int(v) for v in bd['image_shape']['cam_front'][0][:2])
 
     def fuse(c2, c3, c4):
-        c4.features = om.centerpoint_fusion(sd_f, [(c.indices, c.features) for c in (c2, c3, c4)], img, calib, hw,
-                                            synth.NUSC_CAMS, synth.NUSC_VOXEL, synth.NUSC_RANGE, 2.0 / 3.0, CP_DEPTH_THRES)
+        # the adapter sees the rows in spconv's GPU order (strided outputs sorted by flat index, spconv_ops.h:119-137);
+        # the CPU rulebook of the oracle emits them in first-touch order, and "last writer wins" on the image plane
+        # depends on that order
+        lv = [tuple(np.ascontiguousarray(a) for a in om.sort_rows(c.indices, c.features)) for c in (c2, c3, c4)]
+        out = om.centerpoint_fusion(sd_f, lv, img, calib, hw, synth.NUSC_CAMS, synth.NUSC_VOXEL, synth.NUSC_RANGE,
+                                    2.0 / 3.0, CP_DEPTH_THRES)
+        c4.indices, c4.features, c4.rulebooks = lv[2][0], out, {}
         return c4
     o_bev, o_ms = om.centerpoint_backbone(sd, sweep["feats"], sweep["coors"], 1, [1440, 1440, 40], fuse=fuse)
     assert tuple(bev.shape) == o_bev.shape == (1, 256, 180, 180)
@@ -94,7 +101,9 @@ def test_full_grid_voxelize_and_hot_path_vs_oracle(sweep):
         assert np.array_equal(mi, oi), name                                       # index sets: bit-exact
         assert len(mi) > 20000
         scale = np.abs(of).max()
-        assert np.abs(mf - of).max() <= 1e-3 * scale, (name, np.abs(mf - of).max() / scale)
+        err = np.abs(mf - of).max(1) / scale
+        assert err.max() <= 1e-3, (name, "max rel err %.3e, rows above 1e-3: %d of %d, above 1e-2: %d" % (
+            err.max(), int((err > 1e-3).sum()), len(err), int((err > 1e-2).sum())))
     d = bev.cpu().numpy()
     assert np.array_equal(d != 0, o_bev != 0) or (np.abs(d - o_bev).max() <= 1e-3 * np.abs(o_bev).max())
     assert np.abs(d - o_bev).max() <= 1e-3 * np.abs(o_bev).max()
