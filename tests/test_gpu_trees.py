@@ -265,16 +265,22 @@ def test_voxel_rcnn_backbone_vs_oracle_and_fusion_runs():
 
 
 def test_two_frames_in_flight_equal_sequential():
-    """bench.py keeps two frames in flight per GPU (one host thread + HIP stream + model replica each).  Frames are
-    independent: concurrent execution must give every frame exactly the result of a sequential run (per-thread
-    geometry stream / ordering events in the native executor, no shared scratch)."""
+    """A serving process may keep two frames in flight per GPU (one host thread + HIP stream + model replica each).
+    Frames are independent: concurrent execution must give every frame exactly the result of a sequential run
+    (per-thread geometry stream / ordering events in the native executor, no shared scratch)."""
     import threading
-    import bench
+    import types
+    from dualfusion import synth
+    from dualfusion.fusion import build_centerpoint_fusion, synthetic_camera_inputs
+    from dualfusion.pipeline import CenterPointHotPath
     dev = torch.device("cuda:0")
+    bench = types.SimpleNamespace(run_step=lambda m, p, e: m(p, batch_dict=e[0], example=e[1]))
     slots = []
     for i in range(2):
-        m = bench.build_model("cp_fusion", dev)
-        pts, extra = bench.make_inputs("cp_fusion", 1, i, dev)            # different sweeps / cameras per slot
+        torch.manual_seed(0)
+        m = CenterPointHotPath(fusion=build_centerpoint_fusion()).eval().to(dev)
+        pts = [torch.from_numpy(synth.nusc_sweep(seed=i * 1000)).to(dev)]   # different sweeps / cameras per slot
+        extra = synthetic_camera_inputs(1, dev, seed=1234 + i)
         slots.append((m, pts, extra, torch.cuda.Stream()))
     want = []
     for m, pts, extra, _ in slots:
