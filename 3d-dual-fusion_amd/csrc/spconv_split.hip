@@ -176,7 +176,22 @@ struct SplitConvArgs {
   int ldo;               // floats per output row
   int gy;                // gridDim.y
   const int32_t *cols;   // optional [gy][2] = (first output column, valid columns) of a block: compact fp32 stores
+  const int32_t *order;  // optional [n_out]: tile t of the output-stationary kernel owns rows order[t*TM .. t*TM+TM-1]
+  unsigned long long *trace;   // builds with -DDF3D_OS_TRACE: [workgroup][wave][8] s_memtime stamps (tuning aid)
 };
+
+#ifdef DF3D_OS_TRACE
+#define OS_STAMP(slot)                                                                                          \
+  do {                                                                                                          \
+    if (a.trace && (threadIdx.x & 63) == 0)                                                                     \
+      a.trace[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (threadIdx.x >> 6)) * 8 + (slot)] =        \
+          __builtin_amdgcn_s_memtime();                                                                         \
+  } while (0)
+static unsigned long long *g_os_trace = nullptr;
+extern "C" void df3d_debug_set_os_trace(void *p) { g_os_trace = (unsigned long long *)p; }
+#else
+#define OS_STAMP(slot) do { } while (0)
+#endif
 
 // tuning experiments of the output-stationary kernel (DF3D_OS_DBG bits: 1 no gathers, 2 no W staging, 4 no MFMAs,
 // 8 raised wave priority around the MFMAs, 16 MFMAs without B-operand LDS reads, 32 no output stores) exist only in
@@ -463,6 +478,38 @@ __global__ __launch_bounds__(256, 1) void spconv_split_kernel(SplitConvArgs a, i
   }  // passes over the row range
 }
 
+// (offset, channel block) of a step of the output-stationary kernels, advanced one step at a time from the set of the
+// tile's active offsets.  Everything lives in scalar registers: looking the offset of a step up in LDS put one (and with
+// the neighbour index two) exposed LDS round trips into every step's instruction stream, right behind the MFMA batch --
+// an in-order wave cannot hide them, and the barrier re-aligns the two waves of a SIMD every step.
+// Past the last step the cursor stays on it (a valid weight tile) with live = false (zero A rows).
+struct StepCursor {
+  unsigned m;
+  int k, kb;
+  bool live;
+  __device__ __forceinline__ void init(unsigned mask) {
+    m = mask;
+    live = mask != 0u;
+    k = live ? __builtin_ctz(mask) : 0;
+    kb = 0;
+  }
+  template <int KB>
+  __device__ __forceinline__ void next() {
+    if (!live) return;
+    if (++kb == KB) {
+      const unsigned m2 = m & (m - 1u);
+      if (m2) {
+        m = m2;
+        k = __builtin_ctz(m2);
+        kb = 0;
+      } else {
+        live = false;
+        kb = KB - 1;
+      }
+    }
+  }
+};
+
 // rows without a neighbour gather this all-zero split row (keeps the gathers branch-free, so that the
 // compiler can count its vmcnt waits instead of draining the whole load queue at every step)
 __device__ u32x4 g_zero_row[128];          // up to 512 input channels
@@ -488,8 +535,8 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   constexpr int WPT = (WQ + NT - 1) / NT;
   __shared__ u32x4 Wl[2][WQ];
   __shared__ int nbrL[DF3D_MAX_KVOL][TM];
+  __shared__ int rowL[TM];
   __shared__ unsigned wg_mask;
-  __shared__ int actL[DF3D_MAX_KVOL + 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
@@ -498,6 +545,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   const int row0 = tile * TM;
   const int col0 = blockIdx.y * CW;
 
+  OS_STAMP(0);
   if (tid == 0) wg_mask = 0u;
   __syncthreads();
   // neighbour tile -> LDS; a wave covers 64 rows (or TM) of one offset per pass, so the set of offsets with at
@@ -506,7 +554,12 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     constexpr int KSTEP = NT / TM;               // offsets covered per pass (NT = 4*TM/RT... >= 1)
     static_assert(NT % TM == 0 && KSTEP >= 1, "tile shape");
     const int r = tid % TM, k0 = tid / TM;
-    const int row = row0 + r;
+    // the tile's rows: consecutive, or -- with a tiling order -- whatever rows the order puts next to each other
+    // (rows that are neighbours in space and share their neighbour pattern: fewer active offsets per tile, gathers
+    // that stay inside one XCD's L2); n_out marks the padding of the last tile
+    int row = row0 + r;
+    row = row < a.n_out ? (a.order ? a.order[row] : row) : a.n_out;
+    if (k0 == 0) rowL[r] = row;
     unsigned mine = 0u;
     int v[(DF3D_MAX_KVOL + KSTEP - 1) / KSTEP];
 #pragma unroll
@@ -527,13 +580,8 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     if (TM >= 64 && lane == 0 && mine) atomicOr(&wg_mask, mine);
   }
   __syncthreads();
-  const unsigned gmask = wg_mask;
+  const unsigned gmask = __builtin_amdgcn_readfirstlane(wg_mask);
   const int nact = __popc(gmask);
-  if (tid < 32) {
-    if ((gmask >> tid) & 1u) actL[__popc(gmask & ((1u << tid) - 1u))] = tid;
-    if (tid == 0) actL[nact] = 0;
-  }
-  __syncthreads();
   const int steps = nact * KB;
 
   f32x4 acc[RT][CT];
@@ -548,17 +596,21 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   // The W tile of step s+4 is fetched at step s and parked in one of three register sets until step s+3 stores it
   // to LDS: three whole steps cover the L2 / HBM latency (with a single set the store waited for a load issued one
   // step earlier, which made every step at least one memory round trip long).  WD = 1 where a set is too large.
+  // Which (offset, channel block) a fetch belongs to comes from two scalar cursors (cw for the weight stream, ca for
+  // the gathers), each advanced once per fetch.
   constexpr int WD = WPT <= 4 ? 3 : 1;
   u32x4 w0[WPT], w1[WPT], w2[WPT];
-  auto load_w = [&](int s, u32x4 (&wreg)[WPT]) {
-    s = s < steps ? s : steps - 1;
-    const int k = __builtin_amdgcn_readfirstlane(actL[s / KB]);
-    const u32x4 *src = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)(k * KB + s % KB)) * WQ;   // KPS consecutive [kb] tiles
+  StepCursor cw, ca;
+  cw.init(gmask);
+  ca.init(gmask);
+  auto load_w = [&](u32x4 (&wreg)[WPT]) {          // the next tile of the weight stream
+    const u32x4 *src = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)(cw.k * KB + cw.kb)) * WQ;   // KPS consecutive [kb] tiles
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       int e = tid + NT * i;
       wreg[i] = src[(WQ % NT == 0 || e < WQ) ? e : 0];
     }
+    cw.template next<KB>();
   };
   auto store_w = [&](int buf, u32x4 (&wreg)[WPT]) {
 #pragma unroll
@@ -567,16 +619,31 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       if (WQ % NT == 0 || e < WQ) Wl[buf][e] = wreg[i];
     }
   };
-  u32x4 a0[RT][KPS][NP], a1[RT][KPS][NP], a2[RT][KPS][NP];
-  auto load_a = [&](int s, u32x4 (&dst)[RT][KPS][NP]) {
-    const bool live = s < steps;
-    const int sc = live ? s : 0;
-    const int k = __builtin_amdgcn_readfirstlane(actL[sc / KB]), kb = (sc % KB) * KPS;
+  // A fragments of the next AD steps in a register ring (AD sets, rotated by name: the step loop is unrolled AD times).
+  // The gathers of a step are issued AD - 1 whole steps before its matrix instructions need them.  Measured on MI355X
+  // (tools/ubench/sk_probe.py, -DDF3D_OS_ADEPTH=6): depth 6 changes nothing (conv4 93.4 vs 91.6 us) -- the gathers are
+  // not what a step waits for -- and costs 24 registers, so the ring stays at 3.
+#ifndef DF3D_OS_ADEPTH
+#define DF3D_OS_ADEPTH 3
+#endif
+  constexpr int AD = (RT * KPS * NP <= 4) ? DF3D_OS_ADEPTH : 3;
+  static_assert(AD % 3 == 0, "the W register sets rotate with period 3");
+  u32x4 ar[AD][RT][KPS][NP];
+  // the gathers of the next step of the A stream, in two halves: peek_a reads the neighbour indices from LDS (issued at
+  // the TOP of a step, so that the round trip runs under the step's matrix instructions), issue_a turns them into
+  // addresses and issues the loads (at the END of the step, into the fragment registers the step has just freed)
+  int idxn[RT];
+  auto peek_a = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) idxn[rt] = nbrL[ca.k][wave * WROWS + rt * 16 + n];
+  };
+  auto issue_a = [&](u32x4 (&dst)[RT][KPS][NP]) {
+    const int kb = ca.kb * KPS;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      int idx = nbrL[k][wave * WROWS + rt * 16 + n];
-      const u32x4 *p = (live && idx >= 0 && !OS_DBG(1)) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff
-                                                          : g_zero_row;
+      const int idx = idxn[rt];
+      const u32x4 *p = (ca.live && idx >= 0 && !OS_DBG(1)) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff
+                                                             : g_zero_row;
       p += (kb * 4 + g) * NP;
 #pragma unroll
       for (int j = 0; j < KPS; ++j) {
@@ -584,6 +651,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         for (int q = 0; q < NP; ++q) dst[rt][j][q] = p[j * 4 * NP + q];
       }
     }
+    ca.template next<KB>();
   };
   // Step s: barrier; W(s+1) (fetched during step s-1) -> LDS; fetch W(s+2); MFMAs of step s; fetch A(s+3).
   auto step = [&](int s, u32x4 (&cur)[RT][KPS][NP], u32x4 (&wset)[WPT]) {
@@ -595,13 +663,14 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       if (!OS_DBG(2)) {
         if constexpr (WD == 3) {
           store_w((s + 1) & 1, wset);
-          load_w(s + 4, wset);
+          load_w(wset);                            // W(s + 4)
         } else {
           store_w((s + 1) & 1, w0);
-          load_w(s + 2, w0);
+          load_w(w0);                              // W(s + 2)
         }
       }
     };
+    peek_a();                                      // neighbour indices of step s + AD
     constexpr int WPOS = (KPS * CT / 2) > 1 ? 1 : 0;
     if (WPOS == 0) stage_w();
     const u32x4 *wb = Wl[s & 1] + lane;
@@ -655,28 +724,39 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       }
       if (OS_DBG(8)) __builtin_amdgcn_s_setprio(0);
     }
-    load_a(s + 3, cur);
+    issue_a(cur);
   };
 
+  OS_STAMP(1);
   if (steps > 0) {
-    load_w(0, w0);
+    load_w(w0);                                    // W(0)
     store_w(0, w0);
     if constexpr (WD == 3) {
-      load_w(1, w1);
-      load_w(2, w2);
-      load_w(3, w0);
+      load_w(w1);                                  // W(1), W(2), W(3)
+      load_w(w2);
+      load_w(w0);
     } else {
-      load_w(1, w0);
+      load_w(w0);                                  // W(1)
     }
-    load_a(0, a0);
-    load_a(1, a1);
-    load_a(2, a2);
-    for (int s = 0; s < steps; s += 3) {
-      step(s, a0, w1);
-      step(s + 1, a1, w2);
-      step(s + 2, a2, w0);
+#pragma unroll
+    for (int j = 0; j < AD; ++j) {
+      peek_a();
+      issue_a(ar[j]);
+    }
+    OS_STAMP(2);
+    for (int s = 0; s < steps; s += AD) {
+#pragma unroll
+      for (int j = 0; j < AD; j += 3) {
+        step(s + j, ar[j], w1);
+        step(s + j + 1, ar[j + 1], w2);
+        step(s + j + 2, ar[j + 2], w0);
+      }
     }
   }
+  OS_STAMP(3);
+#ifdef DF3D_OS_TRACE
+  if (a.trace && (threadIdx.x & 63) == 0) a.trace[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (threadIdx.x >> 6)) * 8 + 5] = steps;
+#endif
 
   // ---- epilogue: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the CT
   //      consecutive columns n*CT .. n*CT+CT-1 of its rows (packed-weight layout 1): 16-byte stores ----
@@ -692,7 +772,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
+        const int row = rowL[wave * WROWS + rt * 16 + 4 * g + r];
         if (row >= a.n_out) continue;
         float2 v = make_float2((acc[rt][0][r] + bi.x) * sc.x + sh.x, (acc[rt][1][r] + bi.y) * sc.y + sh.y);
         if (a.cols) {                        // compact layout: only the block's valid columns exist in the output
@@ -735,6 +815,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         }
       }
     }
+    OS_STAMP(4);
     return;
   } else {
   f32x4 bi[CT / 4], sc[CT / 4], sh[CT / 4];
@@ -749,7 +830,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = row0 + wave * WROWS + rt * 16 + 4 * g + r;
+      const int row = rowL[wave * WROWS + rt * 16 + 4 * g + r];
       if (row >= a.n_out) continue;
       if (OS_DBG(32) && acc[rt][0][r] != 1234.567f) continue;      // experiment: no output stores
       const size_t o = (size_t)row * a.ldo + col0 + n * CT;
@@ -795,6 +876,279 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       }
     }
   }
+  OS_STAMP(4);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Output-stationary kernel with the kernel OFFSETS split over two wave groups ("split-K inside the workgroup").
+//
+// What bounds spconv_os_split_kernel is the LDS: per (offset, 32-channel) step every wave reads the whole packed
+// weight tile (16 KB at 128 columns) as B fragments for ONE 16-row MFMA tile -- 8 waves x 16 KB = 128 KB per step per
+// CU against 24 MFMAs per wave.  Rows per wave cannot simply grow: the nuScenes layers have 30-85 k rows, i.e. 30-80
+// rows per SIMD of the chip, so 32-row waves already leave one wave per SIMD and nothing to hide latencies with.
+// Here a wave owns 32 rows (two MFMA row tiles per B fragment: half the LDS bytes per matrix instruction) and the
+// second wave of a SIMD works on the SAME 32 rows but on the other half of the steps (wave group h takes steps
+// 2d + h of iteration d; each iteration stages two weight tiles).  The two partial accumulators of a row are summed
+// through LDS once, after the last step, and the epilogue is shared (group h finalises row tile h).
+// Per iteration (= two steps of the plain kernel): 8 waves x 16 KB of B fragments instead of 2 x 8 x 16 KB, one
+// barrier instead of two, the same MFMAs.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) void spconv_os_sk2_kernel(SplitConvArgs a) {
+  constexpr int NP = 2, RT = 2, NW = 8, NWR = 4, NT = NW * 64;
+  constexpr int CW = COUT > 128 ? 128 : COUT;
+  constexpr int KB = CIN / 32, CT = CW / 16, WROWS = 16 * RT, TM = WROWS * NWR;
+  constexpr int WQ = CT * NP * 64;                // u32x4 per (offset, 32-channel block) weight tile
+  constexpr int WQ2 = 2 * WQ;                     // per iteration: the tiles of steps 2d and 2d + 1
+  constexpr int WPT = (WQ2 + NT - 1) / NT;
+  static_assert(WQ % 64 == 0, "a wave stages one tile at a time");
+  static_assert(sizeof(u32x4) * 2 * WQ2 >= sizeof(f32x4) * NW * CT * 64, "partial sums are exchanged through the W buffers");
+  __shared__ u32x4 Wl[2][WQ2];
+  __shared__ int nbrL[DF3D_MAX_KVOL][TM];
+  __shared__ int rowL[TM];
+  __shared__ unsigned wg_mask;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = wave >> 2, wr = wave & 3;         // wave group (which half of the steps), row slice of the tile
+  const int g = lane >> 4, n = lane & 15;
+  int nt = gridDim.x, bid = blockIdx.x, tile = bid;
+  if ((nt & 7) == 0) tile = (bid & 7) * (nt >> 3) + (bid >> 3);     // consecutive tiles stay on one XCD / L2
+  const int row0 = tile * TM;
+  const int col0 = blockIdx.y * CW;
+
+  if (tid == 0) wg_mask = 0u;
+  __syncthreads();
+  {
+    constexpr int KSTEP = NT / TM;               // offsets covered per pass
+    constexpr int NPASS = (DF3D_MAX_KVOL + KSTEP - 1) / KSTEP;
+    const int r = tid % TM, k0 = tid / TM;
+    int row = row0 + r;
+    row = row < a.n_out ? (a.order ? a.order[row] : row) : a.n_out;
+    if (k0 == 0) rowL[r] = row;
+    unsigned mine = 0u;
+    int v[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      int k = k0 + i * KSTEP;
+      v[i] = (k < a.K && row < a.n_out) ? a.nbr[(size_t)k * a.n_out + row] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      int k = k0 + i * KSTEP;
+      if (k < a.K) nbrL[k][r] = v[i];
+      if (__ballot(v[i] >= 0) != 0ull) mine |= 1u << (k & 31);     // TM >= 64: the whole wave looks at one offset
+    }
+    if (lane == 0 && mine) atomicOr(&wg_mask, mine);
+  }
+  __syncthreads();
+  const unsigned gmask = __builtin_amdgcn_readfirstlane(wg_mask);
+  const int nact = __popc(gmask);
+  const int steps = nact * KB;
+  const int iters = (steps + 1) / 2;
+
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // weight tiles of iteration d: fetched at iteration d - 4 .. d - 2 into one of three register sets, stored to LDS
+  // during iteration d - 1 (same rotation as spconv_os_split_kernel).  Scalar cursors: cw walks the steps 2d (its copy
+  // advanced by one is step 2d + 1), ca the steps 2d + h of this wave group.
+  u32x4 w0[WPT], w1[WPT], w2[WPT];
+  StepCursor cw, ca;
+  cw.init(gmask);
+  ca.init(gmask);
+  if (h) ca.template next<KB>();
+  auto load_w = [&](u32x4 (&wreg)[WPT]) {          // the two tiles of the next iteration of the weight stream
+    StepCursor c1 = cw;
+    c1.template next<KB>();
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      int e = tid + NT * i;
+      if (WQ2 % NT != 0 && e >= WQ2) e = 0;
+      const int second = __builtin_amdgcn_readfirstlane(e / WQ);       // uniform over the wave (WQ % 64 == 0)
+      const int k = second ? c1.k : cw.k, kb = second ? c1.kb : cw.kb;
+      wreg[i] = a.w[((size_t)blockIdx.y * a.K * KB + (size_t)(k * KB + kb)) * WQ + e % WQ];
+    }
+    cw = c1;
+    cw.template next<KB>();
+  };
+  auto store_w = [&](int buf, u32x4 (&wreg)[WPT]) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      int e = tid + NT * i;
+      if (WQ2 % NT == 0 || e < WQ2) Wl[buf][e] = wreg[i];
+    }
+  };
+  u32x4 a0[RT][NP], a1[RT][NP], a2[RT][NP];
+  int idxn[RT];
+  auto peek_a = [&]() {                            // neighbour indices of this group's next step (LDS round trip)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) idxn[rt] = nbrL[ca.k][wr * WROWS + rt * 16 + n];
+  };
+  auto issue_a = [&](u32x4 (&dst)[RT][NP]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int idx = idxn[rt];
+      const u32x4 *p = (ca.live && idx >= 0) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff : g_zero_row;
+      p += (ca.kb * 4 + g) * NP;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) dst[rt][q] = p[q];
+    }
+    ca.template next<KB>();
+    ca.template next<KB>();
+  };
+  auto iter = [&](int d, u32x4 (&cur)[RT][NP], u32x4 (&wset)[WPT]) {
+    __syncthreads();
+    peek_a();                                     // indices of iteration d + 3
+    const u32x4 *wb = Wl[d & 1] + h * WQ + lane;
+    constexpr int NBATCH = CT / 2;
+    u32x4 bq[2][2 * NP];
+#pragma unroll
+    for (int q = 0; q < 2 * NP; ++q) bq[0][q] = wb[q * 64];
+#pragma unroll
+    for (int i = 0; i < NBATCH; ++i) {
+      const int c2 = i * 2;
+      if (i == (NBATCH > 1 ? 1 : 0)) {            // next iteration's tiles go to LDS in the shadow of the first MFMA batch
+        store_w((d + 1) & 1, wset);
+        load_w(wset);                             // tiles of iteration d + 4
+      }
+      if (i + 1 < NBATCH) {
+#pragma unroll
+        for (int q = 0; q < 2 * NP; ++q) bq[(i + 1) & 1][q] = wb[((i + 1) * 2 * NP + q) * 64];
+      }
+      const u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][1], bh1 = bq[i & 1][2], bl1 = bq[i & 1][3];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {           // lo * hi
+        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][1], bh0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][1], bh1, acc[rt][c2 + 1]);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {           // hi * lo
+        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][0], bl0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][0], bl1, acc[rt][c2 + 1]);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {           // hi * hi
+        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][0], bh0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][0], bh1, acc[rt][c2 + 1]);
+      }
+    }
+    issue_a(cur);
+  };
+
+  if (iters > 0) {
+    load_w(w0);                                   // iteration 0
+    store_w(0, w0);
+    load_w(w1);                                   // iterations 1, 2, 3
+    load_w(w2);
+    load_w(w0);
+    peek_a();
+    issue_a(a0);
+    peek_a();
+    issue_a(a1);
+    peek_a();
+    issue_a(a2);
+    for (int d = 0; d < iters; d += 3) {          // padding iterations multiply zero rows
+      iter(d, a0, w1);
+      iter(d + 1, a1, w2);
+      iter(d + 2, a2, w0);
+    }
+  }
+
+  // ---- the two partial sums of a row meet: group h keeps row tile h and hands the other one to its partner ----
+  f32x4 fin[CT];
+  {
+    __syncthreads();                              // every wave is done with the weight buffers
+    f32x4 *ex = (f32x4 *)&Wl[0][0];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      fin[ct] = h ? acc[1][ct] : acc[0][ct];
+      ex[(wave * CT + ct) * 64 + lane] = h ? acc[0][ct] : acc[1][ct];
+    }
+    __syncthreads();
+    const int partner = wave ^ 4;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) fin[ct] += ex[(partner * CT + ct) * 64 + lane];
+  }
+
+  // ---- epilogue of row tile h: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the
+  //      CT consecutive columns n*CT .. n*CT+CT-1 (packed-weight layout 1) ----
+  static_assert(CT == 2 || CT == 4 || CT == 8, "COUT must be 32, 64, 128 or 256");
+  if constexpr (CT == 2) {
+    const int col = col0 + n * 2;
+    const float2 bi = a.bias ? *(const float2 *)(a.bias + col) : make_float2(0.f, 0.f);
+    const float2 sc = a.scale ? *(const float2 *)(a.scale + col) : make_float2(1.f, 1.f);
+    const float2 sh = a.shift ? *(const float2 *)(a.shift + col) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rowL[wr * WROWS + h * 16 + 4 * g + r];
+      if (row >= a.n_out) continue;
+      float2 v = make_float2((fin[0][r] + bi.x) * sc.x + sh.x, (fin[1][r] + bi.y) * sc.y + sh.y);
+      const size_t o = (size_t)row * a.ldo + col;
+      if (a.residual) {
+        const float2 rr = *(const float2 *)(a.residual + o);
+        v.x += rr.x;
+        v.y += rr.y;
+      }
+      if (a.relu) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+      }
+      if (a.out) *(float2 *)(a.out + o) = v;
+      if (a.out_split) {
+        unsigned hp, lp;
+        split_pair(v.x, v.y, hp, lp);
+        char *blk = (char *)a.out_split + (o >> 3) * 32 + (n & 3) * 4;     // 8-channel block = [hi 16 B | lo 16 B]
+        *(unsigned *)blk = hp;
+        *(unsigned *)(blk + 16) = lp;
+      }
+    }
+  } else {
+    f32x4 bi[CT / 4], sc[CT / 4], sh[CT / 4];
+#pragma unroll
+    for (int q = 0; q < CT / 4; ++q) {
+      const int col = col0 + n * CT + q * 4;
+      bi[q] = a.bias ? *(const f32x4 *)(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      sc[q] = a.scale ? *(const f32x4 *)(a.scale + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      sh[q] = a.shift ? *(const f32x4 *)(a.shift + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rowL[wr * WROWS + h * 16 + 4 * g + r];
+      if (row >= a.n_out) continue;
+      const size_t o = (size_t)row * a.ldo + col0 + n * CT;
+      unsigned hh[CT / 2], ll[CT / 2];         // packed pairs
+#pragma unroll
+      for (int q = 0; q < CT / 4; ++q) {
+        f32x4 v = (f32x4){fin[q * 4][r], fin[q * 4 + 1][r], fin[q * 4 + 2][r], fin[q * 4 + 3][r]};
+        v = (v + bi[q]) * sc[q] + sh[q];
+        if (a.residual) v += *(const f32x4 *)(a.residual + o + q * 4);
+        if (a.relu) {
+          v[0] = fmaxf(v[0], 0.f);
+          v[1] = fmaxf(v[1], 0.f);
+          v[2] = fmaxf(v[2], 0.f);
+          v[3] = fmaxf(v[3], 0.f);
+        }
+        if (a.out) *(f32x4 *)(a.out + o + q * 4) = v;
+        if (a.out_split) {
+          split_pair(v[0], v[1], hh[q * 2], ll[q * 2]);
+          split_pair(v[2], v[3], hh[q * 2 + 1], ll[q * 2 + 1]);
+        }
+      }
+      if (a.out_split) {
+        char *blk = (char *)a.out_split + (o >> 3) * 32;             // 8-channel block = [hi 16 B | lo 16 B]
+        if constexpr (CT == 8) {
+          *(u32x4 *)blk = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+          *(u32x4 *)(blk + 16) = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+        } else {
+          blk += (n & 1) * 8;                                        // two lanes share a block
+          *(u32x2 *)blk = (u32x2){hh[0], hh[1]};
+          *(u32x2 *)(blk + 16) = (u32x2){ll[0], ll[1]};
+        }
+      }
+    }
   }
 }
 
@@ -805,6 +1159,16 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
   // bytes per launch, more than the gathers), so more rows per workgroup = less L2 traffic; bigger register
   // tiles (RT 2) leave too few waves on the 256 CUs at these row counts.
   int rt = 1, nw = a.n_out >= 16 * 1024 ? 8 : 2, kps = 1;
+  // offsets split over two wave groups (spconv_os_sk2_kernel): measured on MI355X (tools/ubench/sk_probe.py) it wins
+  // where a tile has many steps of wide weight tiles -- the 128 -> 128 layers (conv4 K=27: 93 -> 85..88 us, dense K=9:
+  // 40.7 -> 39.1) -- and loses on the 64- and 32-channel layers (64 -> 74 us, 35 -> 38 us), so it serves CIN = COUT = 128
+  // only.  DF3D_OS_SK=0 / 2 forces it off / on for every shape (tuning aid).
+  static const char *sk = getenv("DF3D_OS_SK");
+  const bool sk2 = sk ? sk[0] == '2' : (CIN == 128 && COUT == 128 && a.K >= 9);
+  if (sk2 && !a.cols && a.n_out >= 4 * 1024) {
+    hipLaunchKernelGGL((spconv_os_sk2_kernel<CIN, COUT>), dim3(cdiv(a.n_out, 128), a.gy), dim3(512), 0, stream, a);
+    return DF3D_OK;
+  }
   static const char *cfg = getenv("DF3D_OS_CFG");       // tuning aid: "RT,NW[,KPS]"
   if (cfg && cfg[0] && cfg[1] == ',') {
     rt = cfg[0] - '0';
@@ -1016,6 +1380,10 @@ extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int 
                      out, (u32x4 *)out_split, n_in, n_out, kvol, relu,
                      getenv("DF3D_OS_DBG") ? atoi(getenv("DF3D_OS_DBG")) : 0,
                      cin / 4, 0, cout, cout > 128 ? cout / 128 : 1, nullptr};
+  if (ntiles == -1 && tile_rows) a.order = tile_rows;       // tiling order of the output-stationary kernel
+#ifdef DF3D_OS_TRACE
+  a.trace = g_os_trace;
+#endif
   int rec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 1, stream);
   int rc;
   if (split_layout(cin, cout) == 1) {

@@ -321,8 +321,9 @@ def split_rows(features):
 
 
 def sparse_conv_split(features_split, packed, nbr, n_out, cin, cout, bias=None, scale=None, shift=None,
-                      residual=None, relu=False, tiles=None, emit_split=True):
-    """Split-precision twin of sparse_conv_fused.  Returns (out fp32 [n_out, cout], split rows of out or None)."""
+                      residual=None, relu=False, tiles=None, emit_split=True, order=None):
+    """Split-precision twin of sparse_conv_fused.  Returns (out fp32 [n_out, cout], split rows of out or None).
+    order: optional int32 [n_out] tiling order of the output-stationary kernel (which rows share a workgroup tile)."""
     lib = _lib.load()
     _chk(features_split, torch.uint8, "features_split")
     _chk(packed, torch.uint8, "packed")
@@ -338,7 +339,8 @@ def sparse_conv_split(features_split, packed, nbr, n_out, cin, cout, bias=None, 
     out_split = torch.empty((n_out, 4 * cout), dtype=torch.uint8, device=nbr.device) if emit_split else None
     rc = lib.df3d_sparse_conv_split(_ptr(features_split), n_in, cin, _ptr(packed), K, cout, _ptr(nbr), n_out,
                                     _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out),
-                                    _ptr(out_split), _ptr(tiles), (tiles.shape[0] - 1) if tiles is not None else 0,
+                                    _ptr(out_split), _ptr(order if order is not None else tiles),
+                                    -1 if order is not None else ((tiles.shape[0] - 1) if tiles is not None else 0),
                                     _stream())
     _lib.check(rc, "df3d_sparse_conv_split")
     return out, out_split
