@@ -109,8 +109,9 @@ class CenterHead(nn.Module):
 
     def forward(self, x, *kwargs):
         if (self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32
-                or _ops.CONV_PRECISION != "split" or not self._row_kernels_fit(x)):
+                or _ops.CONV_PRECISION == "fp32" or not self._row_kernels_fit(x)):
             return self.forward_reference(x)
+        # the head's own convolutions stay split precision (fp32-grade) in the bf16 mode of the backbone / neck
         return self.forward_rows(x)
 
     # ------------------------------------------------------------------ the three conv depths as three launches
@@ -184,7 +185,7 @@ class CenterHead(nn.Module):
         plan = self._plan()
         B, _, H, W = x.shape
         rows, split = _rows_of(x)
-        if split is None:
+        if split is None or split.dtype != torch.uint8:     # no hi/lo rows cached (bf16 mode of the neck caches bf16 rows)
             split = _ops.split_rows(rows.contiguous())
         if (B, H, W) not in plan["nbr"]:
             plan["nbr"][(B, H, W)] = _ops.conv2d_neighbors(B, H, W, 3, 3, 1, 1, False, x.device)[0]

@@ -295,8 +295,8 @@ class TransFusionHead(nn.Module):
             local_max[:, :, pad:heatmap.shape[2] - pad, pad:heatmap.shape[3] - pad] = inner
             for c in _EXEMPT.get(self.test_cfg['dataset'], ()):
                 local_max[:, c] = heatmap[:, c]
-            heatmap = (heatmap * (heatmap == local_max)).view(B, heatmap.shape[1], -1)
-            top = heatmap.view(B, -1).argsort(dim=-1, descending=True, stable=True)[..., :self.num_proposals]
+            heatmap = (heatmap * (heatmap == local_max)).reshape(B, heatmap.shape[1], -1)
+            top = heatmap.reshape(B, -1).argsort(dim=-1, descending=True, stable=True)[..., :self.num_proposals]
             top_class = top // heatmap.shape[-1]
             top_index = top % heatmap.shape[-1]
             query_feat = flat.gather(index=top_index[:, None, :].expand(-1, flat.shape[1], -1), dim=-1)
@@ -333,8 +333,9 @@ class TransFusionHead(nn.Module):
 
     def forward_single(self, inputs, img_inputs=None, img_metas=None):
         if (self.training or torch.is_grad_enabled() or not inputs.is_cuda or inputs.dtype != torch.float32
-                or _ops.CONV_PRECISION != "split" or not self._row_kernels_fit(inputs)):
+                or _ops.CONV_PRECISION == "fp32" or not self._row_kernels_fit(inputs)):
             return self.forward_reference(inputs)
+        # the head's own convolutions stay split precision (fp32-grade) in the bf16 mode of the backbone / neck
         return self.forward_rows(inputs)
 
     def forward(self, feats, img_feats=None, img_metas=None):
@@ -466,7 +467,7 @@ class TransFusionHead(nn.Module):
         B, _, H, W = x.shape
         n, C, K, dev = B * H * W, self.num_classes, self.num_proposals, x.device
         rows, split = _rows_of(x)
-        if split is None:
+        if split is None or split.dtype != torch.uint8:     # no hi/lo rows cached (bf16 mode of the neck caches bf16 rows)
             split = _ops.split_rows(rows.contiguous())
         if (B, H, W) not in plan["nbr"]:
             plan["nbr"][(B, H, W)] = _ops.conv2d_neighbors(B, H, W, 3, 3, 1, 1, False, dev)[0]

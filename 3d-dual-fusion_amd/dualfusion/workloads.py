@@ -32,6 +32,7 @@ def _voxelize_batch(points, vs, rng, max_points, max_voxels):
 
 class TransFusionWorkload(object):
     name, unit_name = "tf_fusion", "sweeps"
+    hot_path_what = "the same K steps ending at the encoder's dense BEV map (voxelize + SparseEncoderFusion + ACTR; no neck / head)"
 
     def __init__(self, args, rank, world, dev):
         from .backbones import SparseEncoderFusion
@@ -96,6 +97,7 @@ class TransFusionWorkload(object):
 class VoxelRCNNWorkload(object):
     name, unit_name = "vr_fusion", "frames"
     metric = "KITTI frames/sec (0.05 m voxel, ~19k pts, 1 camera)"
+    hot_path_what = "identical to the step (this tree ends at the fused sparse backbone)"
 
     def __init__(self, args, rank, world, dev):
         from .backbones import VoxelBackBone8xFusion

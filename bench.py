@@ -514,8 +514,9 @@ def main():
                                      if k in ("loss", "hm_loss", "loc_loss")}
         if "hot_path" in extra:
             res["hot_path"] = {"ms_per_step": per_step(extra["hot_path"]), "value": round(units / extra["hot_path"], 3),
-                               "unit": "sweeps/s", "what": "the same K steps ending at the dense BEV tensor [B,256,180,180] "
-                                                           "(no neck / head / losses / reduce): round 1's step"}
+                               "unit": wl.unit_name + "/s",
+                               "what": getattr(wl, "hot_path_what", "the same K steps ending at the dense BEV tensor "
+                                       "[B,256,180,180] (no neck / head / losses / reduce): round 1's step")}
         if "fp32_detect" in extra or "fp32_hot_path" in extra:
             res["fp32"] = {"what": "every sparse conv on the exact-fp32 MFMA kernels (--conv-precision fp32; neck / head "
                                    "through torch / MIOpen fp32)"}
