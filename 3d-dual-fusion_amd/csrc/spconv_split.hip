@@ -674,6 +674,42 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     constexpr int WPOS = (KPS * CT / 2) > 1 ? 1 : 0;
     if (WPOS == 0) stage_w();
     const u32x4 *wb = Wl[s & 1] + lane;
+#ifdef DF3D_OS_PRODUCT_MAJOR
+    // experiment: the three products of a step run product-major over groups of G column tiles, so that two matrix
+    // instructions on the same accumulator are G instructions apart (the default order keeps them 2 apart, and the
+    // compiler schedules them back to back)
+    if constexpr (NP == 2 && RT == 1 && KPS == 1 && CT >= 4) {
+      constexpr int G = 4;
+      u32x4 bg[2][G][2];
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        bg[0][c][0] = wb[(c * 2 + 0) * 64];
+        bg[0][c][1] = wb[(c * 2 + 1) * 64];
+      }
+#pragma unroll
+      for (int b = 0; b < CT / G; ++b) {
+        if (b == 0 && WPOS > 0) stage_w();
+        if (b + 1 < CT / G) {
+#pragma unroll
+          for (int c = 0; c < G; ++c) {
+            bg[(b + 1) & 1][c][0] = wb[(((b + 1) * G + c) * 2 + 0) * 64];
+            bg[(b + 1) & 1][c][1] = wb[(((b + 1) * G + c) * 2 + 1) * 64];
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < G; ++c) acc[0][b * G + c] = DF3D_MFMA_BF16(cur[0][0][1], bg[b & 1][c][0], acc[0][b * G + c]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < G; ++c) acc[0][b * G + c] = DF3D_MFMA_BF16(cur[0][0][0], bg[b & 1][c][1], acc[0][b * G + c]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < G; ++c) acc[0][b * G + c] = DF3D_MFMA_BF16(cur[0][0][0], bg[b & 1][c][0], acc[0][b * G + c]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      issue_a(cur);
+      return;
+    }
+#endif
     // B fragments of the next column pair are fetched from LDS while the MFMAs of the current pair run
     constexpr int NBATCH = KPS * CT / 2;
     u32x4 bq[2][2 * NP];
@@ -881,32 +917,45 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Output-stationary kernel with the kernel OFFSETS split over two wave groups ("split-K inside the workgroup").
+// Output-stationary kernel, third structure: both operands arrive by LDS-DMA in full cache lines, two wave groups work
+// in anti-phase ("ping-pong").
 //
-// What bounds spconv_os_split_kernel is the LDS: per (offset, 32-channel) step every wave reads the whole packed
-// weight tile (16 KB at 128 columns) as B fragments for ONE 16-row MFMA tile -- 8 waves x 16 KB = 128 KB per step per
-// CU against 24 MFMAs per wave.  Rows per wave cannot simply grow: the nuScenes layers have 30-85 k rows, i.e. 30-80
-// rows per SIMD of the chip, so 32-row waves already leave one wave per SIMD and nothing to hide latencies with.
-// Here a wave owns 32 rows (two MFMA row tiles per B fragment: half the LDS bytes per matrix instruction) and the
-// second wave of a SIMD works on the SAME 32 rows but on the other half of the steps (wave group h takes steps
-// 2d + h of iteration d; each iteration stages two weight tiles).  The two partial accumulators of a row are summed
-// through LDS once, after the last step, and the epilogue is shared (group h finalises row tile h).
-// Per iteration (= two steps of the plain kernel): 8 waves x 16 KB of B fragments instead of 2 x 8 x 16 KB, one
-// barrier instead of two, the same MFMAs.
+// What the s_memtime stamps of the kernels above show (tools/ubench/pp_trace.py): a step's matrix instructions take their
+// issue time (~800 cycles for the two waves of a SIMD) and no more, but the MEMORY work of a step -- the gathers of the
+// A fragments and the staging of the weight tile -- takes 1300-1700 cycles of the CU's vector-memory path, whatever the
+// order, the prefetch depth or the phase relation of the waves.  The gathers were fragment-shaped: a quarter-wave of 16
+// lanes reads 16 B from each of 16 DIFFERENT rows, i.e. 64 cache-line requests per wave instruction for 1 KB of payload,
+// and every 128-byte line was requested twice (hi and lo parts by separate instructions).
+// Here every vector-memory instruction moves eight whole 128-byte lines:
+//   A  the 32-channel block (hi | lo, 128 B = one line) of each of the tile's 128 rows goes global -> LDS by
+//      global_load_lds_dwordx4, 8 rows per wave instruction; the LDS image of a row is XOR-swizzled in 16-byte units
+//      (on the SOURCE address: an LDS-DMA writes lane-linearly) so that the MFMA-shaped ds_read_b128 of a row tile is
+//      bank-conflict-free;
+//   W  the packed weight tile (already the B-operand image) goes global -> LDS the same way, 1 KB per instruction;
+// no register staging, no ds_write.  A wave owns 32 rows x all columns (two MFMA row tiles per B fragment); the two waves
+// of a SIMD (groups h = 0 / 1) work on the same rows but on alternate steps, one in its matrix phase (20 ds_read_b128,
+// 48 MFMAs) while the other is in its memory phase (8 LDS-DMA instructions for its turn after next, counted vmcnt wait
+// for the previous ones), raw s_barrier between the phases -- the DMAs stay in flight across it.
+// Per group two A and two W buffers; the partial sums of the two groups meet through LDS after the last step.
+#define DF3D_WAIT_BARRIER(VM) asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(512) void spconv_os_sk2_kernel(SplitConvArgs a) {
   constexpr int NP = 2, RT = 2, NW = 8, NWR = 4, NT = NW * 64;
   constexpr int CW = COUT > 128 ? 128 : COUT;
   constexpr int KB = CIN / 32, CT = CW / 16, WROWS = 16 * RT, TM = WROWS * NWR;
   constexpr int WQ = CT * NP * 64;                // u32x4 per (offset, 32-channel block) weight tile
-  constexpr int WQ2 = 2 * WQ;                     // per iteration: the tiles of steps 2d and 2d + 1
-  constexpr int WPT = (WQ2 + NT - 1) / NT;
-  static_assert(WQ % 64 == 0, "a wave stages one tile at a time");
-  static_assert(sizeof(u32x4) * 2 * WQ2 >= sizeof(f32x4) * NW * CT * 64, "partial sums are exchanged through the W buffers");
-  __shared__ u32x4 Wl[2][WQ2];
+  constexpr int AQ = TM * 8;                      // u32x4 per A tile: 128 rows x 128 B
+  constexpr int WI = WQ / 64 / NWR;               // weight DMA instructions per wave and turn (WQ = CT * 128)
+  constexpr int AI = AQ / 64 / NWR;               // gather DMA instructions per wave and turn (4)
+  static_assert(WQ % (64 * NWR) == 0 || WQ == 128, "weight tile = whole DMA instructions");
+  constexpr int WIE = WI > 0 ? WI : 1;            // COUT = 32: two instructions for four waves
+  __shared__ u32x4 Wl[2][2][WQ];                  // [wave group][buffer]
+  __shared__ u32x4 Al[2][2][AQ];
   __shared__ int nbrL[DF3D_MAX_KVOL][TM];
   __shared__ int rowL[TM];
   __shared__ unsigned wg_mask;
+  static_assert(sizeof(u32x4) * 4 * AQ >= sizeof(f32x4) * NW * CT * 64, "partial sums are exchanged through the A buffers");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = wave >> 2, wr = wave & 3;         // wave group (which half of the steps), row slice of the tile
@@ -944,7 +993,7 @@ __global__ __launch_bounds__(512) void spconv_os_sk2_kernel(SplitConvArgs a) {
   const unsigned gmask = __builtin_amdgcn_readfirstlane(wg_mask);
   const int nact = __popc(gmask);
   const int steps = nact * KB;
-  const int iters = (steps + 1) / 2;
+  const int turns = (steps + 1 - h) / 2;          // this group's turns: its j-th turn is step 2j + h
 
   f32x4 acc[RT][CT];
 #pragma unroll
@@ -952,57 +1001,52 @@ __global__ __launch_bounds__(512) void spconv_os_sk2_kernel(SplitConvArgs a) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // weight tiles of iteration d: fetched at iteration d - 4 .. d - 2 into one of three register sets, stored to LDS
-  // during iteration d - 1 (same rotation as spconv_os_split_kernel).  Scalar cursors: cw walks the steps 2d (its copy
-  // advanced by one is step 2d + 1), ca the steps 2d + h of this wave group.
-  u32x4 w0[WPT], w1[WPT], w2[WPT];
-  StepCursor cw, ca;
-  cw.init(gmask);
-  ca.init(gmask);
-  if (h) ca.template next<KB>();
-  auto load_w = [&](u32x4 (&wreg)[WPT]) {          // the two tiles of the next iteration of the weight stream
-    StepCursor c1 = cw;
-    c1.template next<KB>();
+  StepCursor cu;                                  // the step of this group's next memory phase
+  cu.init(gmask);
+  if (h) cu.template next<KB>();
+  // XOR swizzle of a row's eight 16-byte units, by the row's position in its 16-row MFMA tile: makes the four lane
+  // groups of a ds_read_b128 (rows n, units g*2 + q) hit 16 distinct bank columns (brute-forced; linear over GF(2))
+  auto swz = [](int nn) { return ((nn >> 2) & 1) | (((nn >> 1) & 1) << 2); };
+  // memory phase of turn j: eight LDS-DMA instructions per wave into buffer j & 1 of the group
+  auto mem = [&](int j) {
+    if (j >= turns) return;
+    const int buf = j & 1;
+    // gathers: instruction t = wr * AI + i moves rows 8t .. 8t+7, lane -> (row 8t + lane / 8, LDS unit lane % 8)
+    int idx[AI];
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      int e = tid + NT * i;
-      if (WQ2 % NT != 0 && e >= WQ2) e = 0;
-      const int second = __builtin_amdgcn_readfirstlane(e / WQ);       // uniform over the wave (WQ % 64 == 0)
-      const int k = second ? c1.k : cw.k, kb = second ? c1.kb : cw.kb;
-      wreg[i] = a.w[((size_t)blockIdx.y * a.K * KB + (size_t)(k * KB + kb)) * WQ + e % WQ];
+    for (int i = 0; i < AI; ++i) idx[i] = nbrL[cu.k][(wr * AI + i) * 8 + (lane >> 3)];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int r = (wr * AI + i) * 8 + (lane >> 3);
+      const int unit = (lane & 7) ^ swz(r & 15);
+      const u32x4 *src = idx[i] >= 0 ? a.feat + (size_t)idx[i] * a.ldi + blockIdx.y * a.in_goff + cu.kb * 8 + unit
+                                     : g_zero_row + (lane & 7);
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)&Al[h][buf][(wr * AI + i) * 64], 16, 0, 0);
     }
-    cw = c1;
-    cw.template next<KB>();
-  };
-  auto store_w = [&](int buf, u32x4 (&wreg)[WPT]) {
+    const u32x4 *wsrc = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)(cu.k * KB + cu.kb)) * WQ;
+    if constexpr (WI > 0) {
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      int e = tid + NT * i;
-      if (WQ2 % NT == 0 || e < WQ2) Wl[buf][e] = wreg[i];
+      for (int i = 0; i < WI; ++i)
+        __builtin_amdgcn_global_load_lds(wsrc + (wr * WI + i) * 64 + lane,
+                                         (__attribute__((address_space(3))) void *)&Wl[h][buf][(wr * WI + i) * 64], 16, 0, 0);
+    } else {                                      // WQ = 128: waves 0 and 1 of the group move one instruction each
+      if (wr < 2)
+        __builtin_amdgcn_global_load_lds(wsrc + wr * 64 + lane, (__attribute__((address_space(3))) void *)&Wl[h][buf][wr * 64], 16, 0, 0);
     }
+    cu.template next<KB>();
+    cu.template next<KB>();
   };
-  u32x4 a0[RT][NP], a1[RT][NP], a2[RT][NP];
-  int idxn[RT];
-  auto peek_a = [&]() {                            // neighbour indices of this group's next step (LDS round trip)
+  // matrix phase of turn j
+  auto mma = [&](int j) {
+    if (j >= turns) return;
+    const int buf = j & 1;
+    const u32x4 *ab = &Al[h][buf][0];
+    u32x4 af[RT][NP];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) idxn[rt] = nbrL[ca.k][wr * WROWS + rt * 16 + n];
-  };
-  auto issue_a = [&](u32x4 (&dst)[RT][NP]) {
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int idx = idxn[rt];
-      const u32x4 *p = (ca.live && idx >= 0) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff : g_zero_row;
-      p += (ca.kb * 4 + g) * NP;
-#pragma unroll
-      for (int q = 0; q < NP; ++q) dst[rt][q] = p[q];
-    }
-    ca.template next<KB>();
-    ca.template next<KB>();
-  };
-  auto iter = [&](int d, u32x4 (&cur)[RT][NP], u32x4 (&wset)[WPT]) {
-    __syncthreads();
-    peek_a();                                     // indices of iteration d + 3
-    const u32x4 *wb = Wl[d & 1] + h * WQ + lane;
+      for (int q = 0; q < NP; ++q) af[rt][q] = ab[(wr * WROWS + rt * 16 + n) * 8 + ((g * 2 + q) ^ swz(n))];
+    const u32x4 *wb = &Wl[h][buf][0] + lane;
     constexpr int NBATCH = CT / 2;
     u32x4 bq[2][2 * NP];
 #pragma unroll
@@ -1010,10 +1054,6 @@ __global__ __launch_bounds__(512) void spconv_os_sk2_kernel(SplitConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NBATCH; ++i) {
       const int c2 = i * 2;
-      if (i == (NBATCH > 1 ? 1 : 0)) {            // next iteration's tiles go to LDS in the shadow of the first MFMA batch
-        store_w((d + 1) & 1, wset);
-        load_w(wset);                             // tiles of iteration d + 4
-      }
       if (i + 1 < NBATCH) {
 #pragma unroll
         for (int q = 0; q < 2 * NP; ++q) bq[(i + 1) & 1][q] = wb[((i + 1) * 2 * NP + q) * 64];
@@ -1021,54 +1061,99 @@ __global__ __launch_bounds__(512) void spconv_os_sk2_kernel(SplitConvArgs a) {
       const u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][1], bh1 = bq[i & 1][2], bl1 = bq[i & 1][3];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {           // lo * hi
-        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][1], bh0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][1], bh1, acc[rt][c2 + 1]);
+        acc[rt][c2] = DF3D_MFMA_BF16(af[rt][1], bh0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(af[rt][1], bh1, acc[rt][c2 + 1]);
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {           // hi * lo
-        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][0], bl0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][0], bl1, acc[rt][c2 + 1]);
+        acc[rt][c2] = DF3D_MFMA_BF16(af[rt][0], bl0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(af[rt][0], bl1, acc[rt][c2 + 1]);
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {           // hi * hi
-        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][0], bh0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][0], bh1, acc[rt][c2 + 1]);
+        acc[rt][c2] = DF3D_MFMA_BF16(af[rt][0], bh0, acc[rt][c2]);
+        acc[rt][c2 + 1] = DF3D_MFMA_BF16(af[rt][0], bh1, acc[rt][c2 + 1]);
       }
     }
-    issue_a(cur);
   };
 
-  if (iters > 0) {
-    load_w(w0);                                   // iteration 0
-    store_w(0, w0);
-    load_w(w1);                                   // iterations 1, 2, 3
-    load_w(w2);
-    load_w(w0);
-    peek_a();
-    issue_a(a0);
-    peek_a();
-    issue_a(a1);
-    peek_a();
-    issue_a(a2);
-    for (int d = 0; d < iters; d += 3) {          // padding iterations multiply zero rows
-      iter(d, a0, w1);
-      iter(d + 1, a1, w2);
-      iter(d + 2, a2, w0);
+  // Phases (every phase ends with the same barrier for all eight waves):
+  //   group 0:  mem(0) | mem(1) | mma(0) | mem(2) | mma(1) | mem(3) | ...
+  //   group 1:  mem(0) |  --    | mem(1) | mma(0) | mem(2) | mma(1) | ...
+  // A memory phase ends with a counted wait that leaves only ITS OWN DMAs in flight: the data of turn j, issued in
+  // mem(j), has landed when mem(j + 1) ends, one phase before mma(j) reads it.
+  const int maxturns = (steps + 1) / 2;           // group 0's count (>= group 1's)
+  constexpr int DPW = AI + WIE;                   // DMA instructions a wave issues per memory phase
+  static_assert(WI > 0, "every wave issues the same number of DMAs (the counted waits rely on it)");
+  // end of a memory phase: leave this phase's own DMAs in flight (if it issued any), everything older has landed
+  auto end_mem = [&](int j) {
+    if (j < turns) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DPW) : "memory");
+    else DF3D_WAIT_BARRIER(0);
+  };
+  auto end_mma = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#ifdef DF3D_OS_TRACE
+  unsigned long long t_mma = 0, t_mem = 0, t_bar = 0, t_x;
+#define PP_T0() t_x = __builtin_amdgcn_s_memtime()
+#define PP_ACC(v) do { unsigned long long t_y = __builtin_amdgcn_s_memtime(); v += t_y - t_x; t_x = t_y; } while (0)
+#else
+#define PP_T0() do { } while (0)
+#define PP_ACC(v) do { } while (0)
+#endif
+  OS_STAMP(0);
+  PP_T0();
+  if (h == 0) {
+    mem(0);
+    end_mem(0);
+    mem(1);
+    end_mem(1);
+    PP_T0();
+    for (int j = 0; j < maxturns; ++j) {
+      mma(j);
+      PP_ACC(t_mma);
+      end_mma();
+      PP_ACC(t_bar);
+      mem(j + 2);
+      PP_ACC(t_mem);
+      end_mem(j + 2);
+      PP_ACC(t_bar);
     }
+    end_mma();                                    // group 1's last matrix phase
+  } else {
+    mem(0);
+    end_mem(0);
+    end_mma();
+    PP_T0();
+    for (int j = 0; j < maxturns; ++j) {
+      mem(j + 1);
+      PP_ACC(t_mem);
+      end_mem(j + 1);
+      PP_ACC(t_bar);
+      mma(j);
+      PP_ACC(t_mma);
+      end_mma();
+      PP_ACC(t_bar);
+    }
+    end_mma();
   }
+#ifdef DF3D_OS_TRACE
+  if (a.trace && lane == 0) {
+    unsigned long long *t = a.trace + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16 + wave) * 8;
+    t[1] = t_mma, t[2] = t_mem, t[3] = t_bar, t[5] = maxturns;
+  }
+  OS_STAMP(4);
+#endif
 
   // ---- the two partial sums of a row meet: group h keeps row tile h and hands the other one to its partner ----
   f32x4 fin[CT];
   {
-    __syncthreads();                              // every wave is done with the weight buffers
-    f32x4 *ex = (f32x4 *)&Wl[0][0];
+    f32x4 *ex = (f32x4 *)&Al[0][0][0];
+    const int partner = wave ^ 4;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       fin[ct] = h ? acc[1][ct] : acc[0][ct];
       ex[(wave * CT + ct) * 64 + lane] = h ? acc[0][ct] : acc[1][ct];
     }
     __syncthreads();
-    const int partner = wave ^ 4;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) fin[ct] += ex[(partner * CT + ct) * 64 + lane];
   }
@@ -1159,10 +1244,10 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
   // bytes per launch, more than the gathers), so more rows per workgroup = less L2 traffic; bigger register
   // tiles (RT 2) leave too few waves on the 256 CUs at these row counts.
   int rt = 1, nw = a.n_out >= 16 * 1024 ? 8 : 2, kps = 1;
-  // offsets split over two wave groups (spconv_os_sk2_kernel): measured on MI355X (tools/ubench/sk_probe.py) it wins
-  // where a tile has many steps of wide weight tiles -- the 128 -> 128 layers (conv4 K=27: 93 -> 85..88 us, dense K=9:
-  // 40.7 -> 39.1) -- and loses on the 64- and 32-channel layers (64 -> 74 us, 35 -> 38 us), so it serves CIN = COUT = 128
-  // only.  DF3D_OS_SK=0 / 2 forces it off / on for every shape (tuning aid).
+  // LDS-DMA ping-pong kernel (spconv_os_sk2_kernel): measured on MI355X (tools/ubench/sk_probe.py, pp_trace.py) it wins
+  // where a tile has many steps of wide weight tiles -- the 128 -> 128 layers (conv4 K=27: 90 -> 86 us, dense K=9:
+  // 40.2 -> 39.0) -- and loses on the 64- and 32-channel layers, where its 142 KB of LDS leave one workgroup per CU
+  // (65 -> 85 us, 35 -> 48 us), so it serves CIN = COUT = 128 only.  DF3D_OS_SK=0 / 2 forces it off / on (tuning aid).
   static const char *sk = getenv("DF3D_OS_SK");
   const bool sk2 = sk ? sk[0] == '2' : (CIN == 128 && COUT == 128 && a.K >= 9);
   if (sk2 && !a.cols && a.n_out >= 4 * 1024) {

@@ -1,43 +1,96 @@
 #!/usr/bin/env python3
-"""Distil a gpurun_out/<dir> produced by the profiling recipe in DESIGN.md section 5 into profiles/r<NN>_*.
-usage: make_profiles.py <gpurun_out dir> <round tag, e.g. r01>"""
+"""Distil gpurun_out/prof_r02 (written by tools/profile_r02.sh on an MI355X box) into profiles/<tag>_*.
+usage: make_profiles.py <gpurun_out/prof_r02> <round tag, e.g. r02>"""
+import collections
 import csv
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1].rstrip("/") + "/", sys.argv[2]
 out = os.path.join(ROOT, "profiles") + "/"
-KEY = "spconv_os_split_kernel<128, 128"
+KEY = "spconv_os_sk2_kernel<128, 128"          # the conv4 layers (K = 27) and the neck's 128 -> 128 layers (K = 9)
+NECK_GRID = (32400 + 127) // 128 * 512          # the dense 180 x 180 map: 254 workgroups of 512 threads
+N_CAL = 1 << 21
 
 
-def mean_counter(fn, cname):
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(src + fn))
-            if KEY in r["Kernel_Name"] and r["Counter_Name"] == cname]
-    return sum(vals) / len(vals), len(vals)
+def rows(fn):
+    return list(csv.DictReader(open(src + fn)))
 
 
-f, nf = mean_counter("fetch_counter_collection.csv", "FETCH_SIZE")
-w, nw = mean_counter("write_counter_collection.csv", "WRITE_SIZE")
-bench = json.loads(open(src + "bench.json").read().strip().splitlines()[-1])
-pm = {"kernel": "spconv_os_split_kernel<128,128,RT=1,NW=8> (conv4 stage: 4 x K=27 residual-block layers + the K=3 tail)",
+def mean(rs, cname, pred):
+    vals = [float(r["Counter_Value"]) for r in rs if r["Counter_Name"] == cname and pred(r)]
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+conv4 = lambda r: KEY in r["Kernel_Name"] and int(r["Grid_Size"]) != NECK_GRID      # noqa: E731
+cal = lambda r: "spconv_os" in r["Kernel_Name"] and int(r["Grid_Size"]) == N_CAL // 128 * 512    # noqa: E731
+fetch, write = rows("fetch/fetch_counter_collection.csv"), rows("write/write_counter_collection.csv")
+f, nf = mean(fetch, "FETCH_SIZE", conv4)
+w, nw = mean(write, "WRITE_SIZE", conv4)
+cf, ncf = mean(rows("calib_fetch/fetch_counter_collection.csv"), "FETCH_SIZE", cal)
+cw, ncw = mean(rows("calib_write/write_counter_collection.csv"), "WRITE_SIZE", cal)
+exp_f, exp_w = (N_CAL * 512 + N_CAL * 4) / 1024.0, 2 * N_CAL * 512 / 1024.0
+kf, kw = exp_f / cf, exp_w / cw
+calib = {"what": "K = 1 'convolution' 128 -> 128 over 2^21 rows, neighbour table = random permutation: every 512-byte split row "
+                 "of the 1 GiB input is gathered exactly once by the conv kernel itself (tools/ubench/pmc_calib.py)",
+         "expected_fetch_KB": exp_f, "FETCH_SIZE_KB_mean": cf, "fetch_factor": round(kf, 4),
+         "expected_write_KB": exp_w, "WRITE_SIZE_KB_mean": cw, "write_factor": round(kw, 4), "launches": ncf}
+json.dump(calib, open(out + tag + "_pmc_calibration.json", "w"), indent=1)
+bench = json.loads([l for l in open(src + "bench.json").read().strip().splitlines() if l.startswith("{")][-1])
+roof = bench["roofline"]
+traffic = int((kf * f + kw * w) * 1024)
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows("trace/stats_kernel_trace.csv")
+       if KEY in r["Kernel_Name"] and int(r["Grid_Size_X"]) != NECK_GRID]
+pm = {"kernel": "spconv_os_sk2_kernel<128,128> launched with K = 27 (the four residual-block layers of conv4; the neck's K = 9 "
+                "launches of the same kernel are excluded by their grid size)",
       "kernel_key": [128, 128, 27, 1], "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w, "launches_averaged": nf,
-      "correction": "FETCH_SIZE x2 (gfx950 rocprofv3 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); "
-                    "WRITE_SIZE as reported; x1024 (values are KB)",
-      "traffic_bytes_per_launch": int((2 * f + w) * 1024),
-      "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-      "note": "mean over all <128,128> launches of a step; below the algorithmic bytes because gathered input rows are "
-              "re-read out of L2 / Infinity Cache, not HBM; the packed filter bank is re-read by every workgroup out of L2",
-      "command": "rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate pass) --kernel-trace --output-format csv -- "
-                 "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing"}
+      "fetch_calibration": {"factor": round(kf, 4), "write_factor": round(kw, 4),
+                            "source": "profiles/%s_pmc_calibration.json (known-size gather by the same kernel)" % tag},
+      "correction": "FETCH_SIZE x %.3f, WRITE_SIZE x %.3f (calibrated on a known-size gather in this kernel's access pattern, "
+                    "MI355X_MICROARCH.md HBM section); x1024 (values are KB)" % (kf, kw),
+      "traffic_bytes_per_launch": traffic, "fetch_bytes_per_launch": int(kf * f * 1024), "write_bytes_per_launch": int(kw * w * 1024),
+      "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "compulsory_bytes": roof.get("compulsory_bytes"),
+      "rocprofv3_avg_launch_us": round(sum(dur) / len(dur), 2), "bench_hip_event_avg_launch_us": roof["avg_launch_us"],
+      "hbm_rate_GBps_over_rocprof_time": round(traffic / (sum(dur) / len(dur) * 1e-6) / 1e9, 1),
+      "command": "tools/profile_r02.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate passes) --kernel-trace "
+                 "--output-format csv -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-passes "
+                 "--no-kernel-timing (8 rotating frames)"}
 json.dump(pm, open(out + tag + "_pmc_spconv_split.json", "w"), indent=1)
-shutil.copy(src + "stats_kernel_stats.csv", out + tag + "_bench_cp_fusion_kernel_stats.csv")
-shutil.copy(src + "bench.json", out + tag + "_bench_cp_fusion.json")
-for fn, o in (("fetch_counter_collection.csv", "_pmc_fetch_size.csv"), ("write_counter_collection.csv", "_pmc_write_size.csv")):
-    rows = list(csv.reader(open(src + fn)))
-    keep = [rows[0]] + [r for r in rows[1:] if "spconv" in r[8] or "ffn_split" in r[8] or "img_proj" in r[8]]
-    csv.writer(open(out + tag + o, "w", newline="")).writerows(keep)
+shutil.copy(src + "trace/stats_kernel_stats.csv", out + tag + "_bench_cp_fusion_kernel_stats.csv")
+json.dump(bench, open(out + tag + "_bench_cp_fusion.json", "w"), indent=1)
+for fn, o, cn in (("fetch/fetch_counter_collection.csv", "_pmc_fetch_size.csv", "FETCH_SIZE"),
+                  ("write/write_counter_collection.csv", "_pmc_write_size.csv", "WRITE_SIZE")):
+    agg = collections.OrderedDict()
+    for r in rows(fn):
+        if r["Counter_Name"] != cn or not ("spconv" in r["Kernel_Name"] or "ffn_split" in r["Kernel_Name"] or "img_proj" in r["Kernel_Name"]
+                                           or "msda" in r["Kernel_Name"]):
+            continue
+        k = (r["Kernel_Name"].split("(")[0][:90], r["Grid_Size"])
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    with open(out + tag + o, "w", newline="") as fh:
+        wr = csv.writer(fh)
+        wr.writerow(["Kernel_Name", "Grid_Size", "Launches", cn + "_KB_mean"])
+        for (k, g), (n, s) in agg.items():
+            wr.writerow([k, g, n, "%.1f" % (s / n)])
+# SQ counters of the dominant kernel
+try:
+    sq = rows("sq/sq_counter_collection.csv")
+    names = sorted(set(r["Counter_Name"] for r in sq))
+    summ = {c: mean(sq, c, conv4)[0] for c in names}
+    json.dump({"kernel": pm["kernel"], "mean_per_launch": summ,
+               "note": "SQ_* counters count quad-cycles per SIMD-wave slot except SQ_VALU_MFMA_BUSY_CYCLES (cycles); "
+                       "GRBM_GUI_ACTIVE / kernel time = effective clock"},
+              open(out + tag + "_pmc_sq_spconv.json", "w"), indent=1)
+except Exception as e:      # the SQ pass is optional
+    print("no SQ summary:", e)
+ps = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_summary.py"), src + "trace/stats_kernel_trace.csv", "--csv",
+                     out + tag + "_bench_cp_fusion_per_step.csv"], capture_output=True, text=True)
+print(ps.stdout[:3000])
 print(json.dumps(pm, indent=1))
-print("bench:", bench["value"], bench["roofline"])
+print(json.dumps(calib, indent=1))

@@ -65,7 +65,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 import numpy as np
 iters = sys.argv[1] if len(sys.argv) > 1 else "30"
 outs = {}
-for tag, env in (("os", {}), ("sk2", {"DF3D_OS_SK": "2"})):
+for tag, env in (("os", {"DF3D_OS_SK": "0"}), ("sk2", {"DF3D_OS_SK": "2"})):
     print("----", tag, flush=True)
     path = "/tmp/sk_probe_%s.npz" % tag
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "child", iters, path], env=dict(os.environ, **env))
