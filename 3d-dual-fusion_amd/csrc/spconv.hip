@@ -597,6 +597,119 @@ __global__ __launch_bounds__(256) void spconv_generic_kernel(ConvArgs a) {
   a.out[t] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// C <= 16 input channels and 16 output channels (conv_input 5 -> 16, the conv1 blocks 16 -> 16): vector-ALU kernel.
+// These layers are 0.06 GFLOP on ~38 k rows with ~3 neighbours per row -- nothing for the matrix cores to do.  The
+// MFMA kernel above ran them as 27 barrier-separated steps of four tiny matrix instructions with a one-step gather
+// prefetch: ~0.8 us per step of pure latency, 22-29 us per launch for ~15 MB of traffic.
+// Here a row is owned by COUT / 4 adjacent lanes (4 output channels each), the whole filter bank sits in LDS (27.6 KB,
+// fetched once per persistent workgroup, read as broadcast float4), the 27 neighbour lookups are one batch of
+// independent loads and only the present neighbours are gathered; no barrier after the weights are in.
+// Measured on MI355X: 16 -> 16 29.5 -> 17.5 us, 5 -> 16 26 -> 16 us per launch.  (Tried and slower: splitting the
+// INPUT channels over the lanes with branch-free gathers, 36 us; the same kernel for 16 -> 32, 40-68 us vs 38.)
+// The accumulation order is the MFMA kernel's (offsets ascending; inside an offset the channels in the order the
+// 16x16x4 k-groups consumed them: ci = g * KS + j for j outer, g inner), one fmaf per product: bit-identical results.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_small_kernel(ConvArgs a) {
+  constexpr int LPR = COUT / 4;                   // lanes per row
+  constexpr int RPB = 256 / LPR;                  // rows per workgroup pass
+  constexpr int CINP = CIN <= 8 ? 8 : 16;         // the padded channel count the MFMA kernel worked on
+  constexpr int KS = CINP / 4;
+  extern __shared__ float Wl[];                   // [K][CIN][COUT]
+  const int tid = threadIdx.x;
+  for (int e = tid; e < a.K * CIN * COUT / 4; e += 256) ((f32x4 *)Wl)[e] = ((const f32x4 *)a.w)[e];
+  __syncthreads();
+  const int c4 = (tid % LPR) * 4;
+  // persistent workgroups: the filter bank is fetched once per workgroup, not once per 64 rows
+  for (int row = blockIdx.x * RPB + tid / LPR; row < a.n_out; row += gridDim.x * RPB) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int idx[DF3D_MAX_KVOL];
+#pragma unroll
+    for (int k = 0; k < DF3D_MAX_KVOL; ++k) idx[k] = k < a.K ? a.nbr[(size_t)k * a.n_out + row] : -1;
+#pragma unroll
+    for (int k = 0; k < DF3D_MAX_KVOL; ++k) {
+      if (idx[k] < 0) continue;
+      const float *f = a.feat + (size_t)idx[k] * CIN;
+      float x[CINP];
+      if constexpr (CIN % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < CIN / 4; ++q) {
+          const f32x4 v = *(const f32x4 *)(f + q * 4);
+          x[q * 4] = v[0], x[q * 4 + 1] = v[1], x[q * 4 + 2] = v[2], x[q * 4 + 3] = v[3];
+        }
+      } else {
+#pragma unroll
+        for (int ci = 0; ci < CINP; ++ci) x[ci] = ci < CIN ? f[ci] : 0.f;
+      }
+      const float *wk = Wl + (size_t)k * CIN * COUT + c4;
+#pragma unroll
+      for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ci = g * KS + j;
+          if (ci >= CIN) continue;
+          const f32x4 w = *(const f32x4 *)(wk + ci * COUT);
+          acc[0] = fmaf(x[ci], w[0], acc[0]);
+          acc[1] = fmaf(x[ci], w[1], acc[1]);
+          acc[2] = fmaf(x[ci], w[2], acc[2]);
+          acc[3] = fmaf(x[ci], w[3], acc[3]);
+        }
+    }
+    f32x4 v = acc;
+    if (a.bias) v += *(const f32x4 *)(a.bias + c4);
+    if (a.scale) v = v * *(const f32x4 *)(a.scale + c4) + *(const f32x4 *)(a.shift + c4);
+    else if (a.shift) v += *(const f32x4 *)(a.shift + c4);
+    const size_t o = (size_t)row * COUT + c4;
+    if (a.residual) v += *(const f32x4 *)(a.residual + o);
+    if (a.relu) {
+      v[0] = fmaxf(v[0], 0.f);
+      v[1] = fmaxf(v[1], 0.f);
+      v[2] = fmaxf(v[2], 0.f);
+      v[3] = fmaxf(v[3], 0.f);
+    }
+    *(f32x4 *)(a.out + o) = v;
+  }
+}
+
+static int num_cu_small() {
+  static int n = 0;
+  if (!n) {
+    hipDeviceProp_t p;
+    n = (hipGetDeviceProperties(&p, 0) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <int CIN, int COUT>
+static int launch_small(const ConvArgs &a, hipStream_t stream) {
+  const size_t lds = (size_t)a.K * CIN * COUT * 4;
+  static bool configured = false;
+  if (!configured && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)spconv_small_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(DF3D_MAX_KVOL * CIN * COUT * 4));
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+      return DF3D_EHIP;
+    }
+    configured = true;
+  }
+  constexpr int RPB = 256 / (COUT / 4);
+  const int per_cu = lds > 40 * 1024 ? 2 : 4;      // resident workgroups per CU (LDS-limited)
+  const int nblk = cdiv(a.n_out, RPB), grid = nblk < num_cu_small() * per_cu ? nblk : num_cu_small() * per_cu;
+  hipLaunchKernelGGL((spconv_small_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, stream, a);
+  return 1;
+}
+
+// -> 1 served, 0 not a small shape, < 0 error
+static int dispatch_small(const ConvArgs &a, hipStream_t stream) {
+  static const bool off = getenv("DF3D_SMALL_CONV") && getenv("DF3D_SMALL_CONV")[0] == '0';
+  if (off || a.n_out < 2048) return 0;
+  if (a.cin == 16 && a.cout == 16) return launch_small<16, 16>(a, stream);
+  if (a.cin == 5 && a.cout == 16) return launch_small<5, 16>(a, stream);
+  if (a.cin == 4 && a.cout == 16) return launch_small<4, 16>(a, stream);
+  return 0;
+}
+
 template <int CINP, int COUT, int KC, bool VEC>
 static void launch_mfma(const ConvArgs &a, hipStream_t stream) {
   // small layers: 64-row tiles so that the grid still covers the 256 CUs several times
@@ -828,9 +941,14 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
   a.relu = relu;
   const int trec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 0, stream);
   bool done = false;
+  {
+    int r = dispatch_small(a, stream);             // C <= 16 input channels: vector-ALU kernel
+    if (r < 0) return r;
+    done = r == 1;
+  }
   // compute-bound shapes: pair-compacted kernel (DF3D_SPCONV_V1=1 forces the output-stationary kernel)
   static const bool use_v2 = getenv("DF3D_SPCONV_V1") == nullptr;
-  if (use_v2) {
+  if (use_v2 && !done) {
     int r = dispatch_pair(a, tile_rows, ntiles, stream);
     if (r < 0) return r;
     done = r == 1;
