@@ -576,10 +576,23 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         ind = x.indices
         v3d = ind[:, 1:].float() * voxel_stride * self.voxel_size + self.point_cloud_range[:3]      # (z,y,x)
         xyz = v3d[:, [2, 1, 0]]
-        for k in ("noise_scale", "noise_rot", "flip_x", "flip_y"):
-            if k in batch_dict:
-                raise NotImplementedError("inverse 3-D augmentation (%s) is a training-time row" % k)
-        P = batch_dict["lidar2img"].float()[ind[:, 0].long()]                                        # [N,3,4]
+        bi = ind[:, 0].long()
+        # the point cloud the camera saw: undo the recorded augmentations in the reference's order (:701-714) --
+        # global scale, rotation about z by -noise_rot (rotate_points_along_z, VR/pcdet/utils/common_utils.py:35-57),
+        # flip about the x axis (y -> -y), flip about the y axis (x -> -x)
+        if "noise_scale" in batch_dict:
+            xyz = xyz / torch.as_tensor(batch_dict["noise_scale"], dtype=xyz.dtype, device=xyz.device)[bi][:, None]
+        if "noise_rot" in batch_dict:
+            ang = -torch.as_tensor(batch_dict["noise_rot"], dtype=xyz.dtype, device=xyz.device)[bi]
+            ca, sa = torch.cos(ang), torch.sin(ang)
+            xyz = torch.stack([xyz[:, 0] * ca - xyz[:, 1] * sa, xyz[:, 0] * sa + xyz[:, 1] * ca, xyz[:, 2]], 1)
+        if "flip_x" in batch_dict:
+            sgn = 1.0 - 2.0 * torch.as_tensor(batch_dict["flip_x"], device=xyz.device)[bi].to(xyz.dtype)
+            xyz = torch.stack([xyz[:, 0], xyz[:, 1] * sgn, xyz[:, 2]], 1)
+        if "flip_y" in batch_dict:
+            sgn = 1.0 - 2.0 * torch.as_tensor(batch_dict["flip_y"], device=xyz.device)[bi].to(xyz.dtype)
+            xyz = torch.stack([xyz[:, 0] * sgn, xyz[:, 1], xyz[:, 2]], 1)
+        P = batch_dict["lidar2img"].float()[bi]                                                      # [N,3,4]
         # broadcast multiply-adds: einsum lowers to a batched GEMM over N tiny 3x4 matrices (2.4 ms per call at 200k voxels)
         h = P[:, :, 0] * xyz[:, 0:1] + P[:, :, 1] * xyz[:, 1:2] + P[:, :, 2] * xyz[:, 2:3] + P[:, :, 3]
         uv = h[:, :2] / h[:, 2:3]

@@ -41,16 +41,52 @@ class ACTRFusionLayer(nn.Module):
         K = torch.stack([torch.as_tensor(m['cam_intrinsic'], dtype=torch.float32) for m in img_metas]).to(dev)  # [B,6,3,3]
         return l2c, K
 
+    @staticmethod
+    def _undo_3d_augmentation(xyz, b, img_metas):
+        """The points the cameras saw: the 3-D augmentations recorded in `img_meta` are undone in reverse order before
+        the projection, `apply_3d_transformation(points, 'LIDAR', img_meta, reverse=True)` of the reference
+        (TF/mmdet3d/models/fusion_layers/coord_transform.py:6-94 over core/points/base_points.py:77-141,199-205,
+        lidar_points.py:28-33): 'T' subtracts pcd_trans, 'S' multiplies by 1 / pcd_scale_factor, 'R' multiplies the
+        row vectors by the inverse of pcd_rotation, 'HF' / 'VF' negate y / x when the sample was flipped."""
+        if not any(m.get('transformation_3d_flow') for m in img_metas):
+            return xyz
+        xyz = xyz.clone()
+        for i, m in enumerate(img_metas):
+            flow = list(m.get('transformation_3d_flow', []))
+            if not flow:
+                continue
+            sel = (b == i).nonzero(as_tuple=True)[0]
+            x = xyz[sel]
+            rot = torch.as_tensor(m['pcd_rotation'], dtype=x.dtype, device=x.device) if 'pcd_rotation' in m \
+                else torch.eye(3, dtype=x.dtype, device=x.device)
+            trans = torch.as_tensor(m['pcd_trans'], dtype=x.dtype, device=x.device) if 'pcd_trans' in m \
+                else torch.zeros(3, dtype=x.dtype, device=x.device)
+            scale = m.get('pcd_scale_factor', 1.)
+            for op in flow[::-1]:
+                if op == 'T':
+                    x = x + (-trans)
+                elif op == 'S':
+                    x = x * (1.0 / scale)
+                elif op == 'R':
+                    x = x @ rot.inverse()
+                elif op == 'HF':
+                    if m.get('pcd_horizontal_flip', False):
+                        x = x * x.new_tensor([1.0, -1.0, 1.0])
+                elif op == 'VF':
+                    if m.get('pcd_vertical_flip', False):
+                        x = x * x.new_tensor([-1.0, 1.0, 1.0])
+                else:
+                    raise ValueError("This 3D data transformation op (%s) is not supported" % op)
+            xyz[sel] = x
+        return xyz
+
     def project(self, pts, img_metas):
         """pts [N,4] (b,x,y,z) batch-sorted -> cam_id [N] int64, coor_norm [N,2], coor_pix [N,2] (input-image px)."""
         dev = pts.device
-        for m in img_metas:
-            if any(k in m for k in ('pcd_rotation', 'pcd_trans', 'pcd_scale_factor')) or m.get('pcd_horizontal_flip') \
-                    or m.get('pcd_vertical_flip'):
-                raise NotImplementedError("inverse 3-D augmentation is a training-time row (SURVEY.md §8f)")
         l2c, K = self._calib(img_metas, dev)
         b = pts[:, 0].long()
-        xyz1 = torch.cat([pts[:, 1:4], torch.ones_like(pts[:, :1])], 1)              # [N,4]
+        xyz = self._undo_3d_augmentation(pts[:, 1:4], b, img_metas)
+        xyz1 = torch.cat([xyz, torch.ones_like(pts[:, :1])], 1)                      # [N,4]
         # broadcast multiply-sum instead of einsum: einsum lowers to a batched GEMM over N*6 tiny 3x4 matrices
         # (9 ms at nuScenes size); this is two element-wise passes
         cam = (l2c[b][:, :, :3, :] * xyz1[:, None, None, :]).sum(-1)                 # [N,6,3]
@@ -104,7 +140,7 @@ class ACTRFusionLayer(nn.Module):
         qpts = pts_feats.new_zeros((N6, max_pts, 3))
         v_feat[seg, slot] = pts_feats
         grid[seg, slot] = norm
-        qpts[seg, slot] = pts[:, 1:4]
+        qpts[seg, slot] = pts[:, 1:4]                    # the reference keeps the AUGMENTED points as lidar_grid (pts_b, :441)
         ic = (pix.to(torch.long) // 4)
         v_i_feat[seg, slot] = img_feats[0][seg, :, ic[:, 1], ic[:, 0]]
         return v_feat, v_i_feat, grid, qpts, seg, slot

@@ -923,6 +923,419 @@ def gen_iou3d():
     save("iou3d.npz", **out)
 
 
+# ------------------------------------------------------------------ TransFusion fusion layer (point_fusion.ACTR)
+TFF = dict(batch=2, n=350, ori_hw=(225, 400), in_hw=(112, 200), feat_hw=(28, 50), focal=316.0, yaw=2.7)
+
+
+def _rot_z(deg):
+    a = np.deg2rad(deg)
+    return np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+
+
+def _quat_from_matrix(R):
+    """unit quaternion (w, x, y, z) of a rotation matrix (Shepperd's method)."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = [0.0, 0.0, 0.0, 0.0]
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    q = np.array(q)
+    return q / np.linalg.norm(q)
+
+
+class _Quaternion(object):
+    """pyquaternion (0.9.x, absent here and unpinned by the reference) restated from its published definition:
+    Quaternion([w, x, y, z]).rotation_matrix of the normalised quaternion."""
+
+    def __init__(self, q):
+        self.q = np.asarray(q, np.float64)
+
+    @property
+    def rotation_matrix(self):
+        w, x, y, z = self.q / np.linalg.norm(self.q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _view_points(points, view, normalize):
+    """nuscenes-devkit (1.1.x, absent here and unpinned by the reference) `geometry_utils.view_points`, restated from
+    its published definition: pad the intrinsic to 4x4, multiply, divide by depth."""
+    viewpad = np.eye(4)
+    viewpad[:view.shape[0], :view.shape[1]] = view
+    nbr = points.shape[1]
+    pts = np.concatenate((points, np.ones((1, nbr))))
+    pts = np.dot(viewpad, pts)[:3, :]
+    if normalize:
+        pts = pts / pts[2:3, :].repeat(3, 0).reshape(3, nbr)
+    return pts
+
+
+def tff_calibration(sample):
+    """Synthetic nuScenes records of one sample whose lidar -> camera chain (lidar sensor -> ego at the sweep -> global
+    -> ego at the image -> camera sensor, point_fusion.py:586-607) composes to six pinhole cameras at 60 deg spacing.
+    Returns (records for the fake DB, lidar2cam [6,4,4] float64 composed from the SAME records, intrinsics [6,3,3])."""
+    cams = synth.nusc_cameras(image_hw=TFF["ori_hw"], focal=TFF["focal"], yaw_offset_deg=TFF["yaw"] + 0.9 * sample)
+    R_ls, t_ls = _rot_z(1.3), np.array([0.94, 0.0, 1.84])                    # lidar sensor -> ego
+    R_el, t_el = _rot_z(33.0 + sample), np.array([410.0 + sample, 1180.0, 0.0])          # ego (sweep time) -> global
+    R_ec, t_ec = _rot_z(33.4 + sample), np.array([410.3 + sample, 1180.2, 0.0])          # ego (image time) -> global
+    A = R_ec.T @ R_el @ R_ls
+    avec = R_ec.T @ (R_el @ t_ls + t_el - t_ec)
+    rec = {"calibrated_sensor": {"cs_lidar%d" % sample: dict(rotation=_quat_from_matrix(R_ls).tolist(), translation=t_ls.tolist())},
+           "ego_pose": {"ep_lidar%d" % sample: dict(rotation=_quat_from_matrix(R_el).tolist(), translation=t_el.tolist())},
+           "sample_data": {"sd_lidar%d" % sample: dict(calibrated_sensor_token="cs_lidar%d" % sample, ego_pose_token="ep_lidar%d" % sample)},
+           "sample": {"s%d" % sample: dict(data={"LIDAR_TOP": "sd_lidar%d" % sample})}}
+    l2c, Ks = [], []
+    for name in synth.NUSC_CAMS:
+        T, K = cams[name]
+        T = T.astype(np.float64)
+        R_cs = A @ T[:3, :3].T
+        t_cs = avec - R_cs @ T[:3, 3]
+        q = _quat_from_matrix(R_cs)
+        rec["calibrated_sensor"]["cs%d_" % sample + name] = dict(rotation=q.tolist(), translation=t_cs.tolist(),
+                                                      camera_intrinsic=K.astype(np.float64).tolist())
+        rec["ego_pose"]["ep%d_" % sample + name] = dict(rotation=_quat_from_matrix(R_ec).tolist(), translation=t_ec.tolist())
+        rec["sample_data"]["sd%d_" % sample + name] = dict(calibrated_sensor_token="cs%d_" % sample + name, ego_pose_token="ep%d_" % sample + name)
+        rec["sample"]["s%d" % sample]["data"][name] = "sd%d_" % sample + name
+        # compose from the records exactly as the reference walks them
+        Rq = lambda r: _Quaternion(r).rotation_matrix              # noqa: E731
+        Rls, Rel, Rec, Rcs = (Rq(rec["calibrated_sensor"]["cs_lidar%d" % sample]["rotation"]), Rq(rec["ego_pose"]["ep_lidar%d" % sample]["rotation"]),
+                              Rq(rec["ego_pose"]["ep%d_" % sample + name]["rotation"]), Rq(q))
+        Rt = Rcs.T @ Rec.T @ Rel @ Rls
+        tt = Rcs.T @ (Rec.T @ (Rel @ t_ls + t_el - t_ec) - t_cs)
+        M = np.eye(4)
+        M[:3, :3], M[:3, 3] = Rt, tt
+        l2c.append(M)
+        Ks.append(K.astype(np.float64))
+    return rec, np.stack(l2c), np.stack(Ks)
+
+
+def tff_inputs():
+    B, n = TFF["batch"], TFF["n"]
+    rs = np.random.RandomState(77)
+    pts = [np.concatenate([rs.uniform(-30, 30, (n, 2)), rs.uniform(-3, 1, (n, 1))], 1).astype(np.float32) for _ in range(B)]
+    feats = detgen.randn("tff_feats", (B * n, 128))
+    img = detgen.randn("tff_img", (B * 6, 256) + TFF["feat_hw"])
+    return pts, feats, img
+
+
+def tff_metas(aug):
+    """img_metas of the two samples (reference keys) + the fake DB records + composed calibration for OUR layer."""
+    ori, inp = TFF["ori_hw"], TFF["in_hw"]
+    sf = [inp[1] / ori[1], inp[0] / ori[0], inp[1] / ori[1], inp[0] / ori[0]]
+    metas, recs, l2cs, Ks = [], {}, [], []
+    for b in range(TFF["batch"]):
+        rec, l2c, K = tff_calibration(b)
+        for tbl, d in rec.items():
+            recs.setdefault(tbl, {}).update(d)
+        m = dict(sample_idx="s%d" % b, filename=["samples/%s/n015__%s__%d.jpg" % (c, c, b) for c in synth.NUSC_CAMS],
+                 ori_shape=(ori[0], ori[1], 3), img_shape=(inp[0], inp[1], 3), input_shape=(inp[0], inp[1]),
+                 scale_factor=np.array(sf, np.float32), flip=False)
+        if aug:
+            ang = 0.3 - 0.5 * b
+            c, s_ = np.cos(ang), np.sin(ang)
+            # mmdet3d GlobalRotScaleTrans / RandomFlip3D records: rotation matrix applied as points @ R, scale, translation
+            m.update(pcd_rotation=np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32).T, pcd_scale_factor=1.04 - 0.07 * b,
+                     pcd_trans=np.array([0.4, -0.3, 0.1], np.float32) * (b + 1), pcd_horizontal_flip=(b == 0),
+                     pcd_vertical_flip=(b == 1), transformation_3d_flow=['HF', 'VF', 'R', 'S', 'T'])
+        metas.append(m)
+        l2cs.append(l2c)
+        Ks.append(K)
+    return metas, recs, np.stack(l2cs), np.stack(Ks)
+
+
+def import_reference_tf_fusion():
+    R = "/root/reference/TransFusion/mmdet3d"
+    for pkg, path in [("mmdet3d", R), ("mmdet3d.models", R + "/models"), ("mmdet3d.models.model_utils", R + "/models/model_utils"),
+                      ("mmdet3d.models.model_utils.ops", R + "/models/model_utils/ops"), ("mmdet3d.ops", R + "/ops"),
+                      ("mmdet3d.core", R + "/core"), ("mmdet3d.core.bbox", R + "/core/bbox"),
+                      ("mmdet3d.models.fusion_layers", R + "/models/fusion_layers")]:
+        _stub(pkg).__path__ = [path]
+    _stub("cv2")
+    tv = _stub("torchvision", __version__="0.25.0")
+    tv.ops = _stub("torchvision.ops")
+    tv.ops.misc = _stub("torchvision.ops.misc", _NewEmptyTensorOp=None)
+    _stub("MultiScaleDeformableAttention")
+
+    class ConvModule(torch.nn.Module):
+        def __init__(s, *a, **k):
+            super().__init__()
+
+    _stub("mmcv")
+    _stub("mmcv.cnn", ConvModule=ConvModule, xavier_init=lambda *a, **k: None)
+    for n, a in [("mmdet3d.ops.gather_points.gather_points", "gather_points"),
+                 ("mmdet3d.ops.furthest_point_sample.points_sampler", "Points_Sampler"),
+                 ("mmdet3d.ops.group_points.group_points", "QueryAndGroup")]:
+        _stub(n.rsplit(".", 1)[0])
+        _stub(n, **{a: None})
+
+    class _Registry(object):
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    _stub("mmdet3d.models.registry", FUSION_LAYERS=_Registry())
+    _stub("mmdet3d.core.bbox.structures", get_proj_mat_by_coord_type=lambda meta, coord: np.eye(4, dtype=np.float32))
+    _stub("nuscenes")
+    _stub("nuscenes.utils")
+    _stub("nuscenes.utils.geometry_utils", view_points=_view_points)
+    _stub("nuscenes.nuscenes", NuScenes=None)
+    _stub("pyquaternion", Quaternion=_Quaternion)
+    importlib.import_module("mmdet3d.core.points")                       # the reference's own LiDARPoints (pure torch)
+    ct = importlib.import_module("mmdet3d.models.fusion_layers.coord_transform")
+    sys.modules["mmdet3d.models.fusion_layers"].apply_3d_transformation = ct.apply_3d_transformation
+    func = importlib.import_module("mmdet3d.models.model_utils.ops.functions.ms_deform_attn_func")
+
+    class _F:
+        apply = staticmethod(lambda v, s, l, loc, w, step: func.ms_deform_attn_core_pytorch(v, s, loc, w))
+
+    importlib.import_module("mmdet3d.models.model_utils.ops.modules.ms_deform_attn").MSDeformAttnFunction = _F
+    return importlib.import_module("mmdet3d.models.fusion_layers.point_fusion")
+
+
+def gen_tf_fusion():
+    """The reference's own fusion layer -- point_fusion.ACTR.forward with its get_2d_coor_multi / projection /
+    split_param / agg_param (TF/mmdet3d/models/fusion_layers/point_fusion.py:342-643) -- on synthetic nuScenes records,
+    without and with a 3-D augmentation flow to undo (coord_transform.py:6-94)."""
+    pf = import_reference_tf_fusion()
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        layer = pf.ACTR(pfat_cfg=Cfg(ACTR_CFG)).eval()
+    shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+    layer.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.det_state_dict(shapes).items()})
+    pts, feats, img = tff_inputs()
+    out = {"param_names": np.array(sorted(shapes))}
+    for tag, aug in (("plain", False), ("aug", True)):
+        metas, recs, l2c, K = tff_metas(aug)
+
+        class FakeNusc(object):
+            def get(self, table, token):
+                return recs[table][token]
+
+        layer.nusc = FakeNusc()
+        coords, coords_o = [], []
+        # The reference runs on the GPU, where `points.cpu().numpy()` (point_fusion.py:585) is a COPY that its in-place
+        # rotate / translate helpers may overwrite; on this CPU-only box the same expression aliases the input tensor
+        # and camera n would see the points camera n-1 left behind.  Tensor.cpu() is made to copy for the duration.
+        orig_cpu = torch.Tensor.cpu
+        torch.Tensor.cpu = lambda self, *a, **k: orig_cpu(self, *a, **k).clone()
+        for b, m in enumerate(metas):
+            c2, c2o = pf.get_2d_coor_multi(img_meta=m, points=torch.from_numpy(pts[b]), proj_mat=torch.eye(4), coord_type='LIDAR',
+                                           img_scale_factor=torch.from_numpy(m['scale_factor'][:2]), img_crop_offset=0,
+                                           img_flip=False, img_pad_shape=m['input_shape'][:2], img_shape=m['img_shape'][:2],
+                                           nusc=layer.nusc)
+            coords.append(c2.numpy())
+            coords_o.append(c2o.numpy())
+        with torch.no_grad():
+            fused = layer([torch.from_numpy(img)], [torch.from_numpy(p) for p in pts], torch.from_numpy(feats), metas, None)
+        torch.Tensor.cpu = orig_cpu
+        out[tag + "_coor_2d"] = np.concatenate(coords)
+        out[tag + "_coor_2d_o"] = np.concatenate(coords_o)
+        out[tag + "_fused"] = fused.numpy()
+        out[tag + "_lidar2cam"] = l2c
+        out[tag + "_intrinsic"] = K
+        seen = np.concatenate(coords_o)[:, 1:].any(1)
+        print(tag, "cameras used:", np.bincount(np.concatenate(coords)[:, 0].astype(int), minlength=6), "seen", int(seen.sum()))
+    save("tf_fusion.npz", **out)
+
+
+# ------------------------------------------------------------------ Voxel-RCNN fusion glue (VoxelBackBone8xFusion.point_fusion)
+VRF = dict(batch=2, hw=(96, 320), n1=900, n4=260,
+           lt=dict(npoint=64, radius=2.0, nsample=8, num_layers=2),
+           actr=dict(fusion_method='sum', feature_modal='hybrid', num_bins=80, num_channels=[256], query_num_feat=64,
+                     num_enc_layers=4, max_num_ne_voxel=20000, pos_encode_method='depth'),
+           hybrid=dict(attn_layer='BiGateSum1D_2', q_method='sum', q_rep_place=['weight']))
+
+
+def vrf_calib(b):
+    """KITTI-style calibration of sample b: P2 [3,4], R0 [3,3], Tr_velo2cam [3,4] (float32 as the devkit files are read)."""
+    H, W = VRF["hw"]
+    P2 = np.array([[180.0 + 3 * b, 0, W / 2 + 1.5, 11.0], [0, 180.0 + 3 * b, H / 2 - 0.7, 0.3], [0, 0, 1, 0.002]], np.float32)
+    a = np.deg2rad(0.4 + 0.3 * b)
+    R0 = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    V2C = np.array([[0.003, -1, 0.01, 0.01], [0.012, 0.008, -1, -0.08], [1, 0.004, 0.011, -0.27]], np.float32)
+    return P2, R0, V2C
+
+
+def vrf_inputs():
+    """Index sets at stride 1 (conv1, 16 ch) and stride 8 (conv4, 64 ch) on the KITTI grid [41, 1600, 1408], the two
+    camera feature maps, and per-sample augmentation records (noise_scale, noise_rot, flip_x)."""
+    B, (H, W) = VRF["batch"], VRF["hw"]
+    rs = np.random.RandomState(11)
+
+    def voxels(n, stride):
+        out = []
+        for b in range(B):
+            # x in 4..45 m, |y| < 12 m, z -2.5 .. 0.5: inside the camera frustum mostly, some outside
+            x = rs.uniform(4, 45, n), rs.uniform(-12, 12, n), rs.uniform(-2.6, 0.6, n)
+            zi = np.floor((x[2] + 3) / (0.1 * stride)).astype(np.int32)
+            yi = np.floor((x[1] + 40) / (0.05 * stride)).astype(np.int32)
+            xi = np.floor(x[0] / (0.05 * stride)).astype(np.int32)
+            ind = np.unique(np.stack([np.full(n, b, np.int32), zi, yi, xi], 1), axis=0)
+            out.append(ind)
+        return np.concatenate(out)
+    ind1, ind4 = voxels(VRF["n1"], 1), voxels(VRF["n4"], 8)
+    f1 = detgen.randn("vrf_f1", (len(ind1), 16))
+    f4 = detgen.randn("vrf_f4", (len(ind4), 64))
+    mvx = detgen.randn("vrf_mvx", (B, 16, H // 4, W // 4))
+    img = detgen.randn("vrf_img", (B, 256, H // 4, W // 4))
+    aug = dict(noise_scale=np.array([1.03, 0.96], np.float32), noise_rot=np.array([0.21, -0.33], np.float32),
+               flip_x=np.array([True, False]))
+    return ind1, f1, ind4, f4, mvx, img, aug
+
+
+def import_reference_vr_backbone():
+    R = "/root/reference/VoxelRCNN/pcdet"
+    for pkg, path in [("pcdet", R), ("pcdet.models", R + "/models"), ("pcdet.models.model_utils", R + "/models/model_utils"),
+                      ("pcdet.models.model_utils.ops", R + "/models/model_utils/ops"), ("pcdet.ops", R + "/ops"),
+                      ("pcdet.utils", R + "/utils"), ("pcdet.models.backbones_3d", R + "/models/backbones_3d"),
+                      ("pcdet.models.backbones_3d.SemanticSeg", R + "/models/backbones_3d/SemanticSeg")]:
+        _stub(pkg).__path__ = [path]
+    _stub("cv2")
+    _stub("SharedArray")
+    tv = _stub("torchvision", __version__="0.25.0")
+    tv.ops = _stub("torchvision.ops")
+    tv.ops.misc = _stub("torchvision.ops.misc", _NewEmptyTensorOp=None)
+    _stub("MultiScaleDeformableAttention")
+    _stub("mmcv")
+
+    class ConvModule(torch.nn.Module):
+        """mmcv.cnn.ConvModule (absent) restated for the two configurations pointformer.py uses."""
+
+        def __init__(self, cin, cout, k, norm_cfg=None, act_cfg=dict(type="ReLU")):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(cin, cout, k, bias=norm_cfg is None)
+            if norm_cfg is not None:
+                self.bn = torch.nn.BatchNorm2d(cout)
+            if act_cfg is not None:
+                self.activate = torch.nn.ReLU(inplace=True)
+
+        def forward(self, x):
+            x = self.conv(x)
+            if hasattr(self, "bn"):
+                x = self.bn(x)
+            if hasattr(self, "activate"):
+                x = self.activate(x)
+            return x
+
+    _stub("mmcv.cnn", ConvModule=ConvModule)
+    from oracle import oracle as orc
+
+    class Sampler(torch.nn.Module):
+        def __init__(self, num_point, mods):
+            super().__init__()
+            self.m = num_point[0]
+
+        def forward(self, xyz, feats):
+            return torch.from_numpy(orc.furthest_point_sample(xyz.numpy(), self.m))
+
+    class Grouper(torch.nn.Module):
+        def __init__(self, radius, nsample, **kw):
+            super().__init__()
+            self.r, self.ns = radius, nsample
+
+        def forward(self, xyz, new_xyz, feats):
+            idx = orc.ball_query(0.0, self.r, self.ns, xyz.numpy(), new_xyz.numpy())
+            gx = orc.group_points(xyz.transpose(1, 2).contiguous().numpy(), idx)
+            gf = orc.group_points(feats.numpy(), idx)
+            return torch.from_numpy(gf), torch.from_numpy(gx), torch.from_numpy(idx)
+
+    # the reference's four CUDA-only index ops are bound to the oracle (pinned to the reference's own unit-test literals
+    # by gen_pointops), exactly as gen_local_transformer does
+    _stub("pcdet.ops.gather_points")
+    _stub("pcdet.ops.gather_points.gather_points",
+          gather_points=lambda f, i: torch.from_numpy(orc.gather_points(f.numpy(), i.numpy())))
+    _stub("pcdet.ops.furthest_point_sample")
+    _stub("pcdet.ops.furthest_point_sample.points_sampler", Points_Sampler=Sampler)
+    _stub("pcdet.ops.group_points")
+    _stub("pcdet.ops.group_points.group_points", QueryAndGroup=Grouper)
+    # import-only stubs of modules the fusion glue never touches
+
+    class _SparseT(object):
+        def __init__(self, features, indices, spatial_shape, batch_size):
+            self.features, self.indices, self.spatial_shape, self.batch_size = features, indices, spatial_shape, batch_size
+
+    sp = types.SimpleNamespace(SparseModule=torch.nn.Module, SparseConvTensor=_SparseT, SparseSequential=torch.nn.Sequential)
+    _stub("pcdet.utils.spconv_utils", spconv=sp, replace_feature=lambda t, f: _SparseT(f, t.indices, t.spatial_shape, t.batch_size))
+    _stub("pcdet.models.backbones_3d.SemanticSeg.pyramid_ffn", PyramidFeat2D=None)
+    _stub("pcdet.models.backbones_3d.SemanticSeg.aux_seg_loss", AuxConsistencyLoss=None)
+    _stub("pcdet.models.dense_heads", __all__={})
+    _stub("pcdet.models.model_utils.attention", __all__={})
+    func = importlib.import_module("pcdet.models.model_utils.ops.functions.ms_deform_attn_func")
+
+    class _F:
+        apply = staticmethod(lambda v, s, l, loc, w, step: func.ms_deform_attn_core_pytorch(v, s, loc, w))
+
+    importlib.import_module("pcdet.models.model_utils.ops.modules.ms_deform_attn").MSDeformAttnFunction = _F
+    pf = importlib.import_module("pcdet.models.model_utils.pointformer")
+    _fw = pf.TransformerEncoderLayerPreNorm.forward
+    pf.TransformerEncoderLayerPreNorm.forward = lambda self, src, src_mask=None, src_key_padding_mask=None, **kw: \
+        _fw(self, src, src_mask, src_key_padding_mask)
+    bb = importlib.import_module("pcdet.models.backbones_3d.spconv_backbone")
+    cal = importlib.import_module("pcdet.utils.calibration_kitti")
+    actr = importlib.import_module("pcdet.models.model_utils.actr")
+    return bb, cal, actr, sp
+
+
+def gen_vr_fusion():
+    """The reference's own VoxelBackBone8xFusion.point_fusion (VR/pcdet/models/backbones_3d/spconv_backbone.py:650-827)
+    called as a plain function on a stand-in `self` that carries exactly the attributes it reads, with the reference's
+    KITTI `Calibration.lidar_to_img`, its `rotate_points_along_z`, and the reference's ACTRv2 (d_model 64, 4 encoder
+    layers, LocalTransformer per layer) built by its own `build`: (a) the MVX nearest-pixel sum at stride 1, (b) the
+    ACTRv2 dual-query fusion at stride 8, each without and with augmentation records to undo."""
+    bb, cal, actr_mod, sp = import_reference_vr_backbone()
+    torch.set_num_threads(1)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        actr = actr_mod.build(Cfg(VRF["actr"]), model_name="ACTRv2", lt_cfg=Cfg(VRF["lt"]), hybrid_cfg=Cfg(VRF["hybrid"])).eval()
+    shapes = {k: tuple(v.shape) for k, v in actr.state_dict().items()}
+    actr.load_state_dict({k: torch.from_numpy(v) for k, v in detgen.det_state_dict(shapes).items()})
+    ind1, f1, ind4, f4, mvx, img, aug = vrf_inputs()
+    B, (H, W) = VRF["batch"], VRF["hw"]
+    calibs, l2i = [], []
+    for b in range(B):
+        P2, R0, V2C = vrf_calib(b)
+        calibs.append(cal.Calibration(dict(P2=P2, R0=R0, Tr_velo2cam=V2C)))
+        # the same chain in float64 for OUR layer: P2 @ [R0 0; 0 1] @ [V2C; 0 0 0 1]
+        R0e, Ve = np.eye(4), np.eye(4)
+        R0e[:3, :3], Ve[:3, :4] = R0, V2C
+        l2i.append(P2.astype(np.float64) @ R0e @ Ve)
+    me = types.SimpleNamespace(voxel_size=torch.tensor([0.1, 0.05, 0.05]), point_cloud_range=torch.tensor([-3., -40., 0., 1., 40., 70.4]),
+                               inv_idx=torch.tensor([2, 1, 0]), max_num_nev=VRF["actr"]["max_num_ne_voxel"], actr=actr,
+                               attention=False)
+    out = dict(param_names=np.array(sorted(shapes)), lidar2img=np.stack(l2i))
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self                 # the glue calls .cuda() on fresh tensors; no GPU here
+    try:
+        for tag, with_aug in (("plain", False), ("aug", True)):
+            bd = dict(calib=calibs, batch_size=B, images=torch.zeros(B, 3, H, W))
+            if with_aug:
+                bd.update(noise_scale=torch.from_numpy(aug["noise_scale"]), noise_rot=torch.from_numpy(aug["noise_rot"]),
+                          flip_x=torch.from_numpy(aug["flip_x"]))
+            x1 = sp.SparseConvTensor(torch.from_numpy(f1.copy()), torch.from_numpy(ind1.copy()), [41, 1600, 1408], B)
+            with torch.no_grad():
+                y1 = bb.VoxelBackBone8xFusion.point_fusion(me, [x1], bd, {"mvx_layer1_feat2d": torch.from_numpy(mvx)}, "MVX", 1)
+            x4 = sp.SparseConvTensor(torch.from_numpy(f4.copy()), torch.from_numpy(ind4.copy()), [5, 200, 176], B)
+            with torch.no_grad():
+                y4 = bb.VoxelBackBone8xFusion.point_fusion(me, [x4], bd, {"layer1_feat2d": torch.from_numpy(img)}, "ACTRv2", 8)
+            out[tag + "_mvx"] = y1.features.numpy()
+            out[tag + "_actr"] = y4.features.numpy()
+            print(tag, "MVX rows changed:", int((np.abs(y1.features.numpy() - f1).max(1) > 0).sum()), "of", len(f1),
+                  "| ACTR |delta| max %.3f" % np.abs(y4.features.numpy() - f4).max())
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    save("vr_fusion.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "headloss", "conv_bwd", "pool"]
     if "iou3d" in which:
@@ -952,6 +1365,10 @@ if __name__ == "__main__":
         gen_pointops()
     if "lt" in which:
         gen_local_transformer()
+    if "tf_fusion" in which:
+        gen_tf_fusion()
+    if "vr_fusion" in which:
+        gen_vr_fusion()
     if "fusion" in which:
         if "det3d" not in sys.modules:
             import_reference_actr()

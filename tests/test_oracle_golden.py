@@ -437,3 +437,31 @@ def test_centerhead_loss_vs_reference_golden(golden):
     gw = [head.shared_conv[0].weight.grad.abs().sum(dtype=torch.float64).item(),
           head.tasks[1].hm[3].bias.grad.abs().sum(dtype=torch.float64).item()]
     np.testing.assert_allclose(gw, g["gw"], rtol=1e-4)
+
+
+def test_transfusion_projection_vs_reference_golden(golden):
+    """ACTRFusionLayer.project (pure device-side torch, runs on the CPU as well) against the reference's own
+    get_2d_coor_multi / projection walk through nuScenes records (golden tf_fusion.npz, tests/golden/make_golden.py
+    gen_tf_fusion): camera assignment (last visible camera wins, unseen -> camera 0 at (0, 0)) exact, image coordinates
+    to 5e-3 px -- the reference projects in float64 through five frames, the layer in fp32 through the composed
+    lidar2cam.  Second case: a 3-D augmentation flow (flip, flip, rotate, scale, translate) that must be undone first."""
+    import torch
+    from dualfusion.fusion_tf import ACTRFusionLayer
+    from make_golden import ACTR_CFG, TFF, tff_inputs, tff_metas
+    g = golden("tf_fusion.npz")
+    layer = ACTRFusionLayer(pfat_cfg=dict(ACTR_CFG)).eval()
+    pts, _, _ = tff_inputs()
+    cat = torch.cat([torch.cat([torch.full((len(p), 1), float(b)), torch.from_numpy(p)], 1) for b, p in enumerate(pts)])
+    for tag, aug in (("plain", False), ("aug", True)):
+        metas, _, _, _ = tff_metas(aug)
+        ours = []
+        for b, m in enumerate(metas):
+            mm = {k: v for k, v in m.items() if k not in ("sample_idx", "filename")}
+            mm["lidar2cam"], mm["cam_intrinsic"] = g[tag + "_lidar2cam"][b], g[tag + "_intrinsic"][b]
+            ours.append(mm)
+        cam_id, norm, pix = layer.project(cat, ours)
+        want, want_o = g[tag + "_coor_2d"], g[tag + "_coor_2d_o"]
+        assert np.array_equal(cam_id.numpy(), want[:, 0].astype(np.int64)), tag
+        assert len(set(want[:, 0].astype(int))) == 6 and (want_o[:, 1:] == 0).all(1).sum() > 5      # all cameras, some unseen
+        np.testing.assert_allclose(pix.numpy(), want_o[:, 1:], atol=5e-3, rtol=0)
+        np.testing.assert_allclose(norm.numpy(), want[:, 1:], atol=5e-5, rtol=0)
