@@ -196,6 +196,12 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         self.attn_layer = hybrid_cfg['attn_layer']
         self.q_method = hybrid_cfg.get('q_method', None)
         self.q_rep_place = hybrid_cfg.get('q_rep_place', None)
+        # Where the bidirectional gate sits differs between the reference's source trees: CenterPoint / TransFusion run
+        # the two FFNs first and gate last (CP/det3d/models/model_utils/actr_transformer.py:417-425), Voxel-RCNN gates
+        # right after the attention and runs the FFNs on the gated streams (VR/pcdet/models/model_utils/
+        # actr_transformer.py:503-512).  Not configurable in the reference (two copies of the file); here a key of
+        # hybrid_cfg that `VoxelBackBone8xFusion` sets.  Found by the golden of the reference's own VR fusion glue.
+        self.gate_before_ffn = bool(hybrid_cfg.get('gate_before_ffn', False))
         self.d_model = d_model
         self.self_attn = MSDeformAttn(d_model, q_model, n_levels, n_heads, n_points, q_method=self.q_method,
                                       q_rep_place=self.q_rep_place)
@@ -223,10 +229,14 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         iq = q_i_feat if q_pos is None else q_i_feat + q_pos
         att = self.self_attn(lq, reference_points, src, spatial_shapes, level_start_index, padding_mask, i_query=iq)
         q_i_feat = self.norm1(q_i_feat + self.dropout1(att))
+        if self.gate_before_ffn:
+            q_feat, q_i_feat = self.fusion_layer(q_feat, q_i_feat)
         q_i_feat = self.norm2(q_i_feat + self.dropout3(
             self.linear2(self.dropout2(self.activation(self.linear1(q_i_feat))))))
         q_feat = self.norm3(q_feat + self.dropout5(
             self.linear4(self.dropout4(self.activation(self.linear3(q_feat))))))
+        if self.gate_before_ffn:
+            return q_feat, q_i_feat
         return self.fusion_layer(q_feat, q_i_feat)
 
 
@@ -298,8 +308,13 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
                                         sa.attention_weights(Bw), sa.n_levels, sa.n_points, pixel_scale, image_bias)
         att = sa.output_proj(out)
         qi = _ops.add_layernorm(q_i_feat, att, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qi, q = self._ffn_pair(qi, q_feat)
         g = self.fusion_layer
+        if self.gate_before_ffn:
+            q, qi = _ops.bigate_sum(q_feat, qi, g.b_conv1d.weight.view(-1), g.b_conv1d.bias, g.a_conv1d.weight.view(-1),
+                                    g.a_conv1d.bias)
+            qi, q = self._ffn_pair(qi, q)
+            return q, qi
+        qi, q = self._ffn_pair(qi, q_feat)
         return _ops.bigate_sum(q, qi, g.b_conv1d.weight.view(-1), g.b_conv1d.bias, g.a_conv1d.weight.view(-1),
                                g.a_conv1d.bias)
 

@@ -547,7 +547,7 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
     frozen DeepLabV3) is out of scope, so its outputs are read from `batch_dict['img_dict']`
     ({'mvx_layer1_feat2d' | 'layer1_feat2d': [B,C,h,w]}); the KITTI calibration objects, whose
     `lidar_to_img` runs in numpy on the CPU (:717-718), are replaced by `batch_dict['lidar2img']`
-    [B,3,4] = P2 @ R0 @ Tr on the device.  I_FUSION_METHOD (image gate) is not implemented for this tree:
+    [B,3,4] on the device (`lidar2img_from_kitti` composes it from P2 / R0 / Tr the way the devkit projects).  I_FUSION_METHOD (image gate) is not implemented for this tree:
     the shipped `_ifat` yaml cannot be constructed by the reference itself."""
 
     def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
@@ -566,9 +566,23 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
             model_name = self.fusion_method if "MVX+" not in self.fusion_method else self.fusion_method[4:]
             actr_cfg = get("ACTR_CFG", None)
             assert actr_cfg is not None
-            self.actr = build_actr(actr_cfg, model_name=model_name, lt_cfg=get("LT_CFG", None),
-                                   hybrid_cfg=get("HYBRID_CFG", None))
+            hybrid = dict(get("HYBRID_CFG", None) or {})
+            hybrid.setdefault("gate_before_ffn", True)      # this tree's layer order (VR actr_transformer.py:503-512)
+            self.actr = build_actr(actr_cfg, model_name=model_name, lt_cfg=get("LT_CFG", None), hybrid_cfg=hybrid)
             self.max_num_nev = actr_cfg.get("max_num_ne_voxel", 26000)
+
+    @staticmethod
+    def lidar2img_from_kitti(P2, R0, V2C):
+        """[3, 4] matrix for `batch_dict['lidar2img']` from a KITTI calibration (P2 [3,4], R0 [3,3], Tr_velo2cam [3,4]):
+        rows 0 and 1 of P2 @ R0 @ Tr, row 2 = the depth row of R0 @ Tr.  The reference's `Calibration.lidar_to_img`
+        divides the pixel numerators by the rectified-camera DEPTH, not by the homogeneous coordinate of the P2 product
+        (VR/pcdet/utils/calibration_kitti.py:65-93), and P2[2, 3] is not zero in the devkit files."""
+        import numpy as np
+        R0e, Ve = np.eye(4), np.eye(4)
+        R0e[:3, :3], Ve[:3, :4] = np.asarray(R0, np.float64), np.asarray(V2C, np.float64)
+        M = np.asarray(P2, np.float64) @ R0e @ Ve
+        M[2] = (R0e @ Ve)[2]
+        return M.astype(np.float32)
 
     # ------------------------------------------------------------------ geometry (device-side)
     def _project(self, x, voxel_stride, batch_dict):

@@ -1305,10 +1305,14 @@ def gen_vr_fusion():
     for b in range(B):
         P2, R0, V2C = vrf_calib(b)
         calibs.append(cal.Calibration(dict(P2=P2, R0=R0, Tr_velo2cam=V2C)))
-        # the same chain in float64 for OUR layer: P2 @ [R0 0; 0 1] @ [V2C; 0 0 0 1]
+        # the same chain in float64 for OUR layer (VoxelBackBone8xFusion.lidar2img_from_kitti): rows 0, 1 of
+        # P2 @ [R0 0; 0 1] @ [V2C; 0 0 0 1], row 2 = the rectified-camera depth row -- the devkit divides by the rect
+        # depth, not by the homogeneous coordinate (calibration_kitti.py:80-82)
         R0e, Ve = np.eye(4), np.eye(4)
         R0e[:3, :3], Ve[:3, :4] = R0, V2C
-        l2i.append(P2.astype(np.float64) @ R0e @ Ve)
+        M = P2.astype(np.float64) @ R0e @ Ve
+        M[2] = (R0e @ Ve)[2]
+        l2i.append(M)
     me = types.SimpleNamespace(voxel_size=torch.tensor([0.1, 0.05, 0.05]), point_cloud_range=torch.tensor([-3., -40., 0., 1., 40., 70.4]),
                                inv_idx=torch.tensor([2, 1, 0]), max_num_nev=VRF["actr"]["max_num_ne_voxel"], actr=actr,
                                attention=False)
@@ -1325,8 +1329,22 @@ def gen_vr_fusion():
             with torch.no_grad():
                 y1 = bb.VoxelBackBone8xFusion.point_fusion(me, [x1], bd, {"mvx_layer1_feat2d": torch.from_numpy(mvx)}, "MVX", 1)
             x4 = sp.SparseConvTensor(torch.from_numpy(f4.copy()), torch.from_numpy(ind4.copy()), [5, 200, 176], B)
+            stages, hooks = {}, []
+            enc = actr.transformer.encoder
+            for nm, mod in (("lt0", enc.lidar_attns[0]), ("layer0", enc.layers[0]), ("lt1", enc.lidar_attns[1])):
+                hooks.append(mod.register_forward_hook(
+                    lambda m_, i_, o_, nm=nm: stages.__setitem__(nm, (o_[0] if isinstance(o_, tuple) else o_).detach().numpy().copy())))
+            def grab(m_, args, kwargs):
+                stages["in_ref"] = args[2].detach().numpy().copy()
+                stages["in_qpos"] = kwargs["q_pos"].detach().numpy().copy()
+                stages["in_qi"] = kwargs["q_i_feat"].detach().numpy().copy()
+            hooks.append(enc.layers[0].register_forward_pre_hook(grab, with_kwargs=True))
             with torch.no_grad():
                 y4 = bb.VoxelBackBone8xFusion.point_fusion(me, [x4], bd, {"layer1_feat2d": torch.from_numpy(img)}, "ACTRv2", 8)
+            for h_ in hooks:
+                h_.remove()
+            for nm, v in stages.items():               # intermediate LiDAR queries [B, n_max, 64] (localise a deviation)
+                out[tag + "_stage_" + nm] = v
             out[tag + "_mvx"] = y1.features.numpy()
             out[tag + "_actr"] = y4.features.numpy()
             print(tag, "MVX rows changed:", int((np.abs(y1.features.numpy() - f1).max(1) > 0).sum()), "of", len(f1),

@@ -259,9 +259,26 @@ def test_voxel_rcnn_fusion_glue_vs_reference_golden(golden, tag, with_aug):
                   flip_x=torch.from_numpy(aug["flip_x"]).to(dev))
     x1 = sp.SparseConvTensor(torch.from_numpy(f1).to(dev), torch.from_numpy(ind1).to(dev), [41, 1600, 1408], B)
     x4 = sp.SparseConvTensor(torch.from_numpy(f4).to(dev), torch.from_numpy(ind4).to(dev), [5, 200, 176], B)
+    stages, hooks = {}, []
+    enc = m.actr.transformer.encoder
+    for nm, mod in (("lt0", enc.lidar_attns[0]), ("layer0", enc.layers[0]), ("lt1", enc.lidar_attns[1])):
+        hooks.append(mod.register_forward_hook(
+            lambda m_, i_, o_, nm=nm: stages.__setitem__(nm, (o_[0] if isinstance(o_, tuple) else o_).detach().cpu().numpy().copy())))
+    def grab(m_, args, kwargs):
+        stages["in_ref"] = args[2].detach().cpu().numpy().copy()
+        stages["in_qpos"] = kwargs["q_pos"].detach().cpu().numpy().copy()
+        stages["in_qi"] = kwargs["q_i_feat"].detach().cpu().numpy().copy()
+    hooks.append(enc.layers[0].register_forward_pre_hook(grab, with_kwargs=True))
     with torch.no_grad():
         y1 = m._fuse1(x1, bd).features.cpu().numpy()
         y4 = m._fuse4(None, None, x4, bd).features.cpu().numpy()
+    for h_ in hooks:
+        h_.remove()
+    for nm in ("in_ref", "in_qpos", "in_qi", "lt0", "layer0", "lt1"):                 # intermediate LiDAR queries of the reference: localises a deviation
+        want = g[tag + "_stage_" + nm]
+        got = stages[nm].reshape(want.shape)
+        e = np.abs(got - want).max() / np.abs(want).max()
+        assert e <= 1e-3, (nm, e)
     want1, want4 = g[tag + "_mvx"], g[tag + "_actr"]
     # MVX: the gathered pixel is a truncation of a projected coordinate -- a voxel within 1e-3 px of a pixel boundary may
     # land on either side in fp32 vs the reference's float64 numpy projection; everything else must agree to 1e-4
