@@ -30,6 +30,7 @@ struct ProjArgs {
   uint8_t *mask;            // [ncam,n]
   float *pinv;              // [n,3]
   float *depth;             // [ncam,n] or null
+  const float *aug;         // [B][30] or null: translate (3), then three row-vector 3x3 factors (rescale, rotate, flip)
 };
 
 // k-ordered FMA chain, the accumulation a BLAS sgemm micro-kernel performs on the 4-vector
@@ -59,6 +60,23 @@ __global__ __launch_bounds__(256) void project_voxels_kernel(ProjArgs a) {
   py = py + a.miny;
   float pz = (float)p[1] * a.sz;
   pz = pz + a.minz;
+  if (a.aug) {
+    // the point the cameras saw: undo the recorded 3-D augmentations in the reference's order
+    // (point_to_image_projection.py:121-128): p += translate; p = p @ rescale; p = p @ rotate; p = p @ flip.
+    // Absent factors arrive as zeros / identities, which leave the value unchanged bit for bit.
+    const float *g = a.aug + (size_t)b * 30;
+    px = px + g[0];
+    py = py + g[1];
+    pz = pz + g[2];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const float *m = g + 3 + 9 * f;
+      const float qx = fmaf(pz, m[6], fmaf(py, m[3], px * m[0]));
+      const float qy = fmaf(pz, m[7], fmaf(py, m[4], px * m[1]));
+      const float qz = fmaf(pz, m[8], fmaf(py, m[5], px * m[2]));
+      px = qx, py = qy, pz = qz;
+    }
+  }
   if (cam == 0) {
     a.pinv[(size_t)i * 3 + 0] = px;
     a.pinv[(size_t)i * 3 + 1] = py;
@@ -202,14 +220,14 @@ extern "C" int df3d_project_voxels(const int32_t *indices, int n, int batch, int
                                    const float *pc_min, const float *lidar2cam, const float *intrinsic,
                                    const int32_t *raw_hw, const float *depth_thres, float image_scale,
                                    const float *feat_scale, int32_t *grid_xy, uint8_t *mask, float *point_inv,
-                                   float *depth, void *stream_) {
+                                   float *depth, const float *aug_inv, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(indices && lidar2cam && intrinsic && raw_hw && depth_thres && feat_scale && grid_xy && mask &&
                      point_inv && scale_xyz && pc_min,
                  "project_voxels: null argument");
   if (n == 0) return DF3D_OK;
   ProjArgs a = {indices, n, batch, ncam, scale_xyz[0], scale_xyz[1], scale_xyz[2], pc_min[0], pc_min[1], pc_min[2],
-                lidar2cam, intrinsic, raw_hw, depth_thres, image_scale, feat_scale, grid_xy, mask, point_inv, depth};
+                lidar2cam, intrinsic, raw_hw, depth_thres, image_scale, feat_scale, grid_xy, mask, point_inv, depth, aug_inv};
   hipLaunchKernelGGL(project_voxels_kernel, dim3(cdiv((long long)n * ncam, 256)), dim3(256), 0, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;

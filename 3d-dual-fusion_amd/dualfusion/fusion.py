@@ -175,7 +175,25 @@ class VoxelWithPointProjection(nn.Module):
         self._calib_cache = (hit[0], hit[1], dict(hit[2], **self._shape_cache[1]))
         out = dict(self._calib_cache[2])
         out.update(imgs=imgs, img_ptrs=img_ptrs, B=B, ncam=ncam, Ci=Ci, h=h, w=w)
+        if 'aug_matrix_inv' in batch_dict:
+            out['aug_inv'] = self._aug_inverse(batch_dict['aug_matrix_inv'], B, dev)
         return out
+
+    @staticmethod
+    def _aug_inverse(aug_matrix_inv, B, dev):
+        """batch_dict['aug_matrix_inv'] (one dict per sample with any of 'translate' [3] / 'rescale' / 'rotate' / 'flip'
+        [3,3], as CP/det3d/datasets/pipelines/preprocess.py:309-354 records them) -> [B, 30] fp32 for
+        df3d_project_voxels: translate, then the three row-vector factors in the order the reference applies them
+        (point_to_image_projection.py:121-128)."""
+        rows = np.zeros((B, 30), np.float32)
+        for b in range(B):
+            rec = aug_matrix_inv[b] if not isinstance(aug_matrix_inv, dict) else aug_matrix_inv
+            if 'translate' in rec:
+                rows[b, :3] = np.asarray(rec['translate'], np.float32).reshape(-1)[:3]
+            for f, key in enumerate(('rescale', 'rotate', 'flip')):
+                m = np.asarray(rec[key], np.float32).reshape(3, 3) if key in rec else np.eye(3, dtype=np.float32)
+                rows[b, 3 + 9 * f:12 + 9 * f] = m.reshape(-1)
+        return torch.from_numpy(rows).to(dev)
 
     def _pointer_table(self, imgs, dev):
         """Device table of the maps' addresses.  Feature buffers are normally recycled by the caching allocator,
@@ -279,7 +297,8 @@ class VoxelWithPointProjection(nn.Module):
         mp, k2 = _lib.float_arr(pmin)
         rc = lib.df3d_project_voxels(_p(ind), n, inp['B'], ncam, sp, mp, _p(inp['l2c']), _p(inp['intr']),
                                      _p(inp['raw_hw']), _p(inp['thres']), float(np.float32(self.image_scale)),
-                                     _p(inp['feat_scale']), _p(grid), _p(mask), _p(pinv), None, _ops._stream())
+                                     _p(inp['feat_scale']), _p(grid), _p(mask), _p(pinv), None, _p(inp.get('aug_inv')),
+                                     _ops._stream())
         _lib.check(rc, "df3d_project_voxels")
         return grid, mask, pinv
 

@@ -456,6 +456,9 @@ int df3d_gather_points(const float *features, const int32_t *idx, int B, int C, 
  *   * image_scale .long(), * feat_scale .long()); mask = 0<x<W_raw, 0<y<H_raw, depth > thres.
  *   grid_xy [ncam,n,2] i32 (feature-map x,y; 0 where masked), mask [ncam,n] u8,
  *   point_inv [n,3] f32 (LiDAR xyz), depth [ncam,n] f32 or NULL.
+ *   aug_inv [B][30] f32 or NULL: the inverse 3-D augmentation of every sample, applied to the voxel corner before the
+ *   camera transform in the reference's order (point_to_image_projection.py:121-128, batch_dict['aug_matrix_inv']):
+ *   + translate [3], then the row vector times rescale / rotate / flip [3][3] each (identity / zero where absent).
  * df3d_scatter_to_image ("pts2img"): canvas [B*ncam, C+3, H, W] <- (features | xyz) of the
  *   visible voxels, last writer wins (highest row); winner [B*ncam,H,W] i32 is scratch.
  * df3d_assemble_queries: zero-padded per-camera query tensors for ACTR; pos [ncam,n] i32 = slot
@@ -467,7 +470,8 @@ int df3d_project_voxels(const int32_t *indices, int n, int batch, int ncam,
                         const float *scale_xyz_host, const float *pc_min_host,
                         const float *lidar2cam, const float *intrinsic, const int32_t *raw_hw,
                         const float *depth_thres, float image_scale, const float *feat_scale,
-                        int32_t *grid_xy, uint8_t *mask, float *point_inv, float *depth, void *stream);
+                        int32_t *grid_xy, uint8_t *mask, float *point_inv, float *depth, const float *aug_inv,
+                        void *stream);
 int df3d_scatter_to_image(const float *features, const float *point_inv, const int32_t *indices,
                           const int32_t *grid_xy, const uint8_t *mask, int n, int channels,
                           int batch, int ncam, int H, int W, int32_t *winner, float *canvas,

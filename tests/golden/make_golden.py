@@ -282,6 +282,21 @@ def fusion_inputs():
     return sets, feats, cams, img
 
 
+def fusion_aug_inv():
+    """aug_matrix_inv records of the two samples in the pipeline's format (preprocess.py:309-354): flip, rotate, rescale
+    as TRANSPOSED inverse matrices for row vectors, translate as the negated noise."""
+    out = []
+    for b in range(FUS["batch"]):
+        a = -(0.17 - 0.3 * b)
+        c, s_ = np.cos(a), np.sin(a)
+        sc = 1.0 / (1.05 - 0.08 * b)
+        out.append(dict(flip=np.array([[[1, -1][b == 0], 0, 0], [0, [1, -1][b == 1], 0], [0, 0, 1]], np.float32),
+                        rotate=np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32),
+                        rescale=np.array([[sc, 0, 0], [0, sc, 0], [0, 0, sc]], np.float32),
+                        translate=-np.array([0.21, -0.13, 0.05], np.float32) * (b + 1)))
+    return out
+
+
 def gen_fusion():
     """Reference VoxelWithPointProjection.forward (fuse_mode 'pfat', ACTR + ifat gate) on CPU.
     Environment shims only: `.cuda()` -> identity, torch.tensor(device='cuda') -> cpu, and kornia
@@ -372,6 +387,18 @@ def gen_fusion():
             pd = mod.point_projector(voxel_coords=torch.from_numpy(sets[2]).float(), image_scale=FUS["image_scale"],
                                      batch_dict=batch_dict, cam_key=n.lower(), d_factor=8)
             counts[:, ci] = pd['point_mask'].sum(1).numpy()
+        # second case: 3-D augmentation records to undo before the projection (point_to_image_projection.py:121-128)
+        batch_dict['aug_matrix_inv'] = fusion_aug_inv()
+        xs = [SpT(f, i) for f, i in zip(feats, sets)]
+        with torch.no_grad():
+            out_aug = mod(batch_dict, {}, encoded_voxel_list=xs, layer_name='layer1_ori', fuse_mode='pfat',
+                          d_factor_list=[2, 4, 8])
+        counts_aug = np.zeros((B, 6), np.int64)
+        for ci, n in enumerate(synth.NUSC_CAMS):
+            pd = mod.point_projector(voxel_coords=torch.from_numpy(sets[2]).float(), image_scale=FUS["image_scale"],
+                                     batch_dict=batch_dict, cam_key=n.lower(), d_factor=8)
+            counts_aug[:, ci] = pd['point_mask'].sum(1).numpy()
+        save("fusion_cp_aug.npz", out=out_aug.features.numpy(), counts=counts_aug)
         names = np.array(sorted(shapes))
         save("fusion_cp.npz", coords2=sets[0].astype(np.int16), coords3=sets[1].astype(np.int16),
              coords4=sets[2].astype(np.int16), out=out.features.numpy(), counts=counts, param_names=names,

@@ -143,6 +143,23 @@ def test_centerpoint_fusion_adapter_vs_reference_golden(golden):
     ref = g["out"]
     err = np.abs(out.features.cpu().numpy() - ref).max()
     assert err <= 1e-3 * max(1.0, np.abs(ref).max()), err
+    # second case: 3-D augmentation records to undo before the projection (batch_dict['aug_matrix_inv'],
+    # point_to_image_projection.py:121-128) -- golden from the same reference module
+    from make_golden import fusion_aug_inv
+    ga = golden("fusion_cp_aug.npz")
+    batch_dict = dict(batch_dict, aug_matrix_inv=fusion_aug_inv())
+    xs = [spconv.SparseConvTensor(torch.from_numpy(f).to(dev), torch.from_numpy(i).to(dev), shp, B)
+          for f, i, shp in zip(feats, sets, shapes)]
+    inp = mod._gather_inputs(batch_dict, 'layer1_ori', dev)
+    grid, mask, pinv = mod._project(xs[2], 8, inp)
+    counts = np.array([[int((mask[c].bool() & (bcol == b)).sum()) for c in range(6)] for b in range(B)])
+    # an augmented lattice has no exact ties, but a corner may sit within 1 ulp of a pixel boundary: allow one voxel
+    assert np.abs(counts - ga["counts"]).sum() <= 1, (counts, ga["counts"])
+    out = mod(batch_dict, {}, encoded_voxel_list=xs, layer_name='layer1_ori', fuse_mode='pfat', d_factor_list=[2, 4, 8])
+    ref = ga["out"]
+    row_err = np.abs(out.features.cpu().numpy() - ref).max(1)
+    assert (row_err > 1e-3 * max(1.0, np.abs(ref).max())).sum() <= (0 if np.array_equal(counts, ga["counts"]) else 40), row_err.max()
+    assert np.abs(ref - g["out"]).max() > 1.0               # the augmentation records do change the result
 
 
 # ------------------------------------------------------------------------- LocalTransformer (a13) / point ops
