@@ -108,3 +108,149 @@ def all_reduce_value(data, op="sum", average=False):
         assert op.upper() == "SUM"
         return out / dist.get_world_size()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Gradient reduction of the data-parallel training step
+def allreduce_grads(params, coalesce=True, bucket_size_mb=-1):
+    """The reference's synchronous gradient average (CP/det3d/core/utils/dist_utils.py:8-42, called by its
+    DistOptimizerHook after `loss.backward()`): all-reduce every `param.grad`, divided by the world size -- coalesced
+    into flat buffers (one per dtype, or buckets of `bucket_size_mb`) or tensor by tensor."""
+    grads = [p.grad.data for p in params if p.requires_grad and p.grad is not None]
+    if not is_dist() or not grads:
+        return
+    world = dist.get_world_size()
+    if not coalesce:
+        for g in grads:
+            dist.all_reduce(g.div_(world))
+        return
+    buckets = {}
+    if bucket_size_mb > 0:
+        limit, cur, size = bucket_size_mb * 1024 * 1024, [], 0
+        out = []
+        for g in grads:
+            if cur and (size + g.numel() * g.element_size() > limit or g.dtype != cur[0].dtype):
+                out.append(cur)
+                cur, size = [], 0
+            cur.append(g)
+            size += g.numel() * g.element_size()
+        if cur:
+            out.append(cur)
+        groups = out
+    else:
+        for g in grads:
+            buckets.setdefault(g.dtype, []).append(g)
+        groups = list(buckets.values())
+    for group in groups:
+        flat = torch.cat([g.reshape(-1) for g in group])
+        dist.all_reduce(flat)
+        flat.div_(world)
+        pos = 0
+        for g in group:
+            g.copy_(flat[pos:pos + g.numel()].view_as(g))
+            pos += g.numel()
+
+
+class GradBucketReducer(object):
+    """Bucketed gradient all-reduce overlapped with backward -- what `DistributedDataParallel` does for the reference
+    (CP/det3d/torchie/apis/train.py:289-295), laid out for one MI355X node: xGMI is point-to-point (a ring all-reduce is
+    bound by one ~150 GB/s link), so the gradients travel in FEW LARGE buckets (default 64 MB: the whole CenterPoint
+    detector is two), and the buckets are the gradients' own storage:
+
+      * at construction every parameter's `.grad` becomes a view into one flat buffer per bucket (parameters in reverse
+        registration order = the order backward produces them) -- no flatten / copy-back passes per step (the
+        reference's coalesced path copies every gradient twice);
+      * a post-accumulate-grad hook counts a bucket's finished gradients; the last one launches the bucket's all-reduce
+        asynchronously (RCCL runs it on its own stream while backward continues);
+      * `finish()` waits for the outstanding buckets and scales by 1 / world size (folded into the all-reduce for
+        backends with an AVG op).
+
+    Parameters that received no gradient in a step (unused branches) keep zeros in the bucket, like
+    `find_unused_parameters=True`; their bucket is launched by `finish()`."""
+
+    def __init__(self, params, bucket_mb=64.0):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = dist.get_world_size() if is_dist() else 1
+        self.buckets = []            # dict(flat, params, pending, handle)
+        limit = int(bucket_mb * 1024 * 1024)
+        cur, size = [], 0
+        for p in reversed(self.params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (size + nbytes > limit or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self._seal(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self._seal(cur)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._launched = set()
+
+    def _seal(self, plist):
+        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+        pos = 0
+        for p in plist:
+            p.grad = flat[pos:pos + p.numel()].view_as(p)
+            pos += p.numel()
+        b = dict(flat=flat, params=plist, pending=len(plist), handle=None, index=len(self.buckets))
+        for p in plist:
+            p._df3d_bucket = b
+        self.buckets.append(b)
+
+    def _launch(self, b):
+        if b["index"] in self._launched:
+            return
+        self._launched.add(b["index"])
+        if self.world > 1:
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        b = p._df3d_bucket
+        if p.grad.data_ptr() != b["flat"].data_ptr() + self._offset(b, p):
+            # an optimizer / zero_grad(set_to_none=True) replaced the view: copy back into the bucket and restore it
+            view = self._view(b, p)
+            view.copy_(p.grad)
+            p.grad = view
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    @staticmethod
+    def _offset(b, p):
+        off = 0
+        for q in b["params"]:
+            if q is p:
+                return off * p.element_size()
+            off += q.numel()
+        raise KeyError("parameter not in bucket")
+
+    def _view(self, b, p):
+        off = self._offset(b, p) // p.element_size()
+        return b["flat"][off:off + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        """Zero the buckets (keeps the gradient views in place; use INSTEAD of optimizer.zero_grad(set_to_none=True))."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"] = len(b["params"])
+            b["handle"] = None
+            for p in b["params"]:
+                if p.grad is None or p.grad.data_ptr() != self._view(b, p).data_ptr():
+                    p.grad = self._view(b, p)
+        self._launched = set()
+
+    def finish(self):
+        """After backward: launch what is left (buckets with unused parameters), wait, average."""
+        for b in self.buckets:
+            self._launch(b)
+        for b in self.buckets:
+            if b["handle"] is not None:
+                b["handle"].wait()
+                b["handle"] = None
+            if self.world > 1:
+                b["flat"].div_(self.world)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

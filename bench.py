@@ -52,8 +52,10 @@ def parse():
                     help="cp_fusion = BASELINE configs[1] (default, the headline); cp_lidar = configs[0] shape; tf_fusion = "
                          "configs[2] (TransFusion-L + 3D-DF, bs=4, bf16 convs); vr_fusion = configs[4] (Voxel-RCNN + 3D-DF, "
                          "KITTI, bs=8); protocol = launcher / barrier / reduce protocol only, no GPU work (CPU tests)")
-    ap.add_argument("--stage", default="detect", choices=["detect", "hot_path"],
-                    help="detect (default): ... -> neck -> head -> losses -> reduce_dict; hot_path: stop at the dense BEV")
+    ap.add_argument("--stage", default="detect", choices=["detect", "hot_path", "train"],
+                    help="detect (default): ... -> neck -> head -> losses -> reduce_dict; hot_path: stop at the dense BEV; "
+                         "train (cp_lidar only): forward + backward + bucketed gradient all-reduce overlapped with backward "
+                         "+ AdamW step + reduce_dict of the losses -- a real data-parallel training step")
     ap.add_argument("--batch", type=int, default=0, help="sweeps per GPU per step (0 = the workload's BASELINE batch)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames the steps rotate through")
     ap.add_argument("--conv-precision", default=os.environ.get("DF3D_CONV_PRECISION", ""),
@@ -158,9 +160,26 @@ class CenterPointWorkload(object):
                             "SpMiddleResNetFHD, dense BEV, RPN neck, CenterHead, detection losses), fp32 [BASELINE "
                             "configs[0] shape; camera fusion not in this line]"}[self.name]
 
+    def _train_setup(self):
+        from dualfusion import dist as D
+        self.model.train()
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.reducer = D.GradBucketReducer(params, bucket_mb=64.0)
+        self.optimizer = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, foreach=True)
+        self.n_params = sum(p.numel() for p in params)
+
     def step(self, i, stage):
         fr = self.frames[i % len(self.frames)]
         bd, example = self.fresh_inputs(fr)
+        if stage == "train":
+            if getattr(self, "reducer", None) is None:
+                self._train_setup()
+            self.reducer.zero_grad()
+            rets = self.model.training_step(fr["points"], example)
+            self.reducer.finish()                      # waits for the bucket all-reduces launched during backward
+            self.optimizer.step()
+            return {k: torch.stack([v.detach().to(self.dev).float().reshape(()) for v in rets[k]])
+                    for k in ("loss", "hm_loss", "loc_loss")}
         if stage == "hot_path":
             hp = self.model.hot_path
             neck, hp.neck, hp.backbone.dense_layout = hp.neck, None, "nchw"
@@ -173,6 +192,8 @@ class CenterPointWorkload(object):
     def check(self, out, stage):
         if stage == "hot_path":
             assert tuple(out.shape) == (self.batch, 256, 180, 180), out.shape
+        elif stage == "train":
+            assert bool(torch.isfinite(out["loss"]).all()), out
         else:
             v = out["loss"].float().cpu()
             assert v.shape == (6,) and bool(torch.isfinite(v).all()), v
@@ -396,7 +417,7 @@ def timed_steps(wl, stage, steps, first, barrier, reduce_losses):
     out = None
     for k in range(steps):
         out = wl.step(first + k, stage)
-        if isinstance(out, dict) and stage == "detect":
+        if isinstance(out, dict) and stage in ("detect", "train"):
             out = reduce_losses(out)
     barrier()                                  # synchronises the device (all streams) and the ranks
     return time.perf_counter() - t0, out
@@ -432,7 +453,7 @@ def main():
 
     for k in range(args.warmup):
         out = wl.step(k, stage)
-        if isinstance(out, dict) and stage == "detect":
+        if isinstance(out, dict) and stage in ("detect", "train"):
             out = reduce_losses(out)
     barrier()
     # Roofline: HIP events around EVERY conv launch cost the timed region ~6 % (30 launches per frame).  The roofline
@@ -459,7 +480,9 @@ def main():
     elapsed = D.max_over_ranks(elapsed, dev)
     wl.check(out, stage)
     extra = {}
-    if not (args.no_extra_passes or protocol):
+    if stage == "train":
+        assert args.workload == "cp_lidar", "--stage train: the LiDAR detector only (the fused camera adapter has no backward)"
+    if not (args.no_extra_passes or protocol or stage == "train"):
         # the same K steps ending at the dense BEV tensor (round 1's step), and both stages on the exact-fp32 kernels
         if stage == "detect":
             wl.step(0, "hot_path")
@@ -509,7 +532,11 @@ def main():
                                       "scalars%s)" % (world, ", RCCL" if use_gpu and world > 1 else "")},
             "collective_backend": (torch.distributed.get_backend() if D.is_dist() else None), "world_size": world,
         }
-        if stage == "detect" and isinstance(out, dict) and "encoded_spconv_tensor" not in out:
+        if stage == "train":
+            res["config"]["training"] = {"trainable_parameters": getattr(wl, "n_params", None), "optimizer": "AdamW (foreach)",
+                                         "gradient_reduction": "GradBucketReducer: %d bucket(s) of <= 64 MB, all-reduce launched "
+                                                               "from post-accumulate-grad hooks during backward" % len(wl.reducer.buckets)}
+        if stage in ("detect", "train") and isinstance(out, dict) and "encoded_spconv_tensor" not in out:
             res["reduced_losses"] = {k: [round(float(x), 5) for x in v.reshape(-1).float().cpu()] for k, v in out.items()
                                      if k in ("loss", "hm_loss", "loc_loss")}
         if "hot_path" in extra:

@@ -100,3 +100,65 @@ def test_reduce_dict_mixed_shapes_two_ranks(tmp_path):
     r = json.load(open(os.path.join(str(tmp_path), "r.json")))
     assert r["loss"] == [0.5, 1.5, 2.5, 3.5, 4.5, 5.5] and abs(r["elem"] - 1.5) < 1e-6 and r["shape"] == [6, 10]
     assert abs(r["n"] - 2.0) < 1e-6
+
+
+def test_gradient_reduction_two_ranks(tmp_path):
+    """allreduce_grads (the reference's synchronous coalesced average) and GradBucketReducer (bucketed, overlapped with
+    backward, gradients living inside the buckets) against the analytic average over two ranks, incl. a parameter that
+    gets no gradient and a second step after zero_grad()."""
+    worker = textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, os.path.join(%r, "3d-dual-fusion_amd"))
+        import torch
+        from dualfusion import dist as D
+        rank, local, world = D.init_from_env("gloo")
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        unused = torch.nn.Parameter(torch.ones(4))
+        params = list(net.parameters()) + [unused]
+        x = torch.arange(12.0).view(2, 6) * (rank + 1) / 10
+        def local_grads():
+            for p in params:
+                p.grad = None
+            net(x).square().sum().backward()
+            return [None if p.grad is None else p.grad.clone() for p in params]
+        mine = local_grads()
+        # analytic average: gather both ranks' local gradients
+        want = []
+        for g in mine[:-1]:
+            both = [torch.zeros_like(g) for _ in range(world)]
+            torch.distributed.all_gather(both, g)
+            want.append(sum(both) / world)
+        # (a) the reference's synchronous path, coalesced / bucketed / per tensor
+        errs = []
+        for kw in (dict(coalesce=True), dict(coalesce=True, bucket_size_mb=1), dict(coalesce=False)):
+            local_grads()
+            D.allreduce_grads(params, **kw)
+            errs.append(max(float((p.grad - w).abs().max()) for p, w in zip(params[:-1], want)))
+        # (b) the overlapped reducer: gradients are views of two buckets (tiny bucket size forces a split)
+        red = D.GradBucketReducer(params, bucket_mb=0.0002)
+        nb = len(red.buckets)
+        for step in range(2):
+            red.zero_grad()
+            net(x).square().sum().backward()
+            red.finish()
+            errs.append(max(float((p.grad - w).abs().max()) for p, w in zip(params[:-1], want)))
+        ok_unused = bool((unused.grad == 0).all())
+        views = all(p.grad.data_ptr() == red._view(p._df3d_bucket, p).data_ptr() for p in params)
+        with open(os.path.join(os.environ["DF3D_TEST_OUT"], "g%%d.json" %% rank), "w") as f:
+            json.dump({"errs": errs, "buckets": nb, "unused_zero": ok_unused, "views": views}, f)
+        D.barrier()
+        torch.distributed.destroy_process_group()
+    """) % ROOT
+    script = tmp_path / "w.py"
+    script.write_text(worker)
+    sys.path.insert(0, os.path.join(ROOT, "3d-dual-fusion_amd"))
+    from dualfusion import dist as D
+    rc = D.launch_ranks(2, str(script), [], env=dict(os.environ, OMP_NUM_THREADS="1", DF3D_TEST_OUT=str(tmp_path)),
+                        timeout=300)
+    assert rc == 0
+    import json
+    for r in (0, 1):
+        res = json.load(open(os.path.join(str(tmp_path), "g%d.json" % r)))
+        assert max(res["errs"]) < 1e-5, res
+        assert res["buckets"] >= 2 and res["unused_zero"] and res["views"], res
