@@ -93,6 +93,8 @@ struct FfnArgs {
   long long rows;
   int H;
   int dbg;     // tuning experiments (DF3D_FFN_DBG): 1 = no MFMAs, 2 = no weight staging
+  int bf16;    // 1: bf16 operands (activations and weights rounded to bf16 = their hi parts, ONE product per pair),
+               //    fp32 accumulate, fp32 bias / residual / LayerNorm -- the reduced-precision mode of BASELINE configs[2]
 };
 
 // NW waves per workgroup, RT 16-row tiles per wave.  RT = 2 halves the LDS fragment reads per MFMA (every operand
@@ -104,7 +106,9 @@ struct FfnJobs {
   FfnArgs s[4];
 };
 
-template <int NW, int RT>
+// NP = operand parts: 2 = split precision (hi + lo, three products), 1 = bf16 (hi parts only, one product; the lo
+// halves of the packed stream and of the activations are simply not read)
+template <int NW, int RT, int NP = 2>
 __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
   const FfnArgs &a = jobs.s[blockIdx.y];
   if ((long long)blockIdx.x * (16 * RT * NW) >= a.rows) return;
@@ -177,24 +181,26 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
       // operand fragments of the next tile pair come from LDS while the MFMAs of the current pair run
       u32x4 fq[2][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) fq[0][q] = wb[q * 64];
+      for (int q = 0; q < 4; q += (NP == 2 ? 1 : 2)) fq[0][q] = wb[q * 64];
 #pragma unroll
       for (int t = 0; t < 8; t += 2) {
         const int cur = (t >> 1) & 1;
         if (t + 2 < 8) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) fq[cur ^ 1][q] = wb[((t + 2) * 2 + q) * 64];
+          for (int q = 0; q < 4; q += (NP == 2 ? 1 : 2)) fq[cur ^ 1][q] = wb[((t + 2) * 2 + q) * 64];
         }
         const u32x4 ah0 = fq[cur][0], al0 = fq[cur][1], ah1 = fq[cur][2], al1 = fq[cur][3];
+        if constexpr (NP == 2) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          acc1[rt][t] = DF3D_MFMA_BF16(ah0, xl[rt][kb], acc1[rt][t]);
-          acc1[rt][t + 1] = DF3D_MFMA_BF16(ah1, xl[rt][kb], acc1[rt][t + 1]);
-        }
+          for (int rt = 0; rt < RT; ++rt) {
+            acc1[rt][t] = DF3D_MFMA_BF16(ah0, xl[rt][kb], acc1[rt][t]);
+            acc1[rt][t + 1] = DF3D_MFMA_BF16(ah1, xl[rt][kb], acc1[rt][t + 1]);
+          }
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          acc1[rt][t] = DF3D_MFMA_BF16(al0, xh[rt][kb], acc1[rt][t]);
-          acc1[rt][t + 1] = DF3D_MFMA_BF16(al1, xh[rt][kb], acc1[rt][t + 1]);
+          for (int rt = 0; rt < RT; ++rt) {
+            acc1[rt][t] = DF3D_MFMA_BF16(al0, xh[rt][kb], acc1[rt][t]);
+            acc1[rt][t + 1] = DF3D_MFMA_BF16(al1, xh[rt][kb], acc1[rt][t + 1]);
+          }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -233,24 +239,26 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
       if (a.dbg & 1) continue;
       u32x4 fq[2][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) fq[0][k] = wb[k * 64];
+      for (int k = 0; k < 4; k += (NP == 2 ? 1 : 2)) fq[0][k] = wb[k * 64];
 #pragma unroll
       for (int ct = 0; ct < 8; ct += 2) {
         const int cur = (ct >> 1) & 1;
         if (ct + 2 < 8) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) fq[cur ^ 1][k] = wb[((ct + 2) * 2 + k) * 64];
+          for (int k = 0; k < 4; k += (NP == 2 ? 1 : 2)) fq[cur ^ 1][k] = wb[((ct + 2) * 2 + k) * 64];
         }
         const u32x4 bh0 = fq[cur][0], bl0 = fq[cur][1], bh1 = fq[cur][2], bl1 = fq[cur][3];
+        if constexpr (NP == 2) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          acc2[rt][ct] = DF3D_MFMA_BF16(hl[rt][q], bh0, acc2[rt][ct]);
-          acc2[rt][ct + 1] = DF3D_MFMA_BF16(hl[rt][q], bh1, acc2[rt][ct + 1]);
-        }
+          for (int rt = 0; rt < RT; ++rt) {
+            acc2[rt][ct] = DF3D_MFMA_BF16(hl[rt][q], bh0, acc2[rt][ct]);
+            acc2[rt][ct + 1] = DF3D_MFMA_BF16(hl[rt][q], bh1, acc2[rt][ct + 1]);
+          }
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          acc2[rt][ct] = DF3D_MFMA_BF16(hh[rt][q], bl0, acc2[rt][ct]);
-          acc2[rt][ct + 1] = DF3D_MFMA_BF16(hh[rt][q], bl1, acc2[rt][ct + 1]);
+          for (int rt = 0; rt < RT; ++rt) {
+            acc2[rt][ct] = DF3D_MFMA_BF16(hh[rt][q], bl0, acc2[rt][ct]);
+            acc2[rt][ct + 1] = DF3D_MFMA_BF16(hh[rt][q], bl1, acc2[rt][ct + 1]);
+          }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -330,11 +338,24 @@ extern "C" int df3d_ffn_pack(const float *w1, const float *w2, int d_model, int 
 
 static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, hipStream_t stream) {
   static const int cfg = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 81;      // tuning aid: NW*10 + RT
+  if (jobs.s[0].bf16) {                          // every job of a launch shares the precision mode
+    hipLaunchKernelGGL((ffn_split_kernel<8, 1, 1>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+  }
   if (cfg == 42) hipLaunchKernelGGL((ffn_split_kernel<4, 2>), dim3(cdiv(max_rows, 128), njobs), dim3(256), 0, stream, jobs);
   else if (cfg == 82) hipLaunchKernelGGL((ffn_split_kernel<8, 2>), dim3(cdiv(max_rows, 256), njobs), dim3(512), 0, stream, jobs);
   else if (cfg == 41) hipLaunchKernelGGL((ffn_split_kernel<4, 1>), dim3(cdiv(max_rows, 64), njobs), dim3(256), 0, stream, jobs);
   else hipLaunchKernelGGL((ffn_split_kernel<8, 1>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
   DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+static int g_ffn_bf16 = 0;
+// reduced-precision switch of the fused feed-forward kernel (process-wide, like DF3D_CONV_PRECISION for the convs):
+// 0 = split precision (fp32-grade), 1 = bf16 operands with fp32 accumulate
+extern "C" int df3d_ffn_set_precision(int bf16) {
+  g_ffn_bf16 = bf16 ? 1 : 0;
   return DF3D_OK;
 }
 
@@ -350,7 +371,7 @@ extern "C" int df3d_ffn_fused(const float *x, long long rows, int d_model, int d
   FfnJobs jobs;
   memset(&jobs, 0, sizeof(jobs));
   jobs.s[0] = {x, (const u32x4 *)packed, b1, b2, residual, ln_weight, ln_bias, eps, out, rows, d_ffn,
-               getenv("DF3D_FFN_DBG") ? atoi(getenv("DF3D_FFN_DBG")) : 0};
+               getenv("DF3D_FFN_DBG") ? atoi(getenv("DF3D_FFN_DBG")) : 0, g_ffn_bf16};
   return ffn_launch(jobs, 1, rows, stream);
 }
 
@@ -368,7 +389,7 @@ extern "C" int df3d_ffn_fused_jobs(const df3d_ffn_job *j, int njobs, int d_model
     DF3D_CHECK_ARG((j[i].ln_weight == nullptr) == (j[i].ln_bias == nullptr),
                    "ffn_fused_jobs: LayerNorm needs weight and bias");
     jobs.s[i] = {j[i].x, (const u32x4 *)j[i].packed, j[i].b1, j[i].b2, j[i].residual, j[i].ln_weight, j[i].ln_bias,
-                 j[i].eps, j[i].out, j[i].rows > 0 ? j[i].rows : 0, d_ffn, 0};
+                 j[i].eps, j[i].out, j[i].rows > 0 ? j[i].rows : 0, d_ffn, 0, g_ffn_bf16};
     if (j[i].rows > max_rows) max_rows = j[i].rows;
   }
   if (max_rows <= 0) return DF3D_OK;

@@ -86,6 +86,7 @@ SIGNATURES = {
     "df3d_ffn_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "df3d_ffn_fused": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_float, c_void_p, c_void_p]),
+    "df3d_ffn_set_precision": (c_int, [c_int]),
     "df3d_ffn_fused_jobs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "df3d_timing_count_pairs": (c_int, [c_int]),
     "df3d_timing_filter": (c_int, [c_int, c_int, c_int]),

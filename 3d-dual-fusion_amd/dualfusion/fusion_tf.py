@@ -145,7 +145,57 @@ class ACTRFusionLayer(nn.Module):
         v_i_feat[seg, slot] = img_feats[0][seg, :, ic[:, 1], ic[:, 0]]
         return v_feat, v_i_feat, grid, qpts, seg, slot
 
-    def _actr(self, v_feat, grid, img_feats, qpts, v_i_feat):
+    def _forward_native(self, img_feats, pts, pts_feats, cam_id, norm, pix, batch_size):
+        """split_param / agg_param on the kernels of the CenterPoint adapter (csrc/fusion.hip) instead of advanced
+        indexing: every voxel belongs to exactly one (sample, camera) list, so the per-camera visibility mask is
+        one-hot; slots by df3d_query_slots, query tensors (LiDAR rows, image features at pixel // 4 gathered from the
+        channel-first maps, points, depth position embedding) by df3d_assemble_queries2 with only the padding rows
+        cleared, the additive write-back by df3d_fusion_writeback.  One host round trip (the longest list), as the
+        reference has."""
+        import ctypes
+        from . import _lib
+        from . import ops as _ops
+        lib = _lib.load()
+        P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)   # noqa: E731
+        dev = pts.device
+        n, C = pts_feats.shape
+        ncam = self.num_cams
+        f0 = img_feats[0].contiguous()
+        NI, Ci, H, W = f0.shape
+        cams = torch.arange(ncam, device=dev, dtype=cam_id.dtype)
+        mask = (cam_id[None, :] == cams[:, None]).to(torch.uint8).contiguous()                 # [ncam, n] one-hot
+        ic = (pix.to(torch.long) // 4).to(torch.int32)
+        grid = ic[None].expand(ncam, n, 2).contiguous()
+        ind = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        ind[:, 0] = pts[:, 0].to(torch.int32)
+        pinv = pts[:, 1:4].contiguous()
+        pos = torch.empty((ncam, n), dtype=torch.int32, device=dev)
+        counts = torch.empty((batch_size * ncam,), dtype=torch.int32, device=dev)
+        _lib.check(lib.df3d_query_slots(P(mask), P(ind), n, batch_size, ncam, P(pos), P(counts), _ops._stream()),
+                   "df3d_query_slots")
+        max_ne = int(counts.max().item()) if n > 0 else 0                                      # the one host sync
+        N6 = batch_size * ncam
+        v_feat = torch.empty((N6, max_ne, C), dtype=torch.float32, device=dev)
+        v_i_feat = torch.empty((N6, max_ne, Ci), dtype=torch.float32, device=dev)
+        qgrid = torch.empty((N6, max_ne, 2), dtype=torch.float32, device=dev)
+        qpts = torch.empty((N6, max_ne, 3), dtype=torch.float32, device=dev)
+        depth_pos = self.actr.pos_encode_method == "depth" and C % 2 == 0
+        qpos = torch.empty((N6, max_ne, C), dtype=torch.float32, device=dev) if depth_pos else None
+        _lib.check(lib.df3d_assemble_queries2(P(pts_feats), P(pinv), P(ind), P(grid), P(mask), P(pos), P(f0), None, None, n, C,
+                                              Ci, batch_size, ncam, H, W, max_ne, P(v_feat), P(v_i_feat), P(qgrid), P(qpts),
+                                              P(qpos), P(counts), _ops._stream()), "df3d_assemble_queries2")
+        # the reference's query coordinates are the un-truncated image coordinates over the padded input shape
+        # (coor_2d, :538-546), not pixel centres of the feature map: overwrite the kernel's integer-grid values
+        seg = pts[:, 0].long() * ncam + cam_id
+        slot = pos[cam_id, torch.arange(n, device=dev)].long()
+        qgrid[seg, slot] = norm
+        enh = self._actr(v_feat, qgrid, [f0], qpts, v_i_feat, q_pos=qpos).contiguous()
+        out = torch.empty_like(pts_feats)
+        _lib.check(lib.df3d_fusion_writeback(P(pts_feats), P(enh), P(ind), P(mask), P(pos), n, C, ncam, max_ne, P(out),
+                                             _ops._stream()), "df3d_fusion_writeback")
+        return out
+
+    def _actr(self, v_feat, grid, img_feats, qpts, v_i_feat, q_pos=None):
         """ACTR on the assembled queries.  Inference with the 3D-DF configuration (one 256-channel level, two dual-query
         layers) takes the fold-through path of the CenterPoint adapter: the input projection runs on the matrix cores
         straight from the channel-first camera maps (csrc/imgproj.hip) and GroupNorm + both value projections are
@@ -168,7 +218,7 @@ class ACTRFusionLayer(nn.Module):
                 base, step = f0.data_ptr(), Ci * H * W * 4
                 self._ptrs = (pkey, torch.tensor([base + i * step for i in range(NI)], dtype=torch.int64, device=f0.device))
             u, _ = _ops.imgproj_split(self._ptrs[1], NI, Ci, H * W, self._wpack[1])
-            return actr.forward_folded(v_feat, grid, u, None, (H, W), v_i_feat, qpts)
+            return actr.forward_folded(v_feat, grid, u, None, (H, W), v_i_feat, qpts, q_pos=q_pos)
         return actr(v_feat=v_feat, grid=grid, i_feats=img_feats, lidar_grid=qpts, v_i_feat=v_i_feat)
 
     def forward(self, img_feats, pts, pts_feats, img_metas, imgs=None):
@@ -186,6 +236,10 @@ class ACTRFusionLayer(nn.Module):
             raise ValueError("ACTRFusionLayer expects the stride-4 camera feature map: input %dx%d needs at least "
                              "%dx%d, got %dx%d" % (ih, iw, -(-ih // 4), -(-iw // 4), fh, fw))
         cam_id, norm, pix = self.project(pts, img_metas)
+        if (pts_feats.is_cuda and pts_feats.dtype == torch.float32 and self.fusion_method == 'sum' and not self.activate_out
+                and not torch.is_grad_enabled() and len(img_feats) == 1 and img_feats[0].dtype == torch.float32
+                and os.environ.get("DF3D_TF_NATIVE_ASSEMBLE", "1") == "1"):
+            return self._forward_native(img_feats, pts, pts_feats.contiguous(), cam_id, norm, pix, batch_size)
         v_feat, v_i_feat, grid, qpts, seg, slot = self.assemble(img_feats, pts, pts_feats, cam_id, norm, pix, batch_size)
         enh = self._actr(v_feat, grid, img_feats, qpts, v_i_feat)
         enh_cat = enh[seg, slot]

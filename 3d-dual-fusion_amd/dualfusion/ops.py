@@ -986,9 +986,16 @@ def ffn_pack(w1, w2):
     return packed
 
 
+def _ffn_precision(lib):
+    """bf16 mode of the process (DF3D_CONV_PRECISION=bf16 / ops.CONV_PRECISION, BASELINE configs[2]) -> the fused
+    feed-forward kernel runs one bf16 product per operand pair instead of the three split-precision ones."""
+    lib.df3d_ffn_set_precision(1 if CONV_PRECISION == "bf16" else 0)
+
+
 def ffn_fused(x, packed, b1, b2, d_ffn, residual=None, ln_weight=None, ln_bias=None, eps=1e-5):
     """LayerNorm(residual + W2 relu(W1 x + b1) + b2) on [.., 128] rows in one kernel."""
     lib = _lib.load()
+    _ffn_precision(lib)
     _chk(x, torch.float32, "x")
     if residual is not None:
         _chk(residual, torch.float32, "residual")
@@ -1009,6 +1016,7 @@ class _FfnJob(ctypes.Structure):
 def ffn_fused_jobs(jobs, d_ffn):
     """jobs: list of dicts (x, packed, b1, b2, residual, ln_weight, ln_bias, eps) -> list of outputs; one launch."""
     lib = _lib.load()
+    _ffn_precision(lib)
     arr = (_FfnJob * len(jobs))()
     outs = []
     C = jobs[0]["x"].shape[-1]

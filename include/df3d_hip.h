@@ -601,6 +601,10 @@ typedef struct df3d_ffn_job {
   float *out;
 } df3d_ffn_job;
 int df3d_ffn_fused_jobs(const df3d_ffn_job *jobs, int njobs, int d_model, int d_ffn, void *stream);
+/* Reduced-precision mode of the fused feed-forward kernel (BASELINE configs[2], "bf16 with fp32 accumulate"): 1 = the
+ * activations and weights enter the matrix cores rounded to bf16 (one product per operand pair instead of three), the
+ * accumulation, bias, residual and LayerNorm stay fp32; 0 (default) = split precision, fp32-grade.  Process-wide. */
+int df3d_ffn_set_precision(int bf16);
 
 /* ------------------------------------------------------------------------------------
  * Image side of the fusion on the bf16 matrix cores, split precision (csrc/imgproj.hip).  Replaces the 1x1

@@ -414,6 +414,39 @@ def test_ffn_fused(dev, rows, H, ln, res):
     assert err < 5e-5, err
 
 
+@pytest.mark.parametrize("rows", [37, 5000])
+def test_ffn_fused_bf16_mode(dev, rows):
+    """The bf16 mode of the fused feed-forward kernel (BASELINE configs[2]: bf16 operands, fp32 accumulate): against the
+    float64 composition evaluated on the SAME bf16-rounded operands (x, W1, the hidden activation, W2) the result agrees
+    to fp32 summation noise; against the unrounded fp32 layer it sits at bf16 level (a few 1e-3 of the output scale)."""
+    from dualfusion import ops
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    C, H = 128, 1024
+    x = (torch.randn(rows, C, generator=g) * 1.3).to(dev)
+    w1 = (torch.randn(H, C, generator=g) / C ** 0.5).to(dev)
+    w2 = (torch.randn(C, H, generator=g) / H ** 0.5).to(dev)
+    b1, b2 = torch.randn(H, generator=g).to(dev) * 0.3, torch.randn(C, generator=g).to(dev) * 0.3
+    lw, lb = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    packed = ops.ffn_pack(w1, w2)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = "bf16"
+    try:
+        y = ops.ffn_fused(x, packed, b1, b2, H, residual=x, ln_weight=lw, ln_bias=lb, eps=1e-5)
+    finally:
+        ops.CONV_PRECISION = old
+    y32 = ops.ffn_fused(x, packed, b1, b2, H, residual=x, ln_weight=lw, ln_bias=lb, eps=1e-5)      # split precision again
+    r = lambda t: t.to(torch.bfloat16).double()        # noqa: E731  (round to nearest even, like the kernel's hi part)
+    hid = torch.relu(r(x) @ r(w1).t() + b1.double())
+    ref = r(hid.float()) @ r(w2).t() + b2.double() + x.double()
+    ref = torch.nn.functional.layer_norm(ref, (C,), lw.double(), lb.double(), 1e-5)
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-4, err                              # hidden values that round across a bf16 boundary differ by 1 ulp
+    full = torch.relu(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double() + x.double()
+    full = torch.nn.functional.layer_norm(full, (C,), lw.double(), lb.double(), 1e-5)
+    assert float((y.double() - full).abs().max() / full.abs().max()) < 2e-2
+    assert float((y32.double() - full).abs().max() / full.abs().max()) < 5e-5          # the switch went back
+
+
 @pytest.mark.parametrize("N,Q,C,G", [(6, 5189, 128, 32), (2, 77, 256, 32), (1, 1, 64, 16), (3, 300, 128, 8)])
 def test_rows_groupnorm(dev, N, Q, C, G):
     """GroupNorm on the [N, Q, C] layout == the reference's GroupNorm on the Conv1d layout [N, C, Q]."""
