@@ -5,6 +5,7 @@ constructor arguments and parameter names (CP/det3d/models/bbox_heads/center_hea
 instead of ~30 launches and three host round trips per (task, sample).  `loss` (center_head.py:250-298) is the
 reference's torch composition (training row)."""
 import copy
+import os
 
 import torch
 from torch import nn
@@ -151,6 +152,7 @@ class CenterHead(nn.Module):
         s_scale, s_shift = self._fold(sbn)
         dev = sc.weight.device
         mid_packed, mid_bias, mid_scale, mid_shift, fin_packed, fin_bias, cols, layout = [], [], [], [], [], [], [], []
+        fin_w4, fin_b4 = [], []
         c0 = 0
         for t, task in enumerate(self.tasks):
             for head in task.heads:
@@ -163,6 +165,9 @@ class CenterHead(nn.Module):
                 k = fc[3].out_channels
                 fin_packed.append(_ops.conv_pack_weights(self._filters(fc[3], 32)))
                 fin_bias.append(torch.cat([fc[3].bias.detach().float(), torch.zeros(32 - k, device=dev)]))
+                if k <= 4:           # [9, 64, 4] tap-major filters for the vector-ALU kernel (csrc/headconv.hip)
+                    fin_w4.append(self._filters(fc[3], 4))
+                    fin_b4.append(torch.cat([fc[3].bias.detach().float(), torch.zeros(4 - k, device=dev)]))
                 cols.append((c0, k))
                 layout.append((t, head, c0, k))
                 c0 += k
@@ -172,7 +177,9 @@ class CenterHead(nn.Module):
                     mid_scale=torch.cat(mid_scale).contiguous(), mid_shift=torch.cat(mid_shift).contiguous(),
                     fin=torch.cat(fin_packed), fin_bias=torch.cat(fin_bias).contiguous(),
                     cols=torch.tensor(cols, dtype=torch.int32, device=dev).contiguous(), layout=layout,
-                    groups=len(cols), width=(c0 + 7) // 8 * 8, nbr={})
+                    groups=len(cols), width=(c0 + 7) // 8 * 8, nbr={},
+                    fin_w4=torch.stack(fin_w4).contiguous() if len(fin_w4) == len(cols) else None,
+                    fin_b4=torch.stack(fin_b4).contiguous() if len(fin_b4) == len(cols) else None)
         self.__dict__["_row_plan"] = plan
         return plan
 
@@ -196,8 +203,13 @@ class CenterHead(nn.Module):
                                      plan["s_shift"], relu=True, want_out=False, want_split=True)
         _, s2 = _ops.conv_rows_split(s1, 64, 0, plan["mid"], 64, G, nbr, n, plan["mid_bias"], plan["mid_scale"],
                                      plan["mid_shift"], relu=True, want_out=False, want_split=True)
-        out, _ = _ops.conv_rows_split(s2, 64, 64, plan["fin"], 32, G, nbr, n, plan["fin_bias"], None, None, relu=False,
-                                      out_channels=plan["width"], out_cols=plan["cols"])
+        if plan["fin_w4"] is not None and os.environ.get("DF3D_HEAD_FINAL", "valu") == "valu":
+            # 72 output maps of 36 branches: vector-ALU kernel over LDS halo tiles (every activation read 1.6x, exact
+            # fp32 products of hi + lo) instead of a block-diagonal matrix-core launch padded to 32 columns per branch
+            out = _ops.head_final_conv(s2, B, H, W, plan["fin_w4"], plan["fin_b4"], plan["cols"], plan["width"])
+        else:
+            out, _ = _ops.conv_rows_split(s2, 64, 64, plan["fin"], 32, G, nbr, n, plan["fin_bias"], None, None, relu=False,
+                                          out_channels=plan["width"], out_cols=plan["cols"])
         rets = [dict() for _ in self.tasks]
         for t, head, c0, k in plan["layout"]:
             r = out[:, c0:c0 + k]

@@ -484,6 +484,28 @@ def conv_rows_split(in_split, cin, in_group_stride, packed, cout, groups, nbr, n
     return out, osp
 
 
+def head_final_conv(in_split, batch, H, W, weights, bias, out_cols, out_channels):
+    """The last 3x3 convolution of every (task, head) branch of a CenterPoint-style head in one launch
+    (csrc/headconv.hip).  in_split [B*H*W, 4*in_channels] uint8 split rows (branch g = channels g*64 .. g*64+63),
+    weights [G, 9, 64, 4] fp32, bias [G, 4], out_cols [G, 2] int32 -> out [B*H*W, out_channels] fp32."""
+    lib = _lib.load()
+    _chk(in_split, torch.uint8, "in_split")
+    _chk(weights, torch.float32, "weights")
+    _chk(bias, torch.float32, "bias")
+    _chk(out_cols, torch.int32, "out_cols")
+    G = weights.shape[0]
+    if tuple(weights.shape[1:]) != (9, 64, 4) or tuple(bias.shape) != (G, 4) or tuple(out_cols.shape) != (G, 2):
+        raise _lib.Df3dError("head_final_conv: weights [G,9,64,4], bias [G,4], out_cols [G,2] expected")
+    n = int(batch) * int(H) * int(W)
+    if in_split.shape[0] != n:
+        raise _lib.Df3dError("head_final_conv: %d rows for a %dx%dx%d map" % (in_split.shape[0], batch, H, W))
+    out = torch.empty((n, int(out_channels)), dtype=torch.float32, device=in_split.device)
+    rc = lib.df3d_head_final_conv(_ptr(in_split), in_split.shape[1] // 4, int(batch), int(H), int(W), G, _ptr(weights),
+                                  _ptr(bias), _ptr(out_cols), _ptr(out), int(out_channels), _stream())
+    _lib.check(rc, "df3d_head_final_conv")
+    return out
+
+
 def sparse_to_dense(features, indices, batch, shape):
     lib = _lib.load()
     _chk(features, torch.float32, "features")

@@ -286,6 +286,14 @@ int df3d_centerhead_predict(const df3d_head_task *tasks, int ntasks, const df3d_
                             float *out_scores, int32_t *out_labels, int32_t *out_counts, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* df3d_head_final_conv: the LAST convolution of every (task, head) branch of a CenterPoint-style head in one launch
+ * (SepHead, CP/det3d/models/bbox_heads/center_head.py:66-110: Conv2d 64 -> k, 3x3, padding 1, bias, k <= 4 output maps
+ * per branch).  in_split: split rows [batch*H*W, in_channels] (32 B per 8 channels: hi | lo) whose columns
+ * g*64 .. g*64+63 are branch g's activations; weights [groups][9][64][4] fp32 (tap-major, output maps padded to 4),
+ * bias [groups][4]; out_cols [groups][2] = (first output column, valid maps) in out [batch*H*W, out_channels] fp32. */
+int df3d_head_final_conv(const void *in_split, int in_channels, int batch, int H, int W, int groups, const float *weights,
+                         const float *bias, const int32_t *out_cols, float *out, int out_channels, void *stream);
+
 /* df3d_centerhead_loss replaces CenterHead.loss for a no-grad evaluation of the detection losses
  * (CP/det3d/models/bbox_heads/center_head.py:250-298 over FastFocalLoss / RegLoss,
  * CP/det3d/models/losses/centernet_loss.py:6-58): per task the CornerNet focal loss of the clamped sigmoid heat map
