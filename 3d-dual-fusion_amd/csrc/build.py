@@ -24,15 +24,15 @@ def _newer(target, deps):
 
 def build(force=False, verbose=False):
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-    if not force and _newer(OUT, srcs + HEADERS):
-        return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("DF3D_HIPCC_FLAGS", "").split()          # e.g. -DDF3D_OS_EXPERIMENTS for the tuning flags
-    os.makedirs(OBJ_DIR, exist_ok=True)
     stamp = os.path.join(OBJ_DIR, "flags.txt")
     flags_txt = " ".join(CFLAGS + extra)
-    if not os.path.exists(stamp) or open(stamp).read() != flags_txt:
-        force = True
+    if os.path.isdir(OBJ_DIR) and (not os.path.exists(stamp) or open(stamp).read() != flags_txt):
+        force = True                                                 # built with other flags before
+    if not force and _newer(OUT, srcs + HEADERS):
+        return OUT
+    os.makedirs(OBJ_DIR, exist_ok=True)
     objs, jobs = [], []
     for src in srcs:
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")

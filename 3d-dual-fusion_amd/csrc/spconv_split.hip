@@ -483,6 +483,18 @@ __global__ __launch_bounds__(256, 1) void spconv_split_kernel(SplitConvArgs a, i
 // the neighbour index two) exposed LDS round trips into every step's instruction stream, right behind the MFMA batch --
 // an in-order wave cannot hide them, and the barrier re-aligns the two waves of a SIMD every step.
 // Past the last step the cursor stays on it (a valid weight tile) with live = false (zero A rows).
+// Workgroups go to the eight XCDs round-robin by their linear id; this maps id -> tile so that every XCD (= every L2)
+// owns one contiguous range of tiles, for any tile count.
+__device__ __forceinline__ int xcd_tile(int bid, int nt) {
+  const int q = nt >> 3, r = nt & 7, x = bid & 7;
+  return x * q + (x < r ? x : r) + (bid >> 3);
+}
+
+// 32-bit LDS byte address of a __shared__ object (operand of the inline-asm ds_read_b128 below)
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
+}
+
 struct StepCursor {
   unsigned m;
   int k, kb;
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
   int nt = gridDim.x, bid = blockIdx.x, tile = bid;
-  if ((nt & 7) == 0) tile = (bid & 7) * (nt >> 3) + (bid >> 3);     // consecutive tiles stay on one XCD / L2
+  tile = xcd_tile(bid, nt);                       // consecutive tiles stay on one XCD / L2
   const int row0 = tile * TM;
   const int col0 = blockIdx.y * CW;
 
@@ -917,58 +929,59 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Output-stationary kernel, third structure: both operands arrive by LDS-DMA in full cache lines, two wave groups work
-// in anti-phase ("ping-pong").
+// Output-stationary kernel, second structure: four matrix waves and eight loader waves per workgroup, both operands by
+// LDS-DMA in whole cache lines.
 //
-// What the s_memtime stamps of the kernels above show (tools/ubench/pp_trace.py): a step's matrix instructions take their
-// issue time (~800 cycles for the two waves of a SIMD) and no more, but the MEMORY work of a step -- the gathers of the
-// A fragments and the staging of the weight tile -- takes 1300-1700 cycles of the CU's vector-memory path, whatever the
-// order, the prefetch depth or the phase relation of the waves.  The gathers were fragment-shaped: a quarter-wave of 16
-// lanes reads 16 B from each of 16 DIFFERENT rows, i.e. 64 cache-line requests per wave instruction for 1 KB of payload,
-// and every 128-byte line was requested twice (hi and lo parts by separate instructions).
-// Here every vector-memory instruction moves eight whole 128-byte lines:
-//   A  the 32-channel block (hi | lo, 128 B = one line) of each of the tile's 128 rows goes global -> LDS by
-//      global_load_lds_dwordx4, 8 rows per wave instruction; the LDS image of a row is XOR-swizzled in 16-byte units
-//      (on the SOURCE address: an LDS-DMA writes lane-linearly) so that the MFMA-shaped ds_read_b128 of a row tile is
-//      bank-conflict-free;
-//   W  the packed weight tile (already the B-operand image) goes global -> LDS the same way, 1 KB per instruction;
-// no register staging, no ds_write.  A wave owns 32 rows x all columns (two MFMA row tiles per B fragment); the two waves
-// of a SIMD (groups h = 0 / 1) work on the same rows but on alternate steps, one in its matrix phase (20 ds_read_b128,
-// 48 MFMAs) while the other is in its memory phase (8 LDS-DMA instructions for its turn after next, counted vmcnt wait
-// for the previous ones), raw s_barrier between the phases -- the DMAs stay in flight across it.
-// Per group two A and two W buffers; the partial sums of the two groups meet through LDS after the last step.
-#define DF3D_WAIT_BARRIER(VM) asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(512) void spconv_os_sk2_kernel(SplitConvArgs a) {
-  constexpr int NP = 2, RT = 2, NW = 8, NWR = 4, NT = NW * 64;
-  constexpr int CW = COUT > 128 ? 128 : COUT;
-  constexpr int KB = CIN / 32, CT = CW / 16, WROWS = 16 * RT, TM = WROWS * NWR;
-  constexpr int WQ = CT * NP * 64;                // u32x4 per (offset, 32-channel block) weight tile
-  constexpr int AQ = TM * 8;                      // u32x4 per A tile: 128 rows x 128 B
-  constexpr int WI = WQ / 64 / NWR;               // weight DMA instructions per wave and turn (WQ = CT * 128)
-  constexpr int AI = AQ / 64 / NWR;               // gather DMA instructions per wave and turn (4)
-  static_assert(WQ % (64 * NWR) == 0 || WQ == 128, "weight tile = whole DMA instructions");
-  constexpr int WIE = WI > 0 ? WI : 1;            // COUT = 32: two instructions for four waves
-  __shared__ u32x4 Wl[2][2][WQ];                  // [wave group][buffer]
-  __shared__ u32x4 Al[2][2][AQ];
+// What the measurements of the kernel above and of two intermediate structures (a two-group LDS-DMA ping-pong with and
+// without "helper" DMAs from the group in its matrix phase, a 256-row tile with the offsets split over workgroups) say
+// (tools/ubench/cu_ingest.hip, consumer_loop.hip, lc_trace.py, ablate_probe.py on MI355X):
+//   * fragment-shaped register gathers cost 64 line requests per wave instruction; an LDS-DMA of eight whole 128-byte
+//     lines (8 rows x one 32-channel block, hi | lo) costs one;
+//   * one wave gets an LDS-DMA instruction of 1 KB accepted only every 110-180 clocks (6-9 B/clk), a compute unit as a
+//     whole takes 47-50 B/clk from L2 once eight or more waves issue (16 B/clk for lines from the Infinity Cache,
+//     12 B/clk from HBM); a 128 x 128 x 32 step needs 32 KB per 768 MFMA clocks = 42 B/clk;
+//   * in a ping-pong of two wave groups every phase begins with an exposed LDS round trip (~300 clocks before the first
+//     MFMA), the DMA issue stalls of a wave sit in ITS instruction stream in front of its own next MFMAs, and MFMA time,
+//     LDS start-up and DMA issue time simply add up (34 % + ~15 % + ~30 % of the kernel);
+//   * splitting the offsets of a tile over workgroups needs device-scope fences per workgroup: slower than the idle CUs
+//     it fills (128 -> 128 K = 27, 29k rows: 158 us without, 176 us with the split).
+// Here the roles never change: waves 0-3 (one per SIMD) own 32 rows x all columns of the block each and do nothing but
+// fragment reads and MFMAs, waves 4-11 do nothing but address resolution and LDS-DMA (two row pieces + one or two
+// filter pieces per step each).  The operands go through a ring of four stages; one s_barrier per step.  At the barrier
+// that ends step s the loaders guarantee that the stages of steps <= s + 2 are complete (each has waited for its own
+// pieces) and the matrix waves that they have left the stage of step s, which the loaders then refill with step s + 4.
+// A matrix wave therefore reads the first fragments of step s + 1 BEFORE that barrier, behind the MFMAs of the last
+// batches of step s, and issues MFMAs back to back across steps.  Its fragment reads are inline asm on purpose: the
+// compiler puts a full s_waitcnt vmcnt(0) in front of every LDS read it can see that may alias an LDS-DMA destination,
+// and it clusters the reads of a batch -- four ds_read_b128 in a row hold the wave's issue slot for ~32 clocks in which
+// the matrix pipe of its SIMD runs dry (consumer_loop.hip: 460 -> 386 ns per step).  Every read is issued alone in an
+// MFMA gap, one batch ahead of its use, so the only wait is a full lgkmcnt(0) at a batch boundary.
+template <int CIN, int CW>
+__global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
+  constexpr int NP = 2, TM = 128, KB = CIN / 32, NS = 4;
+  constexpr int RT = 2, CT = CW / 16;             // per matrix wave: 2 row tiles x CT column tiles of 16 x 16
+  static_assert(CW == 128, "column block (a 64-column variant of this structure was measured: 24 KB per 384 MFMA clocks "
+                           "makes the loaders the pole, 64 -> 64 K = 27 on 66k rows 85 us against 66 us of the kernel above)");
+  constexpr int WQ = CT * NP * 64;                // u32x4 per (offset, 32-channel block) filter tile
+  constexpr int AQ = TM * 8;                      // u32x4 per A stage: 128 rows x 128 B
+  constexpr int NLOAD = 8, APL = 16 / NLOAD, WPL = (WQ / 64) / NLOAD;      // row / filter pieces per loader wave and step
+  __shared__ u32x4 Al[NS][AQ];
+  __shared__ u32x4 Wl[NS][WQ];
   __shared__ int nbrL[DF3D_MAX_KVOL][TM];
   __shared__ int rowL[TM];
   __shared__ unsigned wg_mask;
-  static_assert(sizeof(u32x4) * 4 * AQ >= sizeof(f32x4) * NW * CT * 64, "partial sums are exchanged through the A buffers");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = wave >> 2, wr = wave & 3;         // wave group (which half of the steps), row slice of the tile
   const int g = lane >> 4, n = lane & 15;
-  int nt = gridDim.x, bid = blockIdx.x, tile = bid;
-  if ((nt & 7) == 0) tile = (bid & 7) * (nt >> 3) + (bid >> 3);     // consecutive tiles stay on one XCD / L2
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);                 // consecutive tiles stay on one XCD / L2
   const int row0 = tile * TM;
   const int col0 = blockIdx.y * CW;
+  OS_STAMP(6);
 
   if (tid == 0) wg_mask = 0u;
   __syncthreads();
   {
-    constexpr int KSTEP = NT / TM;               // offsets covered per pass
+    constexpr int KSTEP = 768 / TM;              // offsets covered per pass
     constexpr int NPASS = (DF3D_MAX_KVOL + KSTEP - 1) / KSTEP;
     const int r = tid % TM, k0 = tid / TM;
     int row = row0 + r;
@@ -985,212 +998,194 @@ __global__ __launch_bounds__(512) void spconv_os_sk2_kernel(SplitConvArgs a) {
     for (int i = 0; i < NPASS; ++i) {
       int k = k0 + i * KSTEP;
       if (k < a.K) nbrL[k][r] = v[i];
-      if (__ballot(v[i] >= 0) != 0ull) mine |= 1u << (k & 31);     // TM >= 64: the whole wave looks at one offset
+      if (__ballot(v[i] >= 0) != 0ull) mine |= 1u << (k & 31);       // TM >= 64: the whole wave looks at one offset
     }
     if (lane == 0 && mine) atomicOr(&wg_mask, mine);
   }
   __syncthreads();
   const unsigned gmask = __builtin_amdgcn_readfirstlane(wg_mask);
-  const int nact = __popc(gmask);
-  const int steps = nact * KB;
-  const int turns = (steps + 1 - h) / 2;          // this group's turns: its j-th turn is step 2j + h
+  const int steps = __popc(gmask) * KB;
+  // XOR swizzle of a row's eight 16-byte units, by the row's position in its 16-row MFMA tile (applied to the SOURCE
+  // address of the DMA: an LDS-DMA writes lane-linearly): makes the four lane groups of a ds_read_b128 (rows n, units
+  // g*2 + q) hit 16 distinct bank columns (brute-forced; linear over GF(2))
+  auto swz = [](int nn) { return ((nn >> 2) & 1) | (((nn >> 1) & 1) << 2); };
+  OS_STAMP(0);
+#ifdef DF3D_OS_TRACE
+  unsigned long long t_a = 0, t_b = 0, t_c = 0, t_x = 0;
+#define LC_T0() t_x = __builtin_amdgcn_s_memtime()
+#define LC_ACC(v) do { unsigned long long t_y = __builtin_amdgcn_s_memtime(); v += t_y - t_x; t_x = t_y; } while (0)
+#define LC_DUMP()                                                                                                   \
+  do {                                                                                                              \
+    if (a.trace && lane == 0) {                                                                                     \
+      unsigned long long *t_ = a.trace + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16 + wave) * 8;           \
+      t_[1] = t_a, t_[2] = t_b, t_[3] = t_c, t_[5] = steps;                                                         \
+    }                                                                                                               \
+  } while (0)
+#else
+#define LC_T0() do { } while (0)
+#define LC_ACC(v) do { } while (0)
+#define LC_DUMP() do { } while (0)
+#endif
 
+  if (wave >= 4) {
+    // ------------------------------------------------ loader waves ------------------------------------------------
+    // (they are the pole: above the matrix waves in priority)
+    __builtin_amdgcn_s_setprio(3);
+    const int lw = wave - 4;
+    StepCursor cu;                                // the step that is fetched next
+    cu.init(gmask);
+    auto issue = [&](int t) {
+      const int st = t & (NS - 1);
+      int idx[APL];
+#pragma unroll
+      for (int i = 0; i < APL; ++i) idx[i] = nbrL[cu.k][(lw * APL + i) * 8 + (lane >> 3)];
+      if (OS_DBG(64)) {                           // experiment: no DMAs
+        cu.template next<KB>();
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < APL; ++i) {
+        const int r = (lw * APL + i) * 8 + (lane >> 3);
+        const int unit = (lane & 7) ^ swz(r & 15);
+        const u32x4 *src = idx[i] >= 0 ? a.feat + (size_t)idx[i] * a.ldi + blockIdx.y * a.in_goff + cu.kb * 8 + unit
+                                       : g_zero_row + (lane & 7);
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)&Al[st][(lw * APL + i) * 64], 16, 0, 0);
+      }
+      const u32x4 *wsrc = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)(cu.k * KB + cu.kb)) * WQ;
+#pragma unroll
+      for (int i = 0; i < WPL; ++i)
+        __builtin_amdgcn_global_load_lds(wsrc + (lw * WPL + i) * 64 + lane,
+                                         (__attribute__((address_space(3))) void *)&Wl[st][(lw * WPL + i) * 64], 16, 0, 0);
+      cu.template next<KB>();
+    };
+    constexpr int PPS = APL + WPL;                // pieces per loader wave and step
+    LC_T0();
+    for (int t = 0; t < NS && t < steps; ++t) issue(t);
+    LC_ACC(t_a);
+    for (int s = -1; s < steps; ++s) {
+      // steps <= s + 2 have landed; the pieces of step s + 3 (the newest issued) may still be in flight
+      if (s + 3 < steps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      LC_ACC(t_b);
+      asm volatile("s_barrier" ::: "memory");
+      LC_ACC(t_c);
+      if (s >= 0 && s + NS < steps) issue(s + NS);                   // into the stage step s has just left
+      LC_ACC(t_a);
+    }
+    LC_DUMP();
+    return;
+  }
+
+  // -------------------------------------------------- matrix waves --------------------------------------------------
+  __builtin_amdgcn_s_setprio(1);
+  const int wr = wave;                            // rows wr * 32 .. + 31
   f32x4 acc[RT][CT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned a_lds = lds_addr(&Al[0][0]) + (unsigned)((wr * 32 + n) * 8) * 16u;
+  const unsigned a_addr0 = a_lds + (unsigned)((g * 2) ^ swz(n)) * 16u;
+  const unsigned a_addr1 = a_lds + (unsigned)((g * 2 + 1) ^ swz(n)) * 16u;
+  const unsigned w_addr = lds_addr(&Wl[0][0]) + (unsigned)lane * 16u;
+#define LC_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LC_SB() __builtin_amdgcn_sched_barrier(0)
+#define LC_M(rt, c, ap, br, buf, slot) acc[rt][c] = DF3D_MFMA_BF16(af[buf][rt][ap], bq[slot][br], acc[rt][c])
+  // Batch i of a step = the two column tiles 2i, 2i + 1 x both row tiles x the three products (lo*hi, hi*lo, hi*hi:
+  // the summation order of the kernel above): 12 MFMAs on B slot `slot`; RA .. RH = single fragment reads issued behind
+  // MFMAs 0 .. 7
+#define LC_BATCH(i, buf, slot, RA, RB, RC, RD, RE, RF, RG, RH)                    \
+  do {                                                                            \
+    if (OS_DBG(4)) break;                                                         \
+    LC_M(0, (i) * 2, 1, 0, buf, slot); LC_SB(); RA; LC_SB();                      \
+    LC_M(0, (i) * 2 + 1, 1, 2, buf, slot); LC_SB(); RB; LC_SB();                  \
+    LC_M(1, (i) * 2, 1, 0, buf, slot); LC_SB(); RC; LC_SB();                      \
+    LC_M(1, (i) * 2 + 1, 1, 2, buf, slot); LC_SB(); RD; LC_SB();                  \
+    LC_M(0, (i) * 2, 0, 1, buf, slot); LC_SB(); RE; LC_SB();                      \
+    LC_M(0, (i) * 2 + 1, 0, 3, buf, slot); LC_SB(); RF; LC_SB();                  \
+    LC_M(1, (i) * 2, 0, 1, buf, slot); LC_SB(); RG; LC_SB();                      \
+    LC_M(1, (i) * 2 + 1, 0, 3, buf, slot); LC_SB(); RH; LC_SB();                  \
+    LC_M(0, (i) * 2, 0, 0, buf, slot);                                            \
+    LC_M(0, (i) * 2 + 1, 0, 2, buf, slot);                                        \
+    LC_M(1, (i) * 2, 0, 0, buf, slot);                                            \
+    LC_M(1, (i) * 2 + 1, 0, 2, buf, slot);                                        \
+    LC_SB();                                                                      \
+  } while (0)
+#define LC_BATCH_X(...) LC_BATCH(__VA_ARGS__)       /* expands LC_READ_B4 / LC_READ_A4 into four arguments first */
+#define LC_WAITALL(buf)                                                                                                \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                  \
+               : "+v"(af[buf][0][0]), "+v"(af[buf][0][1]), "+v"(af[buf][1][0]), "+v"(af[buf][1][1]), "+v"(bq[0][0]),   \
+                 "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[1][2]), "+v"(bq[1][3]))
+#define LC_NONE do { } while (0)
+#define LC_READ_B4(slot, wa, i)  /* the four fragments of batch i as statements RA .. RD */                            \
+  LC_READ(bq[slot][0], wa, ((i) * 4 + 0) * 1024), LC_READ(bq[slot][1], wa, ((i) * 4 + 1) * 1024),                      \
+      LC_READ(bq[slot][2], wa, ((i) * 4 + 2) * 1024), LC_READ(bq[slot][3], wa, ((i) * 4 + 3) * 1024)
+#define LC_READ_A4(buf, aa0, aa1)                                                                                      \
+  LC_READ(af[buf][0][0], aa0, 0), LC_READ(af[buf][0][1], aa1, 0), LC_READ(af[buf][1][0], aa0, 16 * 128),               \
+      LC_READ(af[buf][1][1], aa1, 16 * 128)
+  // one step: on entry the reads of its A fragments (buffer `buf`) and of B batch 0 (slot 0) are in flight; on exit the
+  // same holds for step s + 1 (buffer buf ^ 1) -- its stage was complete at the previous barrier already (behind the
+  // last step the same reads fetch a stale stage and nobody uses them: no branch in the loop body)
+#define LC_STEP(s, buf)                                                                                                \
+  do {                                                                                                                 \
+    const unsigned wt = w_addr + (unsigned)((s) & (NS - 1)) * (WQ * 16u);                                              \
+    const unsigned wn = w_addr + (unsigned)(((s) + 1) & (NS - 1)) * (WQ * 16u);                                        \
+    const unsigned an0 = a_addr0 + (unsigned)(((s) + 1) & (NS - 1)) * (AQ * 16u);                                      \
+    const unsigned an1 = a_addr1 + (unsigned)(((s) + 1) & (NS - 1)) * (AQ * 16u);                                      \
+    LC_WAITALL(buf);                                                                                                   \
+    LC_BATCH_X(0, buf, 0, LC_READ_B4(1, wt, 1), LC_NONE, LC_NONE, LC_NONE, LC_NONE);                                   \
+    LC_WAITALL(buf);                                                                                                   \
+    LC_BATCH_X(1, buf, 1, LC_READ_B4(0, wt, 2), LC_NONE, LC_NONE, LC_NONE, LC_NONE);                                   \
+    LC_WAITALL(buf);                                                                                                   \
+    LC_BATCH_X(2, buf, 0, LC_READ_B4(1, wt, 3), LC_READ_A4((buf) ^ 1, an0, an1));                                      \
+    LC_WAITALL(buf);                                                                                                   \
+    LC_BATCH_X(3, buf, 1, LC_READ_B4(0, wn, 0), LC_NONE, LC_NONE, LC_NONE, LC_NONE);                                   \
+    LC_ACC(t_a);                                                                                                       \
+    asm volatile("s_barrier" ::: "memory");                                                                            \
+    LC_ACC(t_c);                                                                                                       \
+  } while (0)
 
-  StepCursor cu;                                  // the step of this group's next memory phase
-  cu.init(gmask);
-  if (h) cu.template next<KB>();
-  // XOR swizzle of a row's eight 16-byte units, by the row's position in its 16-row MFMA tile: makes the four lane
-  // groups of a ds_read_b128 (rows n, units g*2 + q) hit 16 distinct bank columns (brute-forced; linear over GF(2))
-  auto swz = [](int nn) { return ((nn >> 2) & 1) | (((nn >> 1) & 1) << 2); };
-  // memory phase of turn j: eight LDS-DMA instructions per wave into buffer j & 1 of the group
-  auto mem = [&](int j) {
-    if (j >= turns) return;
-    const int buf = j & 1;
-    // gathers: instruction t = wr * AI + i moves rows 8t .. 8t+7, lane -> (row 8t + lane / 8, LDS unit lane % 8)
-    int idx[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) idx[i] = nbrL[cu.k][(wr * AI + i) * 8 + (lane >> 3)];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int r = (wr * AI + i) * 8 + (lane >> 3);
-      const int unit = (lane & 7) ^ swz(r & 15);
-      const u32x4 *src = idx[i] >= 0 ? a.feat + (size_t)idx[i] * a.ldi + blockIdx.y * a.in_goff + cu.kb * 8 + unit
-                                     : g_zero_row + (lane & 7);
-      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)&Al[h][buf][(wr * AI + i) * 64], 16, 0, 0);
-    }
-    const u32x4 *wsrc = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)(cu.k * KB + cu.kb)) * WQ;
-    if constexpr (WI > 0) {
-#pragma unroll
-      for (int i = 0; i < WI; ++i)
-        __builtin_amdgcn_global_load_lds(wsrc + (wr * WI + i) * 64 + lane,
-                                         (__attribute__((address_space(3))) void *)&Wl[h][buf][(wr * WI + i) * 64], 16, 0, 0);
-    } else {                                      // WQ = 128: waves 0 and 1 of the group move one instruction each
-      if (wr < 2)
-        __builtin_amdgcn_global_load_lds(wsrc + wr * 64 + lane, (__attribute__((address_space(3))) void *)&Wl[h][buf][wr * 64], 16, 0, 0);
-    }
-    cu.template next<KB>();
-    cu.template next<KB>();
-  };
-  // matrix phase of turn j
-  auto mma = [&](int j) {
-    if (j >= turns) return;
-    const int buf = j & 1;
-    const u32x4 *ab = &Al[h][buf][0];
-    u32x4 af[RT][NP];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int q = 0; q < NP; ++q) af[rt][q] = ab[(wr * WROWS + rt * 16 + n) * 8 + ((g * 2 + q) ^ swz(n))];
-    const u32x4 *wb = &Wl[h][buf][0] + lane;
-    constexpr int NBATCH = CT / 2;
-    u32x4 bq[2][2 * NP];
-#pragma unroll
-    for (int q = 0; q < 2 * NP; ++q) bq[0][q] = wb[q * 64];
-#pragma unroll
-    for (int i = 0; i < NBATCH; ++i) {
-      const int c2 = i * 2;
-      if (i + 1 < NBATCH) {
-#pragma unroll
-        for (int q = 0; q < 2 * NP; ++q) bq[(i + 1) & 1][q] = wb[((i + 1) * 2 * NP + q) * 64];
-      }
-      const u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][1], bh1 = bq[i & 1][2], bl1 = bq[i & 1][3];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {           // lo * hi
-        acc[rt][c2] = DF3D_MFMA_BF16(af[rt][1], bh0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(af[rt][1], bh1, acc[rt][c2 + 1]);
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {           // hi * lo
-        acc[rt][c2] = DF3D_MFMA_BF16(af[rt][0], bl0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(af[rt][0], bl1, acc[rt][c2 + 1]);
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {           // hi * hi
-        acc[rt][c2] = DF3D_MFMA_BF16(af[rt][0], bh0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(af[rt][0], bh1, acc[rt][c2 + 1]);
-      }
-    }
-  };
-
-  // Phases (every phase ends with the same barrier for all eight waves):
-  //   group 0:  mem(0) | mem(1) | mma(0) | mem(2) | mma(1) | mem(3) | ...
-  //   group 1:  mem(0) |  --    | mem(1) | mma(0) | mem(2) | mma(1) | ...
-  // A memory phase ends with a counted wait that leaves only ITS OWN DMAs in flight: the data of turn j, issued in
-  // mem(j), has landed when mem(j + 1) ends, one phase before mma(j) reads it.
-  const int maxturns = (steps + 1) / 2;           // group 0's count (>= group 1's)
-  constexpr int DPW = AI + WIE;                   // DMA instructions a wave issues per memory phase
-  static_assert(WI > 0, "every wave issues the same number of DMAs (the counted waits rely on it)");
-  // end of a memory phase: leave this phase's own DMAs in flight (if it issued any), everything older has landed
-  auto end_mem = [&](int j) {
-    if (j < turns) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DPW) : "memory");
-    else DF3D_WAIT_BARRIER(0);
-  };
-  auto end_mma = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-#ifdef DF3D_OS_TRACE
-  unsigned long long t_mma = 0, t_mem = 0, t_bar = 0, t_x;
-#define PP_T0() t_x = __builtin_amdgcn_s_memtime()
-#define PP_ACC(v) do { unsigned long long t_y = __builtin_amdgcn_s_memtime(); v += t_y - t_x; t_x = t_y; } while (0)
-#else
-#define PP_T0() do { } while (0)
-#define PP_ACC(v) do { } while (0)
-#endif
-  OS_STAMP(0);
-  PP_T0();
-  if (h == 0) {
-    mem(0);
-    end_mem(0);
-    mem(1);
-    end_mem(1);
-    PP_T0();
-    for (int j = 0; j < maxturns; ++j) {
-      mma(j);
-      PP_ACC(t_mma);
-      end_mma();
-      PP_ACC(t_bar);
-      mem(j + 2);
-      PP_ACC(t_mem);
-      end_mem(j + 2);
-      PP_ACC(t_bar);
-    }
-    end_mma();                                    // group 1's last matrix phase
-  } else {
-    mem(0);
-    end_mem(0);
-    end_mma();
-    PP_T0();
-    for (int j = 0; j < maxturns; ++j) {
-      mem(j + 1);
-      PP_ACC(t_mem);
-      end_mem(j + 1);
-      PP_ACC(t_bar);
-      mma(j);
-      PP_ACC(t_mma);
-      end_mma();
-      PP_ACC(t_bar);
-    }
-    end_mma();
-  }
-#ifdef DF3D_OS_TRACE
-  if (a.trace && lane == 0) {
-    unsigned long long *t = a.trace + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16 + wave) * 8;
-    t[1] = t_mma, t[2] = t_mem, t[3] = t_bar, t[5] = maxturns;
-  }
-  OS_STAMP(4);
-#endif
-
-  // ---- the two partial sums of a row meet: group h keeps row tile h and hands the other one to its partner ----
-  f32x4 fin[CT];
+  u32x4 af[2][RT][NP];
+  u32x4 bq[2][2 * NP];
+  asm volatile("s_barrier" ::: "memory");         // steps 0 and 1 are in their stages
   {
-    f32x4 *ex = (f32x4 *)&Al[0][0][0];
-    const int partner = wave ^ 4;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      fin[ct] = h ? acc[1][ct] : acc[0][ct];
-      ex[(wave * CT + ct) * 64 + lane] = h ? acc[0][ct] : acc[1][ct];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) fin[ct] += ex[(partner * CT + ct) * 64 + lane];
+    LC_READ(af[0][0][0], a_addr0, 0);
+    LC_READ(af[0][0][1], a_addr1, 0);
+    LC_READ(af[0][1][0], a_addr0, 16 * 128);
+    LC_READ(af[0][1][1], a_addr1, 16 * 128);
+    LC_READ(bq[0][0], w_addr, 0 * 1024);
+    LC_READ(bq[0][1], w_addr, 1 * 1024);
+    LC_READ(bq[0][2], w_addr, 2 * 1024);
+    LC_READ(bq[0][3], w_addr, 3 * 1024);
   }
+  LC_T0();
+  int s = 0;
+  for (; s + 1 < steps; s += 2) {
+    LC_STEP(s, 0);
+    LC_STEP(s + 1, 1);
+  }
+  if (s < steps) LC_STEP(s, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef LC_READ
+#undef LC_SB
+#undef LC_M
+#undef LC_BATCH
+#undef LC_BATCH_X
+#undef LC_WAITALL
+#undef LC_NONE
+#undef LC_READ_B4
+#undef LC_READ_A4
+#undef LC_STEP
+  __builtin_amdgcn_s_setprio(0);
+  LC_DUMP();
+#undef LC_T0
+#undef LC_ACC
+#undef LC_DUMP
+  OS_STAMP(4);
 
-  // ---- epilogue of row tile h: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the
-  //      CT consecutive columns n*CT .. n*CT+CT-1 (packed-weight layout 1) ----
-  static_assert(CT == 2 || CT == 4 || CT == 8, "COUT must be 32, 64, 128 or 256");
-  if constexpr (CT == 2) {
-    const int col = col0 + n * 2;
-    const float2 bi = a.bias ? *(const float2 *)(a.bias + col) : make_float2(0.f, 0.f);
-    const float2 sc = a.scale ? *(const float2 *)(a.scale + col) : make_float2(1.f, 1.f);
-    const float2 sh = a.shift ? *(const float2 *)(a.shift + col) : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rowL[wr * WROWS + h * 16 + 4 * g + r];
-      if (row >= a.n_out) continue;
-      float2 v = make_float2((fin[0][r] + bi.x) * sc.x + sh.x, (fin[1][r] + bi.y) * sc.y + sh.y);
-      const size_t o = (size_t)row * a.ldo + col;
-      if (a.residual) {
-        const float2 rr = *(const float2 *)(a.residual + o);
-        v.x += rr.x;
-        v.y += rr.y;
-      }
-      if (a.relu) {
-        v.x = fmaxf(v.x, 0.f);
-        v.y = fmaxf(v.y, 0.f);
-      }
-      if (a.out) *(float2 *)(a.out + o) = v;
-      if (a.out_split) {
-        unsigned hp, lp;
-        split_pair(v.x, v.y, hp, lp);
-        char *blk = (char *)a.out_split + (o >> 3) * 32 + (n & 3) * 4;     // 8-channel block = [hi 16 B | lo 16 B]
-        *(unsigned *)blk = hp;
-        *(unsigned *)(blk + 16) = lp;
-      }
-    }
-  } else {
+  // ---- epilogue: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the CT consecutive
+  //      columns n * CT .. n * CT + CT - 1 (packed-weight layout 1) ----
+  {
     f32x4 bi[CT / 4], sc[CT / 4], sh[CT / 4];
 #pragma unroll
     for (int q = 0; q < CT / 4; ++q) {
@@ -1200,41 +1195,63 @@ __global__ __launch_bounds__(512) void spconv_os_sk2_kernel(SplitConvArgs a) {
       sh[q] = a.shift ? *(const f32x4 *)(a.shift + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rowL[wr * WROWS + h * 16 + 4 * g + r];
-      if (row >= a.n_out) continue;
-      const size_t o = (size_t)row * a.ldo + col0 + n * CT;
-      unsigned hh[CT / 2], ll[CT / 2];         // packed pairs
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int q = 0; q < CT / 4; ++q) {
-        f32x4 v = (f32x4){fin[q * 4][r], fin[q * 4 + 1][r], fin[q * 4 + 2][r], fin[q * 4 + 3][r]};
-        v = (v + bi[q]) * sc[q] + sh[q];
-        if (a.residual) v += *(const f32x4 *)(a.residual + o + q * 4);
-        if (a.relu) {
-          v[0] = fmaxf(v[0], 0.f);
-          v[1] = fmaxf(v[1], 0.f);
-          v[2] = fmaxf(v[2], 0.f);
-          v[3] = fmaxf(v[3], 0.f);
+      for (int r = 0; r < 4; ++r) {
+        const int row = rowL[wr * 32 + rt * 16 + 4 * g + r];
+        if (row >= a.n_out) continue;
+        const size_t o = (size_t)row * a.ldo + col0 + n * CT;
+        unsigned hh[CT / 2], ll[CT / 2];
+#pragma unroll
+        for (int q = 0; q < CT / 4; ++q) {
+          f32x4 v = (f32x4){acc[rt][q * 4][r], acc[rt][q * 4 + 1][r], acc[rt][q * 4 + 2][r], acc[rt][q * 4 + 3][r]};
+          v = (v + bi[q]) * sc[q] + sh[q];
+          if (a.residual) v += *(const f32x4 *)(a.residual + o + q * 4);
+          if (a.relu) {
+            v[0] = fmaxf(v[0], 0.f);
+            v[1] = fmaxf(v[1], 0.f);
+            v[2] = fmaxf(v[2], 0.f);
+            v[3] = fmaxf(v[3], 0.f);
+          }
+          if (a.out) *(f32x4 *)(a.out + o + q * 4) = v;
+          if (a.out_split) {
+            split_pair(v[0], v[1], hh[q * 2], ll[q * 2]);
+            split_pair(v[2], v[3], hh[q * 2 + 1], ll[q * 2 + 1]);
+          }
         }
-        if (a.out) *(f32x4 *)(a.out + o + q * 4) = v;
         if (a.out_split) {
-          split_pair(v[0], v[1], hh[q * 2], ll[q * 2]);
-          split_pair(v[2], v[3], hh[q * 2 + 1], ll[q * 2 + 1]);
-        }
-      }
-      if (a.out_split) {
-        char *blk = (char *)a.out_split + (o >> 3) * 32;             // 8-channel block = [hi 16 B | lo 16 B]
-        if constexpr (CT == 8) {
+          char *blk = (char *)a.out_split + (o >> 3) * 32;           // 8-channel block = [hi 16 B | lo 16 B]
           *(u32x4 *)blk = (u32x4){hh[0], hh[1], hh[2], hh[3]};
           *(u32x4 *)(blk + 16) = (u32x4){ll[0], ll[1], ll[2], ll[3]};
-        } else {
-          blk += (n & 1) * 8;                                        // two lanes share a block
-          *(u32x2 *)blk = (u32x2){hh[0], hh[1]};
-          *(u32x2 *)(blk + 16) = (u32x2){ll[0], ll[1]};
         }
       }
-    }
   }
+  OS_STAMP(7);
+}
+
+static int g_num_cu = 0;
+static int num_cu() {
+  if (!g_num_cu) {
+    hipDeviceProp_t p;
+    g_num_cu = (hipGetDeviceProperties(&p, 0) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return g_num_cu;
+}
+
+// The loader / consumer kernel serves 128-column blocks from ~190 workgroups on (below that the 64-row tiles of the
+// kernel above fill the chip better); DF3D_OS_LC=0 / 1 forces it off / on.
+template <int CIN>
+static int launch_os_lc(const SplitConvArgs &a, hipStream_t stream) {
+  hipLaunchKernelGGL((spconv_os_lc_kernel<CIN, 128>), dim3(cdiv(a.n_out, 128), a.gy), dim3(768), 0, stream, a);
+  return DF3D_OK;
+}
+
+static bool use_lc(const SplitConvArgs &a) {
+  static const char *t = getenv("DF3D_OS_LC");
+  if (a.cols) return false;
+  if (t && t[0] == '0') return false;
+  if (t && t[0] == '1') return true;
+  return (long long)cdiv(a.n_out, 128) * a.gy >= 190;
 }
 
 template <int CIN, int COUT>
@@ -1244,15 +1261,8 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
   // bytes per launch, more than the gathers), so more rows per workgroup = less L2 traffic; bigger register
   // tiles (RT 2) leave too few waves on the 256 CUs at these row counts.
   int rt = 1, nw = a.n_out >= 16 * 1024 ? 8 : 2, kps = 1;
-  // LDS-DMA ping-pong kernel (spconv_os_sk2_kernel): measured on MI355X (tools/ubench/sk_probe.py, pp_trace.py) it wins
-  // where a tile has many steps of wide weight tiles -- the 128 -> 128 layers (conv4 K=27: 90 -> 86 us, dense K=9:
-  // 40.2 -> 39.0) -- and loses on the 64- and 32-channel layers, where its 142 KB of LDS leave one workgroup per CU
-  // (65 -> 85 us, 35 -> 48 us), so it serves CIN = COUT = 128 only.  DF3D_OS_SK=0 / 2 forces it off / on (tuning aid).
-  static const char *sk = getenv("DF3D_OS_SK");
-  const bool sk2 = sk ? sk[0] == '2' : (CIN == 128 && COUT == 128 && a.K >= 9);
-  if (sk2 && !a.cols && a.n_out >= 4 * 1024) {
-    hipLaunchKernelGGL((spconv_os_sk2_kernel<CIN, COUT>), dim3(cdiv(a.n_out, 128), a.gy), dim3(512), 0, stream, a);
-    return DF3D_OK;
+  if constexpr (COUT == 128 && CIN % 32 == 0) {
+    if (use_lc(a)) return launch_os_lc<CIN>(a, stream);
   }
   static const char *cfg = getenv("DF3D_OS_CFG");       // tuning aid: "RT,NW[,KPS]"
   if (cfg && cfg[0] && cfg[1] == ',') {
@@ -1287,6 +1297,9 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
 template <int CIN, int COUT>
 static int launch_os_split_wide(const SplitConvArgs &a, hipStream_t stream) {
   const int CS = a.gy;
+  if constexpr (COUT % 128 == 0) {
+    if (use_lc(a)) return launch_os_lc<CIN>(a, stream);
+  }
   int rt = 1, nw = (long long)a.n_out * CS >= 128 * 384 ? 8 : (long long)a.n_out * CS >= 64 * 192 ? 4 : 2;
   static const char *cfg = getenv("DF3D_OS_WIDE");
   if (cfg && cfg[0] && cfg[1] == ',') {
@@ -1305,14 +1318,6 @@ static int launch_os_split_wide(const SplitConvArgs &a, hipStream_t stream) {
   return DF3D_OK;
 }
 
-static int g_num_cu = 0;
-static int num_cu() {
-  if (!g_num_cu) {
-    hipDeviceProp_t p;
-    g_num_cu = (hipGetDeviceProperties(&p, 0) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-  }
-  return g_num_cu;
-}
 
 template <int CIN, int COUT>
 static int launch_split(const SplitConvArgs &a, const int32_t *tile_rows, int ntiles, hipStream_t stream) {

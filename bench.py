@@ -221,7 +221,7 @@ def conv_algorithmic(rec, pairs):
     return by, 2 * pairs * cin * cout, extra
 
 
-def roofline_from_timer(timer, meta_timer):
+def roofline_from_timer(timer, meta_timer, key=None):
     """Dominant sparse-conv kernel of the timed region: HIP-event time per launch (`timer`) against the algorithmic
     bytes / flops of the same launches (pair counts from `meta_timer`: one extra untimed pass over every frame).
     Bound = whichever roof the kernel's arithmetic intensity puts it under: fp32 MFMA (157 TF) for the exact-fp32
@@ -248,7 +248,10 @@ def roofline_from_timer(timer, meta_timer):
         g["extra"] += extra
     if not groups:
         return None, {}
-    key = max(groups, key=lambda k: groups[k]["ms"])
+    if key is None:
+        key = max(groups, key=lambda k: groups[k]["ms"])
+    elif key not in groups:
+        return None, {}
     cin, cout, K, split = key
     g = groups[key]
     sec = g["ms"] * 1e-3
@@ -560,6 +563,15 @@ def main():
                                          "picked by an untimed probe step with events on every launch)")
             res["roofline"] = roof
             res["conv_kernel_ms_probe_step"] = per_kernel
+            # the other 3-D sparse-conv kernels against the same roofs, from the launches of the untimed probe step (the
+            # timed region carries events around the dominant kernel only); round 1 / 2 quoted conv4 = 128x128 K=27
+            others = {}
+            for k in sorted({(r["cin"], r["cout"], r["kvol"], r["split"]) for r in probe.records if r["kvol"] == 27}):
+                ro, _ = roofline_from_timer(probe, meta_timer, key=k)
+                if ro is not None:
+                    others["%dx%d_k%d" % k[:3]] = {f: ro[f] for f in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us",
+                                                                       "algorithmic_bytes_per_launch") if f in ro}
+            res["roofline_probe_step_by_kernel"] = others
         if world == 1 and not args.no_cpu_baseline and args.workload in ("cp_fusion", "cp_lidar"):
             res["cpu_baseline"] = cpu_baseline(wl, args.cpu_sweeps)
         print(json.dumps(res))

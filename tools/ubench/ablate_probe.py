@@ -59,5 +59,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 
 iters = sys.argv[1] if len(sys.argv) > 1 else "30"
-for dbg in (0, 1, 2, 16, 4, 32, 3, 19, 23, 55, 20, 5):
+for dbg in [int(x) for x in os.environ.get("ABLATE_SET", "0,1,2,16,4,32,3,19,23,55,20,5").split(",")]:
     subprocess.call([sys.executable, os.path.abspath(__file__), "child", iters], env=dict(os.environ, DF3D_OS_DBG=str(dbg)))

@@ -41,6 +41,11 @@ for stage, x in (("conv4", xs[3]), ("conv3", xs[2])):
     t = tr.cpu().numpy()[:, :8, :].astype(np.float64)
     turns = t[:, 0, 5]
     whole = t[:, :, 4] - t[:, :, 0]
+    t0 = t[:, :, 6].min()
+    print("%s: %d workgroups; ticks (10 ns) from the first wave's start: WG start mean %.0f max %.0f | loop start mean %.0f | loop end mean %.0f | "
+          "WG end mean %.0f max %.0f ; per WG: prologue %.0f  loop %.0f  epilogue %.0f" % (
+              stage, nwg, (t[:, :, 6] - t0).mean(), (t[:, :, 6] - t0).max(), (t[:, :, 0] - t0).mean(), (t[:, :, 4] - t0).mean(),
+              (t[:, :, 7] - t0).mean(), (t[:, :, 7] - t0).max(), (t[:, :, 0] - t[:, :, 6]).mean(), whole.mean(), (t[:, :, 7] - t[:, :, 4]).mean()))
     for grp, sl in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)", slice(4, 8))):
         mma, mem, bar = t[:, sl, 1].mean(), t[:, sl, 2].mean(), t[:, sl, 3].mean()
         print("%s %s: per wave ticks mma %.0f  mem %.0f  barrier wait %.0f  | loop total %.0f (turns %.1f -> per turn mma %.0f mem %.0f bar %.0f)" % (

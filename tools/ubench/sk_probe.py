@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""spconv_os_sk2_kernel (offsets split over two wave groups) against spconv_os_split_kernel: values and time, on one
-SubM layer of every split-precision backbone stage and on the dense neck shape.  usage: sk_probe.py [iters]"""
+"""spconv_os_lc_kernel (loader / consumer waves, LDS-DMA) against spconv_os_split_kernel: values and time, on one SubM layer
+of every split-precision backbone stage and on the dense neck shape.  usage: sk_probe.py [iters]"""
 import os
 import subprocess
 import sys
@@ -65,14 +65,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 import numpy as np
 iters = sys.argv[1] if len(sys.argv) > 1 else "30"
 outs = {}
-for tag, env in (("os", {"DF3D_OS_SK": "0"}), ("sk2", {"DF3D_OS_SK": "2"})):
+for tag, env in (("os", {"DF3D_OS_LC": "0"}), ("lc", {"DF3D_OS_LC": "1"}), ("lc_offset_major", {"DF3D_OS_LC": "1", "DF3D_OS_BLOCK_MAJOR": "0"})):
     print("----", tag, flush=True)
     path = "/tmp/sk_probe_%s.npz" % tag
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "child", iters, path], env=dict(os.environ, **env))
     outs[tag] = np.load(path)
-for k in outs["os"].files:
-    a, b = outs["os"][k], outs["sk2"][k]
-    if k.endswith("_out"):
-        print("%-14s max |diff| / max |ref| = %.3e" % (k, np.abs(a - b).max() / np.abs(a).max()))
-    else:
-        print("%-14s split rows differing bytes: %d of %d" % (k, int((a != b).sum()), a.size))
+for tag in list(outs)[1:]:
+    for k in outs["os"].files:
+        a, b = outs["os"][k], outs[tag][k]
+        if k.endswith("_out"):
+            print("%-10s %-14s max |diff| / max |ref| = %.3e" % (tag, k, np.abs(a - b).max() / np.abs(a).max()))
+        else:
+            print("%-10s %-14s split rows differing bytes: %d of %d" % (tag, k, int((a != b).sum()), a.size))
