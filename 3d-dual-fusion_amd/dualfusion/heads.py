@@ -151,13 +151,13 @@ class CenterHead(nn.Module):
         sc, sbn = self.shared_conv[0], self.shared_conv[1]
         s_scale, s_shift = self._fold(sbn)
         dev = sc.weight.device
-        mid_packed, mid_bias, mid_scale, mid_shift, fin_packed, fin_bias, cols, layout = [], [], [], [], [], [], [], []
+        mid_filters, mid_bias, mid_scale, mid_shift, fin_packed, fin_bias, cols, layout = [], [], [], [], [], [], [], []
         fin_w4, fin_b4 = [], []
         c0 = 0
         for t, task in enumerate(self.tasks):
             for head in task.heads:
                 fc = getattr(task, head)
-                mid_packed.append(_ops.conv_pack_weights(self._filters(fc[0])))
+                mid_filters.append(self._filters(fc[0]))
                 mid_bias.append(fc[0].bias.detach().float())
                 a, b = self._fold(fc[1])
                 mid_scale.append(a)
@@ -171,9 +171,14 @@ class CenterHead(nn.Module):
                 cols.append((c0, k))
                 layout.append((t, head, c0, k))
                 c0 += k
+        # All branches read the same 64 shared channels, so two neighbouring 64-column branches form one 128-column block
+        # of one convolution 64 -> 64 * branches: half the gathers of the input rows, and the 128-column kernel
+        mid_pair = 2 if len(mid_filters) % 2 == 0 else 1
+        mid_packed = [_ops.conv_pack_weights(torch.cat(mid_filters[i:i + mid_pair], dim=2).contiguous())
+                      for i in range(0, len(mid_filters), mid_pair)]
         plan = dict(key=key, shared=_ops.conv_pack_weights(self._filters(sc)), s_bias=sc.bias.detach().float().contiguous(),
                     s_scale=s_scale.contiguous(), s_shift=s_shift.contiguous(),
-                    mid=torch.cat(mid_packed), mid_bias=torch.cat(mid_bias).contiguous(),
+                    mid=torch.cat(mid_packed), mid_pair=mid_pair, mid_bias=torch.cat(mid_bias).contiguous(),
                     mid_scale=torch.cat(mid_scale).contiguous(), mid_shift=torch.cat(mid_shift).contiguous(),
                     fin=torch.cat(fin_packed), fin_bias=torch.cat(fin_bias).contiguous(),
                     cols=torch.tensor(cols, dtype=torch.int32, device=dev).contiguous(), layout=layout,
@@ -201,8 +206,9 @@ class CenterHead(nn.Module):
         G = plan["groups"]
         _, s1 = _ops.conv_rows_split(split, 512, 0, plan["shared"], 64, 1, nbr, n, plan["s_bias"], plan["s_scale"],
                                      plan["s_shift"], relu=True, want_out=False, want_split=True)
-        _, s2 = _ops.conv_rows_split(s1, 64, 0, plan["mid"], 64, G, nbr, n, plan["mid_bias"], plan["mid_scale"],
-                                     plan["mid_shift"], relu=True, want_out=False, want_split=True)
+        _, s2 = _ops.conv_rows_split(s1, 64, 0, plan["mid"], 64 * plan["mid_pair"], G // plan["mid_pair"], nbr, n,
+                                     plan["mid_bias"], plan["mid_scale"], plan["mid_shift"], relu=True, want_out=False,
+                                     want_split=True)
         if plan["fin_w4"] is not None and os.environ.get("DF3D_HEAD_FINAL", "valu") == "valu":
             # 72 output maps of 36 branches: vector-ALU kernel over LDS halo tiles (every activation read 1.6x, exact
             # fp32 products of hi + lo) instead of a block-diagonal matrix-core launch padded to 32 columns per branch

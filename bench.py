@@ -221,7 +221,7 @@ def conv_algorithmic(rec, pairs):
     return by, 2 * pairs * cin * cout, extra
 
 
-def roofline_from_timer(timer, meta_timer, key=None):
+def roofline_from_timer(timer, meta_timer, want=None):
     """Dominant sparse-conv kernel of the timed region: HIP-event time per launch (`timer`) against the algorithmic
     bytes / flops of the same launches (pair counts from `meta_timer`: one extra untimed pass over every frame).
     Bound = whichever roof the kernel's arithmetic intensity puts it under: fp32 MFMA (157 TF) for the exact-fp32
@@ -248,9 +248,11 @@ def roofline_from_timer(timer, meta_timer, key=None):
         g["extra"] += extra
     if not groups:
         return None, {}
-    if key is None:
+    if want is None:
         key = max(groups, key=lambda k: groups[k]["ms"])
-    elif key not in groups:
+    elif want in groups:
+        key = want
+    else:
         return None, {}
     cin, cout, K, split = key
     g = groups[key]
@@ -567,11 +569,16 @@ def main():
             # timed region carries events around the dominant kernel only); round 1 / 2 quoted conv4 = 128x128 K=27
             others = {}
             for k in sorted({(r["cin"], r["cout"], r["kvol"], r["split"]) for r in probe.records if r["kvol"] == 27}):
-                ro, _ = roofline_from_timer(probe, meta_timer, key=k)
+                ro, _ = roofline_from_timer(probe, meta_timer, want=k)
                 if ro is not None:
                     others["%dx%d_k%d" % k[:3]] = {f: ro[f] for f in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us",
                                                                        "algorithmic_bytes_per_launch") if f in ro}
             res["roofline_probe_step_by_kernel"] = others
+            rows_of = {}
+            for r in meta_timer.records:
+                if r["kvol"] == 27:
+                    rows_of.setdefault("%dx%d_k27" % (r["cin"], r["cout"]), set()).add(r["n_out"])
+            res["conv_rows_by_kernel"] = {k: sorted(v) for k, v in rows_of.items()}   # identifies the launches in a rocprofv3 trace
         if world == 1 and not args.no_cpu_baseline and args.workload in ("cp_fusion", "cp_lidar"):
             res["cpu_baseline"] = cpu_baseline(wl, args.cpu_sweeps)
         print(json.dumps(res))

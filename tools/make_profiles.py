@@ -12,8 +12,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1].rstrip("/") + "/", sys.argv[2]
 out = os.path.join(ROOT, "profiles") + "/"
-KEY = "spconv_os_sk2_kernel<128, 128"          # the conv4 layers (K = 27) and the neck's 128 -> 128 layers (K = 9)
-NECK_GRID = (32400 + 127) // 128 * 512          # the dense 180 x 180 map: 254 workgroups of 512 threads
 N_CAL = 1 << 21
 
 
@@ -26,11 +24,24 @@ def mean(rs, cname, pred):
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-conv4 = lambda r: KEY in r["Kernel_Name"] and int(r["Grid_Size"]) != NECK_GRID      # noqa: E731
-cal = lambda r: "spconv_os" in r["Kernel_Name"] and int(r["Grid_Size"]) == N_CAL // 128 * 512    # noqa: E731
+bench = json.loads([l for l in open(src + "bench.json").read().strip().splitlines() if l.startswith("{")][-1])
+roof = bench["roofline"]
+
+
+def wgs(r):
+    return int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+
+
+def selector(cin, cout):
+    """The K = 27 launches of the cin -> cout split-precision kernel: by template arguments and tile count (the
+    neck / head launch the same kernels on the dense 180 x 180 / 90 x 90 maps with other tile counts)."""
+    tiles = {(n + 127) // 128 for n in bench["conv_rows_by_kernel"]["%dx%d_k27" % (cin, cout)]}
+    pat = "<%d, %d" % (cin, cout)
+    return lambda r: "spconv_os" in r["Kernel_Name"] and pat in r["Kernel_Name"] and wgs(r) in tiles
+
+
+cal = lambda r: "spconv_os" in r["Kernel_Name"] and wgs(r) == N_CAL // 128    # noqa: E731
 fetch, write = rows("fetch/fetch_counter_collection.csv"), rows("write/write_counter_collection.csv")
-f, nf = mean(fetch, "FETCH_SIZE", conv4)
-w, nw = mean(write, "WRITE_SIZE", conv4)
 cf, ncf = mean(rows("calib_fetch/fetch_counter_collection.csv"), "FETCH_SIZE", cal)
 cw, ncw = mean(rows("calib_write/write_counter_collection.csv"), "WRITE_SIZE", cal)
 exp_f, exp_w = (N_CAL * 512 + N_CAL * 4) / 1024.0, 2 * N_CAL * 512 / 1024.0
@@ -40,25 +51,50 @@ calib = {"what": "K = 1 'convolution' 128 -> 128 over 2^21 rows, neighbour table
          "expected_fetch_KB": exp_f, "FETCH_SIZE_KB_mean": cf, "fetch_factor": round(kf, 4),
          "expected_write_KB": exp_w, "WRITE_SIZE_KB_mean": cw, "write_factor": round(kw, 4), "launches": ncf}
 json.dump(calib, open(out + tag + "_pmc_calibration.json", "w"), indent=1)
-bench = json.loads([l for l in open(src + "bench.json").read().strip().splitlines() if l.startswith("{")][-1])
-roof = bench["roofline"]
-traffic = int((kf * f + kw * w) * 1024)
-dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows("trace/stats_kernel_trace.csv")
-       if KEY in r["Kernel_Name"] and int(r["Grid_Size_X"]) != NECK_GRID]
-pm = {"kernel": "spconv_os_sk2_kernel<128,128> launched with K = 27 (the four residual-block layers of conv4; the neck's K = 9 "
-                "launches of the same kernel are excluded by their grid size)",
-      "kernel_key": [128, 128, 27, 1], "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w, "launches_averaged": nf,
-      "fetch_calibration": {"factor": round(kf, 4), "write_factor": round(kw, 4),
-                            "source": "profiles/%s_pmc_calibration.json (known-size gather by the same kernel)" % tag},
-      "correction": "FETCH_SIZE x %.3f, WRITE_SIZE x %.3f (calibrated on a known-size gather in this kernel's access pattern, "
-                    "MI355X_MICROARCH.md HBM section); x1024 (values are KB)" % (kf, kw),
-      "traffic_bytes_per_launch": traffic, "fetch_bytes_per_launch": int(kf * f * 1024), "write_bytes_per_launch": int(kw * w * 1024),
-      "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "compulsory_bytes": roof.get("compulsory_bytes"),
-      "rocprofv3_avg_launch_us": round(sum(dur) / len(dur), 2), "bench_hip_event_avg_launch_us": roof["avg_launch_us"],
-      "hbm_rate_GBps_over_rocprof_time": round(traffic / (sum(dur) / len(dur) * 1e-6) / 1e9, 1),
-      "command": "tools/profile_r02.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate passes) --kernel-trace "
-                 "--output-format csv -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-passes "
-                 "--no-kernel-timing (8 rotating frames)"}
+trace = rows("trace/stats_kernel_trace.csv")
+
+
+def summarize(cin, cout):
+    sel = selector(cin, cout)
+    f, nf = mean(fetch, "FETCH_SIZE", sel)
+    w, nw = mean(write, "WRITE_SIZE", sel)
+    tiles = {(n + 127) // 128 for n in bench["conv_rows_by_kernel"]["%dx%d_k27" % (cin, cout)]}
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trace
+           if "spconv_os" in r["Kernel_Name"] and "<%d, %d" % (cin, cout) in r["Kernel_Name"]
+           and int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) in tiles and int(r["Grid_Size_Y"]) == 1]
+    names = sorted({r["Kernel_Name"].split("(")[0] for r in fetch if sel(r)})
+    traffic = int((kf * f + kw * w) * 1024)
+    return {"kernel": "%s launched with K = 27 (3-D SubM layers; the dense-map launches of the same kernel are excluded by their "
+                      "tile count)" % " / ".join(names),
+            "kernel_key": [cin, cout, 27, 1], "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w, "launches_averaged": nf,
+            "traffic_bytes_per_launch": traffic, "fetch_bytes_per_launch": int(kf * f * 1024),
+            "write_bytes_per_launch": int(kw * w * 1024), "rocprofv3_avg_launch_us": round(sum(dur) / len(dur), 2),
+            "hbm_rate_GBps_over_rocprof_time": round(traffic / (sum(dur) / len(dur) * 1e-6) / 1e9, 1)}, sel
+
+
+import re
+m = re.search(r"cin=(\d+),cout=(\d+),K=(\d+)", roof["kernel"])
+dom = (int(m.group(1)), int(m.group(2)))
+pm, conv_sel = summarize(*dom)
+pm.update({"fetch_calibration": {"factor": round(kf, 4), "write_factor": round(kw, 4),
+                                 "source": "profiles/%s_pmc_calibration.json (known-size gather by the conv kernel)" % tag},
+           "correction": "FETCH_SIZE x %.3f, WRITE_SIZE x %.3f (calibrated on a known-size gather in this kernel's access pattern, "
+                         "MI355X_MICROARCH.md HBM section); x1024 (values are KB)" % (kf, kw),
+           "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "compulsory_bytes": roof.get("compulsory_bytes"),
+           "bench_hip_event_avg_launch_us": roof["avg_launch_us"],
+           "command": "tools/profile_r02.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate passes) --kernel-trace "
+                      "--output-format csv -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-passes "
+                      "--no-kernel-timing (8 rotating frames)"})
+others = {}
+for key in bench["conv_rows_by_kernel"]:
+    cin, cout = [int(v) for v in key.split("_")[0].split("x")]
+    if (cin, cout) != dom and cin >= 32:
+        try:
+            others[key] = summarize(cin, cout)[0]
+            others[key]["probe_step"] = bench.get("roofline_probe_step_by_kernel", {}).get(key)
+        except Exception as e:
+            print("no summary for", key, e)
+pm["other_k27_kernels"] = others
 json.dump(pm, open(out + tag + "_pmc_spconv_split.json", "w"), indent=1)
 shutil.copy(src + "trace/stats_kernel_stats.csv", out + tag + "_bench_cp_fusion_kernel_stats.csv")
 json.dump(bench, open(out + tag + "_bench_cp_fusion.json", "w"), indent=1)
@@ -82,11 +118,16 @@ for fn, o, cn in (("fetch/fetch_counter_collection.csv", "_pmc_fetch_size.csv", 
 try:
     sq = rows("sq/sq_counter_collection.csv")
     names = sorted(set(r["Counter_Name"] for r in sq))
-    summ = {c: mean(sq, c, conv4)[0] for c in names}
-    json.dump({"kernel": pm["kernel"], "mean_per_launch": summ,
-               "note": "SQ_* counters count quad-cycles per SIMD-wave slot except SQ_VALU_MFMA_BUSY_CYCLES (cycles); "
-                       "GRBM_GUI_ACTIVE / kernel time = effective clock"},
-              open(out + tag + "_pmc_sq_spconv.json", "w"), indent=1)
+    doc = {"note": "SQ_* counters count quad-cycles per SIMD-wave slot except SQ_VALU_MFMA_BUSY_CYCLES (cycles); "
+                   "GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time = effective clock", "kernels": {}}
+    for key in bench["conv_rows_by_kernel"]:
+        cin, cout = [int(v) for v in key.split("_")[0].split("x")]
+        if cin < 32:
+            continue
+        sel = selector(cin, cout)
+        doc["kernels"][key] = {"kernel": " / ".join(sorted({r["Kernel_Name"].split("(")[0] for r in sq if sel(r)})),
+                               "mean_per_launch": {c: mean(sq, c, sel)[0] for c in names}}
+    json.dump(doc, open(out + tag + "_pmc_sq_spconv.json", "w"), indent=1)
 except Exception as e:      # the SQ pass is optional
     print("no SQ summary:", e)
 ps = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_summary.py"), src + "trace/stats_kernel_trace.csv", "--csv",
