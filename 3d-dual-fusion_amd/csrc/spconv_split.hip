@@ -1034,28 +1034,36 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
     const int lw = wave - 4;
     StepCursor cu;                                // the step that is fetched next
     cu.init(gmask);
+    // The channel blocks of one offset are consecutive steps and gather the SAME rows: the neighbour-table lookups and
+    // the address arithmetic happen once per offset (`abase`, per-lane block stride 0 for the all-zero row), a step only
+    // adds its block offset.
+    const u32x4 *abase[APL], *wbase = nullptr;
+    int astep[APL];
     auto issue = [&](int t) {
       const int st = t & (NS - 1);
-      int idx[APL];
+      if (cu.kb == 0) {
+        int idx[APL];
 #pragma unroll
-      for (int i = 0; i < APL; ++i) idx[i] = nbrL[cu.k][(lw * APL + i) * 8 + (lane >> 3)];
-      if (OS_DBG(64)) {                           // experiment: no DMAs
-        cu.template next<KB>();
-        return;
+        for (int i = 0; i < APL; ++i) idx[i] = nbrL[cu.k][(lw * APL + i) * 8 + (lane >> 3)];
+#pragma unroll
+        for (int i = 0; i < APL; ++i) {
+          const int r = (lw * APL + i) * 8 + (lane >> 3);
+          const int unit = (lane & 7) ^ swz(r & 15);
+          abase[i] = idx[i] >= 0 ? a.feat + (size_t)idx[i] * a.ldi + blockIdx.y * a.in_goff + unit : g_zero_row + (lane & 7);
+          astep[i] = idx[i] >= 0 ? 8 : 0;
+        }
+        wbase = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)cu.k * KB) * WQ + (lw * WPL) * 64 + lane;
       }
+      if (!OS_DBG(64)) {                          // (experiment: no DMAs)
 #pragma unroll
-      for (int i = 0; i < APL; ++i) {
-        const int r = (lw * APL + i) * 8 + (lane >> 3);
-        const int unit = (lane & 7) ^ swz(r & 15);
-        const u32x4 *src = idx[i] >= 0 ? a.feat + (size_t)idx[i] * a.ldi + blockIdx.y * a.in_goff + cu.kb * 8 + unit
-                                       : g_zero_row + (lane & 7);
-        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)&Al[st][(lw * APL + i) * 64], 16, 0, 0);
+        for (int i = 0; i < APL; ++i)
+          __builtin_amdgcn_global_load_lds(abase[i] + cu.kb * astep[i],
+                                           (__attribute__((address_space(3))) void *)&Al[st][(lw * APL + i) * 64], 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WPL; ++i)
+          __builtin_amdgcn_global_load_lds(wbase + (size_t)cu.kb * WQ + i * 64,
+                                           (__attribute__((address_space(3))) void *)&Wl[st][(lw * WPL + i) * 64], 16, 0, 0);
       }
-      const u32x4 *wsrc = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)(cu.k * KB + cu.kb)) * WQ;
-#pragma unroll
-      for (int i = 0; i < WPL; ++i)
-        __builtin_amdgcn_global_load_lds(wsrc + (lw * WPL + i) * 64 + lane,
-                                         (__attribute__((address_space(3))) void *)&Wl[st][(lw * WPL + i) * 64], 16, 0, 0);
       cu.template next<KB>();
     };
     constexpr int PPS = APL + WPL;                // pieces per loader wave and step

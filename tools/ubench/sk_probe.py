@@ -65,7 +65,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 import numpy as np
 iters = sys.argv[1] if len(sys.argv) > 1 else "30"
 outs = {}
-for tag, env in (("os", {"DF3D_OS_LC": "0"}), ("lc", {"DF3D_OS_LC": "1"}), ("lc_offset_major", {"DF3D_OS_LC": "1", "DF3D_OS_BLOCK_MAJOR": "0"})):
+for tag, env in (("os", {"DF3D_OS_LC": "0"}), ("lc", {"DF3D_OS_LC": "1"})):
     print("----", tag, flush=True)
     path = "/tmp/sk_probe_%s.npz" % tag
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "child", iters, path], env=dict(os.environ, **env))
