@@ -251,6 +251,19 @@ extern "C" int df3d_scatter_to_image(const float *features, const float *point_i
   return DF3D_OK;
 }
 
+extern "C" int df3d_scatter_winner(const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask, int n, int batch,
+                                   int ncam, int H, int W, int32_t *winner, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(winner && batch > 0 && ncam > 0 && H > 0 && W > 0, "scatter_winner: bad arguments");
+  DF3D_HIP(hipMemsetAsync(winner, 0xff, (size_t)batch * ncam * H * W * sizeof(int32_t), stream));
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(indices && grid_xy && mask, "scatter_winner: null input");
+  ScatArgs a = {nullptr, nullptr, indices, grid_xy, mask, n, 0, ncam, H, W, winner, nullptr};
+  hipLaunchKernelGGL(scatter_winner_kernel, dim3(cdiv((long long)n * ncam, 256)), dim3(256), 0, stream, a);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
 extern "C" int df3d_assemble_queries(const float *features, const float *point_inv, const int32_t *indices,
                                      const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
                                      const float *img_feats, int n, int channels, int img_channels, int batch,

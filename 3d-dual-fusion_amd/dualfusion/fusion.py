@@ -20,6 +20,7 @@ import os
 import numpy as np
 import torch
 from torch import nn
+from torch.nn import functional as F
 
 from . import _lib, synth
 from . import ops as _ops
@@ -93,6 +94,31 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
         pt_img = self.reduced_dim2(pt_img)
         fused = self.reduced_dim3(img_feat) + pt_img          # [NI,1,H,W] broadcast over the channels
         return img_feat * torch.sigmoid(self.spatial_basic(fused))
+
+
+    def forward_rows(self, img_feat, canvases):
+        """forward_batched on pixel-major canvases {scale idx: [NI, H*W, C_s+3]}, with every convolution written as a
+        matrix product (the 1x1 convs) or as nine shifted sums of one (the 3x3 conv to one channel): same values,
+        differentiable, and none of it goes through MIOpen, whose fp32 fallback kernels for these shapes take
+        20-160 ms per call forward / backward."""
+        NI, Ci, H, W = img_feat.shape
+        pt = None
+        for conv_idx in self.voxel_idx:
+            f = canvases[conv_idx]
+            if len(self.voxel_idx) > 1 and conv_idx != self.voxel_idx[-1]:
+                cv = self.reduced_dim[conv_idx]
+                f = F.linear(f, cv.weight[:, :, 0, 0], cv.bias)
+            pt = f if pt is None else pt + f
+        pt = F.linear(pt, self.reduced_dim2.weight[:, :, 0, 0], self.reduced_dim2.bias)              # [NI, HW, last]
+        summary = torch.matmul(self.reduced_dim3.weight[:, :, 0, 0], img_feat.reshape(NI, Ci, H * W))   # [NI, 1, HW]
+        fused = pt + (summary.transpose(1, 2) + self.reduced_dim3.bias)
+        taps = F.linear(fused, self.spatial_basic.weight[0].permute(1, 2, 0).reshape(9, -1))         # [NI, HW, 9]
+        taps = F.pad(taps.view(NI, H, W, 9), (0, 0, 1, 1, 1, 1))                                     # zero padding of the 3x3
+        y = self.spatial_basic.bias.view(1, 1, 1)
+        for ty in range(3):
+            for tx in range(3):
+                y = y + taps[:, ty:ty + H, tx:tx + W, ty * 3 + tx]
+        return img_feat * torch.sigmoid(y).unsqueeze(1)
 
 
 ifat_all = {'Basicgate_patch_iv_multivoxel': Basicgate_patch_iv_multivoxel}
@@ -327,17 +353,89 @@ class VoxelWithPointProjection(nn.Module):
         max_ne = int(counts.max().item()) if n > 0 else 0                                     # the one host sync
         return pos, max_ne, counts
 
-    @torch.no_grad()
     def forward(self, batch_dict, example, encoded_voxel_list=None, layer_name=None, img_conv_func=None,
                 fuse_mode=None, d_factor_list=None):
         if fuse_mode != 'pfat':
             raise NotImplementedError("fuse_mode %r" % (fuse_mode,))
-        if self.training and any(p.requires_grad for p in self.parameters()):
-            # this adapter is the inference formulation (folded gate matrices, fused ACTR layers, no autograd graph):
-            # a training step through it would run and silently stop fusion.pfat.* / fusion.ifat.* from learning
-            raise NotImplementedError("VoxelWithPointProjection.forward is inference-only on the MI355X path: call "
-                                      ".eval() (or freeze the fusion parameters) -- the fused adapter records no "
-                                      "gradients for fusion.pfat.* / fusion.ifat.* or the voxel features")
+        if torch.is_grad_enabled() and (encoded_voxel_list[-1].features.requires_grad
+                                        or (self.training and any(p.requires_grad for p in self.parameters()))):
+            # the inference formulation below (folded gate matrices, fused ACTR layers) records no autograd graph: a
+            # training step takes the differentiable composition instead, so that fusion.pfat.* / fusion.ifat.* and the
+            # voxel features keep learning
+            return self.forward_autograd(batch_dict, example, encoded_voxel_list, layer_name, img_conv_func, d_factor_list)
+        with torch.no_grad():
+            return self._forward_inference(batch_dict, example, encoded_voxel_list, layer_name, img_conv_func, d_factor_list)
+
+    def forward_autograd(self, batch_dict, example, encoded_voxel_list, layer_name=None, img_conv_func=None,
+                         d_factor_list=None):
+        """Training formulation of forward(): the integer work (projection with the reference's truncations, the winning
+        voxel of every pixel, the per-camera query slots) comes from the same native kernels as in inference; every
+        floating-point stage is a differentiable torch composition over them -- the image gate on gathered canvases
+        (attention.py:31-61), ACTR through its module path (MSDeformAttnFunction backward = csrc/msda.hip), the additive
+        write-back in camera order -- so gradients reach the voxel features of every scale the gate reads, the last
+        scale's features, and all fusion parameters.  Same values as the inference path up to summation order."""
+        x_last = encoded_voxel_list[-1]
+        dev = x_last.features.device
+        with torch.no_grad():
+            inp = self._gather_inputs(batch_dict, layer_name, dev)
+            B, ncam, H, W = inp['B'], inp['ncam'], inp['h'], inp['w']
+            NI = B * ncam
+            last = len(encoded_voxel_list) - 1
+            need = set([last]) | (set(self.ifat.voxel_idx) if self.ifat_cfg is not None else set())
+            proj = {s_: self._project(encoded_voxel_list[s_], d_factor_list[s_], inp) for s_ in sorted(need)}
+        imgs = torch.stack(inp['imgs'], 0)                                          # [NI, Ci, H, W]
+        if img_conv_func is not None:
+            imgs = img_conv_func(imgs)
+        gated = imgs
+        if self.ifat_cfg is not None:
+            canvases = {}
+            for sidx in self.ifat.voxel_idx:
+                x = encoded_voxel_list[sidx]
+                grid_s, mask_s, pinv_s = proj[sidx]
+                with torch.no_grad():
+                    winner = self._winner(x, grid_s, mask_s, inp)                   # [NI, H, W] row index or -1
+                    img_w, pix_w = torch.nonzero(winner.view(NI, H * W) >= 0, as_tuple=True)
+                    row_w = winner.view(NI, H * W)[img_w, pix_w].long()
+                rows = torch.cat([x.features, pinv_s], 1)                           # [n, C + 3]
+                # pts2img: the winner's row at its pixel, zero elsewhere (a gather over the occupied pixels only: the
+                # backward of a dense gather with every empty pixel clamped to one row serialises on that row)
+                canvases[sidx] = rows.new_zeros((NI, H * W, rows.shape[1])).index_put((img_w, pix_w), rows[row_w])
+            gated = self.ifat.forward_rows(imgs, canvases)
+        grid, mask, pinv = proj[last]
+        feats = x_last.features
+        ind = x_last.indices.contiguous()
+        n, C = feats.shape
+        with torch.no_grad():
+            pos, max_ne, counts = self._query_slots(ind, mask, B)
+            # (camera, row) pairs that own a query slot, camera-major
+            cam_i, row_i = torch.nonzero((mask != 0) & (pos.long() < max_ne), as_tuple=True)
+            img_i = ind[row_i, 0].long() * ncam + cam_i
+            slot_i = pos[cam_i, row_i].long()
+            gx, gy = grid[cam_i, row_i, 0].long(), grid[cam_i, row_i, 1].long()
+        Ci = gated.shape[1]
+        v_feat = feats.new_zeros((NI, max_ne, C)).index_put((img_i, slot_i), feats[row_i])
+        v_i_feat = feats.new_zeros((NI, max_ne, Ci)).index_put((img_i, slot_i), gated[img_i, :, gy, gx])
+        qgrid = feats.new_zeros((NI, max_ne, 2)).index_put(
+            (img_i, slot_i), torch.stack([gx.to(feats.dtype) / float(W), gy.to(feats.dtype) / float(H)], 1))
+        qpts = feats.new_zeros((NI, max_ne, 3)).index_put((img_i, slot_i), pinv[row_i])
+        enh = self.pfat(v_feat, qgrid, [gated], v_i_feat, qpts)                     # [NI, max_ne, C]
+        out = feats
+        for cam in range(ncam):                                                     # additive, camera order (writeback_kernel)
+            sel = cam_i == cam
+            out = out.index_add(0, row_i[sel], enh[img_i[sel], slot_i[sel]])
+        return x_last.replace_feature(out)
+
+    def _winner(self, x, grid, mask, inp):
+        """Row index of the voxel that owns each image pixel (-1: none): the pts2img scatter's last writer."""
+        n = x.features.shape[0]
+        NI = inp['B'] * inp['ncam']
+        winner = torch.empty((NI, inp['h'], inp['w']), dtype=torch.int32, device=x.features.device)
+        rc = _lib.load().df3d_scatter_winner(_p(x.indices.contiguous()), _p(grid), _p(mask), n, inp['B'], inp['ncam'],
+                                             inp['h'], inp['w'], _p(winner), _ops._stream())
+        _lib.check(rc, "df3d_scatter_winner")
+        return winner
+
+    def _forward_inference(self, batch_dict, example, encoded_voxel_list, layer_name, img_conv_func, d_factor_list):
         lib = _lib.load()
         x_last = encoded_voxel_list[-1]
         dev = x_last.features.device

@@ -114,22 +114,27 @@ class CenterPointDetector(nn.Module):
     def neck(self):
         return self.hot_path.neck
 
-    def training_step(self, points_list, example):
-        """One forward + backward of the LiDAR detector in train() mode, the way the reference's trainer drives it
+    def training_step(self, points_list, example, batch_dict=None):
+        """One forward + backward of the detector in train() mode, the way the reference's trainer drives it
         (`model(example, return_loss=True)` -> `parse_second_losses` -> `loss.backward()`, CP/det3d/torchie/trainer/
         trainer.py:366-380): voxelisation without gradients, then backbone (sparse-conv autograd Functions, BatchNorm in
-        torch) -> dense BEV -> RPN neck -> CenterHead -> `loss` (the reference's composition) -> backward.  The caller
-        owns gradient reduction and the optimizer.  Returns the merged loss dict.  The camera-fusion adapter is an
-        inference formulation without an autograd graph, so a detector built with `fusion=` refuses."""
-        if self.hot_path.fusion is not None:
-            raise NotImplementedError("training through the fused camera adapter is not implemented (inference-only path)")
+        torch; with `fusion=` the camera adapter's differentiable composition, `VoxelWithPointProjection.
+        forward_autograd`, between conv4 and the dense map) -> dense BEV -> RPN neck -> CenterHead -> `loss` (the
+        reference's composition) -> backward.  The caller owns gradient reduction and the optimizer.  Returns the merged
+        loss dict."""
         hp = self.hot_path
+        if hp.fusion is not None and batch_dict is None:
+            raise ValueError("training_step: a detector with a camera-fusion adapter needs batch_dict (camera features / calibration)")
         with torch.no_grad():
             feats, coors = hp.voxelize(points_list)
         layout, hp.backbone.dense_layout = getattr(hp.backbone, "dense_layout", "nchw"), "nchw"
         try:
             with torch.enable_grad():
-                bev, _ = hp.backbone(feats, coors, len(points_list), hp.grid_size_xyz)
+                if hp.fusion is None:
+                    bev, _ = hp.backbone(feats, coors, len(points_list), hp.grid_size_xyz)
+                else:
+                    bev, _ = hp.backbone(feats, batch_dict, coors, len(points_list), hp.grid_size_xyz, example,
+                                         fuse_func=hp.fusion)
                 preds = self.bbox_head(self.neck(bev))
                 rets = self.bbox_head.loss(example, preds, {})
                 sum(rets["loss"]).backward()

@@ -54,7 +54,7 @@ def parse():
                          "KITTI, bs=8); protocol = launcher / barrier / reduce protocol only, no GPU work (CPU tests)")
     ap.add_argument("--stage", default="detect", choices=["detect", "hot_path", "train"],
                     help="detect (default): ... -> neck -> head -> losses -> reduce_dict; hot_path: stop at the dense BEV; "
-                         "train (cp_lidar only): forward + backward + bucketed gradient all-reduce overlapped with backward "
+                         "train (cp_lidar, cp_fusion): forward + backward + bucketed gradient all-reduce overlapped with backward "
                          "+ AdamW step + reduce_dict of the losses -- a real data-parallel training step")
     ap.add_argument("--batch", type=int, default=0, help="sweeps per GPU per step (0 = the workload's BASELINE batch)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames the steps rotate through")
@@ -175,7 +175,7 @@ class CenterPointWorkload(object):
             if getattr(self, "reducer", None) is None:
                 self._train_setup()
             self.reducer.zero_grad()
-            rets = self.model.training_step(fr["points"], example)
+            rets = self.model.training_step(fr["points"], example, batch_dict=bd)
             self.reducer.finish()                      # waits for the bucket all-reduces launched during backward
             self.optimizer.step()
             return {k: torch.stack([v.detach().to(self.dev).float().reshape(()) for v in rets[k]])
@@ -486,7 +486,7 @@ def main():
     wl.check(out, stage)
     extra = {}
     if stage == "train":
-        assert args.workload == "cp_lidar", "--stage train: the LiDAR detector only (the fused camera adapter has no backward)"
+        assert args.workload in ("cp_lidar", "cp_fusion"), "--stage train: the CenterPoint detectors"
     if not (args.no_extra_passes or protocol or stage == "train"):
         # the same K steps ending at the dense BEV tensor (round 1's step), and both stages on the exact-fp32 kernels
         if stage == "detect":

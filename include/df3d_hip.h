@@ -504,6 +504,11 @@ int df3d_fusion_writeback(const float *features, const float *enh, const int32_t
  *   how the reference holds them (one dict entry per camera) -- no stacking copy.  counts (optional, from
  *   df3d_query_slots): when given, only the padding rows (slot >= counts[image]) are zeroed instead of the whole
  *   padded tensors. */
+/* df3d_scatter_winner: winner [B*ncam, H, W] = highest voxel row projected onto each pixel (-1: none) -- the "last writer"
+ * of the reference's pts2img index_put (voxel_with_point_projection.py:283-352) on its own, for callers that gather the
+ * canvas themselves (the differentiable training path of dualfusion.fusion). */
+int df3d_scatter_winner(const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask, int n, int batch, int ncam,
+                        int H, int W, int32_t *winner, void *stream);
 int df3d_gate_scatter(const float *s9, const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask,
                       int n, int batch, int ncam, int H, int W, int32_t *winner, float *S, int clear, void *stream);
 int df3d_gate_finish(const float *gate, const float *S, const float *kg, int nimg, int H, int W, float *att,

@@ -162,6 +162,71 @@ def test_centerpoint_fusion_adapter_vs_reference_golden(golden):
     assert np.abs(ref - g["out"]).max() > 1.0               # the augmentation records do change the result
 
 
+def test_centerpoint_fusion_adapter_training_path(golden):
+    """The differentiable formulation of the adapter (forward_autograd: same native integer work, torch compositions +
+    the ACTR module path for every floating-point stage) reproduces the REFERENCE module's output on the golden inputs,
+    and gradients reach the voxel features of every scale it reads and every fusion parameter."""
+    from dualfusion import fusion as fz, spconv, synth
+    from make_golden import ACTR_CFG, FUS, FUS_IFAT, FUS_LT
+    dev = torch.device("cuda:0")
+    g = golden("fusion_cp.npz")
+    sets = [g["coords2"].astype(np.int32), g["coords3"].astype(np.int32), g["coords4"].astype(np.int32)]
+    feats = [detgen.randn("fus_feat%d" % i, (len(s), c)) for i, (s, c) in enumerate(zip(sets, [32, 64, 128]))]
+    mod = fz.VoxelWithPointProjection(fuse_mode='pfat', interpolate=False, voxel_size=FUS["voxel_size"],
+                                      pc_range=FUS["pc_range"], image_list=synth.NUSC_CAMS,
+                                      image_scale=FUS["image_scale"], depth_thres=FUS["depth_thres"],
+                                      pfat_cfg=dict(ACTR_CFG), lt_cfg=dict(FUS_LT), ifat_cfg=dict(FUS_IFAT),
+                                      model_name='ACTR')
+    sd = detgen.det_state_dict({k: tuple(v.shape) for k, v in mod.state_dict().items()})
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    mod = mod.to(dev).train()
+    for m in mod.modules():                                     # the golden was taken without dropout
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    B = FUS["batch"]
+    cams = synth.nusc_cameras(image_hw=FUS["raw_hw"], focal=FUS["focal"])
+    H, W = FUS["img_hw"]
+    batch_dict = {'image_shape': {}, 'img_feat': {'layer1_ori_feat2d': {}}, 'calib': {}}
+    for n in synth.NUSC_CAMS:
+        key = n.lower()
+        batch_dict['image_shape'][key] = torch.tensor([[H, W, 3]] * B)
+        batch_dict['img_feat']['layer1_ori_feat2d'][key] = torch.from_numpy(
+            detgen.randn("fus_img_" + n, (B, 256) + tuple(FUS["feat_hw"]))).to(dev)
+        T, K = cams[n]
+        batch_dict['calib']['lidar2cam_' + key.lstrip('cam_')] = torch.from_numpy(np.stack([T] * B)).to(dev)
+        batch_dict['calib']['cam_intrinsic_' + key.lstrip('cam_')] = torch.from_numpy(np.stack([K] * B)).to(dev)
+    shapes = [[21, 128, 128], [11, 64, 64], [5, 32, 32]]
+    leaves = [torch.from_numpy(f).to(dev).requires_grad_(True) for f in feats]
+    xs = [spconv.SparseConvTensor(f, torch.from_numpy(i).to(dev), shp, B) for f, i, shp in zip(leaves, sets, shapes)]
+    out = mod(batch_dict, {}, encoded_voxel_list=xs, layer_name='layer1_ori', fuse_mode='pfat', d_factor_list=[2, 4, 8])
+    assert out.features.requires_grad                           # forward() took the differentiable composition
+    ref = g["out"]
+    err = np.abs(out.features.detach().cpu().numpy() - ref).max()
+    assert err <= 1e-3 * max(1.0, np.abs(ref).max()), err
+    wgt = torch.from_numpy(detgen.randn("fus_train_w", tuple(out.features.shape))).to(dev)
+    (out.features * wgt).sum().backward()
+    for i in (0, 2):                                            # the gate reads scales 0 and 2, the queries scale 2
+        gr = leaves[i].grad
+        assert gr is not None and torch.isfinite(gr).all() and float(gr.abs().sum()) > 0, i
+    assert leaves[1].grad is None                               # scale 1 is not an input of this configuration
+    missing = [k for k, p_ in mod.named_parameters()
+               if p_.requires_grad and (p_.grad is None or not torch.isfinite(p_.grad).all() or float(p_.grad.abs().sum()) == 0)]
+    # parameters the 3D-DF configuration never reaches, in the reference as here: the level embedding (one level, no
+    # positional term), the image-query half of the LAST layer's gate (nobody reads its qi output), the gate's reduction
+    # conv of a scale that is not in voxel_idx
+    nlay = len(mod.pfat.transformer.encoder.layers)
+    unused = ["pfat.transformer.level_embed", "pfat.transformer.encoder.layers.%d.fusion_layer.a_conv1d." % (nlay - 1)] + \
+             ["ifat.reduced_dim.%d." % i for i in range(mod.ifat.voxel_idx[-1]) if i not in mod.ifat.voxel_idx]
+    assert all(any(k.startswith(u) for u in unused) for k in missing), missing
+    # d(loss)/d(voxel feature) of a row no camera sees is exactly the upstream weight (identity write-back)
+    inp = mod._gather_inputs(batch_dict, 'layer1_ori', dev)
+    _, mask, _ = mod._project(xs[2], 8, inp)
+    unseen = (mask.sum(0) == 0)
+    win_free = unseen.clone()                                   # ... unless it also owns a pixel of the gate canvas (it cannot: unseen)
+    assert int(win_free.sum()) > 0
+    np.testing.assert_allclose(leaves[2].grad[win_free].cpu().numpy(), wgt[win_free].cpu().numpy(), rtol=0, atol=1e-6)
+
+
 # ------------------------------------------------------------------------- LocalTransformer (a13) / point ops
 def test_pointops_reference_test_vectors_on_gpu(golden):
     from dualfusion import ops

@@ -217,3 +217,32 @@ def test_device_losses_no_positive_and_no_vel():
     np.testing.assert_allclose(got["loc_loss_elem"].cpu().numpy(), np.stack([v.numpy() for v in want["loc_loss_elem"]]),
                                rtol=2e-5, atol=1e-6)
     assert float(got["num_positive"][0]) == 0.0
+
+
+def test_detector_training_step_with_camera_fusion():
+    """One training step of the whole CenterPoint + 3D-DF detector at BASELINE size: losses finite, gradients on the
+    backbone in front of the adapter (they pass through the adapter's autograd formulation), on the fusion parameters
+    and on the head; an optimizer step changes all of them."""
+    from dualfusion import synth
+    from dualfusion.fusion import build_centerpoint_fusion, synthetic_camera_inputs
+    from dualfusion.pipeline import NUSC_TASKS, CenterPointDetector
+    torch.manual_seed(0)
+    det = CenterPointDetector(fusion=build_centerpoint_fusion()).to(DEV).train()
+    pts = [torch.from_numpy(synth.nusc_sweep(seed=11)).to(DEV)]
+    bd, ex = synthetic_camera_inputs(1, DEV, seed=3)
+    tg = synth.centerhead_targets(1, [t["num_class"] for t in NUSC_TASKS], seed=4)
+    ex = dict(ex, **{k: [torch.from_numpy(a).to(DEV) for a in v] for k, v in tg.items()})
+    fus = det.hot_path.fusion
+    probe = {"backbone": det.hot_path.backbone.conv2[0].weight,
+             "fusion": fus.pfat.transformer.encoder.layers[0].linear1.weight, "gate": fus.ifat.reduced_dim2.weight,
+             "head": det.bbox_head.shared_conv[0].weight}
+    before = {k: v.detach().clone() for k, v in probe.items()}
+    opt = torch.optim.SGD([p for p in det.parameters() if p.requires_grad], lr=1e-3)
+    opt.zero_grad()
+    rets = det.training_step(pts, ex, batch_dict=bd)
+    assert all(bool(torch.isfinite(v).all()) for v in rets["loss"])
+    for k, v in probe.items():
+        assert v.grad is not None and bool(torch.isfinite(v.grad).all()) and float(v.grad.abs().sum()) > 0, k
+    opt.step()
+    for k, v in probe.items():
+        assert float((v.detach() - before[k]).abs().max()) > 0, k
