@@ -15,6 +15,8 @@
 
 namespace df3d {
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -129,7 +131,8 @@ struct MsdaFusedArgs {
 
 // msda_vec4_kernel + in-kernel softmax over the L*P logits of a (query, head) and
 // loc = ref + off / (W_l, H_l) (ms_deform_attn.py:149-166, reference_points with 2 coordinates).
-template <int LPG>
+// VBF16: `value` holds bf16 rows (vstride counts bf16 elements); everything else stays fp32
+template <int LPG, bool VBF16 = false>
 __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs a) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)a.N * a.Lq * a.M * LPG;
@@ -176,7 +179,18 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs a) {
       float lx = rx + ox / (float)W;
       float ly = ry + oy / (float)H;
       const size_t pix0 = (size_t)b * a.S + (size_t)a.lstart[l];
-      const float *vbase = a.value + pix0 * a.vstride + m * a.D + sub * 4;
+      const size_t voff = pix0 * a.vstride + m * a.D + sub * 4;          // in elements of the value type
+      const float *vbase = a.value + voff;
+      const unsigned short *vbase16 = (const unsigned short *)a.value + voff;
+      auto corner = [&](size_t p) -> f32x4 {
+        if constexpr (VBF16) {
+          const u32x2 t = *(const u32x2 *)(vbase16 + p * a.vstride);
+          return (f32x4){__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u), __uint_as_float(t[1] << 16),
+                         __uint_as_float(t[1] & 0xffff0000u)};
+        } else {
+          return *(const f32x4 *)(vbase + p * a.vstride);
+        }
+      };
       const float *sbase = a.pscale ? a.pscale + pix0 : nullptr;
       float h_im = ly * (float)H - 0.5f;
       float w_im = lx * (float)W - 0.5f;
@@ -192,10 +206,10 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(MsdaFusedArgs a) {
         const bool in3 = h_high <= H - 1 && w_low >= 0, in4 = h_high <= H - 1 && w_high <= W - 1;
         const size_t p1 = (size_t)h_low * W + w_low, p2 = (size_t)h_low * W + w_high;
         const size_t p3 = (size_t)h_high * W + w_low, p4 = (size_t)h_high * W + w_high;
-        if (in1) v1 = *(const f32x4 *)(vbase + p1 * a.vstride);
-        if (in2) v2 = *(const f32x4 *)(vbase + p2 * a.vstride);
-        if (in3) v3 = *(const f32x4 *)(vbase + p3 * a.vstride);
-        if (in4) v4 = *(const f32x4 *)(vbase + p4 * a.vstride);
+        if (in1) v1 = corner(p1);
+        if (in2) v2 = corner(p2);
+        if (in3) v3 = corner(p3);
+        if (in4) v4 = corner(p4);
         if (sbase) {
           // value(p) = s_p * raw_p + c: the scale rides on the corner weight, the constant on the in-bounds weight sum
           float ws = (in1 ? w1 : 0.f) + (in2 ? w2 : 0.f) + (in3 ? w3 : 0.f) + (in4 ? w4 : 0.f);
@@ -415,11 +429,10 @@ extern "C" int df3d_bigate_sum(const float *q, const float *qi, const float *wb,
   return DF3D_OK;
 }
 
-extern "C" int df3d_ms_deform_attn_fused(const float *value, long long value_stride, const int64_t *spatial_shapes,
-                                         const int64_t *level_start_index, const float *ref_xy,
-                                         const float *offsets, const float *logits, const float *pixel_scale,
-                                         const float *image_bias, long long bias_stride, int N, int S, int M, int D,
-                                         int Lq, int L, int P, float *out, void *stream_) {
+static int msda_fused_launch(const void *value, bool vbf16, long long value_stride, const int64_t *spatial_shapes,
+                             const int64_t *level_start_index, const float *ref_xy, const float *offsets,
+                             const float *logits, const float *pixel_scale, const float *image_bias, long long bias_stride,
+                             int N, int S, int M, int D, int Lq, int L, int P, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(value && spatial_shapes && level_start_index && ref_xy && offsets && logits && out,
                  "ms_deform_attn_fused: null argument");
@@ -428,14 +441,15 @@ extern "C" int df3d_ms_deform_attn_fused(const float *value, long long value_str
   if (N == 0 || Lq == 0) return DF3D_OK;
   DF3D_CHECK_ARG(!pixel_scale || image_bias, "ms_deform_attn_fused: pixel_scale needs image_bias");
   DF3D_CHECK_ARG(!image_bias || bias_stride % 4 == 0, "ms_deform_attn_fused: bias stride must be a multiple of 4");
-  MsdaFusedArgs a = {value, spatial_shapes, level_start_index, ref_xy, offsets, logits, out, N, S, M, D, Lq, L, P,
+  MsdaFusedArgs a = {(const float *)value, spatial_shapes, level_start_index, ref_xy, offsets, logits, out, N, S, M, D, Lq, L, P,
                      value_stride, pixel_scale, image_bias, bias_stride};
   long long total;
   switch (D / 4) {
-#define DF3D_CASE(G)                                                                                \
-  case G:                                                                                           \
-    total = (long long)N * Lq * M * G;                                                              \
-    hipLaunchKernelGGL(msda_fused_kernel<G>, dim3(cdiv(total, 256)), dim3(256), 0, stream, a);      \
+#define DF3D_CASE(G)                                                                                       \
+  case G:                                                                                                  \
+    total = (long long)N * Lq * M * G;                                                                     \
+    if (vbf16) hipLaunchKernelGGL((msda_fused_kernel<G, true>), dim3(cdiv(total, 256)), dim3(256), 0, stream, a);  \
+    else hipLaunchKernelGGL((msda_fused_kernel<G, false>), dim3(cdiv(total, 256)), dim3(256), 0, stream, a);       \
     break;
     DF3D_CASE(1)
     DF3D_CASE(2)
@@ -492,4 +506,22 @@ extern "C" int df3d_rows_groupnorm(const float *x, int N, int Q, int C, int grou
                      eps, Q, C, C / groups, n4, out);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
+}
+
+extern "C" int df3d_ms_deform_attn_fused(const float *value, long long value_stride, const int64_t *spatial_shapes,
+                                         const int64_t *level_start_index, const float *ref_xy,
+                                         const float *offsets, const float *logits, const float *pixel_scale,
+                                         const float *image_bias, long long bias_stride, int N, int S, int M, int D,
+                                         int Lq, int L, int P, float *out, void *stream_) {
+  return msda_fused_launch(value, false, value_stride, spatial_shapes, level_start_index, ref_xy, offsets, logits,
+                           pixel_scale, image_bias, bias_stride, N, S, M, D, Lq, L, P, out, stream_);
+}
+
+extern "C" int df3d_ms_deform_attn_fused_bf16(const void *value_bf16, long long value_stride,
+                                              const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                              const float *ref_xy, const float *offsets, const float *logits,
+                                              const float *pixel_scale, const float *image_bias, long long bias_stride,
+                                              int N, int S, int M, int D, int Lq, int L, int P, float *out, void *stream_) {
+  return msda_fused_launch(value_bf16, true, value_stride, spatial_shapes, level_start_index, ref_xy, offsets, logits,
+                           pixel_scale, image_bias, bias_stride, N, S, M, D, Lq, L, P, out, stream_);
 }

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void gn_fold_pack_kernel(const double *__restr
 }
 
 // value[n][p][0:256] = u[n][p][0:128] . Wf[n]^T: rows contiguous, weights per image (blockIdx.y)
+template <bool BF16>
 __global__ __launch_bounds__(512) void rows_gemm_split_kernel(const u32x4 *__restrict__ us, const u32x4 *__restrict__ Wp,
                                                               int S, float *__restrict__ out) {
   __shared__ u32x4 Wl[2][RG_WQ];                 // 64 KB
@@ -358,10 +359,18 @@ __global__ __launch_bounds__(512) void rows_gemm_split_kernel(const u32x4 *__res
   for (int r = 0; r < 4; ++r) {
     const int p = blockIdx.x * 128 + wave * 16 + 4 * g + r;
     if (p >= S) continue;
-    float *o = out + ((size_t)nimg * S + p) * RG_COUT + n * 4;
+    if constexpr (BF16) {                       // bf16 rows (round to nearest even): half the bytes for the sampler's gathers
+      unsigned short *o = (unsigned short *)out + ((size_t)nimg * S + p) * RG_COUT + n * 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *(f32x4 *)(o + q * 64) = (f32x4){acc[q * 4][r], acc[q * 4 + 1][r], acc[q * 4 + 2][r], acc[q * 4 + 3][r]};
+      for (int q = 0; q < 4; ++q)
+        *(u32x2 *)(o + q * 64) = (u32x2){ip_bf16_bits(acc[q * 4][r]) | (ip_bf16_bits(acc[q * 4 + 1][r]) << 16),
+                                         ip_bf16_bits(acc[q * 4 + 2][r]) | (ip_bf16_bits(acc[q * 4 + 3][r]) << 16)};
+    } else {
+      float *o = out + ((size_t)nimg * S + p) * RG_COUT + n * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4 *)(o + q * 64) = (f32x4){acc[q * 4][r], acc[q * 4 + 1][r], acc[q * 4 + 2][r], acc[q * 4 + 3][r]};
+    }
   }
 }
 
@@ -397,10 +406,31 @@ extern "C" int df3d_imgproj_split(const float *const *img_ptrs, int nimg, int ci
   return DF3D_OK;
 }
 
+static int value_fold_gemm(const void *u_split, const float *att, int nimg, int S, const float *conv_bias,
+                          const float *gn_weight, const float *gn_bias, float eps, int groups, const float *W,
+                          const float *wb, double *moments, void *packed_w, float *cf, void *value, bool bf16,
+                          void *stream_);
+
 extern "C" int df3d_value_fold_gemm(const void *u_split, const float *att, int nimg, int S, const float *conv_bias,
                                     const float *gn_weight, const float *gn_bias, float eps, int groups,
                                     const float *W, const float *wb, double *moments, void *packed_w, float *cf,
                                     float *value, void *stream_) {
+  return value_fold_gemm(u_split, att, nimg, S, conv_bias, gn_weight, gn_bias, eps, groups, W, wb, moments, packed_w, cf,
+                         value, false, stream_);
+}
+
+extern "C" int df3d_value_fold_gemm_bf16(const void *u_split, const float *att, int nimg, int S, const float *conv_bias,
+                                         const float *gn_weight, const float *gn_bias, float eps, int groups,
+                                         const float *W, const float *wb, double *moments, void *packed_w, float *cf,
+                                         void *value_bf16, void *stream_) {
+  return value_fold_gemm(u_split, att, nimg, S, conv_bias, gn_weight, gn_bias, eps, groups, W, wb, moments, packed_w, cf,
+                         value_bf16, true, stream_);
+}
+
+static int value_fold_gemm(const void *u_split, const float *att, int nimg, int S, const float *conv_bias,
+                          const float *gn_weight, const float *gn_bias, float eps, int groups, const float *W,
+                          const float *wb, double *moments, void *packed_w, float *cf, void *value, bool bf16,
+                          void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(u_split && gn_weight && gn_bias && W && moments && packed_w && cf && value,
                  "value_fold_gemm: null argument");
@@ -412,8 +442,12 @@ extern "C" int df3d_value_fold_gemm(const void *u_split, const float *att, int n
                      S, rpb, moments);
   hipLaunchKernelGGL(gn_fold_pack_kernel, dim3(nimg), dim3(256), 0, stream, moments, conv_bias, gn_weight, gn_bias, eps,
                      S, groups, W, wb, (u32x4 *)packed_w, cf);
-  hipLaunchKernelGGL(rows_gemm_split_kernel, dim3(cdiv(S, 128), nimg), dim3(512), 0, stream, (const u32x4 *)u_split,
-                     (const u32x4 *)packed_w, S, value);
+  if (bf16)
+    hipLaunchKernelGGL(rows_gemm_split_kernel<true>, dim3(cdiv(S, 128), nimg), dim3(512), 0, stream, (const u32x4 *)u_split,
+                       (const u32x4 *)packed_w, S, (float *)value);
+  else
+    hipLaunchKernelGGL(rows_gemm_split_kernel<false>, dim3(cdiv(S, 128), nimg), dim3(512), 0, stream, (const u32x4 *)u_split,
+                       (const u32x4 *)packed_w, S, (float *)value);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -136,6 +136,8 @@ SIGNATURES = {
     "df3d_imgproj_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_value_fold_gemm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_value_fold_gemm_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_backbone_run": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_size_t, c_void_p, c_void_p, c_void_p]),
     "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
@@ -146,6 +148,9 @@ SIGNATURES = {
     "df3d_ms_deform_attn_fused": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_longlong,
                                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_ms_deform_attn_fused_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_longlong,
+                                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_rows_groupnorm": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                                     c_void_p, c_void_p]),
     "df3d_scaled_moments": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_void_p,

@@ -535,7 +535,9 @@ class ACTR(nn.Module):
         if u.dtype == torch.uint8:
             # u arrives as pixel-major split rows (csrc/imgproj.hip): moments, fold and the value GEMM of all
             # layers in one native call on the bf16 matrix cores
-            value, cf = _ops.value_fold_gemm(u, gate, conv.bias, gn, W, wb)
+            # reduced-precision mode (DF3D_CONV_PRECISION=bf16, the reference's fp16-AMP configurations): the value rows
+            # the sampler gathers are bf16 -- half the bytes; weights, accumulation and output stay fp32
+            value, cf = _ops.value_fold_gemm(u, gate, conv.bias, gn, W, wb, bf16=_ops.CONV_PRECISION == "bf16")
         else:
             Wf, cf = _ops.groupnorm_fold(u, gate, conv.bias, gn, W, wb)
             value = torch.bmm(u[:, :C].transpose(1, 2), Wf.transpose(1, 2))         # [N, S, nlayers*C]

@@ -942,8 +942,8 @@ def ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, offse
         _chk(t, torch.float32, name)
     _chk(spatial_shapes, torch.int64, "spatial_shapes")
     _chk(level_start_index, torch.int64, "level_start_index")
-    if not value.is_cuda or value.dtype != torch.float32:
-        raise _lib.Df3dError("value must be a float32 GPU tensor")
+    if not value.is_cuda or value.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.Df3dError("value must be a float32 or bfloat16 GPU tensor")
     N, S, M, D = value.shape
     if value.stride(3) != 1 or value.stride(2) != D or value.stride(0) != S * value.stride(1):
         raise _lib.Df3dError("value must be [N,S,M,D] with contiguous heads and a uniform pixel stride")
@@ -956,7 +956,8 @@ def ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, offse
             raise _lib.Df3dError("image_bias must be float32 [N, M*D] with unit channel stride")
         bstride = int(image_bias.stride(0))
     out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
-    rc = lib.df3d_ms_deform_attn_fused(_ptr(value), int(value.stride(1)), _ptr(spatial_shapes),
+    fn = lib.df3d_ms_deform_attn_fused_bf16 if value.dtype == torch.bfloat16 else lib.df3d_ms_deform_attn_fused
+    rc = fn(_ptr(value), int(value.stride(1)), _ptr(spatial_shapes),
                                        _ptr(level_start_index), _ptr(ref_xy), _ptr(offsets), _ptr(logits),
                                        _ptr(pixel_scale), _ptr(image_bias), bstride, N, S, M, D,
                                        Lq, int(n_levels), int(n_points), _ptr(out), _stream())
@@ -1087,8 +1088,9 @@ def imgproj_split(img_ptrs, nimg, cin, S, packed):
     return u, gate
 
 
-def value_fold_gemm(u_split, att, conv_bias, gn, W, wb):
-    """-> (value fp32 [nimg, S, 256], cf [nimg, 256]): W GroupNorm(att*u + conv_bias) + wb = att_p * value_p + cf."""
+def value_fold_gemm(u_split, att, conv_bias, gn, W, wb, bf16=False):
+    """-> (value fp32 (or, bf16=True, torch.bfloat16) [nimg, S, 256], cf [nimg, 256]): W GroupNorm(att*u + conv_bias) + wb =
+    att_p * value_p + cf."""
     lib = _lib.load()
     _chk(u_split, torch.uint8, "u_split")
     nimg, S = u_split.shape[0], u_split.shape[1]
@@ -1100,10 +1102,10 @@ def value_fold_gemm(u_split, att, conv_bias, gn, W, wb):
     mom = torch.empty((nimg, 128, 2), dtype=torch.float64, device=dev)
     pw = torch.empty((nimg, 128 * 1024), dtype=torch.uint8, device=dev)
     cf = torch.empty((nimg, 256), dtype=torch.float32, device=dev)
-    value = torch.empty((nimg, S, 256), dtype=torch.float32, device=dev)
-    rc = lib.df3d_value_fold_gemm(_ptr(u_split), _ptr(att), nimg, S, _ptr(conv_bias), _ptr(gn.weight), _ptr(gn.bias),
-                                  float(gn.eps), int(gn.num_groups), _ptr(W), _ptr(wb), _ptr(mom), _ptr(pw), _ptr(cf),
-                                  _ptr(value), _stream())
+    value = torch.empty((nimg, S, 256), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+    fn = lib.df3d_value_fold_gemm_bf16 if bf16 else lib.df3d_value_fold_gemm
+    rc = fn(_ptr(u_split), _ptr(att), nimg, S, _ptr(conv_bias), _ptr(gn.weight), _ptr(gn.bias), float(gn.eps),
+            int(gn.num_groups), _ptr(W), _ptr(wb), _ptr(mom), _ptr(pw), _ptr(cf), _ptr(value), _stream())
     _lib.check(rc, "df3d_value_fold_gemm")
     return value, cf
 

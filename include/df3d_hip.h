@@ -570,6 +570,14 @@ int df3d_ms_deform_attn_fused(const float *value, long long value_stride, const 
                               const float *logits, const float *pixel_scale, const float *image_bias,
                               long long bias_stride, int N, int S, int M, int D, int Lq, int L, int P,
                               float *out, void *stream);
+/* The same sampler on bf16 value rows (value_stride in bf16 elements): the reduced-precision mode of the reference's
+ * fp16-AMP configurations (TF/configs/...: fp16 = dict(loss_scale=512.)); offsets, logits, weights, the accumulation and
+ * the output stay fp32.  Produced by df3d_value_fold_gemm_bf16. */
+int df3d_ms_deform_attn_fused_bf16(const void *value_bf16, long long value_stride, const int64_t *spatial_shapes,
+                                   const int64_t *level_start_index, const float *ref_xy, const float *offsets,
+                                   const float *logits, const float *pixel_scale, const float *image_bias,
+                                   long long bias_stride, int N, int S, int M, int D, int Lq, int L, int P,
+                                   float *out, void *stream);
 
 /* GroupNorm of the gated input projection folded into the value projection (actr.py:139-149 input_proj[l] =
  * Conv2d 1x1 + GroupNorm, ms_deform_attn.py:139 value_proj).  With x = a_p*u + b (u = W_ip*img without bias,
@@ -639,6 +647,10 @@ int df3d_imgproj_split(const float *const *img_ptrs, int nimg, int cin, int S, c
 int df3d_value_fold_gemm(const void *u_split, const float *att, int nimg, int S, const float *conv_bias,
                          const float *gn_weight, const float *gn_bias, float eps, int groups, const float *W,
                          const float *wb, double *moments, void *packed_w, float *cf, float *value, void *stream);
+/* ... writing the value rows as bf16 [nimg, S, 256] (round to nearest even) for df3d_ms_deform_attn_fused_bf16 */
+int df3d_value_fold_gemm_bf16(const void *u_split, const float *att, int nimg, int S, const float *conv_bias,
+                         const float *gn_weight, const float *gn_bias, float eps, int groups, const float *W,
+                         const float *wb, double *moments, void *packed_w, float *cf, void *value_bf16, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Native executor for a chain of fused sparse-convolution layers (csrc/executor.hip): the sparse backbones'

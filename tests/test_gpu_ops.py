@@ -326,6 +326,41 @@ def test_msda_fused_vs_oracle(dev, D, L, P, wide):
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-3, atol=2e-5)
 
 
+@pytest.mark.parametrize("D,L,P,wide", [(16, 1, 4, False), (16, 1, 4, True), (8, 2, 3, False)])
+def test_msda_fused_bf16_value(dev, D, L, P, wide):
+    """The sampler on bf16 value rows (reduced-precision mode): against the oracle evaluated on the SAME bf16-rounded values
+    it agrees to fp32 noise (weights, accumulation and output stay fp32); with a per-pixel scale and an image constant too."""
+    from dualfusion import ops
+    N, M, Lq = 2, 8, 257
+    shp = [(17, 23), (9, 11)][:L]
+    S = sum(h * w for h, w in shp)
+    tag = "mfb%d_%d_%d" % (D, L, P)
+    value = detgen.randn(tag + "v", (N, S, M, D))
+    ref = detgen.rand(tag + "r", (N, Lq, 2), -0.05, 1.05)
+    off = detgen.randn(tag + "o", (N, Lq, M, L, P, 2)) * 2.0
+    lg = detgen.randn(tag + "l", (N, Lq, M, L * P)) * 3.0
+    norm = np.array([[w, h] for h, w in shp], np.float32)
+    loc = (ref[:, :, None, None, None, :] + off / norm[None, None, None, :, None, :]).astype(np.float32)
+    aw = _softmax(lg).reshape(N, Lq, M, L, P)
+    v16 = T(value, dev).to(torch.bfloat16)
+    rounded = v16.float().cpu().numpy()
+    shapes = torch.as_tensor(shp, dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    v = v16
+    if wide:
+        buf = torch.full((N, S, 2, M, D), 7.0, device=dev, dtype=torch.bfloat16)
+        buf[:, :, 1] = v16
+        v = buf[:, :, 1]
+    y = ops.ms_deform_attn_fused(v, shapes, lsi, T(ref, dev), T(off.reshape(N, Lq, -1), dev), T(lg, dev), L, P)
+    np.testing.assert_allclose(y.cpu().numpy(), orc.ms_deform_attn(rounded, shp, loc, aw), rtol=1e-3, atol=2e-5)
+    scale = detgen.rand(tag + "s", (N, S), 0.2, 1.5)
+    cb = detgen.randn(tag + "c", (N, M * D))
+    y = ops.ms_deform_attn_fused(v, shapes, lsi, T(ref, dev), T(off.reshape(N, Lq, -1), dev), T(lg, dev), L, P,
+                                 pixel_scale=T(scale, dev), image_bias=T(cb, dev))
+    want = orc.ms_deform_attn(rounded * scale[:, :, None, None] + cb.reshape(N, 1, M, D), shp, loc, aw)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-3, atol=5e-5)
+
+
 @pytest.mark.parametrize("C,rows", [(128, 1000), (64, 77), (256, 3), (1024, 5), (16, 130)])
 def test_actr_rowwise_kernels(dev, C, rows):
     """actr_prep / add_layernorm / bigate_sum against the torch expressions the reference layer runs
