@@ -1255,7 +1255,7 @@ static int launch_os_lc(const SplitConvArgs &a, hipStream_t stream) {
 }
 
 static bool use_lc(const SplitConvArgs &a) {
-  static const char *t = getenv("DF3D_OS_LC");
+  const char *t = getenv("DF3D_OS_LC");         // read per call: the tests switch it inside one process
   if (a.cols) return false;
   if (t && t[0] == '0') return false;
   if (t && t[0] == '1') return true;

@@ -233,6 +233,57 @@ def test_sparse_conv_split_precision(dev, cin, cout, n_seeds):
         assert np.abs(y32.cpu().numpy() - ref).max() / np.abs(ref).max() < 5e-6
 
 
+@pytest.mark.parametrize("cin,cout", [(128, 128), (64, 128), (128, 256)])
+def test_loader_consumer_conv_kernel_forced_on_small_and_ragged_shapes(dev, cin, cout):
+    """The loader / consumer LDS-DMA kernel normally serves layers of >= 190 workgroups; forced on (DF3D_OS_LC=1) it must
+    give the register-gather kernel's result BIT FOR BIT (same summation order) on every shape: a single row, row counts
+    around the 128-row tile, tiles whose last rows are padding, offsets without any pair in a tile, a 1-offset rulebook
+    (fewer steps than ring stages), every epilogue combination, 256 columns as two blocks, a tiling order."""
+    import os
+    from dualfusion import ops
+    shape, batch = [9, 48, 48], 2
+    filt = detgen.randn("lcw%d_%d" % (cin, cout), (27, cin, cout), 0.5 / np.sqrt(cin))
+    packed = ops.conv_pack_weights(T(filt, dev))
+    packed1 = ops.conv_pack_weights(T(filt[13:14].copy(), dev))
+    bias, scale, shift = (T(detgen.randn("lc%s%d" % (t, cout), (cout,), 0.2), dev) for t in "bsh")
+    old = os.environ.get("DF3D_OS_LC")
+
+    def both(fn):
+        os.environ["DF3D_OS_LC"] = "0"
+        a = fn()
+        os.environ["DF3D_OS_LC"] = "1"
+        b = fn()
+        return a, b
+    try:
+        for n_seeds, walk in ((1, 1), (1, 40), (2, 64), (3, 90), (8, 200), (40, 200)):
+            ind = detgen.clustered_voxels("lc%d_%d" % (n_seeds, walk), batch, shape, n_seeds=n_seeds, walk=walk)
+            ind_t = T(ind, dev)
+            feats = detgen.randn("lcf%d_%d_%d" % (cin, n_seeds, walk), (len(ind), cin))
+            fsplit = ops.split_rows(T(feats, dev))
+            for subm in (1, 0):
+                outids, nbr, _ = _hip_rulebook(ind_t, batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], subm)
+                n_out = outids.shape[0]
+                res = T(detgen.randn("lcr%d_%d" % (cout, n_out), (n_out, cout)), dev)
+                for kw in (dict(), dict(bias=bias, relu=True), dict(bias=bias, scale=scale, shift=shift, residual=res, relu=True)):
+                    (y0, s0), (y1, s1) = both(lambda: ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, **kw))
+                    assert torch.equal(y0, y1) and torch.equal(s0, s1), (n_out, subm, sorted(kw))
+                if subm:
+                    order = torch.randperm(n_out, device=dev, dtype=torch.int64).to(torch.int32)
+                    (y0, s0), (y1, s1) = both(lambda: ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, bias=bias,
+                                                                          order=order))
+                    assert torch.equal(y0, y1) and torch.equal(s0, s1)
+                    nb1 = nbr[13:14].contiguous()                                     # 1 x 1 x 1 "convolution": KB steps in all
+                    (y0, _), (y1, _) = both(lambda: ops.sparse_conv_split(fsplit, packed1, nb1, n_out, cin, cout, bias=bias))
+                    assert torch.equal(y0, y1)
+                    want = feats.astype(np.float64) @ filt[13].astype(np.float64) + bias.cpu().numpy()
+                    assert np.abs(y1.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-9) < 5e-5
+    finally:
+        if old is None:
+            os.environ.pop("DF3D_OS_LC", None)
+        else:
+            os.environ["DF3D_OS_LC"] = old
+
+
 def test_rulebook_empty_and_single(dev):
     from dualfusion import ops
     shape, batch = [5, 8, 8], 1
