@@ -135,6 +135,74 @@ __global__ __launch_bounds__(256) void conv_mark_kernel(const int32_t *__restric
   if (mask) atomicOr(&bits[cur], mask);
 }
 
+// Transposed convolution (geometry.h:88-142): input voxel `in` writes, through kernel index c, the output cell
+// in*stride - pad + c*dil.  One thread per (voxel, cz, cy), the cx taps merged per 64-cell word as above.
+__global__ __launch_bounds__(256) void conv_mark_transpose_kernel(const int32_t *__restrict__ ind, int n, ConvGeom cg,
+                                                                  long long out_vol,
+                                                                  unsigned long long *__restrict__ bits) {
+  const int KZY = cg.ks[0] * cg.ks[1];
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * KZY) return;
+  int i = (int)(t / KZY);
+  int kzy = (int)(t - (long long)i * KZY);
+  const int32_t *p = ind + (size_t)i * 4;
+  int kk[2] = {kzy / cg.ks[1], kzy % cg.ks[1]};
+  int o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    o[d] = p[1 + d] * cg.st[d] - cg.pad[d] + kk[d] * cg.dil[d];
+    if (o[d] < 0 || o[d] >= cg.out_shape[d]) return;
+  }
+  const long long row = (long long)p[0] * out_vol + ((long long)o[0] * cg.out_shape[1] + o[1]) * cg.out_shape[2];
+  long long cur = -1;
+  unsigned long long mask = 0ull;
+  for (int kx = 0; kx < cg.ks[2]; ++kx) {
+    int ox = p[3] * cg.st[2] - cg.pad[2] + kx * cg.dil[2];
+    if (ox < 0 || ox >= cg.out_shape[2]) continue;
+    long long flat = row + ox;
+    if ((flat >> 6) != cur) {
+      if (mask) atomicOr(&bits[cur], mask);
+      cur = flat >> 6;
+      mask = 0ull;
+    }
+    mask |= 1ull << (flat & 63);
+  }
+  if (mask) atomicOr(&bits[cur], mask);
+}
+
+// nbr[k][o] of a transposed convolution: the input cell (out + pad - c*dil) / stride when divisible (at most one per
+// kernel index, as for the forward convolution)
+__global__ __launch_bounds__(256) void neighbors_transpose_kernel(GridView g, const int32_t *__restrict__ perm,
+                                                                  const int32_t *__restrict__ out_ind, int n, ConvGeom cg,
+                                                                  int32_t *__restrict__ nbr) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * cg.K) return;
+  int k = (int)(t / n);
+  int o = (int)(t - (long long)k * n);
+  const int32_t *p = out_ind + (size_t)o * 4;
+  int c[3];
+  c[2] = k % cg.ks[2];
+  int kt = k / cg.ks[2];
+  c[1] = kt % cg.ks[1];
+  c[0] = kt / cg.ks[1];
+  int in[3];
+  bool ok = true;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int num = p[1 + d] + cg.pad[d] - c[d] * cg.dil[d];
+    if (num < 0 || (num % cg.st[d]) != 0) ok = false;
+    in[d] = num / cg.st[d];
+    if (in[d] >= g.shape[d]) ok = false;
+  }
+  int r = -1;
+  if (ok) {
+    long long flat = (long long)p[0] * g.vol + ((long long)in[0] * g.shape[1] + in[1]) * g.shape[2] + in[2];
+    r = grid_rank(g, flat);
+    if (r >= 0 && perm) r = perm[r];
+  }
+  nbr[t] = r;
+}
+
 // one thread per 64-cell word: emit the coordinates of its set bits at prefix[word]...
 __global__ __launch_bounds__(256) void grid_enumerate_kernel(GridView g, unsigned long long nwords,
                                                              int32_t *__restrict__ out_ind, int cap) {
@@ -329,6 +397,59 @@ extern "C" int df3d_conv_out_indices(const int32_t *indices, int n, int batch, c
   hipLaunchKernelGGL(grid_enumerate_kernel, dim3(cdiv((long long)h.nwords, 256)), dim3(256), 0, stream, g, h.nwords,
                      out_indices, out_cap);
   DF3D_HIP(hipMemcpyAsync(num_out, (char *)out_grid + h.off_total, sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_conv_transpose_out_indices(const int32_t *indices, int n, int batch, const int *in_shape,
+                                               const int *out_shape, const int *ksize, const int *stride,
+                                               const int *padding, const int *dilation, void *out_grid,
+                                               size_t out_grid_bytes, int32_t *out_indices, int out_cap,
+                                               int32_t *num_out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(indices && out_grid && out_indices && num_out, "conv_transpose_out_indices: null argument");
+  ConvGeom cg;
+  int K = fill_geom(cg, ksize, stride, padding, dilation, in_shape, out_shape);
+  DF3D_CHECK_ARG(K <= DF3D_MAX_KVOL, "conv_transpose_out_indices: kernel volume %d > %d", K, DF3D_MAX_KVOL);
+  for (int d = 0; d < 3; ++d) DF3D_CHECK_ARG(cg.dil[d] >= 1 && cg.st[d] >= 1, "conv_transpose_out_indices: bad stride / dilation");
+  GridHeader h = grid_layout(batch, out_shape);
+  if (out_grid_bytes < h.off_scratch + h.scratch_bytes) {
+    set_error("conv_transpose_out_indices: grid blob too small");
+    return DF3D_ENOMEM;
+  }
+  unsigned long long *bits = (unsigned long long *)((char *)out_grid + h.off_bits);
+  DF3D_HIP(hipMemsetAsync(bits, 0, (size_t)h.nwords * 8, stream));
+  long long out_vol = (long long)out_shape[0] * out_shape[1] * out_shape[2];
+  if (n > 0) {
+    long long total = (long long)n * cg.ks[0] * cg.ks[1];
+    hipLaunchKernelGGL(conv_mark_transpose_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, indices, n, cg, out_vol,
+                       bits);
+  }
+  int rc = grid_finish(out_grid, h, stream);
+  if (rc) return rc;
+  GridView g = grid_view(out_grid, h);
+  hipLaunchKernelGGL(grid_enumerate_kernel, dim3(cdiv((long long)h.nwords, 256)), dim3(256), 0, stream, g, h.nwords,
+                     out_indices, out_cap);
+  DF3D_HIP(hipMemcpyAsync(num_out, (char *)out_grid + h.off_total, sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_conv_transpose_neighbors(const void *in_grid, const int32_t *in_perm, const int32_t *out_indices,
+                                             int n_out, int batch, const int *in_shape, const int *ksize,
+                                             const int *stride, const int *padding, const int *dilation, int32_t *nbr,
+                                             void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(in_grid && out_indices && nbr, "conv_transpose_neighbors: null argument");
+  ConvGeom cg;
+  int K = fill_geom(cg, ksize, stride, padding, dilation, in_shape, nullptr);
+  DF3D_CHECK_ARG(K <= DF3D_MAX_KVOL, "conv_transpose_neighbors: kernel volume %d > %d", K, DF3D_MAX_KVOL);
+  if (n_out == 0) return DF3D_OK;
+  GridHeader h = grid_layout(batch, in_shape);
+  GridView g = grid_view(in_grid, h);
+  long long total = (long long)n_out * K;
+  hipLaunchKernelGGL(neighbors_transpose_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, g, in_perm, out_indices,
+                     n_out, cg, nbr);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

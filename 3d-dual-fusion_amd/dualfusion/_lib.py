@@ -38,6 +38,10 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p]),
     "df3d_conv_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_conv_transpose_out_indices": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p]),
+    "df3d_conv_transpose_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_nbr_to_pairs_workspace_bytes": (c_size_t, [c_int, c_int]),
     "df3d_nbr_to_pairs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_pairs_to_nbr": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

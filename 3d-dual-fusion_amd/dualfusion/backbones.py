@@ -196,7 +196,8 @@ from .registry import CONV_LAYERS  # noqa: E402
 
 for _n, _c in (("SubMConv3d", spconv.SubMConv3d), ("SparseConv3d", spconv.SparseConv3d),
                ("SubMConv2d", spconv.SubMConv2d), ("SparseConv2d", spconv.SparseConv2d),
-               ("SparseInverseConv3d", spconv.SparseInverseConv3d)):
+               ("SparseInverseConv3d", spconv.SparseInverseConv3d),
+               ("SparseConvTranspose3d", spconv.SparseConvTranspose3d), ("SparseConvTranspose2d", spconv.SparseConvTranspose2d)):
     if CONV_LAYERS.get(_n) is None:
         CONV_LAYERS.register_module(_c, name=_n)
 

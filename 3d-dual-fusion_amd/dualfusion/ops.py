@@ -127,17 +127,18 @@ def subm_neighbors(grid, indices, ksize, dilation=(1, 1, 1)):
     return nbr
 
 
-def conv_out_indices(indices, batch, in_shape, out_shape, ksize, stride, padding, dilation=(1, 1, 1)):
-    """-> (out_indices [n_out,4] sorted by flat index, GridDirectory of the outputs).  One D2H read (n_out)."""
+def conv_out_indices(indices, batch, in_shape, out_shape, ksize, stride, padding, dilation=(1, 1, 1), transpose=False):
+    """-> (out_indices [n_out,4] sorted by flat index, GridDirectory of the outputs).  One D2H read (n_out).
+    transpose: the output set of a transposed convolution (every input writes in*stride - pad + c*dil)."""
     lib = _lib.load()
     _chk(indices, torch.int32, "indices")
     n = indices.shape[0]
     K = int(ksize[0] * ksize[1] * ksize[2])
     vol_out = int(batch) * int(out_shape[0]) * int(out_shape[1]) * int(out_shape[2])
-    # per axis an input feeds at most ceil(k/s) outputs
+    # per axis an input feeds at most ceil(k/s) outputs (a transposed convolution: every kernel index)
     fan = 1
     for d in range(3):
-        fan *= -(-int(ksize[d]) // int(stride[d]))
+        fan *= int(ksize[d]) if transpose else -(-int(ksize[d]) // int(stride[d]))
     cap = max(min(n * min(fan, K), vol_out), 1)
     osh_p, k0 = _lib.int3(out_shape)
     nbytes = lib.df3d_grid_bytes(int(batch), osh_p)
@@ -149,8 +150,9 @@ def conv_out_indices(indices, batch, in_shape, out_shape, ksize, stride, padding
     st_p, k3 = _lib.int3(stride)
     pd_p, k4 = _lib.int3(padding)
     dl_p, k5 = _lib.int3(dilation)
-    rc = lib.df3d_conv_out_indices(_ptr(indices), n, int(batch), ish_p, osh_p, ks_p, st_p, pd_p, dl_p, _ptr(blob),
-                                   nbytes, _ptr(out_ind), cap, _ptr(count), _stream())
+    fn = lib.df3d_conv_transpose_out_indices if transpose else lib.df3d_conv_out_indices
+    rc = fn(_ptr(indices), n, int(batch), ish_p, osh_p, ks_p, st_p, pd_p, dl_p, _ptr(blob), nbytes, _ptr(out_ind), cap,
+            _ptr(count), _stream())
     _lib.check(rc, "df3d_conv_out_indices")
     n_out = int(count.item())
     if n_out > cap:
@@ -158,7 +160,7 @@ def conv_out_indices(indices, batch, in_shape, out_shape, ksize, stride, padding
     return out_ind[:n_out], GridDirectory(blob, None, batch, out_shape)
 
 
-def conv_neighbors(in_grid, out_indices, ksize, stride, padding, dilation=(1, 1, 1)):
+def conv_neighbors(in_grid, out_indices, ksize, stride, padding, dilation=(1, 1, 1), transpose=False):
     lib = _lib.load()
     n_out = out_indices.shape[0]
     K = int(ksize[0] * ksize[1] * ksize[2])
@@ -168,8 +170,9 @@ def conv_neighbors(in_grid, out_indices, ksize, stride, padding, dilation=(1, 1,
     st_p, k3 = _lib.int3(stride)
     pd_p, k4 = _lib.int3(padding)
     dl_p, k5 = _lib.int3(dilation)
-    rc = lib.df3d_conv_neighbors(_ptr(in_grid.blob), _ptr(in_grid.perm), _ptr(out_indices), n_out, in_grid.batch,
-                                 ish_p, ks_p, st_p, pd_p, dl_p, _ptr(nbr), _stream())
+    fn = lib.df3d_conv_transpose_neighbors if transpose else lib.df3d_conv_neighbors
+    rc = fn(_ptr(in_grid.blob), _ptr(in_grid.perm), _ptr(out_indices), n_out, in_grid.batch, ish_p, ks_p, st_p, pd_p, dl_p,
+            _ptr(nbr), _stream())
     _lib.check(rc, "df3d_conv_neighbors")
     return nbr
 

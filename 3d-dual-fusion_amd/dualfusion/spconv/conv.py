@@ -120,8 +120,6 @@ class SparseConvolution(SparseModule):
             return inv
         if self.indice_key is not None and datas is not None:
             return datas
-        if self.transposed:
-            raise Df3dError("transposed sparse convolution is not implemented on the MI355X path")
         # SubM convs without an indice_key (every BasicBlock conv of the TransFusion encoder,
         # sparse_block.py:85-100) rebuild an identical rulebook in the reference; the neighbour table
         # only depends on the index set and the kernel geometry, so it is shared here.
@@ -135,7 +133,8 @@ class SparseConvolution(SparseModule):
         directory = input.directory()
         outids, nbr, out_shape, out_dir = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape,
                                                              self.kernel_size, self.stride, self.padding,
-                                                             self.dilation, self.subm, directory=directory)
+                                                             self.dilation, self.subm, directory=directory,
+                                                             transpose=self.transposed, out_padding=self.output_padding)
         rb = Rulebook(outids, input.indices, nbr, input.spatial_shape, out_shape, out_rows_sorted=not self.subm)
         if out_dir is not None and not self.subm:
             input._directories.put(outids, out_dir)
@@ -271,6 +270,23 @@ class SparseConv3d(SparseConvolution):
                  indice_key=None):
         super(SparseConv3d, self).__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
                                            groups, bias, indice_key=indice_key)
+
+
+class SparseConvTranspose2d(SparseConvolution):
+    """conv.py:262-285 of the vendored spconv."""
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SparseConvTranspose2d, self).__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                                    groups, bias, transposed=True, indice_key=indice_key)
+
+
+class SparseConvTranspose3d(SparseConvolution):
+    """conv.py:287-310 of the vendored spconv: every input voxel writes the cells in*stride - pad + c*dilation; the
+    same gather-GEMM kernels on the transposed rulebook."""
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SparseConvTranspose3d, self).__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                                    groups, bias, transposed=True, indice_key=indice_key)
 
 
 class SubMConv2d(SparseConvolution):

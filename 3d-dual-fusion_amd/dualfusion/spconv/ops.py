@@ -35,8 +35,10 @@ def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, o
     return output_size
 
 
-def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm, directory=None):
-    """-> (outids, nbr [K,n_out], out_shape, out_directory or None).  Kernel-facing form."""
+def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm, directory=None,
+                   transpose=False, out_padding=(0, 0, 0)):
+    """-> (outids, nbr [K,n_out], out_shape, out_directory or None).  Kernel-facing form.  transpose: the rulebook of a
+    transposed convolution (ops.py:72-94: deconv output size; geometry.h:88-142)."""
     indices = indices.contiguous()
     if len(spatial_shape) != 3:
         raise Df3dError("only 3-D sparse convolutions are implemented on the MI355X path")
@@ -45,10 +47,13 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     if subm:
         nbr = _ops.subm_neighbors(directory, indices, ksize, dilation)
         return indices, nbr, list(spatial_shape), directory
-    out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
+    if transpose:
+        out_shape = get_deconv_output_size(spatial_shape, ksize, stride, padding, dilation, list(out_padding))
+    else:
+        out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
     outids, out_dir = _ops.conv_out_indices(indices, batch_size, spatial_shape, out_shape, ksize, stride, padding,
-                                            dilation)
-    nbr = _ops.conv_neighbors(directory, outids, ksize, stride, padding, dilation)
+                                            dilation, transpose=transpose)
+    nbr = _ops.conv_neighbors(directory, outids, ksize, stride, padding, dilation, transpose=transpose)
     return outids, nbr, out_shape, out_dir
 
 
@@ -57,9 +62,9 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     ndim = indices.shape[1] - 1
     lst = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
     ksize, stride, padding, dilation = lst(ksize), lst(stride), lst(padding), lst(dilation)
-    if transpose:
-        raise Df3dError("transposed sparse convolution is not on the 3D-DF hot path (unused by its backbones)")
-    outids, nbr, _, _ = build_rulebook(indices.int(), batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+    out_padding = lst(out_padding)
+    outids, nbr, _, _ = build_rulebook(indices.int(), batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
+                                       transpose=bool(transpose), out_padding=out_padding)
     pairs, num = _ops.nbr_to_pairs(nbr, indices.shape[0])
     return outids, pairs, num
 

@@ -112,6 +112,17 @@ int df3d_conv_neighbors(const void *in_grid, const int32_t *in_perm, const int32
                         int n_out, int batch, const int *in_shape_host, const int *ksize_host,
                         const int *stride_host, const int *padding_host, const int *dilation_host,
                         int32_t *nbr, void *stream);
+/* Transposed convolution (TF/mmdet3d/ops/spconv/conv.py:262-455 SparseConvTranspose2d/3d, get_indice_pairs(transpose=True):
+ * ops.py:72-94 -> spconv_ops.h:27-141 -> geometry.h:88-142,194-245): input voxel `in` writes output cell
+ * in*stride - pad + c*dil through kernel index c; out_shape = (in-1)*stride - 2*pad + k + output_padding.  Same
+ * contracts as df3d_conv_out_indices / df3d_conv_neighbors (outputs sorted by flat index, nbr [K, n_out]). */
+int df3d_conv_transpose_out_indices(const int32_t *indices, int n, int batch, const int *in_shape, const int *out_shape,
+                                    const int *ksize, const int *stride, const int *padding, const int *dilation,
+                                    void *out_grid, size_t out_grid_bytes, int32_t *out_indices, int out_cap,
+                                    int32_t *num_out, void *stream);
+int df3d_conv_transpose_neighbors(const void *in_grid, const int32_t *in_perm, const int32_t *out_indices, int n_out,
+                                  int batch, const int *in_shape, const int *ksize, const int *stride,
+                                  const int *padding, const int *dilation, int32_t *nbr, void *stream);
 size_t df3d_nbr_to_pairs_workspace_bytes(int kvol, int n_out);
 int df3d_nbr_to_pairs(const int32_t *nbr, int kvol, int n_out, int n_in,
                       int32_t *indice_pairs, int32_t *indice_num,

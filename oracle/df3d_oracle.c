@@ -156,6 +156,82 @@ static int get_valid_out_pos(const int *in, const int *ks, const int *st, const 
   return cnt;
 }
 
+/* getValidOutPosTranspose restates geometry.h:88-142 (transposed convolution): per axis lowers = in*s - p,
+ * uppers = lowers + (k-1)*d; enumerate val = uppers - counter*d with the LAST axis fastest; kernel offset =
+ * sum_j m_j*(val_j - lowers_j)/d_j, i.e. kernel index c writes the output cell in*s - p + c*d. */
+static int get_valid_out_pos_transpose(const int *in, const int *ks, const int *st, const int *pad,
+                                       const int *dil, const int *oshape, int *out) {
+  int lowers[3], uppers[3], counter[3], csize[3];
+  int npts = 1, cnt = 0;
+  for (int i = 0; i < 3; ++i) {
+    lowers[i] = in[i] * st[i] - pad[i];
+    uppers[i] = lowers[i] + (ks[i] - 1) * dil[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    csize[i] = (uppers[i] - lowers[i]) / dil[i] + 1;
+    npts *= csize[i];
+    counter[i] = 0;
+  }
+  for (int i = 0; i < npts; ++i) {
+    int valid = 1, m = 1, offset = 0;
+    for (int j = 2; j >= 0; --j) {
+      int val = uppers[j] - counter[j] * dil[j];
+      out[cnt * 4 + j] = val;
+      if (val < 0 || val > oshape[j] - 1) valid = 0;
+      offset += m * (val - lowers[j]) / dil[j];
+      m *= ks[j];
+    }
+    out[cnt * 4 + 3] = offset;
+    if (valid) ++cnt;
+    counter[2] += 1;
+    for (int c = 2; c >= 0; --c) {
+      if (counter[c] == csize[c] && c > 0) {
+        counter[c - 1] += 1;
+        counter[c] = 0;
+      }
+    }
+  }
+  return cnt;
+}
+
+/* getIndicePairsDeConv (geometry.h:194-245): the loop of getIndicePairsConv over getValidOutPosTranspose.
+ * out_shape = (in-1)*s - 2p + k + output_padding (ops.py:33-44).  Same conventions and order as below. */
+int orc_get_indice_pairs_transpose(const int32_t *indices, int N, int batch, const int *out_shape,
+                                   const int *ksize, const int *stride, const int *padding,
+                                   const int *dilation, int32_t *outids, int32_t *pairs, int32_t *num) {
+  int K = ksize[0] * ksize[1] * ksize[2];
+  size_t vol = (size_t)out_shape[0] * out_shape[1] * out_shape[2];
+  int32_t *grid = (int32_t *)malloc(vol * batch * sizeof(int32_t));
+  if (!grid) return -1;
+  memset(grid, 0xff, vol * batch * sizeof(int32_t));
+  for (size_t i = 0; i < (size_t)K * 2 * N; ++i) pairs[i] = -1;
+  for (int k = 0; k < K; ++k) num[k] = 0;
+  int *vp = (int *)malloc(sizeof(int) * K * 4);
+  int numAct = 0;
+  for (int j = 0; j < N; ++j) {
+    const int32_t *p = indices + (size_t)j * 4;
+    int nv = get_valid_out_pos_transpose(p + 1, ksize, stride, padding, dilation, out_shape, vp);
+    for (int i = 0; i < nv; ++i) {
+      const int *q = vp + i * 4;
+      int off = q[3];
+      size_t idx = ((size_t)q[0] * out_shape[1] + q[1]) * out_shape[2] + q[2] + vol * p[0];
+      if (grid[idx] == -1) {
+        outids[(size_t)numAct * 4 + 0] = p[0];
+        outids[(size_t)numAct * 4 + 1] = q[0];
+        outids[(size_t)numAct * 4 + 2] = q[1];
+        outids[(size_t)numAct * 4 + 3] = q[2];
+        grid[idx] = numAct++;
+      }
+      pairs[((size_t)off * 2 + 0) * N + num[off]] = j;
+      pairs[((size_t)off * 2 + 1) * N + num[off]] = grid[idx];
+      num[off] += 1;
+    }
+  }
+  free(vp);
+  free(grid);
+  return numAct;
+}
+
 /* getIndicePairsSubM (geometry.h:247-297) / getIndicePairsConv (geometry.h:144-192),
  * with the host-side conventions of getIndicePair<3> (spconv_ops.h:27-141):
  * subM forces stride 1, pad k/2 (:76-79); indicePairs [K,2,N] prefilled -1,

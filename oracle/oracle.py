@@ -82,6 +82,31 @@ def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
             for i in range(len(input_size))]
 
 
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    """TF/mmdet3d/ops/spconv/ops.py:33-44."""
+    return [(input_size[i] - 1) * stride[i] - 2 * padding[i] + kernel_size[i] + output_padding[i]
+            for i in range(len(input_size))]
+
+
+def get_indice_pairs_transpose(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, output_padding=(0, 0, 0)):
+    """get_indice_pairs(..., transpose=True) (ops.py:46-94 -> spconv_ops.h:27-141 -> geometry.h:88-142,194-245, CPU path).
+    Returns (outids, indice_pairs [K,2,N], indice_num [K], out_shape) in the reference CPU order."""
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    N = indices.shape[0]
+    K = int(np.prod(ksize))
+    out_shape = get_deconv_output_size(spatial_shape, ksize, stride, padding, dilation, list(output_padding))
+    outids = np.zeros((max(N * K, 1), 4), np.int32)
+    pairs = np.empty((K, 2, max(N, 1)), np.int32)
+    num = np.zeros((K,), np.int32)
+    arr = lambda v: np.asarray(v, np.int32)
+    os_, ks_, st_, pd_, dl_ = arr(out_shape), arr(ksize), arr(stride), arr(padding), arr(dilation)
+    n_out = lib().orc_get_indice_pairs_transpose(_p(indices, _i32), N, int(batch_size), _p(os_, _i32), _p(ks_, _i32),
+                                                 _p(st_, _i32), _p(pd_, _i32), _p(dl_, _i32), _p(outids, _i32),
+                                                 _p(pairs, _i32), _p(num, _i32))
+    assert n_out >= 0
+    return outids[:n_out].copy(), pairs[:, :, :N], num, out_shape
+
+
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm):
     """TF/mmdet3d/ops/spconv/ops.py:46-94 -> spconv_ops.h:27-141 -> geometry.h:144-297 (CPU path).
     Returns (outids [N_out,4], indice_pairs [K,2,N] (-1 padded), indice_num [K], out_shape),

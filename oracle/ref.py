@@ -70,6 +70,21 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding,
     return outids.numpy(), pairs.numpy(), num.numpy(), out_shape
 
 
+def get_indice_pairs_transpose(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, output_padding=(0, 0, 0)):
+    """sparse_conv_ext.get_indice_pairs_3d with transpose = 1 (ops.py:72-94: deconv output size, out_padding)."""
+    import numpy as np
+    import torch
+    from . import oracle as _o  # only for get_deconv_output_size (pure arithmetic)
+    m = load("sparse_conv_ext")
+    ind = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32))
+    out_shape = _o.get_deconv_output_size(spatial_shape, ksize, stride, padding, dilation, list(output_padding))
+    outids, pairs, num = m.get_indice_pairs_3d(ind, int(batch_size), [int(v) for v in out_shape],
+                                               [int(v) for v in spatial_shape], [int(v) for v in ksize],
+                                               [int(v) for v in stride], [int(v) for v in padding],
+                                               [int(v) for v in dilation], [int(v) for v in output_padding], 0, 1)
+    return outids.numpy(), pairs.numpy(), num.numpy(), out_shape
+
+
 def indice_conv(features, filters, pairs, num, num_act_out, subm, inverse=False):
     """sparse_conv_ext.indice_conv_fp32 (TF/.../spconv_ops.h:260-361)."""
     import numpy as np

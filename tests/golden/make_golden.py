@@ -927,6 +927,31 @@ def gen_pool():
     save("pool.npz", **out)
 
 
+CONVT_CASES = (("k3s2p1", [3, 3, 3], [2, 2, 2], [1, 1, 1], [0, 0, 0]), ("k2s2", [2, 2, 2], [2, 2, 2], [0, 0, 0], [0, 0, 0]),
+               ("k3s2p1op1", [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1]), ("k311s211", [3, 1, 1], [2, 1, 1], [0, 0, 0], [0, 0, 0]))
+
+
+def convt_case():
+    ind = detgen.clustered_voxels("convt", CONV_BWD_BATCH, CONV_BWD_SHAPE, n_seeds=3, walk=40)
+    return ind, detgen.randn("convt_f", (len(ind), 16))
+
+
+def gen_conv_transpose():
+    """Transposed sparse convolution of the reference's compiled CPU code (oracle/_ref/sparse_conv_ext.so):
+    get_indice_pairs_3d(transpose = 1) (ops.py:72-94, geometry.h:88-142,194-245) and indice_conv_fp32 on that rulebook
+    (what SparseConvTranspose3d.forward runs, conv.py:114-204) for four geometries incl. output_padding."""
+    ind, f = convt_case()
+    out = {}
+    for tag, ks, st, pd, op in CONVT_CASES:
+        outids, pairs, num, oshape = ref.get_indice_pairs_transpose(ind, CONV_BWD_BATCH, CONV_BWD_SHAPE, ks, st, pd, [1, 1, 1], op)
+        w = detgen.randn("convt_w_" + tag, tuple(ks) + (16, 16), 0.2)
+        y = ref.indice_conv(f, w, pairs, num, len(outids), 0)
+        order = np.lexsort(outids.T[::-1])                      # canonical out-voxel order (SURVEY section 8c)
+        out.update({"outids_" + tag: outids[order], "y_" + tag: y[order], "num_" + tag: num,
+                    "oshape_" + tag: np.asarray(oshape, np.int32)})
+    save("conv_transpose.npz", **out)
+
+
 def gen_iou3d():
     """Rotated BEV IoU from the reference's own CPU path (oracle/_ref/iou3d_nms_cuda.so: boxes_iou_bev_cpu,
     CP/det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:224-252) on detgen boxes, and the greedy keep list that the reference's
@@ -1382,13 +1407,15 @@ def gen_vr_fusion():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "headloss", "conv_bwd", "pool"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "headloss", "conv_bwd", "pool", "conv_transpose"]
     if "iou3d" in which:
         gen_iou3d()
     if "conv_bwd" in which:
         gen_conv_bwd()
     if "pool" in which:
         gen_pool()
+    if "conv_transpose" in which:
+        gen_conv_transpose()
     if "centerhead" in which:
         gen_centerhead()
     if "tfhead" in which:

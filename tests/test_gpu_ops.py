@@ -808,6 +808,39 @@ def test_dynamic_voxelize_golden_and_oracle(golden, dev):
     assert ops.dynamic_voxelize(torch.zeros((0, 4), device=dev), POOL_VS, POOL_RANGE).shape == (0, 3)
 
 
+def test_sparse_conv_transpose_golden(golden, dev):
+    """SparseConvTranspose3d / get_indice_pairs(transpose=True) against the reference's compiled CPU code
+    (tests/golden/conv_transpose.npz): output sets bit for bit (sorted = canonical order), per-offset pair counts,
+    features <= 1e-3 (measured ~1e-6); the reference-format rulebook through spconv.ops too; autograd runs."""
+    from dualfusion import spconv
+    from make_golden import CONV_BWD_BATCH, CONV_BWD_SHAPE, CONVT_CASES, convt_case
+    g = golden("conv_transpose.npz")
+    ind, f = convt_case()
+    for tag, ks, st, pd, op in CONVT_CASES:
+        m = spconv.SparseConvTranspose3d(16, 16, ks, stride=st, padding=pd, bias=False).to(dev).eval()
+        m.output_padding = list(op)
+        w = detgen.randn("convt_w_" + tag, tuple(ks) + (16, 16), 0.2)
+        with torch.no_grad():
+            m.weight.copy_(T(w, dev))
+        x = spconv.SparseConvTensor(T(f, dev), T(ind, dev), CONV_BWD_SHAPE, CONV_BWD_BATCH)
+        with torch.no_grad():
+            y = m(x)
+        assert list(y.spatial_shape) == list(g["oshape_" + tag])
+        assert np.array_equal(y.indices.cpu().numpy(), g["outids_" + tag])
+        ref_y = g["y_" + tag]
+        assert np.abs(y.features.cpu().numpy() - ref_y).max() <= 1e-3 * np.abs(ref_y).max()
+        outids, pairs, num = spconv.ops.get_indice_pairs(T(ind, dev), CONV_BWD_BATCH, CONV_BWD_SHAPE, ks, st, pd, 1, list(op),
+                                                         subm=False, transpose=True)
+        assert np.array_equal(outids.cpu().numpy(), g["outids_" + tag]) and np.array_equal(num.cpu().numpy(), g["num_" + tag])
+        y2 = spconv.ops.indice_conv(T(f, dev), T(w, dev), pairs, num, outids.shape[0])
+        assert np.abs(y2.cpu().numpy() - ref_y).max() <= 1e-3 * np.abs(ref_y).max()
+    m.train()
+    xf = T(f, dev).requires_grad_(True)
+    out = m(spconv.SparseConvTensor(xf, T(ind, dev), CONV_BWD_SHAPE, CONV_BWD_BATCH))
+    out.features.square().sum().backward()
+    assert torch.isfinite(xf.grad).all() and float(xf.grad.abs().sum()) > 0 and float(m.weight.grad.abs().sum()) > 0
+
+
 def test_sparse_conv2d_and_pool2d_vs_dense_torch(dev):
     """SparseConv2d / SubMConv2d / SparseMaxPool2d (TF/mmdet3d/ops/spconv/conv.py:207-260, pool.py:73-78) run on the
     3-D kernels as a one-slice volume; values against torch's dense conv2d / max_pool2d at the active sites."""

@@ -398,6 +398,37 @@ def test_maxpool_inverse_conv_dynamic_voxelize_oracle_vs_reference_golden(golden
     assert np.array_equal(dyn, g["dyn"]) and (dyn[:, 0] == -1).sum() > 100 and (dyn[:, 0] >= 0).sum() > 1000
 
 
+def test_transposed_conv_oracle_vs_reference_golden(golden):
+    """get_indice_pairs(transpose=True) + indice_conv of the oracle against the reference's compiled CPU code on four
+    geometries (incl. output_padding): output sets and pair counts bit for bit, features <= 2e-5."""
+    from make_golden import CONV_BWD_BATCH, CONV_BWD_SHAPE, CONVT_CASES, convt_case
+    g = golden("conv_transpose.npz")
+    ind, f = convt_case()
+    for tag, ks, st, pd, op in CONVT_CASES:
+        outids, pairs, num, oshape = orc.get_indice_pairs_transpose(ind, CONV_BWD_BATCH, CONV_BWD_SHAPE, ks, st, pd, [1, 1, 1], op)
+        assert list(oshape) == list(g["oshape_" + tag])
+        order = np.lexsort(outids.T[::-1])
+        assert np.array_equal(outids[order], g["outids_" + tag]) and np.array_equal(num, g["num_" + tag])
+        assert int(num.sum()) == len(ind) * int(np.prod(ks)) or tag != "k2s2"       # stride = kernel: every input writes all taps
+        w = detgen.randn("convt_w_" + tag, tuple(ks) + (16, 16), 0.2)
+        y = orc.indice_conv(f, w, pairs, num, len(outids), 0)
+        ref_y = g["y_" + tag]
+        assert np.abs(y[order] - ref_y).max() <= 2e-5 * np.abs(ref_y).max()
+
+
+@needs_ref
+def test_transposed_rulebook_oracle_vs_ref_build_fresh():
+    ind = detgen.clustered_voxels("convt_fresh", 2, [6, 14, 11], n_seeds=5, walk=90)
+    for ks, st, pd, op in (([3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 0, 1]), ([2, 3, 2], [2, 1, 2], [0, 1, 0], [0, 0, 0]),
+                           ([3, 3, 3], [1, 1, 1], [1, 1, 1], [0, 0, 0])):
+        o = orc.get_indice_pairs_transpose(ind, 2, [6, 14, 11], ks, st, pd, [1, 1, 1], op)
+        r = ref.get_indice_pairs_transpose(ind, 2, [6, 14, 11], ks, st, pd, [1, 1, 1], op)
+        n = len(o[0])
+        assert np.array_equal(o[0], r[0][:n]) and np.array_equal(o[2], r[2]) and list(o[3]) == list(r[3])
+        for k in range(len(o[2])):
+            assert np.array_equal(o[1][k, :, :o[2][k]], r[1][k, :, :r[2][k]])
+
+
 @needs_ref
 def test_maxpool_dynamic_voxelize_oracle_vs_ref_build_fresh():
     ind = detgen.clustered_voxels("pool_fresh", 2, [9, 18, 16], n_seeds=5, walk=150)
