@@ -615,21 +615,39 @@ __global__ __launch_bounds__(256) void spconv_small_kernel(ConvArgs a) {
   constexpr int RPB = 256 / LPR;                  // rows per workgroup pass
   constexpr int CINP = CIN <= 8 ? 8 : 16;         // the padded channel count the MFMA kernel worked on
   constexpr int KS = CINP / 4;
-  extern __shared__ float Wl[];                   // [K][CIN][COUT]
+  constexpr int WSTR = CIN * COUT + 32;           // floats between two offsets' filters: rows that stand on different
+                                                  // offsets read different bank halves
+  extern __shared__ float Wl[];                   // [K][WSTR] filters, then [RPB][K] compacted (offset, input row) lists
   const int tid = threadIdx.x;
-  for (int e = tid; e < a.K * CIN * COUT / 4; e += 256) ((f32x4 *)Wl)[e] = ((const f32x4 *)a.w)[e];
+  for (int e = tid; e < a.K * CIN * COUT / 4; e += 256) {
+    const int k = e / (CIN * COUT / 4), r = e - k * (CIN * COUT / 4);
+    *(f32x4 *)(Wl + (size_t)k * WSTR + r * 4) = ((const f32x4 *)a.w)[e];
+  }
+  int *lists = (int *)(Wl + (size_t)a.K * WSTR);
   __syncthreads();
-  const int c4 = (tid % LPR) * 4;
+  const int c4 = (tid % LPR) * 4, rl = tid / LPR;
+  int *mine = lists + rl * DF3D_MAX_KVOL;
   // persistent workgroups: the filter bank is fetched once per workgroup, not once per 64 rows
-  for (int row = blockIdx.x * RPB + tid / LPR; row < a.n_out; row += gridDim.x * RPB) {
+  for (int row = blockIdx.x * RPB + rl; row < a.n_out; row += gridDim.x * RPB) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the row's present neighbours, compacted in offset order (every lane of the row computes the same list, lane 0
+    // writes it): the loop below then runs max-over-the-wave(list length) times, not |union of the rows' offsets| times --
+    // a stride-2 layer has 2 of 27 offsets per row, and 8-16 rows share a wave
     int idx[DF3D_MAX_KVOL];
 #pragma unroll
     for (int k = 0; k < DF3D_MAX_KVOL; ++k) idx[k] = k < a.K ? a.nbr[(size_t)k * a.n_out + row] : -1;
+    int cnt = 0;
 #pragma unroll
     for (int k = 0; k < DF3D_MAX_KVOL; ++k) {
-      if (idx[k] < 0) continue;
-      const float *f = a.feat + (size_t)idx[k] * CIN;
+      if (idx[k] >= 0) {
+        if (c4 == 0) mine[cnt] = idx[k] | (k << 26);
+        ++cnt;
+      }
+    }
+    for (int j = 0; j < cnt; ++j) {
+      const int pk = mine[j];                     // written by this row's lane 0 of the same wave, in program order
+      const int k = (unsigned)pk >> 26;
+      const float *f = a.feat + (size_t)(pk & 0x3ffffff) * CIN;
       float x[CINP];
       if constexpr (CIN % 4 == 0) {
 #pragma unroll
@@ -641,12 +659,12 @@ __global__ __launch_bounds__(256) void spconv_small_kernel(ConvArgs a) {
 #pragma unroll
         for (int ci = 0; ci < CINP; ++ci) x[ci] = ci < CIN ? f[ci] : 0.f;
       }
-      const float *wk = Wl + (size_t)k * CIN * COUT + c4;
+      const float *wk = Wl + (size_t)k * WSTR + c4;
 #pragma unroll
-      for (int j = 0; j < KS; ++j)
+      for (int jj = 0; jj < KS; ++jj)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int ci = g * KS + j;
+          const int ci = g * KS + jj;
           if (ci >= CIN) continue;
           const f32x4 w = *(const f32x4 *)(wk + ci * COUT);
           acc[0] = fmaf(x[ci], w[0], acc[0]);
@@ -682,11 +700,12 @@ static int num_cu_small() {
 
 template <int CIN, int COUT>
 static int launch_small(const ConvArgs &a, hipStream_t stream) {
-  const size_t lds = (size_t)a.K * CIN * COUT * 4;
+  constexpr int RPB0 = 256 / (COUT / 4);
+  const size_t lds = (size_t)a.K * (CIN * COUT + 32) * 4 + (size_t)RPB0 * DF3D_MAX_KVOL * 4;
   static bool configured = false;
   if (!configured && lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)spconv_small_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(DF3D_MAX_KVOL * CIN * COUT * 4));
+                                       (int)(DF3D_MAX_KVOL * (CIN * COUT + 32) * 4 + RPB0 * DF3D_MAX_KVOL * 4));
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
       return DF3D_EHIP;
@@ -707,6 +726,7 @@ static int dispatch_small(const ConvArgs &a, hipStream_t stream) {
   if (a.cin == 16 && a.cout == 16) return launch_small<16, 16>(a, stream);
   if (a.cin == 5 && a.cout == 16) return launch_small<5, 16>(a, stream);
   if (a.cin == 4 && a.cout == 16) return launch_small<4, 16>(a, stream);
+  if (a.cin == 16 && a.cout == 32) return launch_small<16, 32>(a, stream);
   return 0;
 }
 
