@@ -89,13 +89,7 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
   hipStream_t gstream = stream;
   size_t next_event = 0;
   if (two_streams) {
-    if (!g_geo_stream) {
-      // highest priority: the rulebook kernels are tiny and latency-bound, the convolutions of the NEXT stage wait for them,
-      // and beside the convolutions of the current stage they would otherwise get the left-over CUs
-      int lo = 0, hi = 0;
-      DF3D_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      DF3D_HIP(hipStreamCreateWithPriority(&g_geo_stream, hipStreamNonBlocking, hi));
-    }
+    if (!g_geo_stream) DF3D_HIP(hipStreamCreateWithFlags(&g_geo_stream, hipStreamNonBlocking));
     gstream = g_geo_stream;
     hipEvent_t e = order_event(next_event++);
     DF3D_CHECK_ARG(e != nullptr, "backbone_run: cannot create an event");
