@@ -155,14 +155,18 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
 // registers without spilling (the 1024-thread kernel has 128 VGPRs per thread).  The reference's result depends on
 // its block size through the tie rule ("equal distance: lower thread id wins", thread id = k mod 1024); every
 // physical thread therefore plays two virtual threads and the reduction compares VIRTUAL ids (k & (VT - 1)).
+// One iteration = distances (packed fp32), the thread's arg-max as a TREE over its points, the wave's arg-max by DPP
+// (no LDS traffic), ONE barrier, and every thread reducing the eight wave results itself (round 2; before: a serial
+// compare chain over 48 points, 18 ds_bpermutes, a serial reduction by thread 0 between two barriers: 4.1 us per
+// iteration at 24k points).
 template <int PT>
 __global__ __launch_bounds__(512) void fps_kernel_half(const float *__restrict__ xyz, int N, int m, int VT,
                                                        int32_t *__restrict__ idx) {
   typedef float f2 __attribute__((ext_vector_type(2)));
   static_assert(PT % 4 == 0, "points are processed in same-parity pairs");
-  __shared__ float s_v[8];
-  __shared__ int s_t[8], s_k[8];
-  __shared__ int s_old;
+  constexpr int NQ = PT / 4;
+  __shared__ float s_v[2][8];
+  __shared__ int s_t[2][8], s_k[2][8];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const float *p = xyz + (size_t)b * N * 3;
@@ -170,16 +174,17 @@ __global__ __launch_bounds__(512) void fps_kernel_half(const float *__restrict__
   // point i of this thread is k = tid + 512 i; its virtual thread (the reference's 1024-thread block) is tid for even i
   // and tid + 512 for odd i.  Pairs (i, i + 2) share the parity: [parity e][pair q] <-> i = 4q + e, 4q + e + 2.
   // Two points per packed instruction (v_pk_add / v_pk_mul / v_pk_fma_f32).
-  f2 temp[2][PT / 4], px[2][PT / 4], py[2][PT / 4], pz[2][PT / 4];
+  f2 temp[2][NQ], px[2][NQ], py[2][NQ], pz[2][NQ];
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int q = 0; q < PT / 4; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = tid + (4 * q + e + 2 * h) * 512;
         const int kk = k < N ? k : N - 1;
-        temp[e][q][h] = 1e10f;
+        // a slot past the end never wins: its running minimum starts (and stays) below every real distance
+        temp[e][q][h] = k < N ? 1e10f : -1.f;
         px[e][q][h] = p[kk * 3];
         py[e][q][h] = p[kk * 3 + 1];
         pz[e][q][h] = p[kk * 3 + 2];
@@ -187,59 +192,81 @@ __global__ __launch_bounds__(512) void fps_kernel_half(const float *__restrict__
   if (tid == 0 && m > 0) o[0] = 0;
   float x1 = p[0], y1 = p[1], z1 = p[2];
   const int vmask = VT - 1;
+  // wave-level all-reduce steps that stay in the VALU: xor 1, xor 2 inside a quad, then mirrors inside 8 and 16 lanes
+  // (any pairing works: `better` is a total order)
+#define FPS_DPP_STEP(CTRL)                                                                            \
+  do {                                                                                                \
+    Best ot;                                                                                          \
+    ot.v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, me.v), CTRL, 0xf, 0xf, false)); \
+    ot.tid = __builtin_amdgcn_update_dpp(0, me.tid, CTRL, 0xf, 0xf, false);                           \
+    ot.k = __builtin_amdgcn_update_dpp(0, me.k, CTRL, 0xf, 0xf, false);                               \
+    me = better(me, ot);                                                                              \
+  } while (0)
   for (int j = 1; j < m; ++j) {
     // The reference's thread scans its points in increasing k with a strict '>' (the first maximum stays); the block
     // reduction breaks ties towards the lower thread id.  For a physical thread playing two virtual threads that is:
-    // all even-i points first (virtual thread tid), then the odd ones (tid + 512), strict '>' throughout.
-    float bv = -1.f;
-    int bk = 0;
+    // all even-i points first (virtual thread tid), then the odd ones (tid + 512), strict '>' throughout -- i.e. the
+    // maximum, ties to the EARLIER slot of the list [e = 0: q, h ascending][e = 1: q, h ascending].  A tree over that
+    // list in which the right operand wins only when strictly greater gives the same slot with depth 6 instead of 48.
+    float cv[PT];
+    int cs[PT];
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int q = 0; q < PT / 4; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const f2 dx = px[e][q] - x1, dy = py[e][q] - y1, dz = pz[e][q] - z1;
         const f2 d = dx * dx + dy * dy + dz * dz;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int k = tid + (4 * q + e + 2 * h) * 512;
           const float d2 = fminf(d[h], temp[e][q][h]);
           temp[e][q][h] = d2;
-          if (k < N && d2 > bv) {
-            bv = d2;
-            bk = k;
-          }
+          cv[e * (PT / 2) + q * 2 + h] = d2;
+          cs[e * (PT / 2) + q * 2 + h] = 4 * q + e + 2 * h;          // slot -> i
         }
       }
-    Best me = {bv, bv < 0.f ? 0x7fffffff : (bk & vmask), bk};
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      Best ot;
-      ot.v = __shfl_xor(me.v, off, 64);
-      ot.tid = __shfl_xor(me.tid, off, 64);
-      ot.k = __shfl_xor(me.k, off, 64);
-      me = better(me, ot);
-    }
-    if (lane == 0) {
-      s_v[wave] = me.v;
-      s_t[wave] = me.tid;
-      s_k[wave] = me.k;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      Best r = {s_v[0], s_t[0], s_k[0]};
-      for (int w = 1; w < 8; ++w) {
-        Best ot = {s_v[w], s_t[w], s_k[w]};
-        r = better(r, ot);
+    for (int w = 1; w < PT; w *= 2)
+#pragma unroll
+      for (int a0 = 0; a0 + w < PT; a0 += 2 * w) {
+        const bool take = cv[a0 + w] > cv[a0];
+        cv[a0] = take ? cv[a0 + w] : cv[a0];
+        cs[a0] = take ? cs[a0 + w] : cs[a0];
       }
-      s_old = r.k;
-      o[j] = r.k;
+    const float bv = cv[0];
+    const int bk = tid + cs[0] * 512;
+    Best me = {bv, bv < 0.f ? 0x7fffffff : (bk & vmask), bk};
+    FPS_DPP_STEP(0xB1);                              // quad_perm [1, 0, 3, 2]
+    FPS_DPP_STEP(0x4E);                              // quad_perm [2, 3, 0, 1]
+    FPS_DPP_STEP(0x141);                             // row_half_mirror
+    FPS_DPP_STEP(0x140);                             // row_mirror: every lane of a row of 16 holds the row's best
+    Best wb = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.v), 0)),
+               __builtin_amdgcn_readlane(me.tid, 0), __builtin_amdgcn_readlane(me.k, 0)};
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      Best ot = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.v), r * 16)),
+                 __builtin_amdgcn_readlane(me.tid, r * 16), __builtin_amdgcn_readlane(me.k, r * 16)};
+      wb = better(wb, ot);
+    }
+    const int par = j & 1;                           // two result buffers: the next iteration writes the other one
+    if (lane == 0) {
+      s_v[par][wave] = wb.v;
+      s_t[par][wave] = wb.tid;
+      s_k[par][wave] = wb.k;
     }
     __syncthreads();
-    const int old = s_old;
+    Best r = {s_v[par][0], s_t[par][0], s_k[par][0]};
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+      Best ot = {s_v[par][w], s_t[par][w], s_k[par][w]};
+      r = better(r, ot);
+    }
+    const int old = r.k;
+    if (tid == 0) o[j] = old;
     x1 = p[old * 3];
     y1 = p[old * 3 + 1];
     z1 = p[old * 3 + 2];
   }
+#undef FPS_DPP_STEP
 }
 
 // out[b,c,p,s] = feat[b,c,idx[b,p,s]]  (gather_points: nsample == 1)

@@ -625,7 +625,7 @@ def test_fps_block_sizes(dev, N):
     if N >= 1000:
         xyz[1, N - N // 5:] = 0
         xyz[0, ::7] = xyz[0, 3]          # duplicated points spread over many threads
-    m = min(N, 40)
+    m = min(N, 40 if N < 17000 else 300)      # the half-block kernel (16k < N <= 24k) runs long enough to alternate its buffers
     assert np.array_equal(ops.furthest_point_sample(T(xyz, dev), m).cpu().numpy(), orc.furthest_point_sample(xyz, m))
 
 
