@@ -222,7 +222,8 @@ int df3d_sparse_conv_bf16(const void *features_bf16, int n_in, int cin, const vo
  *       inv[k] = nbr[K-1-k].
  *   filter gradient = df3d_sparse_conv_grad_filters: grad_filters[k][ci][co] = sum_o features[nbr[k][o]][ci] *
  *       grad_out[o][co] ([K][Cin][Cout], zero-filled here; fp32 MFMA partial tiles are added with fp32 atomics, so
- *       the summation order varies between runs like the reference's cuBLAS split-K).  Cout <= 128. */
+ *       the summation order varies between runs like the reference's cuBLAS split-K).  Channel counts that are multiples
+ *       of 4 run on the LDS-staged pair-compacted kernel (any Cout); anything else on the direct kernel (Cout <= 128). */
 int df3d_invert_neighbors(const int32_t *nbr, int kvol, int n_out, int n_in, int32_t *inv, void *stream);
 int df3d_sparse_conv_grad_filters(const float *features, int n_in, int cin, const float *grad_out, int n_out, int cout,
                                   const int32_t *nbr, int kvol, float *grad_filters, void *stream);

@@ -870,3 +870,39 @@ def test_sparse_conv2d_and_pool2d_vs_dense_torch(dev):
         p = spconv.SparseMaxPool2d(3, 2, 1)(y)
         wantp = F.max_pool2d(got.clamp_min(0), 3, 2, 1)                    # the reference's pool starts from zero
         assert torch.equal(p.indices, z.indices) and (p.dense() - wantp).abs().max() <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,K,n_in,n_out,density", [
+    (128, 128, 27, 3000, 3000, 0.4), (64, 64, 27, 5000, 4100, 0.3), (32, 64, 27, 2500, 900, 0.5),
+    (16, 16, 27, 20000, 20000, 0.35), (16, 32, 8, 7000, 1777, 0.9), (64, 128, 27, 1300, 300, 0.02),
+    (256, 256, 9, 2100, 2100, 0.95), (48, 20, 27, 999, 1001, 0.4), (128, 64, 1, 70, 70, 1.0), (12, 20, 27, 500, 400, 0.5)])
+def test_filter_gradient_kernels_against_float64(cin, cout, K, n_in, n_out, density):
+    """df3d_sparse_conv_grad_filters: the LDS-staged pair-compacted kernel (channel counts that are multiples of 4) and the
+    direct kernel (everything else, DF3D_WGRAD=0) against sum over pairs of features[in]^T grad_out[out] in float64:
+    ragged row counts, empty offsets, channel counts that do not fill a tile."""
+    import os
+    from dualfusion import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(cin * 1000 + cout)
+    nbr = torch.randint(0, n_in, (K, n_out), generator=gen, dtype=torch.int32)
+    nbr[torch.rand((K, n_out), generator=gen) >= density] = -1
+    if K > 2:
+        nbr[1] = -1                                        # an offset without pairs
+    feats = torch.randn((n_in, cin), generator=gen)
+    gout = torch.randn((n_out, cout), generator=gen)
+    ref = torch.zeros((K, cin, cout), dtype=torch.float64)
+    for k in range(K):
+        o = (nbr[k] >= 0).nonzero(as_tuple=True)[0]
+        ref[k] = feats[nbr[k][o].long()].double().t() @ gout[o].double()
+    scale = max(1.0, float(ref.abs().max()))
+    outs = {}
+    for mode in ("1", "0"):
+        if mode == "0" and cout > 128:
+            continue
+        os.environ["DF3D_WGRAD"] = mode
+        try:
+            outs[mode] = ops.sparse_conv_grad_filters(feats.to(dev), gout.to(dev), nbr.to(dev)).cpu().double()
+        finally:
+            os.environ.pop("DF3D_WGRAD", None)
+        assert float((outs[mode] - ref).abs().max()) <= 2e-5 * scale, mode
