@@ -1451,6 +1451,20 @@ extern "C" int df3d_conv_pack_weights(const float *filters, int kvol, int cin, i
   return DF3D_OK;
 }
 
+extern "C" int df3d_conv_pack_weights_groups(const float *filters, int groups, int kvol, int cin, int cout, void *packed,
+                                             void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(filters && packed && groups >= 1, "conv_pack_weights_groups: bad argument");
+  DF3D_CHECK_ARG(df3d_conv_packed_weight_bytes(kvol, cin, cout) != 0 && cout <= 128,
+                 "conv_pack_weights_groups: shape K=%d cin=%d cout=%d has no grouped split-precision kernel", kvol, cin, cout);
+  // one column block per filter bank: the packed image is offset-major, so G banks back to back are one bank of G * K offsets
+  size_t total = (size_t)groups * kvol * cin * cout / 4;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, stream, filters, groups * kvol,
+                     cin, cout, split_layout(cin, cout), (u32x4 *)packed);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
 extern "C" int df3d_split_rows(const float *features, long long n, int c, void *split, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(features && split, "split_rows: null argument");

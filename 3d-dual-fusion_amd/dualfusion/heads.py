@@ -49,6 +49,45 @@ def fast_focal_loss(out, target, ind, mask, cat):
     return -(pos_loss + neg_loss) / num_pos
 
 
+class _BranchConvFunction(torch.autograd.Function):
+    """First convolutions of all G head branches (3x3, 64 -> 64 each, every branch reads the same shared rows) with
+    autograd, on the kernels the inference path uses: forward = ONE grouped launch (two branches per 128-column
+    block); input gradient = one grouped launch over the G gradient slices with the transposed filters and the
+    mirrored table, then the sum over branches; filter gradient = df3d_sparse_conv_grad_filters with G * 64 output
+    columns.  rows [P, 64], w [G, 9, 64, 64] (tap, cin, cout), bias [G * 64] -> [P, G * 64]."""
+
+    @staticmethod
+    def forward(ctx, rows, w, bias, nbr, nbr_mirror):
+        G, K, cin, cout = w.shape
+        P = rows.shape[0]
+        pair = 2 if G % 2 == 0 else 1
+        wd = w.detach().float()
+        wp = wd.view(G // pair, pair, K, cin, cout).permute(0, 2, 3, 1, 4).reshape(G // pair, K, cin, cout * pair)
+        packed = _ops.conv_pack_weights_groups(wp.contiguous())
+        out, _ = _ops.conv_rows_split(_ops.split_rows(rows.contiguous()), cin, 0, packed, cout * pair, G // pair, nbr, P,
+                                      bias.detach().float().contiguous() if bias is not None else None, None, None,
+                                      relu=False)
+        ctx.save_for_backward(rows, w, nbr, nbr_mirror)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        rows, w, nbr, nbr_mirror = ctx.saved_tensors
+        G, K, cin, cout = w.shape
+        P = rows.shape[0]
+        go = grad_out.contiguous().float()
+        packed_t = _ops.conv_pack_weights_groups(w.detach().float().transpose(2, 3).contiguous())
+        part, _ = _ops.conv_rows_split(_ops.split_rows(go), cout, cout, packed_t, cin, G, nbr_mirror, P, None, None, None,
+                                       relu=False)
+        g_rows = part.view(P, G, cin).sum(1)
+        g_w = _ops.sparse_conv_grad_filters(rows.contiguous(), go, nbr)            # [K, cin, G * cout]
+        g_w = g_w.view(K, cin, G, cout).permute(2, 0, 1, 3)
+        g_b = go.sum(0) if ctx.has_bias else None
+        return g_rows, g_w, g_b, None, None
+
+
 class SepHead(nn.Module):
     def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, bn=False, init_bias=-2.19, **kwargs):
         super(SepHead, self).__init__(**kwargs)
@@ -109,9 +148,12 @@ class CenterHead(nn.Module):
         return [task(x) for task in self.tasks]
 
     def forward(self, x, *kwargs):
+        if ((self.training or torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
+                and _ops.CONV_PRECISION == "split" and self._row_kernels_fit(x)):
+            return self.forward_rows_train(x)
         if (self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32
                 or _ops.CONV_PRECISION == "fp32" or not self._row_kernels_fit(x)):
-            return self.forward_reference(x)
+            return self.forward_reference(x.contiguous())
         # the head's own convolutions stay split precision (fp32-grade) in the bf16 mode of the backbone / neck
         return self.forward_rows(x)
 
@@ -222,6 +264,50 @@ class CenterHead(nn.Module):
             v = r.view(B, H, W, k).permute(0, 3, 1, 2)
             v._df3d_rows = (r, None, v._version)
             rets[t][head] = v
+        return rets
+
+    def forward_rows_train(self, x):
+        """`forward` with autograd (training rows) over channels-last pixel rows: the shared
+        convolution and the first convolution of all branches run on the sparse-convolution kernels (forward, input
+        gradient and filter gradient; `_BranchConvFunction` batches the 36 branches into single launches), their
+        BatchNorms as ONE batch-statistics normalisation over the 36 x 64 planes; the final 64 -> classes convolutions
+        (1 - 3 maps each) stay the library's, per branch."""
+        from .necks import _bn_rows, _rows_of, _train_stack
+        F = torch.nn.functional
+        tables = self.__dict__.setdefault("_train_tables", {})
+        B, _, H, W = x.shape
+        rows, _ = _rows_of(x)
+        sc, sbn = self.shared_conv[0], self.shared_conv[1]
+        s, _, _ = _train_stack([(sc, sbn, True, 1)], rows, B, H, W, tables)
+        nbr = tables[(B, H, W, 3, 3, 1, 1, False)][0]
+        mkey = (B, H, W, "mirror")
+        if mkey not in tables:
+            tables[mkey] = nbr.flip(0).contiguous()
+        branches = [(t, head, getattr(task, head)) for t, task in enumerate(self.tasks) for head in task.heads]
+        G = len(branches)
+        w = torch.stack([fc[0].weight.permute(2, 3, 1, 0).reshape(9, 64, 64) for _, _, fc in branches])
+        b = torch.cat([fc[0].bias for _, _, fc in branches])
+        m = _BranchConvFunction.apply(s, w, b, nbr, tables[mkey])                       # [P, G * 64]
+        # rows [P, G * 64] -> one NCHW volume [B, G * 64, H, W] (a single layout change for all branches; the library's
+        # spatial BatchNorm and final convolutions want planes, and torch's channels-last BatchNorm kernels crawl at
+        # 2304 channels), ONE batch-statistics BatchNorm over the 36 x 64 planes, ReLU, the branches as channel slices
+        # (`split`: its backward is one concatenation -- indexing would zero-fill the whole volume per branch)
+        vol = m.view(B, H * W, G * 64).transpose(1, 2).contiguous().view(B, G * 64, H, W)
+        bns = [fc[1] for _, _, fc in branches]
+        training = bns[0].training
+        mean = torch.cat([bn.running_mean for bn in bns])
+        var = torch.cat([bn.running_var for bn in bns])
+        vol = F.batch_norm(vol, mean, var, torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns]),
+                           training, bns[0].momentum, bns[0].eps)
+        if training:
+            with torch.no_grad():
+                torch._foreach_copy_([bn.running_mean for bn in bns], list(mean.split(64)))
+                torch._foreach_copy_([bn.running_var for bn in bns], list(var.split(64)))
+                torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+        maps = torch.relu(vol).split(64, dim=1)
+        rets = [dict() for _ in self.tasks]
+        for g, (t, head, fc) in enumerate(branches):
+            rets[t][head] = fc[3](maps[g])
         return rets
 
     def loss(self, example, preds_dicts, batch_dict=None, **kwargs):

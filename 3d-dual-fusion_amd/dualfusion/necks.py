@@ -27,6 +27,55 @@ def _bn(norm_cfg, planes):
     return nn.BatchNorm2d(planes, **cfg)
 
 
+def _bn_rows(bn, x):
+    """BatchNorm2d on channels-last pixel rows [P, C] (training: batch statistics over the rows, running statistics
+    updated like nn.BatchNorm2d.forward does)."""
+    F = torch.nn.functional
+    use_batch = bn.training or not bn.track_running_stats
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    return F.batch_norm(x, bn.running_mean if not bn.training or bn.track_running_stats else None,
+                        bn.running_var if not bn.training or bn.track_running_stats else None,
+                        bn.weight, bn.bias, use_batch, momentum, bn.eps)
+
+
+def _train_stack(groups, rows, B, H, W, tables):
+    """A block / deblock of (conv | deconv, BN, ReLU) groups over pixel rows WITH autograd (training rows, SURVEY.md
+    section 8f row 4): every convolution is `SparseConvFunction` on the layer's full neighbour table -- forward and
+    input gradient on the split-precision kernel, filter gradient on df3d_sparse_conv_grad_filters -- so training
+    does not leave the channels-last rows either; BatchNorm over the rows, ReLU.  -> (rows, H, W)."""
+    from .spconv.conv import SparseConvFunction
+    for conv, bn, relu, pad in groups:
+        transposed = isinstance(conv, nn.ConvTranspose2d)
+        kh, kw, stride = int(conv.kernel_size[0]), int(conv.kernel_size[1]), int(conv.stride[0])
+        key = (B, H, W, kh, kw, stride, pad, transposed)
+        if key not in tables:
+            tables[key] = _ops.conv2d_neighbors(B, H, W, kh, kw, stride, pad, transposed, rows.device)
+        nbr, Ho, Wo = tables[key]
+        same = (not transposed) and stride == 1 and Ho == H and Wo == W and kh % 2 == 1 and kw % 2 == 1
+        inv = None
+        if not same:                                     # strided / transposed layers: inverse table kept with the table
+            ikey = key + ("inv",)
+            if ikey not in tables:
+                tables[ikey] = _ops.invert_neighbors(nbr, rows.shape[0])
+            inv = tables[ikey]
+        # [cout, cin, kh, kw] (deconv: [cin, cout, s, s]) -> [kh, kw, cin, cout]; autograd carries the gradient back
+        w = conv.weight.permute(2, 3, 0, 1) if transposed else conv.weight.permute(2, 3, 1, 0)
+        rows = SparseConvFunction.apply(rows.contiguous(), w, conv.bias, nbr, nbr.shape[1], same, inv)
+        rows = _bn_rows(bn, rows)
+        if relu:
+            rows = torch.relu(rows)
+        H, W = Ho, Wo
+    return rows, H, W
+
+
+def _train_rows_ok(x):
+    return x.is_cuda and x.dtype == torch.float32
+
+
 class _Layer(object):
     """One conv/deconv + BN(eval) + ReLU group prepared for the row kernels."""
 
@@ -204,11 +253,31 @@ class RPN(nn.Module):
         out = torch.cat([u for u, _, _ in ups], 1) if len(ups) > 1 else ups[0][0]
         return out.view(B, uh, uw, -1).permute(0, 3, 1, 2)
 
+    def forward_rows_train(self, rows, B, H, W):
+        """`forward_rows` with autograd and BatchNorm in whatever mode the module is in (`_train_stack`)."""
+        tables = self.__dict__.setdefault("_train_tables", {})
+        ups = []
+        for i, blk in enumerate(self.blocks):
+            rows, H, W = _train_stack(self._groups(blk), rows, B, H, W, tables)
+            j = i - self._upsample_start_idx
+            if j >= 0:
+                ups.append(_train_stack(self._groups(self.deblocks[j]), rows, B, H, W, tables))
+        # contiguous NCHW out: a channels-last view would pull the head's library convolutions onto their NHWC kernels
+        # (a filter re-layout per call and branch)
+        if not ups:
+            return rows.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+        uh, uw = ups[0][1], ups[0][2]
+        assert all(h == uh and w == uw for _, h, w in ups)
+        out = torch.cat([u for u, _, _ in ups], 1) if len(ups) > 1 else ups[0][0]
+        return out.view(B, uh, uw, -1).permute(0, 3, 1, 2).contiguous()
+
     def forward(self, x):
-        if self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32:
+        if not x.is_cuda or x.dtype != torch.float32:
             return self.forward_reference(x)
         B, C, H, W = x.shape
         rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        if self.training or torch.is_grad_enabled():
+            return self.forward_rows_train(rows, B, H, W)
         return self.forward_rows(rows, B, H, W)
 
 
@@ -295,6 +364,15 @@ class SECOND(_RowStacks):
         return tuple(outs)
 
     def forward(self, x):
+        if (self.training or torch.is_grad_enabled()) and _train_rows_ok(x):
+            tables = self.__dict__.setdefault("_train_tables", {})
+            B, _, H, W = x.shape
+            rows, _ = _rows_of(x)
+            outs = []
+            for blk in self.blocks:
+                rows, H, W = _train_stack(RPN._groups(blk), rows, B, H, W, tables)
+                outs.append(rows.view(B, H, W, -1).permute(0, 3, 1, 2))
+            return tuple(outs)
         if self.training or not self._fast(x):
             return self.forward_reference(x)
         stacks, tables = self._stacks("blocks", self.blocks)
@@ -348,6 +426,16 @@ class SECONDFPN(_RowStacks):
 
     def forward(self, x):
         assert len(x) == len(self.in_channels)
+        if (self.training or torch.is_grad_enabled()) and all(_train_rows_ok(t) for t in x):
+            tables = self.__dict__.setdefault("_train_tables", {})
+            ups = []
+            for t, d in zip(x, self.deblocks):
+                B, _, H, W = t.shape
+                ups.append(_train_stack(RPN._groups(d), _rows_of(t)[0], B, H, W, tables))
+            H, W = ups[0][1], ups[0][2]
+            assert all(h == H and w == W for _, h, w in ups)
+            rows = torch.cat([u for u, _, _ in ups], 1) if len(ups) > 1 else ups[0][0]
+            return [rows.view(B, H, W, -1).permute(0, 3, 1, 2)]
         if self.training or not all(self._fast(t) for t in x):
             return self.forward_reference(x)
         stacks, tables = self._stacks("deblocks", self.deblocks)

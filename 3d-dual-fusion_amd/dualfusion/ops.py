@@ -312,6 +312,20 @@ def conv_pack_weights(filters):
     return packed
 
 
+def conv_pack_weights_groups(filters):
+    """filters [G, K, cin, cout] fp32 (cout <= 128) -> the G packed banks back to back (what `conv_rows_split` takes)."""
+    lib = _lib.load()
+    _chk(filters, torch.float32, "filters")
+    G, K, cin, cout = filters.shape
+    nbytes = lib.df3d_conv_packed_weight_bytes(K, cin, cout)
+    if nbytes == 0 or cout > 128:
+        raise _lib.Df3dError("no grouped split-precision kernel for K=%d cin=%d cout=%d" % (K, cin, cout))
+    packed = torch.empty((G * nbytes,), dtype=torch.uint8, device=filters.device)
+    rc = lib.df3d_conv_pack_weights_groups(_ptr(filters), G, K, cin, cout, _ptr(packed), _stream())
+    _lib.check(rc, "df3d_conv_pack_weights_groups")
+    return packed
+
+
 def split_rows(features):
     """features [n, c] fp32 -> split rows (uint8 [n, 4c]: per 8 channels 16 B of bf16 hi, 16 B of bf16 lo)."""
     lib = _lib.load()
@@ -452,6 +466,11 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None):
     cout, cin = wt.shape[1], wt.shape[2]
     if conv_split_supported(K, cout, cin):
         g_in, _ = sparse_conv_split(split_rows(grad_out), conv_pack_weights(wt), inv, n_in, cout, cin, emit_split=False)
+    elif cin > 128 and cin % 128 == 0 and conv_split_supported(K, cout, 128):
+        # many input channels (the head's shared conv 512 -> 64, transposed): 128-column blocks of one grouped launch
+        blocks = wt.view(K, cout, cin // 128, 128).permute(2, 0, 1, 3).contiguous()
+        g_in, _ = conv_rows_split(split_rows(grad_out), cout, 0, conv_pack_weights_groups(blocks), 128, cin // 128, inv,
+                                  n_in)
     else:
         g_in = sparse_conv_fused(grad_out, wt, inv, n_in)
     return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr)

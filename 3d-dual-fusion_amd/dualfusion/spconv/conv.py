@@ -31,11 +31,13 @@ class SparseConvFunction(torch.autograd.Function):
     df3d_sparse_conv_grad_filters, bias gradient = column sums."""
 
     @staticmethod
-    def forward(ctx, features, filters, bias, nbr, n_out, mirror):
+    def forward(ctx, features, filters, bias, nbr, n_out, mirror, inv=None):
+        """`inv`: the inverse table [K, n_in] when the caller keeps one (dense layers reuse theirs from step to step);
+        otherwise it is the mirrored forward table (`mirror`) or built in backward."""
         K = nbr.shape[0]
         cin, cout = features.shape[1], filters.shape[-1]
         ctx.save_for_backward(features, filters, nbr)
-        ctx.mirror, ctx.has_bias = mirror, bias is not None
+        ctx.mirror, ctx.has_bias, ctx.inv = mirror, bias is not None, inv
         w = filters.detach().contiguous().view(K, cin, cout)
         b = bias.detach() if bias is not None else None
         if _ops.conv_split_supported(K, cin, cout):            # same split-precision kernel as inference (~1e-5 rel.)
@@ -50,9 +52,9 @@ class SparseConvFunction(torch.autograd.Function):
         K = nbr.shape[0]
         cin, cout = features.shape[1], filters.shape[-1]
         g_in, g_w = _ops.sparse_conv_backward(features, filters.detach().contiguous().view(K, cin, cout),
-                                              grad_out.contiguous().float(), nbr, ctx.mirror)
+                                              grad_out.contiguous().float(), nbr, ctx.mirror, inv=ctx.inv)
         g_b = grad_out.sum(0) if ctx.has_bias else None
-        return g_in, g_w.view_as(filters), g_b, None, None, None
+        return g_in, g_w.view_as(filters), g_b, None, None, None, None
 
 
 class SparseConvolution(SparseModule):

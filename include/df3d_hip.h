@@ -552,6 +552,9 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
  * ---------------------------------------------------------------------------------- */
 size_t df3d_conv_packed_weight_bytes(int kvol, int cin, int cout);
 int df3d_conv_pack_weights(const float *filters, int kvol, int cin, int cout, void *packed, void *stream);
+/* `groups` filter banks [groups][K][Cin][Cout] (Cout <= 128) packed back to back for df3d_conv_rows_split: one launch. */
+int df3d_conv_pack_weights_groups(const float *filters, int groups, int kvol, int cin, int cout, void *packed,
+                                 void *stream);
 int df3d_split_rows(const float *features, long long n, int c, void *split, void *stream);
 int df3d_sparse_conv_split(const void *features_split, int n_in, int cin, const void *packed_filters, int kvol,
                            int cout, const int32_t *nbr, int n_out, const float *bias, const float *scale,

@@ -207,3 +207,29 @@ def test_loss_on_device_equals_cpu():
     lc, xc, wc = run("cpu")
     np.testing.assert_allclose(lg, lc, rtol=1e-4)
     assert np.abs(xg - xc).max() <= 1e-3 * np.abs(xc).max() and np.abs(wg - wc).max() <= 1e-3 * np.abs(wc).max()
+
+
+def test_training_forward_backward_on_row_kernels_vs_float64():
+    """CenterHead in train mode through `forward_rows_train` (shared conv + the 36 branches' first convs batched on the
+    sparse-conv kernels, one BatchNorm over all branches, library final convs): every head map, the input gradient, all
+    parameter gradients and the BatchNorm running statistics against the module's torch composition in float64."""
+    from dualfusion import ops
+    from test_gpu_neck import _train_case
+    if ops.CONV_PRECISION != "split":
+        pytest.skip("the training path batches the branches on the split-precision kernels")
+    head = _head()
+    x = torch.from_numpy(detgen.randn("head_train_x", (2, 512, 12, 16)))
+
+    def run(mod, t):
+        outs = mod(t) if t.is_cuda else mod.forward_reference(t)
+        return torch.cat([outs[i][k] for i in range(len(outs)) for k in sorted(outs[i])], dim=1)
+    # 36 branches x 384 pixels: ONE ReLU mask flipped by forward rounding moves a branch's BatchNorm / filter gradient by a
+    # per cent (which branch changes with the input; the library composition on the same device is at 4e-7) -- the bound on
+    # a single parameter is loose, the median over all parameters is not
+    _train_case(head, run, x, grad_l2=4e-3, flip_l2=3e-2)
+    # and the batched path is the one that ran
+    hd = _head().to(DEV).train()
+    xd = x.to(DEV).requires_grad_(True)
+    assert getattr(hd, "_train_tables", None) is None
+    hd(xd)
+    assert hd.__dict__.get("_train_tables")

@@ -148,3 +148,72 @@ def test_rpn_bf16_mode():
             md.train(False)                       # drops the plan that holds the bf16 filter banks
     assert float((y.cpu() - ref).abs().max() / ref.abs().max()) < 5e-2
     assert float((y.cpu() - ref).abs().mean() / ref.abs().mean()) < 1e-2
+
+
+def _train_case(mod_cpu, run, x, grad_l2=1e-3, flip_l2=None):
+    """Train-mode forward + backward of `run(module, x)` on the CPU in float64 (the oracle) and on the device through the
+    row kernels: outputs, input gradient, every parameter gradient and the running statistics."""
+    import copy
+    flip_l2 = grad_l2 if flip_l2 is None else flip_l2
+    ref = copy.deepcopy(mod_cpu).double().train()
+    xr = x.double().requires_grad_(True)
+    yr = run(ref, xr)
+    g = torch.from_numpy(detgen.randn("neck_train_g", tuple(yr.shape))).double()
+    (yr * g).sum().backward()
+    dev = torch.device("cuda:0")
+    md = copy.deepcopy(mod_cpu).to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    yd = run(md, xd)
+    (yd * g.float().to(dev)).sum().backward()
+    rel = lambda a, b: float((a.detach().cpu().double() - b).abs().max() / max(1e-12, float(b.abs().max())))
+    # gradients: a pre-activation within rounding of zero flips its ReLU mask, which moves single gradient entries by more
+    # than rounding -- the L2 distance is the stable measure, the largest entry gets a looser bound
+    l2 = lambda a, b: float((a.detach().cpu().double() - b).norm() / max(1e-12, float(b.norm())))
+    assert rel(yd, yr.detach()) < 1e-3
+    assert l2(xd.grad, xr.grad) < grad_l2 and rel(xd.grad, xr.grad) < 10 * grad_l2
+    pr = dict(ref.named_parameters())
+    errs = []
+    for name, p in md.named_parameters():
+        assert p.grad is not None, name
+        if float(pr[name].grad.norm()) < 1e-9:             # identically zero (a conv bias in front of a BatchNorm)
+            assert float(p.grad.abs().max()) < 1e-3, name
+            continue
+        errs.append(l2(p.grad, pr[name].grad))
+        assert errs[-1] < flip_l2 and rel(p.grad, pr[name].grad) < 10 * flip_l2, (name, errs[-1])
+    assert float(np.median(errs)) < 1e-3, errs
+    br = dict(ref.named_buffers())
+    for name, b in md.named_buffers():
+        if b.dtype.is_floating_point:
+            assert rel(b, br[name]) < 1e-3, name
+        else:
+            assert int(b) == int(br[name]), name
+
+
+def test_rpn_training_on_row_kernels_vs_float64():
+    """RPN in train mode (conv -> BatchNorm with batch statistics -> ReLU, strided conv, transposed conv, 1x1 conv):
+    forward, input / filter / BN gradients and running statistics against the torch composition in float64."""
+    from dualfusion.necks import RPN
+    m = _det_module(RPN([1, 2], [1, 2], [32, 64], [1, 2], [32, 48], 16))
+    x = torch.from_numpy(detgen.randn("neck_train_x", (2, 16, 20, 28)))
+    x = x * (torch.rand(2, 1, 20, 28, generator=torch.Generator().manual_seed(3)) < 0.5)
+    _train_case(m, lambda mod, t: mod(t) if t.is_cuda else mod.forward_reference(t), x)
+
+
+def test_second_fpn_training_on_row_kernels_vs_float64():
+    from dualfusion.necks import SECOND, SECONDFPN
+    from torch import nn
+
+    class Both(nn.Module):
+        def __init__(self):
+            super(Both, self).__init__()
+            self.bb = SECOND(in_channels=16, out_channels=[32, 64], layer_nums=[1, 1], layer_strides=[1, 2])
+            self.fpn = SECONDFPN(in_channels=[32, 64], out_channels=[32, 32], upsample_strides=[1, 2])
+
+    m = _det_module(Both())
+    x = torch.from_numpy(detgen.randn("second_train_x", (2, 16, 16, 24)))
+
+    def run(mod, t):
+        if t.is_cuda:
+            return mod.fpn(mod.bb(t))[0]
+        return mod.fpn.forward_reference(mod.bb.forward_reference(t))[0]
+    _train_case(m, run, x)
