@@ -83,6 +83,11 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_conv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "df3d_conv_pack_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_bn_rows_supported": (c_int, [c_int]),
+    "df3d_bn_rows_forward": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_bn_rows_backward": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
     "df3d_conv_pack_weights_groups": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_split_rows": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p]),
     "df3d_sparse_conv_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import ops as _ops
 from . import spconv
 from .registry import BACKBONES, BACKBONES_3D, MIDDLE_ENCODERS
 from .spconv import SparseConv3d, SubMConv3d
@@ -77,10 +78,9 @@ class SparseBasicBlock(spconv.SparseModule):
             return _fused_basic_block(x, self.conv1, self.bn1, self.conv2, self.bn2, self.downsample)
         identity = x
         out = self.conv1(x)
-        out = replace_feature(out, self.bn1(out.features))
-        out = replace_feature(out, self.relu(out.features))
+        out = replace_feature(out, _ops.batch_norm_rows(self.bn1, out.features, relu=True))
         out = self.conv2(out)
-        out = replace_feature(out, self.bn2(out.features))
+        out = replace_feature(out, _ops.batch_norm_rows(self.bn2, out.features))
         if self.downsample is not None:
             identity = self.downsample(x)
         out = replace_feature(out, out.features + identity.features)

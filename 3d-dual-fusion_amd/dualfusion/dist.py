@@ -189,10 +189,12 @@ class GradBucketReducer(object):
     def _seal(self, plist):
         flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
         pos = 0
+        offsets = {}
         for p in plist:
             p.grad = flat[pos:pos + p.numel()].view_as(p)
+            offsets[id(p)] = pos
             pos += p.numel()
-        b = dict(flat=flat, params=plist, pending=len(plist), handle=None, index=len(self.buckets))
+        b = dict(flat=flat, params=plist, pending=len(plist), handle=None, index=len(self.buckets), offsets=offsets)
         for p in plist:
             p._df3d_bucket = b
         self.buckets.append(b)
@@ -217,12 +219,12 @@ class GradBucketReducer(object):
 
     @staticmethod
     def _offset(b, p):
-        off = 0
-        for q in b["params"]:
-            if q is p:
-                return off * p.element_size()
-            off += q.numel()
-        raise KeyError("parameter not in bucket")
+        """Byte offset of the parameter's gradient view inside its bucket (looked up, not searched: the hooks and
+        zero_grad call this for every parameter every step)."""
+        try:
+            return b["offsets"][id(p)] * p.element_size()
+        except KeyError:
+            raise KeyError("parameter not in bucket")
 
     def _view(self, b, p):
         off = self._offset(b, p) // p.element_size()

@@ -44,9 +44,9 @@ def fast_focal_loss(out, target, ind, mask, cat):
     pos_pred = pos_pred_pix.gather(2, cat.unsqueeze(2))
     num_pos = mask.sum()
     pos_loss = (torch.log(pos_pred) * torch.pow(1 - pos_pred, 2) * mask.unsqueeze(2)).sum()
-    if num_pos == 0:
-        return -neg_loss
-    return -(pos_loss + neg_loss) / num_pos
+    # the reference branches on num_pos == 0 (-> -neg_loss); pos_loss is exactly 0 then, so dividing by max(num_pos, 1)
+    # is the same value without reading num_pos back to the host in the middle of the step
+    return -(pos_loss + neg_loss) / num_pos.clamp(min=1.0)
 
 
 class _BranchConvFunction(torch.autograd.Function):
@@ -310,7 +310,7 @@ class CenterHead(nn.Module):
             rets[t][head] = fc[3](maps[g])
         return rets
 
-    def loss(self, example, preds_dicts, batch_dict=None, **kwargs):
+    def loss(self, example, preds_dicts, batch_dict=None, host_copies=True, **kwargs):
         """center_head.py:250-298: per task the CornerNet focal loss on the clamped sigmoid heat map
         (losses/centernet_loss.py:29-58) + `weight` x the code-weighted L1 loss of the gathered box regressions
         (:6-27); plain torch (autograd), the targets `hm / ind / mask / cat / anno_box` come with `example` exactly as
@@ -340,8 +340,11 @@ class CenterHead(nn.Module):
                 auxseg_loss = sum(a[task_id] for a in batch_dict['auxseg_loss'])
                 ret['auxseg_loss'] = auxseg_loss
                 loss = loss + auxseg_loss
-            ret.update({'loss': loss, 'hm_loss': hm_loss.detach().cpu(), 'loc_loss': loc_loss,
-                        'loc_loss_elem': box_loss.detach().cpu(), 'num_positive': example['mask'][task_id].float().sum()})
+            # `host_copies=False`: the logged values stay on the device (a `.cpu()` here stalls the host until the forward
+            # has drained, before it could queue the backward); `training_step` copies them after backward
+            keep = (lambda v: v.detach().cpu()) if host_copies else (lambda v: v.detach())
+            ret.update({'loss': loss, 'hm_loss': keep(hm_loss), 'loc_loss': loc_loss,
+                        'loc_loss_elem': keep(box_loss), 'num_positive': example['mask'][task_id].float().sum()})
             rets.append(ret)
         merged = defaultdict(list)
         for ret in rets:

@@ -27,19 +27,9 @@ def _bn(norm_cfg, planes):
     return nn.BatchNorm2d(planes, **cfg)
 
 
-def _bn_rows(bn, x):
-    """BatchNorm2d on channels-last pixel rows [P, C] (training: batch statistics over the rows, running statistics
-    updated like nn.BatchNorm2d.forward does)."""
-    F = torch.nn.functional
-    use_batch = bn.training or not bn.track_running_stats
-    momentum = 0.0 if bn.momentum is None else bn.momentum
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:
-            momentum = 1.0 / float(bn.num_batches_tracked)
-    return F.batch_norm(x, bn.running_mean if not bn.training or bn.track_running_stats else None,
-                        bn.running_var if not bn.training or bn.track_running_stats else None,
-                        bn.weight, bn.bias, use_batch, momentum, bn.eps)
+def _bn_rows(bn, x, relu=False):
+    """BatchNorm2d (+ ReLU) on channels-last pixel rows [P, C]: `ops.batch_norm_rows` (row kernels in train() mode)."""
+    return _ops.batch_norm_rows(bn, x, relu)
 
 
 def _train_stack(groups, rows, B, H, W, tables):
@@ -65,9 +55,7 @@ def _train_stack(groups, rows, B, H, W, tables):
         # [cout, cin, kh, kw] (deconv: [cin, cout, s, s]) -> [kh, kw, cin, cout]; autograd carries the gradient back
         w = conv.weight.permute(2, 3, 0, 1) if transposed else conv.weight.permute(2, 3, 1, 0)
         rows = SparseConvFunction.apply(rows.contiguous(), w, conv.bias, nbr, nbr.shape[1], same, inv)
-        rows = _bn_rows(bn, rows)
-        if relu:
-            rows = torch.relu(rows)
+        rows = _bn_rows(bn, rows, relu)
         H, W = Ho, Wo
     return rows, H, W
 

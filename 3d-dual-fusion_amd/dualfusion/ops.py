@@ -1231,3 +1231,72 @@ def gather_points(features, idx):
     rc = lib.df3d_gather_points(_ptr(features), _ptr(idx), B, C, N, npoint, _ptr(out), _stream())
     _lib.check(rc, "df3d_gather_points")
     return out
+
+
+# ------------------------------------------------------------------------- BatchNorm over rows (training)
+def bn_rows_supported(c):
+    return bool(_lib.load().df3d_bn_rows_supported(int(c)))
+
+
+class BatchNormRowsFunction(torch.autograd.Function):
+    """y = relu?(BatchNorm(x)) with batch statistics over channels-last rows [N, C] (df3d_bn_rows_forward / _backward):
+    the running statistics are updated in place like nn.BatchNorm*.forward in train() mode."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+        lib = _lib.load()
+        x = _chk(x.contiguous(), torch.float32, "x")
+        n, c = x.shape
+        dev = x.device
+        sums = torch.empty((2, c), dtype=torch.float64, device=dev)
+        saved = torch.empty((4, c), dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        w = weight.detach().float().contiguous() if weight is not None else None
+        b = bias.detach().float().contiguous() if bias is not None else None
+        rc = lib.df3d_bn_rows_forward(_ptr(x), n, c, _ptr(w), _ptr(b), float(eps), float(momentum), int(bool(relu)),
+                                      _ptr(running_mean), _ptr(running_var), _ptr(sums), _ptr(saved), _ptr(y), _stream())
+        _lib.check(rc, "df3d_bn_rows_forward")
+        ctx.save_for_backward(x, saved)
+        ctx.relu, ctx.sums = bool(relu), sums
+        ctx.has = (weight is not None, bias is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, saved = ctx.saved_tensors
+        n, c = x.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        dw = torch.empty((c,), dtype=torch.float32, device=x.device) if ctx.has[0] else None
+        db = torch.empty((c,), dtype=torch.float32, device=x.device) if ctx.has[1] else None
+        rc = lib.df3d_bn_rows_backward(_ptr(x), _ptr(dy), n, c, _ptr(saved), int(ctx.relu), _ptr(ctx.sums), _ptr(dx),
+                                       _ptr(dw), _ptr(db), _stream())
+        _lib.check(rc, "df3d_bn_rows_backward")
+        return dx, dw, db, None, None, None, None, None
+
+
+def batch_norm_rows(bn, x, relu=False):
+    """`bn` (nn.BatchNorm1d / 2d in train() mode with running statistics) over rows x [N, C], optionally followed by ReLU:
+    the row kernels when the shape is served, the torch composition otherwise (eval mode, CPU, odd channel counts)."""
+    F = torch.nn.functional
+    fast = (bn.training and bn.track_running_stats and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+            and x.shape[0] > 1 and bn.momentum is not None and bn_rows_supported(x.shape[1]))
+    if fast:
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(1)
+        return BatchNormRowsFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                           relu)
+    y = bn(x) if x.dim() == 2 and isinstance(bn, torch.nn.BatchNorm1d) else None
+    if y is None:
+        use_batch = bn.training or not bn.track_running_stats
+        momentum = 0.0 if bn.momentum is None else bn.momentum
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        y = F.batch_norm(x, bn.running_mean if not bn.training or bn.track_running_stats else None,
+                         bn.running_var if not bn.training or bn.track_running_stats else None,
+                         bn.weight, bn.bias, use_batch, momentum, bn.eps)
+    return torch.relu(y) if relu else y

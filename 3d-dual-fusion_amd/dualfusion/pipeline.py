@@ -136,10 +136,12 @@ class CenterPointDetector(nn.Module):
                     bev, _ = hp.backbone(feats, batch_dict, coors, len(points_list), hp.grid_size_xyz, example,
                                          fuse_func=hp.fusion)
                 preds = self.bbox_head(self.neck(bev))
-                rets = self.bbox_head.loss(example, preds, {})
+                rets = self.bbox_head.loss(example, preds, {}, host_copies=False)
                 sum(rets["loss"]).backward()
         finally:
             hp.backbone.dense_layout = layout
+        for key in ("hm_loss", "loc_loss_elem"):            # the reference's host copies, once the backward is queued
+            rets[key] = [v.cpu() for v in rets[key]]
         return rets
 
     @torch.no_grad()

@@ -116,6 +116,14 @@ class SparseSequential(SparseModule):
                 input = module.forward_fused(input, scale=scale, shift=shift, relu=relu)
                 i += 3 if relu else 2
                 continue
+            if isinstance(module, nn.BatchNorm1d) and module.training and isinstance(input, SparseConvTensor) \
+                    and input.indices.shape[0] > 1 and input.features.is_cuda:
+                # BatchNorm1d(train) [-> ReLU] over the feature rows on the row kernels (csrc/bnrows.hip)
+                from .. import ops as _ops
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1][1], nn.ReLU)
+                input.features = _ops.batch_norm_rows(module, input.features, relu)
+                i += 2 if relu else 1
+                continue
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 self._sparity_dict[k] = input.sparity

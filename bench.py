@@ -169,7 +169,7 @@ class CenterPointWorkload(object):
         self.model.train()
         params = [p for p in self.model.parameters() if p.requires_grad]
         self.reducer = D.GradBucketReducer(params, bucket_mb=64.0)
-        self.optimizer = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, foreach=True)
+        self.optimizer = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
         self.n_params = sum(p.numel() for p in params)
 
     def step(self, i, stage):
@@ -577,7 +577,7 @@ def main():
             "collective_backend": (torch.distributed.get_backend() if D.is_dist() else None), "world_size": world,
         }
         if stage == "train":
-            res["config"]["training"] = {"trainable_parameters": getattr(wl, "n_params", None), "optimizer": "AdamW (foreach)",
+            res["config"]["training"] = {"trainable_parameters": getattr(wl, "n_params", None), "optimizer": "AdamW (fused)",
                                          "gradient_reduction": "GradBucketReducer: %d bucket(s) of <= 64 MB, all-reduce launched "
                                                                "from post-accumulate-grad hooks during backward" % len(wl.reducer.buckets)}
         if stage in ("detect", "train") and isinstance(out, dict) and "encoded_spconv_tensor" not in out:

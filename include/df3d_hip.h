@@ -228,6 +228,21 @@ int df3d_invert_neighbors(const int32_t *nbr, int kvol, int n_out, int n_in, int
 int df3d_sparse_conv_grad_filters(const float *features, int n_in, int cin, const float *grad_out, int n_out, int cout,
                                   const int32_t *nbr, int kvol, float *grad_filters, void *stream);
 
+/* BatchNorm with batch statistics over channels-last rows [n][c] (training rows).  Replace
+ * torch.nn.BatchNorm1d / BatchNorm2d in train() mode behind the convolutions of the sparse backbone, the BEV neck and the head
+ * (CP/det3d/models/backbones/scn.py:51-118, necks/rpn.py:22-163, bbox_heads/center_head.py:66-110), optionally with the ReLU
+ * that follows them.  forward: y = relu?((x - mean) * rstd * weight + bias) with the batch mean / biased variance of the
+ * columns; running_mean / running_var (may be NULL) updated in place with `momentum` and the unbiased variance; `sums`
+ * [2][c] doubles is scratch, `saved` [4][c] floats (mean, rstd, scale, shift) is what backward needs.  backward: dx, dweight
+ * [c], dbias [c] (either may be NULL) from x, dy and `saved`; with relu != 0 the mask is recomputed from x.
+ * Channel counts: multiples of 4 that divide 256 or are multiples of 256 (df3d_bn_rows_supported). */
+int df3d_bn_rows_supported(int c);
+int df3d_bn_rows_forward(const float *x, long long n, int c, const float *weight, const float *bias, float eps,
+                         float momentum, int relu, float *running_mean, float *running_var, double *sums, float *saved,
+                         float *y, void *stream);
+int df3d_bn_rows_backward(const float *x, const float *dy, long long n, int c, const float *saved, int relu, double *sums,
+                          float *dx, float *dweight, float *dbias, void *stream);
+
 /* Grouped / multi-head convolution over pixel (or voxel) rows on the split-precision kernel -- the detection head's
  * stacks (CP/det3d/models/bbox_heads/center_head.py:66-110: per task and per head Conv2d 3x3 64 -> 64 + BN + ReLU
  * + Conv2d 3x3 64 -> classes) as ONE launch per depth instead of one cuDNN call per head.

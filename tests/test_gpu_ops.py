@@ -906,3 +906,39 @@ def test_filter_gradient_kernels_against_float64(cin, cout, K, n_in, n_out, dens
         finally:
             os.environ.pop("DF3D_WGRAD", None)
         assert float((outs[mode] - ref).abs().max()) <= 2e-5 * scale, mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,relu", [(37001, 16, True), (9000, 32, False), (5003, 64, True), (3000, 128, True),
+                                      (2048, 256, False), (777, 512, True), (400, 2304, True), (2, 64, False)])
+def test_batch_norm_rows_kernels_vs_float64(n, c, relu):
+    """df3d_bn_rows_forward / _backward through `ops.batch_norm_rows` against torch's BatchNorm (+ ReLU) in float64: output,
+    input / weight / bias gradients, running statistics, the batch counter."""
+    from dualfusion import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(n + c)
+    x = torch.randn((n, c), generator=gen) * 2.0 + torch.randn((1, c), generator=gen)
+    g = torch.randn((n, c), generator=gen)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).double().train()
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(c, generator=gen).double())
+        ref.bias.copy_(torch.randn(c, generator=gen).double())
+        ref.running_mean.copy_(torch.randn(c, generator=gen).double())
+        ref.running_var.copy_(torch.rand(c, generator=gen).double() + 0.5)
+    import copy
+    bn = copy.deepcopy(ref).float().to(dev)
+    assert ops.bn_rows_supported(c)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    (yr * g.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    yd = ops.batch_norm_rows(bn, xd, relu)
+    (yd * g.to(dev)).sum().backward()
+    rel = lambda a, b: float((a.detach().cpu().double() - b).abs().max() / max(1e-9, float(b.abs().max())))
+    tol = 1e-4 if n > 2 else 2e-3          # two rows: xhat = +-1 and the input gradient is all cancellation
+    assert rel(yd, yr.detach()) < 1e-5
+    assert rel(xd.grad, xr.grad) < tol
+    assert rel(bn.weight.grad, ref.weight.grad) < tol and rel(bn.bias.grad, ref.bias.grad) < tol
+    assert rel(bn.running_mean, ref.running_mean) < 1e-5 and rel(bn.running_var, ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
