@@ -24,7 +24,7 @@ struct BnArgs {
   double *sums;                 // [2][C]
   float *running_mean, *running_var, *dweight, *dbias;
   long long n;
-  int c, cb, qb, rows_per_wg, relu;
+  int c, cb, qb, rows_per_wg, rows_per_wg_red, relu;
   float eps, momentum;
 };
 
@@ -50,10 +50,18 @@ __device__ __forceinline__ void bn_block_reduce(f32x4 a, f32x4 b, int qb, double
 __global__ __launch_bounds__(256) void bn_rows_stats_kernel(BnArgs a) {
   const int tid = threadIdx.x, quad = tid % a.qb, rl = tid / a.qb, rp = 256 / a.qb;
   const int col0 = blockIdx.y * a.cb;
-  const long long r0 = (long long)blockIdx.x * a.rows_per_wg, r1 = min(r0 + a.rows_per_wg, a.n);
+  const long long r0 = (long long)blockIdx.x * a.rows_per_wg_red, r1 = min(r0 + a.rows_per_wg_red, a.n);
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
   const float *p = a.x + col0 + quad * 4;
-  for (long long r = r0 + rl; r < r1; r += rp) {
+  long long r = r0 + rl;
+  for (; r + 3LL * rp < r1; r += 4LL * rp) {          // four independent loads in flight per thread
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const f32x4 *)(p + (r + (long long)u * rp) * a.c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += v[u], ss += v[u] * v[u];
+  }
+  for (; r < r1; r += rp) {
     const f32x4 v = *(const f32x4 *)(p + r * a.c);
     s += v;
     ss += v * v;
@@ -114,18 +122,24 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_reduce_kernel(BnArgs a) {
   const int col0 = blockIdx.y * a.cb, col = col0 + quad * 4;
   const f32x4 mean = *(const f32x4 *)(a.saved + col), rstd = *(const f32x4 *)(a.saved + a.c + col);
   const f32x4 scale = *(const f32x4 *)(a.saved + 2 * a.c + col), shift = *(const f32x4 *)(a.saved + 3 * a.c + col);
-  const long long r0 = (long long)blockIdx.x * a.rows_per_wg, r1 = min(r0 + a.rows_per_wg, a.n);
+  const long long r0 = (long long)blockIdx.x * a.rows_per_wg_red, r1 = min(r0 + a.rows_per_wg_red, a.n);
   f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
-  for (long long r = r0 + rl; r < r1; r += rp) {
-    const f32x4 v = *(const f32x4 *)(a.x + r * a.c + col);
-    f32x4 g = *(const f32x4 *)(a.dy + r * a.c + col);
+  auto take = [&](const f32x4 &v, f32x4 g) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (a.relu && !(fmaf(v[e], scale[e], shift[e]) > 0.f)) g[e] = 0.f;
       sg[e] += g[e];
       sgx[e] += g[e] * ((v[e] - mean[e]) * rstd[e]);
     }
+  };
+  long long r = r0 + rl;
+  for (; r + (long long)rp < r1; r += 2LL * rp) {       // two rows (four loads) in flight per thread
+    const f32x4 v0 = *(const f32x4 *)(a.x + r * a.c + col), g0 = *(const f32x4 *)(a.dy + r * a.c + col);
+    const f32x4 v1 = *(const f32x4 *)(a.x + (r + rp) * a.c + col), g1 = *(const f32x4 *)(a.dy + (r + rp) * a.c + col);
+    take(v0, g0);
+    take(v1, g1);
   }
+  for (; r < r1; r += rp) take(*(const f32x4 *)(a.x + r * a.c + col), *(const f32x4 *)(a.dy + r * a.c + col));
   bn_block_reduce(sg, sgx, a.qb, a.sums, col0, a.c);
 }
 
@@ -171,6 +185,10 @@ static bool bn_shape(BnArgs &a, long long n, int c) {
   long long rows = cdiv(n, (long long)std::max(1, 2048 / ncb));
   rows = std::max<long long>(rows, 8LL * rp);
   a.rows_per_wg = (int)(cdiv(rows, (long long)rp) * rp);
+  // the two reductions end in double atomics on the SAME 2 x C addresses from every workgroup: ~512 workgroups (each
+  // keeps four loads per thread in flight), not 2048, or the atomics serialise into most of the kernel's time
+  rows = std::max<long long>(cdiv(n, (long long)std::max(1, 512 / ncb)), 8LL * rp);
+  a.rows_per_wg_red = (int)(cdiv(rows, (long long)rp) * rp);
   return true;
 }
 
@@ -195,7 +213,8 @@ extern "C" int df3d_bn_rows_forward(const float *x, long long n, int c, const fl
   a.running_mean = running_mean, a.running_var = running_var, a.relu = relu, a.eps = eps, a.momentum = momentum;
   DF3D_HIP(hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(double), stream));
   const dim3 grid((unsigned)cdiv(n, (long long)a.rows_per_wg), c / a.cb);
-  hipLaunchKernelGGL(bn_rows_stats_kernel, grid, dim3(256), 0, stream, a);
+  const dim3 grid_red((unsigned)cdiv(n, (long long)a.rows_per_wg_red), c / a.cb);
+  hipLaunchKernelGGL(bn_rows_stats_kernel, grid_red, dim3(256), 0, stream, a);
   hipLaunchKernelGGL(bn_rows_apply_kernel, grid, dim3(256), 0, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
@@ -211,7 +230,8 @@ extern "C" int df3d_bn_rows_backward(const float *x, const float *dy, long long 
   a.relu = relu;
   DF3D_HIP(hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(double), stream));
   const dim3 grid((unsigned)cdiv(n, (long long)a.rows_per_wg), c / a.cb);
-  hipLaunchKernelGGL(bn_rows_bwd_reduce_kernel, grid, dim3(256), 0, stream, a);
+  const dim3 grid_red((unsigned)cdiv(n, (long long)a.rows_per_wg_red), c / a.cb);
+  hipLaunchKernelGGL(bn_rows_bwd_reduce_kernel, grid_red, dim3(256), 0, stream, a);
   hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, grid, dim3(256), 0, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;

@@ -12,6 +12,7 @@
 // `CenterHead.predict` / `loss_device` read in place.  Each activation is read from memory 1.56 times (halo) instead of 9;
 // 30 KB of LDS per workgroup keeps five workgroups (20 waves) per CU in flight.
 #include "common.h"
+#include <algorithm>
 
 namespace df3d {
 
@@ -103,6 +104,141 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
   }
 }
 
+
+// ---- backward of the final convolutions (training rows) ------------------------------------------
+// Forward (head_final_kernel): O[p][col_g + j] = bias + sum_tap sum_c M[p + off(tap)][g*64 + c] * W[g][tap][c][j].
+//   data gradient:    dM[q][g*64 + c]   = sum_tap sum_j dO[q - off(tap)][col_g + j] * W[g][tap][c][j]
+//   filter gradient:  dW[g][tap][c][j]  = sum_p M[p + off(tap)][g*64 + c] * dO[p][col_g + j]
+// Both on the same (8 x 8 pixel tile, branch) decomposition as the forward kernel, fp32 activations (rows [P][ldm]) and fp32
+// output gradients (rows [P][ldo], branch g at columns cols[2g] .. + cols[2g+1]).
+struct HeadFinalBwdArgs {
+  const float *m;        // activations [B*H*W][ldm] fp32 (filter gradient only)
+  const float *go;       // output gradient [B*H*W][ldo]
+  const float *w;        // [G][9][64][4]
+  const int32_t *cols;   // [G][2]
+  float *gm;             // data gradient [B*H*W][ldm]
+  float *gw;             // filter gradient [G][9][64][4] (atomics; zero-filled by the host entry)
+  int ldm, ldo, B, H, W, G, tiles_x, tiles_y, tiles_per_wg;
+};
+
+__global__ __launch_bounds__(256) void head_final_bwd_data_kernel(HeadFinalBwdArgs a) {
+  __shared__ float go[HF_HP * HF_KMAX];               // the branch's output-gradient halo tile, [pixel][map]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.y, tile = blockIdx.x;
+  const int b = tile / (a.tiles_x * a.tiles_y), t2 = tile - b * (a.tiles_x * a.tiles_y);
+  const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+  const int y0 = ty * HF_TILE - 1, x0 = tx * HF_TILE - 1;
+  const int c0 = a.cols[2 * g], k = a.cols[2 * g + 1];
+  for (int it = tid; it < HF_HP * HF_KMAX; it += 256) {
+    const int p = it >> 2, j = it & 3;
+    const int hy = p / HF_HALO, hx = p - hy * HF_HALO;
+    const int yy = y0 + hy, xx = x0 + hx;
+    float v = 0.f;
+    if (j < k && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) v = a.go[((size_t)(b * a.H + yy) * a.W + xx) * a.ldo + c0 + j];
+    go[it] = v;
+  }
+  __syncthreads();
+  // lane = pixel q of the tile, wave = 16 channels; dM[q][c] = sum_tap <dO[q - off(tap)], W[tap][c]> -- q - off(tap) is halo
+  // pixel (py + 2 - dy, px + 2 - dx) for tap (dy, dx)
+  const int py = lane >> 3, px = lane & 7;
+  f32x4 d[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    d[tap] = *(const f32x4 *)&go[((py + 2 - dy) * HF_HALO + (px + 2 - dx)) * HF_KMAX];
+  }
+  const float *wg = a.w + ((size_t)g * 9 * HF_C + wave * 16) * HF_KMAX;
+  float out[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const f32x4 w4 = *(const f32x4 *)(wg + (tap * HF_C + c) * HF_KMAX);      // wave-uniform: scalar loads
+      acc = fmaf(d[tap][0], w4[0], acc);
+      acc = fmaf(d[tap][1], w4[1], acc);
+      acc = fmaf(d[tap][2], w4[2], acc);
+      acc = fmaf(d[tap][3], w4[3], acc);
+    }
+    out[c] = acc;
+  }
+  const int oy = ty * HF_TILE + py, ox = tx * HF_TILE + px;
+  if (oy < a.H && ox < a.W) {
+    float *dst = a.gm + ((size_t)(b * a.H + oy) * a.W + ox) * a.ldm + g * HF_C + wave * 16;
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) *(f32x4 *)(dst + c) = (f32x4){out[c], out[c + 1], out[c + 2], out[c + 3]};
+  }
+}
+
+__global__ __launch_bounds__(256) void head_final_bwd_filter_kernel(HeadFinalBwdArgs a) {
+  __shared__ float x[HF_C * HF_LD];                  // activation halo tile, [channel][pixel]
+  __shared__ float go[64 * HF_KMAX];                 // output gradient of the tile's 64 pixels, [pixel][map]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.y;
+  const int c0 = a.cols[2 * g], k = a.cols[2 * g + 1];
+  // lane = channel, wave w = taps {w, w + 4, w + 8}: acc[i][j] = dW[tap_i][lane][j]
+  float acc[3][HF_KMAX];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < HF_KMAX; ++j) acc[i][j] = 0.f;
+  const int ntiles = a.B * a.tiles_x * a.tiles_y;
+  const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(t_begin + a.tiles_per_wg, ntiles);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / (a.tiles_x * a.tiles_y), t2 = tile - b * (a.tiles_x * a.tiles_y);
+    const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+    const int y0 = ty * HF_TILE - 1, x0 = tx * HF_TILE - 1;
+    __syncthreads();                                 // the previous tile's reads are done
+    // halo -> LDS: item = (halo pixel, 4-channel piece): 16-byte loads of the fp32 rows
+    for (int it = tid; it < HF_HP * 16; it += 256) {
+      const int p = it >> 4, q = it & 15;
+      const int hy = p / HF_HALO, hx = p - hy * HF_HALO;
+      const int yy = y0 + hy, xx = x0 + hx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+        v = *(const f32x4 *)(a.m + ((size_t)(b * a.H + yy) * a.W + xx) * a.ldm + g * HF_C + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[(q * 4 + e) * HF_LD + p] = v[e];
+    }
+    {
+      const int p = tid >> 2, j = tid & 3;           // 64 pixels x 4 maps
+      const int oy = ty * HF_TILE + (p >> 3), ox = tx * HF_TILE + (p & 7);
+      float v = 0.f;
+      if (j < k && oy < a.H && ox < a.W) v = a.go[((size_t)(b * a.H + oy) * a.W + ox) * a.ldo + c0 + j];
+      go[tid] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int tap = wave + 4 * i;
+      if (tap < 9) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const float *xp = x + lane * HF_LD + dy * HF_HALO + dx;
+        for (int p = 0; p < 64; ++p) {
+          const float xv = xp[(p >> 3) * HF_HALO + (p & 7)];
+          const f32x4 g4 = *(const f32x4 *)&go[p * HF_KMAX];              // broadcast read
+          acc[i][0] = fmaf(xv, g4[0], acc[i][0]);
+          acc[i][1] = fmaf(xv, g4[1], acc[i][1]);
+          acc[i][2] = fmaf(xv, g4[2], acc[i][2]);
+          acc[i][3] = fmaf(xv, g4[3], acc[i][3]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap < 9) {
+      float *dst = a.gw + (((size_t)g * 9 + tap) * HF_C + lane) * HF_KMAX;
+#pragma unroll
+      for (int j = 0; j < HF_KMAX; ++j)
+        if (j < k && acc[i][j] != 0.f) unsafeAtomicAdd(dst + j, acc[i][j]);
+    }
+  }
+}
+
 }  // namespace df3d
 
 using namespace df3d;
@@ -126,6 +262,32 @@ extern "C" int df3d_head_final_conv(const void *in_split, int in_channels, int b
   a.B = batch, a.H = H, a.W = W, a.G = groups;
   a.tiles_x = cdiv(W, HF_TILE), a.tiles_y = cdiv(H, HF_TILE);
   hipLaunchKernelGGL(head_final_kernel, dim3(batch * a.tiles_x * a.tiles_y, groups), dim3(256), 0, stream, a);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_head_final_conv_backward(const float *acts, int act_channels, const float *grad_out, int out_channels,
+                                             int batch, int H, int W, int groups, const float *weights,
+                                             const int32_t *out_cols, float *grad_acts, float *grad_weights, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(grad_out && weights && out_cols && (grad_acts || grad_weights), "head_final_conv_backward: null argument");
+  DF3D_CHECK_ARG(groups >= 1 && act_channels >= groups * HF_C && act_channels % 4 == 0,
+                 "head_final_conv_backward: %d branches of 64 channels do not fit %d-channel rows", groups, act_channels);
+  DF3D_CHECK_ARG(batch >= 1 && H >= 1 && W >= 1 && out_channels >= 1, "head_final_conv_backward: bad sizes");
+  DF3D_CHECK_ARG(!grad_weights || acts, "head_final_conv_backward: the filter gradient needs the activations");
+  HeadFinalBwdArgs a;
+  a.m = acts, a.go = grad_out, a.w = weights, a.cols = out_cols, a.gm = grad_acts, a.gw = grad_weights;
+  a.ldm = act_channels, a.ldo = out_channels, a.B = batch, a.H = H, a.W = W, a.G = groups;
+  a.tiles_x = cdiv(W, HF_TILE), a.tiles_y = cdiv(H, HF_TILE);
+  const int ntiles = batch * a.tiles_x * a.tiles_y;
+  a.tiles_per_wg = 1;
+  if (grad_acts)
+    hipLaunchKernelGGL(head_final_bwd_data_kernel, dim3(ntiles, groups), dim3(256), 0, stream, a);
+  if (grad_weights) {
+    DF3D_HIP(hipMemsetAsync(grad_weights, 0, (size_t)groups * 9 * HF_C * HF_KMAX * sizeof(float), stream));
+    a.tiles_per_wg = std::max(1, cdiv(ntiles, 64));             // <= 64 workgroups per branch add into its 2304 filters
+    hipLaunchKernelGGL(head_final_bwd_filter_kernel, dim3(cdiv(ntiles, a.tiles_per_wg), groups), dim3(256), 0, stream, a);
+  }
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

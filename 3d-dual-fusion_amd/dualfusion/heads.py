@@ -88,6 +88,34 @@ class _BranchConvFunction(torch.autograd.Function):
         return g_rows, g_w, g_b, None, None
 
 
+class _HeadFinalFunction(torch.autograd.Function):
+    """Final convolutions of all head branches (3x3, 64 -> 1..3 maps each) with autograd on the vector-ALU kernels of
+    csrc/headconv.hip: acts [P, G * 64] fp32 rows, w4 [G, 9, 64, 4], b4 [G, 4] -> packed maps [P, width]."""
+
+    @staticmethod
+    def forward(ctx, acts, w4, b4, cols, width, B, H, W):
+        acts = acts.contiguous()
+        w4d, b4d = w4.detach().float().contiguous(), b4.detach().float().contiguous()
+        out = _ops.head_final_conv(_ops.split_rows(acts), B, H, W, w4d, b4d, cols, width)
+        ctx.save_for_backward(acts, w4d, cols)
+        ctx.geom = (B, H, W)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        acts, w4d, cols = ctx.saved_tensors
+        B, H, W = ctx.geom
+        go = grad_out.contiguous().float()
+        g_a, g_w = _ops.head_final_conv_backward(acts, go, B, H, W, w4d.shape[0], w4d, cols)
+        # bias gradient: column sums of the packed maps, gathered into the [G, 4] layout (padding maps: 0)
+        sums = torch.cat([go.sum(0), go.new_zeros(1)])
+        c = cols.long()
+        j = torch.arange(4, device=go.device)
+        idx = torch.where(j[None, :] < c[:, 1:2], c[:, 0:1] + j[None, :], torch.full_like(c[:, 0:1], go.shape[1]))
+        return g_a, g_w, sums[idx], None, None, None, None, None
+
+
 class SepHead(nn.Module):
     def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, bn=False, init_bias=-2.19, **kwargs):
         super(SepHead, self).__init__(**kwargs)
@@ -266,12 +294,44 @@ class CenterHead(nn.Module):
             rets[t][head] = v
         return rets
 
+    def _final_pack(self, branches, dev):
+        """Index tensors that gather the [G, 9, 64, 4] / [G, 4] operands of the final-conv kernel out of the concatenated
+        (flattened) conv weights / biases of the branches (last element of the concatenation = 0 for the padding maps)."""
+        key = (tuple(fc[3].out_channels for _, _, fc in branches), str(dev))
+        hit = self.__dict__.get("_final_pack_cache")
+        if hit is not None and hit["key"] == key:
+            return hit
+        widx, bidx, cols, layout = [], [], [], []
+        wbase = bbase = c0 = 0
+        for _, _, fc in branches:
+            k = fc[3].out_channels
+            assert k <= 4 and fc[3].in_channels == 64 and fc[3].kernel_size == (3, 3)
+            j, c, tap = torch.meshgrid(torch.arange(4), torch.arange(64), torch.arange(9), indexing="ij")
+            idx = wbase + (j * 64 + c) * 9 + tap                         # weight [k, 64, 3, 3] flattened
+            idx = torch.where(j < k, idx, torch.full_like(idx, -1))
+            widx.append(idx.permute(2, 1, 0))                            # [tap, c, j]
+            bidx.append(torch.tensor([bbase + jj if jj < k else -1 for jj in range(4)]))
+            cols.append((c0, k))
+            layout.append((c0, k))
+            wbase += k * 64 * 9
+            bbase += k
+            c0 += k
+        widx = torch.stack(widx)
+        bidx = torch.stack(bidx)
+        widx[widx < 0] = wbase                                           # the appended zero
+        bidx[bidx < 0] = bbase
+        hit = dict(key=key, widx=widx.to(dev), bidx=bidx.to(dev), layout=layout, width=(c0 + 7) // 8 * 8,
+                   cols=torch.tensor(cols, dtype=torch.int32, device=dev).contiguous())
+        self.__dict__["_final_pack_cache"] = hit
+        return hit
+
     def forward_rows_train(self, x):
         """`forward` with autograd (training rows) over channels-last pixel rows: the shared
         convolution and the first convolution of all branches run on the sparse-convolution kernels (forward, input
         gradient and filter gradient; `_BranchConvFunction` batches the 36 branches into single launches), their
-        BatchNorms as ONE batch-statistics normalisation over the 36 x 64 planes; the final 64 -> classes convolutions
-        (1 - 3 maps each) stay the library's, per branch."""
+        BatchNorms as ONE batch-statistics normalisation (+ ReLU) over the 36 x 64 columns (csrc/bnrows.hip); the final
+        64 -> classes convolutions (1 - 3 maps each) on the vector-ALU kernels of csrc/headconv.hip (`_HeadFinalFunction`).
+        Every head map is a column slice of one [B*H*W, 72] buffer."""
         from .necks import _bn_rows, _rows_of, _train_stack
         F = torch.nn.functional
         tables = self.__dict__.setdefault("_train_tables", {})
@@ -285,29 +345,37 @@ class CenterHead(nn.Module):
             tables[mkey] = nbr.flip(0).contiguous()
         branches = [(t, head, getattr(task, head)) for t, task in enumerate(self.tasks) for head in task.heads]
         G = len(branches)
-        w = torch.stack([fc[0].weight.permute(2, 3, 1, 0).reshape(9, 64, 64) for _, _, fc in branches])
+        # [G, cout, cin, 3, 3] -> [G, tap, cin, cout] from ONE concatenation of the flattened filters
+        w = torch.cat([fc[0].weight.reshape(-1) for _, _, fc in branches]).view(G, 64, 64, 3, 3)
+        w = w.permute(0, 3, 4, 2, 1).reshape(G, 9, 64, 64)
         b = torch.cat([fc[0].bias for _, _, fc in branches])
         m = _BranchConvFunction.apply(s, w, b, nbr, tables[mkey])                       # [P, G * 64]
-        # rows [P, G * 64] -> one NCHW volume [B, G * 64, H, W] (a single layout change for all branches; the library's
-        # spatial BatchNorm and final convolutions want planes, and torch's channels-last BatchNorm kernels crawl at
-        # 2304 channels), ONE batch-statistics BatchNorm over the 36 x 64 planes, ReLU, the branches as channel slices
-        # (`split`: its backward is one concatenation -- indexing would zero-fill the whole volume per branch)
-        vol = m.view(B, H * W, G * 64).transpose(1, 2).contiguous().view(B, G * 64, H, W)
+        # ONE batch-statistics BatchNorm + ReLU over the 36 x 64 columns (row kernels), the running statistics copied back
         bns = [fc[1] for _, _, fc in branches]
-        training = bns[0].training
         mean = torch.cat([bn.running_mean for bn in bns])
         var = torch.cat([bn.running_var for bn in bns])
-        vol = F.batch_norm(vol, mean, var, torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns]),
-                           training, bns[0].momentum, bns[0].eps)
-        if training:
+        if bns[0].training and _ops.bn_rows_supported(G * 64):
+            m = _ops.BatchNormRowsFunction.apply(m, torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns]),
+                                                 mean, var, bns[0].momentum, bns[0].eps, True)
+        else:
+            m = torch.relu(F.batch_norm(m, mean, var, torch.cat([bn.weight for bn in bns]),
+                                        torch.cat([bn.bias for bn in bns]), bns[0].training, bns[0].momentum, bns[0].eps))
+        if bns[0].training:
             with torch.no_grad():
                 torch._foreach_copy_([bn.running_mean for bn in bns], list(mean.split(64)))
                 torch._foreach_copy_([bn.running_var for bn in bns], list(var.split(64)))
                 torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
-        maps = torch.relu(vol).split(64, dim=1)
+        # final convolutions of all branches: one launch forward, two backward; the [G, 9, 64, 4] filter bank is gathered
+        # from the flattened conv weights (one cat + one index: the gradient returns through the same two ops)
+        pack = self._final_pack(branches, m.device)
+        flat_w = torch.cat([fc[3].weight.reshape(-1) for _, _, fc in branches] + [m.new_zeros(1)])
+        flat_b = torch.cat([fc[3].bias for _, _, fc in branches] + [m.new_zeros(1)])
+        out = _HeadFinalFunction.apply(m, flat_w[pack["widx"]], flat_b[pack["bidx"]], pack["cols"], pack["width"], B, H, W)
         rets = [dict() for _ in self.tasks]
-        for g, (t, head, fc) in enumerate(branches):
-            rets[t][head] = fc[3](maps[g])
+        maps = out.view(B, H, W, -1)
+        for (t, head, fc), (c0, k) in zip(branches, pack["layout"]):
+            v = maps[..., c0:c0 + k].permute(0, 3, 1, 2)
+            rets[t][head] = v.clone() if head == 'hm' else v       # `loss` applies sigmoid_ to the heat maps in place
         return rets
 
     def loss(self, example, preds_dicts, batch_dict=None, host_copies=True, **kwargs):

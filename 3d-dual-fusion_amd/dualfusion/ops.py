@@ -1233,6 +1233,22 @@ def gather_points(features, idx):
     return out
 
 
+def head_final_conv_backward(acts, grad_out, batch, H, W, groups, weights, out_cols, want_acts=True, want_weights=True):
+    """Backward of `head_final_conv`: acts [P, C] fp32 (branch g at columns g*64 ..), grad_out [P, width] ->
+    (grad_acts [P, C] or None, grad_weights [G, 9, 64, 4] or None)."""
+    lib = _lib.load()
+    _chk(acts, torch.float32, "acts")
+    _chk(grad_out, torch.float32, "grad_out")
+    _chk(weights, torch.float32, "weights")
+    _chk(out_cols, torch.int32, "out_cols")
+    g_a = torch.zeros_like(acts) if (want_acts and acts.shape[1] > groups * 64) else (torch.empty_like(acts) if want_acts else None)
+    g_w = torch.empty_like(weights) if want_weights else None
+    rc = lib.df3d_head_final_conv_backward(_ptr(acts), acts.shape[1], _ptr(grad_out), grad_out.shape[1], int(batch), int(H),
+                                           int(W), int(groups), _ptr(weights), _ptr(out_cols), _ptr(g_a), _ptr(g_w), _stream())
+    _lib.check(rc, "df3d_head_final_conv_backward")
+    return g_a, g_w
+
+
 # ------------------------------------------------------------------------- BatchNorm over rows (training)
 def bn_rows_supported(c):
     return bool(_lib.load().df3d_bn_rows_supported(int(c)))

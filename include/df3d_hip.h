@@ -320,6 +320,13 @@ int df3d_centerhead_predict(const df3d_head_task *tasks, int ntasks, const df3d_
  * bias [groups][4]; out_cols [groups][2] = (first output column, valid maps) in out [batch*H*W, out_channels] fp32. */
 int df3d_head_final_conv(const void *in_split, int in_channels, int batch, int H, int W, int groups, const float *weights,
                          const float *bias, const int32_t *out_cols, float *out, int out_channels, void *stream);
+/* Backward of df3d_head_final_conv for training: `acts` [B*H*W][act_channels] are the fp32
+ * activations the forward convolved (branch g at columns g*64 ..), `grad_out` [B*H*W][out_channels] the gradient of the
+ * packed maps; grad_acts (same shape as acts; columns beyond groups*64 untouched) and / or grad_weights
+ * [groups][9][64][4] (zero-filled here) may be NULL. */
+int df3d_head_final_conv_backward(const float *acts, int act_channels, const float *grad_out, int out_channels, int batch,
+                                  int H, int W, int groups, const float *weights, const int32_t *out_cols,
+                                  float *grad_acts, float *grad_weights, void *stream);
 
 /* df3d_centerhead_loss replaces CenterHead.loss for a no-grad evaluation of the detection losses
  * (CP/det3d/models/bbox_heads/center_head.py:250-298 over FastFocalLoss / RegLoss,

@@ -5,7 +5,11 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name']]
+# a step ends with the optimizer: fused AdamW (kernel name mentions adam) or a burst of >= 30 multi_tensor_apply launches
+idx = [i for i, r in enumerate(rows) if 'adam' in r['Kernel_Name'].lower()]
+burst = 1
+if not idx:
+    idx, burst = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name']], 30
 cl, prev = [], -100
 for i in idx:
     if i - prev > 50:
@@ -13,7 +17,7 @@ for i in idx:
     else:
         cl[-1][1] = i
     prev = i
-cl = [c for c in cl if sum(1 for i in idx if c[0] <= i <= c[1]) >= 30]      # the optimizer's bursts only
+cl = [c for c in cl if sum(1 for i in idx if c[0] <= i <= c[1]) >= burst]
 a, b = cl[-3][1] + 1, cl[-2][1] + 1
 step = rows[a:b]
 print("step span %.2f ms, %d kernels" % ((int(step[-1]['End_Timestamp']) - int(step[0]['Start_Timestamp'])) / 1e6, len(step)))
