@@ -18,10 +18,15 @@ namespace df3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Double atomics from hundreds of workgroups onto the SAME 2 x C addresses serialise (~100 ns each: 43 us of a kernel whose
+// reads take 5): the sums live in BN_REPL replicas [replica][2][C], workgroup i adds into replica i % BN_REPL, readers add
+// the replicas up.
+constexpr int BN_REPL = 16;
+
 struct BnArgs {
   const float *x, *dy, *weight, *bias;
   float *y, *dx, *saved;        // saved [4][C]: mean, rstd, scale, shift
-  double *sums;                 // [2][C]
+  double *sums;                 // [BN_REPL][2][C]
   float *running_mean, *running_var, *dweight, *dbias;
   long long n;
   int c, cb, qb, rows_per_wg, rows_per_wg_red, relu;
@@ -66,16 +71,38 @@ __global__ __launch_bounds__(256) void bn_rows_stats_kernel(BnArgs a) {
     s += v;
     ss += v * v;
   }
-  bn_block_reduce(s, ss, a.qb, a.sums, col0, a.c);
+  bn_block_reduce(s, ss, a.qb, a.sums + (size_t)(blockIdx.x % BN_REPL) * 2 * a.c, col0, a.c);
+}
+
+// Column sums of this thread's four columns: row lane 0 adds the replicas up, the other row lanes of the workgroup read the
+// result from LDS (every thread adding 16 replicas itself doubled the apply kernels' time).
+__device__ __forceinline__ void bn_column_sums(const BnArgs &a, int col, int quad, int rl, double (&s1)[4], double (&s2)[4]) {
+  __shared__ double tot[64 * 8];
+  if (rl == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double x1 = 0.0, x2 = 0.0;
+      for (int r = 0; r < BN_REPL; ++r) {
+        x1 += a.sums[(size_t)r * 2 * a.c + col + e];
+        x2 += a.sums[(size_t)r * 2 * a.c + a.c + col + e];
+      }
+      tot[quad * 8 + e] = x1, tot[quad * 8 + 4 + e] = x2;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s1[e] = tot[quad * 8 + e], s2[e] = tot[quad * 8 + 4 + e];
 }
 
 // scale / shift of this thread's four columns from the column sums (the same arithmetic in every workgroup and in backward)
-__device__ __forceinline__ void bn_columns(const BnArgs &a, int col, f32x4 &mean, f32x4 &rstd, f32x4 &scale, f32x4 &shift,
-                                           f32x4 &var_unbiased) {
+__device__ __forceinline__ void bn_columns(const BnArgs &a, int col, int quad, int rl, f32x4 &mean, f32x4 &rstd, f32x4 &scale,
+                                           f32x4 &shift, f32x4 &var_unbiased) {
+  double s1[4], s2[4];
+  bn_column_sums(a, col, quad, rl, s1, s2);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const double m = a.sums[col + e] / (double)a.n;
-    double v = a.sums[a.c + col + e] / (double)a.n - m * m;
+    const double m = s1[e] / (double)a.n;
+    double v = s2[e] / (double)a.n - m * m;
     v = v > 0.0 ? v : 0.0;
     mean[e] = (float)m;
     rstd[e] = (float)(1.0 / sqrt(v + (double)a.eps));
@@ -90,7 +117,7 @@ __global__ __launch_bounds__(256) void bn_rows_apply_kernel(BnArgs a) {
   const int tid = threadIdx.x, quad = tid % a.qb, rl = tid / a.qb, rp = 256 / a.qb;
   const int col = blockIdx.y * a.cb + quad * 4;
   f32x4 mean, rstd, scale, shift, varu;
-  bn_columns(a, col, mean, rstd, scale, shift, varu);
+  bn_columns(a, col, quad, rl, mean, rstd, scale, shift, varu);
   if (blockIdx.x == 0 && rl == 0) {
     *(f32x4 *)(a.saved + col) = mean;
     *(f32x4 *)(a.saved + a.c + col) = rstd;
@@ -140,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_reduce_kernel(BnArgs a) {
     take(v1, g1);
   }
   for (; r < r1; r += rp) take(*(const f32x4 *)(a.x + r * a.c + col), *(const f32x4 *)(a.dy + r * a.c + col));
-  bn_block_reduce(sg, sgx, a.qb, a.sums, col0, a.c);
+  bn_block_reduce(sg, sgx, a.qb, a.sums + (size_t)(blockIdx.x % BN_REPL) * 2 * a.c, col0, a.c);
 }
 
 __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(BnArgs a) {
@@ -149,16 +176,18 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(BnArgs a) {
   const f32x4 mean = *(const f32x4 *)(a.saved + col), rstd = *(const f32x4 *)(a.saved + a.c + col);
   const f32x4 scale = *(const f32x4 *)(a.saved + 2 * a.c + col), shift = *(const f32x4 *)(a.saved + 3 * a.c + col);
   f32x4 mg, mgx;
+  double s1[4], s2[4];
+  bn_column_sums(a, col, quad, rl, s1, s2);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    mg[e] = (float)(a.sums[col + e] / (double)a.n);
-    mgx[e] = (float)(a.sums[a.c + col + e] / (double)a.n);
+    mg[e] = (float)(s1[e] / (double)a.n);
+    mgx[e] = (float)(s2[e] / (double)a.n);
   }
   if (blockIdx.x == 0 && rl == 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (a.dbias) a.dbias[col + e] = (float)a.sums[col + e];
-      if (a.dweight) a.dweight[col + e] = (float)a.sums[a.c + col + e];
+      if (a.dbias) a.dbias[col + e] = (float)s1[e];
+      if (a.dweight) a.dweight[col + e] = (float)s2[e];
     }
   }
   const long long r0 = (long long)blockIdx.x * a.rows_per_wg, r1 = min(r0 + a.rows_per_wg, a.n);
@@ -211,7 +240,7 @@ extern "C" int df3d_bn_rows_forward(const float *x, long long n, int c, const fl
   DF3D_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_rows_forward: running statistics come as a pair");
   a.x = x, a.weight = weight, a.bias = bias, a.y = y, a.saved = saved, a.sums = sums;
   a.running_mean = running_mean, a.running_var = running_var, a.relu = relu, a.eps = eps, a.momentum = momentum;
-  DF3D_HIP(hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(double), stream));
+  DF3D_HIP(hipMemsetAsync(sums, 0, (size_t)BN_REPL * 2 * c * sizeof(double), stream));
   const dim3 grid((unsigned)cdiv(n, (long long)a.rows_per_wg), c / a.cb);
   const dim3 grid_red((unsigned)cdiv(n, (long long)a.rows_per_wg_red), c / a.cb);
   hipLaunchKernelGGL(bn_rows_stats_kernel, grid_red, dim3(256), 0, stream, a);
@@ -228,7 +257,7 @@ extern "C" int df3d_bn_rows_backward(const float *x, const float *dy, long long 
   DF3D_CHECK_ARG(x && dy && saved && sums && dx, "bn_rows_backward: null argument");
   a.x = x, a.dy = dy, a.saved = const_cast<float *>(saved), a.sums = sums, a.dx = dx, a.dweight = dweight, a.dbias = dbias;
   a.relu = relu;
-  DF3D_HIP(hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(double), stream));
+  DF3D_HIP(hipMemsetAsync(sums, 0, (size_t)BN_REPL * 2 * c * sizeof(double), stream));
   const dim3 grid((unsigned)cdiv(n, (long long)a.rows_per_wg), c / a.cb);
   const dim3 grid_red((unsigned)cdiv(n, (long long)a.rows_per_wg_red), c / a.cb);
   hipLaunchKernelGGL(bn_rows_bwd_reduce_kernel, grid_red, dim3(256), 0, stream, a);
@@ -236,3 +265,5 @@ extern "C" int df3d_bn_rows_backward(const float *x, const float *dy, long long 
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }
+
+extern "C" int df3d_bn_rows_scratch_doubles(int c) { return BN_REPL * 2 * c; }

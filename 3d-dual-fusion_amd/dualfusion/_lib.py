@@ -84,6 +84,7 @@ SIGNATURES = {
     "df3d_conv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "df3d_conv_pack_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_bn_rows_supported": (c_int, [c_int]),
+    "df3d_bn_rows_scratch_doubles": (c_int, [c_int]),
     "df3d_bn_rows_forward": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_bn_rows_backward": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

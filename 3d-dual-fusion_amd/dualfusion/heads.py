@@ -116,6 +116,24 @@ class _HeadFinalFunction(torch.autograd.Function):
         return g_a, g_w, sums[idx], None, None, None, None, None
 
 
+class _PermuteGather(torch.autograd.Function):
+    """out = src[idx] where every element of `src` but the last (a zero used for padding slots) appears exactly once in
+    `idx`: the backward is the gather through the inverse index (`inv[i]` = position of src[i] in out), not an index_add."""
+
+    @staticmethod
+    def forward(ctx, src, idx, inv):
+        ctx.save_for_backward(inv)
+        return src.index_select(0, idx)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        inv, = ctx.saved_tensors
+        g = grad.contiguous().index_select(0, inv)
+        g[-1] = 0                                   # the padding zero is not a parameter
+        return g, None, None
+
+
 class SepHead(nn.Module):
     def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, bn=False, init_bias=-2.19, **kwargs):
         super(SepHead, self).__init__(**kwargs)
@@ -320,7 +338,13 @@ class CenterHead(nn.Module):
         bidx = torch.stack(bidx)
         widx[widx < 0] = wbase                                           # the appended zero
         bidx[bidx < 0] = bbase
+        def inverse(idx, n):                       # position of source element i in idx (the last source element: anywhere)
+            inv = torch.zeros(n + 1, dtype=torch.long)
+            flat = idx.reshape(-1)
+            inv[flat] = torch.arange(flat.numel())
+            return inv
         hit = dict(key=key, widx=widx.to(dev), bidx=bidx.to(dev), layout=layout, width=(c0 + 7) // 8 * 8,
+                   winv=inverse(widx, wbase).to(dev), binv=inverse(bidx, bbase).to(dev),
                    cols=torch.tensor(cols, dtype=torch.int32, device=dev).contiguous())
         self.__dict__["_final_pack_cache"] = hit
         return hit
@@ -370,7 +394,9 @@ class CenterHead(nn.Module):
         pack = self._final_pack(branches, m.device)
         flat_w = torch.cat([fc[3].weight.reshape(-1) for _, _, fc in branches] + [m.new_zeros(1)])
         flat_b = torch.cat([fc[3].bias for _, _, fc in branches] + [m.new_zeros(1)])
-        out = _HeadFinalFunction.apply(m, flat_w[pack["widx"]], flat_b[pack["bidx"]], pack["cols"], pack["width"], B, H, W)
+        w4 = _PermuteGather.apply(flat_w, pack["widx"].reshape(-1), pack["winv"]).view(G, 9, 64, 4)
+        b4 = _PermuteGather.apply(flat_b, pack["bidx"].reshape(-1), pack["binv"]).view(G, 4)
+        out = _HeadFinalFunction.apply(m, w4, b4, pack["cols"], pack["width"], B, H, W)
         rets = [dict() for _ in self.tasks]
         maps = out.view(B, H, W, -1)
         for (t, head, fc), (c0, k) in zip(branches, pack["layout"]):

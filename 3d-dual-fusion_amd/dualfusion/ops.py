@@ -1264,7 +1264,7 @@ class BatchNormRowsFunction(torch.autograd.Function):
         x = _chk(x.contiguous(), torch.float32, "x")
         n, c = x.shape
         dev = x.device
-        sums = torch.empty((2, c), dtype=torch.float64, device=dev)
+        sums = torch.empty((lib.df3d_bn_rows_scratch_doubles(c),), dtype=torch.float64, device=dev)
         saved = torch.empty((4, c), dtype=torch.float32, device=dev)
         y = torch.empty_like(x)
         w = weight.detach().float().contiguous() if weight is not None else None

@@ -233,10 +233,11 @@ int df3d_sparse_conv_grad_filters(const float *features, int n_in, int cin, cons
  * (CP/det3d/models/backbones/scn.py:51-118, necks/rpn.py:22-163, bbox_heads/center_head.py:66-110), optionally with the ReLU
  * that follows them.  forward: y = relu?((x - mean) * rstd * weight + bias) with the batch mean / biased variance of the
  * columns; running_mean / running_var (may be NULL) updated in place with `momentum` and the unbiased variance; `sums`
- * [2][c] doubles is scratch, `saved` [4][c] floats (mean, rstd, scale, shift) is what backward needs.  backward: dx, dweight
+ * (df3d_bn_rows_scratch_doubles(c) doubles) is scratch, `saved` [4][c] floats (mean, rstd, scale, shift) is what backward needs.  backward: dx, dweight
  * [c], dbias [c] (either may be NULL) from x, dy and `saved`; with relu != 0 the mask is recomputed from x.
  * Channel counts: multiples of 4 that divide 256 or are multiples of 256 (df3d_bn_rows_supported). */
 int df3d_bn_rows_supported(int c);
+int df3d_bn_rows_scratch_doubles(int c);
 int df3d_bn_rows_forward(const float *x, long long n, int c, const float *weight, const float *bias, float eps,
                          float momentum, int relu, float *running_mean, float *running_var, double *sums, float *saved,
                          float *y, void *stream);
