@@ -199,7 +199,7 @@ class CenterHead(nn.Module):
             return self.forward_rows_train(x)
         if (self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32
                 or _ops.CONV_PRECISION == "fp32" or not self._row_kernels_fit(x)):
-            return self.forward_reference(x.contiguous())
+            return self.forward_reference(x)
         # the head's own convolutions stay split precision (fp32-grade) in the bf16 mode of the backbone / neck
         return self.forward_rows(x)
 
