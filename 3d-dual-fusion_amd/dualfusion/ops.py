@@ -461,7 +461,13 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None):
     n_in = features.shape[0]
     grad_out = grad_out.contiguous()
     if inv is None:
-        inv = nbr.flip(0).contiguous() if subm else invert_neighbors(nbr, n_in)
+        if subm:          # the mirrored table IS the inverse table; kept with the table (a rulebook serves several layers)
+            inv = getattr(nbr, "_df3d_mirror", None)
+            if inv is None or inv[1] != nbr._version:
+                inv = nbr._df3d_mirror = (nbr.flip(0).contiguous(), nbr._version)
+            inv = inv[0]
+        else:
+            inv = invert_neighbors(nbr, n_in)
     wt = filters.transpose(1, 2).contiguous()                     # [K, cout, cin]
     cout, cin = wt.shape[1], wt.shape[2]
     if conv_split_supported(K, cout, cin):

@@ -233,3 +233,79 @@ def test_training_forward_backward_on_row_kernels_vs_float64():
     assert getattr(hd, "_train_tables", None) is None
     hd(xd)
     assert hd.__dict__.get("_train_tables")
+
+
+def test_final_conv_backward_kernels_vs_torch_float64():
+    """df3d_head_final_conv_backward (data gradient, filter gradient) and the bias gather of `_HeadFinalFunction` against
+    F.conv2d autograd in float64, branch by branch: ragged map sizes (tiles cut by the border), 1 / 2 / 3 maps per branch."""
+    from dualfusion.heads import _HeadFinalFunction
+    F = torch.nn.functional
+    B, H, W = 2, 11, 21
+    ks = [2, 1, 3, 2, 2, 1, 3]
+    G = len(ks)
+    gen = torch.Generator().manual_seed(5)
+    acts = torch.randn((B * H * W, G * 64), generator=gen)
+    ws = [torch.randn((k, 64, 3, 3), generator=gen) * 0.1 for k in ks]
+    bs = [torch.randn((k,), generator=gen) for k in ks]
+    cols, c0 = [], 0
+    for k in ks:
+        cols.append((c0, k))
+        c0 += k
+    width = (c0 + 7) // 8 * 8
+    go = torch.randn((B * H * W, width), generator=gen)
+    # float64 reference
+    a64 = acts.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in ws]
+    b64 = [b.double().requires_grad_(True) for b in bs]
+    vol = a64.view(B, H, W, G, 64).permute(3, 0, 4, 1, 2)
+    outs = [F.conv2d(vol[g], w64[g], b64[g], padding=1) for g in range(G)]
+    ref = torch.cat([o.permute(0, 2, 3, 1).reshape(B * H * W, -1) for o in outs], 1)
+    (ref * go[:, :c0].double()).sum().backward()
+    # device
+    ad = acts.to(DEV).requires_grad_(True)
+    w4 = torch.zeros((G, 9, 64, 4))
+    b4 = torch.zeros((G, 4))
+    for g, k in enumerate(ks):
+        w4[g, :, :, :k] = ws[g].permute(2, 3, 1, 0).reshape(9, 64, k)
+        b4[g, :k] = bs[g]
+    w4d, b4d = w4.to(DEV).requires_grad_(True), b4.to(DEV).requires_grad_(True)
+    out = _HeadFinalFunction.apply(ad, w4d, b4d, torch.tensor(cols, dtype=torch.int32, device=DEV), width, B, H, W)
+    (out * go.to(DEV)).sum().backward()
+    rel = lambda a, b: float((a.detach().cpu().double() - b).abs().max() / float(b.abs().max()))
+    assert rel(out[:, :c0], ref.detach()) < 1e-5
+    assert rel(ad.grad, a64.grad) < 1e-5
+    for g, k in enumerate(ks):
+        assert rel(w4d.grad[g, :, :, :k], w64[g].grad.permute(2, 3, 1, 0).reshape(9, 64, k)) < 1e-5, g
+        assert float(w4d.grad[g, :, :, k:].abs().max()) == 0.0 if k < 4 else True
+        assert rel(b4d.grad[g, :k], b64[g].grad) < 1e-5, g
+
+
+def test_branch_conv_function_vs_torch_float64():
+    """`_BranchConvFunction` (grouped forward, grouped input gradient + sum, one filter-gradient launch) against G separate
+    F.conv2d in float64."""
+    from dualfusion import ops
+    from dualfusion.heads import _BranchConvFunction
+    if ops.CONV_PRECISION != "split":
+        pytest.skip("split-precision kernels only")
+    F = torch.nn.functional
+    B, H, W, G = 2, 9, 14, 6
+    gen = torch.Generator().manual_seed(6)
+    rows = torch.randn((B * H * W, 64), generator=gen)
+    w = torch.randn((G, 64, 64, 3, 3), generator=gen) * 0.05            # [G, cout, cin, 3, 3]
+    b = torch.randn((G * 64,), generator=gen)
+    go = torch.randn((B * H * W, G * 64), generator=gen)
+    r64, w64, b64 = rows.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    x = r64.view(B, H, W, 64).permute(0, 3, 1, 2)
+    ref = torch.cat([F.conv2d(x, w64[g], b64[g * 64:(g + 1) * 64], padding=1).permute(0, 2, 3, 1).reshape(-1, 64)
+                     for g in range(G)], 1)
+    (ref * go.double()).sum().backward()
+    nbr = ops.conv2d_neighbors(B, H, W, 3, 3, 1, 1, False, DEV)[0]
+    rd, bd = rows.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    out = _BranchConvFunction.apply(rd, wd.permute(0, 3, 4, 2, 1).reshape(G, 9, 64, 64), bd, nbr, nbr.flip(0).contiguous())
+    (out * go.to(DEV)).sum().backward()
+    rel = lambda a, c: float((a.detach().cpu().double() - c).abs().max() / float(c.abs().max()))
+    assert rel(out, ref.detach()) < 1e-4
+    assert rel(rd.grad, r64.grad) < 1e-4
+    assert rel(wd.grad, w64.grad) < 1e-4
+    assert rel(bd.grad, b64.grad) < 1e-4
