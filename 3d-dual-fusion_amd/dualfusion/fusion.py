@@ -112,7 +112,7 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
         pt = _linear_rows(pt, self.reduced_dim2.weight[:, :, 0, 0], self.reduced_dim2.bias)          # [NI, HW, last]
         summary = torch.matmul(self.reduced_dim3.weight[:, :, 0, 0], img_feat.reshape(NI, Ci, H * W))   # [NI, 1, HW]
         fused = pt + (summary.transpose(1, 2) + self.reduced_dim3.bias)
-        taps = F.linear(fused, self.spatial_basic.weight[0].permute(1, 2, 0).reshape(9, -1))         # [NI, HW, 9]
+        taps = _linear_rows(fused, self.spatial_basic.weight[0].permute(1, 2, 0).reshape(9, -1))     # [NI, HW, 9]
         taps = F.pad(taps.view(NI, H, W, 9), (0, 0, 1, 1, 1, 1))                                     # zero padding of the 3x3
         y = self.spatial_basic.bias.view(1, 1, 1)
         for ty in range(3):
@@ -129,31 +129,48 @@ def _col_sum(g2):
     its rows on 192 threads (2.5 ms on MI355X; rocBLAS' gemv for ones^T g is no faster); the first stage of the split has
     n / d x c independent outputs."""
     n = g2.shape[0]
-    d = _SUM_SPLIT.get(n)
-    if d is None:
-        d = next((k for k in range(min(n, 2048), 63, -1) if n % k == 0), 0)
-        _SUM_SPLIT[n] = d
+    d = _row_split(n)
     if d == 0 or n // d < 8:
         return g2.sum(0)
     return g2.view(n // d, d, g2.shape[1]).sum(1).sum(0)
 
 
-class _AddBias(torch.autograd.Function):
-    """y + bias over the last dimension with the bias gradient through `_col_sum`."""
+def _row_split(n):
+    d = _SUM_SPLIT.get(n)
+    if d is None:
+        d = next((k for k in range(min(n, 2048), 63, -1) if n % k == 0), 0)
+        _SUM_SPLIT[n] = d
+    return d
+
+
+class _LinearRows(torch.autograd.Function):
+    """F.linear over a few hundred thousand pixel rows with few channels.  The library's backward is two long
+    reductions -- the bias gradient (`_col_sum`) and the weight gradient g^T x with K = rows, for which hipBLASLt picks a
+    32 x 32 x 256 tile without split-K (550 us for 120 MB): here a batched product over row chunks, then the sum of the
+    per-chunk [cout, cin] matrices."""
 
     @staticmethod
-    def forward(ctx, y, bias):
-        return y + bias
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        return g, _col_sum(g.reshape(-1, g.shape[-1]))
+        x, weight = ctx.saved_tensors
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        gx = (g2 @ weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        n, d = g2.shape[0], _row_split(g2.shape[0])
+        if d and n // d >= 8:
+            gw = torch.bmm(g2.view(n // d, d, -1).transpose(1, 2), x2.view(n // d, d, -1)).sum(0)
+        else:
+            gw = g2.t() @ x2
+        return gx, gw, (_col_sum(g2) if ctx.has_bias else None)
 
 
-def _linear_rows(x, weight, bias):
-    y = F.linear(x, weight)
-    return y if bias is None else _AddBias.apply(y, bias)
+def _linear_rows(x, weight, bias=None):
+    return _LinearRows.apply(x, weight, bias)
 
 
 ifat_all = {'Basicgate_patch_iv_multivoxel': Basicgate_patch_iv_multivoxel}
