@@ -69,6 +69,27 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     return outids, pairs, num
 
 
+def _half_entry(fn):
+    """The reference registers every op twice, `*_fp32` and `*_half` (TF/mmdet3d/ops/spconv/src/all.cc:21-51, dispatched
+    on the dtype in ops.py:112-184).  Here fp16 tensors ride the fp32 kernels: rows and filters are widened (exact), the
+    products accumulate in fp32 (the reference's half GEMM rounds its accumulator to fp16 at least once per offset), and
+    every floating-point result is rounded to fp16 once."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        half = any(isinstance(a, torch.Tensor) and a.dtype == torch.float16 for a in args)
+        if not half:
+            return fn(*args, **kwargs)
+        args = [a.float() if isinstance(a, torch.Tensor) and a.dtype == torch.float16 else a for a in args]
+        out = fn(*args, **kwargs)
+        if isinstance(out, (list, tuple)):
+            return type(out)(o.half() if isinstance(o, torch.Tensor) and o.is_floating_point() else o for o in out)
+        return out.half()
+    return wrapped
+
+
+@_half_entry
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
     """sparse_conv_ext.indice_conv_fp32 (spconv_ops.h:260-361) from a reference-format rulebook."""
     if features.dtype != torch.float32:
@@ -83,6 +104,7 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
                                   int(num_activate_out))
 
 
+@_half_entry
 def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
     """sparse_conv_ext.indice_conv_backward_fp32 (spconv_ops.h:363-456) from a reference-format rulebook:
     -> [input_grad [N_in, Cin], filters_grad (shape of `filters`)]."""
@@ -99,6 +121,7 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     return [g_in, g_w.view_as(filters)]
 
 
+@_half_entry
 def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, num_activate_out, inverse, subm):
     """sparse_conv_ext.fused_indice_conv_fp32 (fused_spconv_ops.h:28-132): conv + bias."""
     pairs = indice_pairs.contiguous()
@@ -111,6 +134,7 @@ def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, nu
                                   int(num_activate_out), bias=bias.contiguous())
 
 
+@_half_entry
 def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
     """sparse_conv_ext.indice_maxpool_fp32 (pool_ops.h:26-58) from a reference-format rulebook."""
     if features.dtype != torch.float32:
@@ -119,6 +143,7 @@ def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
     return _ops.sparse_maxpool(features.contiguous(), nbr, int(num_activate_out))
 
 
+@_half_entry
 def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num):
     """sparse_conv_ext.indice_maxpool_backward_fp32 (pool_ops.h:60-94)."""
     if features.dtype != torch.float32:

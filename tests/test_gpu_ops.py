@@ -942,3 +942,42 @@ def test_batch_norm_rows_kernels_vs_float64(n, c, relu):
     assert rel(bn.weight.grad, ref.weight.grad) < tol and rel(bn.bias.grad, ref.bias.grad) < tol
     assert rel(bn.running_mean, ref.running_mean) < 1e-5 and rel(bn.running_var, ref.running_var) < 1e-5
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+def test_half_entry_points_of_the_spconv_mirror(dev):
+    """`*_half` registrations of the reference extension (src/all.cc:21-51; ops.py:112-184 dispatches on the dtype): fp16
+    features / filters through `spconv.ops.indice_conv`, `fused_indice_conv`, `indice_conv_backward`, `indice_maxpool` --
+    fp16 in, fp16 out, equal to the fp32 entry on the widened operands rounded once."""
+    from dualfusion import spconv
+    shape, batch = [8, 20, 24], 2
+    ind = detgen.clustered_voxels("half", batch, shape, n_seeds=4, walk=150)
+    f = (detgen.randn("half_f", (len(ind), 16)) * 0.5).astype(np.float16)
+    w = (detgen.randn("half_w", (3, 3, 3, 16, 32)) * 0.1).astype(np.float16)
+    b = detgen.randn("half_b", (32,), 0.1).astype(np.float16)
+    outids, pairs, num = spconv.ops.get_indice_pairs(T(ind, dev), batch, shape, 3, 2, 1, 1, subm=False)
+    n_out = outids.shape[0]
+    fh, wh, bh = T(f, dev), T(w, dev), T(b, dev)
+    assert fh.dtype == torch.float16
+    y = spconv.ops.indice_conv(fh, wh, pairs, num, n_out)
+    y32 = spconv.ops.indice_conv(fh.float(), wh.float(), pairs, num, n_out)
+    assert y.dtype == torch.float16 and torch.equal(y, y32.half())
+    yb = spconv.ops.fused_indice_conv(fh, wh, bh, pairs, num, n_out, False, False)
+    assert yb.dtype == torch.float16
+    assert torch.equal(yb, spconv.ops.fused_indice_conv(fh.float(), wh.float(), bh.float(), pairs, num, n_out, False, False).half())
+    go = T((detgen.randn("half_g", (n_out, 32)) * 0.5).astype(np.float16), dev)
+    gi, gw = spconv.ops.indice_conv_backward(fh, wh, go, pairs, num)
+    gi32, gw32 = spconv.ops.indice_conv_backward(fh.float(), wh.float(), go.float(), pairs, num)
+    assert gi.dtype == gw.dtype == torch.float16 and tuple(gw.shape) == tuple(wh.shape)
+    assert torch.equal(gi, gi32.half())
+    assert float((gw.float() - gw32).abs().max()) <= 2e-3 * float(gw32.abs().max())      # atomics: summation order varies
+    p = spconv.ops.indice_maxpool(fh, pairs, num, n_out)
+    assert p.dtype == torch.float16 and torch.equal(p, spconv.ops.indice_maxpool(fh.float(), pairs, num, n_out).half())
+    # float64 reference of the convolution itself (fp16 operands are exact in float64)
+    pr, nm = pairs.cpu().numpy(), num.cpu().numpy()
+    ref = np.zeros((n_out, 32))
+    f64, w64 = f.astype(np.float64), w.astype(np.float64).reshape(27, 16, 32)
+    for k in range(27):
+        i, o = pr[k, 0, :nm[k]], pr[k, 1, :nm[k]]
+        np.add.at(ref, o, f64[i] @ w64[k])
+    assert np.abs(y.float().cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
