@@ -981,3 +981,19 @@ def test_half_entry_points_of_the_spconv_mirror(dev):
         i, o = pr[k, 0, :nm[k]], pr[k, 1, :nm[k]]
         np.add.at(ref, o, f64[i] @ w64[k])
     assert np.abs(y.float().cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,m,ns,rmin,rmax", [(24000, 2051, 16, 0.0, 1.0), (5000, 300, 70, 0.5, 3.0), (1024, 16, 8, 0.0, 0.05),
+                                              (777, 5, 32, 1.0, 40.0)])
+def test_ball_query_wave_kernel_vs_oracle(dev, N, m, ns, rmin, rmax):
+    """The wave-per-centre ball query against the reference's serial scan (oracle): index order of the hits, the first hit
+    repeated in unused slots, zero rows for centres without a hit, the d2 == 0 clause with a positive inner radius, more
+    samples than lanes, row counts that do not fill a tile / a workgroup."""
+    from dualfusion import ops
+    xyz = detgen.rand("bqw_xyz%d" % N, (2, N, 3), -20, 20)
+    new_xyz = np.concatenate([xyz[:, : m // 2], detgen.rand("bqw_c%d" % N, (2, m - m // 2, 3), -25, 25)], 1)
+    got = ops.ball_query(rmin, rmax, ns, T(xyz, dev), T(new_xyz, dev)).cpu().numpy()
+    want = orc.ball_query(rmin, rmax, ns, xyz, new_xyz)
+    assert np.array_equal(got, want)
+    assert (want[:, m // 2:].max(-1) == 0).any() or rmax > 10          # some centres really have no hit
