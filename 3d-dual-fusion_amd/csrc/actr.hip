@@ -36,43 +36,54 @@ __global__ __launch_bounds__(256) void actr_prep_kernel(const float *__restrict_
   ((f32x4 *)Bw)[i] = lq + (b + p);          // (q + pos) + (qi + pos): the reference's association
 }
 
-// one wave per row; C <= 1024, C % 4 == 0
+// LPR lanes per row (16 / 32 / 64: the smallest that covers C / 4 vectors, so a 64-channel row keeps a quarter wave busy and a
+// wave normalises four rows -- one wave per row left 48 of 64 lanes idle there: 113 us for 262 k rows); C <= 1024, C % 4 == 0
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPR>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float eps, long long rows,
                                                             int C, float *__restrict__ out) {
-  long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
-  if (row >= rows) return;
+  constexpr int RPW = 64 / LPR, NK = LPR == 64 ? 4 : 1;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const long long row = wave * RPW + lane / LPR;
+  const bool live = row < rows;
   const int nv = C / 4;
-  f32x4 v[4];
+  f32x4 v[NK];
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int c4 = lane + 64 * k;
+  for (int k = 0; k < NK; ++k) {
+    int c4 = sub + LPR * k;
     v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (c4 < nv) {
+    if (live && c4 < nv) {
       f32x4 a = ((const f32x4 *)(x + row * C))[c4];
       if (y) a += ((const f32x4 *)(y + row * C))[c4];
       v[k] = a;
       s += a[0] + a[1] + a[2] + a[3];
     }
   }
-  float mean = wave_sum(s) / (float)C;
+  float mean = group_sum<LPR>(s) / (float)C;
   float ss = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int c4 = lane + 64 * k;
+  for (int k = 0; k < NK; ++k) {
+    int c4 = sub + LPR * k;
     if (c4 < nv) {
       f32x4 d = v[k] - mean;
       ss += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
     }
   }
-  float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  float rstd = rsqrtf(group_sum<LPR>(ss) / (float)C + eps);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int c4 = lane + 64 * k;
-    if (c4 < nv) {
+  for (int k = 0; k < NK; ++k) {
+    int c4 = sub + LPR * k;
+    if (live && c4 < nv) {
       f32x4 g = ((const f32x4 *)gamma)[c4], b = ((const f32x4 *)beta)[c4];
       ((f32x4 *)(out + row * C))[c4] = (v[k] - mean) * rstd * g + b;
     }
@@ -411,8 +422,15 @@ extern "C" int df3d_add_layernorm(const float *x, const float *y, const float *g
   DF3D_CHECK_ARG(x && gamma && beta && out, "add_layernorm: null argument");
   DF3D_CHECK_ARG(C % 4 == 0 && C <= 1024, "add_layernorm: C must be a multiple of 4 and <= 1024 (got %d)", C);
   if (rows == 0) return DF3D_OK;
-  hipLaunchKernelGGL(add_layernorm_kernel, dim3(cdiv(rows * 64, 256)), dim3(256), 0, stream, x, y, gamma, beta, eps,
-                     rows, C, out);
+  if (C <= 64)
+    hipLaunchKernelGGL(add_layernorm_kernel<16>, dim3(cdiv(cdiv(rows, 4) * 64, 256)), dim3(256), 0, stream, x, y, gamma, beta,
+                       eps, rows, C, out);
+  else if (C <= 128)
+    hipLaunchKernelGGL(add_layernorm_kernel<32>, dim3(cdiv(cdiv(rows, 2) * 64, 256)), dim3(256), 0, stream, x, y, gamma, beta,
+                       eps, rows, C, out);
+  else
+    hipLaunchKernelGGL(add_layernorm_kernel<64>, dim3(cdiv(rows * 64, 256)), dim3(256), 0, stream, x, y, gamma, beta, eps,
+                       rows, C, out);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -412,7 +412,7 @@ def test_msda_fused_bf16_value(dev, D, L, P, wide):
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-3, atol=5e-5)
 
 
-@pytest.mark.parametrize("C,rows", [(128, 1000), (64, 77), (256, 3), (1024, 5), (16, 130)])
+@pytest.mark.parametrize("C,rows", [(128, 1000), (64, 77), (256, 3), (1024, 5), (16, 130), (20, 9), (100, 31), (132, 6)])
 def test_actr_rowwise_kernels(dev, C, rows):
     """actr_prep / add_layernorm / bigate_sum against the torch expressions the reference layer runs
     (actr_transformer.py:399-426, attentions.py:96-117), fp32 within 1e-5."""
