@@ -334,6 +334,81 @@ extern "C" int df3d_furthest_point_sample(const float *xyz, int B, int N, int m,
   return DF3D_OK;
 }
 
+// Self-attention inside small groups (the LocalTransformer of ACTRv2, VR/pcdet/models/.../pointformer.py:10-44 through
+// nn.MultiheadAttention: L = nsample tokens per ball-query group, heads of 16 channels).  qkv [L * G][3 * C] fp32 rows in the
+// encoder's sequence-first order (row = token * G + group; q | k | v column blocks, the in-projection's output), out
+// [L * G][C].  A workgroup owns a group: K and V of its L tokens in LDS, thread = (token, head): scores against the L keys
+// with an online softmax, 16 accumulators.  The library's flash kernel spends 300 us per layer on these 16 k sequences of 32.
+template <int D>
+__global__ void group_attention_kernel(const float *__restrict__ qkv, int L, int G, int H, float scale,
+                                       float *__restrict__ out) {
+  extern __shared__ __align__(16) float ga_smem[];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int C = H * D, g = blockIdx.x, tid = threadIdx.x;
+  float *sk = ga_smem, *sv = ga_smem + (size_t)L * C;
+  const int c4n = C / 4;
+  for (int it = tid; it < L * c4n * 2; it += blockDim.x) {
+    const int kv = it / (L * c4n), r = it - kv * (L * c4n);
+    const int t = r / c4n, c4 = r - t * c4n;
+    const f4 v = *(const f4 *)(qkv + ((size_t)t * G + g) * 3 * C + (1 + kv) * C + c4 * 4);
+    *(f4 *)((kv ? sv : sk) + t * C + c4 * 4) = v;
+  }
+  __syncthreads();
+  if (tid >= L * H) return;
+  const int h = tid / L, t = tid - h * L;
+  float q[D], acc[D];
+  const float *qp = qkv + ((size_t)t * G + g) * 3 * C + h * D;
+#pragma unroll
+  for (int e = 0; e < D; e += 4) {
+    const f4 v = *(const f4 *)(qp + e);
+    q[e] = v[0] * scale, q[e + 1] = v[1] * scale, q[e + 2] = v[2] * scale, q[e + 3] = v[3] * scale;
+  }
+#pragma unroll
+  for (int e = 0; e < D; ++e) acc[e] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const float *kp = sk + j * C + h * D, *vp = sv + j * C + h * D;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < D; e += 4) {
+      const f4 k4 = *(const f4 *)(kp + e);
+      s = fmaf(q[e], k4[0], s), s = fmaf(q[e + 1], k4[1], s), s = fmaf(q[e + 2], k4[2], s), s = fmaf(q[e + 3], k4[3], s);
+    }
+    const float mn = fmaxf(m, s);
+    const float a = __expf(m - mn), p = __expf(s - mn);
+    l = l * a + p;
+#pragma unroll
+    for (int e = 0; e < D; e += 4) {
+      const f4 v4 = *(const f4 *)(vp + e);
+      acc[e] = fmaf(p, v4[0], acc[e] * a), acc[e + 1] = fmaf(p, v4[1], acc[e + 1] * a);
+      acc[e + 2] = fmaf(p, v4[2], acc[e + 2] * a), acc[e + 3] = fmaf(p, v4[3], acc[e + 3] * a);
+    }
+    m = mn;
+  }
+  const float inv = 1.f / l;
+  float *op = out + ((size_t)t * G + g) * C + h * D;
+#pragma unroll
+  for (int e = 0; e < D; e += 4) *(f4 *)(op + e) = (f4){acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv};
+}
+
+extern "C" int df3d_group_attention(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out,
+                                    void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(qkv && out, "group_attention: null argument");
+  DF3D_CHECK_ARG(tokens >= 1 && groups >= 0 && heads >= 1 && head_dim == 16, "group_attention: heads of 16 channels only (got %d)",
+                 head_dim);
+  const int C = heads * head_dim;
+  const size_t lds = (size_t)2 * tokens * C * sizeof(float);
+  DF3D_CHECK_ARG(tokens * heads <= 1024 && lds <= 64 * 1024, "group_attention: %d tokens x %d heads does not fit a workgroup",
+                 tokens, heads);
+  if (groups == 0) return DF3D_OK;
+  const int threads = cdiv(tokens * heads, 64) * 64;
+  hipLaunchKernelGGL(group_attention_kernel<16>, dim3(groups), dim3(threads), lds, stream, qkv, tokens, groups, heads,
+                     1.f / sqrtf((float)head_dim), out);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
 extern "C" int df3d_ball_query(const float *new_xyz, const float *xyz, int B, int N, int m, float min_radius,
                                float max_radius, int nsample, int32_t *idx, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;

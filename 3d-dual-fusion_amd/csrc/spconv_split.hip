@@ -1373,7 +1373,8 @@ static bool split_shape_wide(int cin, int cout) {      // served by the output-s
 }
 
 static bool split_shape_head(int cin, int cout) {      // detection heads: shared conv 512 -> 64 | 128, final convs -> <= 32
-  return (cin == 512 && (cout == 64 || cout == 128)) || ((cin == 64 || cin == 128) && cout == 32);
+  return (cin == 512 && (cout == 64 || cout == 128)) || ((cin == 64 || cin == 128) && cout == 32) ||
+         (cin == 128 && cout == 64);                       // + the second linear of a 64-channel transformer FFN
 }
 
 // output-stationary launch of any served (cin, cout per column block) pair
@@ -1420,6 +1421,7 @@ static int launch_os_any(int cin, int cout, const SplitConvArgs &a, hipStream_t 
   if (cin == 512 && cout == 64) return launch_os_split_wide<512, 64>(a, stream);
   if (cin == 512 && cout == 128) return launch_os_split_wide<512, 128>(a, stream);
   if (cin == 128 && cout == 32) return launch_os_split<128, 32>(a, stream);
+  if (cin == 128 && cout == 64) return launch_os_split<128, 64>(a, stream);
   if (cin == 128 && cout == 128) return launch_os_split<128, 128>(a, stream);
   if (cin == 64 && cout == 128) return launch_os_split<64, 128>(a, stream);
   if (cin == 64 && cout == 64) return launch_os_split<64, 64>(a, stream);

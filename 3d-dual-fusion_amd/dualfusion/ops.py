@@ -1322,3 +1322,49 @@ def batch_norm_rows(bn, x, relu=False):
                          bn.running_var if not bn.training or bn.track_running_stats else None,
                          bn.weight, bn.bias, use_batch, momentum, bn.eps)
     return torch.relu(y) if relu else y
+
+
+# ------------------------------------------------------------------------- small-group transformer layers on row kernels
+def group_attention(qkv, tokens, groups, heads):
+    """softmax(q k^T / sqrt(16)) v inside every group: qkv [tokens * groups, 3 * heads * 16] fp32 rows (row = token * groups +
+    group; q | k | v blocks) -> [tokens * groups, heads * 16]."""
+    lib = _lib.load()
+    _chk(qkv, torch.float32, "qkv")
+    C = heads * 16
+    if qkv.shape != (tokens * groups, 3 * C):
+        raise ValueError("qkv must be [tokens * groups, 3 * heads * 16]")
+    out = torch.empty((tokens * groups, C), dtype=torch.float32, device=qkv.device)
+    rc = lib.df3d_group_attention(_ptr(qkv), int(tokens), int(groups), int(heads), 16, _ptr(out), _stream())
+    _lib.check(rc, "df3d_group_attention")
+    return out
+
+
+_IDENTITY_TABLES = {}
+
+
+def identity_table(n, device):
+    """[1, n] int32 neighbour table of a 1x1 'convolution' over rows: a linear layer on the split-precision conv kernels."""
+    key = (int(n), str(device))
+    t = _IDENTITY_TABLES.get(key)
+    if t is None:
+        if len(_IDENTITY_TABLES) > 8:
+            _IDENTITY_TABLES.clear()
+        t = _IDENTITY_TABLES[key] = torch.arange(n, dtype=torch.int32, device=device).view(1, n)
+    return t
+
+
+def packed_linear(weight, group=None):
+    """nn.Linear weight [cout, cin] -> packed split-precision operand of the conv kernels (kept with the weight): one bank
+    [1, cin, cout], or with `group` columns per bank cout / group banks (wide outputs through `conv_rows_split`)."""
+    hit = getattr(weight, "_df3d_packed_linear", None)
+    key = (weight._version, group, CONV_PRECISION)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = weight.detach().float()
+    cout, cin = w.shape
+    if group is None:
+        packed = conv_pack_weights(w.t().contiguous().view(1, cin, cout))
+    else:
+        packed = conv_pack_weights_groups(w.view(cout // group, group, cin).transpose(1, 2).contiguous().view(cout // group, 1, cin, group))
+    weight._df3d_packed_linear = (key, packed)
+    return packed

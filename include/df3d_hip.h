@@ -467,6 +467,12 @@ int df3d_ms_deform_attn_backward(const float *value, const int64_t *spatial_shap
                                  int S, int M, int D, int Lq, int L, int P, float *grad_value,
                                  float *grad_sampling_loc, float *grad_attn_weight, void *stream);
 
+/* Self-attention inside small token groups: nn.MultiheadAttention's scaled-dot-product core for the LocalTransformer of
+ * ACTRv2 (VR/pcdet/models/backbones_3d/.../pointformer.py:10-44, 232-262): qkv [tokens*groups][3*heads*16] fp32 rows in
+ * sequence-first order (row = token * groups + group; the in-projection's q | k | v blocks) -> out [tokens*groups][heads*16];
+ * softmax(q k^T / 4) v per group and head, no masks. */
+int df3d_group_attention(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Point ops of LocalTransformer (CP/det3d/models/model_utils/pointformer.py:349-380).
  * furthest_point_sampling_wrapper (CP/det3d/ops/furthest_point_sample/src/

@@ -527,3 +527,34 @@ def test_training_step_gradients_vs_dense_torch():
                             (seq[1].bias.grad, b1.grad, "bn1.bias")):
         err = float((got.cpu().double() - want).abs().max() / max(1.0, float(want.abs().max())))
         assert err <= 2e-4, (name, err)
+
+
+@pytest.mark.parametrize("L,G", [(32, 70), (16, 257), (5, 3)])
+def test_local_transformer_layer_on_row_kernels_vs_float64(L, G):
+    """TransformerEncoderLayerPreNorm at the ACTRv2 sizes (64 channels, 4 heads of 16, FFN 128): the row-kernel path
+    (`_forward_rows`: conv kernels over an identity table for the four linears, `df3d_group_attention`, fused
+    add + LayerNorm) against the module's torch composition in float64 (pointformer.py:10-44)."""
+    import copy
+    from dualfusion import ops
+    from dualfusion.pointformer import TransformerEncoderLayerPreNorm
+    if ops.CONV_PRECISION != "split":
+        pytest.skip("row path of the layer runs on the split-precision kernels")
+    dev = torch.device("cuda:0")
+    m = TransformerEncoderLayerPreNorm(d_model=64, nhead=4, dim_feedforward=128, dropout=0.0).eval()
+    sd = detgen.det_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = torch.from_numpy(detgen.randn("ltl_x_%d_%d" % (L, G), (L, G, 64)))
+    with torch.no_grad():
+        ref = copy.deepcopy(m).double()(x.double())
+        md = m.to(dev)
+        assert md._rows_fit(x.to(dev), None, None)
+        y = md(x.to(dev))
+    err = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
+    # the attention core alone against torch's
+    qkv = torch.from_numpy(detgen.randn("ltl_qkv_%d_%d" % (L, G), (L * G, 192)))
+    o = ops.group_attention(qkv.to(dev), L, G, 4).cpu()
+    q, k, v = [t.view(L, G, 4, 16).permute(1, 2, 0, 3).double() for t in qkv.split(64, 1)]
+    want = torch.softmax(q @ k.transpose(-1, -2) / 4.0, -1) @ v                          # [G, H, L, 16]
+    want = want.permute(2, 0, 1, 3).reshape(L * G, 64)
+    assert float((o.double() - want).abs().max()) < 1e-5
