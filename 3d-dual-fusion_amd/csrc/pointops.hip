@@ -11,6 +11,7 @@
 #include <math.h>
 
 #include "common.h"
+#include <algorithm>
 
 namespace df3d {
 
@@ -405,6 +406,62 @@ extern "C" int df3d_group_attention(const float *qkv, int tokens, int groups, in
   const int threads = cdiv(tokens * heads, 64) * 64;
   hipLaunchKernelGGL(group_attention_kernel<16>, dim3(groups), dim3(threads), lds, stream, qkv, tokens, groups, heads,
                      1.f / sqrtf((float)head_dim), out);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+// Grouped features + positional MLP of the LocalTransformer in one pass (pointformer.py:232-262: x = group(features) +
+// pe(grouped xyz), pe = Conv1x1(3 -> C/2) + BN + ReLU + Conv1x1(C/2 -> C); BN folded by the caller):
+//   out[r][:] = feat[sel[r]][:] + W1 relu(W0 xyz[r] + b0) + b1
+// 16 lanes x 4 channels per row (C = 64), the 3 -> C/2 layer recomputed per lane (96 FMAs), W1 transposed in LDS.  The library
+// runs the two tall-skinny products (K = 3, K = 32 over 524 k rows) at 300 us each and needs a gather and an add on top.
+__global__ __launch_bounds__(256) void pe_gather_add_kernel(const float *__restrict__ feat, const int64_t *__restrict__ sel,
+                                                            const float *__restrict__ xyz, const float *__restrict__ w0,
+                                                            const float *__restrict__ b0, const float *__restrict__ w1,
+                                                            const float *__restrict__ b1, long long rows, int C, int H1,
+                                                            float *__restrict__ out) {
+  extern __shared__ __align__(16) float pe_smem[];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  float *w1t = pe_smem;                     // [H1][C]
+  float *w0s = pe_smem + (size_t)H1 * C;     // [H1][4] = w0 row | b0
+  for (int i = threadIdx.x; i < H1 * C; i += 256) {
+    const int k = i / C, o = i - k * C;
+    w1t[i] = w1[(size_t)o * H1 + k];
+  }
+  for (int i = threadIdx.x; i < H1; i += 256) {
+    w0s[i * 4] = w0[i * 3], w0s[i * 4 + 1] = w0[i * 3 + 1], w0s[i * 4 + 2] = w0[i * 3 + 2], w0s[i * 4 + 3] = b0[i];
+  }
+  __syncthreads();
+  const int lpr = C / 4;                     // lanes per row
+  const int rpb = 256 / lpr;
+  const int sub = threadIdx.x % lpr;
+  for (long long r = (long long)blockIdx.x * rpb + threadIdx.x / lpr; r < rows; r += (long long)gridDim.x * rpb) {
+    const float x = xyz[r * 3], y = xyz[r * 3 + 1], z = xyz[r * 3 + 2];
+    f4 acc = *(const f4 *)(b1 + sub * 4);
+    for (int k = 0; k < H1; ++k) {
+      const f4 w = *(const f4 *)(w0s + k * 4);
+      const float h = fmaxf(fmaf(w[0], x, fmaf(w[1], y, fmaf(w[2], z, w[3]))), 0.f);
+      const f4 v = *(const f4 *)(w1t + (size_t)k * C + sub * 4);
+      acc[0] = fmaf(h, v[0], acc[0]), acc[1] = fmaf(h, v[1], acc[1]), acc[2] = fmaf(h, v[2], acc[2]), acc[3] = fmaf(h, v[3], acc[3]);
+    }
+    const f4 f = *(const f4 *)(feat + (size_t)sel[r] * C + sub * 4);
+    *(f4 *)(out + r * C + sub * 4) = acc + f;
+  }
+}
+
+extern "C" int df3d_pe_gather_add(const float *feat, const int64_t *sel, const float *xyz, const float *w0, const float *b0,
+                                  const float *w1, const float *b1, long long rows, int channels, int hidden, float *out,
+                                  void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(feat && sel && xyz && w0 && b0 && w1 && b1 && out, "pe_gather_add: null argument");
+  DF3D_CHECK_ARG(channels % 4 == 0 && channels >= 4 && 256 % (channels / 4) == 0 && hidden >= 1 &&
+                     (size_t)hidden * (channels + 4) * 4 <= 64 * 1024,
+                 "pe_gather_add: %d channels / %d hidden not served", channels, hidden);
+  if (rows == 0) return DF3D_OK;
+  const int rpb = 256 / (channels / 4);
+  const long long blocks = std::min<long long>(cdiv(rows, rpb), 4096);
+  hipLaunchKernelGGL(pe_gather_add_kernel, dim3((unsigned)blocks), dim3(256), (size_t)hidden * (channels + 4) * sizeof(float),
+                     stream, feat, sel, xyz, w0, b0, w1, b1, rows, channels, hidden, out);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -62,6 +62,8 @@ SIGNATURES = {
     "df3d_ms_deform_attn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                              c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_furthest_point_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_pe_gather_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int,
+                                   c_void_p, c_void_p]),
     "df3d_group_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_ball_query": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p]),
     "df3d_group_points": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

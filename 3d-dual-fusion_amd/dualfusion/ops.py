@@ -1368,3 +1368,17 @@ def packed_linear(weight, group=None):
         packed = conv_pack_weights_groups(w.view(cout // group, group, cin).transpose(1, 2).contiguous().view(cout // group, 1, cin, group))
     weight._df3d_packed_linear = (key, packed)
     return packed
+
+
+def pe_gather_add(feat, sel, xyz, w0, b0, w1, b1):
+    """feat[sel] + W1 relu(W0 xyz + b0) + b1 -> [rows, C] (df3d_pe_gather_add)."""
+    lib = _lib.load()
+    for t, nm in ((feat, "feat"), (xyz, "xyz"), (w0, "w0"), (b0, "b0"), (w1, "w1"), (b1, "b1")):
+        _chk(t, torch.float32, nm)
+    _chk(sel, torch.int64, "sel")
+    rows, C, H1 = sel.shape[0], feat.shape[1], w0.shape[0]
+    out = torch.empty((rows, C), dtype=torch.float32, device=feat.device)
+    rc = lib.df3d_pe_gather_add(_ptr(feat), _ptr(sel), _ptr(xyz), _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), rows, C, H1,
+                                _ptr(out), _stream())
+    _lib.check(rc, "df3d_pe_gather_add")
+    return out

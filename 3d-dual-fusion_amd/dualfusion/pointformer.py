@@ -232,6 +232,22 @@ class LocalTransformer(nn.Module):
             h = torch.relu_(h)
         return F.linear(h, c1.conv.weight[:, :, 0, 0], c1.conv.bias)
 
+    def _pe_gather(self, flat, sel, gx):
+        """flat[sel] + pe(gx): one kernel when the positional MLP has the usual form (BN folded + ReLU, then linear)."""
+        c0, c1 = self.pe[0], self.pe[1]
+        C = flat.shape[1]
+        if not (c0.with_activation and c1.conv.bias is not None and C % 4 == 0 and 256 % (C // 4) == 0 and C <= 256):
+            return flat.index_select(0, sel) + self._pe_rows(gx)
+        w0, b0 = c0.conv.weight[:, :, 0, 0], c0.conv.bias
+        if c0.with_norm:
+            inv = torch.rsqrt(c0.bn.running_var + c0.bn.eps) * c0.bn.weight
+            w0 = w0 * inv[:, None]
+            b0 = c0.bn.bias - c0.bn.running_mean * inv + (b0 * inv if b0 is not None else 0)
+        elif b0 is None:
+            b0 = w0.new_zeros(w0.shape[0])
+        return _ops.pe_gather_add(flat, sel, gx, w0.contiguous(), b0.contiguous(),
+                                  c1.conv.weight[:, :, 0, 0].contiguous(), c1.conv.bias.contiguous())
+
     def _forward_rows(self, xyz, rows):
         """Inference path without a single transpose: `rows` [B,N,C] is the caller's query tensor (updated in place,
         'replace' semantics); grouped features are row gathers, the positional MLP runs on coordinate rows, the
@@ -241,7 +257,7 @@ class LocalTransformer(nn.Module):
         sel, gx, src, has = self._row_plan(xyz, group_idx, group_xyz)
         ns, np_ = group_idx.shape[2], group_idx.shape[1]
         flat = rows.reshape(B * N, C)
-        x = flat.index_select(0, sel) + self._pe_rows(gx)
+        x = self._pe_gather(flat, sel, gx)
         y = self.chunk(x.view(ns, B * np_, C)).reshape(ns * B * np_, C)
         flat.copy_(torch.where(has, y.index_select(0, src), flat))
         return rows

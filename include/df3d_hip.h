@@ -473,6 +473,12 @@ int df3d_ms_deform_attn_backward(const float *value, const int64_t *spatial_shap
  * softmax(q k^T / 4) v per group and head, no masks. */
 int df3d_group_attention(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out, void *stream);
 
+/* Grouped features + positional MLP of the LocalTransformer (pointformer.py:232-262) in one pass:
+ * out[r] = feat[sel[r]] + W1 relu(W0 xyz[r] + b0) + b1 with feat [*, channels], sel [rows] int64, xyz [rows][3], W0 [hidden][3]
+ * (BatchNorm folded), W1 [channels][hidden]. */
+int df3d_pe_gather_add(const float *feat, const int64_t *sel, const float *xyz, const float *w0, const float *b0, const float *w1,
+                       const float *b1, long long rows, int channels, int hidden, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Point ops of LocalTransformer (CP/det3d/models/model_utils/pointformer.py:349-380).
  * furthest_point_sampling_wrapper (CP/det3d/ops/furthest_point_sample/src/

@@ -997,3 +997,19 @@ def test_ball_query_wave_kernel_vs_oracle(dev, N, m, ns, rmin, rmax):
     want = orc.ball_query(rmin, rmax, ns, xyz, new_xyz)
     assert np.array_equal(got, want)
     assert (want[:, m // 2:].max(-1) == 0).any() or rmax > 10          # some centres really have no hit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C,n_feat", [(5000, 64, 900), (333, 32, 50), (70, 128, 7), (1, 16, 3)])
+def test_pe_gather_add_vs_torch(dev, rows, C, n_feat):
+    """df3d_pe_gather_add = feat[sel] + W1 relu(W0 xyz + b0) + b1 against the torch expression in float64."""
+    from dualfusion import ops
+    gen = torch.Generator().manual_seed(rows + C)
+    feat = torch.randn((n_feat, C), generator=gen)
+    sel = torch.randint(0, n_feat, (rows,), generator=gen)
+    xyz = torch.randn((rows, 3), generator=gen) * 3
+    w0, b0 = torch.randn((C // 2, 3), generator=gen), torch.randn((C // 2,), generator=gen)
+    w1, b1 = torch.randn((C, C // 2), generator=gen) * 0.3, torch.randn((C,), generator=gen)
+    want = feat.double()[sel] + torch.relu(xyz.double() @ w0.double().t() + b0.double()) @ w1.double().t() + b1.double()
+    got = ops.pe_gather_add(*[t.to(dev) for t in (feat, sel, xyz, w0, b0, w1, b1)]).cpu().double()
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
