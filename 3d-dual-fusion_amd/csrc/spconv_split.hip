@@ -1259,7 +1259,8 @@ static bool use_lc(const SplitConvArgs &a) {
   if (a.cols) return false;
   if (t && t[0] == '0') return false;
   if (t && t[0] == '1') return true;
-  return (long long)cdiv(a.n_out, 128) * a.gy >= 190;
+  // (one offset = a linear layer over rows: the ring's fill and drain would be most of a two-step tile)
+  return a.K > 1 && (long long)cdiv(a.n_out, 128) * a.gy >= 190;
 }
 
 template <int CIN, int COUT>

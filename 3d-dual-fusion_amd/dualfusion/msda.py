@@ -90,7 +90,7 @@ class MSDeformAttn(nn.Module):
 
     def project_value(self, input_flatten, input_padding_mask=None):
         N, Len_in, _ = input_flatten.shape
-        value = self.value_proj(input_flatten)
+        value = _ops.linear_rows(input_flatten, self.value_proj)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         return value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
@@ -136,4 +136,4 @@ class MSDeformAttn(nn.Module):
         locations = self._locations(reference_points, offsets, input_spatial_shapes)
         output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, locations, weights,
                                             self.im2col_step)
-        return self.output_proj(output)
+        return _ops.linear_rows(output, self.output_proj)
