@@ -42,33 +42,37 @@ __device__ __forceinline__ void ffn_split2(float x, unsigned &hi, unsigned &lo) 
   lo = ffn_bf16_bits(x - __uint_as_float(hi << 16));
 }
 
-constexpr int FFN_C = 128;            // model width
 constexpr int FFN_WQ = 8 * 2 * 64;    // u32x4 per step tile (8 operand tiles x hi/lo x 64 lanes) = 16 KB
+// Model width C = 128 (ACTR of the CenterPoint / TransFusion trees) or 64 (ACTRv2 and the LocalTransformer of the Voxel-RCNN
+// tree): C / 32 phase-1 steps per chunk, C / 16 output column tiles (lane n owns C / 16 consecutive columns).  Every step
+// tile of the stream keeps the 16 KB stride; the phase-2 tiles of C = 64 use the first half.
 
 // stream tile (chunk c, step j): j < 4 -> W1 rows 128c..128c+127, input channels 32j..32j+31 (A operands);
 //                                j >= 4 -> W2 columns of hidden units 128c + 32(j-4) .. +31 (B operands)
+template <int C>
 __global__ __launch_bounds__(256) void pack_ffn_kernel(const float *__restrict__ w1, const float *__restrict__ w2,
                                                        int H, u32x4 *__restrict__ out) {
+  constexpr int KB = C / 32, CT = C / 16, SPC = KB + 4;      // steps per chunk
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)(H / 128) * 8 * FFN_WQ;
+  size_t total = (size_t)(H / 128) * SPC * FFN_WQ;
   if (i >= total) return;
   int lane = (int)(i & 63);
   int part = (int)((i >> 6) & 1);
   int t = (int)((i >> 7) & 7);
-  int j = (int)((i >> 10) & 7);
-  int c = (int)(i >> 13);
+  int sj = (int)((i >> 10) % SPC);
+  int c = (int)((i >> 10) / SPC);
   int n = lane & 15, g = lane >> 4;
   unsigned v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    float w;
-    if (j < 4) {
+    float w = 0.f;
+    if (sj < KB) {
       int hid = c * 128 + t * 16 + n;            // A operand row m = n
-      int ch = j * 32 + g * 8 + e;
-      w = w1[(size_t)hid * FFN_C + ch];
-    } else {
-      int q = j - 4;
-      int col = n * 8 + t;                       // lane n owns 8 consecutive output columns
+      int ch = sj * 32 + g * 8 + e;
+      w = w1[(size_t)hid * C + ch];
+    } else if (t < CT) {
+      int q = sj - KB;
+      int col = n * CT + t;                      // lane n owns CT consecutive output columns
       int hid = c * 128 + (2 * q + (e >> 2)) * 16 + 4 * g + (e & 3);
       w = w2[(size_t)col * H + hid];
     }
@@ -108,8 +112,9 @@ struct FfnJobs {
 
 // NP = operand parts: 2 = split precision (hi + lo, three products), 1 = bf16 (hi parts only, one product; the lo
 // halves of the packed stream and of the activations are simply not read)
-template <int NW, int RT, int NP = 2>
+template <int NW, int RT, int NP = 2, int C = 128>
 __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
+  constexpr int KB = C / 32, CT = C / 16, SPC = KB + 4;
   const FfnArgs &a = jobs.s[blockIdx.y];
   if ((long long)blockIdx.x * (16 * RT * NW) >= a.rows) return;
   constexpr int NT = NW * 64, WR = 16 * RT, TM = NW * WR;
@@ -121,17 +126,17 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
   const int g = lane >> 4, n = lane & 15;
   const long long wrow0 = (long long)blockIdx.x * TM + wave * WR;
   const int nchunks = a.H / 128;
-  const int steps = nchunks * 8;
+  const int steps = nchunks * SPC;
 
   // x fragments of the wave's rows: lane (row n of tile rt, g) holds channels 32kb + 8g .. +7, split hi/lo
-  u32x4 xh[RT][4], xl[RT][4];
+  u32x4 xh[RT][KB], xl[RT][KB];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const long long row_n = wrow0 + rt * 16 + n;
     const long long row_ld = row_n < a.rows ? row_n : a.rows - 1;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const float *p = a.x + row_ld * FFN_C + kb * 32 + g * 8;
+    for (int kb = 0; kb < KB; ++kb) {
+      const float *p = a.x + row_ld * C + kb * 32 + g * 8;
       f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
       split_pair(v0[0], v0[1], xh[rt][kb][0], xl[rt][kb][0]);
       split_pair(v0[2], v0[3], xh[rt][kb][1], xl[rt][kb][1]);
@@ -152,11 +157,11 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
     for (int i = 0; i < WPT; ++i) Wl[buf][tid + NT * i] = wreg[i];
   };
 
-  f32x4 acc2[RT][8];
+  f32x4 acc2[RT][CT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) acc2[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < CT; ++ct) acc2[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   load_w(0);
   store_w(0);
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
       for (int t = 0; t < 8; ++t) acc1[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // ---- phase 1: H^T chunk = W1_c x^T ----
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int s = c * 8 + kb;
+    for (int kb = 0; kb < KB; ++kb) {
+      const int s = c * SPC + kb;
       __syncthreads();
       if (!(a.dbg & 2)) {
         store_w((s + 1) & 1);
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
     // ---- phase 2: Y += H_c W2_c^T ----
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int s = c * 8 + 4 + q;
+      const int s = c * SPC + KB + q;
       __syncthreads();
       if (!(a.dbg & 2)) {
         store_w((s + 1) & 1);
@@ -241,9 +246,9 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
 #pragma unroll
       for (int k = 0; k < 4; k += (NP == 2 ? 1 : 2)) fq[0][k] = wb[k * 64];
 #pragma unroll
-      for (int ct = 0; ct < 8; ct += 2) {
+      for (int ct = 0; ct < CT; ct += 2) {
         const int cur = (ct >> 1) & 1;
-        if (ct + 2 < 8) {
+        if (ct + 2 < CT) {
 #pragma unroll
           for (int k = 0; k < 4; k += (NP == 2 ? 1 : 2)) fq[cur ^ 1][k] = wb[((ct + 2) * 2 + k) * 64];
         }
@@ -269,14 +274,18 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
     }
   }
 
-  // ---- epilogue: lane (n, g) holds rows 4g+r, columns 8n..8n+7: + b2, + residual, LayerNorm over the row ----
-  const f32x4 bA = *(const f32x4 *)(a.b2 + n * 8), bB = *(const f32x4 *)(a.b2 + n * 8 + 4);
-  f32x4 gA = (f32x4){1.f, 1.f, 1.f, 1.f}, gB = gA, zA = (f32x4){0.f, 0.f, 0.f, 0.f}, zB = zA;
-  if (a.ln_g) {
-    gA = *(const f32x4 *)(a.ln_g + n * 8);
-    gB = *(const f32x4 *)(a.ln_g + n * 8 + 4);
-    zA = *(const f32x4 *)(a.ln_b + n * 8);
-    zB = *(const f32x4 *)(a.ln_b + n * 8 + 4);
+  // ---- epilogue: lane (n, g) holds rows 4g+r, columns CT*n .. CT*n + CT-1: + b2, + residual, LayerNorm over the row ----
+  constexpr int NV = CT / 4;                     // 16-byte vectors per lane and row
+  f32x4 bias[NV], gam[NV], bet[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    bias[v] = *(const f32x4 *)(a.b2 + n * CT + 4 * v);
+    gam[v] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    bet[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.ln_g) {
+      gam[v] = *(const f32x4 *)(a.ln_g + n * CT + 4 * v);
+      bet[v] = *(const f32x4 *)(a.ln_b + n * CT + 4 * v);
+    }
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
@@ -286,29 +295,33 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
       const long long row = rbase + r;
       const bool live = row < a.rows;
       const long long rr = live ? row : a.rows - 1;
-      f32x4 vA = (f32x4){acc2[rt][0][r], acc2[rt][1][r], acc2[rt][2][r], acc2[rt][3][r]} + bA;
-      f32x4 vB = (f32x4){acc2[rt][4][r], acc2[rt][5][r], acc2[rt][6][r], acc2[rt][7][r]} + bB;
-      if (a.res) {
-        vA += *(const f32x4 *)(a.res + rr * FFN_C + n * 8);
-        vB += *(const f32x4 *)(a.res + rr * FFN_C + n * 8 + 4);
+      f32x4 val[NV];
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        val[v] = (f32x4){acc2[rt][4 * v][r], acc2[rt][4 * v + 1][r], acc2[rt][4 * v + 2][r], acc2[rt][4 * v + 3][r]} + bias[v];
+        if (a.res) val[v] += *(const f32x4 *)(a.res + rr * C + n * CT + 4 * v);
+        s += val[v][0] + val[v][1] + val[v][2] + val[v][3];
       }
       if (a.ln_g) {
-        float s = vA[0] + vA[1] + vA[2] + vA[3] + vB[0] + vB[1] + vB[2] + vB[3];
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);      // the 16 lanes of this row group
-        const float mean = s * (1.f / FFN_C);
-        f32x4 dA = vA - mean, dB = vB - mean;
-        float ss = dA[0] * dA[0] + dA[1] * dA[1] + dA[2] * dA[2] + dA[3] * dA[3] + dB[0] * dB[0] + dB[1] * dB[1] +
-                   dB[2] * dB[2] + dB[3] * dB[3];
+        const float mean = s * (1.f / C);
+        float ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          val[v] = val[v] - mean;
+          ss += val[v][0] * val[v][0] + val[v][1] * val[v][1] + val[v][2] * val[v][2] + val[v][3] * val[v][3];
+        }
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float rstd = rsqrtf(ss * (1.f / FFN_C) + a.eps);
-        vA = dA * rstd * gA + zA;
-        vB = dB * rstd * gB + zB;
+        const float rstd = rsqrtf(ss * (1.f / C) + a.eps);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) val[v] = val[v] * rstd * gam[v] + bet[v];
       }
       if (live) {
-        *(f32x4 *)(a.out + row * FFN_C + n * 8) = vA;
-        *(f32x4 *)(a.out + row * FFN_C + n * 8 + 4) = vB;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) *(f32x4 *)(a.out + row * C + n * CT + 4 * v) = val[v];
       }
     }
   }
@@ -319,24 +332,36 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
 using namespace df3d;
 
 extern "C" size_t df3d_ffn_packed_bytes(int d_model, int d_ffn) {
-  if (d_model != FFN_C || d_ffn <= 0 || d_ffn % 128 != 0) return 0;
-  return (size_t)(d_ffn / 128) * 8 * FFN_WQ * 16;
+  if ((d_model != 128 && d_model != 64) || d_ffn <= 0 || d_ffn % 128 != 0) return 0;
+  return (size_t)(d_ffn / 128) * (d_model / 32 + 4) * FFN_WQ * 16;
 }
 
 extern "C" int df3d_ffn_pack(const float *w1, const float *w2, int d_model, int d_ffn, void *packed, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(w1 && w2 && packed, "ffn_pack: null argument");
   DF3D_CHECK_ARG(df3d_ffn_packed_bytes(d_model, d_ffn) != 0,
-                 "ffn_pack: the fused feed-forward kernel serves d_model 128 and d_ffn %% 128 == 0 (got %d, %d)",
+                 "ffn_pack: the fused feed-forward kernel serves d_model 64 / 128 and d_ffn %% 128 == 0 (got %d, %d)",
                  d_model, d_ffn);
-  size_t total = (size_t)(d_ffn / 128) * 8 * FFN_WQ;
-  hipLaunchKernelGGL(pack_ffn_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, stream, w1, w2, d_ffn,
-                     (u32x4 *)packed);
+  size_t total = (size_t)(d_ffn / 128) * (d_model / 32 + 4) * FFN_WQ;
+  if (d_model == 128)
+    hipLaunchKernelGGL(pack_ffn_kernel<128>, dim3(cdiv((long long)total, 256)), dim3(256), 0, stream, w1, w2, d_ffn,
+                       (u32x4 *)packed);
+  else
+    hipLaunchKernelGGL(pack_ffn_kernel<64>, dim3(cdiv((long long)total, 256)), dim3(256), 0, stream, w1, w2, d_ffn,
+                       (u32x4 *)packed);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }
 
-static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, hipStream_t stream) {
+static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, int d_model, hipStream_t stream) {
+  if (d_model == 64) {                           // 64-wide rows: 8 waves x 16 rows, either precision
+    if (jobs.s[0].bf16)
+      hipLaunchKernelGGL((ffn_split_kernel<8, 1, 1, 64>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
+    else
+      hipLaunchKernelGGL((ffn_split_kernel<8, 1, 2, 64>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+  }
   static const int cfg = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 81;      // tuning aid: NW*10 + RT
   if (jobs.s[0].bf16) {                          // every job of a launch shares the precision mode
     hipLaunchKernelGGL((ffn_split_kernel<8, 1, 1>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
@@ -372,7 +397,7 @@ extern "C" int df3d_ffn_fused(const float *x, long long rows, int d_model, int d
   memset(&jobs, 0, sizeof(jobs));
   jobs.s[0] = {x, (const u32x4 *)packed, b1, b2, residual, ln_weight, ln_bias, eps, out, rows, d_ffn,
                getenv("DF3D_FFN_DBG") ? atoi(getenv("DF3D_FFN_DBG")) : 0, g_ffn_bf16};
-  return ffn_launch(jobs, 1, rows, stream);
+  return ffn_launch(jobs, 1, rows, d_model, stream);
 }
 
 extern "C" int df3d_ffn_fused_jobs(const df3d_ffn_job *j, int njobs, int d_model, int d_ffn, void *stream_) {
@@ -393,5 +418,5 @@ extern "C" int df3d_ffn_fused_jobs(const df3d_ffn_job *j, int njobs, int d_model
     if (j[i].rows > max_rows) max_rows = j[i].rows;
   }
   if (max_rows <= 0) return DF3D_OK;
-  return ffn_launch(jobs, njobs, max_rows, stream);
+  return ffn_launch(jobs, njobs, max_rows, d_model, stream);
 }

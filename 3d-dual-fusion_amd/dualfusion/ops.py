@@ -1029,7 +1029,7 @@ def ffn_pack(w1, w2):
     d_ffn, d_model = w1.shape
     nbytes = lib.df3d_ffn_packed_bytes(d_model, d_ffn)
     if nbytes == 0 or tuple(w2.shape) != (d_model, d_ffn):
-        raise _lib.Df3dError("fused FFN serves d_model 128, d_ffn %% 128 == 0 (got %s, %s)" % (tuple(w1.shape),
+        raise _lib.Df3dError("fused FFN serves d_model 64 / 128, d_ffn %% 128 == 0 (got %s, %s)" % (tuple(w1.shape),
                                                                                               tuple(w2.shape)))
     packed = torch.empty((nbytes,), dtype=torch.uint8, device=w1.device)
     rc = lib.df3d_ffn_pack(_ptr(w1), _ptr(w2), d_model, d_ffn, _ptr(packed), _stream())
@@ -1044,7 +1044,8 @@ def _ffn_precision(lib):
 
 
 def ffn_fused(x, packed, b1, b2, d_ffn, residual=None, ln_weight=None, ln_bias=None, eps=1e-5):
-    """LayerNorm(residual + W2 relu(W1 x + b1) + b2) on [.., 128] rows in one kernel."""
+    """LayerNorm(residual + W2 relu(W1 x + b1) + b2) on [.., 128] or [.., 64] rows in one kernel (no LayerNorm without its
+    affine pair)."""
     lib = _lib.load()
     _ffn_precision(lib)
     _chk(x, torch.float32, "x")

@@ -68,13 +68,14 @@ class TransformerEncoderLayerPreNorm(nn.Module):
         a = self.self_attn
         return (src_mask is None and src_key_padding_mask is None and _ops.CONV_PRECISION == "split" and src.dim() == 3
                 and src.shape[-1] == 64 and a.embed_dim == 64 and a.head_dim == 16 and a._qkv_same_embed_dim
-                and a.in_proj_bias is not None and self.linear1.out_features == 128 and src.shape[0] * a.num_heads <= 1024
+                and a.in_proj_bias is not None and _ops.ffn_supported(64, self.linear1.out_features)
+                and src.shape[0] * a.num_heads <= 1024
                 and src.shape[0] <= 64)
 
     def _forward_rows(self, src):
         """LN1 -> in-projection (three 64-column banks of one grouped launch of the split-precision conv kernel over an
-        identity table) -> `group_attention` -> out-projection -> LN2(x + .) -> FFN (linear1 + ReLU emits split rows only,
-        linear2 adds the residual in its epilogue): fp32-grade products (bf16 hi + lo operands), no library GEMM (hipBLASLt
+        identity table) -> `group_attention` -> out-projection -> LN2(x + .) -> FFN + residual (the fused feed-forward kernel,
+        hidden activation in registers): fp32-grade products (bf16 hi + lo operands), no library GEMM (hipBLASLt
         runs these [524 k, 64] x [64, 64..192] fp32 products at ~20 TFLOP/s: 8 ms per Voxel-RCNN step) and no flash kernel
         on sequences of 32."""
         L, G, C = src.shape
@@ -88,10 +89,14 @@ class TransformerEncoderLayerPreNorm(nn.Module):
         att, _ = _ops.sparse_conv_split(_ops.split_rows(o), _ops.packed_linear(a.out_proj.weight), ident, R, C, C,
                                         bias=a.out_proj.bias.detach(), emit_split=False)
         x3 = _ops.add_layernorm(x1, att, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        _, h = _ops.conv_rows_split(_ops.split_rows(x3), C, 0, _ops.packed_linear(self.linear1.weight), 128, 1, ident, R,
-                                    self.linear1.bias.detach(), relu=True, want_out=False, want_split=True)
-        out, _ = _ops.sparse_conv_split(h, _ops.packed_linear(self.linear2.weight), ident, R, 128, C,
-                                        bias=self.linear2.bias.detach(), residual=x3, emit_split=False)
+        # FFN + residual: the fused feed-forward kernel (csrc/ffn.hip, 64-wide rows): the hidden activation stays in registers
+        key = (self.linear1.weight._version, self.linear2.weight._version, self.linear1.weight.data_ptr())
+        hit = self.__dict__.get("_ffn_packed")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_ffn_packed"] = (key, _ops.ffn_pack(self.linear1.weight.detach().contiguous(),
+                                                                     self.linear2.weight.detach().contiguous()))
+        out = _ops.ffn_fused(x3, hit[1], self.linear1.bias.detach(), self.linear2.bias.detach(), self.linear1.out_features,
+                             residual=x3)
         return out.view(L, G, C)
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None):

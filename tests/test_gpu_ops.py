@@ -474,14 +474,15 @@ def test_groupnorm_fold(dev, gated):
     torch.testing.assert_close(y1, y0, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("rows,H,ln,res", [(1000, 1024, True, True), (37, 256, True, False), (130, 128, False, True),
-                                            (31000, 1024, True, True)])
-def test_ffn_fused(dev, rows, H, ln, res):
+@pytest.mark.parametrize("rows,H,ln,res,C", [(1000, 1024, True, True, 128), (37, 256, True, False, 128),
+                                              (130, 128, False, True, 128), (31000, 1024, True, True, 128),
+                                              (1000, 1024, True, True, 64), (37, 128, False, True, 64),
+                                              (40001, 128, False, True, 64), (513, 256, True, False, 64)])
+def test_ffn_fused(dev, rows, H, ln, res, C):
     """LayerNorm(x + W2 relu(W1 x + b1) + b2) in one split-precision kernel against the float64 composition
     (actr_transformer.py:413-424); 5e-5 of the output scale (parity bar 1e-3)."""
     from dualfusion import ops
-    g = torch.Generator(device="cpu").manual_seed(rows + H)
-    C = 128
+    g = torch.Generator(device="cpu").manual_seed(rows + H + C)
     x = (torch.randn(rows, C, generator=g) * 1.3).to(dev)
     w1 = (torch.randn(H, C, generator=g) / C ** 0.5).to(dev)
     w2 = (torch.randn(C, H, generator=g) / H ** 0.5).to(dev)
