@@ -613,14 +613,31 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         uv = h[:, :2] / h[:, 2:3]
         return xyz, uv
 
+    @staticmethod
+    def _bilinear_taps(dst, in_size, out_size):
+        """Source taps of torch's bilinear upsample (align_corners=False) for integer destination indices:
+        src = max(in / out * (dst + 0.5) - 0.5, 0) in fp32, taps floor(src) and its right neighbour (if any)."""
+        scale = np.float32(in_size) / np.float32(out_size)
+        src = ((dst.to(torch.float32) + 0.5) * float(scale) - 0.5).clamp_(min=0)
+        i0 = src.floor().long().clamp_(max=in_size - 1)
+        i1 = i0 + (i0 < in_size - 1).long()
+        lam = src - i0.to(torch.float32)
+        return i0, i1, lam
+
     def _sample_int(self, fmap, b, uv, hw):
-        """bilinear upsample to the image size, then nearest-integer (truncated) pixel gather (:682-731)."""
+        """bilinear upsample to the image size, then nearest-integer (truncated) pixel gather (:682-731) -- evaluated at the
+        gathered pixels only: the four taps and weights torch's `interpolate(mode='bilinear')` uses for that pixel
+        (materialising the upsampled [B, C, 375, 1242] volume took 0.9 ms per call for ~10^5 gathered pixels)."""
         h, w = hw
-        up = nn.functional.interpolate(fmap, (h, w), mode="bilinear")
         px = uv.long()                                      # torch.Tensor(voxels_2d).long(): truncation
         ok = (px[:, 1] >= 0) & (px[:, 1] < h) & (px[:, 0] >= 0) & (px[:, 0] < w)
-        pxc = torch.stack([px[:, 0].clamp(0, w - 1), px[:, 1].clamp(0, h - 1)], 1)
-        feat = up[b, :, pxc[:, 1], pxc[:, 0]]
+        y0, y1, ly = self._bilinear_taps(px[:, 1].clamp(0, h - 1), fmap.shape[2], h)
+        x0, x1, lx = self._bilinear_taps(px[:, 0].clamp(0, w - 1), fmap.shape[3], w)
+        f = fmap.permute(0, 2, 3, 1)                        # [B, H, W, C] view: a tap is one row gather
+        ly, lx = ly[:, None].to(fmap.dtype), lx[:, None].to(fmap.dtype)
+        top = (1 - lx) * f[b, y0, x0] + lx * f[b, y0, x1]
+        bot = (1 - lx) * f[b, y1, x0] + lx * f[b, y1, x1]
+        feat = (1 - ly) * top + ly * bot
         return torch.where(ok[:, None], feat, torch.zeros_like(feat))
 
     def _fuse1(self, x_conv1, batch_dict):
