@@ -633,10 +633,14 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         ok = (px[:, 1] >= 0) & (px[:, 1] < h) & (px[:, 0] >= 0) & (px[:, 0] < w)
         y0, y1, ly = self._bilinear_taps(px[:, 1].clamp(0, h - 1), fmap.shape[2], h)
         x0, x1, lx = self._bilinear_taps(px[:, 0].clamp(0, w - 1), fmap.shape[3], w)
-        f = fmap.permute(0, 2, 3, 1)                        # [B, H, W, C] view: a tap is one row gather
+        # channels-last copy of the (small) feature map: a tap is then one contiguous row gather
+        f = fmap.permute(0, 2, 3, 1).contiguous().view(-1, fmap.shape[1])
+        Hin, Win = fmap.shape[2], fmap.shape[3]
+        base = b * (Hin * Win)
+        tap = lambda yy, xx: f.index_select(0, base + yy * Win + xx)
         ly, lx = ly[:, None].to(fmap.dtype), lx[:, None].to(fmap.dtype)
-        top = (1 - lx) * f[b, y0, x0] + lx * f[b, y0, x1]
-        bot = (1 - lx) * f[b, y1, x0] + lx * f[b, y1, x1]
+        top = (1 - lx) * tap(y0, x0) + lx * tap(y0, x1)
+        bot = (1 - lx) * tap(y1, x0) + lx * tap(y1, x1)
         feat = (1 - ly) * top + ly * bot
         return torch.where(ok[:, None], feat, torch.zeros_like(feat))
 
