@@ -395,14 +395,14 @@ __global__ void group_attention_kernel(const float *__restrict__ qkv, int L, int
 extern "C" int df3d_group_attention(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out,
                                     void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  DF3D_CHECK_ARG(qkv && out, "group_attention: null argument");
   DF3D_CHECK_ARG(tokens >= 1 && groups >= 0 && heads >= 1 && head_dim == 16, "group_attention: heads of 16 channels only (got %d)",
                  head_dim);
   const int C = heads * head_dim;
   const size_t lds = (size_t)2 * tokens * C * sizeof(float);
   DF3D_CHECK_ARG(tokens * heads <= 1024 && lds <= 64 * 1024, "group_attention: %d tokens x %d heads does not fit a workgroup",
                  tokens, heads);
-  if (groups == 0) return DF3D_OK;
+  if (groups == 0) return DF3D_OK;               // (empty tensors carry null pointers)
+  DF3D_CHECK_ARG(qkv && out, "group_attention: null argument");
   const int threads = cdiv(tokens * heads, 64) * 64;
   hipLaunchKernelGGL(group_attention_kernel<16>, dim3(groups), dim3(threads), lds, stream, qkv, tokens, groups, heads,
                      1.f / sqrtf((float)head_dim), out);
@@ -453,7 +453,7 @@ extern "C" int df3d_pe_gather_add(const float *feat, const int64_t *sel, const f
                                   const float *w1, const float *b1, long long rows, int channels, int hidden, float *out,
                                   void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  DF3D_CHECK_ARG(feat && sel && xyz && w0 && b0 && w1 && b1 && out, "pe_gather_add: null argument");
+  DF3D_CHECK_ARG(rows == 0 || (feat && sel && xyz && w0 && b0 && w1 && b1 && out), "pe_gather_add: null argument");
   DF3D_CHECK_ARG(channels % 4 == 0 && channels >= 4 && 256 % (channels / 4) == 0 && hidden >= 1 &&
                      (size_t)hidden * (channels + 4) * 4 <= 64 * 1024,
                  "pe_gather_add: %d channels / %d hidden not served", channels, hidden);
@@ -469,8 +469,9 @@ extern "C" int df3d_pe_gather_add(const float *feat, const int64_t *sel, const f
 extern "C" int df3d_ball_query(const float *new_xyz, const float *xyz, int B, int N, int m, float min_radius,
                                float max_radius, int nsample, int32_t *idx, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  DF3D_CHECK_ARG(new_xyz && xyz && idx && nsample > 0, "ball_query: bad arguments");
+  DF3D_CHECK_ARG(nsample > 0, "ball_query: bad arguments");
   if (B == 0 || m == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(new_xyz && xyz && idx, "ball_query: null argument");
   DF3D_CHECK_ARG(nsample <= 1024, "ball_query: at most 1024 samples per centre (got %d)", nsample);
   // (every slot of every centre is written: no hit = zeros, like the reference's zero-initialised idx)
   const size_t lds = (size_t)(BQ_TILE * 3 + BQ_WAVES * nsample) * sizeof(float);

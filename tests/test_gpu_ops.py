@@ -1033,3 +1033,37 @@ def test_ffn_rows_on_conv_kernels_vs_float64(dev, rows, d, f):
         assert ops.ffn_rows_supported(x.to(dev), la, lb)
         got = ops.ffn_rows(x.to(dev), la, lb).cpu().double()
     assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_round2_entries_on_empty_and_minimal_inputs(dev):
+    """Empty / one-row inputs of the entries added in round 2: no launch, no fault, the reference's result shape."""
+    from dualfusion import ops
+    # filter gradient: no output rows, no input rows, a table without a single pair
+    nbr0 = torch.empty((27, 0), dtype=torch.int32, device=dev)
+    gw = ops.sparse_conv_grad_filters(torch.randn(5, 16, device=dev), torch.empty((0, 32), device=dev), nbr0)
+    assert tuple(gw.shape) == (27, 16, 32) and float(gw.abs().max()) == 0.0
+    nbr = torch.full((27, 9), -1, dtype=torch.int32, device=dev)
+    gw = ops.sparse_conv_grad_filters(torch.randn(5, 16, device=dev), torch.randn(9, 32, device=dev), nbr)
+    assert float(gw.abs().max()) == 0.0
+    nbr[13, 4] = 2                                             # exactly one pair
+    f, g = torch.randn(5, 16, device=dev), torch.randn(9, 32, device=dev)
+    gw = ops.sparse_conv_grad_filters(f, g, nbr)
+    torch.testing.assert_close(gw[13], torch.outer(f[2], g[4]), rtol=1e-6, atol=1e-6)
+    assert float(gw[:13].abs().max()) == 0.0 and float(gw[14:].abs().max()) == 0.0
+    # group attention / positional gather / ball query without groups, rows, centres
+    assert tuple(ops.group_attention(torch.empty((0, 192), device=dev), 32, 0, 4).shape) == (0, 64)
+    o = ops.group_attention(torch.randn(1, 192, device=dev), 1, 1, 4)              # one token: softmax of one score = v
+    assert tuple(o.shape) == (1, 64)
+    e = ops.pe_gather_add(torch.randn(3, 64, device=dev), torch.empty((0,), dtype=torch.int64, device=dev),
+                          torch.empty((0, 3), device=dev), torch.randn(32, 3, device=dev), torch.randn(32, device=dev),
+                          torch.randn(64, 32, device=dev), torch.randn(64, device=dev))
+    assert tuple(e.shape) == (0, 64)
+    bq = ops.ball_query(0.0, 1.0, 8, torch.randn(2, 50, 3, device=dev), torch.empty((2, 0, 3), device=dev))
+    assert tuple(bq.shape) == (2, 0, 8)
+    bq = ops.ball_query(0.0, 1e-6, 8, torch.ones(1, 3, 3, device=dev), torch.zeros(1, 2, 3, device=dev))   # no hit at all
+    assert int(bq.abs().max()) == 0
+    # BatchNorm rows: a single row takes the module's own path (no batch statistics to speak of), two rows the kernels
+    bn = torch.nn.BatchNorm1d(16).to(dev).train()
+    y = ops.batch_norm_rows(bn, torch.randn(2, 16, device=dev), relu=True)
+    assert tuple(y.shape) == (2, 16) and bool(torch.isfinite(y).all()) and int(bn.num_batches_tracked) == 1
