@@ -133,6 +133,8 @@ SIGNATURES = {
     "df3d_centerhead_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "df3d_centerhead_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_centerhead_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float,
+                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_heatmap_proposals_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "df3d_heatmap_proposals": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_int, c_void_p, c_int,
                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -704,8 +704,9 @@ def _fill_head_tasks(arr, tasks, rows):
         arr[i].label_base = int(t.get("label_base", 0))
 
 
-def centerhead_loss(tasks, targets, batch, H, W, code_weights, weight):
-    """Detection losses of all tasks in two launches (csrc/loss.hip).  tasks: as for centerhead_predict; targets: list of
+def centerhead_loss(tasks, targets, batch, H, W, code_weights, weight, grad_tasks=None):
+    """Detection losses of all tasks in two launches (csrc/loss.hip); with `grad_tasks` (zero-filled maps in the layout of
+    `tasks`) also the gradient of the summed task losses with respect to every head map.  tasks: as for centerhead_predict; targets: list of
     dicts {'hm' [B, C, H, W] f32, 'ind' [B, M] i64, 'mask' [B, M] u8, 'cat' [B, M] i64, 'anno_box' [B, M, D] f32} on
     the device.  Returns [T, LOSS_FIELDS] f32 on the device: loss, hm_loss, loc_loss, num_positive, loc_loss_elem[10]."""
     lib = _lib.load()
@@ -739,11 +740,45 @@ def centerhead_loss(tasks, targets, batch, H, W, code_weights, weight):
     out = torch.empty((n, LOSS_FIELDS), dtype=torch.float32, device=dev)
     nbytes = int(lib.df3d_centerhead_loss_workspace_bytes(n, int(batch), int(H), int(W)))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    if grad_tasks is not None:
+        garr = (_HeadTask * n)()
+        _fill_head_tasks(garr, grad_tasks, batch * H * W)
+        rc = lib.df3d_centerhead_loss_grad(ctypes.byref(arr), ctypes.byref(garr), ctypes.byref(tg), n, int(batch), int(H),
+                                           int(W), M, D, ctypes.cast(cw, ctypes.c_void_p), len(code_weights), float(weight),
+                                           _ptr(out), _ptr(ws), nbytes, _stream())
+        _lib.check(rc, "df3d_centerhead_loss_grad")
+        return out
     rc = lib.df3d_centerhead_loss(ctypes.byref(arr), ctypes.byref(tg), n, int(batch), int(H), int(W), M, D,
                                   ctypes.cast(cw, ctypes.c_void_p), len(code_weights), float(weight), _ptr(out), _ptr(ws),
                                   nbytes, _stream())
     _lib.check(rc, "df3d_centerhead_loss")
     return out
+
+
+class CenterHeadLossFunction(torch.autograd.Function):
+    """All tasks' CenterHead losses from the packed head maps `rows` [B*H*W, width] (every map a column slice, `cols` =
+    per task {head: (first column, columns)}) with their gradient in the same two launches: -> [T, LOSS_FIELDS]
+    (loss, hm_loss, loc_loss, num_positive, loc_loss_elem[10]); only the `loss` column carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, rows, cols, targets, batch, H, W, code_weights, weight):
+        rows = rows.contiguous()
+        grad = torch.zeros_like(rows)
+        view = lambda buf: [{k: buf[:, c0:c0 + n] for k, (c0, n) in t.items()} for t in cols]
+        vals = centerhead_loss(view(rows.detach()), targets, batch, H, W, code_weights, weight, grad_tasks=view(grad))
+        ctx.save_for_backward(grad)
+        ctx.cols = cols
+        return vals
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gv):
+        grad, = ctx.saved_tensors
+        scale = torch.zeros((grad.shape[1],), dtype=grad.dtype, device=grad.device)
+        idx = torch.tensor([c for t in ctx.cols for (c0, n) in t.values() for c in range(c0, c0 + n)], device=grad.device)
+        tid = torch.tensor([i for i, t in enumerate(ctx.cols) for (c0, n) in t.values() for _ in range(n)], device=grad.device)
+        scale[idx] = gv[:, 0][tid]
+        return grad * scale, None, None, None, None, None, None, None
 
 
 class _QueryHeads(ctypes.Structure):

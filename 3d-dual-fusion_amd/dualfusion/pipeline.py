@@ -136,7 +136,9 @@ class CenterPointDetector(nn.Module):
                     bev, _ = hp.backbone(feats, batch_dict, coors, len(points_list), hp.grid_size_xyz, example,
                                          fuse_func=hp.fusion)
                 preds = self.bbox_head(self.neck(bev))
-                rets = self.bbox_head.loss(example, preds, {}, host_copies=False)
+                rets = self.bbox_head.loss_rows(example) if hasattr(self.bbox_head, "loss_rows") else None
+                if rets is None:
+                    rets = self.bbox_head.loss(example, preds, {}, host_copies=False)
                 sum(rets["loss"]).backward()
         finally:
             hp.backbone.dense_layout = layout

@@ -354,6 +354,12 @@ size_t df3d_centerhead_loss_workspace_bytes(int ntasks, int batch, int H, int W)
 int df3d_centerhead_loss(const df3d_head_task *tasks, const df3d_head_targets *targets, int ntasks, int batch, int H, int W,
                          int max_objs, int box_dim, const float *code_weights, int ncodes, float weight, float *out,
                          void *workspace, size_t workspace_bytes, void *stream);
+/* The same two launches for TRAINING: additionally d(sum over tasks of `loss`) / d(every head
+ * map), written into `grad_tasks` (the layout of `tasks`; the heat-map gradients are stored, the box-code gradients added:
+ * zero those maps first).  Replaces the backward of ~45 torch ops per task (centernet_loss.py:6-58 through autograd). */
+int df3d_centerhead_loss_grad(const df3d_head_task *tasks, const df3d_head_task *grad_tasks, const df3d_head_targets *targets,
+                              int ntasks, int batch, int H, int W, int max_objs, int box_dim, const float *code_weights,
+                              int ncodes, float weight, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * TransFusionHead (LiDAR-only branch), the index and decode steps.

@@ -309,3 +309,47 @@ def test_branch_conv_function_vs_torch_float64():
     assert rel(rd.grad, r64.grad) < 1e-4
     assert rel(wd.grad, w64.grad) < 1e-4
     assert rel(bd.grad, b64.grad) < 1e-4
+
+
+def test_loss_rows_values_and_gradients_equal_the_autograd_loss():
+    """`CenterHead.loss_rows` (losses of all tasks + the gradient of every head map from the two launches of csrc/loss.hip)
+    against `CenterHead.loss` (the reference's torch composition through autograd) on the same packed maps: values 1e-5,
+    gradient of the packed buffer 1e-4 of its scale; also with a task that has no positives."""
+    from dualfusion import ops
+    from make_golden import HEAD_SHAPE, head_loss_example
+    if ops.CONV_PRECISION != "split":
+        pytest.skip("the packed training maps come from the split-precision row path")
+    head = _head().to(DEV).train()
+    x = torch.from_numpy(detgen.randn("head_loss_x", HEAD_SHAPE)).to(DEV)
+    ex = {k: [torch.from_numpy(a).to(DEV) for a in v] for k, v in head_loss_example().items()}
+    ex["mask"][2] = torch.zeros_like(ex["mask"][2])                       # a task without positives
+    preds = head(x)
+    out, cols, geom = head.__dict__["_packed_train"]
+    # reference: the torch loss on a leaf copy of the packed buffer
+    leaf = out.detach().clone().requires_grad_(True)
+    B, H, W = geom
+    maps = leaf.view(B, H, W, -1)
+    pr = [{k: (maps[..., c0:c0 + n].permute(0, 3, 1, 2).clone() if k == "hm" else maps[..., c0:c0 + n].permute(0, 3, 1, 2))
+           for k, (c0, n) in t.items()} for t in cols]
+    ref = head.loss(ex, pr, {})
+    sum(ref["loss"]).backward()
+    leaf2 = out.detach().clone().requires_grad_(True)
+    head.__dict__["_packed_train"] = (leaf2, cols, geom)
+    got = head.loss_rows(ex)
+    assert got is not None
+    sum(got["loss"]).backward()
+    for k in ("loss", "hm_loss", "loc_loss"):
+        np.testing.assert_allclose([float(v.detach()) for v in got[k]], [float(v.detach()) for v in ref[k]], rtol=2e-5, atol=1e-6)
+    for a, b in zip(got["loc_loss_elem"], ref["loc_loss_elem"]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    g, r = leaf2.grad, leaf.grad
+    assert float((g - r).abs().max()) <= 1e-4 * float(r.abs().max())
+    # per-task coefficients reach the gradient
+    head.__dict__["_packed_train"] = (out.detach().clone().requires_grad_(True), cols, geom)
+    leaf3 = head.__dict__["_packed_train"][0]
+    got = head.loss_rows(ex)
+    (2.0 * got["loss"][0] + 0.0 * sum(got["loss"][1:])).backward()
+    c_hm = cols[0]["hm"]
+    torch.testing.assert_close(leaf3.grad[:, c_hm[0]:c_hm[0] + c_hm[1]], 2.0 * r[:, c_hm[0]:c_hm[0] + c_hm[1]], rtol=1e-3, atol=1e-7)
+    c1 = cols[1]["hm"]
+    assert float(leaf3.grad[:, c1[0]:c1[0] + c1[1]].abs().max()) == 0.0
