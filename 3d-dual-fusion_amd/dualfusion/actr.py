@@ -262,8 +262,6 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         """norm(x + lin_b(relu(lin_a(x)))): one fused kernel (csrc/ffn.hip) when the sizes fit it."""
         from . import ops as _ops
         if not _ops.ffn_supported(lin_a.in_features, lin_a.out_features):
-            if _ops.ffn_rows_supported(x, lin_a, lin_b):
-                return _ops.add_layernorm(x, _ops.ffn_rows(x, lin_a, lin_b).contiguous(), norm.weight, norm.bias, norm.eps)
             return _ops.add_layernorm(x, lin_b(self._linear_relu(lin_a, x)), norm.weight, norm.bias, norm.eps)
         key = (lin_a.weight.data_ptr(), lin_a.weight._version, lin_b.weight.data_ptr(), lin_b.weight._version)
         hit = getattr(self, slot, None)

@@ -1433,34 +1433,3 @@ def linear_rows(x, lin, min_rows=16384):
     out, _ = sparse_conv_split(split_rows(x2), packed_linear(lin.weight), identity_table(rows, x.device), rows, cin, cout,
                                bias=lin.bias.detach() if lin.bias is not None else None, emit_split=False)
     return out.view(*x.shape[:-1], cout)
-
-
-def ffn_rows_supported(x, lin_a, lin_b):
-    d, f = lin_a.in_features, lin_a.out_features
-    return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and CONV_PRECISION == "split"
-            and lin_b.in_features == f and lin_b.out_features == d and f % 512 == 0 and f <= 4096
-            and x.numel() // d >= 4096 and conv_split_supported(1, d, 128) and conv_split_supported(1, 512, d))
-
-
-def ffn_rows(x, lin_a, lin_b):
-    """lin_b(relu(lin_a(x))) for a narrow model width and a wide hidden layer (ACTRv2 of the Voxel-RCNN tree: 64 -> 1024 -> 64
-    on ~40 k query rows) on the split-precision conv kernels over an identity table: the first linear as hidden / 128 banks
-    of one grouped launch that emits split rows only (ReLU in the epilogue), the second as hidden / 512 banks over column
-    slices of those rows (partial sums added here).  hipBLASLt takes 370 + 225 us for the pair in fp32."""
-    d, f = lin_a.in_features, lin_a.out_features
-    rows = x.numel() // d
-    x2 = x.reshape(rows, d).contiguous()
-    ident = identity_table(rows, x.device)
-    _, h = conv_rows_split(split_rows(x2), d, 0, packed_linear(lin_a.weight, 128), 128, f // 128, ident, rows,
-                           lin_a.bias.detach(), relu=True, want_out=False, want_split=True)
-    # second linear: K = hidden split into 512-wide slices; W2 [d, f] -> banks [f / 512][1][512][d]
-    hit = getattr(lin_b.weight, "_df3d_packed_kslices", None)
-    key = (lin_b.weight._version, CONV_PRECISION)
-    if hit is None or hit[0] != key:
-        w = lin_b.weight.detach().float().t().contiguous().view(f // 512, 1, 512, d)
-        hit = lin_b.weight._df3d_packed_kslices = (key, conv_pack_weights_groups(w))
-    part, _ = conv_rows_split(h, 512, 512, hit[1], d, f // 512, ident, rows)
-    y = part.view(rows, f // 512, d).sum(1)
-    if lin_b.bias is not None:
-        y = y + lin_b.bias
-    return y.view(*x.shape[:-1], d)

@@ -1016,24 +1016,6 @@ def test_pe_gather_add_vs_torch(dev, rows, C, n_feat):
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("rows,d,f", [(5000, 64, 1024), (4100, 64, 512)])
-def test_ffn_rows_on_conv_kernels_vs_float64(dev, rows, d, f):
-    """`ops.ffn_rows` (banked 1x1 'convolutions' over an identity table) = lin_b(relu(lin_a(x))) in float64."""
-    from dualfusion import ops
-    if ops.CONV_PRECISION != "split":
-        pytest.skip("split-precision kernels only")
-    gen = torch.Generator().manual_seed(rows)
-    la, lb = torch.nn.Linear(d, f), torch.nn.Linear(f, d)
-    x = torch.randn((2, rows // 2, d), generator=gen)
-    with torch.no_grad():
-        want = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x.double(), la.weight.double(), la.bias.double())),
-                                          lb.weight.double(), lb.bias.double())
-        la, lb = la.to(dev), lb.to(dev)
-        assert ops.ffn_rows_supported(x.to(dev), la, lb)
-        got = ops.ffn_rows(x.to(dev), la, lb).cpu().double()
-    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
-
 
 @pytest.mark.gpu
 def test_round2_entries_on_empty_and_minimal_inputs(dev):
