@@ -25,3 +25,10 @@ python tools/ubench/ablate_probe.py 50            # needs DF3D_HIPCC_FLAGS=-DDF3
 bash tools/ubench/conv4_pmc.sh lc                 # L2 hit rate / L1->L2 latency / LDS conflicts / wave-state cycles of conv4
 python tools/ubench/xattn_probe.py                # the split-key cross-attention kernel alone
 python tools/ubench/topk_probe.py                 # the top-k select of both heads alone
+python tools/ubench/fps_probe.py                  # FPS kernel alone (us per iteration at 8 x 24k points)
+python tools/ubench/wgrad_probe.py                # filter-gradient kernels on the submanifold layers of a sweep (direct vs LDS-staged)
+bash tools/ubench/wgrad_pmc.sh a                  # MFMA busy / wait / LDS / L2 counters of the conv4 filter gradient
+bash tools/debug/train_prof.sh                    # kernel table of ONE training step (WL=cp_fusion for the fusion graph) -> profiles/r02_train_*_kernels.txt
+python tools/debug/train_phases.py                # host time to queue each phase of the training step vs its wall time
+WL=vr_fusion bash tools/debug/wl_prof.sh          # kernel table of an inference workload (cp_fusion | tf_fusion | vr_fusion)
+python tools/debug/torch_ops.py                   # ATen ops with device time in one detector step
