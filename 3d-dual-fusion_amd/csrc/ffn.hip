@@ -362,9 +362,14 @@ static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, int d_
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
   }
-  static const int cfg = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 81;      // tuning aid: NW*10 + RT
+  static const int cfg = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 81;      // tuning aid: NW*10 + RT (1081: bf16 mode with one row tile)
   if (jobs.s[0].bf16) {                          // every job of a launch shares the precision mode
-    hipLaunchKernelGGL((ffn_split_kernel<8, 1, 1>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
+    // one product per operand pair: the kernel is bound by the 1 MB weight stream every workgroup pulls from L2, so many
+    // rows take two row tiles per wave (half the stream per row); DF3D_FFN_CFG=81 keeps one
+    if (max_rows >= 32 * 1024 && cfg != 81 + 1000)
+      hipLaunchKernelGGL((ffn_split_kernel<8, 2, 1>), dim3(cdiv(max_rows, 256), njobs), dim3(512), 0, stream, jobs);
+    else
+      hipLaunchKernelGGL((ffn_split_kernel<8, 1, 1>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
   }

@@ -501,7 +501,7 @@ def test_ffn_fused(dev, rows, H, ln, res, C):
     assert err < 5e-5, err
 
 
-@pytest.mark.parametrize("rows", [37, 5000])
+@pytest.mark.parametrize("rows", [37, 5000, 40001])
 def test_ffn_fused_bf16_mode(dev, rows):
     """The bf16 mode of the fused feed-forward kernel (BASELINE configs[2]: bf16 operands, fp32 accumulate): against the
     float64 composition evaluated on the SAME bf16-rounded operands (x, W1, the hidden activation, W2) the result agrees
