@@ -1049,3 +1049,23 @@ def test_round2_entries_on_empty_and_minimal_inputs(dev):
     bn = torch.nn.BatchNorm1d(16).to(dev).train()
     y = ops.batch_norm_rows(bn, torch.randn(2, 16, device=dev), relu=True)
     assert tuple(y.shape) == (2, 16) and bool(torch.isfinite(y).all()) and int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cin,cout,bias", [(20000, 64, 64, True), (16500, 128, 64, False), (17000, 64, 128, True),
+                                                (100, 64, 64, True), (20000, 48, 64, True)])
+def test_linear_rows_helper(dev, rows, cin, cout, bias):
+    """`ops.linear_rows` = nn.Linear over many narrow rows on the split-precision conv kernel (identity table) when the
+    shape is served, torch otherwise (few rows, unsupported widths, grad mode): values against float64 either way."""
+    from dualfusion import ops
+    gen = torch.Generator().manual_seed(rows + cin)
+    lin = torch.nn.Linear(cin, cout, bias=bias)
+    x = torch.randn((2, rows // 2, cin), generator=gen)
+    want = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double() if bias else None)
+    lin = lin.to(dev)
+    with torch.no_grad():
+        got = ops.linear_rows(x.to(dev), lin)
+    assert tuple(got.shape) == (2, rows // 2, cout)
+    assert float((got.cpu().double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    y = ops.linear_rows(x.to(dev).requires_grad_(True), lin)               # grad mode: the module itself
+    assert y.requires_grad
