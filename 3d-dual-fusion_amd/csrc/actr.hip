@@ -49,7 +49,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float eps, long long rows,
-                                                            int C, float *__restrict__ out) {
+                                                            int C, float *__restrict__ out,
+                                                            unsigned *__restrict__ out_split = nullptr) {
   constexpr int RPW = 64 / LPR, NK = LPR == 64 ? 4 : 1;
   const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63, sub = lane % LPR;
@@ -85,7 +86,15 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
     int c4 = sub + LPR * k;
     if (live && c4 < nv) {
       f32x4 g = ((const f32x4 *)gamma)[c4], b = ((const f32x4 *)beta)[c4];
-      ((f32x4 *)(out + row * C))[c4] = (v[k] - mean) * rstd * g + b;
+      const f32x4 o = (v[k] - mean) * rstd * g + b;
+      ((f32x4 *)(out + row * C))[c4] = o;
+      if (out_split) {       // split rows for the next conv / linear: per 8 channels 16 B of bf16 hi, 16 B of bf16 lo
+        unsigned h0, l0, h1, l1;
+        split_pair(o[0], o[1], h0, l0);
+        split_pair(o[2], o[3], h1, l1);
+        unsigned *p = out_split + (size_t)row * C + (c4 >> 1) * 8 + (c4 & 1) * 2;      // u32 units: 8 per 8 channels
+        p[0] = h0, p[1] = h1, p[4] = l0, p[5] = l1;
+      }
     }
   }
 }
@@ -416,23 +425,34 @@ extern "C" int df3d_actr_prep(const float *q, const float *qi, const float *pos,
   return DF3D_OK;
 }
 
-extern "C" int df3d_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, float eps,
-                                  long long rows, int C, float *out, void *stream_) {
+static int add_layernorm_impl(const float *x, const float *y, const float *gamma, const float *beta, float eps,
+                                  long long rows, int C, float *out, unsigned *out_split, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(x && gamma && beta && out, "add_layernorm: null argument");
   DF3D_CHECK_ARG(C % 4 == 0 && C <= 1024, "add_layernorm: C must be a multiple of 4 and <= 1024 (got %d)", C);
   if (rows == 0) return DF3D_OK;
   if (C <= 64)
     hipLaunchKernelGGL(add_layernorm_kernel<16>, dim3(cdiv(cdiv(rows, 4) * 64, 256)), dim3(256), 0, stream, x, y, gamma, beta,
-                       eps, rows, C, out);
+                       eps, rows, C, out, out_split);
   else if (C <= 128)
     hipLaunchKernelGGL(add_layernorm_kernel<32>, dim3(cdiv(cdiv(rows, 2) * 64, 256)), dim3(256), 0, stream, x, y, gamma, beta,
-                       eps, rows, C, out);
+                       eps, rows, C, out, out_split);
   else
     hipLaunchKernelGGL(add_layernorm_kernel<64>, dim3(cdiv(rows * 64, 256)), dim3(256), 0, stream, x, y, gamma, beta, eps,
-                       rows, C, out);
+                       rows, C, out, out_split);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
+}
+
+extern "C" int df3d_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, float eps,
+                                  long long rows, int C, float *out, void *stream_) {
+  return add_layernorm_impl(x, y, gamma, beta, eps, rows, C, out, nullptr, stream_);
+}
+
+extern "C" int df3d_add_layernorm_split(const float *x, const float *y, const float *gamma, const float *beta, float eps,
+                                        long long rows, int C, float *out, void *out_split, void *stream_) {
+  DF3D_CHECK_ARG(out_split && C % 8 == 0, "add_layernorm_split: split rows need a multiple of 8 channels (got %d)", C);
+  return add_layernorm_impl(x, y, gamma, beta, eps, rows, C, out, (unsigned *)out_split, stream_);
 }
 
 extern "C" int df3d_bigate_sum(const float *q, const float *qi, const float *wb, const float *bb, const float *wa,

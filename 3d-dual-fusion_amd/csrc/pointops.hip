@@ -342,7 +342,7 @@ extern "C" int df3d_furthest_point_sample(const float *xyz, int B, int N, int m,
 // with an online softmax, 16 accumulators.  The library's flash kernel spends 300 us per layer on these 16 k sequences of 32.
 template <int D>
 __global__ void group_attention_kernel(const float *__restrict__ qkv, int L, int G, int H, float scale,
-                                       float *__restrict__ out) {
+                                       float *__restrict__ out, unsigned *__restrict__ out_split) {
   extern __shared__ __align__(16) float ga_smem[];
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int C = H * D, g = blockIdx.x, tid = threadIdx.x;
@@ -387,13 +387,31 @@ __global__ void group_attention_kernel(const float *__restrict__ qkv, int L, int
     m = mn;
   }
   const float inv = 1.f / l;
-  float *op = out + ((size_t)t * G + g) * C + h * D;
 #pragma unroll
-  for (int e = 0; e < D; e += 4) *(f4 *)(op + e) = (f4){acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv};
+  for (int e = 0; e < D; ++e) acc[e] *= inv;
+  if (out) {
+    float *op = out + ((size_t)t * G + g) * C + h * D;
+#pragma unroll
+    for (int e = 0; e < D; e += 4) *(f4 *)(op + e) = (f4){acc[e], acc[e + 1], acc[e + 2], acc[e + 3]};
+  }
+  if (out_split) {           // split rows for the out-projection (per 8 channels: 16 B bf16 hi | 16 B bf16 lo)
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    unsigned *sp = out_split + ((size_t)t * G + g) * C + h * D;          // u32 units: one per channel
+#pragma unroll
+    for (int b = 0; b < D / 8; ++b) {
+      u4 hi, lo;
+      split_pair(acc[8 * b], acc[8 * b + 1], hi[0], lo[0]);
+      split_pair(acc[8 * b + 2], acc[8 * b + 3], hi[1], lo[1]);
+      split_pair(acc[8 * b + 4], acc[8 * b + 5], hi[2], lo[2]);
+      split_pair(acc[8 * b + 6], acc[8 * b + 7], hi[3], lo[3]);
+      *(u4 *)(sp + 8 * b) = hi;
+      *(u4 *)(sp + 8 * b + 4) = lo;
+    }
+  }
 }
 
-extern "C" int df3d_group_attention(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out,
-                                    void *stream_) {
+static int group_attention_impl(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out,
+                                unsigned *out_split, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(tokens >= 1 && groups >= 0 && heads >= 1 && head_dim == 16, "group_attention: heads of 16 channels only (got %d)",
                  head_dim);
@@ -402,12 +420,22 @@ extern "C" int df3d_group_attention(const float *qkv, int tokens, int groups, in
   DF3D_CHECK_ARG(tokens * heads <= 1024 && lds <= 64 * 1024, "group_attention: %d tokens x %d heads does not fit a workgroup",
                  tokens, heads);
   if (groups == 0) return DF3D_OK;               // (empty tensors carry null pointers)
-  DF3D_CHECK_ARG(qkv && out, "group_attention: null argument");
+  DF3D_CHECK_ARG(qkv && (out || out_split), "group_attention: null argument");
   const int threads = cdiv(tokens * heads, 64) * 64;
   hipLaunchKernelGGL(group_attention_kernel<16>, dim3(groups), dim3(threads), lds, stream, qkv, tokens, groups, heads,
-                     1.f / sqrtf((float)head_dim), out);
+                     1.f / sqrtf((float)head_dim), out, out_split);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
+}
+
+extern "C" int df3d_group_attention(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out,
+                                    void *stream_) {
+  return group_attention_impl(qkv, tokens, groups, heads, head_dim, out, nullptr, stream_);
+}
+
+extern "C" int df3d_group_attention_split(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out,
+                                          void *out_split, void *stream_) {
+  return group_attention_impl(qkv, tokens, groups, heads, head_dim, out, (unsigned *)out_split, stream_);
 }
 
 // Grouped features + positional MLP of the LocalTransformer in one pass (pointformer.py:232-262: x = group(features) +

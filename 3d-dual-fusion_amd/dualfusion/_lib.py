@@ -65,6 +65,7 @@ SIGNATURES = {
     "df3d_pe_gather_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int,
                                    c_void_p, c_void_p]),
     "df3d_group_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_group_attention_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_ball_query": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p]),
     "df3d_group_points": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_gather_points": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -161,6 +162,8 @@ SIGNATURES = {
     "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,
                                    c_void_p]),
+    "df3d_add_layernorm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,
+                                   c_void_p, c_void_p]),
     "df3d_bigate_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int,
                                 c_void_p, c_void_p, c_void_p]),
     "df3d_ms_deform_attn_fused": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

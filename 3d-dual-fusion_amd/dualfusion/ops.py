@@ -1199,14 +1199,22 @@ def actr_prep(q, qi, pos):
     return A, Bw
 
 
-def add_layernorm(x, y, weight, bias, eps):
-    """LayerNorm(x + y) over the last dimension (y may be None)."""
+def add_layernorm(x, y, weight, bias, eps, want_split=False):
+    """LayerNorm(x + y) over the last dimension (y may be None); `want_split`: -> (out, split rows of out) for a following
+    split-precision layer (saves the separate `split_rows` pass)."""
     lib = _lib.load()
     _chk(x, torch.float32, "x")
     if y is not None:
         _chk(y, torch.float32, "y")
     C = x.shape[-1]
     out = torch.empty_like(x)
+    if want_split:
+        rows = x.numel() // C
+        sp = torch.empty((rows, 4 * C), dtype=torch.uint8, device=x.device)
+        rc = lib.df3d_add_layernorm_split(_ptr(x), _ptr(y), _ptr(weight), _ptr(bias), float(eps), rows, C, _ptr(out),
+                                          _ptr(sp), _stream())
+        _lib.check(rc, "df3d_add_layernorm_split")
+        return out, sp
     rc = lib.df3d_add_layernorm(_ptr(x), _ptr(y), _ptr(weight), _ptr(bias), float(eps), x.numel() // C, C, _ptr(out),
                                 _stream())
     _lib.check(rc, "df3d_add_layernorm")
@@ -1361,7 +1369,7 @@ def batch_norm_rows(bn, x, relu=False):
 
 
 # ------------------------------------------------------------------------- small-group transformer layers on row kernels
-def group_attention(qkv, tokens, groups, heads):
+def group_attention(qkv, tokens, groups, heads, split_only=False):
     """softmax(q k^T / sqrt(16)) v inside every group: qkv [tokens * groups, 3 * heads * 16] fp32 rows (row = token * groups +
     group; q | k | v blocks) -> [tokens * groups, heads * 16]."""
     lib = _lib.load()
@@ -1369,6 +1377,11 @@ def group_attention(qkv, tokens, groups, heads):
     C = heads * 16
     if qkv.shape != (tokens * groups, 3 * C):
         raise ValueError("qkv must be [tokens * groups, 3 * heads * 16]")
+    if split_only:                                   # split rows for the out-projection, no fp32 copy
+        sp = torch.empty((tokens * groups, 4 * C), dtype=torch.uint8, device=qkv.device)
+        rc = lib.df3d_group_attention_split(_ptr(qkv), int(tokens), int(groups), int(heads), 16, None, _ptr(sp), _stream())
+        _lib.check(rc, "df3d_group_attention_split")
+        return sp
     out = torch.empty((tokens * groups, C), dtype=torch.float32, device=qkv.device)
     rc = lib.df3d_group_attention(_ptr(qkv), int(tokens), int(groups), int(heads), 16, _ptr(out), _stream())
     _lib.check(rc, "df3d_group_attention")

@@ -82,11 +82,12 @@ class TransformerEncoderLayerPreNorm(nn.Module):
         R = L * G
         a = self.self_attn
         ident = _ops.identity_table(R, src.device)
-        x1 = _ops.add_layernorm(src.reshape(R, C).contiguous(), None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qkv, _ = _ops.conv_rows_split(_ops.split_rows(x1), C, 0, _ops.packed_linear(a.in_proj_weight, 64), 64, 3, ident, R,
+        x1, s1 = _ops.add_layernorm(src.reshape(R, C).contiguous(), None, self.norm1.weight, self.norm1.bias, self.norm1.eps,
+                                    want_split=True)
+        qkv, _ = _ops.conv_rows_split(s1, C, 0, _ops.packed_linear(a.in_proj_weight, 64), 64, 3, ident, R,
                                       a.in_proj_bias.detach())
-        o = _ops.group_attention(qkv, L, G, a.num_heads)
-        att, _ = _ops.sparse_conv_split(_ops.split_rows(o), _ops.packed_linear(a.out_proj.weight), ident, R, C, C,
+        so = _ops.group_attention(qkv, L, G, a.num_heads, split_only=True)
+        att, _ = _ops.sparse_conv_split(so, _ops.packed_linear(a.out_proj.weight), ident, R, C, C,
                                         bias=a.out_proj.bias.detach(), emit_split=False)
         x3 = _ops.add_layernorm(x1, att, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         # FFN + residual: the fused feed-forward kernel (csrc/ffn.hip, 64-wide rows): the hidden activation stays in registers

@@ -478,6 +478,10 @@ int df3d_ms_deform_attn_backward(const float *value, const int64_t *spatial_shap
  * sequence-first order (row = token * groups + group; the in-projection's q | k | v blocks) -> out [tokens*groups][heads*16];
  * softmax(q k^T / 4) v per group and head, no masks. */
 int df3d_group_attention(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out, void *stream);
+/* ... also (or only: out may be NULL) as split rows [tokens*groups][heads*16 * 4 bytes] (per 8 channels 16 B bf16 hi | 16 B
+ * bf16 lo), what the out-projection on the split-precision kernels reads. */
+int df3d_group_attention_split(const float *qkv, int tokens, int groups, int heads, int head_dim, float *out, void *out_split,
+                               void *stream);
 
 /* Grouped features + positional MLP of the LocalTransformer (pointformer.py:232-262) in one pass:
  * out[r] = feat[sel[r]] + W1 relu(W0 xyz[r] + b0) + b1 with feat [*, channels], sel [rows] int64, xyz [rows][3], W0 [hidden][3]
@@ -619,6 +623,9 @@ int df3d_actr_prep(const float *q, const float *qi, const float *pos, long long 
                    void *stream);
 int df3d_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, float eps,
                        long long rows, int C, float *out, void *stream);
+/* df3d_add_layernorm that also writes the split rows of its output (C % 8 == 0) for a following split-precision layer. */
+int df3d_add_layernorm_split(const float *x, const float *y, const float *gamma, const float *beta, float eps, long long rows,
+                             int C, float *out, void *out_split, void *stream);
 int df3d_bigate_sum(const float *q, const float *qi, const float *wb, const float *bb, const float *wa,
                     const float *ba, long long rows, int C, float *q_out, float *qi_out, void *stream);
 int df3d_ms_deform_attn_fused(const float *value, long long value_stride, const int64_t *spatial_shapes,

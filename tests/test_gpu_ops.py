@@ -1069,3 +1069,19 @@ def test_linear_rows_helper(dev, rows, cin, cout, bias):
     assert float((got.cpu().double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
     y = ops.linear_rows(x.to(dev).requires_grad_(True), lin)               # grad mode: the module itself
     assert y.requires_grad
+
+
+@pytest.mark.gpu
+def test_split_row_outputs_of_layernorm_and_group_attention(dev):
+    """The split rows `add_layernorm(want_split=True)` and `group_attention(split_only=True)` write equal `split_rows` of
+    their fp32 outputs bit for bit."""
+    from dualfusion import ops
+    gen = torch.Generator().manual_seed(11)
+    for C in (64, 128, 256):
+        x, y = torch.randn((777, C), generator=gen).to(dev), torch.randn((777, C), generator=gen).to(dev)
+        w, b = torch.randn(C, generator=gen).to(dev), torch.randn(C, generator=gen).to(dev)
+        out, sp = ops.add_layernorm(x, y, w, b, 1e-5, want_split=True)
+        assert torch.equal(out, ops.add_layernorm(x, y, w, b, 1e-5)) and torch.equal(sp, ops.split_rows(out))
+    qkv = torch.randn((32 * 41, 192), generator=gen).to(dev)
+    o = ops.group_attention(qkv, 32, 41, 4)
+    assert torch.equal(ops.group_attention(qkv, 32, 41, 4, split_only=True), ops.split_rows(o))
