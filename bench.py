@@ -292,6 +292,11 @@ def roofline_from_timer(timer, meta_timer, want=None):
     # same kernel; otherwise null.
     try:
         pm = json.load(open(PMC_SUMMARY))
+        if pm.get("kernel_key") != [cin, cout, K, split]:      # the summary's main entry is another kernel: its table of the
+            cal = pm.get("fetch_calibration")                   # other K = 27 kernels of the same passes may hold this one
+            pm = next((v for v in pm.get("other_k27_kernels", {}).values() if v.get("kernel_key") == [cin, cout, K, split]), {})
+            if pm and cal and "fetch_calibration" not in pm:
+                pm["fetch_calibration"] = cal
         if pm.get("kernel_key") == [cin, cout, K, split]:
             roof["traffic"] = pm["traffic_bytes_per_launch"]
             roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, separate passes, same command)" % os.path.basename(PMC_SUMMARY)
