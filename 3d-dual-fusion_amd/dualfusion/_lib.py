@@ -142,6 +142,16 @@ SIGNATURES = {
                                        c_void_p, c_size_t, c_void_p]),
     "df3d_transfusion_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
+    "df3d_boxes_overlap_bev_xyxyr": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "df3d_tf_match_cost": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_draw_heatmap_gaussian": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                           c_void_p, c_void_p]),
+    "df3d_gaussian_focal_loss_workspace_bytes": (c_size_t, [c_longlong]),
+    "df3d_gaussian_focal_loss": (c_int, [c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_float,
+                                         c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_tf_query_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_sparse_maxpool": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "df3d_sparse_maxpool_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "df3d_dynamic_voxelize": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -36,21 +36,28 @@ def launch_ranks(nprocs, script, argv, master_port=None, env=None, timeout=None)
     return subprocess.call(cmd, env=e, timeout=timeout)
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, single=False):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run).
-    Returns (rank, local_rank, world_size); no-op for a single process."""
+    Returns (rank, local_rank, world_size).  A single process stays without a process group unless `single` is set (or
+    the launcher exported WORLD_SIZE=1 explicitly): then a one-rank group is created, so that the collectives of the step
+    run through the backend (RCCL) at N = 1 exactly as they do at N > 1."""
+    launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend, init_method="env://")
+        if launched and "MASTER_PORT" in os.environ:
+            dist.init_process_group(backend, init_method="env://")
+        else:
+            dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1)
     return rank, local, world
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """A process group exists (any world size: a one-rank RCCL group still runs its collectives)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def frame_shard(num_frames, rank, world):
@@ -154,23 +161,28 @@ def allreduce_grads(params, coalesce=True, bucket_size_mb=-1):
 class GradBucketReducer(object):
     """Bucketed gradient all-reduce overlapped with backward -- what `DistributedDataParallel` does for the reference
     (CP/det3d/torchie/apis/train.py:289-295), laid out for one MI355X node: xGMI is point-to-point (a ring all-reduce is
-    bound by one ~150 GB/s link), so the gradients travel in FEW LARGE buckets (default 64 MB: the whole CenterPoint
-    detector is two), and the buckets are the gradients' own storage:
+    bound by one ~150 GB/s link), so the gradients travel in FEW LARGE buckets (default 16 MB: the 35.8 MB of the
+    CenterPoint detector are three, so the first two travel while backward still runs), and the buckets are the
+    gradients' own storage:
 
       * at construction every parameter's `.grad` becomes a view into one flat buffer per bucket (parameters in reverse
         registration order = the order backward produces them) -- no flatten / copy-back passes per step (the
         reference's coalesced path copies every gradient twice);
-      * a post-accumulate-grad hook counts a bucket's finished gradients; the last one launches the bucket's all-reduce
-        asynchronously (RCCL runs it on its own stream while backward continues);
+      * a post-accumulate-grad hook counts a bucket's finished gradients; a complete bucket is launched asynchronously
+        (RCCL runs it on its own stream while backward continues) -- STRICTLY IN BUCKET ORDER: bucket i only once buckets
+        0..i-1 are launched, otherwise it waits for them or for `finish()`.  Every rank therefore issues the same sequence
+        of collectives even when the set of parameters that received a gradient differs between ranks (a data-dependent
+        branch), which is what DDP guarantees with its fixed bucket order;
       * `finish()` waits for the outstanding buckets and scales by 1 / world size (folded into the all-reduce for
         backends with an AVG op).
 
     Parameters that received no gradient in a step (unused branches) keep zeros in the bucket, like
     `find_unused_parameters=True`; their bucket is launched by `finish()`."""
 
-    def __init__(self, params, bucket_mb=64.0):
+    def __init__(self, params, bucket_mb=16.0):
         self.params = [p for p in params if p.requires_grad]
         self.world = dist.get_world_size() if is_dist() else 1
+        self._group = is_dist()
         self.buckets = []            # dict(flat, params, pending, handle)
         limit = int(bucket_mb * 1024 * 1024)
         cur, size = [], 0
@@ -184,7 +196,7 @@ class GradBucketReducer(object):
         if cur:
             self._seal(cur)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        self._launched = set()
+        self._next = 0               # buckets [0, _next) are launched
 
     def _seal(self, plist):
         flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
@@ -199,12 +211,15 @@ class GradBucketReducer(object):
             p._df3d_bucket = b
         self.buckets.append(b)
 
-    def _launch(self, b):
-        if b["index"] in self._launched:
-            return
-        self._launched.add(b["index"])
-        if self.world > 1:
-            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+    def _launch_ready(self, force=False):
+        """Launch buckets in index order while they are complete (all of them with `force`)."""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b["pending"] > 0 and not force:
+                return
+            self._next += 1
+            if self._group:
+                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
 
     def _on_grad(self, p):
         b = p._df3d_bucket
@@ -215,7 +230,7 @@ class GradBucketReducer(object):
             p.grad = view
         b["pending"] -= 1
         if b["pending"] == 0:
-            self._launch(b)
+            self._launch_ready()
 
     @staticmethod
     def _offset(b, p):
@@ -239,12 +254,11 @@ class GradBucketReducer(object):
             for p in b["params"]:
                 if p.grad is None or p.grad.data_ptr() != self._view(b, p).data_ptr():
                     p.grad = self._view(b, p)
-        self._launched = set()
+        self._next = 0
 
     def finish(self):
         """After backward: launch what is left (buckets with unused parameters), wait, average."""
-        for b in self.buckets:
-            self._launch(b)
+        self._launch_ready(force=True)
         for b in self.buckets:
             if b["handle"] is not None:
                 b["handle"].wait()

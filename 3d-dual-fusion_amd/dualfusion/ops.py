@@ -781,6 +781,139 @@ class CenterHeadLossFunction(torch.autograd.Function):
         return grad * scale, None, None, None, None, None, None, None
 
 
+
+# ------------------------------------------------------------------------- TransFusion head: matching costs + losses
+class _TfMatchCfg(ctypes.Structure):
+    _fields_ = [("out_size_factor", ctypes.c_float), ("voxel_size", ctypes.c_float * 2), ("pc_range", ctypes.c_float * 2),
+                ("point_cloud_range", ctypes.c_float * 6), ("cls_weight", ctypes.c_float), ("cls_alpha", ctypes.c_float),
+                ("cls_gamma", ctypes.c_float), ("cls_eps", ctypes.c_float), ("reg_weight", ctypes.c_float),
+                ("iou_weight", ctypes.c_float)]
+
+
+class _TfSplatCfg(ctypes.Structure):
+    _fields_ = [("voxel_size", ctypes.c_float * 2), ("out_size_factor", ctypes.c_float),
+                ("point_cloud_range", ctypes.c_float * 2), ("gaussian_overlap", ctypes.c_double), ("min_radius", ctypes.c_int)]
+
+
+class _TfLossCfg(ctypes.Structure):
+    _fields_ = [("encode_step", ctypes.c_float * 2), ("pc_range", ctypes.c_float * 2), ("cls_alpha", ctypes.c_float),
+                ("cls_gamma", ctypes.c_float), ("cls_loss_weight", ctypes.c_float), ("bbox_loss_weight", ctypes.c_float),
+                ("pos_weight", ctypes.c_float), ("code_weights", ctypes.c_float * 10)]
+
+
+def boxes_overlap_bev_xyxyr(boxes_a, boxes_b):
+    """[N,5] x [M,5] boxes (x1, y1, x2, y2, angle) -> [N,M] overlap areas (the TransFusion tree's boxes_overlap_bev_gpu)."""
+    lib = _lib.load()
+    boxes_a, boxes_b = boxes_a.contiguous(), boxes_b.contiguous()
+    _chk(boxes_a, torch.float32, "boxes_a")
+    _chk(boxes_b, torch.float32, "boxes_b")
+    if boxes_a.dim() != 2 or boxes_b.dim() != 2 or boxes_a.shape[1] != 5 or boxes_b.shape[1] != 5:
+        raise ValueError("boxes must be [N, 5] (x1, y1, x2, y2, angle)")
+    out = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
+    rc = lib.df3d_boxes_overlap_bev_xyxyr(_ptr(boxes_a), boxes_a.shape[0], _ptr(boxes_b), boxes_b.shape[0], _ptr(out), _stream())
+    _lib.check(rc, "df3d_boxes_overlap_bev_xyxyr")
+    return out
+
+
+def _gt_pack_check(gt, gt_labels, gt_off, batch):
+    _chk(gt, torch.float32, "gt")
+    _chk(gt_labels, torch.int32, "gt_labels")
+    _chk(gt_off, torch.int32, "gt_off")
+    if gt.dim() != 2 or gt_labels.shape[0] != gt.shape[0] or gt_off.shape[0] != batch + 1:
+        raise ValueError("gt must be [G, D], gt_labels [G], gt_off [B + 1]")
+
+
+def tf_match_cost(rows, col_cls, num_classes, gt, gt_labels, gt_off, gmax, out_size_factor, voxel_size, pc_range,
+                  point_cloud_range, cls_weight, cls_alpha, cls_gamma, cls_eps, reg_weight, iou_weight):
+    """df3d_tf_match_cost.  rows [B, P, ld] fp32 -> (cost [B, P, gmax], iou [B, P, gmax], boxes [B, P, 7])."""
+    lib = _lib.load()
+    _chk(rows, torch.float32, "rows")
+    B, P, ld = rows.shape
+    _gt_pack_check(gt, gt_labels, gt_off, B)
+    cfg = _TfMatchCfg()
+    cfg.out_size_factor = float(out_size_factor)
+    for i in range(2):
+        cfg.voxel_size[i], cfg.pc_range[i] = float(voxel_size[i]), float(pc_range[i])
+    for i in range(6):
+        cfg.point_cloud_range[i] = float(point_cloud_range[i])
+    cfg.cls_weight, cfg.cls_alpha, cfg.cls_gamma, cfg.cls_eps = float(cls_weight), float(cls_alpha), float(cls_gamma), float(cls_eps)
+    cfg.reg_weight, cfg.iou_weight = float(reg_weight), float(iou_weight)
+    gmax = int(gmax)
+    cost = torch.empty((B, P, gmax), dtype=torch.float32, device=rows.device)
+    iou = torch.empty((B, P, gmax), dtype=torch.float32, device=rows.device)
+    boxes = torch.empty((B, P, 7), dtype=torch.float32, device=rows.device)
+    rc = lib.df3d_tf_match_cost(_ptr(rows), B, P, ld, int(col_cls), int(num_classes), _ptr(gt), _ptr(gt_labels), _ptr(gt_off),
+                                int(gt.shape[1]), gmax, ctypes.byref(cfg), _ptr(cost), _ptr(iou), _ptr(boxes), _stream())
+    _lib.check(rc, "df3d_tf_match_cost")
+    return cost, iou, boxes
+
+
+def draw_heatmap_gaussian(gt, gt_labels, gt_off, batch, num_classes, H, W, voxel_size, out_size_factor, point_cloud_range,
+                          gaussian_overlap, min_radius):
+    """df3d_draw_heatmap_gaussian -> heat-map targets [B, C, H, W] fp32."""
+    lib = _lib.load()
+    _gt_pack_check(gt, gt_labels, gt_off, int(batch))
+    cfg = _TfSplatCfg()
+    cfg.voxel_size[0], cfg.voxel_size[1] = float(voxel_size[0]), float(voxel_size[1])
+    cfg.out_size_factor = float(out_size_factor)
+    cfg.point_cloud_range[0], cfg.point_cloud_range[1] = float(point_cloud_range[0]), float(point_cloud_range[1])
+    cfg.gaussian_overlap, cfg.min_radius = float(gaussian_overlap), int(min_radius)
+    heat = torch.empty((int(batch), int(num_classes), int(H), int(W)), dtype=torch.float32, device=gt_off.device)
+    rc = lib.df3d_draw_heatmap_gaussian(_ptr(gt), _ptr(gt_labels), _ptr(gt_off), int(gt.shape[1]), int(gt.shape[0]), int(batch),
+                                        int(num_classes), int(H), int(W), ctypes.byref(cfg), _ptr(heat), _stream())
+    _lib.check(rc, "df3d_draw_heatmap_gaussian")
+    return heat
+
+
+def gaussian_focal_loss(logits, target, alpha=2.0, gamma=4.0, loss_weight=1.0, want_grad=False):
+    """df3d_gaussian_focal_loss.  logits: fp32 [B, C, H, W] view (NCHW or a permuted channels-last map), target
+    contiguous [B, C, H, W].  Returns (out [3] = loss, #ones, gradient scale; grad [B, C, H, W] unscaled or None)."""
+    lib = _lib.load()
+    _chk(target, torch.float32, "target")
+    B, C, H, W = target.shape
+    if (not logits.is_cuda or logits.dtype != torch.float32 or tuple(logits.shape) != (B, C, H, W)
+            or logits.stride(2) != W * logits.stride(3)):
+        raise ValueError("logits must be a CUDA fp32 [B, C, H, W] view whose pixels are evenly strided")
+    n = B * C * H * W
+    ws = torch.empty((max(int(lib.df3d_gaussian_focal_loss_workspace_bytes(n)), 8),), dtype=torch.uint8, device=target.device)
+    out = torch.empty((3,), dtype=torch.float32, device=target.device)
+    grad = torch.empty((B, C, H, W), dtype=torch.float32, device=target.device) if want_grad else None
+    rc = lib.df3d_gaussian_focal_loss(_ptr(logits), logits.stride(0), logits.stride(1), logits.stride(3), _ptr(target), B, C,
+                                      H * W, float(alpha), float(gamma), float(loss_weight), _ptr(grad), _ptr(out), _ptr(ws),
+                                      ws.numel(), _stream())
+    _lib.check(rc, "df3d_gaussian_focal_loss")
+    return out, grad
+
+
+def tf_query_loss(rows, assigned, iou, num_proposals, col_cls, num_classes, code_size, gt, gt_labels, gt_off, encode_step,
+                  pc_range, cls_alpha, cls_gamma, cls_loss_weight, bbox_loss_weight, pos_weight, code_weights,
+                  want_grad=False):
+    """df3d_tf_query_loss.  Returns (out [2 * layers + 2], grad [B, P_all, ld] or None)."""
+    lib = _lib.load()
+    _chk(rows, torch.float32, "rows")
+    _chk(assigned, torch.int32, "assigned")
+    _chk(iou, torch.float32, "iou")
+    B, P_all, ld = rows.shape
+    _gt_pack_check(gt, gt_labels, gt_off, B)
+    if tuple(assigned.shape) != (B, P_all) or iou.shape[:2] != rows.shape[:2]:
+        raise ValueError("assigned must be [B, P_all] and iou [B, P_all, gmax]")
+    cfg = _TfLossCfg()
+    for i in range(2):
+        cfg.encode_step[i], cfg.pc_range[i] = float(encode_step[i]), float(pc_range[i])
+    cfg.cls_alpha, cfg.cls_gamma = float(cls_alpha), float(cls_gamma)
+    cfg.cls_loss_weight, cfg.bbox_loss_weight, cfg.pos_weight = float(cls_loss_weight), float(bbox_loss_weight), float(pos_weight)
+    for i in range(10):
+        cfg.code_weights[i] = float(code_weights[i]) if i < len(code_weights) else 0.0
+    layers = P_all // int(num_proposals)
+    out = torch.empty((2 * layers + 2,), dtype=torch.float32, device=rows.device)
+    grad = torch.zeros_like(rows) if want_grad else None
+    rc = lib.df3d_tf_query_loss(_ptr(rows), _ptr(assigned), _ptr(iou), B, P_all, int(num_proposals), ld, int(col_cls),
+                                int(num_classes), int(code_size), _ptr(gt), _ptr(gt_labels), _ptr(gt_off), int(gt.shape[1]),
+                                int(iou.shape[2]), ctypes.byref(cfg), _ptr(grad), _ptr(out), _stream())
+    _lib.check(rc, "df3d_tf_query_loss")
+    return out, grad
+
+
 class _QueryHeads(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("heatmap", "center", "height", "dim", "rot", "vel")] + \
                [(n, ctypes.c_int) for n in ("ld_heatmap", "ld_center", "ld_height", "ld_dim", "ld_rot", "ld_vel")]

@@ -131,3 +131,18 @@ def centerhead_targets(batch, num_classes, hw=(180, 180), max_objs=500, seed=0, 
         ex["hm"].append(hm), ex["ind"].append(ind), ex["mask"].append(mask), ex["cat"].append(cat)
         ex["anno_box"].append(box)
     return ex
+
+
+def nusc_gt_boxes(seed=0, objs=(15, 60), num_classes=10, pc_range=NUSC_RANGE):
+    """Ground truth of one nuScenes-shaped sample as mmdet3d hands it to the head: boxes [G, 9] f32
+    (x, y, z_bottom, w, l, h, yaw, vx, vy) inside the BEV range and a class id per box [G] i64."""
+    rs = np.random.RandomState(90000 + seed)
+    n = int(rs.randint(objs[0], objs[1] + 1))
+    xy = rs.uniform(0.92 * pc_range[0], 0.92 * pc_range[3], (n, 2))
+    cls = rs.randint(0, num_classes, n)
+    base = np.array([[1.95, 4.6, 1.7], [2.5, 6.9, 2.8], [2.9, 6.4, 3.2], [2.9, 11.0, 3.5], [2.9, 12.3, 3.9], [2.5, 0.5, 1.0],
+                     [0.8, 2.1, 1.5], [0.6, 1.7, 1.3], [0.7, 0.7, 1.8], [0.4, 0.4, 1.1]])[cls % 10]
+    dims = base * np.exp(rs.normal(0, 0.12, (n, 3)))
+    boxes = np.concatenate([xy, rs.uniform(-2.5, -0.5, (n, 1)), dims, rs.uniform(-np.pi, np.pi, (n, 1)),
+                            rs.normal(0, 1.5, (n, 2))], 1).astype(np.float32)
+    return boxes, cls.astype(np.int64)

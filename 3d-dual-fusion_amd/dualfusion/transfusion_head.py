@@ -13,7 +13,12 @@ Device path in eval mode:
     200 x 32 400 cross-attention as `df3d_cross_attention` (keys split over workgroups, log-sum-exp merge), all
     prediction heads as two GEMMs (BN folded, block-diagonal second layer);
   * `get_bboxes` = `df3d_transfusion_decode` (one launch).
-Training-mode forward runs the plain torch modules (autograd); `loss` / target assignment are out of scope."""
+Training-mode forward runs the plain torch modules (autograd).
+
+`loss` / `get_targets` (transfusion_head.py:1048-1283; round 3): Hungarian target assignment + focal / L1 / Gaussian-focal
+losses.  Plain torch formulation (`loss`, autograd) from dualfusion/tf_losses.py; on the device the matching costs
+(incl. the rotated 3-D IoU), the Gaussian heat-map targets and the three losses with their gradients are csrc/tfloss.hip
+kernels (`loss_device`), the assignment itself `scipy.optimize.linear_sum_assignment` on the host as in the reference."""
 import copy
 
 import torch
@@ -21,6 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops as _ops
+from . import tf_losses as _tl
 from .registry import HEADS, MM_HEADS
 
 
@@ -167,7 +173,7 @@ class TransFusionBBoxCoder(object):
         self.post_center_range, self.score_threshold, self.code_size = post_center_range, score_threshold, code_size
 
     def encode(self, dst_boxes):
-        t = torch.zeros([dst_boxes.shape[0], self.code_size]).to(dst_boxes.device)
+        t = dst_boxes.new_zeros((dst_boxes.shape[0], self.code_size))
         t[:, 0] = (dst_boxes[:, 0] - self.pc_range[0]) / (self.out_size_factor * self.voxel_size[0])
         t[:, 1] = (dst_boxes[:, 1] - self.pc_range[1]) / (self.out_size_factor * self.voxel_size[1])
         t[:, 3:6] = dst_boxes[:, 3:6].log()
@@ -198,6 +204,47 @@ class TransFusionBBoxCoder(object):
             mask &= final_scores > self.score_threshold
         return [dict(bboxes=boxes[i, mask[i]], scores=final_scores[i, mask[i]], labels=final_preds[i, mask[i]])
                 for i in range(B)]
+
+
+class _GaussianFocalFunction(torch.autograd.Function):
+    """loss_heatmap on the device (df3d_gaussian_focal_loss); backward = the stored gradient x its normaliser."""
+
+    @staticmethod
+    def forward(ctx, logits, target, alpha, gamma, loss_weight, want_grad):
+        out, grad = _ops.gaussian_focal_loss(logits.detach(), target, alpha, gamma, loss_weight, want_grad=want_grad)
+        ctx.saved = (grad, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, out = ctx.saved
+        if grad is None:
+            raise RuntimeError("loss_device ran without gradients enabled")
+        return grad * (g * out[2]), None, None, None, None, None
+
+
+class _QueryLossFunction(torch.autograd.Function):
+    """Per-layer classification / box losses (df3d_tf_query_loss).  The kernel writes d(loss_cls_l) / d(class logits) and
+    d(loss_bbox_l) / d(box codes) into disjoint columns of one buffer; backward scales each block by its upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, rows, assigned, iou, K, code, C, gt, lab, off, step, pc_range, alpha, gamma, w_cls, w_bbox, pos_weight,
+                code_weights, want_grad):
+        out, grad = _ops.tf_query_loss(rows.detach(), assigned, iou, K, code, C, code, gt, lab, off, step, pc_range, alpha, gamma,
+                                       w_cls, w_bbox, pos_weight, code_weights, want_grad=want_grad)
+        ctx.saved = (grad, K, code, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, K, code, C = ctx.saved
+        if grad is None:
+            raise RuntimeError("loss_device ran without gradients enabled")
+        B, P_all, ld = grad.shape
+        layers = P_all // K
+        pair = g[:2 * layers].view(layers, 1, 2)                                 # (d cls, d bbox) per layer
+        mult = torch.cat([pair[..., 1:2].expand(layers, K, code), pair[..., 0:1].expand(layers, K, C)], 2).reshape(1, P_all, ld)
+        return (grad * mult,) + (None,) * 17
 
 
 _EXEMPT = {'nuScenes': (8, 9), 'Waymo': (1, 2)}        # transfusion_head.py:856-861
@@ -235,6 +282,9 @@ class TransFusionHead(nn.Module):
         coder = dict(bbox_coder or {})
         coder.pop('type', None)
         self.bbox_coder = TransFusionBBoxCoder(**coder) if coder else None
+        self.loss_cls, self.loss_bbox = _tl.build_loss(loss_cls), _tl.build_loss(loss_bbox)
+        self.loss_iou, self.loss_heatmap = _tl.build_loss(loss_iou), _tl.build_loss(loss_heatmap)
+        self.sampling = False
         self.fuse_img = False
         self.shared_conv = nn.Conv2d(in_channels, hidden_channel, kernel_size=3, padding=1, bias=bool(bias))
         if initialize_by_heatmap:
@@ -261,6 +311,16 @@ class TransFusionHead(nn.Module):
         y_size = self.test_cfg['grid_size'][1] // self.test_cfg['out_size_factor']
         self.bev_pos = self.create_2D_grid(x_size, y_size)
         self.query_labels = None
+        self._init_assigner_sampler()
+
+    def _init_assigner_sampler(self):
+        """transfusion_head.py:781-795."""
+        if self.train_cfg is None:
+            return
+        self.bbox_sampler = _tl.PseudoSampler()
+        assigner = self.train_cfg['assigner']
+        self.bbox_assigner = ([_tl.build_assigner(a) for a in assigner] if isinstance(assigner, list)
+                              else _tl.build_assigner(assigner))
 
     def create_2D_grid(self, x_size, y_size):
         """[1, x_size * y_size, 2]: entry i * y_size + j = (j + 0.5, i + 0.5) (transfusion_head.py:758-765)."""
@@ -302,7 +362,7 @@ class TransFusionHead(nn.Module):
             query_feat = flat.gather(index=top_index[:, None, :].expand(-1, flat.shape[1], -1), dim=-1)
             self.query_labels = top_class
             one_hot = F.one_hot(top_class, num_classes=self.num_classes).permute(0, 2, 1)
-            query_feat = query_feat + self.class_encoding(one_hot.float())
+            query_feat = query_feat + self.class_encoding(one_hot.to(query_feat.dtype))
             query_pos = bev_pos.gather(index=top_index[:, :, None].expand(-1, -1, 2), dim=1)
         else:
             query_feat = self.query_feat.repeat(B, 1, 1)
@@ -502,9 +562,217 @@ class TransFusionHead(nn.Module):
         return self._collect(ret_dicts)
 
     # ------------------------------------------------------------------ boxes
-    def loss(self, *args, **kwargs):
-        raise NotImplementedError("target assignment and losses are training rows outside this build's scope "
-                                  "(SURVEY.md section 8f row 4)")
+    def get_targets(self, gt_bboxes_3d, gt_labels_3d, preds_dict):
+        """transfusion_head.py:1048-1086: per-sample targets concatenated over the batch.  Returns labels [B, P],
+        label_weights [B, P], bbox_targets [B, P, code], bbox_weights [B, P, code], ious [B, P], num_pos, matched_ious
+        (mean over samples) and, with heat-map initialisation, the dense heat-map target [B, C, H, W]."""
+        per_sample = []
+        for b in range(len(gt_bboxes_3d)):
+            one = {k: v[b:b + 1] for k, v in preds_dict[0].items()}
+            per_sample.append(self.get_targets_single(gt_bboxes_3d[b], gt_labels_3d[b], one, b))
+        cols = list(zip(*per_sample))
+        out = [torch.cat(cols[i], dim=0) for i in range(5)] + [int(sum(cols[5])), float(sum(cols[6]) / max(len(cols[6]), 1))]
+        if self.initialize_by_heatmap:
+            out.append(torch.cat(cols[7], dim=0))
+        return tuple(out)
+
+    def _gt_tensor(self, gt_bboxes_3d, device):
+        t = gt_bboxes_3d.tensor if hasattr(gt_bboxes_3d, "tensor") else gt_bboxes_3d
+        return t.to(device)
+
+    def get_targets_single(self, gt_bboxes_3d, gt_labels_3d, preds_dict, batch_idx):
+        """transfusion_head.py:1088-1216 for one sample (HungarianAssigner3D + PseudoSampler)."""
+        if self.train_cfg is None:
+            raise RuntimeError("TransFusionHead needs train_cfg for target assignment")
+        if self.train_cfg['assigner']['type'] != 'HungarianAssigner3D':
+            raise NotImplementedError("only HungarianAssigner3D (the 3D-Dual-Fusion configs' assigner)")
+        P_all = preds_dict['center'].shape[-1]
+        dev = preds_dict['center'].device
+        d = {k: preds_dict[k].detach().clone() for k in ('heatmap', 'center', 'height', 'dim', 'rot')}
+        vel = preds_dict['vel'].detach().clone() if 'vel' in preds_dict else None
+        boxes = self.bbox_coder.decode(d['heatmap'], d['rot'], d['dim'], d['center'], d['height'], vel)[0]['bboxes']
+        gt = self._gt_tensor(gt_bboxes_3d, dev)
+        gt_labels_3d = gt_labels_3d.to(dev)
+        layers = self.num_decoder_layers if self.auxiliary else 1
+        K = self.num_proposals
+        results = [self.bbox_assigner.assign(boxes[K * i:K * (i + 1)], gt, gt_labels_3d, d['heatmap'][..., K * i:K * (i + 1)],
+                                             self.train_cfg) for i in range(layers)]
+        gt_inds = torch.cat([r.gt_inds for r in results])
+        # the reference concatenates `max_overlaps` and so cannot take a frame without ground truth (None); zeros here
+        ious = torch.cat([r.max_overlaps if r.max_overlaps is not None else boxes.new_zeros(K) for r in results])
+        sampled = self.bbox_sampler.sample(_tl.AssignResult(sum(r.num_gts for r in results), gt_inds, ious,
+                                                            torch.cat([r.labels for r in results])), boxes, gt)
+        pos, neg = sampled.pos_inds, sampled.neg_inds
+        assert len(pos) + len(neg) == P_all
+        code = self.bbox_coder.code_size
+        bbox_targets, bbox_weights = boxes.new_zeros((P_all, code)), boxes.new_zeros((P_all, code))
+        ious = torch.clamp(ious, min=0.0, max=1.0)
+        labels = boxes.new_zeros(P_all, dtype=torch.long)
+        label_weights = boxes.new_zeros(P_all, dtype=torch.long)
+        if gt_labels_3d is not None:
+            labels += self.num_classes
+        if len(pos) > 0:
+            bbox_targets[pos, :] = self.bbox_coder.encode(sampled.pos_gt_bboxes)
+            bbox_weights[pos, :] = 1.0
+            labels[pos] = gt_labels_3d[sampled.pos_assigned_gt_inds] if gt_labels_3d is not None else 1
+            pw = self.train_cfg['pos_weight']
+            label_weights[pos] = 1.0 if pw <= 0 else pw
+        if len(neg) > 0:
+            label_weights[neg] = 1.0
+        mean_iou = float(ious[pos].sum() / max(len(pos), 1))
+        ret = [labels[None], label_weights[None], bbox_targets[None], bbox_weights[None], ious[None], int(pos.shape[0]), mean_iou]
+        if self.initialize_by_heatmap:
+            ret.append(self.heatmap_targets([gt], [gt_labels_3d], dev))
+        return tuple(ret)
+
+    def _splat_geometry(self, gt):
+        """Per ground-truth box (x, y, z_bottom, w, l, h, ...): integer centre pixel and radius of its Gaussian
+        (transfusion_head.py:1186-1207), element-wise in fp32; radius < 0 marks a box that is not drawn."""
+        cfg = self.train_cfg
+        osf = cfg['out_size_factor']
+        vs = gt.new_tensor(cfg['voxel_size'])
+        pc = gt.new_tensor(cfg['point_cloud_range'])
+        width, length = gt[:, 3] / vs[0] / osf, gt[:, 4] / vs[1] / osf
+        ok = (width > 0) & (length > 0)
+        radius = _tl.gaussian_radius((length, width), min_overlap=cfg['gaussian_overlap'])
+        radius = torch.clamp(torch.nan_to_num(radius, nan=0.0).to(torch.int32), min=int(cfg['min_radius']))
+        cx = ((gt[:, 0] - pc[0]) / vs[0] / osf).to(torch.int32)
+        cy = ((gt[:, 1] - pc[1]) / vs[1] / osf).to(torch.int32)
+        return cx, cy, torch.where(ok, radius, torch.full_like(radius, -1))
+
+    def heatmap_targets(self, gt_list, label_list, device):
+        """Dense heat-map targets [B, C, y_len, x_len] of a list of per-sample ground truth tensors."""
+        cfg = self.train_cfg
+        fx, fy = [int(g) // cfg['out_size_factor'] for g in cfg['grid_size'][:2]]
+        heatmap = torch.zeros((len(gt_list), self.num_classes, fy, fx), dtype=torch.float32, device=device)
+        for b, (gt, lab) in enumerate(zip(gt_list, label_list)):
+            if gt.shape[0] == 0:
+                continue
+            cx, cy, radius = [t.tolist() for t in self._splat_geometry(gt.float())]
+            for i, c in enumerate(lab.tolist()):
+                if radius[i] >= 0:
+                    _tl.draw_heatmap_gaussian(heatmap[b, c], (cx[i], cy[i]), radius[i])
+        return heatmap
+
+    def loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, **kwargs):
+        """transfusion_head.py:1218-1283: dict(loss_heatmap, layer_{i}_loss_cls, layer_{i}_loss_bbox, matched_ious).
+        Like the reference this turns `preds_dicts[0][0]['dense_heatmap']` into clamped probabilities IN PLACE."""
+        targets = self.get_targets(gt_bboxes_3d, gt_labels_3d, preds_dicts[0])
+        labels, label_weights, bbox_targets, bbox_weights, ious, num_pos, matched_ious = targets[:7]
+        if hasattr(self, 'on_the_image_mask'):
+            label_weights = label_weights * self.on_the_image_mask
+            bbox_weights = bbox_weights * self.on_the_image_mask[:, :, None]
+            num_pos = bbox_weights.max(-1).values.sum()
+        p = preds_dicts[0][0]
+        losses = dict()
+        if self.initialize_by_heatmap:
+            heatmap = targets[7]
+            losses['loss_heatmap'] = self.loss_heatmap(_tl.clip_sigmoid(p['dense_heatmap']), heatmap,
+                                                       avg_factor=max(heatmap.eq(1).float().sum().item(), 1))
+        K = self.num_proposals
+        code_weights = self.train_cfg.get('code_weights', None)
+        layers = self.num_decoder_layers if self.auxiliary else 1
+        for i in range(layers):
+            last = i == self.num_decoder_layers - 1 or (i == 0 and self.auxiliary is False)
+            prefix = 'layer_-1' if last else 'layer_%d' % i
+            sl = slice(i * K, (i + 1) * K)
+            scores = p['heatmap'][..., sl].permute(0, 2, 1).reshape(-1, self.num_classes)
+            loss_cls = self.loss_cls(scores, labels[..., sl].reshape(-1), label_weights[..., sl].reshape(-1),
+                                     avg_factor=max(num_pos, 1))
+            parts = [p[k][..., sl] for k in ('center', 'height', 'dim', 'rot') + (('vel',) if 'vel' in p else ())]
+            boxes = torch.cat(parts, dim=1).permute(0, 2, 1)
+            reg_weights = bbox_weights[:, sl, :] * bbox_weights.new_tensor(code_weights)
+            losses[prefix + '_loss_cls'] = loss_cls
+            losses[prefix + '_loss_bbox'] = self.loss_bbox(boxes, bbox_targets[:, sl, :], reg_weights, avg_factor=max(num_pos, 1))
+        losses['matched_ious'] = loss_cls.new_tensor(matched_ious)
+        return losses
+
+    # ------------------------------------------------------------------ losses on the device (csrc/tfloss.hip)
+    def _pack_gt(self, gt_bboxes_3d, gt_labels_3d, dev):
+        """Ground truth of a batch as one [G, D] fp32 tensor + labels [G] i32 + offsets [B + 1] i32 on the device, and the
+        per-sample counts on the host (they come from the host: no synchronisation)."""
+        boxes = [(g.tensor if hasattr(g, "tensor") else g).float() for g in gt_bboxes_3d]
+        counts = [int(t.shape[0]) for t in boxes]
+        dim = max([t.shape[1] for t in boxes] + [7])
+        gt = torch.cat([t.reshape(-1, dim) for t in boxes]) if sum(counts) else torch.zeros((0, dim))
+        lab = torch.cat([l.reshape(-1) for l in gt_labels_3d]).to(torch.int32) if sum(counts) else torch.zeros((0,), dtype=torch.int32)
+        off = torch.zeros(len(counts) + 1, dtype=torch.int32)
+        off[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int32), 0)
+        nb = gt.device.type == "cpu"
+        return (gt.to(dev, non_blocking=nb).contiguous(), lab.to(dev, non_blocking=nb).contiguous(),
+                off.to(dev, non_blocking=True), counts)
+
+    def _match_cfg(self):
+        a, c = self.bbox_assigner, self.bbox_coder
+        if not isinstance(a.cls_cost, _tl.FocalLossCost) or not isinstance(a.reg_cost, _tl.BBoxBEVL1Cost):
+            raise NotImplementedError("the device matcher evaluates FocalLossCost + BBoxBEVL1Cost + IoU3DCost")
+        return dict(out_size_factor=c.out_size_factor, voxel_size=c.voxel_size, pc_range=c.pc_range,
+                    point_cloud_range=self.train_cfg['point_cloud_range'], cls_weight=a.cls_cost.weight,
+                    cls_alpha=a.cls_cost.alpha, cls_gamma=a.cls_cost.gamma, cls_eps=a.cls_cost.eps,
+                    reg_weight=a.reg_cost.weight, iou_weight=a.iou_cost.weight)
+
+    def loss_device(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, **kwargs):
+        """`loss` with every tensor operation on the device in seven launches for the whole batch: matching costs (decode +
+        focal cost + BEV-centre cost + rotated 3-D IoU) -> host `linear_sum_assignment` per sample and decoder layer, as the
+        reference -> query losses; Gaussian heat-map targets and their focal loss run while the host matches.  Differentiable
+        (the kernels also write the gradients; `torch.is_grad_enabled()` decides).  Same keys / values as `loss`; unlike it
+        the dense heat-map prediction is left untouched."""
+        import numpy as np
+        if self.train_cfg is None:
+            raise RuntimeError("TransFusionHead needs train_cfg for target assignment")
+        p = preds_dicts[0][0]
+        dev = p['center'].device
+        if dev.type != "cuda":
+            raise _ops._lib.Df3dError("loss_device needs the predictions on the GPU (got %s)" % dev)
+        names = ('center', 'height', 'dim', 'rot') + (('vel',) if 'vel' in p else ())
+        code = self.bbox_coder.code_size
+        rows = torch.cat([p[k] for k in names] + [p['heatmap']], 1).float().permute(0, 2, 1).contiguous()   # [B, P_all, code + C]
+        if rows.shape[2] != code + self.num_classes:
+            raise ValueError("prediction heads do not match bbox_coder.code_size = %d" % code)
+        B, P_all, _ = rows.shape
+        K, C = self.num_proposals, self.num_classes
+        layers = self.num_decoder_layers if self.auxiliary else 1
+        assert P_all == layers * K
+        gt, lab, off, counts = self._pack_gt(gt_bboxes_3d, gt_labels_3d, dev)
+        gmax = max(counts + [1])
+        want_grad = torch.is_grad_enabled() and (rows.requires_grad or p['dense_heatmap'].requires_grad)
+        cfg = self.train_cfg
+        cost, iou, _ = _ops.tf_match_cost(rows.detach(), code, C, gt, lab, off, gmax, **self._match_cfg())
+        host = torch.empty(cost.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(cost, non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
+        losses = dict()
+        if self.initialize_by_heatmap:                      # independent of the matching: overlaps the host's work
+            fx, fy = [int(g) // cfg['out_size_factor'] for g in cfg['grid_size'][:2]]
+            target = _ops.draw_heatmap_gaussian(gt, lab, off, B, C, fy, fx, cfg['voxel_size'], cfg['out_size_factor'],
+                                                cfg['point_cloud_range'], cfg['gaussian_overlap'], cfg['min_radius'])
+            lh = self.loss_heatmap
+            losses['loss_heatmap'] = _GaussianFocalFunction.apply(p['dense_heatmap'], target, lh.alpha, lh.gamma, lh.loss_weight,
+                                                                 want_grad)
+        copied.synchronize()
+        cost_np = host.numpy()
+        assigned = np.full((B, P_all), -1, np.int32)
+        start = 0
+        for b, n in enumerate(counts):
+            if n:
+                for l in range(layers):
+                    r, c = _tl.HungarianAssigner3D.match(cost_np[b, l * K:(l + 1) * K, :n])
+                    assigned[b, l * K + np.asarray(r)] = start + np.asarray(c)
+            start += n
+        assigned = torch.from_numpy(assigned).to(dev, non_blocking=True)
+        c = self.bbox_coder
+        step = [float(c.out_size_factor * c.voxel_size[0]), float(c.out_size_factor * c.voxel_size[1])]
+        out = _QueryLossFunction.apply(rows, assigned, iou, K, code, C, gt, lab, off, step, list(c.pc_range), self.loss_cls.alpha,
+                                       self.loss_cls.gamma, self.loss_cls.loss_weight, self.loss_bbox.loss_weight,
+                                       cfg['pos_weight'], list(cfg.get('code_weights', None) or [1.0] * code), want_grad)
+        for i in range(layers):
+            last = i == self.num_decoder_layers - 1 or (i == 0 and self.auxiliary is False)
+            prefix = 'layer_-1' if last else 'layer_%d' % i
+            losses[prefix + '_loss_cls'], losses[prefix + '_loss_bbox'] = out[2 * i], out[2 * i + 1]
+        losses['matched_ious'] = out[2 * layers + 1].detach()
+        self.__dict__['_last_num_pos'] = out[2 * layers].detach()
+        return losses
 
     def get_bboxes_device(self, preds_dicts):
         """Device-resident result of get_bboxes with nms_type=None: (boxes [B, K, 7|9], scores [B, K], labels [B, K] i32,

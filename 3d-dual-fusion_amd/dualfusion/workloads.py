@@ -8,8 +8,11 @@
               self-attention), KITTI 0.05 m grid, bs = 8 frames x 1 camera (small-grid / high-sparsity rulebook stress).
 
 Inputs are synthetic and resident in HBM; every step takes the next of `--frames` distinct frames.  Voxelisation of the
-batch is part of the step.  These trees have no loss on the device path, so their steps carry no collective: with N > 1
-ranks they run as independent replicas behind bench.py's barrier (frames sharded by rank seed)."""
+batch is part of the step.  The tf_fusion step ends like the CenterPoint one: detection losses of the head
+(`TransFusionHead.loss_device`: Hungarian target assignment + focal / L1 / Gaussian-focal losses) which bench.py reduces
+over the ranks (`reduce_dict`) -- BASELINE configs[3]'s "RCCL all-reduce of detection losses"; `--stage boxes` ends at
+the decoded boxes instead (round 2's step).  The Voxel-RCNN tree ends at its fused backbone (no head in the reference's
+3D-DF addition): replicas behind bench.py's barrier."""
 import numpy as np
 import torch
 
@@ -56,7 +59,18 @@ class TransFusionWorkload(object):
             common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)),
             bbox_coder=dict(type='TransFusionBBoxCoder', pc_range=[-54.0, -54.0], voxel_size=[0.075, 0.075],
                             out_size_factor=8, post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
-                            score_threshold=0.0, code_size=10), loss_cls=dict(use_sigmoid=True),
+                            score_threshold=0.0, code_size=10),
+            # TF/configs/transfusion_nusc_voxel_L.py:212-234
+            loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2, alpha=0.25, reduction='mean', loss_weight=1.0),
+            loss_bbox=dict(type='L1Loss', reduction='mean', loss_weight=0.25),
+            loss_heatmap=dict(type='GaussianFocalLoss', reduction='mean', loss_weight=1.0),
+            train_cfg=dict(dataset='nuScenes',
+                           assigner=dict(type='HungarianAssigner3D', iou_calculator=dict(type='BboxOverlaps3D', coordinate='lidar'),
+                                         cls_cost=dict(type='FocalLossCost', gamma=2, alpha=0.25, weight=0.15),
+                                         reg_cost=dict(type='BBoxBEVL1Cost', weight=0.25), iou_cost=dict(type='IoU3DCost', weight=0.25)),
+                           pos_weight=-1, gaussian_overlap=0.1, min_radius=2, grid_size=[1440, 1440, 40],
+                           voxel_size=synth.NUSC_VOXEL, out_size_factor=8,
+                           code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2], point_cloud_range=synth.NUSC_RANGE),
             test_cfg=dict(dataset='nuScenes', grid_size=[1440, 1440, 40], out_size_factor=8, pc_range=[-54.0, -54.0],
                           voxel_size=[0.075, 0.075], nms_type=None)).to(dev).eval()
         ori_hw, in_hw, fh, fw = (900, 1600), (448, 800), 112, 200          # stride-4 level (the layer indexes pix // 4)
@@ -68,14 +82,17 @@ class TransFusionWorkload(object):
             metas = [dict(lidar2cam=np.stack([cams[n][0] for n in synth.NUSC_CAMS]),
                           cam_intrinsic=np.stack([cams[n][1] for n in synth.NUSC_CAMS]), ori_shape=ori_hw + (3,),
                           img_shape=in_hw + (3,), input_shape=in_hw, scale_factor=sf, flip=False) for _ in range(B)]
+            gts = [synth.nusc_gt_boxes(seed * 16 + b) for b in range(B)]    # host tensors, as the data loader hands them over
             self.frames.append(dict(
                 points=[torch.from_numpy(synth.nusc_sweep(seed=seed * 16 + b)).to(dev) for b in range(B)],
-                img=torch.from_numpy(synth.camera_features(B * 6, 256, (fh, fw), 1234 + seed)).to(dev), metas=metas))
+                img=torch.from_numpy(synth.camera_features(B * 6, 256, (fh, fw), 1234 + seed)).to(dev), metas=metas,
+                gt_boxes=[torch.from_numpy(g[0]) for g in gts], gt_labels=[torch.from_numpy(g[1]) for g in gts]))
 
     def describe(self):
         return ("TransFusion-L + 3D-DF (voxelize+VFE, SparseEncoderFusion + ACTR fusion layer on %d x 6 synthetic "
-                "ResNet50-stride-4-shaped cam feats [256,112,200], SECOND + SECONDFPN, TransFusionHead 200 proposals -> "
-                "boxes), 0.075 m voxel, bs=%d [BASELINE configs[2]]" % (self.batch, self.batch))
+                "ResNet50-stride-4-shaped cam feats [256,112,200], SECOND + SECONDFPN, TransFusionHead 200 proposals, Hungarian "
+                "target assignment + detection losses), 0.075 m voxel, bs=%d [BASELINE configs[2]; configs[3] per GPU]"
+                % (self.batch, self.batch))
 
     @torch.no_grad()
     def step(self, i, stage):
@@ -85,13 +102,20 @@ class TransFusionWorkload(object):
         x = self.enc(f, c, self.batch, img_feats=[fr["img"]], img_metas=metas)
         if stage == "hot_path":
             return x
-        return self.head.get_bboxes_device(self.head(self.fpn(self.second(x))))
+        preds = self.head(self.fpn(self.second(x)))
+        if stage == "boxes":
+            return self.head.get_bboxes_device(preds)
+        losses = self.head.loss_device(fr["gt_boxes"], fr["gt_labels"], preds)
+        return {k: v.reshape(1) for k, v in losses.items()}
 
     def check(self, out, stage):
         if stage == "hot_path":
             assert out.shape[0] == self.batch and out.shape[-2:] == (180, 180), out.shape
-        else:
+        elif stage == "boxes":
             assert out[0].shape[0] == self.batch and bool(torch.isfinite(out[1]).all())
+        else:
+            assert set(out) == {"loss_heatmap", "layer_-1_loss_cls", "layer_-1_loss_bbox", "matched_ious"}, sorted(out)
+            assert all(bool(torch.isfinite(v).all()) for v in out.values()), out
 
 
 class VoxelRCNNWorkload(object):

@@ -52,10 +52,11 @@ def parse():
                     help="cp_fusion = BASELINE configs[1] (default, the headline); cp_lidar = configs[0] shape; tf_fusion = "
                          "configs[2] (TransFusion-L + 3D-DF, bs=4, bf16 convs); vr_fusion = configs[4] (Voxel-RCNN + 3D-DF, "
                          "KITTI, bs=8); protocol = launcher / barrier / reduce protocol only, no GPU work (CPU tests)")
-    ap.add_argument("--stage", default="detect", choices=["detect", "hot_path", "train"],
+    ap.add_argument("--stage", default="detect", choices=["detect", "hot_path", "train", "boxes"],
                     help="detect (default): ... -> neck -> head -> losses -> reduce_dict; hot_path: stop at the dense BEV; "
                          "train (cp_lidar, cp_fusion): forward + backward + bucketed gradient all-reduce overlapped with backward "
-                         "+ AdamW step + reduce_dict of the losses -- a real data-parallel training step")
+                         "+ AdamW step + reduce_dict of the losses -- a real data-parallel training step; boxes (tf_fusion): "
+                         "... -> head -> decoded boxes instead of the losses")
     ap.add_argument("--batch", type=int, default=0, help="sweeps per GPU per step (0 = the workload's BASELINE batch)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames the steps rotate through")
     ap.add_argument("--inflight", type=int, default=1,
@@ -168,7 +169,7 @@ class CenterPointWorkload(object):
         from dualfusion import dist as D
         self.model.train()
         params = [p for p in self.model.parameters() if p.requires_grad]
-        self.reducer = D.GradBucketReducer(params, bucket_mb=64.0)
+        self.reducer = D.GradBucketReducer(params)      # 16 MB buckets: three for this detector
         self.optimizer = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
         self.n_params = sum(p.numel() for p in params)
 
@@ -480,7 +481,15 @@ def main():
     if use_gpu:
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local) if use_gpu else torch.device("cpu")
-    rank, local, world = D.init_from_env(args.backend or ("nccl" if use_gpu else "gloo"))   # nccl == RCCL on ROCm
+    # nccl == RCCL on ROCm.  At N = 1 a one-rank group is created as well, so the step's collectives (reduce of the loss
+    # scalars, gradient buckets) go through RCCL exactly as at N > 1 -- `collective_backend` on the JSON line says so.
+    try:
+        rank, local, world = D.init_from_env(args.backend or ("nccl" if use_gpu else "gloo"), single=use_gpu and not protocol)
+    except Exception as e:                                       # noqa: BLE001
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise
+        print("bench.py: one-rank process group not available (%s); running without" % (e,), file=sys.stderr)
+        rank, local, world = 0, 0, 1
     assert world == max(1, args.gpus), "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     precision = args.conv_precision or ("bf16" if args.workload == "tf_fusion" else "split")
     if not protocol:
@@ -592,11 +601,11 @@ def main():
         }
         if stage == "train":
             res["config"]["training"] = {"trainable_parameters": getattr(wl, "n_params", None), "optimizer": "AdamW (fused)",
-                                         "gradient_reduction": "GradBucketReducer: %d bucket(s) of <= 64 MB, all-reduce launched "
-                                                               "from post-accumulate-grad hooks during backward" % len(wl.reducer.buckets)}
+                                         "gradient_reduction": "GradBucketReducer: %d bucket(s) of <= 16 MB, all-reduces launched in "
+                                                               "bucket order from post-accumulate-grad hooks during backward" % len(wl.reducer.buckets)}
         if stage in ("detect", "train") and isinstance(out, dict) and "encoded_spconv_tensor" not in out:
             res["reduced_losses"] = {k: [round(float(x), 5) for x in v.reshape(-1).float().cpu()] for k, v in out.items()
-                                     if k in ("loss", "hm_loss", "loc_loss")}
+                                     if "loss" in k or k == "matched_ious"}
         if "in_flight" in extra:
             res["in_flight"] = {"frames_in_flight": args.inflight, "ms_per_step": per_step(extra["in_flight"]),
                                 "value": round(units / extra["in_flight"], 3), "unit": res["unit"],

@@ -761,6 +761,75 @@ int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *featur
                       int in_channels, int batch, const int *shape_host, void *arena, size_t arena_bytes,
                       df3d_layer_view *views, size_t *arena_used, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * TransFusion head: target-assignment costs and losses (round 3).
+ *
+ * df3d_boxes_overlap_bev_xyxyr replaces `iou3d_cuda.boxes_overlap_bev_gpu` of the TransFusion tree
+ * (TF/mmdet3d/ops/iou3d/src/iou3d.cpp:66-90 over iou3d_kernel.cu:122-258): boxes [n][5] f32 (x1, y1, x2, y2, angle),
+ * out[na][nb] = overlap area.  Called by LiDARInstance3DBoxes.overlaps (core/bbox/structures/base_box3d.py:414-423).
+ *
+ * df3d_tf_match_cost: what HungarianAssigner3D.assign computes before the host-side linear_sum_assignment
+ * (TF/mmdet3d/core/bbox/assigners/hungarian_assigner.py:121-131) for every sample of a batch in ONE launch, from the
+ * head's raw predictions: `rows` [batch][proposals][ld] f32 with columns center 0:2 (feature-map units), height 2
+ * (gravity centre), dim 3:6 (log), rot 6:8 (sin, cos), class logits at [col_cls, col_cls + num_classes) -- the column
+ * order of the reference's `preds` (transfusion_head.py:1264-1268).  Proposals are decoded as
+ * TransFusionBBoxCoder.decode does (transfusion_bbox_coder.py:62-71); ground truth gt[total][gt_dim] f32
+ * (x, y, z_bottom, w, l, h, yaw, ...), gt_labels[total] i32, sample b owns rows [gt_off[b], gt_off[b+1]) (device i32).
+ *   cost[batch][proposals][gmax] = FocalLossCost + BBoxBEVL1Cost + IoU3DCost (columns >= the sample's count: 0),
+ *   iou [batch][proposals][gmax] = 3-D IoU (BboxOverlaps3D 'lidar'), boxes[batch][proposals][7] decoded (may be NULL). */
+typedef struct df3d_tf_match_cfg {
+  float out_size_factor, voxel_size[2], pc_range[2];   /* bbox coder */
+  float point_cloud_range[6];                          /* train_cfg */
+  float cls_weight, cls_alpha, cls_gamma, cls_eps;     /* FocalLossCost */
+  float reg_weight, iou_weight;
+} df3d_tf_match_cfg;
+int df3d_boxes_overlap_bev_xyxyr(const float *boxes_a, int na, const float *boxes_b, int nb, float *out, void *stream);
+int df3d_tf_match_cost(const float *rows, int batch, int proposals, int ld, int col_cls, int num_classes, const float *gt,
+                       const int32_t *gt_labels, const int32_t *gt_off, int gt_dim, int gmax, const df3d_tf_match_cfg *cfg,
+                       float *cost, float *iou, float *boxes, void *stream);
+
+/* df3d_draw_heatmap_gaussian replaces the per-box Python loop of get_targets_single (transfusion_head.py:1186-1207 over
+ * gaussian_radius / draw_heatmap_gaussian, TF/mmdet3d/core/utils/gaussian.py:25-86): heatmap[batch][num_classes][height]
+ * [width] f32 is zeroed and every ground-truth box of every sample is splatted with max() in one launch.
+ * gaussian_overlap is a double because Python evaluates (1 - o), 4 * o ... in double before torch rounds them. */
+typedef struct df3d_tf_splat_cfg {
+  float voxel_size[2], out_size_factor, point_cloud_range[2];
+  double gaussian_overlap;
+  int min_radius;
+} df3d_tf_splat_cfg;
+int df3d_draw_heatmap_gaussian(const float *gt, const int32_t *gt_labels, const int32_t *gt_off, int gt_dim, int total,
+                               int batch, int num_classes, int height, int width, const df3d_tf_splat_cfg *cfg,
+                               float *heatmap, void *stream);
+
+/* df3d_gaussian_focal_loss = loss_heatmap of TransFusionHead.loss (transfusion_head.py:1241-1244): mmdet's
+ * GaussianFocalLoss(alpha, gamma) of clip_sigmoid(logits) against the dense target, normalised by max(#target == 1, 1)
+ * counted on the device (the reference: `.item()`).  logits element (b, c, pix) at b*stride_b + c*stride_c + pix*stride_pix
+ * (NCHW or the row kernels' channels-last maps); target and grad contiguous [batch][num_classes][hw].
+ *   out[0] = loss, out[1] = #ones, out[2] = loss_weight / max(#ones, 1);  grad (may be NULL) = d(sum)/d logits UNSCALED:
+ *   multiply by out[2].  workspace: df3d_gaussian_focal_loss_workspace_bytes(batch * num_classes * hw). */
+size_t df3d_gaussian_focal_loss_workspace_bytes(long long n);
+int df3d_gaussian_focal_loss(const float *logits, long long stride_b, long long stride_c, long long stride_pix,
+                             const float *target, int batch, int num_classes, int hw, float alpha, float gamma,
+                             float loss_weight, float *grad, float *out, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
+/* df3d_tf_query_loss = the per-layer classification / box losses of TransFusionHead.loss (transfusion_head.py:1246-1281)
+ * with the targets of get_targets_single (:1154-1181) built on the fly from the matching: assigned[batch][proposals_all]
+ * i32 = global ground-truth row matched to the proposal or -1; proposals_all = layers * proposals (auxiliary heads).
+ *   out[2*l], out[2*l+1] = loss_cls, loss_bbox of layer l (FocalLoss / L1Loss, avg_factor max(num_pos, 1));
+ *   out[2*layers] = num_pos, out[2*layers+1] = matched_ious;  grad (may be NULL) [batch][proposals_all][ld] = gradient of the
+ *   SUM of all layer losses w.r.t. `rows` (class-logit and box-code columns; other columns untouched). */
+typedef struct df3d_tf_loss_cfg {
+  float encode_step[2];     /* out_size_factor * voxel_size, evaluated in double and rounded once (coder.encode) */
+  float pc_range[2];
+  float cls_alpha, cls_gamma, cls_loss_weight, bbox_loss_weight, pos_weight;
+  float code_weights[DF3D_LOSS_MAX_CODES];
+} df3d_tf_loss_cfg;
+int df3d_tf_query_loss(const float *rows, const int32_t *assigned, const float *iou, int batch, int proposals_all,
+                       int proposals, int ld, int col_cls, int num_classes, int code_size, const float *gt,
+                       const int32_t *gt_labels, const int32_t *gt_off, int gt_dim, int gmax, const df3d_tf_loss_cfg *cfg,
+                       float *grad, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

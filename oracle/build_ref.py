@@ -25,6 +25,11 @@ Built here:
                                      `boxes_overlap_bev_gpu / boxes_iou_bev_gpu / nms_gpu / nms_normal_gpu`, which
                                      the -m gpu tests run beside ours on the MI355X)
 
+  oracle/_ref/iou3d_cuda.so      <- TF/mmdet3d/ops/iou3d/src/{iou3d.cpp, iou3d_kernel.cu}: the TransFusion tree's
+                                     `boxes_overlap_bev_gpu / boxes_iou_bev_gpu / nms_gpu / nms_normal_gpu` (GPU only; the
+                                     overlap kernel the Hungarian matcher's 3-D IoU runs on).  tests/test_gpu_tfloss.py runs it
+                                     beside ours and beside the oracle's restatement on the MI355X.
+
 Nothing outside tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
 may load these libraries.
 """
@@ -49,7 +54,7 @@ def build(verbose=False):
         return False
     os.makedirs(OUT, exist_ok=True)
     want = [os.path.join(OUT, "sparse_conv_ext.so"), os.path.join(OUT, "voxel_layer.so"),
-            os.path.join(OUT, "iou3d_nms_cuda.so")]
+            os.path.join(OUT, "iou3d_nms_cuda.so"), os.path.join(OUT, "iou3d_cuda.so")]
     if all(os.path.exists(w) for w in want) and not os.environ.get("DF3D_REBUILD_REF"):
         return True
     os.environ.setdefault("PYTORCH_ROCM_ARCH", "gfx950")
@@ -100,6 +105,17 @@ def build(verbose=False):
              extra_include_paths=[io], extra_cflags=["-w"], extra_cuda_cflags=["-w"], build_directory=bdir,
              with_cuda=True, verbose=verbose)
         shutil.copy(os.path.join(bdir, "iou3d_nms_cuda.so"), want[2])
+
+        # ---- TransFusion tree's iou3d (hipified GPU kernels only) --------
+        it = os.path.join(stage, "iou3d_tf")
+        shutil.copytree(os.path.join(REF, "iou3d", "src"), it)
+        os.system("chmod -R u+w %s" % it)
+        bdir = os.path.join(it, "out")
+        os.makedirs(bdir)
+        load(name="iou3d_cuda", sources=[os.path.join(it, f) for f in ("iou3d.cpp", "iou3d_kernel.cu")],
+             extra_include_paths=[it], extra_cflags=["-w"], extra_cuda_cflags=["-w"], build_directory=bdir,
+             with_cuda=True, verbose=verbose)
+        shutil.copy(os.path.join(bdir, "iou3d_cuda.so"), want[3])
     finally:
         shutil.rmtree(stage, ignore_errors=True)
     return True

@@ -523,3 +523,76 @@ int orc_nms_bev(const float *boxes, int n, float thresh, int rotated, int64_t *k
   if (n_close) *n_close = close;
   return nk;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * TransFusion tree's BEV overlap (TF/mmdet3d/ops/iou3d/src/iou3d_kernel.cu:56-240): boxes are
+ * [x1, y1, x2, y2, angle]; corners are turned by -angle about the box centre (rotate_around_center :106-114 with
+ * cos(angle), sin(angle)), the containment test turns the point back (check_in_box2d :56-79, margin 1e-5).
+ * The reference has no CPU build of this kernel: this restatement is pinned on the GPU box against the reference's
+ * own kernel (oracle/_ref/iou3d_cuda_tf.so, tests/test_gpu_tfloss.py). */
+static int orc_tf_in_box2d(const float *box, orc_pt p) {
+  const float margin = 1e-5f;
+  float cx = (box[0] + box[2]) / 2, cy = (box[1] + box[3]) / 2;
+  float ca = cosf(-box[4]), sa = sinf(-box[4]);
+  float rx = (p.x - cx) * ca + (p.y - cy) * sa + cx;
+  float ry = -(p.x - cx) * sa + (p.y - cy) * ca + cy;
+  return rx > box[0] - margin && rx < box[2] + margin && ry > box[1] - margin && ry < box[3] + margin;
+}
+
+static void orc_tf_corners(const float *box, orc_pt *c) {
+  float cx = (box[0] + box[2]) / 2, cy = (box[1] + box[3]) / 2, ca = cosf(box[4]), sa = sinf(box[4]);
+  float px[4] = {box[0], box[2], box[2], box[0]}, py[4] = {box[1], box[1], box[3], box[3]};
+  for (int k = 0; k < 4; ++k) {
+    c[k].x = (px[k] - cx) * ca + (py[k] - cy) * sa + cx;
+    c[k].y = -(px[k] - cx) * sa + (py[k] - cy) * ca + cy;
+  }
+  c[4] = c[0];
+}
+
+float orc_tf_box_overlap(const float *a, const float *b) { /* iou3d_kernel.cu:122-230 */
+  orc_pt ca[5], cb[5], pts[16], ctr = {0.f, 0.f};
+  int cnt = 0;
+  orc_tf_corners(a, ca);
+  orc_tf_corners(b, cb);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (orc_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], &pts[cnt])) {
+        ctr.x += pts[cnt].x;
+        ctr.y += pts[cnt].y;
+        cnt++;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (orc_tf_in_box2d(a, cb[k])) {
+      ctr.x += cb[k].x;
+      ctr.y += cb[k].y;
+      pts[cnt++] = cb[k];
+    }
+    if (orc_tf_in_box2d(b, ca[k])) {
+      ctr.x += ca[k].x;
+      ctr.y += ca[k].y;
+      pts[cnt++] = ca[k];
+    }
+  }
+  ctr.x /= cnt;
+  ctr.y /= cnt;
+  for (int j = 0; j < cnt - 1; ++j)
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (atan2f(pts[i].y - ctr.y, pts[i].x - ctr.x) > atan2f(pts[i + 1].y - ctr.y, pts[i + 1].x - ctr.x)) {
+        orc_pt t = pts[i];
+        pts[i] = pts[i + 1];
+        pts[i + 1] = t;
+      }
+  float area = 0;
+  for (int k = 0; k < cnt - 1; ++k) {
+    float ax = pts[k].x - pts[0].x, ay = pts[k].y - pts[0].y;
+    float bx = pts[k + 1].x - pts[0].x, by = pts[k + 1].y - pts[0].y;
+    area += ax * by - ay * bx;
+  }
+  return fabsf(area) / 2.0f;
+}
+
+/* boxes_overlap_bev_gpu (iou3d.cpp:66-90): out[i, j] = overlap area of a[i] and b[j], boxes [n, 5] xyxyr */
+void orc_tf_boxes_overlap_bev(const float *a, int na, const float *b, int nb, float *out) {
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j) out[(size_t)i * nb + j] = orc_tf_box_overlap(a + i * 5, b + j * 5);
+}

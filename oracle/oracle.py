@@ -354,6 +354,38 @@ def boxes_pairwise_bev(boxes_a, boxes_b, mode="iou"):
     return out
 
 
+def tf_boxes_overlap_bev(boxes_a, boxes_b):
+    """TF/mmdet3d/ops/iou3d/src/iou3d_kernel.cu:122-240 + iou3d.cpp:66-90 (boxes_overlap_bev_gpu): [N,5] x [M,5]
+    boxes (x1, y1, x2, y2, angle) -> overlap areas [N,M]."""
+    a = np.ascontiguousarray(boxes_a, np.float32)
+    b = np.ascontiguousarray(boxes_b, np.float32)
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    if a.shape[0] and b.shape[0]:
+        lib().orc_tf_boxes_overlap_bev(_p(a, _f32), a.shape[0], _p(b, _f32), b.shape[0], _p(out, _f32))
+    return out
+
+
+def tf_bbox_overlaps_3d(boxes1, boxes2):
+    """BboxOverlaps3D(coordinate='lidar') of the TransFusion tree: TF/mmdet3d/core/bbox/iou_calculators/
+    iou3d_calculator.py:138-166 -> LiDARInstance3DBoxes.overlaps (core/bbox/structures/base_box3d.py:352-438):
+    boxes (x, y, z_bottom, w, l, h, yaw, ...) -> 3-D IoU [N,M] in fp32."""
+    f32 = np.float32
+    b1, b2 = np.asarray(boxes1, f32)[:, :7], np.asarray(boxes2, f32)[:, :7]
+    if len(b1) * len(b2) == 0:
+        return np.zeros((len(b1), len(b2)), f32)
+
+    def xyxyr(b):                                            # bev (lidar_box3d.py:87-90) -> xywhr2xyxyr (utils.py:64-82)
+        hw, hl = b[:, 3] / f32(2), b[:, 4] / f32(2)
+        return np.stack([b[:, 0] - hw, b[:, 1] - hl, b[:, 0] + hw, b[:, 1] + hl, b[:, 6]], 1).astype(f32)
+    top1, bot1 = (b1[:, 2] + b1[:, 5])[:, None], b1[:, 2][:, None]
+    top2, bot2 = (b2[:, 2] + b2[:, 5])[None], b2[:, 2][None]
+    oh = np.maximum(np.minimum(top1, top2) - np.maximum(bot1, bot2), f32(0))
+    o3 = (tf_boxes_overlap_bev(xyxyr(b1), xyxyr(b2)) * oh).astype(f32)
+    v1 = (b1[:, 3] * b1[:, 4] * b1[:, 5])[:, None]
+    v2 = (b2[:, 3] * b2[:, 4] * b2[:, 5])[None]
+    return (o3 / np.maximum(v1 + v2 - o3, f32(1e-8))).astype(f32)
+
+
 def nms_bev(boxes_sorted, thresh, rotated=True, margin=0.0):
     """iou3d_nms.cpp:88-139 (nms_gpu) / :142-188 (nms_normal_gpu) on boxes already sorted by descending score.
     Returns (keep indices int64, number of evaluated IoUs within `margin` of the threshold)."""

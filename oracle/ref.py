@@ -20,7 +20,7 @@ def available(name="sparse_conv_ext"):
 
 
 def load(name):
-    """name in {'sparse_conv_ext', 'voxel_layer', 'iou3d_nms_cuda'} -> the reference's pybind module."""
+    """name in {'sparse_conv_ext', 'voxel_layer', 'iou3d_nms_cuda', 'iou3d_cuda'} -> the reference's pybind module."""
     if name in _mods:
         return _mods[name]
     import torch  # noqa: F401  (libtorch must be loaded first)

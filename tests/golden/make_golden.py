@@ -820,6 +820,207 @@ def gen_transfusion_head():
     save("transfusion_head.npz", **out)
 
 
+# ------------------------------------------------------------------ TransFusionHead.loss (round 3)
+TFL_SHAPE = (2, 512, 20, 20)                       # square map: the reference's target heat map is [C, y_len, x_len]
+TFL_RANGE = [-6.0, -6.0, -5.0, 6.0, 6.0, 3.0]      # while forward_single lays the BEV grid out as [x_len, y_len]
+TFL_CODER = dict(pc_range=TFL_RANGE[:2], voxel_size=[0.075, 0.075], out_size_factor=8,
+                 post_center_range=[-5.2, -5.9, -10.0, 5.0, 5.6, 10.0], score_threshold=0.0, code_size=10)
+TFL_TEST_CFG = dict(dataset='nuScenes', grid_size=[160, 160, 40], out_size_factor=8, pc_range=TFL_RANGE[:2],
+                    voxel_size=[0.075, 0.075], nms_type=None)
+# transfusion_nusc_voxel_L.py:217-234
+TFL_TRAIN_CFG = dict(dataset='nuScenes',
+                     assigner=dict(type='HungarianAssigner3D', iou_calculator=dict(type='BboxOverlaps3D', coordinate='lidar'),
+                                   cls_cost=dict(type='FocalLossCost', gamma=2, alpha=0.25, weight=0.15),
+                                   reg_cost=dict(type='BBoxBEVL1Cost', weight=0.25), iou_cost=dict(type='IoU3DCost', weight=0.25)),
+                     pos_weight=-1, gaussian_overlap=0.1, min_radius=2, grid_size=[160, 160, 40], voxel_size=[0.075, 0.075, 0.2],
+                     out_size_factor=8, code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2],
+                     point_cloud_range=TFL_RANGE)
+TFL_LOSSES = dict(loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2, alpha=0.25, reduction='mean', loss_weight=1.0),
+                  loss_bbox=dict(type='L1Loss', reduction='mean', loss_weight=0.25),
+                  loss_heatmap=dict(type='GaussianFocalLoss', reduction='mean', loss_weight=1.0))
+
+
+class CfgDict(dict):
+    """mmcv.ConfigDict as the head uses it: attribute access, nested."""
+
+    def __init__(self, d):
+        super().__init__({k: CfgDict(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+    __getattr__ = dict.__getitem__
+
+
+def import_reference_transfusion_loss():
+    """The reference's own transfusion_head.py, hungarian_assigner.py, iou3d_calculator.py, core/bbox/structures/*,
+    core/utils/gaussian.py, models/utils/clip_sigmoid.py and transfusion_bbox_coder.py, imported from /root/reference
+    under synthetic parent packages.  What the reference takes from the absent mmdet 2.10.0 / mmcv is restated in
+    tests/golden/mmdet_restated.py (losses, FocalLossCost, AssignResult, PseudoSampler) and above (ConvModule);
+    the CUDA-only iou3d_cuda.boxes_overlap_bev_gpu is bound to the oracle's restatement of that kernel
+    (oracle/df3d_oracle.c orc_tf_box_overlap; pinned against the reference's kernel on the GPU box)."""
+    import importlib.util
+    import mmdet_restated as mr
+    from oracle import oracle as orc
+    hm0 = import_reference_transfusion_head()             # ConvModule / registry stubs of the forward golden
+    R = "/root/reference/TransFusion/mmdet3d"
+    heads = sys.modules["mmdet3d.models.builder"].HEADS
+
+    def overlap_bev(a, b, out):
+        out.copy_(torch.from_numpy(orc.tf_boxes_overlap_bev(a.detach().numpy(), b.detach().numpy())))
+    for name, path in [("mmdet3d", R), ("mmdet3d.core", R + "/core"), ("mmdet3d.core.bbox", R + "/core/bbox"),
+                       ("mmdet3d.core.utils", R + "/core/utils"), ("mmdet3d.core.bbox.assigners", R + "/core/bbox/assigners"),
+                       ("mmdet3d.core.bbox.iou_calculators", R + "/core/bbox/iou_calculators"), ("mmdet3d.ops", R + "/ops"),
+                       ("mmdet3d.models.utils", R + "/models/utils")]:
+        _stub(name).__path__ = [path]
+    _stub("mmdet3d.ops.iou3d", iou3d_cuda=types.SimpleNamespace(boxes_overlap_bev_gpu=overlap_bev))
+    _stub("mmdet3d.ops.roiaware_pool3d", points_in_boxes_gpu=None, points_in_boxes_batch=None)
+    sys.modules["mmdet3d.ops"].points_in_boxes_batch = None
+    sys.modules.pop("mmdet3d.core.bbox.structures", None)   # the forward golden's placeholder
+    importlib.import_module("mmdet3d.core.points")
+    st = importlib.import_module("mmdet3d.core.bbox.structures")
+    gs = importlib.import_module("mmdet3d.core.utils.gaussian")
+    cs = importlib.import_module("mmdet3d.models.utils.clip_sigmoid")
+
+    class Reg:
+        def __init__(self):
+            self.d = {}
+
+        def register_module(self, *a, **k):
+            def deco(c):
+                self.d[c.__name__] = c
+                return c
+            return deco
+
+        def build(self, cfg):
+            cfg = dict(cfg)
+            return self.d[cfg.pop('type')](**cfg)
+    assigners, costs, ious, coders = Reg(), Reg(), Reg(), sys.modules["mmdet.core.bbox.builder"].BBOX_CODERS
+    costs.d["FocalLossCost"] = mr.FocalLossCost
+    _stub("mmdet.core.bbox", BaseBBoxCoder=object, bbox_overlaps=None)
+    _stub("mmdet.core.bbox.builder", BBOX_ASSIGNERS=assigners, BBOX_CODERS=coders)
+    _stub("mmdet.core.bbox.assigners", AssignResult=mr.AssignResult, BaseAssigner=object)
+    _stub("mmdet.core.bbox.match_costs", build_match_cost=costs.build)
+    _stub("mmdet.core.bbox.match_costs.builder", MATCH_COST=costs)
+    _stub("mmdet.core.bbox.iou_calculators", build_iou_calculator=ious.build)
+    _stub("mmdet.core.bbox.iou_calculators.builder", IOU_CALCULATORS=ious)
+    importlib.import_module("mmdet3d.core.bbox.iou_calculators.iou3d_calculator")
+    importlib.import_module("mmdet3d.core.bbox.assigners.hungarian_assigner")
+
+    def multi_apply(func, *args):
+        return tuple(map(list, zip(*map(func, *args))))
+
+    def build_bbox_coder(cfg):
+        cfg = dict(cfg)
+        return coders.d[cfg.pop('type')](**cfg)
+    _stub("mmdet.core", build_bbox_coder=build_bbox_coder, multi_apply=multi_apply, build_assigner=assigners.build,
+          build_sampler=None, AssignResult=mr.AssignResult)
+    core = sys.modules["mmdet3d.core"]
+    core.__dict__.update(circle_nms=None, draw_heatmap_gaussian=gs.draw_heatmap_gaussian, gaussian_radius=gs.gaussian_radius,
+                         xywhr2xyxyr=st.xywhr2xyxyr, limit_period=st.limit_period, PseudoSampler=mr.PseudoSampler,
+                         Box3DMode=st.Box3DMode, LiDARInstance3DBoxes=st.LiDARInstance3DBoxes)
+    mb = _stub("mmdet3d.models.builder", HEADS=heads, build_loss=mr.build_loss)
+    _stub("mmdet3d.models", builder=mb)
+    sys.modules["mmdet3d.models.utils"].clip_sigmoid = cs.clip_sigmoid
+    _stub("mmdet3d.models.fusion_layers", apply_3d_transformation=None)
+    _stub("mmdet3d.ops.iou3d.iou3d_utils", nms_gpu=None)
+    spec = importlib.util.spec_from_file_location("tf_head_loss", R + "/models/dense_heads/transfusion_head.py")
+    hm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hm)
+    return hm, st
+
+
+def tfl_gt_boxes(pred_boxes, b):
+    """Ground truth of sample b: a few jittered copies of decoded proposals (non-zero 3-D IoU for the matcher) plus
+    free boxes; (x, y, z_bottom, w, l, h, yaw, vx, vy) and a class per box."""
+    rs = np.random.RandomState(700 + b)
+    n_near, n_free = 4 + b, 3
+    pick = rs.choice(len(pred_boxes), n_near, replace=False)
+    near = pred_boxes[pick].copy()
+    near[:, :2] += rs.normal(scale=0.25, size=(n_near, 2))
+    near[:, 2] += rs.normal(scale=0.1, size=n_near)
+    near[:, 3:6] *= np.exp(rs.normal(scale=0.15, size=(n_near, 3)))
+    near[:, 6] += rs.normal(scale=0.2, size=n_near)
+    free = np.zeros((n_free, 9))
+    free[:, :2] = rs.uniform(-5, 5, size=(n_free, 2))
+    free[:, 2] = rs.uniform(-2, 0, size=n_free)
+    free[:, 3:6] = rs.uniform(0.5, 4.0, size=(n_free, 3))
+    free[:, 6] = rs.uniform(-3.1, 3.1, size=n_free)
+    free[:, 7:] = rs.normal(size=(n_free, 2))
+    boxes = np.concatenate([near, free]).astype(np.float32)
+    boxes[:, :2] = np.clip(boxes[:, :2], -5.6, 5.6)
+    return boxes, rs.randint(0, 10, size=len(boxes)).astype(np.int64)
+
+
+def gen_transfusion_head_loss():
+    """Reference TransFusionHead.forward + get_targets + loss (transfusion_head.py:1048-1283) with the reference's
+    HungarianAssigner3D (hungarian_assigner.py:100-160), BboxOverlaps3D, TransFusionBBoxCoder.encode, gaussian
+    heat-map targets, and the gradient the summed losses send back; eval mode (no dropout, running BN statistics)."""
+    hm, st = import_reference_transfusion_loss()
+    kw = dict(TFH_KW)
+    head = hm.TransFusionHead(train_cfg=CfgDict(TFL_TRAIN_CFG), test_cfg=dict(TFL_TEST_CFG), loss_iou=dict(type='VarifocalLoss'),
+                              bbox_coder=dict(type='TransFusionBBoxCoder', **TFL_CODER), **TFL_LOSSES, **kw)
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    sd = tfh_weight_shift(detgen.det_state_dict(shapes))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    head.eval()
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for k in range(50):
+            x = torch.from_numpy(detgen.randn("tfl_x_%d" % k, TFL_SHAPE)).requires_grad_(True)
+            res = head([x], None, [{}])
+            p = res[0][0]
+            with torch.no_grad():
+                dec = head.bbox_coder.decode(p['heatmap'].clone(), p['rot'].clone(), p['dim'].clone(), p['center'].clone(),
+                                             p['height'].clone(), p['vel'].clone())
+            gts = [tfl_gt_boxes(dec[b]['bboxes'].numpy(), b) for b in range(TFL_SHAPE[0])]
+            gt_boxes = [st.LiDARInstance3DBoxes(torch.from_numpy(g[0]), box_dim=9) for g in gts]
+            gt_labels = [torch.from_numpy(g[1]) for g in gts]
+            # the matching must survive a small perturbation of the cost matrix (different summation orders / ulps)
+            from scipy.optimize import linear_sum_assignment
+            stable, costs = True, []
+            for b in range(TFL_SHAPE[0]):
+                a = head.bbox_assigner
+                boxes = dec[b]['bboxes']
+                cost = (a.cls_cost(p['heatmap'][b].detach().T, gt_labels[b]) + a.reg_cost(boxes, gt_boxes[b].tensor, head.train_cfg)
+                        + a.iou_cost(a.iou_calculator(boxes, gt_boxes[b].tensor))).numpy()
+                costs.append(cost)
+                r0 = linear_sum_assignment(cost)
+                for j in range(8):
+                    noise = detgen.randn("tfl_noise_%d_%d_%d" % (k, b, j), cost.shape)
+                    r1 = linear_sum_assignment(cost + 2e-4 * noise)
+                    stable &= np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1])
+            if stable:
+                break
+        else:
+            raise RuntimeError("no stable matching found")
+        targets = head.get_targets(gt_boxes, gt_labels, res[0])
+        dense_logits = p['dense_heatmap'].detach().clone()       # loss() applies sigmoid_ in place to this prediction
+        losses = head.loss(gt_boxes, gt_labels, res)
+        total = sum(v for n, v in losses.items() if 'loss' in n)
+        total.backward()
+    finally:
+        torch.Tensor.cuda = _cuda
+    out = dict(seed=np.int64(k), keys=np.array(sorted(shapes)), query_labels=head.query_labels.numpy(),
+               dense_logits=dense_logits.numpy(),
+               labels=targets[0].numpy(), label_weights=targets[1].numpy(), bbox_targets=targets[2].numpy(),
+               bbox_weights=targets[3].numpy(), ious=targets[4].numpy(), num_pos=np.int64(targets[5]),
+               matched_ious=np.float64(targets[6]), heatmap=targets[7].numpy(),
+               gx=np.array([x.grad.sum(dtype=torch.float64).item(), x.grad.abs().sum(dtype=torch.float64).item()]),
+               gw=np.array([head.shared_conv.weight.grad.abs().sum(dtype=torch.float64).item(),
+                            head.heatmap_head[1].bias.grad.abs().sum(dtype=torch.float64).item(),
+                            head.prediction_heads[0].center[1].weight.grad.abs().sum(dtype=torch.float64).item(),
+                            head.decoder[0].multihead_attn.in_proj_weight.grad.abs().sum(dtype=torch.float64).item()]),
+               gx_slice=x.grad[:, :8].numpy())
+    for b, (g, l) in enumerate(gts):
+        out["gt_boxes_%d" % b], out["gt_labels_%d" % b], out["cost_%d" % b] = g, l, costs[b]
+    for name, v in p.items():
+        if name != 'dense_heatmap':
+            out["pred_" + name] = v.detach().numpy()
+    for name, v in losses.items():
+        out["loss_" + name] = np.float64(v.item())
+    print("seed", k, {n: float(v) for n, v in losses.items()}, "num_pos", targets[5], "matched_ious", targets[6])
+    save("transfusion_head_loss.npz", **out)
+
+
 def head_loss_example():
     """Assigner outputs for CenterHead.loss on the golden map (HEAD_SHAPE): per task a heat-map target with a few unit
     peaks, flat pixel indices, mask, category id and box codes of M = 6 object slots."""
@@ -1407,7 +1608,7 @@ def gen_vr_fusion():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "headloss", "conv_bwd", "pool", "conv_transpose"]
+    which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "tfloss", "headloss", "conv_bwd", "pool", "conv_transpose"]
     if "iou3d" in which:
         gen_iou3d()
     if "conv_bwd" in which:
@@ -1420,6 +1621,8 @@ if __name__ == "__main__":
         gen_centerhead()
     if "tfhead" in which:
         gen_transfusion_head()
+    if "tfloss" in which:
+        gen_transfusion_head_loss()
     if "headloss" in which:
         gen_centerhead_loss()
     if "voxelize" in which:

@@ -162,3 +162,63 @@ def test_gradient_reduction_two_ranks(tmp_path):
         res = json.load(open(os.path.join(str(tmp_path), "g%d.json" % r)))
         assert max(res["errs"]) < 1e-5, res
         assert res["buckets"] >= 2 and res["unused_zero"] and res["views"], res
+
+
+def test_gradient_buckets_rank_dependent_unused_parameters(tmp_path):
+    """the set of parameters without a gradient differs between the ranks (a data-dependent branch: rank 0
+    skips the LAST layer's bucket, rank 1 the FIRST layer's).  Buckets are launched strictly in index order, so both ranks
+    issue the same sequence of collectives and the averaged gradients are right (an as-soon-as-complete launch order
+    pairs buffers of different buckets across ranks: wrong sums or a hang)."""
+    worker = textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, os.path.join(%r, "3d-dual-fusion_amd"))
+        import torch
+        from dualfusion import dist as D
+        rank, local, world = D.init_from_env("gloo")
+        torch.manual_seed(0)
+        a, b, c = torch.nn.Linear(8, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 8)
+        params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())
+        red = D.GradBucketReducer(params, bucket_mb=0.0002)            # one bucket per tensor or so
+        order = []
+        real = torch.distributed.all_reduce
+        def spy(t, *args, **kw):
+            order.append(int(t.numel()))
+            return real(t, *args, **kw)
+        torch.distributed.all_reduce = spy
+        x = torch.arange(16.0).view(2, 8) / 10
+        def run():
+            red.zero_grad()
+            h = a(x)
+            y = b(h) if rank == 0 else c(h)                 # rank 0 never touches c, rank 1 never touches b
+            y.square().sum().backward()
+            red.finish()
+        run(); run()
+        torch.distributed.all_reduce = real
+        # expected: average of (rank-0 gradient, rank-1 gradient), zeros where a rank skipped the layer
+        def local(r):
+            for p in params:
+                p.grad = None
+            h = a(x)
+            (b(h) if r == 0 else c(h)).square().sum().backward()
+            return [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in params]
+        got = [p.grad.clone() for p in params]
+        red.remove()
+        want = [(g0 + g1) / 2 for g0, g1 in zip(local(0), local(1))]
+        err = max(float((g - w).abs().max()) for g, w in zip(got, want))
+        sizes = [int(bk["flat"].numel()) for bk in red.buckets]
+        with open(os.path.join(os.environ["DF3D_TEST_OUT"], "u%%d.json" %% rank), "w") as f:
+            json.dump({"err": err, "order": order, "sizes": sizes}, f)
+        D.barrier()
+        torch.distributed.destroy_process_group()
+    """) % ROOT
+    script = tmp_path / "w.py"
+    script.write_text(worker)
+    sys.path.insert(0, os.path.join(ROOT, "3d-dual-fusion_amd"))
+    from dualfusion import dist as D
+    rc = D.launch_ranks(2, str(script), [], env=dict(os.environ, OMP_NUM_THREADS="1", DF3D_TEST_OUT=str(tmp_path)),
+                        timeout=300)
+    assert rc == 0
+    import json
+    res = [json.load(open(os.path.join(str(tmp_path), "u%d.json" % r))) for r in (0, 1)]
+    assert res[0]["order"] == res[1]["order"] == res[0]["sizes"] * 2 and len(res[0]["sizes"]) >= 3, res
+    assert max(r["err"] for r in res) < 1e-6, res

@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's neck / head interfaces: constructor keys,
 parameter names and shapes of the checkpoints, registry resolution, torch composition on the CPU -- and that the
 device-only entry points refuse CPU tensors instead of falling back.  No GPU needed."""
+import numpy as np
 import pytest
 
 torch = pytest.importorskip("torch")
@@ -125,8 +126,8 @@ def test_transfusion_head_matches_reference_checkpoint_layout():
     assert len(dets) == 2 and dets[0][0].shape[1] == 9 and dets[0][2].dtype == torch.int32
     with pytest.raises(NotImplementedError):
         build_from_cfg(_tf_head_cfg(fuse_img=True, num_views=6), HEADS)
-    with pytest.raises(NotImplementedError):
-        head.loss(None, None, res)
+    with pytest.raises(RuntimeError):                                         # no train_cfg: no target assignment
+        head.loss([torch.zeros(1, 9)], [torch.zeros(1, dtype=torch.long)], res)
     coder = TransFusionBBoxCoder(pc_range=[-54.0, -54.0], out_size_factor=8, voxel_size=[0.075, 0.075],
                                  post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], code_size=10)
     boxes = torch.tensor([[1.0, -2.0, 0.5, 4.0, 2.0, 1.5, 0.3, 0.1, -0.2]])
@@ -144,3 +145,89 @@ def test_spconv_pool_inverse_and_dynamic_voxelize_interfaces():
     assert up.inverse and tuple(up.weight.shape) == (3, 3, 3, 32, 16)
     with pytest.raises(Df3dError):                                            # device-only: no CPU fallback
         voxel.voxelization(torch.zeros(4, 4), [0.1, 0.1, 0.1], [0, 0, 0, 1, 1, 1], -1, 100)
+
+
+def _tfl_head():
+    from make_golden import TFH_KW, TFL_CODER, TFL_LOSSES, TFL_TEST_CFG, TFL_TRAIN_CFG, tfh_weight_shift
+    import detgen
+    from dualfusion.transfusion_head import TransFusionHead
+    head = TransFusionHead(train_cfg=dict(TFL_TRAIN_CFG), test_cfg=dict(TFL_TEST_CFG), loss_iou=dict(type='VarifocalLoss'),
+                           bbox_coder=dict(type='TransFusionBBoxCoder', **TFL_CODER), **TFL_LOSSES, **TFH_KW)
+    shapes = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    sd = tfh_weight_shift(detgen.det_state_dict(shapes))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return head.eval(), shapes
+
+
+def test_transfusion_head_loss_vs_reference_golden(golden):
+    """TransFusionHead.get_targets / loss (plain torch path, CPU) against the reference module's own outputs
+    (tests/golden/transfusion_head_loss.npz: transfusion_head.py:1048-1283 + hungarian_assigner.py run by make_golden.py).
+    The 3-D IoU of the matcher comes from the oracle here (the product's BboxOverlaps3D is a device kernel and refuses
+    CPU tensors); everything else is the product code."""
+    import detgen
+    from make_golden import TFL_SHAPE
+    from dualfusion import Df3dError
+    from dualfusion.box3d import LiDARInstance3DBoxes
+    from oracle import oracle as orc
+    g = golden("transfusion_head_loss.npz")
+    head, shapes = _tfl_head()
+    assert sorted(shapes) == list(g["keys"])                                  # the reference's parameter names
+    x = torch.from_numpy(detgen.randn("tfl_x_%d" % int(g["seed"]), TFL_SHAPE)).requires_grad_(True)
+    res = head([x], None, [{}])
+    p = res[0][0]
+    for k in ("center", "height", "dim", "rot", "vel", "heatmap", "query_heatmap_score"):
+        assert np.abs(p[k].detach().numpy() - g["pred_" + k]).max() < 2e-4, k
+    assert np.array_equal(head.query_labels.numpy(), g["query_labels"])
+    gt_boxes = [LiDARInstance3DBoxes(torch.from_numpy(g["gt_boxes_%d" % b]), box_dim=9) for b in range(TFL_SHAPE[0])]
+    gt_labels = [torch.from_numpy(g["gt_labels_%d" % b]) for b in range(TFL_SHAPE[0])]
+    with pytest.raises(Df3dError):                                            # no CPU fallback of the IoU kernel
+        head.get_targets(gt_boxes, gt_labels, res[0])
+    head.bbox_assigner.iou_calculator = lambda a, b: torch.from_numpy(orc.tf_bbox_overlaps_3d(a.detach().numpy(), b.detach().numpy()))
+    for b in range(TFL_SHAPE[0]):                                             # cost matrix of the matcher
+        one = {k: v[b:b + 1].detach() for k, v in p.items()}
+        boxes = head.bbox_coder.decode(one["heatmap"].clone(), one["rot"].clone(), one["dim"].clone(), one["center"].clone(),
+                                       one["height"].clone(), one["vel"].clone())[0]["bboxes"]
+        cost, _ = head.bbox_assigner.cost_matrix(boxes, gt_boxes[b].tensor, gt_labels[b], one["heatmap"], head.train_cfg)
+        assert np.abs(cost.numpy() - g["cost_%d" % b]).max() < 2e-4
+    t = head.get_targets(gt_boxes, gt_labels, res[0])
+    assert np.array_equal(t[0].numpy(), g["labels"]) and np.array_equal(t[1].numpy(), g["label_weights"])
+    assert np.array_equal(t[3].numpy(), g["bbox_weights"]) and t[5] == int(g["num_pos"])
+    assert np.abs(t[2].numpy() - g["bbox_targets"]).max() < 1e-5 and np.abs(t[4].numpy() - g["ious"]).max() < 1e-5
+    assert abs(t[6] - float(g["matched_ious"])) < 1e-5
+    assert np.array_equal(t[7].numpy(), g["heatmap"])                         # Gaussian targets: bit for bit
+    losses = head.loss(gt_boxes, gt_labels, res)
+    for k in ("loss_heatmap", "layer_-1_loss_cls", "layer_-1_loss_bbox", "matched_ious"):
+        ref = float(g["loss_" + k])
+        assert abs(losses[k].item() - ref) < 2e-5 * max(1.0, abs(ref)), (k, losses[k].item(), ref)
+    sum(v for n, v in losses.items() if "loss" in n).backward()
+    gx = np.array([x.grad.sum(dtype=torch.float64).item(), x.grad.abs().sum(dtype=torch.float64).item()])
+    assert np.abs(gx - g["gx"]).max() < 1e-3 * g["gx"][1]
+    # fp32 noise floor of this (saturated heat map) problem: the module in float64 differs from BOTH fp32 runs by 1.2e-4 /
+    # 1.5e-4 at the worst element and 2.4e-6 on average (gradient scale: max 1.8e-2, mean 3.2e-3)
+    d = np.abs(x.grad[:, :8].numpy() - g["gx_slice"])
+    assert d.max() < 1.5e-2 * np.abs(g["gx_slice"]).max() and d.mean() < 2e-3 * np.abs(g["gx_slice"]).mean()
+    gw = [head.shared_conv.weight.grad, head.heatmap_head[1].bias.grad, head.prediction_heads[0].center[1].weight.grad,
+          head.decoder[0].multihead_attn.in_proj_weight.grad]
+    gw = np.array([w.abs().sum(dtype=torch.float64).item() for w in gw])
+    assert np.abs(gw / g["gw"] - 1).max() < 3e-3           # |.|-sums collect the rounding noise of near-zero entries
+    # a frame without ground truth (the reference cannot take one): every proposal is background, no box loss
+    empty = head.get_targets([torch.zeros((0, 9))] + gt_boxes[1:], [torch.zeros((0,), dtype=torch.long)] + gt_labels[1:], res[0])
+    assert (empty[0][0] == head.num_classes).all() and empty[3][0].sum() == 0 and empty[7][0].sum() == 0
+
+
+def test_oracle_tf_overlap_matches_cp_convention():
+    """The two trees' rotated-overlap kernels differ in box format and turning sense only: TF's xyxyr boxes turned by
+    -angle (iou3d_kernel.cu:106-114) cover the same area as CP's centre boxes with heading = -angle.  Ties the new
+    oracle restatement to the one pinned bit for bit against the reference's CPU build (oracle/_ref, iou3d.npz)."""
+    import detgen
+    from oracle import oracle as orc
+    a = detgen.bev_boxes("tfov_a", 150, 8.0)
+    b = detgen.bev_boxes("tfov_b", 120, 8.0, special=False)
+
+    def xyxyr(v):
+        return np.stack([v[:, 0] - v[:, 3] / 2, v[:, 1] - v[:, 4] / 2, v[:, 0] + v[:, 3] / 2, v[:, 1] + v[:, 4] / 2, -v[:, 6]], 1)
+    tf = orc.tf_boxes_overlap_bev(xyxyr(a), xyxyr(b))
+    cp = orc.boxes_pairwise_bev(a, b, "overlap")
+    assert (tf > 0).sum() > 200
+    # the corner-containment margins differ (1e-5 vs 1e-2): touching configurations may gain / lose a sliver
+    assert np.abs(tf - cp).max() < 5e-2 and np.median(np.abs(tf - cp)[tf > 0]) < 1e-5
