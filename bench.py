@@ -605,7 +605,7 @@ def main():
                                                                "bucket order from post-accumulate-grad hooks during backward" % len(wl.reducer.buckets)}
         if stage in ("detect", "train") and isinstance(out, dict) and "encoded_spconv_tensor" not in out:
             res["reduced_losses"] = {k: [round(float(x), 5) for x in v.reshape(-1).float().cpu()] for k, v in out.items()
-                                     if "loss" in k or k == "matched_ious"}
+                                     if ("loss" in k and not k.endswith("_elem")) or k == "matched_ious"}
         if "in_flight" in extra:
             res["in_flight"] = {"frames_in_flight": args.inflight, "ms_per_step": per_step(extra["in_flight"]),
                                 "value": round(units / extra["in_flight"], 3), "unit": res["unit"],
