@@ -311,6 +311,72 @@ static int fps_block(int n) {
   return t;
 }
 
+// F-FPS form of the sampler (furthest_point_sample_cuda.cu:213-330): the distance of point k to the last pick comes from a
+// precomputed [N, N] matrix instead of coordinates.  Same per-thread strided scan and the same tie rule as fps_kernel
+// (running minima in `temp_g`, as the reference keeps them).
+__global__ __launch_bounds__(1024) void fps_with_dist_kernel(const float *__restrict__ dist, int N, int m,
+                                                             float *__restrict__ temp_g, int32_t *__restrict__ idx) {
+  __shared__ float s_v[16];
+  __shared__ int s_t[16], s_k[16];
+  __shared__ int s_old;
+  const int b = blockIdx.x, tid = threadIdx.x, bs = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = (bs + 63) >> 6;
+  const float *d = dist + (size_t)b * N * N;
+  float *tg = temp_g + (size_t)b * N;
+  int32_t *o = idx + (size_t)b * m;
+  for (int k = tid; k < N; k += bs) tg[k] = 1e10f;
+  if (tid == 0 && m > 0) o[0] = 0;
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    Best me = {-1.f, tid, 0};
+    for (int k = tid; k < N; k += bs) {
+      const float d2 = fminf(d[(size_t)old * N + k], tg[k]);
+      tg[k] = d2;
+      if (d2 > me.v) {
+        me.v = d2;
+        me.k = k;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      Best ot;
+      ot.v = __shfl_xor(me.v, off, 64);
+      ot.tid = __shfl_xor(me.tid, off, 64);
+      ot.k = __shfl_xor(me.k, off, 64);
+      me = better(me, ot);
+    }
+    if (lane == 0) {
+      s_v[wave] = me.v;
+      s_t[wave] = me.tid;
+      s_k[wave] = me.k;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      Best r = {s_v[0], s_t[0], s_k[0]};
+      for (int w = 1; w < nw; ++w) {
+        Best ot = {s_v[w], s_t[w], s_k[w]};
+        r = better(r, ot);
+      }
+      s_old = r.k;
+      o[j] = r.k;
+    }
+    __syncthreads();
+    old = s_old;
+  }
+}
+
+// Backward of group_points / gather_points (group_points_cuda.cu:10-31, gather_points_cuda.cu:48-70): the output gradient is
+// scatter-added onto the source points; thread = one (channel, output element), fp32 hardware atomics.
+__global__ __launch_bounds__(256) void index_add_grad_kernel(const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
+                                                             int C, int N, long long per, float *__restrict__ grad_points) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (i >= per) return;
+  const int src = idx[(size_t)b * per + i];
+  if (src < 0 || src >= N) return;
+  atomicAdd(grad_points + ((size_t)b * C + c) * N + src, grad_out[((size_t)b * C + c) * per + i]);
+}
+
 extern "C" int df3d_furthest_point_sample(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
                                           void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -524,4 +590,34 @@ extern "C" int df3d_group_points(const float *features, const int32_t *idx, int 
 extern "C" int df3d_gather_points(const float *features, const int32_t *idx, int B, int C, int N, int npoint,
                                   float *out, void *stream_) {
   return df3d_group_points(features, idx, B, C, N, npoint, 1, out, stream_);
+}
+
+extern "C" int df3d_furthest_point_sample_with_dist(const float *dist, int B, int N, int m, float *temp, int32_t *idx,
+                                                    void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(dist && idx && temp, "furthest_point_sample_with_dist: null argument");
+  DF3D_CHECK_ARG(B >= 0 && N > 0 && m >= 0, "furthest_point_sample_with_dist: bad sizes");
+  if (B == 0 || m == 0) return DF3D_OK;
+  hipLaunchKernelGGL(fps_with_dist_kernel, dim3(B), dim3(fps_block(N)), 0, stream, dist, N, m, temp, idx);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_group_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int npoint, int nsample,
+                                      float *grad_points, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(B >= 0 && C >= 0 && N > 0 && npoint >= 0 && nsample >= 0, "group_points_grad: bad sizes");
+  const long long per = (long long)npoint * nsample;
+  if (B == 0 || C == 0 || per == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(grad_out && idx && grad_points, "group_points_grad: null argument");
+  DF3D_CHECK_ARG(C <= 65535 && B <= 65535, "group_points_grad: more than 65535 channels / samples");
+  hipLaunchKernelGGL(index_add_grad_kernel, dim3(cdiv(per, 256), C, B), dim3(256), 0, stream, grad_out, idx, C, N, per,
+                     grad_points);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_gather_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int npoint,
+                                       float *grad_points, void *stream) {
+  return df3d_group_points_grad(grad_out, idx, B, C, N, npoint, 1, grad_points, stream);
 }

@@ -142,6 +142,9 @@ SIGNATURES = {
                                        c_void_p, c_size_t, c_void_p]),
     "df3d_transfusion_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
+    "df3d_furthest_point_sample_with_dist": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_group_points_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_gather_points_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_boxes_overlap_bev_xyxyr": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "df3d_tf_match_cost": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

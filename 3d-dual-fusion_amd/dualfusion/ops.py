@@ -92,6 +92,30 @@ def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels, break
     return (voxels[:n] if voxels is not None else None, coors[:n], num[:n], mean[:n] if mean is not None else None)
 
 
+def hard_voxelize_into(points, voxels, coors, num, voxel_size, coors_range, max_points, max_voxels, break_at_cap=True):
+    """df3d_hard_voxelize into CALLER-ALLOCATED outputs (the contract of the reference's `voxel_layer.hard_voxelize`,
+    TF/mmdet3d/ops/voxel/voxelize.py:46-57): voxels [>= max_voxels, max_points, C], coors [>= max_voxels, 3] i32,
+    num [>= max_voxels] i32.  Returns the number of voxels (one D2H read)."""
+    lib = _lib.load()
+    _chk(points, torch.float32, "points")
+    _chk(voxels, torch.float32, "voxels")
+    _chk(coors, torch.int32, "coors")
+    _chk(num, torch.int32, "num_points_per_voxel")
+    P, C = points.shape
+    cap = P if (max_voxels < 0 or max_voxels > P) else int(max_voxels)
+    if min(voxels.shape[0], coors.shape[0], num.shape[0]) < cap:
+        raise ValueError("output buffers hold fewer than %d voxels" % cap)
+    count = torch.empty((1,), dtype=torch.int32, device=points.device)
+    wsb = lib.df3d_hard_voxelize_workspace_bytes(P, int(max_points), cap)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=points.device)
+    vs_p, vs_keep = _lib.float_arr(list(voxel_size))
+    rg_p, rg_keep = _lib.float_arr(list(coors_range))
+    rc = lib.df3d_hard_voxelize(_ptr(points), P, C, vs_p, rg_p, int(max_points), cap, int(bool(break_at_cap)), _ptr(voxels),
+                                _ptr(coors), _ptr(num), None, _ptr(count), _ptr(ws), wsb, _stream())
+    _lib.check(rc, "df3d_hard_voxelize")
+    return _read_count(count, None)
+
+
 # ------------------------------------------------------------------------- rulebook
 class GridDirectory(object):
     """Occupancy directory of a voxel set (see csrc/rulebook.hip)."""
@@ -1033,12 +1057,13 @@ def sparse_maxpool_backward(features, out_features, grad_out, inv):
     return gin
 
 
-def dynamic_voxelize(points, voxel_size, coors_range):
-    """df3d_dynamic_voxelize: coors [P, 3] int32 (z, y, x), -1 rows for points outside the grid."""
+def dynamic_voxelize(points, voxel_size, coors_range, out=None):
+    """df3d_dynamic_voxelize: coors [P, 3] int32 (z, y, x), -1 rows for points outside the grid (written into `out`
+    when the caller brings the buffer, as the reference's extension expects)."""
     lib = _lib.load()
     _chk(points, torch.float32, "points")
     P, F = points.shape
-    coors = torch.empty((P, 3), dtype=torch.int32, device=points.device)
+    coors = torch.empty((P, 3), dtype=torch.int32, device=points.device) if out is None else _chk(out, torch.int32, "coors")
     vs = (ctypes.c_float * 3)(*[float(v) for v in voxel_size])
     rng = (ctypes.c_float * 6)(*[float(v) for v in coors_range])
     rc = lib.df3d_dynamic_voxelize(_ptr(points), P, F, ctypes.cast(vs, ctypes.c_void_p), ctypes.cast(rng, ctypes.c_void_p),

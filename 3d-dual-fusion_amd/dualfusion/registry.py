@@ -86,6 +86,9 @@ BACKBONES_3D = Registry("pcdet backbone_3d")   # pcdet uses a plain dict `__all_
 def late_register():
     """Register our classes into the real frameworks' registries when those are importable, so the
     reference configs resolve `type=` / `NAME:` strings to the MI355X modules unchanged."""
+    import importlib
+    for m in ("spconv", "voxel", "backbones", "fusion", "fusion_tf", "necks", "heads", "transfusion_head"):
+        importlib.import_module("." + m, __package__)          # every module that registers classes (some import lazily)
     done = []
     try:
         from mmcv.cnn import CONV_LAYERS as MMCV_CONV
@@ -95,7 +98,10 @@ def late_register():
     except Exception:
         pass
     try:
-        from mmdet3d.models.builder import FUSION_LAYERS as F3, MIDDLE_ENCODERS as M3, VOXEL_ENCODERS as V3
+        try:
+            from mmdet3d.models.builder import FUSION_LAYERS as F3, MIDDLE_ENCODERS as M3, VOXEL_ENCODERS as V3
+        except ImportError:                                     # TF/mmdet3d/models/registry.py holds them in this tree
+            from mmdet3d.models.registry import FUSION_LAYERS as F3, MIDDLE_ENCODERS as M3, VOXEL_ENCODERS as V3
         for src, dst in ((FUSION_LAYERS, F3), (MIDDLE_ENCODERS, M3), (VOXEL_ENCODERS, V3)):
             for k, v in src.module_dict.items():
                 dst.register_module(name=k, module=v, force=True)

@@ -508,6 +508,17 @@ int df3d_group_points(const float *features, const int32_t *idx, int B, int C, i
                       int nsample, float *out, void *stream);
 int df3d_gather_points(const float *features, const int32_t *idx, int B, int C, int N, int npoint,
                        float *out, void *stream);
+/* The remaining entry points of the point-op extension modules (round 3):
+ *   furthest_point_sampling_with_dist_wrapper (TF/mmdet3d/ops/furthest_point_sample/src/furthest_point_sample.cpp:45-57,
+ *     furthest_point_sample_cuda.cu:213-330): dist [B,N,N] pairwise distances instead of coordinates, same scan / tie rule;
+ *   group_points_ext.backward (group_points/src/group_points.cpp:35-47, group_points_cuda.cu:10-31) and
+ *   gather_points_grad_wrapper (gather_points/src/gather_points.cpp:38-51, gather_points_cuda.cu:48-70):
+ *     grad_points [B,C,N] += grad_out scattered by idx (the caller zeroes grad_points, as the reference's wrappers do). */
+int df3d_furthest_point_sample_with_dist(const float *dist, int B, int N, int m, float *temp, int32_t *idx, void *stream);
+int df3d_group_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int npoint, int nsample,
+                           float *grad_points, void *stream);
+int df3d_gather_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int npoint, float *grad_points,
+                            void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Camera-fusion glue of the CenterPoint adapter (rows a7-a9 of SURVEY.md §8a).  The reference has
