@@ -131,7 +131,10 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(LossArgs a, const doub
   for (int s = threadIdx.x; s < slots; s += 256) {
     const float m = g.mask[s] ? 1.f : 0.f;
     const long long ind = g.ind[s];
-    if (ind < 0 || ind >= a.hw) continue;              // the reference's gather would fault; contribute nothing
+    if (ind < 0 || ind >= a.hw) {                      // the reference's gather would fault; the slot contributes no
+      npos += m;                                       // terms, but it counts as a positive like mask.sum() does -- the
+      continue;                                        // same normaliser as the gradient kernels' task_positives()
+    }
     const int b = s / a.max_objs;
     const long long r = (long long)b * a.hw + ind;
     const long long c = g.cat[s];

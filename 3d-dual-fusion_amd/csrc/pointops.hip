@@ -569,6 +569,14 @@ extern "C" int df3d_ball_query(const float *new_xyz, const float *xyz, int B, in
   DF3D_CHECK_ARG(nsample <= 1024, "ball_query: at most 1024 samples per centre (got %d)", nsample);
   // (every slot of every centre is written: no hit = zeros, like the reference's zero-initialised idx)
   const size_t lds = (size_t)(BQ_TILE * 3 + BQ_WAVES * nsample) * sizeof(float);
+  if (lds > 64 * 1024) {                               // nsample > 832: beyond the default dynamic-LDS limit (160 KB per CU)
+    static bool raised = false;
+    if (!raised) {
+      DF3D_HIP(hipFuncSetAttribute((const void *)ball_query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((BQ_TILE * 3 + BQ_WAVES * 1024) * sizeof(float))));
+      raised = true;
+    }
+  }
   hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(m, BQ_WAVES), B), dim3(BQ_WAVES * 64), lds, stream, new_xyz, xyz, N, m,
                      min_radius * min_radius, max_radius * max_radius, nsample, idx);
   DF3D_LAUNCH_CHECK();

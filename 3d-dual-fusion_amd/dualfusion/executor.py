@@ -131,14 +131,17 @@ class BackbonePlan(object):
 
     # ---------------------------------------------------------------- layer specs -> C table
     def _signature(self):
-        """Cheap change detector for the cached table: parameter version counters (bumped by every in-place
-        update, e.g. load_state_dict / optimizer steps) + storage addresses of the first and last filter bank."""
-        v = 0
+        """Change detector for the cached table: (storage address, version counter) of EVERY tensor the table is folded
+        from -- filters, conv biases, BatchNorm weight / bias / running_mean / running_var.  Version counters are bumped by
+        every in-place update (load_state_dict, optimizer steps, `bn.bias.add_()` under no_grad ...); addresses catch re-assigned
+        parameters."""
+        sig = []
         for s in self.specs:
-            v += s.conv.weight._version
+            ts = [s.conv.weight, getattr(s.conv, "bias", None)]
             if s.bn is not None:
-                v += s.bn.running_var._version + s.bn.weight._version
-        return (v, self.specs[0].conv.weight.data_ptr(), self.specs[-1].conv.weight.data_ptr(), _ops.CONV_PRECISION)
+                ts += [s.bn.weight, s.bn.bias, s.bn.running_mean, s.bn.running_var]
+            sig.extend((t.data_ptr(), t._version) if t is not None else None for t in ts)
+        return (tuple(sig), _ops.CONV_PRECISION)
 
     def _build_table(self):
         n = len(self.specs)

@@ -194,8 +194,9 @@ class CenterHead(nn.Module):
         return [task(x) for task in self.tasks]
 
     def forward(self, x, *kwargs):
+        self.__dict__.pop("_packed_train", None)          # a previous step's packed maps (and their graph) are not kept
         if ((self.training or torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
-                and _ops.CONV_PRECISION == "split" and self._row_kernels_fit(x)):
+                and _ops.CONV_PRECISION == "split" and self._row_kernels_fit(x) and self._train_rows_fit()):
             return self.forward_rows_train(x)
         if (self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32
                 or _ops.CONV_PRECISION == "fp32" or not self._row_kernels_fit(x)):
@@ -217,6 +218,16 @@ class CenterHead(nn.Module):
                 ok = ok and len(fc) == 4 and isinstance(fc[1], nn.BatchNorm2d) and fc[0].kernel_size == (3, 3) \
                     and fc[0].out_channels == 64 and fc[3].out_channels <= 32
         return ok
+
+    def _train_rows_fit(self):
+        """What `forward_rows_train` assumes on top of `_row_kernels_fit`: final convs of <= 4 maps (HF_KMAX of
+        headconv.hip) with a bias, biased first convs, and ONE set of BatchNorm hyper-parameters over all branches (their 36
+        BatchNorms run as one).  Anything else (e.g. a single 10-class task) trains through `forward_reference`."""
+        bns = [getattr(task, head)[1] for task in self.tasks for head in task.heads]
+        fcs = [getattr(task, head) for task in self.tasks for head in task.heads]
+        return (all(fc[3].out_channels <= 4 and fc[3].bias is not None and fc[0].bias is not None for fc in fcs)
+                and all((b.momentum, b.eps, b.training, b.affine, b.track_running_stats) ==
+                        (bns[0].momentum, bns[0].eps, bns[0].training, bns[0].affine, bns[0].track_running_stats) for b in bns))
 
     @staticmethod
     def _filters(conv, pad_to=None):
@@ -436,6 +447,7 @@ class CenterHead(nn.Module):
         the reference's assigner provides them.  Like the reference it replaces preds_dict['hm'] by its sigmoid in
         place and returns {key: [per-task values]}."""
         from collections import defaultdict
+        self.__dict__.pop("_packed_train", None)          # the reference flow head(x) -> head.loss(...) never calls loss_rows
         rets = []
         for task_id, preds_dict in enumerate(preds_dicts):
             preds_dict['hm'] = _clamped_sigmoid(preds_dict['hm'])

@@ -398,6 +398,45 @@ def test_native_executor_matches_module_path():
             assert torch.equal(y_fast, y_slow)
 
 
+def test_native_executor_table_follows_every_parameter():
+    """an in-place edit of ANY tensor the folded table is built from -- conv bias, BatchNorm bias /
+    running_mean alone, not only filters / running_var / BatchNorm weight -- must rebuild the table: after each edit the
+    executor's output equals the per-module path's (which reads the parameters directly)."""
+    import os
+    from dualfusion import synth
+    from dualfusion.pipeline import CenterPointHotPath
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    model = CenterPointHotPath().eval().to(dev)
+    pts = torch.from_numpy(synth.nusc_sweep(seed=2)[:20000].copy()).to(dev)
+    bb = model.backbone
+    bn0 = next(m for m in bb.modules() if isinstance(m, torch.nn.BatchNorm1d))
+    block_conv = bb.conv1[0].conv1                                    # a BasicBlock conv: it has a bias (scn.py:68-73)
+    assert block_conv.bias is not None
+
+    def both():
+        with torch.no_grad():
+            feats, coors = model.voxelize([pts])
+            fast = bb._stem(feats, coors, 1, model.grid_size_xyz)
+            os.environ["DF3D_EXECUTOR"] = "0"
+            try:
+                slow = bb._stem(feats, coors, 1, model.grid_size_xyz)
+            finally:
+                os.environ["DF3D_EXECUTOR"] = "1"
+        return fast[-1].features.clone(), slow[-1].features.clone()
+    f0, s0 = both()
+    assert torch.equal(f0, s0)
+    # (edits under no_grad bump the tensors' version counters, as optimizers and load_state_dict do; writes through
+    # `.data` bypass the counters by design and are not tracked by any of the caches)
+    for edit in (lambda: bn0.bias.add_(0.37), lambda: bn0.running_mean.add_(0.21), lambda: block_conv.bias.add_(0.4)):
+        with torch.no_grad():
+            edit()
+        f1, s1 = both()
+        assert torch.equal(f1, s1), "stale executor table"
+        assert not torch.equal(f1, f0)
+        f0 = f1
+
+
 # ------------------------------------------------------------------------- sparse conv backward (SURVEY section 8f row 4)
 @pytest.mark.parametrize("subm", [1, 0])
 def test_conv_backward_golden_and_autograd(golden, subm):

@@ -246,3 +246,47 @@ def test_detector_training_step_with_camera_fusion():
     opt.step()
     for k, v in probe.items():
         assert float((v.detach() - before[k]).abs().max()) > 0, k
+
+
+def test_rulebooks_beyond_the_int32_flat_index(sweep):
+    """Batch 27 of the full grid: flat index = b * 41 * 1440 * 1440 passes 2^31 at b = 26, where the reference's int32
+    `index` overflows (TF/mmdet3d/ops/spconv/include/spconv/indice.cu.h:59-60, geometry.h rowArrayIdxInv).  The directory and
+    both rulebook kinds use 64-bit cell numbers: the same voxel set placed in samples 0, 25 and 26 must give the same
+    sub-manifold neighbourhoods, strided output sets and pair tables in every sample, and sample 0's must be the oracle's."""
+    from dualfusion import ops
+    B = 27
+    assert B * GRID[0] * GRID[1] * GRID[2] > 2 ** 31
+    base = sweep["coors"][::7].copy()                      # ~9 k voxels of the sweep, real geometry
+    n = len(base)
+    parts = []
+    for b in (0, 25, 26):
+        c = base.copy()
+        c[:, 0] = b
+        parts.append(c)
+    ind = np.concatenate(parts)
+    ind_t = T(ind)
+    grid = ops.grid_build(ind_t, B, GRID)
+    nbr = ops.subm_neighbors(grid, ind_t, [3, 3, 3]).cpu().numpy()                       # [27, 3n]
+    for s in (1, 2):                                       # same table, shifted by the sample's row offset
+        blk = nbr[:, s * n:(s + 1) * n]
+        assert np.array_equal(np.where(blk >= 0, blk - s * n, -1), nbr[:, :n])
+    _, opairs, onum, _ = orc.get_indice_pairs(base, 1, GRID, [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], 1)
+    pairs, num = ops.nbr_to_pairs(T(np.ascontiguousarray(nbr[:, :n])), n)
+    a = orc.canonical_rulebook(base, pairs.cpu().numpy(), num.cpu().numpy())
+    b_ = orc.canonical_rulebook(base, opairs, onum)
+    assert np.array_equal(a[0], b_[0]) and all(np.array_equal(x, y) for x, y in zip(a[1], b_[1]))
+    # strided layer
+    ks, st, pd = [3, 3, 3], [2, 2, 2], [1, 1, 1]
+    oshape = orc.get_conv_output_size(GRID, ks, st, pd, [1, 1, 1])
+    outids, _ = ops.conv_out_indices(ind_t, B, GRID, oshape, ks, st, pd)
+    o = outids.cpu().numpy()
+    per = [o[o[:, 0] == b][:, 1:] for b in (0, 25, 26)]
+    assert len(per[0]) > 0 and sum(len(p) for p in per) == len(o)
+    assert np.array_equal(per[0], per[1]) and np.array_equal(per[0], per[2])
+    oo, _, _, _ = orc.get_indice_pairs(base, 1, GRID, ks, st, pd, [1, 1, 1], 0)
+    assert np.array_equal(per[0], oo[np.lexsort(oo.T[::-1])][:, 1:])
+    nb2 = ops.conv_neighbors(grid, outids, ks, st, pd).cpu().numpy()
+    m = len(per[0])
+    for s in (1, 2):
+        blk = nb2[:, s * m:(s + 1) * m]
+        assert np.array_equal(np.where(blk >= 0, blk - s * n, -1), nb2[:, :m])
