@@ -1263,8 +1263,15 @@ static bool use_lc(const SplitConvArgs &a) {
   return a.K > 1 && (long long)cdiv(a.n_out, 128) * a.gy >= 190;
 }
 
+#include "spconv_halo.h"
+
 template <int CIN, int COUT>
 static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
+  // 3 x 3 (x 3) rulebooks of the backbone shapes: input rows staged through LDS (spconv_halo.h)
+  if constexpr ((CIN == 32 && (COUT == 32 || COUT == 64)) || (CIN == 64 && (COUT == 64 || COUT == 128)) ||
+                (CIN == 128 && COUT == 128)) {
+    if (halo_mode(a)) return launch_halo<CIN, COUT>(a, stream);
+  }
   // measured on MI355X (tools/conv_probe.py, DF3D_OS_CFG sweep): 8 waves x 1 row tile wins at the nuScenes layer
   // sizes (30k-70k rows).  The W step tiles are re-read from L2 by every workgroup (n_out/TM x 4*K*CIN*COUT
   // bytes per launch, more than the gathers), so more rows per workgroup = less L2 traffic; bigger register
