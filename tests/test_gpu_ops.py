@@ -284,6 +284,64 @@ def test_loader_consumer_conv_kernel_forced_on_small_and_ragged_shapes(dev, cin,
             os.environ["DF3D_OS_LC"] = old
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (128, 128), (32, 64)])
+@pytest.mark.parametrize("mode", ["2", "4", "8", "9"])
+def test_staged_range_conv_kernels_match_the_default_kernel(dev, cin, cout, mode):
+    """The opt-in staged-range kernels (csrc/spconv_halo.h, DF3D_CONV_HALO=1: input rows of an offset group loaded once, as
+    one contiguous rank range, into LDS) against the default kernel: same products, another summation order (<= 2e-5 of
+    the output scale), identical split rows of their own fp32 result.  Row counts around the 128 / 256-row tiles, SubM and
+    strided rulebooks, rows in SHUFFLED order (ranges longer than the staging capacity: the chunked path), a tiling
+    order, every epilogue combination, tiles and kz groups without any neighbour."""
+    import os
+    from dualfusion import ops
+    shape, batch = [9, 48, 48], 2
+    filt = detgen.randn("hw%d_%d" % (cin, cout), (27, cin, cout), 0.5 / np.sqrt(cin))
+    packed = ops.conv_pack_weights(T(filt, dev))
+    bias, scale, shift = (T(detgen.randn("h%s%d" % (t, cout), (cout,), 0.2), dev) for t in "bsh")
+    old = {k: os.environ.get(k) for k in ("DF3D_CONV_HALO", "DF3D_HALO_RT", "DF3D_OS_LC")}
+
+    def both(fn):
+        os.environ["DF3D_CONV_HALO"] = "0"
+        a = fn()
+        os.environ["DF3D_CONV_HALO"], os.environ["DF3D_HALO_RT"] = "1", mode
+        b = fn()
+        return a, b
+    try:
+        for n_seeds, walk, shuffle in ((1, 1, False), (2, 64, False), (8, 200, False), (40, 200, False), (40, 200, True)):
+            ind = detgen.clustered_voxels("h%d_%d" % (n_seeds, walk), batch, shape, n_seeds=n_seeds, walk=walk)
+            if shuffle:
+                ind = ind[np.random.RandomState(1).permutation(len(ind))]
+            else:
+                ind = ind[np.lexsort(ind.T[::-1])]                    # rows sorted by cell, as every stage hands them over
+            ind_t = T(ind, dev)
+            feats = detgen.randn("hf%d_%d_%d" % (cin, n_seeds, walk), (len(ind), cin))
+            fsplit = ops.split_rows(T(feats, dev))
+            for subm in (1, 0):
+                outids, nbr, _ = _hip_rulebook(ind_t, batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], subm)
+                n_out = outids.shape[0]
+                res = T(detgen.randn("hr%d_%d" % (cout, n_out), (n_out, cout)), dev)
+                for kw in (dict(), dict(bias=bias, scale=scale, shift=shift, residual=res, relu=True)):
+                    (y0, s0), (y1, s1) = both(lambda: ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, **kw))
+                    assert float((y0 - y1).abs().max()) <= 2e-5 * max(float(y0.abs().max()), 1e-6), (n_out, subm, sorted(kw))
+                    assert torch.equal(ops.split_rows(y1), s1)
+                if subm and n_out > 1:
+                    order = torch.randperm(n_out, device=dev, dtype=torch.int64).to(torch.int32)
+                    (y0, _), (y1, _) = both(lambda: ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, bias=bias, order=order))
+                    assert float((y0 - y1).abs().max()) <= 2e-5 * max(float(y0.abs().max()), 1e-6)
+        # a dense 3 x 3 layer over pixel rows (K = 9: one group holds all taps)
+        nb9, Ho, Wo = ops.conv2d_neighbors(2, 37, 41, 3, 3, 1, 1, False, torch.device(dev))
+        f9 = ops.split_rows(T(detgen.randn("h9f%d" % cin, (2 * 37 * 41, cin)), dev))
+        p9 = ops.conv_pack_weights(T(filt[:9].copy(), dev))
+        (y0, _), (y1, _) = both(lambda: ops.sparse_conv_split(f9, p9, nb9, 2 * Ho * Wo, cin, cout, bias=bias, relu=True))
+        assert float((y0 - y1).abs().max()) <= 2e-5 * float(y0.abs().max())
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_rulebook_empty_and_single(dev):
     from dualfusion import ops
     shape, batch = [5, 8, 8], 1
