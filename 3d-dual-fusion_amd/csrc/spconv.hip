@@ -40,6 +40,10 @@ struct ConvArgs {
   const float *bias, *scale, *shift, *residual;
   float *out;
   int n_in, n_out, K, cin, cout, relu;
+  // MFMA kernel only (df3d_sparse_conv_grouped): floats per input / output row (the operands may be column slices of
+  // wider rows), and the column offset between the slices of two consecutive groups (blockIdx.y; filters, bias, scale
+  // and shift of a group follow the previous group's)
+  int ldi, ldo, gi, go;
 };
 
 template <int KS>
@@ -66,6 +70,15 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
+  if (gridDim.y > 1) {                          // grouped launch: this workgroup's slice of the operands
+    const int grp = blockIdx.y;
+    a.feat += (size_t)grp * a.gi;
+    a.w += (size_t)grp * a.K * a.cin * COUT;
+    a.out += (size_t)grp * a.go;
+    if (a.bias) a.bias += grp * COUT;
+    if (a.scale) a.scale += grp * COUT;
+    if (a.shift) a.shift += grp * COUT;
+  }
 
   // XCD-aware tile order: consecutive tiles (which share neighbour rows) stay on one XCD/L2
   int nt = gridDim.x;
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < KS / 4; ++q) {
           f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (idx >= 0) v = *(const f32x4 *)(a.feat + (size_t)idx * a.cin + c0 + q * 4);
+          if (idx >= 0) v = *(const f32x4 *)(a.feat + (size_t)idx * a.ldi + c0 + q * 4);
           anext[rt].v[q * 4 + 0] = v[0];
           anext[rt].v[q * 4 + 1] = v[1];
           anext[rt].v[q * 4 + 2] = v[2];
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
           float v = 0.f;
-          if (idx >= 0 && c0 + j < a.cin) v = a.feat[(size_t)idx * a.cin + c0 + j];
+          if (idx >= 0 && c0 + j < a.cin) v = a.feat[(size_t)idx * a.ldi + c0 + j];
           anext[rt].v[j] = v;
         }
       }
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
           float v = (acc[rt][ct][r] + bi) * sc + sh;
           if (a.residual) v += a.residual[(size_t)row * COUT + col];
           if (a.relu) v = fmaxf(v, 0.f);
-          a.out[(size_t)row * COUT + col] = v;
+          a.out[(size_t)row * a.ldo + col] = v;
         }
       }
     }
@@ -731,29 +744,36 @@ static int dispatch_small(const ConvArgs &a, hipStream_t stream) {
 }
 
 template <int CINP, int COUT, int KC, bool VEC>
-static void launch_mfma(const ConvArgs &a, hipStream_t stream) {
+static void launch_mfma(const ConvArgs &a, hipStream_t stream, int groups = 1) {
   // small layers: 64-row tiles so that the grid still covers the 256 CUs several times
-  if (a.n_out < 128 * 1024) {
-    int nt = cdiv(a.n_out, 64);
-    hipLaunchKernelGGL((spconv_mfma_kernel<CINP, COUT, KC, 1, VEC>), dim3(nt), dim3(256), 0, stream, a);
+  // (grouped launches of the narrow final convs of the detection heads: 64 / 128 / 256 rows per workgroup measured
+  // within 5 % of each other on MI355X -- 358 .. 383 us for 36 groups of 64 -> 16 on 32 400 rows)
+  const int rt = (long long)a.n_out * groups < 128 * 1024 ? 1 : 2;
+  if (rt == 1) {
+    hipLaunchKernelGGL((spconv_mfma_kernel<CINP, COUT, KC, 1, VEC>), dim3(cdiv(a.n_out, 64), groups), dim3(256), 0, stream, a);
   } else {
-    int nt = cdiv(a.n_out, 128);
-    hipLaunchKernelGGL((spconv_mfma_kernel<CINP, COUT, KC, 2, VEC>), dim3(nt), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((spconv_mfma_kernel<CINP, COUT, KC, 2, VEC>), dim3(cdiv(a.n_out, 128), groups), dim3(256), 0, stream, a);
   }
 }
 
 template <int COUT>
-static bool dispatch_cin(const ConvArgs &a, hipStream_t stream) {
+static bool dispatch_cin(const ConvArgs &a, hipStream_t stream, int groups = 1) {
   if (a.cin <= 8) {
+    if (groups > 1) return false;
     if (a.cin % 4 == 0) launch_mfma<8, COUT, 8, false>(a, stream);
     else launch_mfma<8, COUT, 8, false>(a, stream);
     return true;
   }
+  // the filter tile of a step is KC x COUT floats, double buffered: 16-channel slices keep 256 columns inside 64 KB
+  constexpr int KW = COUT > 128 ? 16 : 32;
   switch (a.cin) {
-    case 16: launch_mfma<16, COUT, 16, true>(a, stream); return true;
-    case 32: launch_mfma<32, COUT, 32, true>(a, stream); return true;
-    case 64: launch_mfma<64, COUT, 32, true>(a, stream); return true;
-    case 128: launch_mfma<128, COUT, 32, true>(a, stream); return true;
+    case 16: launch_mfma<16, COUT, 16, true>(a, stream, groups); return true;
+    case 32: launch_mfma<32, COUT, KW, true>(a, stream, groups); return true;
+    case 64: launch_mfma<64, COUT, KW, true>(a, stream, groups); return true;
+    case 128: launch_mfma<128, COUT, KW, true>(a, stream, groups); return true;
+    // BEV neck / detection heads in the exact-fp32 mode (round 3): 256- and 512-channel inputs
+    case 256: launch_mfma<256, COUT, KW, true>(a, stream, groups); return true;
+    case 512: launch_mfma<512, COUT, KW, true>(a, stream, groups); return true;
     default: return false;
   }
 }
@@ -914,10 +934,34 @@ extern "C" int df3d_conv_tiles(const int32_t *nbr, int kvol, int n_out, int ntil
   return DF3D_OK;
 }
 
+struct ConvGroups;
 static int sparse_conv_impl(const float *features, int n_in, int cin, const float *filters, int kvol, int cout,
                             const int32_t *nbr, int n_out, const float *bias, const float *scale, const float *shift,
                             const float *residual, int relu, float *out, const int32_t *tile_rows, int ntiles,
-                            void *stream_);
+                            void *stream_, const ConvGroups *cg = nullptr);
+
+struct ConvGroups {
+  int groups, ld_in, group_in, ld_out, group_out;
+};
+
+extern "C" int df3d_sparse_conv_grouped(const float *features, int n_in, int cin, int ld_in, int group_in, const float *filters,
+                                        int kvol, int cout, int groups, const int32_t *nbr, int n_out, const float *bias,
+                                        const float *scale, const float *shift, int relu, float *out, int ld_out, int group_out,
+                                        void *stream_) {
+  DF3D_CHECK_ARG(groups >= 1 && groups <= 65535 && ld_in >= cin && ld_in % 4 == 0 && group_in % 4 == 0 && group_in >= 0 &&
+                     ld_out >= cout && group_out >= 0,
+                 "sparse_conv_grouped: bad strides (groups %d, ld_in %d, group_in %d, ld_out %d, group_out %d)", groups, ld_in,
+                 group_in, ld_out, group_out);
+  DF3D_CHECK_ARG(cin >= 16 && (cin & (cin - 1)) == 0 && cin <= 512 &&
+                     (cout == 16 || cout == 32 || cout == 64 || cout == 128 || cout == 256),
+                 "sparse_conv_grouped: served by the MFMA kernel for cin 16..512 (power of two), cout 16..256; got %d -> %d", cin,
+                 cout);
+  DF3D_CHECK_ARG((groups - 1) * (long long)group_in + cin <= ld_in && (groups - 1) * (long long)group_out + cout <= ld_out,
+                 "sparse_conv_grouped: the slices of %d groups do not fit the rows", groups);
+  const ConvGroups cg = {groups, ld_in, group_in, ld_out, group_out};
+  return sparse_conv_impl(features, n_in, cin, filters, kvol, cout, nbr, n_out, bias, scale, shift, nullptr, relu, out,
+                          nullptr, 0, stream_, &cg);
+}
 
 extern "C" int df3d_sparse_conv_fused(const float *features, int n_in, int cin, const float *filters, int kvol,
                                       int cout, const int32_t *nbr, int n_out, const float *bias, const float *scale,
@@ -938,7 +982,7 @@ extern "C" int df3d_sparse_conv_fused_tiled(const float *features, int n_in, int
 static int sparse_conv_impl(const float *features, int n_in, int cin, const float *filters, int kvol, int cout,
                             const int32_t *nbr, int n_out, const float *bias, const float *scale, const float *shift,
                             const float *residual, int relu, float *out, const int32_t *tile_rows, int ntiles,
-                            void *stream_) {
+                            void *stream_, const ConvGroups *cg) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(features && filters && nbr && out, "sparse_conv_fused: null argument");
   DF3D_CHECK_ARG(kvol > 0 && kvol <= DF3D_MAX_KVOL, "sparse_conv_fused: kernel volume %d unsupported", kvol);
@@ -959,8 +1003,26 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
   a.cin = cin;
   a.cout = cout;
   a.relu = relu;
-  const int trec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 0, stream);
+  a.ldi = cg ? cg->ld_in : cin;
+  a.ldo = cg ? cg->ld_out : cout;
+  a.gi = cg ? cg->group_in : 0;
+  a.go = cg ? cg->group_out : 0;
+  const int trec = timing_rec_begin(cin, cout * (cg ? cg->groups : 1), kvol, n_out, nbr, 0, stream);
   bool done = false;
+  if (cg) {                                          // column slices of wider rows, groups: the output-stationary MFMA kernel
+    switch (cout) {
+      case 16: done = dispatch_cin<16>(a, stream, cg->groups); break;
+      case 32: done = dispatch_cin<32>(a, stream, cg->groups); break;
+      case 64: done = dispatch_cin<64>(a, stream, cg->groups); break;
+      case 128: done = dispatch_cin<128>(a, stream, cg->groups); break;
+      case 256: done = dispatch_cin<256>(a, stream, cg->groups); break;
+      default: break;
+    }
+    DF3D_CHECK_ARG(done, "sparse_conv_grouped: shape %d -> %d not served", cin, cout);
+    timing_rec_end(trec, stream);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+  }
   {
     int r = dispatch_small(a, stream);             // C <= 16 input channels: vector-ALU kernel
     if (r < 0) return r;
@@ -978,6 +1040,7 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
     case 32: done = dispatch_cin<32>(a, stream); break;
     case 64: done = dispatch_cin<64>(a, stream); break;
     case 128: done = dispatch_cin<128>(a, stream); break;
+    case 256: done = a.cin >= 16 && dispatch_cin<256>(a, stream); break;
     default: break;
   }
   if (!done) {

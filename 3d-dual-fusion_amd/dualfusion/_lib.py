@@ -47,6 +47,8 @@ SIGNATURES = {
     "df3d_pairs_to_nbr": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_sparse_conv_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "df3d_sparse_conv_grouped": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "df3d_conv_tile_count": (c_int, [c_int, c_int, c_int, c_int]),
     "df3d_conv_tiles_workspace_bytes": (c_size_t, [c_int]),
     "df3d_conv_tiles": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -145,6 +147,9 @@ SIGNATURES = {
     "df3d_furthest_point_sample_with_dist": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_group_points_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_gather_points_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_rows_linear_packed_bytes": (c_size_t, [c_int, c_int]),
+    "df3d_rows_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                                 c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "df3d_boxes_overlap_bev_xyxyr": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "df3d_tf_match_cost": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -303,11 +303,25 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         elif isinstance(value, tuple):
             value, pixel_scale, image_bias = value
         ref_xy = reference_points[:, :, 0, :].contiguous()
-        A, Bw = _ops.actr_prep(q_feat, q_i_feat, q_pos)
-        out = _ops.ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, sa.sampling_offsets(A),
-                                        sa.attention_weights(Bw), sa.n_levels, sa.n_points, pixel_scale, image_bias)
-        att = sa.output_proj(out)
-        qi = _ops.add_layernorm(q_i_feat, att, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        C = q_feat.shape[-1]
+        n_off, n_w = sa.sampling_offsets.out_features, sa.attention_weights.out_features
+        if (_ops.CONV_PRECISION != "fp32" and n_off % 16 == 0 and _ops.rows_linear_supported(C, n_off + n_w)
+                and _ops.rows_linear_supported(C, C) and sa.output_proj.out_features == C and C % 16 == 0):
+            # the two query mixtures are formed on load and both linears run as one launch on the matrix cores; the
+            # output projection carries its residual + LayerNorm (csrc/rowlinear.hip): 2 launches instead of 5
+            pk = _ops.rows_linear_pack([sa.sampling_offsets.weight, sa.attention_weights.weight],
+                                       [sa.sampling_offsets.bias, sa.attention_weights.bias])
+            offsets, logits = _ops.rows_linear(q_feat, pk, x1=q_i_feat, x2=q_pos, csplit=n_off, n0=n_off, n1=n_w)
+            out = _ops.ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, offsets, logits, sa.n_levels,
+                                            sa.n_points, pixel_scale, image_bias)
+            qi = _ops.rows_linear(out.contiguous(), _ops.rows_linear_pack(sa.output_proj.weight, sa.output_proj.bias),
+                                  ln=(q_i_feat, self.norm1))
+        else:
+            A, Bw = _ops.actr_prep(q_feat, q_i_feat, q_pos)
+            out = _ops.ms_deform_attn_fused(value, spatial_shapes, level_start_index, ref_xy, sa.sampling_offsets(A),
+                                            sa.attention_weights(Bw), sa.n_levels, sa.n_points, pixel_scale, image_bias)
+            att = sa.output_proj(out)
+            qi = _ops.add_layernorm(q_i_feat, att, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         g = self.fusion_layer
         if self.gate_before_ffn:
             q, qi = _ops.bigate_sum(q_feat, qi, g.b_conv1d.weight.view(-1), g.b_conv1d.bias, g.a_conv1d.weight.view(-1),
@@ -479,7 +493,12 @@ class ACTR(nn.Module):
     def project_image_queries(self, v_i_feat):
         """i_input_proj on [N, Q, Cimg]: the 1x1 Conv1d as a GEMM, GroupNorm over (group, Q)."""
         conv, gn = self.i_input_proj[0], self.i_input_proj[1]
-        y = F.linear(v_i_feat, conv.weight[:, :, 0], conv.bias)            # [N, Q, C]
+        from . import ops as _ops
+        if (v_i_feat.is_cuda and v_i_feat.dtype == torch.float32 and not torch.is_grad_enabled() and v_i_feat.shape[1] > 0
+                and _ops.CONV_PRECISION != "fp32" and _ops.rows_linear_supported(conv.in_channels, conv.out_channels)):
+            y = _ops.rows_linear(v_i_feat.contiguous(), _ops.rows_linear_pack(conv.weight, conv.bias))
+        else:
+            y = F.linear(v_i_feat, conv.weight[:, :, 0], conv.bias)        # [N, Q, C]
         if y.is_cuda and y.dtype == torch.float32 and not torch.is_grad_enabled() \
                 and (gn.num_channels // gn.num_groups) % 4 == 0 and y.shape[1] > 0:
             from . import ops as _ops

@@ -199,8 +199,10 @@ class CenterHead(nn.Module):
                 and _ops.CONV_PRECISION == "split" and self._row_kernels_fit(x) and self._train_rows_fit()):
             return self.forward_rows_train(x)
         if (self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32
-                or _ops.CONV_PRECISION == "fp32" or not self._row_kernels_fit(x)):
+                or not self._row_kernels_fit(x)):
             return self.forward_reference(x)
+        if _ops.CONV_PRECISION == "fp32":
+            return self.forward_rows_fp32(x)
         # the head's own convolutions stay split precision (fp32-grade) in the bf16 mode of the backbone / neck
         return self.forward_rows(x)
 
@@ -286,6 +288,61 @@ class CenterHead(nn.Module):
                     fin_b4=torch.stack(fin_b4).contiguous() if len(fin_b4) == len(cols) else None)
         self.__dict__["_row_plan"] = plan
         return plan
+
+    @torch.no_grad()
+    def forward_rows_fp32(self, x):
+        """The exact-fp32 mode (DF3D_CONV_PRECISION=fp32) on the native kernels: the three conv depths of the head as three
+        launches of the fp32 MFMA kernel (`v_mfma_f32_16x16x4_f32`, csrc/spconv.hip) over the dense 3 x 3 neighbour table:
+        shared conv 512 -> 64; the first convs of all branches as ONE grouped launch (every group reads the same 64 shared
+        channels; 64 -> 128 per group = two branches) into a [pixels, 64 * branches] buffer; the final convs as ONE grouped
+        launch, each group reading its branch's 64 columns of that buffer in place (64 -> classes padded to 16)."""
+        from .necks import _rows_of
+        key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        plan = self.__dict__.get("_row_plan_fp32")
+        if plan is None or plan["key"] != key:
+            sc, sbn = self.shared_conv[0], self.shared_conv[1]
+            dev = sc.weight.device
+            s_scale, s_shift = self._fold(sbn)
+            branches = [(t, head, getattr(task, head)) for t, task in enumerate(self.tasks) for head in task.heads]
+            nb = len(branches)
+            per = int(os.environ.get("DF3D_HEAD_FP32_PAIR", "2"))          # branches per group of the first convs
+            if nb % per:
+                per = 1
+            folds = [self._fold(fc[1]) for _, _, fc in branches]
+            mid_w = torch.stack([torch.cat([self._filters(fc[0]) for _, _, fc in branches[i:i + per]], 2)
+                                 for i in range(0, nb, per)]).contiguous()                     # [nb / per, 9, 64, 64 * per]
+            mid_bias = torch.cat([fc[0].bias.detach().float() if fc[0].bias is not None else torch.zeros(64, device=dev)
+                                  for _, _, fc in branches]).contiguous()
+            kp = 16 if max(fc[3].out_channels for _, _, fc in branches) <= 16 else 32
+            fin_w = torch.stack([self._filters(fc[3], kp) for _, _, fc in branches]).contiguous()  # [nb, 9, 64, kp]
+            fin_b = torch.cat([torch.cat([fc[3].bias.detach().float() if fc[3].bias is not None
+                                          else torch.zeros(fc[3].out_channels, device=dev),
+                                          torch.zeros(kp - fc[3].out_channels, device=dev)]) for _, _, fc in branches]).contiguous()
+            plan = dict(key=key, shared=self._filters(sc), s_bias=sc.bias.detach().float().contiguous() if sc.bias is not None else None,
+                        s_scale=s_scale.contiguous(), s_shift=s_shift.contiguous(), branches=branches, kp=kp,
+                        mid_w=mid_w, mid_bias=mid_bias, mid_scale=torch.cat([f[0] for f in folds]).contiguous(),
+                        mid_shift=torch.cat([f[1] for f in folds]).contiguous(), fin_w=fin_w, fin_b=fin_b, nbr={})
+            self.__dict__["_row_plan_fp32"] = plan
+        B, _, H, W = x.shape
+        rows, _ = _rows_of(x)
+        if (B, H, W) not in plan["nbr"]:
+            plan["nbr"][(B, H, W)] = _ops.conv2d_neighbors(B, H, W, 3, 3, 1, 1, False, x.device)[0]
+        nbr = plan["nbr"][(B, H, W)]
+        n = B * H * W
+        s1 = _ops.sparse_conv_fused(rows.contiguous(), plan["shared"], nbr, n, bias=plan["s_bias"], scale=plan["s_scale"],
+                                    shift=plan["s_shift"], relu=True)
+        mid = _ops.sparse_conv_grouped(s1, plan["mid_w"], nbr, n, bias=plan["mid_bias"], scale=plan["mid_scale"],
+                                       shift=plan["mid_shift"], relu=True, group_in=0)
+        out = _ops.sparse_conv_grouped(mid, plan["fin_w"], nbr, n, bias=plan["fin_b"], group_in=64)
+        rets = [dict() for _ in self.tasks]
+        kp = plan["kp"]
+        for i, (t, head, fc) in enumerate(plan["branches"]):
+            k = fc[3].out_channels
+            r = out[:, i * kp:i * kp + k]
+            v = r.view(B, H, W, k).permute(0, 3, 1, 2)
+            v._df3d_rows = (r, None, v._version)
+            rets[t][head] = v
+        return rets
 
     @torch.no_grad()
     def forward_rows(self, x):

@@ -285,11 +285,53 @@ def conv_tiles(nbr, cin, cout):
     return tiles
 
 
+def sparse_conv_grouped(features, filters, nbr, n_out, bias=None, scale=None, shift=None, relu=False, group_in=0, out=None,
+                        out_col=0):
+    """`groups` convolutions over one neighbour table in one launch of the exact-fp32 MFMA kernel
+    (df3d_sparse_conv_grouped).  features: [n_in, >= cin] rows, possibly a column slice of wider rows (stride(1) == 1);
+    filters [G, K, cin, cout]; group g reads columns g * group_in .. + cin (group_in = 0: all groups read the same columns)
+    and writes columns out_col + g * cout .. of `out` ([n_out, >= out_col + G * cout] rows, allocated when None).
+    bias / scale / shift: [G * cout].  -> out"""
+    lib = _lib.load()
+    if features.dtype != torch.float32 or not features.is_cuda or features.dim() != 2 or features.stride(1) != 1:
+        raise _lib.Df3dError("sparse_conv_grouped: features must be float32 device rows with unit column stride")
+    _chk(filters, torch.float32, "filters")
+    _chk(nbr, torch.int32, "nbr")
+    G, K, cin, cout = filters.shape
+    if nbr.shape != (K, n_out):
+        raise _lib.Df3dError("sparse_conv_grouped: neighbour table %s, expected (%d, %d)" % (tuple(nbr.shape), K, n_out))
+    if (G - 1) * group_in + cin > features.shape[1]:
+        raise _lib.Df3dError("sparse_conv_grouped: %d groups x %d columns (+%d) do not fit rows of %d columns"
+                             % (G, group_in, cin, features.shape[1]))
+    for t, nm in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+            if t.numel() != G * cout:
+                raise _lib.Df3dError("sparse_conv_grouped: %s has %d entries, expected %d" % (nm, t.numel(), G * cout))
+    if (scale is None) != (shift is None):
+        raise _lib.Df3dError("sparse_conv_grouped: scale and shift come together")
+    if out is None:
+        out = torch.empty((n_out, out_col + G * cout), dtype=torch.float32, device=features.device)
+    elif (out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1 or out.shape[0] != n_out
+          or out_col + G * cout > out.shape[1]):
+        raise _lib.Df3dError("sparse_conv_grouped: out must be float32 [n_out, >= %d] rows" % (out_col + G * cout))
+    dst = out[:, out_col:] if out_col else out
+    rc = lib.df3d_sparse_conv_grouped(_ptr(features), features.shape[0], cin, int(features.stride(0)), int(group_in), _ptr(filters),
+                                      K, cout, G, _ptr(nbr), n_out, _ptr(bias), _ptr(scale), _ptr(shift), int(bool(relu)),
+                                      _ptr(dst), int(out.stride(0)), cout, _stream())
+    _lib.check(rc, "df3d_sparse_conv_grouped")
+    return out
+
+
 def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shift=None, residual=None, relu=False,
                       tiles=None):
     """out[o] = act((sum_k features[nbr[k,o]] @ filters[k] + bias) * scale + shift + residual).
     `tiles`: optional pair-balanced row ranges from conv_tiles()."""
     lib = _lib.load()
+    if features.dim() == 2 and features.is_cuda and features.stride(1) == 1 and features.stride(0) != features.shape[1]:
+        if residual is not None:
+            raise _lib.Df3dError("sparse_conv_fused: a column slice of wider rows takes no residual")
+        return sparse_conv_grouped(features, filters.reshape((1,) + tuple(filters.shape[-3:])), nbr, n_out, bias, scale, shift, relu)
     _chk(features, torch.float32, "features")
     _chk(filters, torch.float32, "filters")
     _chk(nbr, torch.int32, "nbr")
@@ -805,6 +847,77 @@ class CenterHeadLossFunction(torch.autograd.Function):
         return grad * scale, None, None, None, None, None, None, None
 
 
+
+
+# ------------------------------------------------------------------------- query-side dense layers (csrc/rowlinear.hip)
+_ROWLIN_CACHE = {}
+
+
+def rows_linear_supported(cin, cout):
+    """DF3D_ROWS_LINEAR=0 keeps the library GEMMs (A/B switch, read per call)."""
+    if os.environ.get("DF3D_ROWS_LINEAR", "1") == "0":
+        return False
+    return _lib.load().df3d_rows_linear_packed_bytes(int(cin), int(cout)) > 0
+
+
+def rows_linear_pack(weights, biases=None):
+    """weights: one nn.Linear weight [cout, cin] or a list of them (concatenated along the outputs) -> (packed uint8,
+    bias fp32 [16 * tiles] or None, cout).  Cached per (storage, version) of the parameters."""
+    ws = list(weights) if isinstance(weights, (list, tuple)) else [weights]
+    bs = list(biases) if isinstance(biases, (list, tuple)) else ([biases] if biases is not None else [None] * len(ws))
+    key = tuple((w.data_ptr(), w._version) for w in ws) + tuple((b.data_ptr(), b._version) if b is not None else None for b in bs)
+    hit = _ROWLIN_CACHE.get(key)
+    if hit is not None:
+        return hit
+    W = torch.cat([w.detach().float().reshape(w.shape[0], -1) for w in ws], 0)
+    cout, cin = W.shape
+    if not rows_linear_supported(cin, cout):
+        raise _lib.Df3dError("rows_linear serves cin 128 | 256 and <= 128 outputs (got %d -> %d)" % (cin, cout))
+    CT, KB = (cout + 15) // 16, cin // 32
+    Wp = W.new_zeros((CT * 16, cin))
+    Wp[:cout] = W
+    hi = Wp.to(torch.bfloat16)
+    lo = (Wp - hi.float()).to(torch.bfloat16)
+    parts = [t.view(CT, 16, KB, 4, 8).permute(2, 0, 3, 1, 4) for t in (hi, lo)]           # [KB, CT, g, n, e]
+    packed = torch.stack(parts, 2).contiguous().view(torch.uint8).reshape(-1)              # [KB, CT, part, lane, 8] bf16
+    bias = None
+    if any(b is not None for b in bs):
+        bias = W.new_zeros(CT * 16)
+        bias[:cout] = torch.cat([b.detach().float() if b is not None else W.new_zeros(w.shape[0]) for w, b in zip(ws, bs)])
+    if len(_ROWLIN_CACHE) > 64:
+        _ROWLIN_CACHE.clear()
+    _ROWLIN_CACHE[key] = (packed, bias, cout)
+    return _ROWLIN_CACHE[key]
+
+
+def rows_linear(x0, pack, x1=None, x2=None, csplit=None, n0=None, n1=0, ln=None):
+    """df3d_rows_linear.  x0 (x1, x2) fp32 [..., cin]; pack = rows_linear_pack(...).  Output columns < csplit multiply
+    a0 = x0 (+ x2), the others a1 = a0 + (x1 + x2).  Returns out0 [..., n0] (and out1 [..., n1] when n1 > 0);
+    ln = (residual [..., n0], LayerNorm module): out0 = LayerNorm(residual + y)."""
+    lib = _lib.load()
+    packed, bias, cout = pack
+    cin = x0.shape[-1]
+    for t, nm in ((x0, "x0"), (x1, "x1"), (x2, "x2")):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+            if t.shape != x0.shape:
+                raise ValueError("rows_linear: operand shapes differ")
+    rows = x0.numel() // cin
+    n0 = cout if n0 is None else int(n0)
+    csplit = (-(-cout // 16) * 16) if csplit is None else int(csplit)
+    lead = tuple(x0.shape[:-1])
+    out0 = torch.empty(lead + (n0,), dtype=torch.float32, device=x0.device)
+    out1 = torch.empty(lead + (int(n1),), dtype=torch.float32, device=x0.device) if n1 else None
+    res = gamma = beta = None
+    eps = 0.0
+    if ln is not None:
+        res, norm = ln
+        _chk(res, torch.float32, "ln residual")
+        gamma, beta, eps = norm.weight, norm.bias, float(norm.eps)
+    rc = lib.df3d_rows_linear(_ptr(x0), _ptr(x1), _ptr(x2), rows, int(cin), _ptr(packed), int(cout), csplit, _ptr(bias),
+                              _ptr(out0), n0, n0, _ptr(out1), int(n1), int(n1), _ptr(res), _ptr(gamma), _ptr(beta), eps, _stream())
+    _lib.check(rc, "df3d_rows_linear")
+    return (out0, out1) if n1 else out0
 
 # ------------------------------------------------------------------------- TransFusion head: matching costs + losses
 class _TfMatchCfg(ctypes.Structure):

@@ -312,6 +312,76 @@ def roofline_from_timer(timer, meta_timer, want=None):
     return roof, per_kernel
 
 
+
+# ------------------------------------------------------------------------------------------------ per-kernel rooflines
+def api_probe(wl, stage):
+    """One untimed step with HIP events around every C-ABI call (dualfusion/apitimer.py), on the per-module path
+    (DF3D_EXECUTOR=0: the same kernels as the native executor launches, but the rulebook entries are visible one by one)."""
+    from dualfusion.apitimer import ApiTimer, summarize
+    old = os.environ.get("DF3D_EXECUTOR")
+    os.environ["DF3D_EXECUTOR"] = "0"
+    try:
+        wl.step(0, stage)                                     # the module path's own caches
+        torch.cuda.synchronize()
+        t = ApiTimer().start()
+        try:
+            wl.step(0, stage)
+        finally:
+            recs = t.stop()
+    finally:
+        if old is None:
+            os.environ.pop("DF3D_EXECUTOR", None)
+        else:
+            os.environ["DF3D_EXECUTOR"] = old
+    return summarize(recs)
+
+
+def roofline_by_kernel(probe, meta_timer, api, min_us=30.0):
+    """Every kernel (class) of one step that takes >= `min_us`, with its own roofline: SURVEY.md section 8(d) algorithmic bytes
+    (or flops) / measured time against the roof that bounds it.  Convolutions: HIP events inside the library (probe step of
+    the timed configuration) by (cin, cout, K); everything else: HIP events around the C-ABI entry point (api_probe)."""
+    out = []
+    keys = sorted({(r["cin"], r["cout"], r["kvol"], r["split"]) for r in probe.records})
+    first_rows = None
+    for k in keys:
+        ro, _ = roofline_from_timer(probe, meta_timer, want=k)
+        if ro is None:
+            continue
+        us = ro["avg_launch_us"] * ro["launches"]
+        if k[0] <= 5 and k[2] == 27:
+            first_rows = [r["n_out"] for r in probe.records if (r["cin"], r["kvol"]) == (k[0], 27)][0]
+        if us < min_us:
+            continue
+        out.append({"kernel": "conv %d->%d K=%d" % k[:3], "us_per_step": round(us, 1), "launches": ro["launches"],
+                    "bound": ro["bound"], "achieved": ro["achieved"], "peak": ro["peak"], "unit": ro["unit"], "frac": ro["frac"],
+                    "what": "%s; %s" % (ro["kernel"], ro["precision"])})
+    # rulebook bytes: 16 N_in + 8 R + 16 N_out per distinct table of the step (pairs from the metadata pass)
+    tables = {(r["kvol"], r["n_out"]): r["pairs"] for r in meta_timer.records if r["kvol"] == 27}
+    rb_bytes = sum(32 * n + 8 * R for (_, n), R in tables.items())
+    for name, e in api.items():
+        us = e["ms"] * 1e3
+        by, fl, bound = e["bytes"], e["flops"], e["bound"]
+        if name == "rulebook":
+            by, fl = rb_bytes, 0
+        if name.startswith("df3d_hard_voxelize") and first_rows:
+            by += 36 * first_rows
+        if us < min_us:
+            continue
+        ent = {"kernel": name, "us_per_step": round(us, 1), "launches": e["calls"], "what": e["what"]}
+        if bound is not None and not e["unknown"] and us > 0:
+            peak_tf = PEAK_BF16_MFMA_TF / 3.0
+            if bound == "mfma" or (fl and by and fl / by >= peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)):
+                ach = fl / (us * 1e-6) / 1e12
+                ent.update({"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
+                            "frac": round(ach / peak_tf, 4)})
+            else:
+                ach = by / (us * 1e-6) / 1e9
+                ent.update({"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(ach / PEAK_HBM_GBS, 4)})
+        out.append(ent)
+    out.sort(key=lambda d: -d["us_per_step"])
+    return out
+
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_model_string():
     try:
@@ -576,6 +646,12 @@ def main():
             wl.step(k, stage)
         torch.cuda.synchronize()
         meta_timer.stop()
+    api = None
+    if kernel_timing and rank == 0 and stage in ("detect", "hot_path"):
+        try:
+            api = api_probe(wl, stage)
+        except Exception as e:                                   # noqa: BLE001  (a measurement aid must not fail the bench line)
+            print("bench.py: api probe failed: %r" % (e,), file=sys.stderr)
     if rank == 0:
         units = args.steps * wl.batch * world
         per_step = lambda e: round(e / args.steps * 1e3, 4)      # noqa: E731
@@ -618,8 +694,8 @@ def main():
                                "what": getattr(wl, "hot_path_what", "the same K steps ending at the dense BEV tensor "
                                        "[B,256,180,180] (no neck / head / losses / reduce): round 1's step")}
         if "fp32_detect" in extra or "fp32_hot_path" in extra:
-            res["fp32"] = {"what": "every sparse conv on the exact-fp32 MFMA kernels (--conv-precision fp32; neck / head "
-                                   "through torch / MIOpen fp32)"}
+            res["fp32"] = {"what": "every convolution (sparse backbone, BEV neck, detection head) on the exact-fp32 MFMA "
+                                   "kernels (--conv-precision fp32)"}
             if "fp32_detect" in extra:
                 res["fp32"]["ms_per_step"] = per_step(extra["fp32_detect"])
                 res["ms_per_step_fp32"] = per_step(extra["fp32_detect"])
@@ -647,6 +723,13 @@ def main():
                 if r["kvol"] == 27:
                     rows_of.setdefault("%dx%d_k27" % (r["cin"], r["cout"]), set()).add(r["n_out"])
             res["conv_rows_by_kernel"] = {k: sorted(v) for k, v in rows_of.items()}   # identifies the launches in a rocprofv3 trace
+            if api is not None:
+                res["roofline_by_kernel"] = roofline_by_kernel(probe, meta_timer, api)
+                res["roofline_by_kernel_note"] = (
+                    "every kernel class of ONE step that takes >= 30 us: us_per_step = HIP-event time (convolutions: events "
+                    "inside libdf3d_hip.so around each launch, untimed probe step of the timed configuration; others: events "
+                    "around the C-ABI entry on its stream, one untimed step on the per-module path), achieved = SURVEY 8(d) "
+                    "algorithmic bytes or flops / that time; mfma peak = dense bf16 / 3 (split precision spends three products)")
         if world == 1 and not args.no_cpu_baseline and args.workload in ("cp_fusion", "cp_lidar"):
             res["cpu_baseline"] = cpu_baseline(wl, args.cpu_sweeps)
         print(json.dumps(res))

@@ -184,6 +184,16 @@ int df3d_timing_get2(int i, int *shape4, float *ms, long long *pairs, int *split
 
 /* SparseConvTensor.dense() (TF/mmdet3d/ops/spconv/structure.py:5-18,55-64): zero-fill +
  * scatter + permute fused; out [B, C, D, H, W] f32 (the backbones view it as [B, C*D, H, W]). */
+/* `groups` convolutions over ONE neighbour table in one launch of the exact-fp32 MFMA kernel, operands read and written
+ * in place as COLUMN SLICES of wider rows: group g convolves features[:, g * group_in : g * group_in + cin] (row stride
+ * ld_in floats) with filters[g] ([groups, kvol, cin, cout]) and bias / scale / shift[g * cout : (g + 1) * cout] into
+ * out[:, g * group_out : g * group_out + cout] (row stride ld_out floats).  group_in = 0: every group reads the same
+ * columns.  This is the detection heads' exact-fp32 mode (CP/det3d/models/bbox_heads/center_head.py:66-110: the first
+ * convs of all branches read the 64 shared channels, each final conv reads its branch's 64 channels); epilogue as
+ * df3d_sparse_conv_fused without the residual.  cin in {16 .. 512} (power of two), cout in {16, 32, 64, 128, 256}. */
+int df3d_sparse_conv_grouped(const float *features, int n_in, int cin, int ld_in, int group_in, const float *filters, int kvol,
+                             int cout, int groups, const int32_t *nbr, int n_out, const float *bias, const float *scale,
+                             const float *shift, int relu, float *out, int ld_out, int group_out, void *stream);
 int df3d_sparse_to_dense(const float *features, const int32_t *indices, int n, int channels,
                          int batch, const int *shape_host, float *out, void *stream);
 
@@ -840,6 +850,24 @@ int df3d_tf_query_loss(const float *rows, const int32_t *assigned, const float *
                        int proposals, int ld, int col_cls, int num_classes, int code_size, const float *gt,
                        const int32_t *gt_labels, const int32_t *gt_off, int gt_dim, int gmax, const df3d_tf_loss_cfg *cfg,
                        float *grad, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Query-side dense layers of the dual-query fusion encoder layer on the matrix cores (round 3, csrc/rowlinear.hip):
+ * y = W x + b for fp32 rows [rows][cin] (cin 128 | 256) and cout <= 128 outputs, fp32-grade (operands split into bf16
+ * hi + lo on load, three MFMA products).  Replaces the library GEMMs behind `sampling_offsets` / `attention_weights`
+ * (CP/det3d/models/model_utils/ops/modules/ms_deform_attn.py:129-157 on the mixed queries of actr_transformer.py:399-411),
+ * `output_proj` + residual + `norm1` (ms_deform_attn.py:188, actr_transformer.py:412-414) and `i_input_proj`'s 1x1 Conv1d
+ * (actr.py:96-104).
+ *   operands: a0 = x0 (+ x2), a1 = a0 + (x1 + x2) (x1, x2 may be NULL); output columns < csplit_cols (a multiple of 16)
+ *   use a0, the others a1.  Columns [0, n0) go to out0 (row stride ld0), [n0, n0 + n1) to out1 (row stride ld1).
+ *   ln_res != NULL: out0 = LayerNorm(ln_res + y) over the n0 == 16 * ceil(cout / 16) columns (ln_res contiguous [rows][n0]).
+ *   packed: df3d_rows_linear_packed_bytes(cin, cout) bytes = [cin/32][ceil(cout/16)][hi|lo][lane 64][8 x bf16], lane (n, g) =
+ *   column tile*16 + n, channels block*32 + g*8 .. +7 (W[cout][cin] row-major as nn.Linear keeps it; padding columns zero);
+ *   dualfusion.ops.rows_linear_pack builds it.  0 bytes = shape not served. */
+size_t df3d_rows_linear_packed_bytes(int cin, int cout);
+int df3d_rows_linear(const float *x0, const float *x1, const float *x2, long long rows, int cin, const void *packed, int cout,
+                     int csplit_cols, const float *bias, float *out0, int ld0, int n0, float *out1, int ld1, int n1,
+                     const float *ln_res, const float *ln_gamma, const float *ln_beta, float eps, void *stream);
 
 #ifdef __cplusplus
 }

@@ -185,6 +185,32 @@ def test_forward_rows_vs_torch_cpu_and_end_to_end():
         assert same.mean() > 0.9
 
 
+def test_forward_rows_fp32_mode_vs_torch_cpu():
+    """DF3D_CONV_PRECISION=fp32: the head's three conv depths on the exact-fp32 MFMA kernel (shared conv, first convs of
+    two branches per launch, final convs on the column slices in place) against the torch fp32 CPU composition."""
+    from dualfusion import ops
+    head = _head()
+    x = torch.from_numpy(detgen.randn("head_fw_x", (2, 512, 20, 24)))
+    old = ops.CONV_PRECISION
+    try:
+        ops.CONV_PRECISION = "fp32"
+        with torch.no_grad():
+            ref = head.forward_reference(x)
+            hd = head.to(DEV)
+            got = hd(x.to(DEV))
+            again = hd.forward_rows_fp32(x.to(DEV))
+    finally:
+        ops.CONV_PRECISION = old
+    for t in range(6):
+        assert set(got[t]) == set(ref[t])
+        for k in ref[t]:
+            assert tuple(got[t][k].shape) == tuple(ref[t][k].shape)
+            err = float((got[t][k].cpu() - ref[t][k]).abs().max() / ref[t][k].abs().max())
+            assert err < 1e-4, (t, k, err)
+            assert torch.equal(got[t][k], again[t][k])
+    assert getattr(got[0]["hm"], "_df3d_rows", None) is not None
+
+
 def test_loss_on_device_equals_cpu():
     """CenterHead forward (training path: autograd through the torch modules) + loss + backward on the MI355X against the
     same computation on the CPU (which tests/test_oracle_golden.py pins to the reference's own loss)."""

@@ -1143,3 +1143,98 @@ def test_split_row_outputs_of_layernorm_and_group_attention(dev):
     qkv = torch.randn((32 * 41, 192), generator=gen).to(dev)
     o = ops.group_attention(qkv, 32, 41, 4)
     assert torch.equal(ops.group_attention(qkv, 32, 41, 4, split_only=True), ops.split_rows(o))
+
+
+@pytest.mark.parametrize("cin,couts,rows", [(128, (64, 32), 18611), (128, (128,), 777), (256, (128,), 4097), (128, (32,), 33), (128, (16, 16), 1)])
+def test_rows_linear_vs_float64(dev, cin, couts, rows):
+    """df3d_rows_linear (csrc/rowlinear.hip): mixed operands formed on load, two output tensors, the LayerNorm epilogue --
+    against float64 (fp32-grade: <= 2e-5 of the output scale)."""
+    from dualfusion import ops
+    gen = torch.Generator().manual_seed(rows)
+    lins = [torch.nn.Linear(cin, c) for c in couts]
+    for l in lins:
+        l.weight.data = torch.randn(l.weight.shape, generator=gen) / np.sqrt(cin)
+        l.bias.data = torch.randn(l.bias.shape, generator=gen)
+        l.to(dev)
+    x0, x1, x2 = (torch.randn(3, rows // 3 + 1, cin, generator=gen).to(dev)[:, :max(rows // 3, 1)] .contiguous() for _ in range(3))
+    pk = ops.rows_linear_pack([l.weight for l in lins], [l.bias for l in lins])
+    W = torch.cat([l.weight for l in lins]).double().cpu()
+    b = torch.cat([l.bias for l in lins]).double().cpu()
+    a0 = (x0 + x2).double().cpu()
+    a1 = ((x0 + x2) + (x1 + x2)).double().cpu()
+
+    def close(got, want):
+        assert got.shape == want.shape
+        assert float((got.double().cpu() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-6)
+    if len(couts) == 2:
+        o0, o1 = ops.rows_linear(x0, pk, x1=x1, x2=x2, csplit=couts[0], n0=couts[0], n1=couts[1])
+        close(o0, a0 @ W[:couts[0]].t() + b[:couts[0]])
+        close(o1, a1 @ W[couts[0]:].t() + b[couts[0]:])
+    else:
+        close(ops.rows_linear(x0, pk), x0.double().cpu() @ W.t() + b)
+        close(ops.rows_linear(x0, pk, x2=x2), a0 @ W.t() + b)
+        if couts[0] == 128 and cin == 128:
+            norm = torch.nn.LayerNorm(128).to(dev)
+            norm.weight.data.uniform_(0.5, 1.5)
+            norm.bias.data.normal_()
+            res = torch.randn(x0.shape, generator=gen).to(dev)
+            got = ops.rows_linear(x0, pk, ln=(res, norm))
+            y = res.double().cpu() + x0.double().cpu() @ W.t() + b
+            want = torch.nn.functional.layer_norm(y, (128,), norm.weight.double().cpu(), norm.bias.double().cpu(), norm.eps)
+            close(got, want)
+    with pytest.raises(Exception):
+        ops.rows_linear_pack(torch.zeros(200, 128, device=dev))                 # > 128 outputs
+    with pytest.raises(Exception):
+        ops.rows_linear(x0.cpu(), pk)
+
+
+@pytest.mark.parametrize("cin,ld,c0,cout", [(64, 128, 64, 16), (64, 128, 0, 128), (32, 96, 32, 64), (256, 512, 256, 256),
+                                            (512, 512, 0, 256)])
+def test_sparse_conv_fused_on_column_slices(dev, cin, ld, c0, cout):
+    """df3d_sparse_conv_fused_ld: the exact-fp32 MFMA kernel reading a column slice of wider rows in place == the same
+    convolution of a contiguous copy of the slice (bit-exact: same kernel, same order) and the float64 gather-GEMM."""
+    from dualfusion import ops
+    DEV = dev
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    n, K = 3000, 9
+    wide = torch.randn(n, ld, generator=g).to(DEV)
+    w = (torch.randn(K, cin, cout, generator=g) * 0.1).to(DEV)
+    nbr = torch.randint(-1, n, (K, n), generator=g, dtype=torch.int32).to(DEV)
+    bias = torch.randn(cout, generator=g).to(DEV)
+    x = wide[:, c0:c0 + cin]
+    got = ops.sparse_conv_fused(x, w, nbr, n, bias=bias, relu=True)
+    if ld != cin:
+        want = ops.sparse_conv_fused(x.contiguous(), w, nbr, n, bias=bias, relu=True)
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    xd, wd = x.double().cpu(), w.double().cpu()
+    ref = torch.zeros(n, cout, dtype=torch.float64)
+    nb = nbr.cpu().long()
+    for k in range(K):
+        m = nb[k] >= 0
+        ref[m] += xd[nb[k][m]] @ wd[k]
+    ref = torch.relu(ref + bias.double().cpu())
+    assert (got.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("G,cin,gin,cout", [(6, 64, 64, 16), (3, 64, 0, 128), (4, 32, 32, 32), (2, 128, 0, 256)])
+def test_sparse_conv_grouped_vs_per_group_launches(dev, G, cin, gin, cout):
+    """df3d_sparse_conv_grouped: G convolutions over one neighbour table in one launch (operands as column slices of wider
+    rows) == G launches of the same kernel on contiguous copies, bit for bit; out_col places the block inside wider rows."""
+    from dualfusion import ops
+    g = torch.Generator().manual_seed(G * 131 + cin)
+    n, K = 70000 if cout == 16 else 5000, 9
+    wide = torch.randn(n, max(cin, (G - 1) * gin + cin), generator=g).to(dev)
+    w = (torch.randn(G, K, cin, cout, generator=g) * 0.1).to(dev)
+    nbr = torch.randint(-1, n, (K, n), generator=g, dtype=torch.int32).to(dev)
+    bias, scale, shift = (torch.randn(G * cout, generator=g).to(dev) for _ in range(3))
+    out = torch.full((n, 8 + G * cout + 4), -7.0, device=dev)
+    got = ops.sparse_conv_grouped(wide, w, nbr, n, bias=bias, scale=scale, shift=shift, relu=True, group_in=gin, out=out, out_col=8)
+    assert got is out and bool((out[:, :8] == -7).all()) and bool((out[:, 8 + G * cout:] == -7).all())
+    for i in range(G):
+        x = wide[:, i * gin:i * gin + cin].contiguous()
+        sl = slice(i * cout, (i + 1) * cout)
+        want = ops.sparse_conv_grouped(x, w[i:i + 1].contiguous(), nbr, n, bias=bias[sl].contiguous(), scale=scale[sl].contiguous(),
+                                       shift=shift[sl].contiguous(), relu=True)
+        assert torch.equal(out[:, 8 + i * cout:8 + (i + 1) * cout], want), i
+    with pytest.raises(Exception):
+        ops.sparse_conv_grouped(wide[:, :cin], w, nbr, n, group_in=max(gin, 4))      # the groups' slices leave the rows
