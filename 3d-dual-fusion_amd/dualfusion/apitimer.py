@@ -17,6 +17,11 @@ CONV_ENTRIES = ("df3d_sparse_conv_fused", "df3d_sparse_conv_grouped", "df3d_spar
                 "df3d_conv_rows_split", "df3d_backbone_run")
 
 
+def _ops_stream():
+    from . import ops
+    return ops._stream()
+
+
 def _ival(a):
     if isinstance(a, bool):
         return int(a)
@@ -69,7 +74,9 @@ class ApiTimer(object):
         stream = args[-1] if args else None
         if isinstance(stream, int):
             stream = ctypes.c_void_p(stream)
-        if not isinstance(stream, ctypes.c_void_p):
+        # only calls whose last argument IS torch's current stream are bracketed (an entry point without a stream argument
+        # ends in some other pointer: recording an event "on" it would be a wild pointer dereference inside the runtime)
+        if not isinstance(stream, ctypes.c_void_p) or (stream.value or 0) != (_ops_stream().value or 0):
             return fn(*args)
         extra = None
         if name == "df3d_ffn_fused_jobs":                       # rows live in the job structs

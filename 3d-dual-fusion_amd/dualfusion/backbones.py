@@ -504,6 +504,9 @@ class VoxelBackBone8x(nn.Module):
     def _fuse1(self, x_conv1, batch_dict):
         return x_conv1
 
+    def _prefetch_fuse4(self, coords, batch_dict, ready):
+        return None
+
     def _fuse4(self, x_conv2, x_conv3, x_conv4, batch_dict):
         return x_conv4
 
@@ -513,6 +516,10 @@ class VoxelBackBone8x(nn.Module):
         x0 = spconv.SparseConvTensor(voxel_features, voxel_coords.int(), self.sparse_shape, batch_size)
         runner = self._runner() if voxel_features.is_cuda and voxel_features.shape[0] > 0 else None
         if runner is not None:
+            # (measured: starting the side stream's work here, before the first segment is queued, beats starting it after
+            # conv1 -- 19.1 vs 19.6 ms per step: furthest point sampling is the longest chain of the step, every
+            # microsecond it starts earlier counts; without it 20.6 ms)
+            self._prefetch_fuse4(x0.indices, batch_dict, torch.cuda.current_stream().record_event())
             keep = {}
 
             def hook(i, name, t):
@@ -586,9 +593,8 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         return M.astype(np.float32)
 
     # ------------------------------------------------------------------ geometry (device-side)
-    def _project(self, x, voxel_stride, batch_dict):
-        """voxel corner (z,y,x) -> LiDAR xyz -> image pixel (float) through lidar2img [B,3,4]."""
-        ind = x.indices
+    def _voxel_xyz(self, ind, voxel_stride, batch_dict):
+        """voxel corner (b,z,y,x) -> LiDAR xyz of the point cloud the camera saw."""
         v3d = ind[:, 1:].float() * voxel_stride * self.voxel_size + self.point_cloud_range[:3]      # (z,y,x)
         xyz = v3d[:, [2, 1, 0]]
         bi = ind[:, 0].long()
@@ -607,11 +613,73 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         if "flip_y" in batch_dict:
             sgn = 1.0 - 2.0 * torch.as_tensor(batch_dict["flip_y"], device=xyz.device)[bi].to(xyz.dtype)
             xyz = torch.stack([xyz[:, 0] * sgn, xyz[:, 1], xyz[:, 2]], 1)
+        return xyz, bi
+
+    @staticmethod
+    def _pixels(xyz, bi, batch_dict):
+        """LiDAR xyz -> image pixel (float) through lidar2img [B,3,4]."""
         P = batch_dict["lidar2img"].float()[bi]                                                      # [N,3,4]
         # broadcast multiply-adds: einsum lowers to a batched GEMM over N tiny 3x4 matrices (2.4 ms per call at 200k voxels)
         h = P[:, :, 0] * xyz[:, 0:1] + P[:, :, 1] * xyz[:, 1:2] + P[:, :, 2] * xyz[:, 2:3] + P[:, :, 3]
-        uv = h[:, :2] / h[:, 2:3]
-        return xyz, uv
+        return h[:, :2] / h[:, 2:3]
+
+    def _project(self, x, voxel_stride, batch_dict):
+        """voxel corner (z,y,x) -> LiDAR xyz -> image pixel (float) through lidar2img [B,3,4]."""
+        xyz, bi = self._voxel_xyz(x.indices, voxel_stride, batch_dict)
+        return xyz, self._pixels(xyz, bi, batch_dict)
+
+    @staticmethod
+    def _query_slots(ind, B):
+        """Rows (batch-sorted) -> (sample, slot inside the sample's padded query list, longest list).  One host read."""
+        b = ind[:, 0].long()
+        counts = torch.bincount(b, minlength=B)
+        n_max = int(counts.max().item())                      # host sync (the reference pads to max_num_nev then slices)
+        starts = torch.cumsum(counts, 0) - counts
+        slot = torch.arange(ind.shape[0], device=ind.device) - starts[b]       # rows are batch-sorted
+        return b, slot, n_max
+
+    # ------------------------------------------------------------------ stride-8 query geometry ahead of the convolutions
+    def _prefetch_fuse4(self, coords, batch_dict, ready):
+        """The coordinates of conv4's voxels follow from the input coordinates alone (three strided index sets), and so do
+        the ACTRv2 queries' LiDAR positions and everything the 3-D local self-attention derives from them: furthest point
+        sampling (2048 SERIAL iterations on one workgroup per sample: 4.7 ms on 8 of the 256 CUs), ball query, grouped
+        coordinates, the 'unique' winners.  They are computed HERE, on a side stream that waits for the input coordinates
+        only (`ready`), and run beside the backbone's convolutions; `_fuse4` waits for the event.  The reference computes them after conv4
+        and again in every encoder layer (VR actr_transformer.py:482-486)."""
+        previous = self.__dict__.pop("_fuse4_pre", None)
+        if (4 not in self.fusion_pos or "ACTR" not in self.fusion_method or torch.is_grad_enabled()
+                or os.environ.get("DF3D_VR_PREFETCH", "1") != "1" or not coords.is_cuda or coords.shape[0] == 0):
+            return
+        lts = getattr(getattr(self.actr.transformer, "encoder", None), "lidar_attns", None)
+        if lts is None or len(lts) == 0:
+            return
+        from .spconv.conv import SparseConvolution
+        from .spconv.ops import get_conv_output_size
+        side = self.__dict__.get("_geo_stream")
+        if side is None:
+            side = self.__dict__["_geo_stream"] = torch.cuda.Stream(device=coords.device)
+        side.wait_event(ready)
+        # the previous frame's tensors stay referenced until here: their readers on the main stream were queued before `ready`
+        B = batch_dict["batch_size"]
+        with torch.cuda.stream(side):
+            ind, shape = coords.int().contiguous(), list(self.sparse_shape)
+            for stage in (self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4):
+                for m in stage.modules():
+                    if isinstance(m, SparseConvolution) and not m.subm:
+                        out_shape = get_conv_output_size(shape, m.kernel_size, m.stride, m.padding, m.dilation)
+                        ind, _ = _ops.conv_out_indices(ind, B, shape, out_shape, m.kernel_size, m.stride, m.padding, m.dilation)
+                        shape = list(out_shape)
+            xyz, _ = self._voxel_xyz(ind, 8, batch_dict)
+            b, slot, n_max = self._query_slots(ind, B)
+            pts = xyz.new_zeros((B, n_max, 3))
+            pts[b, slot] = xyz
+            lt = lts[0]
+            lt._row_plan(pts, *lt._geometry(pts))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        del previous
+        self.__dict__["_fuse4_pre"] = dict(n=int(ind.shape[0]), shape=shape, xyz=xyz, b=b, slot=slot, n_max=n_max, pts=pts, event=ev)
+
 
     @staticmethod
     def _bilinear_taps(dst, in_size, out_size):
@@ -660,25 +728,29 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         img_dict = batch_dict["img_dict"]
         x_rgb = [v for k, v in img_dict.items() if k != "mvx_layer1_feat2d"]
         hw = tuple(batch_dict["images"].shape[2:]) if "images" in batch_dict else tuple(batch_dict["image_hw"])
-        xyz, uv = self._project(x_conv4, 8, batch_dict)
         ind = x_conv4.indices
-        b = ind[:, 0].long()
         B = batch_dict["batch_size"]
         feats = x_conv4.features
+        pre = self.__dict__.get("_fuse4_pre")
+        if pre is not None and pre["n"] == ind.shape[0] and list(pre["shape"]) == list(x_conv4.spatial_shape):
+            # positions, slots and the local-attention geometry were computed beside the convolutions (`_prefetch_fuse4`:
+            # the same strided index sets in the same flat-index order)
+            torch.cuda.current_stream().wait_event(pre["event"])
+            xyz, b, slot, n_max, pts = pre["xyz"], pre["b"], pre["slot"], pre["n_max"], pre["pts"]
+            uv = self._pixels(xyz, b, batch_dict)
+        else:
+            xyz, uv = self._project(x_conv4, 8, batch_dict)
+            b, slot, n_max = self._query_slots(ind, B)
+            pts = feats.new_zeros((B, n_max, 3))
+            pts[b, slot] = xyz
         i_feat = self._sample_int(x_rgb[0], b, uv, hw)
-        counts = torch.bincount(b, minlength=B)
-        n_max = int(counts.max().item())                      # host sync (the reference pads to max_num_nev then slices)
-        starts = torch.cumsum(counts, 0) - counts
-        slot = torch.arange(ind.shape[0], device=ind.device) - starts[b]       # rows are batch-sorted
         C = feats.shape[1]
         v_feat = feats.new_zeros((B, n_max, C))
         v_i = feats.new_zeros((B, n_max, i_feat.shape[1]))
         grid = feats.new_zeros((B, n_max, 2))
-        pts = feats.new_zeros((B, n_max, 3))
         v_feat[b, slot] = feats
         v_i[b, slot] = i_feat
         grid[b, slot] = uv / torch.tensor([hw[1], hw[0]], dtype=torch.float32, device=uv.device)
-        pts[b, slot] = xyz
         enh = self.actr(v_feat=v_feat, v_i_feat=v_i, grid=grid, i_feats=x_rgb, lidar_grid=pts)
         return x_conv4.replace_feature(enh[b, slot] + feats)                  # fuse_sum=True (:808-810)
 

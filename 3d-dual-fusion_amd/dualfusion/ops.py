@@ -1659,6 +1659,55 @@ def group_attention(qkv, tokens, groups, heads, split_only=False):
     return out
 
 
+def _lt_fragments(w):
+    """[out, in] fp32 weights -> MFMA fragments [out / 16, in / 32, 64 lanes, 8] in the token-layout contraction order of
+    csrc/ltlayer.hip: element j of lane (n, g) = W[16 ot + n][16 (2 s + (j >> 2)) + 4 g + (j & 3)]."""
+    out_c, in_c = w.shape
+    lane = torch.arange(64, device=w.device)
+    n, g = lane & 15, lane >> 4
+    j = torch.arange(8, device=w.device)
+    ot = torch.arange(out_c // 16, device=w.device)
+    s = torch.arange(in_c // 32, device=w.device)
+    rows = (ot[:, None, None, None] * 16 + n[None, None, :, None]).expand(out_c // 16, in_c // 32, 64, 8)
+    cols = (16 * (2 * s[None, :, None, None] + (j >> 2)[None, None, None, :]) + 4 * g[None, None, :, None]
+            + (j & 3)[None, None, None, :]).expand(out_c // 16, in_c // 32, 64, 8)
+    return w[rows, cols]
+
+
+def lt_layer_pack(in_proj_weight, in_proj_bias, out_w, out_b, w1, b1, w2, b2, g1, be1, g2, be2):
+    """-> (packed fragments uint8 [df3d_lt_layer_packed_bytes], vector fp32 [df3d_lt_layer_vector_floats]) of one
+    TransformerEncoderLayerPreNorm for df3d_lt_layer (layout: include/df3d_hip.h)."""
+    lib = _lib.load()
+    frags = torch.cat([_lt_fragments(w.detach().float()).reshape(-1, 64, 8) for w in (in_proj_weight, out_w, w1, w2)])
+    hi = frags.to(torch.bfloat16)
+    lo = (frags - hi.float()).to(torch.bfloat16)
+    packed = torch.stack([hi, lo], 1).contiguous().view(torch.uint8).reshape(-1)
+    if packed.numel() != int(lib.df3d_lt_layer_packed_bytes()):
+        raise _lib.Df3dError("lt_layer_pack: %d bytes, the kernel expects %d" % (packed.numel(), lib.df3d_lt_layer_packed_bytes()))
+    vec = torch.cat([t.detach().float().reshape(-1) for t in (in_proj_bias, out_b, b1, b2, g1, be1, g2, be2)]).contiguous()
+    if vec.numel() != int(lib.df3d_lt_layer_vector_floats()):
+        raise _lib.Df3dError("lt_layer_pack: %d vector entries, the kernel expects %d" % (vec.numel(), lib.df3d_lt_layer_vector_floats()))
+    return packed, vec
+
+
+def lt_layer(x, packed, vec, heads, ffn, eps1, eps2, group_major=False):
+    """One pre-norm encoder layer in one kernel (df3d_lt_layer) over [L = 32, G, 64] sequence-first rows, or
+    (group_major) over [G, L = 32, 64] rows -> same shape."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    _chk(packed, torch.uint8, "packed")
+    _chk(vec, torch.float32, "vec")
+    if group_major:
+        G, L, C = x.shape
+    else:
+        L, G, C = x.shape
+    out = torch.empty_like(x)
+    rc = lib.df3d_lt_layer(_ptr(x), int(L), int(G), int(C), int(heads), int(ffn), int(bool(group_major)), _ptr(packed), _ptr(vec),
+                           float(eps1), float(eps2), _ptr(out), _stream())
+    _lib.check(rc, "df3d_lt_layer")
+    return out
+
+
 _IDENTITY_TABLES = {}
 
 

@@ -11,6 +11,7 @@ layers are plain library GEMMs.  Parameter names follow the reference (`pe.0.con
 `pe.1.conv`, `chunk.layers.j.{self_attn,linear1,linear2,norm1,norm2}`), SURVEY.md Appendix B.
 """
 import copy
+import os
 
 import threading
 import weakref
@@ -72,6 +73,23 @@ class TransformerEncoderLayerPreNorm(nn.Module):
                 and src.shape[0] * a.num_heads <= 1024
                 and src.shape[0] <= 64)
 
+    def _fused_fit(self, src):
+        """The whole layer as ONE kernel (csrc/ltlayer.hip): groups of 32 tokens, 4 heads of 16, feed-forward 128."""
+        a = self.self_attn
+        return (src.shape[0] == 32 and a.num_heads == 4 and self.linear1.out_features == 128 and src.is_contiguous()
+                and self.linear1.bias is not None and self.linear2.bias is not None and a.out_proj.bias is not None
+                and os.environ.get("DF3D_LT_FUSED", "1") == "1")
+
+    def _forward_fused(self, src):
+        a = self.self_attn
+        ts = (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, self.linear1.weight, self.linear1.bias,
+              self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias)
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        hit = self.__dict__.get("_lt_packed")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_lt_packed"] = (key,) + tuple(_ops.lt_layer_pack(*ts))
+        return _ops.lt_layer(src, hit[1], hit[2], a.num_heads, self.linear1.out_features, self.norm1.eps, self.norm2.eps)
+
     def _forward_rows(self, src):
         """LN1 -> in-projection (three 64-column banks of one grouped launch of the split-precision conv kernel over an
         identity table) -> `group_attention` -> out-projection -> LN2(x + .) -> FFN + residual (the fused feed-forward kernel,
@@ -103,6 +121,8 @@ class TransformerEncoderLayerPreNorm(nn.Module):
     def forward(self, src, src_mask=None, src_key_padding_mask=None):
         if (src.is_cuda and src.dtype == torch.float32 and not self.training and not torch.is_grad_enabled()
                 and self._rows_fit(src, src_mask, src_key_padding_mask)):
+            if self._fused_fit(src):
+                return self._forward_fused(src)
             return self._forward_rows(src)
         if (src.is_cuda and src.dtype == torch.float32 and not self.training and not torch.is_grad_enabled()
                 and src.shape[-1] % 4 == 0):

@@ -572,7 +572,11 @@ def main():
         D.barrier(dev if use_gpu else None)
 
     def reduce_losses(losses):
-        return D.reduce_dict(losses)            # CP/det3d/torchie/trainer/utils.py:157-183: rank 0 holds the average
+        # CP/det3d/torchie/trainer/utils.py:157-183: rank 0 holds the average.  Only a dict of loss tensors is reduced: the
+        # Voxel-RCNN tree's step ends at the backbone and hands back its batch_dict (no detection head in the reference path)
+        if not all(hasattr(v, "reshape") for v in losses.values()):
+            return losses
+        return D.reduce_dict(losses)
 
     # Setup, before the W warm-up steps: every distinct frame once.  The timed steps rotate through the frames, and the
     # first visit of a frame sizes the caching allocator's blocks for ITS voxel counts and fills the address-keyed tables;

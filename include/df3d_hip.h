@@ -869,6 +869,24 @@ int df3d_rows_linear(const float *x0, const float *x1, const float *x2, long lon
                      int csplit_cols, const float *bias, float *out0, int ld0, int n0, float *out1, int ld1, int n1,
                      const float *ln_res, const float *ln_gamma, const float *ln_beta, float eps, void *stream);
 
+/* One pre-norm transformer encoder layer of the ACTRv2 LocalTransformer over groups of 32 tokens x 64 channels as ONE
+ * kernel (csrc/ltlayer.hip): x1 = norm1(x); x2 = x1 + out_proj(MHA(x1)); x3 = norm2(x2); out = x3 + linear2(relu(linear1(x3)))
+ * -- CP/det3d/models/model_utils/pointformer.py:10-44 (TransformerEncoderLayerPreNorm with nn.MultiheadAttention, 4 heads of
+ * 16), applied to [L, G, C] sequence-first rows (row = token * G + group) as pointformer.py:349-380 does, or -- group_major
+ * = 1 -- to [G, L, C] rows (a group's 32 tokens are one contiguous 8 KB block; in and out alike).  Replaces the chain
+ * LayerNorm / in-projection / attention / out-projection / add + LayerNorm / feed-forward of eight launches.
+ *   packed: df3d_lt_layer_packed_bytes() bytes = 64 fragment pairs [pair][hi | lo][lane 64][8 x bf16] of in_proj_weight
+ *           [192, 64] (pairs 0..23: out tile * 2 + k-step), out_proj.weight (24..31), linear1.weight [128, 64] (32..47),
+ *           linear2.weight [64, 128] (48..63: out tile * 4 + k-step); element j of lane (n, g) of the fragment (out tile ot,
+ *           k-step s) = W[16 ot + n][16 (2 s + (j >> 2)) + 4 g + (j & 3)]; dualfusion.ops.lt_layer_pack builds it.
+ *   vec:    df3d_lt_layer_vector_floats() floats = in_proj_bias 192 | out_proj.bias 64 | linear1.bias 128 | linear2.bias 64 |
+ *           norm1.weight | norm1.bias | norm2.weight | norm2.bias (64 each).
+ * Served: L = 32, C = 64, heads = 4, ffn = 128 (the ACTRv2 configuration); anything else is refused. */
+long long df3d_lt_layer_packed_bytes(void);
+int df3d_lt_layer_vector_floats(void);
+int df3d_lt_layer(const float *x, int L, int G, int C, int heads, int ffn, int group_major, const void *packed, const float *vec,
+                  float eps1, float eps2, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

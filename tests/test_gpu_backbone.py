@@ -597,3 +597,46 @@ def test_local_transformer_layer_on_row_kernels_vs_float64(L, G):
     want = torch.softmax(q @ k.transpose(-1, -2) / 4.0, -1) @ v                          # [G, H, L, 16]
     want = want.permute(2, 0, 1, 3).reshape(L * G, 64)
     assert float((o.double() - want).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("G", [1, 70, 2100, 5000])
+def test_local_transformer_layer_as_one_kernel_vs_float64_and_row_kernels(G):
+    """df3d_lt_layer (csrc/ltlayer.hip: a wave owns a group of 32 tokens from load to store, every product on the matrix
+    cores in one register layout) against the module's torch composition in float64 (pointformer.py:10-44) and against
+    the eight-launch row-kernel path; group counts below / above one pass of the persistent waves, input untouched."""
+    import copy
+    import os
+    from dualfusion import ops
+    from dualfusion.pointformer import TransformerEncoderLayerPreNorm
+    if ops.CONV_PRECISION != "split":
+        pytest.skip("row path of the layer runs on the split-precision kernels")
+    dev = torch.device("cuda:0")
+    m = TransformerEncoderLayerPreNorm(d_model=64, nhead=4, dim_feedforward=128, dropout=0.0).eval()
+    sd = detgen.det_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = torch.from_numpy(detgen.randn("ltf_x_%d" % G, (32, G, 64))) * 1.5 + 0.3
+    with torch.no_grad():
+        ref = copy.deepcopy(m).double()(x.double())
+        md = m.to(dev)
+        xd = x.to(dev)
+        keep = xd.clone()
+        assert md._fused_fit(xd)
+        y = md(xd)
+        assert torch.equal(xd, keep)
+        old = os.environ.get("DF3D_LT_FUSED")
+        os.environ["DF3D_LT_FUSED"] = "0"
+        try:
+            rows = md(xd)
+        finally:
+            if old is None:
+                del os.environ["DF3D_LT_FUSED"]
+            else:
+                os.environ["DF3D_LT_FUSED"] = old
+    scale = float(ref.abs().max())
+    assert float((y.cpu().double() - ref).abs().max()) < 3e-5 * scale
+    assert float((y - rows).abs().max()) < 5e-5 * scale
+    # a parameter update re-packs the fragments
+    with torch.no_grad():
+        md.linear2.bias.add_(1.0)
+        y2 = md(xd)
+    assert float((y2 - y - 1.0).abs().max()) < 1e-4 * scale
