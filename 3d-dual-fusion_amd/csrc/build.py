@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["common.hip", "voxelize.hip", "rulebook.hip", "spconv.hip", "spconv_split.hip", "dense.hip", "msda.hip", "pointops.hip",
            "fusion.hip", "actr.hip", "ffn.hip", "imgproj.hip", "executor.hip", "nms.hip", "dettail.hip", "topk.hip", "pool.hip", "tfhead.hip", "xattn.hip",
-           "spconv_bwd.hip", "loss.hip", "headconv.hip", "bnrows.hip", "tfloss.hip", "rowlinear.hip", "ltlayer.hip"]
+           "spconv_bwd.hip", "loss.hip", "headconv.hip", "bnrows.hip", "tfloss.hip", "rowlinear.hip", "ltlayer.hip", "mvx.hip"]
 OUT = os.path.join(HERE, "libdf3d_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]

@@ -150,6 +150,9 @@ SIGNATURES = {
     "df3d_rows_linear_packed_bytes": (c_size_t, [c_int, c_int]),
     "df3d_rows_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
                                  c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "df3d_voxel_image_sample": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "df3d_lt_layer_packed_bytes": (c_longlong, []),
     "df3d_lt_layer_vector_floats": (c_int, []),
     "df3d_lt_layer": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),

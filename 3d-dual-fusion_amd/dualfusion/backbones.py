@@ -712,12 +712,54 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         feat = (1 - ly) * top + ly * bot
         return torch.where(ok[:, None], feat, torch.zeros_like(feat))
 
+    # ------------------------------------------------------------------ the sampling as one kernel (csrc/mvx.hip)
+    def _geometry_floats(self):
+        hit = self.__dict__.get("_geo_floats")
+        if hit is None:                                  # one device read, at the first call
+            hit = self.__dict__["_geo_floats"] = (self.voxel_size.tolist(), self.point_cloud_range[:3].tolist())
+        return hit
+
+    @staticmethod
+    def _aug_params(batch_dict, B, dev):
+        """[B, 5] = global scale, cos(-rot), sin(-rot), flip_x sign, flip_y sign of every sample (identity where a key is
+        absent), computed with the same torch operations as `_voxel_xyz`; kept in the batch_dict for the second call."""
+        hit = batch_dict.get("_df3d_aug")
+        if hit is not None and hit.device == dev:
+            return hit
+        one = torch.ones(B, dtype=torch.float32, device=dev)
+        cols = [one, one, torch.zeros_like(one), one, one]
+        if "noise_scale" in batch_dict:
+            cols[0] = torch.as_tensor(batch_dict["noise_scale"], dtype=torch.float32, device=dev).reshape(B)
+        if "noise_rot" in batch_dict:
+            ang = -torch.as_tensor(batch_dict["noise_rot"], dtype=torch.float32, device=dev).reshape(B)
+            cols[1], cols[2] = torch.cos(ang), torch.sin(ang)
+        if "flip_x" in batch_dict:
+            cols[3] = 1.0 - 2.0 * torch.as_tensor(batch_dict["flip_x"], device=dev).to(torch.float32).reshape(B)
+        if "flip_y" in batch_dict:
+            cols[4] = 1.0 - 2.0 * torch.as_tensor(batch_dict["flip_y"], device=dev).to(torch.float32).reshape(B)
+        aug = torch.stack(cols, 1).contiguous()
+        batch_dict["_df3d_aug"] = aug
+        return aug
+
+    def _sample_native(self, x, batch_dict, fmap):
+        return (x.features.is_cuda and not torch.is_grad_enabled() and x.features.dtype == torch.float32
+                and fmap.dtype == torch.float32 and fmap.is_contiguous() and fmap.shape[1] % 4 == 0
+                and x.indices.dtype == torch.int32 and os.environ.get("DF3D_VR_SAMPLE", "1") == "1")
+
     def _fuse1(self, x_conv1, batch_dict):
         if 1 not in self.fusion_pos:
             return x_conv1
         img_dict = batch_dict["img_dict"]
         fmap = img_dict["mvx_layer1_feat2d"] if "mvx_layer1_feat2d" in img_dict else next(iter(img_dict.values()))
         hw = tuple(batch_dict["images"].shape[2:]) if "images" in batch_dict else tuple(batch_dict["image_hw"])
+        if self._sample_native(x_conv1, batch_dict, fmap) and x_conv1.features.shape[1] == fmap.shape[1]:
+            B = batch_dict["batch_size"]
+            vs, r0 = self._geometry_floats()
+            out, _ = _ops.voxel_image_sample(x_conv1.indices.contiguous(), B, 1.0, vs, r0,
+                                             self._aug_params(batch_dict, B, fmap.device),
+                                             batch_dict["lidar2img"].float().contiguous(), fmap, hw,
+                                             add=x_conv1.features.contiguous())
+            return x_conv1.replace_feature(out)                               # MVX, fuse_sum=True (:746-748)
         _, uv = self._project(x_conv1, 1, batch_dict)
         img_feat = self._sample_int(fmap, x_conv1.indices[:, 0].long(), uv, hw)
         return x_conv1.replace_feature(x_conv1.features + img_feat)           # MVX, fuse_sum=True (:746-748)
@@ -737,14 +779,29 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
             # the same strided index sets in the same flat-index order)
             torch.cuda.current_stream().wait_event(pre["event"])
             xyz, b, slot, n_max, pts = pre["xyz"], pre["b"], pre["slot"], pre["n_max"], pre["pts"]
-            uv = self._pixels(xyz, b, batch_dict)
+            uv = None
         else:
             xyz, uv = self._project(x_conv4, 8, batch_dict)
             b, slot, n_max = self._query_slots(ind, B)
             pts = feats.new_zeros((B, n_max, 3))
             pts[b, slot] = xyz
-        i_feat = self._sample_int(x_rgb[0], b, uv, hw)
         C = feats.shape[1]
+        if self._sample_native(x_conv4, batch_dict, x_rgb[0]):
+            # image features of the queries and their normalised pixels, written straight into the padded tensors
+            rows = b * n_max + slot
+            v_feat = feats.new_zeros((B, n_max, C))
+            v_i = feats.new_zeros((B, n_max, x_rgb[0].shape[1]))
+            grid = feats.new_zeros((B, n_max, 2))
+            vs, r0 = self._geometry_floats()
+            _ops.voxel_image_sample(ind.contiguous(), B, 8.0, vs, r0, self._aug_params(batch_dict, B, feats.device),
+                                    batch_dict["lidar2img"].float().contiguous(), x_rgb[0], hw, rows=rows,
+                                    out=v_i.view(B * n_max, -1), grid=grid.view(B * n_max, 2))
+            v_feat.view(B * n_max, C).index_copy_(0, rows, feats)
+            enh = self.actr(v_feat=v_feat, v_i_feat=v_i, grid=grid, i_feats=x_rgb, lidar_grid=pts)
+            return x_conv4.replace_feature(enh.reshape(B * n_max, -1).index_select(0, rows) + feats)   # fuse_sum=True (:808-810)
+        if uv is None:
+            uv = self._pixels(xyz, b, batch_dict)
+        i_feat = self._sample_int(x_rgb[0], b, uv, hw)
         v_feat = feats.new_zeros((B, n_max, C))
         v_i = feats.new_zeros((B, n_max, i_feat.shape[1]))
         grid = feats.new_zeros((B, n_max, 2))

@@ -1659,6 +1659,47 @@ def group_attention(qkv, tokens, groups, heads, split_only=False):
     return out
 
 
+def voxel_image_sample(indices, batch, voxel_stride, voxel_size_zyx, range_min_zyx, aug, lidar2img, fmap, hw, add=None,
+                       rows=None, out=None, want_uv=False, grid=None):
+    """Voxel -> camera pixel -> bilinearly upsampled image feature at the truncated pixel, one launch
+    (df3d_voxel_image_sample).  indices [n, 4] int32; voxel_size_zyx / range_min_zyx: python floats; aug [B, 5], lidar2img
+    [B, 3, 4], fmap [B, C, Hin, Win] on the device; hw = image size.  -> (out [n | rows, C], uv [n, 2] or None)."""
+    import numpy as np
+    lib = _lib.load()
+    _chk(indices, torch.int32, "indices")
+    _chk(aug, torch.float32, "aug")
+    _chk(lidar2img, torch.float32, "lidar2img")
+    _chk(fmap, torch.float32, "fmap")
+    n = indices.shape[0]
+    B, C, Hin, Win = fmap.shape
+    if aug.shape != (batch, 5) or lidar2img.numel() != batch * 12 or B != batch:
+        raise _lib.Df3dError("voxel_image_sample: per-sample tensors do not match the batch size %d" % batch)
+    if add is not None:
+        _chk(add, torch.float32, "add")
+        if add.shape != (n, C):
+            raise _lib.Df3dError("voxel_image_sample: add must be [n, C]")
+    if rows is not None:
+        _chk(rows, torch.int64, "rows")
+        if out is None:
+            raise _lib.Df3dError("voxel_image_sample: a row map needs a caller-provided output")
+    if out is None:
+        out = torch.empty((n, C), dtype=torch.float32, device=fmap.device)
+    else:
+        _chk(out, torch.float32, "out")
+    uv = torch.empty((n, 2), dtype=torch.float32, device=fmap.device) if want_uv else None
+    if grid is not None:
+        _chk(grid, torch.float32, "grid")
+    vs = (ctypes.c_float * 3)(*[float(v) for v in voxel_size_zyx])
+    r0 = (ctypes.c_float * 3)(*[float(v) for v in range_min_zyx])
+    h, w = int(hw[0]), int(hw[1])
+    sy = float(np.float32(Hin) / np.float32(h))
+    sx = float(np.float32(Win) / np.float32(w))
+    rc = lib.df3d_voxel_image_sample(_ptr(indices), n, int(batch), float(voxel_stride), vs, r0, _ptr(aug), _ptr(lidar2img), _ptr(fmap),
+                                     C, Hin, Win, h, w, sy, sx, _ptr(add), _ptr(rows), _ptr(out), _ptr(uv), _ptr(grid), _stream())
+    _lib.check(rc, "df3d_voxel_image_sample")
+    return out, uv
+
+
 def _lt_fragments(w):
     """[out, in] fp32 weights -> MFMA fragments [out / 16, in / 32, 64 lanes, 8] in the token-layout contraction order of
     csrc/ltlayer.hip: element j of lane (n, g) = W[16 ot + n][16 (2 s + (j >> 2)) + 4 g + (j & 3)]."""

@@ -887,6 +887,20 @@ int df3d_lt_layer_vector_floats(void);
 int df3d_lt_layer(const float *x, int L, int G, int C, int heads, int ffn, int group_major, const void *packed, const float *vec,
                   float eps1, float eps2, float *out, void *stream);
 
+/* Point fusion of the Voxel-RCNN tree in one launch (csrc/mvx.hip): voxel (b, z, y, x) -> LiDAR corner
+ * ((index * voxel_stride) * voxel size + range minimum) -> the point the camera saw (per sample `aug` [B, 5] = global scale,
+ * cos(-rot), sin(-rot), flip_x sign on y, flip_y sign on x; identity = 1, 1, 0, 1, 1) -> pixel through lidar2img [B, 3, 4]
+ * (u, v = rows 0, 1 over row 2) -> truncated pixel -> the value torch's bilinear upsample (align_corners = False) of `fmap`
+ * [B, C, Hin, Win] to the image size [img_h, img_w] has at that pixel, zero outside the image
+ * (VR/pcdet/models/backbones_3d/spconv_backbone.py:682-756, 760-814).  out[row] = (add[i] +) feature, row = out_rows[i] or
+ * i; uv [n, 2] (optional) = the float pixel coordinates; grid [rows, 2] (optional) = (u / img_w, v / img_h).
+ * voxel_size_zyx / range_min_zyx: HOST arrays of 3 floats; scale_y / scale_x = float32(Hin) / float32(img_h), float32(Win) /
+ * float32(img_w) as torch computes them.  C % 4 == 0.  Same operations in the same order as the torch composition. */
+int df3d_voxel_image_sample(const int32_t *indices, int n, int batch, float voxel_stride, const float *voxel_size_zyx,
+                            const float *range_min_zyx, const float *aug, const float *lidar2img, const float *fmap, int C,
+                            int Hin, int Win, int img_h, int img_w, float scale_y, float scale_x, const float *add,
+                            const long long *out_rows, float *out, float *uv, float *grid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -405,3 +405,61 @@ def test_two_frames_in_flight_equal_sequential():
             for a, b in zip(idx, want[i][1]):
                 assert torch.equal(a, b)
             assert float((dense - want[i][0]).abs().max()) <= 1e-5 * float(want[i][0].abs().max())
+
+
+@pytest.mark.parametrize("aug", [False, True])
+def test_voxel_image_sample_kernel_equals_the_torch_composition(aug):
+    """df3d_voxel_image_sample (csrc/mvx.hip: voxel -> augmentation inverse -> pixel -> bilinear upsample tap at the
+    truncated pixel -> sum / padded scatter in one launch) against the torch composition it replaces
+    (`_project` + `_sample_int`, pinned to the reference's point_fusion by tests/golden/vr_fusion.npz): same operations
+    in the same order, so the pixels and features agree BIT FOR BIT, incl. voxels that project outside the image,
+    behind the camera and onto the image border."""
+    from dualfusion import ops
+    from dualfusion.backbones import VoxelBackBone8xFusion
+    dev = torch.device("cuda:0")
+    B, H, W = 3, 96, 320
+    m = VoxelBackBone8xFusion(dict(VR_CFG), 4, [512, 512, 40]).to(dev).eval()
+    g = torch.Generator().manual_seed(5 + int(aug))
+    n = 60000
+    ind = torch.stack([torch.randint(0, B, (n,), generator=g), torch.randint(0, 41, (n,), generator=g),
+                       torch.randint(0, 512, (n,), generator=g), torch.randint(0, 512, (n,), generator=g)], 1).int()
+    ind = ind[torch.argsort(ind[:, 0], stable=True)].contiguous().to(dev)
+    K = np.array([[180., 0, W / 2, 0.3], [0, 180., H / 2, -0.2], [0, 0, 1, 0.002]], np.float32)
+    Tr = np.array([[0, -1, 0, 0.01], [0, 0, -1, -0.08], [1, 0, 0, -0.27], [0, 0, 0, 1]], np.float32)
+    l2i = torch.from_numpy(np.stack([K @ Tr] * B)).to(dev)
+    bd = dict(batch_size=B, lidar2img=l2i, image_hw=(H, W))
+    if aug:
+        bd.update(noise_scale=[1.03, 0.97, 1.0], noise_rot=[0.31, -0.2, 0.0], flip_x=[True, False, False], flip_y=[False, True, False])
+
+    class X(object):
+        pass
+    for C, stride in ((16, 1), (256, 8)):
+        fmap = torch.randn(B, C, H // 4, W // 4, generator=g).to(dev)
+        feats = torch.randn(n, C, generator=g).to(dev)
+        x = X()
+        x.indices, x.features = ind, feats
+        with torch.no_grad():
+            xyz, uv = m._project(x, stride, bd)
+            want = m._sample_int(fmap, ind[:, 0].long(), uv, (H, W))
+            vs, r0 = m._geometry_floats()
+            got, guv = ops.voxel_image_sample(ind, B, float(stride), vs, r0, m._aug_params(dict(bd), B, dev), l2i, fmap, (H, W),
+                                              want_uv=True)
+            assert torch.equal(guv, uv)
+            inside = ((uv[:, 0] >= 0) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 1] < H)).float().mean().item()
+            assert 0.02 < inside < 0.98                                   # both cases are exercised
+            assert torch.equal(got, want)
+            # sum with the voxel features and the padded scatter + normalised grid
+            got2, _ = ops.voxel_image_sample(ind, B, float(stride), vs, r0, m._aug_params(dict(bd), B, dev), l2i, fmap, (H, W),
+                                             add=feats)
+            assert torch.equal(got2, feats + want)
+            b, slot, n_max = m._query_slots(ind, B)
+            rows = b * n_max + slot
+            out = torch.zeros(B * n_max, C, device=dev)
+            grid = torch.zeros(B * n_max, 2, device=dev)
+            ops.voxel_image_sample(ind, B, float(stride), vs, r0, m._aug_params(dict(bd), B, dev), l2i, fmap, (H, W), rows=rows,
+                                   out=out, grid=grid)
+            ref = torch.zeros(B, n_max, C, device=dev)
+            ref[b, slot] = want
+            rg = torch.zeros(B, n_max, 2, device=dev)
+            rg[b, slot] = uv / torch.tensor([W, H], dtype=torch.float32, device=dev)
+            assert torch.equal(out.view(B, n_max, C), ref) and torch.equal(grid.view(B, n_max, 2), rg)
