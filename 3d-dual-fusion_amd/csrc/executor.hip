@@ -39,6 +39,7 @@ struct LayerOut {
   void *rows16 = nullptr;      // bf16 rows of `features` (bf16 layers; converted on demand for fp32 producers)
   int set = -1;
   int channels = 0;
+  bool ran = false;            // the convolution of this layer was launched (false: geometry-only layer)
 };
 
 struct Bump {
@@ -123,6 +124,24 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
   // ---- per layer: geometry (neighbour table; for strided layers the output index set, with the one host round
   //      trip for its size) on the geometry stream, then the fused convolution on the caller's stream ----
   std::vector<const int32_t *> layer_nbr(nlayers, nullptr);
+  // Which layers must emit fp32 rows next to their split rows: exported stages (flag bit 2, set by the caller), residual
+  // sources, inputs of layers that do not run on the split-precision kernels.  The first convolution of every residual block
+  // feeds exactly one split-precision convolution: its fp32 rows were written and never read (round 2: every output twice).
+  std::vector<char> need_f32(nlayers, 0);
+  {
+    bool flagged = false;
+    for (int li = 0; li < nlayers; ++li) flagged = flagged || (layers[li].reserved & 4);
+    static const bool write_all = getenv("DF3D_EXEC_F32_ALL") && atoi(getenv("DF3D_EXEC_F32_ALL"));   // A / B of the PMC passes
+    if (write_all) flagged = false;
+    for (int li = 0; li < nlayers; ++li) {
+      const df3d_layer &L = layers[li];
+      if (!flagged || (L.reserved & 4) || li == nlayers - 1) need_f32[li] = 1;
+      if (L.residual >= 0 && L.residual < nlayers) need_f32[L.residual] = 1;
+      const bool split_consumer = L.packed && !(L.reserved & 2) && !(L.reserved & 1) &&
+                                  df3d_conv_packed_weight_bytes(kvol_of(L.ksize), L.cin, L.cout) != 0;
+      if (L.input >= 0 && L.input < nlayers && !split_consumer) need_f32[L.input] = 1;
+    }
+  }
   for (int li = 0; li < nlayers; ++li) {
     const df3d_layer &L = layers[li];
     DF3D_CHECK_ARG(L.input >= -1 && L.input < li && L.residual >= -1 && L.residual < li,
@@ -244,9 +263,13 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
       memcpy(v.shape, GS.shape, sizeof(v.shape));
       continue;
     }
-    DF3D_CHECK_ARG(L.input < 0 || outs[L.input].features, "backbone_run: layer %d reads a geometry-only layer", li);
-    o.features = (float *)mem.take((size_t)n_out * L.cout * 4);
-    DF3D_ARENA_CHECK(o.features);
+    DF3D_CHECK_ARG(L.input < 0 || outs[L.input].ran, "backbone_run: layer %d reads a geometry-only layer", li);
+    o.ran = true;
+    const bool split_layer = L.packed && !(L.reserved & 2) && df3d_conv_packed_weight_bytes(K, L.cin, L.cout) != 0;
+    if (need_f32[li] || !split_layer) {
+      o.features = (float *)mem.take((size_t)n_out * L.cout * 4);
+      DF3D_ARENA_CHECK(o.features);
+    }
     const float *res = L.residual < 0 ? nullptr : outs[L.residual].features;
     if (L.residual >= 0)
       DF3D_CHECK_ARG(outs[L.residual].set == out_set && outs[L.residual].channels == L.cout,

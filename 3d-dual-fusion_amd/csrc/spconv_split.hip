@@ -1493,10 +1493,11 @@ extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int 
                                       float *out, void *out_split, const int32_t *tile_rows, int ntiles,
                                       void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  DF3D_CHECK_ARG(features_split && packed_filters && nbr && out, "sparse_conv_split: null argument");
+  DF3D_CHECK_ARG(features_split && packed_filters && nbr && (out || out_split), "sparse_conv_split: null argument");
   DF3D_CHECK_ARG(kvol > 0 && kvol <= DF3D_MAX_KVOL, "sparse_conv_split: kernel volume %d unsupported", kvol);
   DF3D_CHECK_ARG(split_shape_ok(cin, cout), "sparse_conv_split: cin=%d cout=%d has no split-precision kernel", cin,
                  cout);
+  DF3D_CHECK_ARG(out || split_layout(cin, cout) == 1, "sparse_conv_split: the pair-compacted kernel always writes fp32 rows");
   if (n_out == 0) return DF3D_OK;
   SplitConvArgs a = {(const u32x4 *)features_split, (const u32x4 *)packed_filters, nbr, bias, scale, shift, residual,
                      out, (u32x4 *)out_split, n_in, n_out, kvol, relu,
@@ -1506,7 +1507,7 @@ extern "C" int df3d_sparse_conv_split(const void *features_split, int n_in, int 
 #ifdef DF3D_OS_TRACE
   a.trace = g_os_trace;
 #endif
-  int rec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 1, stream);
+  int rec = timing_rec_begin(cin, cout, kvol, n_out, nbr, 1 | (out && out_split ? 8 : 0), stream);   // bit 3: both row formats written
   int rc;
   if (split_layout(cin, cout) == 1) {
     rc = launch_os_any(cin, cout, a, stream);

@@ -147,6 +147,7 @@ class BackbonePlan(object):
         n = len(self.specs)
         table = (_Layer * n)()
         keep = []
+        exported = set(self.exports.values())
         for i, s in enumerate(self.specs):
             c = s.conv
             L = table[i]
@@ -161,6 +162,8 @@ class BackbonePlan(object):
                     L.stride[d], L.padding[d] = 1, int(c.kernel_size[d]) // 2
             L.relu = int(bool(s.relu))
             L.reserved = 1 if s.geometry_only else 0
+            if i in exported:
+                L.reserved |= 4                      # fp32 rows of this layer are read by the caller
             K = int(c.kernel_size[0] * c.kernel_size[1] * c.kernel_size[2])
             w = c.weight.detach().contiguous().view(K, c.in_channels, c.out_channels)
             if w.dtype != torch.float32:

@@ -257,8 +257,9 @@ class KernelTimer(object):
         for i in range(n):
             _lib.check(lib.df3d_timing_get2(i, ctypes.cast(shape, ctypes.c_void_p), ctypes.addressof(ms),
                                             ctypes.addressof(pairs), ctypes.addressof(split)), "df3d_timing_get2")
+            # split: 0 = fp32 MFMA kernel, 1 = split precision, 2 = bf16 rows; bit 3 = the launch wrote fp32 AND split rows
             self.records.append(dict(cin=shape[0], cout=shape[1], kvol=shape[2], n_out=shape[3], ms=float(ms.value),
-                                     pairs=int(pairs.value), split=int(split.value)))
+                                     pairs=int(pairs.value), split=int(split.value) & 3, both=bool(int(split.value) & 8)))
         return self.records
 
 

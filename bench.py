@@ -39,7 +39,7 @@ import torch  # noqa: E402
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_MFMA_TF = 157.3   # dense fp32 MFMA (= vector) peak
 PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 MFMA peak; the split-precision kernels spend 3 bf16 products per fp32 product
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_spconv_split.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_spconv_split.json")
 
 
 def parse():
@@ -217,12 +217,14 @@ def make_workload(args, rank, world, dev):
 def conv_algorithmic(rec, pairs):
     """SURVEY.md section 8(d), per launch:  bytes = R*Cin*s + N_out*Cout*s + 8*R + K*Cin*Cout*s ;  flops = 2*R*Cin*Cout
     (R = valid rulebook pairs, s = bytes per element of the rows: 4, or 2 for the bf16 kernels).  Every output row is
-    counted ONCE: the second copy the split-precision epilogue writes for the next layer (hi/lo bf16 rows) is an
-    implementation choice, reported separately as `extra_written_bytes_per_launch`."""
+    counted ONCE: the second copy the split-precision epilogue writes when BOTH the caller / a residual add (fp32 rows) and
+    the next layer (hi/lo bf16 rows) read the output is an implementation choice, reported separately as
+    `extra_written_bytes_per_launch` (round 3: only the launches that really write both -- the first conv of a residual
+    block writes split rows only)."""
     cin, cout, K, n_out = rec["cin"], rec["cout"], rec["kvol"], rec["n_out"]
     s = 2 if rec["split"] == 2 else 4
     by = pairs * cin * s + n_out * cout * s + 8 * pairs + K * cin * cout * s
-    extra = n_out * cout * 4 if rec["split"] else 0
+    extra = n_out * cout * 4 if rec.get("both") else 0
     return by, 2 * pairs * cin * cout, extra
 
 

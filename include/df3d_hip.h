@@ -614,7 +614,8 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
  *   df3d_conv_pack_weights:  filters [kvol][cin][cout] fp32 -> packed MFMA B operands (once per weight)
  *   df3d_split_rows:         features [n][c] fp32 -> split rows [n][c/8][hi 8 x bf16 | lo 8 x bf16], c % 8 == 0
  *   df3d_sparse_conv_split:  out fp32 [n_out][cout]; out_split (optional) receives the split rows of `out`
- *                            so that the next convolution needs no df3d_split_rows pass.
+ *                            so that the next convolution needs no df3d_split_rows pass.  out may be NULL when
+ *                            out_split is given (a layer whose only reader is the next split-precision convolution).
  * ---------------------------------------------------------------------------------- */
 size_t df3d_conv_packed_weight_bytes(int kvol, int cin, int cout);
 int df3d_conv_pack_weights(const float *filters, int kvol, int cin, int cout, void *packed, void *stream);
@@ -759,7 +760,11 @@ typedef struct df3d_layer {
   int relu;
   int reserved;          /* flags: bit 0 = geometry only (build the rulebook, export it, do not run the conv);
                           *        bit 1 = `packed` holds bf16 weights (df3d_conv_pack_weights_bf16): the layer runs on
-                          *                df3d_sparse_conv_bf16 with bf16 rows */
+                          *                df3d_sparse_conv_bf16 with bf16 rows;
+                          *        bit 2 = the caller reads this layer's fp32 rows (an exported stage).  When any layer of
+                          *                the table carries it, split-precision layers that are neither flagged, nor a
+                          *                residual source, nor read by a non-split layer write split rows ONLY (their view
+                          *                has features = NULL); a table without the flag keeps fp32 rows everywhere */
   const float *weight;   /* [kvol][cin][cout] fp32 */
   const void *packed;
   const float *bias, *scale, *shift;

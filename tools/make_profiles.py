@@ -82,9 +82,9 @@ pm.update({"fetch_calibration": {"factor": round(kf, 4), "write_factor": round(k
                          "MI355X_MICROARCH.md HBM section); x1024 (values are KB)" % (kf, kw),
            "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "compulsory_bytes": roof.get("compulsory_bytes"),
            "bench_hip_event_avg_launch_us": roof["avg_launch_us"],
-           "command": "tools/profile_r02.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate passes) --kernel-trace "
+           "command": "tools/profile_%s.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate passes) --kernel-trace "
                       "--output-format csv -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-passes "
-                      "--no-kernel-timing (8 rotating frames)"})
+                      "--no-kernel-timing (8 rotating frames)" % ("r02" if tag == "r02" else tag + "_pmc")})
 others = {}
 for key in bench["conv_rows_by_kernel"]:
     cin, cout = [int(v) for v in key.split("_")[0].split("x")]
@@ -130,6 +130,34 @@ try:
     json.dump(doc, open(out + tag + "_pmc_sq_spconv.json", "w"), indent=1)
 except Exception as e:      # the SQ pass is optional
     print("no SQ summary:", e)
+# round 3: WRITE_SIZE of the sparse-conv kernels with and without the fp32 copies nobody reads (DF3D_EXEC_F32_ALL=1 = round 2)
+if os.path.exists(src + "write_all/write_counter_collection.csv"):
+    def totals(fn):
+        agg = collections.OrderedDict()
+        for r in rows(fn):
+            if r["Counter_Name"] == "WRITE_SIZE" and "spconv" in r["Kernel_Name"] and int(r["Grid_Size"]) // int(r["Workgroup_Size"]) > 0:
+                k = r["Kernel_Name"].split("(")[0][:80]
+                a = agg.setdefault(k, [0, 0.0])
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+        return agg
+    now, before = totals("write/write_counter_collection.csv"), totals("write_all/write_counter_collection.csv")
+    doc = {"what": "WRITE_SIZE (KB, x %.3f calibration) summed over ALL launches of every sparse-conv kernel in the same bench "
+                   "command (tools/profile_%s_pmc.sh), default build vs DF3D_EXEC_F32_ALL=1 (every layer writes fp32 AND split "
+                   "rows, as in round 2).  Since round 3 a split-precision layer of the native executor writes fp32 rows only "
+                   "when they are read: exported stages, residual sources, inputs of non-split layers." % (kw, tag),
+           "kernels": {}}
+    tn = tb = 0.0
+    for k in before:
+        n = now.get(k, [0, 0.0])
+        doc["kernels"][k] = {"launches": before[k][0], "write_KB_round2_behaviour": round(before[k][1] * kw, 1),
+                             "write_KB_now": round(n[1] * kw, 1), "launches_now": n[0]}
+        tn += n[1] * kw
+        tb += before[k][1] * kw
+    doc["total_write_KB_round2_behaviour"], doc["total_write_KB_now"] = round(tb, 1), round(tn, 1)
+    doc["saved_fraction"] = round(1 - tn / tb, 4) if tb else None
+    json.dump(doc, open(out + tag + "_pmc_write_ab.json", "w"), indent=1)
+    print(json.dumps({k: doc[k] for k in ("total_write_KB_round2_behaviour", "total_write_KB_now", "saved_fraction")}))
 ps = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_summary.py"), src + "trace/stats_kernel_trace.csv", "--csv",
                      out + tag + "_bench_cp_fusion_per_step.csv"], capture_output=True, text=True)
 print(ps.stdout[:3000])
