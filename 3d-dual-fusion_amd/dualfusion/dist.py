@@ -103,6 +103,68 @@ def reduce_dict(input_dict, average=True):
         return out
 
 
+def _collective_device():
+    """Device the collective buffers live on: the current GPU under RCCL, the host under gloo."""
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def all_gather(data):
+    """CP/det3d/torchie/trainer/utils.py:114-157: all_gather of an arbitrary picklable object -> list over ranks (the
+    evaluation loop's `all_predictions = all_gather(detections)`, trainer.py:471).  Same protocol -- the sizes first, then
+    the pickles padded to the longest -- as two collectives of ONE tensor each (`all_gather_into_tensor`) instead of
+    2 x world_size one-element tensors."""
+    import pickle
+    if not is_dist() or dist.get_world_size() == 1:
+        return [data]
+    world = dist.get_world_size()
+    dev = _collective_device()
+    buf = torch.frombuffer(bytearray(pickle.dumps(data)), dtype=torch.uint8).to(dev)
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([buf.numel()], dtype=torch.int64, device=dev))
+    sizes = sizes.tolist()
+    cap = max(sizes)
+    padded = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    padded[:buf.numel()] = buf
+    out = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, padded)
+    host = out.cpu().numpy()
+    return [pickle.loads(host[r * cap:r * cap + sizes[r]].tobytes()) for r in range(world)]
+
+
+def gather_detections(frame_ids, boxes, scores, labels, counts):
+    """Detections of every rank on every rank without pickling: the fixed-capacity device tensors the detection tails
+    produce (`CenterHead.predict_device`, `TransFusionHead.get_bboxes`: boxes [F, cap, D], scores / labels [F, cap], counts [F]
+    for this rank's F frames, `frame_ids` [F] = their global indices) travel as ONE packed fp32 buffer through one
+    `all_gather_into_tensor` -- F may differ between ranks (7 frames over 2 ranks), so the frame counts go first.
+    -> {frame id: dict(box3d_lidar, scores, label_preds)} over all ranks, the merge `predictions.update(p)` of the
+    reference's evaluation loop (trainer.py:471-480)."""
+    F, cap, D = boxes.shape
+    pack = torch.cat([torch.as_tensor(frame_ids, device=boxes.device).reshape(F, 1).float(), counts.reshape(F, 1).float(),
+                      scores.reshape(F, cap).float(), labels.reshape(F, cap).float(), boxes.reshape(F, cap * D).float()], 1)
+    width = pack.shape[1]
+    if not is_dist() or dist.get_world_size() == 1:
+        allp, nf = pack, [F]
+    else:
+        world = dist.get_world_size()
+        dev = _collective_device()
+        nfr = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(nfr, torch.tensor([F], dtype=torch.int64, device=dev))
+        nf = nfr.tolist()
+        fmax = max(nf)
+        mine = torch.zeros((fmax, width), dtype=torch.float32, device=dev)
+        mine[:F] = pack.to(dev)
+        got = torch.empty((world * fmax, width), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(got, mine)
+        allp = torch.cat([got[r * fmax:r * fmax + nf[r]] for r in range(world)])
+    out = {}
+    host = allp.cpu()
+    for row in host:
+        fid, k = int(row[0]), int(row[1])
+        out[fid] = dict(scores=row[2:2 + k].clone(), label_preds=row[2 + cap:2 + cap + k].long(),
+                        box3d_lidar=row[2 + 2 * cap:].reshape(cap, D)[:k].clone())
+    return out
+
+
 def all_reduce_value(data, op="sum", average=False):
     """VR/pcdet/utils/commu_utils.py:148-162."""
     if not is_dist():

@@ -222,3 +222,53 @@ def test_gradient_buckets_rank_dependent_unused_parameters(tmp_path):
     res = [json.load(open(os.path.join(str(tmp_path), "u%d.json" % r))) for r in (0, 1)]
     assert res[0]["order"] == res[1]["order"] == res[0]["sizes"] * 2 and len(res[0]["sizes"]) >= 3, res
     assert max(r["err"] for r in res) < 1e-6, res
+
+
+def test_all_gather_of_detections_two_ranks(tmp_path):
+    """The evaluation loop's collective (CP/det3d/torchie/trainer/utils.py:114-157, trainer.py:471): `all_gather` of
+    picklable per-rank detections, and `gather_detections` -- the same merge for the fixed-capacity tensors of the device
+    tails, one packed buffer per rank, 7 frames sharded 4 + 3."""
+    worker = textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, os.path.join(%r, "3d-dual-fusion_amd"))
+        import torch
+        from dualfusion import dist as D
+        rank, local, world = D.init_from_env("gloo")
+        frames = D.frame_shard(7, rank, world)
+        dets = {"tok%%d" %% f: {"scores": torch.full((f + 1,), float(f)), "meta": "r%%d" %% rank} for f in frames}
+        allp = D.all_gather(dets)
+        merged = {}
+        for p in allp:
+            merged.update(p)
+        cap, dim = 5, 9
+        g = torch.Generator().manual_seed(100)
+        every = torch.randn(7, cap, dim, generator=g)
+        counts = torch.tensor([(f * 3) %% (cap + 1) for f in frames])
+        boxes, scores = every[frames], every[frames][:, :, 0] * 2
+        labels = torch.arange(cap).repeat(len(frames), 1) + torch.tensor(frames)[:, None]
+        got = D.gather_detections(frames, boxes, scores, labels, counts)
+        ok = sorted(got) == list(range(7))
+        for f in range(7):
+            k = (f * 3) %% (cap + 1)
+            ok = ok and got[f]["box3d_lidar"].shape == (k, dim) and torch.equal(got[f]["box3d_lidar"], every[f, :k])
+            ok = ok and torch.equal(got[f]["scores"], every[f, :k, 0] * 2) and got[f]["label_preds"].tolist() == [f + i for i in range(k)]
+        with open(os.path.join(os.environ["DF3D_TEST_OUT"], "rank%%d.json" %% rank), "w") as fh:
+            json.dump({"keys": sorted(merged), "lens": [int(merged[k]["scores"].numel()) for k in sorted(merged)],
+                       "meta": [merged[k]["meta"] for k in sorted(merged)], "ok": bool(ok)}, fh)
+        D.barrier()
+        torch.distributed.destroy_process_group()
+    """) % ROOT
+    script = tmp_path / "worker.py"
+    script.write_text(worker)
+    port = 29500 + ((os.getpid() + 991) % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", DF3D_TEST_OUT=str(tmp_path))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    for r in (0, 1):
+        with open(os.path.join(str(tmp_path), "rank%d.json" % r)) as f:
+            res = json.load(f)
+        assert res["keys"] == ["tok%d" % f for f in range(7)] and res["lens"] == [f + 1 for f in range(7)]
+        assert res["meta"] == ["r0", "r1", "r0", "r1", "r0", "r1", "r0"] and res["ok"]
