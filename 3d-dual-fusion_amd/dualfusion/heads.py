@@ -196,7 +196,7 @@ class CenterHead(nn.Module):
     def forward(self, x, *kwargs):
         self.__dict__.pop("_packed_train", None)          # a previous step's packed maps (and their graph) are not kept
         if ((self.training or torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
-                and _ops.CONV_PRECISION == "split" and self._row_kernels_fit(x) and self._train_rows_fit()):
+                and _ops.CONV_PRECISION in ("split", "bf16") and self._row_kernels_fit(x) and self._train_rows_fit()):
             return self.forward_rows_train(x)
         if (self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32
                 or not self._row_kernels_fit(x)):

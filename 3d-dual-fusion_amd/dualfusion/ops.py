@@ -521,9 +521,10 @@ def sparse_conv_grad_filters(features, grad_out, nbr):
     return gw
 
 
-def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None):
+def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=False):
     """indice_conv backward from the kernel-facing rulebook: -> (grad_features [n_in, cin], grad_filters [K, cin, cout]).
-    filters [K, cin, cout]."""
+    filters [K, cin, cout].  bf16: the input gradient on the bf16 kernel (mixed-precision training: gradient rows and
+    transposed filters rounded to bf16, fp32 accumulate, fp32 rows out); the filter gradient stays on the fp32 matrix cores."""
     K = nbr.shape[0]
     n_in = features.shape[0]
     grad_out = grad_out.contiguous()
@@ -537,7 +538,10 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None):
             inv = invert_neighbors(nbr, n_in)
     wt = filters.transpose(1, 2).contiguous()                     # [K, cout, cin]
     cout, cin = wt.shape[1], wt.shape[2]
-    if conv_split_supported(K, cout, cin):
+    if bf16 and conv_bf16_supported(K, cout, cin):
+        g_in, _ = sparse_conv_bf16(rows_to_bf16(grad_out), conv_pack_weights_bf16(wt), inv, n_in, cout, cin, want_f32=True,
+                                   want_bf16=False)
+    elif conv_split_supported(K, cout, cin):
         g_in, _ = sparse_conv_split(split_rows(grad_out), conv_pack_weights(wt), inv, n_in, cout, cin, emit_split=False)
     elif cin > 128 and cin % 128 == 0 and conv_split_supported(K, cout, 128):
         # many input channels (the head's shared conv 512 -> 64, transposed): 128-column blocks of one grouped launch

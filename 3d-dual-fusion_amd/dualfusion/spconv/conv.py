@@ -40,6 +40,13 @@ class SparseConvFunction(torch.autograd.Function):
         ctx.mirror, ctx.has_bias, ctx.inv = mirror, bias is not None, inv
         w = filters.detach().contiguous().view(K, cin, cout)
         b = bias.detach() if bias is not None else None
+        ctx.amp = _ops.CONV_PRECISION == "bf16" and _ops.conv_bf16_supported(K, cin, cout)
+        if ctx.amp:
+            # bf16 mixed-precision training (the reference's fp16-AMP configurations): operands rounded to
+            # bf16 for the matrix cores, fp32 accumulate and fp32 rows out (BatchNorm, residuals, losses and the master
+            # weights stay fp32, as under torch.autocast); the backward does the same for the input gradient
+            return _ops.sparse_conv_bf16(_ops.rows_to_bf16(features), _ops.conv_pack_weights_bf16(w), nbr, n_out, cin, cout,
+                                         bias=b, want_f32=True, want_bf16=False)[0]
         if _ops.conv_split_supported(K, cin, cout):            # same split-precision kernel as inference (~1e-5 rel.)
             return _ops.sparse_conv_split(_ops.split_rows(features), _ops.conv_pack_weights(w), nbr, n_out, cin, cout,
                                           bias=b, emit_split=False)[0]
@@ -52,7 +59,7 @@ class SparseConvFunction(torch.autograd.Function):
         K = nbr.shape[0]
         cin, cout = features.shape[1], filters.shape[-1]
         g_in, g_w = _ops.sparse_conv_backward(features, filters.detach().contiguous().view(K, cin, cout),
-                                              grad_out.contiguous().float(), nbr, ctx.mirror, inv=ctx.inv)
+                                              grad_out.contiguous().float(), nbr, ctx.mirror, inv=ctx.inv, bf16=ctx.amp)
         g_b = grad_out.sum(0) if ctx.has_bias else None
         return g_in, g_w.view_as(filters), g_b, None, None, None, None
 
