@@ -197,6 +197,14 @@ extern "C" void df3d_debug_set_os_trace(void *p) { g_os_trace = (unsigned long l
 // 8 raised wave priority around the MFMAs, 16 MFMAs without B-operand LDS reads, 32 no output stores) exist only in
 // builds with -DDF3D_OS_EXPERIMENTS: as run-time flags they cost the production kernel ~20 % (uniform branches
 // inside the MFMA batches)
+// DF3D_OS_QGATHER (build flag, round-3 experiment): the output-stationary kernel issues its gathers quad-coalesced and permutes
+#ifdef DF3D_OS_QGATHER
+#define OS_QROW (lane >> 2)
+#define OS_QSUB (lane & 3)
+#else
+#define OS_QROW n
+#define OS_QSUB g
+#endif
 #ifdef DF3D_OS_EXPERIMENTS
 #define OS_DBG(bit) ((a.dbg & (bit)) != 0)
 #else
@@ -647,7 +655,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   int idxn[RT];
   auto peek_a = [&]() {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) idxn[rt] = nbrL[ca.k][wave * WROWS + rt * 16 + n];
+    for (int rt = 0; rt < RT; ++rt) idxn[rt] = nbrL[ca.k][wave * WROWS + rt * 16 + OS_QROW];
   };
   auto issue_a = [&](u32x4 (&dst)[RT][KPS][NP]) {
     const int kb = ca.kb * KPS;
@@ -656,7 +664,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       const int idx = idxn[rt];
       const u32x4 *p = (ca.live && idx >= 0 && !OS_DBG(1)) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff
                                                              : g_zero_row;
-      p += (kb * 4 + g) * NP;
+      p += (kb * 4 + OS_QSUB) * NP;
 #pragma unroll
       for (int j = 0; j < KPS; ++j) {
 #pragma unroll
@@ -666,7 +674,22 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     ca.template next<KB>();
   };
   // Step s: barrier; W(s+1) (fetched during step s-1) -> LDS; fetch W(s+2); MFMAs of step s; fetch A(s+3).
-  auto step = [&](int s, u32x4 (&cur)[RT][KPS][NP], u32x4 (&wset)[WPT]) {
+  auto step = [&](int s, u32x4 (&raw)[RT][KPS][NP], u32x4 (&wset)[WPT]) {
+#ifdef DF3D_OS_QGATHER
+    // quad-coalesced gathers (lane l loaded sub-block l & 3 of row l >> 2): into the MFMA operand shape before the barrier
+    u32x4 cur[RT][KPS][NP];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < KPS; ++j)
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            cur[rt][j][q][d] = (unsigned)__builtin_amdgcn_ds_bpermute((4 * n + g) * 4, (int)raw[rt][j][q][d]);
+#else
+    u32x4 (&cur)[RT][KPS][NP] = raw;
+#endif
     __syncthreads();
     // the next step's weight tile goes to LDS (and the one after the ring is fetched) in the shadow of the first MFMA
     // batch instead of in front of it: right after the barrier a wave should do nothing but fetch B fragments and issue
@@ -772,7 +795,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       }
       if (OS_DBG(8)) __builtin_amdgcn_s_setprio(0);
     }
-    issue_a(cur);
+    issue_a(raw);
   };
 
   OS_STAMP(1);
@@ -1264,9 +1287,16 @@ static bool use_lc(const SplitConvArgs &a) {
 }
 
 #include "spconv_halo.h"
+#include "spconv_ws.h"
 
 template <int CIN, int COUT>
 static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
+  // weight-stationary kernel (spconv_ws.h): filters of whole offset groups in LDS, free-running waves
+  if constexpr ((CIN == 32 && (COUT == 32 || COUT == 64)) || (CIN == 64 && (COUT == 64 || COUT == 128)) ||
+                (CIN == 128 && COUT == 128)) {
+    const int ws = ws_mode_env();
+    if (ws_applicable(a) && (ws == 1 || (ws < 0 && ws_default<CIN, COUT>()))) return launch_ws<CIN, COUT>(a, stream);
+  }
   // 3 x 3 (x 3) rulebooks of the backbone shapes: input rows staged through LDS (spconv_halo.h)
   if constexpr ((CIN == 32 && (COUT == 32 || COUT == 64)) || (CIN == 64 && (COUT == 64 || COUT == 128)) ||
                 (CIN == 128 && COUT == 128)) {

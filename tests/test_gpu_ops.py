@@ -1238,3 +1238,47 @@ def test_sparse_conv_grouped_vs_per_group_launches(dev, G, cin, gin, cout):
         assert torch.equal(out[:, 8 + i * cout:8 + (i + 1) * cout], want), i
     with pytest.raises(Exception):
         ops.sparse_conv_grouped(wide[:, :cin], w, nbr, n, group_in=max(gin, 4))      # the groups' slices leave the rows
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
+def test_weight_stationary_conv_kernel_is_bit_identical(dev, cin, cout):
+    """The opt-in weight-stationary kernel (csrc/spconv_ws.h, DF3D_CONV_WS=1: filters of whole offset groups in LDS, free-running
+    waves over up to three 16-row tiles each, empty (tile, offset) pairs skipped, quad-coalesced gathers permuted into the
+    operand shape) against the default kernels: same operands, same accumulation order per output element -> IDENTICAL
+    fp32 rows and split rows.  SubM and strided rulebooks, row counts below / above one pass of the workgroups, tiles
+    without any neighbour, every epilogue combination, fp32 rows omitted."""
+    import os
+    from dualfusion import ops
+    shape, batch = [9, 64, 64], 2
+    filt = detgen.randn("ws%d_%d" % (cin, cout), (27, cin, cout), 0.5 / np.sqrt(cin))
+    packed = ops.conv_pack_weights(T(filt, dev))
+    bias, scale, shift = (T(detgen.randn("w%s%d" % (t, cout), (cout,), 0.2), dev) for t in "bsh")
+    old = os.environ.get("DF3D_CONV_WS")
+
+    def both(fn):
+        os.environ["DF3D_CONV_WS"] = "0"
+        a = fn()
+        os.environ["DF3D_CONV_WS"] = "1"
+        b = fn()
+        return a, b
+    try:
+        for n_seeds, walk in ((30, 300), (80, 400)):
+            ind = detgen.clustered_voxels("ws%d_%d" % (n_seeds, walk), batch, shape, n_seeds=n_seeds, walk=walk)
+            ind = ind[np.lexsort(ind.T[::-1])]
+            ind_t = T(ind, dev)
+            feats = detgen.randn("wsf%d_%d" % (cin, n_seeds), (len(ind), cin))
+            fsplit = ops.split_rows(T(feats, dev))
+            for subm in (1, 0):
+                outids, nbr, _ = _hip_rulebook(ind_t, batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], subm)
+                n_out = outids.shape[0]
+                if n_out < 4096:                                  # the kernel serves layers of >= 4096 rows
+                    continue
+                res = T(detgen.randn("wsr%d_%d" % (cout, n_out), (n_out, cout)), dev)
+                for kw in (dict(), dict(bias=bias, scale=scale, shift=shift, residual=res, relu=True)):
+                    (y0, s0), (y1, s1) = both(lambda: ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, **kw))
+                    assert torch.equal(y0, y1) and torch.equal(s0, s1), (n_out, subm, sorted(kw))
+    finally:
+        if old is None:
+            os.environ.pop("DF3D_CONV_WS", None)
+        else:
+            os.environ["DF3D_CONV_WS"] = old
