@@ -674,10 +674,12 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     ca.template next<KB>();
   };
   // Step s: barrier; W(s+1) (fetched during step s-1) -> LDS; fetch W(s+2); MFMAs of step s; fetch A(s+3).
-  auto step = [&](int s, u32x4 (&raw)[RT][KPS][NP], u32x4 (&wset)[WPT]) {
 #ifdef DF3D_OS_QGATHER
-    // quad-coalesced gathers (lane l loaded sub-block l & 3 of row l >> 2): into the MFMA operand shape before the barrier
-    u32x4 cur[RT][KPS][NP];
+  // quad-coalesced gathers (lane l loaded sub-block l & 3 of row l >> 2): brought into the MFMA operand shape by ds_bpermute
+  // ONE STEP AHEAD of their use, into a second register set, so that the permute's round trip runs under the barrier and
+  // the weight staging of the next step
+  u32x4 rdy[RT][KPS][NP];
+  auto to_operand = [&](u32x4 (&raw)[RT][KPS][NP]) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -686,7 +688,12 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         for (int q = 0; q < NP; ++q)
 #pragma unroll
           for (int d = 0; d < 4; ++d)
-            cur[rt][j][q][d] = (unsigned)__builtin_amdgcn_ds_bpermute((4 * n + g) * 4, (int)raw[rt][j][q][d]);
+            rdy[rt][j][q][d] = (unsigned)__builtin_amdgcn_ds_bpermute((4 * n + g) * 4, (int)raw[rt][j][q][d]);
+  };
+#endif
+  auto step = [&](int s, u32x4 (&raw)[RT][KPS][NP], u32x4 (&rawn)[RT][KPS][NP], u32x4 (&wset)[WPT]) {
+#ifdef DF3D_OS_QGATHER
+    u32x4 (&cur)[RT][KPS][NP] = rdy;
 #else
     u32x4 (&cur)[RT][KPS][NP] = raw;
 #endif
@@ -796,6 +803,11 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       if (OS_DBG(8)) __builtin_amdgcn_s_setprio(0);
     }
     issue_a(raw);
+#ifdef DF3D_OS_QGATHER
+    to_operand(rawn);                              // the next step's fragments (gathered two steps ago)
+#else
+    (void)rawn;
+#endif
   };
 
   OS_STAMP(1);
@@ -815,12 +827,15 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       issue_a(ar[j]);
     }
     OS_STAMP(2);
+#ifdef DF3D_OS_QGATHER
+    to_operand(ar[0]);
+#endif
     for (int s = 0; s < steps; s += AD) {
 #pragma unroll
       for (int j = 0; j < AD; j += 3) {
-        step(s + j, ar[j], w1);
-        step(s + j + 1, ar[j + 1], w2);
-        step(s + j + 2, ar[j + 2], w0);
+        step(s + j, ar[j], ar[(j + 1) % AD], w1);
+        step(s + j + 1, ar[j + 1], ar[(j + 2) % AD], w2);
+        step(s + j + 2, ar[j + 2], ar[(j + 3) % AD], w0);
       }
     }
   }
