@@ -47,6 +47,11 @@ typedef __bf16 lt_bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LT_PAIRS = 64;                      // fragment pairs (hi, lo) of one layer: 24 in-proj, 8 out-proj, 16 + 16 FFN
 constexpr int LT_WBYTES = LT_PAIRS * 2 * 64 * 16; // 128 KB
 constexpr int LT_NVEC = 704;                      // b_qkv 192 | b_o 64 | b_1 128 | b_2 64 | g1 | be1 | g2 | be2 (64 each)
+// gather mode (the first layer of a LocalTransformer chunk): 4 more pairs = the positional MLP's second linear [64, 32]
+// (pairs 64..67 = out tile), and 192 more floats = its first linear (BatchNorm folded) w0 [32][3] | b0 [32] | b1 [64]
+constexpr int LT_PE_PAIRS = 4;
+constexpr int LT_PE_WBYTES = LT_PE_PAIRS * 2 * 64 * 16;
+constexpr int LT_PE_NVEC = 192;
 
 struct LtArgs {
   const float *x;          // [32][G][64] rows (sequence-first: row = token * G + group)
@@ -56,6 +61,11 @@ struct LtArgs {
   int G;
   float eps1, eps2;
   long long ts, gs;        // floats between two tokens of a group / between two groups (input and output alike)
+  // GATHER: token (t, grp) reads row sel[t * G + grp] of `x` ([rows, 64]) and adds the positional MLP of gxyz[t * G + grp]
+  const long long *sel;
+  const float *gxyz;       // [32 * G, 3]
+  // SCATTER: besides nothing else, token (t, grp) writes its row to out[dst[t * G + grp]] when dst >= 0 (out = [rows, 64])
+  const long long *dst;
 };
 
 struct LtOp {
@@ -116,26 +126,29 @@ __device__ __forceinline__ void lt_gemm_t(const lt_u32x4 *Wl, int pair, int lane
   acc1 = LT_MFMA(wh, b1.hi, acc1);
 }
 
-template <int NW>
+template <int NW, bool GATHER, bool SCATTER>
 __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
+  constexpr int WBYTES = LT_WBYTES + (GATHER ? LT_PE_WBYTES : 0);
+  constexpr int NVEC = LT_NVEC + (GATHER ? LT_PE_NVEC : 0);
   extern __shared__ __align__(16) unsigned char lt_smem[];
   lt_u32x4 *Wl = (lt_u32x4 *)lt_smem;
-  float *vl = (float *)(lt_smem + LT_WBYTES);
+  float *vl = (float *)(lt_smem + WBYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, n = lane & 15;
   {
-    constexpr int TOT = LT_WBYTES / 16, PER = TOT / (NW * 64);
-    static_assert(TOT % (NW * 64) == 0 && PER % 8 == 0, "weight image size");
+    constexpr int TOT = WBYTES / 16, PER = TOT / (NW * 64);
+    static_assert(TOT % (NW * 64) == 0, "weight image size");
 #pragma unroll 1
     for (int b = 0; b < PER; b += 8) {              // eight 16-byte loads in flight per thread
       lt_u32x4 t[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = a.w[tid + NW * 64 * (b + i)];
+      for (int i = 0; i < 8; ++i) t[i] = a.w[tid + NW * 64 * ((b + i) < PER ? (b + i) : 0)];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) Wl[tid + NW * 64 * (b + i)] = t[i];
+      for (int i = 0; i < 8; ++i)
+        if (b + i < PER) Wl[tid + NW * 64 * (b + i)] = t[i];
     }
-    for (int e = tid; e < LT_NVEC; e += NW * 64) vl[e] = a.vec[e];
+    for (int e = tid; e < NVEC; e += NW * 64) vl[e] = a.vec[e];
   }
   __syncthreads();
   const float *bqkv = vl, *bo = vl + 192, *b1 = vl + 256, *b2 = vl + 384;
@@ -146,11 +159,44 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
   for (int grp = blockIdx.x * NW + wave; grp < a.G; grp += gridDim.x * NW) {
     // ---- rows of the group in layout T, LayerNorm 1 ------------------------------------------------------------
     lt_f32x4 xT[2][4];
+    if constexpr (GATHER) {
+      // x = flat[sel] + pe(xyz): the gathered point row plus the positional MLP 3 -> 32 (ReLU) -> 64 of the grouped coordinate
+      // (pointformer.py:287-290,362-364); the second linear is one more transposed product, its hidden operand = the 8 hidden
+      // channels 16 (j >> 2) + 4 g + (j & 3) this lane computes itself
+      const float *w0 = vl + LT_NVEC, *b0 = w0 + 96, *b1p = b0 + 32;
+      LtOp ho[2];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const float *row = a.x + (size_t)(tt * 16 + n) * a.ts + (size_t)grp * a.gs + 4 * g;
+      for (int tt = 0; tt < 2; ++tt) {
+        const size_t tok = (size_t)(tt * 16 + n) * a.G + grp;
+        const float *row = a.x + (size_t)a.sel[tok] * 64 + 4 * g;
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) xT[tt][ct] = *(const lt_f32x4 *)(row + ct * 16);
+        for (int ct = 0; ct < 4; ++ct) xT[tt][ct] = *(const lt_f32x4 *)(row + ct * 16);
+        const float px = a.gxyz[tok * 3], py = a.gxyz[tok * 3 + 1], pz = a.gxyz[tok * 3 + 2];
+        lt_f32x4 h[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ch = (j >> 2) * 16 + 4 * g + (j & 3);
+          const float v = fmaf(w0[ch * 3 + 2], pz, fmaf(w0[ch * 3 + 1], py, fmaf(w0[ch * 3], px, b0[ch])));
+          h[j >> 2][j & 3] = fmaxf(v, 0.f);
+        }
+        ho[tt] = lt_split(h[0], h[1]);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) {
+        lt_f32x4 a0 = zero4, a1 = zero4;
+        lt_gemm_t(Wl, LT_PAIRS + ot, lane, ho[0], ho[1], a0, a1);
+        const lt_f32x4 bb = *(const lt_f32x4 *)(b1p + ot * 16 + 4 * g);
+        xT[0][ot] += a0 + bb;
+        xT[1][ot] += a1 + bb;
+      }
+      LT_FENCE();
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const float *row = a.x + (size_t)(tt * 16 + n) * a.ts + (size_t)grp * a.gs + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) xT[tt][ct] = *(const lt_f32x4 *)(row + ct * 16);
+      }
     }
     lt_layernorm(xT[0], g1, be1, a.eps1, g);
     lt_layernorm(xT[1], g1, be1, a.eps1, g);
@@ -289,7 +335,16 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
     }
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-      float *row = a.out + (size_t)(tt * 16 + n) * a.ts + (size_t)grp * a.gs + 4 * g;
+      float *row;
+      if constexpr (SCATTER) {
+        // 'unique' + 'replace' aggregation (pointformer.py:315-347,371-372): only the winning occurrence of a point writes,
+        // straight into the point's row of the query tensor
+        const long long d = a.dst[(size_t)(tt * 16 + n) * a.G + grp];
+        if (d < 0) continue;
+        row = a.out + (size_t)d * 64 + 4 * g;
+      } else {
+        row = a.out + (size_t)(tt * 16 + n) * a.ts + (size_t)grp * a.gs + 4 * g;
+      }
 #pragma unroll
       for (int ot = 0; ot < 4; ++ot)
         *(lt_f32x4 *)(row + ot * 16) = xT[tt][ot] + yT[tt][ot] + *(const lt_f32x4 *)(b2 + ot * 16 + 4 * g);
@@ -303,21 +358,17 @@ using namespace df3d;
 
 extern "C" long long df3d_lt_layer_packed_bytes(void) { return LT_WBYTES; }
 extern "C" int df3d_lt_layer_vector_floats(void) { return LT_NVEC; }
+extern "C" long long df3d_lt_layer_pe_packed_bytes(void) { return LT_PE_WBYTES; }
+extern "C" int df3d_lt_layer_pe_vector_floats(void) { return LT_PE_NVEC; }
 
-extern "C" int df3d_lt_layer(const float *x, int L, int G, int C, int heads, int ffn, int group_major, const void *packed,
-                             const float *vec, float eps1, float eps2, float *out, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  DF3D_CHECK_ARG(x && packed && vec && out, "lt_layer: null argument");
-  DF3D_CHECK_ARG(L == 32 && C == 64 && heads == 4 && ffn == 128,
-                 "lt_layer: built for 32 tokens x 64 channels, 4 heads, feed-forward 128 (got %d x %d, %d heads, %d)", L, C,
-                 heads, ffn);
-  DF3D_CHECK_ARG(G >= 0, "lt_layer: bad group count");
-  if (G == 0) return DF3D_OK;
+template <bool GATHER, bool SCATTER>
+static int lt_launch(const LtArgs &a, hipStream_t stream) {
   constexpr int NW = 8;
-  const size_t lds = (size_t)LT_WBYTES + LT_NVEC * sizeof(float);
+  const size_t lds = (size_t)LT_WBYTES + (GATHER ? LT_PE_WBYTES : 0) + (LT_NVEC + (GATHER ? LT_PE_NVEC : 0)) * sizeof(float);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)lt_layer_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)lt_layer_kernel<NW, GATHER, SCATTER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
       return DF3D_EHIP;
@@ -329,10 +380,41 @@ extern "C" int df3d_lt_layer(const float *x, int L, int G, int C, int heads, int
     hipDeviceProp_t p;
     num_cu = (hipGetDeviceProperties(&p, 0) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
   }
-  int grid = cdiv(G, NW);
+  int grid = cdiv(a.G, NW);
   if (grid > num_cu) grid = num_cu;                 // one workgroup per CU (its weights fill the LDS), waves walk the groups
-  LtArgs a = {x, (const lt_u32x4 *)packed, vec, out, G, eps1, eps2, group_major ? 64LL : (long long)G * 64, group_major ? 32LL * 64 : 64LL};
-  hipLaunchKernelGGL((lt_layer_kernel<NW>), dim3(grid), dim3(NW * 64), lds, stream, a);
+  hipLaunchKernelGGL((lt_layer_kernel<NW, GATHER, SCATTER>), dim3(grid), dim3(NW * 64), lds, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
+}
+
+extern "C" int df3d_lt_layer(const float *x, int L, int G, int C, int heads, int ffn, int group_major, const void *packed,
+                             const float *vec, float eps1, float eps2, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(x && packed && vec && out, "lt_layer: null argument");
+  DF3D_CHECK_ARG(L == 32 && C == 64 && heads == 4 && ffn == 128,
+                 "lt_layer: built for 32 tokens x 64 channels, 4 heads, feed-forward 128 (got %d x %d, %d heads, %d)", L, C,
+                 heads, ffn);
+  DF3D_CHECK_ARG(G >= 0, "lt_layer: bad group count");
+  if (G == 0) return DF3D_OK;
+  LtArgs a = {x, (const lt_u32x4 *)packed, vec, out, G, eps1, eps2, group_major ? 64LL : (long long)G * 64,
+              group_major ? 32LL * 64 : 64LL, nullptr, nullptr, nullptr};
+  return lt_launch<false, false>(a, stream);
+}
+
+extern "C" int df3d_lt_layer_gather(const float *points, const long long *sel, const float *gxyz, int G, const void *packed,
+                                    const float *vec, float eps1, float eps2, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(points && sel && gxyz && packed && vec && out && G >= 0, "lt_layer_gather: bad argument");
+  if (G == 0) return DF3D_OK;
+  LtArgs a = {points, (const lt_u32x4 *)packed, vec, out, G, eps1, eps2, (long long)G * 64, 64LL, sel, gxyz, nullptr};
+  return lt_launch<true, false>(a, stream);
+}
+
+extern "C" int df3d_lt_layer_scatter(const float *x, int G, const void *packed, const float *vec, float eps1, float eps2,
+                                     const long long *dst, float *points, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(x && dst && packed && vec && points && G >= 0, "lt_layer_scatter: bad argument");
+  if (G == 0) return DF3D_OK;
+  LtArgs a = {x, (const lt_u32x4 *)packed, vec, points, G, eps1, eps2, (long long)G * 64, 64LL, nullptr, nullptr, dst};
+  return lt_launch<false, true>(a, stream);
 }

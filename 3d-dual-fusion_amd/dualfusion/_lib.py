@@ -156,6 +156,10 @@ SIGNATURES = {
     "df3d_lt_layer_packed_bytes": (c_longlong, []),
     "df3d_lt_layer_vector_floats": (c_int, []),
     "df3d_lt_layer": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "df3d_lt_layer_pe_packed_bytes": (c_longlong, []),
+    "df3d_lt_layer_pe_vector_floats": (c_int, []),
+    "df3d_lt_layer_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "df3d_lt_layer_scatter": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "df3d_boxes_overlap_bev_xyxyr": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "df3d_tf_match_cost": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

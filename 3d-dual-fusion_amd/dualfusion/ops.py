@@ -1754,6 +1754,57 @@ def lt_layer(x, packed, vec, heads, ffn, eps1, eps2, group_major=False):
     return out
 
 
+def lt_layer_pack_pe(packed, vec, w0, b0, w1, b1):
+    """Fragments / vector of a layer extended by the positional MLP (w0 [32, 3] with its BatchNorm folded, b0 [32], w1 [64, 32],
+    b1 [64]) for df3d_lt_layer_gather."""
+    lib = _lib.load()
+    frags = _lt_fragments(w1.detach().float()).reshape(-1, 64, 8)
+    hi = frags.to(torch.bfloat16)
+    lo = (frags - hi.float()).to(torch.bfloat16)
+    pe = torch.stack([hi, lo], 1).contiguous().view(torch.uint8).reshape(-1)
+    if pe.numel() != int(lib.df3d_lt_layer_pe_packed_bytes()):
+        raise _lib.Df3dError("lt_layer_pack_pe: %d bytes, the kernel expects %d" % (pe.numel(), lib.df3d_lt_layer_pe_packed_bytes()))
+    v = torch.cat([t.detach().float().reshape(-1) for t in (w0, b0, b1)])
+    if v.numel() != int(lib.df3d_lt_layer_pe_vector_floats()):
+        raise _lib.Df3dError("lt_layer_pack_pe: %d vector entries, the kernel expects %d" % (v.numel(), lib.df3d_lt_layer_pe_vector_floats()))
+    return torch.cat([packed, pe]).contiguous(), torch.cat([vec, v]).contiguous()
+
+
+def lt_layer_gather(points, sel, gxyz, groups, packed_pe, vec_pe, eps1, eps2):
+    """First layer of a LocalTransformer chunk: rows points[sel] + pe(gxyz) in, [32, groups, 64] out (df3d_lt_layer_gather)."""
+    lib = _lib.load()
+    _chk(points, torch.float32, "points")
+    _chk(sel, torch.int64, "sel")
+    _chk(gxyz, torch.float32, "gxyz")
+    _chk(packed_pe, torch.uint8, "packed")
+    _chk(vec_pe, torch.float32, "vec")
+    if points.shape[1] != 64 or sel.numel() != 32 * groups or gxyz.shape != (32 * groups, 3):
+        raise _lib.Df3dError("lt_layer_gather: points [rows, 64], sel [32 * groups], gxyz [32 * groups, 3]")
+    out = torch.empty((32, groups, 64), dtype=torch.float32, device=points.device)
+    rc = lib.df3d_lt_layer_gather(_ptr(points), _ptr(sel), _ptr(gxyz), int(groups), _ptr(packed_pe), _ptr(vec_pe), float(eps1),
+                                  float(eps2), _ptr(out), _stream())
+    _lib.check(rc, "df3d_lt_layer_gather")
+    return out
+
+
+def lt_layer_scatter(x, packed, vec, eps1, eps2, dst, points):
+    """Last layer of a LocalTransformer chunk: [32, groups, 64] in, row (t, grp) written to points[dst[t * groups + grp]] where
+    dst >= 0 (df3d_lt_layer_scatter).  -> points (updated in place)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    _chk(dst, torch.int64, "dst")
+    _chk(points, torch.float32, "points")
+    _chk(packed, torch.uint8, "packed")
+    _chk(vec, torch.float32, "vec")
+    L, G, C = x.shape
+    if L != 32 or C != 64 or dst.numel() != L * G or points.shape[1] != 64:
+        raise _lib.Df3dError("lt_layer_scatter: x [32, groups, 64], dst [32 * groups], points [rows, 64]")
+    rc = lib.df3d_lt_layer_scatter(_ptr(x), int(G), _ptr(packed), _ptr(vec), float(eps1), float(eps2), _ptr(dst), _ptr(points),
+                                   _stream())
+    _lib.check(rc, "df3d_lt_layer_scatter")
+    return points
+
+
 _IDENTITY_TABLES = {}
 
 

@@ -80,6 +80,16 @@ class TransformerEncoderLayerPreNorm(nn.Module):
                 and self.linear1.bias is not None and self.linear2.bias is not None and a.out_proj.bias is not None
                 and os.environ.get("DF3D_LT_FUSED", "1") == "1")
 
+    def _packed_fused(self):
+        a = self.self_attn
+        ts = (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, self.linear1.weight, self.linear1.bias,
+              self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias)
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        hit = self.__dict__.get("_lt_packed")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_lt_packed"] = (key,) + tuple(_ops.lt_layer_pack(*ts))
+        return hit[1], hit[2]
+
     def _forward_fused(self, src):
         a = self.self_attn
         ts = (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, self.linear1.weight, self.linear1.bias,
@@ -241,7 +251,11 @@ class LocalTransformer(nn.Module):
         w = win.clamp(min=0)
         p_w, s_w = w // ns, w % ns
         src = s_w * (B * np_) + torch.arange(B, device=w.device)[:, None] * np_ + p_w   # row of y [ns*B*np, C]
-        plan = (sel, gx, src.reshape(-1), has.reshape(-1, 1))
+        # the inverse map for the fused last layer: token row -> the point row it wins (or -1)
+        dst = torch.full((ns * B * np_,), -1, dtype=torch.int64, device=w.device)
+        hf = has.reshape(-1)
+        dst[src.reshape(-1)[hf]] = torch.arange(B * N, device=w.device)[hf]
+        plan = (sel, gx, src.reshape(-1), has.reshape(-1, 1), dst)
         _GEO.rows = (group_idx, plan)
         return plan
 
@@ -274,15 +288,52 @@ class LocalTransformer(nn.Module):
         return _ops.pe_gather_add(flat, sel, gx, w0.contiguous(), b0.contiguous(),
                                   c1.conv.weight[:, :, 0, 0].contiguous(), c1.conv.bias.contiguous())
 
+    def _fused_chunk(self, flat, ns, groups):
+        """(layers, first layer's fragments + positional MLP, its vector) when the chunk runs as fused launches, else None."""
+        layers = list(self.chunk.layers)
+        c0, c1 = self.pe[0], self.pe[1]
+        probe = flat.new_empty((ns, 1, flat.shape[1]))
+        if (len(layers) < 2 or flat.shape[1] != 64 or not flat.is_contiguous() or os.environ.get("DF3D_LT_GATHER", "1") != "1"
+                or not all(l._rows_fit(probe, None, None) and l._fused_fit(probe) for l in layers)
+                or not (c0.with_activation and c1.conv.bias is not None and c0.conv.out_channels == 32 and c0.conv.in_channels == 3)):
+            return None
+        w0, b0 = c0.conv.weight[:, :, 0, 0], c0.conv.bias
+        if c0.with_norm:
+            inv = torch.rsqrt(c0.bn.running_var + c0.bn.eps) * c0.bn.weight
+            w0 = w0 * inv[:, None]
+            b0 = c0.bn.bias - c0.bn.running_mean * inv + (b0 * inv if b0 is not None else 0)
+        elif b0 is None:
+            b0 = w0.new_zeros(w0.shape[0])
+        ts = [c0.conv.weight, c0.conv.bias, c1.conv.weight, c1.conv.bias] + ([c0.bn.weight, c0.bn.bias, c0.bn.running_mean,
+                                                                              c0.bn.running_var] if c0.with_norm else [])
+        pk, vc = layers[0]._packed_fused()
+        key = (pk.data_ptr(), vc.data_ptr()) + tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+        hit = self.__dict__.get("_pe_packed")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_pe_packed"] = (key,) + tuple(_ops.lt_layer_pack_pe(pk, vc, w0, b0, c1.conv.weight[:, :, 0, 0],
+                                                                                    c1.conv.bias))
+        return layers, hit[1], hit[2]
+
     def _forward_rows(self, xyz, rows):
         """Inference path without a single transpose: `rows` [B,N,C] is the caller's query tensor (updated in place,
         'replace' semantics); grouped features are row gathers, the positional MLP runs on coordinate rows, the
         encoder sees [ns, B*np, C] directly and the winners are gathered back by row."""
         B, N, C = rows.shape
         group_idx, group_xyz = self._geometry(xyz)
-        sel, gx, src, has = self._row_plan(xyz, group_idx, group_xyz)
+        sel, gx, src, has, dst = self._row_plan(xyz, group_idx, group_xyz)
         ns, np_ = group_idx.shape[2], group_idx.shape[1]
         flat = rows.reshape(B * N, C)
+        fused = self._fused_chunk(flat, ns, B * np_)
+        if fused is not None:
+            # the whole module as len(layers) launches: gather + positional MLP in the first layer's load, the 'unique' /
+            # 'replace' write-back in the last layer's store (in place: the first launch has read `flat` before the last writes)
+            layers, packed_pe, vec_pe = fused
+            y = _ops.lt_layer_gather(flat, sel, gx, B * np_, packed_pe, vec_pe, layers[0].norm1.eps, layers[0].norm2.eps)
+            for l in layers[1:-1]:
+                y = l._forward_fused(y)
+            pk, vc = layers[-1]._packed_fused()
+            _ops.lt_layer_scatter(y, pk, vc, layers[-1].norm1.eps, layers[-1].norm2.eps, dst, flat)
+            return rows
         x = self._pe_gather(flat, sel, gx)
         y = self.chunk(x.view(ns, B * np_, C)).reshape(ns * B * np_, C)
         flat.copy_(torch.where(has, y.index_select(0, src), flat))

@@ -891,6 +891,22 @@ long long df3d_lt_layer_packed_bytes(void);
 int df3d_lt_layer_vector_floats(void);
 int df3d_lt_layer(const float *x, int L, int G, int C, int heads, int ffn, int group_major, const void *packed, const float *vec,
                   float eps1, float eps2, float *out, void *stream);
+/* The first and the last layer of a LocalTransformer chunk with the module's gather / scatter in their load / store
+ * (pointformer.py:287-290,315-347,349-380; 32 tokens x 64 channels, 4 heads, feed-forward 128 as above):
+ *   df3d_lt_layer_gather:  token (t, grp) = points[sel[t * G + grp]] + pe(gxyz[t * G + grp]) with the positional MLP
+ *                          3 -> 32 (BatchNorm folded, ReLU) -> 64; `packed` = the layer's fragments followed by
+ *                          df3d_lt_layer_pe_packed_bytes() more (pairs 64..67 = the MLP's second linear [64, 32], same
+ *                          fragment format), `vec` = the layer's vector followed by df3d_lt_layer_pe_vector_floats() floats
+ *                          (w0 [32][3] | b0 [32] | b1 [64]); out [32, G, 64] sequence-first rows.
+ *   df3d_lt_layer_scatter: x [32, G, 64] sequence-first rows in; token (t, grp) writes its output row to
+ *                          points[dst[t * G + grp]] when dst >= 0 (the 'unique' winner of its point, 'replace' aggregation),
+ *                          nothing otherwise.  points may be the tensor df3d_lt_layer_gather read (stream order). */
+long long df3d_lt_layer_pe_packed_bytes(void);
+int df3d_lt_layer_pe_vector_floats(void);
+int df3d_lt_layer_gather(const float *points, const long long *sel, const float *gxyz, int G, const void *packed,
+                         const float *vec, float eps1, float eps2, float *out, void *stream);
+int df3d_lt_layer_scatter(const float *x, int G, const void *packed, const float *vec, float eps1, float eps2,
+                          const long long *dst, float *points, void *stream);
 
 /* Point fusion of the Voxel-RCNN tree in one launch (csrc/mvx.hip): voxel (b, z, y, x) -> LiDAR corner
  * ((index * voxel_stride) * voxel size + range minimum) -> the point the camera saw (per sample `aug` [B, 5] = global scale,

@@ -640,3 +640,58 @@ def test_local_transformer_layer_as_one_kernel_vs_float64_and_row_kernels(G):
         md.linear2.bias.add_(1.0)
         y2 = md(xd)
     assert float((y2 - y - 1.0).abs().max()) < 1e-4 * scale
+
+
+def test_local_transformer_chunk_as_fused_launches():
+    """LocalTransformer at the ACTRv2 size of the Voxel-RCNN tree (64 channels, nsample 32, two layers) on the row-layout
+    path: gather + positional MLP inside the first layer's load and the 'unique' / 'replace' write-back inside the last
+    layer's store (df3d_lt_layer_gather / df3d_lt_layer_scatter: two launches for the module) against the module's own
+    channel-first composition (grouping, positional convs, encoder layers, scatter: pointformer.py:349-380) in float64 on
+    the CPU geometry, and against the unfused row path; points outside every group keep their features bit for bit."""
+    import copy
+    import os
+    from dualfusion import pointformer
+    from dualfusion.pointformer import LocalTransformer
+    dev = torch.device("cuda:0")
+    B, N, C = 2, 1500, 64
+    m = LocalTransformer(96, 2.5, 32, C, C, num_layers=2, attn_feat_agg_method="unique", feat_agg_method="replace").eval()
+    sd = detgen.det_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g = torch.Generator().manual_seed(9)
+    xyz = torch.rand(B, N, 3, generator=g) * torch.tensor([40.0, 40.0, 3.0])
+    rows = torch.randn(B, N, C, generator=g)
+    md = copy.deepcopy(m).to(dev)
+    old = os.environ.get("DF3D_LT_GATHER")
+    with torch.no_grad():
+        xd = xyz.to(dev)
+        r1 = rows.clone().to(dev)
+        y1 = md(xd, r1.permute(0, 2, 1))
+        assert y1.data_ptr() == r1.data_ptr() and md._fused_chunk(r1.reshape(B * N, C), 32, B * 96) is not None
+        os.environ["DF3D_LT_GATHER"] = "0"
+        try:
+            pointformer._GEO.__dict__.clear()
+            r0 = rows.clone().to(dev)
+            y0 = md(xd.clone(), r0.permute(0, 2, 1))
+        finally:
+            if old is None:
+                os.environ.pop("DF3D_LT_GATHER", None)
+            else:
+                os.environ["DF3D_LT_GATHER"] = old
+        # float64 module composition on the same geometry (group indices from the device ops)
+        group_idx, group_xyz = md._geometry(xd)
+        gi = group_idx.cpu().long()
+        feats = rows.double().permute(0, 2, 1)                                          # [B, C, N]
+        m64 = copy.deepcopy(m).double()
+        grouped = torch.gather(feats[:, :, None, :].expand(B, C, 96, N), 3, gi[:, None].expand(B, C, 96, 32))
+        x = grouped + m64.pe(group_xyz.cpu().double())
+        x = x.permute(0, 2, 1, 3).reshape(-1, C, 32).permute(2, 0, 1)
+        y = m64.chunk(x).permute(1, 2, 0).reshape(B, 96, C, 32).transpose(1, 2)         # [B, C, np, ns]
+        want = feats.clone().contiguous()
+        m64.scatter(want, y, group_idx.cpu())
+        want = want.permute(0, 2, 1)
+    scale = float(want.abs().max())
+    assert float((y1.cpu().double() - want).abs().max()) < 5e-5 * scale
+    assert float((y1 - y0).abs().max()) < 5e-5 * scale
+    untouched = torch.ones(B, N, dtype=torch.bool)
+    untouched.scatter_(1, gi.reshape(B, -1), False)
+    assert int(untouched.sum()) > 0 and torch.equal(y1.cpu()[untouched], rows[untouched])
