@@ -675,7 +675,7 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
             pts[b, slot] = xyz
             lt = lts[0]
             lt._row_plan(pts, *lt._geometry(pts))
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)       # (timing: tools/debug/vr_stall.py reads how long `_fuse4` waits for it)
             ev.record(side)
         del previous
         self.__dict__["_fuse4_pre"] = dict(n=int(ind.shape[0]), shape=shape, xyz=xyz, b=b, slot=slot, n_max=n_max, pts=pts, event=ev)
