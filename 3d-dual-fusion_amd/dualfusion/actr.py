@@ -414,8 +414,16 @@ class DeformableTransformerACTR(nn.Module):
         shapes = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         # contiguous [N, sum HW, C]: value_proj on a transposed view makes hipBLASLt pick a 25x slower kernel
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1).contiguous()
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=dev)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        # cached by value: a fresh host -> device copy of this tiny tensor is a pageable-memory copy, i.e. the host waits for
+        # everything queued on the stream before it (1.4 ms per step in the Voxel-RCNN tree)
+        skey = (tuple(shapes), str(dev))
+        hit = self.__dict__.get("_level_cache")
+        if hit is None or hit[0] != skey:
+            spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=dev)
+            hit = (skey, spatial_shapes,
+                   torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1])))
+            self.__dict__["_level_cache"] = hit
+        spatial_shapes, level_start_index = hit[1], hit[2]
         N = src_flatten.shape[0]
         if masks is None or all(m is None for m in masks):
             valid_ratios = torch.ones((N, len(srcs), 2), dtype=torch.float32, device=dev)

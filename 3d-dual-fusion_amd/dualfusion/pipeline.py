@@ -26,6 +26,9 @@ class CenterPointHotPath(nn.Module):
         else:
             self.backbone = SpMiddleResNetFHDFusion(num_input_features=num_input_features)
         self.fusion = fusion
+        # set by a caller whose point clouds are complete in device memory before forward() is called (a data loader's
+        # synchronised copies; bench.py): voxelisation then runs on its own stream (ops.hard_voxelize_clouds)
+        self.resident_inputs = False
         # optional BEV neck (necks.RPN): the backbone then hands over channels-last pixel
         # rows and forward returns the neck's [B, 512, 180, 180] map instead of the dense BEV tensor
         self.neck = neck
@@ -39,15 +42,11 @@ class CenterPointHotPath(nn.Module):
         """list of [P_b, C] device tensors -> (features [M, C], coors [M, 4] (b,z,y,x) int32).
         CenterPoint voxelises with the numba kernel's cap semantics (point_cloud_ops.py:46-47).
         `while_waiting`: enqueued behind the first sweep's voxelizer while the host waits for its voxel count."""
-        feats, coors = [], []
-        for b, pts in enumerate(points_list):
-            mean, c, _ = self.voxel_layer.voxelize_mean(pts, break_at_cap=False, batch_index=b,
-                                                        while_waiting=while_waiting if b == 0 else None)
-            feats.append(mean)
-            coors.append(c)
-        if len(feats) == 1:
-            return feats[0], coors[0]
-        return torch.cat(feats), torch.cat(coors)
+        from . import ops as _ops
+        vl = self.voxel_layer                       # a batch: all clouds queued, ONE round trip for their voxel counts
+        return _ops.hard_voxelize_clouds([p.contiguous().float() for p in points_list], vl.voxel_size, vl.point_cloud_range,
+                                         vl.max_num_points, vl._cap(), break_at_cap=False, while_waiting=while_waiting,
+                                         resident_inputs=self.resident_inputs)
 
     @torch.no_grad()
     def forward(self, points_list, batch_dict=None, example=None):

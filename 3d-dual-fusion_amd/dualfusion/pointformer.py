@@ -252,9 +252,13 @@ class LocalTransformer(nn.Module):
         p_w, s_w = w // ns, w % ns
         src = s_w * (B * np_) + torch.arange(B, device=w.device)[:, None] * np_ + p_w   # row of y [ns*B*np, C]
         # the inverse map for the fused last layer: token row -> the point row it wins (or -1)
-        dst = torch.full((ns * B * np_,), -1, dtype=torch.int64, device=w.device)
-        hf = has.reshape(-1)
-        dst[src.reshape(-1)[hf]] = torch.arange(B * N, device=w.device)[hf]
+        # (no boolean-mask indexing: its size is a device -> host round trip, and this runs on the side stream behind the
+        # 4.7 ms of furthest point sampling -- the host would sit there instead of queueing the backbone)
+        R = ns * B * np_
+        dst = torch.full((R + 1,), -1, dtype=torch.int64, device=w.device)
+        dst.scatter_(0, torch.where(has.reshape(-1), src.reshape(-1), torch.full_like(src.reshape(-1), R)),
+                     torch.arange(B * N, device=w.device))
+        dst = dst[:R]
         plan = (sel, gx, src.reshape(-1), has.reshape(-1, 1), dst)
         _GEO.rows = (group_idx, plan)
         return plan

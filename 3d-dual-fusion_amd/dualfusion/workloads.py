@@ -14,6 +14,8 @@ over the ranks (`reduce_dict`) -- BASELINE configs[3]'s "RCCL all-reduce of dete
 the decoded boxes instead (round 2's step).  The Voxel-RCNN tree ends at its fused backbone (no head in the reference's
 3D-DF addition): replicas behind bench.py's barrier."""
 import numpy as np
+import os
+
 import torch
 
 from . import ops, synth
@@ -25,12 +27,9 @@ TF_ACTR_CFG = dict(fusion_method="sum", feature_modal="hybrid",
 
 
 def _voxelize_batch(points, vs, rng, max_points, max_voxels):
-    feats, coors = [], []
-    for b, pts in enumerate(points):
-        _, c, _, mean = ops.hard_voxelize(pts, vs, rng, max_points, max_voxels, want_voxels=False, batch_index=b)
-        feats.append(mean)
-        coors.append(c)
-    return torch.cat(feats), torch.cat(coors)
+    # the frames' point clouds are resident inputs (bench.py's contract): voxelise on the voxel stream
+    return ops.hard_voxelize_clouds(points, vs, rng, max_points, max_voxels,
+                                    resident_inputs=os.environ.get("DF3D_VOXEL_STREAM", "1") == "1")
 
 
 class TransFusionWorkload(object):

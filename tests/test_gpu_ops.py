@@ -1282,3 +1282,21 @@ def test_weight_stationary_conv_kernel_is_bit_identical(dev, cin, cout):
             os.environ.pop("DF3D_CONV_WS", None)
         else:
             os.environ["DF3D_CONV_WS"] = old
+
+
+def test_hard_voxelize_clouds_equals_per_cloud_calls(dev):
+    """hard_voxelize_clouds (all clouds queued, one round trip for the counts) == the per-cloud calls it replaces, bit for bit,
+    with and without work queued while waiting; a cloud without points in range contributes nothing."""
+    from dualfusion import ops, synth
+    clouds = [torch.from_numpy(synth.kitti_sweep(seed=30 + b)[:, :4].copy()).to(dev) for b in range(3)]
+    clouds.insert(1, torch.full((50, 4), 1000.0, device=dev))                       # nothing inside the range
+    feats, coors = [], []
+    for b, pts in enumerate(clouds):
+        _, c, _, mean = ops.hard_voxelize(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 40000, want_voxels=False, batch_index=b)
+        feats.append(mean)
+        coors.append(c)
+    flag = []
+    for ww in (None, lambda: flag.append(1)):
+        f, c = ops.hard_voxelize_clouds(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 40000, while_waiting=ww)
+        assert torch.equal(f, torch.cat(feats)) and torch.equal(c, torch.cat(coors))
+    assert flag == [1] and not bool((torch.cat(coors)[:, 0] == 1).any())
