@@ -63,7 +63,13 @@ int kvol_of(const int *k) { return k[0] * k[1] * k[2]; }
 // Second stream for the geometry work + a small pool of ordering events, created once per HOST THREAD: frames are
 // independent, and a caller that keeps several frames in flight drives each from its own thread and stream.
 thread_local hipStream_t g_geo_stream = nullptr;
-thread_local std::vector<hipEvent_t> g_events;
+// Sixteen event sets, one per run in rotation: with df3d_backbone_inputs_ready the geometry of run k + 1 records its events while
+// the caller's stream may not yet have reached the waits it queued for run k's events -- a re-recorded event must not be one a
+// pending wait refers to.
+thread_local std::vector<hipEvent_t> g_event_sets[16];
+thread_local unsigned g_run_counter = 0;
+#define g_events g_event_sets[g_run_counter & 15]
+thread_local hipEvent_t g_inputs_ready = nullptr;     // df3d_backbone_inputs_ready: consumed by the next df3d_backbone_run
 hipEvent_t order_event(size_t i) {
   while (g_events.size() <= i) {
     hipEvent_t e = nullptr;
@@ -75,10 +81,18 @@ hipEvent_t order_event(size_t i) {
 
 }  // namespace
 
+extern "C" int df3d_backbone_inputs_ready(void *event) {
+  g_inputs_ready = (hipEvent_t)event;
+  return DF3D_OK;
+}
+
 extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *features, const int32_t *indices,
                                  int n, int in_channels, int batch, const int *shape, void *arena,
                                  size_t arena_bytes, df3d_layer_view *views, size_t *arena_used, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  hipEvent_t inputs_ready = g_inputs_ready;
+  g_inputs_ready = nullptr;
+  ++g_run_counter;
   DF3D_CHECK_ARG(layers && nlayers > 0 && features && indices && shape && arena && views,
                  "backbone_run: null argument");
   DF3D_CHECK_ARG(n > 0 && batch > 0, "backbone_run: empty input (n=%d, batch=%d)", n, batch);
@@ -92,10 +106,17 @@ extern "C" int df3d_backbone_run(const df3d_layer *layers, int nlayers, const fl
   if (two_streams) {
     if (!g_geo_stream) DF3D_HIP(hipStreamCreateWithFlags(&g_geo_stream, hipStreamNonBlocking));
     gstream = g_geo_stream;
-    hipEvent_t e = order_event(next_event++);
-    DF3D_CHECK_ARG(e != nullptr, "backbone_run: cannot create an event");
-    DF3D_HIP(hipEventRecord(e, stream));               // inputs (voxel features / coordinates) are ready
-    DF3D_HIP(hipStreamWaitEvent(gstream, e, 0));
+    if (inputs_ready) {
+      // the caller vouches that the COORDINATES are complete at this event (df3d_backbone_inputs_ready) and that the arena is
+      // not in use by earlier work of `stream`: the geometry then does not wait for whatever the caller's stream still has
+      // queued (the previous frame), and the host passes its round trips while that frame is still running
+      DF3D_HIP(hipStreamWaitEvent(gstream, inputs_ready, 0));
+    } else {
+      hipEvent_t e = order_event(next_event++);
+      DF3D_CHECK_ARG(e != nullptr, "backbone_run: cannot create an event");
+      DF3D_HIP(hipEventRecord(e, stream));               // inputs (voxel features / coordinates) are ready
+      DF3D_HIP(hipStreamWaitEvent(gstream, e, 0));
+    }
   }
   void *gs_ = (void *)gstream;
   Bump mem(arena, arena_bytes);

@@ -153,6 +153,7 @@ SIGNATURES = {
     "df3d_voxel_image_sample": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),
+    "df3d_backbone_inputs_ready": (c_int, [c_void_p]),
     "df3d_lt_layer_packed_bytes": (c_longlong, []),
     "df3d_lt_layer_vector_floats": (c_int, []),
     "df3d_lt_layer": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),

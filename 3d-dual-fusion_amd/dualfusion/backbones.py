@@ -398,11 +398,11 @@ class SparseEncoderFusion(SparseEncoder):
     def coor2pts(self, x, pad=0.0):
         """:309-319: voxel index (+pad) -> metric (x, y, z); ratio taken from the y dimension."""
         ratio = self.sparse_shape[1] / x.spatial_shape[1]
-        scale = torch.tensor((list(self.voxel_size) + [1])[::-1], dtype=torch.float32, device=x.indices.device)
+        scale = _ops.device_constant([float(v) for v in (list(self.voxel_size) + [1])[::-1]], torch.float32, x.indices.device)
         pts = (x.indices.to(torch.float) + pad) * scale * ratio
         pts[:, 0] = pts[:, 0] / ratio - pad
-        pts[:, 1:] += torch.tensor(self.point_cloud_range[:3][::-1], dtype=torch.float32, device=pts.device)
-        pts[:, 1:] = pts[:, [3, 2, 1]]
+        pts[:, 1:] += _ops.device_constant([float(v) for v in self.point_cloud_range[:3][::-1]], torch.float32, pts.device)
+        pts[:, 1:] = pts[:, 1:].flip(1)            # (z, y, x) -> (x, y, z); a Python index list would be a host -> device copy
         return pts            # [N, 4] (b, x, y, z); rows are batch-sorted
 
     def forward(self, voxel_features, coors, batch_size, img_feats=None, img_metas=None, points=None,
@@ -507,6 +507,17 @@ class VoxelBackBone8x(nn.Module):
     def _prefetch_fuse4(self, coords, batch_dict, ready):
         return None
 
+    def _throttle(self, depth=2):
+        """Back-pressure for callers that run ahead of the GPU (side-stream work that no longer waits for the previous frame):
+        at most `depth` frames in flight -- the side stream's buffers of frame k are released when frame k + 2 starts."""
+        q = self.__dict__.setdefault("_inflight", [])
+        if len(q) >= depth:
+            q.pop(0).synchronize()
+
+    def _frame_done(self):
+        q = self.__dict__.setdefault("_inflight", [])
+        q.append(torch.cuda.current_stream().record_event())
+
     def _fuse4(self, x_conv2, x_conv3, x_conv4, batch_dict):
         return x_conv4
 
@@ -519,7 +530,11 @@ class VoxelBackBone8x(nn.Module):
             # (measured: starting the side stream's work here, before the first segment is queued, beats starting it after
             # conv1 -- 19.1 vs 19.6 ms per step: furthest point sampling is the longest chain of the step, every
             # microsecond it starts earlier counts; without it 20.6 ms)
-            self._prefetch_fuse4(x0.indices, batch_dict, torch.cuda.current_stream().record_event())
+            # ... and it waits for the COORDINATES only: the voxeliser's own event when it ran on the voxel stream
+            # (ops.hard_voxelize_clouds), else everything queued on this stream so far
+            ready = getattr(voxel_coords, "_df3d_ready", None) or torch.cuda.current_stream().record_event()
+            self._throttle()
+            self._prefetch_fuse4(x0.indices, batch_dict, ready)
             keep = {}
 
             def hook(i, name, t):
@@ -539,6 +554,8 @@ class VoxelBackBone8x(nn.Module):
             x_conv3 = self.conv3(x_conv2)
             x_conv4 = self._fuse4(x_conv2, x_conv3, self.conv4(x_conv3), batch_dict)
         out = self.conv_out(x_conv4)
+        if runner is not None:
+            self._frame_done()
         batch_dict.update({"encoded_spconv_tensor": out, "encoded_spconv_tensor_stride": 8})
         batch_dict.update({"multi_scale_3d_features": {"x_conv1": x_conv1, "x_conv2": x_conv2, "x_conv3": x_conv3,
                                                        "x_conv4": x_conv4}})
@@ -596,7 +613,7 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
     def _voxel_xyz(self, ind, voxel_stride, batch_dict):
         """voxel corner (b,z,y,x) -> LiDAR xyz of the point cloud the camera saw."""
         v3d = ind[:, 1:].float() * voxel_stride * self.voxel_size + self.point_cloud_range[:3]      # (z,y,x)
-        xyz = v3d[:, [2, 1, 0]]
+        xyz = v3d.flip(1)                            # (z, y, x) -> (x, y, z) without a host index list
         bi = ind[:, 0].long()
         # the point cloud the camera saw: undo the recorded augmentations in the reference's order (:701-714) --
         # global scale, rotation about z by -noise_rot (rotate_points_along_z, VR/pcdet/utils/common_utils.py:35-57),
@@ -646,7 +663,10 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         coordinates, the 'unique' winners.  They are computed HERE, on a side stream that waits for the input coordinates
         only (`ready`), and run beside the backbone's convolutions; `_fuse4` waits for the event.  The reference computes them after conv4
         and again in every encoder layer (VR actr_transformer.py:482-486)."""
-        previous = self.__dict__.pop("_fuse4_pre", None)
+        # the side stream's tensors of frame k - 1 may still be read by the main stream (this chain no longer waits for it):
+        # they are released one frame later, when `_throttle` has seen frame k - 1 complete
+        self.__dict__["_fuse4_pre_old"] = self.__dict__.pop("_fuse4_pre", None)
+        previous = None
         if (4 not in self.fusion_pos or "ACTR" not in self.fusion_method or torch.is_grad_enabled()
                 or os.environ.get("DF3D_VR_PREFETCH", "1") != "1" or not coords.is_cuda or coords.shape[0] == 0):
             return
@@ -807,7 +827,7 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         grid = feats.new_zeros((B, n_max, 2))
         v_feat[b, slot] = feats
         v_i[b, slot] = i_feat
-        grid[b, slot] = uv / torch.tensor([hw[1], hw[0]], dtype=torch.float32, device=uv.device)
+        grid[b, slot] = uv / _ops.device_constant([float(hw[1]), float(hw[0])], torch.float32, uv.device)
         enh = self.actr(v_feat=v_feat, v_i_feat=v_i, grid=grid, i_feats=x_rgb, lidar_grid=pts)
         return x_conv4.replace_feature(enh[b, slot] + feats)                  # fuse_sum=True (:808-810)
 

@@ -58,7 +58,10 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
         csrc/fusion.hip "Image-side gate without dense canvases"):
           T[idx] [9, C_idx+3]: tap responses of a voxel row of scale idx;  kg [19] = k_t, g_t, bias;
           w3 [1, Cimg], b3: the 1-channel image summary (reduced_dim3)."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        ps = self.__dict__.get("_param_list")
+        if ps is None:                                # collected once: the module-tree walk of parameters() is host time per step
+            ps = self.__dict__["_param_list"] = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in ps)
         hit = getattr(self, "_folded", None)
         if hit is not None and hit[0] == key:
             return hit[1]

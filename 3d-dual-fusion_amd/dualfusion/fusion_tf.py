@@ -37,8 +37,11 @@ class ACTRFusionLayer(nn.Module):
     # ------------------------------------------------------------------ geometry
     @staticmethod
     def _calib(img_metas, dev):
-        l2c = torch.stack([torch.as_tensor(m['lidar2cam'], dtype=torch.float32) for m in img_metas]).to(dev)   # [B,6,4,4]
-        K = torch.stack([torch.as_tensor(m['cam_intrinsic'], dtype=torch.float32) for m in img_metas]).to(dev)  # [B,6,3,3]
+        import numpy as np
+        from . import ops as _ops
+        # cached by value (ops.device_constant): a per-call host -> device copy drains the stream first
+        l2c = _ops.device_constant(np.stack([np.asarray(m['lidar2cam'], np.float32) for m in img_metas]), torch.float32, dev)  # [B,6,4,4]
+        K = _ops.device_constant(np.stack([np.asarray(m['cam_intrinsic'], np.float32) for m in img_metas]), torch.float32, dev)  # [B,6,3,3]
         return l2c, K
 
     @staticmethod
@@ -94,19 +97,22 @@ class ACTRFusionLayer(nn.Module):
         uvw = (K[b] * cam[:, :, None, :]).sum(-1)
         u = uvw[..., 0] / uvw[..., 2]
         v = uvw[..., 1] / uvw[..., 2]
-        ori = torch.tensor([[m['ori_shape'][0], m['ori_shape'][1]] for m in img_metas], dtype=torch.float32, device=dev)
+        from . import ops as _ops
+        const = lambda v, dt=torch.float32: _ops.device_constant(v, dt, dev)         # noqa: E731  (cached by value)
+        ori = const([[m['ori_shape'][0], m['ori_shape'][1]] for m in img_metas])
         H = ori[b, 0][:, None]
         W = ori[b, 1][:, None]
         vis = (depth > 1.0) & (u > 1) & (u < W - 1) & (v > 1) & (v < H - 1)
-        sf = torch.tensor([list(m.get('scale_factor', [1.0, 1.0]))[:2] for m in img_metas], dtype=torch.float32, device=dev)
-        off = torch.tensor([list(m.get('img_crop_offset', [0.0, 0.0]))[:2] if not isinstance(m.get('img_crop_offset', 0), (int, float))
-                            else [float(m.get('img_crop_offset', 0))] * 2 for m in img_metas], dtype=torch.float32, device=dev)
+        sf = const([[float(v) for v in list(m.get('scale_factor', [1.0, 1.0]))[:2]] for m in img_metas])
+        off = const([[float(v) for v in list(m.get('img_crop_offset', [0.0, 0.0]))[:2]]
+                     if not isinstance(m.get('img_crop_offset', 0), (int, float))
+                     else [float(m.get('img_crop_offset', 0))] * 2 for m in img_metas])
         x = u * sf[b, 0][:, None] - off[b, 0][:, None]
         y = v * sf[b, 1][:, None] - off[b, 1][:, None]
-        flip = torch.tensor([bool(m.get('flip', False)) for m in img_metas], device=dev)
-        iw = torch.tensor([m['img_shape'][1] for m in img_metas], dtype=torch.float32, device=dev)
+        flip = const([bool(m.get('flip', False)) for m in img_metas], torch.bool)
+        iw = const([float(m['img_shape'][1]) for m in img_metas])
         x = torch.where(flip[b][:, None], iw[b][:, None] - x, x)
-        pad = torch.tensor([[m['input_shape'][0], m['input_shape'][1]] for m in img_metas], dtype=torch.float32, device=dev)
+        pad = const([[float(m['input_shape'][0]), float(m['input_shape'][1])] for m in img_metas])
         # last visible camera wins; none -> camera 0 at (0,0)
         ncam = vis.shape[1]
         order = torch.arange(1, ncam + 1, device=dev)[None, :] * vis.long()

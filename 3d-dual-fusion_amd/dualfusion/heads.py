@@ -208,10 +208,25 @@ class CenterHead(nn.Module):
 
     # ------------------------------------------------------------------ the three conv depths as three launches
     def train(self, mode=True):
-        self.__dict__.pop("_row_plan", None)
+        for k in ("_row_plan", "_row_fit", "_plan_tensors"):
+            self.__dict__.pop(k, None)
         return super(CenterHead, self).train(mode)
 
+    def _state_tensors(self):
+        """Every parameter and buffer of the head, collected ONCE (the module tree walk of `parameters()` cost ~1 ms of host
+        time per step); the objects stay valid across load_state_dict / optimizer steps, `train()` drops the list."""
+        ts = self.__dict__.get("_plan_tensors")
+        if ts is None:
+            ts = self.__dict__["_plan_tensors"] = list(self.parameters()) + list(self.buffers())
+        return ts
+
     def _row_kernels_fit(self, x):
+        hit = self.__dict__.get("_row_fit")
+        if hit is None:
+            hit = self.__dict__["_row_fit"] = self._row_kernels_fit_uncached()
+        return hit
+
+    def _row_kernels_fit_uncached(self):
         sc = self.shared_conv[0]
         ok = sc.in_channels == 512 and sc.out_channels == 64 and sc.kernel_size == (3, 3)
         for task in self.tasks:
@@ -244,8 +259,7 @@ class CenterHead(nn.Module):
         return scale, bn.bias.float() - bn.running_mean.float() * scale
 
     def _plan(self):
-        params = [p for p in self.parameters()] + [b for b in self.buffers()]
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = tuple((p.data_ptr(), p._version) for p in self._state_tensors())
         plan = self.__dict__.get("_row_plan")
         if plan is not None and plan["key"] == key:
             return plan
@@ -297,7 +311,7 @@ class CenterHead(nn.Module):
         channels; 64 -> 128 per group = two branches) into a [pixels, 64 * branches] buffer; the final convs as ONE grouped
         launch, each group reading its branch's 64 columns of that buffer in place (64 -> classes padded to 16)."""
         from .necks import _rows_of
-        key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        key = tuple((p.data_ptr(), p._version) for p in self._state_tensors())
         plan = self.__dict__.get("_row_plan_fp32")
         if plan is None or plan["key"] != key:
             sc, sbn = self.shared_conv[0], self.shared_conv[1]

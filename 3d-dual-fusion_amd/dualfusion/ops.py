@@ -37,6 +37,26 @@ def _chk(t, dtype, name):
     return t
 
 
+# ------------------------------------------------------------------------- small host constants on the device
+_CONST_CACHE = {}
+
+
+def device_constant(values, dtype, device):
+    """Device tensor holding `values` (nested lists / numpy / scalars), cached BY VALUE.  `torch.tensor(values, device=...)`
+    per call is a copy from pageable memory: the host blocks until the stream has drained before it (measured: ten such
+    calls per step = 1.3 ms of the 8.4 ms TransFusion step, one = 1.4 ms of the Voxel-RCNN step).  Calibration / shape
+    metadata repeats from frame to frame; the cache holds the last 256 distinct values.  The result must not be modified."""
+    import numpy as np
+    arr = np.ascontiguousarray(np.asarray(values))
+    key = (arr.tobytes(), arr.shape, str(arr.dtype), dtype, str(device))
+    hit = _CONST_CACHE.get(key)
+    if hit is None:
+        if len(_CONST_CACHE) >= 256:
+            _CONST_CACHE.clear()
+        hit = _CONST_CACHE[key] = torch.as_tensor(arr).to(device=device, dtype=dtype)
+    return hit
+
+
 # ------------------------------------------------------------------------- voxelize
 _PINNED_COUNTS = {}
 
@@ -119,9 +139,14 @@ def hard_voxelize_clouds(clouds, voxel_size, coors_range, max_points, max_voxels
             while_waiting()                                   # independent work of the caller goes to ITS stream first
         with torch.cuda.stream(vs):
             feats, coors = hard_voxelize_clouds(clouds, voxel_size, coors_range, max_points, max_voxels, break_at_cap)
+            done = torch.cuda.Event()
+            done.record(vs)
         main.wait_stream(vs)
         feats.record_stream(main)
         coors.record_stream(main)
+        # consumers whose work depends on the coordinates alone (index sets, furthest point sampling ...) may wait for THIS
+        # event on their own stream instead of for the caller's stream, i.e. start before the previous frame has finished
+        coors._df3d_ready = done
         return feats, coors
     if len(clouds) == 1:
         _, c, _, mean = hard_voxelize(clouds[0], voxel_size, coors_range, max_points, max_voxels, break_at_cap=break_at_cap,

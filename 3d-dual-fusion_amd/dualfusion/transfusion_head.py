@@ -198,7 +198,7 @@ class TransFusionBBoxCoder(object):
             return [dict(bboxes=boxes[i], scores=final_scores[i], labels=final_preds[i]) for i in range(B)]
         if self.post_center_range is None:
             raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range is not None for now!')
-        rng = torch.tensor(self.post_center_range, device=heatmap.device, dtype=boxes.dtype)
+        rng = _ops.device_constant([float(v) for v in self.post_center_range], boxes.dtype, heatmap.device)
         mask = (boxes[..., :3] >= rng[:3]).all(2) & (boxes[..., :3] <= rng[3:]).all(2)
         if self.score_threshold:
             mask &= final_scores > self.score_threshold
@@ -337,6 +337,7 @@ class TransFusionHead(nn.Module):
 
     def train(self, mode=True):
         self.__dict__.pop("_row_plan", None)
+        self.__dict__.pop("_plan_tensors", None)
         return super(TransFusionHead, self).train(mode)
 
     # ------------------------------------------------------------------ plain torch path (training / CPU)
@@ -427,7 +428,9 @@ class TransFusionHead(nn.Module):
         return scale.contiguous(), (bn.bias.detach().float() - bn.running_mean.float() * scale).contiguous()
 
     def _plan(self):
-        params = [p for p in self.parameters()] + [b for b in self.buffers()]
+        params = self.__dict__.get("_plan_tensors")
+        if params is None:                            # collected once (train() drops it): parameters() walks the module tree
+            params = self.__dict__["_plan_tensors"] = [p for p in self.parameters()] + [b for b in self.buffers()]
         key = tuple((p.data_ptr(), p._version) for p in params)
         plan = self.__dict__.get("_row_plan")
         if plan is not None and plan["key"] == key:
@@ -696,11 +699,10 @@ class TransFusionHead(nn.Module):
         dim = max([t.shape[1] for t in boxes] + [7])
         gt = torch.cat([t.reshape(-1, dim) for t in boxes]) if sum(counts) else torch.zeros((0, dim))
         lab = torch.cat([l.reshape(-1) for l in gt_labels_3d]).to(torch.int32) if sum(counts) else torch.zeros((0,), dtype=torch.int32)
-        off = torch.zeros(len(counts) + 1, dtype=torch.int32)
-        off[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int32), 0)
+        import numpy as np
+        off = _ops.device_constant(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), torch.int32, dev)   # cached by value
         nb = gt.device.type == "cpu"
-        return (gt.to(dev, non_blocking=nb).contiguous(), lab.to(dev, non_blocking=nb).contiguous(),
-                off.to(dev, non_blocking=True), counts)
+        return (gt.to(dev, non_blocking=nb).contiguous(), lab.to(dev, non_blocking=nb).contiguous(), off, counts)
 
     def _match_cfg(self):
         a, c = self.bbox_assigner, self.bbox_coder

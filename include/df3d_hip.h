@@ -783,6 +783,16 @@ typedef struct df3d_layer_view {
   int reserved;          /* bit 1: `split` holds bf16 rows [n][channels] instead of split rows */
 } df3d_layer_view;
 
+/* Optional, before df3d_backbone_run on the same host thread (consumed by that call): `event` (hipEvent_t) marks the input
+ * COORDINATES complete -- e.g. recorded by a voxeliser that ran on its own stream.  The geometry stream then waits for this
+ * event instead of for everything queued on the caller's stream, so the rulebooks (and the host's round trips for the output
+ * counts) of frame k + 1 proceed while frame k is still running on the caller's stream.  The caller guarantees that `arena` is
+ * not read or written by work still queued on `stream`, bounds the runs in flight (16 event sets rotate), and that NOTHING
+ * it later reads on other streams relied on the old implicit order "host passed a count round trip => the caller's stream has
+ * reached this call".  Without this call the geometry waits for the caller's stream, as before.  (Round 3: built and measured
+ * -- the Python side does not use it yet: the fusion adapters' side streams read calibration tensors produced on the caller's
+ * stream under exactly that implicit order) */
+int df3d_backbone_inputs_ready(void *event);
 int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *features, const int32_t *indices, int n,
                       int in_channels, int batch, const int *shape_host, void *arena, size_t arena_bytes,
                       df3d_layer_view *views, size_t *arena_used, void *stream);
