@@ -113,14 +113,18 @@ class CenterPointDetector(nn.Module):
     def neck(self):
         return self.hot_path.neck
 
-    def training_step(self, points_list, example, batch_dict=None):
+    def training_step(self, points_list, example, batch_dict=None, host_copies=True):
         """One forward + backward of the detector in train() mode, the way the reference's trainer drives it
         (`model(example, return_loss=True)` -> `parse_second_losses` -> `loss.backward()`, CP/det3d/torchie/trainer/
         trainer.py:366-380): voxelisation without gradients, then backbone (sparse-conv autograd Functions, BatchNorm in
         torch; with `fusion=` the camera adapter's differentiable composition, `VoxelWithPointProjection.
         forward_autograd`, between conv4 and the dense map) -> dense BEV -> RPN neck -> CenterHead -> `loss` (the
         reference's composition) -> backward.  The caller owns gradient reduction and the optimizer.  Returns the merged
-        loss dict."""
+        loss dict.
+        host_copies: True = the reference's logging copies (`hm_loss` / `loc_loss_elem` as CPU tensors: `.cpu()` right after the
+        backward is queued -- the host then waits for the whole backward before it queues the optimizer step and the next frame);
+        "async" = the same values into pinned host memory without waiting: they are valid once `rets["host_copies_ready"]`
+        (an event) has completed, and the host goes on queueing -- a trainer that logs every N steps synchronises there."""
         hp = self.hot_path
         if hp.fusion is not None and batch_dict is None:
             raise ValueError("training_step: a detector with a camera-fusion adapter needs batch_dict (camera features / calibration)")
@@ -141,6 +145,16 @@ class CenterPointDetector(nn.Module):
                 sum(rets["loss"]).backward()
         finally:
             hp.backbone.dense_layout = layout
+        if host_copies == "async":
+            for key in ("hm_loss", "loc_loss_elem"):
+                outs = []
+                for v in rets[key]:
+                    h = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                    h.copy_(v.detach(), non_blocking=True)
+                    outs.append(h)
+                rets[key] = outs
+            rets["host_copies_ready"] = torch.cuda.current_stream().record_event()
+            return rets
         for key in ("hm_loss", "loc_loss_elem"):            # the reference's host copies, once the backward is queued
             rets[key] = [v.cpu() for v in rets[key]]
         return rets

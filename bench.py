@@ -182,7 +182,10 @@ class CenterPointWorkload(object):
             if getattr(self, "reducer", None) is None:
                 self._train_setup()
             self.reducer.zero_grad()
-            rets = self.model.training_step(fr["points"], example, batch_dict=bd)
+            # logging copies without a host wait (a trainer reads them every N steps, behind `host_copies_ready`): the host
+            # queues the optimizer step and the next frame while the backward still runs
+            rets = self.model.training_step(fr["points"], example, batch_dict=bd,
+                                            host_copies="async" if os.environ.get("DF3D_TRAIN_ASYNC_LOG", "1") == "1" else True)
             self.reducer.finish()                      # waits for the bucket all-reduces launched during backward
             self.optimizer.step()
             return {k: torch.stack([v.detach().to(self.dev).float().reshape(()) for v in rets[k]])
