@@ -1,5 +1,7 @@
 """TransFusion and Voxel-RCNN flavours of the hot path (BASELINE configs 3-5 shapes, reduced grids):
 sparse encoders vs the oracle compositions; fusion-layer glue vs loop restatements of the reference code."""
+import os
+
 import numpy as np
 import pytest
 
@@ -463,3 +465,54 @@ def test_voxel_image_sample_kernel_equals_the_torch_composition(aug):
             rg = torch.zeros(B, n_max, 2, device=dev)
             rg[b, slot] = uv / torch.tensor([W, H], dtype=torch.float32, device=dev)
             assert torch.equal(out.view(B, n_max, C), ref) and torch.equal(grid.view(B, n_max, 2), rg)
+
+
+def test_pipelined_frames_equal_isolated_frames():
+    """bench.py's mode of the Voxel-RCNN tree and of the CenterPoint detector: resident point clouds voxelised on the voxel
+    stream (`hard_voxelize_clouds(resident_inputs=True)`), the stride-8 query geometry on a side stream that waits for the
+    voxeliser's event only, two frames in flight at most, NO synchronisation between frames -- against the same frames run
+    one at a time with a device synchronisation after each and everything on the current stream.  Outputs must be
+    identical, frame by frame, over several rounds (buffers of frame k are released while frame k + 1 / k + 2 run)."""
+    import types
+    from dualfusion import ops, synth, workloads
+    from dualfusion.fusion import build_centerpoint_fusion, synthetic_camera_inputs
+    from dualfusion.pipeline import CenterPointHotPath
+    dev = torch.device("cuda:0")
+    args = types.SimpleNamespace(workload="vr_fusion", frames=3, batch=2, inflight=1)
+    wl = workloads.make(args, 0, 1, dev)
+    old = os.environ.get("DF3D_VOXEL_STREAM")
+    try:
+        os.environ["DF3D_VOXEL_STREAM"] = "0"
+        want = []
+        for k in range(3):
+            out = wl.step(k, "detect")
+            torch.cuda.synchronize()
+            want.append((out["encoded_spconv_tensor"].features.clone(), out["encoded_spconv_tensor"].indices.clone()))
+        os.environ["DF3D_VOXEL_STREAM"] = "1"
+        got = []
+        for k in range(9):                                        # three rounds over the frames, back to back
+            out = wl.step(k, "detect")
+            got.append((out["encoded_spconv_tensor"].features.clone(), out["encoded_spconv_tensor"].indices.clone()))
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop("DF3D_VOXEL_STREAM", None)
+        else:
+            os.environ["DF3D_VOXEL_STREAM"] = old
+    for k, (f, i) in enumerate(got):
+        assert torch.equal(i, want[k % 3][1]) and torch.equal(f, want[k % 3][0]), k
+    # CenterPoint hot path with the camera fusion: resident inputs on / off
+    torch.manual_seed(0)
+    m = CenterPointHotPath(fusion=build_centerpoint_fusion()).eval().to(dev)
+    frames = [([torch.from_numpy(synth.nusc_sweep(seed=40 + j)).to(dev)], synthetic_camera_inputs(1, dev, seed=j)) for j in range(3)]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = []
+        for pts, (bd, ex) in frames:
+            want.append(m(pts, batch_dict=dict(bd), example=dict(ex))[0].clone())
+            torch.cuda.synchronize()
+        m.resident_inputs = True
+        got = [m(pts, batch_dict=dict(bd), example=dict(ex))[0].clone() for _ in range(3) for pts, (bd, ex) in frames]
+        torch.cuda.synchronize()
+    for k, y in enumerate(got):
+        assert torch.equal(y, want[k % 3]), k
