@@ -404,6 +404,110 @@ __global__ __launch_bounds__(256) void assemble_queries2_kernel(AsmArgs2 a) {
   }
 }
 
+// assemble_queries2 with the LANES OVER QUERIES (round 3).  The kernel above gives a query to a wave and strides its lanes
+// over the image channels of a channel-first map: 64 lanes = 64 different 64-byte sectors for 256 useful bytes (77 us for
+// 18.6 k queries, 265 us at four samples: 3 % of the HBM rate).  Voxel rows are sorted by cell, so CONSECUTIVE SLOTS of a
+// camera's query list are neighbouring voxels and project to neighbouring pixels: here a workgroup owns 64 consecutive slots
+// of one image, lane = slot, and walks the channels -- one load instruction reads the 64 queries' pixels of one channel
+// plane (a handful of sectors), the values meet in an LDS tile and leave as whole rows.  The voxel of a slot is found by
+// binary search in the camera's monotone slot table (no inverse table, no extra launch).  Same values as the kernel above.
+constexpr int ASM3_CH = 64;      // channels per LDS tile
+__global__ __launch_bounds__(256) void assemble_queries3_kernel(AsmArgs2 a, const int32_t *__restrict__ counts) {
+  __shared__ float tile[64][ASM3_CH + 1];
+  __shared__ int rowL[64], pixL[64];
+  __shared__ float gL[64];
+  const int img = blockIdx.y, cam = img % a.ncam, b = img / a.ncam;
+  const int cnt = counts[img] < a.max_ne ? counts[img] : a.max_ne;
+  const int s0 = blockIdx.x * 64;
+  if (s0 >= cnt) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t hw = (size_t)a.H * a.W;
+  if (tid < 64) {
+    int row = -1, pix = 0;
+    float g = 0.f;
+    const int s = s0 + tid;
+    if (s < cnt) {
+      // rows of sample b: [lo, hi); inside, pos[cam][.] counts the visible rows before each row
+      int lo = 0, hi = a.n;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a.ind[(size_t)mid * 4] < b) lo = mid + 1;
+        else hi = mid;
+      }
+      int r0 = lo;
+      hi = a.n;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a.ind[(size_t)mid * 4] < b + 1) lo = mid + 1;
+        else hi = mid;
+      }
+      int r1 = lo;
+      const int32_t *pc = a.pos + (size_t)cam * a.n;
+      const uint8_t *mc = a.mask + (size_t)cam * a.n;
+      // pos is the EXCLUSIVE count of visible rows: it equals s on the invisible rows in front of the slot's voxel and on the
+      // voxel itself, s + 1 behind it -- the voxel is the last row with pos <= s
+      lo = r0, hi = r1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pc[mid] <= s) lo = mid + 1;
+        else hi = mid;
+      }
+      row = lo - 1;
+      if (!mc[row]) row = -1;                // cannot happen for s < cnt; guards a corrupt table
+      if (row >= 0) {
+        const int gx = a.grid[((size_t)cam * a.n + row) * 2], gy = a.grid[((size_t)cam * a.n + row) * 2 + 1];
+        pix = gy * a.W + gx;
+        g = a.att ? a.att[(size_t)img * hw + pix] : 1.f;
+      }
+      if (row >= 0 && blockIdx.z == 0) {
+        const int gx = a.grid[((size_t)cam * a.n + row) * 2], gy = a.grid[((size_t)cam * a.n + row) * 2 + 1];
+        const size_t q = (size_t)img * a.max_ne + s;
+        a.qgrid[q * 2 + 0] = (float)gx / (float)a.W;
+        a.qgrid[q * 2 + 1] = (float)gy / (float)a.H;
+        a.qpts[q * 3 + 0] = a.pinv[(size_t)row * 3 + 0];
+        a.qpts[q * 3 + 1] = a.pinv[(size_t)row * 3 + 1];
+        a.qpts[q * 3 + 2] = a.pinv[(size_t)row * 3 + 2];
+      }
+    }
+    rowL[tid] = row;
+    pixL[tid] = pix;
+    gL[tid] = g;
+  }
+  __syncthreads();
+  const float *base = a.img ? a.img + (size_t)img * a.Ci * hw : a.img_ptrs[img];
+  // image features: [channel chunk][slot] loads (lane = slot), [slot][channel] stores (lane = channel)
+  for (int c0 = blockIdx.z * ASM3_CH; c0 < a.Ci; c0 += gridDim.z * ASM3_CH) {     // channel chunks over blockIdx.z
+    const int myrow = rowL[lane];
+    const float g = gL[lane];
+    const float *src = base + pixL[lane];
+#pragma unroll 4
+    for (int c = wave; c < ASM3_CH; c += 4)
+      tile[lane][c] = (myrow >= 0 && c0 + c < a.Ci) ? src[(size_t)(c0 + c) * hw] * g : 0.f;
+    __syncthreads();
+    for (int r = wave; r < 64; r += 4) {
+      if (rowL[r] < 0 || c0 + lane >= a.Ci) continue;
+      a.v_i_feat[((size_t)img * a.max_ne + s0 + r) * a.Ci + c0 + lane] = tile[r][lane];
+    }
+    __syncthreads();
+  }
+  // voxel features and the depth position embedding: row copies, lane = channel
+  if (blockIdx.z != 0) return;
+  for (int r = wave; r < 64; r += 4) {
+    const int row = rowL[r];
+    if (row < 0) continue;
+    const size_t q = (size_t)img * a.max_ne + s0 + r;
+    for (int c = lane; c < a.C; c += 64) a.v_feat[q * a.C + c] = a.feat[(size_t)row * a.C + c];
+    if (a.qpos) {
+      const float d = a.pinv[(size_t)row * 3] / 60.f * 6.283185307179586f;
+      for (int c = lane; c < a.C; c += 64) {
+        const float dim_t = powf(10000.f, (float)(2 * (c / 2)) / (float)a.C);
+        const float v = d / dim_t;
+        a.qpos[q * a.C + c] = (c & 1) ? cosf(v) : sinf(v);
+      }
+    }
+  }
+}
+
 // position embedding of a padded (all-zero) query: sin(0) = 0 on even, cos(0) = 1 on odd channels
 __global__ __launch_bounds__(256) void qpos_pad_kernel(float *__restrict__ qpos, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -536,7 +640,15 @@ extern "C" int df3d_assemble_queries2(const float *features, const float *point_
                  "assemble_queries2: null input");
   AsmArgs2 a = {features, point_inv, indices, grid_xy, mask, pos, img_feats, img_ptrs, att, n, channels, img_channels, ncam, H, W,
                 max_ne, v_feat, v_i_feat, qgrid, qpts, qpos};
-  hipLaunchKernelGGL(assemble_queries2_kernel, dim3(cdiv((long long)n * ncam * 64, 256)), dim3(256), 0, stream, a);
+  // measured on MI355X: lanes over queries 265 -> ~150 us at four samples x six cameras (TransFusion tree, step 8.02 -> 7.91 ms),
+  // but 96-100 us against 82-85 us of the wave-per-query kernel at one sample (too few workgroups): chosen by image count;
+  // DF3D_ASSEMBLE=1 / 2 forces one or the other
+  static const int forced = getenv("DF3D_ASSEMBLE") ? atoi(getenv("DF3D_ASSEMBLE")) : 0;
+  const bool by_slot = forced == 1 || (forced != 2 && batch * ncam >= 12);
+  if (counts && by_slot)      // lanes over queries (needs the list lengths)
+    hipLaunchKernelGGL(assemble_queries3_kernel, dim3(cdiv(max_ne, 64), batch * ncam, cdiv(img_channels, ASM3_CH)), dim3(256), 0, stream, a, counts);
+  else
+    hipLaunchKernelGGL(assemble_queries2_kernel, dim3(cdiv((long long)n * ncam * 64, 256)), dim3(256), 0, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -1300,3 +1300,42 @@ def test_hard_voxelize_clouds_equals_per_cloud_calls(dev):
         f, c = ops.hard_voxelize_clouds(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 40000, while_waiting=ww)
         assert torch.equal(f, torch.cat(feats)) and torch.equal(c, torch.cat(coors))
     assert flag == [1] and not bool((torch.cat(coors)[:, 0] == 1).any())
+
+
+def test_assemble_queries_by_slot_equals_by_voxel(dev):
+    """df3d_assemble_queries2 with the lanes over the queries of an image (taken for >= 12 images when the list lengths are
+    given: B = 4 x 3 cameras here) against the wave-per-voxel kernel (no list lengths):
+    identical query tensors, incl. gate, depth position embedding, images given as a pointer table, empty lists."""
+    import ctypes
+    from dualfusion import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    B, ncam, H, W, C, Ci, n = 4, 3, 20, 36, 128, 256, 5000
+    ind = torch.zeros(n, 4, dtype=torch.int32)
+    ind[:, 0] = (torch.arange(n) >= 2600).int() + (torch.arange(n) >= 3700).int() + (torch.arange(n) >= 4400).int()
+    mask = (torch.rand(ncam, n, generator=g) < 0.3).to(torch.uint8)
+    mask[2, :2600] = 0                                               # an empty list (sample 0, camera 2)
+    grid = torch.stack([torch.randint(0, W, (ncam, n), generator=g), torch.randint(0, H, (ncam, n), generator=g)], 2).int()
+    feat, pinv = torch.randn(n, C, generator=g), torch.rand(n, 3, generator=g) * 50
+    img, att = torch.randn(B * ncam, Ci, H, W, generator=g), torch.rand(B * ncam, H, W, generator=g)
+    t = lambda x: x.to(dev).contiguous()                             # noqa: E731
+    ind, mask, grid, feat, pinv, img, att = [t(x) for x in (ind, mask, grid, feat, pinv, img, att)]
+    pos = torch.empty((ncam, n), dtype=torch.int32, device=dev)
+    counts = torch.empty((B * ncam,), dtype=torch.int32, device=dev)
+    P = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None else ctypes.c_void_p(0)   # noqa: E731
+    _lib.check(lib.df3d_query_slots(P(mask), P(ind), n, B, ncam, P(pos), P(counts), ops._stream()))
+    max_ne = int(counts.max())
+    assert int(counts[2]) == 0
+
+    def run(with_counts, use_att, use_pos):
+        outs = [torch.full((B * ncam, max_ne, k), -3.0, device=dev) for k in (C, Ci, 2, 3, C)]
+        if not with_counts:
+            pass                                                    # the entry clears everything itself
+        _lib.check(lib.df3d_assemble_queries2(P(feat), P(pinv), P(ind), P(grid), P(mask), P(pos), P(img), None, P(att) if use_att else None,
+                                              n, C, Ci, B, ncam, H, W, max_ne, P(outs[0]), P(outs[1]), P(outs[2]), P(outs[3]),
+                                              P(outs[4]) if use_pos else None, P(counts) if with_counts else None, ops._stream()))
+        return outs[:4] + ([outs[4]] if use_pos else [])
+    for use_att, use_pos in ((True, True), (False, False)):
+        a, b = run(True, use_att, use_pos), run(False, use_att, use_pos)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
