@@ -116,6 +116,8 @@ class CenterPointWorkload(object):
         self.model = CenterPointDetector(fusion=fusion).eval().to(dev)
         # the sweeps are resident inputs, complete before the timed region: voxelisation may run on its own stream
         self.model.hot_path.resident_inputs = os.environ.get("DF3D_VOXEL_STREAM", "1") == "1"
+        if fusion is not None:
+            fusion.resident_inputs = self.model.hot_path.resident_inputs
         self.num_classes = [t["num_class"] for t in NUSC_TASKS]
         self.frames = []
         for f in range(max(1, args.frames)):

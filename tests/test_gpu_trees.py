@@ -511,8 +511,8 @@ def test_pipelined_frames_equal_isolated_frames():
         for pts, (bd, ex) in frames:
             want.append(m(pts, batch_dict=dict(bd), example=dict(ex))[0].clone())
             torch.cuda.synchronize()
-        m.resident_inputs = True
-        got = [m(pts, batch_dict=dict(bd), example=dict(ex))[0].clone() for _ in range(3) for pts, (bd, ex) in frames]
+        m.resident_inputs = m.fusion.resident_inputs = True
+        got = [m(pts, batch_dict=dict(bd), example=dict(ex))[0].clone() for _ in range(4) for pts, (bd, ex) in frames]
         torch.cuda.synchronize()
-    for k, y in enumerate(got):
-        assert torch.equal(y, want[k % 3]), k
+        for k, y in enumerate(got):
+            assert torch.equal(y, want[k % 3]), k
