@@ -166,6 +166,15 @@ MODELS = {
     "df3d_bigate_sum": lambda a, x: _rows(2 * a[6] * a[7], 2 * a[6] * a[7], "bidirectional gate (%d rows)" % a[6]),
     "df3d_rows_groupnorm": lambda a, x: _rows(2 * a[1] * a[2] * a[3], a[1] * a[2] * a[3], "GroupNorm over query rows (two passes)"),
     "df3d_fusion_writeback": lambda a, x: _rows(a[5] * a[6] + a[7] * a[8] * a[6], a[5] * a[6], "additive write-back of %d voxels" % a[5]),
+    "df3d_rows_linear": lambda a, x: (a[3] * (a[4] + a[6]) * 4 + a[4] * a[6] * 4, 2 * a[3] * a[4] * a[6], "hbm",
+                                      "query linear %d -> %d over %d rows (one input stream counted)" % (a[4], a[6], a[3])),
+    "df3d_lt_layer": lambda a, x: (2 * a[1] * a[2] * a[3] * 4, a[1] * a[2] * 2 * (3 * 64 * 64 + 64 * 64 + 2 * 128 * 64 + 2 * 32 * 64), "hbm",
+                                   "LocalTransformer layer over %d groups of %d tokens" % (a[2], a[1])),
+    "df3d_lt_layer_gather": lambda a, x: (2 * 32 * a[3] * 64 * 4 + 32 * a[3] * 20, 32 * a[3] * 2 * (3 * 64 * 64 + 64 * 64 + 2 * 128 * 64 + 2 * 32 * 64 + 32 * 64), "hbm",
+                                          "LocalTransformer layer with gather + positional MLP, %d groups" % a[3]),
+    "df3d_lt_layer_scatter": lambda a, x: (2 * 32 * a[1] * 64 * 4 + 32 * a[1] * 8, 32 * a[1] * 2 * (3 * 64 * 64 + 64 * 64 + 2 * 128 * 64 + 2 * 32 * 64), "hbm",
+                                           "LocalTransformer layer with winner write-back, %d groups" % a[1]),
+    "df3d_voxel_image_sample": lambda a, x: (a[1] * (16 + a[9] * 4 * 5), 0, "hbm", "point-fusion sampling of %d voxels x %d channels" % (a[1], a[9])),
     "df3d_project_voxels": lambda a, x: (a[1] * 16 + a[1] * a[3] * (8 + 1 + 12 + 4), 0, "hbm", "projection of %d voxels into %d cameras" % (a[1], a[3])),
     "df3d_query_slots": lambda a, x: (a[2] * a[4] * 5 + a[2] * 16, 0, "hbm", "per-camera query slots of %d voxels" % a[2]),
 }
