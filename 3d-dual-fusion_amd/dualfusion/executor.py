@@ -7,6 +7,7 @@ the table cannot express (training mode, 1x1 convs, down-sampled residuals, unkn
 return None and the caller keeps the per-module path; both paths launch the same kernels, so the outputs are
 bit-identical."""
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -76,6 +77,8 @@ class BackbonePlan(object):
         self._sig = None
         self._keep = None
         self._arena_bytes = 256 << 20
+        self._ring = []            # decoupled runs: up to three persistent [arena, event recorded at the start of the NEXT run]
+        self._ring_last = 0
 
     # ---------------------------------------------------------------- module tree -> layer specs
     def _rulebook_id(self, conv):
@@ -205,16 +208,49 @@ class BackbonePlan(object):
         views = (_View * nl)()
         used = ctypes.c_size_t(0)
         shp = (ctypes.c_int * 3)(*[int(v) for v in spatial_shape])
+        # Resident inputs (DF3D_EXEC_DECOUPLE=0 switches this off): coordinates produced on the voxeliser's own stream carry the event that marks them complete; the
+        # geometry stream then waits for that event only (df3d_backbone_inputs_ready) and the rulebooks of this frame (with the
+        # host's round trips for the output counts) proceed while the previous frame still runs on the current stream.  The
+        # geometry stream writes into the arena WITHOUT being ordered behind the current stream, so in this mode the arena must
+        # never be a block the caching allocator recycles (a freed tensor of the previous frame whose kernels are still queued
+        # would be handed out as "free" -- found as garbage output counts and memory faults): three PERSISTENT arenas are
+        # used in rotation, each guarded by an event recorded when the run after its own starts; a stage tensor of frame k
+        # therefore stays valid until frame k + 3 starts.
+        ready = getattr(coors, "_df3d_ready", None) if os.environ.get("DF3D_EXEC_DECOUPLE", "1") == "1" else None
+        slot = None
+        if ready is not None:
+            mark = torch.cuda.current_stream(feats.device).record_event()
+            if self._ring and self._ring[self._ring_last][1] is None:
+                self._ring[self._ring_last][1] = mark
+            if len(self._ring) < 3:
+                self._ring.append([None, None])
+                slot = len(self._ring) - 1
+            else:
+                slot = (self._ring_last + 1) % 3
+            if self._ring[slot][1] is not None:
+                self._ring[slot][1].synchronize()              # the frame that used this arena three runs ago has finished
+                self._ring[slot][1] = None
         while True:
-            arena = torch.empty((self._arena_bytes,), dtype=torch.uint8, device=feats.device)
+            if slot is None:
+                arena = torch.empty((self._arena_bytes,), dtype=torch.uint8, device=feats.device)
+            else:
+                if self._ring[slot][0] is None or self._ring[slot][0].numel() < self._arena_bytes:
+                    torch.cuda.synchronize(feats.device)       # (re)allocation: rare, and the old block must be idle
+                    self._ring[slot][0] = torch.empty((self._arena_bytes,), dtype=torch.uint8, device=feats.device)
+                arena = self._ring[slot][0]
+                lib.df3d_backbone_inputs_ready(ctypes.c_void_p(ready.cuda_event))
             rc = lib.df3d_backbone_run(self._table, nl, _ops._ptr(feats), _ops._ptr(coors), n, feats.shape[1],
                                        int(batch_size), shp, _ops._ptr(arena), self._arena_bytes, views,
                                        ctypes.byref(used), _ops._stream())
             if rc == _lib.DF3D_ENOMEM and self._arena_bytes < (64 << 30):
                 self._arena_bytes *= 2
+                if ready is not None:
+                    torch.cuda.synchronize(feats.device)   # the failed attempt's geometry kernels still write the small arena
                 continue
             _lib.check(rc, "df3d_backbone_run")
             break
+        if slot is not None:
+            self._ring_last = slot
         base = arena.data_ptr()
 
         def view(ptr, nbytes, dtype, shape):

@@ -789,9 +789,9 @@ typedef struct df3d_layer_view {
  * counts) of frame k + 1 proceed while frame k is still running on the caller's stream.  The caller guarantees that `arena` is
  * not read or written by work still queued on `stream`, bounds the runs in flight (16 event sets rotate), and that NOTHING
  * it later reads on other streams relied on the old implicit order "host passed a count round trip => the caller's stream has
- * reached this call".  Without this call the geometry waits for the caller's stream, as before.  (Round 3: built and measured
- * -- the Python side does not use it yet: the fusion adapters' side streams read calibration tensors produced on the caller's
- * stream under exactly that implicit order) */
+ * reached this call".  In particular the arena must not be a block a stream-ordered allocator has just recycled from the
+ * caller's stream: dualfusion/executor.py rotates three persistent arenas, each guarded by an event.  Without this call the
+ * geometry waits for the caller's stream, as before. */
 int df3d_backbone_inputs_ready(void *event);
 int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *features, const int32_t *indices, int n,
                       int in_channels, int batch, const int *shape_host, void *arena, size_t arena_bytes,

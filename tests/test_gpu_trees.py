@@ -470,7 +470,8 @@ def test_voxel_image_sample_kernel_equals_the_torch_composition(aug):
 def test_pipelined_frames_equal_isolated_frames():
     """bench.py's mode of the Voxel-RCNN tree and of the CenterPoint detector: resident point clouds voxelised on the voxel
     stream (`hard_voxelize_clouds(resident_inputs=True)`), the stride-8 query geometry on a side stream that waits for the
-    voxeliser's event only, two frames in flight at most, NO synchronisation between frames -- against the same frames run
+    voxeliser's event only, the native executor's geometry stream likewise (three persistent arenas in rotation), two to three
+    frames in flight at most, NO synchronisation between frames -- against the same frames run
     one at a time with a device synchronisation after each and everything on the current stream.  Outputs must be
     identical, frame by frame, over several rounds (buffers of frame k are released while frame k + 1 / k + 2 run)."""
     import types
@@ -490,7 +491,7 @@ def test_pipelined_frames_equal_isolated_frames():
             want.append((out["encoded_spconv_tensor"].features.clone(), out["encoded_spconv_tensor"].indices.clone()))
         os.environ["DF3D_VOXEL_STREAM"] = "1"
         got = []
-        for k in range(9):                                        # three rounds over the frames, back to back
+        for k in range(18):                                       # six rounds over the frames, back to back
             out = wl.step(k, "detect")
             got.append((out["encoded_spconv_tensor"].features.clone(), out["encoded_spconv_tensor"].indices.clone()))
         torch.cuda.synchronize()
@@ -512,7 +513,12 @@ def test_pipelined_frames_equal_isolated_frames():
             want.append(m(pts, batch_dict=dict(bd), example=dict(ex))[0].clone())
             torch.cuda.synchronize()
         m.resident_inputs = m.fusion.resident_inputs = True
-        got = [m(pts, batch_dict=dict(bd), example=dict(ex))[0].clone() for _ in range(4) for pts, (bd, ex) in frames]
-        torch.cuda.synchronize()
-        for k, y in enumerate(got):
-            assert torch.equal(y, want[k % 3]), k
+        for decouple in ("1", "0"):          # the executor's geometry stream waits for the voxeliser's event only / for the stream
+            os.environ["DF3D_EXEC_DECOUPLE"] = decouple
+            try:
+                got = [m(pts, batch_dict=dict(bd), example=dict(ex))[0].clone() for _ in range(8) for pts, (bd, ex) in frames]
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("DF3D_EXEC_DECOUPLE", None)
+            for k, y in enumerate(got):
+                assert torch.equal(y, want[k % 3]), (decouple, k)
