@@ -10,6 +10,7 @@ a dense 3x3 convolution over channels-last pixel rows IS the sparse convolution 
 every layer (conv + folded BatchNorm + ReLU) is one launch of the split-precision kernel of csrc/spconv_split.hip
 (`forward_rows`; 126 GFLOP per nuScenes sweep).  `SparseConvTensor.dense()` can feed it rows directly
 (`ops.sparse_to_dense_rows`), which removes the NCHW volume and its permute."""
+import os
 import numpy as np
 import torch
 from torch import nn
@@ -191,13 +192,31 @@ class RPN(nn.Module):
         return super(RPN, self).train(mode)
 
     @staticmethod
-    def _run(layer, pad, rows, split, B, H, W, tables):
+    def _table(layer, pad, B, H, W, tables, device):
         layer.prepare(pad)
         key = (B, H, W, layer.kh, layer.kw, layer.stride, layer.pad, layer.transposed)
         if key not in tables:
             tables[key] = _ops.conv2d_neighbors(B, H, W, layer.kh, layer.kw, layer.stride, layer.pad, layer.transposed,
-                                                rows.device)
-        nbr, Ho, Wo = tables[key]
+                                                device)
+        return tables[key]
+
+    @staticmethod
+    def _cat_width(plan):
+        """Channels of the concatenated upsampled maps if their last layers can write them in place (split-precision
+        output-stationary kernels, 8-channel column offsets; round 3: no cat copy, no operand split in the head), else 0."""
+        if plan.get("cat", (None, 0))[0] != _ops.CONV_PRECISION:       # the packs follow the precision switch
+            lasts = [stack[-1] for stack in plan["deblocks"] if stack]
+            for layer, pad in lasts:
+                layer.prepare(pad)
+            ok = (len(lasts) > 1 and len(lasts) == len(plan["deblocks"]) and os.environ.get("DF3D_NECK_CAT", "1") != "0"
+                  and os.environ.get("DF3D_SPLIT_KERNEL", "o")[:1] != "p"
+                  and all(l.packed is not None and l.packed16 is None and l.filters.shape[2] % 8 == 0 for l, _ in lasts))
+            plan["cat"] = (_ops.CONV_PRECISION, sum(l.filters.shape[2] for l, _ in lasts) if ok else 0)
+        return plan["cat"][1]
+
+    @staticmethod
+    def _run(layer, pad, rows, split, B, H, W, tables):
+        nbr, Ho, Wo = RPN._table(layer, pad, B, H, W, tables, rows.device)
         K, cin, cout = layer.filters.shape
         n_out = nbr.shape[1]
         if layer.packed16 is not None:                       # DF3D_CONV_PRECISION=bf16: bf16 rows from layer to layer
@@ -225,19 +244,35 @@ class RPN(nn.Module):
         tables = plan["nbr"]
         x, xs = rows.contiguous(), None
         ups = []
+        cat, cat_rows, cat_split, col0 = self._cat_width(plan), None, None, 0
         for i, blk in enumerate(plan["blocks"]):
             for layer, pad in blk:
                 x, xs, H, W = self._run(layer, pad, x, xs, B, H, W, tables)
             j = i - self._upsample_start_idx
             if j >= 0:
                 u, us, uh, uw = x, xs, H, W
-                for layer, pad in plan["deblocks"][j]:
+                stack = plan["deblocks"][j]
+                for layer, pad in stack[:-1] if cat else stack:
                     u, us, uh, uw = self._run(layer, pad, u, us, B, uh, uw, tables)
+                if cat:                          # the last layer writes its columns of the concatenated rows itself
+                    layer, pad = stack[-1]
+                    nbr, uh, uw = self._table(layer, pad, B, uh, uw, tables, x.device)
+                    if cat_rows is None:
+                        cat_rows = torch.empty((nbr.shape[1], cat), dtype=torch.float32, device=x.device)
+                        cat_split = torch.empty((nbr.shape[1], 4 * cat), dtype=torch.uint8, device=x.device)
+                    K, cin, cout = layer.filters.shape
+                    _ops.conv_rows_split(us if us is not None else _ops.split_rows(u), cin, 0, layer.packed, cout, 1, nbr,
+                                         nbr.shape[1], layer.bias, layer.scale, layer.shift, layer.relu,
+                                         into=(cat_rows, cat_split, col0))
+                    col0 += cout
+                    u = None
                 ups.append((u, uh, uw))
         if not ups:
             return x.view(B, H, W, -1).permute(0, 3, 1, 2)
         uh, uw = ups[0][1], ups[0][2]
         assert all(h == uh and w == uw for _, h, w in ups)
+        if cat:
+            return _as_nchw(cat_rows, cat_split, B, uh, uw)
         out = torch.cat([u for u, _, _ in ups], 1) if len(ups) > 1 else ups[0][0]
         return out.view(B, uh, uw, -1).permute(0, 3, 1, 2)
 

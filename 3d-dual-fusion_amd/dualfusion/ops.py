@@ -630,9 +630,11 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=
 
 
 def conv_rows_split(in_split, cin, in_group_stride, packed, cout, groups, nbr, n_out, bias=None, scale=None, shift=None,
-                    relu=False, out_channels=None, out_cols=None, want_out=True, want_split=False):
+                    relu=False, out_channels=None, out_cols=None, want_out=True, want_split=False, into=None):
     """Grouped / multi-head convolution over split rows (df3d_conv_rows_split).  in_split [n_in, 4*in_channels] uint8.
-    Returns (out fp32 [n_out, out_channels] or None, split rows of it or None)."""
+    Returns (out fp32 [n_out, out_channels] or None, split rows of it or None).
+    into = (rows fp32 [n_out, C] or None, split rows uint8 [n_out, 4*C] or None, col0): write the groups * cout output
+    columns at col0 of these wider rows instead of allocating (a concatenation without the copy); returns them."""
     lib = _lib.load()
     _chk(in_split, torch.uint8, "in_split")
     _chk(packed, torch.uint8, "packed")
@@ -648,8 +650,30 @@ def conv_rows_split(in_split, cin, in_group_stride, packed, cout, groups, nbr, n
                 raise _lib.Df3dError("%s must have groups * cout = %d entries" % (nm, groups * cout))
     if out_cols is not None:
         _chk(out_cols, torch.int32, "out_cols")
-    oc = int(out_channels if out_channels is not None else groups * cout)
     dev = nbr.device
+    if into is not None:
+        out, osp, col0 = into
+        col0 = int(col0)
+        if out_cols is not None or (out is None and osp is None) or col0 % 8:
+            raise _lib.Df3dError("conv_rows_split: `into` takes rows and a column offset that is a multiple of 8")
+        oc = out.shape[1] if out is not None else osp.shape[1] // 4
+        for t, dt, w, nm in ((out, torch.float32, oc, "into rows"), (osp, torch.uint8, 4 * oc, "into split rows")):
+            if t is not None:
+                _chk(t, dt, nm)
+                if tuple(t.shape) != (n_out, w):
+                    raise _lib.Df3dError("conv_rows_split: %s must be [%d, %d]" % (nm, n_out, w))
+        if col0 + groups * cout > oc:
+            raise _lib.Df3dError("conv_rows_split: columns [%d, %d) outside %d-channel rows" % (col0, col0 + groups * cout, oc))
+        # the kernel addresses row * oc + group * cout (+ the 128-column block) from the pointers it is given; split rows
+        # hold 4 bytes per channel in 8-channel blocks, so a column offset is a byte offset of 4 * col0 there too
+        po = out.data_ptr() + 4 * col0 if out is not None else None
+        ps = osp.data_ptr() + 4 * col0 if osp is not None else None
+        rc = lib.df3d_conv_rows_split(_ptr(in_split), n_in, in_channels, int(cin), int(in_group_stride), _ptr(packed), K,
+                                      int(cout), int(groups), _ptr(nbr), int(n_out), _ptr(bias), _ptr(scale),
+                                      _ptr(shift), int(bool(relu)), po, oc, None, ps, _stream())
+        _lib.check(rc, "df3d_conv_rows_split")
+        return out, osp
+    oc = int(out_channels if out_channels is not None else groups * cout)
     out = torch.empty((n_out, oc), dtype=torch.float32, device=dev) if want_out else None
     osp = torch.empty((n_out, 4 * oc), dtype=torch.uint8, device=dev) if want_split else None
     rc = lib.df3d_conv_rows_split(_ptr(in_split), n_in, in_channels, int(cin), int(in_group_stride), _ptr(packed), K,

@@ -34,6 +34,27 @@ def test_rpn_rows_vs_torch_cpu(B, H, W):
     assert float((y_lib.cpu() - ref).abs().max() / ref.abs().max()) < 1e-3
 
 
+def test_rpn_concatenation_written_in_place(monkeypatch):
+    """Round 3: the last layer of each upsampling stack writes its columns of the concatenated rows (fp32 and operand
+    split) itself.  Same bits as the separate maps + torch.cat, and the split rows handed to the head are the split of
+    the fp32 rows."""
+    from dualfusion import ops
+    from dualfusion.necks import RPN, _rows_of
+    dev = torch.device("cuda:0")
+    m = _det_module(RPN([5, 5], [1, 2], [128, 256], [1, 2], [256, 256], 256)).to(dev)
+    x = torch.from_numpy(detgen.randn("neck_cat", (2, 256, 44, 36))).to(dev)
+    with torch.no_grad():
+        y = m(x)
+        rows, split = _rows_of(y)
+        assert split is not None and tuple(rows.shape) == (2 * 44 * 36, 512)
+        assert torch.equal(split, ops.split_rows(rows))
+        monkeypatch.setenv("DF3D_NECK_CAT", "0")
+        m.__dict__.pop("_row_plan", None)
+        y0 = m(x)
+        assert _rows_of(y0)[1] is None
+    assert torch.equal(y, y0)
+
+
 def test_rpn_parameter_layout_and_exact_path():
     """state_dict keys of the reference checkpoint layout; DF3D_CONV_PRECISION=fp32 path through the same module."""
     from dualfusion import ops
