@@ -25,10 +25,11 @@ constexpr int HF_LD = HF_HP + 1;                       // pixels per channel row
 struct HeadFinalArgs {
   const u32x4 *in;       // split rows [B*H*W][ld] (u32x4 units), branch g at columns g*16 .. g*16+15 (64 channels)
   const float *w;        // [G][9][64][HF_KMAX] fp32, output maps padded to 4
+  const u32x4 *wp;       // the same filters as B operands of head_final_mfma_kernel (head_final_pack_kernel) or null
   const float *bias;     // [G][HF_KMAX]
   const int32_t *cols;   // [G][2] (first output column, valid maps)
   float *out;            // [B*H*W][ldo]
-  int ld, ldo, B, H, W, G, tiles_x, tiles_y;
+  int ld, ldo, B, H, W, G, tiles_x, tiles_y, gpad;
 };
 
 __device__ __forceinline__ float bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
@@ -102,6 +103,140 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
     const float v = ((part[0][lane][k] + part[1][lane][k]) + (part[2][lane][k] + part[3][lane][k])) + a.bias[g * HF_KMAX + k];
     a.out[((size_t)(b * a.H + oy) * a.W + ox) * a.ldo + a.cols[2 * g] + k] = v;
   }
+}
+
+
+// ---- round 3: the same convolutions on the matrix cores, "multiply, then shift" ---------------------------------------------
+// head_final_kernel is bound by its vector ALU, not by memory (tools/ubench/head_final.py: 150 us with the loads, 122 us
+// without them): unpacking the bf16 halves costs as many instructions as the 576 FMAs per pixel, all of them at one wave64
+// instruction per 4 clocks.  The split rows ARE matrix-core operands, though: 16 bytes of a row = 8 bf16 channels = what one
+// lane of v_mfma_f32_16x16x32_bf16 holds of its A operand.  Contracting over the 576 = 9 taps x 64 channels directly would
+// make every activation an operand nine times (and the k <= 4 output maps fill 4 of the 16 columns).  Instead the taps go
+// into the COLUMNS: for every pixel q of a 16 x 16 halo tile
+//     D[q][tap * 4 + j] = sum_c M[q][c] * W[tap][c][j]          (256 x 64 times 64 x 36: each activation is an operand ONCE,
+//                                                                straight from global memory, no LDS, no conversion)
+// and the convolution is the shifted sum  O[p][j] = sum_tap D[p + off(tap)][tap * 4 + j]  over the 14 x 14 interior, through
+// LDS.  Three products per k-step as everywhere (M_hi W_hi + M_lo W_hi + M_hi W_lo; the filters are split in the kernel, 48
+// values per lane): 288 MFMAs and 37 KB of LDS per (tile, branch); the launch is bound by reading the activations
+// (1.31x for the halo).
+constexpr int HM_HALO = 16, HM_TILE = HM_HALO - 2, HM_PS = 9 * HF_KMAX;      // LDS floats per halo pixel
+typedef __bf16 hm_bf16x8 __attribute__((ext_vector_type(8)));
+#define HM_MFMA(A, B, C) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hm_bf16x8, A), __builtin_bit_cast(hm_bf16x8, B), C, 0, 0, 0)
+
+// B operand of lane (column `col` = (tap, map j), channel group kg) for k-step s: channels 32 s + 8 kg .. + 7, hi and lo
+__device__ __forceinline__ void hm_split_filters(const float *w, int g, int col, int tap, int j, int s, int kg, u32x4 &bh,
+                                                 u32x4 &bl) {
+  bh = bl = (u32x4){0u, 0u, 0u, 0u};
+  if (col >= HM_PS) return;
+  const float *wp = w + ((size_t)(g * 9 + tap) * HF_C + 32 * s + 8 * kg) * HF_KMAX + j;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_pair(wp[(2 * e) * HF_KMAX], wp[(2 * e + 1) * HF_KMAX], bh[e], bl[e]);
+}
+
+// [G][9][64][4] fp32 -> [G][column tile 3][k-step 2][hi | lo][lane 64] x 16 B: what the lanes of the kernel below load
+__global__ __launch_bounds__(64) void head_final_pack_kernel(const float *__restrict__ w, u32x4 *__restrict__ out) {
+  const int lane = threadIdx.x, n = lane & 15, kg = lane >> 4;
+  const int s = blockIdx.x & 1, ct = (blockIdx.x >> 1) % 3, g = blockIdx.x / 6;
+  const int col = 16 * ct + n;
+  u32x4 bh, bl;
+  hm_split_filters(w, g, col, col >> 2, col & 3, s, kg, bh, bl);
+  u32x4 *q = out + (size_t)blockIdx.x * 128 + lane;
+  q[0] = bh;
+  q[64] = bl;
+}
+
+__global__ __launch_bounds__(256) void head_final_mfma_kernel(HeadFinalArgs a) {
+  __shared__ float d[HM_HALO * HM_HALO * HM_PS];
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // branch-fastest workgroup order: the workgroups in flight read neighbouring 256-byte pieces of the same pixels' rows.
+  // With the tile fastest they would all read ONE branch -- addresses 9216 B apart (36 x 256 B) that fall on a quarter of the
+  // memory channels.
+  int g, tile;
+  if (a.gpad) {
+    g = blockIdx.x % a.gpad, tile = blockIdx.x / a.gpad;
+    if (g >= a.G) return;
+  } else {
+    g = blockIdx.y, tile = blockIdx.x;
+  }
+  const int b = tile / (a.tiles_x * a.tiles_y), t2 = tile - b * (a.tiles_x * a.tiles_y);
+  const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+  const int y0 = ty * HM_TILE - 1, x0 = tx * HM_TILE - 1;
+  // ---- A operands: MFMA row tile rt of this wave = halo row 4 * wave + rt, row n of the tile = halo column n; k-step s,
+  //      lane group kg = channels 32 s + 8 kg .. + 7 = block 4 s + kg of the branch's 8 (hi 16 B | lo 16 B).  Zeros outside ----
+  u32x4 ah[4][2], al[4][2];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int yy = y0 + 4 * wave + rt, xx = x0 + n;
+    const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+    const u32x4 *src = a.in + ((size_t)(b * a.H + (in ? yy : 0)) * a.W + (in ? xx : 0)) * a.ld + g * 16 + kg * 2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ah[rt][s] = al[rt][s] = (u32x4){0u, 0u, 0u, 0u};
+      if (in) {
+        ah[rt][s] = src[s * 8];
+        al[rt][s] = src[s * 8 + 1];
+      }
+    }
+  }
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    // ---- B operands: column 16 ct + n = (tap, map j); lane group kg = the same 8 channels as in A ----
+    const int col = 16 * ct + n, tap = col >> 2, j = col & 3;
+    u32x4 bh[2], bl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (a.wp) {                                        // packed once per set of filters: two coalesced 16-byte loads
+        const u32x4 *q = a.wp + ((size_t)(g * 3 + ct) * 2 + s) * 128 + lane;
+        bh[s] = q[0];
+        bl[s] = q[64];
+        continue;
+      }
+      hm_split_filters(a.w, g, col, tap, j, s, kg, bh[s], bl[s]);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        acc[rt][ct] = HM_MFMA(al[rt][s], bh[s], acc[rt][ct]);
+        acc[rt][ct] = HM_MFMA(ah[rt][s], bl[s], acc[rt][ct]);
+        acc[rt][ct] = HM_MFMA(ah[rt][s], bh[s], acc[rt][ct]);
+      }
+  }
+  // ---- D -> LDS [halo pixel][tap][map]: the lane holds halo columns 4 kg + r of halo row 4 wave + rt, column 16 ct + n ----
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+      const int col = 16 * ct + n;
+      if (col < HM_PS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[((4 * wave + rt) * HM_HALO + 4 * kg + r) * HM_PS + col] = acc[rt][ct][r];
+      }
+    }
+  __syncthreads();
+  // ---- thread = interior pixel: the nine shifted partial sums, + bias ----
+  if (tid >= HM_TILE * HM_TILE) return;
+  const int oy = tid / HM_TILE, ox = tid - oy * HM_TILE;
+  const int gy = ty * HM_TILE + oy, gx = tx * HM_TILE + ox;
+  if (gy >= a.H || gx >= a.W) return;
+  f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    sum += *(const f32x4 *)&d[((oy + dy) * HM_HALO + ox + dx) * HM_PS + tap * HF_KMAX];
+  }
+  const int c0 = a.cols[2 * g], k = a.cols[2 * g + 1];
+  float *dst = a.out + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldo + c0;
+#pragma unroll
+  for (int j = 0; j < HF_KMAX; ++j)
+    if (j < k) dst[j] = sum[j] + a.bias[g * HF_KMAX + j];
 }
 
 
@@ -243,25 +378,70 @@ __global__ __launch_bounds__(256) void head_final_bwd_filter_kernel(HeadFinalBwd
 
 using namespace df3d;
 
+extern "C" size_t df3d_head_final_packed_bytes(int groups) { return groups > 0 ? (size_t)groups * 6 * 128 * 16 : 0; }
+
+extern "C" int df3d_head_final_pack(const float *weights, int groups, void *packed, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(weights && packed && groups >= 1, "head_final_pack: bad argument");
+  hipLaunchKernelGGL(head_final_pack_kernel, dim3(groups * 6), dim3(64), 0, stream, weights, (u32x4 *)packed);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+static int head_final_impl(const void *in_split, int in_channels, int batch, int H, int W, int groups, const float *weights,
+                           const void *packed, const float *bias, const int32_t *out_cols, float *out, int out_channels,
+                           void *stream_);
+
 extern "C" int df3d_head_final_conv(const void *in_split, int in_channels, int batch, int H, int W, int groups,
                                     const float *weights, const float *bias, const int32_t *out_cols, float *out,
                                     int out_channels, void *stream_) {
+  return head_final_impl(in_split, in_channels, batch, H, W, groups, weights, nullptr, bias, out_cols, out, out_channels,
+                         stream_);
+}
+
+extern "C" int df3d_head_final_conv_packed(const void *in_split, int in_channels, int batch, int H, int W, int groups,
+                                           const void *packed, const float *bias, const int32_t *out_cols, float *out,
+                                           int out_channels, void *stream_) {
+  DF3D_CHECK_ARG(packed, "head_final_conv_packed: null argument");
+  return head_final_impl(in_split, in_channels, batch, H, W, groups, nullptr, packed, bias, out_cols, out, out_channels,
+                         stream_);
+}
+
+static int head_final_impl(const void *in_split, int in_channels, int batch, int H, int W, int groups, const float *weights,
+                           const void *packed, const float *bias, const int32_t *out_cols, float *out, int out_channels,
+                           void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  DF3D_CHECK_ARG(in_split && weights && bias && out_cols && out, "head_final_conv: null argument");
+  DF3D_CHECK_ARG(in_split && (weights || packed) && bias && out_cols && out, "head_final_conv: null argument");
   DF3D_CHECK_ARG(groups >= 1 && in_channels >= groups * HF_C && in_channels % 8 == 0,
                  "head_final_conv: %d branches of 64 channels do not fit %d-channel rows", groups, in_channels);
   DF3D_CHECK_ARG(batch >= 1 && H >= 1 && W >= 1 && out_channels >= 1, "head_final_conv: bad sizes");
   HeadFinalArgs a;
   a.in = (const u32x4 *)in_split;
   a.w = weights;
+  a.wp = (const u32x4 *)packed;
   a.bias = bias;
   a.cols = out_cols;
   a.out = out;
   a.ld = in_channels / 4;                              // u32x4 per split row: 16 bytes carry 4 channels' worth (hi+lo of 8 per 32 B)
   a.ldo = out_channels;
   a.B = batch, a.H = H, a.W = W, a.G = groups;
-  a.tiles_x = cdiv(W, HF_TILE), a.tiles_y = cdiv(H, HF_TILE);
-  hipLaunchKernelGGL(head_final_kernel, dim3(batch * a.tiles_x * a.tiles_y, groups), dim3(256), 0, stream, a);
+  static const bool valu = getenv("DF3D_HEADFINAL") && getenv("DF3D_HEADFINAL")[0] == 'v';   // rounds 1-2: fp32 FMAs
+  if (valu) {
+    DF3D_CHECK_ARG(weights, "head_final_conv: the vector-ALU kernel (DF3D_HEADFINAL=valu) takes the fp32 filters");
+    a.gpad = 0;
+    a.tiles_x = cdiv(W, HF_TILE), a.tiles_y = cdiv(H, HF_TILE);
+    hipLaunchKernelGGL(head_final_kernel, dim3(batch * a.tiles_x * a.tiles_y, groups), dim3(256), 0, stream, a);
+  } else {
+    static const int order = getenv("DF3D_HEADFINAL_ORDER") ? atoi(getenv("DF3D_HEADFINAL_ORDER")) : 2;
+    a.tiles_x = cdiv(W, HM_TILE), a.tiles_y = cdiv(H, HM_TILE);
+    const long long tiles = (long long)batch * a.tiles_x * a.tiles_y;
+    a.gpad = order == 1 ? (groups + 7) & ~7 : (order == 2 ? groups : 0);
+    if (a.gpad && tiles * a.gpad > 0x7fffffffLL) a.gpad = 0;
+    if (a.gpad)
+      hipLaunchKernelGGL(head_final_mfma_kernel, dim3((unsigned)(tiles * a.gpad)), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL(head_final_mfma_kernel, dim3((unsigned)tiles, groups), dim3(256), 0, stream, a);
+  }
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -131,6 +131,10 @@ SIGNATURES = {
                                         c_size_t, c_void_p]),
     "df3d_head_final_conv": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_void_p]),
+    "df3d_head_final_packed_bytes": (c_size_t, [c_int]),
+    "df3d_head_final_pack": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "df3d_head_final_conv_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_int, c_void_p]),
     "df3d_head_final_conv_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p]),
     "df3d_centerhead_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

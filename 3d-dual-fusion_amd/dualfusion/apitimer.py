@@ -159,6 +159,8 @@ MODELS = {
     "df3d_sparse_to_dense_rows": lambda a, x: (a[2] * a[3] * 4, 0, "hbm", "dense() as pixel rows: %d rows x %d channels (+ the zero fill)" % (a[2], a[3])),
     "df3d_head_final_conv": lambda a, x: (a[2] * a[3] * a[4] * (a[1] * 4 + a[10] * 4), 2 * a[2] * a[3] * a[4] * a[5] * 9 * 64 * 4, "hbm",
                                           "final 3x3 convs of %d head branches on %d pixels" % (a[5], a[2] * a[3] * a[4])),
+    "df3d_head_final_conv_packed": lambda a, x: (a[2] * a[3] * a[4] * (a[1] * 4 + a[10] * 4), 2 * a[2] * a[3] * a[4] * a[5] * 9 * 64 * 4, "hbm",
+                                                 "final 3x3 convs of %d head branches on %d pixels (taps as matrix-core columns)" % (a[5], a[2] * a[3] * a[4])),
     "df3d_split_rows": lambda a, x: _rows(a[1] * a[2], a[1] * a[2], "fp32 rows -> split rows (%d x %d)" % (a[1], a[2])),
     "df3d_actr_prep": lambda a, x: _rows(3 * a[3] * a[4], 2 * a[3] * a[4], "query + position sums (%d rows)" % a[3]),
     "df3d_add_layernorm": lambda a, x: _rows(2 * a[5] * a[6], a[5] * a[6], "add + LayerNorm (%d rows)" % a[5]),

@@ -380,9 +380,14 @@ class CenterHead(nn.Module):
                                      plan["mid_bias"], plan["mid_scale"], plan["mid_shift"], relu=True, want_out=False,
                                      want_split=True)
         if plan["fin_w4"] is not None and os.environ.get("DF3D_HEAD_FINAL", "valu") == "valu":
-            # 72 output maps of 36 branches: vector-ALU kernel over LDS halo tiles (every activation read 1.6x, exact
-            # fp32 products of hi + lo) instead of a block-diagonal matrix-core launch padded to 32 columns per branch
-            out = _ops.head_final_conv(s2, B, H, W, plan["fin_w4"], plan["fin_b4"], plan["cols"], plan["width"])
+            # 72 output maps of 36 branches in one launch of csrc/headconv.hip (round 3: the taps are COLUMNS of a matrix-core
+            # product over each halo pixel's 64 channels, the shifted sum runs through LDS; every activation read 1.3x)
+            # instead of a block-diagonal matrix-core launch padded to 32 columns per branch
+            if "fin_pk" not in plan:
+                plan["fin_pk"] = (_ops.head_final_pack(plan["fin_w4"])
+                                  if os.environ.get("DF3D_HEADFINAL", "mfma")[:1] != "v" else None)
+            out = _ops.head_final_conv(s2, B, H, W, plan["fin_w4"], plan["fin_b4"], plan["cols"], plan["width"],
+                                       packed=plan["fin_pk"])
         else:
             out, _ = _ops.conv_rows_split(s2, 64, 64, plan["fin"], 32, G, nbr, n, plan["fin_bias"], None, None, relu=False,
                                           out_channels=plan["width"], out_cols=plan["cols"])

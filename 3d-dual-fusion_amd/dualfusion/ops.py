@@ -683,7 +683,19 @@ def conv_rows_split(in_split, cin, in_group_stride, packed, cout, groups, nbr, n
     return out, osp
 
 
-def head_final_conv(in_split, batch, H, W, weights, bias, out_cols, out_channels):
+def head_final_pack(weights):
+    """weights [G, 9, 64, 4] fp32 -> the filters as matrix-core operands of `head_final_conv(..., packed=)`."""
+    lib = _lib.load()
+    _chk(weights, torch.float32, "weights")
+    G = weights.shape[0]
+    if tuple(weights.shape[1:]) != (9, 64, 4):
+        raise _lib.Df3dError("head_final_pack: weights [G,9,64,4] expected")
+    packed = torch.empty(int(lib.df3d_head_final_packed_bytes(G)), dtype=torch.uint8, device=weights.device)
+    _lib.check(lib.df3d_head_final_pack(_ptr(weights), G, _ptr(packed), _stream()), "df3d_head_final_pack")
+    return packed
+
+
+def head_final_conv(in_split, batch, H, W, weights, bias, out_cols, out_channels, packed=None):
     """The last 3x3 convolution of every (task, head) branch of a CenterPoint-style head in one launch
     (csrc/headconv.hip).  in_split [B*H*W, 4*in_channels] uint8 split rows (branch g = channels g*64 .. g*64+63),
     weights [G, 9, 64, 4] fp32, bias [G, 4], out_cols [G, 2] int32 -> out [B*H*W, out_channels] fp32."""
@@ -699,6 +711,15 @@ def head_final_conv(in_split, batch, H, W, weights, bias, out_cols, out_channels
     if in_split.shape[0] != n:
         raise _lib.Df3dError("head_final_conv: %d rows for a %dx%dx%d map" % (in_split.shape[0], batch, H, W))
     out = torch.empty((n, int(out_channels)), dtype=torch.float32, device=in_split.device)
+    if packed is not None:
+        _chk(packed, torch.uint8, "packed")
+        if packed.numel() != lib.df3d_head_final_packed_bytes(G):
+            raise _lib.Df3dError("head_final_conv: packed filters do not match %d branches" % G)
+        rc = lib.df3d_head_final_conv_packed(_ptr(in_split), in_split.shape[1] // 4, int(batch), int(H), int(W), G,
+                                             _ptr(packed), _ptr(bias), _ptr(out_cols), _ptr(out), int(out_channels),
+                                             _stream())
+        _lib.check(rc, "df3d_head_final_conv_packed")
+        return out
     rc = lib.df3d_head_final_conv(_ptr(in_split), in_split.shape[1] // 4, int(batch), int(H), int(W), G, _ptr(weights),
                                   _ptr(bias), _ptr(out_cols), _ptr(out), int(out_channels), _stream())
     _lib.check(rc, "df3d_head_final_conv")

@@ -331,6 +331,15 @@ int df3d_centerhead_predict(const df3d_head_task *tasks, int ntasks, const df3d_
  * bias [groups][4]; out_cols [groups][2] = (first output column, valid maps) in out [batch*H*W, out_channels] fp32. */
 int df3d_head_final_conv(const void *in_split, int in_channels, int batch, int H, int W, int groups, const float *weights,
                          const float *bias, const int32_t *out_cols, float *out, int out_channels, void *stream);
+/* The same with the filters packed once as matrix-core operands (round 3: the kernel multiplies every halo pixel's 64
+ * channels with all 9 taps' filters on the matrix cores -- split precision, 3 products -- and sums the shifted partial
+ * maps in LDS).  df3d_head_final_conv splits the fp32 filters inside the kernel (48 scattered loads per lane);
+ * `packed` = df3d_head_final_packed_bytes(groups) bytes written by df3d_head_final_pack from weights [groups][9][64][4]. */
+size_t df3d_head_final_packed_bytes(int groups);
+int df3d_head_final_pack(const float *weights, int groups, void *packed, void *stream);
+int df3d_head_final_conv_packed(const void *in_split, int in_channels, int batch, int H, int W, int groups,
+                                const void *packed, const float *bias, const int32_t *out_cols, float *out,
+                                int out_channels, void *stream);
 /* Backward of df3d_head_final_conv for training: `acts` [B*H*W][act_channels] are the fp32
  * activations the forward convolved (branch g at columns g*64 ..), `grad_out` [B*H*W][out_channels] the gradient of the
  * packed maps; grad_acts (same shape as acts; columns beyond groups*64 untouched) and / or grad_weights

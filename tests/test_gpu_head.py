@@ -261,6 +261,40 @@ def test_training_forward_backward_on_row_kernels_vs_float64():
     assert hd.__dict__.get("_train_tables")
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 11, 21), (1, 30, 44), (1, 14, 14), (1, 3, 2)])
+def test_final_conv_forward_vs_torch_float64(B, H, W):
+    """df3d_head_final_conv (round 3: taps as matrix-core columns + shifted sum; filters split in the kernel or packed once)
+    against F.conv2d in float64 on the values the split rows carry: map sizes that cut the 14 x 14 tiles, 1..4 maps."""
+    from dualfusion import ops
+    F = torch.nn.functional
+    ks = [2, 1, 3, 4, 2]
+    G = len(ks)
+    gen = torch.Generator().manual_seed(17)
+    acts = torch.randn((B * H * W, G * 64 + 8), generator=gen)            # rows wider than the branches use
+    ws = [torch.randn((k, 64, 3, 3), generator=gen) * 0.1 for k in ks]
+    bs = [torch.randn((k,), generator=gen) for k in ks]
+    cols, c0 = [], 0
+    for k in ks:
+        cols.append((c0, k))
+        c0 += k
+    width = (c0 + 7) // 8 * 8
+    vol = acts[:, :G * 64].double().view(B, H, W, G, 64).permute(3, 0, 4, 1, 2)
+    ref = torch.cat([F.conv2d(vol[g], ws[g].double(), bs[g].double(), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, -1)
+                     for g in range(G)], 1)
+    w4, b4 = torch.zeros((G, 9, 64, 4)), torch.zeros((G, 4))
+    for g, k in enumerate(ks):
+        w4[g, :, :, :k] = ws[g].permute(2, 3, 1, 0).reshape(9, 64, k)
+        b4[g, :k] = bs[g]
+    w4d, b4d = w4.to(DEV), b4.to(DEV)
+    cd = torch.tensor(cols, dtype=torch.int32, device=DEV)
+    split = ops.split_rows(acts.to(DEV))
+    out = ops.head_final_conv(split, B, H, W, w4d, b4d, cd, width)
+    out_pk = ops.head_final_conv(split, B, H, W, w4d, b4d, cd, width, packed=ops.head_final_pack(w4d))
+    assert torch.equal(out[:, :c0], out_pk[:, :c0])                      # the same operands, whoever split the filters
+    err = float((out[:, :c0].cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err                                               # split precision: hi*hi + lo*hi + hi*lo
+
+
 def test_final_conv_backward_kernels_vs_torch_float64():
     """df3d_head_final_conv_backward (data gradient, filter gradient) and the bias gather of `_HeadFinalFunction` against
     F.conv2d autograd in float64, branch by branch: ragged map sizes (tiles cut by the border), 1 / 2 / 3 maps per branch."""
