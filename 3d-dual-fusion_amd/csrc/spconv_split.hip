@@ -178,6 +178,7 @@ struct SplitConvArgs {
   const int32_t *cols;   // optional [gy][2] = (first output column, valid columns) of a block: compact fp32 stores
   const int32_t *order;  // optional [n_out]: tile t of the output-stationary kernel owns rows order[t*TM .. t*TM+TM-1]
   unsigned long long *trace;   // builds with -DDF3D_OS_TRACE: [workgroup][wave][8] s_memtime stamps (tuning aid)
+  int cbw;               // loader / consumer kernel: column blocks (or groups) one workgroup walks (0 = 1), gridDim.y = ceil(gy / cbw)
 };
 
 #ifdef DF3D_OS_TRACE
@@ -1013,7 +1014,13 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
   const int g = lane >> 4, n = lane & 15;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);                 // consecutive tiles stay on one XCD / L2
   const int row0 = tile * TM;
-  const int col0 = blockIdx.y * CW;
+  // Round 3: a workgroup walks `cbw` column blocks of its row tile without leaving the step pipeline -- the neighbour
+  // table, the ring's fill and the wait for the last stores at the end of the workgroup are paid once per row tile
+  // instead of once per (row tile, block) (head middle convolutions, 18 blocks of 18 steps: prologue 7 % + epilogue 23 %
+  // of a workgroup's life, one workgroup per CU so nothing overlapped them: tools/ubench/lc_trace_head.py).
+  const int cbw = a.cbw > 0 ? a.cbw : 1;
+  const int cb0 = blockIdx.y * cbw;
+  const int ncb = min(cbw, a.gy - cb0);
   OS_STAMP(6);
 
   if (tid == 0) wg_mask = 0u;
@@ -1042,7 +1049,8 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
   }
   __syncthreads();
   const unsigned gmask = __builtin_amdgcn_readfirstlane(wg_mask);
-  const int steps = __popc(gmask) * KB;
+  const int steps = __popc(gmask) * KB;             // per column block
+  const int total = steps * ncb;
   // XOR swizzle of a row's eight 16-byte units, by the row's position in its 16-row MFMA tile (applied to the SOURCE
   // address of the DMA: an LDS-DMA writes lane-linearly): makes the four lane groups of a ds_read_b128 (rows n, units
   // g*2 + q) hit 16 distinct bank columns (brute-forced; linear over GF(2))
@@ -1077,6 +1085,7 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
     // adds its block offset.
     const u32x4 *abase[APL], *wbase = nullptr;
     int astep[APL];
+    int cbl = cb0;                                // column block of the step that is fetched next
     auto issue = [&](int t) {
       const int st = t & (NS - 1);
       if (cu.kb == 0) {
@@ -1087,10 +1096,10 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
         for (int i = 0; i < APL; ++i) {
           const int r = (lw * APL + i) * 8 + (lane >> 3);
           const int unit = (lane & 7) ^ swz(r & 15);
-          abase[i] = idx[i] >= 0 ? a.feat + (size_t)idx[i] * a.ldi + blockIdx.y * a.in_goff + unit : g_zero_row + (lane & 7);
+          abase[i] = idx[i] >= 0 ? a.feat + (size_t)idx[i] * a.ldi + cbl * a.in_goff + unit : g_zero_row + (lane & 7);
           astep[i] = idx[i] >= 0 ? 8 : 0;
         }
-        wbase = a.w + ((size_t)blockIdx.y * a.K * KB + (size_t)cu.k * KB) * WQ + (lw * WPL) * 64 + lane;
+        wbase = a.w + ((size_t)cbl * a.K * KB + (size_t)cu.k * KB) * WQ + (lw * WPL) * 64 + lane;
       }
       if (!OS_DBG(64)) {                          // (experiment: no DMAs)
 #pragma unroll
@@ -1103,19 +1112,23 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
                                            (__attribute__((address_space(3))) void *)&Wl[st][(lw * WPL + i) * 64], 16, 0, 0);
       }
       cu.template next<KB>();
+      if (!cu.live) {                             // the block's last step: the same offsets again, next block's filters
+        ++cbl;
+        cu.init(gmask);
+      }
     };
     constexpr int PPS = APL + WPL;                // pieces per loader wave and step
     LC_T0();
-    for (int t = 0; t < NS && t < steps; ++t) issue(t);
+    for (int t = 0; t < NS && t < total; ++t) issue(t);
     LC_ACC(t_a);
-    for (int s = -1; s < steps; ++s) {
+    for (int s = -1; s < total; ++s) {
       // steps <= s + 2 have landed; the pieces of step s + 3 (the newest issued) may still be in flight
-      if (s + 3 < steps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPS) : "memory");
+      if (s + 3 < total) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       LC_ACC(t_b);
       asm volatile("s_barrier" ::: "memory");
       LC_ACC(t_c);
-      if (s >= 0 && s + NS < steps) issue(s + NS);                   // into the stage step s has just left
+      if (s >= 0 && s + NS < total) issue(s + NS);                   // into the stage step s has just left
       LC_ACC(t_a);
     }
     LC_DUMP();
@@ -1191,6 +1204,67 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
     LC_ACC(t_c);                                                                                                       \
   } while (0)
 
+  // ---- epilogue of one column block: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the
+  //      CT consecutive columns n * CT .. n * CT + CT - 1 (packed-weight layout 1).  Leaves the accumulators at zero.
+  //      Round 3: the arguments live in locals (the step loop's asm memory clobbers made every row re-load them from the
+  //      kernel arguments) and the per-column vectors pass through an asm after their one wait -- the compiler could not
+  //      prove those loads complete at the loop joins and put an s_waitcnt vmcnt(0) in front of EVERY row, i.e. it also
+  //      waited for the previous row's stores: eight store round trips in a row, ~8000 clocks of a one-workgroup-per-CU
+  //      kernel (lc_trace_head.py).  Now the stores of a block queue up behind each other ----
+  const float *e_res = a.residual;
+  float *e_out = a.out;
+  char *e_split = (char *)a.out_split;
+  const float *e_bias = a.bias, *e_scale = a.scale, *e_shift = a.shift;
+  const int e_relu = a.relu, e_ldo = a.ldo, e_nout = a.n_out;
+  static_assert(CT == 8, "two f32x4 per lane and vector below");
+  auto epilogue = [&](int cb) {
+    const int col0 = cb * CW;
+    f32x4 bi[2], sc[2], sh[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int col = col0 + n * CT + q * 4;
+      bi[q] = e_bias ? *(const f32x4 *)(e_bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      sc[q] = e_scale ? *(const f32x4 *)(e_scale + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      sh[q] = e_shift ? *(const f32x4 *)(e_shift + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bi[0]), "+v"(bi[1]), "+v"(sc[0]), "+v"(sc[1]), "+v"(sh[0]), "+v"(sh[1]));
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rowL[wr * 32 + rt * 16 + 4 * g + r];
+        if (row >= e_nout) continue;
+        const size_t o = (size_t)row * e_ldo + col0 + n * CT;
+        unsigned hh[CT / 2], ll[CT / 2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          f32x4 v = (f32x4){acc[rt][q * 4][r], acc[rt][q * 4 + 1][r], acc[rt][q * 4 + 2][r], acc[rt][q * 4 + 3][r]};
+          v = (v + bi[q]) * sc[q] + sh[q];
+          if (e_res) v += *(const f32x4 *)(e_res + o + q * 4);
+          if (e_relu) {
+            v[0] = fmaxf(v[0], 0.f);
+            v[1] = fmaxf(v[1], 0.f);
+            v[2] = fmaxf(v[2], 0.f);
+            v[3] = fmaxf(v[3], 0.f);
+          }
+          if (e_out) *(f32x4 *)(e_out + o + q * 4) = v;
+          if (e_split) {
+            split_pair(v[0], v[1], hh[q * 2], ll[q * 2]);
+            split_pair(v[2], v[3], hh[q * 2 + 1], ll[q * 2 + 1]);
+          }
+        }
+        if (e_split) {
+          char *blk = e_split + (o >> 3) * 32;                       // 8-channel block = [hi 16 B | lo 16 B]
+          *(u32x4 *)blk = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+          *(u32x4 *)(blk + 16) = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+        }
+      }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
   u32x4 af[2][RT][NP];
   u32x4 bq[2][2 * NP];
   asm volatile("s_barrier" ::: "memory");         // steps 0 and 1 are in their stages
@@ -1205,13 +1279,37 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
     LC_READ(bq[0][3], w_addr, 3 * 1024);
   }
   LC_T0();
-  int s = 0;
-  for (; s + 1 < steps; s += 2) {
-    LC_STEP(s, 0);
-    LC_STEP(s + 1, 1);
+  // behind a block's last step: the fragment reads of the next step are in flight.  They land, the epilogue runs without
+  // them (they would cost it 32 live registers: spills), and the same reads are issued again -- the stage of step s + 1
+  // is not refilled before the barrier that ends it.  The epilogue's stores drain behind the next block's MFMAs.
+  static_assert(KB % 2 == 0, "a block's steps come in pairs: the fragment buffers restart at 0 with every block");
+  int t = 0;
+  for (int cb = cb0; cb < cb0 + ncb && steps > 0; ++cb) {
+    for (int s = 0; s < steps; s += 2, t += 2) {
+      LC_STEP(t, 0);
+      LC_STEP(t + 1, 1);
+    }
+    LC_WAITALL(0);
+    __builtin_amdgcn_s_setprio(0);
+    epilogue(cb);
+    __builtin_amdgcn_s_setprio(1);
+    if (cb + 1 < cb0 + ncb) {
+      const unsigned rn0 = a_addr0 + (unsigned)(t & (NS - 1)) * (AQ * 16u);
+      const unsigned rn1 = a_addr1 + (unsigned)(t & (NS - 1)) * (AQ * 16u);
+      const unsigned rwn = w_addr + (unsigned)(t & (NS - 1)) * (WQ * 16u);
+      LC_READ(af[0][0][0], rn0, 0);
+      LC_READ(af[0][0][1], rn1, 0);
+      LC_READ(af[0][1][0], rn0, 16 * 128);
+      LC_READ(af[0][1][1], rn1, 16 * 128);
+      LC_READ(bq[0][0], rwn, 0 * 1024);
+      LC_READ(bq[0][1], rwn, 1 * 1024);
+      LC_READ(bq[0][2], rwn, 2 * 1024);
+      LC_READ(bq[0][3], rwn, 3 * 1024);
+    }
   }
-  if (s < steps) LC_STEP(s, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (steps == 0)                                // a tile without a single neighbour: bias / shift rows
+    for (int cb = cb0; cb < cb0 + ncb; ++cb) epilogue(cb);
 #undef LC_READ
 #undef LC_SB
 #undef LC_M
@@ -1229,49 +1327,6 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
 #undef LC_DUMP
   OS_STAMP(4);
 
-  // ---- epilogue: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the CT consecutive
-  //      columns n * CT .. n * CT + CT - 1 (packed-weight layout 1) ----
-  {
-    f32x4 bi[CT / 4], sc[CT / 4], sh[CT / 4];
-#pragma unroll
-    for (int q = 0; q < CT / 4; ++q) {
-      const int col = col0 + n * CT + q * 4;
-      bi[q] = a.bias ? *(const f32x4 *)(a.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      sc[q] = a.scale ? *(const f32x4 *)(a.scale + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
-      sh[q] = a.shift ? *(const f32x4 *)(a.shift + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rowL[wr * 32 + rt * 16 + 4 * g + r];
-        if (row >= a.n_out) continue;
-        const size_t o = (size_t)row * a.ldo + col0 + n * CT;
-        unsigned hh[CT / 2], ll[CT / 2];
-#pragma unroll
-        for (int q = 0; q < CT / 4; ++q) {
-          f32x4 v = (f32x4){acc[rt][q * 4][r], acc[rt][q * 4 + 1][r], acc[rt][q * 4 + 2][r], acc[rt][q * 4 + 3][r]};
-          v = (v + bi[q]) * sc[q] + sh[q];
-          if (a.residual) v += *(const f32x4 *)(a.residual + o + q * 4);
-          if (a.relu) {
-            v[0] = fmaxf(v[0], 0.f);
-            v[1] = fmaxf(v[1], 0.f);
-            v[2] = fmaxf(v[2], 0.f);
-            v[3] = fmaxf(v[3], 0.f);
-          }
-          if (a.out) *(f32x4 *)(a.out + o + q * 4) = v;
-          if (a.out_split) {
-            split_pair(v[0], v[1], hh[q * 2], ll[q * 2]);
-            split_pair(v[2], v[3], hh[q * 2 + 1], ll[q * 2 + 1]);
-          }
-        }
-        if (a.out_split) {
-          char *blk = (char *)a.out_split + (o >> 3) * 32;           // 8-channel block = [hi 16 B | lo 16 B]
-          *(u32x4 *)blk = (u32x4){hh[0], hh[1], hh[2], hh[3]};
-          *(u32x4 *)(blk + 16) = (u32x4){ll[0], ll[1], ll[2], ll[3]};
-        }
-      }
-  }
   OS_STAMP(7);
 }
 
@@ -1287,8 +1342,21 @@ static int num_cu() {
 // The loader / consumer kernel serves 128-column blocks from ~190 workgroups on (below that the 64-row tiles of the
 // kernel above fill the chip better); DF3D_OS_LC=0 / 1 forces it off / on.
 template <int CIN>
-static int launch_os_lc(const SplitConvArgs &a, hipStream_t stream) {
-  hipLaunchKernelGGL((spconv_os_lc_kernel<CIN, 128>), dim3(cdiv(a.n_out, 128), a.gy), dim3(768), 0, stream, a);
+static int launch_os_lc(const SplitConvArgs &a_, hipStream_t stream) {
+  SplitConvArgs a = a_;
+  // column blocks per workgroup: the split into ny workgroups per row tile with the fewest (rounds over the CUs) x (blocks
+  // walked + ~half a block of prologue and drain per workgroup); DF3D_LC_CBW overrides (tuning aid)
+  const int tiles = cdiv(a.n_out, 128), ncu = num_cu();
+  int best_ny = a.gy;
+  double best = 1e30;
+  for (int ny = 1; ny <= a.gy; ++ny) {
+    const double cost = (double)cdiv((long long)tiles * ny, ncu) * (cdiv(a.gy, ny) + 0.5);
+    if (cost < best - 1e-9) best = cost, best_ny = ny;
+  }
+  a.cbw = cdiv(a.gy, best_ny);
+  static const char *force = getenv("DF3D_LC_CBW");
+  if (force && atoi(force) > 0) a.cbw = atoi(force) < a.gy ? atoi(force) : a.gy;
+  hipLaunchKernelGGL((spconv_os_lc_kernel<CIN, 128>), dim3(tiles, cdiv(a.gy, a.cbw)), dim3(768), 0, stream, a);
   return DF3D_OK;
 }
 
@@ -1595,6 +1663,9 @@ extern "C" int df3d_conv_rows_split(const void *in_split, int n_in, int in_chann
   SplitConvArgs a = {(const u32x4 *)in_split, (const u32x4 *)packed_filters, nbr, bias, scale, shift, nullptr,
                      out, (u32x4 *)out_split, n_in, n_out, kvol, relu,
                      getenv("DF3D_OS_DBG") ? atoi(getenv("DF3D_OS_DBG")) : 0, in_channels / 4, in_group_stride / 4, out_channels, blocks, out_cols};
+#ifdef DF3D_OS_TRACE
+  a.trace = g_os_trace;
+#endif
   int rec = timing_rec_begin(cin, cout * groups, kvol, n_out, nbr, 1, stream);
   int rc = launch_os_any(cin, cout, a, stream);
   if (rc) return rc;
