@@ -145,16 +145,20 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
     }
   }
 
-  u32x4 wreg[WPT];
-  auto load_w = [&](int s) {
+  // The stream tile of step s + 1 goes to LDS during step s.  Round 3: it was fetched TWO steps before that (two register
+  // sets in turn; SPC is even, so the set of a step is a compile-time constant of the unrolled chunk) -- with one step of
+  // ~1000 clocks between the load and its use every step began with the rest of an L2 round trip.
+  static_assert(SPC % 2 == 0, "register set = step parity");
+  u32x4 wreg[2][WPT];
+  auto load_w = [&](int s, int set) {
     s = s < steps ? s : steps - 1;
     const u32x4 *src = a.w + (size_t)s * FFN_WQ;
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) wreg[i] = src[tid + NT * i];
+    for (int i = 0; i < WPT; ++i) wreg[set][i] = src[tid + NT * i];
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](int buf, int set) {
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) Wl[buf][tid + NT * i] = wreg[i];
+    for (int i = 0; i < WPT; ++i) Wl[buf][tid + NT * i] = wreg[set][i];
   };
 
   f32x4 acc2[RT][CT];
@@ -163,9 +167,10 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc2[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  load_w(0);
-  store_w(0);
-  load_w(1);
+  load_w(0, 0);
+  store_w(0, 0);
+  load_w(1, 1);
+  load_w(2, 0);
   for (int c = 0; c < nchunks; ++c) {
     f32x4 acc1[RT][8];
 #pragma unroll
@@ -178,8 +183,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
       const int s = c * SPC + kb;
       __syncthreads();
       if (!(a.dbg & 2)) {
-        store_w((s + 1) & 1);
-        load_w(s + 2);
+        store_w((s + 1) & 1, (kb + 1) & 1);
+        load_w(s + 3, (kb + 1) & 1);
       }
       const u32x4 *wb = Wl[s & 1] + lane;
       if (a.dbg & 1) continue;
@@ -237,8 +242,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
       const int s = c * SPC + KB + q;
       __syncthreads();
       if (!(a.dbg & 2)) {
-        store_w((s + 1) & 1);
-        load_w(s + 2);
+        store_w((s + 1) & 1, (KB + q + 1) & 1);
+        load_w(s + 3, (KB + q + 1) & 1);
       }
       const u32x4 *wb = Wl[s & 1] + lane;
       if (a.dbg & 1) continue;
@@ -362,7 +367,12 @@ static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, int d_
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
   }
-  static const int cfg = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 81;      // tuning aid: NW*10 + RT (1081: bf16 mode with one row tile)
+  // tuning aid: NW*10 + RT (1081: bf16 mode with one row tile).  Default (round 3, tools/ubench/ffn_probe.py): two row tiles
+  // per wave once their 256-row workgroups fill most of the CUs -- every operand fragment read from LDS then feeds two
+  // MFMAs, and the LDS pipe (128 KB of fragment reads per step and CU with one row tile: 1024 clocks against 768 of MFMAs) is
+  // what bounds this kernel: 2 x 31134 rows 122 -> 104 us
+  static const int cfg_env = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 0;
+  const int cfg = cfg_env ? cfg_env : ((long long)cdiv(max_rows, 256) * njobs >= 160 ? 82 : 81);
   if (jobs.s[0].bf16) {                          // every job of a launch shares the precision mode
     // one product per operand pair: the kernel is bound by the 1 MB weight stream every workgroup pulls from L2, so many
     // rows take two row tiles per wave (half the stream per row); DF3D_FFN_CFG=81 keeps one

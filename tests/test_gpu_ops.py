@@ -534,6 +534,7 @@ def test_groupnorm_fold(dev, gated):
 
 @pytest.mark.parametrize("rows,H,ln,res,C", [(1000, 1024, True, True, 128), (37, 256, True, False, 128),
                                               (130, 128, False, True, 128), (31000, 1024, True, True, 128),
+                                              (45001, 256, True, True, 128),      # two row tiles per wave (>= 160 workgroups)
                                               (1000, 1024, True, True, 64), (37, 128, False, True, 64),
                                               (40001, 128, False, True, 64), (513, 256, True, False, 64)])
 def test_ffn_fused(dev, rows, H, ln, res, C):
