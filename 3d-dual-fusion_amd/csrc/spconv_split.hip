@@ -1176,9 +1176,13 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
                : "+v"(af[buf][0][0]), "+v"(af[buf][0][1]), "+v"(af[buf][1][0]), "+v"(af[buf][1][1]), "+v"(bq[0][0]),   \
                  "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[1][2]), "+v"(bq[1][3]))
 #define LC_NONE do { } while (0)
+#ifdef DF3D_LC_NOB   /* experiment: no B-fragment reads (64 of the 80 KB a step reads from LDS) */
+#define LC_READ_B4(slot, wa, i) LC_NONE, LC_NONE, LC_NONE, LC_NONE
+#else
 #define LC_READ_B4(slot, wa, i)  /* the four fragments of batch i as statements RA .. RD */                            \
   LC_READ(bq[slot][0], wa, ((i) * 4 + 0) * 1024), LC_READ(bq[slot][1], wa, ((i) * 4 + 1) * 1024),                      \
       LC_READ(bq[slot][2], wa, ((i) * 4 + 2) * 1024), LC_READ(bq[slot][3], wa, ((i) * 4 + 3) * 1024)
+#endif
 #define LC_READ_A4(buf, aa0, aa1)                                                                                      \
   LC_READ(af[buf][0][0], aa0, 0), LC_READ(af[buf][0][1], aa1, 0), LC_READ(af[buf][1][0], aa0, 16 * 128),               \
       LC_READ(af[buf][1][1], aa1, 16 * 128)

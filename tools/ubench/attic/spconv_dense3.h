@@ -20,10 +20,10 @@
 // two steps to arrive with a ring of three stages (four would not fit beside the resident rows).
 //
 // NOT BUILT (round 3 negative result): bit-identical to the table path on every tested map and it halves
-// what a step moves into the CU, but the head's middle convolutions take 274 us with it against 267 us without.  Ablations of
-// the loader / consumer kernel in a -DDF3D_OS_EXPERIMENTS build (DF3D_OS_DBG=4 / 64 / 68 on tools/ubench/lc_trace_head.py)
-// show why: with NEITHER DMAs NOR MFMAs the launch still takes 215 us of 270 -- the matrix waves' LDS fragment reads (80 KB per
-// step and CU, ~900 clocks against 768 of MFMAs) and the epilogue's 298 MB of stores bound it, not the ingest.  It was wired as
+// what the loader waves issue per step, but the head's middle convolutions take 274 us with it against 267 us without.  In the
+// loader / consumer kernel the matrix waves (~916 clocks per step, 768 of them MFMAs) and the loader waves (~760 clocks issuing
+// four LDS-DMAs + the landing wait) are balanced and meet at a barrier; taking work off one side changes nothing (ablations:
+// no MFMAs 70 %, no DMAs 83 %, neither 54 %, no B-fragment LDS reads 100 % of the launch).  It was wired as
 // df3d_conv_rows_split_map3x3(in_split, in_channels, cin, in_group_stride, packed, cout, groups, nbr, batch, H, W, ...) with
 // SplitConvArgs.dH / dW and `#include "spconv_dense3.h"` behind spconv_ws.h.
 #pragma once
