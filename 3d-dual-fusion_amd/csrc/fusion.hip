@@ -333,6 +333,56 @@ __global__ __launch_bounds__(256) void gate_scatter_kernel(const float *__restri
   for (int k = 0; k < 9; ++k) dst[(size_t)k * hw] += s9[(size_t)i * 9 + k];   // row response is camera independent
 }
 
+// The same with the row responses computed on the fly (round 3): s[row][t] = <(features[row], pinv[row]), T[t]> only for the
+// WINNER rows -- the caller's torch.cat + [n, C + 3] x [C + 3, 9] GEMM per scale (two launches and ~25 us for a product only
+// the ~10 % winning rows of use) are gone.  T stands in LDS; all lanes of a wave read the same element (broadcast).
+__global__ __launch_bounds__(256) void gate_scatter_rows_kernel(const float *__restrict__ feat, int C,
+                                                                const float *__restrict__ pinv, const float *__restrict__ T,
+                                                                const int32_t *__restrict__ ind,
+                                                                const int32_t *__restrict__ grid,
+                                                                const uint8_t *__restrict__ mask,
+                                                                const int32_t *__restrict__ winner, int n, int ncam, int H,
+                                                                int W, float *__restrict__ S) {
+  extern __shared__ float Tl[];                     // [C + 3][9]
+  const int CE = C + 3;
+  for (int e = threadIdx.x; e < 9 * CE; e += 256) {
+    const int k = e / CE, c = e - k * CE;
+    Tl[c * 9 + k] = T[e];
+  }
+  __syncthreads();
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * ncam) return;
+  int cam = (int)(t / n), i = (int)(t - (long long)cam * n);
+  if (!mask[(size_t)cam * n + i]) return;
+  int gx = grid[((size_t)cam * n + i) * 2], gy = grid[((size_t)cam * n + i) * 2 + 1];
+  if (gx < 0 || gx >= W || gy < 0 || gy >= H) return;
+  int img = ind[(size_t)i * 4] * ncam + cam;
+  size_t pix = (size_t)gy * W + gx;
+  if (winner[(size_t)img * H * W + pix] != i) return;
+  float acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+  const float *f = feat + (size_t)i * C;
+  for (int c = 0; c < C; c += 4) {
+    const float4 v = *(const float4 *)(f + c);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[k] = fmaf(x[j], Tl[(c + j) * 9 + k], acc[k]);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float x = pinv[(size_t)i * 3 + j];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = fmaf(x, Tl[(C + j) * 9 + k], acc[k]);
+  }
+  size_t hw = (size_t)H * W;
+  float *dst = S + (size_t)img * 9 * hw + pix;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dst[(size_t)k * hw] += acc[k];
+}
+
 // att[img][p] = sigmoid(bias + sum_t inside * (k[t] + g[t]*gate[p+t] + S[t][p+t]))
 __global__ __launch_bounds__(256) void gate_finish_kernel(const float *__restrict__ gate, const float *__restrict__ S,
                                                           const float *__restrict__ kg /* [9] k_t, [9] g_t, bias */,
@@ -596,6 +646,26 @@ extern "C" int df3d_gate_scatter(const float *s9, const int32_t *indices, const 
   dim3 g(cdiv((long long)n * ncam, 256));
   hipLaunchKernelGGL(scatter_winner_kernel, g, dim3(256), 0, stream, a);
   hipLaunchKernelGGL(gate_scatter_kernel, g, dim3(256), 0, stream, s9, indices, grid_xy, mask, winner, n, ncam, H, W, S);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_gate_scatter_rows(const float *features, int channels, const float *point_inv, const float *T,
+                                      const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask, int n, int batch,
+                                      int ncam, int H, int W, int32_t *winner, float *S, int clear, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(winner && S, "gate_scatter_rows: null output");
+  DF3D_CHECK_ARG(channels > 0 && channels % 4 == 0 && channels <= 1024, "gate_scatter_rows: %d channels", channels);
+  size_t nimg = (size_t)batch * ncam;
+  if (clear) DF3D_HIP(hipMemsetAsync(S, 0, nimg * 9 * (size_t)H * W * sizeof(float), stream));
+  DF3D_HIP(hipMemsetAsync(winner, 0xff, nimg * H * W * sizeof(int32_t), stream));
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(features && point_inv && T && indices && grid_xy && mask, "gate_scatter_rows: null input");
+  ScatArgs a = {nullptr, nullptr, indices, grid_xy, mask, n, 0, ncam, H, W, winner, nullptr};
+  dim3 g(cdiv((long long)n * ncam, 256));
+  hipLaunchKernelGGL(scatter_winner_kernel, g, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(gate_scatter_rows_kernel, g, dim3(256), (size_t)(channels + 3) * 9 * sizeof(float), stream, features,
+                     channels, point_inv, T, indices, grid_xy, mask, winner, n, ncam, H, W, S);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -562,11 +562,21 @@ class VoxelWithPointProjection(nn.Module):
             for sidx in self.ifat.voxel_idx:
                 x = encoded_voxel_list[sidx]
                 grid_s, mask_s, pinv_s = proj[sidx]
-                rows = torch.cat([x.features, pinv_s], 1)
-                s9 = (rows @ T[sidx].t()).contiguous()                          # [n, 9]
-                rc = lib.df3d_gate_scatter(_p(s9), _p(x.indices.contiguous()), _p(grid_s), _p(mask_s), rows.shape[0],
-                                           B, ncam, H, W, _p(winner), _p(S), int(first), _ops._stream())
-                _lib.check(rc, "df3d_gate_scatter")
+                feats_s, Ts = x.features, T[sidx]
+                if (feats_s.dtype == torch.float32 and feats_s.shape[1] % 4 == 0 and Ts.dtype == torch.float32
+                        and os.environ.get("DF3D_GATE_ROWS", "1") == "1"):
+                    # the 9 responses of a row matter for the rows that win a pixel only: computed inside the scatter
+                    rc = lib.df3d_gate_scatter_rows(_p(feats_s.contiguous()), feats_s.shape[1], _p(pinv_s.contiguous()),
+                                                    _p(Ts.contiguous()), _p(x.indices.contiguous()), _p(grid_s), _p(mask_s),
+                                                    feats_s.shape[0], B, ncam, H, W, _p(winner), _p(S), int(first),
+                                                    _ops._stream())
+                    _lib.check(rc, "df3d_gate_scatter_rows")
+                else:
+                    rows = torch.cat([feats_s, pinv_s], 1)
+                    s9 = (rows @ Ts.t()).contiguous()                           # [n, 9]
+                    rc = lib.df3d_gate_scatter(_p(s9), _p(x.indices.contiguous()), _p(grid_s), _p(mask_s), rows.shape[0],
+                                               B, ncam, H, W, _p(winner), _p(S), int(first), _ops._stream())
+                    _lib.check(rc, "df3d_gate_scatter")
                 first = False
             att = torch.empty((NI, H, W), dtype=torch.float32, device=dev)
             rc = lib.df3d_gate_finish(_p(gate), _p(S), _p(kg), NI, H, W, _p(att), _ops._stream())

@@ -598,6 +598,11 @@ int df3d_scatter_winner(const int32_t *indices, const int32_t *grid_xy, const ui
                         int H, int W, int32_t *winner, void *stream);
 int df3d_gate_scatter(const float *s9, const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask,
                       int n, int batch, int ncam, int H, int W, int32_t *winner, float *S, int clear, void *stream);
+/* df3d_gate_scatter with the row responses computed inside (round 3): s9[row] = T [9][channels + 3] . (features[row],
+ * point_inv[row]) for the winning rows only -- replaces the caller's cat + GEMM per scale (attention.py:31-61 by linearity). */
+int df3d_gate_scatter_rows(const float *features, int channels, const float *point_inv, const float *T,
+                           const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask, int n, int batch, int ncam,
+                           int H, int W, int32_t *winner, float *S, int clear, void *stream);
 int df3d_gate_finish(const float *gate, const float *S, const float *kg, int nimg, int H, int W, float *att,
                      void *stream);
 /* df3d_query_slots: pos[cam][i] = number of visible voxels (mask[cam][.] != 0) of voxel i's sample before i,

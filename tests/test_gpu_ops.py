@@ -1340,3 +1340,46 @@ def test_assemble_queries_by_slot_equals_by_voxel(dev):
         a, b = run(True, use_att, use_pos), run(False, use_att, use_pos)
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [32, 128])
+def test_gate_scatter_with_row_responses_inside(C):
+    """df3d_gate_scatter_rows (round 3: the 9 tap responses of a voxel row computed inside the scatter, for the rows that win
+    a pixel only) against torch.cat + GEMM + df3d_gate_scatter: same winners, S within fp32 summation noise; two scales
+    accumulate into one S (clear only on the first)."""
+    import ctypes
+    from dualfusion import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(C)
+    B, ncam, H, W, n = 2, 3, 24, 40, 5000
+    p = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    outs = []
+    for rows_inside in (False, True):
+        S = torch.full((B * ncam, 9, H, W), 7.0, device=dev)
+        gen.manual_seed(C)
+        for scale in range(2):
+            feats = torch.randn((n, C), generator=gen).to(dev)
+            pinv = torch.randn((n, 3), generator=gen).to(dev)
+            T = (torch.randn((9, C + 3), generator=gen) * 0.2).to(dev)
+            ind = torch.zeros((n, 4), dtype=torch.int32)
+            ind[:, 0] = torch.sort(torch.randint(0, B, (n,), generator=gen)).values.int()
+            grid = torch.stack([torch.randint(-3, W + 3, (ncam, n), generator=gen),
+                                torch.randint(-3, H + 3, (ncam, n), generator=gen)], -1).int().contiguous().to(dev)
+            mask = (torch.rand((ncam, n), generator=gen) < 0.6).to(torch.uint8).to(dev)
+            ind = ind.to(dev)
+            winner = torch.empty((B * ncam, H, W), dtype=torch.int32, device=dev)
+            if rows_inside:
+                rc = lib.df3d_gate_scatter_rows(p(feats), C, p(pinv), p(T), p(ind), p(grid), p(mask), n, B, ncam, H, W,
+                                                p(winner), p(S), int(scale == 0), None)
+            else:
+                s9 = (torch.cat([feats, pinv], 1) @ T.t()).contiguous()
+                rc = lib.df3d_gate_scatter(p(s9), p(ind), p(grid), p(mask), n, B, ncam, H, W, p(winner), p(S),
+                                           int(scale == 0), None)
+            assert rc == 0
+        torch.cuda.synchronize()
+        outs.append((S.cpu(), winner.cpu()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 0.5
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-5 * max(1.0, float(outs[0][0].abs().max()))
