@@ -146,6 +146,9 @@ class CenterPointDetector(nn.Module):
         finally:
             hp.backbone.dense_layout = layout
         if host_copies == "async":
+            # (the device tensors stay available for a loss reduction over the ranks: reading them back from the pinned copies
+            # would be a blocking H2D copy queued behind the whole step)
+            rets["on_device"] = {key: list(rets[key]) for key in ("hm_loss", "loc_loss_elem", "loc_loss") if key in rets}
             for key in ("hm_loss", "loc_loss_elem"):
                 outs = []
                 for v in rets[key]:

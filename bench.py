@@ -190,7 +190,8 @@ class CenterPointWorkload(object):
                                             host_copies="async" if os.environ.get("DF3D_TRAIN_ASYNC_LOG", "1") == "1" else True)
             self.reducer.finish()                      # waits for the bucket all-reduces launched during backward
             self.optimizer.step()
-            return {k: torch.stack([v.detach().to(self.dev).float().reshape(()) for v in rets[k]])
+            dev_side = rets.get("on_device", {})           # async logging: the pinned host copies are not read back here
+            return {k: torch.stack([v.detach().to(self.dev).float().reshape(()) for v in dev_side.get(k, rets[k])])
                     for k in ("loss", "hm_loss", "loc_loss")}
         if stage == "hot_path":
             hp = self.model.hot_path
