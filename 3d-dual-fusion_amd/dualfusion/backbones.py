@@ -152,6 +152,17 @@ class SpMiddleResNetFHD(nn.Module):
             out = plan.run(voxel_features, coors, batch_size, [int(v) for v in sparse_shape])
             return out["conv1"], out["conv2"], out["conv3"], out["conv4"]
         ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape, batch_size)
+        ready = getattr(coors, "_df3d_ready", None)
+        if ready is not None and voxel_features.is_cuda and os.environ.get("DF3D_TRAIN_GEO_STREAM", "1") == "1":
+            # module path (training) on resident inputs: rulebooks on a stream of their own behind the voxeliser's event
+            # (spconv/conv.py `_rulebook`): their count round trips do not wait for the previous step's backward
+            from .spconv.conv import GEOMETRY_STREAM_KEY
+            geo = self.__dict__.get("_rulebook_stream")
+            if geo is None:
+                geo = self.__dict__["_rulebook_stream"] = torch.cuda.Stream(device=coors.device)
+            geo.wait_event(ready)
+            coors.record_stream(geo)
+            ret.indice_dict[GEOMETRY_STREAM_KEY] = geo
         x = self.conv_input(ret)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)

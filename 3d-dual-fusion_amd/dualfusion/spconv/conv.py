@@ -24,6 +24,10 @@ def _fan_in_hwio(weight):
     return int(np.prod(weight.shape[:-1]))
 
 
+
+# indice_dict entry (shared by every tensor derived from the network input) that holds the stream rulebooks are built on
+GEOMETRY_STREAM_KEY = "__df3d_geometry_stream"
+
 class SparseConvFunction(torch.autograd.Function):
     """indice_conv + its backward (TF/mmdet3d/ops/spconv/functional.py:20-75 -> ops.indice_conv /
     ops.indice_conv_backward) on the kernel-facing rulebook: forward = the exact-fp32 fused kernel (conv + bias),
@@ -139,11 +143,34 @@ class SparseConvolution(SparseModule):
             hit = input.indice_dict.get(auto_key)
             if hit is not None:
                 return hit
-        directory = input.directory()
-        outids, nbr, out_shape, out_dir = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape,
-                                                             self.kernel_size, self.stride, self.padding,
-                                                             self.dilation, self.subm, directory=directory,
-                                                             transpose=self.transposed, out_padding=self.output_padding)
+        geo = input.indice_dict.get(GEOMETRY_STREAM_KEY)
+        if geo is not None and input.indices.is_cuda:
+            # Training on resident inputs (backbones._stem): the rulebooks depend on the coordinates alone, so they are built
+            # on a side stream that was ordered behind the voxeliser's event only -- the host's round trip for an output
+            # count then waits for the few geometry kernels in front of it, not for the previous step's backward still
+            # queued on the caller's stream.  The caller's stream waits for the side stream; every tensor produced there is
+            # marked as used on the caller's stream (the allocator must not hand it to the next step's geometry early).
+            main = torch.cuda.current_stream(input.indices.device)
+            with torch.cuda.stream(geo):
+                directory = input.directory()
+                outids, nbr, out_shape, out_dir = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape,
+                                                                     self.kernel_size, self.stride, self.padding,
+                                                                     self.dilation, self.subm, directory=directory,
+                                                                     transpose=self.transposed,
+                                                                     out_padding=self.output_padding)
+            main.wait_stream(geo)
+            for d in (directory, out_dir):
+                for t in ((d.blob, d.perm) if d is not None else ()):
+                    if t is not None:
+                        t.record_stream(main)
+            for t in (outids, nbr):
+                t.record_stream(main)
+        else:
+            directory = input.directory()
+            outids, nbr, out_shape, out_dir = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape,
+                                                                 self.kernel_size, self.stride, self.padding,
+                                                                 self.dilation, self.subm, directory=directory,
+                                                                 transpose=self.transposed, out_padding=self.output_padding)
         rb = Rulebook(outids, input.indices, nbr, input.spatial_shape, out_shape, out_rows_sorted=not self.subm)
         if out_dir is not None and not self.subm:
             input._directories.put(outids, out_dir)
