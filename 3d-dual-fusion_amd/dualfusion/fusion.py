@@ -13,6 +13,7 @@ Execution differs: the reference loops cameras x samples x scales in Python (boo
 the only host sync is the read of max_ne (the padded query length), which the reference needs too.
 Semantics kept bug-for-bug.
 """
+import contextlib
 import ctypes
 
 import os
@@ -446,13 +447,49 @@ class VoxelWithPointProjection(nn.Module):
         scale's features, and all fusion parameters.  Same values as the inference path up to summation order."""
         x_last = encoded_voxel_list[-1]
         dev = x_last.features.device
-        with torch.no_grad():
+        # ---- integer work: it depends on the voxel COORDINATES and the calibration only.  When the rulebooks of this step were
+        #      built on a geometry stream (training on resident inputs, backbones._stem) it runs there too, so its host round
+        #      trips (three index lists, the longest camera list) wait for a few small kernels instead of for everything the
+        #      caller's stream still holds -- the previous step's backward included ----
+        from .spconv.conv import GEOMETRY_STREAM_KEY
+        geo = x_last.indice_dict.get(GEOMETRY_STREAM_KEY) if dev.type == "cuda" else None
+        main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        made = []
+
+        def keep(*ts):
+            made.extend(t for t in ts if torch.is_tensor(t))
+            return ts[0] if len(ts) == 1 else ts
+
+        with torch.no_grad(), (torch.cuda.stream(geo) if geo is not None else contextlib.nullcontext()):
             inp = self._gather_inputs(batch_dict, layer_name, dev)
             B, ncam, H, W = inp['B'], inp['ncam'], inp['h'], inp['w']
             NI = B * ncam
             last = len(encoded_voxel_list) - 1
             need = set([last]) | (set(self.ifat.voxel_idx) if self.ifat_cfg is not None else set())
-            proj = {s_: self._project(encoded_voxel_list[s_], d_factor_list[s_], inp) for s_ in sorted(need)}
+            proj = {s_: keep(*self._project(encoded_voxel_list[s_], d_factor_list[s_], inp)) for s_ in sorted(need)}
+            winners = {}
+            if self.ifat_cfg is not None:
+                for sidx in self.ifat.voxel_idx:
+                    grid_s, mask_s, pinv_s = proj[sidx]
+                    winner = self._winner(encoded_voxel_list[sidx], grid_s, mask_s, inp)    # [NI, H, W] row index or -1
+                    img_w, pix_w = torch.nonzero(winner.view(NI, H * W) >= 0, as_tuple=True)
+                    row_w = winner.view(NI, H * W)[img_w, pix_w].long()
+                    winners[sidx] = keep(img_w, pix_w, row_w)
+            grid, mask, pinv = proj[last]
+            ind = x_last.indices.contiguous()
+            pos, max_ne, counts = self._query_slots(ind, mask, B)
+            # (camera, row) pairs that own a query slot, camera-major
+            cam_i, row_i = torch.nonzero((mask != 0) & (pos.long() < max_ne), as_tuple=True)
+            img_i = ind[row_i, 0].long() * ncam + cam_i
+            slot_i = pos[cam_i, row_i].long()
+            gx, gy = grid[cam_i, row_i, 0].long(), grid[cam_i, row_i, 1].long()
+            qg = torch.stack([gx.to(torch.float32) / float(W), gy.to(torch.float32) / float(H)], 1)
+            per_cam = torch.bincount(cam_i, minlength=ncam).tolist()        # camera-major lists: contiguous ranges
+            keep(pos, counts, cam_i, row_i, img_i, slot_i, gx, gy, qg)
+        if geo is not None:
+            main.wait_stream(geo)
+            for t in made:
+                t.record_stream(main)
         imgs = torch.stack(inp['imgs'], 0)                                          # [NI, Ci, H, W]
         if img_conv_func is not None:
             imgs = img_conv_func(imgs)
@@ -461,38 +498,27 @@ class VoxelWithPointProjection(nn.Module):
             canvases = {}
             for sidx in self.ifat.voxel_idx:
                 x = encoded_voxel_list[sidx]
-                grid_s, mask_s, pinv_s = proj[sidx]
-                with torch.no_grad():
-                    winner = self._winner(x, grid_s, mask_s, inp)                   # [NI, H, W] row index or -1
-                    img_w, pix_w = torch.nonzero(winner.view(NI, H * W) >= 0, as_tuple=True)
-                    row_w = winner.view(NI, H * W)[img_w, pix_w].long()
-                rows = torch.cat([x.features, pinv_s], 1)                           # [n, C + 3]
+                img_w, pix_w, row_w = winners[sidx]
+                rows = torch.cat([x.features, proj[sidx][2]], 1)                    # [n, C + 3]
                 # pts2img: the winner's row at its pixel, zero elsewhere (a gather over the occupied pixels only: the
                 # backward of a dense gather with every empty pixel clamped to one row serialises on that row)
                 canvases[sidx] = rows.new_zeros((NI, H * W, rows.shape[1])).index_put((img_w, pix_w), rows[row_w])
             gated = self.ifat.forward_rows(imgs, canvases)
-        grid, mask, pinv = proj[last]
         feats = x_last.features
-        ind = x_last.indices.contiguous()
         n, C = feats.shape
-        with torch.no_grad():
-            pos, max_ne, counts = self._query_slots(ind, mask, B)
-            # (camera, row) pairs that own a query slot, camera-major
-            cam_i, row_i = torch.nonzero((mask != 0) & (pos.long() < max_ne), as_tuple=True)
-            img_i = ind[row_i, 0].long() * ncam + cam_i
-            slot_i = pos[cam_i, row_i].long()
-            gx, gy = grid[cam_i, row_i, 0].long(), grid[cam_i, row_i, 1].long()
         Ci = gated.shape[1]
         v_feat = feats.new_zeros((NI, max_ne, C)).index_put((img_i, slot_i), feats[row_i])
         v_i_feat = feats.new_zeros((NI, max_ne, Ci)).index_put((img_i, slot_i), gated[img_i, :, gy, gx])
-        qgrid = feats.new_zeros((NI, max_ne, 2)).index_put(
-            (img_i, slot_i), torch.stack([gx.to(feats.dtype) / float(W), gy.to(feats.dtype) / float(H)], 1))
+        qgrid = feats.new_zeros((NI, max_ne, 2)).index_put((img_i, slot_i), qg.to(feats.dtype))
         qpts = feats.new_zeros((NI, max_ne, 3)).index_put((img_i, slot_i), pinv[row_i])
         enh = self.pfat(v_feat, qgrid, [gated], v_i_feat, qpts)                     # [NI, max_ne, C]
         out = feats
+        a = 0
         for cam in range(ncam):                                                     # additive, camera order (writeback_kernel)
-            sel = cam_i == cam
-            out = out.index_add(0, row_i[sel], enh[img_i[sel], slot_i[sel]])
+            b = a + int(per_cam[cam])
+            if b > a:
+                out = out.index_add(0, row_i[a:b], enh[img_i[a:b], slot_i[a:b]])
+            a = b
         return x_last.replace_feature(out)
 
     def _winner(self, x, grid, mask, inp):
