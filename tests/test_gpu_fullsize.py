@@ -248,6 +248,46 @@ def test_detector_training_step_with_camera_fusion():
         assert float((v.detach() - before[k]).abs().max()) > 0, k
 
 
+def test_training_steps_with_geometry_on_its_own_stream(monkeypatch):
+    """Training on resident inputs (what bench.py --stage train runs): rulebooks and the adapter's integer work on a stream of
+    their own behind the voxeliser's event (`spconv/conv.py` `_rulebook`, `fusion.forward_autograd`), three steps queued back to
+    back without a host wait in between.  Losses and a backbone filter gradient of every step must be those of the same steps
+    with everything on the caller's stream (DF3D_TRAIN_GEO_STREAM=0) up to the summation order of the atomics."""
+    from dualfusion import synth
+    from dualfusion.fusion import build_centerpoint_fusion, synthetic_camera_inputs
+    from dualfusion.pipeline import NUSC_TASKS, CenterPointDetector
+    torch.manual_seed(0)
+    det = CenterPointDetector(fusion=build_centerpoint_fusion()).to(DEV).train()
+    det.hot_path.resident_inputs = True
+    det.hot_path.fusion.resident_inputs = True
+    frames = []
+    for k in range(3):
+        pts = [torch.from_numpy(synth.nusc_sweep(seed=21 + k)).to(DEV)]
+        bd, ex = synthetic_camera_inputs(1, DEV, seed=5 + k)
+        tg = synth.centerhead_targets(1, [t["num_class"] for t in NUSC_TASKS], seed=8 + k)
+        frames.append((pts, bd, dict(ex, **{k_: [torch.from_numpy(a).to(DEV) for a in v] for k_, v in tg.items()})))
+    torch.cuda.synchronize()
+    w = det.hot_path.backbone.conv3[0].weight
+    state = {k: v.detach().clone() for k, v in det.state_dict().items()}       # BatchNorm running statistics move
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DF3D_TRAIN_GEO_STREAM", mode)
+        det.load_state_dict(state)
+        torch.manual_seed(7)                                                   # the encoder layers' dropout masks
+        torch.cuda.manual_seed_all(7)
+        outs = []
+        for pts, bd, ex in frames:                                             # no synchronisation between the steps
+            det.zero_grad(set_to_none=True)
+            rets = det.training_step(pts, dict(ex), batch_dict=dict(bd), host_copies="async")
+            outs.append((torch.stack([v.detach().reshape(()) for v in rets["loss"]]), w.grad.detach().clone()))
+        torch.cuda.synchronize()
+        results[mode] = [(l.cpu(), g.cpu()) for l, g in outs]
+    for (l1, g1), (l0, g0) in zip(results["1"], results["0"]):
+        assert bool(torch.isfinite(l1).all())
+        torch.testing.assert_close(l1, l0, rtol=1e-4, atol=1e-5)
+        assert float((g1 - g0).abs().max()) <= 2e-3 * float(g0.abs().max())
+
+
 def test_rulebooks_beyond_the_int32_flat_index(sweep):
     """Batch 27 of the full grid: flat index = b * 41 * 1440 * 1440 passes 2^31 at b = 26, where the reference's int32
     `index` overflows (TF/mmdet3d/ops/spconv/include/spconv/indice.cu.h:59-60, geometry.h rowArrayIdxInv).  The directory and
