@@ -338,11 +338,11 @@ __global__ __launch_bounds__(256) void gate_scatter_kernel(const float *__restri
 // the ~10 % winning rows of use) are gone.  T stands in LDS; all lanes of a wave read the same element (broadcast).
 __global__ __launch_bounds__(256) void gate_scatter_rows_kernel(const float *__restrict__ feat, int C,
                                                                 const float *__restrict__ pinv, const float *__restrict__ T,
-                                                                const int32_t *__restrict__ ind,
-                                                                const int32_t *__restrict__ grid,
-                                                                const uint8_t *__restrict__ mask,
-                                                                const int32_t *__restrict__ winner, int n, int ncam, int H,
-                                                                int W, float *__restrict__ S) {
+                                                                const int32_t *__restrict__ winner, long long npix, int hw,
+                                                                int clear, float *__restrict__ S) {
+  // one thread per (image, pixel): the pixel's winner row (scatter_winner_kernel; -1 = none) is the only row that
+  // contributes, so only it is multiplied; with `clear` the thread WRITES its nine values (zeros without a winner) and the
+  // caller needs no zero fill of S
   extern __shared__ float Tl[];                     // [C + 3][9]
   const int CE = C + 3;
   for (int e = threadIdx.x; e < 9 * CE; e += 256) {
@@ -350,15 +350,19 @@ __global__ __launch_bounds__(256) void gate_scatter_rows_kernel(const float *__r
     Tl[c * 9 + k] = T[e];
   }
   __syncthreads();
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)n * ncam) return;
-  int cam = (int)(t / n), i = (int)(t - (long long)cam * n);
-  if (!mask[(size_t)cam * n + i]) return;
-  int gx = grid[((size_t)cam * n + i) * 2], gy = grid[((size_t)cam * n + i) * 2 + 1];
-  if (gx < 0 || gx >= W || gy < 0 || gy >= H) return;
-  int img = ind[(size_t)i * 4] * ncam + cam;
-  size_t pix = (size_t)gy * W + gx;
-  if (winner[(size_t)img * H * W + pix] != i) return;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npix) return;
+  const long long img = t / hw;
+  const int pix = (int)(t - img * hw);
+  float *dst = S + (size_t)img * 9 * hw + pix;
+  const int i = winner[t];
+  if (i < 0) {
+    if (clear) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dst[(size_t)k * hw] = 0.f;
+    }
+    return;
+  }
   float acc[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.f;
@@ -377,10 +381,8 @@ __global__ __launch_bounds__(256) void gate_scatter_rows_kernel(const float *__r
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = fmaf(x, Tl[(C + j) * 9 + k], acc[k]);
   }
-  size_t hw = (size_t)H * W;
-  float *dst = S + (size_t)img * 9 * hw + pix;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) dst[(size_t)k * hw] += acc[k];
+  for (int k = 0; k < 9; ++k) dst[(size_t)k * hw] = clear ? acc[k] : dst[(size_t)k * hw] + acc[k];
 }
 
 // att[img][p] = sigmoid(bias + sum_t inside * (k[t] + g[t]*gate[p+t] + S[t][p+t]))
@@ -657,15 +659,18 @@ extern "C" int df3d_gate_scatter_rows(const float *features, int channels, const
   DF3D_CHECK_ARG(winner && S, "gate_scatter_rows: null output");
   DF3D_CHECK_ARG(channels > 0 && channels % 4 == 0 && channels <= 1024, "gate_scatter_rows: %d channels", channels);
   size_t nimg = (size_t)batch * ncam;
-  if (clear) DF3D_HIP(hipMemsetAsync(S, 0, nimg * 9 * (size_t)H * W * sizeof(float), stream));
   DF3D_HIP(hipMemsetAsync(winner, 0xff, nimg * H * W * sizeof(int32_t), stream));
-  if (n == 0) return DF3D_OK;
+  if (n == 0) {
+    if (clear) DF3D_HIP(hipMemsetAsync(S, 0, nimg * 9 * (size_t)H * W * sizeof(float), stream));
+    return DF3D_OK;
+  }
   DF3D_CHECK_ARG(features && point_inv && T && indices && grid_xy && mask, "gate_scatter_rows: null input");
+  DF3D_CHECK_ARG((long long)H * W < 0x7fffffffLL, "gate_scatter_rows: map size");
   ScatArgs a = {nullptr, nullptr, indices, grid_xy, mask, n, 0, ncam, H, W, winner, nullptr};
-  dim3 g(cdiv((long long)n * ncam, 256));
-  hipLaunchKernelGGL(scatter_winner_kernel, g, dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(gate_scatter_rows_kernel, g, dim3(256), (size_t)(channels + 3) * 9 * sizeof(float), stream, features,
-                     channels, point_inv, T, indices, grid_xy, mask, winner, n, ncam, H, W, S);
+  hipLaunchKernelGGL(scatter_winner_kernel, dim3(cdiv((long long)n * ncam, 256)), dim3(256), 0, stream, a);
+  const long long npix = (long long)nimg * H * W;
+  hipLaunchKernelGGL(gate_scatter_rows_kernel, dim3(cdiv(npix, 256)), dim3(256), (size_t)(channels + 3) * 9 * sizeof(float),
+                     stream, features, channels, point_inv, T, winner, npix, H * W, clear, S);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }
