@@ -48,10 +48,21 @@ def init_from_env(backend=None, single=False):
     if (world > 1 or single or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if launched and "MASTER_PORT" in os.environ:
+        if world > 1:
+            # several ranks: ALWAYS the launcher's rendezvous.  A private one-rank group here would leave every rank
+            # believing it is alone while frame_shard() still divides the frames by `world`.
+            missing = [k for k in ("MASTER_ADDR", "MASTER_PORT") if k not in os.environ]
+            if missing:
+                raise RuntimeError("init_from_env: WORLD_SIZE=%d but %s not set (launch with torch.distributed.run "
+                                   "--master-addr 127.0.0.1 --master-port P)" % (world, " / ".join(missing)))
+            dist.init_process_group(backend, init_method="env://")
+        elif launched and "MASTER_PORT" in os.environ:
             dist.init_process_group(backend, init_method="env://")
         else:
             dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1)
+    if dist.is_initialized() and dist.get_world_size() != world:
+        raise RuntimeError("init_from_env: process group has %d ranks, WORLD_SIZE says %d"
+                           % (dist.get_world_size(), world))
     return rank, local, world
 
 

@@ -44,9 +44,13 @@ class CenterPointHotPath(nn.Module):
         `while_waiting`: enqueued behind the first sweep's voxelizer while the host waits for its voxel count."""
         from . import ops as _ops
         vl = self.voxel_layer                       # a batch: all clouds queued, ONE round trip for their voxel counts
-        return _ops.hard_voxelize_clouds([p.contiguous().float() for p in points_list], vl.voxel_size, vl.point_cloud_range,
+        clouds = [p.contiguous().float() for p in points_list]
+        # `resident_inputs` promises clouds that are COMPLETE in device memory; a cloud this method had to convert (dtype /
+        # layout copy queued on the caller's stream just now) is not -- the voxel stream would race with that copy (ADVICE r3)
+        resident = self.resident_inputs and all(q is p for q, p in zip(clouds, points_list))
+        return _ops.hard_voxelize_clouds(clouds, vl.voxel_size, vl.point_cloud_range,
                                          vl.max_num_points, vl._cap(), break_at_cap=False, while_waiting=while_waiting,
-                                         resident_inputs=self.resident_inputs)
+                                         resident_inputs=resident)
 
     @torch.no_grad()
     def forward(self, points_list, batch_dict=None, example=None):

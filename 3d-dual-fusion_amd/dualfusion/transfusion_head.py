@@ -737,6 +737,10 @@ class TransFusionHead(nn.Module):
         assert P_all == layers * K
         gt, lab, off, counts = self._pack_gt(gt_bboxes_3d, gt_labels_3d, dev)
         gmax = max(counts + [1])
+        if sum(counts) == 0:
+            # a batch in which NO sample has ground truth (accepted here): the kernels still want
+            # non-null tables for gmax = 1 -- one zero row that no sample's [off[b], off[b+1]) range refers to
+            gt, lab = gt.new_zeros((1, gt.shape[1])), lab.new_zeros((1,))
         want_grad = torch.is_grad_enabled() and (rows.requires_grad or p['dense_heatmap'].requires_grad)
         cfg = self.train_cfg
         cost, iou, _ = _ops.tf_match_cost(rows.detach(), code, C, gt, lab, off, gmax, **self._match_cfg())

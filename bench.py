@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the hot_path / fp32 passes after the timed region")
+    ap.add_argument("--no-side-configs", dest="side_configs", action="store_false",
+                    help="skip the ~10-step passes over BASELINE configs[0] / [2] / [4] after the headline (N = 1 only)")
     ap.add_argument("--cpu-sweeps", type=int, default=5, help="sweeps of the CPU baseline at all threads (after 1 warm-up)")
     return ap.parse_args()
 
@@ -236,6 +238,20 @@ def conv_algorithmic(rec, pairs):
     return by, 2 * pairs * cin * cout, extra
 
 
+def trace_kernel_name(cin, cout, K, split, n_out):
+    """Name of the kernel libdf3d_hip.so launches for this shape, as a rocprofv3 kernel trace prints it (so that this table
+    joins `profiles/*_kernel_stats.csv`): mirrors the dispatch in csrc/spconv.hip (`dispatch_small`, `dispatch_cin`) and
+    csrc/spconv_split.hip (`launch_os_split`, `launch_os_split_wide`, `use_lc`)."""
+    if not split:
+        if n_out >= 2048 and (cin, cout) in ((16, 16), (5, 16), (4, 16), (16, 32)):
+            return "spconv_small_kernel<%d, %d>" % (cin, cout)
+        return "spconv_mfma_kernel<%d, %d, ...>" % (max(cin, 8), cout)
+    gy = max(1, cout // 128) if cout % 128 == 0 else 1
+    if cout % 128 == 0 and cin % 32 == 0 and K > 1 and -(-n_out // 128) * gy >= 190:
+        return "spconv_os_lc_kernel<%d, 128>" % cin
+    return "spconv_os_split_kernel<%d, %d, ...>" % (cin, cout)
+
+
 def roofline_from_timer(timer, meta_timer, want=None):
     """Dominant sparse-conv kernel of the timed region: HIP-event time per launch (`timer`) against the algorithmic
     bytes / flops of the same launches (pair counts from `meta_timer`: one extra untimed pass over every frame).
@@ -284,11 +300,10 @@ def roofline_from_timer(timer, meta_timer, want=None):
         ach = by / sec / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(ach / PEAK_HBM_GBS, 4)}
-    kname = ("spconv_os_split_kernel" if split else ("spconv_pair_kernel" if cout == 128 and cin >= 64
-                                                     else "spconv_mfma_kernel"))
     n_out_avg = g["n_out"] // g["n"]
+    kname = trace_kernel_name(cin, cout, K, split, n_out_avg)
     s = 2 if split == 2 else 4
-    roof.update({"traffic": None, "kernel": "%s<cin=%d,cout=%d,K=%d>" % (kname, cin, cout, K),
+    roof.update({"traffic": None, "kernel": "%s K=%d" % (kname, K),
                  "precision": ("bf16 rows and weights, fp32 accumulate" if split == 2 else
                                "split bf16 hi/lo operands, 3 MFMA products, fp32 accumulate" if split else "fp32 MFMA"),
                  "launches": g["n"], "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),
@@ -505,6 +520,46 @@ def cpu_baseline(wl, n_sweeps=5):
                           ", camera fusion through the oracle port (kind 'port' for that stage)" if fusion_on else "", wall)}
 
 
+# ------------------------------------------------------------------------------------------------ the other configs
+SIDE_CONFIGS = (("cp_lidar", "configs[0] shape", "split"), ("tf_fusion", "configs[2]", "bf16"), ("vr_fusion", "configs[4]", "split"))
+
+
+def side_configs(args, rank, world, dev, barrier, reduce_losses, steps=10):
+    """BASELINE configs[0] (shape), [2] and [4] after the headline, ~`steps` timed steps each with the same protocol (every
+    distinct frame once, warm-up, barrier, K steps, barrier): compact numbers for the END of the JSON line, where the
+    driver's record keeps them.  A failure of one of them is reported in its entry and does not fail the bench line."""
+    import copy
+    import gc
+    from dualfusion import ops
+    out = {}
+    keep = ops.CONV_PRECISION
+    for name, cfg, prec in SIDE_CONFIGS:
+        if name == args.workload:
+            continue
+        a = copy.copy(args)
+        a.workload, a.batch, a.frames = name, 0, 4
+        try:
+            ops.CONV_PRECISION = prec
+            w = make_workload(a, rank, world, dev)
+            for k in range(len(w.frames) + 3):
+                o = w.step(k, "detect")
+                if isinstance(o, dict):
+                    reduce_losses(o)
+            e, o = timed_steps(w, "detect", steps, 0, barrier, reduce_losses)
+            w.check(o, "detect")
+            out[name] = {"cfg": cfg, "ms_per_step": round(e / steps * 1e3, 3), "bs": w.batch,
+                         "value": round(steps * w.batch * world / e, 1), "unit": w.unit_name + "/s",
+                         "dtype": {"split": "f32(split-bf16x3)", "bf16": "bf16", "fp32": "f32"}[prec], "steps": steps}
+            del w, o
+        except Exception as ex:                                  # noqa: BLE001
+            out[name] = {"cfg": cfg, "error": repr(ex)[:120]}
+        finally:
+            ops.CONV_PRECISION = keep
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ main
 def timed_steps(wl, stage, steps, first, barrier, reduce_losses):
     barrier()
@@ -666,6 +721,10 @@ def main():
             api = api_probe(wl, stage)
         except Exception as e:                                   # noqa: BLE001  (a measurement aid must not fail the bench line)
             print("bench.py: api probe failed: %r" % (e,), file=sys.stderr)
+    side = None
+    if (world == 1 and args.side_configs and not protocol and stage == "detect" and args.workload == "cp_fusion"
+            and not args.no_extra_passes):
+        side = side_configs(args, rank, world, dev, barrier, reduce_losses)
     if rank == 0:
         units = args.steps * wl.batch * world
         per_step = lambda e: round(e / args.steps * 1e3, 4)      # noqa: E731
@@ -690,7 +749,14 @@ def main():
             "collective_backend": (torch.distributed.get_backend() if D.is_dist() else None), "world_size": world,
         }
         if stage == "train":
+            async_log = os.environ.get("DF3D_TRAIN_ASYNC_LOG", "1") == "1"
             res["config"]["training"] = {"trainable_parameters": getattr(wl, "n_params", None), "optimizer": "AdamW (fused)",
+                                         "loss_logging": ("async: hm_loss / loc_loss_elem go to pinned host memory without a host "
+                                                          "wait (a trainer reads them every N steps behind an event); NOT the "
+                                                          "reference's per-step .cpu() of parse_second_losses -- "
+                                                          "DF3D_TRAIN_ASYNC_LOG=0 times that" if async_log else
+                                                          "sync: the reference's per-step .cpu() copies of the logged losses "
+                                                          "(trainer.py parse_second_losses) inside the timed step"),
                                          "gradient_reduction": "GradBucketReducer: %d bucket(s) of <= 16 MB, all-reduces launched in "
                                                                "bucket order from post-accumulate-grad hooks during backward" % len(wl.reducer.buckets)}
         if stage in ("detect", "train") and isinstance(out, dict) and "encoded_spconv_tensor" not in out:
@@ -746,6 +812,13 @@ def main():
                     "algorithmic bytes or flops / that time; mfma peak = dense bf16 / 3 (split precision spends three products)")
         if world == 1 and not args.no_cpu_baseline and args.workload in ("cp_fusion", "cp_lidar"):
             res["cpu_baseline"] = cpu_baseline(wl, args.cpu_sweeps)
+        if "fp32_detect" in extra:
+            # the like-for-like number (every convolution on exact-fp32 MFMA) inside a field the driver's record keeps
+            res["dtype"] = "%s; exact-fp32 step %.2f ms = %.1f %s/s" % (
+                res["dtype"].split(" (")[0] + " split-bf16x3 convs+FFN, fp32 accumulate, <=1e-4 of scale",
+                per_step(extra["fp32_detect"]), units / extra["fp32_detect"], wl.unit_name)
+        if side is not None:
+            res["configs"] = side                                   # LAST key: the driver's record keeps the tail of the line
         print(json.dumps(res))
         sys.stdout.flush()
     if D.is_dist():

@@ -73,6 +73,51 @@ def test_bench_self_spawn_two_ranks_gloo():
     assert res["ms_per_step"] >= 2.0 and abs(res["value"] - 2 * 1e3 / res["ms_per_step"]) < 0.5
 
 
+def test_bench_eight_ranks_gloo_driver_launch():
+    """The launch line the driver uses at the target width -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...` -- with the protocol workload over gloo: eight ranks
+    rendezvous, barrier, time the steps (MAX over ranks), reduce the loss scalars to rank 0, ONE JSON line, n_gpus = 8."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "protocol",
+           "--backend", "gloo", "--steps", "4", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["world_size"] == 8 and res["collective_backend"] == "gloo"
+    assert res["config"]["global_batch"] == 8 and res["scaling"] == "weak"
+    # loss = 1 + rank averaged over 8 ranks = 4.5; hm_loss = 10 (1 + rank) -> 45
+    assert abs(res["reduced_losses"]["loss"][0] - 4.5) < 1e-6 and abs(res["reduced_losses"]["hm_loss"][0] - 45.0) < 1e-5
+    assert abs(res["value"] - 8 * 1e3 / res["ms_per_step"]) < 2.0
+
+
+def test_init_from_env_refuses_a_private_group_when_world_size_says_more(tmp_path):
+    """WORLD_SIZE > 1 without MASTER_PORT must not fall back to a private one-rank group (the ranks would
+    shard the frames by WORLD_SIZE and reduce over a world of one): it raises."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, os.path.join(%r, "3d-dual-fusion_amd"))
+        from dualfusion import dist as D
+        try:
+            D.init_from_env("gloo")
+        except RuntimeError as e:
+            assert "MASTER_PORT" in str(e), e
+            print("REFUSED")
+        else:
+            print("ACCEPTED")
+    """) % ROOT)
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
+    env.pop("MASTER_PORT", None)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0 and "REFUSED" in out.stdout, out.stdout + out.stderr[-1500:]
+
+
 def test_reduce_dict_mixed_shapes_two_ranks(tmp_path):
     """reduce_dict with per-task vectors and a matrix in one dict (CenterHead.loss_device's layout): one collective."""
     worker = textwrap.dedent("""

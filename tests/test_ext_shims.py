@@ -23,7 +23,7 @@ PYBIND = {
     "ball_query_ext": ["ball_query_wrapper"],
     "group_points_ext": ["forward", "backward"],
     "gather_points_ext": ["gather_points_wrapper", "gather_points_grad_wrapper"],
-    "iou3d_cuda": ["boxes_overlap_bev_gpu", "boxes_iou_bev_gpu"],
+    "iou3d_cuda": ["boxes_overlap_bev_gpu", "boxes_iou_bev_gpu", "nms_gpu", "nms_normal_gpu"],
 }
 
 

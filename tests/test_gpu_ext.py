@@ -218,3 +218,47 @@ def test_iou3d_cuda_entries_fill_the_callers_tensor():
     iou3d_cuda.boxes_iou_bev_gpu(T(xy(a)), T(xy(b)), iou)
     sa, sb = (a[:, 3] * a[:, 4])[:, None], (b[:, 3] * b[:, 4])[None]
     assert np.abs(iou.cpu().numpy() - want / np.maximum(sa + sb - want, 1e-8)).max() < 2e-4
+
+
+def test_iou3d_cuda_nms_entries_vs_oracle_and_reference_kernel():
+    """`nms_gpu` / `nms_normal_gpu` under the reference's calling protocol (iou3d_utils.py:27-75): score-sorted [N, 5] boxes,
+    a CPU int64 `keep`, the number kept returned -- against the greedy pass over the oracle's overlap matrix and, where it is
+    built, the reference's own kernels on the same GPU (oracle/_ref/iou3d_cuda.so)."""
+    from dualfusion.ext import iou3d_cuda
+    from oracle import ref
+    v = detgen.bev_boxes("ioue_nms", 300, 7.0)
+    xy = np.stack([v[:, 0] - v[:, 3] / 2, v[:, 1] - v[:, 4] / 2, v[:, 0] + v[:, 3] / 2, v[:, 1] + v[:, 4] / 2, v[:, 6]], 1).astype(np.float32)
+    ov = orc.tf_boxes_overlap_bev(xy, xy)
+    s = (xy[:, 2] - xy[:, 0]) * (xy[:, 3] - xy[:, 1])
+    iou = ov / np.maximum(s[:, None] + s[None] - ov, 1e-8)
+    l, r = np.maximum(xy[:, None, 0], xy[None, :, 0]), np.minimum(xy[:, None, 2], xy[None, :, 2])
+    t, b = np.maximum(xy[:, None, 1], xy[None, :, 1]), np.minimum(xy[:, None, 3], xy[None, :, 3])
+    inter = np.maximum(r - l, 0) * np.maximum(b - t, 0)
+    iou_n = inter / np.maximum(s[:, None] + s[None] - inter, 1e-8)
+
+    def greedy(m, th):
+        rem, out = np.zeros(len(m), bool), []
+        for i in range(len(m)):
+            if not rem[i]:
+                out.append(i)
+                rem[i + 1:] |= m[i, i + 1:] > th
+        return out
+    for name, mat, lo, hi in (("nms_gpu", iou, 0.15, 0.25), ("nms_normal_gpu", iou_n, 0.25, 0.35)):
+        # a pair within rounding of the threshold may flip between float implementations: the threshold is put into the
+        # middle of the widest gap between the IoUs of this box set inside [lo, hi]
+        vals = np.sort(np.concatenate([[lo], mat[np.triu_indices(len(mat), 1)], [hi]]))
+        vals = vals[(vals >= lo) & (vals <= hi)]
+        g = int(np.argmax(np.diff(vals)))
+        th = float((vals[g] + vals[g + 1]) / 2)
+        assert np.abs(mat[np.triu_indices(len(mat), 1)] - th).min() > 1e-4
+        keep = torch.zeros(len(xy), dtype=torch.long)
+        n = getattr(iou3d_cuda, name)(T(xy), keep, th, 0)
+        want = greedy(mat, th)
+        assert n == len(want) and keep[:n].tolist() == want and 5 < n < len(xy)
+        if ref.available("iou3d_cuda"):
+            keep_r = torch.zeros(len(xy), dtype=torch.long)
+            n_r = getattr(ref.load("iou3d_cuda"), name)(T(xy), keep_r, th, 0)
+            assert n_r == n and keep_r[:n_r].tolist() == want
+    assert iou3d_cuda.nms_gpu(torch.zeros((0, 5), device=DEV), torch.zeros(0, dtype=torch.long), 0.2, 0) == 0
+    with pytest.raises(RuntimeError):
+        iou3d_cuda.nms_gpu(T(xy), torch.zeros(len(xy), dtype=torch.int32), 0.2, 0)

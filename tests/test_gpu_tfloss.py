@@ -200,6 +200,32 @@ def test_full_size_properties_and_empty_samples():
     assert 0 < ones <= sum(len(g[1]) for g in gts)
 
 
+def test_batch_without_any_ground_truth():
+    """every sample of the batch empty -- `loss_device` must accept it (the torch `loss` path does) and give
+    the same all-negative losses and gradients."""
+    head = _nusc_head()
+    B, K, C = 2, 200, 10
+    rs = np.random.RandomState(5)
+    p = {"center": rs.uniform(5, 175, (B, 2, K)), "height": rs.uniform(-2, 0, (B, 1, K)), "dim": rs.normal(0.7, 0.5, (B, 3, K)),
+         "rot": rs.normal(0, 1, (B, 2, K)), "vel": rs.normal(0, 1, (B, 2, K)), "heatmap": rs.normal(-2, 1.5, (B, C, K)),
+         "dense_heatmap": rs.normal(-3, 1.5, (B, C, 180, 180))}
+    p = {k: torch.from_numpy(v.astype(np.float32)).to(DEV).requires_grad_(True) for k, v in p.items()}
+    gt_boxes = [torch.zeros((0, 9)) for _ in range(B)]
+    gt_labels = [torch.zeros((0,), dtype=torch.int64) for _ in range(B)]
+    dl = head.loss_device(gt_boxes, gt_labels, ([p],))
+    sum(v for n, v in dl.items() if "loss" in n).backward()
+    grads_dev = {k: (v.grad.clone() if v.grad is not None else None) for k, v in p.items()}
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    tl = head.loss(gt_boxes, gt_labels, ([{k: v * 1 for k, v in leaf.items()}],))
+    sum(v for n, v in tl.items() if "loss" in n).backward()
+    for k in dl:
+        assert abs(dl[k].item() - tl[k].item()) < 2e-4 * max(1.0, abs(tl[k].item())), (k, dl[k].item(), tl[k].item())
+    assert dl["layer_-1_loss_bbox"].item() == 0.0 and int(head._last_num_pos.item()) == 0
+    for k in ("heatmap", "dense_heatmap"):
+        d = (grads_dev[k] - leaf[k].grad).abs().max().item()
+        assert d < 1e-4 * leaf[k].grad.abs().max().item() + 1e-8, (k, d)
+
+
 def _nusc_head():
     from dualfusion import synth
     from dualfusion.transfusion_head import TransFusionHead
