@@ -194,6 +194,15 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_backbone_run": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_size_t, c_void_p, c_void_p, c_void_p]),
+    "df3d_backbone_geometry": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    "df3d_backbone_convs": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "df3d_backbone_geometry_wait": (c_int, [c_void_p, c_void_p]),
+    "df3d_head_worker_create": (c_void_p, [c_int]),
+    "df3d_head_worker_destroy": (c_int, [c_void_p]),
+    "df3d_frame_head_submit": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_frame_head_wait": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_backbone_release": (c_int, [c_void_p]),
     "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,
                                    c_void_p]),

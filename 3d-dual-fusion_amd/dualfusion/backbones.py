@@ -144,10 +144,29 @@ class SpMiddleResNetFHD(nn.Module):
         object.__setattr__(self, "_exec_plan", False)
         return super(SpMiddleResNetFHD, self).train(mode)
 
-    def _stem(self, voxel_features, coors, batch_size, input_shape):
+    # the stages the camera-fusion adapter reads and their down-sampling factors (forward() of the fusion variant below)
+    FUSE_STAGES = ("conv2", "conv3", "conv4")
+    FUSE_D_FACTORS = [2, 4, 8]
+
+    def prepare_geometry(self, coors, in_channels, batch_size, input_shape):
+        """Every rulebook / index set of this backbone from the voxel COORDINATES alone (executor phase 1,
+        `BackbonePlan.build_geometry`): blocks the calling thread for the strided layers' output counts, so it is meant for a
+        helper thread that works a frame ahead (dualfusion/prefetch.py).  -> PreparedGeometry for `forward(..., prepared=)`,
+        or None when the native plan is not available (training mode, DF3D_EXECUTOR=0)."""
+        plan = self._plan() if coors.is_cuda and not torch.is_grad_enabled() else None
+        if plan is None or coors.shape[0] == 0:
+            return None
+        sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
+        return plan.build_geometry(coors.int(), in_channels, batch_size, [int(v) for v in sparse_shape],
+                             ready=getattr(coors, "_df3d_ready", None))
+
+    def _stem(self, voxel_features, coors, batch_size, input_shape, prepared=None):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
         coors = coors.int()
         plan = self._plan() if voxel_features.is_cuda and not torch.is_grad_enabled() else None
+        if prepared is not None and plan is not None and prepared.plan is plan:
+            out = plan.run_convs(prepared, voxel_features)
+            return out["conv1"], out["conv2"], out["conv3"], out["conv4"]
         if plan is not None and voxel_features.shape[0] > 0:
             out = plan.run(voxel_features, coors, batch_size, [int(v) for v in sparse_shape])
             return out["conv1"], out["conv2"], out["conv3"], out["conv4"]
@@ -183,8 +202,8 @@ class SpMiddleResNetFHD(nn.Module):
             ret = ret.view(N, C * D, H, W)
         return ret, {'conv1': x_conv1, 'conv2': x_conv2, 'conv3': x_conv3, 'conv4': x_conv4}
 
-    def forward(self, voxel_features, coors, batch_size, input_shape):
-        return self._tail(*self._stem(voxel_features, coors, batch_size, input_shape))
+    def forward(self, voxel_features, coors, batch_size, input_shape, prepared=None):
+        return self._tail(*self._stem(voxel_features, coors, batch_size, input_shape, prepared=prepared))
 
 
 @BACKBONES.register_module
@@ -192,8 +211,8 @@ class SpMiddleResNetFHDFusion(SpMiddleResNetFHD):
     def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHDFusion", **kwargs):
         super(SpMiddleResNetFHDFusion, self).__init__(num_input_features, norm_cfg, name, **kwargs)
 
-    def forward(self, voxel_features, batch_dict, coors, batch_size, input_shape, example, fuse_func=None):
-        x_conv1, x_conv2, x_conv3, x_conv4 = self._stem(voxel_features, coors, batch_size, input_shape)
+    def forward(self, voxel_features, batch_dict, coors, batch_size, input_shape, example, fuse_func=None, prepared=None):
+        x_conv1, x_conv2, x_conv3, x_conv4 = self._stem(voxel_features, coors, batch_size, input_shape, prepared=prepared)
         if fuse_func is not None and fuse_func.fuse_mode == 'pfat':
             x_conv4 = fuse_func(batch_dict, example, encoded_voxel_list=[x_conv2, x_conv3, x_conv4],
                                 layer_name='layer1_ori', fuse_mode='pfat', d_factor_list=[2, 4, 8])

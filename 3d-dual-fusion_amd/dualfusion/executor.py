@@ -8,6 +8,7 @@ return None and the caller keeps the per-module path; both paths launch the same
 bit-identical."""
 import ctypes
 import os
+import threading
 
 import torch
 from torch import nn
@@ -79,6 +80,9 @@ class BackbonePlan(object):
         self._arena_bytes = 256 << 20
         self._ring = []            # decoupled runs: up to three persistent [arena, event recorded at the start of the NEXT run]
         self._ring_last = 0
+        self._geo_bytes = 128 << 20
+        self._frames = _FrameRing()      # build_geometry() / run_convs(): arenas of the frames in flight
+        self._lock = threading.Lock()
 
     # ---------------------------------------------------------------- module tree -> layer specs
     def _rulebook_id(self, conv):
@@ -251,24 +255,32 @@ class BackbonePlan(object):
             break
         if slot is not None:
             self._ring_last = slot
-        base = arena.data_ptr()
+        return self._export(views, (arena,), coors, batch_size)
+
+    def _export(self, views, arenas, coors, batch_size, features=True):
+        """views (filled by the native call) -> {stage name: SparseConvTensor} whose tensors are views into the arenas.
+        features=False: the geometry only (index tensors, directories); the feature tensors are attached by `run_convs`."""
+        spans = [(a.data_ptr(), a.data_ptr() + a.numel(), a) for a in arenas]
 
         def view(ptr, nbytes, dtype, shape):
-            off = ptr - base
-            return arena[off:off + nbytes].view(dtype).view(shape)
+            for lo, hi, a in spans:
+                if lo <= ptr < hi:
+                    off = ptr - lo
+                    return a[off:off + nbytes].view(dtype).view(shape)
+            raise _lib.Df3dError("executor: a view points outside the arenas")
 
         out, idict, dirs = {}, {}, DirectoryCache()
         for name, li in self.exports.items():
             v = views[li]
-            f = view(v.features, v.n * v.channels * 4, torch.float32, (v.n, v.channels))
             # SubM stages of the first index set keep the caller's index tensor
             ind = coors if v.indices == coors.data_ptr() else view(v.indices, v.n * 16, torch.int32, (v.n, 4))
+            f = view(v.features, v.n * v.channels * 4, torch.float32, (v.n, v.channels)) if features else None
             t = SparseConvTensor(f, ind, [v.shape[0], v.shape[1], v.shape[2]], batch_size)
             t.indice_dict, t._directories = idict, dirs
             t._indices_synced = True      # the host has waited for these coordinates (count round trip)
-            if v.split and (v.reserved & 2):
+            if features and v.split and (v.reserved & 2):
                 t._bf16 = (f, view(v.split, v.n * v.channels * 2, torch.bfloat16, (v.n, v.channels)))
-            elif v.split:
+            elif features and v.split:
                 t._split = (f, view(v.split, v.n * v.channels * 4, torch.uint8, (v.n, v.channels * 4)))
             if v.grid and v.rows_sorted:
                 # the occupancy directory the executor built is handed to the module path (e.g. a conv that runs
@@ -286,6 +298,144 @@ class BackbonePlan(object):
                           out_rows_sorted=True)
             x._prebuilt[id(self.specs[li].conv)] = rb
         return out
+
+    # ---------------------------------------------------------------- the run as two calls (geometry ahead of the convolutions)
+    def build_geometry(self, coors, in_channels, batch_size, spatial_shape, ready=None):
+        """Phase 1 (`df3d_backbone_geometry`): every rulebook / index set of the chain from the COORDINATES alone, on the calling
+        thread's geometry stream, behind `ready` (event: coordinates complete).  Meant for a helper thread that works a frame
+        ahead (dualfusion/prefetch.py): the call blocks for the strided layers' output counts.  -> PreparedGeometry whose
+        `.stages` are SparseConvTensors WITHOUT features (indices / directories only); hand it to `run_convs`."""
+        lib = _lib.load()
+        with self._lock:
+            sig = self._signature()
+            if self._table is None or sig != self._sig:
+                self._build_table()
+                self._sig = sig
+            table, keep = self._table, self._keep
+            slot = self._frames.acquire()
+        coors = coors.contiguous()
+        n, nl = coors.shape[0], len(self.specs)
+        views = (_View * nl)()
+        used = ctypes.c_size_t(0)
+        shp = (ctypes.c_int * 3)(*[int(v) for v in spatial_shape])
+        handle = ctypes.c_void_p(0)
+        while True:
+            arena = slot.arena("geo", self._geo_bytes, coors.device)
+            rc = lib.df3d_backbone_geometry(table, nl, _ops._ptr(coors), n, int(in_channels), int(batch_size), shp,
+                                            _ops._ptr(arena), arena.numel(),
+                                            ctypes.c_void_p(ready.cuda_event) if ready is not None else None, views,
+                                            ctypes.byref(used), ctypes.byref(handle))
+            if rc == _lib.DF3D_ENOMEM and self._geo_bytes < (64 << 30):
+                self._geo_bytes *= 2
+                torch.cuda.synchronize(coors.device)           # the failed attempt's kernels still write the small arena
+                continue
+            _lib.check(rc, "df3d_backbone_geometry")
+            break
+        geo = PreparedGeometry(self, handle, views, slot, coors, int(batch_size), (table, keep), sig)
+        geo.spatial_shape = [int(v) for v in spatial_shape]
+        geo.stages = self._export(views, (arena,), coors, batch_size, features=False)
+        return geo
+
+    def run_convs(self, geo, features):
+        """Phase 2 (`df3d_backbone_convs`): the fused convolutions of a PreparedGeometry on the current stream.  Same result as
+        `run` (the same kernels on the same tables)."""
+        lib = _lib.load()
+        if geo.plan is not self or geo.handle is None:
+            raise _lib.Df3dError("executor.convs: the geometry belongs to another plan or was already consumed")
+        feats = features.contiguous()
+        if feats.dtype != torch.float32:
+            feats = feats.float()
+        if self._signature() != geo.sig:
+            # the parameters changed between the two phases (an optimizer step, load_state_dict): the table the geometry call
+            # saw is stale -- run the frame through the one-call path instead
+            geo.release()
+            return self.run(feats, geo.coors, geo.batch_size, geo.spatial_shape)
+        mark = torch.cuda.current_stream(feats.device).record_event()
+        self._frames.consumed(geo.slot, mark)
+        used = ctypes.c_size_t(0)
+        while True:
+            arena = geo.slot.arena("feat", self._arena_bytes, feats.device)
+            rc = lib.df3d_backbone_convs(geo.handle, _ops._ptr(feats), _ops._ptr(arena), arena.numel(), geo.views,
+                                         ctypes.byref(used), _ops._stream())
+            if rc == _lib.DF3D_ENOMEM and self._arena_bytes < (64 << 30):
+                self._arena_bytes *= 2
+                torch.cuda.synchronize(feats.device)
+                continue
+            _lib.check(rc, "df3d_backbone_convs")
+            break
+        out = self._export(geo.views, (arena, geo.slot.arenas["geo"]), geo.coors, geo.batch_size)
+        geo.release()
+        return out
+
+
+class _FrameSlot(object):
+    """Persistent arenas of one frame in flight + the event after which they may be rewritten."""
+
+    def __init__(self):
+        self.arenas = {}
+        self.guard = None          # event recorded (on the consumer's stream) when the NEXT frame's convolutions start
+        self.pending = False       # handed out, not yet guarded
+
+    def arena(self, kind, nbytes, device):
+        a = self.arenas.get(kind)
+        if a is None or a.numel() < nbytes:
+            if a is not None:
+                torch.cuda.synchronize(device)     # a larger block: rare, and the old one must be idle
+            with torch.cuda.stream(torch.cuda.default_stream(device)):
+                a = self.arenas[kind] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        return a
+
+
+class _FrameRing(object):
+    """Frame slots in rotation.  Slot of frame k is rewritten by frame k + N: by then every reader of frame k has been
+    QUEUED (the guard event is recorded on the consumer's stream when frame k + 1's convolutions start, i.e. after the host
+    has queued everything of frame k) and the writer waits for that event on the host."""
+
+    def __init__(self, n=4):
+        self.slots = [_FrameSlot() for _ in range(n)]
+        self.next = 0
+        self.last_consumed = None
+
+    def acquire(self):
+        slot = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        if slot.guard is not None:
+            slot.guard.synchronize()
+        elif slot.pending:
+            torch.cuda.synchronize()       # handed out and never guarded (a dropped frame): wait for everything
+        slot.guard, slot.pending = None, True
+        return slot
+
+    def consumed(self, slot, mark):
+        """`mark` was just recorded on the consumer's stream, BEFORE anything of `slot`'s frame is queued there: it guards the
+        slot of the frame consumed before."""
+        prev, self.last_consumed = self.last_consumed, slot
+        if prev is not None and prev is not slot:
+            prev.guard, prev.pending = mark, False
+
+
+class PreparedGeometry(object):
+    def __init__(self, plan, handle, views, slot, coors, batch_size, keep, sig):
+        self.plan, self.handle, self.views, self.slot, self.coors = plan, handle, views, slot, coors
+        self.batch_size, self.keep, self.sig = batch_size, keep, sig
+        self.stages = None
+        self.spatial_shape = None
+
+    def wait(self):
+        """The CURRENT stream waits (on the device) for the geometry: before anything other than `plan.run_convs` reads the index
+        tensors of `.stages`."""
+        _lib.check(_lib.load().df3d_backbone_geometry_wait(self.handle, _ops._stream()), "df3d_backbone_geometry_wait")
+
+    def release(self):
+        if self.handle is not None:
+            _lib.load().df3d_backbone_release(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:             # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def compile_stages(stages, geometry_stages=()):

@@ -210,6 +210,7 @@ class VoxelWithPointProjection(nn.Module):
         # without having to wait for the caller's stream (needed once the backbone's geometry no longer waits for it either)
         self.resident_inputs = False
         self._prefetched = None
+        self._prepared = None
         self._ptr_tables = {}
         self._wcat = None
         self._wpack = None
@@ -374,9 +375,64 @@ class VoxelWithPointProjection(nn.Module):
         """The image-side projection issued early on the CURRENT stream (no co-running, just earlier in the frame)."""
         feats = batch_dict['img_feat'][layer_name + '_feat2d']
         dev = next(iter(feats.values())).device
-        inp = self._gather_inputs(batch_dict, layer_name, dev)
+        prep = self._prepared
+        if prep is not None and prep[0] == id(batch_dict) and prep[1] == layer_name:
+            inp = prep[2]['inp']                 # gathered by prepare_geometry (another host thread, a frame ahead)
+        else:
+            inp = self._gather_inputs(batch_dict, layer_name, dev)
         both = self._image_projection(inp, img_conv_func)
         self._prefetched = (id(batch_dict), layer_name, inp, both, None)
+
+    def prepare_geometry(self, batch_dict, layer_name, levels, d_factor_list):
+        """Everything of forward() that depends on the voxel COORDINATES and the calibration alone, on the current stream: the
+        kernel inputs (`_gather_inputs`), the camera projection of every scale the gate or the queries read, the per-camera
+        query slots and the adapter's one host round trip (longest query list).  `levels`: the encoded_voxel_list as tensors
+        whose `.indices` are complete on the current stream (features are not read).  A caller that builds a frame's geometry
+        ahead (dualfusion/prefetch.py) runs this there and hands the result over with `use_prepared`."""
+        last = len(levels) - 1
+        dev = levels[last].indices.device
+        inp = self._gather_inputs(batch_dict, layer_name, dev)
+        need = set([last])
+        if self.ifat_cfg is not None:
+            need |= set(self.ifat.voxel_idx)
+        proj = {s_: self._project(levels[s_], d_factor_list[s_], inp) for s_ in sorted(need)}
+        early = self._query_slots(levels[last].indices.contiguous(), proj[last][1], inp['B'])
+        return dict(inp=inp, proj=proj, early=early)
+
+    def head_request(self, batch_dict, layer_name, layers, d_factor_list, dev):
+        """What `prepare_geometry` computes, as a job description for the native frame-head worker (dualfusion/prefetch.py):
+        the kernel inputs gathered now (on the calling thread), the stages to project (`layers`: executor layer index of every
+        entry of the encoded_voxel_list) with their voxel sizes, the stage whose visible voxels become queries."""
+        inp = self._gather_inputs(batch_dict, layer_name, dev)
+        last = len(layers) - 1
+        need = set([last])
+        if self.ifat_cfg is not None:
+            need |= set(self.ifat.voxel_idx)
+        levels = [(s_, layers[s_], [float(np.float32(np.float32(v) * np.float32(d_factor_list[s_]))) for v in self.voxel_size])
+                  for s_ in sorted(need)]
+        # the calibration stacks may have just been queued on the side stream: the worker's stream waits for them
+        if self.resident_inputs and self._side is not None:
+            ready = self._side.record_event()
+        else:                                   # stacked on the caller's stream: the worker then waits for that stream
+            ready = torch.cuda.current_stream(dev).record_event()
+        return dict(inp=inp, levels=levels, slots_level=last, pc_min=[float(np.float32(v)) for v in self.pc_range[:3]],
+                    image_scale=self.image_scale, ready=ready)
+
+    def use_prepared(self, batch_dict, layer_name, prepared):
+        """Hand over a `prepare_geometry` result for the forward() of this batch_dict; its tensors must be complete on (and
+        known to the allocator for) the stream forward() runs on."""
+        self._prepared = (id(batch_dict), layer_name, prepared)
+
+    @staticmethod
+    def prepared_tensors(prepared):
+        out = []
+        for v in prepared['proj'].values():
+            out.extend(v)
+        out.extend([prepared['early'][0], prepared['early'][2]])
+        inp = prepared['inp']
+        out.extend(t for t in (inp.get('l2c'), inp.get('intr'), inp.get('raw_hw'), inp.get('feat_scale'), inp.get('thres'),
+                               inp.get('img_ptrs'), inp.get('aug_inv')) if torch.is_tensor(t))
+        return out
 
     def _project(self, x, d_factor, inp):
         lib = _lib.load()
@@ -536,6 +592,8 @@ class VoxelWithPointProjection(nn.Module):
         x_last = encoded_voxel_list[-1]
         dev = x_last.features.device
         pre, self._prefetched = self._prefetched, None
+        prep, self._prepared = self._prepared, None
+        prep = prep[2] if (prep is not None and prep[0] == id(batch_dict) and prep[1] == layer_name) else None
         if pre is not None and pre[0] == id(batch_dict) and pre[1] == layer_name:
             inp, both, ev = pre[2], pre[3], pre[4]
             if ev is not None:                       # produced on the side stream
@@ -544,7 +602,7 @@ class VoxelWithPointProjection(nn.Module):
                 for t_ in (both if isinstance(both, tuple) else (both,)):
                     t_.record_stream(main)
         else:
-            inp = self._gather_inputs(batch_dict, layer_name, dev)
+            inp = prep['inp'] if prep is not None else self._gather_inputs(batch_dict, layer_name, dev)
             both = self._image_projection(inp, img_conv_func)
         B, ncam = inp['B'], inp['ncam']
         NI = B * ncam
@@ -556,7 +614,9 @@ class VoxelWithPointProjection(nn.Module):
             need |= set(self.ifat.voxel_idx)
         proj = {}
         early = None
-        if getattr(x_last, "_indices_synced", False) and os.environ.get("DF3D_EARLY_SLOTS", "1") == "1":
+        if prep is not None:
+            proj, early = dict(prep['proj']), prep['early']
+        elif getattr(x_last, "_indices_synced", False) and os.environ.get("DF3D_EARLY_SLOTS", "1") == "1":
             # The query lists depend on the voxel COORDINATES only, and those are complete (the host has read their
             # count).  Project + count on a side stream now: the one host round trip of this adapter (max list
             # length) then does not wait for the convolutions still queued on the main stream, and the host can

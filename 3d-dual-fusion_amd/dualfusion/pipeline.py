@@ -36,6 +36,7 @@ class CenterPointHotPath(nn.Module):
             self.backbone.dense_layout = "rows"
         gs = self.voxel_layer.grid_size.tolist()
         self.grid_size_xyz = [int(gs[0]), int(gs[1]), int(gs[2])]
+        object.__setattr__(self, "_ahead", None)           # dualfusion.prefetch.FrameHead, created by prefetch()
 
     @torch.no_grad()
     def voxelize(self, points_list, while_waiting=None):
@@ -52,8 +53,72 @@ class CenterPointHotPath(nn.Module):
                                          vl.max_num_points, vl._cap(), break_at_cap=False, while_waiting=while_waiting,
                                          resident_inputs=resident)
 
+    # ------------------------------------------------------------------ geometry of the next frame on a helper thread
+    @staticmethod
+    def _frame_key(points_list, batch_dict):
+        return (tuple(int(p.data_ptr()) for p in points_list), id(batch_dict) if batch_dict is not None else 0)
+
+    def prefetch(self, points_list, batch_dict=None):
+        """Start the head of a LATER forward(points_list, batch_dict=batch_dict) now, on the detector's native worker thread
+        (dualfusion/prefetch.py, `df3d_frame_head_*`): voxelisation, the backbone's rulebooks, the fusion adapter's projection /
+        query slots -- and their host round trips.  Returns at once (False: not applicable, forward() does it in line).
+        The inputs must be complete in device memory (`resident_inputs`, what a data loader hands over) and must be passed to
+        forward() as the same objects.  Inference on the native executor plan only."""
+        if not points_list or not points_list[0].is_cuda or not self.resident_inputs or self.training:
+            return False
+        if any(p.dtype != torch.float32 or not p.is_contiguous() for p in points_list):
+            return False
+        with torch.no_grad():
+            plan = self.backbone._plan()
+        if plan is None:
+            return False
+        dev = points_list[0].device
+        if self._ahead is None:
+            from .prefetch import FrameHead
+            object.__setattr__(self, "_ahead", FrameHead(dev))
+        if len(self._ahead._pending) >= 2:                  # stale submissions (a caller that changed its frame order)
+            self._ahead.drop_all()
+        vl = self.voxel_layer
+        vox = dict(voxel_size=vl.voxel_size, coors_range=vl.point_cloud_range, max_points=vl.max_num_points,
+                   max_voxels=vl._cap(), break_at_cap=False)
+        shape = [self.grid_size_xyz[2] + 1, self.grid_size_xyz[1], self.grid_size_xyz[0]]     # backbones._stem: (z + 1, y, x)
+        cam = None
+        fusion = self.fusion
+        if fusion is not None and batch_dict is not None and hasattr(fusion, "head_request"):
+            layers = [plan.exports[name] for name in self.backbone.FUSE_STAGES]
+            cam = fusion.head_request(batch_dict, 'layer1_ori', layers, self.backbone.FUSE_D_FACTORS, dev)
+        self._ahead.submit(self._frame_key(points_list, batch_dict), plan, points_list, vox, shape, cam)
+        return True
+
+    def close(self):
+        if self._ahead is not None:
+            self._ahead.close()
+            object.__setattr__(self, "_ahead", None)
+
     @torch.no_grad()
     def forward(self, points_list, batch_dict=None, example=None):
+        prep = self._ahead.take(self._frame_key(points_list, batch_dict)) if self._ahead is not None else None
+        if prep is not None:
+            B = len(points_list)
+            if prep.geometry is None:                       # an empty sweep: nothing was prepared beyond the voxeliser
+                return self._forward_inline(points_list, batch_dict, example)
+            prep.hand_over()
+            if self.fusion is not None and prep.fusion is not None:
+                self.fusion.use_prepared(batch_dict, 'layer1_ori', prep.fusion)
+                if os.environ.get("DF3D_EARLY_IMGPROJ", "1") == "1":
+                    self.fusion.prefetch_inline(batch_dict, 'layer1_ori')
+            if self.fusion is None:
+                bev, multi = self.backbone(prep.feats, prep.coors, B, self.grid_size_xyz, prepared=prep.geometry)
+            else:
+                bev, multi = self.backbone(prep.feats, batch_dict, prep.coors, B, self.grid_size_xyz, example,
+                                           fuse_func=self.fusion, prepared=prep.geometry)
+            if self.neck is not None:
+                rows, (nb, _, h, w) = bev
+                bev = self.neck.forward_rows(rows, nb, h, w)
+            return bev, multi
+        return self._forward_inline(points_list, batch_dict, example)
+
+    def _forward_inline(self, points_list, batch_dict=None, example=None):
         if (self.fusion is not None and batch_dict is not None and hasattr(self.fusion, "prefetch")
                 and os.environ.get("DF3D_PREFETCH", "0") == "1"):
             # opt-in experiment: start the image-side projection (depends on the camera maps only) on a side stream.
@@ -165,6 +230,13 @@ class CenterPointDetector(nn.Module):
         for key in ("hm_loss", "loc_loss_elem"):            # the reference's host copies, once the backward is queued
             rets[key] = [v.cpu() for v in rets[key]]
         return rets
+
+    def prefetch(self, points_list, batch_dict=None):
+        """`CenterPointHotPath.prefetch`: the head of a later forward() of the same inputs, on the helper thread."""
+        return self.hot_path.prefetch(points_list, batch_dict)
+
+    def close(self):
+        self.hot_path.close()
 
     @torch.no_grad()
     def forward(self, points_list, batch_dict=None, example=None, return_loss=True):

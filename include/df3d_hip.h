@@ -811,6 +811,99 @@ int df3d_backbone_run(const df3d_layer *layers, int nlayers, const float *featur
                       int in_channels, int batch, const int *shape_host, void *arena, size_t arena_bytes,
                       df3d_layer_view *views, size_t *arena_used, void *stream);
 
+/* The same run as TWO calls, for callers that build a frame's geometry ahead of its convolutions -- the reference's
+ * data-loader workers voxelise the next sample while the GPU step runs (CP/det3d/datasets/pipelines/preprocess.py `Voxelization`
+ * inside the DataLoader's worker processes); here the rulebooks (which depend on the coordinates alone) go ahead as well:
+ *   df3d_backbone_geometry  every neighbour table / index set / directory of the table's layers on the calling HOST THREAD's
+ *                           geometry stream, which first waits for `inputs_ready` (hipEvent_t: the coordinates are complete;
+ *                           NULL = they are complete now).  Blocks the calling thread for the output-count round trips of
+ *                           the strided layers only; allocates from `arena` (DF3D_ENOMEM + *arena_used as above).  Fills the
+ *                           geometry fields of `views` (indices, n, shape, grid, nbr, kvol; features = split = NULL) and
+ *                           returns an opaque `handle`.
+ *   df3d_backbone_convs     the fused convolutions of the same table on `stream` (any host thread), after a stream-side wait
+ *                           for the geometry; features / split rows come from a SECOND arena (may be retried with a larger one
+ *                           after DF3D_ENOMEM); completes `views`.  Launches exactly the kernels df3d_backbone_run launches:
+ *                           results are bit-identical.
+ *   df3d_backbone_release   frees the handle (not the arenas: the caller owns them and keeps the geometry arena alive while
+ *                           anything reads the views).
+ * `layers` and `indices` must stay valid until the handle is released. */
+int df3d_backbone_geometry(const df3d_layer *layers, int nlayers, const int32_t *indices, int n, int in_channels, int batch,
+                           const int *shape_host, void *arena, size_t arena_bytes, void *inputs_ready,
+                           df3d_layer_view *views, size_t *arena_used, void **handle);
+int df3d_backbone_convs(void *handle, const float *features, void *arena, size_t arena_bytes, df3d_layer_view *views,
+                        size_t *arena_used, void *stream);
+/* ------------------------------------------------------------------------------------
+ * Frame head on a native worker thread (round 4): everything of a frame that depends on its RAW INPUTS alone, with all its
+ * count round trips, built while the caller still queues the previous frame -- what the reference's DataLoader worker
+ * processes do for the voxelisation (CP/det3d/datasets/pipelines/preprocess.py:`Voxelization`, torch DataLoader prefetch),
+ * extended to the rulebooks (functions of the voxel coordinates) and the fusion adapter's projection / query slots
+ * (coordinates + calibration; CP/det3d/models/fusion/voxel_with_point_projection.py:294-335).
+ *   df3d_head_worker_create / _destroy   one worker thread (with its own HIP stream) per detector
+ *   df3d_frame_head_submit               copies `desc`, queues the job, returns at once.  The job, on the worker's stream:
+ *       df3d_hard_voxelize_batched of every cloud (mean VFE rows [n, C], coors [n, 4]) -> ONE round trip for the voxel counts
+ *       -> the geometry phase of df3d_backbone_geometry over `layers` -> df3d_project_voxels of the listed stages and
+ *       df3d_query_slots of stage `slots_proj` -> the round trip for the longest camera list.  Every buffer comes from `arena`
+ *       (bump allocation; the caller keeps it alive while anything reads the results).
+ *   df3d_frame_head_wait                 blocks until the job is done (normally it is), fills `views` (geometry fields), `out`
+ *       and `handle` -- the df3d_backbone_geometry handle: df3d_backbone_geometry_wait(handle, stream) before anything reads the
+ *       results, then df3d_backbone_convs / df3d_backbone_release as usual.  DF3D_ENOMEM with *arena_used: resubmit with a
+ *       larger arena.  Frees the ticket in every case.
+ * All device pointers of `desc` (point clouds, calibration tables, the layer table's weights) must stay valid and unchanged
+ * until df3d_frame_head_wait returns; the inputs must be COMPLETE in device memory at submit (the worker's stream does not
+ * wait for the caller's). */
+#define DF3D_HEAD_MAX_PROJ 4
+typedef struct df3d_head_project {
+  int layer;              /* the stage: index into `layers`, its OUTPUT index set is projected */
+  float scale_xyz[3];     /* voxel size of that stage (fp32 voxel size * down-sampling factor) */
+} df3d_head_project;
+
+typedef struct df3d_frame_head_desc {
+  int batch, point_channels;
+  const float *const *points;       /* host array of `batch` device pointers [P_b, point_channels] f32 */
+  const int *num_points;            /* host array P_b */
+  float voxel_size[3], coors_range[6];
+  int max_points, max_voxels, break_at_cap;
+  const df3d_layer *layers;         /* may be NULL with nlayers = 0: voxelisation only */
+  int nlayers;
+  int shape[3];
+  int ncam;                         /* 0: no camera side */
+  const float *lidar2cam, *intrinsic;
+  const int32_t *raw_hw;
+  const float *depth_thres;
+  float image_scale;
+  const float *feat_scale;
+  const float *aug_inv;             /* may be NULL */
+  float pc_min[3];
+  int nproj;
+  df3d_head_project proj[DF3D_HEAD_MAX_PROJ];
+  int slots_proj;                   /* index into proj[] of the stage whose visible voxels become queries; -1: none */
+  void *inputs_ready;               /* hipEvent_t or NULL: the worker's stream waits for it first (e.g. calibration tables the
+                                     * caller has just queued on a side stream) */
+} df3d_frame_head_desc;
+
+typedef struct df3d_frame_head_out {
+  float *features;                  /* [n, point_channels] mean VFE rows */
+  int32_t *coors;                   /* [n, 4] (b, z, y, x) */
+  int n;
+  int max_ne;                       /* longest (sample, camera) query list */
+  int32_t *grid_xy[DF3D_HEAD_MAX_PROJ];   /* per projection: [ncam, proj_n, 2] */
+  uint8_t *mask[DF3D_HEAD_MAX_PROJ];      /* [ncam, proj_n] */
+  float *point_inv[DF3D_HEAD_MAX_PROJ];   /* [proj_n, 3] */
+  int proj_n[DF3D_HEAD_MAX_PROJ];
+  int32_t *pos;                     /* [ncam, proj_n[slots_proj]] */
+  int32_t *counts;                  /* [batch * ncam] */
+} df3d_frame_head_out;
+
+void *df3d_head_worker_create(int device);
+int df3d_head_worker_destroy(void *worker);
+int df3d_frame_head_submit(void *worker, const df3d_frame_head_desc *desc, void *arena, size_t arena_bytes, void **ticket);
+int df3d_frame_head_wait(void *ticket, df3d_layer_view *views, df3d_frame_head_out *out, size_t *arena_used, void **handle);
+
+/* `stream` waits (on the device) until the geometry of `handle` is complete: for work other than the table's own convolutions
+ * that reads the index sets / tables of `views` (e.g. the camera projection of the fusion adapter). */
+int df3d_backbone_geometry_wait(void *handle, void *stream);
+int df3d_backbone_release(void *handle);
+
 /* ------------------------------------------------------------------------------------
  * TransFusion head: target-assignment costs and losses (round 3).
  *

@@ -522,3 +522,73 @@ def test_pipelined_frames_equal_isolated_frames():
                 os.environ.pop("DF3D_EXEC_DECOUPLE", None)
             for k, y in enumerate(got):
                 assert torch.equal(y, want[k % 3]), (decouple, k)
+
+
+def test_prefetched_geometry_equals_isolated_frames():
+    """Round 4: the head of frame k + 1 (voxelisation, every rulebook of the backbone, the fusion adapter's projection and
+    query slots -- with all count round trips) built on the detector's helper thread while frame k is queued
+    (`CenterPointHotPath.prefetch`, dualfusion/prefetch.py, `df3d_backbone_geometry` + `df3d_backbone_convs`), then TWO
+    detector replicas alternating over two streams from one host thread (bench.py's `in_flight` pass) -- against the same
+    frames run one at a time with a device synchronisation after each.  Bit-identical, frame by frame, over several rounds
+    (frame slots of the executor's arenas are rewritten while later frames run)."""
+    from dualfusion import synth
+    from dualfusion.fusion import build_centerpoint_fusion, synthetic_camera_inputs
+    from dualfusion.pipeline import CenterPointHotPath
+    dev = torch.device("cuda:0")
+    frames = [([torch.from_numpy(synth.nusc_sweep(seed=70 + j)).to(dev)], synthetic_camera_inputs(1, dev, seed=20 + j)) for j in range(3)]
+
+    def model():
+        torch.manual_seed(0)
+        return CenterPointHotPath(fusion=build_centerpoint_fusion()).eval().to(dev)
+    m = model()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = []
+        for pts, (bd, ex) in frames:
+            y, multi = m(pts, batch_dict=dict(bd), example=dict(ex))
+            want.append((y.clone(), [multi[k].indices.clone() for k in ("conv1", "conv2", "conv3", "conv4")],
+                         multi["conv4"].features.clone()))
+            torch.cuda.synchronize()
+        m.resident_inputs = m.fusion.resident_inputs = True
+        # (1) one replica, the next frame prefetched while the current one is queued
+        nf, rounds = len(frames), 8
+        staged = dict(frames[0][1][0])
+        assert m.prefetch(frames[0][0], staged)
+        got = []
+        for k in range(rounds * nf):
+            pts, (bd, ex) = frames[k % nf]
+            cur, staged = staged, dict(frames[(k + 1) % nf][1][0])
+            m.prefetch(frames[(k + 1) % nf][0], staged)
+            y, multi = m(pts, batch_dict=cur, example=dict(ex))
+            got.append((y.clone(), [multi[n].indices.clone() for n in ("conv1", "conv2", "conv3", "conv4")],
+                        multi["conv4"].features.clone()))
+        torch.cuda.synchronize()
+        for k, (y, idx, f4) in enumerate(got):
+            w = want[k % nf]
+            assert all(torch.equal(a, b) for a, b in zip(idx, w[1])), k
+            assert torch.equal(f4, w[2]) and torch.equal(y, w[0]), k
+        # a frame that was NOT prefetched takes the in-line path; a prefetched one that is never consumed is dropped
+        y = m(frames[1][0], batch_dict=dict(frames[1][1][0]), example={})[0]
+        assert torch.equal(y, want[1][0])
+        # (2) two replicas / two streams / one host thread, each replica prefetching its own next frame (stride 2)
+        ms = [m, model()]
+        ms[1].resident_inputs = ms[1].fusion.resident_inputs = True
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        staged = [None, None]
+        for r in range(2):
+            staged[r] = dict(frames[r % nf][1][0])
+            ms[r].prefetch(frames[r % nf][0], staged[r])
+        got = []
+        for k in range(rounds * nf):
+            r = k % 2
+            with torch.cuda.stream(streams[r]):
+                cur, staged[r] = staged[r], dict(frames[(k + 2) % nf][1][0])
+                ms[r].prefetch(frames[(k + 2) % nf][0], staged[r])
+                y, multi = ms[r](frames[k % nf][0], batch_dict=cur, example={})
+                got.append((y.clone(), multi["conv4"].indices.clone()))
+                y.record_stream(streams[r])
+        torch.cuda.synchronize()
+        for k, (y, i4) in enumerate(got):
+            assert torch.equal(i4, want[k % nf][1][3]) and torch.equal(y, want[k % nf][0]), k
+    for mm in ms:
+        mm.close()

@@ -18,6 +18,7 @@ import bench  # noqa: E402
 
 class A(object):
     workload, frames, batch, inflight = sys.argv[1] if len(sys.argv) > 1 else "cp_fusion", 8, 0, 1
+    prefetch = os.environ.get("DF3D_PROBE_PREFETCH", "1") == "1"
 
 
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -73,6 +74,21 @@ for obj, name, fn in saved:
     except AttributeError:
         setattr(obj, name, fn)
 
+def ahead_stats(w, reset=False):
+    a = getattr(w.model.hot_path, "_ahead", None)
+    if a is None:
+        return "no worker thread"
+    st = a.stats
+    msg = "native worker: submit %.3f ms, take %.3f ms of which waiting for the worker %.3f ms (per frame, host)" % (
+        st["submit_s"] / max(st["submits"], 1) * 1e3, st["take_s"] / max(st["takes"], 1) * 1e3,
+        st["take_wait_s"] / max(st["takes"], 1) * 1e3)
+    if reset:
+        for k in st:
+            st[k] = 0 if isinstance(st[k], int) else 0.0
+    return msg
+
+
+print("      " + ahead_stats(wl, reset=True))
 # ---- (b) back to back, one stream
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -83,9 +99,14 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print("(b) one stream: %.3f ms per step (host returned after %.3f ms per step) = %.1f sweeps/s" % (
     el / steps * 1e3, t_enq / steps * 1e3, steps / el))
+print("      " + ahead_stats(wl, reset=True))
+if os.environ.get("DF3D_PROBE_TRACE"):
+    sys.exit(0)
 
 # ---- (c) two streams / replicas, one thread
 wls = [wl, bench.make_workload(A(), 0, 1, dev)]
+for w in wls:
+    w.stride = 2
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 for k in range(16):
     with torch.cuda.stream(streams[k % 2]):
@@ -101,3 +122,6 @@ for rep in range(2):
     el = time.perf_counter() - t0
     print("(c) two streams, one thread: %.3f ms per step (host returned after %.3f) = %.1f sweeps/s" % (
         el / steps * 1e3, t_enq / steps * 1e3, steps / el))
+    print("      " + ahead_stats(wls[0], reset=True))
+for w in wls:
+    w.close()
