@@ -10,6 +10,7 @@
 // nothing is freed inside a run), and the only host round trips left are the output counts of the strided
 // layers.  The kernels are exactly the ones the per-layer API launches (the extern "C" entry points below call
 // the same functions), so results are bit-identical to the module path.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -572,6 +573,15 @@ int frame_head_run(HeadTicket &t) {
   void *gs_ = (void *)gs;
   const int B = d.batch, C = d.point_channels;
   memset(&t.out, 0, sizeof(t.out));
+  static const bool dbg = getenv("DF3D_HEAD_DEBUG") != nullptr;     // phase by phase, synchronised (localises a device fault)
+#define HEAD_PHASE(msg)                                                   \
+  do {                                                                    \
+    if (dbg) {                                                            \
+      hipError_t e__ = hipStreamSynchronize(gs);                          \
+      fprintf(stderr, "df3d frame head: %s -> %d\n", msg, (int)e__);     \
+      fflush(stderr);                                                     \
+    }                                                                     \
+  } while (0)
   if (d.inputs_ready) DF3D_HIP(hipStreamWaitEvent(gs, (hipEvent_t)d.inputs_ready, 0));
   // ---- 1. voxelisation + mean VFE of every cloud, ONE round trip for the voxel counts ----
   std::vector<float *> mean(B);
@@ -594,6 +604,7 @@ int frame_head_run(HeadTicket &t) {
                                         nullptr, coors[b], num, mean[b], counts_dev + b, ws, wsb, gs_);
     if (rc) return rc;
   }
+  HEAD_PHASE("voxelize queued");
   std::vector<int32_t> cnt(B, 0);
   DF3D_HIP(hipMemcpyAsync(cnt.data(), counts_dev, (size_t)B * 4, hipMemcpyDeviceToHost, gs));
   DF3D_HIP(hipStreamSynchronize(gs));
@@ -626,9 +637,16 @@ int frame_head_run(HeadTicket &t) {
     // ---- 2. the backbone's geometry ----
     S->gmem = &t.mem;
     int rc = state_init(*S, d.layers, d.nlayers, ind, (int)total, C, B, d.shape);
+    HEAD_PHASE("voxel counts read");
+    if (dbg) fprintf(stderr, "df3d frame head: n = %lld, arena used %zu of %zu\n", total, t.mem.used, t.arena_bytes);
     for (int li = 0; li < d.nlayers && !rc; ++li) {
       bool new_table = false;
       rc = geo_layer(*S, li, gs, &new_table);
+      if (dbg) {
+        char b[64];
+        snprintf(b, sizeof(b), "geometry layer %d rc %d", li, rc);
+        HEAD_PHASE(b);
+      }
     }
     if (rc) return rc;
     t.views.assign(d.nlayers, df3d_layer_view());
@@ -668,6 +686,7 @@ int frame_head_run(HeadTicket &t) {
       }
     }
   }
+  HEAD_PHASE("projection / slots");
   DF3D_HIP(hipEventRecord(S->done, gs));
   return DF3D_OK;
 }

@@ -379,8 +379,11 @@ class _FrameSlot(object):
     def arena(self, kind, nbytes, device):
         a = self.arenas.get(kind)
         if a is None or a.numel() < nbytes:
-            if a is not None:
-                torch.cuda.synchronize(device)     # a larger block: rare, and the old one must be idle
+            # (Re)allocation: rare (the first frames).  The device must be idle: the block the caching allocator hands out may be
+            # one it has just recycled from a stream whose kernels are still queued -- legal for work ordered behind that
+            # stream, but these arenas are written by streams that are not (the frame-head worker's, other frames' streams)
+            torch.cuda.synchronize(device)
+            self.arenas[kind] = None
             with torch.cuda.stream(torch.cuda.default_stream(device)):
                 a = self.arenas[kind] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         return a

@@ -209,7 +209,8 @@ class VoxelWithPointProjection(nn.Module):
         # the small per-frame tensors derived from them are then produced on the adapter's side stream, which later reads them
         # without having to wait for the caller's stream (needed once the backbone's geometry no longer waits for it either)
         self.resident_inputs = False
-        self._prefetched = None
+        self._prefetched = {}                 # (id(batch_dict), layer name) -> (inputs, image projection, event or None)
+        self._img_stream = None
         self._prepared = None
         self._ptr_tables = {}
         self._wcat = None
@@ -354,22 +355,39 @@ class VoxelWithPointProjection(nn.Module):
             torch.matmul(wcat, f.view(Ci, S_pix), out=both[i])
         return both
 
-    def prefetch(self, batch_dict, layer_name='layer1_ori', img_conv_func=None):
+    def prefetch(self, batch_dict, layer_name='layer1_ori', img_conv_func=None, inp=None, ahead=False):
         """Start the image-side projection (it depends on the camera maps only) on a side stream, so that it
         overlaps the LiDAR branch; forward() picks the result up.  Optional: forward() computes it itself
-        when prefetch was not called for this batch_dict."""
+        when prefetch was not called for this batch_dict.
+        ahead: the camera maps are COMPLETE in device memory (resident inputs) and this is a LATER frame's batch_dict: the
+        side stream does not wait for the caller's stream, so the projection runs beside whatever the GPU is doing now --
+        with a frame of lookahead that is the previous frame's low-channel sparse convolutions, which leave most of the chip
+        idle (round 4; inside ONE frame the same co-run loses)."""
         feats = batch_dict['img_feat'][layer_name + '_feat2d']
         dev = next(iter(feats.values())).device
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream(dev)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            inp = self._gather_inputs(batch_dict, layer_name, dev)
+        if ahead:
+            if self._img_stream is None:
+                self._img_stream = torch.cuda.Stream(device=dev)
+            side = self._img_stream
+        else:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            if inp is None:
+                inp = self._gather_inputs(batch_dict, layer_name, dev)
+            elif ahead and inp.get('_ready') is not None:
+                side.wait_event(inp['_ready'])            # calibration-independent, but the pointer table / maps of `inp`
             both = self._image_projection(inp, img_conv_func)
             ev = torch.cuda.Event()
-            ev.record(self._side)
-        self._prefetched = (id(batch_dict), layer_name, inp, both, ev)
+            ev.record(side)
+        self._remember_prefetched(batch_dict, layer_name, inp, both, ev)
+
+    def _remember_prefetched(self, batch_dict, layer_name, inp, both, ev):
+        if len(self._prefetched) >= 4:                     # entries nobody consumed (a caller that changed its frame order)
+            self._prefetched.pop(next(iter(self._prefetched)))
+        self._prefetched[(id(batch_dict), layer_name)] = (inp, both, ev)
 
     def prefetch_inline(self, batch_dict, layer_name='layer1_ori', img_conv_func=None):
         """The image-side projection issued early on the CURRENT stream (no co-running, just earlier in the frame)."""
@@ -380,8 +398,10 @@ class VoxelWithPointProjection(nn.Module):
             inp = prep[2]['inp']                 # gathered by prepare_geometry (another host thread, a frame ahead)
         else:
             inp = self._gather_inputs(batch_dict, layer_name, dev)
+        if (id(batch_dict), layer_name) in self._prefetched:
+            return                                            # already projected on the side stream (prefetch(ahead=True))
         both = self._image_projection(inp, img_conv_func)
-        self._prefetched = (id(batch_dict), layer_name, inp, both, None)
+        self._remember_prefetched(batch_dict, layer_name, inp, both, None)
 
     def prepare_geometry(self, batch_dict, layer_name, levels, d_factor_list):
         """Everything of forward() that depends on the voxel COORDINATES and the calibration alone, on the current stream: the
@@ -591,11 +611,11 @@ class VoxelWithPointProjection(nn.Module):
         lib = _lib.load()
         x_last = encoded_voxel_list[-1]
         dev = x_last.features.device
-        pre, self._prefetched = self._prefetched, None
+        pre = self._prefetched.pop((id(batch_dict), layer_name), None)
         prep, self._prepared = self._prepared, None
         prep = prep[2] if (prep is not None and prep[0] == id(batch_dict) and prep[1] == layer_name) else None
-        if pre is not None and pre[0] == id(batch_dict) and pre[1] == layer_name:
-            inp, both, ev = pre[2], pre[3], pre[4]
+        if pre is not None:
+            inp, both, ev = pre
             if ev is not None:                       # produced on the side stream
                 main = torch.cuda.current_stream(dev)
                 main.wait_event(ev)

@@ -77,10 +77,14 @@ class FrameHead(object):
         self.stats = {"submits": 0, "submit_s": 0.0, "takes": 0, "take_wait_s": 0.0, "take_s": 0.0}   # host seconds
 
     # ------------------------------------------------------------------ submit
-    def submit(self, key, plan, points_list, vox, shape, cam=None):
+    def submit(self, key, plan, points_list, vox, shape, cam=None, owner=None):
+        """owner: objects whose id() is part of `key` (the batch_dict): referenced until the head is taken, so that the id
+        cannot be reused by another object meanwhile."""
         t0 = time.perf_counter()
         try:
-            return self._submit_job(key, plan, points_list, vox, shape, cam)
+            t = self._submit_job(key, plan, points_list, vox, shape, cam)
+            t.owner = owner
+            return t
         finally:
             self.stats["submits"] += 1
             self.stats["submit_s"] += time.perf_counter() - t0
@@ -219,6 +223,9 @@ class FrameHead(object):
             self.drop_all()
             self.lib.df3d_head_worker_destroy(self.worker)
             self.worker = None
+            # the last job's kernels may still be writing the frame slots' arenas on the worker's stream (a stream the caching
+            # allocator knows nothing about): nothing may recycle that memory before they are done
+            torch.cuda.synchronize(self.device)
 
     def __del__(self):
         try:

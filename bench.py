@@ -647,6 +647,11 @@ def timed_steps_in_flight(wls, stage, steps, first, barrier):
     return time.perf_counter() - t0
 
 
+def note(msg):
+    if os.environ.get("DF3D_BENCH_TRACE"):
+        print("bench.py: " + msg, file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     from dualfusion import dist as D
@@ -717,6 +722,7 @@ def main():
                 tot[k] = tot.get(k, 0.0) + r["ms"]
         timer = ops.KernelTimer(only=max(tot, key=tot.get)) if tot else ops.KernelTimer()
         timer.start()
+    note("timed region")
     elapsed, out = timed_steps(wl, stage, args.steps, args.warmup, barrier, reduce_losses)
     if timer is not None:
         timer.stop()
@@ -728,12 +734,14 @@ def main():
     if not (args.no_extra_passes or protocol or stage == "train"):
         # the same K steps ending at the dense BEV tensor (round 1's step), and both stages on the exact-fp32 kernels
         if stage == "detect":
+            note("hot_path pass")
             wl.step(0, "hot_path")
             e, o = timed_steps(wl, "hot_path", args.steps, args.warmup, barrier, reduce_losses)
             wl.check(o, "hot_path")
             extra["hot_path"] = D.max_over_ranks(e, dev)
         if stage == "detect" and world == 1 and args.workload in ("cp_fusion", "cp_lidar") and args.inflight > 1:
             F = args.inflight
+            note("in_flight pass")
             wls = [wl] + [make_workload(args, rank, world, dev) for _ in range(F - 1)]
             if args.prefetch:
                 streams = [torch.cuda.Stream() for _ in wls]
@@ -753,6 +761,7 @@ def main():
             del wls
         if precision == "split" and args.workload in ("cp_fusion", "cp_lidar"):
             ops.CONV_PRECISION = "fp32"
+            note("fp32 passes")
             try:
                 for st in (["detect", "hot_path"] if stage == "detect" else ["hot_path"]):
                     for k in range(3):
@@ -767,6 +776,7 @@ def main():
     if kernel_timing:
         # metadata pass, outside the timed region: every frame once more, counting the valid rulebook pairs of every
         # conv launch (the unit the algorithmic bytes are stated in)
+        note("metadata pass")
         meta_timer = ops.KernelTimer(count_pairs=True)
         meta_timer.start()
         for k in range(len(getattr(wl, "frames", [0]))):
@@ -776,12 +786,14 @@ def main():
     api = None
     if kernel_timing and rank == 0 and stage in ("detect", "hot_path"):
         try:
+            note("api probe")
             api = api_probe(wl, stage)
         except Exception as e:                                   # noqa: BLE001  (a measurement aid must not fail the bench line)
             print("bench.py: api probe failed: %r" % (e,), file=sys.stderr)
     side = None
     if (world == 1 and args.side_configs and not protocol and stage == "detect" and args.workload == "cp_fusion"
             and not args.no_extra_passes):
+        note("side configs")
         side = side_configs(args, rank, world, dev, barrier, reduce_losses)
     if rank == 0:
         units = args.steps * wl.batch * world
