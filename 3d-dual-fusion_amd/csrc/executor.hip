@@ -117,6 +117,7 @@ struct RunState {
   void *split0 = nullptr;      // split rows of the network input, built on demand
   void *rows16_0 = nullptr;    // its bf16 rows (bf16 layers)
   hipEvent_t done = nullptr;   // split API: the geometry phase is complete on its stream
+  hipEvent_t img_done = nullptr;   // frame head: the image projection is complete on the worker's second stream
   int geometry_layers = 0;     // layers whose geometry has been built
 };
 
@@ -505,10 +506,17 @@ extern "C" int df3d_backbone_geometry_wait(void *handle, void *stream_) {
   return DF3D_OK;
 }
 
+extern "C" int df3d_frame_head_image_wait(void *handle, void *stream_) {
+  DF3D_CHECK_ARG(handle && ((RunState *)handle)->img_done, "frame_head_image_wait: no image projection in this handle");
+  DF3D_HIP(hipStreamWaitEvent((hipStream_t)stream_, ((RunState *)handle)->img_done, 0));
+  return DF3D_OK;
+}
+
 extern "C" int df3d_backbone_release(void *handle) {
   if (!handle) return DF3D_OK;
   RunState *S = (RunState *)handle;
   if (S->done) (void)hipEventDestroy(S->done);
+  if (S->img_done) (void)hipEventDestroy(S->img_done);
   delete S;
   return DF3D_OK;
 }
@@ -548,6 +556,8 @@ struct HeadWorker {
   bool stop = false;
   int device = 0;
 };
+
+thread_local hipStream_t g_img_stream = nullptr;      // the worker's second stream (default priority): image projection
 
 #define HEAD_TAKE(ptr, type, bytes)              \
   do {                                           \
@@ -632,6 +642,22 @@ int frame_head_run(HeadTicket &t) {
   if (hipEventCreateWithFlags(&S->done, hipEventDisableTiming) != hipSuccess) {
     set_error("frame_head: cannot create an event");
     return DF3D_EHIP;
+  }
+  if (d.img_ptrs && d.img_count > 0) {
+    // the image-side projection: beside the geometry below, on a stream of default priority
+    if (!g_img_stream) DF3D_HIP(hipStreamCreateWithFlags(&g_img_stream, hipStreamNonBlocking));
+    HEAD_TAKE(t.out.img_split, void *, (size_t)d.img_count * d.img_pixels * 512);
+    HEAD_TAKE(t.out.img_gate, float *, (size_t)d.img_count * d.img_pixels * 4);
+    if (hipEventCreateWithFlags(&S->img_done, hipEventDisableTiming) != hipSuccess) {
+      set_error("frame_head: cannot create an event");
+      return DF3D_EHIP;
+    }
+    if (d.inputs_ready) DF3D_HIP(hipStreamWaitEvent(g_img_stream, (hipEvent_t)d.inputs_ready, 0));
+    int rc = df3d_imgproj_split(d.img_ptrs, d.img_count, d.img_cin, d.img_pixels, d.img_packed, t.out.img_split, t.out.img_gate,
+                                (void *)g_img_stream);
+    if (rc) return rc;
+    DF3D_HIP(hipEventRecord(S->img_done, g_img_stream));
+    t.out.img_done = S->img_done;
   }
   if (total > 0 && d.nlayers > 0) {
     // ---- 2. the backbone's geometry ----
@@ -775,6 +801,7 @@ extern "C" int df3d_frame_head_wait(void *ticket, df3d_layer_view *views, df3d_f
     else set_error("%s", t->err.c_str());
     if (t->state) {
       if (t->state->done) (void)hipEventDestroy(t->state->done);
+      if (t->state->img_done) (void)hipEventDestroy(t->state->img_done);
       delete t->state;
     }
     delete t;

@@ -80,7 +80,7 @@ class BackbonePlan(object):
         self._arena_bytes = 256 << 20
         self._ring = []            # decoupled runs: up to three persistent [arena, event recorded at the start of the NEXT run]
         self._ring_last = 0
-        self._geo_bytes = 128 << 20
+        self._geo_bytes = 384 << 20
         self._frames = _FrameRing()      # build_geometry() / run_convs(): arenas of the frames in flight
         self._lock = threading.Lock()
 

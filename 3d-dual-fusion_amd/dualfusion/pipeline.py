@@ -88,9 +88,6 @@ class CenterPointHotPath(nn.Module):
             layers = [plan.exports[name] for name in self.backbone.FUSE_STAGES]
             cam = fusion.head_request(batch_dict, 'layer1_ori', layers, self.backbone.FUSE_D_FACTORS, dev)
         self._ahead.submit(self._frame_key(points_list, batch_dict), plan, points_list, vox, shape, cam, owner=batch_dict)
-        if cam is not None and hasattr(fusion, "prefetch") and os.environ.get("DF3D_IMGPROJ_AHEAD", "1") == "1":
-            # the image-side projection depends on the camera maps alone: on a side stream now, beside the current frame
-            fusion.prefetch(batch_dict, 'layer1_ori', inp=cam["inp"], ahead=True)
         return True
 
     def close(self):

@@ -36,14 +36,17 @@ class _Desc(ctypes.Structure):
                 ("lidar2cam", ctypes.c_void_p), ("intrinsic", ctypes.c_void_p), ("raw_hw", ctypes.c_void_p),
                 ("depth_thres", ctypes.c_void_p), ("image_scale", ctypes.c_float), ("feat_scale", ctypes.c_void_p),
                 ("aug_inv", ctypes.c_void_p), ("pc_min", ctypes.c_float * 3), ("nproj", ctypes.c_int),
-                ("proj", _Project * MAX_PROJ), ("slots_proj", ctypes.c_int), ("inputs_ready", ctypes.c_void_p)]
+                ("proj", _Project * MAX_PROJ), ("slots_proj", ctypes.c_int), ("inputs_ready", ctypes.c_void_p),
+                ("img_ptrs", ctypes.c_void_p), ("img_count", ctypes.c_int), ("img_cin", ctypes.c_int),
+                ("img_pixels", ctypes.c_int), ("img_packed", ctypes.c_void_p)]
 
 
 class _Out(ctypes.Structure):
     _fields_ = [("features", ctypes.c_void_p), ("coors", ctypes.c_void_p), ("n", ctypes.c_int), ("max_ne", ctypes.c_int),
                 ("grid_xy", ctypes.c_void_p * MAX_PROJ), ("mask", ctypes.c_void_p * MAX_PROJ),
                 ("point_inv", ctypes.c_void_p * MAX_PROJ), ("proj_n", ctypes.c_int * MAX_PROJ), ("pos", ctypes.c_void_p),
-                ("counts", ctypes.c_void_p)]
+                ("counts", ctypes.c_void_p), ("img_split", ctypes.c_void_p), ("img_gate", ctypes.c_void_p),
+                ("img_done", ctypes.c_void_p)]
 
 
 class Prepared(object):
@@ -58,6 +61,9 @@ class Prepared(object):
         frame slot's persistent arena, so the caching allocator has nothing to learn."""
         if self.geometry is not None:
             self.geometry.wait()
+            if self.fusion is not None and "both" in self.fusion:
+                _lib.check(_lib.load().df3d_frame_head_image_wait(self.geometry.handle, _ops._stream()),
+                           "df3d_frame_head_image_wait")
 
 
 class _Ticket(object):
@@ -137,6 +143,11 @@ class FrameHead(object):
             if cam.get("ready") is not None:
                 d.inputs_ready = cam["ready"].cuda_event
                 keep.append(cam["ready"])
+            img = cam.get("image_projection")
+            if img is not None:                 # dict(packed=<df3d_imgproj_pack tensor>, cin=, pixels=): project the maps as well
+                d.img_ptrs, d.img_count = inp["img_ptrs"].data_ptr(), len(inp["imgs"])
+                d.img_cin, d.img_pixels, d.img_packed = int(img["cin"]), int(img["pixels"]), img["packed"].data_ptr()
+                keep.append(img["packed"])
             keep.append(inp)
         t.job = (d, ptrs, nums, keep)
         self._submit(t)
@@ -208,6 +219,10 @@ class FrameHead(object):
                 early = (view(out.pos, ncam * m * 4, torch.int32, (ncam, m)), int(out.max_ne),
                          view(out.counts, B * ncam * 4, torch.int32, (B * ncam,)))
             prep.fusion = dict(inp=cam["inp"], proj=proj, early=early)
+            if out.img_split:
+                ni, px = int(t.job[0].img_count), int(t.job[0].img_pixels)
+                prep.fusion["both"] = (view(out.img_split, ni * px * 512, torch.uint8, (ni, px, 512)),
+                                       view(out.img_gate, ni * px * 4, torch.float32, (ni, px)))
         self.stats["takes"] += 1
         self.stats["take_s"] += time.perf_counter() - t_take
         return prep

@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="sweeps per GPU per step (0 = the workload's BASELINE batch)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames the steps rotate through")
     ap.add_argument("--inflight", type=int, default=2,
-                    help="extra pass at N = 1: the same steps with this many frames in flight (threads + streams + detector "
-                         "replicas); reported as `in_flight`, never as `value`.  Measured on MI355X (round 2): 2 in flight "
-                         "3.51 ms per step against 3.36 ms alone -- the GPU is ~90 %% busy already -- so off by default")
+                    help="extra pass at N = 1: the same steps with this many frames in flight in ONE process -- detector "
+                         "replicas, one HIP stream each, all queued by one host thread; every replica's count round trips are "
+                         "taken a frame ahead by its native frame-head worker.  Reported as `in_flight` (with per-frame latency), "
+                         "never as `value`.  1 = skip the pass")
     ap.add_argument("--conv-precision", default=os.environ.get("DF3D_CONV_PRECISION", ""),
                     choices=["", "split", "fp32", "bf16"],
                     help="sparse-conv arithmetic: split (fp32-grade: bf16 hi+lo operands, 3 MFMA products), fp32 (exact fp32 "
@@ -543,7 +544,7 @@ def cpu_baseline(wl, n_sweeps=5):
 SIDE_CONFIGS = (("cp_lidar", "configs[0] shape", "split"), ("tf_fusion", "configs[2]", "bf16"), ("vr_fusion", "configs[4]", "split"))
 
 
-def side_configs(args, rank, world, dev, barrier, reduce_losses, steps=10):
+def side_configs(args, rank, world, dev, barrier, reduce_losses, steps=12):
     """BASELINE configs[0] (shape), [2] and [4] after the headline, ~`steps` timed steps each with the same protocol (every
     distinct frame once, warm-up, barrier, K steps, barrier): compact numbers for the END of the JSON line, where the
     driver's record keeps them.  A failure of one of them is reported in its entry and does not fail the bench line."""
@@ -560,7 +561,7 @@ def side_configs(args, rank, world, dev, barrier, reduce_losses, steps=10):
         try:
             ops.CONV_PRECISION = prec
             w = make_workload(a, rank, world, dev)
-            for k in range(len(w.frames) + 3):
+            for k in range(2 * len(w.frames) + 4):              # two visits of every frame (allocator, address-keyed tables)
                 o = w.step(k, "detect")
                 if isinstance(o, dict):
                     reduce_losses(o)

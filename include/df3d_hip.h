@@ -879,6 +879,11 @@ typedef struct df3d_frame_head_desc {
   int slots_proj;                   /* index into proj[] of the stage whose visible voxels become queries; -1: none */
   void *inputs_ready;               /* hipEvent_t or NULL: the worker's stream waits for it first (e.g. calibration tables the
                                      * caller has just queued on a side stream) */
+  /* optional: df3d_imgproj_split of the frame's camera maps (it depends on the maps alone), on a SECOND worker stream of
+   * default priority, beside the head and whatever the GPU is doing for the previous frame */
+  const float *const *img_ptrs;     /* device table of img_count pointers, or NULL */
+  int img_count, img_cin, img_pixels;
+  const void *img_packed;           /* df3d_imgproj_pack */
 } df3d_frame_head_desc;
 
 typedef struct df3d_frame_head_out {
@@ -892,6 +897,9 @@ typedef struct df3d_frame_head_out {
   int proj_n[DF3D_HEAD_MAX_PROJ];
   int32_t *pos;                     /* [ncam, proj_n[slots_proj]] */
   int32_t *counts;                  /* [batch * ncam] */
+  void *img_split;                  /* [img_count][img_pixels][128] split rows, or NULL */
+  float *img_gate;                  /* [img_count][img_pixels] */
+  void *img_done;                   /* hipEvent_t (owned by the handle): the projection is complete */
 } df3d_frame_head_out;
 
 void *df3d_head_worker_create(int device);
@@ -902,6 +910,8 @@ int df3d_frame_head_wait(void *ticket, df3d_layer_view *views, df3d_frame_head_o
 /* `stream` waits (on the device) until the geometry of `handle` is complete: for work other than the table's own convolutions
  * that reads the index sets / tables of `views` (e.g. the camera projection of the fusion adapter). */
 int df3d_backbone_geometry_wait(void *handle, void *stream);
+/* the same for the frame head's image projection (df3d_frame_head_out.img_split / img_gate) */
+int df3d_frame_head_image_wait(void *handle, void *stream);
 int df3d_backbone_release(void *handle);
 
 /* ------------------------------------------------------------------------------------
