@@ -51,6 +51,24 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const float *__restrict
   out[row * ((size_t)C * D) + (size_t)c * D + p[1]] = feat[t];
 }
 
+// The same rows in the operand format of the split-precision convolutions ([row][col / 8][hi 8 x bf16 | lo 8 x bf16]): the
+// neck's first convolution reads these; an all-zero buffer is the split of zero.
+__global__ __launch_bounds__(256) void dense_rows_split_kernel(const float *__restrict__ feat, const int32_t *__restrict__ ind,
+                                                               int n, int C, int D, int H, int W,
+                                                               unsigned short *__restrict__ out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * C) return;
+  int i = (int)(t / C), c = (int)(t - (long long)i * C);
+  const int32_t *p = ind + (size_t)i * 4;
+  size_t row = ((size_t)p[0] * H + p[2]) * W + p[3];
+  const size_t col = (size_t)c * D + p[1];
+  unsigned h, l;
+  split_pair(feat[t], 0.f, h, l);
+  unsigned short *blk = out + (row * ((size_t)C * D) + (col & ~(size_t)7)) * 2;      // 16 halfwords per 8 columns
+  blk[col & 7] = (unsigned short)(h & 0xffffu);
+  blk[8 + (col & 7)] = (unsigned short)(l & 0xffffu);
+}
+
 // Neighbour table of a dense 2-D convolution over rows (b*H + y)*W + x: nbr[k][o], k = ky*kw + kx,
 // input pixel (oy*stride - pad + ky, ox*stride - pad + kx) or -1 outside the map.
 __global__ __launch_bounds__(256) void conv2d_neighbors_kernel(int B, int H, int W, int Ho, int Wo, int kh, int kw,
@@ -109,6 +127,22 @@ extern "C" int df3d_sparse_to_dense_rows(const float *features, const int32_t *i
   DF3D_CHECK_ARG(features && indices, "sparse_to_dense_rows: null input");
   hipLaunchKernelGGL(dense_rows_kernel, dim3(cdiv((long long)n * channels, 256)), dim3(256), 0, stream, features,
                      indices, n, channels, shape[0], shape[1], shape[2], out_rows);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_sparse_to_dense_rows_split(const float *features, const int32_t *indices, int n, int channels, int batch,
+                                               const int *shape, void *out_split, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(out_split && shape && batch > 0 && channels > 0, "sparse_to_dense_rows_split: bad arguments");
+  DF3D_CHECK_ARG(((long long)channels * shape[0]) % 8 == 0, "sparse_to_dense_rows_split: %d columns per row (need a multiple of 8)",
+                 channels * shape[0]);
+  size_t total = (size_t)batch * channels * shape[0] * shape[1] * shape[2];
+  DF3D_HIP(hipMemsetAsync(out_split, 0, total * sizeof(float), stream));
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(features && indices, "sparse_to_dense_rows_split: null input");
+  hipLaunchKernelGGL(dense_rows_split_kernel, dim3(cdiv((long long)n * channels, 256)), dim3(256), 0, stream, features, indices,
+                     n, channels, shape[0], shape[1], shape[2], (unsigned short *)out_split);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

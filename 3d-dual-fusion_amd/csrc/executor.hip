@@ -695,6 +695,12 @@ int frame_head_run(HeadTicket &t) {
                                  d.depth_thres, d.image_scale, d.feat_scale, t.out.grid_xy[p], t.out.mask[p],
                                  t.out.point_inv[p], nullptr, d.aug_inv, gs_);
         if (rc) return rc;
+        if (d.proj[p].want_winner && d.feat_h > 0 && d.feat_w > 0) {
+          HEAD_TAKE(t.out.winner[p], int32_t *, (size_t)B * d.ncam * d.feat_h * d.feat_w * 4);
+          rc = df3d_scatter_winner(T.indices, t.out.grid_xy[p], t.out.mask[p], T.n, B, d.ncam, d.feat_h, d.feat_w,
+                                   t.out.winner[p], gs_);
+          if (rc) return rc;
+        }
       }
       if (d.slots_proj >= 0) {
         const int p = d.slots_proj;

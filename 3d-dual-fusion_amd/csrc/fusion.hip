@@ -14,6 +14,9 @@
 // All are HBM/latency-bound gathers over <= ~10^5 rows.
 #include "common.h"
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 namespace df3d {
 
 struct ProjArgs {
@@ -212,6 +215,44 @@ __global__ __launch_bounds__(256) void writeback_kernel(const float *__restrict_
   out[t] = v;
 }
 
+// The same, eight channels per thread (two 16-byte loads per operand), optionally with the split rows (bf16 hi | lo, the
+// operand format of the split-precision convolutions) of the result: the convolution behind the adapter reads those, a
+// separate df3d_split_rows pass over the rows is not needed.  Same additions in the same (camera) order: bit-identical.
+__global__ __launch_bounds__(256) void writeback8_kernel(const float *__restrict__ feat, const float *__restrict__ enh,
+                                                         const int32_t *__restrict__ ind, const uint8_t *__restrict__ mask,
+                                                         const int32_t *__restrict__ pos, int n, int C, int ncam, int max_ne,
+                                                         float *__restrict__ out, u32x4 *__restrict__ out_split) {
+  const int C8 = C >> 3;
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * C8) return;
+  const int i = (int)(t / C8), c8 = (int)(t - (long long)i * C8);
+  const float *f = feat + (size_t)i * C + c8 * 8;
+  f32x4 v0 = *(const f32x4 *)f, v1 = *(const f32x4 *)(f + 4);
+  const int b = ind[(size_t)i * 4];
+  for (int cam = 0; cam < ncam; ++cam) {
+    if (mask[(size_t)cam * n + i]) {
+      const int slot = pos[(size_t)cam * n + i];
+      if (slot < max_ne) {
+        const float *e = enh + ((size_t)(b * ncam + cam) * max_ne + slot) * C + c8 * 8;
+        v0 += *(const f32x4 *)e;
+        v1 += *(const f32x4 *)(e + 4);
+      }
+    }
+  }
+  float *o = out + (size_t)i * C + c8 * 8;
+  *(f32x4 *)o = v0;
+  *(f32x4 *)(o + 4) = v1;
+  if (out_split) {
+    u32x4 h, l;
+    split_pair(v0[0], v0[1], h[0], l[0]);
+    split_pair(v0[2], v0[3], h[1], l[1]);
+    split_pair(v1[0], v1[1], h[2], l[2]);
+    split_pair(v1[2], v1[3], h[3], l[3]);
+    out_split[((size_t)i * C8 + c8) * 2] = h;
+    out_split[((size_t)i * C8 + c8) * 2 + 1] = l;
+  }
+}
+
 }  // namespace df3d
 
 using namespace df3d;
@@ -386,7 +427,11 @@ __global__ __launch_bounds__(256) void gate_scatter_rows_kernel(const float *__r
 }
 
 // att[img][p] = sigmoid(bias + sum_t inside * (k[t] + g[t]*gate[p+t] + S[t][p+t]))
-__global__ __launch_bounds__(256) void gate_finish_kernel(const float *__restrict__ gate, const float *__restrict__ S,
+// BIAS: the image summary arrives without the bias of its 1x1 convolution (`gate_bias[0]` is added here, as the caller's
+// separate element-wise pass did: same operation, same order)
+template <bool BIAS>
+__global__ __launch_bounds__(256) void gate_finish_kernel(const float *__restrict__ gate, const float *__restrict__ gate_bias,
+                                                          const float *__restrict__ S,
                                                           const float *__restrict__ kg /* [9] k_t, [9] g_t, bias */,
                                                           int nimg, int H, int W, float *__restrict__ att) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,6 +441,7 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const float *__restric
   int p = (int)(t - (long long)img * hw);
   int y = p / W, x = p - y * W;
   float acc = kg[18];
+  const float gb = BIAS ? gate_bias[0] : 0.f;
 #pragma unroll
   for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
@@ -404,7 +450,8 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const float *__restric
       if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;   // zero padding of the 3x3 conv
       int k = ty * 3 + tx;
       size_t q = (size_t)yy * W + xx;
-      acc += kg[k] + kg[9 + k] * gate[(size_t)img * hw + q] + S[((size_t)img * 9 + k) * hw + q];
+      const float gq = BIAS ? gate[(size_t)img * hw + q] + gb : gate[(size_t)img * hw + q];
+      acc += kg[k] + kg[9 + k] * gq + S[((size_t)img * 9 + k) * hw + q];
     }
   att[t] = 1.f / (1.f + __expf(-acc));
 }
@@ -675,13 +722,54 @@ extern "C" int df3d_gate_scatter_rows(const float *features, int channels, const
   return DF3D_OK;
 }
 
+// df3d_gate_scatter_rows for a winner map the caller already holds (it depends on the voxel coordinates alone: the frame-head
+// worker builds it a frame ahead): the rows kernel only
+extern "C" int df3d_gate_rows(const float *features, int channels, const float *point_inv, const float *T, const int32_t *winner,
+                              int nimg, int H, int W, float *S, int clear, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(features && point_inv && T && winner && S, "gate_rows: null argument");
+  DF3D_CHECK_ARG(channels > 0 && channels % 4 == 0 && channels <= 1024, "gate_rows: %d channels", channels);
+  DF3D_CHECK_ARG((long long)H * W < 0x7fffffffLL, "gate_rows: map size");
+  const long long npix = (long long)nimg * H * W;
+  if (npix == 0) return DF3D_OK;
+  hipLaunchKernelGGL(gate_scatter_rows_kernel, dim3(cdiv(npix, 256)), dim3(256), (size_t)(channels + 3) * 9 * sizeof(float),
+                     stream, features, channels, point_inv, T, winner, npix, H * W, clear, S);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_gate_finish_bias(const float *gate, const float *gate_bias, const float *S, const float *kg, int nimg, int H,
+                                     int W, float *att, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(gate && gate_bias && S && kg && att, "gate_finish_bias: null argument");
+  long long tot = (long long)nimg * H * W;
+  if (tot == 0) return DF3D_OK;
+  hipLaunchKernelGGL(gate_finish_kernel<true>, dim3(cdiv(tot, 256)), dim3(256), 0, stream, gate, gate_bias, S, kg, nimg, H, W, att);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_fusion_writeback_split(const float *features, const float *enh, const int32_t *indices, const uint8_t *mask,
+                                           const int32_t *pos, int n, int channels, int ncam, int max_ne, float *out,
+                                           void *out_split, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(out && channels > 0 && channels % 8 == 0, "fusion_writeback_split: channels must be a multiple of 8");
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(features && enh && indices && mask && pos, "fusion_writeback_split: null input");
+  hipLaunchKernelGGL(writeback8_kernel, dim3(cdiv((long long)n * (channels / 8), 256)), dim3(256), 0, stream, features, enh,
+                     indices, mask, pos, n, channels, ncam, max_ne, out, (u32x4 *)out_split);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
 extern "C" int df3d_gate_finish(const float *gate, const float *S, const float *kg, int nimg, int H, int W, float *att,
                                 void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(gate && S && kg && att, "gate_finish: null argument");
   long long tot = (long long)nimg * H * W;
   if (tot == 0) return DF3D_OK;
-  hipLaunchKernelGGL(gate_finish_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, gate, S, kg, nimg, H, W, att);
+  hipLaunchKernelGGL(gate_finish_kernel<false>, dim3(cdiv(tot, 256)), dim3(256), 0, stream, gate, (const float *)nullptr, S, kg,
+                     nimg, H, W, att);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -195,7 +195,14 @@ class SpMiddleResNetFHD(nn.Module):
             # channels-last pixel rows for the row-kernel neck (necks.RPN.forward_rows): same values as
             # dense().view(N, C*D, H, W), laid out [N*H*W, C*D]
             D, H, W = [int(v) for v in ret.spatial_shape]
-            ret = (ret.dense_rows(), (ret.batch_size, ret.features.shape[1] * D, H, W))
+            ok = getattr(self, "dense_split", None)
+            if ok is not None and (ret.features.shape[1] * D) % 8 == 0 and ok():
+                # the consumer (the row-kernel neck) reads split rows only: written directly, no fp32 map, no split pass
+                from .necks import SplitRows
+                rows = SplitRows(ret.dense_rows(split=True), ret.features.shape[1] * D)
+            else:
+                rows = ret.dense_rows()
+            ret = (rows, (ret.batch_size, ret.features.shape[1] * D, H, W))
         else:
             ret = ret.dense()
             N, C, D, H, W = ret.shape

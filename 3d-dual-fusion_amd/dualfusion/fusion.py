@@ -437,7 +437,9 @@ class VoxelWithPointProjection(nn.Module):
         else:                                   # stacked on the caller's stream: the worker then waits for that stream
             ready = torch.cuda.current_stream(dev).record_event()
         req = dict(inp=inp, levels=levels, slots_level=last, pc_min=[float(np.float32(v)) for v in self.pc_range[:3]],
-                   image_scale=self.image_scale, ready=ready)
+                   image_scale=self.image_scale, ready=ready,
+                   # the image gate's "winning voxel per pixel" maps depend on the coordinates alone as well
+                   winner_levels=tuple(self.ifat.voxel_idx) if self.ifat_cfg is not None else ())
         packed = self._native_projection_weights(inp)
         if packed is not None and os.environ.get("DF3D_IMGPROJ_AHEAD", "0") == "1":
             # the image-side projection depends on the camera maps alone: the worker can run it too, on a second stream of
@@ -695,14 +697,29 @@ class VoxelWithPointProjection(nn.Module):
             # (a9) image-side gate, canvas-free: the projection above also produced the gate's 1-channel image
             # summary (extra GEMM row); the voxel side is 9 scalars per visible voxel
             T, kg, w3, b3 = self.ifat.folded()
-            gate = (both[1] if isinstance(both, tuple) else both[:, w_ip.shape[0]]) + b3     # [NI, H*W]
+            fused_tail = os.environ.get("DF3D_FUSION_TAIL", "1") == "1"
+            gate = both[1] if isinstance(both, tuple) else both[:, w_ip.shape[0]]                # [NI, H*W]
+            gate_bias = b3 if (fused_tail and gate.is_contiguous() and b3.numel() == 1 and b3.dtype == torch.float32) else None
+            if gate_bias is None:
+                gate = gate + b3
             S = torch.empty((NI, 9, H, W), dtype=torch.float32, device=dev)
-            winner = torch.empty((NI, H, W), dtype=torch.int32, device=dev)
+            winner = None
+            have = prep.get('winner', {}) if (prep is not None and fused_tail) else {}
             first = True
             for sidx in self.ifat.voxel_idx:
                 x = encoded_voxel_list[sidx]
                 grid_s, mask_s, pinv_s = proj[sidx]
                 feats_s, Ts = x.features, T[sidx]
+                if (sidx in have and feats_s.dtype == torch.float32 and feats_s.shape[1] % 4 == 0 and Ts.dtype == torch.float32
+                        and os.environ.get("DF3D_GATE_ROWS", "1") == "1"):
+                    # the winner map of this scale came with the frame head (it depends on the coordinates alone)
+                    rc = lib.df3d_gate_rows(_p(feats_s.contiguous()), feats_s.shape[1], _p(pinv_s.contiguous()),
+                                            _p(Ts.contiguous()), _p(have[sidx]), NI, H, W, _p(S), int(first), _ops._stream())
+                    _lib.check(rc, "df3d_gate_rows")
+                    first = False
+                    continue
+                if winner is None:
+                    winner = torch.empty((NI, H, W), dtype=torch.int32, device=dev)
                 if (feats_s.dtype == torch.float32 and feats_s.shape[1] % 4 == 0 and Ts.dtype == torch.float32
                         and os.environ.get("DF3D_GATE_ROWS", "1") == "1"):
                     # the 9 responses of a row matter for the rows that win a pixel only: computed inside the scatter
@@ -719,7 +736,10 @@ class VoxelWithPointProjection(nn.Module):
                     _lib.check(rc, "df3d_gate_scatter")
                 first = False
             att = torch.empty((NI, H, W), dtype=torch.float32, device=dev)
-            rc = lib.df3d_gate_finish(_p(gate), _p(S), _p(kg), NI, H, W, _p(att), _ops._stream())
+            if gate_bias is not None:                       # the summary's bias is added inside (no element-wise pass)
+                rc = lib.df3d_gate_finish_bias(_p(gate), _p(gate_bias), _p(S), _p(kg), NI, H, W, _p(att), _ops._stream())
+            else:
+                rc = lib.df3d_gate_finish(_p(gate), _p(S), _p(kg), NI, H, W, _p(att), _ops._stream())
             _lib.check(rc, "df3d_gate_finish")
         fold = self.pfat.can_fold()
         if not fold:
@@ -754,6 +774,16 @@ class VoxelWithPointProjection(nn.Module):
             enh = self.pfat.forward_projected(v_feat, qgrid, src_conv, v_i_feat, qpts, q_pos=qpos).contiguous()
         # write-back, additive, camera order (Appendix C item 8)
         out = torch.empty_like(feats)
+        if C % 8 == 0 and os.environ.get("DF3D_FUSION_TAIL", "1") == "1":
+            # 16-byte accesses + the operand split the convolution behind the adapter reads (no df3d_split_rows pass)
+            osplit = torch.empty((n, 4 * C), dtype=torch.uint8, device=dev) if _ops.CONV_PRECISION == "split" else None
+            rc = lib.df3d_fusion_writeback_split(_p(feats), _p(enh), _p(ind), _p(mask), _p(pos), n, C, ncam, max_ne, _p(out),
+                                                 _p(osplit), _ops._stream())
+            _lib.check(rc, "df3d_fusion_writeback_split")
+            y = x_last.replace_feature(out)
+            if osplit is not None:
+                y._split = (out, osplit)
+            return y
         rc = lib.df3d_fusion_writeback(_p(feats), _p(enh), _p(ind), _p(mask), _p(pos), n, C, ncam, max_ne, _p(out),
                                        _ops._stream())
         _lib.check(rc, "df3d_fusion_writeback")

@@ -65,6 +65,21 @@ def _train_rows_ok(x):
     return x.is_cuda and x.dtype == torch.float32
 
 
+class SplitRows(object):
+    """Pixel rows handed over in the operand format of the split-precision kernels only ([rows, 4 * C] uint8: bf16 hi | lo
+    per 8 columns) -- what `SparseConvTensor.dense_rows(split=True)` produces and `RPN.forward_rows` accepts."""
+
+    def __init__(self, split, channels):
+        self.split, self.channels = split, int(channels)
+
+
+class _NoRows(object):
+    """Stands in for the fp32 rows of a map that exists as split rows only (the row kernels never read them)."""
+
+    def __init__(self, device):
+        self.device = device
+
+
 class _Layer(object):
     """One conv/deconv + BN(eval) + ReLU group prepared for the row kernels."""
 
@@ -200,6 +215,18 @@ class RPN(nn.Module):
                                                 device)
         return tables[key]
 
+    def accepts_split_rows(self):
+        """True when forward_rows can take its input as split rows (`SplitRows`): the first layer runs on the
+        split-precision kernel, which reads nothing else."""
+        if _ops.CONV_PRECISION != "split" or self.training or os.environ.get("DF3D_FUSION_TAIL", "1") != "1":
+            return False
+        plan = self._plan()
+        if not plan["blocks"] or not plan["blocks"][0]:
+            return False
+        layer, pad = plan["blocks"][0][0]
+        layer.prepare(pad)
+        return layer.packed is not None and layer.packed16 is None
+
     @staticmethod
     def _cat_width(plan):
         """Channels of the concatenated upsampled maps if their last layers can write them in place (split-precision
@@ -242,7 +269,10 @@ class RPN(nn.Module):
         """rows [B*H*W, C] fp32 channels-last (row = (b, y, x)) -> NCHW-shaped, channels-last-strided output."""
         plan = self._plan()
         tables = plan["nbr"]
-        x, xs = rows.contiguous(), None
+        if isinstance(rows, SplitRows):              # the producer wrote the operand format of the first layer directly
+            x, xs = _NoRows(rows.split.device), rows.split
+        else:
+            x, xs = rows.contiguous(), None
         ups = []
         cat, cat_rows, cat_split, col0 = self._cat_width(plan), None, None, 0
         for i, blk in enumerate(plan["blocks"]):

@@ -753,6 +753,20 @@ def sparse_to_dense_rows(features, indices, batch, shape):
     return out
 
 
+def sparse_to_dense_rows_split(features, indices, batch, shape):
+    """`sparse_to_dense_rows` written as split rows [B*H*W, 4 * C*D] uint8 (bf16 hi | lo per 8 columns), no fp32 copy."""
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    _chk(indices, torch.int32, "indices")
+    n, C = features.shape
+    D, H, W = [int(v) for v in shape]
+    out = torch.empty((int(batch) * H * W, 4 * C * D), dtype=torch.uint8, device=features.device)
+    shp_p, keep = _lib.int3(shape)
+    rc = lib.df3d_sparse_to_dense_rows_split(_ptr(features), _ptr(indices), n, C, int(batch), shp_p, _ptr(out), _stream())
+    _lib.check(rc, "df3d_sparse_to_dense_rows_split")
+    return out
+
+
 def conv2d_neighbors(batch, H, W, kh, kw, stride, pad, transposed, device):
     """Neighbour table [kh*kw, B*Ho*Wo] int32 of a dense (transposed) convolution over row-major pixel rows."""
     lib = _lib.load()

@@ -34,6 +34,8 @@ class CenterPointHotPath(nn.Module):
         self.neck = neck
         if neck is not None:
             self.backbone.dense_layout = "rows"
+            # a neck that reads split rows only gets them straight from the scatter (necks.SplitRows)
+            self.backbone.dense_split = getattr(neck, "accepts_split_rows", None)
         gs = self.voxel_layer.grid_size.tolist()
         self.grid_size_xyz = [int(gs[0]), int(gs[1]), int(gs[2])]
         object.__setattr__(self, "_ahead", None)           # dualfusion.prefetch.FrameHead, created by prefetch()

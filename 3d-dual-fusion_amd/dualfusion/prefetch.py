@@ -25,7 +25,7 @@ MAX_PROJ = 4
 
 
 class _Project(ctypes.Structure):
-    _fields_ = [("layer", ctypes.c_int), ("scale_xyz", ctypes.c_float * 3)]
+    _fields_ = [("layer", ctypes.c_int), ("scale_xyz", ctypes.c_float * 3), ("want_winner", ctypes.c_int)]
 
 
 class _Desc(ctypes.Structure):
@@ -38,7 +38,8 @@ class _Desc(ctypes.Structure):
                 ("aug_inv", ctypes.c_void_p), ("pc_min", ctypes.c_float * 3), ("nproj", ctypes.c_int),
                 ("proj", _Project * MAX_PROJ), ("slots_proj", ctypes.c_int), ("inputs_ready", ctypes.c_void_p),
                 ("img_ptrs", ctypes.c_void_p), ("img_count", ctypes.c_int), ("img_cin", ctypes.c_int),
-                ("img_pixels", ctypes.c_int), ("img_packed", ctypes.c_void_p)]
+                ("img_pixels", ctypes.c_int), ("img_packed", ctypes.c_void_p), ("feat_h", ctypes.c_int),
+                ("feat_w", ctypes.c_int)]
 
 
 class _Out(ctypes.Structure):
@@ -46,7 +47,7 @@ class _Out(ctypes.Structure):
                 ("grid_xy", ctypes.c_void_p * MAX_PROJ), ("mask", ctypes.c_void_p * MAX_PROJ),
                 ("point_inv", ctypes.c_void_p * MAX_PROJ), ("proj_n", ctypes.c_int * MAX_PROJ), ("pos", ctypes.c_void_p),
                 ("counts", ctypes.c_void_p), ("img_split", ctypes.c_void_p), ("img_gate", ctypes.c_void_p),
-                ("img_done", ctypes.c_void_p)]
+                ("img_done", ctypes.c_void_p), ("winner", ctypes.c_void_p * MAX_PROJ)]
 
 
 class Prepared(object):
@@ -138,8 +139,10 @@ class FrameHead(object):
                 d.proj[j].layer = int(layer)
                 for i in range(3):
                     d.proj[j].scale_xyz[i] = float(scale[i])
+                d.proj[j].want_winner = int(lvl in cam.get("winner_levels", ()))
                 if lvl == cam["slots_level"]:
                     d.slots_proj = j
+            d.feat_h, d.feat_w = int(inp["h"]), int(inp["w"])
             if cam.get("ready") is not None:
                 d.inputs_ready = cam["ready"].cuda_event
                 keep.append(cam["ready"])
@@ -207,9 +210,13 @@ class FrameHead(object):
         cam = t.cam
         if cam is not None:
             ncam = int(t.job[0].ncam)
-            proj = {}
+            proj, winners = {}, {}
+            hw = int(t.job[0].feat_h) * int(t.job[0].feat_w)
             for j, (lvl, layer, scale) in enumerate(cam["levels"]):
                 m = int(out.proj_n[j])
+                if out.winner[j]:
+                    winners[lvl] = view(out.winner[j], B * ncam * hw * 4, torch.int32,
+                                        (B * ncam, int(t.job[0].feat_h), int(t.job[0].feat_w)))
                 proj[lvl] = (view(out.grid_xy[j], ncam * m * 8, torch.int32, (ncam, m, 2)),
                              view(out.mask[j], ncam * m, torch.uint8, (ncam, m)),
                              view(out.point_inv[j], m * 12, torch.float32, (m, 3)))
@@ -218,7 +225,7 @@ class FrameHead(object):
                 m = int(out.proj_n[int(t.job[0].slots_proj)])
                 early = (view(out.pos, ncam * m * 4, torch.int32, (ncam, m)), int(out.max_ne),
                          view(out.counts, B * ncam * 4, torch.int32, (B * ncam,)))
-            prep.fusion = dict(inp=cam["inp"], proj=proj, early=early)
+            prep.fusion = dict(inp=cam["inp"], proj=proj, early=early, winner=winners)
             if out.img_split:
                 ni, px = int(t.job[0].img_count), int(t.job[0].img_pixels)
                 prep.fusion["both"] = (view(out.img_split, ni * px * 512, torch.uint8, (ni, px, 512)),

@@ -181,8 +181,12 @@ class SparseConvTensor(object):
             return out.permute(0, *range(2, nd + 2), 1).contiguous()
         return out
 
-    def dense_rows(self):
-        """dense().view(B, C*D, H, W) as channels-last pixel rows [B*H*W, C*D] (3-D tensors only)."""
+    def dense_rows(self, split=False):
+        """dense().view(B, C*D, H, W) as channels-last pixel rows [B*H*W, C*D] (3-D tensors only).
+        split: the same rows in the operand format of the split-precision kernels only ([B*H*W, 4 * C*D] uint8)."""
+        if split:
+            return _ops.sparse_to_dense_rows_split(self.features.contiguous(), self.indices.contiguous(), self.batch_size,
+                                                   self.spatial_shape)
         return _ops.sparse_to_dense_rows(self.features.contiguous(), self.indices.contiguous(), self.batch_size,
                                          self.spatial_shape)
 

@@ -207,6 +207,10 @@ int df3d_sparse_to_dense(const float *features, const int32_t *indices, int n, i
  * [kh*kw][Cin][Cout] (Conv2d weight.permute(2,3,1,0); ConvTranspose2d weight.permute(2,3,0,1)). */
 int df3d_sparse_to_dense_rows(const float *features, const int32_t *indices, int n, int channels, int batch,
                               const int *shape_host, float *out_rows, void *stream);
+/* the same rows as split rows (bf16 hi | lo per 8 columns, the operand format of df3d_sparse_conv_split): what the BEV neck's
+ * first convolution reads -- no fp32 copy, no df3d_split_rows pass (channels * shape[0] must be a multiple of 8) */
+int df3d_sparse_to_dense_rows_split(const float *features, const int32_t *indices, int n, int channels, int batch,
+                                    const int *shape_host, void *out_split, void *stream);
 int df3d_conv2d_neighbors(int batch, int H, int W, int kh, int kw, int stride, int pad, int transposed,
                           int32_t *nbr, void *stream);
 
@@ -605,6 +609,20 @@ int df3d_gate_scatter_rows(const float *features, int channels, const float *poi
                            int H, int W, int32_t *winner, float *S, int clear, void *stream);
 int df3d_gate_finish(const float *gate, const float *S, const float *kg, int nimg, int H, int W, float *att,
                      void *stream);
+/* round 4: the same steps with fewer passes around them --
+ * df3d_gate_rows: df3d_gate_scatter_rows for a winner map the caller already holds (df3d_scatter_winner: it depends on the
+ *   voxel coordinates alone, so the frame head builds it a frame ahead);
+ * df3d_gate_finish_bias: df3d_gate_finish on an image summary WITHOUT the bias of its 1x1 convolution, gate_bias [1] added
+ *   inside (attention.py:31-61: conv bias);
+ * df3d_fusion_writeback_split: df3d_fusion_writeback with 16-byte accesses and, optionally, the split rows of the result
+ *   (out_split may be NULL), which the convolution behind the adapter reads. */
+int df3d_gate_rows(const float *features, int channels, const float *point_inv, const float *T, const int32_t *winner,
+                   int nimg, int H, int W, float *S, int clear, void *stream);
+int df3d_gate_finish_bias(const float *gate, const float *gate_bias, const float *S, const float *kg, int nimg, int H, int W,
+                          float *att, void *stream);
+int df3d_fusion_writeback_split(const float *features, const float *enh, const int32_t *indices, const uint8_t *mask,
+                                const int32_t *pos, int n, int channels, int ncam, int max_ne, float *out, void *out_split,
+                                void *stream);
 /* df3d_query_slots: pos[cam][i] = number of visible voxels (mask[cam][.] != 0) of voxel i's sample before i,
  *   counts[b*ncam + cam] = visible voxels of sample b in camera cam (voxel_with_point_projection.py:318-335 builds
  *   these lists with boolean indexing per camera); indices must be batch-sorted. */
@@ -855,6 +873,7 @@ int df3d_backbone_convs(void *handle, const float *features, void *arena, size_t
 typedef struct df3d_head_project {
   int layer;              /* the stage: index into `layers`, its OUTPUT index set is projected */
   float scale_xyz[3];     /* voxel size of that stage (fp32 voxel size * down-sampling factor) */
+  int want_winner;        /* != 0: also df3d_scatter_winner of this stage (the image gate's "last writer" per pixel) */
 } df3d_head_project;
 
 typedef struct df3d_frame_head_desc {
@@ -884,6 +903,7 @@ typedef struct df3d_frame_head_desc {
   const float *const *img_ptrs;     /* device table of img_count pointers, or NULL */
   int img_count, img_cin, img_pixels;
   const void *img_packed;           /* df3d_imgproj_pack */
+  int feat_h, feat_w;               /* camera feature map size (winner maps) */
 } df3d_frame_head_desc;
 
 typedef struct df3d_frame_head_out {
@@ -900,6 +920,7 @@ typedef struct df3d_frame_head_out {
   void *img_split;                  /* [img_count][img_pixels][128] split rows, or NULL */
   float *img_gate;                  /* [img_count][img_pixels] */
   void *img_done;                   /* hipEvent_t (owned by the handle): the projection is complete */
+  int32_t *winner[DF3D_HEAD_MAX_PROJ];    /* [batch * ncam, feat_h, feat_w] or NULL */
 } df3d_frame_head_out;
 
 void *df3d_head_worker_create(int device);

@@ -238,3 +238,62 @@ def test_second_fpn_training_on_row_kernels_vs_float64():
             return mod.fpn(mod.bb(t))[0]
         return mod.fpn.forward_reference(mod.bb.forward_reference(t))[0]
     _train_case(m, run, x)
+
+
+def test_round4_tail_fusions_are_bit_identical_to_the_separate_passes():
+    """The small fusions around the camera adapter and the dense map (round 4) against the passes they replace:
+    dense rows written as split rows == df3d_split_rows(dense rows); write-back with 16-byte accesses + split rows ==
+    df3d_fusion_writeback (+ df3d_split_rows); gate finish with the summary's bias added inside == the element-wise add in
+    front of df3d_gate_finish; gate rows on a given winner map == df3d_gate_scatter_rows."""
+    import ctypes
+    from dualfusion import _lib, ops
+    from dualfusion import spconv
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    # ---- dense rows
+    B, D, H, W, C, n = 2, 2, 45, 37, 128, 1500
+    flat = torch.randperm(B * D * H * W, generator=g)[:n].sort().values
+    ind = torch.stack([flat // (D * H * W), (flat // (H * W)) % D, (flat // W) % H, flat % W], 1).to(torch.int32).to(dev)
+    feats = torch.randn(n, C, generator=g).to(dev)
+    x = spconv.SparseConvTensor(feats, ind, [D, H, W], B)
+    rows = x.dense_rows()
+    assert torch.equal(x.dense_rows(split=True), ops.split_rows(rows))
+    # ---- write-back
+    ncam, max_ne, nq = 6, 300, 1200
+    n4 = 1000
+    ind4 = torch.stack([torch.arange(n4) // 500, torch.zeros(n4, dtype=torch.long), torch.arange(n4) % 31,
+                        torch.arange(n4) % 17], 1).to(torch.int32).to(dev)
+    mask = (torch.rand(ncam, n4, generator=g) < 0.3).to(torch.uint8).to(dev)
+    pos = torch.randint(0, max_ne + 40, (ncam, n4), generator=g).to(torch.int32).to(dev)      # some slots beyond max_ne
+    f4 = torch.randn(n4, C, generator=g).to(dev)
+    enh = torch.randn(B * ncam, max_ne, C, generator=g).to(dev)
+    want = torch.empty_like(f4)
+    _lib.check(lib.df3d_fusion_writeback(P(f4), P(enh), P(ind4), P(mask), P(pos), n4, C, ncam, max_ne, P(want), ops._stream()))
+    got, gsplit = torch.empty_like(f4), torch.empty((n4, 4 * C), dtype=torch.uint8, device=dev)
+    _lib.check(lib.df3d_fusion_writeback_split(P(f4), P(enh), P(ind4), P(mask), P(pos), n4, C, ncam, max_ne, P(got), P(gsplit),
+                                               ops._stream()))
+    assert torch.equal(got, want) and torch.equal(gsplit, ops.split_rows(want))
+    # ---- image gate
+    NI, Hf, Wf, Cs = B * ncam, 20, 33, 32
+    gate = torch.randn(NI, Hf * Wf, generator=g).to(dev)
+    b3 = torch.randn(1, generator=g).to(dev)
+    S = torch.randn(NI, 9, Hf, Wf, generator=g).to(dev)
+    kg = torch.randn(19, generator=g).to(dev)
+    a0, a1 = torch.empty(NI, Hf, Wf, device=dev), torch.empty(NI, Hf, Wf, device=dev)
+    _lib.check(lib.df3d_gate_finish(P((gate + b3).contiguous()), P(S), P(kg), NI, Hf, Wf, P(a0), ops._stream()))
+    _lib.check(lib.df3d_gate_finish_bias(P(gate), P(b3), P(S), P(kg), NI, Hf, Wf, P(a1), ops._stream()))
+    assert torch.equal(a0, a1)
+    fs = torch.randn(n4, Cs, generator=g).to(dev)
+    pinv = torch.randn(n4, 3, generator=g).to(dev)
+    Tm = torch.randn(9, Cs + 3, generator=g).to(dev)
+    grid = torch.stack([torch.randint(0, Wf, (ncam, n4), generator=g), torch.randint(0, Hf, (ncam, n4), generator=g)], 2) \
+        .to(torch.int32).to(dev).contiguous()
+    w0, S0 = torch.empty(NI, Hf, Wf, dtype=torch.int32, device=dev), torch.empty(NI, 9, Hf, Wf, device=dev)
+    _lib.check(lib.df3d_gate_scatter_rows(P(fs), Cs, P(pinv), P(Tm), P(ind4), P(grid), P(mask), n4, B, ncam, Hf, Wf, P(w0), P(S0),
+                                          1, ops._stream()))
+    w1, S1 = torch.empty_like(w0), torch.empty_like(S0)
+    _lib.check(lib.df3d_scatter_winner(P(ind4), P(grid), P(mask), n4, B, ncam, Hf, Wf, P(w1), ops._stream()))
+    _lib.check(lib.df3d_gate_rows(P(fs), Cs, P(pinv), P(Tm), P(w1), NI, Hf, Wf, P(S1), 1, ops._stream()))
+    assert torch.equal(w0, w1) and torch.equal(S0, S1) and int((w1 >= 0).sum()) > 100

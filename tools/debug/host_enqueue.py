@@ -104,24 +104,25 @@ if os.environ.get("DF3D_PROBE_TRACE"):
     sys.exit(0)
 
 # ---- (c) two streams / replicas, one thread
-wls = [wl, bench.make_workload(A(), 0, 1, dev)]
+F = int(os.environ.get("DF3D_PROBE_INFLIGHT", "2"))
+wls = [wl] + [bench.make_workload(A(), 0, 1, dev) for _ in range(F - 1)]
 for w in wls:
-    w.stride = 2
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-for k in range(16):
-    with torch.cuda.stream(streams[k % 2]):
-        wls[k % 2].step(k, "detect")
+    w.stride = F
+streams = [torch.cuda.Stream() for _ in wls]
+for k in range(8 * F):
+    with torch.cuda.stream(streams[k % F]):
+        wls[k % F].step(k, "detect")
 torch.cuda.synchronize()
 for rep in range(2):
     t0 = time.perf_counter()
     for k in range(steps):
-        with torch.cuda.stream(streams[k % 2]):
-            wls[k % 2].step(k, "detect")
+        with torch.cuda.stream(streams[k % F]):
+            wls[k % F].step(k, "detect")
     t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print("(c) two streams, one thread: %.3f ms per step (host returned after %.3f) = %.1f sweeps/s" % (
-        el / steps * 1e3, t_enq / steps * 1e3, steps / el))
+    print("(c) %d streams / replicas, one thread: %.3f ms per step (host returned after %.3f) = %.1f sweeps/s" % (
+        F, el / steps * 1e3, t_enq / steps * 1e3, steps / el))
     print("      " + ahead_stats(wls[0], reset=True))
 for w in wls:
     w.close()
