@@ -153,7 +153,8 @@ int state_init(RunState &S, const df3d_layer *layers, int nlayers, const int32_t
     if (!flagged || (L.reserved & 4) || li == nlayers - 1) S.need_f32[li] = 1;
     if (L.residual >= 0 && L.residual < nlayers) S.need_f32[L.residual] = 1;
     const bool split_consumer = L.packed && !(L.reserved & 2) && !(L.reserved & 1) &&
-                                df3d_conv_packed_weight_bytes(kvol_of(L.ksize), L.cin, L.cout) != 0;
+                                ((L.reserved & 8) ? df3d_conv_packed_weight_bytes3(kvol_of(L.ksize), L.cin, L.cout) != 0
+                                                  : df3d_conv_packed_weight_bytes(kvol_of(L.ksize), L.cin, L.cout) != 0);
     if (L.input >= 0 && L.input < nlayers && !split_consumer) S.need_f32[L.input] = 1;
   }
   return DF3D_OK;
@@ -300,7 +301,9 @@ int conv_layer(RunState &S, int li, const float *features, df3d_layer_view *view
   }
   DF3D_CHECK_ARG(L.input < 0 || S.outs[L.input].ran, "backbone_run: layer %d reads a geometry-only layer", li);
   o.ran = true;
-  const bool split_layer = L.packed && !(L.reserved & 2) && df3d_conv_packed_weight_bytes(K, L.cin, L.cout) != 0;
+  const bool split_layer = L.packed && !(L.reserved & 2) &&
+                           ((L.reserved & 8) ? df3d_conv_packed_weight_bytes3(K, L.cin, L.cout) != 0
+                                             : df3d_conv_packed_weight_bytes(K, L.cin, L.cout) != 0);
   if (S.need_f32[li] || !split_layer) {
     o.features = (float *)mem.take((size_t)n_out * L.cout * 4);
     if (!o.features) return DF3D_ENOMEM;
@@ -335,6 +338,21 @@ int conv_layer(RunState &S, int li, const float *features, df3d_layer_view *view
     int rc = df3d_sparse_conv_bf16(*in16, n_in, L.cin, L.packed, K, L.cout, nbr, n_out, L.bias, L.scale, L.shift, res16,
                                    L.relu, o.features, o.rows16, stream_);
     if (rc) return rc;
+  } else if (L.packed && (L.reserved & 8)) {     // three-part operands ("split3" precision)
+    DF3D_CHECK_ARG(df3d_conv_packed_weight_bytes3(K, L.cin, L.cout) != 0,
+                   "backbone_run: layer %d has no three-part kernel (K=%d cin=%d cout=%d)", li, K, L.cin, L.cout);
+    void **in3 = L.input < 0 ? &S.split0 : &S.outs[L.input].split;
+    if (!*in3) {
+      *in3 = mem.take((size_t)n_in * L.cin * 6);
+      if (!*in3) return DF3D_ENOMEM;
+      int rc = df3d_split_rows3(in_feat, n_in, L.cin, *in3, stream_);
+      if (rc) return rc;
+    }
+    o.split = mem.take((size_t)n_out * L.cout * 6);
+    if (!o.split) return DF3D_ENOMEM;
+    int rc = df3d_conv_rows_split3(*in3, n_in, L.cin, L.cin, 0, L.packed, K, L.cout, 1, nbr, n_out, L.bias, L.scale, L.shift,
+                                   res, L.relu, o.features, L.cout, nullptr, o.split, stream_);
+    if (rc) return rc;
   } else if (L.packed && df3d_conv_packed_weight_bytes(K, L.cin, L.cout) != 0) {
     void **in_split = L.input < 0 ? &S.split0 : &S.outs[L.input].split;
     if (!*in_split) {
@@ -355,7 +373,7 @@ int conv_layer(RunState &S, int li, const float *features, df3d_layer_view *view
   }
   v.features = o.features;
   v.split = o.split ? o.split : o.rows16;      // reserved bit 1 tells the caller which format this is
-  v.reserved = o.rows16 && !o.split ? 2 : 0;
+  v.reserved = o.rows16 && !o.split ? 2 : ((L.reserved & 8) && o.split ? 4 : 0);
   return DF3D_OK;
 }
 

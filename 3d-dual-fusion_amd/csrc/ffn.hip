@@ -372,7 +372,20 @@ static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, int d_
   // MFMAs, and the LDS pipe (128 KB of fragment reads per step and CU with one row tile: 1024 clocks against 768 of MFMAs) is
   // what bounds this kernel: 2 x 31134 rows 122 -> 104 us
   static const int cfg_env = getenv("DF3D_FFN_CFG") ? atoi(getenv("DF3D_FFN_CFG")) : 0;
-  const int cfg = cfg_env ? cfg_env : ((long long)cdiv(max_rows, 256) * njobs >= 160 ? 82 : 81);
+  // Round 4: a 256-row workgroup keeps the matrix and LDS pipes of a CU busy by itself; TWO of them on one CU (registers and
+  // the 32 KB of LDS allow it) each run at half speed, and the launch takes twice as long as with one per CU.  That happened
+  // (a) by count -- 260 workgroups on 256 CUs: 186 us instead of 103 (profiles/r04_start_pmc_by_kernel.json) -- and (b) by
+  // placement, whenever another stream's kernels held some CUs at dispatch time and the dispatcher doubled up elsewhere
+  // (178 us with 240 workgroups).  (a): more workgroups than CUs -> 128-row workgroups (two per CU share it evenly);
+  // (b): the 256-row configuration reserves enough LDS that a second one does not fit beside it (DF3D_FFN_PAD=0: off).
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t prop;
+    ncu = (hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const long long wg82 = (long long)cdiv(max_rows, 256) * njobs;
+  static const bool balance = !(getenv("DF3D_FFN_PAD") && getenv("DF3D_FFN_PAD")[0] == '0');
+  const int cfg = cfg_env ? cfg_env : (wg82 >= 160 && !(balance && wg82 > ncu) ? 82 : 81);
   if (jobs.s[0].bf16) {                          // every job of a launch shares the precision mode
     // one product per operand pair: the kernel is bound by the 1 MB weight stream every workgroup pulls from L2, so many
     // rows take two row tiles per wave (half the stream per row); DF3D_FFN_CFG=81 keeps one
@@ -384,7 +397,19 @@ static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, int d_
     return DF3D_OK;
   }
   if (cfg == 42) hipLaunchKernelGGL((ffn_split_kernel<4, 2>), dim3(cdiv(max_rows, 128), njobs), dim3(256), 0, stream, jobs);
-  else if (cfg == 82) hipLaunchKernelGGL((ffn_split_kernel<8, 2>), dim3(cdiv(max_rows, 256), njobs), dim3(512), 0, stream, jobs);
+  else if (cfg == 82) {
+    size_t pad = 0;
+    if (balance && wg82 <= ncu) {
+      pad = 52 * 1024;                          // 32 KB static + 52 KB > half of the CU's 160 KB
+      static bool attr = false;
+      if (!attr) {
+        attr = hipFuncSetAttribute((const void *)ffn_split_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)pad) == hipSuccess;
+        if (!attr) pad = 0;
+      }
+    }
+    hipLaunchKernelGGL((ffn_split_kernel<8, 2>), dim3(cdiv(max_rows, 256), njobs), dim3(512), pad, stream, jobs);
+  }
   else if (cfg == 41) hipLaunchKernelGGL((ffn_split_kernel<4, 1>), dim3(cdiv(max_rows, 64), njobs), dim3(256), 0, stream, jobs);
   else hipLaunchKernelGGL((ffn_split_kernel<8, 1>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
   DF3D_LAUNCH_CHECK();

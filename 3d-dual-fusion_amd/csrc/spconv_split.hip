@@ -46,6 +46,28 @@ __device__ __forceinline__ void split2(float x, unsigned &hi, unsigned &lo) {
   lo = bf16_bits(x - __uint_as_float(hi << 16));
 }
 
+// three-way split (round 4, "split3" precision): x = hi + mid + lo EXACTLY for finite normal x (8 + 8 + 8 significand bits),
+// every part a bf16 number; pairs packed like split_pair
+__device__ __forceinline__ void split3_pair_ref(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+  unsigned h, m;
+  split_pair(x0, x1, h, m);                                        // h = bf16(x), m = bf16(x - h)
+  const float r0 = (x0 - __uint_as_float(h << 16)) - __uint_as_float(m << 16);
+  const float r1 = (x1 - __uint_as_float(h & 0xffff0000u)) - __uint_as_float(m & 0xffff0000u);
+  unsigned l, unused;
+  split_pair(r0, r1, l, unused);
+  hi = h, mid = m, lo = l;
+}
+
+// (outputs may be vector elements, which cannot bind to references)
+#define split3_pair(x0, x1, HI, MID, LO)                         \
+  do {                                                           \
+    unsigned s3_h__, s3_m__, s3_l__;                             \
+    df3d::split3_pair_ref(x0, x1, s3_h__, s3_m__, s3_l__);       \
+    (HI) = s3_h__;                                               \
+    (MID) = s3_m__;                                              \
+    (LO) = s3_l__;                                               \
+  } while (0)
+
 __device__ __forceinline__ float bf16lo_to_f32(unsigned packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(unsigned packed) { return __uint_as_float(packed & 0xffff0000u); }
 
@@ -112,6 +134,48 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
   split_pair(b[2], b[3], ho[3], lo[3]);
   out[2 * i] = ho;
   out[2 * i + 1] = lo;
+}
+
+// fp32 rows -> three-part rows [n][C/8][hi 8 x bf16 | mid | lo] (48 B per 8 channels)
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restrict__ x, size_t nblk, u32x4 *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblk) return;
+  f32x4 a = ((const f32x4 *)x)[2 * i], b = ((const f32x4 *)x)[2 * i + 1];
+  u32x4 ho, mo, lo;
+  split3_pair(a[0], a[1], ho[0], mo[0], lo[0]);
+  split3_pair(a[2], a[3], ho[1], mo[1], lo[1]);
+  split3_pair(b[0], b[1], ho[2], mo[2], lo[2]);
+  split3_pair(b[2], b[3], ho[3], mo[3], lo[3]);
+  out[3 * i] = ho;
+  out[3 * i + 1] = mo;
+  out[3 * i + 2] = lo;
+}
+
+// W -> packed B operands of the output-stationary kernel with THREE parts: [half][k][kb][ct][hi|mid|lo][lane] (layout 1)
+__global__ __launch_bounds__(256) void pack_weights3_kernel(const float *__restrict__ w, int K, int cin, int cout,
+                                                            u32x4 *__restrict__ out) {
+  const int KB = cin / 32;
+  size_t total = (size_t)K * cin * cout / 8 * 3;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lane = (int)(i & 63);
+  size_t r = i >> 6;
+  int part = (int)(r % 3); r /= 3;
+  int n = lane & 15, g = lane >> 4;
+  const int CW = cout > 128 ? 128 : cout, CT = CW / 16;
+  int ct = (int)(r % CT); r /= CT;
+  int kb = (int)(r % KB); r /= KB;
+  int k = (int)(r % K);
+  int col = (int)(r / K) * CW + n * CT + ct;
+  int ch0 = kb * 32 + g * 8;
+  unsigned v[8];
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    unsigned h, m, l;
+    split3_pair(w[((size_t)k * cin + ch0 + e) * cout + col], w[((size_t)k * cin + ch0 + e + 1) * cout + col], h, m, l);
+    v[e >> 1] = part == 0 ? h : (part == 1 ? m : l);
+  }
+  out[i] = (u32x4){v[0], v[1], v[2], v[3]};
 }
 
 // ---- W[K][CIN][COUT] fp32 -> packed B operands -----------------------------------------------------------
@@ -533,7 +597,7 @@ struct StepCursor {
 
 // rows without a neighbour gather this all-zero split row (keeps the gathers branch-free, so that the
 // compiler can count its vmcnt waits instead of draining the whole load queue at every step)
-__device__ u32x4 g_zero_row[128];          // up to 512 input channels
+__device__ u32x4 g_zero_row[192];          // up to 512 input channels, three parts
 
 // ---------------------------------------------------------------------------------------------------------
 // Output-stationary variant: a wave owns 16*RT output rows and all COUT columns, accumulators in registers,
@@ -768,6 +832,30 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 #pragma unroll
         for (int q = 0; q < 2 * NP; ++q) bq[(i + 1) & 1][q] = wb[((i + 1) * 2 * NP + q) * 64];
       }
+      if constexpr (NP == 3) {
+        // six products per operand pair, smallest terms first: (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi);
+        // the dropped ones are <= 2^-24 of the product
+        const u32x4 *bp = bq[i & 1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const u32x4 a0 = cur[rt][j][0], a1 = cur[rt][j][1], a2 = cur[rt][j][2];
+          f32x4 c0 = acc[rt][c2], c1 = acc[rt][c2 + 1];
+          c0 = DF3D_MFMA_BF16(a2, bp[0], c0);
+          c1 = DF3D_MFMA_BF16(a2, bp[3], c1);
+          c0 = DF3D_MFMA_BF16(a1, bp[1], c0);
+          c1 = DF3D_MFMA_BF16(a1, bp[4], c1);
+          c0 = DF3D_MFMA_BF16(a0, bp[2], c0);
+          c1 = DF3D_MFMA_BF16(a0, bp[5], c1);
+          c0 = DF3D_MFMA_BF16(a1, bp[0], c0);
+          c1 = DF3D_MFMA_BF16(a1, bp[3], c1);
+          c0 = DF3D_MFMA_BF16(a0, bp[1], c0);
+          c1 = DF3D_MFMA_BF16(a0, bp[4], c1);
+          c0 = DF3D_MFMA_BF16(a0, bp[0], c0);
+          c1 = DF3D_MFMA_BF16(a0, bp[3], c1);
+          acc[rt][c2] = c0, acc[rt][c2 + 1] = c1;
+        }
+        continue;
+      }
       if constexpr (NP == 1) {
         const u32x4 b0 = bq[i & 1][0], b1 = bq[i & 1][1];
 #pragma unroll
@@ -777,7 +865,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         }
         continue;
       }
-      u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][NP == 2 ? 1 : 0], bh1 = bq[i & 1][NP == 2 ? 2 : 0], bl1 = bq[i & 1][NP == 2 ? 3 : 0];
+      u32x4 bh0 = bq[i & 1][0], bl0 = bq[i & 1][NP >= 2 ? 1 : 0], bh1 = bq[i & 1][NP >= 2 ? 2 : 0], bl1 = bq[i & 1][NP >= 2 ? 3 : 0];
       if (OS_DBG(16)) {                    // experiment: MFMAs without the LDS reads of their B operands
         bh0 = cur[0][j][0];
         bl0 = cur[0][j][NP - 1];
@@ -890,6 +978,15 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         }
         if (a.out) *(float2 *)(a.out + o) = v;
         if (a.out_split) {
+          if constexpr (NP == 3) {
+            unsigned hp, mp, lp;
+            split3_pair(v.x, v.y, hp, mp, lp);
+            char *blk = (char *)a.out_split + (o >> 3) * 48 + (n & 3) * 4;   // 8-channel block = [hi | mid | lo] 16 B each
+            *(unsigned *)blk = hp;
+            *(unsigned *)(blk + 16) = mp;
+            *(unsigned *)(blk + 32) = lp;
+            continue;
+          }
           unsigned hp, lp;
           split_pair(v.x, v.y, hp, lp);
           if constexpr (NP == 1) {
@@ -921,7 +1018,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
       if (row >= a.n_out) continue;
       if (OS_DBG(32) && acc[rt][0][r] != 1234.567f) continue;      // experiment: no output stores
       const size_t o = (size_t)row * a.ldo + col0 + n * CT;
-      unsigned h[CT / 2], l[CT / 2];         // packed pairs
+      unsigned h[CT / 2], l[CT / 2], m3[CT / 2];         // packed pairs
 #pragma unroll
       for (int q = 0; q < CT / 4; ++q) {
         f32x4 v = (f32x4){acc[rt][q * 4][r], acc[rt][q * 4 + 1][r], acc[rt][q * 4 + 2][r], acc[rt][q * 4 + 3][r]};
@@ -942,9 +1039,30 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
         }
         if (a.out) *(f32x4 *)(a.out + o + q * 4) = v;
         if (a.out_split) {
-          split_pair(v[0], v[1], h[q * 2], l[q * 2]);
-          split_pair(v[2], v[3], h[q * 2 + 1], l[q * 2 + 1]);
+          if constexpr (NP == 3) {
+            split3_pair(v[0], v[1], h[q * 2], m3[q * 2], l[q * 2]);
+            split3_pair(v[2], v[3], h[q * 2 + 1], m3[q * 2 + 1], l[q * 2 + 1]);
+          } else {
+            split_pair(v[0], v[1], h[q * 2], l[q * 2]);
+            split_pair(v[2], v[3], h[q * 2 + 1], l[q * 2 + 1]);
+          }
         }
+      }
+      if constexpr (NP == 3) {
+        if (a.out_split) {
+          char *blk = (char *)a.out_split + (o >> 3) * 48;            // 8-channel block = [hi | mid | lo] 16 B each
+          if constexpr (CT == 8) {
+            *(u32x4 *)blk = (u32x4){h[0], h[1], h[2], h[3]};
+            *(u32x4 *)(blk + 16) = (u32x4){m3[0], m3[1], m3[2], m3[3]};
+            *(u32x4 *)(blk + 32) = (u32x4){l[0], l[1], l[2], l[3]};
+          } else {
+            blk += (n & 1) * 8;
+            *(u32x2 *)blk = (u32x2){h[0], h[1]};
+            *(u32x2 *)(blk + 16) = (u32x2){m3[0], m3[1]};
+            *(u32x2 *)(blk + 32) = (u32x2){l[0], l[1]};
+          }
+        }
+        continue;
       }
       if (a.out_split && NP == 1) {                                   // bf16 rows: this lane's CT columns
         char *dst = (char *)a.out_split + o * 2;
@@ -1557,9 +1675,108 @@ static int launch_os_any(int cin, int cout, const SplitConvArgs &a, hipStream_t 
   return DF3D_EINVAL;
 }
 
+// three-part operands (NP = 3, six products): one configuration per shape -- 8 waves per workgroup on the large maps, 4 / 2 on
+// the small ones (the same rule as the bf16 launches); the loader / consumer kernel has no three-part form
+template <int CIN, int COUT>
+static int launch_os_p3(const SplitConvArgs &a, hipStream_t stream) {
+  const long long work = (long long)a.n_out * a.gy;
+  if (work >= 32 * 1024)
+    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 8, 1, 3>), dim3(cdiv(a.n_out, 128), a.gy), dim3(512), 0, stream, a);
+  else if (work >= 12 * 1024)
+    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 4, 1, 3>), dim3(cdiv(a.n_out, 64), a.gy), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 2, 1, 3>), dim3(cdiv(a.n_out, 32), a.gy), dim3(128), 0, stream, a);
+  return DF3D_OK;
+}
+
+static int launch_os_p3_any(int cin, int cout, const SplitConvArgs &a, hipStream_t stream) {
+  if (cin == 256 && cout == 256) return launch_os_p3<256, 256>(a, stream);
+  if (cin == 256 && cout == 128) return launch_os_p3<256, 128>(a, stream);
+  if (cin == 128 && cout == 256) return launch_os_p3<128, 256>(a, stream);
+  if (cin == 512 && cout == 64) return launch_os_p3<512, 64>(a, stream);
+  if (cin == 512 && cout == 128) return launch_os_p3<512, 128>(a, stream);
+  if (cin == 128 && cout == 32) return launch_os_p3<128, 32>(a, stream);
+  if (cin == 128 && cout == 64) return launch_os_p3<128, 64>(a, stream);
+  if (cin == 128 && cout == 128) return launch_os_p3<128, 128>(a, stream);
+  if (cin == 64 && cout == 128) return launch_os_p3<64, 128>(a, stream);
+  if (cin == 64 && cout == 64) return launch_os_p3<64, 64>(a, stream);
+  if (cin == 32 && cout == 64) return launch_os_p3<32, 64>(a, stream);
+  if (cin == 64 && cout == 32) return launch_os_p3<64, 32>(a, stream);
+  if (cin == 32 && cout == 32) return launch_os_p3<32, 32>(a, stream);
+  set_error("no three-part split kernel for cin=%d cout=%d", cin, cout);
+  return DF3D_EINVAL;
+}
+
 }  // namespace df3d
 
 using namespace df3d;
+
+// ---- "split3" precision (round 4): operands as THREE bf16 parts (hi + mid + lo = the fp32 value exactly), six MFMA products
+//      per operand pair, fp32 accumulate: fp32-grade results (dropped terms <= 2^-24 of a product) at 1/6 of the bf16 rate --
+//      2.6x the fp32 matrix rate.  Same shapes as the output-stationary split kernels. ----
+extern "C" size_t df3d_conv_packed_weight_bytes3(int kvol, int cin, int cout) {
+  if (!split_shape_ok(cin, cout) || split_layout(cin, cout) != 1 || kvol <= 0 || kvol > DF3D_MAX_KVOL) return 0;
+  return (size_t)kvol * cin * cout * 6;
+}
+
+extern "C" int df3d_conv_pack_weights3(const float *filters, int groups, int kvol, int cin, int cout, void *packed, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(filters && packed && groups >= 1, "conv_pack_weights3: bad argument");
+  DF3D_CHECK_ARG(df3d_conv_packed_weight_bytes3(kvol, cin, cout) != 0 && (groups == 1 || cout <= 128),
+                 "conv_pack_weights3: shape K=%d cin=%d cout=%d has no three-part kernel", kvol, cin, cout);
+  // (G filter banks back to back are one bank of G * K offsets, as in df3d_conv_pack_weights_groups)
+  size_t total = (size_t)groups * kvol * cin * cout / 8 * 3;
+  hipLaunchKernelGGL(pack_weights3_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, stream, filters, groups * kvol, cin,
+                     cout, (u32x4 *)packed);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_split_rows3(const float *features, long long n, int c, void *split3, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(features && split3, "split_rows3: null argument");
+  DF3D_CHECK_ARG(c > 0 && c % 8 == 0 && n >= 0, "split_rows3: channels must be a multiple of 8 (got %d)", c);
+  size_t nblk = (size_t)n * c / 8;
+  if (nblk == 0) return DF3D_OK;
+  hipLaunchKernelGGL(split3_rows_kernel, dim3(cdiv((long long)nblk, 256)), dim3(256), 0, stream, features, nblk, (u32x4 *)split3);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+// df3d_conv_rows_split on three-part rows / filters (in_split3 rows of in_channels * 6 bytes; out_split3 likewise); with
+// groups = 1, in_group_stride = 0 and out_channels = cout it is the sparse convolution itself; `residual` fp32 rows or NULL
+extern "C" int df3d_conv_rows_split3(const void *in_split3, int n_in, int in_channels, int cin, int in_group_stride,
+                                     const void *packed3, int kvol, int cout, int groups, const int32_t *nbr, int n_out,
+                                     const float *bias, const float *scale, const float *shift, const float *residual,
+                                     int relu, float *out, int out_channels, const int32_t *out_cols, void *out_split3,
+                                     void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(in_split3 && packed3 && nbr && (out || out_split3), "conv_rows_split3: null argument");
+  DF3D_CHECK_ARG(df3d_conv_packed_weight_bytes3(kvol, cin, cout) != 0, "conv_rows_split3: K=%d cin=%d cout=%d has no three-part kernel",
+                 kvol, cin, cout);
+  DF3D_CHECK_ARG(groups >= 1 && groups <= 65535, "conv_rows_split3: groups");
+  DF3D_CHECK_ARG(in_channels % 8 == 0 && in_group_stride % 8 == 0 && in_group_stride >= 0 &&
+                     (long long)(groups - 1) * in_group_stride + cin <= in_channels,
+                 "conv_rows_split3: input columns of the groups must lie inside the %d-channel rows", in_channels);
+  DF3D_CHECK_ARG(!residual || (groups == 1 && out_channels == cout), "conv_rows_split3: a residual needs one group and dense output rows");
+  const int blocks = groups * (cout > 128 ? cout / 128 : 1);
+  if (out_cols) {
+    DF3D_CHECK_ARG(cout == 32 && !out_split3, "conv_rows_split3: compact output columns need cout = 32 and no split output");
+  } else {
+    DF3D_CHECK_ARG(out_channels % 8 == 0 && (long long)groups * cout <= out_channels,
+                   "conv_rows_split3: %d x %d output columns do not fit %d-channel rows", groups, cout, out_channels);
+  }
+  if (n_out == 0) return DF3D_OK;
+  SplitConvArgs a = {(const u32x4 *)in_split3, (const u32x4 *)packed3, nbr, bias, scale, shift, residual,
+                     out, (u32x4 *)out_split3, n_in, n_out, kvol, relu, 0,
+                     in_channels / 8 * 3, in_group_stride / 8 * 3, out_channels, blocks, out_cols};
+  int rec = timing_rec_begin(cin, cout * groups, kvol, n_out, nbr, 3, stream);
+  int rc = launch_os_p3_any(cin, cout, a, stream);
+  if (rc) return rc;
+  timing_rec_end(rec, stream);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
 
 extern "C" size_t df3d_conv_packed_weight_bytes(int kvol, int cin, int cout) {
   if (!split_shape_ok(cin, cout) || kvol <= 0 || kvol > DF3D_MAX_KVOL) return 0;

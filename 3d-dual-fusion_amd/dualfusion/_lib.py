@@ -129,6 +129,12 @@ SIGNATURES = {
                                               c_void_p]),
     "df3d_conv_rows_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_conv_packed_weight_bytes3": (c_size_t, [c_int, c_int, c_int]),
+    "df3d_conv_pack_weights3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_split_rows3": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p]),
+    "df3d_conv_rows_split3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                      c_void_p]),
     "df3d_boxes_bev_pairwise": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "df3d_nms_bev_workspace_bytes": (c_size_t, [c_int, c_int]),
     "df3d_nms_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -187,6 +187,8 @@ class BackbonePlan(object):
                 p = c._packed_weight(c.weight.detach(), K)
                 keep.append(p)
                 L.packed = p.data_ptr()
+                if _ops.CONV_PRECISION == "split3":
+                    L.reserved |= 8                  # three-part rows / filters
             if c.bias is not None:
                 L.bias = c.bias.detach().data_ptr()
             if s.bn is not None:
@@ -281,7 +283,8 @@ class BackbonePlan(object):
             if features and v.split and (v.reserved & 2):
                 t._bf16 = (f, view(v.split, v.n * v.channels * 2, torch.bfloat16, (v.n, v.channels)))
             elif features and v.split:
-                t._split = (f, view(v.split, v.n * v.channels * 4, torch.uint8, (v.n, v.channels * 4)))
+                pb = 6 if (v.reserved & 4) else 4
+                t._split = (f, view(v.split, v.n * v.channels * pb, torch.uint8, (v.n, v.channels * pb)))
             if v.grid and v.rows_sorted:
                 # the occupancy directory the executor built is handed to the module path (e.g. a conv that runs
                 # after a fusion step): SparseConvTensor.directory() finds it by the identity of `indices`

@@ -259,7 +259,7 @@ class CenterHead(nn.Module):
         return scale, bn.bias.float() - bn.running_mean.float() * scale
 
     def _plan(self):
-        key = tuple((p.data_ptr(), p._version) for p in self._state_tensors())
+        key = tuple((p.data_ptr(), p._version) for p in self._state_tensors()) + (_ops.split_parts(),)
         plan = self.__dict__.get("_row_plan")
         if plan is not None and plan["key"] == key:
             return plan
@@ -367,7 +367,8 @@ class CenterHead(nn.Module):
         plan = self._plan()
         B, _, H, W = x.shape
         rows, split = _rows_of(x)
-        if split is None or split.dtype != torch.uint8:     # no hi/lo rows cached (bf16 mode of the neck caches bf16 rows)
+        if (split is None or split.dtype != torch.uint8     # no hi/lo rows cached (bf16 mode of the neck caches bf16 rows)
+                or split.shape[1] != _ops.split_width(rows.shape[1])):
             split = _ops.split_rows(rows.contiguous())
         if (B, H, W) not in plan["nbr"]:
             plan["nbr"][(B, H, W)] = _ops.conv2d_neighbors(B, H, W, 3, 3, 1, 1, False, x.device)[0]
@@ -379,7 +380,8 @@ class CenterHead(nn.Module):
         _, s2 = _ops.conv_rows_split(s1, 64, 0, plan["mid"], 64 * plan["mid_pair"], G // plan["mid_pair"], nbr, n,
                                      plan["mid_bias"], plan["mid_scale"], plan["mid_shift"], relu=True, want_out=False,
                                      want_split=True)
-        if plan["fin_w4"] is not None and os.environ.get("DF3D_HEAD_FINAL", "valu") == "valu":
+        if (plan["fin_w4"] is not None and os.environ.get("DF3D_HEAD_FINAL", "valu") == "valu"
+                and _ops.CONV_PRECISION != "split3"):       # (csrc/headconv.hip reads two-part rows)
             # 72 output maps of 36 branches in one launch of csrc/headconv.hip (round 3: the taps are COLUMNS of a matrix-core
             # product over each halo pixel's 64 channels, the shifted sum runs through LDS; every activation read 1.3x)
             # instead of a block-diagonal matrix-core launch padded to 32 columns per branch

@@ -289,7 +289,7 @@ class RPN(nn.Module):
                     nbr, uh, uw = self._table(layer, pad, B, uh, uw, tables, x.device)
                     if cat_rows is None:
                         cat_rows = torch.empty((nbr.shape[1], cat), dtype=torch.float32, device=x.device)
-                        cat_split = torch.empty((nbr.shape[1], 4 * cat), dtype=torch.uint8, device=x.device)
+                        cat_split = torch.empty((nbr.shape[1], _ops.split_width(cat)), dtype=torch.uint8, device=x.device)
                     K, cin, cout = layer.filters.shape
                     _ops.conv_rows_split(us if us is not None else _ops.split_rows(u), cin, 0, layer.packed, cout, 1, nbr,
                                          nbr.shape[1], layer.bias, layer.scale, layer.shift, layer.relu,

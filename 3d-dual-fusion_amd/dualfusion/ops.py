@@ -432,10 +432,26 @@ def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shif
 # ---- split-precision convolution (csrc/spconv_split.hip) --------------------------------------------------
 # "split": C >= 64 layers run on the bf16 matrix cores with hi/lo-split fp32 operands (~1e-5 relative error);
 # "fp32":  every layer on the exact fp32 MFMA kernels (csrc/spconv.hip).  DF3D_CONV_PRECISION overrides.
+# "split3": the same layers with operands in THREE bf16 parts (hi + mid + lo = the fp32 value exactly) and six products:
+#          fp32-grade results (~1e-7) at 2.6x the fp32 matrix rate.  The functions below (`split_rows`, `conv_pack_weights`,
+#          `sparse_conv_split`, `conv_rows_split`) then produce / consume three-part buffers: their callers treat split rows
+#          and packed filters as opaque, so the sparse backbone, the BEV neck and the head run on it unchanged.
 CONV_PRECISION = os.environ.get("DF3D_CONV_PRECISION", "split")
 
 
+def split_parts():
+    """bf16 parts per value of the split rows / packed filters of the current precision mode."""
+    return 3 if CONV_PRECISION == "split3" else 2
+
+
+def split_width(channels):
+    """Bytes per row of the split rows of a `channels`-wide map in the current precision mode."""
+    return 2 * split_parts() * int(channels)
+
+
 def conv_split_supported(kvol, cin, cout):
+    if CONV_PRECISION == "split3":
+        return _lib.load().df3d_conv_packed_weight_bytes3(int(kvol), int(cin), int(cout)) > 0
     if CONV_PRECISION != "split":
         return False
     return _lib.load().df3d_conv_packed_weight_bytes(int(kvol), int(cin), int(cout)) > 0
@@ -446,6 +462,13 @@ def conv_pack_weights(filters):
     lib = _lib.load()
     _chk(filters, torch.float32, "filters")
     K, cin, cout = filters.shape
+    if CONV_PRECISION == "split3":
+        nbytes = lib.df3d_conv_packed_weight_bytes3(K, cin, cout)
+        if nbytes == 0:
+            raise _lib.Df3dError("no three-part kernel for K=%d cin=%d cout=%d" % (K, cin, cout))
+        packed = torch.empty((nbytes,), dtype=torch.uint8, device=filters.device)
+        _lib.check(lib.df3d_conv_pack_weights3(_ptr(filters), 1, K, cin, cout, _ptr(packed), _stream()), "df3d_conv_pack_weights3")
+        return packed
     nbytes = lib.df3d_conv_packed_weight_bytes(K, cin, cout)
     if nbytes == 0:
         raise _lib.Df3dError("no split-precision kernel for K=%d cin=%d cout=%d" % (K, cin, cout))
@@ -460,6 +483,13 @@ def conv_pack_weights_groups(filters):
     lib = _lib.load()
     _chk(filters, torch.float32, "filters")
     G, K, cin, cout = filters.shape
+    if CONV_PRECISION == "split3":
+        nbytes = lib.df3d_conv_packed_weight_bytes3(K, cin, cout)
+        if nbytes == 0 or cout > 128:
+            raise _lib.Df3dError("no grouped three-part kernel for K=%d cin=%d cout=%d" % (K, cin, cout))
+        packed = torch.empty((G * nbytes,), dtype=torch.uint8, device=filters.device)
+        _lib.check(lib.df3d_conv_pack_weights3(_ptr(filters), G, K, cin, cout, _ptr(packed), _stream()), "df3d_conv_pack_weights3")
+        return packed
     nbytes = lib.df3d_conv_packed_weight_bytes(K, cin, cout)
     if nbytes == 0 or cout > 128:
         raise _lib.Df3dError("no grouped split-precision kernel for K=%d cin=%d cout=%d" % (K, cin, cout))
@@ -474,6 +504,10 @@ def split_rows(features):
     lib = _lib.load()
     _chk(features, torch.float32, "features")
     n, c = features.shape
+    if CONV_PRECISION == "split3":
+        out = torch.empty((n, 6 * c), dtype=torch.uint8, device=features.device)
+        _lib.check(lib.df3d_split_rows3(_ptr(features), n, c, _ptr(out), _stream()), "df3d_split_rows3")
+        return out
     out = torch.empty((n, 4 * c), dtype=torch.uint8, device=features.device)
     rc = lib.df3d_split_rows(_ptr(features), n, c, _ptr(out), _stream())
     _lib.check(rc, "df3d_split_rows")
@@ -490,12 +524,20 @@ def sparse_conv_split(features_split, packed, nbr, n_out, cin, cout, bias=None, 
     _chk(nbr, torch.int32, "nbr")
     n_in = features_split.shape[0]
     K = nbr.shape[0]
-    if features_split.shape[1] != 4 * cin or packed.numel() != K * cin * cout * 4:
-        raise _lib.Df3dError("split operands do not match K=%d cin=%d cout=%d" % (K, cin, cout))
+    pb = 2 * split_parts()
+    if features_split.shape[1] != pb * cin or packed.numel() != K * cin * cout * pb:
+        raise _lib.Df3dError("split operands do not match K=%d cin=%d cout=%d (%d parts)" % (K, cin, cout, split_parts()))
     for t, nm in ((bias, "bias"), (scale, "scale"), (shift, "shift"), (residual, "residual")):
         if t is not None:
             _chk(t, torch.float32, nm)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=nbr.device)
+    if CONV_PRECISION == "split3":
+        out_split = torch.empty((n_out, 6 * cout), dtype=torch.uint8, device=nbr.device) if emit_split else None
+        rc = lib.df3d_conv_rows_split3(_ptr(features_split), n_in, cin, cin, 0, _ptr(packed), K, cout, 1, _ptr(nbr), n_out,
+                                       _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out), cout,
+                                       None, _ptr(out_split), _stream())
+        _lib.check(rc, "df3d_conv_rows_split3")
+        return out, out_split
     out_split = torch.empty((n_out, 4 * cout), dtype=torch.uint8, device=nbr.device) if emit_split else None
     rc = lib.df3d_sparse_conv_split(_ptr(features_split), n_in, cin, _ptr(packed), K, cout, _ptr(nbr), n_out,
                                     _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out),
@@ -631,33 +673,45 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=
 
 def conv_rows_split(in_split, cin, in_group_stride, packed, cout, groups, nbr, n_out, bias=None, scale=None, shift=None,
                     relu=False, out_channels=None, out_cols=None, want_out=True, want_split=False, into=None):
-    """Grouped / multi-head convolution over split rows (df3d_conv_rows_split).  in_split [n_in, 4*in_channels] uint8.
+    """Grouped / multi-head convolution over split rows (df3d_conv_rows_split; df3d_conv_rows_split3 in the "split3" mode).
+    in_split [n_in, pb * in_channels] uint8 with pb = 4 (two parts) or 6 (three parts) bytes per channel.
     Returns (out fp32 [n_out, out_channels] or None, split rows of it or None).
-    into = (rows fp32 [n_out, C] or None, split rows uint8 [n_out, 4*C] or None, col0): write the groups * cout output
+    into = (rows fp32 [n_out, C] or None, split rows uint8 [n_out, pb*C] or None, col0): write the groups * cout output
     columns at col0 of these wider rows instead of allocating (a concatenation without the copy); returns them."""
     lib = _lib.load()
     _chk(in_split, torch.uint8, "in_split")
     _chk(packed, torch.uint8, "packed")
     _chk(nbr, torch.int32, "nbr")
-    n_in, in_channels = in_split.shape[0], in_split.shape[1] // 4
+    p3 = CONV_PRECISION == "split3"
+    pb = 6 if p3 else 4
+    n_in, in_channels = in_split.shape[0], in_split.shape[1] // pb
     K = nbr.shape[0]
-    if packed.numel() != groups * K * cin * cout * 4:
-        raise _lib.Df3dError("packed filters do not match groups=%d K=%d cin=%d cout=%d" % (groups, K, cin, cout))
+    if packed.numel() != groups * K * cin * cout * pb or in_split.shape[1] != pb * in_channels:
+        raise _lib.Df3dError("packed filters do not match groups=%d K=%d cin=%d cout=%d (%d parts)" % (groups, K, cin, cout, pb // 2))
     for t, nm in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
         if t is not None:
             _chk(t, torch.float32, nm)
-            if t.numel() != groups * cout:
-                raise _lib.Df3dError("%s must have groups * cout = %d entries" % (nm, groups * cout))
-    if out_cols is not None:
-        _chk(out_cols, torch.int32, "out_cols")
-    dev = nbr.device
+    dev = in_split.device
+
+    def launch(po, oc, pcols, ps):
+        if p3:
+            rc = lib.df3d_conv_rows_split3(_ptr(in_split), n_in, in_channels, int(cin), int(in_group_stride), _ptr(packed), K,
+                                           int(cout), int(groups), _ptr(nbr), int(n_out), _ptr(bias), _ptr(scale),
+                                           _ptr(shift), None, int(bool(relu)), po, oc, pcols, ps, _stream())
+            _lib.check(rc, "df3d_conv_rows_split3")
+        else:
+            rc = lib.df3d_conv_rows_split(_ptr(in_split), n_in, in_channels, int(cin), int(in_group_stride), _ptr(packed), K,
+                                          int(cout), int(groups), _ptr(nbr), int(n_out), _ptr(bias), _ptr(scale),
+                                          _ptr(shift), int(bool(relu)), po, oc, pcols, ps, _stream())
+            _lib.check(rc, "df3d_conv_rows_split")
+
     if into is not None:
         out, osp, col0 = into
         col0 = int(col0)
         if out_cols is not None or (out is None and osp is None) or col0 % 8:
             raise _lib.Df3dError("conv_rows_split: `into` takes rows and a column offset that is a multiple of 8")
-        oc = out.shape[1] if out is not None else osp.shape[1] // 4
-        for t, dt, w, nm in ((out, torch.float32, oc, "into rows"), (osp, torch.uint8, 4 * oc, "into split rows")):
+        oc = out.shape[1] if out is not None else osp.shape[1] // pb
+        for t, dt, w, nm in ((out, torch.float32, oc, "into rows"), (osp, torch.uint8, pb * oc, "into split rows")):
             if t is not None:
                 _chk(t, dt, nm)
                 if tuple(t.shape) != (n_out, w):
@@ -665,21 +719,15 @@ def conv_rows_split(in_split, cin, in_group_stride, packed, cout, groups, nbr, n
         if col0 + groups * cout > oc:
             raise _lib.Df3dError("conv_rows_split: columns [%d, %d) outside %d-channel rows" % (col0, col0 + groups * cout, oc))
         # the kernel addresses row * oc + group * cout (+ the 128-column block) from the pointers it is given; split rows
-        # hold 4 bytes per channel in 8-channel blocks, so a column offset is a byte offset of 4 * col0 there too
-        po = out.data_ptr() + 4 * col0 if out is not None else None
-        ps = osp.data_ptr() + 4 * col0 if osp is not None else None
-        rc = lib.df3d_conv_rows_split(_ptr(in_split), n_in, in_channels, int(cin), int(in_group_stride), _ptr(packed), K,
-                                      int(cout), int(groups), _ptr(nbr), int(n_out), _ptr(bias), _ptr(scale),
-                                      _ptr(shift), int(bool(relu)), po, oc, None, ps, _stream())
-        _lib.check(rc, "df3d_conv_rows_split")
+        # hold pb bytes per channel in 8-channel blocks, so a column offset is a byte offset of pb * col0 there
+        po = ctypes.c_void_p(out.data_ptr() + 4 * col0) if out is not None else None
+        ps = ctypes.c_void_p(osp.data_ptr() + pb * col0) if osp is not None else None
+        launch(po, oc, None, ps)
         return out, osp
     oc = int(out_channels if out_channels is not None else groups * cout)
     out = torch.empty((n_out, oc), dtype=torch.float32, device=dev) if want_out else None
-    osp = torch.empty((n_out, 4 * oc), dtype=torch.uint8, device=dev) if want_split else None
-    rc = lib.df3d_conv_rows_split(_ptr(in_split), n_in, in_channels, int(cin), int(in_group_stride), _ptr(packed), K,
-                                  int(cout), int(groups), _ptr(nbr), int(n_out), _ptr(bias), _ptr(scale), _ptr(shift),
-                                  int(bool(relu)), _ptr(out), oc, _ptr(out_cols), _ptr(osp), _stream())
-    _lib.check(rc, "df3d_conv_rows_split")
+    osp = torch.empty((n_out, pb * oc), dtype=torch.uint8, device=dev) if want_split else None
+    launch(_ptr(out), oc, _ptr(out_cols), _ptr(osp))
     return out, osp
 
 

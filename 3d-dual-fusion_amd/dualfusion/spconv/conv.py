@@ -283,7 +283,7 @@ class SparseConvolution(SparseModule):
 
     def _packed_weight(self, w, K):
         """hi/lo bf16 MFMA operands of the filter bank, rebuilt only when the parameter changes."""
-        key = (w.data_ptr(), w._version, str(w.device))
+        key = (w.data_ptr(), w._version, str(w.device), _ops.split_parts())
         hit = getattr(self, "_packed", None)
         if hit is None or hit[0] != key:
             hit = (key, _ops.conv_pack_weights(w.contiguous().view(K, self.in_channels, self.out_channels)))

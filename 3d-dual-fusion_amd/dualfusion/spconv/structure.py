@@ -116,7 +116,8 @@ class SparseConvTensor(object):
     def split_features(self):
         """Split rows (bf16 hi | lo) of `features` for the split-precision conv kernels; emitted by the producing
         conv's epilogue when there is one, otherwise computed here once."""
-        if self._split is None or self._split[0] is not self.features:
+        if (self._split is None or self._split[0] is not self.features
+                or self._split[1].shape[1] != _ops.split_width(self.features.shape[1])):      # (another precision mode's rows)
             feats = self.features.contiguous()
             self._split = (self.features, _ops.split_rows(feats))
         return self._split[1]

@@ -276,6 +276,23 @@ int df3d_conv_rows_split(const void *in_split, int n_in, int in_channels, int ci
                          int out_channels, const int32_t *out_cols, void *out_split, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * "split3" precision (round 4): the same convolutions with operands in THREE bf16 parts -- hi + mid + lo is the fp32 value
+ * exactly -- and six matrix-core products per operand pair (every product of parts i, j with i + j <= 2; what is dropped is
+ * <= 2^-24 of a product), fp32 accumulate.  Results are fp32-grade (the reference's own precision: spconv_ops.h:260-361
+ * runs torch::mm in fp32) at 1/6 of the bf16 matrix rate = 2.6x the fp32 matrix rate of gfx950.
+ *   rows     [n][C/8][hi 8 x bf16 | mid | lo]   48 B per 8 channels (df3d_split_rows3, or a convolution's out_split3)
+ *   filters  df3d_conv_pack_weights3 (groups filter banks [groups][kvol][cin][cout] back to back; groups = 1 for one bank)
+ * df3d_conv_rows_split3 = df3d_conv_rows_split on these formats, plus the optional fp32 `residual` rows of
+ * df3d_sparse_conv_split (one group, dense output rows): it serves the sparse backbone, the BEV neck and the head alike. */
+size_t df3d_conv_packed_weight_bytes3(int kvol, int cin, int cout);
+int df3d_conv_pack_weights3(const float *filters, int groups, int kvol, int cin, int cout, void *packed, void *stream);
+int df3d_split_rows3(const float *features, long long n, int c, void *split3, void *stream);
+int df3d_conv_rows_split3(const void *in_split3, int n_in, int in_channels, int cin, int in_group_stride, const void *packed3,
+                          int kvol, int cout, int groups, const int32_t *nbr, int n_out, const float *bias, const float *scale,
+                          const float *shift, const float *residual, int relu, float *out, int out_channels,
+                          const int32_t *out_cols, void *out_split3, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Detection tail: rotated BEV overlap / IoU / NMS.  Replace the pybind module
  * `iou3d_nms_cuda` (CP/det3d/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17): boxes_overlap_bev_gpu / boxes_iou_bev_gpu
  * (iou3d_nms.cpp:38-85) and nms_gpu / nms_normal_gpu (iou3d_nms.cpp:88-188), plus the numba circle NMS
@@ -793,6 +810,8 @@ typedef struct df3d_layer {
   int reserved;          /* flags: bit 0 = geometry only (build the rulebook, export it, do not run the conv);
                           *        bit 1 = `packed` holds bf16 weights (df3d_conv_pack_weights_bf16): the layer runs on
                           *                df3d_sparse_conv_bf16 with bf16 rows;
+                          *        bit 3 = `packed` holds THREE-part filters (df3d_conv_pack_weights3): the layer runs on
+                          *                df3d_conv_rows_split3 with three-part rows ("split3" precision);
                           *        bit 2 = the caller reads this layer's fp32 rows (an exported stage).  When any layer of
                           *                the table carries it, split-precision layers that are neither flagged, nor a
                           *                residual source, nor read by a non-split layer write split rows ONLY (their view
@@ -812,7 +831,7 @@ typedef struct df3d_layer_view {
   int shape[3];
   const int32_t *nbr;    /* the layer's neighbour table [kvol][n] */
   int kvol;
-  int reserved;          /* bit 1: `split` holds bf16 rows [n][channels] instead of split rows */
+  int reserved;          /* bit 1: `split` holds bf16 rows [n][channels] instead of split rows; bit 2: three-part rows */
 } df3d_layer_view;
 
 /* Optional, before df3d_backbone_run on the same host thread (consumed by that call): `event` (hipEvent_t) marks the input

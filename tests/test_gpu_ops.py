@@ -1383,3 +1383,89 @@ def test_gate_scatter_with_row_responses_inside(C):
     assert torch.equal(outs[0][1], outs[1][1])
     assert float(outs[0][0].abs().max()) > 0.5
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-5 * max(1.0, float(outs[0][0].abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (512, 64)])
+def test_sparse_conv_three_part_precision(dev, cin, cout):
+    """"split3" precision (round 4): operands in three bf16 parts (hi + mid + lo = the fp32 value exactly), six matrix-core
+    products, fp32 accumulate -- against the float64 contraction: <= 4e-6 of the output scale (the exact-fp32 MFMA kernel
+    sits at ~1e-6, the two-part split at ~1e-5), fused epilogue included; the emitted three-part rows equal
+    split_rows(out) of the mode bit for bit and reconstruct the fp32 rows EXACTLY."""
+    from dualfusion import ops
+    shape, batch = [9, 48, 48], 2
+    ind = detgen.clustered_voxels("c3s", batch, shape, n_seeds=8, walk=200)
+    ind_t = T(ind, dev)
+    feats = detgen.randn("c3f%d" % cin, (len(ind), cin))
+    filt = detgen.randn("c3w%d_%d" % (cin, cout), (27, cin, cout), 0.5 / np.sqrt(cin))
+    bias = detgen.randn("c3b%d" % cout, (cout,), 0.1)
+    scale = 1 + detgen.randn("c3s%d" % cout, (cout,), 0.1)
+    shift = detgen.randn("c3h%d" % cout, (cout,), 0.1)
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = "split3"
+    try:
+        assert ops.conv_split_supported(27, cin, cout) and ops.split_parts() == 3
+        packed = ops.conv_pack_weights(T(filt, dev))
+        fsplit = ops.split_rows(T(feats, dev))
+        assert tuple(fsplit.shape) == (len(ind), 6 * cin)
+        # hi + mid + lo == x exactly
+        parts = fsplit.view(len(ind), cin // 8, 3, 8, 2).cpu().numpy().view(np.uint16).reshape(len(ind), cin // 8, 3, 8)
+        recon = sum((parts[:, :, p].astype(np.uint32) << 16).view(np.float32).astype(np.float64) for p in range(3))
+        assert np.array_equal(recon.reshape(len(ind), cin).astype(np.float32), feats)
+        for subm in (1, 0):
+            ks, st, pd, dl = [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1]
+            outids, nbr, _ = _hip_rulebook(ind_t, batch, shape, ks, st, pd, dl, subm)
+            n_out = outids.shape[0]
+            res = detgen.randn("c3r%d" % cout, (n_out, cout))
+            y, ys = ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, bias=T(bias, dev), scale=T(scale, dev),
+                                          shift=T(shift, dev), residual=T(res, dev), relu=True)
+            nb = nbr.cpu().numpy()
+            acc = np.zeros((n_out, cout), np.float64)
+            for k in range(27):
+                m = nb[k] >= 0
+                acc[m] += feats[nb[k][m]].astype(np.float64) @ filt[k].astype(np.float64)
+            ref = np.maximum((acc + bias) * scale + shift + res, 0)
+            err = np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max()
+            assert err < 4e-6, (subm, err)          # (fp32 accumulation over up to 27 x 512 terms; exact-fp32 MFMA kernel: < 5e-6)
+            assert torch.equal(ys, ops.split_rows(y))
+            # grouped / strided form (what the neck and the heads call): same result
+            y2, _ = ops.conv_rows_split(fsplit, cin, 0, packed, cout, 1, nbr, n_out, T(bias, dev), T(scale, dev), T(shift, dev),
+                                        relu=False)
+            y1, _ = ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, bias=T(bias, dev), scale=T(scale, dev),
+                                          shift=T(shift, dev), relu=False, emit_split=False)
+            assert torch.equal(y1, y2)
+    finally:
+        ops.CONV_PRECISION = old
+
+
+def test_three_part_mode_end_to_end_detector():
+    """The CenterPoint detector forward (backbone through the native executor, camera fusion, neck, head) in the "split3"
+    mode against the exact-fp32 mode: every head map within 2e-5 of its scale (both are fp32-grade; the two-part split mode
+    is ~1e-4), identical index sets."""
+    from dualfusion import ops, synth
+    from dualfusion.fusion import build_centerpoint_fusion, synthetic_camera_inputs
+    from dualfusion.pipeline import CenterPointDetector
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = CenterPointDetector(fusion=build_centerpoint_fusion()).eval().to(dev)
+    pts = [torch.from_numpy(synth.nusc_sweep(seed=9)).to(dev)]
+    bd, ex = synthetic_camera_inputs(1, dev, seed=3, yaw_offset_deg=7.3)
+    outs = {}
+    old = ops.CONV_PRECISION
+    try:
+        for mode in ("fp32", "split3", "split"):
+            ops.CONV_PRECISION = mode
+            with torch.no_grad():
+                x, multi = m.hot_path(pts, batch_dict=dict(bd), example=dict(ex))
+                preds = m.bbox_head(x)
+            outs[mode] = (multi["conv4"].indices.clone(), [{k: v.clone() for k, v in p.items()} for p in preds])
+    finally:
+        ops.CONV_PRECISION = old
+    assert torch.equal(outs["fp32"][0], outs["split3"][0])
+    worst3 = worst2 = 0.0
+    for t in range(len(outs["fp32"][1])):
+        for k, ref in outs["fp32"][1][t].items():
+            s = float(ref.abs().max())
+            worst3 = max(worst3, float((outs["split3"][1][t][k] - ref).abs().max()) / s)
+            worst2 = max(worst2, float((outs["split"][1][t][k] - ref).abs().max()) / s)
+    assert worst3 < 2e-5, (worst3, worst2)
+    assert worst2 < 1e-3
