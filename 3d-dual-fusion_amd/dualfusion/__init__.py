@@ -3,7 +3,15 @@
 
 Sub-modules import lazily; every op loads the HIP library on first use and raises Df3dError if it
 is missing (there is no CPU fallback)."""
-from ._lib import Df3dError, LIB_PATH, load as require  # noqa: F401
+import os as _os
+
+# HIP maps a process's streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4) and serialises the streams that share
+# one.  The frame pipeline of this package runs ~8 streams per detector (frame-head worker, geometry, voxeliser, adapter side
+# streams, the caller's); with 4 queues two frames in flight did not overlap at all (DESIGN.md section 8).  Effective only when
+# this import happens before the HIP runtime initialises (import dualfusion before the first CUDA call, or export it yourself).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+from ._lib import Df3dError, LIB_PATH, load as require  # noqa: E402,F401
 
 __all__ = ["require", "Df3dError", "LIB_PATH", "spconv", "ops", "voxel", "msda", "actr", "fusion", "backbones",
            "pipeline", "registry", "synth", "necks", "executor", "fusion_tf", "iou3d_nms", "heads", "transfusion_head"]

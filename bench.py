@@ -33,6 +33,12 @@ for p in (ROOT, os.path.join(ROOT, "3d-dual-fusion_amd"), os.path.join(ROOT, "te
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# HIP maps a process's streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue run their
+# kernels one after the other.  A detector step here uses ~8 streams (frame-head worker, geometry, voxeliser, adapter side streams,
+# RCCL) and the in_flight pass two detectors: with 4 queues the two frames in flight did not overlap at all (2.95 ms per step
+# against 2.40 with 16, profiles/r04_*).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -544,41 +550,32 @@ def cpu_baseline(wl, n_sweeps=5):
 SIDE_CONFIGS = (("cp_lidar", "configs[0] shape", "split"), ("tf_fusion", "configs[2]", "bf16"), ("vr_fusion", "configs[4]", "split"))
 
 
-def side_configs(args, rank, world, dev, barrier, reduce_losses, steps=12):
+def side_configs(args, steps=12):
     """BASELINE configs[0] (shape), [2] and [4] after the headline, ~`steps` timed steps each with the same protocol (every
     distinct frame once, warm-up, barrier, K steps, barrier): compact numbers for the END of the JSON line, where the
-    driver's record keeps them.  A failure of one of them is reported in its entry and does not fail the bench line."""
-    import copy
-    import gc
-    from dualfusion import ops
+    driver's record keeps them.  Each runs as `python bench.py --workload ...` in a process of its own, after this process
+    has released its device memory (in-process they ran 10-50 % slower than alone: allocator state and streams of the headline
+    workload).  A failure of one of them is reported in its entry and does not fail the bench line."""
+    import subprocess
     out = {}
-    keep = ops.CONV_PRECISION
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
     for name, cfg, prec in SIDE_CONFIGS:
         if name == args.workload:
             continue
-        a = copy.copy(args)
-        a.workload, a.batch, a.frames = name, 0, 4
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", "4",
+               "--frames", "4", "--conv-precision", prec, "--no-cpu-baseline", "--no-extra-passes", "--no-kernel-timing",
+               "--no-side-configs", "--inflight", "1"]
         try:
-            ops.CONV_PRECISION = prec
-            w = make_workload(a, rank, world, dev)
-            for k in range(2 * len(w.frames) + 4):              # two visits of every frame (allocator, address-keyed tables)
-                o = w.step(k, "detect")
-                if isinstance(o, dict):
-                    reduce_losses(o)
-            e, o = timed_steps(w, "detect", steps, 0, barrier, reduce_losses)
-            w.check(o, "detect")
-            out[name] = {"cfg": cfg, "ms_per_step": round(e / steps * 1e3, 3), "bs": w.batch,
-                         "value": round(steps * w.batch * world / e, 1), "unit": w.unit_name + "/s",
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                raise RuntimeError("rc %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1][:100] if r.stderr.strip() else ""))
+            d = json.loads(line[-1])
+            out[name] = {"cfg": cfg, "ms_per_step": d["ms_per_step"], "bs": d["config"]["sweeps_per_gpu_per_step"],
+                         "value": d["value"], "unit": d["unit"],
                          "dtype": {"split": "f32(split-bf16x3)", "bf16": "bf16", "fp32": "f32"}[prec], "steps": steps}
-            if hasattr(w, "close"):
-                w.close()
-            del w, o
         except Exception as ex:                                  # noqa: BLE001
             out[name] = {"cfg": cfg, "error": repr(ex)[:120]}
-        finally:
-            ops.CONV_PRECISION = keep
-        gc.collect()
-        torch.cuda.empty_cache()
     return out
 
 
@@ -750,8 +747,9 @@ def main():
                     w.stride = F
                 nf = len(wl.frames)
                 timed_steps_alternating(wls, streams, stage, 2 * nf, 0, barrier)        # every replica sees every frame once
-                e, lat = timed_steps_alternating(wls, streams, stage, args.steps, 2 * nf, barrier)
-                extra["in_flight"], extra["in_flight_latency_ms"] = e, lat
+                if_steps = max(args.steps, 48)                    # (the pipeline fills and drains once per pass)
+                e, lat = timed_steps_alternating(wls, streams, stage, if_steps, 2 * nf, barrier)
+                extra["in_flight"], extra["in_flight_latency_ms"] = e * args.steps / if_steps, lat
                 for w in wls:
                     w.stride = 1
             else:
@@ -794,11 +792,6 @@ def main():
             api = api_probe(wl, stage)
         except Exception as e:                                   # noqa: BLE001  (a measurement aid must not fail the bench line)
             print("bench.py: api probe failed: %r" % (e,), file=sys.stderr)
-    side = None
-    if (world == 1 and args.side_configs and not protocol and stage == "detect" and args.workload == "cp_fusion"
-            and not args.no_extra_passes):
-        note("side configs")
-        side = side_configs(args, rank, world, dev, barrier, reduce_losses)
     if rank == 0:
         units = args.steps * wl.batch * world
         per_step = lambda e: round(e / args.steps * 1e3, 4)      # noqa: E731
@@ -908,8 +901,17 @@ def main():
                 res["dtype"].split(" (")[0] + " split-bf16x3 convs+FFN, fp32 accumulate, <=1e-4 of scale",
                 per_step(extra.get("split3_detect", 0.0)), units / extra["split3_detect"] if "split3_detect" in extra else 0.0,
                 wl.unit_name, per_step(extra["fp32_detect"]))
-        if side is not None:
-            res["configs"] = side                                   # LAST key: the driver's record keeps the tail of the line
+        if (world == 1 and args.side_configs and not protocol and stage == "detect" and args.workload == "cp_fusion"
+                and not args.no_extra_passes):
+            note("side configs")
+            if hasattr(wl, "close"):
+                wl.close()
+            wl = None
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()                                # the other workloads get the device memory
+            res["configs"] = side_configs(args)                     # LAST key: the driver's record keeps the tail of the line
         print(json.dumps(res))
         sys.stdout.flush()
     if hasattr(wl, "close"):
