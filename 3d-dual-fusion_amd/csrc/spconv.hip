@@ -829,6 +829,8 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const int32_t *__restr
 }
 static bool g_timing_on = false;
 static int g_timing_filter[3] = {0, 0, 0};   // (cin, cout, kvol) of the only launches to time; 0 = any
+static int g_timing_every = 1;               // df3d_timing_sample: events around every N-th matching launch only
+static unsigned g_timing_seen = 0;
 static std::mutex g_timing_mu;          // several host threads (frames in flight) launch convolutions concurrently
 static std::vector<TimingRec> g_timing;
 static std::vector<hipEvent_t> g_event_pool;
@@ -850,6 +852,7 @@ int timing_rec_begin(int cin, int cout, int kvol, int n_out, const int32_t *nbr,
       (g_timing_filter[2] && g_timing_filter[2] != kvol))
     return -1;
   std::lock_guard<std::mutex> lock(g_timing_mu);
+  if (g_timing_every > 1 && (g_timing_seen++ % (unsigned)g_timing_every) != 0) return -1;
   TimingRec r = {timing_event(), timing_event(), cin, cout, kvol, n_out, -1, split};
   if (!r.e0 || !r.e1) return -1;
   if (g_timing_pairs && nbr) {
@@ -1086,6 +1089,15 @@ extern "C" int df3d_timing_get2(int i, int *shape4, float *ms, long long *pairs,
   shape4[3] = r.n_out;
   *pairs = r.pairs;
   *split = r.split;
+  return DF3D_OK;
+}
+
+// Events around every `every`-th launch that passes the filter (1 = all): a pair of event records costs the launching stream
+// a marker packet each and breaks back-to-back dispatch -- around the four launches per frame of the dominant kernel that was
+// ~5 % of the timed step (3.00 against 2.85 ms); a sample of them measures the same average.
+extern "C" int df3d_timing_sample(int every) {
+  g_timing_every = every > 1 ? every : 1;
+  g_timing_seen = 0;
   return DF3D_OK;
 }
 

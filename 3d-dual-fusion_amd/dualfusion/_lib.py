@@ -115,6 +115,7 @@ SIGNATURES = {
     "df3d_ffn_fused_jobs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "df3d_timing_count_pairs": (c_int, [c_int]),
     "df3d_timing_filter": (c_int, [c_int, c_int, c_int]),
+    "df3d_timing_sample": (c_int, [c_int]),
     "df3d_timing_get2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_sparse_to_dense_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_conv2d_neighbors": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -309,16 +309,19 @@ class KernelTimer(object):
     launch comes from the per-layer API or from the native executor.  `count_pairs=True` is the metadata mode for
     an extra pass OUTSIDE the timed region: each launch also reports its valid rulebook pairs."""
 
-    def __init__(self, count_pairs=False, only=None):
-        """only = (cin, cout, kvol): time just these launches (the dominant kernel of a previous, untimed probe)."""
+    def __init__(self, count_pairs=False, only=None, every=1):
+        """only = (cin, cout, kvol): time just these launches (the dominant kernel of a previous, untimed probe);
+        every = N: events around every N-th of them only (a sample: the events themselves cost the stream time)."""
         self.count_pairs = count_pairs
         self.only = only
+        self.every = int(every)
         self.records = []   # dicts: cin, cout, kvol, n_out, ms, pairs, split
 
     def start(self):
         lib = _lib.load()
         lib.df3d_timing_count_pairs(1 if self.count_pairs else 0)
         lib.df3d_timing_filter(*([int(v) for v in self.only] if self.only else [0, 0, 0]))
+        lib.df3d_timing_sample(self.every)
         lib.df3d_timing_begin()
 
     def stop(self):
@@ -326,6 +329,7 @@ class KernelTimer(object):
         n = lib.df3d_timing_end()
         lib.df3d_timing_count_pairs(0)
         lib.df3d_timing_filter(0, 0, 0)
+        lib.df3d_timing_sample(1)
         shape = (ctypes.c_int * 4)()
         ms = ctypes.c_float()
         pairs = ctypes.c_longlong()

@@ -180,6 +180,8 @@ int df3d_timing_count_pairs(int on);
 /* Only launches of this (cin, cout, kernel volume) are timed (0 = any): event pairs around EVERY conv launch cost the
  * timed region ~6 %; the roofline needs the dominant kernel only. */
 int df3d_timing_filter(int cin, int cout, int kvol);
+/* events around every `every`-th launch that passes the filter only (1 = all; reset by the call) */
+int df3d_timing_sample(int every);
 int df3d_timing_get2(int i, int *shape4, float *ms, long long *pairs, int *split);
 
 /* SparseConvTensor.dense() (TF/mmdet3d/ops/spconv/structure.py:5-18,55-64): zero-fill +
