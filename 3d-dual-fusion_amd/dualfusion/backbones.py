@@ -442,8 +442,46 @@ class SparseEncoderFusion(SparseEncoder):
         pts[:, 1:] = pts[:, 1:].flip(1)            # (z, y, x) -> (x, y, z); a Python index list would be a host -> device copy
         return pts            # [N, 4] (b, x, y, z); rows are batch-sorted
 
+    # ---- frame head a frame ahead (dualfusion/prefetch.py): voxelisation + the rulebooks of the first executor segment ----
+    def prefetch(self, points_list, voxel_size, point_cloud_range, max_points, max_voxels):
+        """Start voxelisation (mmdet3d's hard voxelisation: `break` at the cap) + mean VFE and every rulebook of the encoder for
+        these point clouds on the module's native worker thread; returns at once.  `take_head(points_list)` later hands back
+        (features, coors, prepared) for `forward(features, coors, B, ..., prepared=prepared)`.  The clouds must be complete in
+        device memory and be passed as the same tensors."""
+        if self.training or not points_list or not points_list[0].is_cuda:
+            return False
+        with torch.no_grad():
+            cuts = [p + 1 for p in (self.fusion_pos or [])]
+            runner = self._runner(cuts)
+        if runner is None:
+            return False
+        head = self.__dict__.get("_head_worker")
+        if head is None:
+            from .prefetch import FrameHead
+            head = self.__dict__["_head_worker"] = FrameHead(points_list[0].device)
+        if len(head._pending) >= 2:
+            head.drop_all()
+        cap = max_voxels if isinstance(max_voxels, int) else max_voxels[1]
+        vox = dict(voxel_size=voxel_size, coors_range=point_cloud_range, max_points=max_points, max_voxels=cap, break_at_cap=True)
+        head.submit(tuple(int(p.data_ptr()) for p in points_list), runner.segments[0][2], points_list, vox,
+                    [int(v) for v in self.sparse_shape], None)
+        return True
+
+    def take_head(self, points_list):
+        head = self.__dict__.get("_head_worker")
+        prep = head.take(tuple(int(p.data_ptr()) for p in points_list)) if head is not None else None
+        if prep is None or prep.geometry is None:
+            return None
+        prep.hand_over()
+        return prep.feats, prep.coors, prep.geometry
+
+    def close(self):
+        head = self.__dict__.pop("_head_worker", None)
+        if head is not None:
+            head.close()
+
     def forward(self, voxel_features, coors, batch_size, img_feats=None, img_metas=None, points=None,
-                ret_lidar_features=False, img=None):
+                ret_lidar_features=False, img=None, prepared=None):
         coors = coors.int()
         x0 = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
         encode_features, lidar_features = [], []
@@ -461,7 +499,7 @@ class SparseEncoderFusion(SparseEncoder):
         cuts = [p + 1 for p in (self.fusion_pos or [])]
         runner = self._runner(cuts) if voxel_features.is_cuda and voxel_features.shape[0] > 0 else None
         if runner is not None:
-            runner.run(x0, hook=lambda i, name, t: t if i == 0 else fuse(i - 1, t))
+            runner.run(x0, hook=lambda i, name, t: t if i == 0 else fuse(i - 1, t), prepared=prepared)
         else:
             x = self.conv_input(x0)
             for idx, encoder_layer in enumerate(self.encoder_layers._modules.values()):

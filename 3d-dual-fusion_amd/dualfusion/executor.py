@@ -471,14 +471,18 @@ class SegmentedRunner(object):
                 raise Unsupported("segment %d" % k)
             self.segments.append((a, b, plan))
 
-    def run(self, x, hook=None):
+    def run(self, x, hook=None, prepared=None):
         """x: SparseConvTensor (network input).  hook(stage_index, name, tensor) -> tensor is called after every
         stage in order (identity when None) -- stages inside a segment see their output after the segment ran,
         which is fine for hooks that only READ; hooks that MODIFY features must sit at a cut.
+        prepared: PreparedGeometry of the FIRST segment's plan (a frame head built ahead, dualfusion/prefetch.py).
         Returns {stage name: tensor}."""
         outs = {}
-        for a, b, plan in self.segments:
-            res = plan.run(x.features, x.indices, x.batch_size, x.spatial_shape)
+        for k, (a, b, plan) in enumerate(self.segments):
+            if k == 0 and prepared is not None and prepared.plan is plan:
+                res = plan.run_convs(prepared, x.features)
+            else:
+                res = plan.run(x.features, x.indices, x.batch_size, x.spatial_shape)
             for i in range(a, b):
                 name = self.stages[i][0]
                 t = res[name]

@@ -42,6 +42,7 @@ class TransFusionWorkload(object):
         from .transfusion_head import TransFusionHead
         self.batch = B = args.batch or 4
         self.dev = dev
+        self.prefetch = bool(getattr(args, "prefetch", True)) and os.environ.get("DF3D_VOXEL_STREAM", "1") == "1"
         torch.manual_seed(0)
         ch = ((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128))
         pad = ((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0))
@@ -93,12 +94,24 @@ class TransFusionWorkload(object):
                 "target assignment + detection losses), 0.075 m voxel, bs=%d [BASELINE configs[2]; configs[3] per GPU]"
                 % (self.batch, self.batch))
 
+    def close(self):
+        self.enc.close()
+
     @torch.no_grad()
     def step(self, i, stage):
         fr = self.frames[i % len(self.frames)]
-        f, c = _voxelize_batch(fr["points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000)
+        head = self.enc.take_head(fr["points"]) if self.prefetch else None
+        if self.prefetch:
+            # the next batch's voxelisation and rulebooks (with their count round trips) start on the encoder's worker thread
+            # while this batch is queued -- what the reference's DataLoader workers do for the voxelisation
+            self.enc.prefetch(self.frames[(i + 1) % len(self.frames)]["points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000)
         metas = [dict(m) for m in fr["metas"]]                    # fresh meta dicts per iteration
-        x = self.enc(f, c, self.batch, img_feats=[fr["img"]], img_metas=metas)
+        if head is not None:
+            f, c, prepared = head
+        else:
+            f, c = _voxelize_batch(fr["points"], synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 120000)
+            prepared = None
+        x = self.enc(f, c, self.batch, img_feats=[fr["img"]], img_metas=metas, prepared=prepared)
         if stage == "hot_path":
             return x
         preds = self.head(self.fpn(self.second(x)))

@@ -592,3 +592,45 @@ def test_prefetched_geometry_equals_isolated_frames():
             assert torch.equal(i4, want[k % nf][1][3]) and torch.equal(y, want[k % nf][0]), k
     for mm in ms:
         mm.close()
+
+
+def test_transfusion_encoder_frame_head_equals_inline():
+    """The TransFusion encoder with its frame head (voxelisation of the batch + every rulebook) built ahead on the module's
+    worker thread (`SparseEncoderFusion.prefetch` / `take_head`, bench.py's tf_fusion step) against the in-line path:
+    bit-identical dense maps, frame by frame, in split precision and in the bf16 mode of configs[2]."""
+    from dualfusion import ops, synth
+    from dualfusion.backbones import SparseEncoderFusion
+    from make_golden import ACTR_CFG
+    dev = torch.device("cuda:0")
+    B, ori_hw, in_hw, fh, fw = 2, (225, 400), (112, 200), 28, 50
+    rng = [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0]
+    enc = SparseEncoderFusion(in_channels=5, sparse_shape=[41, 256, 256], output_channels=128, encoder_channels=TF_CH,
+                              encoder_paddings=TF_PAD, block_type='basicblock', fusion_pos=[3], voxel_size=[0.075, 0.075, 0.2],
+                              point_cloud_range=rng, fusion_layer=dict(type='ACTR', pfat_cfg=dict(ACTR_CFG)))
+    enc, _ = _load_det(enc, dev)
+    cams = synth.nusc_cameras(image_hw=ori_hw, focal=316.0)
+    metas = _tf_metas(B, cams, ori_hw, in_hw)
+    img = torch.from_numpy(np.random.RandomState(0).standard_normal((B * 6, 256, fh, fw)).astype(np.float32)).to(dev)
+    frames = [[torch.from_numpy(synth.nusc_sweep(seed=90 + 7 * j + b)).to(dev) for b in range(B)] for j in range(3)]
+    old = ops.CONV_PRECISION
+    try:
+        for mode in ("split", "bf16"):
+            ops.CONV_PRECISION = mode
+            with torch.no_grad():
+                want = []
+                for pts in frames:
+                    f, c = ops.hard_voxelize_clouds(pts, synth.NUSC_VOXEL, rng, 10, 120000)
+                    want.append(enc(f, c, B, img_feats=[img], img_metas=[dict(m) for m in metas]).clone())
+                    torch.cuda.synchronize()
+                assert enc.prefetch(frames[0], synth.NUSC_VOXEL, rng, 10, 120000)
+                for k in range(9):
+                    head = enc.take_head(frames[k % 3])
+                    assert head is not None
+                    enc.prefetch(frames[(k + 1) % 3], synth.NUSC_VOXEL, rng, 10, 120000)
+                    f, c, prepared = head
+                    y = enc(f, c, B, img_feats=[img], img_metas=[dict(m) for m in metas], prepared=prepared)
+                    assert torch.equal(y, want[k % 3]), (mode, k)
+                torch.cuda.synchronize()
+    finally:
+        ops.CONV_PRECISION = old
+        enc.close()
