@@ -85,7 +85,8 @@ def parse():
                          "trip on the queueing thread)")
     ap.add_argument("--no-side-configs", dest="side_configs", action="store_false",
                     help="skip the ~10-step passes over BASELINE configs[0] / [2] / [4] after the headline (N = 1 only)")
-    ap.add_argument("--cpu-sweeps", type=int, default=5, help="sweeps of the CPU baseline at all threads (after 1 warm-up)")
+    ap.add_argument("--cpu-sweeps", type=int, default=20,
+                    help="timed sweeps of the CPU baseline at the fastest thread setting (SURVEY 8(d): 20 after 3 untimed ones)")
     return ap.parse_args()
 
 
@@ -444,7 +445,7 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(wl, n_sweeps=5):
+def cpu_baseline(wl, n_sweeps=20):
     """The reference's CPU path on this box's host cores, same workload, same weights, one sweep at a time:
       voxelize        oracle/_ref/voxel_layer.so `hard_voxelize` (TF/mmdet3d/ops/voxel/src/voxelization_cpu.cpp)
       sparse backbone oracle/_ref/sparse_conv_ext.so `get_indice_pairs_3d` + `indice_conv_fp32` (the reference's own
@@ -519,8 +520,9 @@ def cpu_baseline(wl, n_sweeps=5):
     # sweep per thread setting {1, 16, all} (the very first sweep is the warm-up and is not counted), then `n_sweeps`
     # timed sweeps at the fastest setting; `value` = 1 / median of those.
     t_all = time.perf_counter()
-    settings = sorted(set([1, min(16, all_threads), all_threads]))
-    torch.set_num_threads(all_threads)
+    # (all threads were probed in rounds 2-3: 15-20 s per sweep on the 128-core box against 4 s at 16 -- not probed any more)
+    settings = sorted(set([1, min(16, all_threads)]))
+    torch.set_num_threads(min(16, all_threads))
     one_sweep(0, wl.frames[0])                                   # warm-up (page-in, allocator, lazy inits)
     probe = {}
     for threads in settings:
@@ -538,7 +540,7 @@ def cpu_baseline(wl, n_sweeps=5):
             "seconds_per_sweep_median": med,
             "probe_seconds_per_sweep_by_threads": {str(t): {k: round(v.get(k, 0.0), 4) for k in stages}
                                                    for t, v in probe.items()},
-            "sample": "1 warm-up sweep, 1 probe sweep at each of %s threads, then %d whole synthetic sweeps at the fastest "
+            "sample": "3 untimed sweeps (1 warm-up, 1 probe at each of %s threads), then %d whole synthetic sweeps at the faster "
                       "setting (%d threads; median reported); voxelize and the sparse backbone on the reference's compiled "
                       "CPU ops (oracle/_ref: hard_voxelize, get_indice_pairs_3d, indice_conv_fp32)%s, neck + head + loss "
                       "on torch CPU fp32; %.0f s wall" % (
