@@ -638,6 +638,70 @@ class VoxelBackBone8x(nn.Module):
         return batch_dict
 
 
+class BasicGate(nn.Module):
+    """VR/pcdet/models/model_utils/attention.py:88-177 -- the image gate of the Voxel-RCNN tree (`I_FUSION_METHOD: BasicGate`,
+    called at spconv_backbone.py:797-800 right before ACTR): per image level s, the voxels of `x_list[s]` are projected into the
+    camera, their feature rows scattered onto the level's feature map (`pts2img`, attention.py:945-967: pixels clamped to the
+    border, the last row written wins, a (H + 1) x (W + 1) canvas cropped back), two 3 x 3 convolutions reduce the canvas to
+    one map, and the image features are multiplied by its sigmoid.
+    Kept bug for bug: the convolution stacks live in a plain Python list (`spatial_basic_list`), so they are NOT registered --
+    no `state_dict` keys, never seen by an optimizer, moved to the device inside `forward` -- exactly as in the reference.
+    Device formulation: the projection is the backbone's (`lidar2img` on the device instead of the numpy `Calibration`
+    object); the scatter resolves "last writer" with an arg-max over row indices (deterministic; the reference's `index_put_`
+    is sequential on the CPU and racy on a GPU)."""
+
+    def __init__(self, img_channel_list, pts_channel_list, sparse_shape, voxel_size, point_cloud_range, inv_idx, pts_idx,
+                 num_conv=2):
+        super(BasicGate, self).__init__()
+        self.voxel_size, self.point_cloud_range, self.inv_idx = voxel_size, point_cloud_range, inv_idx
+        self.g_channel_list = list(pts_channel_list)
+        self.sparse_shape = sparse_shape
+        self.pts_idx = pts_idx
+        self.spatial_basic_list = []
+        for c in self.g_channel_list:
+            mods = []
+            for _ in range(num_conv - 1):
+                mods += [nn.Conv2d(c, c, kernel_size=3, stride=1, padding=1), nn.BatchNorm2d(c, eps=1e-3, momentum=0.01), nn.ReLU()]
+            mods.append(nn.Conv2d(c, 1, kernel_size=3, stride=1, padding=1))
+            self.spatial_basic_list.append(nn.Sequential(*mods))
+        self.sigmoid = nn.Sigmoid()
+
+    def canvas(self, x, uv, image_hw, feat_hw, batch_size):
+        """pts2img of a whole batch: uv [n, 2] float pixels (x, y) in the image -> [B, C, Hf, Wf]."""
+        h, w = image_hw
+        Hf, Wf = feat_hw
+        norm = (uv / uv.new_tensor([float(w), float(h)])).clamp(min=0.0, max=1.0)
+        iy = (norm[:, 1] * Hf).long()
+        ix = (norm[:, 0] * Wf).long()
+        b = x.indices[:, 0].long()
+        lin = (b * (Hf + 1) + iy) * (Wf + 1) + ix
+        rows = torch.arange(lin.shape[0], device=lin.device)
+        win = torch.full((batch_size * (Hf + 1) * (Wf + 1),), -1, dtype=torch.long, device=lin.device)
+        win.scatter_reduce_(0, lin, rows, "amax", include_self=True)
+        feats = x.features
+        out = feats.new_zeros((win.shape[0], feats.shape[1]))
+        hit = win >= 0
+        out[hit] = feats[win[hit]]
+        return out.view(batch_size, Hf + 1, Wf + 1, -1)[:, :-1, :-1].permute(0, 3, 1, 2).contiguous()
+
+    def forward(self, x_rgb, x_list, batch_dict, project=None):
+        """project(x, voxel_stride) -> (xyz, uv): the backbone's projection of a sparse tensor's voxel corners (with the
+        recorded augmentations undone) -- `VoxelBackBone8xFusion._project`."""
+        if project is None:
+            raise ValueError("BasicGate.forward needs the backbone's projection (project=)")
+        B = batch_dict["batch_size"]
+        image_hw = tuple(batch_dict["images"].shape[2:]) if "images" in batch_dict else tuple(batch_dict["image_hw"])
+        out = []
+        for s, f in enumerate(x_rgb):
+            x = x_list[s]
+            ratio = self.sparse_shape[1] / x.spatial_shape[1]
+            _, uv = project(x, ratio)
+            pts_img = self.canvas(x, uv, image_hw, tuple(f.shape[2:]), B)
+            pts = self.spatial_basic_list[s].to(device=f.device)(pts_img)
+            out.append(f * torch.sigmoid(pts))
+        return out
+
+
 class VoxelBackBone8xFusion(VoxelBackBone8x):
     """VR/pcdet/models/backbones_3d/spconv_backbone.py:436-928, camera branch reduced to the hot path:
     MVX nearest-pixel sum at stride 1 (:733-756, FUSION_POS has 1) and ACTR(v2) dual-query fusion at
@@ -647,8 +711,9 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
     frozen DeepLabV3) is out of scope, so its outputs are read from `batch_dict['img_dict']`
     ({'mvx_layer1_feat2d' | 'layer1_feat2d': [B,C,h,w]}); the KITTI calibration objects, whose
     `lidar_to_img` runs in numpy on the CPU (:717-718), are replaced by `batch_dict['lidar2img']`
-    [B,3,4] on the device (`lidar2img_from_kitti` composes it from P2 / R0 / Tr the way the devkit projects).  I_FUSION_METHOD (image gate) is not implemented for this tree:
-    the shipped `_ifat` yaml cannot be constructed by the reference itself."""
+    [B,3,4] on the device (`lidar2img_from_kitti` composes it from P2 / R0 / Tr the way the devkit projects).  `I_FUSION_METHOD:
+    BasicGate` (the image gate in front of ACTR, `BasicGate` above) is mirrored since round 4; the shipped `_ifat` yaml cannot be
+    constructed by the reference itself (no `pts_idx`) -- the default [0, 2] of the PV-RCNN yaml is taken."""
 
     def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
         super().__init__(model_cfg, input_channels, grid_size, **kwargs)
@@ -659,8 +724,18 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         self.register_buffer("voxel_size", torch.tensor([0.1, 0.05, 0.05]), persistent=False)          # z, y, x
         self.register_buffer("point_cloud_range", torch.tensor([-3., -40., 0., 1., 40., 70.4]), persistent=False)
         self.img_out_channel = 16 if 1 in self.fusion_pos else 64
-        if get("I_FUSION_METHOD", False):
-            raise NotImplementedError("I_FUSION_METHOD for the Voxel-RCNN tree")
+        self.ifat = None
+        method = get("I_FUSION_METHOD", False)
+        if method:
+            if method != "BasicGate":
+                raise NotImplementedError("I_FUSION_METHOD %r: the Voxel-RCNN 3D-DF config names BasicGate" % (method,))
+            cfg = get("IFAT_CFG", None) or {}
+            lv0 = self.feature_levels[0]
+            # (spconv_backbone.py:546-560; the shipped yaml has no `pts_idx`, which the reference's constructor requires)
+            self.ifat = BasicGate(img_channel_list=cfg["img_num_channels"][lv0:lv0 + len(self.feature_levels)],
+                                  pts_channel_list=cfg["pts_num_channels"], sparse_shape=self.sparse_shape,
+                                  voxel_size=self.voxel_size, point_cloud_range=self.point_cloud_range, inv_idx=[2, 1, 0],
+                                  pts_idx=cfg.get("pts_idx", [0, 2]))
         if "ACTR" in self.fusion_method:
             from .actr import build as build_actr
             model_name = self.fusion_method if "MVX+" not in self.fusion_method else self.fusion_method[4:]
@@ -892,7 +967,8 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
                                     batch_dict["lidar2img"].float().contiguous(), x_rgb[0], hw, rows=rows,
                                     out=v_i.view(B * n_max, -1), grid=grid.view(B * n_max, 2))
             v_feat.view(B * n_max, C).index_copy_(0, rows, feats)
-            enh = self.actr(v_feat=v_feat, v_i_feat=v_i, grid=grid, i_feats=x_rgb, lidar_grid=pts)
+            i_feats = x_rgb if self.ifat is None else self._gate_images(x_rgb, [x_conv2, x_conv3, x_conv4], batch_dict)
+            enh = self.actr(v_feat=v_feat, v_i_feat=v_i, grid=grid, i_feats=i_feats, lidar_grid=pts)
             return x_conv4.replace_feature(enh.reshape(B * n_max, -1).index_select(0, rows) + feats)   # fuse_sum=True (:808-810)
         if uv is None:
             uv = self._pixels(xyz, b, batch_dict)
@@ -903,8 +979,14 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         v_feat[b, slot] = feats
         v_i[b, slot] = i_feat
         grid[b, slot] = uv / _ops.device_constant([float(hw[1]), float(hw[0])], torch.float32, uv.device)
-        enh = self.actr(v_feat=v_feat, v_i_feat=v_i, grid=grid, i_feats=x_rgb, lidar_grid=pts)
+        i_feats = x_rgb if self.ifat is None else self._gate_images(x_rgb, [x_conv2, x_conv3, x_conv4], batch_dict)
+        enh = self.actr(v_feat=v_feat, v_i_feat=v_i, grid=grid, i_feats=i_feats, lidar_grid=pts)
         return x_conv4.replace_feature(enh[b, slot] + feats)                  # fuse_sum=True (:808-810)
+
+    def _gate_images(self, x_rgb, x_list, batch_dict):
+        """spconv_backbone.py:797-800: the image features ACTR attends over pass the image gate first (the queries' own image
+        features were sampled from the un-gated maps above, as in the reference)."""
+        return self.ifat(x_rgb, x_list, batch_dict, project=lambda x, stride: self._project(x, stride, batch_dict))
 
 
 BACKBONES_3D.register_module(VoxelBackBone8x)

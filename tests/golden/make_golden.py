@@ -1607,6 +1607,68 @@ def gen_vr_fusion():
     save("vr_fusion.npz", **out)
 
 
+def gen_vr_gate():
+    """The reference's own `BasicGate` (VR/pcdet/models/model_utils/attention.py:88-177, the image gate of
+    `voxel_rcnn_car_mm_mvx+actrv2_hybrid_ifat.yaml`; called at spconv_backbone.py:797-800 with x_list = [x_conv2, x_conv3,
+    x_conv4] and one image level): stride-2 voxels (32 channels) projected with its KITTI `Calibration.lidar_to_img`, scattered
+    by its `pts2img`, two 3x3 convolutions, sigmoid, product with the image features -- without and with augmentation records.
+    Its convolution stack lives in a plain Python list (not registered: no state_dict keys); the values are stored here."""
+    bb, cal, actr_mod, sp = import_reference_vr_backbone()
+    import importlib
+    sys.modules.pop("pcdet.models.model_utils.attention", None)          # the import harness above stubs it for the backbone
+    att_mod = importlib.import_module("pcdet.models.model_utils.attention")     # the reference's own file
+    torch.set_num_threads(1)
+    B, (H, W) = VRF["batch"], VRF["hw"]
+    rs = np.random.RandomState(23)
+    inds = []
+    for b in range(B):
+        n = 1500
+        x = rs.uniform(2, 60, n), rs.uniform(-25, 25, n), rs.uniform(-2.8, 0.8, n)      # part of them outside the image
+        zi = np.floor((x[2] + 3) / 0.2).astype(np.int32)
+        yi = np.floor((x[1] + 40) / 0.1).astype(np.int32)
+        xi = np.floor(x[0] / 0.1).astype(np.int32)
+        inds.append(np.unique(np.stack([np.full(n, b, np.int32), zi, yi, xi], 1), axis=0))
+    ind2 = np.concatenate(inds)
+    f2 = detgen.randn("vrg_f2", (len(ind2), 32))
+    img = detgen.randn("vrg_img", (B, 256, H // 4, W // 4))
+    gate = att_mod.BasicGate(img_channel_list=[256], pts_channel_list=[32], sparse_shape=[41, 1600, 1408],
+                             voxel_size=torch.tensor([0.1, 0.05, 0.05]), point_cloud_range=torch.tensor([-3., -40., 0., 1., 40., 70.4]),
+                             inv_idx=torch.tensor([2, 1, 0]), pts_idx=[0]).eval()
+    stack = gate.spatial_basic_list[0].eval()
+    shapes = {k: tuple(v.shape) for k, v in stack.state_dict().items()}
+    sd = detgen.det_state_dict(shapes)
+    stack.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    calibs, l2i = [], []
+    for b in range(B):
+        P2, R0, V2C = vrf_calib(b)
+        calibs.append(cal.Calibration(dict(P2=P2, R0=R0, Tr_velo2cam=V2C)))
+        R0e, Ve = np.eye(4), np.eye(4)
+        R0e[:3, :3], Ve[:3, :4] = R0, V2C
+        M = P2.astype(np.float64) @ R0e @ Ve
+        M[2] = (R0e @ Ve)[2]
+        l2i.append(M)
+    aug = dict(noise_scale=np.array([1.03, 0.96], np.float32), noise_rot=np.array([0.21, -0.33], np.float32),
+               flip_x=np.array([True, False]))
+    out = dict(ind2=ind2, lidar2img=np.stack(l2i), **{"stack_" + k: v for k, v in sd.items()})
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, with_aug in (("plain", False), ("aug", True)):
+            bd = dict(calib=calibs, batch_size=B, images=torch.zeros(B, 3, H, W))
+            if with_aug:
+                bd.update(noise_scale=torch.from_numpy(aug["noise_scale"]), noise_rot=torch.from_numpy(aug["noise_rot"]),
+                          flip_x=torch.from_numpy(aug["flip_x"]))
+            x2 = sp.SparseConvTensor(torch.from_numpy(f2.copy()), torch.from_numpy(ind2.copy()), [21, 800, 704], B)
+            with torch.no_grad():
+                y = gate(x_rgb=[torch.from_numpy(img)], x_list=[x2], batch_dict=bd)
+            out[tag + "_gated"] = y[0].numpy()[:, :4].copy()         # (the gate is one map per pixel: four channels pin it)
+            a = (y[0].numpy() / np.where(img == 0, 1, img))[:, 0]
+            print(tag, "gate range %.3f .. %.3f, pixels != sigmoid(bias-only) %d" % (a.min(), a.max(), int((np.abs(a - np.median(a)) > 1e-6).sum())))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    save("vr_gate.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["voxelize", "rulebook", "msda", "actr", "fusion", "pointops", "lt", "iou3d", "centerhead", "tfhead", "tfloss", "headloss", "conv_bwd", "pool", "conv_transpose"]
     if "iou3d" in which:
@@ -1644,6 +1706,8 @@ if __name__ == "__main__":
         gen_tf_fusion()
     if "vr_fusion" in which:
         gen_vr_fusion()
+    if "vr_gate" in which:
+        gen_vr_gate()
     if "fusion" in which:
         if "det3d" not in sys.modules:
             import_reference_actr()

@@ -634,3 +634,42 @@ def test_transfusion_encoder_frame_head_equals_inline():
     finally:
         ops.CONV_PRECISION = old
         enc.close()
+
+
+@pytest.mark.parametrize("tag,with_aug", [("plain", False), ("aug", True)])
+def test_voxel_rcnn_basic_gate_vs_reference_golden(golden, tag, with_aug):
+    """`I_FUSION_METHOD: BasicGate` of the Voxel-RCNN tree (round 4) against the reference's own class
+    (VR/pcdet/models/model_utils/attention.py:88-177; golden vr_gate.npz, make_golden.py gen_vr_gate): stride-2 voxels
+    projected through the KITTI calibration, `pts2img` (clamped pixels, last writer wins, cropped canvas), two 3 x 3
+    convolutions, sigmoid, product with the image features -- without and with augmentation records.  The projection runs
+    in fp32 on the device where the reference goes through numpy: a voxel within rounding of a pixel boundary may land in the
+    neighbouring pixel, which moves the 5 x 5 neighbourhood of that pixel; at most 1 % of the pixels may differ."""
+    import detgen
+    from dualfusion import spconv as sp
+    from dualfusion.backbones import VoxelBackBone8xFusion
+    from make_golden import VRF
+    dev = torch.device("cuda:0")
+    g = golden("vr_gate.npz")
+    cfg = dict(NAME='VoxelBackBone8xFusion', USE_IMG=True, FUSION_POS=[1, 4], FUSION_METHOD='MVX+ACTRv2', FEATURE_LEVELS=[0],
+               LT_CFG=dict(VRF["lt"]), ACTR_CFG=dict(VRF["actr"]), HYBRID_CFG=dict(VRF["hybrid"]),
+               I_FUSION_METHOD="BasicGate", IFAT_CFG=dict(img_num_channels=[256, 512, 1024], pts_num_channels=[32, 64, 64]))
+    m = VoxelBackBone8xFusion(cfg, 4, [1408, 1600, 40]).to(dev).eval()
+    assert m.ifat is not None and not any(k.startswith("ifat") for k in m.state_dict())     # unregistered, as in the reference
+    stack = m.ifat.spatial_basic_list[0].eval()
+    stack.load_state_dict({k[len("stack_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("stack_")})
+    B, (H, W) = VRF["batch"], VRF["hw"]
+    ind2 = g["ind2"]
+    f2 = detgen.randn("vrg_f2", (len(ind2), 32))
+    img = detgen.randn("vrg_img", (B, 256, H // 4, W // 4))
+    bd = dict(batch_size=B, lidar2img=torch.from_numpy(g["lidar2img"][:, :3].astype(np.float32)).to(dev), image_hw=(H, W))
+    if with_aug:
+        bd.update(noise_scale=torch.tensor([1.03, 0.96]).to(dev), noise_rot=torch.tensor([0.21, -0.33]).to(dev),
+                  flip_x=torch.tensor([True, False]).to(dev))
+    x2 = sp.SparseConvTensor(torch.from_numpy(f2).to(dev), torch.from_numpy(ind2).to(dev), [21, 800, 704], B)
+    with torch.no_grad():
+        y = m._gate_images([torch.from_numpy(img).to(dev)], [x2, None, None], bd)[0]
+    got, want = y[:, :4].cpu().numpy(), g[tag + "_gated"]
+    err = np.abs(got - want).max(1)                                  # per pixel
+    bad = (err > 1e-3 * np.abs(want).max()).mean()
+    assert bad <= 0.01, (tag, bad, float(err.max()))
+    assert np.median(err) < 1e-5

@@ -231,3 +231,29 @@ def test_oracle_tf_overlap_matches_cp_convention():
     assert (tf > 0).sum() > 200
     # the corner-containment margins differ (1e-5 vs 1e-2): touching configurations may gain / lose a sliver
     assert np.abs(tf - cp).max() < 5e-2 and np.median(np.abs(tf - cp)[tf > 0]) < 1e-5
+
+
+def test_voxel_rcnn_basic_gate_module_contract():
+    """`BasicGate` of the Voxel-RCNN tree (attention.py:88-177): constructor keys of the reference, the convolution stacks in a
+    plain list (no state_dict keys -- bug for bug), `pts2img` semantics of the canvas on the CPU: clamped pixels, last row
+    wins, the (H + 1) x (W + 1) canvas cropped."""
+    import types
+    from dualfusion.backbones import BasicGate
+    gate = BasicGate(img_channel_list=[256], pts_channel_list=[8], sparse_shape=[41, 1600, 1408], voxel_size=None,
+                     point_cloud_range=None, inv_idx=[2, 1, 0], pts_idx=[0])
+    assert len(gate.state_dict()) == 0 and len(gate.spatial_basic_list) == 1
+    mods = list(gate.spatial_basic_list[0])
+    assert [type(m).__name__ for m in mods] == ["Conv2d", "BatchNorm2d", "ReLU", "Conv2d"] and mods[-1].out_channels == 1
+    feats = torch.arange(5 * 8, dtype=torch.float32).view(5, 8) + 1
+    ind = torch.tensor([[0, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, 2], [1, 0, 0, 0], [1, 0, 0, 1]], dtype=torch.int32)
+    x = types.SimpleNamespace(features=feats, indices=ind, spatial_shape=[21, 800, 704])
+    # image 40 x 80, feature map 4 x 8: rows 0 and 1 hit the same pixel (1, 2); row 2 lies outside (clamped to the cropped
+    # border column); row 3 projects left of the image (clamped to column 0); row 4 to pixel (3, 7)
+    uv = torch.tensor([[25.0, 12.0], [29.9, 19.9], [95.0, 10.0], [-7.0, 5.0], [79.9, 39.9]])
+    c = gate.canvas(x, uv, (40, 80), (4, 8), 2)
+    assert tuple(c.shape) == (2, 8, 4, 8)
+    assert torch.equal(c[0, :, 1, 2], feats[1])                      # the later row wins
+    assert float(c[0].abs().sum()) == float(feats[1].abs().sum())    # row 2 fell into the cropped border
+    assert torch.equal(c[1, :, 0, 0], feats[3]) and torch.equal(c[1, :, 3, 7], feats[4])
+    out = gate([torch.ones(2, 256, 4, 8)], [x], dict(batch_size=2, image_hw=(40, 80)), project=lambda t, s: (None, uv))
+    assert tuple(out[0].shape) == (2, 256, 4, 8) and bool(((out[0] > 0) & (out[0] < 1)).all())
