@@ -727,9 +727,23 @@ int frame_head_run(HeadTicket &t) {
         HEAD_TAKE(t.out.counts, int32_t *, (size_t)B * d.ncam * 4);
         rc = df3d_query_slots(t.out.mask[p], T.indices, T.n, B, d.ncam, t.out.pos, t.out.counts, gs_);
         if (rc) return rc;
+        int32_t *ptot = nullptr;
+        if (d.want_pixrow && d.feat_h > 0 && d.feat_w > 0) {   // pixels that carry a query, ranked (df3d_query_pixel_rows)
+          const size_t wsb = df3d_query_pixel_rows_workspace_bytes(B, d.ncam, d.feat_h, d.feat_w);
+          void *ws;
+          HEAD_TAKE(t.out.pixrow, int32_t *, (size_t)B * d.ncam * d.feat_h * d.feat_w * 4);
+          HEAD_TAKE(ptot, int32_t *, 256);
+          HEAD_TAKE(ws, void *, wsb);
+          rc = df3d_query_pixel_rows(T.indices, t.out.grid_xy[p], t.out.mask[p], T.n, B, d.ncam, d.feat_h, d.feat_w, t.out.pixrow,
+                                     ptot, ws, wsb, gs_);
+          if (rc) return rc;
+        }
         std::vector<int32_t> qc((size_t)B * d.ncam, 0);
         DF3D_HIP(hipMemcpyAsync(qc.data(), t.out.counts, qc.size() * 4, hipMemcpyDeviceToHost, gs));
+        int32_t tot = 0;
+        if (ptot) DF3D_HIP(hipMemcpyAsync(&tot, ptot, 4, hipMemcpyDeviceToHost, gs));
         DF3D_HIP(hipStreamSynchronize(gs));               // the adapter's one host round trip: the longest camera list
+        t.out.pixrow_total = tot;
         int mx = 0;
         for (int v : qc) mx = v > mx ? v : mx;
         t.out.max_ne = mx;

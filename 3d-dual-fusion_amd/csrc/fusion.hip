@@ -456,6 +456,26 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const float *__restric
   att[t] = 1.f / (1.f + __expf(-acc));
 }
 
+// Pixels that carry a query: flag[img * HW + pixel] = 1 for every (camera, voxel) pair that is visible (round 4: the image
+// projection copies exactly these pixels' raw rows into a compact pixel-major buffer)
+__global__ __launch_bounds__(256) void mark_query_pixels_kernel(const int32_t *__restrict__ ind, const int32_t *__restrict__ grid,
+                                                                const uint8_t *__restrict__ mask, int n, int ncam, int H, int W,
+                                                                uint32_t *__restrict__ flag) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * ncam) return;
+  const int cam = (int)(t / n), i = (int)(t - (long long)cam * n);
+  if (!mask[t]) return;
+  const int img = ind[(size_t)i * 4] * ncam + cam;
+  const int gx = grid[t * 2], gy = grid[t * 2 + 1];
+  flag[(size_t)img * H * W + (size_t)gy * W + gx] = 1u;
+}
+
+__global__ __launch_bounds__(256) void pixrow_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ rank, size_t n,
+                                                     int32_t *__restrict__ pixrow) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pixrow[i] = flag[i] ? (int32_t)rank[i] : -1;
+}
+
 struct AsmArgs2 {
   const float *feat, *pinv;
   const int32_t *ind, *grid;
@@ -466,6 +486,8 @@ struct AsmArgs2 {
   const float *att;       // [B*ncam, H, W] or null
   int n, C, Ci, ncam, H, W, max_ne;
   float *v_feat, *v_i_feat, *qgrid, *qpts, *qpos;   // qpos [B*ncam, max_ne, C] depth sine embedding or null
+  const int32_t *pixrow;  // round 4: with `compact`, the image features come from the pixel-major rows compact[pixrow[img][pix]]
+  const float *compact;
 };
 
 // assemble_queries with (a) the gate applied on the fly to the sampled image feature and (b) the depth
@@ -486,8 +508,13 @@ __global__ __launch_bounds__(256) void assemble_queries2_kernel(AsmArgs2 a) {
   size_t hw = (size_t)a.H * a.W;
   size_t pix = (size_t)gy * a.W + gx;
   float g = a.att ? a.att[(size_t)img * hw + pix] : 1.f;
-  const float *src = (a.img ? a.img + (size_t)img * a.Ci * hw : a.img_ptrs[img]) + pix;
-  for (int c = lane; c < a.Ci; c += 64) a.v_i_feat[q * a.Ci + c] = src[(size_t)c * hw] * g;
+  if (a.compact) {
+    const float *src = a.compact + (size_t)a.pixrow[(size_t)img * hw + pix] * a.Ci;
+    for (int c = lane; c < a.Ci; c += 64) a.v_i_feat[q * a.Ci + c] = src[c] * g;
+  } else {
+    const float *src = (a.img ? a.img + (size_t)img * a.Ci * hw : a.img_ptrs[img]) + pix;
+    for (int c = lane; c < a.Ci; c += 64) a.v_i_feat[q * a.Ci + c] = src[(size_t)c * hw] * g;
+  }
   if (lane == 0) {
     a.qgrid[q * 2 + 0] = (float)gx / (float)a.W;
     a.qgrid[q * 2 + 1] = (float)gy / (float)a.H;
@@ -774,12 +801,12 @@ extern "C" int df3d_gate_finish(const float *gate, const float *S, const float *
   return DF3D_OK;
 }
 
-extern "C" int df3d_assemble_queries2(const float *features, const float *point_inv, const int32_t *indices,
-                                      const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
-                                      const float *img_feats, const float *const *img_ptrs, const float *att, int n,
-                                      int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
-                                      float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
-                                      const int32_t *counts, void *stream_) {
+static int assemble_queries2_impl(const float *features, const float *point_inv, const int32_t *indices,
+                                  const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
+                                  const float *img_feats, const float *const *img_ptrs, const float *att, int n,
+                                  int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
+                                  float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
+                                  const int32_t *counts, const int32_t *pixrow, const float *compact, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(v_feat && v_i_feat && qgrid && qpts, "assemble_queries2: null output");
   size_t nq = (size_t)batch * ncam * max_ne;
@@ -799,10 +826,15 @@ extern "C" int df3d_assemble_queries2(const float *features, const float *point_
     }
   }
   if (n == 0 || max_ne == 0) return DF3D_OK;
-  DF3D_CHECK_ARG(features && point_inv && indices && grid_xy && mask && pos && (img_feats || img_ptrs),
+  DF3D_CHECK_ARG(features && point_inv && indices && grid_xy && mask && pos && (img_feats || img_ptrs || compact),
                  "assemble_queries2: null input");
   AsmArgs2 a = {features, point_inv, indices, grid_xy, mask, pos, img_feats, img_ptrs, att, n, channels, img_channels, ncam, H, W,
-                max_ne, v_feat, v_i_feat, qgrid, qpts, qpos};
+                max_ne, v_feat, v_i_feat, qgrid, qpts, qpos, pixrow, compact};
+  if (compact) {                       // contiguous 1 KB rows: the wave-per-query kernel reads them at full width
+    hipLaunchKernelGGL(assemble_queries2_kernel, dim3(cdiv((long long)n * ncam * 64, 256)), dim3(256), 0, stream, a);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+  }
   // measured on MI355X: lanes over queries 265 -> ~150 us at four samples x six cameras (TransFusion tree, step 8.02 -> 7.91 ms),
   // but 96-100 us against 82-85 us of the wave-per-query kernel at one sample (too few workgroups): chosen by image count;
   // DF3D_ASSEMBLE=1 / 2 forces one or the other
@@ -812,6 +844,64 @@ extern "C" int df3d_assemble_queries2(const float *features, const float *point_
     hipLaunchKernelGGL(assemble_queries3_kernel, dim3(cdiv(max_ne, 64), batch * ncam, cdiv(img_channels, ASM3_CH)), dim3(256), 0, stream, a, counts);
   else
     hipLaunchKernelGGL(assemble_queries2_kernel, dim3(cdiv((long long)n * ncam * 64, 256)), dim3(256), 0, stream, a);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_assemble_queries2(const float *features, const float *point_inv, const int32_t *indices,
+                                      const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
+                                      const float *img_feats, const float *const *img_ptrs, const float *att, int n,
+                                      int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
+                                      float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
+                                      const int32_t *counts, void *stream_) {
+  return assemble_queries2_impl(features, point_inv, indices, grid_xy, mask, pos, img_feats, img_ptrs, att, n, channels,
+                                img_channels, batch, ncam, H, W, max_ne, v_feat, v_i_feat, qgrid, qpts, qpos, counts, nullptr,
+                                nullptr, stream_);
+}
+
+// the same with the image features read from pixel-major rows (df3d_query_pixel_rows + df3d_imgproj_split_compact)
+extern "C" int df3d_assemble_queries2_compact(const float *features, const float *point_inv, const int32_t *indices,
+                                              const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
+                                              const int32_t *pixrow, const float *compact, const float *att, int n, int channels,
+                                              int img_channels, int batch, int ncam, int H, int W, int max_ne, float *v_feat,
+                                              float *v_i_feat, float *qgrid, float *qpts, float *qpos, const int32_t *counts,
+                                              void *stream_) {
+  DF3D_CHECK_ARG(pixrow && compact, "assemble_queries2_compact: null pixel rows");
+  return assemble_queries2_impl(features, point_inv, indices, grid_xy, mask, pos, nullptr, nullptr, att, n, channels,
+                                img_channels, batch, ncam, H, W, max_ne, v_feat, v_i_feat, qgrid, qpts, qpos, counts, pixrow,
+                                compact, stream_);
+}
+
+static size_t df3d_query_pixel_rows_workspace_bytes_impl(long long npix) {
+  return align_up((size_t)npix * 4, 256) * 2 + scan_scratch_bytes((size_t)npix) + 256;
+}
+
+extern "C" size_t df3d_query_pixel_rows_workspace_bytes(int batch, int ncam, int H, int W) {
+  return df3d_query_pixel_rows_workspace_bytes_impl((long long)batch * ncam * H * W);
+}
+
+// pixrow[img * H * W + pixel] = rank of the pixel among the pixels some query of image `img` samples (image-major, row-major
+// order), -1 elsewhere; *total (device) = their number.  Depends on the projection alone: the frame head runs it.
+extern "C" int df3d_query_pixel_rows(const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask, int n, int batch,
+                                     int ncam, int H, int W, int32_t *pixrow, int32_t *total, void *workspace,
+                                     size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(pixrow && total && workspace && batch > 0 && ncam > 0 && H > 0 && W > 0, "query_pixel_rows: bad arguments");
+  const long long npix = (long long)batch * ncam * H * W;
+  DF3D_CHECK_ARG(workspace_bytes >= df3d_query_pixel_rows_workspace_bytes_impl(npix), "query_pixel_rows: workspace too small");
+  char *ws = (char *)workspace;
+  uint32_t *flag = (uint32_t *)ws;
+  uint32_t *rank = (uint32_t *)(ws + align_up((size_t)npix * 4, 256));
+  void *scratch = ws + 2 * align_up((size_t)npix * 4, 256);
+  DF3D_HIP(hipMemsetAsync(flag, 0, (size_t)npix * 4, stream));
+  if (n > 0) {
+    DF3D_CHECK_ARG(indices && grid_xy && mask, "query_pixel_rows: null input");
+    hipLaunchKernelGGL(mark_query_pixels_kernel, dim3(cdiv((long long)n * ncam, 256)), dim3(256), 0, stream, indices, grid_xy, mask,
+                       n, ncam, H, W, flag);
+  }
+  int rc = exclusive_scan_u32(flag, rank, (size_t)npix, (uint32_t *)total, scratch, scan_scratch_bytes((size_t)npix), stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pixrow_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, stream, flag, rank, (size_t)npix, pixrow);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

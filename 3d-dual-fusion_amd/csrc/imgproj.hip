@@ -75,6 +75,11 @@ struct ProjArgs2 {
   float *gate;               // [NI][S] row 128 of Wcat . img (no bias)
   int S;
   int dbg;                   // tuning experiments (DF3D_IP_DBG): 1 = no image loads, 2 = no MFMAs, 4 = no W loads, 8 = no stores
+  // round 4: pixel-major copies of the RAW 256-channel rows of the pixels a query samples (pixrow[img * S + p] = row of the
+  // compact buffer or -1; NULL = none): the tile passes through LDS anyway, and the query assembly then reads one contiguous
+  // 1 KB row per query instead of 256 scattered 4-byte elements of the channel-first map
+  const int32_t *pixrow;
+  float *compact;            // [marked pixels][256]
 };
 
 __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
@@ -135,6 +140,22 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
 #pragma unroll
   for (int t = 0; t < IP_MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // the tile's marked pixels as a compact list (pixel in tile | row of the compact buffer): ~13 % of the pixels
+  __shared__ int mlist[IP_TP][2];
+  __shared__ int mcount;
+  if (a.pixrow) {
+    if (tid == 0) mcount = 0;
+    __syncthreads();
+    if (tid < IP_TP && p0 + tid < S) {
+      const int r = a.pixrow[(size_t)blockIdx.y * S + p0 + tid];
+      if (r >= 0) {
+        const int at = atomicAdd(&mcount, 1);
+        mlist[at][0] = tid;
+        mlist[at][1] = r;
+      }
+    }
+  }
+
   load_tiles(0);
   store_tiles(0);
   load_tiles(1);
@@ -142,6 +163,14 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
     __syncthreads();
     if (kb + 1 < 8) store_tiles((kb + 1) & 1);
     if (kb + 2 < 8) load_tiles(kb + 2);
+    if (a.pixrow) {
+      // this step's 32 channels of every marked pixel: half a wave per pixel, one 128-byte segment each
+      const int nm = mcount;
+      for (int m = tid >> 5; m < nm; m += 16) {
+        const int px = mlist[m][0], k = tid & 31;
+        a.compact[(size_t)mlist[m][1] * IP_CIN + kb * 32 + k] = Xl[kb & 1][k * IP_LD + px];
+      }
+    }
     // B operand: the 8 k-values of this lane's pixel, read transposed from the staged tile, split hi/lo
     const float *xb = &Xl[kb & 1][(g * 8) * IP_LD + wave * 16 + n];
     u32x4 bh, bl;
@@ -400,7 +429,19 @@ extern "C" int df3d_imgproj_split(const float *const *img_ptrs, int nimg, int ci
   DF3D_CHECK_ARG(cin == IP_CIN, "imgproj_split: serves 256 input channels (got %d)", cin);
   if (nimg == 0 || S == 0) return DF3D_OK;
   ProjArgs2 a = {img_ptrs, (const u32x4 *)packed, (u32x4 *)u_split, gate, S,
-                 getenv("DF3D_IP_DBG") ? atoi(getenv("DF3D_IP_DBG")) : 0};
+                 getenv("DF3D_IP_DBG") ? atoi(getenv("DF3D_IP_DBG")) : 0, nullptr, nullptr};
+  hipLaunchKernelGGL(img_proj_split_kernel, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_imgproj_split_compact(const float *const *img_ptrs, int nimg, int cin, int S, const void *packed,
+                                          void *u_split, float *gate, const int32_t *pixrow, float *compact, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(img_ptrs && packed && u_split && gate && pixrow && compact, "imgproj_split_compact: null argument");
+  DF3D_CHECK_ARG(cin == IP_CIN, "imgproj_split_compact: serves 256 input channels (got %d)", cin);
+  if (nimg == 0 || S == 0) return DF3D_OK;
+  ProjArgs2 a = {img_ptrs, (const u32x4 *)packed, (u32x4 *)u_split, gate, S, 0, pixrow, compact};
   hipLaunchKernelGGL(img_proj_split_kernel, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;

@@ -85,6 +85,14 @@ SIGNATURES = {
     "df3d_gate_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_int, c_void_p]),
     "df3d_gate_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_query_pixel_rows_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "df3d_query_pixel_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
+    "df3d_assemble_queries2_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_imgproj_split_compact": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     "df3d_gate_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "df3d_gate_finish_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_fusion_writeback_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

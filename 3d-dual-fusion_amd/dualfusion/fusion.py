@@ -308,7 +308,7 @@ class VoxelWithPointProjection(nn.Module):
         return hit
 
     # ------------------------------------------------------------------ image-side projection
-    def _image_projection(self, inp, img_conv_func=None):
+    def _image_projection(self, inp, img_conv_func=None, pixrow=None):
         """`both` [NI, C(+1+pad), H*W] = input_proj 1x1 conv of every camera map WITHOUT bias (+ the gate's 1-channel
         image summary as an extra row when the image gate is configured): one GEMM per map, written in place."""
         imgs = inp['imgs']
@@ -337,6 +337,12 @@ class VoxelWithPointProjection(nn.Module):
             key = (wcat.data_ptr(), wcat._version)
             if self._wpack is None or self._wpack[0] != key:
                 self._wpack = (key, _ops.imgproj_pack(wcat.contiguous()))
+            if pixrow is not None and os.environ.get("DF3D_ASSEMBLE_COMPACT", "0") == "1":
+                # (round 4, opt-in) also the raw rows of the pixels the queries sample, pixel-major, for the query assembly.
+                # Measured on MI355X: the assembly 77 -> 63 us (it still moves ~110 MB of query rows), the projection
+                # 121 -> 155 us (the per-step copies sit inside its main loop): a loss, so off by default
+                return _ops.imgproj_split(inp['img_ptrs'], len(imgs), imgs[0].shape[0], S_pix, self._wpack[1],
+                                          pixrow=pixrow[0], pixrow_total=pixrow[1])
             return _ops.imgproj_split(inp['img_ptrs'], len(imgs), imgs[0].shape[0], S_pix, self._wpack[1])
         # The camera network runs the cameras as one batch, so the per-camera dict entries are normally views of one
         # tensor at a uniform stride: then the projection is a single batched GEMM over that storage (still no copy).
@@ -401,7 +407,8 @@ class VoxelWithPointProjection(nn.Module):
         if (id(batch_dict), layer_name) in self._prefetched or (prep is not None and prep[0] == id(batch_dict)
                                                                  and "both" in prep[2]):
             return                                            # already projected (side stream / frame-head worker)
-        both = self._image_projection(inp, img_conv_func)
+        pixrow = prep[2].get("pixrow") if (prep is not None and prep[0] == id(batch_dict) and img_conv_func is None) else None
+        both = self._image_projection(inp, img_conv_func, pixrow=pixrow)
         self._remember_prefetched(batch_dict, layer_name, inp, both, None)
 
     def prepare_geometry(self, batch_dict, layer_name, levels, d_factor_list):
@@ -439,7 +446,8 @@ class VoxelWithPointProjection(nn.Module):
         req = dict(inp=inp, levels=levels, slots_level=last, pc_min=[float(np.float32(v)) for v in self.pc_range[:3]],
                    image_scale=self.image_scale, ready=ready,
                    # the image gate's "winning voxel per pixel" maps depend on the coordinates alone as well
-                   winner_levels=tuple(self.ifat.voxel_idx) if self.ifat_cfg is not None else ())
+                   winner_levels=tuple(self.ifat.voxel_idx) if self.ifat_cfg is not None else (),
+                   want_pixrow=os.environ.get("DF3D_ASSEMBLE_COMPACT", "0") == "1")
         packed = self._native_projection_weights(inp)
         if packed is not None and os.environ.get("DF3D_IMGPROJ_AHEAD", "0") == "1":
             # the image-side projection depends on the camera maps alone: the worker can run it too, on a second stream of
@@ -659,7 +667,8 @@ class VoxelWithPointProjection(nn.Module):
             inp, both = prep['inp'], prep['both']          # projected by the frame-head worker (the caller's stream waited)
         else:
             inp = prep['inp'] if prep is not None else self._gather_inputs(batch_dict, layer_name, dev)
-            both = self._image_projection(inp, img_conv_func)
+            both = self._image_projection(inp, img_conv_func,
+                                          pixrow=prep.get("pixrow") if (prep is not None and img_conv_func is None) else None)
         B, ncam = inp['B'], inp['ncam']
         NI = B * ncam
         H, W = inp['h'], inp['w']
@@ -761,10 +770,18 @@ class VoxelWithPointProjection(nn.Module):
         qpts = torch.empty((NI, max_ne, 3), dtype=torch.float32, device=dev)
         depth_pos = self.pfat.pos_encode_method == "depth"
         qpos = torch.empty((NI, max_ne, C), dtype=torch.float32, device=dev) if depth_pos else None
-        rc = lib.df3d_assemble_queries2(_p(feats), _p(pinv), _p(ind), _p(grid), _p(mask), _p(pos), None, _p(inp['img_ptrs']), _p(att), n,
-                                        C, Ci, B, ncam, H, W, max_ne, _p(v_feat), _p(v_i_feat), _p(qgrid), _p(qpts),
-                                        _p(qpos), _p(counts), _ops._stream())
-        _lib.check(rc, "df3d_assemble_queries2")
+        compact = both[2] if (isinstance(both, tuple) and len(both) > 2 and prep is not None and "pixrow" in prep) else None
+        if compact is not None:
+            # the image rows of the sampled pixels are pixel-major (written by the image projection): one 1 KB row per query
+            rc = lib.df3d_assemble_queries2_compact(_p(feats), _p(pinv), _p(ind), _p(grid), _p(mask), _p(pos), _p(prep["pixrow"][0]),
+                                                    _p(compact), _p(att), n, C, Ci, B, ncam, H, W, max_ne, _p(v_feat),
+                                                    _p(v_i_feat), _p(qgrid), _p(qpts), _p(qpos), _p(counts), _ops._stream())
+            _lib.check(rc, "df3d_assemble_queries2_compact")
+        else:
+            rc = lib.df3d_assemble_queries2(_p(feats), _p(pinv), _p(ind), _p(grid), _p(mask), _p(pos), None, _p(inp['img_ptrs']),
+                                            _p(att), n, C, Ci, B, ncam, H, W, max_ne, _p(v_feat), _p(v_i_feat), _p(qgrid),
+                                            _p(qpts), _p(qpos), _p(counts), _ops._stream())
+            _lib.check(rc, "df3d_assemble_queries2")
         # (a10-a12) ACTR
         if fold:
             enh = self.pfat.forward_folded(v_feat, qgrid, both[0] if isinstance(both, tuple) else both,

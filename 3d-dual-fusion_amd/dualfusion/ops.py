@@ -1610,11 +1610,20 @@ def imgproj_pack(wcat):
     return packed
 
 
-def imgproj_split(img_ptrs, nimg, cin, S, packed):
-    """-> (u_split uint8 [nimg, S, 512], gate fp32 [nimg, S]) from the camera maps behind the pointer table."""
+def imgproj_split(img_ptrs, nimg, cin, S, packed, pixrow=None, pixrow_total=0):
+    """-> (u_split uint8 [nimg, S, 512], gate fp32 [nimg, S]) from the camera maps behind the pointer table.
+    pixrow [nimg, S] int32 (df3d_query_pixel_rows) with pixrow_total marked pixels: also -> compact fp32 [pixrow_total, cin],
+    the raw rows of the marked pixels, pixel-major (third element of the result)."""
     lib = _lib.load()
     u = torch.empty((nimg, S, 512), dtype=torch.uint8, device=packed.device)
     gate = torch.empty((nimg, S), dtype=torch.float32, device=packed.device)
+    if pixrow is not None and pixrow_total > 0:
+        _chk(pixrow, torch.int32, "pixrow")
+        compact = torch.empty((int(pixrow_total), cin), dtype=torch.float32, device=packed.device)
+        rc = lib.df3d_imgproj_split_compact(_ptr(img_ptrs), nimg, cin, S, _ptr(packed), _ptr(u), _ptr(gate), _ptr(pixrow),
+                                            _ptr(compact), _stream())
+        _lib.check(rc, "df3d_imgproj_split_compact")
+        return u, gate, compact
     rc = lib.df3d_imgproj_split(_ptr(img_ptrs), nimg, cin, S, _ptr(packed), _ptr(u), _ptr(gate), _stream())
     _lib.check(rc, "df3d_imgproj_split")
     return u, gate

@@ -39,7 +39,7 @@ class _Desc(ctypes.Structure):
                 ("proj", _Project * MAX_PROJ), ("slots_proj", ctypes.c_int), ("inputs_ready", ctypes.c_void_p),
                 ("img_ptrs", ctypes.c_void_p), ("img_count", ctypes.c_int), ("img_cin", ctypes.c_int),
                 ("img_pixels", ctypes.c_int), ("img_packed", ctypes.c_void_p), ("feat_h", ctypes.c_int),
-                ("feat_w", ctypes.c_int)]
+                ("feat_w", ctypes.c_int), ("want_pixrow", ctypes.c_int)]
 
 
 class _Out(ctypes.Structure):
@@ -47,7 +47,8 @@ class _Out(ctypes.Structure):
                 ("grid_xy", ctypes.c_void_p * MAX_PROJ), ("mask", ctypes.c_void_p * MAX_PROJ),
                 ("point_inv", ctypes.c_void_p * MAX_PROJ), ("proj_n", ctypes.c_int * MAX_PROJ), ("pos", ctypes.c_void_p),
                 ("counts", ctypes.c_void_p), ("img_split", ctypes.c_void_p), ("img_gate", ctypes.c_void_p),
-                ("img_done", ctypes.c_void_p), ("winner", ctypes.c_void_p * MAX_PROJ)]
+                ("img_done", ctypes.c_void_p), ("winner", ctypes.c_void_p * MAX_PROJ), ("pixrow", ctypes.c_void_p),
+                ("pixrow_total", ctypes.c_int)]
 
 
 class Prepared(object):
@@ -143,6 +144,7 @@ class FrameHead(object):
                 if lvl == cam["slots_level"]:
                     d.slots_proj = j
             d.feat_h, d.feat_w = int(inp["h"]), int(inp["w"])
+            d.want_pixrow = int(bool(cam.get("want_pixrow")))
             if cam.get("ready") is not None:
                 d.inputs_ready = cam["ready"].cuda_event
                 keep.append(cam["ready"])
@@ -226,6 +228,8 @@ class FrameHead(object):
                 early = (view(out.pos, ncam * m * 4, torch.int32, (ncam, m)), int(out.max_ne),
                          view(out.counts, B * ncam * 4, torch.int32, (B * ncam,)))
             prep.fusion = dict(inp=cam["inp"], proj=proj, early=early, winner=winners)
+            if out.pixrow:
+                prep.fusion["pixrow"] = (view(out.pixrow, B * ncam * hw * 4, torch.int32, (B * ncam, hw)), int(out.pixrow_total))
             if out.img_split:
                 ni, px = int(t.job[0].img_count), int(t.job[0].img_pixels)
                 prep.fusion["both"] = (view(out.img_split, ni * px * 512, torch.uint8, (ni, px, 512)),

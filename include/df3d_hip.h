@@ -653,6 +653,20 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
                            int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
                            float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
                            const int32_t *counts, void *stream);
+/* round 4 -- the queries' image features from PIXEL-MAJOR rows instead of 256 scattered elements of the channel-first map:
+ * df3d_query_pixel_rows: pixrow [batch*ncam*H*W] i32 = rank of every pixel some visible voxel projects to (image-major, -1
+ *   elsewhere), *total (device i32) = their number; depends on the projection alone (the frame head runs it a frame ahead);
+ * df3d_imgproj_split_compact: df3d_imgproj_split that also copies the raw 256-channel rows of exactly these pixels into
+ *   compact [total][256] (the tile is in LDS anyway);
+ * df3d_assemble_queries2_compact: df3d_assemble_queries2 reading compact[pixrow[image][pixel]] -- same values. */
+size_t df3d_query_pixel_rows_workspace_bytes(int batch, int ncam, int H, int W);
+int df3d_query_pixel_rows(const int32_t *indices, const int32_t *grid_xy, const uint8_t *mask, int n, int batch, int ncam, int H,
+                          int W, int32_t *pixrow, int32_t *total, void *workspace, size_t workspace_bytes, void *stream);
+int df3d_assemble_queries2_compact(const float *features, const float *point_inv, const int32_t *indices, const int32_t *grid_xy,
+                                   const uint8_t *mask, const int32_t *pos, const int32_t *pixrow, const float *compact,
+                                   const float *att, int n, int channels, int img_channels, int batch, int ncam, int H, int W,
+                                   int max_ne, float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
+                                   const int32_t *counts, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Split-precision sparse convolution (csrc/spconv_split.hip): same contract as df3d_sparse_conv_fused
@@ -780,6 +794,8 @@ size_t df3d_imgproj_packed_bytes(int rows, int cin);
 int df3d_imgproj_pack(const float *wcat, int rows, int cin, void *packed, void *stream);
 int df3d_imgproj_split(const float *const *img_ptrs, int nimg, int cin, int S, const void *packed, void *u_split,
                        float *gate, void *stream);
+int df3d_imgproj_split_compact(const float *const *img_ptrs, int nimg, int cin, int S, const void *packed, void *u_split,
+                               float *gate, const int32_t *pixrow, float *compact, void *stream);
 int df3d_value_fold_gemm(const void *u_split, const float *att, int nimg, int S, const float *conv_bias,
                          const float *gn_weight, const float *gn_bias, float eps, int groups, const float *W,
                          const float *wb, double *moments, void *packed_w, float *cf, float *value, void *stream);
@@ -925,6 +941,7 @@ typedef struct df3d_frame_head_desc {
   int img_count, img_cin, img_pixels;
   const void *img_packed;           /* df3d_imgproj_pack */
   int feat_h, feat_w;               /* camera feature map size (winner maps) */
+  int want_pixrow;                  /* != 0: also df3d_query_pixel_rows of the query stage */
 } df3d_frame_head_desc;
 
 typedef struct df3d_frame_head_out {
@@ -942,6 +959,8 @@ typedef struct df3d_frame_head_out {
   float *img_gate;                  /* [img_count][img_pixels] */
   void *img_done;                   /* hipEvent_t (owned by the handle): the projection is complete */
   int32_t *winner[DF3D_HEAD_MAX_PROJ];    /* [batch * ncam, feat_h, feat_w] or NULL */
+  int32_t *pixrow;                  /* df3d_query_pixel_rows of the query stage ([batch * ncam * feat_h * feat_w]) or NULL */
+  int pixrow_total;                 /* pixels that carry a query */
 } df3d_frame_head_out;
 
 void *df3d_head_worker_create(int device);
