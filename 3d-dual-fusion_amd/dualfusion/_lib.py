@@ -257,9 +257,19 @@ class Df3dError(RuntimeError):
     pass
 
 
+class StreamArg(c_void_p):
+    """What ops._stream() passes as the stream of a launch: lets a recording launch tape (dualfusion/tape.py) tell launches
+    from queries and find the argument to rewrite."""
+
+
+_recorder = None        # dualfusion/tape.py: stands in for the library while a launch tape records
+
+
 def load():
     """Load (once) and return the ctypes handle.  Raises loudly when the library is absent."""
     global _lib
+    if _recorder is not None:
+        return _recorder
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):

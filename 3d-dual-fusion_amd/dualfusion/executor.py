@@ -9,6 +9,7 @@ bit-identical."""
 import ctypes
 import os
 import threading
+import time
 
 import torch
 from torch import nn
@@ -142,12 +143,21 @@ class BackbonePlan(object):
         from -- filters, conv biases, BatchNorm weight / bias / running_mean / running_var.  Version counters are bumped by
         every in-place update (load_state_dict, optimizer steps, `bn.bias.add_()` under no_grad ...); addresses catch re-assigned
         parameters."""
+        slots = self.__dict__.get("_sig_slots")
+        if slots is None:
+            # (dict, key) of every tensor, looked up in the modules' own _parameters / _buffers dicts: this runs twice per frame
+            # and nn.Module.__getattr__ costs more than the check itself
+            slots = []
+            for s in self.specs:
+                slots += [(s.conv._parameters, "weight"), (s.conv._parameters, "bias")]
+                if s.bn is not None:
+                    slots += [(s.bn._parameters, "weight"), (s.bn._parameters, "bias"),
+                              (s.bn._buffers, "running_mean"), (s.bn._buffers, "running_var")]
+            self.__dict__["_sig_slots"] = slots
         sig = []
-        for s in self.specs:
-            ts = [s.conv.weight, getattr(s.conv, "bias", None)]
-            if s.bn is not None:
-                ts += [s.bn.weight, s.bn.bias, s.bn.running_mean, s.bn.running_var]
-            sig.extend((t.data_ptr(), t._version) if t is not None else None for t in ts)
+        for d, k in slots:
+            t = d.get(k)
+            sig.append(None if t is None else (t.data_ptr(), t._version))
         return (tuple(sig), _ops.CONV_PRECISION)
 
     def _build_table(self):
@@ -401,12 +411,16 @@ class _FrameRing(object):
         self.slots = [_FrameSlot() for _ in range(n)]
         self.next = 0
         self.last_consumed = None
+        self.blocked_s = 0.0       # host time spent waiting for a slot (the GPU is a whole ring behind)
 
     def acquire(self):
         slot = self.slots[self.next]
         self.next = (self.next + 1) % len(self.slots)
         if slot.guard is not None:
-            slot.guard.synchronize()
+            if not slot.guard.query():                 # the host is ahead of the GPU by the whole ring: back-pressure, not work
+                t0 = time.perf_counter()
+                slot.guard.synchronize()
+                self.blocked_s += time.perf_counter() - t0
         elif slot.pending:
             torch.cuda.synchronize()       # handed out and never guarded (a dropped frame): wait for everything
         slot.guard, slot.pending = None, True

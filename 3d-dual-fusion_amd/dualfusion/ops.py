@@ -19,8 +19,8 @@ def _stream():
     """Raw hipStream_t of torch's current stream (the C accessor is ~20x cheaper than torch.cuda.current_stream(),
     which showed up as 15 % of the host time of a step)."""
     if _raw_stream is not None:
-        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _lib.StreamArg(_raw_stream(torch.cuda.current_device()))
+    return _lib.StreamArg(torch.cuda.current_stream().cuda_stream)
 
 
 def _ptr(t):

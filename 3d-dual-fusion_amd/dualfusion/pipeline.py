@@ -29,6 +29,7 @@ class CenterPointHotPath(nn.Module):
         # set by a caller whose point clouds are complete in device memory before forward() is called (a data loader's
         # synchronised copies; bench.py): voxelisation then runs on its own stream (ops.hard_voxelize_clouds)
         self.resident_inputs = False
+        self.defer_neck = False          # CenterPointDetector's launch tape runs the neck itself (with the head)
         # optional BEV neck (necks.RPN): the backbone then hands over channels-last pixel
         # rows and forward returns the neck's [B, 512, 180, 180] map instead of the dense BEV tensor
         self.neck = neck
@@ -114,7 +115,7 @@ class CenterPointHotPath(nn.Module):
             else:
                 bev, multi = self.backbone(prep.feats, batch_dict, prep.coors, B, self.grid_size_xyz, example,
                                            fuse_func=self.fusion, prepared=prep.geometry)
-            if self.neck is not None:
+            if self.neck is not None and not self.defer_neck:
                 rows, (nb, _, h, w) = bev
                 bev = self.neck.forward_rows(rows, nb, h, w)
             return bev, multi
@@ -139,7 +140,7 @@ class CenterPointHotPath(nn.Module):
             bev, multi = self.backbone(feats, coors, B, self.grid_size_xyz)
         else:
             bev, multi = self.backbone(feats, batch_dict, coors, B, self.grid_size_xyz, example, fuse_func=self.fusion)
-        if self.neck is not None:
+        if self.neck is not None and not self.defer_neck:
             rows, (nb, _, h, w) = bev
             bev = self.neck.forward_rows(rows, nb, h, w)
         return bev, multi
@@ -240,10 +241,57 @@ class CenterPointDetector(nn.Module):
     def close(self):
         self.hot_path.close()
 
+    # ---- launch tape over neck + head (dualfusion/tape.py), opt-in: the predictions then live in the tape's buffers and are
+    #      valid until the next forward() of this detector
+    launch_tape = os.environ.get("DF3D_LAUNCH_TAPE", "0") == "1"
+
+    def train(self, mode=True):
+        tape = self.__dict__.get("_tail_tape")
+        if tape is not None:
+            tape.reset()
+        self.__dict__.pop("_tape_tensors", None)
+        return super(CenterPointDetector, self).train(mode)
+
+    def _tail_versions(self):
+        """Cheap change detector over every parameter / buffer of neck and head: the sum of the version counters (in-place
+        updates -- optimizer steps, load_state_dict -- bump them; train() / eval() drop the tapes)."""
+        ts = self.__dict__.get("_tape_tensors")
+        if ts is None:
+            mods = (self.hot_path.neck, self.bbox_head)
+            ts = self.__dict__["_tape_tensors"] = [t for m in mods for t in list(m.parameters()) + list(m.buffers())]
+        v = 0
+        for t in ts:
+            v += t._version
+        return v
+
+    def _neck_head(self, bev):
+        rows, (nb, _, h, w) = bev
+        return self.bbox_head(self.hot_path.neck.forward_rows(rows, nb, h, w))
+
+    def _taped_tail(self, bev):
+        from . import ops as _ops
+        from .necks import SplitRows
+        from .tape import TapedSection
+        rows, (nb, c, h, w) = bev
+        inp = rows.split if isinstance(rows, SplitRows) else rows
+        tape = self.__dict__.get("_tail_tape")
+        if tape is None:
+            tape = self.__dict__["_tail_tape"] = TapedSection()
+        key = (nb, c, h, w, tuple(inp.shape), inp.dtype, _ops.CONV_PRECISION, self._tail_versions(),
+               os.environ.get("DF3D_HEAD_FINAL"), os.environ.get("DF3D_HEADFINAL"))
+        return tape.run(key, lambda: self._neck_head(bev), [inp], _ops._stream())
+
     @torch.no_grad()
     def forward(self, points_list, batch_dict=None, example=None, return_loss=True):
-        x, _ = self.hot_path(points_list, batch_dict=batch_dict, example=example)
-        preds = self.bbox_head(x)
+        hp = self.hot_path
+        taped = (self.launch_tape and not self.training and hp.neck is not None and hasattr(hp.neck, "forward_rows")
+                 and getattr(hp.backbone, "dense_layout", "nchw") == "rows")
+        hp.defer_neck = taped
+        try:
+            x, _ = hp(points_list, batch_dict=batch_dict, example=example)
+        finally:
+            hp.defer_neck = False
+        preds = self._taped_tail(x) if taped else self.bbox_head(x)
         if return_loss:
             return self.bbox_head.loss_device(example, preds)
         return self.bbox_head.predict_device(preds, self.test_cfg)

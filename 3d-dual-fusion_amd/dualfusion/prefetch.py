@@ -82,7 +82,8 @@ class FrameHead(object):
         if not self.worker:
             raise _lib.Df3dError("df3d_head_worker_create failed")
         self._pending = {}
-        self.stats = {"submits": 0, "submit_s": 0.0, "takes": 0, "take_wait_s": 0.0, "take_s": 0.0}   # host seconds
+        # host seconds; take_wait_s = waiting for the worker, slot_wait_s = waiting for a frame slot (GPU a whole ring behind)
+        self.stats = {"submits": 0, "submit_s": 0.0, "takes": 0, "take_wait_s": 0.0, "take_s": 0.0, "slot_wait_s": 0.0}
 
     # ------------------------------------------------------------------ submit
     def submit(self, key, plan, points_list, vox, shape, cam=None, owner=None):
@@ -109,7 +110,9 @@ class FrameHead(object):
                 plan._build_table()
                 plan._sig = sig
             t.keep, t.sig = (plan._table, plan._keep), sig
+            b0 = plan._frames.blocked_s
             t.slot = plan._frames.acquire()
+            self.stats["slot_wait_s"] += plan._frames.blocked_s - b0
         B = len(points_list)
         d = _Desc()
         d.batch, d.point_channels = B, int(points_list[0].shape[1])

@@ -83,6 +83,9 @@ def parse():
                     help="cp_fusion / cp_lidar: do NOT start the next frame's voxelisation / rulebooks / query slots on the "
                          "detector's helper thread while the current frame is queued (round 3's behaviour: every count round "
                          "trip on the queueing thread)")
+    ap.add_argument("--no-tape", dest="tape", action="store_false",
+                    help="cp_fusion / cp_lidar: run neck + head through the module path every frame instead of re-issuing their "
+                         "recorded launches (dualfusion/tape.py; same kernels, same results, ~0.3 ms less host time per frame)")
     ap.add_argument("--no-side-configs", dest="side_configs", action="store_false",
                     help="skip the ~10-step passes over BASELINE configs[0] / [2] / [4] after the headline (N = 1 only)")
     ap.add_argument("--cpu-sweeps", type=int, default=20,
@@ -134,6 +137,7 @@ class CenterPointWorkload(object):
             fusion.resident_inputs = self.model.hot_path.resident_inputs
         self.num_classes = [t["num_class"] for t in NUSC_TASKS]
         self.prefetch = args.prefetch and self.model.hot_path.resident_inputs
+        self.model.launch_tape = bool(getattr(args, "tape", True))
         self.stride, self._staged = 1, {}
         self.frames = []
         for f in range(max(1, args.frames)):
@@ -594,6 +598,14 @@ def timed_steps(wl, stage, steps, first, barrier, reduce_losses):
     return time.perf_counter() - t0, out
 
 
+def host_blocked_s(wl):
+    """Host seconds a workload's detector has spent WAITING so far (for its helper thread's results, for a frame slot the GPU
+    has not released yet): back-pressure, not queueing work."""
+    ahead = getattr(getattr(getattr(wl, "model", None), "hot_path", None), "_ahead", None)
+    st = getattr(ahead, "stats", None)
+    return (st["take_wait_s"] + st["slot_wait_s"]) if st else 0.0
+
+
 def timed_steps_alternating(wls, streams, stage, steps, first, barrier):
     """The same K steps with len(wls) frames in flight from ONE host thread: step k is queued on stream k % F by detector
     replica k % F (frames are independent).  Every count round trip of a frame is taken by its replica's helper thread a frame
@@ -602,6 +614,7 @@ def timed_steps_alternating(wls, streams, stage, steps, first, barrier):
     F = len(wls)
     marks = []
     barrier()
+    blocked0 = sum(host_blocked_s(w) for w in wls)
     t0 = time.perf_counter()
     for k in range(steps):
         st = streams[k % F]
@@ -612,9 +625,11 @@ def timed_steps_alternating(wls, streams, stage, steps, first, barrier):
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(st)
         marks.append((e0, e1))
+    queued = time.perf_counter() - t0                    # the host has queued every step ...
+    queued -= sum(host_blocked_s(w) for w in wls) - blocked0     # ... minus the time it waited for the GPU / the helper thread
     barrier()
     el = time.perf_counter() - t0
-    return el, [a.elapsed_time(b) for a, b in marks]
+    return el, [a.elapsed_time(b) for a, b in marks], queued
 
 
 def timed_steps_in_flight(wls, stage, steps, first, barrier):
@@ -754,8 +769,9 @@ def main():
                 nf = len(wl.frames)
                 timed_steps_alternating(wls, streams, stage, 2 * nf, 0, barrier)        # every replica sees every frame once
                 if_steps = max(args.steps, 48)                    # (the pipeline fills and drains once per pass)
-                e, lat = timed_steps_alternating(wls, streams, stage, if_steps, 2 * nf, barrier)
+                e, lat, queued = timed_steps_alternating(wls, streams, stage, if_steps, 2 * nf, barrier)
                 extra["in_flight"], extra["in_flight_latency_ms"] = e * args.steps / if_steps, lat
+                extra["in_flight_host_ms"] = queued / if_steps * 1e3
                 for w in wls:
                     w.stride = 1
             else:
@@ -843,6 +859,9 @@ def main():
                                 "what": "the same K detector steps in ONE process, step k queued on stream k %% %d by detector "
                                         "replica k %% %d from one host thread; the count round trips of a frame are taken a "
                                         "frame ahead by the replica's helper thread; never `value`" % (args.inflight, args.inflight)}
+            if "in_flight_host_ms" in extra:
+                # (time spent waiting for the helper thread / for a frame slot the GPU still holds is not counted)
+                res["in_flight"]["host_ms_per_frame"] = round(extra["in_flight_host_ms"], 3)
             lat = extra.get("in_flight_latency_ms")
             if lat:
                 res["in_flight"]["frame_latency_ms"] = {"median": round(float(np.median(lat)), 3), "max": round(max(lat), 3),

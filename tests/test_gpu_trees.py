@@ -673,3 +673,76 @@ def test_voxel_rcnn_basic_gate_vs_reference_golden(golden, tag, with_aug):
     bad = (err > 1e-3 * np.abs(want).max()).mean()
     assert bad <= 0.01, (tag, bad, float(err.max()))
     assert np.median(err) < 1e-5
+
+
+def test_launch_tape_over_neck_and_head_equals_plain_detector():
+    """Round 4: neck + head of the CenterPoint detector re-issued from a launch tape (dualfusion/tape.py: the recorded C-ABI
+    calls with the stream and the input address rewritten, buffers from the tape's private pool) -- bit-identical head maps
+    and losses to the plain module path for every frame, through the warm-up / record / replay sequence, on a second stream,
+    and again after an in-place parameter update (which must re-record)."""
+    from dualfusion import synth
+    from dualfusion.pipeline import NUSC_TASKS, CenterPointDetector
+    dev = torch.device("cuda:0")
+    ncls = [t["num_class"] for t in NUSC_TASKS]
+    frames = []
+    for j in range(3):
+        tg = synth.centerhead_targets(1, ncls, seed=40 + j)
+        frames.append(([torch.from_numpy(synth.nusc_sweep(seed=90 + j)).to(dev)],
+                       {k: [torch.from_numpy(a).to(dev) for a in v] for k, v in tg.items()}))
+    torch.manual_seed(0)
+    plain = CenterPointDetector().eval().to(dev)
+    torch.manual_seed(0)
+    taped = CenterPointDetector().eval().to(dev)
+    taped.launch_tape = True
+
+    def run(m, pts, ex, loss):
+        out = m(pts, example=ex, return_loss=loss)
+        if loss:
+            return [torch.stack([v.float().reshape(()) for v in out[k]]).clone() for k in ("loss", "hm_loss", "loc_loss")]
+        return [t.clone() for t in out]                      # predict_device: (boxes, scores, labels, counts)
+
+    def maps(m, pts):
+        x, _ = m.hot_path(pts)
+        return [v.clone() for d in m.bbox_head(x) for _, v in sorted(d.items())]
+
+    with torch.no_grad():
+        want_maps = [maps(plain, pts) for pts, _ in frames]
+        for rnd in range(3):
+            for j, (pts, ex) in enumerate(frames):
+                for a, b in zip(run(taped, pts, ex, True), run(plain, pts, ex, True)):
+                    assert torch.equal(a, b), (rnd, j)
+        st = taped._tail_tape.stats
+        assert st["plain"] == 1 and st["recorded"] == 1 and st["replayed"] == 7, st
+        # the head maps themselves (the tape's result object), and detections decoded from them
+        for j, (pts, ex) in enumerate(frames):
+            hp = taped.hot_path
+            hp.defer_neck = True
+            try:
+                bev, _ = hp(pts)
+            finally:
+                hp.defer_neck = False
+            preds = taped._taped_tail(bev)
+            got = [v.clone() for d in preds for _, v in sorted(d.items())]
+            assert len(got) == len(want_maps[j]) and all(torch.equal(a, b) for a, b in zip(got, want_maps[j])), j
+            for a, b in zip(run(taped, pts, ex, False), run(plain, pts, ex, False)):
+                assert torch.equal(a, b), j
+        # another stream: the replay follows torch's current stream
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            got = run(taped, frames[1][0], frames[1][1], True)
+        side.synchronize()
+        for a, b in zip(got, run(plain, frames[1][0], frames[1][1], True)):
+            assert torch.equal(a, b)
+        # an in-place update of a parameter: the tape is stale, the next frames warm up / record / replay again
+        for m in (plain, taped):
+            bn = m.bbox_head.shared_conv[1]
+            bn.bias.add_(0.125)
+            m.hot_path.neck.blocks[0][1].weight.mul_(1.5)
+        before = dict(st)
+        for rnd in range(2):
+            for j, (pts, ex) in enumerate(frames):
+                for a, b in zip(run(taped, pts, ex, True), run(plain, pts, ex, True)):
+                    assert torch.equal(a, b), ("updated", rnd, j)
+        assert st["plain"] == before["plain"] + 1 and st["recorded"] == before["recorded"] + 1, st
+    torch.cuda.synchronize()
