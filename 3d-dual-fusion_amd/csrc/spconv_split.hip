@@ -608,8 +608,12 @@ __device__ u32x4 g_zero_row[192];          // up to 512 input channels, three pa
 // NP = precision parts of the operands: 2 = fp32 rows split into bf16 hi + lo (three MFMA products per pair, fp32-grade
 // result), 1 = plain bf16 rows and bf16 weights (one product, fp32 accumulate; rows are [N][C] bf16, the packed filter
 // bank holds the hi parts only, `out_split` receives bf16 rows and `residual` is read as bf16 rows).
-template <int CIN, int COUT, int RT, int NW, int KPS, int NP = 2>
-__global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs a) {
+// KS = wave groups per workgroup that split the OFFSETS of the tile between them (each with its own weight stages, the
+// accumulators meet in LDS before the epilogue): the 90 x 90 maps of the BEV neck have 127 row tiles x 2 column halves for
+// 256 CUs -- one wave per SIMD, every step an exposed chain of barrier, fragment reads and matrix instructions (a step costs
+// ~1500 clocks whatever its MFMA count); three groups put three waves on every SIMD without a second pass over memory.
+template <int CIN, int COUT, int RT, int NW, int KPS, int NP = 2, int KS = 1>
+__global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConvArgs a) {
   // KPS = 32-channel blocks per step (one barrier per step)
   // COUT = 256 is computed as two 128-column halves by different workgroups (blockIdx.y): twice the workgroups for
   // the small dense maps of the BEV neck and half the accumulator registers; the gathers of the second half hit L2
@@ -618,12 +622,15 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   constexpr int WQ = KPS * CT * NP * 64;          // u32x4 per W step tile
   constexpr int NT = NW * 64;
   constexpr int WPT = (WQ + NT - 1) / NT;
-  __shared__ u32x4 Wl[2][WQ];
+  __shared__ u32x4 Wl[KS][2][WQ];
   __shared__ int nbrL[DF3D_MAX_KVOL][TM];
   __shared__ int rowL[TM];
   __shared__ unsigned wg_mask;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (with KS groups: `tid` / `wave` are group-local below the neighbour-table pass, `grp` is uniform per wave)
+  const int wtid = threadIdx.x, lane = wtid & 63;
+  const int grp = KS > 1 ? __builtin_amdgcn_readfirstlane(wtid / NT) : 0;
+  const int tid = KS > 1 ? wtid - grp * NT : wtid, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
   int nt = gridDim.x, bid = blockIdx.x, tile = bid;
   tile = xcd_tile(bid, nt);                       // consecutive tiles stay on one XCD / L2
@@ -631,14 +638,14 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   const int col0 = blockIdx.y * CW;
 
   OS_STAMP(0);
-  if (tid == 0) wg_mask = 0u;
+  if (wtid == 0) wg_mask = 0u;
   __syncthreads();
   // neighbour tile -> LDS; a wave covers 64 rows (or TM) of one offset per pass, so the set of offsets with at
   // least one neighbour in the tile falls out of the same pass (one ballot per load)
   {
-    constexpr int KSTEP = NT / TM;               // offsets covered per pass (NT = 4*TM/RT... >= 1)
+    constexpr int KSTEP = NT * KS / TM;          // offsets covered per pass (NT = 4*TM/RT... >= 1)
     static_assert(NT % TM == 0 && KSTEP >= 1, "tile shape");
-    const int r = tid % TM, k0 = tid / TM;
+    const int r = wtid % TM, k0 = wtid / TM;
     // the tile's rows: consecutive, or -- with a tiling order -- whatever rows the order puts next to each other
     // (rows that are neighbours in space and share their neighbour pattern: fewer active offsets per tile, gathers
     // that stay inside one XCD's L2); n_out marks the padding of the last tile
@@ -665,8 +672,18 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     if (TM >= 64 && lane == 0 && mine) atomicOr(&wg_mask, mine);
   }
   __syncthreads();
-  const unsigned gmask = __builtin_amdgcn_readfirstlane(wg_mask);
-  const int nact = __popc(gmask);
+  unsigned gmask = __builtin_amdgcn_readfirstlane(wg_mask);
+  int nact = __popc(gmask);
+  if constexpr (KS > 1) {
+    // this group's share of the active offsets: a contiguous run of ceil(nact / KS) of them; every group walks as many
+    // steps as the longest share (the barriers are the workgroup's), the others multiply zero rows at the end
+    const int per = (nact + KS - 1) / KS;
+    unsigned rest = gmask, mine = 0u;
+    for (int i = 0; rest; ++i, rest &= rest - 1u)
+      if (i / per == grp) mine |= rest & (0u - rest);
+    gmask = mine;
+    nact = per;
+  }
   const int steps = nact * KB;
 
   f32x4 acc[RT][CT];
@@ -701,7 +718,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       int e = tid + NT * i;
-      if (WQ % NT == 0 || e < WQ) Wl[buf][e] = wreg[i];
+      if (WQ % NT == 0 || e < WQ) Wl[grp][buf][e] = wreg[i];
     }
   };
   // A fragments of the next AD steps in a register ring (AD sets, rotated by name: the step loop is unrolled AD times).
@@ -780,7 +797,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
     peek_a();                                      // neighbour indices of step s + AD
     constexpr int WPOS = (KPS * CT / 2) > 1 ? 1 : 0;
     if (WPOS == 0) stage_w();
-    const u32x4 *wb = Wl[s & 1] + lane;
+    const u32x4 *wb = Wl[grp][s & 1] + lane;
 #ifdef DF3D_OS_PRODUCT_MAJOR
     // experiment: the three products of a step run product-major over groups of G column tiles, so that two matrix
     // instructions on the same accumulator are G instructions apart (the default order keeps them 2 apart, and the
@@ -933,6 +950,26 @@ __global__ __launch_bounds__(NW * 64) void spconv_os_split_kernel(SplitConvArgs 
   if (a.trace && (threadIdx.x & 63) == 0) a.trace[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (threadIdx.x >> 6)) * 8 + 5] = steps;
 #endif
 
+  if constexpr (KS > 1) {
+    // the groups' partial sums meet in LDS (over the weight stages, which nobody reads any more); group 0 goes on alone
+    static_assert((KS - 1) * NW * RT * CT * 64 <= KS * 2 * WQ, "the partial sums must fit the weight stages");
+    f32x4 *red = (f32x4 *)&Wl[0][0][0];
+    __syncthreads();
+    if (grp > 0) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) red[((((grp - 1) * NW + wave) * RT + rt) * CT + ct) * 64 + lane] = acc[rt][ct];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int q = 1; q < KS; ++q)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] += red[((((q - 1) * NW + wave) * RT + rt) * CT + ct) * 64 + lane];
+  }
   // ---- epilogue: bias, folded BN, residual, ReLU; optional split rows of the result.  Lane n owns the CT
   //      consecutive columns n*CT .. n*CT+CT-1 of its rows (packed-weight layout 1): 16-byte stores ----
   static_assert(CT == 2 || CT == 4 || CT == 8, "COUT must be 32, 64, 128 or 256");
@@ -1556,6 +1593,17 @@ static int launch_os_split_wide(const SplitConvArgs &a, hipStream_t stream) {
   if (cfg && cfg[0] && cfg[1] == ',') {
     rt = cfg[0] - '0';
     nw = atoi(cfg + 2);
+  }
+  // Small maps (B = 1 at 90 x 90: 127 row tiles x 2 column halves of 4 waves = one wave per SIMD): three wave groups per
+  // workgroup share the offsets of the tile (KS = 3).  DF3D_OS_KSPLIT=0 turns it off (A/B; read per call).
+  if constexpr (CIN <= 256 && COUT % 128 == 0) {
+    const char *ks = getenv("DF3D_OS_KSPLIT");
+    const long long waves = (long long)cdiv(a.n_out, 64) * CS * 4;
+    if (!(cfg && cfg[0]) && nw == 4 && a.K >= 3 && !(ks && ks[0] == '0') && waves <= 6LL * num_cu()) {
+      hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 4, 1, 2, 3>), dim3(cdiv(a.n_out, 64), CS), dim3(768), 0,
+                         stream, a);
+      return DF3D_OK;
+    }
   }
 #define DF3D_OS_LAUNCH(RT, NW)                                                                                  \
   hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, RT, NW, 1>), dim3(cdiv(a.n_out, 16 * RT * NW), CS), \
