@@ -247,6 +247,8 @@ def test_loader_consumer_conv_kernel_forced_on_small_and_ragged_shapes(dev, cin,
     packed1 = ops.conv_pack_weights(T(filt[13:14].copy(), dev))
     bias, scale, shift = (T(detgen.randn("lc%s%d" % (t, cout), (cout,), 0.2), dev) for t in "bsh")
     old = os.environ.get("DF3D_OS_LC")
+    old_ks = os.environ.get("DF3D_OS_KSPLIT")
+    os.environ["DF3D_OS_KSPLIT"] = "0"          # (the register-gather kernel's offset split sums in another order: own test)
 
     def both(fn):
         os.environ["DF3D_OS_LC"] = "0"
@@ -278,10 +280,65 @@ def test_loader_consumer_conv_kernel_forced_on_small_and_ragged_shapes(dev, cin,
                     want = feats.astype(np.float64) @ filt[13].astype(np.float64) + bias.cpu().numpy()
                     assert np.abs(y1.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-9) < 5e-5
     finally:
+        if old_ks is None:
+            os.environ.pop("DF3D_OS_KSPLIT", None)
+        else:
+            os.environ["DF3D_OS_KSPLIT"] = old_ks
         if old is None:
             os.environ.pop("DF3D_OS_LC", None)
         else:
             os.environ["DF3D_OS_LC"] = old
+
+
+@pytest.mark.parametrize("cin,cout", [(256, 256), (128, 256)])
+def test_offset_split_wave_groups_match_the_single_group_kernel(dev, cin, cout):
+    """Round 4: the register-gather kernel with three wave groups per workgroup sharing a tile's offsets (small maps of the BEV
+    neck, `spconv_os_split_kernel<..., KS = 3>`; partial sums meet in LDS) against the single-group launch: the same products
+    in another summation order (<= 2e-6 of the output scale), split rows that are exactly the split of its own fp32 rows.
+    Dense 3 x 3 maps around the 64-row tile (ragged last tile, border tiles without some offsets), a 2 x 2 transposed table
+    (4 offsets: shares of 2 / 2 / 0), a 3-D rulebook with 27 offsets and sparse tiles, every epilogue combination."""
+    import os
+    from dualfusion import ops
+    bias, scale, shift = (T(detgen.randn("ks%s%d" % (t, cout), (cout,), 0.2), dev) for t in "bsh")
+    old = os.environ.get("DF3D_OS_KSPLIT")
+
+    def both(fn):
+        os.environ["DF3D_OS_KSPLIT"] = "0"
+        a = fn()
+        os.environ["DF3D_OS_KSPLIT"] = "1"
+        b = fn()
+        return a, b
+
+    def check(fsplit, packed, nbr, n_out, tag):
+        res = T(detgen.randn("ksr%d_%d" % (cout, n_out), (n_out, cout)), dev)
+        for kw in (dict(), dict(bias=bias, relu=True), dict(bias=bias, scale=scale, shift=shift, residual=res, relu=True)):
+            (y0, s0), (y1, s1) = both(lambda: ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, **kw))
+            sc = float(y0.abs().max())
+            assert float((y0 - y1).abs().max()) <= 2e-6 * sc, (tag, n_out, sorted(kw), float((y0 - y1).abs().max()) / sc)
+            assert torch.equal(s1, ops.split_rows(y1)), (tag, n_out, sorted(kw))
+    try:
+        for (B, H, W) in ((1, 90, 90), (1, 79, 83), (2, 75, 80), (1, 8, 8)):          # (the last one: below the split's range)
+            nbr = ops.conv2d_neighbors(B, H, W, 3, 3, 1, 1, False, dev)[0]
+            n = B * H * W
+            filt = detgen.randn("ksw%d_%d" % (cin, cout), (9, cin, cout), 0.5 / np.sqrt(cin))
+            feats = T(detgen.randn("ksf%d_%d" % (cin, n), (n, cin)), dev)
+            check(ops.split_rows(feats), ops.conv_pack_weights(T(filt, dev)), nbr, n, "3x3")
+        nbr = ops.conv2d_neighbors(1, 45, 45, 2, 2, 2, 0, True, dev)[0]             # 2 x 2 stride-2 transposed: 4 offsets
+        filt = detgen.randn("ksw4_%d_%d" % (cin, cout), (4, cin, cout), 0.5 / np.sqrt(cin))
+        feats = T(detgen.randn("ksf4_%d" % cin, (45 * 45, cin)), dev)
+        check(ops.split_rows(feats), ops.conv_pack_weights(T(filt, dev)), nbr, nbr.shape[1], "2x2T")
+        shape, batch = [9, 48, 48], 2
+        ind = detgen.clustered_voxels("ks3d", batch, shape, n_seeds=40, walk=200)
+        ind_t = T(ind, dev)
+        _, nbr, _ = _hip_rulebook(ind_t, batch, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], 1)
+        filt = detgen.randn("ksw27_%d_%d" % (cin, cout), (27, cin, cout), 0.5 / np.sqrt(cin))
+        feats = T(detgen.randn("ksf27_%d" % cin, (len(ind), cin)), dev)
+        check(ops.split_rows(feats), ops.conv_pack_weights(T(filt, dev)), nbr, len(ind), "3x3x3")
+    finally:
+        if old is None:
+            os.environ.pop("DF3D_OS_KSPLIT", None)
+        else:
+            os.environ["DF3D_OS_KSPLIT"] = old
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (128, 128), (32, 64)])
