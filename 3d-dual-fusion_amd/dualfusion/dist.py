@@ -238,9 +238,12 @@ class GradBucketReducer(object):
     CenterPoint detector are three, so the first two travel while backward still runs), and the buckets are the
     gradients' own storage:
 
-      * at construction every parameter's `.grad` becomes a view into one flat buffer per bucket (parameters in reverse
-        registration order = the order backward produces them) -- no flatten / copy-back passes per step (the
-        reference's coalesced path copies every gradient twice);
+      * every parameter owns a view into one flat buffer per bucket (parameters in reverse registration order = the order
+        backward produces them).  `zero_grad()` sets the gradients to None, so autograd ASSIGNS each produced gradient (no
+        `grad += new` kernel per parameter: ~400 small launches and 1.7 ms of a 36 ms CenterPoint + fusion step, measured);
+        when a bucket is complete its gradients move into the flat buffer in ONE multi-tensor copy and `.grad` becomes the
+        view -- after `finish()` the optimizer reads the reduced gradients in place, no copy-back pass (the reference's
+        coalesced path copies every gradient twice, one launch each);
       * a post-accumulate-grad hook counts a bucket's finished gradients; a complete bucket is launched asynchronously
         (RCCL runs it on its own stream while backward continues) -- STRICTLY IN BUCKET ORDER: bucket i only once buckets
         0..i-1 are launched, otherwise it waits for them or for `finish()`.  Every rank therefore issues the same sequence
@@ -274,12 +277,14 @@ class GradBucketReducer(object):
     def _seal(self, plist):
         flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
         pos = 0
-        offsets = {}
+        offsets, views = {}, []
         for p in plist:
-            p.grad = flat[pos:pos + p.numel()].view_as(p)
+            views.append(flat[pos:pos + p.numel()].view_as(p))
+            p.grad = views[-1]
             offsets[id(p)] = pos
             pos += p.numel()
-        b = dict(flat=flat, params=plist, pending=len(plist), handle=None, index=len(self.buckets), offsets=offsets)
+        b = dict(flat=flat, params=plist, pending=len(plist), handle=None, index=len(self.buckets), offsets=offsets,
+                 views=views)
         for p in plist:
             p._df3d_bucket = b
         self.buckets.append(b)
@@ -291,16 +296,31 @@ class GradBucketReducer(object):
             if b["pending"] > 0 and not force:
                 return
             self._next += 1
+            self._collect(b)
             if self._group:
                 b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
 
+    @staticmethod
+    def _collect(b):
+        """The bucket's gradients -> its flat buffer (one multi-tensor copy; zeros for parameters without a gradient), `.grad` ->
+        the views.  A gradient that already IS its view (accumulated in place: a caller that did not use zero_grad()) stays."""
+        dst, src, zero = [], [], []
+        for p, view in zip(b["params"], b["views"]):
+            g = p.grad
+            if g is None:
+                zero.append(view)
+            elif g.data_ptr() != view.data_ptr():
+                dst.append(view)
+                src.append(g)
+            p.grad = view
+        with torch.no_grad():
+            if dst:
+                torch._foreach_copy_(dst, src)
+            if zero:
+                torch._foreach_zero_(zero)
+
     def _on_grad(self, p):
         b = p._df3d_bucket
-        if p.grad.data_ptr() != b["flat"].data_ptr() + self._offset(b, p):
-            # an optimizer / zero_grad(set_to_none=True) replaced the view: copy back into the bucket and restore it
-            view = self._view(b, p)
-            view.copy_(p.grad)
-            p.grad = view
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch_ready()
@@ -319,14 +339,13 @@ class GradBucketReducer(object):
         return b["flat"][off:off + p.numel()].view_as(p)
 
     def zero_grad(self):
-        """Zero the buckets (keeps the gradient views in place; use INSTEAD of optimizer.zero_grad(set_to_none=True))."""
+        """Start a step: every gradient None (autograd then assigns what backward produces; the buckets are filled -- and
+        zeroed where a parameter got no gradient -- when they are launched).  Use INSTEAD of optimizer.zero_grad()."""
         for b in self.buckets:
-            b["flat"].zero_()
             b["pending"] = len(b["params"])
             b["handle"] = None
             for p in b["params"]:
-                if p.grad is None or p.grad.data_ptr() != self._view(b, p).data_ptr():
-                    p.grad = self._view(b, p)
+                p.grad = None
         self._next = 0
 
     def finish(self):
