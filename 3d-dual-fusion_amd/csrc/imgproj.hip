@@ -226,6 +226,120 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
   }
 }
 
+// Round 4, second structure of the projection: the image tile does NOT pass through LDS.
+// Ablations of the kernel above (tools/ubench/imgproj_probe.py, DF3D_IP_DBG, MI355X): 141 us as shipped, 64 us without the
+// image loads, 122 without the MFMAs, 99 without the stores, 146 without the Wcat loads -- the 246 MB of camera maps cost
+// ~77 us that nothing overlaps: a workgroup keeps ONE 16 KB k-step of the maps in flight (4 float2 per thread, issued one
+// barrier-separated step ahead of its LDS store), two workgroups per CU = 32 KB per CU, and a CU ingests 12 B/clk from HBM
+// only while ~50-100 KB are outstanding.
+// The B operand of a lane IS eight values of its own pixel (k = 8g .. 8g + 7 of the step's 32 channels): here every lane
+// loads them straight from the channel-first map -- a wave instruction reads four 64-byte runs (16 pixels x 4 planes), the
+// other half of each 128-byte line belongs to the neighbouring wave of the workgroup -- into a ring of DEPTH register sets
+// (8 registers per k-step); no LDS write, no transposed LDS read, no barrier between a load and its use.  Only the packed
+// Wcat tiles still go through LDS (shared by the eight waves; staged through registers one step ahead, ISSUED BEFORE the
+// step's image loads so that the in-order vmcnt wait for them releases the image loads of the previous step only).
+// Same operands, same accumulation order: the results are bit-identical to the kernel above.
+template <int D>                                 // image k-steps in registers: one in use, D - 1 in flight
+__global__ __launch_bounds__(512, 4) void img_proj_direct_kernel(ProjArgs2 a) {
+  constexpr int WQP = 3 * 512;                    // a stage padded to three stores per thread: no branch around the third
+  constexpr int W_BYTES = 2 * WQP * 16;
+  constexpr int ROW_PITCH = 528;                  // 512 B row + 16 B: rows start 4 banks apart
+  constexpr int EPI_BYTES = 8 * 16 * ROW_PITCH;
+  __shared__ __attribute__((aligned(16))) char smem[W_BYTES > EPI_BYTES ? W_BYTES : EPI_BYTES];
+  u32x4 (*Wl)[WQP] = (u32x4(*)[WQP])smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int p0 = blockIdx.x * IP_TP;
+  const int S = a.S;
+  const int pix = p0 + wave * 16 + n;
+  // this lane's column of the map: channel 8g + e of step kb at xp[(kb * 32 + e) * cs].  Pixels past the end of the map
+  // read the last pixel (branch-free loads: the compiler can then count its vmcnt waits; their rows are never stored)
+  // (a global-address-space pointer: the table entry is a generic pointer, and flat loads count in lgkmcnt as well --
+  // the compiler then drains every queue at each LDS access)
+  typedef const __attribute__((address_space(1))) float *gptr;
+  const size_t cs = (size_t)S;
+  gptr xp = (gptr)(a.img[blockIdx.y]) + (size_t)(g * 8) * cs + (pix < S ? pix : S - 1);
+
+  float xs[D][8];
+  u32x4 wr[3];
+  auto load_x = [&](int kb, float (&x)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = xp[(size_t)(kb * 32 + e) * cs];
+  };
+  auto load_w = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int e = tid + 512 * i;
+      wr[i] = a.w[(size_t)kb * IP_WQ + (e < IP_WQ ? e : 0)];
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int e = tid + 512 * i;
+      Wl[buf][e] = wr[i];
+    }
+  };
+
+  f32x4 acc[IP_MT];
+#pragma unroll
+  for (int t = 0; t < IP_MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_w(0);
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j) load_x(j, xs[j]);
+  store_w(0);
+  load_w(1);
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    __syncthreads();
+    if (kb + 1 < 8) store_w((kb + 1) & 1);
+    if (kb + 2 < 8) load_w(kb + 2);
+    if (kb + D - 1 < 8) load_x(kb + D - 1, xs[(kb + D - 1) % D]);
+    float (&x)[8] = xs[kb % D];
+    u32x4 bh, bl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_pair(x[2 * e], x[2 * e + 1], bh[e], bl[e]);
+    const u32x4 *wb = Wl[kb & 1] + lane;
+#pragma unroll
+    for (int tg = 0; tg < IP_MT / 3; ++tg) {
+      u32x4 fq[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) fq[q] = wb[(tg * 6 + q) * 64];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[2 * j], bl, acc[tg * 3 + j]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[2 * j + 1], bh, acc[tg * 3 + j]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[2 * j], bh, acc[tg * 3 + j]);
+    }
+  }
+
+  // epilogue of the kernel above: the wave's 16 split rows (8 KB) meet in LDS and leave as whole 512-byte rows
+  __syncthreads();
+  char *wt = smem + wave * 16 * ROW_PITCH;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    unsigned h[2], l[2];
+    split_pair(acc[t][0], acc[t][1], h[0], l[0]);
+    split_pair(acc[t][2], acc[t][3], h[1], l[1]);
+    char *blk = wt + n * ROW_PITCH + (2 * t + (g >> 1)) * 32 + (g & 1) * 8;   // 8-channel block = [hi 16 B | lo 16 B]
+    *(u32x2 *)blk = (u32x2){h[0], h[1]};
+    *(u32x2 *)(blk + 16) = (u32x2){l[0], l[1]};
+  }
+  const int pw = p0 + wave * 16;
+  if (g == 0 && pw + n < S) a.gate[(size_t)blockIdx.y * S + pw + n] = acc[8][0];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = it * 2 + (lane >> 5), c16 = lane & 31;
+    if (pw + r < S) {
+      const u32x4 v = *(const u32x4 *)(wt + r * ROW_PITCH + c16 * 16);
+      a.usplit[((size_t)blockIdx.y * S + pw + r) * 32 + c16] = v;
+    }
+  }
+}
+
 // mom[n][c] = (sum_p a_p u_cp, sum_p (a_p u_cp)^2) from split rows; a may be NULL (a_p = 1)
 __global__ __launch_bounds__(256) void split_moments_kernel(const u32x4 *__restrict__ us, const float *__restrict__ a,
                                                             int S, int rows_per_block, double *__restrict__ mom) {
@@ -430,7 +544,16 @@ extern "C" int df3d_imgproj_split(const float *const *img_ptrs, int nimg, int ci
   if (nimg == 0 || S == 0) return DF3D_OK;
   ProjArgs2 a = {img_ptrs, (const u32x4 *)packed, (u32x4 *)u_split, gate, S,
                  getenv("DF3D_IP_DBG") ? atoi(getenv("DF3D_IP_DBG")) : 0, nullptr, nullptr};
-  hipLaunchKernelGGL(img_proj_split_kernel, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+  // DF3D_IMGPROJ_DIRECT=0: the LDS-staged kernel of round 3 (A/B; read per call)
+  const char *dm = getenv("DF3D_IMGPROJ_DIRECT");
+  if (dm && dm[0] == '0') hipLaunchKernelGGL(img_proj_split_kernel, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+  else {
+    static const int depth = getenv("DF3D_IP_DEPTH") ? atoi(getenv("DF3D_IP_DEPTH")) : 3;      // tuning aid
+    if (depth == 2) hipLaunchKernelGGL(img_proj_direct_kernel<2>, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+    else if (depth == 4) hipLaunchKernelGGL(img_proj_direct_kernel<4>, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+    else if (depth == 5) hipLaunchKernelGGL(img_proj_direct_kernel<5>, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL(img_proj_direct_kernel<3>, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+  }
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }
