@@ -542,15 +542,8 @@ class ACTR(nn.Module):
                 and all(isinstance(l, DeformableTransformerFusionEncoderLayer) and l.fusable_config()
                         for l in layers))
 
-    def forward_folded(self, v_feat, grid, u, gate, hw, v_i_feat, lidar_grid, q_pos=None):
-        """Inference path that never materialises the normalised image map.  `u` [N, >=C, H*W] channel-first is
-        input_proj[0][0] WITHOUT its bias applied to the (un-gated) image, `gate` [N, H*W] the adapter's per-pixel
-        image gate (or None).  input_proj's GroupNorm and every layer's value_proj are folded into one per-image
-        GEMM (csrc/actr.hip gn_fold_kernel); the gate and the folded constant are applied inside the sampler."""
-        from . import ops as _ops
-        conv, gn = self.input_proj[0][0], self.input_proj[0][1]
+    def _value_weights(self):
         layers = self.transformer.encoder.layers
-        C = gn.num_channels
         vkey = tuple((l.self_attn.value_proj.weight.data_ptr(), l.self_attn.value_proj.weight._version,
                       l.self_attn.value_proj.bias._version) for l in layers)
         hit = getattr(self, "_vcat", None)
@@ -558,8 +551,50 @@ class ACTR(nn.Module):
             hit = (vkey, torch.cat([l.self_attn.value_proj.weight for l in layers], 0).contiguous(),
                    torch.cat([l.self_attn.value_proj.bias for l in layers], 0).contiguous())
             object.__setattr__(self, "_vcat", hit)
-        W, wb = hit[1], hit[2]
-        if u.dtype == torch.uint8:
+        return hit[1], hit[2]
+
+    def start_values(self, u, gate):
+        """The image side of forward_folded (moments of the gated projection, GroupNorm fold, value rows of every layer) queued
+        on a stream of its own as soon as the gate exists: it streams 370 MB and depends on nothing the query side produces
+        (query assembly, image-query projection + GroupNorm, the first offset / weight linear: ~150 us of gathers and small
+        launches that leave the memory system idle), so the two run beside each other and meet at the first sampler.
+        Returns what forward_folded takes as `values`.  Outputs come from the CURRENT stream's pool (allocated before the
+        fork event, last used and freed behind the join event): no allocator traffic on the side stream."""
+        from . import ops as _ops
+        conv, gn = self.input_proj[0][0], self.input_proj[0][1]
+        W, wb = self._value_weights()
+        dev = u.device
+        side = self.__dict__.get("_value_stream")
+        if side is None:
+            side = torch.cuda.Stream(device=dev)
+            object.__setattr__(self, "_value_stream", side)
+        main = torch.cuda.current_stream(dev)
+        fork = torch.cuda.Event()
+        # the allocations happen inside value_fold_gemm on the current stream's pool, BEFORE its launches: a recycled block's
+        # earlier users were queued on `main` ahead of this event
+        value_cf = [None]
+        fork.record(main)
+        side.wait_event(fork)
+        value_cf[0] = _ops.value_fold_gemm(u, gate, conv.bias, gn, W, wb, bf16=_ops.CONV_PRECISION == "bf16", stream=side)
+        join = torch.cuda.Event()
+        join.record(side)
+        return value_cf[0][0], value_cf[0][1], join
+
+    def forward_folded(self, v_feat, grid, u, gate, hw, v_i_feat, lidar_grid, q_pos=None, values=None):
+        """Inference path that never materialises the normalised image map.  `u` [N, >=C, H*W] channel-first is
+        input_proj[0][0] WITHOUT its bias applied to the (un-gated) image, `gate` [N, H*W] the adapter's per-pixel
+        image gate (or None).  input_proj's GroupNorm and every layer's value_proj are folded into one per-image
+        GEMM (csrc/actr.hip gn_fold_kernel); the gate and the folded constant are applied inside the sampler.
+        values: the result of start_values(u, gate) (the image side already queued on its own stream)."""
+        from . import ops as _ops
+        conv, gn = self.input_proj[0][0], self.input_proj[0][1]
+        layers = self.transformer.encoder.layers
+        C = gn.num_channels
+        W, wb = self._value_weights()
+        join = None
+        if values is not None:
+            value, cf, join = values
+        elif u.dtype == torch.uint8:
             # u arrives as pixel-major split rows (csrc/imgproj.hip): moments, fold and the value GEMM of all
             # layers in one native call on the bf16 matrix cores
             # reduced-precision mode (DF3D_CONV_PRECISION=bf16, the reference's fp16-AMP configurations): the value rows
@@ -584,6 +619,8 @@ class ACTR(nn.Module):
             shp = (skey, spatial_shapes, spatial_shapes.new_zeros((1,)))
             object.__setattr__(self, "_shape_cache", shp)
         spatial_shapes, level_start_index = shp[1], shp[2]
+        if join is not None:
+            torch.cuda.current_stream(u.device).wait_event(join)       # the value rows: first read by the first sampler
         return self.transformer.encoder(None, spatial_shapes, level_start_index, None, q_feat=v_feat, q_pos=q_pos,
                                         q_reference_points=grid, q_lidar_grid=lidar_grid, q_i_feat=q_i_feat,
                                         layer_values=layer_values)

@@ -757,6 +757,11 @@ class VoxelWithPointProjection(nn.Module):
             if att is not None:
                 src_conv = src_conv * att.view(NI, 1, S_pix)
             src_conv = (src_conv + in_conv.bias[None, :, None]).view(NI, -1, H, W)
+        values = None
+        u_rows = both[0] if isinstance(both, tuple) else both
+        if (fold and u_rows.dtype == torch.uint8 and os.environ.get("DF3D_VALUE_SIDE", "1") == "1"):
+            # the image side of ACTR (370 MB streamed) beside the query assembly and the query-side small launches
+            values = self.pfat.start_values(u_rows, None if att is None else att.view(NI, S_pix))
         # (a8) per-camera query sets from the LAST scale (Appendix C item 4)
         grid, mask, pinv = proj[last]
         feats = x_last.features.contiguous()
@@ -786,7 +791,7 @@ class VoxelWithPointProjection(nn.Module):
         if fold:
             enh = self.pfat.forward_folded(v_feat, qgrid, both[0] if isinstance(both, tuple) else both,
                                            None if att is None else att.view(NI, S_pix), (H, W),
-                                           v_i_feat, qpts, q_pos=qpos).contiguous()
+                                           v_i_feat, qpts, q_pos=qpos, values=values).contiguous()
         else:
             enh = self.pfat.forward_projected(v_feat, qgrid, src_conv, v_i_feat, qpts, q_pos=qpos).contiguous()
         # write-back, additive, camera order (Appendix C item 8)

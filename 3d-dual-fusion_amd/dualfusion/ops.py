@@ -1629,9 +1629,11 @@ def imgproj_split(img_ptrs, nimg, cin, S, packed, pixrow=None, pixrow_total=0):
     return u, gate
 
 
-def value_fold_gemm(u_split, att, conv_bias, gn, W, wb, bf16=False):
+def value_fold_gemm(u_split, att, conv_bias, gn, W, wb, bf16=False, stream=None):
     """-> (value fp32 (or, bf16=True, torch.bfloat16) [nimg, S, 256], cf [nimg, 256]): W GroupNorm(att*u + conv_bias) + wb =
-    att_p * value_p + cf."""
+    att_p * value_p + cf.
+    stream: a torch.cuda.Stream the three kernels are queued on instead of the current one (the outputs are still allocated
+    by the current stream's pool: the caller orders the streams with events on both sides, see ACTR.start_values)."""
     lib = _lib.load()
     _chk(u_split, torch.uint8, "u_split")
     nimg, S = u_split.shape[0], u_split.shape[1]
@@ -1646,8 +1648,11 @@ def value_fold_gemm(u_split, att, conv_bias, gn, W, wb, bf16=False):
     value = torch.empty((nimg, S, 256), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
     fn = lib.df3d_value_fold_gemm_bf16 if bf16 else lib.df3d_value_fold_gemm
     rc = fn(_ptr(u_split), _ptr(att), nimg, S, _ptr(conv_bias), _ptr(gn.weight), _ptr(gn.bias), float(gn.eps),
-            int(gn.num_groups), _ptr(W), _ptr(wb), _ptr(mom), _ptr(pw), _ptr(cf), _ptr(value), _stream())
+            int(gn.num_groups), _ptr(W), _ptr(wb), _ptr(mom), _ptr(pw), _ptr(cf), _ptr(value),
+            _stream() if stream is None else _lib.StreamArg(stream.cuda_stream))
     _lib.check(rc, "df3d_value_fold_gemm")
+    if stream is not None:
+        value._df3d_keep = (mom, pw)            # scratch of kernels that may still be queued on `stream`
     return value, cf
 
 

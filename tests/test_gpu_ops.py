@@ -1526,3 +1526,43 @@ def test_three_part_mode_end_to_end_detector():
             worst2 = max(worst2, float((outs["split"][1][t][k] - ref).abs().max()) / s)
     assert worst3 < 2e-5, (worst3, worst2)
     assert worst2 < 1e-3
+
+
+def test_value_rows_on_a_side_stream_equal_the_in_line_chain(monkeypatch):
+    """Round 4: the image side of ACTR (moments, GroupNorm fold, value rows) queued on its own stream beside the query
+    assembly (ACTR.start_values, DF3D_VALUE_SIDE) -- bit-identical head maps to the single-stream order, over several frames
+    (the buffers of both streams are recycled between them) and from a non-default caller stream."""
+    from dualfusion import synth
+    from dualfusion.fusion import build_centerpoint_fusion, synthetic_camera_inputs
+    from dualfusion.pipeline import CenterPointDetector
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = CenterPointDetector(fusion=build_centerpoint_fusion()).eval().to(dev)
+    frames = []
+    for j in range(3):
+        frames.append(([torch.from_numpy(synth.nusc_sweep(seed=20 + j)).to(dev)],
+                       synthetic_camera_inputs(1, dev, seed=5 + j, yaw_offset_deg=3.0 * j)))
+
+    def run(side):
+        monkeypatch.setenv("DF3D_VALUE_SIDE", side)
+        outs = []
+        with torch.no_grad():
+            for rnd in range(2):
+                for pts, (bd, ex) in frames:
+                    x, _ = m.hot_path(pts, batch_dict=dict(bd), example=dict(ex))
+                    outs.append([v.clone() for p in m.bbox_head(x) for _, v in sorted(p.items())])
+        torch.cuda.synchronize()
+        return outs
+
+    want = run("0")
+    got = run("1")
+    assert m.hot_path.fusion.pfat.__dict__.get("_value_stream") is not None      # the side stream was used
+    for a, b in zip(want, got):
+        assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+    other = torch.cuda.Stream(device=dev)
+    other.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(other):
+        got2 = run("1")
+    other.synchronize()
+    for a, b in zip(want, got2):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
