@@ -685,6 +685,82 @@ __global__ __launch_bounds__(1024) void query_slots_kernel(const uint8_t *__rest
   if (tid == 0) counts[b * ncam + cam] = carry;
 }
 
+// Round 4: the query rows BY SLOT.  assemble_queries2_kernel launches a wave per (camera, voxel) CANDIDATE -- 6 x 29 k waves of
+// which 31 k own a slot -- and every live wave walks a chain of dependent loads (mask -> slot -> sample index -> pixel -> gate ->
+// rows) before its gathers start: 78-84 us for 48 MB, and still 63 us when the image rows are contiguous (round 4, compact
+// copy): the latency chain and the dead waves are the cost, not the plane-strided gathers.  Here a one-thread-per-candidate
+// pass writes the inverse table (slot -> voxel row; ~3 us), and a wave per SLOT of the padded [image][max_ne] tensors does
+// the rest: row <- table, then pixel / feature row / gate / planes at once; slots past the list length write the padding
+// rows (pad_queries_kernel's values), so no other launch touches the outputs.  Same values as assemble_queries2_kernel.
+__global__ __launch_bounds__(256) void query_inverse_kernel(const int32_t *__restrict__ ind, const uint8_t *__restrict__ mask,
+                                                            const int32_t *__restrict__ pos, int n, int ncam, int max_ne,
+                                                            int32_t *__restrict__ inv) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * ncam) return;
+  const int cam = (int)(t / n), i = (int)(t - (long long)cam * n);
+  if (!mask[t]) return;
+  const int slot = pos[t];
+  if (slot >= max_ne) return;
+  inv[(size_t)(ind[(size_t)i * 4] * ncam + cam) * max_ne + slot] = i;
+}
+
+__global__ __launch_bounds__(256) void assemble_queries4_kernel(AsmArgs2 a, const int32_t *__restrict__ counts,
+                                                                const int32_t *__restrict__ inv, int nimg) {
+  const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (w >= (long long)nimg * a.max_ne) return;
+  const int img = (int)(w / a.max_ne), slot = (int)(w - (long long)img * a.max_ne);
+  const size_t q = (size_t)w;
+  if (slot >= counts[img]) {                       // padding row (pad_queries_kernel)
+    for (int c = lane; c < a.C; c += 64) {
+      a.v_feat[q * a.C + c] = 0.f;
+      if (a.qpos) a.qpos[q * a.C + c] = (c & 1) ? 1.f : 0.f;
+    }
+    for (int c = lane; c < a.Ci; c += 64) a.v_i_feat[q * a.Ci + c] = 0.f;
+    if (lane < 2) a.qgrid[q * 2 + lane] = 0.f;
+    if (lane < 3) a.qpts[q * 3 + lane] = 0.f;
+    return;
+  }
+  const int i = inv[q], cam = img % a.ncam;
+  const int2 gxy = *(const int2 *)(a.grid + ((size_t)cam * a.n + i) * 2);
+  const int gx = gxy.x, gy = gxy.y;
+  const size_t hw = (size_t)a.H * a.W, pix = (size_t)gy * a.W + gx;
+  // every load of the row is issued before the first store
+  float vf[4], vi[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vf[j] = (lane + 64 * j < a.C) ? a.feat[(size_t)i * a.C + lane + 64 * j] : 0.f;
+  if (a.compact) {                                 // pixel-major rows written by the image projection: one contiguous row
+    const float *src = a.compact + (size_t)a.pixrow[(size_t)img * hw + pix] * a.Ci;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vi[j] = (lane + 64 * j < a.Ci) ? src[lane + 64 * j] : 0.f;
+  } else {
+    const float *src = (a.img ? a.img + (size_t)img * a.Ci * hw : a.img_ptrs[img]) + pix;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vi[j] = (lane + 64 * j < a.Ci) ? src[(size_t)(lane + 64 * j) * hw] : 0.f;
+  }
+  const float g = a.att ? a.att[(size_t)img * hw + pix] : 1.f;
+  const float p0 = a.pinv[(size_t)i * 3], pl = lane < 3 ? a.pinv[(size_t)i * 3 + lane] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (lane + 64 * j < a.C) a.v_feat[q * a.C + lane + 64 * j] = vf[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (lane + 64 * j < a.Ci) a.v_i_feat[q * a.Ci + lane + 64 * j] = vi[j] * g;
+  if (lane == 0) {
+    a.qgrid[q * 2 + 0] = (float)gx / (float)a.W;
+    a.qgrid[q * 2 + 1] = (float)gy / (float)a.H;
+  }
+  if (lane < 3) a.qpts[q * 3 + lane] = pl;
+  if (a.qpos) {
+    const float d = p0 / 60.f * 6.283185307179586f;
+    for (int c = lane; c < a.C; c += 64) {
+      float dim_t = powf(10000.f, (float)(2 * (c / 2)) / (float)a.C);
+      float v = d / dim_t;
+      a.qpos[q * a.C + c] = (c & 1) ? cosf(v) : sinf(v);
+    }
+  }
+}
+
 // zero rows of the padded query tensors: slots >= counts[image] (one wave per padding row); the position
 // embedding of an all-zero query is sin(0) = 0 on even, cos(0) = 1 on odd channels
 __global__ __launch_bounds__(256) void pad_queries_kernel(const int32_t *__restrict__ counts, int nimg, int max_ne, int C,
@@ -806,11 +882,24 @@ static int assemble_queries2_impl(const float *features, const float *point_inv,
                                   const float *img_feats, const float *const *img_ptrs, const float *att, int n,
                                   int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
                                   float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
-                                  const int32_t *counts, const int32_t *pixrow, const float *compact, void *stream_) {
+                                  const int32_t *counts, const int32_t *pixrow, const float *compact, int32_t *inv,
+                                  void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(v_feat && v_i_feat && qgrid && qpts, "assemble_queries2: null output");
   size_t nq = (size_t)batch * ncam * max_ne;
   if (qpos) DF3D_CHECK_ARG(channels % 2 == 0, "assemble_queries2: odd channel count");
+  if (inv && counts && nq && n && channels <= 256 && img_channels <= 512) {
+    DF3D_CHECK_ARG(features && point_inv && indices && grid_xy && mask && pos && (img_feats || img_ptrs || (compact && pixrow)),
+                   "assemble_queries2: null input");
+    AsmArgs2 a = {features, point_inv, indices, grid_xy, mask, pos, img_feats, img_ptrs, att, n, channels, img_channels, ncam, H, W,
+                  max_ne, v_feat, v_i_feat, qgrid, qpts, qpos, pixrow, compact};
+    hipLaunchKernelGGL(query_inverse_kernel, dim3(cdiv((long long)n * ncam, 256)), dim3(256), 0, stream, indices, mask, pos, n,
+                       ncam, max_ne, inv);
+    hipLaunchKernelGGL(assemble_queries4_kernel, dim3(cdiv((long long)nq * 64, 256)), dim3(256), 0, stream, a, counts, inv,
+                       batch * ncam);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+  }
   if (counts && nq) {
     // only the padding rows (slot >= list length) are cleared; every other row is written by the gather below
     hipLaunchKernelGGL(pad_queries_kernel, dim3(cdiv((long long)nq * 64, 256)), dim3(256), 0, stream, counts,
@@ -856,7 +945,22 @@ extern "C" int df3d_assemble_queries2(const float *features, const float *point_
                                       const int32_t *counts, void *stream_) {
   return assemble_queries2_impl(features, point_inv, indices, grid_xy, mask, pos, img_feats, img_ptrs, att, n, channels,
                                 img_channels, batch, ncam, H, W, max_ne, v_feat, v_i_feat, qgrid, qpts, qpos, counts, nullptr,
-                                nullptr, stream_);
+                                nullptr, nullptr, stream_);
+}
+
+// the same BY SLOT (round 4): slot_rows [batch * ncam * max_ne] i32 is scratch for the slot -> voxel row table
+extern "C" int df3d_assemble_queries2_slots(const float *features, const float *point_inv, const int32_t *indices,
+                                            const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
+                                            const float *img_feats, const float *const *img_ptrs, const float *att, int n,
+                                            int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
+                                            float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
+                                            const int32_t *counts, int32_t *slot_rows, const int32_t *pixrow,
+                                            const float *compact, void *stream_) {
+  DF3D_CHECK_ARG(counts && slot_rows, "assemble_queries2_slots: the list lengths and the table scratch are required");
+  DF3D_CHECK_ARG((pixrow != nullptr) == (compact != nullptr), "assemble_queries2_slots: pixrow and compact come together");
+  return assemble_queries2_impl(features, point_inv, indices, grid_xy, mask, pos, img_feats, img_ptrs, att, n, channels,
+                                img_channels, batch, ncam, H, W, max_ne, v_feat, v_i_feat, qgrid, qpts, qpos, counts, pixrow,
+                                compact, slot_rows, stream_);
 }
 
 // the same with the image features read from pixel-major rows (df3d_query_pixel_rows + df3d_imgproj_split_compact)
@@ -869,7 +973,7 @@ extern "C" int df3d_assemble_queries2_compact(const float *features, const float
   DF3D_CHECK_ARG(pixrow && compact, "assemble_queries2_compact: null pixel rows");
   return assemble_queries2_impl(features, point_inv, indices, grid_xy, mask, pos, nullptr, nullptr, att, n, channels,
                                 img_channels, batch, ncam, H, W, max_ne, v_feat, v_i_feat, qgrid, qpts, qpos, counts, pixrow,
-                                compact, stream_);
+                                compact, nullptr, stream_);
 }
 
 static size_t df3d_query_pixel_rows_workspace_bytes_impl(long long npix) {

@@ -239,7 +239,9 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
 // Wcat tiles still go through LDS (shared by the eight waves; staged through registers one step ahead, ISSUED BEFORE the
 // step's image loads so that the in-order vmcnt wait for them releases the image loads of the previous step only).
 // Same operands, same accumulation order: the results are bit-identical to the kernel above.
-template <int D>                                 // image k-steps in registers: one in use, D - 1 in flight
+// COMPACT: also the raw 256-channel rows of the pixels a query samples, pixel-major (a.pixrow / a.compact as in the kernel
+// above): the lane HOLDS eight consecutive channels of its pixel per step -- two 16-byte stores under the lane's mark, no LDS.
+template <int D, bool COMPACT = false>           // D image k-steps in registers: one in use, D - 1 in flight
 __global__ __launch_bounds__(512, 4) void img_proj_direct_kernel(ProjArgs2 a) {
   constexpr int WQP = 3 * 512;                    // a stage padded to three stores per thread: no branch around the third
   constexpr int W_BYTES = 2 * WQP * 16;
@@ -259,6 +261,8 @@ __global__ __launch_bounds__(512, 4) void img_proj_direct_kernel(ProjArgs2 a) {
   typedef const __attribute__((address_space(1))) float *gptr;
   const size_t cs = (size_t)S;
   gptr xp = (gptr)(a.img[blockIdx.y]) + (size_t)(g * 8) * cs + (pix < S ? pix : S - 1);
+  int prow = -1;
+  if constexpr (COMPACT) prow = pix < S ? a.pixrow[(size_t)blockIdx.y * S + pix] : -1;
 
   float xs[D][8];
   u32x4 wr[3];
@@ -297,6 +301,13 @@ __global__ __launch_bounds__(512, 4) void img_proj_direct_kernel(ProjArgs2 a) {
     if (kb + 2 < 8) load_w(kb + 2);
     if (kb + D - 1 < 8) load_x(kb + D - 1, xs[(kb + D - 1) % D]);
     float (&x)[8] = xs[kb % D];
+    if constexpr (COMPACT) {
+      if (prow >= 0) {
+        f32x4 *dst = (f32x4 *)(a.compact + (size_t)prow * IP_CIN + kb * 32 + g * 8);
+        dst[0] = (f32x4){x[0], x[1], x[2], x[3]};
+        dst[1] = (f32x4){x[4], x[5], x[6], x[7]};
+      }
+    }
     u32x4 bh, bl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) split_pair(x[2 * e], x[2 * e + 1], bh[e], bl[e]);
@@ -565,7 +576,9 @@ extern "C" int df3d_imgproj_split_compact(const float *const *img_ptrs, int nimg
   DF3D_CHECK_ARG(cin == IP_CIN, "imgproj_split_compact: serves 256 input channels (got %d)", cin);
   if (nimg == 0 || S == 0) return DF3D_OK;
   ProjArgs2 a = {img_ptrs, (const u32x4 *)packed, (u32x4 *)u_split, gate, S, 0, pixrow, compact};
-  hipLaunchKernelGGL(img_proj_split_kernel, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+  const char *dm = getenv("DF3D_IMGPROJ_DIRECT");
+  if (dm && dm[0] == '0') hipLaunchKernelGGL(img_proj_split_kernel, dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((img_proj_direct_kernel<3, true>), dim3(cdiv(S, IP_TP), nimg), dim3(512), 0, stream, a);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

@@ -102,6 +102,10 @@ SIGNATURES = {
     "df3d_assemble_queries2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_assemble_queries2_slots": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p]),
     "df3d_conv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "df3d_conv_pack_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_bn_rows_supported": (c_int, [c_int]),

@@ -337,10 +337,12 @@ class VoxelWithPointProjection(nn.Module):
             key = (wcat.data_ptr(), wcat._version)
             if self._wpack is None or self._wpack[0] != key:
                 self._wpack = (key, _ops.imgproj_pack(wcat.contiguous()))
-            if pixrow is not None and os.environ.get("DF3D_ASSEMBLE_COMPACT", "0") == "1":
-                # (round 4, opt-in) also the raw rows of the pixels the queries sample, pixel-major, for the query assembly.
-                # Measured on MI355X: the assembly 77 -> 63 us (it still moves ~110 MB of query rows), the projection
-                # 121 -> 155 us (the per-step copies sit inside its main loop): a loss, so off by default
+            if pixrow is not None and os.environ.get("DF3D_ASSEMBLE_COMPACT", "1") == "1":
+                # (round 4) also the raw rows of the pixels the queries sample, pixel-major, for the query assembly.  With the
+                # LDS-staged projection and the wave-per-candidate assembly this was a loss (assembly 77 -> 63 us, projection
+                # 121 -> 155 us); with the direct projection (the lane holds its pixel's channels: two stores under a mark,
+                # 92 -> 103 us) and the by-slot assembly (78 -> 42 us) it is a gain of ~50 us per step: on by default,
+                # DF3D_ASSEMBLE_COMPACT=0 turns it off
                 return _ops.imgproj_split(inp['img_ptrs'], len(imgs), imgs[0].shape[0], S_pix, self._wpack[1],
                                           pixrow=pixrow[0], pixrow_total=pixrow[1])
             return _ops.imgproj_split(inp['img_ptrs'], len(imgs), imgs[0].shape[0], S_pix, self._wpack[1])
@@ -447,7 +449,7 @@ class VoxelWithPointProjection(nn.Module):
                    image_scale=self.image_scale, ready=ready,
                    # the image gate's "winning voxel per pixel" maps depend on the coordinates alone as well
                    winner_levels=tuple(self.ifat.voxel_idx) if self.ifat_cfg is not None else (),
-                   want_pixrow=os.environ.get("DF3D_ASSEMBLE_COMPACT", "0") == "1")
+                   want_pixrow=os.environ.get("DF3D_ASSEMBLE_COMPACT", "1") == "1")
         packed = self._native_projection_weights(inp)
         if packed is not None and os.environ.get("DF3D_IMGPROJ_AHEAD", "0") == "1":
             # the image-side projection depends on the camera maps alone: the worker can run it too, on a second stream of
@@ -759,7 +761,7 @@ class VoxelWithPointProjection(nn.Module):
             src_conv = (src_conv + in_conv.bias[None, :, None]).view(NI, -1, H, W)
         values = None
         u_rows = both[0] if isinstance(both, tuple) else both
-        if (fold and u_rows.dtype == torch.uint8 and os.environ.get("DF3D_VALUE_SIDE", "1") == "1"):
+        if (fold and u_rows.dtype == torch.uint8 and os.environ.get("DF3D_VALUE_SIDE", "0") == "1"):
             # the image side of ACTR (370 MB streamed) beside the query assembly and the query-side small launches
             values = self.pfat.start_values(u_rows, None if att is None else att.view(NI, S_pix))
         # (a8) per-camera query sets from the LAST scale (Appendix C item 4)
@@ -776,8 +778,19 @@ class VoxelWithPointProjection(nn.Module):
         depth_pos = self.pfat.pos_encode_method == "depth"
         qpos = torch.empty((NI, max_ne, C), dtype=torch.float32, device=dev) if depth_pos else None
         compact = both[2] if (isinstance(both, tuple) and len(both) > 2 and prep is not None and "pixrow" in prep) else None
-        if compact is not None:
-            # the image rows of the sampled pixels are pixel-major (written by the image projection): one 1 KB row per query
+        by_slot = (counts is not None and NI < 12 and C <= 256 and Ci <= 512
+                   and os.environ.get("DF3D_ASSEMBLE_SLOTS", "1") == "1")
+        if by_slot:
+            # a wave per SLOT (no dead candidate waves); with `compact` the image rows of the sampled pixels are pixel-major
+            # (written by the image projection): one contiguous 1 KB row per query instead of 256 scattered elements
+            slot_rows = torch.empty((NI * max_ne,), dtype=torch.int32, device=dev)
+            rc = lib.df3d_assemble_queries2_slots(_p(feats), _p(pinv), _p(ind), _p(grid), _p(mask), _p(pos), None,
+                                                  _p(inp['img_ptrs']), _p(att), n, C, Ci, B, ncam, H, W, max_ne, _p(v_feat),
+                                                  _p(v_i_feat), _p(qgrid), _p(qpts), _p(qpos), _p(counts), _p(slot_rows),
+                                                  _p(prep["pixrow"][0]) if compact is not None else None, _p(compact),
+                                                  _ops._stream())
+            _lib.check(rc, "df3d_assemble_queries2_slots")
+        elif compact is not None:
             rc = lib.df3d_assemble_queries2_compact(_p(feats), _p(pinv), _p(ind), _p(grid), _p(mask), _p(pos), _p(prep["pixrow"][0]),
                                                     _p(compact), _p(att), n, C, Ci, B, ncam, H, W, max_ne, _p(v_feat),
                                                     _p(v_i_feat), _p(qgrid), _p(qpts), _p(qpos), _p(counts), _ops._stream())

@@ -107,6 +107,7 @@ class TapedSection(object):
         self.tapes = {}
         self.retired = []          # tapes of stale keys: their pools are kept (plans built while recording may live there)
         self.stats = {"plain": 0, "recorded": 0, "replayed": 0}
+        self._live = None          # the key of the last call
 
     def reset(self):
         self.retired.extend(t for t in self.tapes.values() if isinstance(t, LaunchTape))
@@ -118,10 +119,16 @@ class TapedSection(object):
             # not record its wrappers
             self.stats["plain"] += 1
             return fn()
+        if key != self._live:
+            # ONE live key at a time.  A recorded launch carries the addresses of everything the section read besides its
+            # input -- packed filters, neighbour tables, plans the modules cache for their CURRENT precision mode / parameter
+            # version and replace (free) when that changes.  A tape of an older key would replay with those stale addresses
+            # once the key comes back (round 4: bench.py's split -> split3 -> split passes faulted in the pass that followed).
+            # A returning key therefore warms up and records again.
+            self.reset()
+            self._live = key
         slot = self.tapes.get(key)
         if slot is None:
-            if len(self.tapes) >= 4:
-                self.reset()
             self.tapes[key] = "warm"
             self.stats["plain"] += 1
             return fn()

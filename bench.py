@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the hot_path / fp32 passes after the timed region")
+    ap.add_argument("--skip-passes", default=os.environ.get("DF3D_BENCH_SKIP", ""),
+                    help="comma list of extra passes to leave out: hot_path, in_flight, split3, fp32 (debugging aid)")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="cp_fusion / cp_lidar: do NOT start the next frame's voxelisation / rulebooks / query slots on the "
                          "detector's helper thread while the current frame is queued (round 3's behaviour: every count round "
@@ -752,13 +754,15 @@ def main():
         assert args.workload in ("cp_lidar", "cp_fusion"), "--stage train: the CenterPoint detectors"
     if not (args.no_extra_passes or protocol or stage == "train"):
         # the same K steps ending at the dense BEV tensor (round 1's step), and both stages on the exact-fp32 kernels
-        if stage == "detect":
+        skip = set(x for x in args.skip_passes.split(",") if x)
+        if stage == "detect" and "hot_path" not in skip:
             note("hot_path pass")
             wl.step(0, "hot_path")
             e, o = timed_steps(wl, "hot_path", args.steps, args.warmup, barrier, reduce_losses)
             wl.check(o, "hot_path")
             extra["hot_path"] = D.max_over_ranks(e, dev)
-        if stage == "detect" and world == 1 and args.workload in ("cp_fusion", "cp_lidar") and args.inflight > 1:
+        if (stage == "detect" and world == 1 and args.workload in ("cp_fusion", "cp_lidar") and args.inflight > 1
+                and "in_flight" not in skip):
             F = args.inflight
             note("in_flight pass")
             wls = [wl] + [make_workload(args, rank, world, dev) for _ in range(F - 1)]
@@ -784,6 +788,8 @@ def main():
             # the like-for-like companions of the headline: every convolution fp32-grade -- "split3" (three bf16 parts per
             # operand, six products, ~1e-7) and "fp32" (the exact-fp32 MFMA kernels)
             for mode in ("split3", "fp32"):
+                if mode in skip:
+                    continue
                 ops.CONV_PRECISION = mode
                 note(mode + " passes")
                 try:

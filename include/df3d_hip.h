@@ -653,6 +653,19 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
                            int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
                            float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
                            const int32_t *counts, void *stream);
+/* round 4 -- df3d_assemble_queries2 BY SLOT: a wave per slot of the padded [B*ncam][max_ne] tensors instead of a wave per
+ * (camera, voxel) candidate (five of six candidates own no slot, and every live wave walked mask -> slot -> sample -> pixel before
+ * its gathers).  slot_rows [B*ncam*max_ne] i32 is scratch (slot -> voxel row, filled by a one-thread-per-candidate pass);
+ * counts is required; padding rows are written by the same launch.  pixrow + compact (both or neither): the image features
+ * come from the pixel-major rows compact[pixrow[image][pixel]] (df3d_query_pixel_rows + df3d_imgproj_split_compact) instead of
+ * the channel-first maps.  Same values (voxel_with_point_projection.py:337-377). */
+int df3d_assemble_queries2_slots(const float *features, const float *point_inv, const int32_t *indices,
+                                 const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
+                                 const float *img_feats, const float *const *img_ptrs, const float *att, int n,
+                                 int channels, int img_channels, int batch, int ncam, int H, int W, int max_ne,
+                                 float *v_feat, float *v_i_feat, float *qgrid, float *qpts, float *qpos,
+                                 const int32_t *counts, int32_t *slot_rows, const int32_t *pixrow, const float *compact,
+                                 void *stream);
 /* round 4 -- the queries' image features from PIXEL-MAJOR rows instead of 256 scattered elements of the channel-first map:
  * df3d_query_pixel_rows: pixrow [batch*ncam*H*W] i32 = rank of every pixel some visible voxel projects to (image-major, -1
  *   elsewhere), *total (device i32) = their number; depends on the projection alone (the frame head runs it a frame ahead);

@@ -2,6 +2,8 @@
 the same seeded inputs and against the golden fixtures generated from the reference.
 Bit-exact for voxel indices / rulebooks (canonical order); fp32 results within
 1e-3 (north_star), in practice ~1e-5.  Run with -m gpu on a MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -692,9 +694,9 @@ def test_image_projection_split_path(dev, S, gated):
     Wv = (torch.randn(256, C, generator=g) * 0.1).to(dev)
     wb = torch.randn(256, generator=g).to(dev)
     with torch.no_grad():
-        value, cf = ops.value_fold_gemm(us, att, b, gn, Wv, wb)
         x = ref_u[:, :C].float() * (att[:, None] if gated else 1.0) + b[None, :, None]
         want = torch.einsum('oc,ncs->nso', Wv.double(), gn(x).double()) + wb.double()
+        value, cf = ops.value_fold_gemm(us, att, b, gn, Wv, wb)
         got = value.double() * (att[..., None].double() if gated else 1.0) + cf[:, None].double()
     assert float((got - want).abs().max() / want.abs().max()) < 5e-5
 
@@ -1393,10 +1395,23 @@ def test_assemble_queries_by_slot_equals_by_voxel(dev):
                                               n, C, Ci, B, ncam, H, W, max_ne, P(outs[0]), P(outs[1]), P(outs[2]), P(outs[3]),
                                               P(outs[4]) if use_pos else None, P(counts) if with_counts else None, ops._stream()))
         return outs[:4] + ([outs[4]] if use_pos else [])
+    def run_slots(use_att, use_pos, ptr_table):
+        """round 4: df3d_assemble_queries2_slots (a wave per slot, padding rows written by the same launch)"""
+        outs = [torch.full((B * ncam, max_ne, k), -3.0, device=dev) for k in (C, Ci, 2, 3, C)]
+        table = torch.empty((B * ncam * max_ne,), dtype=torch.int32, device=dev)
+        ptrs = torch.tensor([img[i].data_ptr() for i in range(B * ncam)], dtype=torch.int64, device=dev) if ptr_table else None
+        _lib.check(lib.df3d_assemble_queries2_slots(P(feat), P(pinv), P(ind), P(grid), P(mask), P(pos), None if ptr_table else P(img),
+                                                    P(ptrs), P(att) if use_att else None, n, C, Ci, B, ncam, H, W, max_ne,
+                                                    P(outs[0]), P(outs[1]), P(outs[2]), P(outs[3]), P(outs[4]) if use_pos else None,
+                                                    P(counts), P(table), None, None, ops._stream()))
+        return outs[:4] + ([outs[4]] if use_pos else [])
     for use_att, use_pos in ((True, True), (False, False)):
         a, b = run(True, use_att, use_pos), run(False, use_att, use_pos)
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+        for ptr_table in (False, True):
+            for x, y in zip(run_slots(use_att, use_pos, ptr_table), b):
+                assert torch.equal(x, y)
 
 
 @pytest.mark.gpu
@@ -1529,8 +1544,8 @@ def test_three_part_mode_end_to_end_detector():
 
 
 def test_value_rows_on_a_side_stream_equal_the_in_line_chain(monkeypatch):
-    """Round 4: the image side of ACTR (moments, GroupNorm fold, value rows) queued on its own stream beside the query
-    assembly (ACTR.start_values, DF3D_VALUE_SIDE) -- bit-identical head maps to the single-stream order, over several frames
+    """Round 4 (opt-in): the image side of ACTR (moments, GroupNorm fold, value rows) queued on its own stream beside the query
+    assembly (ACTR.start_values, DF3D_VALUE_SIDE=1) -- bit-identical head maps to the single-stream order, over several frames
     (the buffers of both streams are recycled between them) and from a non-default caller stream."""
     from dualfusion import synth
     from dualfusion.fusion import build_centerpoint_fusion, synthetic_camera_inputs
@@ -1566,3 +1581,100 @@ def test_value_rows_on_a_side_stream_equal_the_in_line_chain(monkeypatch):
     other.synchronize()
     for a, b in zip(want, got2):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+def test_pixel_major_query_rows_equal_the_channel_first_gather():
+    """Round 4: df3d_query_pixel_rows (rank of every sampled pixel) + df3d_imgproj_split_compact (both projection kernels: the
+    raw rows of the marked pixels, pixel-major, next to unchanged split rows / gate) + df3d_assemble_queries2_slots reading
+    them: identical query tensors to the gather from the channel-first maps; every marked pixel's row equals its map column."""
+    import ctypes
+    from dualfusion import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    B, ncam, H, W, C, Ci, n = 1, 6, 30, 53, 128, 256, 6000
+    S = H * W
+    ind = torch.zeros(n, 4, dtype=torch.int32)
+    mask = (torch.rand(ncam, n, generator=g) < 0.25).to(torch.uint8)
+    grid = torch.stack([torch.randint(0, W, (ncam, n), generator=g), torch.randint(0, H, (ncam, n), generator=g)], 2).int()
+    feat, pinv = torch.randn(n, C, generator=g), torch.rand(n, 3, generator=g) * 50
+    img, att = torch.randn(B * ncam, Ci, H, W, generator=g), torch.rand(B * ncam, H, W, generator=g)
+    t = lambda x: x.to(dev).contiguous()                             # noqa: E731
+    ind, mask, grid, feat, pinv, img, att = [t(x) for x in (ind, mask, grid, feat, pinv, img, att)]
+    P = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None else ctypes.c_void_p(0)   # noqa: E731
+    pos = torch.empty((ncam, n), dtype=torch.int32, device=dev)
+    counts = torch.empty((B * ncam,), dtype=torch.int32, device=dev)
+    _lib.check(lib.df3d_query_slots(P(mask), P(ind), n, B, ncam, P(pos), P(counts), ops._stream()))
+    max_ne = int(counts.max())
+    nws = int(lib.df3d_query_pixel_rows_workspace_bytes(B, ncam, H, W))
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+    pixrow = torch.empty((B * ncam, S), dtype=torch.int32, device=dev)
+    total = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _lib.check(lib.df3d_query_pixel_rows(P(ind), P(grid), P(mask), n, B, ncam, H, W, P(pixrow), P(total), P(ws), nws, ops._stream()))
+    total = int(total)
+    marked = pixrow >= 0
+    assert total == int(marked.sum()) and 0 < total < B * ncam * S
+    assert sorted(pixrow[marked].tolist()) == list(range(total))
+    ptrs = torch.tensor([img[i].data_ptr() for i in range(B * ncam)], dtype=torch.int64, device=dev)
+    packed = ops.imgproj_pack(torch.randn(144, Ci, generator=g).to(dev) * 0.05)
+    u0, g0 = ops.imgproj_split(ptrs, B * ncam, Ci, S, packed)
+    rows_of = img.view(B * ncam, Ci, S).permute(0, 2, 1)[marked]                 # [total, Ci] in (image, pixel) order
+    want_compact = torch.empty_like(rows_of)
+    want_compact[pixrow[marked].long()] = rows_of
+    for direct in ("0", "1"):
+        os.environ["DF3D_IMGPROJ_DIRECT"] = direct
+        try:
+            u1, g1, compact = ops.imgproj_split(ptrs, B * ncam, Ci, S, packed, pixrow=pixrow, pixrow_total=total)
+        finally:
+            os.environ.pop("DF3D_IMGPROJ_DIRECT", None)
+        assert torch.equal(u1, u0) and torch.equal(g1, g0) and torch.equal(compact, want_compact), direct
+
+    def run(use_compact):
+        outs = [torch.full((B * ncam, max_ne, k), -3.0, device=dev) for k in (C, Ci, 2, 3, C)]
+        table = torch.empty((B * ncam * max_ne,), dtype=torch.int32, device=dev)
+        _lib.check(lib.df3d_assemble_queries2_slots(P(feat), P(pinv), P(ind), P(grid), P(mask), P(pos), P(img), None, P(att), n, C, Ci,
+                                                    B, ncam, H, W, max_ne, P(outs[0]), P(outs[1]), P(outs[2]), P(outs[3]), P(outs[4]),
+                                                    P(counts), P(table), P(pixrow) if use_compact else None,
+                                                    P(compact) if use_compact else None, ops._stream()))
+        return outs
+    for x, y in zip(run(True), run(False)):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_detector_with_pixel_major_query_rows_equals_plain(monkeypatch):
+    """The CenterPoint + 3D-DF detector with DF3D_ASSEMBLE_COMPACT=1 (the frame head ranks the sampled pixels, the image
+    projection writes their rows pixel-major, the by-slot assembly reads them) against the default gather: bit-identical head
+    maps, frame after frame through the prefetching step()."""
+    from dualfusion import synth
+    from dualfusion.fusion import build_centerpoint_fusion, synthetic_camera_inputs
+    from dualfusion.pipeline import CenterPointDetector
+    dev = torch.device("cuda:0")
+
+    def run(mode):
+        monkeypatch.setenv("DF3D_ASSEMBLE_COMPACT", mode)
+        frames = []
+        for j in range(3):
+            bd, ex = synthetic_camera_inputs(1, dev, seed=8 + j, yaw_offset_deg=2.0 * j)
+            frames.append(([torch.from_numpy(synth.nusc_sweep(seed=30 + j)).to(dev)], bd, ex))
+        torch.cuda.synchronize()
+        torch.manual_seed(0)
+        m = CenterPointDetector(fusion=build_centerpoint_fusion()).eval().to(dev)
+        m.hot_path.resident_inputs = True                  # the clouds are complete in device memory (synchronised above)
+        if m.hot_path.fusion is not None:
+            m.hot_path.fusion.resident_inputs = True
+        outs, used = [], 0
+        with torch.no_grad():
+            for rnd in range(2):
+                for j, (pts, bd, ex) in enumerate(frames):
+                    used += int(bool(m.hot_path.prefetch(pts, bd)))          # the frame head: pixel ranks come from it
+                    x, _ = m.hot_path(pts, batch_dict=bd, example=ex)
+                    outs.append([v.clone() for p in m.bbox_head(x) for _, v in sorted(p.items())])
+        torch.cuda.synchronize()
+        m.hot_path.close()
+        return outs, used
+    (want, _), (got, used) = run("0"), run("1")
+    assert used >= 4, used
+    for a, b in zip(want, got):
+        assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))

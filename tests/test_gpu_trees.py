@@ -745,4 +745,19 @@ def test_launch_tape_over_neck_and_head_equals_plain_detector():
                 for a, b in zip(run(taped, pts, ex, True), run(plain, pts, ex, True)):
                     assert torch.equal(a, b), ("updated", rnd, j)
         assert st["plain"] == before["plain"] + 1 and st["recorded"] == before["recorded"] + 1, st
+        # a precision round trip (split -> split3 -> split): the modules replace their packed filters / plans when the mode
+        # changes, so the tape of the returning mode must be recorded again instead of replayed with the old addresses
+        from dualfusion import ops as _ops
+        old_mode = _ops.CONV_PRECISION
+        before = dict(st)
+        try:
+            for mode in ("split3", old_mode):
+                _ops.CONV_PRECISION = mode
+                for rnd in range(2):
+                    for j, (pts, ex) in enumerate(frames):
+                        for a, b in zip(run(taped, pts, ex, True), run(plain, pts, ex, True)):
+                            assert torch.equal(a, b), (mode, rnd, j)
+        finally:
+            _ops.CONV_PRECISION = old_mode
+        assert st["plain"] == before["plain"] + 2 and st["recorded"] == before["recorded"] + 2, st
     torch.cuda.synchronize()
