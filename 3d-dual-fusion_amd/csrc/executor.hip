@@ -111,6 +111,8 @@ struct RunState {
   std::vector<std::pair<int, const int32_t *>> rulebooks;     // (rulebook id, nbr table)
   std::vector<int> rulebook_set;                              // index set of the rulebook's outputs
   std::vector<const int32_t *> layer_nbr;
+  std::vector<const void *> rulebook_lists;                   // per rulebook: df3d_nbr_row_lists blob or NULL
+  std::vector<const void *> layer_lists;                      // per layer: its table's row lists or NULL
   std::vector<int> layer_in_set;
   std::vector<char> need_f32;
   int32_t *count_dev = nullptr;
@@ -134,6 +136,7 @@ int state_init(RunState &S, const df3d_layer *layers, int nlayers, const int32_t
   memcpy(S.shape, shape, sizeof(S.shape));
   S.outs.assign(nlayers, LayerOut());
   S.layer_nbr.assign(nlayers, nullptr);
+  S.layer_lists.assign(nlayers, nullptr);
   S.layer_in_set.assign(nlayers, 0);
   IndexSet s0;
   s0.indices = indices;
@@ -181,11 +184,13 @@ int geo_layer(RunState &S, int li, hipStream_t gstream, bool *new_table) {
   }
   // ---- neighbour table: shared through the rulebook id, or built here ----
   const int32_t *nbr = nullptr;
+  const void *lists = nullptr;
   int out_set = -1;
   if (L.rulebook >= 0)
     for (size_t r = 0; r < S.rulebooks.size(); ++r)
       if (S.rulebooks[r].first == L.rulebook) {
         nbr = S.rulebooks[r].second;
+        lists = S.rulebook_lists[r];
         out_set = S.rulebook_set[r];
         DF3D_CHECK_ARG(L.kind != 0 || out_set == in_set,
                        "backbone_run: layer %d shares rulebook %d but reads another index set", li, L.rulebook);
@@ -255,10 +260,30 @@ int geo_layer(RunState &S, int li, hipStream_t gstream, bool *new_table) {
       nbr = t;
     }
     *new_table = true;
+    // Row lists of the table (round 4) when the layer that builds it runs on the small-channel vector kernel: those tables
+    // are ~90 % empty, and the kernel then reads the present pairs instead of all K entries of every row.  Built here, in the
+    // geometry phase (the frame head's stream, a frame ahead); layers that share the rulebook share the lists.
+    static const bool lists_on = !(getenv("DF3D_ROW_LISTS") && getenv("DF3D_ROW_LISTS")[0] == '0');
+    const bool fp32_small = !(L.reserved & 1) && !(L.packed && (L.reserved & (2 | 8))) &&
+                            !(L.packed && df3d_conv_packed_weight_bytes(K, L.cin, L.cout) != 0);   // conv_layer's last branch
+    const int n_rows = S.sets[out_set].n;
+    if (lists_on && fp32_small && L.cin <= 16 && (L.cout == 16 || L.cout == 32) && n_rows >= 2048 &&
+        S.sets[in_set].n < (1 << 26)) {
+      const size_t lb = df3d_nbr_row_lists_bytes(K, n_rows);
+      void *blob = lb ? mem.take(lb) : nullptr;
+      if (lb && !blob) return DF3D_ENOMEM;
+      if (blob) {
+        int rc = df3d_nbr_row_lists(nbr, K, n_rows, S.sets[in_set].n, blob, lb, gs_);
+        if (rc) return rc;
+        lists = blob;
+      }
+    }
     S.rulebooks.push_back(std::make_pair(L.rulebook, nbr));
+    S.rulebook_lists.push_back(lists);
     S.rulebook_set.push_back(out_set);
   }
   S.layer_nbr[li] = nbr;
+  S.layer_lists[li] = lists;
   S.layer_in_set[li] = in_set;
   S.outs[li].set = out_set;
   S.outs[li].channels = L.cout;
@@ -367,8 +392,8 @@ int conv_layer(RunState &S, int li, const float *features, df3d_layer_view *view
                                     res, L.relu, o.features, o.split, nullptr, 0, stream_);
     if (rc) return rc;
   } else {
-    int rc = df3d_sparse_conv_fused(in_feat, n_in, L.cin, L.weight, K, L.cout, nbr, n_out, L.bias, L.scale, L.shift,
-                                    res, L.relu, o.features, stream_);
+    int rc = df3d_sparse_conv_fused_lists(in_feat, n_in, L.cin, L.weight, K, L.cout, nbr, S.layer_lists[li], n_out, L.bias,
+                                          L.scale, L.shift, res, L.relu, o.features, stream_);
     if (rc) return rc;
   }
   v.features = o.features;

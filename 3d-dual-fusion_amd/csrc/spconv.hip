@@ -732,6 +732,153 @@ static int launch_small(const ConvArgs &a, hipStream_t stream) {
   return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 4: the same layers from ROW LISTS.  The table nbr[K][N] of these layers is 89-94 % empty (conv1: ~3 of 27 offsets per
+// row, the stride-2 layer behind it: ~1.5), yet every row read all K entries -- 27 loads per lane and a 27-step compaction
+// for 2-3 gathers: 4-9 MB of indices per launch against 0.2-0.5 MB of present pairs, 12-13 us (16 -> 16) and 33 us
+// (16 -> 32) per launch at 0.03-0.06 of the HBM roof (profiles/r04_pmc_by_kernel.json: waves 64-70 % waiting).  The lists
+// are the table's present entries per row, offsets ascending, packed (offset << 26 | input row), rows back to back:
+// off[N + 1] u32 + ent[pairs] u32 (df3d_nbr_row_lists: count, scan, fill -- in the geometry phase, i.e. on the frame head's
+// stream a frame ahead).  Same products in the same order as spconv_small_kernel: bit-identical results.
+struct RowLists {
+  const uint32_t *off;   // [n_out + 1]
+  const uint32_t *ent;   // [off[n_out]]
+};
+static thread_local RowLists g_lists_hint = {nullptr, nullptr};   // set around sparse_conv_impl by df3d_sparse_conv_fused_lists
+
+template <int CIN, int COUT, int NT>
+__global__ __launch_bounds__(NT) void spconv_small_lists_kernel(ConvArgs a, RowLists L) {
+  constexpr int LPR = COUT / 4;                   // lanes per row
+  constexpr int RPB = NT / LPR;                   // rows per workgroup pass
+  constexpr int CINP = CIN <= 8 ? 8 : 16;
+  constexpr int KS = CINP / 4;
+  constexpr int WSTR = CIN * COUT + 32;
+  extern __shared__ float Wl[];                   // [K][WSTR] filters
+  const int tid = threadIdx.x;
+  const int c4 = (tid % LPR) * 4, rl = tid / LPR;
+  // the first row's list bounds travel while the filter bank is staged
+  int row = blockIdx.x * RPB + rl;
+  uint32_t b = 0u, e = 0u;
+  if (row < a.n_out) b = L.off[row], e = L.off[row + 1];
+  {
+    // filter bank -> LDS, eight 16-byte loads in flight per thread (one load per loop trip made the staging a chain of
+    // 7-14 dependent L2 round trips: most of the launch for a workgroup that owns 32-64 rows)
+    const int total = a.K * CIN * COUT / 4;
+    for (int b0 = 0; b0 < total; b0 += NT * 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = b0 + u * NT + tid;
+        t[u] = ((const f32x4 *)a.w)[i < total ? i : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = b0 + u * NT + tid;
+        if (i < total) {
+          const int k = i / (CIN * COUT / 4), r = i - k * (CIN * COUT / 4);
+          *(f32x4 *)(Wl + (size_t)k * WSTR + r * 4) = t[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (; row < a.n_out; row += gridDim.x * RPB) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t pk = b < e ? L.ent[b] : 0u;
+    // the next pass's bounds (independent of this row's gathers)
+    const int nrow = row + gridDim.x * RPB;
+    uint32_t nb = 0u, ne = 0u;
+    if (nrow < a.n_out) nb = L.off[nrow], ne = L.off[nrow + 1];
+    for (uint32_t j = b; j < e; ++j) {
+      const uint32_t cur = pk;
+      if (j + 1 < e) pk = L.ent[j + 1];           // the next entry while this one's row is gathered
+      const int k = cur >> 26;
+      const float *f = a.feat + (size_t)(cur & 0x3ffffffu) * CIN;
+      float x[CINP];
+      if constexpr (CIN % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < CIN / 4; ++q) {
+          const f32x4 v = *(const f32x4 *)(f + q * 4);
+          x[q * 4] = v[0], x[q * 4 + 1] = v[1], x[q * 4 + 2] = v[2], x[q * 4 + 3] = v[3];
+        }
+      } else {
+#pragma unroll
+        for (int ci = 0; ci < CINP; ++ci) x[ci] = ci < CIN ? f[ci] : 0.f;
+      }
+      const float *wk = Wl + (size_t)k * WSTR + c4;
+#pragma unroll
+      for (int jj = 0; jj < KS; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ci = g * KS + jj;
+          if (ci >= CIN) continue;
+          const f32x4 w = *(const f32x4 *)(wk + ci * COUT);
+          acc[0] = fmaf(x[ci], w[0], acc[0]);
+          acc[1] = fmaf(x[ci], w[1], acc[1]);
+          acc[2] = fmaf(x[ci], w[2], acc[2]);
+          acc[3] = fmaf(x[ci], w[3], acc[3]);
+        }
+    }
+    f32x4 v = acc;
+    if (a.bias) v += *(const f32x4 *)(a.bias + c4);
+    if (a.scale) v = v * *(const f32x4 *)(a.scale + c4) + *(const f32x4 *)(a.shift + c4);
+    else if (a.shift) v += *(const f32x4 *)(a.shift + c4);
+    const size_t o = (size_t)row * COUT + c4;
+    if (a.residual) v += *(const f32x4 *)(a.residual + o);
+    if (a.relu) {
+      v[0] = fmaxf(v[0], 0.f);
+      v[1] = fmaxf(v[1], 0.f);
+      v[2] = fmaxf(v[2], 0.f);
+      v[3] = fmaxf(v[3], 0.f);
+    }
+    *(f32x4 *)(a.out + o) = v;
+    b = nb, e = ne;
+  }
+}
+
+template <int CIN, int COUT, int NT>
+static int launch_small_lists(const ConvArgs &a, const RowLists &L, hipStream_t stream) {
+  constexpr int RPB = NT / (COUT / 4);
+  const size_t lds = (size_t)a.K * (CIN * COUT + 32) * 4;
+  static bool configured = false;
+  if (!configured && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)spconv_small_lists_kernel<CIN, COUT, NT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DF3D_MAX_KVOL * (CIN * COUT + 32) * 4));
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+      return DF3D_EHIP;
+    }
+    configured = true;
+  }
+  const int per_cu = lds > 40 * 1024 ? 2 : 4;      // resident workgroups per CU (LDS-limited)
+  const int nblk = cdiv(a.n_out, RPB), grid = nblk < num_cu_small() * per_cu ? nblk : num_cu_small() * per_cu;
+  hipLaunchKernelGGL((spconv_small_lists_kernel<CIN, COUT, NT>), dim3(grid), dim3(NT), lds, stream, a, L);
+  return 1;
+}
+
+static bool small_shape(int cin, int cout) {
+  return (cin == 16 && (cout == 16 || cout == 32)) || ((cin == 5 || cin == 4) && cout == 16);
+}
+
+// -> 1 served, 0 not a small shape, < 0 error
+static int dispatch_small_lists(const ConvArgs &a, const RowLists &L, hipStream_t stream) {
+  static const bool off = getenv("DF3D_SMALL_CONV") && getenv("DF3D_SMALL_CONV")[0] == '0';
+  if (off || a.n_out < 2048 || !L.off || !L.ent) return 0;
+  static const int nt = getenv("DF3D_SMALL_THREADS") ? atoi(getenv("DF3D_SMALL_THREADS")) : 0;     // tuning aid
+  if (a.cin == 16 && a.cout == 16) return nt == 512 ? launch_small_lists<16, 16, 512>(a, L, stream) : launch_small_lists<16, 16, 256>(a, L, stream);
+  if (a.cin == 5 && a.cout == 16) return launch_small_lists<5, 16, 256>(a, L, stream);
+  if (a.cin == 4 && a.cout == 16) return launch_small_lists<4, 16, 256>(a, L, stream);
+  if (a.cin == 16 && a.cout == 32) {
+    // 54 KB of filters allow two workgroups per CU: at 256 threads that is two waves per SIMD for a kernel that is a chain
+    // of memory round trips per row
+    // (measured on MI355X, 83 k output rows: 256 threads 24.3 us, 512 threads 16.0 us, 1024 threads 20.8 us)
+    if (nt == 256) return launch_small_lists<16, 32, 256>(a, L, stream);
+    if (nt == 1024) return launch_small_lists<16, 32, 1024>(a, L, stream);
+    return launch_small_lists<16, 32, 512>(a, L, stream);
+  }
+  return 0;
+}
+
 // -> 1 served, 0 not a small shape, < 0 error
 static int dispatch_small(const ConvArgs &a, hipStream_t stream) {
   static const bool off = getenv("DF3D_SMALL_CONV") && getenv("DF3D_SMALL_CONV")[0] == '0';
@@ -982,6 +1129,72 @@ extern "C" int df3d_sparse_conv_fused_tiled(const float *features, int n_in, int
                           tile_rows, ntiles, stream_);
 }
 
+// ---- row lists of a neighbour table (round 4; see spconv_small_lists_kernel) ----
+__global__ __launch_bounds__(256) void nbr_row_count_kernel(const int32_t *__restrict__ nbr, int K, int n_out,
+                                                            uint32_t *__restrict__ cnt) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_out) return;
+  uint32_t c = 0;
+  if (r < n_out)
+    for (int k = 0; k < K; ++k) c += nbr[(size_t)k * n_out + r] >= 0 ? 1u : 0u;
+  cnt[r] = c;                                      // cnt[n_out] = 0: the scan then leaves the total in off[n_out]
+}
+
+__global__ __launch_bounds__(256) void nbr_row_fill_kernel(const int32_t *__restrict__ nbr, int K, int n_out,
+                                                           const uint32_t *__restrict__ off, uint32_t *__restrict__ ent) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_out) return;
+  uint32_t j = off[r];
+  for (int k = 0; k < K; ++k) {
+    const int v = nbr[(size_t)k * n_out + r];
+    if (v >= 0) ent[j++] = (uint32_t)v | ((uint32_t)k << 26);
+  }
+}
+
+static size_t lists_off_bytes(int n_out) { return align_up(((size_t)n_out + 1) * 4, 256); }
+
+extern "C" size_t df3d_nbr_row_lists_bytes(int kvol, int n_out) {
+  if (kvol <= 0 || kvol > DF3D_MAX_KVOL || n_out <= 0) return 0;
+  // off | ent (capacity: every entry present) | counts | scan scratch
+  return lists_off_bytes(n_out) + align_up((size_t)kvol * n_out * 4, 256) + lists_off_bytes(n_out) +
+         scan_scratch_bytes((size_t)n_out + 1);
+}
+
+extern "C" int df3d_nbr_row_lists(const int32_t *nbr, int kvol, int n_out, int n_in, void *lists, size_t lists_bytes,
+                                  void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(nbr && lists, "nbr_row_lists: null argument");
+  DF3D_CHECK_ARG(kvol > 0 && kvol <= DF3D_MAX_KVOL && kvol <= 64 && n_out > 0, "nbr_row_lists: bad sizes");
+  DF3D_CHECK_ARG(n_in < (1 << 26), "nbr_row_lists: %d input rows do not fit the packed entry (26 bits)", n_in);
+  DF3D_CHECK_ARG(lists_bytes >= df3d_nbr_row_lists_bytes(kvol, n_out), "nbr_row_lists: blob of %zu bytes is too small", lists_bytes);
+  char *p = (char *)lists;
+  uint32_t *off = (uint32_t *)p;
+  uint32_t *ent = (uint32_t *)(p + lists_off_bytes(n_out));
+  uint32_t *cnt = (uint32_t *)((char *)ent + align_up((size_t)kvol * n_out * 4, 256));
+  void *scratch = (char *)cnt + lists_off_bytes(n_out);
+  hipLaunchKernelGGL(nbr_row_count_kernel, dim3(cdiv(n_out + 1, 256)), dim3(256), 0, stream, nbr, kvol, n_out, cnt);
+  int rc = exclusive_scan_u32(cnt, off, (size_t)n_out + 1, nullptr, scratch, scan_scratch_bytes((size_t)n_out + 1), stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nbr_row_fill_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, stream, nbr, kvol, n_out, off, ent);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_sparse_conv_fused_lists(const float *features, int n_in, int cin, const float *filters, int kvol,
+                                            int cout, const int32_t *nbr, const void *lists, int n_out, const float *bias,
+                                            const float *scale, const float *shift, const float *residual, int relu,
+                                            float *out, void *stream_) {
+  if (lists && n_out > 0 && small_shape(cin, cout)) {
+    const char *p = (const char *)lists;
+    g_lists_hint.off = (const uint32_t *)p;
+    g_lists_hint.ent = (const uint32_t *)(p + lists_off_bytes(n_out));
+  }
+  int rc = sparse_conv_impl(features, n_in, cin, filters, kvol, cout, nbr, n_out, bias, scale, shift, residual, relu, out,
+                            nullptr, 0, stream_);
+  g_lists_hint.off = g_lists_hint.ent = nullptr;
+  return rc;
+}
+
 static int sparse_conv_impl(const float *features, int n_in, int cin, const float *filters, int kvol, int cout,
                             const int32_t *nbr, int n_out, const float *bias, const float *scale, const float *shift,
                             const float *residual, int relu, float *out, const int32_t *tile_rows, int ntiles,
@@ -1027,7 +1240,9 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
     return DF3D_OK;
   }
   {
-    int r = dispatch_small(a, stream);             // C <= 16 input channels: vector-ALU kernel
+    int r = 0;
+    if (g_lists_hint.off) r = dispatch_small_lists(a, g_lists_hint, stream);   // row lists given (df3d_sparse_conv_fused_lists)
+    if (r == 0) r = dispatch_small(a, stream);     // C <= 16 input channels: vector-ALU kernel
     if (r < 0) return r;
     done = r == 1;
   }

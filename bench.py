@@ -277,6 +277,9 @@ def trace_kernel_name(cin, cout, K, split, n_out):
     csrc/spconv_split.hip (`launch_os_split`, `launch_os_split_wide`, `use_lc`)."""
     if not split:
         if n_out >= 2048 and (cin, cout) in ((16, 16), (5, 16), (4, 16), (16, 32)):
+            if os.environ.get("DF3D_ROW_LISTS", "1") != "0" and os.environ.get("DF3D_EXECUTOR", "1") != "0":
+                # the executor builds row lists for these tables (round 4): `dispatch_small_lists`
+                return "spconv_small_lists_kernel<%d, %d, %d>" % (cin, cout, 512 if cout == 32 else 256)
             return "spconv_small_kernel<%d, %d>" % (cin, cout)
         return "spconv_mfma_kernel<%d, %d, ...>" % (max(cin, 8), cout)
     gy = max(1, cout // 128) if cout % 128 == 0 else 1
@@ -684,6 +687,8 @@ def main():
     dev = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     # nccl == RCCL on ROCm.  At N = 1 a one-rank group is created as well, so the step's collectives (reduce of the loss
     # scalars, gradient buckets) go through RCCL exactly as at N > 1 -- `collective_backend` on the JSON line says so.
+    # (The reference's reduce_dict returns its input at one rank, utils.py:164-166; taking that shortcut was measured in
+    # round 4 and is not faster: 2.755 against 2.728 ms per step.)
     try:
         rank, local, world = D.init_from_env(args.backend or ("nccl" if use_gpu else "gloo"), single=use_gpu and not protocol)
     except Exception as e:                                       # noqa: BLE001

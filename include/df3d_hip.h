@@ -165,6 +165,20 @@ int df3d_sparse_conv_fused_tiled(const float *features, int n_in, int cin,
                                  const float *residual, int relu, float *out,
                                  const int32_t *tile_rows, int ntiles, void *stream);
 
+/* round 4 -- ROW LISTS of a neighbour table for the small-channel layers (C_in <= 16, C_out 16 | 32: conv_input and the conv1
+ * stage of the backbones, whose tables are ~90 % empty): the present entries of every output row, offsets ascending, packed
+ * (offset << 26 | input row), rows back to back.  Same role as the reference's compacted indice_pairs[K][2][N] + indice_num[K]
+ * (spconv_ops.h:27-141), transposed to output-row order so that the accumulation order stays the table's.
+ *   df3d_nbr_row_lists_bytes(kvol, n_out)   bytes of the blob (offsets, entries at full capacity, scratch)
+ *   df3d_nbr_row_lists                      builds it (count, scan, fill: three launches, no host round trip); n_in < 2^26
+ *   df3d_sparse_conv_fused_lists            df3d_sparse_conv_fused that takes the blob (NULL, or a shape the small-channel
+ *                                           kernel does not serve: exactly df3d_sparse_conv_fused).  Bit-identical results. */
+size_t df3d_nbr_row_lists_bytes(int kvol, int n_out);
+int df3d_nbr_row_lists(const int32_t *nbr, int kvol, int n_out, int n_in, void *lists, size_t lists_bytes, void *stream);
+int df3d_sparse_conv_fused_lists(const float *features, int n_in, int cin, const float *filters, int kvol, int cout,
+                                 const int32_t *nbr, const void *lists, int n_out, const float *bias, const float *scale,
+                                 const float *shift, const float *residual, int relu, float *out, void *stream);
+
 /* Per-launch timing of the sparse-conv kernels with HIP events recorded on the launching stream, adjacent
  * to the launch (measurement aid for bench.py's roofline leg; off by default, not thread-safe).
  * begin: reset + enable.  end: disable, returns the number of records.  get: shape4 = (cin, cout, kvol,

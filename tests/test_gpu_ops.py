@@ -1678,3 +1678,59 @@ def test_detector_with_pixel_major_query_rows_equals_plain(monkeypatch):
     assert used >= 4, used
     for a, b in zip(want, got):
         assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,strided", [(5, 16, False), (16, 16, False), (16, 32, True)])
+def test_small_channel_conv_from_row_lists(cin, cout, strided):
+    """Round 4: df3d_nbr_row_lists (the present entries of every output row of a neighbour table: offsets, packed entries)
+    against numpy, and df3d_sparse_conv_fused_lists against df3d_sparse_conv_fused on the same table: bit-identical rows
+    (bias, folded BN, residual, ReLU in the epilogue), submanifold and stride-2 geometry of a nuScenes-shaped sweep."""
+    import ctypes
+    from dualfusion import _lib, ops, synth
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    P = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None else ctypes.c_void_p(0)   # noqa: E731
+    pts = synth.nusc_sweep(seed=3)
+    _, c, _, _ = ops.hard_voxelize(torch.from_numpy(pts).to(dev), synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, 60000)
+    shape = [41, 1440, 1440]
+    ind = torch.cat([torch.zeros((c.shape[0], 1), dtype=torch.int32, device=dev), c], 1).contiguous()
+    n_in = ind.shape[0]
+    if strided:
+        oshape = [(v + 2 - 3) // 2 + 1 for v in shape]
+        out_ind, _ = ops.conv_out_indices(ind, 1, shape, oshape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+        out_ind = out_ind.contiguous()
+        grid = ops.grid_build(ind, 1, shape)
+        nbr = ops.conv_neighbors(grid, out_ind, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+        n_out = out_ind.shape[0]
+    else:
+        grid = ops.grid_build(ind, 1, shape)
+        nbr = ops.subm_neighbors(grid, ind, [3, 3, 3])
+        n_out = n_in
+    K = nbr.shape[0]
+    nb = int(lib.df3d_nbr_row_lists_bytes(K, n_out))
+    blob = torch.zeros((nb,), dtype=torch.uint8, device=dev)
+    _lib.check(lib.df3d_nbr_row_lists(P(nbr), K, n_out, n_in, P(blob), nb, ops._stream()))
+    torch.cuda.synchronize()
+    t = nbr.cpu().numpy()                                               # [K, n_out]
+    off = blob[:(n_out + 1) * 4].view(torch.int32).cpu().numpy().astype(np.int64)
+    want_cnt = (t >= 0).sum(0)
+    assert off[0] == 0 and np.array_equal(np.diff(off), want_cnt)
+    off_bytes = ((n_out + 1) * 4 + 255) // 256 * 256
+    ent = blob[off_bytes:off_bytes + int(off[-1]) * 4].view(torch.int32).cpu().numpy().astype(np.int64)
+    ks, rows = np.nonzero(t.T >= 0)[1], np.nonzero(t.T >= 0)[0]           # row-major walk: rows ascending, offsets ascending
+    assert np.array_equal(ent >> 26, ks) and np.array_equal(ent & 0x3ffffff, t.T[rows, ks])
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    feat = torch.randn(n_in, cin, generator=g).to(dev)
+    w = (torch.randn(K, cin, cout, generator=g) * 0.2).to(dev)
+    bias, scale, shift = [torch.randn(cout, generator=g).to(dev) for _ in range(3)]
+    res = torch.randn(n_out, cout, generator=g).to(dev)
+    for use_res, relu in ((True, 1), (False, 0)):
+        want = torch.empty((n_out, cout), device=dev)
+        got = torch.full((n_out, cout), -7.0, device=dev)
+        _lib.check(lib.df3d_sparse_conv_fused(P(feat), n_in, cin, P(w), K, cout, P(nbr), n_out, P(bias), P(scale), P(shift),
+                                              P(res) if use_res else None, relu, P(want), ops._stream()))
+        _lib.check(lib.df3d_sparse_conv_fused_lists(P(feat), n_in, cin, P(w), K, cout, P(nbr), P(blob), n_out, P(bias), P(scale),
+                                                    P(shift), P(res) if use_res else None, relu, P(got), ops._stream()))
+        assert torch.equal(got, want), (use_res, relu)
+    assert float(want.abs().max()) > 0.1
