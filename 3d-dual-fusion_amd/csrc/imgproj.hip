@@ -428,12 +428,19 @@ __global__ __launch_bounds__(256) void gn_fold_pack_kernel(const double *__restr
     tc[tid] = (bc - (float)mean) * rstd * gamma[tid] + beta[tid];
   }
   __syncthreads();
-  for (int o = tid; o < O; o += 256) {
-    float acc = wb ? wb[o] : 0.f;
-    for (int c = 0; c < C; ++c) acc += W[(size_t)o * C + c] * tc[c];
-    cf[(size_t)n * O + o] = acc;
+  // (round 4) gridDim.y workgroups share an image: one workgroup per image was six workgroups walking 32 dependent
+  // iterations each -- 17 us of latency between the moments and the GEMM
+  const int part = blockIdx.y, nparts = gridDim.y;
+  // the folded constant: 16 lanes per output walk the row in channel order 16-apart, partial sums meet by shuffles
+  for (int o = part * 16 + (tid >> 4); o < O; o += 16 * nparts) {
+    const int l = tid & 15;
+    float acc = 0.f;
+    for (int c = l; c < C; c += 16) acc += W[(size_t)o * C + c] * tc[c];
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 16);
+    if (l == 0) cf[(size_t)n * O + o] = acc + (wb ? wb[o] : 0.f);
   }
-  for (int i = tid; i < 4 * RG_WQ; i += 256) {
+  for (int i = part * 256 + tid; i < 4 * RG_WQ; i += 256 * nparts) {
     int lane = i & 63, part = (i >> 6) & 1, ct = (i >> 7) & 15, kb = i >> 11;
     int col = (ct >> 2) * 64 + (lane & 15) * 4 + (ct & 3), gq = lane >> 4;   // store q = ct/4 writes 256 B runs
     unsigned v[8];
@@ -617,7 +624,7 @@ static int value_fold_gemm(const void *u_split, const float *att, int nimg, int 
   const int rpb = 160;          // ~1500 blocks at nuScenes size: enough waves to stream at HBM rate
   hipLaunchKernelGGL(split_moments_kernel, dim3(cdiv(S, rpb), nimg), dim3(256), 0, stream, (const u32x4 *)u_split, att,
                      S, rpb, moments);
-  hipLaunchKernelGGL(gn_fold_pack_kernel, dim3(nimg), dim3(256), 0, stream, moments, conv_bias, gn_weight, gn_bias, eps,
+  hipLaunchKernelGGL(gn_fold_pack_kernel, dim3(nimg, 16), dim3(256), 0, stream, moments, conv_bias, gn_weight, gn_bias, eps,
                      S, groups, W, wb, (u32x4 *)packed_w, cf);
   if (bf16)
     hipLaunchKernelGGL(rows_gemm_split_kernel<true>, dim3(cdiv(S, 128), nimg), dim3(512), 0, stream, (const u32x4 *)u_split,
