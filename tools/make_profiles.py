@@ -73,7 +73,7 @@ def summarize(cin, cout):
 
 
 import re
-m = re.search(r"cin=(\d+),cout=(\d+),K=(\d+)", roof["kernel"])
+m = re.search(r"cin=(\d+),cout=(\d+),K=(\d+)", roof["kernel"]) or re.search(r"<(\d+), (\d+)[^>]*> K=(\d+)", roof["kernel"])
 dom = (int(m.group(1)), int(m.group(2)))
 pm, conv_sel = summarize(*dom)
 pm.update({"fetch_calibration": {"factor": round(kf, 4), "write_factor": round(kw, 4),
