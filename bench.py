@@ -593,14 +593,25 @@ def side_configs(args, steps=12):
 # ------------------------------------------------------------------------------------------------ main
 def timed_steps(wl, stage, steps, first, barrier, reduce_losses):
     barrier()
-    t0 = time.perf_counter()
-    out = None
-    for k in range(steps):
-        out = wl.step(first + k, stage)
-        if isinstance(out, dict) and stage in ("detect", "train"):
-            out = reduce_losses(out)
-    barrier()                                  # synchronises the device (all streams) and the ranks
-    return time.perf_counter() - t0, out
+    # no cyclic-GC pause inside the timed steps (a generation-2 pass over a process holding ~10^5 tensor wrappers takes
+    # milliseconds: more than the queueing thread's slack per frame); reference counting frees everything the steps create
+    import gc
+    gc_was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        out = None
+        for k in range(steps):
+            out = wl.step(first + k, stage)
+            if isinstance(out, dict) and stage in ("detect", "train"):
+                out = reduce_losses(out)
+        barrier()                                  # synchronises the device (all streams) and the ranks
+        el = time.perf_counter() - t0
+    finally:
+        if gc_was:
+            gc.enable()
+    return el, out
 
 
 def host_blocked_s(wl):
