@@ -105,6 +105,10 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
         matrix product (the 1x1 convs) or as nine shifted sums of one (the 3x3 conv to one channel): same values,
         differentiable, and none of it goes through MIOpen, whose fp32 fallback kernels for these shapes take
         20-160 ms per call forward / backward."""
+        return img_feat * self.attention_rows(img_feat, canvases).unsqueeze(1)
+
+    def attention_rows(self, img_feat, canvases):
+        """The gate itself, [NI, H, W] (forward_rows without the product with the image)."""
         NI, Ci, H, W = img_feat.shape
         pt = None
         for conv_idx in self.voxel_idx:
@@ -122,7 +126,7 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
         for ty in range(3):
             for tx in range(3):
                 y = y + taps[:, ty:ty + H, tx:tx + W, ty * 3 + tx]
-        return img_feat * torch.sigmoid(y).unsqueeze(1)
+        return torch.sigmoid(y)
 
 
 _SUM_SPLIT = {}
@@ -614,6 +618,16 @@ class VoxelWithPointProjection(nn.Module):
         if img_conv_func is not None:
             imgs = img_conv_func(imgs)
         gated = imgs
+        att = None
+        # The gate is one scalar per pixel and input_proj's convolution is 1x1, so input_proj(img * att) = att * (W img) + b and
+        # the image feature at a query pixel is img[pixel] * att[pixel]: the gated copy of the camera maps (246 MB), its
+        # gradient, the data-gradient GEMM back to it and the channel reduction of (gradient x image) that autograd ran for
+        # d(att) never exist -- the maps themselves take no gradient (a frozen 2-D network produces them), d(att) comes from
+        # the 128-channel projection.  DF3D_TRAIN_GATED=1: the composition over the gated maps (the reference's order).
+        in_conv = self.pfat.input_proj[0][0]
+        factored = (self.ifat_cfg is not None and os.environ.get("DF3D_TRAIN_GATED", "0") != "1" and not imgs.requires_grad
+                    and tuple(in_conv.kernel_size) == (1, 1) and tuple(in_conv.stride) == (1, 1) and in_conv.groups == 1
+                    and len(self.pfat.input_proj) == 1 and self.pfat.feature_modal in ('image', 'hybrid'))
         if self.ifat_cfg is not None:
             canvases = {}
             for sidx in self.ifat.voxel_idx:
@@ -623,15 +637,27 @@ class VoxelWithPointProjection(nn.Module):
                 # pts2img: the winner's row at its pixel, zero elsewhere (a gather over the occupied pixels only: the
                 # backward of a dense gather with every empty pixel clamped to one row serialises on that row)
                 canvases[sidx] = rows.new_zeros((NI, H * W, rows.shape[1])).index_put((img_w, pix_w), rows[row_w])
-            gated = self.ifat.forward_rows(imgs, canvases)
+            if factored:
+                att = self.ifat.attention_rows(imgs, canvases)                      # [NI, H, W]
+            else:
+                gated = self.ifat.forward_rows(imgs, canvases)
         feats = x_last.features
         n, C = feats.shape
         Ci = gated.shape[1]
         v_feat = feats.new_zeros((NI, max_ne, C)).index_put((img_i, slot_i), feats[row_i])
-        v_i_feat = feats.new_zeros((NI, max_ne, Ci)).index_put((img_i, slot_i), gated[img_i, :, gy, gx])
         qgrid = feats.new_zeros((NI, max_ne, 2)).index_put((img_i, slot_i), qg.to(feats.dtype))
         qpts = feats.new_zeros((NI, max_ne, 3)).index_put((img_i, slot_i), pinv[row_i])
-        enh = self.pfat(v_feat, qgrid, [gated], v_i_feat, qpts)                     # [NI, max_ne, C]
+        if att is not None:
+            rows_i = imgs[img_i, :, gy, gx] * att[img_i, gy, gx].unsqueeze(1)
+            v_i_feat = feats.new_zeros((NI, max_ne, Ci)).index_put((img_i, slot_i), rows_i)
+            u = torch.matmul(in_conv.weight[:, :, 0, 0], imgs.reshape(NI, Ci, H * W))          # [NI, C', H*W]
+            src_conv = u * att.reshape(NI, 1, H * W)
+            if in_conv.bias is not None:
+                src_conv = src_conv + in_conv.bias[None, :, None]
+            enh = self.pfat.forward_projected(v_feat, qgrid, src_conv.view(NI, -1, H, W), v_i_feat, qpts)
+        else:
+            v_i_feat = feats.new_zeros((NI, max_ne, Ci)).index_put((img_i, slot_i), gated[img_i, :, gy, gx])
+            enh = self.pfat(v_feat, qgrid, [gated], v_i_feat, qpts)                     # [NI, max_ne, C]
         out = feats
         a = 0
         for cam in range(ncam):                                                     # additive, camera order (writeback_kernel)

@@ -1,5 +1,7 @@
 """CenterPoint sparse backbone (SpMiddleResNetFHD) on the MI355X modules vs the oracle composition,
 same state_dict, same synthetic sweep.  fp32, tolerance 1e-3 (north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -218,6 +220,26 @@ def test_centerpoint_fusion_adapter_training_path(golden):
     unused = ["pfat.transformer.level_embed", "pfat.transformer.encoder.layers.%d.fusion_layer.a_conv1d." % (nlay - 1)] + \
              ["ifat.reduced_dim.%d." % i for i in range(mod.ifat.voxel_idx[-1]) if i not in mod.ifat.voxel_idx]
     assert all(any(k.startswith(u) for u in unused) for k in missing), missing
+    # round 4: the default formulation factors the per-pixel gate out of input_proj (att * (W img) + b, no gated copy of the
+    # camera maps); the composition over the gated maps (the reference's order, DF3D_TRAIN_GATED=1) gives the same output and
+    # the same gradients for every voxel feature and every parameter
+    got = {"out": out.features.detach().clone(), "leaf0": leaves[0].grad.clone(), "leaf2": leaves[2].grad.clone()}
+    got.update({k: p_.grad.clone() for k, p_ in mod.named_parameters() if p_.grad is not None})
+    mod.zero_grad(set_to_none=True)
+    leaves2 = [torch.from_numpy(f).to(dev).requires_grad_(True) for f in feats]
+    xs2 = [spconv.SparseConvTensor(f, torch.from_numpy(i).to(dev), shp, B) for f, i, shp in zip(leaves2, sets, shapes)]
+    os.environ["DF3D_TRAIN_GATED"] = "1"
+    try:
+        out2 = mod(batch_dict, {}, encoded_voxel_list=xs2, layer_name='layer1_ori', fuse_mode='pfat', d_factor_list=[2, 4, 8])
+        (out2.features * wgt).sum().backward()
+    finally:
+        os.environ.pop("DF3D_TRAIN_GATED", None)
+    want = {"out": out2.features.detach(), "leaf0": leaves2[0].grad, "leaf2": leaves2[2].grad}
+    want.update({k: p_.grad for k, p_ in mod.named_parameters() if p_.grad is not None})
+    assert set(want) == set(got)
+    for k in want:
+        scale = float(want[k].abs().max())
+        assert float((got[k] - want[k]).abs().max()) <= 2e-4 * max(scale, 1e-6), (k, float((got[k] - want[k]).abs().max()), scale)
     # d(loss)/d(voxel feature) of a row no camera sees is exactly the upstream weight (identity write-back)
     inp = mod._gather_inputs(batch_dict, 'layer1_ori', dev)
     _, mask, _ = mod._project(xs[2], 8, inp)
