@@ -129,56 +129,9 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
         return torch.sigmoid(y)
 
 
-_SUM_SPLIT = {}
-
-
-def _col_sum(g2):
-    """Column sums of [n, c] in two stages ([n / d, d, c] -> [n / d, c] -> [c]): torch reduces a [240 k, 64] tensor over
-    its rows on 192 threads (2.5 ms on MI355X; rocBLAS' gemv for ones^T g is no faster); the first stage of the split has
-    n / d x c independent outputs."""
-    n = g2.shape[0]
-    d = _row_split(n)
-    if d == 0 or n // d < 8:
-        return g2.sum(0)
-    return g2.view(n // d, d, g2.shape[1]).sum(1).sum(0)
-
-
-def _row_split(n):
-    d = _SUM_SPLIT.get(n)
-    if d is None:
-        d = next((k for k in range(min(n, 2048), 63, -1) if n % k == 0), 0)
-        _SUM_SPLIT[n] = d
-    return d
-
-
-class _LinearRows(torch.autograd.Function):
-    """F.linear over a few hundred thousand pixel rows with few channels.  The library's backward is two long
-    reductions -- the bias gradient (`_col_sum`) and the weight gradient g^T x with K = rows, for which hipBLASLt picks a
-    32 x 32 x 256 tile without split-K (550 us for 120 MB): here a batched product over row chunks, then the sum of the
-    per-chunk [cout, cin] matrices."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
-
-    @staticmethod
-    @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
-        gx = (g2 @ weight).view(x.shape) if ctx.needs_input_grad[0] else None
-        n, d = g2.shape[0], _row_split(g2.shape[0])
-        if d and n // d >= 8:
-            gw = torch.bmm(g2.view(n // d, d, -1).transpose(1, 2), x2.view(n // d, d, -1)).sum(0)
-        else:
-            gw = g2.t() @ x2
-        return gx, gw, (_col_sum(g2) if ctx.has_bias else None)
-
-
-def _linear_rows(x, weight, bias=None):
-    return _LinearRows.apply(x, weight, bias)
+# (the row-linear autograd Function and its two-stage column sum live in ops.py: the ACTR modules use them too)
+_col_sum = _ops.col_sum_rows
+_linear_rows = _ops.linear_rows_autograd
 
 
 ifat_all = {'Basicgate_patch_iv_multivoxel': Basicgate_patch_iv_multivoxel}
@@ -650,7 +603,7 @@ class VoxelWithPointProjection(nn.Module):
         if att is not None:
             rows_i = imgs[img_i, :, gy, gx] * att[img_i, gy, gx].unsqueeze(1)
             v_i_feat = feats.new_zeros((NI, max_ne, Ci)).index_put((img_i, slot_i), rows_i)
-            u = torch.matmul(in_conv.weight[:, :, 0, 0], imgs.reshape(NI, Ci, H * W))          # [NI, C', H*W]
+            u = _ops.channel_first_linear(imgs.reshape(NI, Ci, H * W), in_conv.weight[:, :, 0, 0])   # [NI, C', H*W]
             src_conv = u * att.reshape(NI, 1, H * W)
             if in_conv.bias is not None:
                 src_conv = src_conv + in_conv.bias[None, :, None]

@@ -2056,12 +2056,106 @@ def pe_gather_add(feat, sel, xyz, w0, b0, w1, b1):
     return out
 
 
+# ------------------------------------------------------------------------- tall-skinny linears with autograd (training)
+_SUM_SPLIT = {}
+
+
+def _row_split(n):
+    d = _SUM_SPLIT.get(n)
+    if d is None:
+        d = next((k for k in range(min(n, 2048), 63, -1) if n % k == 0), 0)
+        _SUM_SPLIT[n] = d
+    return d
+
+
+def col_sum_rows(g2):
+    """Column sums of [n, c] in two stages ([n / d, d, c] -> [n / d, c] -> [c]): torch reduces a [240 k, 64] tensor over
+    its rows on 192 threads (2.5 ms on MI355X; rocBLAS' gemv for ones^T g is no faster); the first stage of the split has
+    n / d x c independent outputs."""
+    n = g2.shape[0]
+    d = _row_split(n)
+    if d == 0 or n // d < 8:
+        return g2.sum(0)
+    return g2.view(n // d, d, g2.shape[1]).sum(1).sum(0)
+
+
+class _LinearRows(torch.autograd.Function):
+    """F.linear over a few hundred thousand pixel rows with few channels.  The library's backward is two long
+    reductions -- the bias gradient (`col_sum_rows`) and the weight gradient g^T x with K = rows, for which hipBLASLt picks a
+    32 x 32 x 256 tile without split-K (550 us for 120 MB): here a batched product over row chunks, then the sum of the
+    per-chunk [cout, cin] matrices."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        gx = (g2 @ weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        n, d = g2.shape[0], _row_split(g2.shape[0])
+        if d and n // d >= 8:
+            gw = torch.bmm(g2.view(n // d, d, -1).transpose(1, 2), x2.view(n // d, d, -1)).sum(0)
+        else:
+            gw = g2.t() @ x2
+        return gx, gw, (col_sum_rows(g2) if ctx.has_bias else None)
+
+
+def linear_rows_autograd(x, weight, bias=None):
+    return _LinearRows.apply(x, weight, bias)
+
+
+class _ChannelFirstLinear(torch.autograd.Function):
+    """y[n] = W x[n] for channel-first maps x [N, Cin, S] with S ~ 40 k pixels (a 1x1 convolution as one batched product).
+    The library's weight gradient sum_n g[n] x[n]^T is N products with K = S and a [Cout, Cin] result: a handful of tiles,
+    no split-K (the same 32 x 32 x 256 kernel as above, ~540 us).  Here every map is cut into pixel chunks that become the
+    batch dimension of one strided batched product per map (views, no copies), and the per-chunk matrices are summed."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.matmul(weight, x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = torch.matmul(weight.t(), g) if ctx.needs_input_grad[0] else None
+        N, Cin, S = x.shape
+        d = _row_split(S)
+        if d and S // d >= 8 and g.is_contiguous() and x.is_contiguous():
+            nc = S // d
+            gw = None
+            for n in range(N):
+                gc = g[n].view(-1, nc, d).permute(1, 0, 2)                 # [chunks, Cout, d], strides (d, S, 1)
+                xc = x[n].view(Cin, nc, d).permute(1, 2, 0)                # [chunks, d, Cin]
+                part = torch.bmm(gc, xc).sum(0)
+                gw = part if gw is None else gw + part
+        else:
+            gw = torch.matmul(g, x.transpose(1, 2)).sum(0)
+        return gx, gw
+
+
+def channel_first_linear(x, weight):
+    """weight [Cout, Cin] times x [N, Cin, S] -> [N, Cout, S], differentiable (see _ChannelFirstLinear)."""
+    if x.is_cuda and (x.requires_grad or weight.requires_grad) and torch.is_grad_enabled():
+        return _ChannelFirstLinear.apply(x, weight)
+    return torch.matmul(weight, x)
+
+
 def linear_rows(x, lin, min_rows=16384):
     """`lin(x)` (nn.Linear) for many rows of few channels in a no-grad forward: the split-precision conv kernel over an
     identity table when the shape is served (fp32-grade: bf16 hi + lo operands, three MFMA products), torch otherwise.
     hipBLASLt runs these tall-skinny fp32 products at ~20 TFLOP/s on MI355X (310 us for [234 k, 64] x [64, 64])."""
     cout, cin = lin.weight.shape
     rows = x.numel() // max(1, x.shape[-1])
+    if (torch.is_grad_enabled() and x.is_cuda and rows >= min_rows and x.shape[-1] == cin
+            and (x.requires_grad or lin.weight.requires_grad)):
+        return linear_rows_autograd(x, lin.weight, lin.bias)       # training: the chunked weight gradient
     if (torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or CONV_PRECISION != "split"
             or rows < min_rows or x.shape[-1] != cin or not conv_split_supported(1, cin, cout)):
         return lin(x)

@@ -180,3 +180,30 @@ def test_late_register_fills_the_frameworks_registries():
                 del sys.modules[k]
         sys.modules.update({k: v for k, v in saved.items() if k.split(".")[0] in _FRAMEWORKS})
     assert R.late_register() == []                                   # nothing importable: nothing claimed
+
+
+def test_tall_skinny_linear_autograd_functions_match_torch():
+    """dualfusion.ops.linear_rows_autograd / channel_first_linear (training: the weight gradient over ~10^5 rows as a batched
+    product over row chunks) against torch's own autograd in float64 on the CPU."""
+    import torch
+    from dualfusion import ops
+    torch.manual_seed(0)
+    x = torch.randn(3, 40, 1602 * 8, dtype=torch.float64)
+    w = torch.randn(24, 40, dtype=torch.float64, requires_grad=True)
+    y = ops._ChannelFirstLinear.apply(x, w)
+    g = torch.randn_like(y)
+    y.backward(g)
+    w2 = w.detach().clone().requires_grad_(True)
+    y2 = torch.matmul(w2, x)
+    y2.backward(g)
+    assert torch.allclose(y, y2) and torch.allclose(w.grad, w2.grad, rtol=1e-10, atol=1e-10)
+    xr = torch.randn(2, 1602 * 9, 16, dtype=torch.float64, requires_grad=True)
+    wl = torch.randn(8, 16, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(8, dtype=torch.float64, requires_grad=True)
+    y = ops.linear_rows_autograd(xr, wl, b)
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref = [t.detach().clone().requires_grad_(True) for t in (xr, wl, b)]
+    torch.nn.functional.linear(*ref).backward(g)
+    for a, r in zip((xr, wl, b), ref):
+        assert torch.allclose(a.grad, r.grad, rtol=1e-10, atol=1e-10)
