@@ -689,23 +689,28 @@ __global__ __launch_bounds__(1024) void query_slots_kernel(const uint8_t *__rest
 // which 31 k own a slot -- and every live wave walks a chain of dependent loads (mask -> slot -> sample index -> pixel -> gate ->
 // rows) before its gathers start: 78-84 us for 48 MB, and still 63 us when the image rows are contiguous (round 4, compact
 // copy): the latency chain and the dead waves are the cost, not the plane-strided gathers.  Here a one-thread-per-candidate
-// pass writes the inverse table (slot -> voxel row; ~3 us), and a wave per SLOT of the padded [image][max_ne] tensors does
+// pass writes the inverse table (slot -> voxel row, pixel, compact row: one 16-byte entry; ~3 us), and a wave per SLOT of the padded [image][max_ne] tensors does
 // the rest: row <- table, then pixel / feature row / gate / planes at once; slots past the list length write the padding
 // rows (pad_queries_kernel's values), so no other launch touches the outputs.  Same values as assemble_queries2_kernel.
 __global__ __launch_bounds__(256) void query_inverse_kernel(const int32_t *__restrict__ ind, const uint8_t *__restrict__ mask,
-                                                            const int32_t *__restrict__ pos, int n, int ncam, int max_ne,
-                                                            int32_t *__restrict__ inv) {
+                                                            const int32_t *__restrict__ pos, const int32_t *__restrict__ grid,
+                                                            const int32_t *__restrict__ pixrow, int n, int ncam, int max_ne,
+                                                            int H, int W, int4 *__restrict__ inv) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)n * ncam) return;
   const int cam = (int)(t / n), i = (int)(t - (long long)cam * n);
   if (!mask[t]) return;
   const int slot = pos[t];
   if (slot >= max_ne) return;
-  inv[(size_t)(ind[(size_t)i * 4] * ncam + cam) * max_ne + slot] = i;
+  // everything the slot's wave needs to start ALL its loads at once: voxel row, pixel, rank of the pixel's compact row
+  const int img = ind[(size_t)i * 4] * ncam + cam;
+  const int gx = grid[(size_t)t * 2], gy = grid[(size_t)t * 2 + 1];
+  const int pr = pixrow ? pixrow[(size_t)img * H * W + (size_t)gy * W + gx] : -1;
+  inv[(size_t)img * max_ne + slot] = make_int4(i, gx, gy, pr);
 }
 
 __global__ __launch_bounds__(256) void assemble_queries4_kernel(AsmArgs2 a, const int32_t *__restrict__ counts,
-                                                                const int32_t *__restrict__ inv, int nimg) {
+                                                                const int4 *__restrict__ inv, int nimg) {
   const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (w >= (long long)nimg * a.max_ne) return;
@@ -721,16 +726,15 @@ __global__ __launch_bounds__(256) void assemble_queries4_kernel(AsmArgs2 a, cons
     if (lane < 3) a.qpts[q * 3 + lane] = 0.f;
     return;
   }
-  const int i = inv[q], cam = img % a.ncam;
-  const int2 gxy = *(const int2 *)(a.grid + ((size_t)cam * a.n + i) * 2);
-  const int gx = gxy.x, gy = gxy.y;
+  const int4 e = inv[q];
+  const int i = e.x, gx = e.y, gy = e.z;
   const size_t hw = (size_t)a.H * a.W, pix = (size_t)gy * a.W + gx;
   // every load of the row is issued before the first store
   float vf[4], vi[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) vf[j] = (lane + 64 * j < a.C) ? a.feat[(size_t)i * a.C + lane + 64 * j] : 0.f;
   if (a.compact) {                                 // pixel-major rows written by the image projection: one contiguous row
-    const float *src = a.compact + (size_t)a.pixrow[(size_t)img * hw + pix] * a.Ci;
+    const float *src = a.compact + (size_t)e.w * a.Ci;
 #pragma unroll
     for (int j = 0; j < 8; ++j) vi[j] = (lane + 64 * j < a.Ci) ? src[lane + 64 * j] : 0.f;
   } else {
@@ -893,10 +897,10 @@ static int assemble_queries2_impl(const float *features, const float *point_inv,
                    "assemble_queries2: null input");
     AsmArgs2 a = {features, point_inv, indices, grid_xy, mask, pos, img_feats, img_ptrs, att, n, channels, img_channels, ncam, H, W,
                   max_ne, v_feat, v_i_feat, qgrid, qpts, qpos, pixrow, compact};
-    hipLaunchKernelGGL(query_inverse_kernel, dim3(cdiv((long long)n * ncam, 256)), dim3(256), 0, stream, indices, mask, pos, n,
-                       ncam, max_ne, inv);
-    hipLaunchKernelGGL(assemble_queries4_kernel, dim3(cdiv((long long)nq * 64, 256)), dim3(256), 0, stream, a, counts, inv,
-                       batch * ncam);
+    hipLaunchKernelGGL(query_inverse_kernel, dim3(cdiv((long long)n * ncam, 256)), dim3(256), 0, stream, indices, mask, pos,
+                       grid_xy, compact ? pixrow : nullptr, n, ncam, max_ne, H, W, (int4 *)inv);
+    hipLaunchKernelGGL(assemble_queries4_kernel, dim3(cdiv((long long)nq * 64, 256)), dim3(256), 0, stream, a, counts,
+                       (const int4 *)inv, batch * ncam);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
   }
@@ -948,7 +952,8 @@ extern "C" int df3d_assemble_queries2(const float *features, const float *point_
                                 nullptr, nullptr, stream_);
 }
 
-// the same BY SLOT (round 4): slot_rows [batch * ncam * max_ne] i32 is scratch for the slot -> voxel row table
+// the same BY SLOT (round 4): slot_rows [batch * ncam * max_ne][4] i32 is scratch for the slot table
+// (voxel row, pixel x, pixel y, rank of the pixel's compact row)
 extern "C" int df3d_assemble_queries2_slots(const float *features, const float *point_inv, const int32_t *indices,
                                             const int32_t *grid_xy, const uint8_t *mask, const int32_t *pos,
                                             const float *img_feats, const float *const *img_ptrs, const float *att, int n,

@@ -762,7 +762,7 @@ class VoxelWithPointProjection(nn.Module):
         if by_slot:
             # a wave per SLOT (no dead candidate waves); with `compact` the image rows of the sampled pixels are pixel-major
             # (written by the image projection): one contiguous 1 KB row per query instead of 256 scattered elements
-            slot_rows = torch.empty((NI * max_ne,), dtype=torch.int32, device=dev)
+            slot_rows = torch.empty((NI * max_ne, 4), dtype=torch.int32, device=dev)
             rc = lib.df3d_assemble_queries2_slots(_p(feats), _p(pinv), _p(ind), _p(grid), _p(mask), _p(pos), None,
                                                   _p(inp['img_ptrs']), _p(att), n, C, Ci, B, ncam, H, W, max_ne, _p(v_feat),
                                                   _p(v_i_feat), _p(qgrid), _p(qpts), _p(qpos), _p(counts), _p(slot_rows),

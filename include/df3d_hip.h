@@ -669,7 +669,8 @@ int df3d_assemble_queries2(const float *features, const float *point_inv, const 
                            const int32_t *counts, void *stream);
 /* round 4 -- df3d_assemble_queries2 BY SLOT: a wave per slot of the padded [B*ncam][max_ne] tensors instead of a wave per
  * (camera, voxel) candidate (five of six candidates own no slot, and every live wave walked mask -> slot -> sample -> pixel before
- * its gathers).  slot_rows [B*ncam*max_ne] i32 is scratch (slot -> voxel row, filled by a one-thread-per-candidate pass);
+ * its gathers).  slot_rows [B*ncam*max_ne][4] i32 is scratch (slot -> voxel row, pixel x, pixel y, compact row; filled by a
+ * one-thread-per-candidate pass);
  * counts is required; padding rows are written by the same launch.  pixrow + compact (both or neither): the image features
  * come from the pixel-major rows compact[pixrow[image][pixel]] (df3d_query_pixel_rows + df3d_imgproj_split_compact) instead of
  * the channel-first maps.  Same values (voxel_with_point_projection.py:337-377). */

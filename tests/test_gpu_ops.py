@@ -1398,7 +1398,7 @@ def test_assemble_queries_by_slot_equals_by_voxel(dev):
     def run_slots(use_att, use_pos, ptr_table):
         """round 4: df3d_assemble_queries2_slots (a wave per slot, padding rows written by the same launch)"""
         outs = [torch.full((B * ncam, max_ne, k), -3.0, device=dev) for k in (C, Ci, 2, 3, C)]
-        table = torch.empty((B * ncam * max_ne,), dtype=torch.int32, device=dev)
+        table = torch.empty((B * ncam * max_ne, 4), dtype=torch.int32, device=dev)
         ptrs = torch.tensor([img[i].data_ptr() for i in range(B * ncam)], dtype=torch.int64, device=dev) if ptr_table else None
         _lib.check(lib.df3d_assemble_queries2_slots(P(feat), P(pinv), P(ind), P(grid), P(mask), P(pos), None if ptr_table else P(img),
                                                     P(ptrs), P(att) if use_att else None, n, C, Ci, B, ncam, H, W, max_ne,
@@ -1632,7 +1632,7 @@ def test_pixel_major_query_rows_equal_the_channel_first_gather():
 
     def run(use_compact):
         outs = [torch.full((B * ncam, max_ne, k), -3.0, device=dev) for k in (C, Ci, 2, 3, C)]
-        table = torch.empty((B * ncam * max_ne,), dtype=torch.int32, device=dev)
+        table = torch.empty((B * ncam * max_ne, 4), dtype=torch.int32, device=dev)
         _lib.check(lib.df3d_assemble_queries2_slots(P(feat), P(pinv), P(ind), P(grid), P(mask), P(pos), P(img), None, P(att), n, C, Ci,
                                                     B, ncam, H, W, max_ne, P(outs[0]), P(outs[1]), P(outs[2]), P(outs[3]), P(outs[4]),
                                                     P(counts), P(table), P(pixrow) if use_compact else None,
