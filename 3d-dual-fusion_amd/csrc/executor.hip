@@ -115,6 +115,7 @@ struct RunState {
   std::vector<const void *> layer_lists;                      // per layer: its table's row lists or NULL
   std::vector<int> layer_in_set;
   std::vector<char> need_f32;
+  std::vector<char> want_split;   // a two-part split-precision layer reads this layer's rows (round 4: the small-channel kernel emits them)
   int32_t *count_dev = nullptr;
   void *split0 = nullptr;      // split rows of the network input, built on demand
   void *rows16_0 = nullptr;    // its bf16 rows (bf16 layers)
@@ -147,6 +148,7 @@ int state_init(RunState &S, const df3d_layer *layers, int nlayers, const int32_t
   // sources, inputs of layers that do not run on the split-precision kernels.  The first convolution of every residual block
   // feeds exactly one split-precision convolution: its fp32 rows were written and never read (round 2: every output twice).
   S.need_f32.assign(nlayers, 0);
+  S.want_split.assign(nlayers, 0);
   bool flagged = false;
   for (int li = 0; li < nlayers; ++li) flagged = flagged || (layers[li].reserved & 4);
   static const bool write_all = getenv("DF3D_EXEC_F32_ALL") && atoi(getenv("DF3D_EXEC_F32_ALL"));   // A / B of the PMC passes
@@ -159,6 +161,7 @@ int state_init(RunState &S, const df3d_layer *layers, int nlayers, const int32_t
                                 ((L.reserved & 8) ? df3d_conv_packed_weight_bytes3(kvol_of(L.ksize), L.cin, L.cout) != 0
                                                   : df3d_conv_packed_weight_bytes(kvol_of(L.ksize), L.cin, L.cout) != 0);
     if (L.input >= 0 && L.input < nlayers && !split_consumer) S.need_f32[L.input] = 1;
+    if (L.input >= 0 && L.input < nlayers && split_consumer && !(L.reserved & 8)) S.want_split[L.input] = 1;
   }
   return DF3D_OK;
 }
@@ -392,8 +395,14 @@ int conv_layer(RunState &S, int li, const float *features, df3d_layer_view *view
                                     res, L.relu, o.features, o.split, nullptr, 0, stream_);
     if (rc) return rc;
   } else {
+    // a matrix-core layer reads this one (the stride-2 16 -> 32 layer feeds conv2's blocks): the operand split of the rows
+    // comes out of the same launch instead of a df3d_split_rows pass in front of the consumer
+    if (S.want_split[li] && S.layer_lists[li] && L.cout % 8 == 0) {
+      o.split = mem.take((size_t)n_out * L.cout * 4);
+      if (!o.split) return DF3D_ENOMEM;
+    }
     int rc = df3d_sparse_conv_fused_lists(in_feat, n_in, L.cin, L.weight, K, L.cout, nbr, S.layer_lists[li], n_out, L.bias,
-                                          L.scale, L.shift, res, L.relu, o.features, stream_);
+                                          L.scale, L.shift, res, L.relu, o.features, o.split, stream_);
     if (rc) return rc;
   }
   v.features = o.features;

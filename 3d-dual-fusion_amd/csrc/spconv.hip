@@ -44,6 +44,7 @@ struct ConvArgs {
   // wider rows), and the column offset between the slices of two consecutive groups (blockIdx.y; filters, bias, scale
   // and shift of a group follow the previous group's)
   int ldi, ldo, gi, go;
+  void *out_split;        // spconv_small_lists_kernel only: also the operand split of the result (hi | lo per 8 channels), or null
 };
 
 template <int KS>
@@ -740,11 +741,14 @@ static int launch_small(const ConvArgs &a, hipStream_t stream) {
 // are the table's present entries per row, offsets ascending, packed (offset << 26 | input row), rows back to back:
 // off[N + 1] u32 + ent[pairs] u32 (df3d_nbr_row_lists: count, scan, fill -- in the geometry phase, i.e. on the frame head's
 // stream a frame ahead).  Same products in the same order as spconv_small_kernel: bit-identical results.
+typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
 struct RowLists {
   const uint32_t *off;   // [n_out + 1]
   const uint32_t *ent;   // [off[n_out]]
 };
 static thread_local RowLists g_lists_hint = {nullptr, nullptr};   // set around sparse_conv_impl by df3d_sparse_conv_fused_lists
+static thread_local void *g_lists_split = nullptr;                // ... with the split rows the caller wants next to `out`
+static thread_local bool g_lists_split_done = false;
 
 template <int CIN, int COUT, int NT>
 __global__ __launch_bounds__(NT) void spconv_small_lists_kernel(ConvArgs a, RowLists L) {
@@ -832,6 +836,15 @@ __global__ __launch_bounds__(NT) void spconv_small_lists_kernel(ConvArgs a, RowL
       v[3] = fmaxf(v[3], 0.f);
     }
     *(f32x4 *)(a.out + o) = v;
+    if (a.out_split) {
+      // the operand split the next (matrix-core) layer reads: 8-channel block = [hi 16 B | lo 16 B], this lane owns 4 of the 8
+      unsigned h0, l0, h1, l1;
+      split_pair(v[0], v[1], h0, l0);
+      split_pair(v[2], v[3], h1, l1);
+      char *blk = (char *)a.out_split + (o >> 3) * 32 + ((o >> 2) & 1) * 8;
+      *(u32x2s *)blk = (u32x2s){h0, h1};
+      *(u32x2s *)(blk + 16) = (u32x2s){l0, l1};
+    }
     b = nb, e = ne;
   }
 }
@@ -1183,15 +1196,22 @@ extern "C" int df3d_nbr_row_lists(const int32_t *nbr, int kvol, int n_out, int n
 extern "C" int df3d_sparse_conv_fused_lists(const float *features, int n_in, int cin, const float *filters, int kvol,
                                             int cout, const int32_t *nbr, const void *lists, int n_out, const float *bias,
                                             const float *scale, const float *shift, const float *residual, int relu,
-                                            float *out, void *stream_) {
+                                            float *out, void *out_split, void *stream_) {
+  DF3D_CHECK_ARG(!out_split || cout % 8 == 0, "sparse_conv_fused_lists: split rows need a multiple of 8 output channels");
   if (lists && n_out > 0 && small_shape(cin, cout)) {
     const char *p = (const char *)lists;
     g_lists_hint.off = (const uint32_t *)p;
     g_lists_hint.ent = (const uint32_t *)(p + lists_off_bytes(n_out));
+    g_lists_split = out_split;
   }
+  g_lists_split_done = false;
   int rc = sparse_conv_impl(features, n_in, cin, filters, kvol, cout, nbr, n_out, bias, scale, shift, residual, relu, out,
                             nullptr, 0, stream_);
   g_lists_hint.off = g_lists_hint.ent = nullptr;
+  g_lists_split = nullptr;
+  if (rc) return rc;
+  // the lists kernel did not serve the launch (no lists, another shape, a tiny layer): the split rows as a pass of their own
+  if (out_split && !g_lists_split_done && n_out > 0) return df3d_split_rows(out, n_out, cout, out_split, stream_);
   return rc;
 }
 
@@ -1223,6 +1243,7 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
   a.ldo = cg ? cg->ld_out : cout;
   a.gi = cg ? cg->group_in : 0;
   a.go = cg ? cg->group_out : 0;
+  a.out_split = nullptr;
   const int trec = timing_rec_begin(cin, cout * (cg ? cg->groups : 1), kvol, n_out, nbr, 0, stream);
   bool done = false;
   if (cg) {                                          // column slices of wider rows, groups: the output-stationary MFMA kernel
@@ -1241,7 +1262,12 @@ static int sparse_conv_impl(const float *features, int n_in, int cin, const floa
   }
   {
     int r = 0;
-    if (g_lists_hint.off) r = dispatch_small_lists(a, g_lists_hint, stream);   // row lists given (df3d_sparse_conv_fused_lists)
+    if (g_lists_hint.off) {                        // row lists given (df3d_sparse_conv_fused_lists)
+      a.out_split = g_lists_split;
+      r = dispatch_small_lists(a, g_lists_hint, stream);
+      if (r == 1) g_lists_split_done = true;
+      a.out_split = nullptr;
+    }
     if (r == 0) r = dispatch_small(a, stream);     // C <= 16 input channels: vector-ALU kernel
     if (r < 0) return r;
     done = r == 1;

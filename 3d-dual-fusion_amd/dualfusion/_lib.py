@@ -50,7 +50,7 @@ SIGNATURES = {
     "df3d_nbr_row_lists_bytes": (c_size_t, [c_int, c_int]),
     "df3d_nbr_row_lists": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "df3d_sparse_conv_fused_lists": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_sparse_conv_grouped": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "df3d_conv_tile_count": (c_int, [c_int, c_int, c_int, c_int]),

@@ -172,12 +172,15 @@ int df3d_sparse_conv_fused_tiled(const float *features, int n_in, int cin,
  *   df3d_nbr_row_lists_bytes(kvol, n_out)   bytes of the blob (offsets, entries at full capacity, scratch)
  *   df3d_nbr_row_lists                      builds it (count, scan, fill: three launches, no host round trip); n_in < 2^26
  *   df3d_sparse_conv_fused_lists            df3d_sparse_conv_fused that takes the blob (NULL, or a shape the small-channel
- *                                           kernel does not serve: exactly df3d_sparse_conv_fused).  Bit-identical results. */
+ *                                           kernel does not serve: exactly df3d_sparse_conv_fused).  Bit-identical results.
+ *                                           out_split (optional, out_channels % 8 == 0): also the df3d_split_rows form of the
+ *                                           result, from the same launch (what a following matrix-core layer reads). */
 size_t df3d_nbr_row_lists_bytes(int kvol, int n_out);
 int df3d_nbr_row_lists(const int32_t *nbr, int kvol, int n_out, int n_in, void *lists, size_t lists_bytes, void *stream);
 int df3d_sparse_conv_fused_lists(const float *features, int n_in, int cin, const float *filters, int kvol, int cout,
                                  const int32_t *nbr, const void *lists, int n_out, const float *bias, const float *scale,
-                                 const float *shift, const float *residual, int relu, float *out, void *stream);
+                                 const float *shift, const float *residual, int relu, float *out, void *out_split,
+                                 void *stream);
 
 /* Per-launch timing of the sparse-conv kernels with HIP events recorded on the launching stream, adjacent
  * to the launch (measurement aid for bench.py's roofline leg; off by default, not thread-safe).

@@ -1730,7 +1730,16 @@ def test_small_channel_conv_from_row_lists(cin, cout, strided):
         got = torch.full((n_out, cout), -7.0, device=dev)
         _lib.check(lib.df3d_sparse_conv_fused(P(feat), n_in, cin, P(w), K, cout, P(nbr), n_out, P(bias), P(scale), P(shift),
                                               P(res) if use_res else None, relu, P(want), ops._stream()))
+        gsplit = torch.zeros((n_out, 4 * cout), dtype=torch.uint8, device=dev)
         _lib.check(lib.df3d_sparse_conv_fused_lists(P(feat), n_in, cin, P(w), K, cout, P(nbr), P(blob), n_out, P(bias), P(scale),
-                                                    P(shift), P(res) if use_res else None, relu, P(got), ops._stream()))
+                                                    P(shift), P(res) if use_res else None, relu, P(got), P(gsplit),
+                                                    ops._stream()))
         assert torch.equal(got, want), (use_res, relu)
+        assert torch.equal(gsplit, ops.split_rows(want))          # the operand split of the rows from the same launch
+        # without lists the entry is df3d_sparse_conv_fused + df3d_split_rows
+        got2, gsplit2 = torch.empty_like(got), torch.zeros_like(gsplit)
+        _lib.check(lib.df3d_sparse_conv_fused_lists(P(feat), n_in, cin, P(w), K, cout, P(nbr), None, n_out, P(bias), P(scale),
+                                                    P(shift), P(res) if use_res else None, relu, P(got2), P(gsplit2),
+                                                    ops._stream()))
+        assert torch.equal(got2, want) and torch.equal(gsplit2, gsplit)
     assert float(want.abs().max()) > 0.1
