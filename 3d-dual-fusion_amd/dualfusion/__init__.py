@@ -10,6 +10,9 @@ import os as _os
 # streams, the caller's); with 4 queues two frames in flight did not overlap at all.  Effective only when
 # this import happens before the HIP runtime initialises (import dualfusion before the first CUDA call, or export it yourself).
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# kernel arguments in device memory (not host-coherent memory read over PCIe at every launch): -125 us on the ~130 dependent
+# launches of a detector frame; same condition -- before the HIP runtime initialises
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from ._lib import Df3dError, LIB_PATH, load as require  # noqa: E402,F401
 
