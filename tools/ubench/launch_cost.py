@@ -23,3 +23,25 @@ for name, fn in (("df3d_split_rows on 64 rows", lambda: ops.split_rows(x)), ("to
     b.record()
     torch.cuda.synchronize()
     print("%-32s %.2f us per launch (HIP_FORCE_DEV_KERNARG=%s)" % (name, a.elapsed_time(b) * 1e3 / N, os.environ.get("HIP_FORCE_DEV_KERNARG")))
+
+# GPU-side cost of a dependent kernel when the host is out of the way: the same launches replayed from a hipGraph
+g = torch.cuda.CUDAGraph()
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    for _ in range(3):
+        y.add_(1.0)
+    with torch.cuda.graph(g, stream=s):
+        for _ in range(1000):
+            y.add_(1.0)
+torch.cuda.synchronize()
+for _ in range(3):
+    g.replay()
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(5):
+    g.replay()
+b.record()
+torch.cuda.synchronize()
+print("hipGraph of 1000 dependent add_ kernels: %.2f us per kernel" % (a.elapsed_time(b) * 1e3 / 5000))
