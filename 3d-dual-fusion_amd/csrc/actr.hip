@@ -15,6 +15,8 @@
 
 namespace df3d {
 
+DF3D_SPLIT_OVERFLOW_TU(actr)
+
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -15,7 +15,7 @@ SOURCES = ["common.hip", "voxelize.hip", "rulebook.hip", "spconv.hip", "spconv_s
 OUT = os.path.join(HERE, "libdf3d_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
-HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "spconv_halo.h"), os.path.join(HERE, "spconv_ws.h"), os.path.join(HERE, "..", "..", "include", "df3d_hip.h")]
+HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "..", "..", "include", "df3d_hip.h")]
 
 
 def _newer(target, deps):

@@ -40,11 +40,39 @@ void set_error(const char *fmt, ...);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 #ifdef __HIPCC__
-// hi/lo bf16 split of two fp32 values with the hardware converter (v_cvt_pk_bf16_f32, round to nearest even):
-// hi = bf16(x), lo = bf16(x - hi); each result packs the pair (x0 in the low 16 bits).  5 VALU per pair.
+// ---- operand splits of the matrix-core kernels ------------------------------------------------------------------------
+// Round 5: the two-part split is an fp16 split.  An fp32 value x, scaled by a fixed power of two S, is stored as
+//     hi = fp16(S x),  lo = fp16(S x - hi)          (S x = hi + lo up to 2^-22 |S x|: 11 + 11 significand bits)
+// and a contraction is evaluated as A_lo W_hi + A_hi W_lo + A_hi W_hi on v_mfma_f32_16x16x32_f16 (fp16 x fp16 products are
+// exact in fp32, accumulation is fp32), then multiplied by 2^-(SA + SW) -- exact.  Same bytes, same three matrix products
+// per operand pair as the bf16 hi/lo split of rounds 1-4 (which kept 8 + 8 bits: ~5e-6 of the output scale against
+// float64), at the accuracy of the exact-fp32 kernels (~1e-6 of scale = fp32 accumulation noise;
+// tools/ubench/f16split_probe.hip).  What fp16 lacks is exponent range: activations are scaled by 2^5 (|x| < 2047;
+// full 22 bits down to |x| = 2^-8, below that an absolute error <= 2^-30), weights by 2^7 (|w| < 511; 2^-32).  A value
+// outside the range does NOT pass silently: every split that writes memory checks it and raises a sticky flag that
+// `df3d_split_overflow()` reads (the Python layer raises on it); `DF3D_CONV_PRECISION=split3` (three bf16 parts, fp32's
+// exponent range, twice the matrix work) is the mode for such data.  MFMA and the converters honour fp16 subnormals.
+#define DF3D_SA_EXP 5
+#define DF3D_SW_EXP 7
+#define DF3D_SA_SCALE 32.0f                        // 2^SA: activations
+#define DF3D_SW_SCALE 128.0f                       // 2^SW: weights
+#define DF3D_SA_INV 0.03125f
+#define DF3D_ACC_UNSCALE 0.000244140625f           // 2^-(SA + SW): accumulators of a two-part product -> fp32 values
+#define DF3D_AA_UNSCALE 0.0009765625f              // 2^-(2 SA): products of two activation operands
 typedef __bf16 df3d_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 df3d_f16x2 __attribute__((ext_vector_type(2)));
 typedef float df3d_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair_ref(float x0, float x1, unsigned &hi, unsigned &lo) {
+typedef _Float16 df3d_f16x8 __attribute__((ext_vector_type(8)));
+
+static __device__ unsigned g_split_overflow_tu;    // one per translation unit (no relocatable device code): see split_overflow_*
+
+// a pair of fp32 values -> packed bf16 (round to nearest even, x0 in the low 16 bits): the operand format of the bf16 mode
+__device__ __forceinline__ unsigned bf16_pair(float x0, float x1) {
+  df3d_f32x2 v = {x0, x1};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, df3d_bf16x2));
+}
+// hi/lo bf16 split of two fp32 values (v_cvt_pk_bf16_f32): the building block of the three-part split
+__device__ __forceinline__ void split_pair_bf16_ref(float x0, float x1, unsigned &hi, unsigned &lo) {
   df3d_f32x2 v = {x0, x1};
   df3d_bf16x2 h = __builtin_convertvector(v, df3d_bf16x2);
   df3d_f32x2 r = v - __builtin_convertvector(h, df3d_f32x2);
@@ -52,14 +80,74 @@ __device__ __forceinline__ void split_pair_ref(float x0, float x1, unsigned &hi,
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
 }
+// hi/lo fp16 split of two fp32 values scaled by `s` (a power of two); each result packs the pair (x0 in the low 16 bits)
+template <bool CHECK>
+__device__ __forceinline__ void split_pair_f16_ref(float x0, float x1, float s, unsigned &hi, unsigned &lo) {
+  df3d_f32x2 v = {x0 * s, x1 * s};
+  if (CHECK) {
+    // (also true for NaN / inf that an unchecked split upstream let through)
+    if (__builtin_expect(!(__builtin_fabsf(v[0]) <= 65504.f) || !(__builtin_fabsf(v[1]) <= 65504.f), 0))
+      atomicOr(&g_split_overflow_tu, 1u);
+  }
+  df3d_f16x2 h = __builtin_convertvector(v, df3d_f16x2);
+  df3d_f32x2 r = v - __builtin_convertvector(h, df3d_f32x2);
+  df3d_f16x2 l = __builtin_convertvector(r, df3d_f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
 // outputs may be vector elements (which cannot bind to references)
-#define split_pair(x0, x1, HI, LO)                 \
-  do {                                             \
-    unsigned sp_h__, sp_l__;                       \
-    df3d::split_pair_ref(x0, x1, sp_h__, sp_l__);  \
-    (HI) = sp_h__;                                 \
-    (LO) = sp_l__;                                 \
+#define DF3D_SPLIT_PAIR_(x0, x1, S, CHECK, HI, LO)                          \
+  do {                                                                      \
+    unsigned sp_h__, sp_l__;                                                \
+    df3d::split_pair_f16_ref<CHECK>(x0, x1, S, sp_h__, sp_l__);             \
+    (HI) = sp_h__;                                                          \
+    (LO) = sp_l__;                                                          \
   } while (0)
+// activations (checked: for splits that go to memory; _nc: in-register operands inside a matrix loop, whose out-of-range
+// values turn into inf / NaN and are caught by the next checked split downstream)
+#define split_pair(x0, x1, HI, LO) DF3D_SPLIT_PAIR_(x0, x1, DF3D_SA_SCALE, true, HI, LO)
+#define split_pair_nc(x0, x1, HI, LO) DF3D_SPLIT_PAIR_(x0, x1, DF3D_SA_SCALE, false, HI, LO)
+// weights / filters (packed once per parameter version)
+#define split_pair_w(x0, x1, HI, LO) DF3D_SPLIT_PAIR_(x0, x1, DF3D_SW_SCALE, true, HI, LO)
+#define split_pair_bf16(x0, x1, HI, LO)                  \
+  do {                                                   \
+    unsigned sp_h__, sp_l__;                             \
+    df3d::split_pair_bf16_ref(x0, x1, sp_h__, sp_l__);   \
+    (HI) = sp_h__;                                       \
+    (LO) = sp_l__;                                       \
+  } while (0)
+// one fp32 value -> the 16-bit patterns of its activation split
+__device__ __forceinline__ void split_one(float x, unsigned &hi, unsigned &lo) {
+  unsigned h, l;
+  split_pair_f16_ref<true>(x, 0.f, DF3D_SA_SCALE, h, l);
+  hi = h & 0xffffu;
+  lo = l & 0xffffu;
+}
+// packed fp16 pair of a split row -> the two fp32 values of that PART (hi or lo), unscaled
+__device__ __forceinline__ df3d_f32x2 split_part_to_f32(unsigned packed) {
+  df3d_f32x2 v = __builtin_convertvector(__builtin_bit_cast(df3d_f16x2, packed), df3d_f32x2);
+  return v * DF3D_SA_INV;
+}
+// hi + lo of a packed pair -> fp32 values (exact: both parts and their sum are fp32 numbers)
+__device__ __forceinline__ df3d_f32x2 split_to_f32(unsigned hi, unsigned lo) {
+  df3d_f32x2 h = __builtin_convertvector(__builtin_bit_cast(df3d_f16x2, hi), df3d_f32x2);
+  df3d_f32x2 l = __builtin_convertvector(__builtin_bit_cast(df3d_f16x2, lo), df3d_f32x2);
+  return (h + l) * DF3D_SA_INV;
+}
+#define DF3D_MFMA_F16(A, B, C) \
+  __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(df3d_f16x8, A), __builtin_bit_cast(df3d_f16x8, B), C, 0, 0, 0)
+#endif
+
+// sticky overflow flags of the fp16 operand splits: every translation unit with device code that splits registers the
+// address of its flag (common.hip keeps the list); see df3d_split_overflow()
+void split_overflow_register(const void *symbol, const char *tu);
+#ifdef __HIPCC__
+#define DF3D_SPLIT_OVERFLOW_TU(name)                                                                       \
+  namespace {                                                                                              \
+  struct SplitOverflowReg_##name {                                                                         \
+    SplitOverflowReg_##name() { df3d::split_overflow_register((const void *)&df3d::g_split_overflow_tu, #name); } \
+  } g_split_overflow_reg_##name;                                                                           \
+  }
 #endif
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

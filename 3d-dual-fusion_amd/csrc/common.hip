@@ -15,6 +15,17 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+// ---------------------------------------------------------------------------- fp16 operand splits: range flags
+// One `static __device__` flag per translation unit (common.h); their host symbols are collected here by static
+// constructors (a plain array: no initialisation order to get wrong) and resolved to device addresses at the first poll.
+static const void *g_ovf_sym[64];
+static const char *g_ovf_tu[64];
+static unsigned *g_ovf_dev[64];
+static int g_ovf_n = 0;
+void split_overflow_register(const void *symbol, const char *tu) {
+  if (g_ovf_n < 64) g_ovf_sym[g_ovf_n] = symbol, g_ovf_tu[g_ovf_n] = tu, ++g_ovf_n;
+}
+
 // ---------------------------------------------------------------------------- scan
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 4;
@@ -166,6 +177,37 @@ int exclusive_scan_popc64(const unsigned long long *words, uint32_t *out, size_t
 extern "C" {
 
 int df3d_version(void) { return 100; }
+
+int df3d_split_overflow(int reset, char *where, int where_len) {
+  // synchronous on purpose (a poll at a frame / test boundary): waits for the device
+  unsigned any = 0;
+  if (where && where_len > 0) where[0] = 0;
+  if (hipDeviceSynchronize() != hipSuccess) {
+    df3d::set_error("df3d_split_overflow: hipDeviceSynchronize failed");
+    return DF3D_EHIP;
+  }
+  for (int i = 0; i < df3d::g_ovf_n; ++i) {
+    if (!df3d::g_ovf_dev[i]) {
+      void *p = nullptr;
+      if (hipGetSymbolAddress(&p, df3d::g_ovf_sym[i]) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        continue;                                   // (no device code of that unit was loaded)
+      }
+      df3d::g_ovf_dev[i] = (unsigned *)p;
+    }
+    unsigned v = 0;
+    DF3D_HIP(hipMemcpy(&v, df3d::g_ovf_dev[i], sizeof(v), hipMemcpyDeviceToHost));
+    if (v) {
+      any |= v;
+      if (where && where_len > 0) {
+        size_t used = strlen(where);
+        snprintf(where + used, (size_t)where_len - used, "%s%s", used ? "," : "", df3d::g_ovf_tu[i]);
+      }
+      if (reset) DF3D_HIP(hipMemset(df3d::g_ovf_dev[i], 0, sizeof(v)));
+    }
+  }
+  return any ? 1 : 0;
+}
 const char *df3d_last_error(void) { return df3d::g_err; }
 
 int df3d_device_count(void) {

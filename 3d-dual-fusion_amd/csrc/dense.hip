@@ -9,6 +9,8 @@
 
 namespace df3d {
 
+DF3D_SPLIT_OVERFLOW_TU(dense)
+
 __global__ __launch_bounds__(256) void dense_scatter_kernel(const float *__restrict__ feat,
                                                             const int32_t *__restrict__ ind, int n, int C,
                                                             int D, int H, int W, float *__restrict__ out) {

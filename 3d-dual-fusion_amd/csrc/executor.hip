@@ -802,12 +802,15 @@ void head_worker_main(HeadWorker *w) {
     }
     int rc = frame_head_run(*t);
     {
+      // notify while holding the lock: df3d_frame_head_wait deletes the ticket as soon as it sees `done`, and it can only
+      // see it after this scope has released the mutex -- i.e. after the notification (a notify behind the
+      // unlock could run on a destroyed condition variable)
       std::lock_guard<std::mutex> lk(t->mu);
       t->rc = rc;
       if (rc) t->err = df3d_last_error();
       t->done = true;
+      t->cv.notify_all();
     }
-    t->cv.notify_all();
   }
 }
 

@@ -1,7 +1,7 @@
 // Fused feed-forward block of the encoder layer for gfx950:
 //     out = LayerNorm(x + W2 relu(W1 x + b1) + b2)          (actr_transformer.py:413-424, d_model 128, d_ffn 1024)
-// as ONE kernel on the bf16 matrix cores with split-precision operands (see spconv_split.hip: x = hi + lo in
-// bf16, products hi*hi + lo*hi + hi*lo, fp32 accumulate, ~1e-5 relative error).  The reference (and the
+// as ONE kernel on the 16-bit matrix cores with split-precision operands (see common.h / spconv_split.hip: S x = hi + lo
+// in fp16, products hi*hi + lo*hi + hi*lo, fp32 accumulate, ~1e-6 of the output scale against float64).  The reference (and the
 // hipBLASLt path) runs two fp32 GEMMs at ~90-110 TFLOP/s plus ReLU, residual add and LayerNorm passes, and moves
 // the [rows, 1024] hidden activation through HBM twice; here the hidden activation never leaves registers.
 //
@@ -17,7 +17,7 @@
 // LayerNorm (16-lane reductions) and the 16-byte stores happen in registers.
 //
 // Algorithmic bytes: rows*128*4 read + rows*128*4 written + 1 MB of weights per workgroup from L2;
-// 2*rows*128*1024*2 flops.  Bound: bf16 MFMA at 3 products per fp32 product.
+// 2*rows*128*1024*2 flops.  Bound: fp16 MFMA at 3 products per fp32 product.
 #include <stdlib.h>
 
 #include <string.h>
@@ -28,19 +28,8 @@ namespace df3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define DF3D_MFMA_BF16(A, B, C) \
-  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
-
-__device__ __forceinline__ unsigned ffn_bf16_bits(float x) {
-  unsigned u = __float_as_uint(x);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void ffn_split2(float x, unsigned &hi, unsigned &lo) {
-  hi = ffn_bf16_bits(x);
-  lo = ffn_bf16_bits(x - __uint_as_float(hi << 16));
-}
+DF3D_SPLIT_OVERFLOW_TU(ffn)
 
 constexpr int FFN_WQ = 8 * 2 * 64;    // u32x4 per step tile (8 operand tiles x hi/lo x 64 lanes) = 16 KB
 // Model width C = 128 (ACTR of the CenterPoint / TransFusion trees) or 64 (ACTRv2 and the LocalTransformer of the Voxel-RCNN
@@ -62,7 +51,7 @@ __global__ __launch_bounds__(256) void pack_ffn_kernel(const float *__restrict__
   int sj = (int)((i >> 10) % SPC);
   int c = (int)((i >> 10) / SPC);
   int n = lane & 15, g = lane >> 4;
-  unsigned v[8];
+  float wv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float w = 0.f;
@@ -76,13 +65,15 @@ __global__ __launch_bounds__(256) void pack_ffn_kernel(const float *__restrict__
       int hid = c * 128 + (2 * q + (e >> 2)) * 16 + 4 * g + (e & 3);
       w = w2[(size_t)col * H + hid];
     }
-    unsigned hi, lo;
-    ffn_split2(w, hi, lo);
-    v[e] = part ? lo : hi;
+    wv[e] = w;
   }
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = v[2 * e] | (v[2 * e + 1] << 16);
+  for (int e = 0; e < 4; ++e) {
+    unsigned hi, lo;
+    split_pair_w(wv[2 * e], wv[2 * e + 1], hi, lo);
+    o[e] = part ? lo : hi;
+  }
   out[i] = o;
 }
 
@@ -97,8 +88,9 @@ struct FfnArgs {
   long long rows;
   int H;
   int dbg;     // tuning experiments (DF3D_FFN_DBG): 1 = no MFMAs, 2 = no weight staging
-  int bf16;    // 1: bf16 operands (activations and weights rounded to bf16 = their hi parts, ONE product per pair),
-               //    fp32 accumulate, fp32 bias / residual / LayerNorm -- the reduced-precision mode of BASELINE configs[2]
+  int bf16;    // 1: 16-bit operands (activations and weights rounded to fp16 = the hi parts of their split, ONE product per
+               //    pair: 11 significand bits where bf16 has 8), fp32 accumulate, fp32 bias / residual / LayerNorm -- the
+               //    reduced-precision mode of BASELINE configs[2]
 };
 
 // NW waves per workgroup, RT 16-row tiles per wave.  RT = 2 halves the LDS fragment reads per MFMA (every operand
@@ -110,7 +102,7 @@ struct FfnJobs {
   FfnArgs s[4];
 };
 
-// NP = operand parts: 2 = split precision (hi + lo, three products), 1 = bf16 (hi parts only, one product; the lo
+// NP = operand parts: 2 = split precision (hi + lo, three products), 1 = 16-bit (hi parts only, one product; the lo
 // halves of the packed stream and of the activations are simply not read)
 template <int NW, int RT, int NP = 2, int C = 128>
 __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
@@ -203,19 +195,19 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
         if constexpr (NP == 2) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            acc1[rt][t] = DF3D_MFMA_BF16(ah0, xl[rt][kb], acc1[rt][t]);
-            acc1[rt][t + 1] = DF3D_MFMA_BF16(ah1, xl[rt][kb], acc1[rt][t + 1]);
+            acc1[rt][t] = DF3D_MFMA_F16(ah0, xl[rt][kb], acc1[rt][t]);
+            acc1[rt][t + 1] = DF3D_MFMA_F16(ah1, xl[rt][kb], acc1[rt][t + 1]);
           }
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            acc1[rt][t] = DF3D_MFMA_BF16(al0, xh[rt][kb], acc1[rt][t]);
-            acc1[rt][t + 1] = DF3D_MFMA_BF16(al1, xh[rt][kb], acc1[rt][t + 1]);
+            acc1[rt][t] = DF3D_MFMA_F16(al0, xh[rt][kb], acc1[rt][t]);
+            acc1[rt][t + 1] = DF3D_MFMA_F16(al1, xh[rt][kb], acc1[rt][t + 1]);
           }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          acc1[rt][t] = DF3D_MFMA_BF16(ah0, xh[rt][kb], acc1[rt][t]);
-          acc1[rt][t + 1] = DF3D_MFMA_BF16(ah1, xh[rt][kb], acc1[rt][t + 1]);
+          acc1[rt][t] = DF3D_MFMA_F16(ah0, xh[rt][kb], acc1[rt][t]);
+          acc1[rt][t + 1] = DF3D_MFMA_F16(ah1, xh[rt][kb], acc1[rt][t + 1]);
         }
       }
     }
@@ -229,10 +221,11 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
         const f32x4 b = *(const f32x4 *)(a.b1 + c * 128 + t * 16 + 4 * g);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          split_pair(fmaxf(acc1[rt][t][0] + b[0], 0.f), fmaxf(acc1[rt][t][1] + b[1], 0.f), hh[rt][q][half * 2],
-                     hl[rt][q][half * 2]);
-          split_pair(fmaxf(acc1[rt][t][2] + b[2], 0.f), fmaxf(acc1[rt][t][3] + b[3], 0.f), hh[rt][q][half * 2 + 1],
-                     hl[rt][q][half * 2 + 1]);
+          // (unchecked: a hidden value beyond fp16's range becomes inf / NaN in the output row, which the next split of
+          // that row reports)
+          const f32x4 hv = acc1[rt][t] * DF3D_ACC_UNSCALE + b;
+          split_pair_nc(fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), hh[rt][q][half * 2], hl[rt][q][half * 2]);
+          split_pair_nc(fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f), hh[rt][q][half * 2 + 1], hl[rt][q][half * 2 + 1]);
         }
       }
     }
@@ -261,19 +254,19 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
         if constexpr (NP == 2) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            acc2[rt][ct] = DF3D_MFMA_BF16(hl[rt][q], bh0, acc2[rt][ct]);
-            acc2[rt][ct + 1] = DF3D_MFMA_BF16(hl[rt][q], bh1, acc2[rt][ct + 1]);
+            acc2[rt][ct] = DF3D_MFMA_F16(hl[rt][q], bh0, acc2[rt][ct]);
+            acc2[rt][ct + 1] = DF3D_MFMA_F16(hl[rt][q], bh1, acc2[rt][ct + 1]);
           }
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            acc2[rt][ct] = DF3D_MFMA_BF16(hh[rt][q], bl0, acc2[rt][ct]);
-            acc2[rt][ct + 1] = DF3D_MFMA_BF16(hh[rt][q], bl1, acc2[rt][ct + 1]);
+            acc2[rt][ct] = DF3D_MFMA_F16(hh[rt][q], bl0, acc2[rt][ct]);
+            acc2[rt][ct + 1] = DF3D_MFMA_F16(hh[rt][q], bl1, acc2[rt][ct + 1]);
           }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          acc2[rt][ct] = DF3D_MFMA_BF16(hh[rt][q], bh0, acc2[rt][ct]);
-          acc2[rt][ct + 1] = DF3D_MFMA_BF16(hh[rt][q], bh1, acc2[rt][ct + 1]);
+          acc2[rt][ct] = DF3D_MFMA_F16(hh[rt][q], bh0, acc2[rt][ct]);
+          acc2[rt][ct + 1] = DF3D_MFMA_F16(hh[rt][q], bh1, acc2[rt][ct + 1]);
         }
       }
     }
@@ -304,7 +297,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_split_kernel(FfnJobs jobs) {
       float s = 0.f;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        val[v] = (f32x4){acc2[rt][4 * v][r], acc2[rt][4 * v + 1][r], acc2[rt][4 * v + 2][r], acc2[rt][4 * v + 3][r]} + bias[v];
+        val[v] = (f32x4){acc2[rt][4 * v][r], acc2[rt][4 * v + 1][r], acc2[rt][4 * v + 2][r], acc2[rt][4 * v + 3][r]} *
+                     DF3D_ACC_UNSCALE + bias[v];
         if (a.res) val[v] += *(const f32x4 *)(a.res + rr * C + n * CT + 4 * v);
         s += val[v][0] + val[v][1] + val[v][2] + val[v][3];
       }

@@ -19,6 +19,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace df3d {
 
+DF3D_SPLIT_OVERFLOW_TU(fusion)
+
 struct ProjArgs {
   const int32_t *ind;       // [n,4] (b,z,y,x)
   int n, batch, ncam;

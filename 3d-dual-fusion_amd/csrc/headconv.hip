@@ -32,8 +32,7 @@ struct HeadFinalArgs {
   int ld, ldo, B, H, W, G, tiles_x, tiles_y, gpad;
 };
 
-__device__ __forceinline__ float bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+DF3D_SPLIT_OVERFLOW_TU(headconv)
 
 __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
   __shared__ float x[HF_C * HF_LD];                  // the branch's halo tile, [channel][pixel]
@@ -69,8 +68,9 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
     const int p = it >> 3, blk = it & 7;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      x[(blk * 8 + 2 * e) * HF_LD + p] = bf16_lo(hi[i][e]) + bf16_lo(lo[i][e]);
-      x[(blk * 8 + 2 * e + 1) * HF_LD + p] = bf16_hi(hi[i][e]) + bf16_hi(lo[i][e]);
+      const df3d_f32x2 xv = split_to_f32(hi[i][e], lo[i][e]);
+      x[(blk * 8 + 2 * e) * HF_LD + p] = xv[0];
+      x[(blk * 8 + 2 * e + 1) * HF_LD + p] = xv[1];
     }
   }
   __syncthreads();
@@ -120,9 +120,7 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
 // values per lane): 288 MFMAs and 37 KB of LDS per (tile, branch); the launch is bound by reading the activations
 // (1.31x for the halo).
 constexpr int HM_HALO = 16, HM_TILE = HM_HALO - 2, HM_PS = 9 * HF_KMAX;      // LDS floats per halo pixel
-typedef __bf16 hm_bf16x8 __attribute__((ext_vector_type(8)));
-#define HM_MFMA(A, B, C) \
-  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hm_bf16x8, A), __builtin_bit_cast(hm_bf16x8, B), C, 0, 0, 0)
+#define HM_MFMA(A, B, C) DF3D_MFMA_F16(A, B, C)
 
 // B operand of lane (column `col` = (tap, map j), channel group kg) for k-step s: channels 32 s + 8 kg .. + 7, hi and lo
 __device__ __forceinline__ void hm_split_filters(const float *w, int g, int col, int tap, int j, int s, int kg, u32x4 &bh,
@@ -131,7 +129,7 @@ __device__ __forceinline__ void hm_split_filters(const float *w, int g, int col,
   if (col >= HM_PS) return;
   const float *wp = w + ((size_t)(g * 9 + tap) * HF_C + 32 * s + 8 * kg) * HF_KMAX + j;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) split_pair(wp[(2 * e) * HF_KMAX], wp[(2 * e + 1) * HF_KMAX], bh[e], bl[e]);
+  for (int e = 0; e < 4; ++e) split_pair_w(wp[(2 * e) * HF_KMAX], wp[(2 * e + 1) * HF_KMAX], bh[e], bl[e]);
 }
 
 // [G][9][64][4] fp32 -> [G][column tile 3][k-step 2][hi | lo][lane 64] x 16 B: what the lanes of the kernel below load
@@ -217,7 +215,8 @@ __global__ __launch_bounds__(256) void head_final_mfma_kernel(HeadFinalArgs a) {
       const int col = 16 * ct + n;
       if (col < HM_PS) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[((4 * wave + rt) * HM_HALO + 4 * kg + r) * HM_PS + col] = acc[rt][ct][r];
+        for (int r = 0; r < 4; ++r)
+          d[((4 * wave + rt) * HM_HALO + 4 * kg + r) * HM_PS + col] = acc[rt][ct][r] * DF3D_ACC_UNSCALE;
       }
     }
   __syncthreads();

@@ -1,4 +1,4 @@
-// Image side of the dual-query fusion on the bf16 matrix cores (split precision, see spconv_split.hip).
+// Image side of the dual-query fusion on the 16-bit matrix cores (split precision: fp16 hi + lo operands, see common.h).
 //
 // The reference runs, per sample, over six [256, 150, 267] camera maps: the image gate's 1x1 summary
 // (attention.py:456), ACTR's input_proj 1x1 conv + GroupNorm (actr.py:139-149) and, per encoder layer, value_proj
@@ -26,20 +26,8 @@ namespace df3d {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define DF3D_MFMA_BF16(A, B, C) \
-  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
-
-__device__ __forceinline__ unsigned ip_bf16_bits(float x) {
-  unsigned u = __float_as_uint(x);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void ip_split2(float x, unsigned &hi, unsigned &lo) {
-  hi = ip_bf16_bits(x);
-  lo = ip_bf16_bits(x - __uint_as_float(hi << 16));
-}
-__device__ __forceinline__ float ip_bf16_to_float(unsigned bits16) { return __uint_as_float(bits16 << 16); }
+DF3D_SPLIT_OVERFLOW_TU(imgproj)
 
 constexpr int IP_CIN = 256;          // camera feature channels
 constexpr int IP_MT = 9;             // 16-row tiles of Wcat: 128 projection rows + gate row + padding = 144
@@ -57,15 +45,16 @@ __global__ __launch_bounds__(256) void pack_proj_kernel(const float *__restrict_
   int t = (i >> 7) % IP_MT, kb = (i >> 7) / IP_MT;
   int m = lane & 15, g = lane >> 4;
   int row = 16 * t + m;
-  unsigned v[8];
+  u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float x = row < rows ? w[(size_t)row * IP_CIN + kb * 32 + g * 8 + e] : 0.f;
+  for (int e = 0; e < 4; ++e) {
+    const float x0 = row < rows ? w[(size_t)row * IP_CIN + kb * 32 + g * 8 + 2 * e] : 0.f;
+    const float x1 = row < rows ? w[(size_t)row * IP_CIN + kb * 32 + g * 8 + 2 * e + 1] : 0.f;
     unsigned hi, lo;
-    ip_split2(x, hi, lo);
-    v[e] = part ? lo : hi;
+    split_pair_w(x0, x1, hi, lo);
+    o[e] = part ? lo : hi;
   }
-  out[i] = (u32x4){v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+  out[i] = o;
 }
 
 struct ProjArgs2 {
@@ -175,7 +164,7 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
     const float *xb = &Xl[kb & 1][(g * 8) * IP_LD + wave * 16 + n];
     u32x4 bh, bl;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) split_pair(xb[(2 * e) * IP_LD], xb[(2 * e + 1) * IP_LD], bh[e], bl[e]);
+    for (int e = 0; e < 4; ++e) split_pair_nc(xb[(2 * e) * IP_LD], xb[(2 * e + 1) * IP_LD], bh[e], bl[e]);   // (checked in the epilogue)
     const u32x4 *wb = Wl[kb & 1] + lane;
     if (a.dbg & 2) continue;
     // three row tiles at a time: their 9 MFMAs are interleaved (no back-to-back dependent pair) and the next
@@ -191,11 +180,11 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
         for (int q = 0; q < 6; ++q) fq[cur ^ 1][q] = wb[((tg + 1) * 6 + q) * 64];
       }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[cur][2 * j], bl, acc[tg * 3 + j]);
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_F16(fq[cur][2 * j], bl, acc[tg * 3 + j]);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[cur][2 * j + 1], bh, acc[tg * 3 + j]);
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_F16(fq[cur][2 * j + 1], bh, acc[tg * 3 + j]);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[cur][2 * j], bh, acc[tg * 3 + j]);
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_F16(fq[cur][2 * j], bh, acc[tg * 3 + j]);
     }
   }
 
@@ -206,14 +195,15 @@ __global__ __launch_bounds__(512) void img_proj_split_kernel(ProjArgs2 a) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     unsigned h[2], l[2];
-    split_pair(acc[t][0], acc[t][1], h[0], l[0]);
-    split_pair(acc[t][2], acc[t][3], h[1], l[1]);
+    const f32x4 uv = acc[t] * DF3D_ACC_UNSCALE;
+    split_pair(uv[0], uv[1], h[0], l[0]);
+    split_pair(uv[2], uv[3], h[1], l[1]);
     char *blk = wt + n * ROW_PITCH + (2 * t + (g >> 1)) * 32 + (g & 1) * 8;   // 8-channel block = [hi 16 B | lo 16 B]
     *(u32x2 *)blk = (u32x2){h[0], h[1]};
     *(u32x2 *)(blk + 16) = (u32x2){l[0], l[1]};
   }
   const int pw = p0 + wave * 16;
-  if (g == 0 && pw + n < S && !(a.dbg & 8)) a.gate[(size_t)blockIdx.y * S + pw + n] = acc[8][0];
+  if (g == 0 && pw + n < S && !(a.dbg & 8)) a.gate[(size_t)blockIdx.y * S + pw + n] = acc[8][0] * DF3D_ACC_UNSCALE;
   __builtin_amdgcn_wave_barrier();
   if (a.dbg & 8) return;
 #pragma unroll
@@ -310,7 +300,7 @@ __global__ __launch_bounds__(512, 4) void img_proj_direct_kernel(ProjArgs2 a) {
     }
     u32x4 bh, bl;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) split_pair(x[2 * e], x[2 * e + 1], bh[e], bl[e]);
+    for (int e = 0; e < 4; ++e) split_pair_nc(x[2 * e], x[2 * e + 1], bh[e], bl[e]);   // (checked in the epilogue)
     const u32x4 *wb = Wl[kb & 1] + lane;
 #pragma unroll
     for (int tg = 0; tg < IP_MT / 3; ++tg) {
@@ -318,11 +308,11 @@ __global__ __launch_bounds__(512, 4) void img_proj_direct_kernel(ProjArgs2 a) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) fq[q] = wb[(tg * 6 + q) * 64];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[2 * j], bl, acc[tg * 3 + j]);
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_F16(fq[2 * j], bl, acc[tg * 3 + j]);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[2 * j + 1], bh, acc[tg * 3 + j]);
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_F16(fq[2 * j + 1], bh, acc[tg * 3 + j]);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_BF16(fq[2 * j], bh, acc[tg * 3 + j]);
+      for (int j = 0; j < 3; ++j) acc[tg * 3 + j] = DF3D_MFMA_F16(fq[2 * j], bh, acc[tg * 3 + j]);
     }
   }
 
@@ -332,14 +322,15 @@ __global__ __launch_bounds__(512, 4) void img_proj_direct_kernel(ProjArgs2 a) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     unsigned h[2], l[2];
-    split_pair(acc[t][0], acc[t][1], h[0], l[0]);
-    split_pair(acc[t][2], acc[t][3], h[1], l[1]);
+    const f32x4 uv = acc[t] * DF3D_ACC_UNSCALE;
+    split_pair(uv[0], uv[1], h[0], l[0]);
+    split_pair(uv[2], uv[3], h[1], l[1]);
     char *blk = wt + n * ROW_PITCH + (2 * t + (g >> 1)) * 32 + (g & 1) * 8;   // 8-channel block = [hi 16 B | lo 16 B]
     *(u32x2 *)blk = (u32x2){h[0], h[1]};
     *(u32x2 *)(blk + 16) = (u32x2){l[0], l[1]};
   }
   const int pw = p0 + wave * 16;
-  if (g == 0 && pw + n < S) a.gate[(size_t)blockIdx.y * S + pw + n] = acc[8][0];
+  if (g == 0 && pw + n < S) a.gate[(size_t)blockIdx.y * S + pw + n] = acc[8][0] * DF3D_ACC_UNSCALE;
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
@@ -366,8 +357,9 @@ __global__ __launch_bounds__(256) void split_moments_kernel(const u32x4 *__restr
     const float ar = a ? a[row] : 1.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float v0 = (ip_bf16_to_float(hi[e] & 0xffffu) + ip_bf16_to_float(lo[e] & 0xffffu)) * ar;
-      float v1 = (ip_bf16_to_float(hi[e] >> 16) + ip_bf16_to_float(lo[e] >> 16)) * ar;
+      const df3d_f32x2 uv = split_to_f32(hi[e], lo[e]);
+      float v0 = uv[0] * ar;
+      float v1 = uv[1] * ar;
       s1[2 * e] += v0;
       s2[2 * e] += v0 * v0;
       s1[2 * e + 1] += v1;
@@ -443,15 +435,15 @@ __global__ __launch_bounds__(256) void gn_fold_pack_kernel(const double *__restr
   for (int i = part * 256 + tid; i < 4 * RG_WQ; i += 256 * nparts) {
     int lane = i & 63, part = (i >> 6) & 1, ct = (i >> 7) & 15, kb = i >> 11;
     int col = (ct >> 2) * 64 + (lane & 15) * 4 + (ct & 3), gq = lane >> 4;   // store q = ct/4 writes 256 B runs
-    unsigned v[8];
+    u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int c = kb * 32 + gq * 8 + e;
+    for (int e = 0; e < 4; ++e) {
+      const int c = kb * 32 + gq * 8 + 2 * e;
       unsigned hi, lo;
-      ip_split2(W[(size_t)col * C + c] * sc[c], hi, lo);
-      v[e] = part ? lo : hi;
+      split_pair_w(W[(size_t)col * C + c] * sc[c], W[(size_t)col * C + c + 1] * sc[c + 1], hi, lo);
+      o[e] = part ? lo : hi;
     }
-    Wp[(size_t)n * 4 * RG_WQ + i] = (u32x4){v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+    Wp[(size_t)n * 4 * RG_WQ + i] = o;
   }
 }
 
@@ -506,12 +498,12 @@ __global__ __launch_bounds__(512) void rows_gemm_split_kernel(const u32x4 *__res
         for (int k = 0; k < 4; ++k) fq[cur ^ 1][k] = wb[((ct + 2) * 2 + k) * 64];
       }
       const u32x4 bh0 = fq[cur][0], bl0 = fq[cur][1], bh1 = fq[cur][2], bl1 = fq[cur][3];
-      acc[ct] = DF3D_MFMA_BF16(al[kb], bh0, acc[ct]);
-      acc[ct + 1] = DF3D_MFMA_BF16(al[kb], bh1, acc[ct + 1]);
-      acc[ct] = DF3D_MFMA_BF16(ah[kb], bl0, acc[ct]);
-      acc[ct + 1] = DF3D_MFMA_BF16(ah[kb], bl1, acc[ct + 1]);
-      acc[ct] = DF3D_MFMA_BF16(ah[kb], bh0, acc[ct]);
-      acc[ct + 1] = DF3D_MFMA_BF16(ah[kb], bh1, acc[ct + 1]);
+      acc[ct] = DF3D_MFMA_F16(al[kb], bh0, acc[ct]);
+      acc[ct + 1] = DF3D_MFMA_F16(al[kb], bh1, acc[ct + 1]);
+      acc[ct] = DF3D_MFMA_F16(ah[kb], bl0, acc[ct]);
+      acc[ct + 1] = DF3D_MFMA_F16(ah[kb], bl1, acc[ct + 1]);
+      acc[ct] = DF3D_MFMA_F16(ah[kb], bh0, acc[ct]);
+      acc[ct + 1] = DF3D_MFMA_F16(ah[kb], bh1, acc[ct + 1]);
     }
   }
   // lane (col_n, g) holds rows 4g+r, columns 64q + 4 col_n + {0..3} of column tile 4q+j: one store instruction
@@ -524,13 +516,14 @@ __global__ __launch_bounds__(512) void rows_gemm_split_kernel(const u32x4 *__res
       unsigned short *o = (unsigned short *)out + ((size_t)nimg * S + p) * RG_COUT + n * 4;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *(u32x2 *)(o + q * 64) = (u32x2){ip_bf16_bits(acc[q * 4][r]) | (ip_bf16_bits(acc[q * 4 + 1][r]) << 16),
-                                         ip_bf16_bits(acc[q * 4 + 2][r]) | (ip_bf16_bits(acc[q * 4 + 3][r]) << 16)};
+        *(u32x2 *)(o + q * 64) = (u32x2){bf16_pair(acc[q * 4][r] * DF3D_ACC_UNSCALE, acc[q * 4 + 1][r] * DF3D_ACC_UNSCALE),
+                                         bf16_pair(acc[q * 4 + 2][r] * DF3D_ACC_UNSCALE, acc[q * 4 + 3][r] * DF3D_ACC_UNSCALE)};
     } else {
       float *o = out + ((size_t)nimg * S + p) * RG_COUT + n * 4;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *(f32x4 *)(o + q * 64) = (f32x4){acc[q * 4][r], acc[q * 4 + 1][r], acc[q * 4 + 2][r], acc[q * 4 + 3][r]};
+        *(f32x4 *)(o + q * 64) =
+            (f32x4){acc[q * 4][r], acc[q * 4 + 1][r], acc[q * 4 + 2][r], acc[q * 4 + 3][r]} * DF3D_ACC_UNSCALE;
     }
   }
 }

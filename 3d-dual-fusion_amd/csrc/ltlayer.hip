@@ -75,10 +75,10 @@ struct LtOp {
 // eight fp32 values (two float4 of the lane) -> one MFMA operand, hi and lo parts
 __device__ __forceinline__ LtOp lt_split(lt_f32x4 a, lt_f32x4 b) {
   LtOp o;
-  split_pair(a[0], a[1], o.hi[0], o.lo[0]);
-  split_pair(a[2], a[3], o.hi[1], o.lo[1]);
-  split_pair(b[0], b[1], o.hi[2], o.lo[2]);
-  split_pair(b[2], b[3], o.hi[3], o.lo[3]);
+  split_pair_bf16(a[0], a[1], o.hi[0], o.lo[0]);
+  split_pair_bf16(a[2], a[3], o.hi[1], o.lo[1]);
+  split_pair_bf16(b[0], b[1], o.hi[2], o.lo[2]);
+  split_pair_bf16(b[2], b[3], o.hi[3], o.lo[3]);
   return o;
 }
 
@@ -234,12 +234,12 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
       for (int tt = 0; tt < 2; ++tt) {
         const lt_f32x4 qq = (q[tt] + bq) * 0.25f, kk = k[tt] + bk;
         unsigned h01, l01, h23, l23;
-        split_pair(kk[0], kk[1], h01, l01);
-        split_pair(kk[2], kk[3], h23, l23);
+        split_pair_bf16(kk[0], kk[1], h01, l01);
+        split_pair_bf16(kk[2], kk[3], h23, l23);
         ka1[tt] = (lt_u32x4){h01, h23, l01, l23};
         ka2[tt] = (lt_u32x4){h01, h23, 0u, 0u};
-        split_pair(qq[0], qq[1], h01, l01);
-        split_pair(qq[2], qq[3], h23, l23);
+        split_pair_bf16(qq[0], qq[1], h01, l01);
+        split_pair_bf16(qq[2], qq[3], h23, l23);
         qb1[tt] = (lt_u32x4){h01, h23, h01, h23};
         qb2[tt] = (lt_u32x4){l01, l23, 0u, 0u};
         v[tt] += bv;

@@ -15,6 +15,8 @@
 
 namespace df3d {
 
+DF3D_SPLIT_OVERFLOW_TU(pointops)
+
 constexpr int FPS_MAXPT = 32;  // points per thread kept in registers (N <= 32 * 1024)
 
 struct Best {

@@ -1,5 +1,5 @@
 // Small dense layers over query rows on the matrix cores (round 3): y = W x + b for [rows, 128 | 256] fp32 rows and
-// <= 128 outputs, fp32-grade (operands split into bf16 hi + lo ON LOAD, three MFMA products, fp32 accumulate).
+// <= 128 outputs, fp32-grade (operands split into fp16 hi + lo ON LOAD -- common.h --, three MFMA products, fp32 accumulate).
 //
 // Reference: the query-side linears of the dual-query fusion encoder layer --
 //   sampling_offsets / attention_weights of MSDeformAttn on the mixed queries (CP/det3d/models/model_utils/ops/modules/
@@ -23,14 +23,12 @@ namespace df3d {
 
 typedef float rl_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int rl_u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 rl_bf16x8 __attribute__((ext_vector_type(8)));
 
-#define RL_MFMA(A, B, C) \
-  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(rl_bf16x8, A), __builtin_bit_cast(rl_bf16x8, B), C, 0, 0, 0)
+#define RL_MFMA(A, B, C) DF3D_MFMA_F16(A, B, C)
 
 struct RowLinArgs {
   const float *x0, *x1, *x2;      // [rows, cin]; x1 / x2 may be null
-  const rl_u32x4 *w;              // packed [kb][ct][hi|lo][lane] (column ct * 16 + n, channels kb * 32 + g * 8 ..)
+  const rl_u32x4 *w;              // packed [kb][ct][hi|lo][lane] (column ct * 16 + n, channels kb * 32 + g * 8 ..): fp16 pairs of 2^7 w
   const float *bias;              // [ct * 16] or null
   float *out0, *out1;             // columns [0, n0) -> out0 (row stride ld0), [n0, n0 + n1) -> out1
   const float *ln_res, *ln_gamma, *ln_beta;   // LayerNorm(ln_res + y) over n0 == CT * 16 columns, or null
@@ -40,10 +38,11 @@ struct RowLinArgs {
 };
 
 __device__ __forceinline__ void rl_split8(rl_f32x4 a, rl_f32x4 b, rl_u32x4 &hi, rl_u32x4 &lo) {
-  split_pair(a[0], a[1], hi[0], lo[0]);
-  split_pair(a[2], a[3], hi[1], lo[1]);
-  split_pair(b[0], b[1], hi[2], lo[2]);
-  split_pair(b[2], b[3], hi[3], lo[3]);
+  // (unchecked: query rows beyond fp16's range leave as inf / NaN rows, which the next checked split reports)
+  split_pair_nc(a[0], a[1], hi[0], lo[0]);
+  split_pair_nc(a[2], a[3], hi[1], lo[1]);
+  split_pair_nc(b[0], b[1], hi[2], lo[2]);
+  split_pair_nc(b[2], b[3], hi[3], lo[3]);
 }
 
 template <int CIN, int CT>
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void rows_linear_kernel(RowLinArgs a) {
         float y[CT], s = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          y[ct] = acc[ct][r] + bia[ct] + (live ? a.ln_res[ro * (CT * 16) + ct * 16 + n] : 0.f);
+          y[ct] = acc[ct][r] * DF3D_ACC_UNSCALE + bia[ct] + (live ? a.ln_res[ro * (CT * 16) + ct * 16 + n] : 0.f);
           s += y[ct];
         }
 #pragma unroll
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void rows_linear_kernel(RowLinArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const int col = ct * 16 + n;
-          const float y = acc[ct][r] + bia[ct];
+          const float y = acc[ct][r] * DF3D_ACC_UNSCALE + bia[ct];
           if (col < a.n0) a.out0[ro * a.ld0 + col] = y;
           else if (col < a.n0 + a.n1) a.out1[ro * a.ld1 + (col - a.n0)] = y;
         }

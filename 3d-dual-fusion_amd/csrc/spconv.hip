@@ -31,6 +31,8 @@
 
 namespace df3d {
 
+DF3D_SPLIT_OVERFLOW_TU(spconv)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {

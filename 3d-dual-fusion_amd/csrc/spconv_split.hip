@@ -1,19 +1,21 @@
-// Sparse convolution on the bf16 matrix cores with fp32-grade accuracy ("split" path) for gfx950.
+// Sparse convolution on the 16-bit matrix cores with fp32-grade accuracy ("split" path) for gfx950.
 //
-// fp32 MFMA on gfx950 runs at 1/16 of the bf16 rate (157 vs 2500 TFLOP/s).  An fp32 value x is split
-// exactly once, where it is PRODUCED, into two bf16 numbers
-//     hi = bf16(x),  lo = bf16(x - hi)            (x = hi + lo up to 2^-17 |x|)
-// and the contraction is evaluated as  A_hi*W_hi + A_lo*W_hi + A_hi*W_lo  with v_mfma_f32_16x16x32_bf16
-// (bf16 x bf16 products are exact in fp32; accumulation is fp32).  The dropped lo*lo term and the split
-// residuals are <= 2^-16 relative per product, i.e. the result carries ~1e-5 relative error against the exact
-// fp32 contraction -- two orders inside the 1e-3 parity bar, the same size as fp32 summation-order noise --
-// at 3/16 of the fp32-MFMA time.  That moves the C >= 64 layers from the MFMA roof onto the gather (L1/L2/HBM)
-// roof, which is where BASELINE.json's north_star measures them.
+// fp32 MFMA on gfx950 runs at 1/16 of the fp16 / bf16 rate (157 vs 2500 TFLOP/s).  An fp32 value x is split
+// exactly once, where it is PRODUCED, into two fp16 numbers of the value scaled by a fixed power of two
+//     hi = fp16(S x),  lo = fp16(S x - hi)            (S x = hi + lo up to 2^-22 |S x|; csrc/common.h)
+// and the contraction is evaluated as  A_lo*W_hi + A_hi*W_lo + A_hi*W_hi  with v_mfma_f32_16x16x32_f16
+// (fp16 x fp16 products are exact in fp32; accumulation is fp32; the epilogue multiplies by 2^-(SA + SW)).  The
+// dropped lo*lo term and the split residuals are <= 2^-21 relative per product: the result sits within fp32
+// accumulation noise of the exact fp32 contraction (~1e-6 of the output scale against float64, like the exact-fp32
+// MFMA kernels of spconv.hip; rounds 1-4 split into bf16 hi + lo: 16 bits, ~5e-6) at 3/16 of the fp32-MFMA time.
+// That moves the C >= 64 layers from the MFMA roof onto the gather (L1/L2/HBM) roof, which is where
+// BASELINE.json's north_star measures them.  Values outside fp16's range raise the flag df3d_split_overflow() reads.
 //
 // Data formats (both produced by kernels in this file or by the conv epilogue):
-//   split rows   [n][C/8][ hi 8 x bf16 | lo 8 x bf16 ]   32 B per 8 channels, same bytes as fp32
-//   packed W     [K][wave 4][kb][ct][hi|lo][lane 64][8 x bf16]: exactly the B operand of every lane, so the
+//   split rows   [n][C/8][ hi 8 x fp16 | lo 8 x fp16 ]   32 B per 8 channels, same bytes as fp32
+//   packed W     [K][wave 4][kb][ct][hi|lo][lane 64][8 x fp16]: exactly the B operand of every lane, so the
 //                per-offset weight fetch is 16 B per lane, coalesced
+// (NP = 3: three bf16 parts per value, six products, fp32's exponent range; NP = 1: plain bf16 rows and filters)
 //
 // Kernel structure = spconv_pair_kernel (spconv.hip): one workgroup per CU, rulebook pairs of a row tile
 // compacted per kernel offset, 16-pair MFMA chunks, per-wave column slice of W in registers, LDS
@@ -37,24 +39,17 @@ int timing_rec_begin(int cin, int cout, int kvol, int n_out, const int32_t *nbr,
                      hipStream_t stream);   // spconv.hip
 void timing_rec_end(int rec, hipStream_t stream);
 
-__device__ __forceinline__ unsigned bf16_bits(float x) {   // round to nearest even; finite inputs
-  unsigned u = __float_as_uint(x);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void split2(float x, unsigned &hi, unsigned &lo) {
-  hi = bf16_bits(x);
-  lo = bf16_bits(x - __uint_as_float(hi << 16));
-}
+DF3D_SPLIT_OVERFLOW_TU(spconv_split)
 
 // three-way split (round 4, "split3" precision): x = hi + mid + lo EXACTLY for finite normal x (8 + 8 + 8 significand bits),
 // every part a bf16 number; pairs packed like split_pair
 __device__ __forceinline__ void split3_pair_ref(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
   unsigned h, m;
-  split_pair(x0, x1, h, m);                                        // h = bf16(x), m = bf16(x - h)
+  split_pair_bf16(x0, x1, h, m);                                   // h = bf16(x), m = bf16(x - h)
   const float r0 = (x0 - __uint_as_float(h << 16)) - __uint_as_float(m << 16);
   const float r1 = (x1 - __uint_as_float(h & 0xffff0000u)) - __uint_as_float(m & 0xffff0000u);
   unsigned l, unused;
-  split_pair(r0, r1, l, unused);
+  split_pair_bf16(r0, r1, l, unused);
   hi = h, mid = m, lo = l;
 }
 
@@ -76,13 +71,7 @@ __global__ __launch_bounds__(256) void bf16_rows_kernel(const float *__restrict_
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nblk) return;
   f32x4 a = ((const f32x4 *)x)[2 * i], b = ((const f32x4 *)x)[2 * i + 1];
-  u32x4 ho;
-  unsigned lo;
-  split_pair(a[0], a[1], ho[0], lo);
-  split_pair(a[2], a[3], ho[1], lo);
-  split_pair(b[0], b[1], ho[2], lo);
-  split_pair(b[2], b[3], ho[3], lo);
-  out[i] = ho;
+  out[i] = (u32x4){bf16_pair(a[0], a[1]), bf16_pair(a[2], a[3]), bf16_pair(b[0], b[1]), bf16_pair(b[2], b[3])};
 }
 
 // bf16 rows -> fp32 rows
@@ -113,11 +102,8 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float *__r
   const int ch0 = kb * 32 + g * 8;
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    unsigned h, l;
-    split_pair(w[((size_t)k * cin + ch0 + 2 * e) * cout + col], w[((size_t)k * cin + ch0 + 2 * e + 1) * cout + col], h, l);
-    o[e] = h;
-  }
+  for (int e = 0; e < 4; ++e)
+    o[e] = bf16_pair(w[((size_t)k * cin + ch0 + 2 * e) * cout + col], w[((size_t)k * cin + ch0 + 2 * e + 1) * cout + col]);
   out[i] = o;
 }
 
@@ -211,17 +197,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
     col = (int)(r / K) * CW + n * CT + ct;     // lane n owns CT consecutive output columns -> vector epilogue
     ch0 = kb * 32 + g * 8;
   }
-  unsigned v[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    int ch = ch0 + e;
-    unsigned hi, lo;
-    split2(w[((size_t)k * cin + ch) * cout + col], hi, lo);
-    v[e] = part ? lo : hi;
-  }
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = v[2 * e] | (v[2 * e + 1] << 16);
+  for (int e = 0; e < 4; ++e) {
+    unsigned hi, lo;
+    split_pair_w(w[((size_t)k * cin + ch0 + 2 * e) * cout + col], w[((size_t)k * cin + ch0 + 2 * e + 1) * cout + col], hi, lo);
+    o[e] = part ? lo : hi;
+  }
   out[i] = o;
 }
 
@@ -278,6 +260,15 @@ extern "C" void df3d_debug_set_os_trace(void *p) { g_os_trace = (unsigned long l
 
 #define DF3D_MFMA_BF16(A, B, C) \
   __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+// the matrix instruction of a precision mode: two-part operands are fp16 pairs (common.h), one / three parts bf16
+template <int NP>
+__device__ __forceinline__ f32x4 mfma_parts(const u32x4 &A, const u32x4 &B, const f32x4 &C) {
+  if constexpr (NP == 2) return DF3D_MFMA_F16(A, B, C);
+  else return DF3D_MFMA_BF16(A, B, C);
+}
+// accumulator -> fp32 value
+template <int NP>
+__device__ __forceinline__ constexpr float acc_unscale() { return NP == 2 ? DF3D_ACC_UNSCALE : 1.0f; }
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 1) void spconv_split_kernel(SplitConvArgs a, int TM,
@@ -491,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void spconv_split_kernel(SplitConvArgs a, i
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
               const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
-              acc[h][ct] = DF3D_MFMA_BF16(cur[h][kb][pa], bc[kb][ct][pb], acc[h][ct]);
+              acc[h][ct] = DF3D_MFMA_F16(cur[h][kb][pa], bc[kb][ct][pb], acc[h][ct]);
             }
       load_a(idxn, tgt);                                  // gathers of item t+3 (into the slot item t-1 freed)
       flush_write(rl_prev, aprev);                        // item t-1's LDS update
@@ -527,7 +518,7 @@ __global__ __launch_bounds__(256, 1) void spconv_split_kernel(SplitConvArgs a, i
       int row = row0 + rl;
       if (rl < TM && row < row_end) {
         f32x4 v = *(const f32x4 *)(myacc + (size_t)rl * CS + lc);
-        v = (v + bi) * sc + sh;
+        v = (v * DF3D_ACC_UNSCALE + bi) * sc + sh;
         size_t o = (size_t)row * COUT + cs0 + lc;
         if (a.residual) v += *(const f32x4 *)(a.residual + o);
         if (a.relu) {
@@ -821,13 +812,13 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
           }
         }
 #pragma unroll
-        for (int c = 0; c < G; ++c) acc[0][b * G + c] = DF3D_MFMA_BF16(cur[0][0][1], bg[b & 1][c][0], acc[0][b * G + c]);
+        for (int c = 0; c < G; ++c) acc[0][b * G + c] = mfma_parts<NP>(cur[0][0][1], bg[b & 1][c][0], acc[0][b * G + c]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < G; ++c) acc[0][b * G + c] = DF3D_MFMA_BF16(cur[0][0][0], bg[b & 1][c][1], acc[0][b * G + c]);
+        for (int c = 0; c < G; ++c) acc[0][b * G + c] = mfma_parts<NP>(cur[0][0][0], bg[b & 1][c][1], acc[0][b * G + c]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < G; ++c) acc[0][b * G + c] = DF3D_MFMA_BF16(cur[0][0][0], bg[b & 1][c][0], acc[0][b * G + c]);
+        for (int c = 0; c < G; ++c) acc[0][b * G + c] = mfma_parts<NP>(cur[0][0][0], bg[b & 1][c][0], acc[0][b * G + c]);
         __builtin_amdgcn_sched_barrier(0);
       }
       issue_a(cur);
@@ -857,18 +848,18 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
         for (int rt = 0; rt < RT; ++rt) {
           const u32x4 a0 = cur[rt][j][0], a1 = cur[rt][j][1], a2 = cur[rt][j][2];
           f32x4 c0 = acc[rt][c2], c1 = acc[rt][c2 + 1];
-          c0 = DF3D_MFMA_BF16(a2, bp[0], c0);
-          c1 = DF3D_MFMA_BF16(a2, bp[3], c1);
-          c0 = DF3D_MFMA_BF16(a1, bp[1], c0);
-          c1 = DF3D_MFMA_BF16(a1, bp[4], c1);
-          c0 = DF3D_MFMA_BF16(a0, bp[2], c0);
-          c1 = DF3D_MFMA_BF16(a0, bp[5], c1);
-          c0 = DF3D_MFMA_BF16(a1, bp[0], c0);
-          c1 = DF3D_MFMA_BF16(a1, bp[3], c1);
-          c0 = DF3D_MFMA_BF16(a0, bp[1], c0);
-          c1 = DF3D_MFMA_BF16(a0, bp[4], c1);
-          c0 = DF3D_MFMA_BF16(a0, bp[0], c0);
-          c1 = DF3D_MFMA_BF16(a0, bp[3], c1);
+          c0 = mfma_parts<NP>(a2, bp[0], c0);
+          c1 = mfma_parts<NP>(a2, bp[3], c1);
+          c0 = mfma_parts<NP>(a1, bp[1], c0);
+          c1 = mfma_parts<NP>(a1, bp[4], c1);
+          c0 = mfma_parts<NP>(a0, bp[2], c0);
+          c1 = mfma_parts<NP>(a0, bp[5], c1);
+          c0 = mfma_parts<NP>(a1, bp[0], c0);
+          c1 = mfma_parts<NP>(a1, bp[3], c1);
+          c0 = mfma_parts<NP>(a0, bp[1], c0);
+          c1 = mfma_parts<NP>(a0, bp[4], c1);
+          c0 = mfma_parts<NP>(a0, bp[0], c0);
+          c1 = mfma_parts<NP>(a0, bp[3], c1);
           acc[rt][c2] = c0, acc[rt][c2 + 1] = c1;
         }
         continue;
@@ -877,8 +868,8 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
         const u32x4 b0 = bq[i & 1][0], b1 = bq[i & 1][1];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][0], b0, acc[rt][c2]);
-          acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][0], b1, acc[rt][c2 + 1]);
+          acc[rt][c2] = mfma_parts<NP>(cur[rt][j][0], b0, acc[rt][c2]);
+          acc[rt][c2 + 1] = mfma_parts<NP>(cur[rt][j][0], b1, acc[rt][c2 + 1]);
         }
         continue;
       }
@@ -893,18 +884,18 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
       if (OS_DBG(8)) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][NP - 1], bh0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][NP - 1], bh1, acc[rt][c2 + 1]);
+        acc[rt][c2] = mfma_parts<NP>(cur[rt][j][NP - 1], bh0, acc[rt][c2]);
+        acc[rt][c2 + 1] = mfma_parts<NP>(cur[rt][j][NP - 1], bh1, acc[rt][c2 + 1]);
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][0], bl0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][0], bl1, acc[rt][c2 + 1]);
+        acc[rt][c2] = mfma_parts<NP>(cur[rt][j][0], bl0, acc[rt][c2]);
+        acc[rt][c2 + 1] = mfma_parts<NP>(cur[rt][j][0], bl1, acc[rt][c2 + 1]);
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        acc[rt][c2] = DF3D_MFMA_BF16(cur[rt][j][0], bh0, acc[rt][c2]);
-        acc[rt][c2 + 1] = DF3D_MFMA_BF16(cur[rt][j][0], bh1, acc[rt][c2 + 1]);
+        acc[rt][c2] = mfma_parts<NP>(cur[rt][j][0], bh0, acc[rt][c2]);
+        acc[rt][c2 + 1] = mfma_parts<NP>(cur[rt][j][0], bh1, acc[rt][c2 + 1]);
       }
       if (OS_DBG(8)) __builtin_amdgcn_s_setprio(0);
     }
@@ -986,7 +977,8 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
       for (int r = 0; r < 4; ++r) {
         const int row = rowL[wave * WROWS + rt * 16 + 4 * g + r];
         if (row >= a.n_out) continue;
-        float2 v = make_float2((acc[rt][0][r] + bi.x) * sc.x + sh.x, (acc[rt][1][r] + bi.y) * sc.y + sh.y);
+        float2 v = make_float2((acc[rt][0][r] * acc_unscale<NP>() + bi.x) * sc.x + sh.x,
+                               (acc[rt][1][r] * acc_unscale<NP>() + bi.y) * sc.y + sh.y);
         if (a.cols) {                        // compact layout: only the block's valid columns exist in the output
           if (a.relu) {
             v.x = fmaxf(v.x, 0.f);
@@ -1024,12 +1016,12 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
             *(unsigned *)(blk + 32) = lp;
             continue;
           }
-          unsigned hp, lp;
-          split_pair(v.x, v.y, hp, lp);
           if constexpr (NP == 1) {
-            *(unsigned *)((char *)a.out_split + o * 2) = hp;
+            *(unsigned *)((char *)a.out_split + o * 2) = bf16_pair(v.x, v.y);
             continue;
           }
+          unsigned hp, lp;
+          split_pair(v.x, v.y, hp, lp);
           char *blk = (char *)a.out_split + (o >> 3) * 32 + (n & 3) * 4;     // 8-channel block = [hi 16 B | lo 16 B]
           *(unsigned *)blk = hp;
           *(unsigned *)(blk + 16) = lp;
@@ -1059,7 +1051,7 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
 #pragma unroll
       for (int q = 0; q < CT / 4; ++q) {
         f32x4 v = (f32x4){acc[rt][q * 4][r], acc[rt][q * 4 + 1][r], acc[rt][q * 4 + 2][r], acc[rt][q * 4 + 3][r]};
-        v = (v + bi[q]) * sc[q] + sh[q];
+        v = (v * acc_unscale<NP>() + bi[q]) * sc[q] + sh[q];
         if (a.residual) {
           if constexpr (NP == 1) {
             const u32x2 rr = *(const u32x2 *)((const char *)a.residual + (o + q * 4) * 2);
@@ -1079,6 +1071,9 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
           if constexpr (NP == 3) {
             split3_pair(v[0], v[1], h[q * 2], m3[q * 2], l[q * 2]);
             split3_pair(v[2], v[3], h[q * 2 + 1], m3[q * 2 + 1], l[q * 2 + 1]);
+          } else if constexpr (NP == 1) {
+            h[q * 2] = bf16_pair(v[0], v[1]);
+            h[q * 2 + 1] = bf16_pair(v[2], v[3]);
           } else {
             split_pair(v[0], v[1], h[q * 2], l[q * 2]);
             split_pair(v[2], v[3], h[q * 2 + 1], l[q * 2 + 1]);
@@ -1304,7 +1299,7 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
   const unsigned w_addr = lds_addr(&Wl[0][0]) + (unsigned)lane * 16u;
 #define LC_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define LC_SB() __builtin_amdgcn_sched_barrier(0)
-#define LC_M(rt, c, ap, br, buf, slot) acc[rt][c] = DF3D_MFMA_BF16(af[buf][rt][ap], bq[slot][br], acc[rt][c])
+#define LC_M(rt, c, ap, br, buf, slot) acc[rt][c] = DF3D_MFMA_F16(af[buf][rt][ap], bq[slot][br], acc[rt][c])
   // Batch i of a step = the two column tiles 2i, 2i + 1 x both row tiles x the three products (lo*hi, hi*lo, hi*hi:
   // the summation order of the kernel above): 12 MFMAs on B slot `slot`; RA .. RH = single fragment reads issued behind
   // MFMAs 0 .. 7
@@ -1398,7 +1393,7 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           f32x4 v = (f32x4){acc[rt][q * 4][r], acc[rt][q * 4 + 1][r], acc[rt][q * 4 + 2][r], acc[rt][q * 4 + 3][r]};
-          v = (v + bi[q]) * sc[q] + sh[q];
+          v = (v * DF3D_ACC_UNSCALE + bi[q]) * sc[q] + sh[q];
           if (e_res) v += *(const f32x4 *)(e_res + o + q * 4);
           if (e_relu) {
             v[0] = fmaxf(v[0], 0.f);
@@ -1528,22 +1523,11 @@ static bool use_lc(const SplitConvArgs &a) {
   return a.K > 1 && (long long)cdiv(a.n_out, 128) * a.gy >= 190;
 }
 
-#include "spconv_halo.h"
-#include "spconv_ws.h"
+// (Round 3's staged-range and weight-stationary experiment kernels -- measured, parity-tested, never faster than the kernels
+// here -- moved out of the library in round 5: tools/ubench/attic/spconv_halo.h, spconv_ws.h)
 
 template <int CIN, int COUT>
 static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
-  // weight-stationary kernel (spconv_ws.h): filters of whole offset groups in LDS, free-running waves
-  if constexpr ((CIN == 32 && (COUT == 32 || COUT == 64)) || (CIN == 64 && (COUT == 64 || COUT == 128)) ||
-                (CIN == 128 && COUT == 128)) {
-    const int ws = ws_mode_env();
-    if (ws_applicable(a) && (ws == 1 || (ws < 0 && ws_default<CIN, COUT>()))) return launch_ws<CIN, COUT>(a, stream);
-  }
-  // 3 x 3 (x 3) rulebooks of the backbone shapes: input rows staged through LDS (spconv_halo.h)
-  if constexpr ((CIN == 32 && (COUT == 32 || COUT == 64)) || (CIN == 64 && (COUT == 64 || COUT == 128)) ||
-                (CIN == 128 && COUT == 128)) {
-    if (halo_mode(a)) return launch_halo<CIN, COUT>(a, stream);
-  }
   // measured on MI355X (tools/conv_probe.py, DF3D_OS_CFG sweep): 8 waves x 1 row tile wins at the nuScenes layer
   // sizes (30k-70k rows).  The W step tiles are re-read from L2 by every workgroup (n_out/TM x 4*K*CIN*COUT
   // bytes per launch, more than the gathers), so more rows per workgroup = less L2 traffic; bigger register

@@ -29,18 +29,27 @@ def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
     return 1
 
 
-def _greedy_keep(over, keep):
+_NMS_ROWS = 2048     # rows of the suppression matrix alive at a time: [2048, N] instead of the dense [N, N]
+
+
+def _greedy_keep(n, over_rows, keep):
     """The reference's host loop over the suppression matrix (iou3d.cpp:127-143): box i survives unless an earlier survivor
-    suppresses it; survivors' indices go into the caller's CPU `keep` tensor, the count is returned."""
+    suppresses it; survivors' indices go into the caller's CPU `keep` tensor, the count is returned.  The matrix is produced
+    and consumed in blocks of `_NMS_ROWS` rows -- `over_rows(i0, i1)` -> bool [i1 - i0, n - i0] on the device, columns from
+    box i0 on (only later boxes matter to a row) -- so device and host memory stay at rows x N where the reference keeps
+    N x N / 64 bit words; same decisions in the same order."""
     import numpy as np
-    m = over.cpu().numpy()
-    n = m.shape[0]
     removed = np.zeros((n,), dtype=bool)
     out = []
-    for i in range(n):
-        if not removed[i]:
-            out.append(i)
-            removed[i + 1:] |= m[i, i + 1:]
+    for i0 in range(0, n, _NMS_ROWS):
+        i1 = min(n, i0 + _NMS_ROWS)
+        if removed[i0:i1].all():
+            continue
+        m = over_rows(i0, i1).cpu().numpy()
+        for i in range(i0, i1):
+            if not removed[i]:
+                out.append(i)
+                removed[i + 1:] |= m[i - i0, i + 1 - i0:]
     keep[:len(out)] = torch.as_tensor(out, dtype=keep.dtype)
     return len(out)
 
@@ -61,11 +70,14 @@ def nms_gpu(boxes, keep, nms_overlap_thresh, device_id=0):
     _check_nms_args(boxes, keep)
     if boxes.shape[0] == 0:
         return 0
-    b = boxes.float()
-    ov = _ops.boxes_overlap_bev_xyxyr(b, b)
+    b = boxes.float().contiguous()
     s = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))
-    iou = ov / torch.clamp(s.view(-1, 1) + s.view(1, -1) - ov, min=1e-8)
-    return _greedy_keep(iou > float(nms_overlap_thresh), keep)
+    thr = float(nms_overlap_thresh)
+
+    def rows(i0, i1):
+        ov = _ops.boxes_overlap_bev_xyxyr(b[i0:i1].contiguous(), b[i0:].contiguous())
+        return ov / torch.clamp(s[i0:i1].view(-1, 1) + s[i0:].view(1, -1) - ov, min=1e-8) > thr
+    return _greedy_keep(b.shape[0], rows, keep)
 
 
 @runtime_errors
@@ -74,10 +86,14 @@ def nms_normal_gpu(boxes, keep, nms_overlap_thresh, device_id=0):
     _check_nms_args(boxes, keep)
     if boxes.shape[0] == 0:
         return 0
-    b = boxes.float()
-    left, right = torch.max(b[:, None, 0], b[None, :, 0]), torch.min(b[:, None, 2], b[None, :, 2])
-    top, bottom = torch.max(b[:, None, 1], b[None, :, 1]), torch.min(b[:, None, 3], b[None, :, 3])
-    inter = torch.clamp(right - left, min=0) * torch.clamp(bottom - top, min=0)
+    b = boxes.float().contiguous()
     s = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))
-    iou = inter / torch.clamp(s.view(-1, 1) + s.view(1, -1) - inter, min=1e-8)
-    return _greedy_keep(iou > float(nms_overlap_thresh), keep)
+    thr = float(nms_overlap_thresh)
+
+    def rows(i0, i1):
+        a, c = b[i0:i1], b[i0:]
+        left, right = torch.max(a[:, None, 0], c[None, :, 0]), torch.min(a[:, None, 2], c[None, :, 2])
+        top, bottom = torch.max(a[:, None, 1], c[None, :, 1]), torch.min(a[:, None, 3], c[None, :, 3])
+        inter = torch.clamp(right - left, min=0) * torch.clamp(bottom - top, min=0)
+        return inter / torch.clamp(s[i0:i1].view(-1, 1) + s[i0:].view(1, -1) - inter, min=1e-8) > thr
+    return _greedy_keep(b.shape[0], rows, keep)

@@ -352,7 +352,8 @@ class VoxelWithPointProjection(nn.Module):
     def _remember_prefetched(self, batch_dict, layer_name, inp, both, ev):
         if len(self._prefetched) >= 4:                     # entries nobody consumed (a caller that changed its frame order)
             self._prefetched.pop(next(iter(self._prefetched)))
-        self._prefetched[(id(batch_dict), layer_name)] = (inp, both, ev)
+        # the entry holds the dict itself: id() of a collected dict can be handed to the next one
+        self._prefetched[(id(batch_dict), layer_name)] = (inp, both, ev, batch_dict)
 
     def prefetch_inline(self, batch_dict, layer_name='layer1_ori', img_conv_func=None):
         """The image-side projection issued early on the CURRENT stream (no co-running, just earlier in the frame)."""
@@ -635,10 +636,12 @@ class VoxelWithPointProjection(nn.Module):
         x_last = encoded_voxel_list[-1]
         dev = x_last.features.device
         pre = self._prefetched.pop((id(batch_dict), layer_name), None)
+        if pre is not None and pre[3] is not batch_dict:
+            pre = None
         prep, self._prepared = self._prepared, None
         prep = prep[2] if (prep is not None and prep[0] == id(batch_dict) and prep[1] == layer_name) else None
         if pre is not None:
-            inp, both, ev = pre
+            inp, both, ev = pre[:3]
             if ev is not None:                       # produced on the side stream
                 main = torch.cuda.current_stream(dev)
                 main.wait_event(ev)

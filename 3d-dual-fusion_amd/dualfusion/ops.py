@@ -434,17 +434,37 @@ def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shif
 
 
 # ---- split-precision convolution (csrc/spconv_split.hip) --------------------------------------------------
-# "split": C >= 64 layers run on the bf16 matrix cores with hi/lo-split fp32 operands (~1e-5 relative error);
+# "split": C >= 32 layers run on the 16-bit matrix cores with fp32 operands split into fp16 hi + lo (csrc/common.h; round 5:
+#          22 significand bits, ~1e-6 of the output scale against float64 = the grade of the exact-fp32 kernels; operands
+#          must stay inside fp16's range after a fixed scaling -- |activation| < 2047, |filter| < 511 --, which every
+#          kernel that writes split rows checks: `check_split_overflow`);
 # "fp32":  every layer on the exact fp32 MFMA kernels (csrc/spconv.hip).  DF3D_CONV_PRECISION overrides.
 # "split3": the same layers with operands in THREE bf16 parts (hi + mid + lo = the fp32 value exactly) and six products:
-#          fp32-grade results (~1e-7) at 2.6x the fp32 matrix rate.  The functions below (`split_rows`, `conv_pack_weights`,
+#          fp32-grade results with fp32's exponent range at twice the matrix work of "split".  The functions below (`split_rows`, `conv_pack_weights`,
 #          `sparse_conv_split`, `conv_rows_split`) then produce / consume three-part buffers: their callers treat split rows
 #          and packed filters as opaque, so the sparse backbone, the BEV neck and the head run on it unchanged.
 CONV_PRECISION = os.environ.get("DF3D_CONV_PRECISION", "split")
 
 
+class grad_precision(object):
+    """Context of a backward pass: gradient rows have no fixed scale (1e-8 .. 1e+2 within one step), which the fp16 parts of
+    the "split" mode cannot hold -- input-gradient convolutions run in the three-part mode (bf16 parts: fp32's exponent range)."""
+
+    def __enter__(self):
+        global CONV_PRECISION
+        self.old = CONV_PRECISION
+        if CONV_PRECISION == "split":
+            CONV_PRECISION = "split3"
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_PRECISION
+        CONV_PRECISION = self.old
+        return False
+
+
 def split_parts():
-    """bf16 parts per value of the split rows / packed filters of the current precision mode."""
+    """16-bit parts per value of the split rows / packed filters of the current precision mode."""
     return 3 if CONV_PRECISION == "split3" else 2
 
 
@@ -660,18 +680,19 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=
             inv = invert_neighbors(nbr, n_in)
     wt = filters.transpose(1, 2).contiguous()                     # [K, cout, cin]
     cout, cin = wt.shape[1], wt.shape[2]
-    if bf16 and conv_bf16_supported(K, cout, cin):
-        g_in, _ = sparse_conv_bf16(rows_to_bf16(grad_out), conv_pack_weights_bf16(wt), inv, n_in, cout, cin, want_f32=True,
-                                   want_bf16=False)
-    elif conv_split_supported(K, cout, cin):
-        g_in, _ = sparse_conv_split(split_rows(grad_out), conv_pack_weights(wt), inv, n_in, cout, cin, emit_split=False)
-    elif cin > 128 and cin % 128 == 0 and conv_split_supported(K, cout, 128):
-        # many input channels (the head's shared conv 512 -> 64, transposed): 128-column blocks of one grouped launch
-        blocks = wt.view(K, cout, cin // 128, 128).permute(2, 0, 1, 3).contiguous()
-        g_in, _ = conv_rows_split(split_rows(grad_out), cout, 0, conv_pack_weights_groups(blocks), 128, cin // 128, inv,
-                                  n_in)
-    else:
-        g_in = sparse_conv_fused(grad_out, wt, inv, n_in)
+    with grad_precision():
+        if bf16 and conv_bf16_supported(K, cout, cin):
+            g_in, _ = sparse_conv_bf16(rows_to_bf16(grad_out), conv_pack_weights_bf16(wt), inv, n_in, cout, cin, want_f32=True,
+                                       want_bf16=False)
+        elif conv_split_supported(K, cout, cin):
+            g_in, _ = sparse_conv_split(split_rows(grad_out), conv_pack_weights(wt), inv, n_in, cout, cin, emit_split=False)
+        elif cin > 128 and cin % 128 == 0 and conv_split_supported(K, cout, 128):
+            # many input channels (the head's shared conv 512 -> 64, transposed): 128-column blocks of one grouped launch
+            blocks = wt.view(K, cout, cin // 128, 128).permute(2, 0, 1, 3).contiguous()
+            g_in, _ = conv_rows_split(split_rows(grad_out), cout, 0, conv_pack_weights_groups(blocks), 128, cin // 128, inv,
+                                      n_in)
+        else:
+            g_in = sparse_conv_fused(grad_out, wt, inv, n_in)
     return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr)
 
 
@@ -1045,6 +1066,49 @@ class CenterHeadLossFunction(torch.autograd.Function):
 _ROWLIN_CACHE = {}
 
 
+SPLIT_ACT_SCALE, SPLIT_W_SCALE = 32.0, 128.0        # csrc/common.h: DF3D_SA_SCALE, DF3D_SW_SCALE
+
+
+def split_overflow(reset=True):
+    """df3d_split_overflow: (flag, units).  True when a kernel met a value outside the range of the fp16 operand split
+    (activations |x| < 2047, filters |w| < 511; or a NaN / inf) since the last reset.  Synchronises the device."""
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(256)
+    rc = lib.df3d_split_overflow(int(bool(reset)), buf, 256)
+    if rc < 0:
+        _lib.check(rc, "df3d_split_overflow")
+    return bool(rc), buf.value.decode()
+
+
+def check_split_overflow():
+    """Raise if the two-part (fp16 hi + lo) operand format lost a value since the last check.  Call at a point where the
+    host waits for the device anyway (after a frame's results are read)."""
+    hit, where = split_overflow(reset=True)
+    if hit:
+        raise _lib.Df3dError("a value left the range of the fp16 operand split (|activation| < %g, |weight| < %g, or NaN / inf; "
+                             "raised in: %s).  The results of the frames since the last check are invalid; run this data with "
+                             "DF3D_CONV_PRECISION=split3 (three bf16 parts, fp32's exponent range)."
+                             % (65504.0 / SPLIT_ACT_SCALE, 65504.0 / SPLIT_W_SCALE, where))
+
+
+def unsplit_rows(split, n, c):
+    """Two-part split rows (uint8 [n, 4 c]: per 8 channels 8 x fp16 hi | 8 x fp16 lo of 2^5 x) -> fp32 [n, c] (exact)."""
+    h = split.reshape(-1).view(torch.float16).view(n, c // 8, 2, 8).float()
+    return ((h[:, :, 0] + h[:, :, 1]) / SPLIT_ACT_SCALE).reshape(n, c)
+
+
+def split_weights_fp16(w, what="weights"):
+    """fp32 weights -> (hi, lo) torch.float16 of 2^7 w, the two-part operand format of the matrix-core kernels
+    (csrc/common.h); raises when a weight leaves fp16's range."""
+    ws = w.detach().float() * SPLIT_W_SCALE
+    if ws.numel() and not bool((ws.abs() <= 65504.0).all()):
+        raise _lib.Df3dError("%s: a weight exceeds the fp16 operand range (|w| < %g); use DF3D_CONV_PRECISION=split3"
+                             % (what, 65504.0 / SPLIT_W_SCALE))
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    return hi, lo
+
+
 def rows_linear_supported(cin, cout):
     """DF3D_ROWS_LINEAR=0 keeps the library GEMMs (A/B switch, read per call)."""
     if os.environ.get("DF3D_ROWS_LINEAR", "1") == "0":
@@ -1072,10 +1136,9 @@ def rows_linear_pack(weights, biases=None):
     CT, KB = (cout + 15) // 16, cin // 32
     Wp = W.new_zeros((CT * 16, cin))
     Wp[:cout] = W
-    hi = Wp.to(torch.bfloat16)
-    lo = (Wp - hi.float()).to(torch.bfloat16)
+    hi, lo = split_weights_fp16(Wp, "rows_linear_pack")
     parts = [t.view(CT, 16, KB, 4, 8).permute(2, 0, 3, 1, 4) for t in (hi, lo)]           # [KB, CT, g, n, e]
-    packed = torch.stack(parts, 2).contiguous().view(torch.uint8).reshape(-1)              # [KB, CT, part, lane, 8] bf16
+    packed = torch.stack(parts, 2).contiguous().view(torch.uint8).reshape(-1)              # [KB, CT, part, lane, 8] fp16
     bias = None
     if any(b is not None for b in bs):
         bias = W.new_zeros(CT * 16)

@@ -59,7 +59,11 @@ class CenterPointHotPath(nn.Module):
     # ------------------------------------------------------------------ geometry of the next frame on a helper thread
     @staticmethod
     def _frame_key(points_list, batch_dict):
-        return (tuple(int(p.data_ptr()) for p in points_list), id(batch_dict) if batch_dict is not None else 0)
+        # address, in-place version counter and shape of every cloud: a loader that rewrites the same buffers between
+        # prefetch() and forward() changes the key, and the stale head is dropped instead of being used; the
+        # frame head keeps `batch_dict` itself as the entry's owner, so its id cannot be recycled while the entry lives
+        return (tuple((int(p.data_ptr()), int(p._version), tuple(p.shape)) for p in points_list),
+                id(batch_dict) if batch_dict is not None else 0)
 
     def prefetch(self, points_list, batch_dict=None):
         """Start the head of a LATER forward(points_list, batch_dict=batch_dict) now, on the detector's native worker thread

@@ -21,6 +21,7 @@ a replayed hipGraph.  Consumers on the same stream (loss, box decoding, NMS) are
 import ctypes
 
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 
 from . import _lib
 
@@ -49,12 +50,41 @@ class _Recorder(object):
         setattr(self._lib, name, value)
 
 
+_FACTORIES = frozenset(("empty", "empty_strided", "empty_like", "new_empty", "new_empty_strided", "detach", "alias",
+                        "lift_fresh", "sym_size", "sym_stride", "sym_numel", "sym_storage_offset", "is_pinned", "size",
+                        "stride", "numel", "dim", "is_contiguous", "storage_offset", "_has_compatible_shallow_copy_type"))
+
+
+def _launches_nothing(func):
+    """True for ATen operators that neither launch a kernel nor touch device data: allocations and views."""
+    packet = getattr(func, "overloadpacket", None)
+    if getattr(packet, "__name__", None) in _FACTORIES:
+        return True
+    rets = func._schema.returns
+    return bool(rets) and all(r.alias_info is not None and not r.alias_info.is_write for r in rets)
+
+
+class _PurityMode(TorchDispatchMode):
+    """Notes every ATen operator of a recording that would launch work of its own: such a launch is not on the
+    tape, a replay would skip it and read its stale output -- a section that contains one is not taped."""
+
+    def __init__(self):
+        super(_PurityMode, self).__init__()
+        self.impure = []
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        if not _launches_nothing(func):
+            self.impure.append(str(func))
+        return func(*args, **(kwargs or {}))
+
+
 class LaunchTape(object):
     def __init__(self, device):
         self.device = torch.device(device)
         self.pool = torch.cuda.MemPool()
         self.calls = []            # (name, fn, args list, index of the stream argument, [(arg index, input index, offset)])
         self.result = None
+        self.impure = []           # ATen operators the recorded section ran besides the library's launches (must be empty)
         self._ranges = []
 
     # ------------------------------------------------------------------ record
@@ -66,11 +96,13 @@ class LaunchTape(object):
         self.calls = []
         lib = _lib.load()
         _lib._recorder = _Recorder(lib, self)
+        purity = _PurityMode()
         try:
-            with torch.cuda.use_mem_pool(self.pool, device=self.device):
+            with torch.cuda.use_mem_pool(self.pool, device=self.device), purity:
                 self.result = fn()
         finally:
             _lib._recorder = None
+        self.impure = purity.impure
         return self.result
 
     def _note(self, name, fn, args):
@@ -106,7 +138,8 @@ class TapedSection(object):
     def __init__(self):
         self.tapes = {}
         self.retired = []          # tapes of stale keys: their pools are kept (plans built while recording may live there)
-        self.stats = {"plain": 0, "recorded": 0, "replayed": 0}
+        self.stats = {"plain": 0, "recorded": 0, "replayed": 0, "refused": 0}
+        self.refused_ops = []      # the operators that made the last recording unusable
         self._live = None          # the key of the last call
 
     def reset(self):
@@ -132,9 +165,21 @@ class TapedSection(object):
             self.tapes[key] = "warm"
             self.stats["plain"] += 1
             return fn()
+        if slot == "plain":                              # this key's section is not pure C-ABI: never replayed
+            self.stats["plain"] += 1
+            return fn()
         if slot == "warm":
             tape = LaunchTape(inputs[0].device)
             out = tape.record(fn, inputs)
+            if tape.impure:
+                # the section launched through torch as well (e.g. the neck's torch.cat when its last layers cannot write
+                # the concatenated rows in place: bf16 / exact-fp32 modes): a replay would skip those launches.  The result
+                # of this (real) run is good; the key runs the module path from now on.
+                self.retired.append(tape)
+                self.tapes[key] = "plain"
+                self.refused_ops = sorted(set(tape.impure))
+                self.stats["refused"] += 1
+                return out
             self.tapes[key] = tape
             self.stats["recorded"] += 1
             return out

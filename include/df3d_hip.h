@@ -43,6 +43,13 @@ const char *df3d_last_error(void);
 /* number of devices visible / name of device 0 ("gfx950..."), for loud failure on a wrong box */
 int df3d_device_count(void);
 int df3d_device_arch(char *buf, int buflen);
+/* Range check of the fp16 operand splits (round 5; csrc/common.h): the matrix-core kernels of the fp32 configurations
+ * take their operands as fp16 hi + lo pairs of the fp32 values scaled by 2^5 (activations: |x| < 2047) or 2^7 (filters:
+ * |w| < 511).  A value outside that range (or a NaN / inf) raises a sticky flag on the device instead of passing
+ * silently.  Returns 1 if any kernel has raised it since the last reset, 0 if not, < 0 on error; `where` (may be NULL)
+ * receives the comma-separated source units that raised it.  SYNCHRONISES the device.  The reference has no counterpart
+ * (its fp32 GEMMs have fp32's range, spconv_ops.h:302,338); data beyond the range belongs on the three-part mode. */
+int df3d_split_overflow(int reset, char *where, int where_len);
 
 /* ------------------------------------------------------------------------------------
  * Voxelisation + fused mean VFE.

@@ -170,37 +170,55 @@ def test_sparse_conv_vs_oracle(dev, cin, cout, n_seeds):
         np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-4)
 
 
-def _np_split(x):
-    """hi = bf16_rne(x), lo = bf16_rne(x - hi) as uint16 bit patterns (csrc/spconv_split.hip split2)."""
-    def rne(v):
-        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
-        return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) & 0xffff).astype(np.uint32)
-    hi = rne(x)
-    hif = (hi << 16).astype(np.uint32).view(np.float32)
-    lo = rne((x.astype(np.float32) - hif).astype(np.float32))
-    return hi.astype(np.uint16), lo.astype(np.uint16)
+def _np_split(x, scale=32.0):
+    """hi = fp16_rne(S x), lo = fp16_rne(S x - hi) as uint16 bit patterns (csrc/common.h split_pair_f16_ref; S = 2^5 for
+    activations, 2^7 for filters)."""
+    xs = (x.astype(np.float32) * np.float32(scale)).astype(np.float32)
+    with np.errstate(over="ignore"):
+        hi = xs.astype(np.float16)
+        lo = (xs - hi.astype(np.float32)).astype(np.float16)
+    return hi.view(np.uint16), lo.view(np.uint16)
 
 
 def test_split_rows_bit_exact(dev):
+    """The two-part operand format: fp16 hi + lo of 2^5 x, bit for bit against numpy's float16 conversion (round to nearest
+    even, subnormals kept); 22 significand bits down to |x| = 2^-8, an absolute error <= 2^-30 below; a value outside
+    fp16's range raises the sticky flag instead of passing silently."""
     from dualfusion import ops
-    x = detgen.randn("splitrows", (1000, 64)) * np.exp(detgen.randn("splitrows_s", (1000, 1)) * 3).astype(np.float32)
-    x[0, :8] = [0.0, -0.0, 1.0, -1.0, 3.0e-39, 1.0e30, -65504.0, 0.333333343]
-    got = ops.split_rows(T(x, dev)).cpu().numpy().view(np.uint16).reshape(1000, 8, 2, 8)
+    ops.split_overflow(reset=True)
+    x = detgen.randn("splitrows", (1000, 64)) * np.exp(detgen.randn("splitrows_s", (1000, 1)) * 2).astype(np.float32)
+    x = np.clip(x, -2000.0, 2000.0).astype(np.float32)
+    x[0, :8] = [0.0, -0.0, 1.0, -1.0, 3.0e-39, 2046.9, -2047.0, 0.333333343]
+    x[1, :4] = [1e-3, 2.0 ** -8, 3e-6, 1e-9]
+    got = ops.split_rows(T(x, dev))
+    assert ops.split_overflow(reset=True) == (False, "")
+    raw = got.cpu().numpy().view(np.uint16).reshape(1000, 8, 2, 8)
     hi, lo = _np_split(x)
-    assert np.array_equal(got[:, :, 0], hi.reshape(1000, 8, 8))
-    assert np.array_equal(got[:, :, 1], lo.reshape(1000, 8, 8))
-    # the pair reproduces x to 2^-16 relative
-    rec = (hi.astype(np.uint32) << 16).view(np.float32) + (lo.astype(np.uint32) << 16).view(np.float32)
-    big = np.abs(x) > 1e-30
-    assert np.max(np.abs(rec - x)[big] / np.abs(x)[big]) < 2.0 ** -16
+    assert np.array_equal(raw[:, :, 0], hi.reshape(1000, 8, 8))
+    assert np.array_equal(raw[:, :, 1], lo.reshape(1000, 8, 8))
+    rec = ops.unsplit_rows(got, 1000, 64).cpu().numpy()
+    err = np.abs(rec.astype(np.float64) - x.astype(np.float64))
+    assert np.all(err <= np.maximum(np.abs(x) * 2.0 ** -22, 2.0 ** -30))
+    # out of range: reported, not silent (and reported once: the flag is sticky until it is reset)
+    x[5, 3] = 3000.0
+    ops.split_rows(T(x, dev))
+    hit, where = ops.split_overflow(reset=True)
+    assert hit and "spconv_split" in where
+    with pytest.raises(Exception):
+        ops.split_rows(T(x, dev))
+        ops.check_split_overflow()
+    x[5, 3] = float("nan")
+    ops.split_rows(T(x, dev))
+    assert ops.split_overflow(reset=True)[0]
+    assert ops.split_overflow(reset=True) == (False, "")
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
 @pytest.mark.parametrize("n_seeds", [4, 60])
 def test_sparse_conv_split_precision(dev, cin, cout, n_seeds):
-    """Split-precision kernel (bf16 hi/lo operands, 3 MFMA products, fp32 accumulate) against the float64
-    contraction: <= 5e-5 of the output scale (parity bar 1e-3; the exact-fp32 kernel sits at ~1e-6), fused
-    epilogue included, and its emitted split rows equal split_rows(out) bit for bit."""
+    """Split-precision kernel (fp16 hi/lo operands, 3 MFMA products, fp32 accumulate) against the float64
+    contraction: <= 4e-6 of the output scale -- the grade of the exact-fp32 kernel (~1e-6; rounds 1-4 split into bf16
+    parts: ~1e-5) --, fused epilogue included, and its emitted split rows equal split_rows(out) bit for bit."""
     from dualfusion import ops
     shape, batch = [9, 48, 48], 2
     ind = detgen.clustered_voxels("cs%d" % n_seeds, batch, shape, n_seeds=n_seeds, walk=200)
@@ -228,7 +246,7 @@ def test_sparse_conv_split_precision(dev, cin, cout, n_seeds):
                 acc[m] += feats[nb[k][m]].astype(np.float64) @ filt[k].astype(np.float64)
             ref = np.maximum((acc + bias) * scale + shift + res, 0)
             err = np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max()
-            assert err < 5e-5, err
+            assert err < 4e-6, err
             assert torch.equal(ys, ops.split_rows(y))
         y32 = ops.sparse_conv_fused(T(feats, dev), T(filt, dev), nbr, n_out, bias=T(bias, dev), scale=T(scale, dev),
                                     shift=T(shift, dev), residual=T(res, dev), relu=True)
@@ -341,64 +359,6 @@ def test_offset_split_wave_groups_match_the_single_group_kernel(dev, cin, cout):
             os.environ.pop("DF3D_OS_KSPLIT", None)
         else:
             os.environ["DF3D_OS_KSPLIT"] = old
-
-
-@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (128, 128), (32, 64)])
-@pytest.mark.parametrize("mode", ["2", "4", "8", "9"])
-def test_staged_range_conv_kernels_match_the_default_kernel(dev, cin, cout, mode):
-    """The opt-in staged-range kernels (csrc/spconv_halo.h, DF3D_CONV_HALO=1: input rows of an offset group loaded once, as
-    one contiguous rank range, into LDS) against the default kernel: same products, another summation order (<= 2e-5 of
-    the output scale), identical split rows of their own fp32 result.  Row counts around the 128 / 256-row tiles, SubM and
-    strided rulebooks, rows in SHUFFLED order (ranges longer than the staging capacity: the chunked path), a tiling
-    order, every epilogue combination, tiles and kz groups without any neighbour."""
-    import os
-    from dualfusion import ops
-    shape, batch = [9, 48, 48], 2
-    filt = detgen.randn("hw%d_%d" % (cin, cout), (27, cin, cout), 0.5 / np.sqrt(cin))
-    packed = ops.conv_pack_weights(T(filt, dev))
-    bias, scale, shift = (T(detgen.randn("h%s%d" % (t, cout), (cout,), 0.2), dev) for t in "bsh")
-    old = {k: os.environ.get(k) for k in ("DF3D_CONV_HALO", "DF3D_HALO_RT", "DF3D_OS_LC")}
-
-    def both(fn):
-        os.environ["DF3D_CONV_HALO"] = "0"
-        a = fn()
-        os.environ["DF3D_CONV_HALO"], os.environ["DF3D_HALO_RT"] = "1", mode
-        b = fn()
-        return a, b
-    try:
-        for n_seeds, walk, shuffle in ((1, 1, False), (2, 64, False), (8, 200, False), (40, 200, False), (40, 200, True)):
-            ind = detgen.clustered_voxels("h%d_%d" % (n_seeds, walk), batch, shape, n_seeds=n_seeds, walk=walk)
-            if shuffle:
-                ind = ind[np.random.RandomState(1).permutation(len(ind))]
-            else:
-                ind = ind[np.lexsort(ind.T[::-1])]                    # rows sorted by cell, as every stage hands them over
-            ind_t = T(ind, dev)
-            feats = detgen.randn("hf%d_%d_%d" % (cin, n_seeds, walk), (len(ind), cin))
-            fsplit = ops.split_rows(T(feats, dev))
-            for subm in (1, 0):
-                outids, nbr, _ = _hip_rulebook(ind_t, batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], subm)
-                n_out = outids.shape[0]
-                res = T(detgen.randn("hr%d_%d" % (cout, n_out), (n_out, cout)), dev)
-                for kw in (dict(), dict(bias=bias, scale=scale, shift=shift, residual=res, relu=True)):
-                    (y0, s0), (y1, s1) = both(lambda: ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, **kw))
-                    assert float((y0 - y1).abs().max()) <= 2e-5 * max(float(y0.abs().max()), 1e-6), (n_out, subm, sorted(kw))
-                    assert torch.equal(ops.split_rows(y1), s1)
-                if subm and n_out > 1:
-                    order = torch.randperm(n_out, device=dev, dtype=torch.int64).to(torch.int32)
-                    (y0, _), (y1, _) = both(lambda: ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, bias=bias, order=order))
-                    assert float((y0 - y1).abs().max()) <= 2e-5 * max(float(y0.abs().max()), 1e-6)
-        # a dense 3 x 3 layer over pixel rows (K = 9: one group holds all taps)
-        nb9, Ho, Wo = ops.conv2d_neighbors(2, 37, 41, 3, 3, 1, 1, False, torch.device(dev))
-        f9 = ops.split_rows(T(detgen.randn("h9f%d" % cin, (2 * 37 * 41, cin)), dev))
-        p9 = ops.conv_pack_weights(T(filt[:9].copy(), dev))
-        (y0, _), (y1, _) = both(lambda: ops.sparse_conv_split(f9, p9, nb9, 2 * Ho * Wo, cin, cout, bias=bias, relu=True))
-        assert float((y0 - y1).abs().max()) <= 2e-5 * float(y0.abs().max())
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def test_rulebook_empty_and_single(dev):
@@ -640,16 +600,16 @@ def test_ffn_fused_bf16_mode(dev, rows):
     finally:
         ops.CONV_PRECISION = old
     y32 = ops.ffn_fused(x, packed, b1, b2, H, residual=x, ln_weight=lw, ln_bias=lb, eps=1e-5)      # split precision again
-    r = lambda t: t.to(torch.bfloat16).double()        # noqa: E731  (round to nearest even, like the kernel's hi part)
+    r = lambda t: t.to(torch.float16).double()         # noqa: E731  (round to nearest even, like the kernel's hi part)
     hid = torch.relu(r(x) @ r(w1).t() + b1.double())
     ref = r(hid.float()) @ r(w2).t() + b2.double() + x.double()
     ref = torch.nn.functional.layer_norm(ref, (C,), lw.double(), lb.double(), 1e-5)
     err = float((y.double() - ref).abs().max() / ref.abs().max())
-    assert err < 2e-4, err                              # hidden values that round across a bf16 boundary differ by 1 ulp
+    assert err < 5e-5, err                              # hidden values that round across an fp16 boundary differ by 1 ulp
     full = torch.relu(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double() + x.double()
     full = torch.nn.functional.layer_norm(full, (C,), lw.double(), lb.double(), 1e-5)
-    assert float((y.double() - full).abs().max() / full.abs().max()) < 2e-2
-    assert float((y32.double() - full).abs().max() / full.abs().max()) < 5e-5          # the switch went back
+    assert float((y.double() - full).abs().max() / full.abs().max()) < 3e-3
+    assert float((y32.double() - full).abs().max() / full.abs().max()) < 4e-6          # the switch went back
 
 
 @pytest.mark.parametrize("N,Q,C,G", [(6, 5189, 128, 32), (2, 77, 256, 32), (1, 1, 64, 16), (3, 300, 128, 8)])
@@ -680,11 +640,10 @@ def test_image_projection_split_path(dev, S, gated):
     us, gate = ops.imgproj_split(ptrs, NI, Cin, S, ops.imgproj_pack(wcat))
     ref_u = torch.stack([wcat.double() @ m.double() for m in maps])             # [NI, 129, S]
     # split rows -> floats
-    w16 = us.view(torch.int16).view(NI, S, 16, 2, 8).to(torch.int32) & 0xffff
-    u_got = ((w16[:, :, :, 0] << 16).view(torch.float32) + (w16[:, :, :, 1] << 16).view(torch.float32)).reshape(NI, S, C)
+    u_got = ops.unsplit_rows(us, NI * S, C).reshape(NI, S, C)
     scale = ref_u.abs().max()
-    assert float((u_got.double() - ref_u[:, :C].transpose(1, 2)).abs().max() / scale) < 2e-5
-    assert float((gate.double() - ref_u[:, C]).abs().max() / scale) < 2e-5
+    assert float((u_got.double() - ref_u[:, :C].transpose(1, 2)).abs().max() / scale) < 4e-6
+    assert float((gate.double() - ref_u[:, C]).abs().max() / scale) < 4e-6
     att = torch.rand(NI, S, generator=g).to(dev) if gated else None
     gn = torch.nn.GroupNorm(32, C).to(dev)
     with torch.no_grad():
@@ -1298,50 +1257,6 @@ def test_sparse_conv_grouped_vs_per_group_launches(dev, G, cin, gin, cout):
         assert torch.equal(out[:, 8 + i * cout:8 + (i + 1) * cout], want), i
     with pytest.raises(Exception):
         ops.sparse_conv_grouped(wide[:, :cin], w, nbr, n, group_in=max(gin, 4))      # the groups' slices leave the rows
-
-
-@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
-def test_weight_stationary_conv_kernel_is_bit_identical(dev, cin, cout):
-    """The opt-in weight-stationary kernel (csrc/spconv_ws.h, DF3D_CONV_WS=1: filters of whole offset groups in LDS, free-running
-    waves over up to three 16-row tiles each, empty (tile, offset) pairs skipped, quad-coalesced gathers permuted into the
-    operand shape) against the default kernels: same operands, same accumulation order per output element -> IDENTICAL
-    fp32 rows and split rows.  SubM and strided rulebooks, row counts below / above one pass of the workgroups, tiles
-    without any neighbour, every epilogue combination, fp32 rows omitted."""
-    import os
-    from dualfusion import ops
-    shape, batch = [9, 64, 64], 2
-    filt = detgen.randn("ws%d_%d" % (cin, cout), (27, cin, cout), 0.5 / np.sqrt(cin))
-    packed = ops.conv_pack_weights(T(filt, dev))
-    bias, scale, shift = (T(detgen.randn("w%s%d" % (t, cout), (cout,), 0.2), dev) for t in "bsh")
-    old = os.environ.get("DF3D_CONV_WS")
-
-    def both(fn):
-        os.environ["DF3D_CONV_WS"] = "0"
-        a = fn()
-        os.environ["DF3D_CONV_WS"] = "1"
-        b = fn()
-        return a, b
-    try:
-        for n_seeds, walk in ((30, 300), (80, 400)):
-            ind = detgen.clustered_voxels("ws%d_%d" % (n_seeds, walk), batch, shape, n_seeds=n_seeds, walk=walk)
-            ind = ind[np.lexsort(ind.T[::-1])]
-            ind_t = T(ind, dev)
-            feats = detgen.randn("wsf%d_%d" % (cin, n_seeds), (len(ind), cin))
-            fsplit = ops.split_rows(T(feats, dev))
-            for subm in (1, 0):
-                outids, nbr, _ = _hip_rulebook(ind_t, batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], subm)
-                n_out = outids.shape[0]
-                if n_out < 4096:                                  # the kernel serves layers of >= 4096 rows
-                    continue
-                res = T(detgen.randn("wsr%d_%d" % (cout, n_out), (n_out, cout)), dev)
-                for kw in (dict(), dict(bias=bias, scale=scale, shift=shift, residual=res, relu=True)):
-                    (y0, s0), (y1, s1) = both(lambda: ops.sparse_conv_split(fsplit, packed, nbr, n_out, cin, cout, **kw))
-                    assert torch.equal(y0, y1) and torch.equal(s0, s1), (n_out, subm, sorted(kw))
-    finally:
-        if old is None:
-            os.environ.pop("DF3D_CONV_WS", None)
-        else:
-            os.environ["DF3D_CONV_WS"] = old
 
 
 def test_hard_voxelize_clouds_equals_per_cloud_calls(dev):

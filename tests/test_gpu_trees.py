@@ -712,7 +712,7 @@ def test_launch_tape_over_neck_and_head_equals_plain_detector():
                 for a, b in zip(run(taped, pts, ex, True), run(plain, pts, ex, True)):
                     assert torch.equal(a, b), (rnd, j)
         st = taped._tail_tape.stats
-        assert st["plain"] == 1 and st["recorded"] == 1 and st["replayed"] == 7, st
+        assert st["plain"] == 1 and st["recorded"] == 1 and st["replayed"] == 7, (st, taped._tail_tape.refused_ops)
         # the head maps themselves (the tape's result object), and detections decoded from them
         for j, (pts, ex) in enumerate(frames):
             hp = taped.hot_path
@@ -760,4 +760,25 @@ def test_launch_tape_over_neck_and_head_equals_plain_detector():
         finally:
             _ops.CONV_PRECISION = old_mode
         assert st["plain"] == before["plain"] + 2 and st["recorded"] == before["recorded"] + 2, st
+        # modes whose neck ends in launches torch dispatches itself (bf16 / exact fp32: torch.cat of the upsampled
+        # maps, a .contiguous() copy) are NOT pure C-ABI sections -- a replay would skip those launches and hand the head the
+        # recording frame's map.  The recording notices the foreign operators and the key runs the module path from then on:
+        # every frame its own result, nothing replayed.
+        for mode in ("bf16", "fp32"):
+            before = dict(st)
+            try:
+                _ops.CONV_PRECISION = mode
+                for rnd in range(3):
+                    for j, (pts, ex) in enumerate(frames):
+                        for a, b in zip(run(taped, pts, ex, True), run(plain, pts, ex, True)):
+                            assert torch.equal(a, b), (mode, rnd, j)
+            finally:
+                _ops.CONV_PRECISION = old_mode
+            assert st["refused"] == before["refused"] + 1 and st["replayed"] == before["replayed"], (mode, st)
+            assert st["recorded"] == before["recorded"] and taped._tail_tape.refused_ops, (mode, st)
+        _ops.CONV_PRECISION = old_mode
+        for rnd in range(2):                                  # back in the taped mode
+            for j, (pts, ex) in enumerate(frames):
+                for a, b in zip(run(taped, pts, ex, True), run(plain, pts, ex, True)):
+                    assert torch.equal(a, b), ("back", rnd, j)
     torch.cuda.synchronize()
