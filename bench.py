@@ -48,7 +48,7 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_MFMA_TF = 157.3   # dense fp32 MFMA (= vector) peak
-PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 MFMA peak; the split-precision kernels spend 3 bf16 products per fp32 product
+PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 / fp16 MFMA peak; the split-precision kernels spend 3 products per fp32 product
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_final_pmc_spconv_split.json")
 
 
@@ -76,7 +76,7 @@ def parse():
                          "never as `value`.  1 = skip the pass")
     ap.add_argument("--conv-precision", default=os.environ.get("DF3D_CONV_PRECISION", ""),
                     choices=["", "split", "split3", "fp32", "bf16"],
-                    help="sparse-conv arithmetic: split (fp32-grade: bf16 hi+lo operands, 3 MFMA products), fp32 (exact fp32 "
+                    help="sparse-conv arithmetic: split (fp32-grade: fp16 hi+lo operands, 3 MFMA products), fp32 (exact fp32 "
                          "MFMA), bf16 (bf16 rows / weights, fp32 accumulate).  Default: split for the fp32 configs, bf16 "
                          "for tf_fusion (configs[2] is a bf16 config)")
     ap.add_argument("--backend", default="", help="torch.distributed backend (default nccl = RCCL; gloo for the CPU tests)")
@@ -345,7 +345,7 @@ def roofline_from_timer(timer, meta_timer, want=None):
     s = 2 if split == 2 else 4
     roof.update({"traffic": None, "kernel": "%s K=%d" % (kname, K),
                  "precision": ("bf16 rows and weights, fp32 accumulate" if split == 2 else
-                               "split bf16 hi/lo operands, 3 MFMA products, fp32 accumulate" if split else "fp32 MFMA"),
+                               "fp16 hi/lo operand pairs, 3 MFMA products, fp32 accumulate (fp32-grade)" if split else "fp32 MFMA"),
                  "launches": g["n"], "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),
                  "algorithmic_flops_per_launch": fl // g["n"], "algorithmic_bytes_per_launch": by // g["n"],
                  "extra_written_bytes_per_launch": extra // g["n"],
@@ -588,13 +588,53 @@ def side_configs(args, steps=12):
             d = json.loads(line[-1])
             out[name] = {"cfg": cfg, "ms_per_step": d["ms_per_step"], "bs": d["config"]["sweeps_per_gpu_per_step"],
                          "value": d["value"], "unit": d["unit"],
-                         "dtype": {"split": "f32(split-bf16x3)", "bf16": "bf16", "fp32": "f32"}[prec], "steps": steps}
+                         "dtype": {"split": "f32(fp16 hi+lo operands, 3 products)", "bf16": "bf16", "fp32": "f32"}[prec], "steps": steps}
         except Exception as ex:                                  # noqa: BLE001
             out[name] = {"cfg": cfg, "error": repr(ex)[:120]}
     return out
 
 
 # ------------------------------------------------------------------------------------------------ main
+def precision_probe(wl, ops, frames=2):
+    """Evidence for `dtype` on the bench line itself: the dense BEV map (after voxelisation, the 21 sparse convolutions and the
+    camera fusion: every matrix-core GEMM of the hot path has contributed) and the detection head's output maps (after the
+    neck and the head's convolutions) of the first frames in the headline mode ("split": fp16 hi + lo operands), in "split3"
+    (three bf16 parts) and with every convolution on the exact-fp32 MFMA kernels, each against the exact-fp32 result:
+    max |difference| / max |reference|."""
+    import torch
+    old = ops.CONV_PRECISION
+    res = {"what": "max |x - x_fp32| / max |x_fp32| over the dense BEV map [B, 256, 180, 180] and over the detection head's "
+                   "output maps of %d frame(s), x = a precision mode's result, x_fp32 = the result with every convolution on "
+                   "v_mfma_f32_16x16x4_f32 (exact fp32 products); all modes run the FFN / query linears / image projection on "
+                   "the fp16 hi + lo kernels" % frames}
+    bev, heads = {}, {}
+    try:
+        for mode in ("fp32", "split", "split3"):
+            ops.CONV_PRECISION = mode
+            bev[mode], heads[mode] = [], []
+            for k in range(frames):
+                fr = wl.frames[k % len(wl.frames)]
+                bd, example = wl.fresh_inputs(fr)
+                bev[mode].append(wl.step(k, "hot_path").float().clone())
+                wl._staged = {}
+                with torch.no_grad():
+                    x, _ = wl.model.hot_path(fr["points"], batch_dict=bd, example=example)
+                    preds = wl.model.bbox_head(x)
+                heads[mode].append(torch.cat([v.float().reshape(-1) for d in preds for _, v in sorted(d.items())]).clone())
+    finally:
+        ops.CONV_PRECISION = old
+    torch.cuda.synchronize()
+    for mode in ("split", "split3"):
+        worst, hworst = 0.0, 0.0
+        for a, b, ha, hb in zip(bev[mode], bev["fp32"], heads[mode], heads["fp32"]):
+            worst = max(worst, float((a - b).abs().max() / b.abs().max()))
+            hworst = max(hworst, float((ha - hb).abs().max() / hb.abs().max()))
+        res[mode] = {"bev_map": float("%.3e" % worst), "head_maps": float("%.3e" % hworst)}
+    res["bev_map_scale"] = float("%.4g" % float(bev["fp32"][0].abs().max()))
+    res["head_maps_scale"] = float("%.4g" % float(heads["fp32"][0].abs().max()))
+    return res
+
+
 def timed_steps(wl, stage, steps, first, barrier, reduce_losses):
     barrier()
     # no cyclic-GC pause inside the timed steps (a generation-2 pass over a process holding ~10^5 tensor wrappers takes
@@ -846,6 +886,18 @@ def main():
             wl.step(k, stage)
         torch.cuda.synchronize()
         meta_timer.stop()
+    precision_evidence = None
+    if (rank == 0 and world == 1 and stage == "detect" and precision == "split" and args.workload in ("cp_fusion", "cp_lidar")
+            and not args.no_extra_passes and not protocol):
+        try:
+            note("precision probe")
+            precision_evidence = precision_probe(wl, ops)
+        except Exception as e:                                   # noqa: BLE001  (a measurement aid must not fail the bench line)
+            print("bench.py: precision probe failed: %r" % (e,), file=sys.stderr)
+    if use_gpu and not protocol:
+        # the fp16 operand split is range-limited (csrc/common.h): a value it could not hold raises a device flag instead of
+        # passing silently -- a bench line must not be printed over such a run
+        ops.check_split_overflow()
     api = None
     if kernel_timing and rank == 0 and stage in ("detect", "hot_path"):
         try:
@@ -861,11 +913,13 @@ def main():
             "unit": wl.unit_name + "/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per_step(elapsed), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"split": "f32 (C>=32 sparse convs, neck / head convs and the FFN: operands split into bf16 hi+lo, 3 MFMA "
-                               "products, fp32 accumulate, ~1e-5 rel. error; everything else exact fp32)",
-                      "fp32": "f32 (exact fp32 MFMA convolutions; FFN split precision)",
+            "dtype": {"split": "f32 (fp32-grade throughout: every matrix-core GEMM -- C>=32 sparse convs, neck / head convs, FFN, "
+                               "query linears, image projection, value GEMM -- takes its fp32 operands as fp16 hi+lo pairs, "
+                               "22 significand bits, 3 MFMA products, fp32 accumulate: <= 4e-6 of scale against float64, the "
+                               "grade of the exact-fp32 MFMA kernels; everything else exact fp32)",
+                      "fp32": "f32 (exact fp32 MFMA convolutions; FFN / query linears / image side on fp16 hi+lo operands)",
                       "split3": "f32 (C>=32 convolutions: operands in three bf16 parts, 6 MFMA products, fp32 accumulate, "
-                                "fp32-grade; FFN two-part split precision)",
+                                "fp32-grade with fp32's exponent range; FFN / query linears / image side on fp16 hi+lo operands)",
                       "bf16": "bf16 sparse convs (bf16 rows and weights, fp32 accumulate and epilogue); fusion adapter, "
                               "ACTR and C<=16 layers f32"}[precision] if not protocol else "none",
             "data": "synthetic",
@@ -959,12 +1013,12 @@ def main():
                     "algorithmic bytes or flops / that time; mfma peak = dense bf16 / 3 (split precision spends three products)")
         if world == 1 and not args.no_cpu_baseline and args.workload in ("cp_fusion", "cp_lidar"):
             res["cpu_baseline"] = cpu_baseline(wl, args.cpu_sweeps)
+        if precision_evidence is not None:
+            res["precision_evidence"] = precision_evidence
         if "fp32_detect" in extra:
-            # the like-for-like numbers (every convolution fp32-grade) inside a field the driver's record keeps
-            res["dtype"] = "%s; fp32-grade step (3 bf16 parts, 6 products) %.2f ms = %.1f %s/s; exact-fp32-MFMA step %.2f ms" % (
-                res["dtype"].split(" (")[0] + " split-bf16x3 convs+FFN, fp32 accumulate, <=1e-4 of scale",
-                per_step(extra.get("split3_detect", 0.0)), units / extra["split3_detect"] if "split3_detect" in extra else 0.0,
-                wl.unit_name, per_step(extra["fp32_detect"]))
+            # the companions (three bf16 parts; exact-fp32 MFMA) inside a field the driver's record keeps
+            res["dtype"] = "%s; same step with 3 bf16 parts / 6 products %.2f ms; with exact-fp32-MFMA convolutions %.2f ms" % (
+                res["dtype"], per_step(extra.get("split3_detect", 0.0)), per_step(extra["fp32_detect"]))
         if (world == 1 and args.side_configs and not protocol and stage == "detect" and args.workload == "cp_fusion"
                 and not args.no_extra_passes):
             note("side configs")
