@@ -172,7 +172,7 @@ def test_forward_rows_vs_torch_cpu_and_end_to_end():
         for k in ref[t]:
             assert tuple(got[t][k].shape) == tuple(ref[t][k].shape)
             err = float((got[t][k].cpu() - ref[t][k]).abs().max() / ref[t][k].abs().max())
-            assert err < 1e-3, (t, k, err)                                   # measured ~1e-5
+            assert err < 1e-5, (t, k, err)                                   # fp32-grade against torch CPU fp32 (bar 1e-3)
     from dualfusion import ops
     if ops.CONV_PRECISION == "split":                       # other precisions take the library composition
         assert getattr(got[0]["hm"], "_df3d_rows", None) is not None
@@ -292,7 +292,7 @@ def test_final_conv_forward_vs_torch_float64(B, H, W):
     out_pk = ops.head_final_conv(split, B, H, W, w4d, b4d, cd, width, packed=ops.head_final_pack(w4d))
     assert torch.equal(out[:, :c0], out_pk[:, :c0])                      # the same operands, whoever split the filters
     err = float((out[:, :c0].cpu().double() - ref).abs().max() / ref.abs().max())
-    assert err < 2e-5, err                                               # split precision: hi*hi + lo*hi + hi*lo
+    assert err < 4e-6, err                                               # fp16 hi + lo operands: hi*hi + lo*hi + hi*lo
 
 
 def test_final_conv_backward_kernels_vs_torch_float64():

@@ -30,7 +30,7 @@ def test_rpn_rows_vs_torch_cpu(B, H, W):
         y_lib = md.forward_reference(x.to(dev))            # MIOpen / hipBLASLt composition, for reference only
     assert tuple(y.shape) == tuple(ref.shape) == (B, 512, H, W)
     err = float((y.cpu() - ref).abs().max() / ref.abs().max())
-    assert err < 1e-3, err                                 # north_star tolerance; measured ~1e-5
+    assert err < 1e-5, err                                 # fp32-grade (north_star tolerance 1e-3): fp32 (torch CPU) against fp32 grade
     assert float((y_lib.cpu() - ref).abs().max() / ref.abs().max()) < 1e-3
 
 

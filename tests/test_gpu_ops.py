@@ -298,7 +298,7 @@ def test_loader_consumer_conv_kernel_forced_on_small_and_ragged_shapes(dev, cin,
                     (y0, _), (y1, _) = both(lambda: ops.sparse_conv_split(fsplit, packed1, nb1, n_out, cin, cout, bias=bias))
                     assert torch.equal(y0, y1)
                     want = feats.astype(np.float64) @ filt[13].astype(np.float64) + bias.cpu().numpy()
-                    assert np.abs(y1.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-9) < 5e-5
+                    assert np.abs(y1.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-9) < 4e-6
     finally:
         if old_ks is None:
             os.environ.pop("DF3D_OS_KSPLIT", None)
@@ -576,7 +576,7 @@ def test_ffn_fused(dev, rows, H, ln, res, C):
     if ln:
         ref = torch.nn.functional.layer_norm(ref, (C,), lw.double(), lb.double(), 1e-5)
     err = float((y.double() - ref).abs().max() / ref.abs().max())
-    assert err < 5e-5, err
+    assert err < 4e-6, err                              # fp32-grade (fp16 hi + lo operands; rounds 1-4, bf16 parts: 5e-5)
 
 
 @pytest.mark.parametrize("rows", [37, 5000, 40001])
@@ -657,7 +657,7 @@ def test_image_projection_split_path(dev, S, gated):
         want = torch.einsum('oc,ncs->nso', Wv.double(), gn(x).double()) + wb.double()
         value, cf = ops.value_fold_gemm(us, att, b, gn, Wv, wb)
         got = value.double() * (att[..., None].double() if gated else 1.0) + cf[:, None].double()
-    assert float((got - want).abs().max() / want.abs().max()) < 5e-5
+    assert float((got - want).abs().max() / want.abs().max()) < 4e-6
 
 
 def test_msda_linearity_at_full_size(dev):
@@ -1184,7 +1184,7 @@ def test_rows_linear_vs_float64(dev, cin, couts, rows):
 
     def close(got, want):
         assert got.shape == want.shape
-        assert float((got.double().cpu() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-6)
+        assert float((got.double().cpu() - want).abs().max()) <= 4e-6 * max(float(want.abs().max()), 1e-6)
     if len(couts) == 2:
         o0, o1 = ops.rows_linear(x0, pk, x1=x1, x2=x2, csplit=couts[0], n0=couts[0], n1=couts[1])
         close(o0, a0 @ W[:couts[0]].t() + b[:couts[0]])
