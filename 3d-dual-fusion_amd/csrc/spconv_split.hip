@@ -603,7 +603,11 @@ __device__ u32x4 g_zero_row[192];          // up to 512 input channels, three pa
 // accumulators meet in LDS before the epilogue): the 90 x 90 maps of the BEV neck have 127 row tiles x 2 column halves for
 // 256 CUs -- one wave per SIMD, every step an exposed chain of barrier, fragment reads and matrix instructions (a step costs
 // ~1500 clocks whatever its MFMA count); three groups put three waves on every SIMD without a second pass over memory.
-template <int CIN, int COUT, int RT, int NW, int KPS, int NP = 2, int KS = 1>
+// MG = masked gathers (round 5): a lane whose row has no neighbour at the offset issues NO request (exec-masked loads into
+// zeroed registers) instead of reading the all-zero row.  The sparse 3 x 3 x 3 layers have ~45 % such lanes, and every lane
+// of a gather instruction costs the texture path a slot whatever it reads (tools/ubench/qperm_probe.hip: gathers + MFMAs
+// of a 64-channel K = 27 layer 52 -> 41 us); dense maps (neck, head) have none and keep the branch-free form.
+template <int CIN, int COUT, int RT, int NW, int KPS, int NP = 2, int KS = 1, bool MG = false>
 __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConvArgs a) {
   // KPS = 32-channel blocks per step (one barrier per step)
   // COUT = 256 is computed as two 128-column halves by different workgroups (blockIdx.y): twice the workgroups for
@@ -735,6 +739,20 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int idx = idxn[rt];
+      if constexpr (MG) {
+#pragma unroll
+        for (int j = 0; j < KPS; ++j)
+#pragma unroll
+          for (int q = 0; q < NP; ++q) dst[rt][j][q] = (u32x4){0u, 0u, 0u, 0u};
+        if (ca.live && idx >= 0) {
+          const u32x4 *p = a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff + (kb * 4 + OS_QSUB) * NP;
+#pragma unroll
+          for (int j = 0; j < KPS; ++j)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) dst[rt][j][q] = p[j * 4 * NP + q];
+        }
+        continue;
+      }
       const u32x4 *p = (ca.live && idx >= 0 && !OS_DBG(1)) ? a.feat + (size_t)idx * a.ldi + blockIdx.y * a.in_goff
                                                              : g_zero_row;
       p += (kb * 4 + OS_QSUB) * NP;
@@ -1555,7 +1573,17 @@ static int launch_os_split(const SplitConvArgs &a, hipStream_t stream) {
     else DF3D_OS_LAUNCH(1, 4, KMAX);
   } else if (nw == 16) DF3D_OS_LAUNCH(1, 16, 1);
   else if (rt == 2 && nw == 8) DF3D_OS_LAUNCH(2, 8, 1);
-  else if (nw == 8) DF3D_OS_LAUNCH(1, 8, 1);
+  else if (nw == 8) {
+    // sparse 3-D rulebooks: masked gathers (DF3D_OS_MASKED=0 / 1 forces them off / on; read per call for the A/B)
+    const char *mg = getenv("DF3D_OS_MASKED");
+    // measured (tools/conv_probe.py, MI355X): 32 -> 32 35.3 -> 33.5 us, 64 -> 64 63.5 -> 68.5 us (the branch costs the wider
+    // kernel more than the requests it saves) -- default on for 32 input channels only
+    const bool masked = mg ? mg[0] == '1' : (a.K == 27 && !a.cols && CIN == 32);
+    if (masked)
+      hipLaunchKernelGGL((spconv_os_split_kernel<CIN, COUT, 1, 8, 1, 2, 1, true>), dim3(cdiv(a.n_out, 128), a.gy), dim3(512), 0,
+                         stream, a);
+    else DF3D_OS_LAUNCH(1, 8, 1);
+  }
   else if (rt == 2 && nw == 4) DF3D_OS_LAUNCH(2, 4, 1);
   else if (rt == 2 && nw == 2) DF3D_OS_LAUNCH(2, 2, 1);
   else if (rt == 1 && nw == 4) DF3D_OS_LAUNCH(1, 4, 1);

@@ -157,7 +157,7 @@ def test_full_size_layer_vs_reference_cpu_build(sweep, stage, cin, cout):
     if ops.conv_split_supported(27, cin, cout):
         ys, _ = ops.sparse_conv_split(ops.split_rows(T(feats)), ops.conv_pack_weights(w), nbr, n_out, cin, cout)
         err = np.abs(ys.cpu().numpy() - want).max() / scale
-        assert err <= 1e-3 and err <= 1e-4, err           # the bar is 1e-3; the split kernel sits two digits below it
+        assert err <= 1e-3 and err <= 2e-5, err           # the bar is 1e-3; fp16 hi + lo operands: the grade of the exact-fp32 kernel above
 
 
 def test_device_losses_vs_reference_golden(golden):
