@@ -181,11 +181,15 @@ def transfusion_encoder(sd, voxel_features, coors, batch_size, sparse_shape, enc
     return d.reshape(B, C * D, H, W), x
 
 
-def voxel_backbone8x(sd, voxel_features, coors, batch_size, sparse_shape):
-    """VR/pcdet/models/backbones_3d/spconv_backbone.py:135-243 (LiDAR branch)."""
+def voxel_backbone8x(sd, voxel_features, coors, batch_size, sparse_shape, fuse1=None, fuse4=None):
+    """VR/pcdet/models/backbones_3d/spconv_backbone.py:135-243 (LiDAR branch); with `fuse1` / `fuse4` the fusion variant's
+    order of operations (:829-916): fuse1(x_conv1) right behind conv1, fuse4(x_conv2, x_conv3, x_conv4) right behind conv4,
+    both in front of whatever reads those tensors next."""
     x = SpTensor(np.asarray(voxel_features, np.float32), np.asarray(coors, np.int32), sparse_shape, batch_size)
     x = _cbr(sd, "conv_input.0", "conv_input.1", x, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, "subm1")
     c1 = _cbr(sd, "conv1.0.0", "conv1.0.1", x, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, "subm1")
+    if fuse1 is not None:
+        c1 = fuse1(c1)
     outs = {"x_conv1": c1}
     cur = c1
     for s, pad in ((2, [1, 1, 1]), (3, [1, 1, 1]), (4, [0, 1, 1])):
@@ -194,6 +198,8 @@ def voxel_backbone8x(sd, voxel_features, coors, batch_size, sparse_shape):
             cur = _cbr(sd, "conv%d.%d.0" % (s, j), "conv%d.%d.1" % (s, j), cur, [3, 3, 3], [1, 1, 1], [1, 1, 1], 1,
                        "subm%d" % s)
         outs["x_conv%d" % s] = cur
+    if fuse4 is not None:
+        cur = outs["x_conv4"] = fuse4(outs["x_conv2"], outs["x_conv3"], cur)
     out = _cbr(sd, "conv_out.0", "conv_out.1", cur, [3, 1, 1], [2, 1, 1], [0, 0, 0], 0)
     return out, outs
 

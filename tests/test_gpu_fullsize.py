@@ -404,7 +404,9 @@ TF_CH = ((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128))
 TF_PAD = ((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0))
 # bf16 mode (rows and filters rounded to bf16 = 2^-9 relative, fp32 accumulate, ~20 layers deep): the stated bound against
 # the ORACLE's fp32 result -- worst element within 5 % of the output scale, mean error within 1 % of the mean magnitude
-BF16_MAX, BF16_MEAN = 5e-2, 1e-2
+# bf16 rows and filters (8 significand bits) through 16 convolutions + the fusion layer, fp32 accumulate and fp32 epilogue:
+# measured on MI355X 2.5e-3 of scale (worst element), 1.6e-3 of the mean magnitude (round 5; the bound of round 4 was 5e-2 / 1e-2)
+BF16_MAX, BF16_MEAN = 1e-2, 3e-3
 
 
 def _load_det(model):
@@ -495,6 +497,8 @@ def test_full_grid_transfusion_encoder_fusion_bs4_vs_oracle():
         ops.CONV_PRECISION = old
     assert torch.equal(x16.indices, x_last.indices)
     d16 = y16.cpu().numpy()
+    print("bf16 mode against the oracle: max %.3e of scale, mean %.3e of mean" % (np.abs(d16 - o_y).max() / scale,
+                                                                                  np.abs(d16 - o_y).mean() / np.abs(o_y).mean()))
     assert np.abs(d16 - o_y).max() <= BF16_MAX * scale, np.abs(d16 - o_y).max() / scale
     assert np.abs(d16 - o_y).mean() <= BF16_MEAN * np.abs(o_y).mean(), np.abs(d16 - o_y).mean() / np.abs(o_y).mean()
 
@@ -504,8 +508,9 @@ def test_full_grid_voxel_rcnn_backbone_bs8_vs_oracle():
     high-sparsity rulebook stress).  `VoxelBackBone8x` against the oracle composition on the reference's compiled CPU ops:
     voxel tensors and the four stages' index sets bit-exact, rows <= 1e-3 of their scale.  `VoxelBackBone8xFusion` (MVX point
     fusion at stride 1 + ACTRv2 at stride 8; both pinned to the reference by tests/golden/vr_fusion.npz at small size) on
-    the same frames: same index sets (fusion changes no geometry), the stride-1 rows = LiDAR rows + the image sample at the
-    voxel's pixel (loop restatement on sampled rows), finite rows after the stride-8 fusion."""
+    the same frames: every stage's rows and the encoded output against the oracle composition with the device fusion layers
+    at its two fusion points (<= 1e-3 of scale; index sets bit-exact), plus the stride-1 rows = LiDAR rows + the image sample
+    at the voxel's pixel (loop restatement on sampled rows)."""
     from dualfusion import ops, synth
     from dualfusion.backbones import VoxelBackBone8x, VoxelBackBone8xFusion
     B, grid = 8, [1408, 1600, 40]
@@ -562,6 +567,41 @@ def test_full_grid_voxel_rcnn_backbone_bs8_vs_oracle():
         assert np.array_equal(a, b_), name
         assert bool(torch.isfinite(ms[name].features).all()), name
     assert bool(torch.isfinite(out["encoded_spconv_tensor"].features).all())
+    # ---- round 5: the fusion variant's OUTPUT against the oracle composition.  Both fusion layers are pinned to the reference
+    # module at small size (tests/golden/vr_fusion.npz, test_gpu_trees.py); here the oracle backbone (the reference's compiled
+    # CPU ops where built) hands ITS rows to the device layers at the two fusion points -- x_conv1 rows through the MVX
+    # sampling, x_conv4 rows (in spconv's GPU order: furthest point sampling starts at row 0 of every sample) through
+    # ACTRv2 with its LocalTransformer -- and goes on from their results, so the comparison covers the full-size encoder on
+    # both sides of the fusion, as the TransFusion test above does.
+    sdf = {k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}
+    SCT = __import__("dualfusion").spconv.SparseConvTensor
+
+    def fuse1(x):
+        with torch.no_grad():
+            y = mf._fuse1(SCT(T(x.features), T(x.indices), mf.sparse_shape, B), dict(bdf))
+        x.features = y.features.cpu().numpy()
+        return x
+
+    def fuse4(c2, c3, c4):
+        oi, ofe = om.sort_rows(c4.indices, c4.features)
+        mf.__dict__.pop("_fuse4_pre", None)                   # (the in-line path: positions and slots from these rows)
+        assert mf.ifat is None
+        with torch.no_grad():
+            y = mf._fuse4(None, None, SCT(T(ofe), T(oi), c4.shape, B), dict(bdf))
+        c4.indices, c4.features, c4.rulebooks = np.ascontiguousarray(oi), y.features.cpu().numpy(), {}
+        return c4
+    with om.using(_impl()):
+        o_out_f, o_ms_f = om.voxel_backbone8x(sdf, of, oc, B, [41, 1600, 1408], fuse1=fuse1, fuse4=fuse4)
+    worst = {}
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        gi, gf = om.sort_rows(ms[name].indices.cpu().numpy(), ms[name].features.cpu().numpy())
+        oi, ofe = om.sort_rows(o_ms_f[name].indices, o_ms_f[name].features)
+        assert np.array_equal(gi, oi), name
+        worst[name] = np.abs(gf - ofe).max() / np.abs(ofe).max()
+        assert worst[name] <= 1e-3, (name, worst)
+    gi, gf = om.sort_rows(out["encoded_spconv_tensor"].indices.cpu().numpy(), out["encoded_spconv_tensor"].features.cpu().numpy())
+    oi, ofe = om.sort_rows(o_out_f.indices, o_out_f.features)
+    assert np.array_equal(gi, oi) and np.abs(gf - ofe).max() <= 1e-3 * np.abs(ofe).max(), (worst, np.abs(gf - ofe).max() / np.abs(ofe).max())
     up = torch.nn.functional.interpolate(bdf["img_dict"]["mvx_layer1_feat2d"], (H, W), mode="bilinear").cpu().numpy()
     ind = plain.indices.cpu().numpy()
     x1 = ms["x_conv1"].features.cpu().numpy()
