@@ -221,9 +221,15 @@ class LocalTransformer(nn.Module):
         of every layer (actr_transformer.py:482-486): the result of the first layer is reused by the others (the
         reference recomputes it -- 2048 serial FPS iterations -- once per layer)."""
         key = (self.npoint, float(self.radius), self.nsample, xyz_in._version, tuple(xyz_in.shape))
-        hit = getattr(_GEO, "entry", None)
-        if hit is not None and hit[0]() is xyz_in and hit[1] == key and not torch.is_grad_enabled():
-            return hit[2], hit[3]
+        # a few entries: the geometry of the NEXT batch may be prepared (VoxelBackBone8xFusion.prefetch) before this batch's
+        # layers ask for theirs
+        entries = getattr(_GEO, "entries", None)
+        if entries is None:
+            entries = _GEO.entries = []
+        if not torch.is_grad_enabled():
+            for hit in entries:
+                if hit[0]() is xyz_in and hit[1] == key:
+                    return hit[2], hit[3]
         xyz = xyz_in.contiguous()
         fps_idx = _ops.furthest_point_sample(xyz, self.npoint)                          # [B,np]
         xyz_t = xyz.transpose(1, 2).contiguous()
@@ -231,16 +237,20 @@ class LocalTransformer(nn.Module):
         group_idx = _ops.ball_query(0.0, self.radius, self.nsample, xyz, new_xyz)       # [B,np,ns]
         group_xyz = _ops.group_points(xyz_t, group_idx)                                 # [B,3,np,ns] (absolute)
         if not torch.is_grad_enabled():
-            _GEO.entry = (weakref.ref(xyz_in), key, group_idx, group_xyz)
+            entries[:] = [e for e in entries if e[0]() is not None][-3:]
+            entries.append((weakref.ref(xyz_in), key, group_idx, group_xyz))
         return group_idx, group_xyz
 
     def _row_plan(self, xyz_in, group_idx, group_xyz):
         """Index tensors of the row-layout path, functions of the geometry alone (cached with it): gather rows of the
         grouped points in [ns, B*np] order, the grouped coordinates as rows, and for every point the row of the
         'unique' winner (lowest flat group position, pointformer.py:320-328) or -1."""
-        hit = getattr(_GEO, "rows", None)
-        if hit is not None and hit[0] is group_idx:
-            return hit[1]
+        rows = getattr(_GEO, "rows", None)
+        if rows is None:
+            rows = _GEO.rows = []
+        for hit in rows:
+            if hit[0] is group_idx:
+                return hit[1]
         B, np_, ns = group_idx.shape
         N = xyz_in.shape[1]
         base = (torch.arange(B, device=group_idx.device, dtype=torch.int64) * N)[:, None, None]
@@ -260,7 +270,8 @@ class LocalTransformer(nn.Module):
                      torch.arange(B * N, device=w.device))
         dst = dst[:R]
         plan = (sel, gx, src.reshape(-1), has.reshape(-1, 1), dst)
-        _GEO.rows = (group_idx, plan)
+        del rows[:-3]
+        rows.append((group_idx, plan))
         return plan
 
     def _pe_rows(self, gx):

@@ -139,6 +139,8 @@ class VoxelRCNNWorkload(object):
         from .backbones import VoxelBackBone8xFusion
         self.batch = B = args.batch or 8
         self.dev = dev
+        self.prefetch = (bool(getattr(args, "prefetch", True)) and os.environ.get("DF3D_VOXEL_STREAM", "1") == "1"
+                         and os.environ.get("DF3D_VR_AHEAD", "1") == "1")
         torch.manual_seed(0)
         cfg = dict(NAME='VoxelBackBone8xFusion', USE_IMG=True, FUSION_POS=[1, 4], FUSION_METHOD='MVX+ACTRv2',
                    FEATURE_LEVELS=[0], LT_CFG=dict(npoint=2048, radius=2.0, nsample=32, num_layers=2),
@@ -169,12 +171,23 @@ class VoxelRCNNWorkload(object):
                 "self-attention, d_model 64, 4 encoder layers), KITTI 0.05 m voxel, bs=%d, 1 camera [BASELINE configs[4]]"
                 % self.batch)
 
-    @torch.no_grad()
-    def step(self, i, stage):
+    def _batch(self, i):
         fr = self.frames[i % len(self.frames)]
         f, c = _voxelize_batch(fr["points"], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 40000)
-        bd = dict(voxel_features=f, voxel_coords=c, batch_size=self.batch, lidar2img=fr["l2i"], image_hw=self.hw,
-                  img_dict={"mvx_layer1_feat2d": fr["mvx"], "layer1_feat2d": fr["img"]})
+        return dict(voxel_features=f, voxel_coords=c, batch_size=self.batch, lidar2img=fr["l2i"], image_hw=self.hw,
+                    img_dict={"mvx_layer1_feat2d": fr["mvx"], "layer1_feat2d": fr["img"]})
+
+    @torch.no_grad()
+    def step(self, i, stage):
+        staged = self.__dict__.pop("_staged", None)
+        bd = staged[1] if staged is not None and staged[0] == i else self._batch(i)
+        if self.prefetch:
+            # the data loader's next batch (round 5): its voxelisation and the stride-8 query geometry -- three strided index
+            # sets, furthest point sampling, ball query -- start now, beside this batch (the reference voxelises batch k + 1 in
+            # its DataLoader workers while the GPU step of batch k runs; VoxelBackBone8xFusion.prefetch)
+            nxt = self._batch(i + 1)
+            self.model.prefetch(nxt["voxel_coords"], nxt)
+            self._staged = (i + 1, nxt)
         return self.model(bd)
 
     def check(self, out, stage):

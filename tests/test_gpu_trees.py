@@ -484,12 +484,15 @@ def test_pipelined_frames_equal_isolated_frames():
     old = os.environ.get("DF3D_VOXEL_STREAM")
     try:
         os.environ["DF3D_VOXEL_STREAM"] = "0"
+        assert wl.prefetch
+        wl.prefetch = False                                       # isolated frames: nothing of a batch starts before its step
         want = []
         for k in range(3):
             out = wl.step(k, "detect")
             torch.cuda.synchronize()
             want.append((out["encoded_spconv_tensor"].features.clone(), out["encoded_spconv_tensor"].indices.clone()))
         os.environ["DF3D_VOXEL_STREAM"] = "1"
+        wl.prefetch = True              # round 5: batch k + 1's voxelisation, index sets, FPS and ball query beside batch k
         got = []
         for k in range(18):                                       # six rounds over the frames, back to back
             out = wl.step(k, "detect")
