@@ -23,3 +23,19 @@ def golden():
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
     return load
+
+
+@pytest.fixture(autouse=True)
+def _no_silent_operand_overflow(request):
+    """Round 5: the two-part operand format (fp16 hi + lo, csrc/common.h) is range-limited and reports a value it could not
+    hold through a sticky device flag.  Every GPU test ends with that flag clear -- a workload of this suite that left the
+    range would otherwise pass on wrong numbers (tests that raise the flag on purpose reset it themselves)."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import torch
+    if not torch.cuda.is_available():
+        return
+    from dualfusion import ops
+    hit, where = ops.split_overflow(reset=True)
+    assert not hit, "a value left the range of the fp16 operand split during this test (raised in: %s)" % where
