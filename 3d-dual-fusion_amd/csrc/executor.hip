@@ -122,6 +122,8 @@ struct RunState {
   hipEvent_t done = nullptr;   // split API: the geometry phase is complete on its stream
   hipEvent_t img_done = nullptr;   // frame head: the image projection is complete on the worker's second stream
   int geometry_layers = 0;     // layers whose geometry has been built
+  const float *input_features = nullptr;   // df3d_backbone_convs_range: the network input of the first range
+  int range_next = 0;                       // ... and the layer the next range starts at
 };
 
 int fail_arena(RunState &S, Bump *m, size_t *arena_used, size_t arena_bytes) {
@@ -548,6 +550,50 @@ extern "C" int df3d_backbone_convs(void *handle, const float *features, void *ar
     }
     if (rc) return rc;
   }
+  if (arena_used) *arena_used = S.fmem->used;
+  return DF3D_OK;
+}
+
+// The convolutions of layers [first, last) of a prepared chain (round 5): a caller whose chain is interrupted by steps that MODIFY
+// a stage's features (a fusion layer between two stages) builds the geometry of the WHOLE chain ahead -- it depends on the
+// coordinates alone, whatever happens to the features -- and runs the convolutions range by range: `features` of the first range
+// (first == 0) is the network input; of a later range it REPLACES the fp32 rows of layer first - 1 (same index set and
+// channel count; the operand split of those rows is rebuilt from them).  Ranges must be consecutive and use the same arena.
+extern "C" int df3d_backbone_convs_range(void *handle, const float *features, int first, int last, void *arena,
+                                         size_t arena_bytes, df3d_layer_view *views, size_t *arena_used, void *stream_) {
+  DF3D_CHECK_ARG(handle && features && arena && views, "backbone_convs_range: null argument");
+  RunState &S = *(RunState *)handle;
+  DF3D_CHECK_ARG(S.geometry_layers == S.nlayers, "backbone_convs_range: the geometry phase of this handle did not finish");
+  DF3D_CHECK_ARG(first >= 0 && first < last && last <= S.nlayers, "backbone_convs_range: bad layer range [%d, %d) of %d", first,
+                 last, S.nlayers);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (first == 0) {
+    DF3D_HIP(hipStreamWaitEvent(stream, S.done, 0));
+    S.own_f = Bump(arena, arena_bytes);
+    S.fmem = &S.own_f;
+    S.split0 = S.rows16_0 = nullptr;
+    for (auto &o : S.outs) o.features = nullptr, o.split = nullptr, o.rows16 = nullptr, o.ran = false;
+    S.input_features = features;
+  } else {
+    DF3D_CHECK_ARG(S.range_next == first && S.fmem == &S.own_f && S.own_f.base == (char *)arena,
+                   "backbone_convs_range: range [%d, %d) does not continue the previous one (next layer %d)", first, last,
+                   S.range_next);
+    LayerOut &p = S.outs[first - 1];
+    DF3D_CHECK_ARG(p.ran, "backbone_convs_range: layer %d has not run", first - 1);
+    p.features = (float *)features;            // the hook's rows; their operand formats are rebuilt on demand
+    p.split = nullptr;
+    p.rows16 = nullptr;
+  }
+  for (int li = first; li < last; ++li) {
+    int rc = conv_layer(S, li, S.input_features, views, stream);
+    if (rc == DF3D_ENOMEM) {
+      if (arena_used) *arena_used = S.fmem->used;
+      set_error("backbone_convs_range: arena of %zu bytes is too small (needed more than %zu)", arena_bytes, S.fmem->used);
+      return DF3D_ENOMEM;
+    }
+    if (rc) return rc;
+  }
+  S.range_next = last;
   if (arena_used) *arena_used = S.fmem->used;
   return DF3D_OK;
 }

@@ -226,6 +226,7 @@ SIGNATURES = {
     "df3d_backbone_geometry": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
     "df3d_backbone_convs": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "df3d_backbone_convs_range": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "df3d_backbone_geometry_wait": (c_int, [c_void_p, c_void_p]),
     "df3d_frame_head_image_wait": (c_int, [c_void_p, c_void_p]),
     "df3d_head_worker_create": (c_void_p, [c_int]),

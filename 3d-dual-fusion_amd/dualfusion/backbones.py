@@ -628,7 +628,7 @@ class VoxelBackBone8x(nn.Module):
                 keep[name] = t
                 return t
 
-            runner.run(x0, hook=hook)
+            runner.run(x0, hook=hook, prepared=batch_dict.get("prepared"))
             x_conv1, x_conv2, x_conv3, x_conv4 = keep["conv1"], keep["conv2"], keep["conv3"], keep["conv4"]
         else:
             x = self.conv_input(x0)
@@ -828,7 +828,42 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         if pre is not None:
             self.__dict__["_fuse4_pre"] = pre
 
-    def prefetch(self, voxel_coords, batch_dict):
+    # ---- frame head a batch ahead (dualfusion/prefetch.py): voxelisation + EVERY rulebook of the chain on the native worker ----
+    def prefetch_frame(self, key, points_list, voxel_size, point_cloud_range, max_points, max_voxels):
+        """Round 5: voxelisation (+ mean VFE) of these point clouds and every rulebook of the conv chain -- the whole chain's, on
+        both sides of the fusion layers: geometry depends on the coordinates alone -- on the module's native worker thread,
+        with all their count round trips; returns at once.  `take_head(key)` hands back (features, coors, prepared) for
+        `forward(dict(voxel_features=, voxel_coords=, prepared=, ...))`.  The clouds must be complete in device memory."""
+        if self.training or not points_list or not points_list[0].is_cuda:
+            return False
+        with torch.no_grad():
+            runner = self._runner()
+        if runner is None or runner.full is None:
+            return False
+        head = self.__dict__.get("_head_worker")
+        if head is None:
+            from .prefetch import FrameHead
+            head = self.__dict__["_head_worker"] = FrameHead(points_list[0].device)
+        if len(head._pending) >= 3:
+            head.drop_all()
+        cap = max_voxels if isinstance(max_voxels, int) else max_voxels[1]
+        vox = dict(voxel_size=voxel_size, coors_range=point_cloud_range, max_points=max_points, max_voxels=cap, break_at_cap=True)
+        head.submit(key, runner.full, points_list, vox, [int(v) for v in self.sparse_shape], None)
+        return True
+
+    def take_head(self, key):
+        head = self.__dict__.get("_head_worker")
+        prep = head.take(key) if head is not None else None
+        if prep is None or prep.geometry is None:
+            return None
+        return prep
+
+    def close(self):
+        head = self.__dict__.pop("_head_worker", None)
+        if head is not None:
+            head.close()
+
+    def prefetch(self, voxel_coords, batch_dict, prepared=None):
         """Round 5: the stride-8 query geometry of a LATER forward(batch_dict with these `voxel_coords`) started NOW -- a batch
         ahead, beside the convolutions of the batch in front of it.  Furthest point sampling is 2048 serial iterations on
         one workgroup per sample (5.2 ms on 8 of the 256 CUs); started inside its own forward it is the step's critical chain
@@ -838,7 +873,7 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         if not voxel_coords.is_cuda or torch.is_grad_enabled() or self.training:
             return False
         ready = getattr(voxel_coords, "_df3d_ready", None) or torch.cuda.current_stream().record_event()
-        pre = self._fuse4_geometry(voxel_coords, batch_dict, ready)
+        pre = self._fuse4_geometry(voxel_coords, batch_dict, ready, prepared=prepared)
         if pre is None:
             return False
         # (a short list: the batch in front of this one has not consumed its entry yet)
@@ -847,7 +882,8 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         ahead.append((voxel_coords, pre))
         return True
 
-    def _fuse4_geometry(self, coords, batch_dict, ready):
+    def _fuse4_geometry(self, coords, batch_dict, ready, prepared=None):
+        """`prepared`: the frame head's PreparedGeometry of the whole chain (`take_head`): conv4's index set is in it already."""
         previous = None
         if (4 not in self.fusion_pos or "ACTR" not in self.fusion_method or torch.is_grad_enabled()
                 or os.environ.get("DF3D_VR_PREFETCH", "1") != "1" or not coords.is_cuda or coords.shape[0] == 0):
@@ -865,12 +901,18 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
             self.__dict__["_geo_turn"] = 0
         self.__dict__["_geo_turn"] ^= 1
         side = sides[self.__dict__["_geo_turn"]]
-        side.wait_event(ready)
+        if prepared is None:
+            side.wait_event(ready)
         # the previous frame's tensors stay referenced until here: their readers on the main stream were queued before `ready`
         B = batch_dict["batch_size"]
         with torch.cuda.stream(side):
             ind, shape = coords.int().contiguous(), list(self.sparse_shape)
-            for stage in (self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4):
+            if prepared is not None and prepared.stages is not None and "conv4" in prepared.stages:
+                # the worker built it with the rest of the chain's geometry: the side stream waits (on the device) for that
+                prepared.wait()
+                ind, shape = prepared.stages["conv4"].indices, list(prepared.stages["conv4"].spatial_shape)
+            else:
+              for stage in (self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4):
                 for m in stage.modules():
                     if isinstance(m, SparseConvolution) and not m.subm:
                         out_shape = get_conv_output_size(shape, m.kernel_size, m.stride, m.padding, m.dilation)

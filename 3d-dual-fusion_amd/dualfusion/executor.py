@@ -269,9 +269,11 @@ class BackbonePlan(object):
             self._ring_last = slot
         return self._export(views, (arena,), coors, batch_size)
 
-    def _export(self, views, arenas, coors, batch_size, features=True):
+    def _export(self, views, arenas, coors, batch_size, features=True, only=None, state=None):
         """views (filled by the native call) -> {stage name: SparseConvTensor} whose tensors are views into the arenas.
-        features=False: the geometry only (index tensors, directories); the feature tensors are attached by `run_convs`."""
+        features=False: the geometry only (index tensors, directories); the feature tensors are attached by `run_convs`.
+        only = (first, last): the stages whose layer lies in that range (`run_convs_range`); `state`: the (indice_dict,
+        directories) pair the stages of one frame share."""
         spans = [(a.data_ptr(), a.data_ptr() + a.numel(), a) for a in arenas]
 
         def view(ptr, nbytes, dtype, shape):
@@ -281,8 +283,11 @@ class BackbonePlan(object):
                     return a[off:off + nbytes].view(dtype).view(shape)
             raise _lib.Df3dError("executor: a view points outside the arenas")
 
-        out, idict, dirs = {}, {}, DirectoryCache()
+        out = {}
+        idict, dirs = state if state is not None else ({}, DirectoryCache())
         for name, li in self.exports.items():
+            if only is not None and not (only[0] <= li < only[1]):
+                continue
             v = views[li]
             # SubM stages of the first index set keep the caller's index tensor
             ind = coors if v.indices == coors.data_ptr() else view(v.indices, v.n * 16, torch.int32, (v.n, 4))
@@ -302,6 +307,8 @@ class BackbonePlan(object):
                 dirs.put(ind, _ops.GridDirectory(blob, None, batch_size, list(t.spatial_shape)))
             out[name] = t
         for src, li in self.geometry:
+            if src not in out:
+                continue
             v = views[li]
             from .spconv.structure import Rulebook
             x = out[src]
@@ -378,6 +385,48 @@ class BackbonePlan(object):
             break
         out = self._export(geo.views, (arena, geo.slot.arenas["geo"]), geo.coors, geo.batch_size)
         geo.release()
+        return out
+
+
+    def run_convs_range(self, geo, features, first, last):
+        """`df3d_backbone_convs_range`: layers [first, last) of a PreparedGeometry of THIS plan on the current stream; `features`
+        = the network input (first == 0) or the rows that replace layer first - 1's output (a hook modified them).  Ranges are
+        consecutive; the last one (last == len(specs)) releases the geometry handle.  -> {stage name: SparseConvTensor} of
+        the stages inside the range, or None when the arena ran out in a LATER range (the caller finishes the frame on the
+        one-call path; the arena is larger from the next frame on)."""
+        lib = _lib.load()
+        if geo.plan is not self or geo.handle is None:
+            raise _lib.Df3dError("executor.convs_range: the geometry belongs to another plan or was already consumed")
+        feats = features.contiguous()
+        if feats.dtype != torch.float32:
+            feats = feats.float()
+        nl = len(self.specs)
+        if first == 0:
+            if self._signature() != geo.sig:
+                geo.release()
+                return None
+            mark = torch.cuda.current_stream(feats.device).record_event()
+            self._frames.consumed(geo.slot, mark)
+            geo._range_state = ({}, DirectoryCache())
+        used = ctypes.c_size_t(0)
+        while True:
+            arena = geo.slot.arena("feat", self._arena_bytes, feats.device)
+            rc = lib.df3d_backbone_convs_range(geo.handle, _ops._ptr(feats), int(first), int(last), _ops._ptr(arena),
+                                               arena.numel(), geo.views, ctypes.byref(used), _ops._stream())
+            if rc == _lib.DF3D_ENOMEM and self._arena_bytes < (64 << 30):
+                self._arena_bytes *= 2
+                if first == 0:
+                    torch.cuda.synchronize(feats.device)
+                    continue
+                geo.release()
+                return None
+            _lib.check(rc, "df3d_backbone_convs_range")
+            break
+        geo._range_keep = getattr(geo, "_range_keep", []) + [feats]        # the replaced rows are read by later launches
+        out = self._export(geo.views, (arena, geo.slot.arenas["geo"]), geo.coors, geo.batch_size, only=(first, last),
+                           state=geo._range_state)
+        if last >= nl:
+            geo.release()
         return out
 
 
@@ -484,6 +533,35 @@ class SegmentedRunner(object):
             if plan is None:
                 raise Unsupported("segment %d" % k)
             self.segments.append((a, b, plan))
+        # Round 5: ONE plan over the whole chain as well -- its geometry (every rulebook, the geometry-only tail) depends on the
+        # coordinates alone and can be built a frame ahead whatever the hooks do to the features; the convolutions then run
+        # range by range (`BackbonePlan.run_convs_range`).  Layer ranges of the segments inside that plan:
+        geo = [(self.stages[-1][0], geometry_module)] if geometry_module is not None else ()
+        self.full = compile_stages(self.stages, geometry_stages=geo) if len(self.segments) > 1 else self.segments[0][2]
+        self.ranges = []
+        if self.full is not None:
+            for k, (a, b, _) in enumerate(self.segments):
+                lo = 0 if a == 0 else self.full.exports[self.stages[a - 1][0]] + 1
+                hi = len(self.full.specs) if b == len(self.stages) else self.full.exports[self.stages[b - 1][0]] + 1
+                self.ranges.append((lo, hi))
+
+    def _run_ranges(self, x, hook, prepared):
+        """The frame on the prepared geometry of the whole chain; None if it has to fall back to the per-segment path."""
+        outs = {}
+        feats = x.features
+        for k, (a, b, _) in enumerate(self.segments):
+            lo, hi = self.ranges[k]
+            res = self.full.run_convs_range(prepared, feats, lo, hi)
+            if res is None:
+                return None if k == 0 else (outs, k)
+            for i in range(a, b):
+                name = self.stages[i][0]
+                t = res[name]
+                if hook is not None:
+                    t = hook(i, name, t)
+                outs[name] = t
+            feats = outs[self.stages[b - 1][0]].features
+        return outs, len(self.segments)
 
     def run(self, x, hook=None, prepared=None):
         """x: SparseConvTensor (network input).  hook(stage_index, name, tensor) -> tensor is called after every
@@ -491,8 +569,18 @@ class SegmentedRunner(object):
         which is fine for hooks that only READ; hooks that MODIFY features must sit at a cut.
         prepared: PreparedGeometry of the FIRST segment's plan (a frame head built ahead, dualfusion/prefetch.py).
         Returns {stage name: tensor}."""
-        outs = {}
+        outs, k0 = {}, 0
+        if prepared is not None and len(self.segments) > 1 and prepared.plan is self.full:
+            got = self._run_ranges(x, hook, prepared)
+            if got is not None:
+                outs, k0 = got
+                if k0 == len(self.segments):
+                    return outs
+                x = outs[self.stages[self.segments[k0][0] - 1][0]]      # (the arena ran out: the rest on the segment plans)
+            prepared = None
         for k, (a, b, plan) in enumerate(self.segments):
+            if k < k0:
+                continue
             if k == 0 and prepared is not None and prepared.plan is plan:
                 res = plan.run_convs(prepared, x.features)
             else:

@@ -141,6 +141,7 @@ class VoxelRCNNWorkload(object):
         self.dev = dev
         self.prefetch = (bool(getattr(args, "prefetch", True)) and os.environ.get("DF3D_VOXEL_STREAM", "1") == "1"
                          and os.environ.get("DF3D_VR_AHEAD", "1") == "1")
+        self.head_worker = os.environ.get("DF3D_VR_HEAD", "1") == "1"
         torch.manual_seed(0)
         cfg = dict(NAME='VoxelBackBone8xFusion', USE_IMG=True, FUSION_POS=[1, 4], FUSION_METHOD='MVX+ACTRv2',
                    FEATURE_LEVELS=[0], LT_CFG=dict(npoint=2048, radius=2.0, nsample=32, num_layers=2),
@@ -171,23 +172,67 @@ class VoxelRCNNWorkload(object):
                 "self-attention, d_model 64, 4 encoder layers), KITTI 0.05 m voxel, bs=%d, 1 camera [BASELINE configs[4]]"
                 % self.batch)
 
+    def _dict(self, i, f, c, **extra):
+        fr = self.frames[i % len(self.frames)]
+        bd = dict(voxel_features=f, voxel_coords=c, batch_size=self.batch, lidar2img=fr["l2i"], image_hw=self.hw,
+                  img_dict={"mvx_layer1_feat2d": fr["mvx"], "layer1_feat2d": fr["img"]})
+        bd.update(extra)
+        return bd
+
     def _batch(self, i):
         fr = self.frames[i % len(self.frames)]
         f, c = _voxelize_batch(fr["points"], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 40000)
-        return dict(voxel_features=f, voxel_coords=c, batch_size=self.batch, lidar2img=fr["l2i"], image_hw=self.hw,
-                    img_dict={"mvx_layer1_feat2d": fr["mvx"], "layer1_feat2d": fr["img"]})
+        return self._dict(i, f, c)
+
+    def close(self):
+        self.model.close()
 
     @torch.no_grad()
     def step(self, i, stage):
-        staged = self.__dict__.pop("_staged", None)
-        bd = staged[1] if staged is not None and staged[0] == i else self._batch(i)
-        if self.prefetch:
-            # the data loader's next batch (round 5): its voxelisation and the stride-8 query geometry -- three strided index
-            # sets, furthest point sampling, ball query -- start now, beside this batch (the reference voxelises batch k + 1 in
-            # its DataLoader workers while the GPU step of batch k runs; VoxelBackBone8xFusion.prefetch)
-            nxt = self._batch(i + 1)
-            self.model.prefetch(nxt["voxel_coords"], nxt)
-            self._staged = (i + 1, nxt)
+        if not self.prefetch:
+            return self.model(self._batch(i))
+        # The data loader runs two batches ahead of the GPU step (round 5), as the reference's DataLoader workers do for the
+        # voxelisation (VR/pcdet/datasets/dataset.py `prepare_data` -> `transform_points_to_voxels` in worker processes):
+        #   batch i + 2   voxelisation + mean VFE + every rulebook of the conv chain on the backbone's native worker thread
+        #                 (`prefetch_frame`: the count round trips of five index sets leave the queueing thread),
+        #   batch i + 1   its head is taken and the stride-8 query geometry -- furthest point sampling (2048 serial iterations),
+        #                 ball query -- starts on a side stream, beside this batch (`prefetch`),
+        #   batch i       the convolutions on the prepared rulebooks, the fusion layers between them.
+        heads = self.__dict__.setdefault("_heads", {})
+        if self.__dict__.get("_last_step") != i - 1 and heads:
+            # the caller jumped (another pass of bench.py starts over): heads prepared for other step numbers are views into
+            # frame slots that later frames have recycled -- drop them all (the worker's pending jobs included)
+            for bd in heads.values():
+                if bd is not None and bd.get("prepared") is not None:
+                    bd["prepared"].release()
+            heads.clear()
+            hw = self.model.__dict__.get("_head_worker")
+            if hw is not None:
+                hw.drop_all()
+            self.model.__dict__.pop("_fuse4_ahead", None)
+        self._last_step = i
+        ahead = 2 if self.head_worker else 0
+        for j in range(i, i + ahead + 1):
+            if j not in heads and self.head_worker:
+                fr = self.frames[j % len(self.frames)]
+                heads[j] = None if self.model.prefetch_frame(("vr", j), fr["points"], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5,
+                                                             40000) else self._batch(j)
+        for j in (i, i + 1):
+            if j not in heads:
+                heads[j] = self._batch(j)                      # (no worker: voxelised on the voxel stream, a batch ahead)
+                fresh = True
+            elif heads[j] is None:
+                prep = self.model.take_head(("vr", j))
+                heads[j] = (self._batch(j) if prep is None else
+                            self._dict(j, prep.feats, prep.coors, prepared=prep.geometry, _head=prep))
+                fresh = True
+            else:
+                fresh = False
+            if fresh:
+                self.model.prefetch(heads[j]["voxel_coords"], heads[j], prepared=heads[j].get("prepared"))
+        bd = heads.pop(i)
+        if "_head" in bd:
+            bd.pop("_head").hand_over()                        # this stream waits (on the device) for the worker's kernels
         return self.model(bd)
 
     def check(self, out, stage):

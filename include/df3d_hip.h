@@ -925,6 +925,16 @@ int df3d_backbone_geometry(const df3d_layer *layers, int nlayers, const int32_t 
                            df3d_layer_view *views, size_t *arena_used, void **handle);
 int df3d_backbone_convs(void *handle, const float *features, void *arena, size_t arena_bytes, df3d_layer_view *views,
                         size_t *arena_used, void *stream);
+/* Round 5: the same convolutions range by range, for chains that a feature-modifying step interrupts (the fusion layers of
+ * VR/pcdet/models/backbones_3d/spconv_backbone.py:829-916 sit between conv1 / conv2 and behind conv4): the geometry of the
+ * WHOLE chain is built ahead (it depends on the coordinates alone), then
+ *   df3d_backbone_convs_range(handle, features, first, last, ...)   layers [first, last) on `stream`;
+ * `features` of the first range (first == 0) is the network input, of a later range it REPLACES the fp32 rows of layer
+ * first - 1 (same index set / channels; their operand split is rebuilt).  Ranges are consecutive and share one arena; a
+ * DF3D_ENOMEM of the first range may be retried with a larger arena, of a later one not (the caller finishes the frame on
+ * df3d_backbone_run over the remaining layers). */
+int df3d_backbone_convs_range(void *handle, const float *features, int first, int last, void *arena, size_t arena_bytes,
+                              df3d_layer_view *views, size_t *arena_used, void *stream);
 /* ------------------------------------------------------------------------------------
  * Frame head on a native worker thread (round 4): everything of a frame that depends on its RAW INPUTS alone, with all its
  * count round trips, built while the caller still queues the previous frame -- what the reference's DataLoader worker
