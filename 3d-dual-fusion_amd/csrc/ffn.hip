@@ -354,6 +354,20 @@ extern "C" int df3d_ffn_pack(const float *w1, const float *w2, int d_model, int 
 
 static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, int d_model, hipStream_t stream) {
   if (d_model == 64) {                           // 64-wide rows: 8 waves x 16 rows, either precision
+    static const int cfg64 = getenv("DF3D_FFN_CFG64") ? atoi(getenv("DF3D_FFN_CFG64")) : 0;
+    if (!jobs.s[0].bf16 && cfg64 == 44) {
+      hipLaunchKernelGGL((ffn_split_kernel<4, 4, 2, 64>), dim3(cdiv(max_rows, 256), njobs), dim3(256), 0, stream, jobs);
+      DF3D_LAUNCH_CHECK();
+      return DF3D_OK;
+    }
+    // (round 5, tools/ubench/ffn_probe64.py: 2 x 160 k rows 390 us with one row tile per wave, 327 us with two -- every
+    // weight fragment read from LDS feeds two row tiles --, 370 us with four on one wave per SIMD: the exposed fragment reads
+    // of a lone wave cost more than the halved LDS traffic saves)
+    if (!jobs.s[0].bf16 && (cfg64 == 82 || (cfg64 == 0 && (long long)cdiv(max_rows, 256) * njobs >= 192))) {
+      hipLaunchKernelGGL((ffn_split_kernel<8, 2, 2, 64>), dim3(cdiv(max_rows, 256), njobs), dim3(512), 0, stream, jobs);
+      DF3D_LAUNCH_CHECK();
+      return DF3D_OK;
+    }
     if (jobs.s[0].bf16)
       hipLaunchKernelGGL((ffn_split_kernel<8, 1, 1, 64>), dim3(cdiv(max_rows, 128), njobs), dim3(512), 0, stream, jobs);
     else
@@ -390,7 +404,8 @@ static int ffn_launch(const FfnJobs &jobs, int njobs, long long max_rows, int d_
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
   }
-  if (cfg == 42) hipLaunchKernelGGL((ffn_split_kernel<4, 2>), dim3(cdiv(max_rows, 128), njobs), dim3(256), 0, stream, jobs);
+  if (cfg == 44) hipLaunchKernelGGL((ffn_split_kernel<4, 4>), dim3(cdiv(max_rows, 256), njobs), dim3(256), 0, stream, jobs);
+  else if (cfg == 42) hipLaunchKernelGGL((ffn_split_kernel<4, 2>), dim3(cdiv(max_rows, 128), njobs), dim3(256), 0, stream, jobs);
   else if (cfg == 82) {
     size_t pad = 0;
     if (balance && wg82 <= ncu) {
