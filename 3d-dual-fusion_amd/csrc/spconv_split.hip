@@ -617,7 +617,14 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
   constexpr int WQ = KPS * CT * NP * 64;          // u32x4 per W step tile
   constexpr int NT = NW * 64;
   constexpr int WPT = (WQ + NT - 1) / NT;
-  __shared__ u32x4 Wl[KS][2][WQ];
+  // Round 5: THREE weight stages where the tile is small (one wave group, <= 4 staging loads per thread): the stage of step
+  // s + 1 is then complete one barrier EARLIER, so a wave reads the first B fragments of step s + 1 behind the last matrix
+  // instructions of step s -- before the barrier -- and issues MFMAs right after it.  With two stages every step began with an
+  // exposed LDS round trip (ISA of round 4: s_barrier, 4 x ds_read_b128, s_waitcnt, MFMA ...; the compiler does not move LDS
+  // reads across a barrier, and a step of 12 MFMAs is ~190 clocks of matrix work against ~120 of that round trip).
+  constexpr bool RING3 = KS == 1 && WPT <= 4;
+  constexpr int NST = RING3 ? 3 : 2;
+  __shared__ u32x4 Wl[KS][NST][WQ];
   __shared__ int nbrL[DF3D_MAX_KVOL][TM];
   __shared__ int rowL[TM];
   __shared__ unsigned wg_mask;
@@ -782,6 +789,7 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
             rdy[rt][j][q][d] = (unsigned)__builtin_amdgcn_ds_bpermute((4 * n + g) * 4, (int)raw[rt][j][q][d]);
   };
 #endif
+  u32x4 bnext[2 * NP];                             // RING3: the first B fragments of the next step (read before its barrier)
   auto step = [&](int s, u32x4 (&raw)[RT][KPS][NP], u32x4 (&rawn)[RT][KPS][NP], u32x4 (&wset)[WPT]) {
 #ifdef DF3D_OS_QGATHER
     u32x4 (&cur)[RT][KPS][NP] = rdy;
@@ -794,7 +802,10 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
     // matrix instructions (the other buffer is not read by anybody during this step)
     auto stage_w = [&]() {
       if (!OS_DBG(2)) {
-        if constexpr (WD == 3) {
+        if constexpr (RING3) {
+          store_w((s + 2) % 3, wset);              // W(s + 2) into the stage step s - 1 has left (everybody is past the barrier)
+          load_w(wset);                            // W(s + 5)
+        } else if constexpr (WD == 3) {
           store_w((s + 1) & 1, wset);
           load_w(wset);                            // W(s + 4)
         } else {
@@ -806,7 +817,7 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
     peek_a();                                      // neighbour indices of step s + AD
     constexpr int WPOS = (KPS * CT / 2) > 1 ? 1 : 0;
     if (WPOS == 0) stage_w();
-    const u32x4 *wb = Wl[grp][s & 1] + lane;
+    const u32x4 *wb = Wl[grp][RING3 ? s % 3 : (s & 1)] + lane;
 #ifdef DF3D_OS_PRODUCT_MAJOR
     // experiment: the three products of a step run product-major over groups of G column tiles, so that two matrix
     // instructions on the same accumulator are G instructions apart (the default order keeps them 2 apart, and the
@@ -846,7 +857,10 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
     // B fragments of the next column pair are fetched from LDS while the MFMAs of the current pair run
     constexpr int NBATCH = KPS * CT / 2;
     u32x4 bq[2][2 * NP];
-    if (!OS_DBG(16)) {
+    if constexpr (RING3) {
+#pragma unroll
+      for (int q = 0; q < 2 * NP; ++q) bq[0][q] = bnext[q];
+    } else if (!OS_DBG(16)) {
 #pragma unroll
       for (int q = 0; q < 2 * NP; ++q) bq[0][q] = wb[q * 64];
     }
@@ -917,6 +931,11 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
       }
       if (OS_DBG(8)) __builtin_amdgcn_s_setprio(0);
     }
+    if constexpr (RING3) {                         // stage (s + 1) % 3 was stored during step s - 1: complete since this step's barrier
+      const u32x4 *wn = Wl[grp][(s + 1) % 3] + lane;
+#pragma unroll
+      for (int q = 0; q < 2 * NP; ++q) bnext[q] = wn[q * 64];
+    }
     issue_a(raw);
 #ifdef DF3D_OS_QGATHER
     to_operand(rawn);                              // the next step's fragments (gathered two steps ago)
@@ -927,6 +946,15 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
 
   OS_STAMP(1);
   if (steps > 0) {
+    if constexpr (RING3) {
+      load_w(w0);                                  // W(0), W(1): the first two stages
+      load_w(w1);
+      store_w(0, w0);
+      store_w(1, w1);
+      load_w(w1);                                  // W(2), W(3), W(4)
+      load_w(w2);
+      load_w(w0);
+    } else {
     load_w(w0);                                    // W(0)
     store_w(0, w0);
     if constexpr (WD == 3) {
@@ -936,10 +964,16 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
     } else {
       load_w(w0);                                  // W(1)
     }
+    }
 #pragma unroll
     for (int j = 0; j < AD; ++j) {
       peek_a();
       issue_a(ar[j]);
+    }
+    if constexpr (RING3) {                         // step 0's first fragments: behind a barrier of their own
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2 * NP; ++q) bnext[q] = Wl[grp][0][lane + q * 64];
     }
     OS_STAMP(2);
 #ifdef DF3D_OS_QGATHER

@@ -420,6 +420,60 @@ def test_native_executor_matches_module_path():
             assert torch.equal(y_fast, y_slow)
 
 
+def test_prepared_chain_geometry_runs_range_by_range():
+    """Round 5, `df3d_backbone_convs_range`: the geometry of a WHOLE conv chain built ahead (`BackbonePlan.build_geometry` on
+    the uncut plan of a `SegmentedRunner`), the convolutions run range by range around hooks -- (1) with identity hooks every
+    stage is bit-identical to the one-call run of the uncut chain; (2) with a hook that REPLACES a stage's rows (what a
+    fusion layer does) everything behind the cut equals the per-segment path fed the same replaced rows; (3) the SparseConv
+    geometry the tail needs (conv_out's rulebook) is attached to the last stage either way."""
+    from dualfusion import ops, spconv, synth
+    from dualfusion.backbones import VoxelBackBone8x
+    from dualfusion.executor import build_runner
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B = 2
+    m = VoxelBackBone8x(dict(NAME='VoxelBackBone8x'), 4, [1408, 1600, 40])
+    import detgen                                           # lively deterministic weights / BatchNorm statistics
+    sd = detgen.det_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    clouds = [torch.from_numpy(synth.kitti_sweep(seed=70 + b)[:, :4].copy()).to(dev) for b in range(B)]
+    f, c = ops.hard_voxelize_clouds(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 40000)
+    stages = [("conv_input", m.conv_input), ("conv1", m.conv1), ("conv2", m.conv2), ("conv3", m.conv3), ("conv4", m.conv4)]
+    with torch.no_grad():
+        whole = build_runner(stages, cuts=[], geometry_module=m.conv_out)
+        cut = build_runner(stages, cuts=[1, 3], geometry_module=m.conv_out)
+        assert whole is not None and cut is not None and len(cut.segments) == 3 and cut.full is not None
+        assert cut.ranges[0][0] == 0 and cut.ranges[-1][1] == len(cut.full.specs)
+        assert all(a[1] == b[0] for a, b in zip(cut.ranges, cut.ranges[1:]))
+        x0 = spconv.SparseConvTensor(f, c, m.sparse_shape, B)
+        want = whole.run(x0)
+        geo = cut.full.build_geometry(c, f.shape[1], B, m.sparse_shape)
+        got = cut.run(x0, prepared=geo)
+        assert geo.handle is None                              # the last range released the handle
+        for name, _ in stages:
+            assert torch.equal(got[name].indices, want[name].indices), name
+            assert torch.equal(got[name].features, want[name].features), name
+        assert torch.equal(m.conv_out(got["conv4"]).features, m.conv_out(want["conv4"]).features)
+
+        # a hook that replaces rows at both cuts
+        def hook(i, name, t):
+            if name == "conv1":
+                return t.replace_feature(t.features * 0.5 + 0.25)
+            if name == "conv3":
+                return t.replace_feature(torch.relu(t.features - 0.1))
+            return t
+        ref = cut.run(x0, hook=hook)                            # per-segment plans (geometry built inside each call)
+        geo = cut.full.build_geometry(c, f.shape[1], B, m.sparse_shape)
+        got = cut.run(x0, hook=hook, prepared=geo)
+        for name, _ in stages:
+            assert torch.equal(got[name].indices, ref[name].indices), name
+            assert torch.equal(got[name].features, ref[name].features), name
+        assert float(want["conv4"].features.abs().max()) > 0 and not torch.equal(got["conv4"].features, want["conv4"].features)
+        assert torch.equal(m.conv_out(got["conv4"]).features, m.conv_out(ref["conv4"]).features)
+    torch.cuda.synchronize()
+
+
 def test_native_executor_table_follows_every_parameter():
     """an in-place edit of ANY tensor the folded table is built from -- conv bias, BatchNorm bias /
     running_mean alone, not only filters / running_var / BatchNorm weight -- must rebuild the table: after each edit the
