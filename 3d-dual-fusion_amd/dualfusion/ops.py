@@ -24,7 +24,16 @@ def _stream():
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    if t is None:
+        return ctypes.c_void_p(0)
+    rec = _lib._recorder
+    if rec is not None:
+        # a launch tape is recording (dualfusion/tape.py): the tape re-issues this ADDRESS, so it keeps the tensor -- a module
+        # that replaces its cached packs / plans later (a precision switch, a new parameter version) then frees nothing a
+        # replay still reads (round 5: bench.py's precision probe switched modes outside the detector's forward, the modules
+        # re-packed, and the tape of the returning mode replayed freed addresses: memory fault)
+        rec._tape.keep.append(t)
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _chk(t, dtype, name):

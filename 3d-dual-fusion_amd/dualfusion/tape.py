@@ -83,6 +83,7 @@ class LaunchTape(object):
         self.device = torch.device(device)
         self.pool = torch.cuda.MemPool()
         self.calls = []            # (name, fn, args list, index of the stream argument, [(arg index, input index, offset)])
+        self.keep = []             # every tensor whose address a recorded call carries (ops._ptr): alive as long as the tape
         self.result = None
         self.impure = []           # ATen operators the recorded section ran besides the library's launches (must be empty)
         self._ranges = []
@@ -94,6 +95,7 @@ class LaunchTape(object):
             raise _lib.Df3dError("launch tape: a recording is already in progress")
         self._ranges = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in inputs]
         self.calls = []
+        self.keep = []
         lib = _lib.load()
         _lib._recorder = _Recorder(lib, self)
         purity = _PurityMode()

@@ -784,4 +784,28 @@ def test_launch_tape_over_neck_and_head_equals_plain_detector():
             for j, (pts, ex) in enumerate(frames):
                 for a, b in zip(run(taped, pts, ex, True), run(plain, pts, ex, True)):
                     assert torch.equal(a, b), ("back", rnd, j)
+        # round 5 (found by bench.py's precision probe: memory fault): a precision switch OUTSIDE the detector's forward -- the
+        # neck and the head called directly in another mode and back -- makes the modules replace their packed filters / plans
+        # without the taped section ever seeing another key.  The tape keeps every tensor whose address it recorded, so the
+        # replay that follows reads live memory with the right contents.
+        assert taped._tail_tape.stats["replayed"] > 0 and isinstance(next(iter(taped._tail_tape.tapes.values())), object)
+        for mode in ("fp32", "split3", old_mode):
+            _ops.CONV_PRECISION = mode
+            try:
+                for m_ in (plain, taped):
+                    x, _ = m_.hot_path(frames[0][0])
+                    m_.bbox_head(x)
+            finally:
+                _ops.CONV_PRECISION = old_mode
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        junk = [torch.full((1 << 22,), float("nan"), device=dev) for _ in range(8)]      # recycle whatever was freed
+        before = dict(st)
+        for rnd in range(2):
+            for j, (pts, ex) in enumerate(frames):
+                for a, b in zip(run(taped, pts, ex, True), run(plain, pts, ex, True)):
+                    assert torch.equal(a, b), ("after an outside switch", rnd, j)
+        assert st["replayed"] > before["replayed"], st
+        del junk
     torch.cuda.synchronize()
