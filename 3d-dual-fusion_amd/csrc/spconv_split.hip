@@ -607,6 +607,9 @@ __device__ u32x4 g_zero_row[192];          // up to 512 input channels, three pa
 // zeroed registers) instead of reading the all-zero row.  The sparse 3 x 3 x 3 layers have ~45 % such lanes, and every lane
 // of a gather instruction costs the texture path a slot whatever it reads (tools/ubench/qperm_probe.hip: gathers + MFMAs
 // of a 64-channel K = 27 layer 52 -> 41 us); dense maps (neck, head) have none and keep the branch-free form.
+// (Round 5, measured and dropped: capping the 64-column two-part kernel at 80 registers for six waves per SIMD -- three 8-wave
+// workgroups per CU, all 519 tiles of a 66 k-row layer resident at once instead of 512 + a round of 7 -- spills 18 dwords
+// into the step loop: 61 -> 173 us.)
 template <int CIN, int COUT, int RT, int NW, int KPS, int NP = 2, int KS = 1, bool MG = false>
 __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConvArgs a) {
   // KPS = 32-channel blocks per step (one barrier per step)
@@ -789,7 +792,12 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
             rdy[rt][j][q][d] = (unsigned)__builtin_amdgcn_ds_bpermute((4 * n + g) * 4, (int)raw[rt][j][q][d]);
   };
 #endif
-  u32x4 bnext[2 * NP];                             // RING3: the first B fragments of the next step (read before its barrier)
+  // RING3: the first B fragments of the next step are read before its barrier -- into fragment slot 0 itself when a step has
+  // an even number of column-pair batches (its last batch reads slot 1), else into a set of their own
+  constexpr int NBATCH_ = KPS * CT / 2;
+  constexpr bool BNEXT_IN_PLACE = RING3 && NBATCH_ % 2 == 0;
+  u32x4 bnext[BNEXT_IN_PLACE ? 1 : 2 * NP];
+  u32x4 bq[2][2 * NP];
   auto step = [&](int s, u32x4 (&raw)[RT][KPS][NP], u32x4 (&rawn)[RT][KPS][NP], u32x4 (&wset)[WPT]) {
 #ifdef DF3D_OS_QGATHER
     u32x4 (&cur)[RT][KPS][NP] = rdy;
@@ -856,8 +864,8 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
 #endif
     // B fragments of the next column pair are fetched from LDS while the MFMAs of the current pair run
     constexpr int NBATCH = KPS * CT / 2;
-    u32x4 bq[2][2 * NP];
-    if constexpr (RING3) {
+    if constexpr (BNEXT_IN_PLACE) {
+    } else if constexpr (RING3) {
 #pragma unroll
       for (int q = 0; q < 2 * NP; ++q) bq[0][q] = bnext[q];
     } else if (!OS_DBG(16)) {
@@ -934,7 +942,7 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
     if constexpr (RING3) {                         // stage (s + 1) % 3 was stored during step s - 1: complete since this step's barrier
       const u32x4 *wn = Wl[grp][(s + 1) % 3] + lane;
 #pragma unroll
-      for (int q = 0; q < 2 * NP; ++q) bnext[q] = wn[q * 64];
+      for (int q = 0; q < 2 * NP; ++q) (BNEXT_IN_PLACE ? bq[0][q] : bnext[q]) = wn[q * 64];
     }
     issue_a(raw);
 #ifdef DF3D_OS_QGATHER
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(NW * KS * 64) void spconv_os_split_kernel(SplitConv
     if constexpr (RING3) {                         // step 0's first fragments: behind a barrier of their own
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 2 * NP; ++q) bnext[q] = Wl[grp][0][lane + q * 64];
+      for (int q = 0; q < 2 * NP; ++q) (BNEXT_IN_PLACE ? bq[0][q] : bnext[q]) = Wl[grp][0][lane + q * 64];
     }
     OS_STAMP(2);
 #ifdef DF3D_OS_QGATHER
