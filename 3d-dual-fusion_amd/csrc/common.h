@@ -107,6 +107,17 @@ __device__ __forceinline__ void split_pair_f16_ref(float x0, float x1, float s, 
 // values turn into inf / NaN and are caught by the next checked split downstream)
 #define split_pair(x0, x1, HI, LO) DF3D_SPLIT_PAIR_(x0, x1, DF3D_SA_SCALE, true, HI, LO)
 #define split_pair_nc(x0, x1, HI, LO) DF3D_SPLIT_PAIR_(x0, x1, DF3D_SA_SCALE, false, HI, LO)
+// checked without a branch per pair: the caller keeps the largest |value| it has split (AMAX, one v_max3 per pair; the values
+// are finite fp32 numbers -- NaN can only follow an overflow that was not flagged) and calls split_range_flag(AMAX) once
+#define split_pair_acc(x0, x1, HI, LO, AMAX)                                                  \
+  do {                                                                                        \
+    (AMAX) = fmaxf((AMAX), fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));                  \
+    DF3D_SPLIT_PAIR_(x0, x1, DF3D_SA_SCALE, false, HI, LO);                                   \
+  } while (0)
+#define split_range_flag(AMAX)                                                                \
+  do {                                                                                        \
+    if (__builtin_expect(!((AMAX) * DF3D_SA_SCALE <= 65504.f), 0)) atomicOr(&df3d::g_split_overflow_tu, 1u); \
+  } while (0)
 // weights / filters (packed once per parameter version)
 #define split_pair_w(x0, x1, HI, LO) DF3D_SPLIT_PAIR_(x0, x1, DF3D_SW_SCALE, true, HI, LO)
 #define split_pair_bf16(x0, x1, HI, LO)                  \

@@ -8,8 +8,10 @@
 // out-projection, add + LayerNorm, fused FFN): ~0.84 ms and ~3 GB of HBM traffic per layer where the rows in and out are
 // 0.27 GB.  Here a WAVE owns a group (32 tokens = two MFMA row tiles) from the load of its rows to the store of the result:
 //
-//  * every matrix product runs on `v_mfma_f32_16x16x32_bf16` with fp32 operands split into bf16 hi + lo (three products,
-//    fp32 accumulate; ~1e-5 of the output scale like the split-precision convolutions);
+//  * every matrix product runs on `v_mfma_f32_16x16x32_f16` with fp32 operands split into fp16 hi + lo of the scaled value
+//    (csrc/common.h: activations x 2^5, weights x 2^7; three products, fp32 accumulate, the accumulator multiplied by 2^-12 --
+//    2^-10 for the two activation x activation products K Q^T and V^T P^T; ~1e-6 of the output scale like the split-precision
+//    convolutions.  Rounds 3-4 split into bf16 pairs: 16 significand bits);
 //  * activations live in registers in ONE layout from start to end -- "token layout" T: lane (n, g) holds, of token
 //    16 tt + n, the channels 16 ct + 4 g + r (ct = 0..3, r = 0..3).  That is the accumulator layout of a product computed
 //    TRANSPOSED (weights as the A operand, D[out channel][token]), and -- because the contraction index of an MFMA may be
@@ -34,11 +36,12 @@
 namespace df3d {
 
 typedef float lt_f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int lt_u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 lt_bf16x8 __attribute__((ext_vector_type(8)));
 
-#define LT_MFMA(A, B, C) \
-  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lt_bf16x8, A), __builtin_bit_cast(lt_bf16x8, B), C, 0, 0, 0)
+DF3D_SPLIT_OVERFLOW_TU(ltlayer)
+typedef unsigned int lt_u32x4 __attribute__((ext_vector_type(4)));
+#define LT_MFMA(A, B, C) DF3D_MFMA_F16(A, B, C)
+#define LT_U DF3D_ACC_UNSCALE       /* weights x activations */
+#define LT_AA DF3D_AA_UNSCALE       /* activations x activations */
 
 // The machine scheduler otherwise hoists the LDS fragment reads of the whole (fully unrolled) layer to the top: 900 live
 // registers.  A scheduling barrier after every stage keeps live ranges to what the stage needs.
@@ -73,12 +76,16 @@ struct LtOp {
 };
 
 // eight fp32 values (two float4 of the lane) -> one MFMA operand, hi and lo parts
-__device__ __forceinline__ LtOp lt_split(lt_f32x4 a, lt_f32x4 b) {
+// (range check without a branch per pair: split_pair_acc / split_range_flag, csrc/common.h)
+__device__ __forceinline__ LtOp lt_split(lt_f32x4 a, lt_f32x4 b, float &amax) {
+  unsigned h[4], l[4];
+  split_pair_acc(a[0], a[1], h[0], l[0], amax);
+  split_pair_acc(a[2], a[3], h[1], l[1], amax);
+  split_pair_acc(b[0], b[1], h[2], l[2], amax);
+  split_pair_acc(b[2], b[3], h[3], l[3], amax);
   LtOp o;
-  split_pair_bf16(a[0], a[1], o.hi[0], o.lo[0]);
-  split_pair_bf16(a[2], a[3], o.hi[1], o.lo[1]);
-  split_pair_bf16(b[0], b[1], o.hi[2], o.lo[2]);
-  split_pair_bf16(b[2], b[3], o.hi[3], o.lo[3]);
+  o.hi = (lt_u32x4){h[0], h[1], h[2], h[3]};
+  o.lo = (lt_u32x4){l[0], l[1], l[2], l[3]};
   return o;
 }
 
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
   for (int grp = blockIdx.x * NW + wave; grp < a.G; grp += gridDim.x * NW) {
     // ---- rows of the group in layout T, LayerNorm 1 ------------------------------------------------------------
     lt_f32x4 xT[2][4];
+    float amax = 0.f;
     if constexpr (GATHER) {
       // x = flat[sel] + pe(xyz): the gathered point row plus the positional MLP 3 -> 32 (ReLU) -> 64 of the grouped coordinate
       // (pointformer.py:287-290,362-364); the second linear is one more transposed product, its hidden operand = the 8 hidden
@@ -179,15 +187,15 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
           const float v = fmaf(w0[ch * 3 + 2], pz, fmaf(w0[ch * 3 + 1], py, fmaf(w0[ch * 3], px, b0[ch])));
           h[j >> 2][j & 3] = fmaxf(v, 0.f);
         }
-        ho[tt] = lt_split(h[0], h[1]);
+        ho[tt] = lt_split(h[0], h[1], amax);
       }
 #pragma unroll
       for (int ot = 0; ot < 4; ++ot) {
         lt_f32x4 a0 = zero4, a1 = zero4;
         lt_gemm_t(Wl, LT_PAIRS + ot, lane, ho[0], ho[1], a0, a1);
         const lt_f32x4 bb = *(const lt_f32x4 *)(b1p + ot * 16 + 4 * g);
-        xT[0][ot] += a0 + bb;
-        xT[1][ot] += a1 + bb;
+        xT[0][ot] += a0 * LT_U + bb;
+        xT[1][ot] += a1 * LT_U + bb;
       }
       LT_FENCE();
     } else {
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) xo[tt][s] = lt_split(xT[tt][2 * s], xT[tt][2 * s + 1]);
+      for (int s = 0; s < 2; ++s) xo[tt][s] = lt_split(xT[tt][2 * s], xT[tt][2 * s + 1], amax);
 
     // ---- self-attention, one head (= one 16-channel tile) at a time ---------------------------------------------
     lt_f32x4 oT[2][4];
@@ -232,17 +240,17 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
       lt_u32x4 ka1[2], ka2[2], qb1[2], qb2[2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        const lt_f32x4 qq = (q[tt] + bq) * 0.25f, kk = k[tt] + bk;
+        const lt_f32x4 qq = (q[tt] * LT_U + bq) * 0.25f, kk = k[tt] * LT_U + bk;
         unsigned h01, l01, h23, l23;
-        split_pair_bf16(kk[0], kk[1], h01, l01);
-        split_pair_bf16(kk[2], kk[3], h23, l23);
+        split_pair_acc(kk[0], kk[1], h01, l01, amax);
+        split_pair_acc(kk[2], kk[3], h23, l23, amax);
         ka1[tt] = (lt_u32x4){h01, h23, l01, l23};
         ka2[tt] = (lt_u32x4){h01, h23, 0u, 0u};
-        split_pair_bf16(qq[0], qq[1], h01, l01);
-        split_pair_bf16(qq[2], qq[3], h23, l23);
+        split_pair_acc(qq[0], qq[1], h01, l01, amax);
+        split_pair_acc(qq[2], qq[3], h23, l23, amax);
         qb1[tt] = (lt_u32x4){h01, h23, h01, h23};
         qb2[tt] = (lt_u32x4){l01, l23, 0u, 0u};
-        v[tt] += bv;
+        v[tt] = v[tt] * LT_U + bv;
       }
       lt_f32x4 sc[2][2];                            // [key tile][query tile]
 #pragma unroll
@@ -253,11 +261,11 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
           sc[kt][qt] = LT_MFMA(ka2[kt], qb2[qt], sc[kt][qt]);
         }
       LT_FENCE();
-      const LtOp va = lt_split(v[0], v[1]);         // V^T as A operand: lane = channel d, slots = tokens of both tiles
+      const LtOp va = lt_split(v[0], v[1], amax);         // V^T as A operand: lane = channel d, slots = tokens of both tiles
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         // softmax over the 32 keys of query 16 qt + n: 8 values here, the rest in the lanes n + 16 g'
-        lt_f32x4 p0 = sc[0][qt], p1 = sc[1][qt];
+        lt_f32x4 p0 = sc[0][qt] * LT_AA, p1 = sc[1][qt] * LT_AA;
         float m = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])), fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
         m = lt_token_max(m);
 #pragma unroll
@@ -266,10 +274,10 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
           p1[r] = __expf(p1[r] - m);
         }
         const float inv = 1.f / lt_token_sum(lt_sum4(p0) + lt_sum4(p1));
-        const LtOp pb = lt_split(p0 * inv, p1 * inv);
+        const LtOp pb = lt_split(p0 * inv, p1 * inv, amax);
         lt_f32x4 o = LT_MFMA(va.lo, pb.hi, zero4);
         o = LT_MFMA(va.hi, pb.lo, o);
-        oT[qt][h] = LT_MFMA(va.hi, pb.hi, o);
+        oT[qt][h] = LT_MFMA(va.hi, pb.hi, o) * LT_AA;
         LT_FENCE();
       }
     }
@@ -280,15 +288,15 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) oo[tt][s] = lt_split(oT[tt][2 * s], oT[tt][2 * s + 1]);
+        for (int s = 0; s < 2; ++s) oo[tt][s] = lt_split(oT[tt][2 * s], oT[tt][2 * s + 1], amax);
 #pragma unroll
       for (int ot = 0; ot < 4; ++ot) {
         lt_f32x4 a0 = zero4, a1 = zero4;
 #pragma unroll
         for (int s = 0; s < 2; ++s) lt_gemm_t(Wl, 24 + ot * 2 + s, lane, oo[0][s], oo[1][s], a0, a1);
         const lt_f32x4 bb = *(const lt_f32x4 *)(bo + ot * 16 + 4 * g);
-        xT[0][ot] += a0 + bb;
-        xT[1][ot] += a1 + bb;
+        xT[0][ot] += a0 * LT_U + bb;
+        xT[1][ot] += a1 * LT_U + bb;
         LT_FENCE();
       }
     }
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) xo[tt][s] = lt_split(xT[tt][2 * s], xT[tt][2 * s + 1]);
+      for (int s = 0; s < 2; ++s) xo[tt][s] = lt_split(xT[tt][2 * s], xT[tt][2 * s + 1], amax);
 
     // ---- feed-forward 64 -> 128 -> 64 in two hidden chunks of 64, + residual (x3) ---------------------------------
     lt_f32x4 yT[2][4];
@@ -314,8 +322,8 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) lt_gemm_t(Wl, 32 + (c * 4 + ht) * 2 + s, lane, xo[0][s], xo[1][s], a0, a1);
         const lt_f32x4 bb = *(const lt_f32x4 *)(b1 + (c * 4 + ht) * 16 + 4 * g);
-        a0 += bb;
-        a1 += bb;
+        a0 = a0 * LT_U + bb;
+        a1 = a1 * LT_U + bb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           a0[r] = fmaxf(a0[r], 0.f);
@@ -327,12 +335,13 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
       }
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {               // k-step 2 c + sl of the 128 hidden channels
-        const LtOp h0 = lt_split(hT[0][2 * sl], hT[0][2 * sl + 1]), h1 = lt_split(hT[1][2 * sl], hT[1][2 * sl + 1]);
+        const LtOp h0 = lt_split(hT[0][2 * sl], hT[0][2 * sl + 1], amax), h1 = lt_split(hT[1][2 * sl], hT[1][2 * sl + 1], amax);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) lt_gemm_t(Wl, 48 + ot * 4 + 2 * c + sl, lane, h0, h1, yT[0][ot], yT[1][ot]);
         LT_FENCE();
       }
     }
+    split_range_flag(amax);
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       float *row;
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void lt_layer_kernel(LtArgs a) {
       }
 #pragma unroll
       for (int ot = 0; ot < 4; ++ot)
-        *(lt_f32x4 *)(row + ot * 16) = xT[tt][ot] + yT[tt][ot] + *(const lt_f32x4 *)(b2 + ot * 16 + 4 * g);
+        *(lt_f32x4 *)(row + ot * 16) = xT[tt][ot] + yT[tt][ot] * LT_U + *(const lt_f32x4 *)(b2 + ot * 16 + 4 * g);
     }
   }
 }

@@ -1431,6 +1431,7 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
   const float *e_bias = a.bias, *e_scale = a.scale, *e_shift = a.shift;
   const int e_relu = a.relu, e_ldo = a.ldo, e_nout = a.n_out;
   static_assert(CT == 8, "two f32x4 per lane and vector below");
+  float e_amax = 0.f;                            // largest |value| written as split rows (range check, once per workgroup)
   auto epilogue = [&](int cb) {
     const int col0 = cb * CW;
     f32x4 bi[2], sc[2], sh[2];
@@ -1463,8 +1464,8 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
           }
           if (e_out) *(f32x4 *)(e_out + o + q * 4) = v;
           if (e_split) {
-            split_pair(v[0], v[1], hh[q * 2], ll[q * 2]);
-            split_pair(v[2], v[3], hh[q * 2 + 1], ll[q * 2 + 1]);
+            split_pair_acc(v[0], v[1], hh[q * 2], ll[q * 2], e_amax);
+            split_pair_acc(v[2], v[3], hh[q * 2 + 1], ll[q * 2 + 1], e_amax);
           }
         }
         if (e_split) {
@@ -1524,6 +1525,7 @@ __global__ __launch_bounds__(768) void spconv_os_lc_kernel(SplitConvArgs a) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (steps == 0)                                // a tile without a single neighbour: bias / shift rows
     for (int cb = cb0; cb < cb0 + ncb; ++cb) epilogue(cb);
+  split_range_flag(e_amax);
 #undef LC_READ
 #undef LC_SB
 #undef LC_M

@@ -2003,8 +2003,7 @@ def lt_layer_pack(in_proj_weight, in_proj_bias, out_w, out_b, w1, b1, w2, b2, g1
     TransformerEncoderLayerPreNorm for df3d_lt_layer (layout: include/df3d_hip.h)."""
     lib = _lib.load()
     frags = torch.cat([_lt_fragments(w.detach().float()).reshape(-1, 64, 8) for w in (in_proj_weight, out_w, w1, w2)])
-    hi = frags.to(torch.bfloat16)
-    lo = (frags - hi.float()).to(torch.bfloat16)
+    hi, lo = split_weights_fp16(frags, "lt_layer_pack")          # (rounds 3-4: bf16 pairs)
     packed = torch.stack([hi, lo], 1).contiguous().view(torch.uint8).reshape(-1)
     if packed.numel() != int(lib.df3d_lt_layer_packed_bytes()):
         raise _lib.Df3dError("lt_layer_pack: %d bytes, the kernel expects %d" % (packed.numel(), lib.df3d_lt_layer_packed_bytes()))
@@ -2037,8 +2036,7 @@ def lt_layer_pack_pe(packed, vec, w0, b0, w1, b1):
     b1 [64]) for df3d_lt_layer_gather."""
     lib = _lib.load()
     frags = _lt_fragments(w1.detach().float()).reshape(-1, 64, 8)
-    hi = frags.to(torch.bfloat16)
-    lo = (frags - hi.float()).to(torch.bfloat16)
+    hi, lo = split_weights_fp16(frags, "lt_layer_pack_pe")
     pe = torch.stack([hi, lo], 1).contiguous().view(torch.uint8).reshape(-1)
     if pe.numel() != int(lib.df3d_lt_layer_pe_packed_bytes()):
         raise _lib.Df3dError("lt_layer_pack_pe: %d bytes, the kernel expects %d" % (pe.numel(), lib.df3d_lt_layer_pe_packed_bytes()))

@@ -709,13 +709,15 @@ def test_local_transformer_layer_as_one_kernel_vs_float64_and_row_kernels(G):
             else:
                 os.environ["DF3D_LT_FUSED"] = old
     scale = float(ref.abs().max())
-    assert float((y.cpu().double() - ref).abs().max()) < 3e-5 * scale
-    assert float((y - rows).abs().max()) < 5e-5 * scale
+    # round 5: fp16 hi + lo operands (22 significand bits) -- the fused layer sits where torch's own fp32 composition does
+    # (2e-7 .. 3e-7 of scale measured; rounds 3-4, bf16 pairs: 1e-5)
+    assert float((y.cpu().double() - ref).abs().max()) < 2e-6 * scale
+    assert float((y - rows).abs().max()) < 2e-6 * scale
     # a parameter update re-packs the fragments
     with torch.no_grad():
         md.linear2.bias.add_(1.0)
         y2 = md(xd)
-    assert float((y2 - y - 1.0).abs().max()) < 1e-4 * scale
+    assert float((y2 - y - 1.0).abs().max()) < 4e-6 * scale
 
 
 def test_local_transformer_chunk_as_fused_launches():
@@ -766,8 +768,8 @@ def test_local_transformer_chunk_as_fused_launches():
         m64.scatter(want, y, group_idx.cpu())
         want = want.permute(0, 2, 1)
     scale = float(want.abs().max())
-    assert float((y1.cpu().double() - want).abs().max()) < 5e-5 * scale
-    assert float((y1 - y0).abs().max()) < 5e-5 * scale
+    assert float((y1.cpu().double() - want).abs().max()) < 4e-6 * scale
+    assert float((y1 - y0).abs().max()) < 4e-6 * scale
     untouched = torch.ones(B, N, dtype=torch.bool)
     untouched.scatter_(1, gi.reshape(B, -1), False)
     assert int(untouched.sum()) > 0 and torch.equal(y1.cpu()[untouched], rows[untouched])
