@@ -114,6 +114,7 @@ struct WgradArgs {
   float *gw;
   int n_out, cin, cout, slice, tiles_n, tiles, kvol, slices;
   unsigned char order[DF3D_MAX_KVOL];   // offsets, the ones with the most pairs first
+  int dbg;                              // wgrad_split3_kernel tuning experiments (DF3D_W3_DBG): 1 no atomics, 2 no MFMAs, 4 no split + LDS stores
 };
 
 constexpr int WG_STAGE = 16, WG_BATCH = 256, WG_LIST = WG_BATCH + 64;
@@ -302,6 +303,259 @@ static void launch_wgrad(const WgradArgs &a, int kvol, hipStream_t stream) {
   hipLaunchKernelGGL((wgrad_f32_kernel<RT, CT>), grid, dim3(256), lds, stream, b);
 }
 
+// ---- filter gradient, third kernel (round 5): the contraction over PAIRS on the 16-bit matrix cores ---------------------------
+// wgrad_f32_kernel runs v_mfma_f32_16x16x4_f32 at about half of its 157 TFLOP/s: 4.4 ms of the 34 ms training step.  Here both
+// operands are split where they are staged into three bf16 parts (x = hi + mid + lo exactly: 24 significand bits and fp32's
+// exponent range, so gradients of any magnitude are safe -- the "split3" format of the gradient convolutions) and six of the
+// nine part products are accumulated in fp32 (lo*hi, mid*mid, hi*lo, mid*hi, hi*mid, hi*hi: the dropped ones are <= 2^-24 of
+// the product): 6 / 16 of the fp32 matrix time per pair.
+// The contraction index of filtersGrad[k] = in^T . gout is the PAIR, i.e. both operands are needed K-major while the rows are
+// channel-major.  gfx950's transposing LDS read does that for free: the staged rows sit row-major in LDS ([32 pairs][channels]
+// bf16 per part, row stride + 32 B so that the four rows a read touches fall on four bank quarters), and
+// ds_read_b64_tr_b16 hands lane (c, g) the column c of four rows -- two reads = the 8 k-slots 8 g .. 8 g + 7 of an A (or B)
+// operand of v_mfma_f32_16x16x32_bf16 (tools/ubench/trread_probe.hip pins the lane <-> element map).
+// A workgroup owns (row slice, offset k, (64 WM) x (64 WN) block of filtersGrad[k]); its WM x WN waves own one 64 x 64 block each
+// and share the staged rows: a 128 x 128 layer reads every pair's two rows ONCE (the fp32 kernel's 64 x 64 workgroups read them
+// twice).  Pairs are compacted from 256 table rows at a time into a workgroup list; a stage = 32 pairs: global loads a stage
+// ahead (registers), split + LDS store, barrier, 48 transposing reads + 96 MFMAs per wave, barrier.  nbr == NULL: pair i = (row
+// i, row i) -- the weight gradient of a linear layer over rows (df3d_rows_grad_weights).
+typedef short w3_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int w3_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int W3_STAGE = 32, W3_BATCH = 256, W3_LIST = W3_BATCH + W3_STAGE;
+
+__device__ __forceinline__ void w3_split_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+  unsigned h, m, l, unused;
+  split_pair_bf16_ref(x0, x1, h, m);
+  const float r0 = (x0 - __uint_as_float(h << 16)) - __uint_as_float(m << 16);
+  const float r1 = (x1 - __uint_as_float(h & 0xffff0000u)) - __uint_as_float(m & 0xffff0000u);
+  split_pair_bf16_ref(r0, r1, l, unused);
+  hi = h, mid = m, lo = l;
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs a) {
+  constexpr int NT = 64 * WM * WN, NWV = WM * WN, TM = 64 * WM, TN = 64 * WN, ST = W3_STAGE;
+  // LDS image of one part: row `r` (a pair) at r * RB + (r >> 3) * 128, its 32-byte slots XOR-ed with (r & 3): a
+  // transposing read serves 32 lanes per pass = the rows r .. r + 3 of TWO 8-row groups; with this image the eight 32-byte
+  // pieces of a pass fall on the eight bank eighths (64 banks x 4 B)
+  constexpr int RBA = TM * 2, RBG = TN * 2, IMA = ST * RBA + 512, IMG = ST * RBG + 512;
+  constexpr int PA = ST * (TM / 4) / NT, PG = ST * (TN / 4) / NT;  // 4-channel pieces per thread and stage
+  static_assert(ST * (TM / 4) % NT == 0 && ST * (TN / 4) % NT == 0, "pieces divide over the workgroup");
+  extern __shared__ __align__(16) unsigned char w3_smem[];
+  unsigned char *imA = w3_smem, *imG = imA + 3 * IMA;
+  int *li = (int *)(imG + 3 * IMG), *lo = li + W3_LIST;
+  int *s_pop = lo + W3_LIST;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int slices_x = (a.slices + 7) >> 3, per_k = slices_x * a.tiles;
+  const int kr = j / per_k, rest = j - kr * per_k;
+  const int sl = (rest / a.tiles) * 8 + xcd, tile = rest % a.tiles;
+  if (sl >= a.slices) return;
+  const int k = a.order[kr];
+  const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
+  const int ci0 = tm * TM, co0 = tn * TN;
+  const int r0 = sl * a.slice, r1 = min(r0 + a.slice, a.n_out);
+  const int32_t *nb = a.nbr ? a.nbr + (size_t)k * a.n_out : nullptr;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int li16 = lane & 15, g = lane >> 4;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[PA], rg[PG];
+  unsigned okm = 0u;
+  auto issue = [&](int st) {
+    okm = 0u;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int p = tid + NT * q, pair = p / (TM / 4), c = ci0 + (p - pair * (TM / 4)) * 4;
+      const int ia = li[st * ST + pair];
+      ra[q] = *(const f32x4 *)(a.feat + (size_t)max(ia, 0) * a.cin + (c < a.cin ? c : 0));
+      okm |= (ia >= 0 && c < a.cin) ? 1u << q : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {
+      const int p = tid + NT * q, pair = p / (TN / 4), c = co0 + (p - pair * (TN / 4)) * 4;
+      const int ia = li[st * ST + pair], og = lo[st * ST + pair];
+      rg[q] = *(const f32x4 *)(a.gout + (size_t)og * a.cout + (c < a.cout ? c : 0));
+      okm |= (ia >= 0 && c < a.cout) ? 1u << (16 + q) : 0u;
+    }
+  };
+  auto put = [&](unsigned char *im, int rb, int imb, int pair, int c4, f32x4 v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    w3_split_pair(v[0], v[1], h0, m0, l0);
+    w3_split_pair(v[2], v[3], h1, m1, l1);
+    unsigned char *d = im + pair * rb + (pair >> 3) * 128 + ((c4 * 8) ^ ((pair & 3) * 32));
+    *(w3_u32x2 *)d = (w3_u32x2){h0, h1};
+    *(w3_u32x2 *)(d + imb) = (w3_u32x2){m0, m1};
+    *(w3_u32x2 *)(d + 2 * imb) = (w3_u32x2){l0, l1};
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int p = tid + NT * q, pair = p / (TM / 4);
+      put(imA, RBA, IMA, pair, p - pair * (TM / 4), (okm >> q & 1u) ? ra[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+    }
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {
+      const int p = tid + NT * q, pair = p / (TN / 4);
+      put(imG, RBG, IMG, pair, p - pair * (TN / 4), (okm >> (16 + q) & 1u) ? rg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+    }
+  };
+  typedef __attribute__((address_space(3))) w3_s16x4 *lds_tr_ptr;
+  // fragment of tile t (16 channels), part p: k-slots 8 g .. 8 g + 7 of channel li16 = two transposing reads of four rows each.
+  // Lane i of a 16-lane group passes the address of piece i & 3 of row i >> 2 (whose slot XOR is i >> 2)
+  auto frag = [&](const unsigned char *base, int rb, int imb, int t, int p) -> w3_bf16x8 {
+    const unsigned char *q = base + p * imb + (((t ^ (li16 >> 2)) & 3) * 32);
+    const w3_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q));
+    const w3_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * rb));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    return __builtin_bit_cast(w3_bf16x8, v);
+  };
+  const unsigned char *abase = imA + (g * 8 + (li16 >> 2)) * RBA + g * 128 + wm * 128 + (li16 & 3) * 8;
+  const unsigned char *gbase = imG + (g * 8 + (li16 >> 2)) * RBG + g * 128 + wn * 128 + (li16 & 3) * 8;
+#define W3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+  auto compute = [&]() {
+    w3_bf16x8 af[4][3];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[mt][p] = frag(abase, RBA, IMA, mt, p);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const w3_bf16x8 b0 = frag(gbase, RBG, IMG, nt, 0), b1 = frag(gbase, RBG, IMG, nt, 1), b2 = frag(gbase, RBG, IMG, nt, 2);
+      // six products, smallest terms first (the order of the three-part convolution kernels); product-major over the four
+      // row tiles: dependent MFMAs four apart
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W3_MFMA(af[mt][2], b0, acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W3_MFMA(af[mt][1], b1, acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W3_MFMA(af[mt][0], b2, acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W3_MFMA(af[mt][1], b0, acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W3_MFMA(af[mt][0], b1, acc[mt][nt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W3_MFMA(af[mt][0], b0, acc[mt][nt]);
+    }
+  };
+#undef W3_MFMA
+
+  int cnt = 0, next = r0;
+  bool had = false;
+  while (true) {
+    if (next < r1) {                                             // 256 table rows -> pairs, appended to the list
+#pragma unroll 1
+      for (int u = 0; u < W3_BATCH / NT; ++u) {
+        const int o = next + u * NT + tid;
+        const int idx = o < r1 ? (nb ? nb[o] : o) : -1;
+        const unsigned long long mask = __ballot(idx >= 0);
+        if (lane == 0) s_pop[wave] = __popcll(mask);
+        __syncthreads();
+        int base = cnt, total = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+          const int pw = s_pop[w];
+          base += w < wave ? pw : 0;
+          total += pw;
+        }
+        if (idx >= 0) {
+          const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+          li[pos] = idx, lo[pos] = o;
+        }
+        cnt += total;
+        __syncthreads();
+      }
+      next += W3_BATCH;
+    }
+    const bool last = next >= r1;
+    const int stages = last ? (cnt + ST - 1) / ST : cnt / ST;
+    if (last) {
+      if (tid < ST && cnt + tid < stages * ST) li[cnt + tid] = -1, lo[cnt + tid] = r0;
+      __syncthreads();
+    }
+    if (stages > 0) {
+      had = true;
+      issue(0);
+      for (int st = 0; st < stages; ++st) {
+        if (!(a.dbg & 4)) stash();
+        __syncthreads();
+        if (st + 1 < stages) issue(st + 1);
+        if (!(a.dbg & 2)) compute();
+        __syncthreads();
+      }
+    }
+    if (last) break;
+    const int done = stages * ST, rem = cnt - done;               // < 32 pairs wait for the next refill
+    int ci_ = 0, co_ = 0;
+    if (tid < rem) ci_ = li[done + tid], co_ = lo[done + tid];
+    __syncthreads();
+    if (tid < rem) li[tid] = ci_, lo[tid] = co_;
+    cnt = rem;
+    __syncthreads();
+  }
+  if (!had || (a.dbg & 1)) return;
+  // every wave owns its 64 x 64 block: one atomic add per element and workgroup
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + wm * 64 + mt * 16 + 4 * g + r, co = co0 + wn * 64 + nt * 16 + li16;
+        const float v = acc[mt][nt][r];
+        if (v != 0.f && ci < a.cin && co < a.cout) unsafeAtomicAdd(a.gw + ((size_t)k * a.cin + ci) * a.cout + co, v);
+      }
+}
+
+template <int WM, int WN>
+static int launch_wgrad3(const WgradArgs &a, int kvol, hipStream_t stream) {
+  constexpr int TM = 64 * WM, TN = 64 * WN;
+  constexpr size_t lds = (size_t)3 * (W3_STAGE * (TM * 2 + TN * 2) + 1024) + (size_t)(2 * W3_LIST + 8) * sizeof(int);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void *)wgrad_split3_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("wgrad_split3: cannot raise the dynamic LDS limit");
+      return DF3D_EHIP;
+    }
+    configured = true;
+  }
+  WgradArgs b = a;
+  b.tiles_n = cdiv(a.cout, TN);
+  b.tiles = cdiv(a.cin, TM) * b.tiles_n, b.kvol = kvol;
+  // enough workgroups to fill the chip a few times over, slices of at least 1024 rows
+  const char *ws = getenv("DF3D_W3_WGS");                          // tuning aid: workgroups wanted per launch
+  const int want = std::max(1, cdiv(ws ? atoi(ws) : 2048, kvol * b.tiles));
+  const int slices = std::min(want, cdiv(a.n_out, 1024));
+  b.dbg = getenv("DF3D_W3_DBG") ? atoi(getenv("DF3D_W3_DBG")) : 0;
+  b.slice = cdiv(cdiv(a.n_out, slices), 256) * 256;
+  b.slices = cdiv(a.n_out, b.slice);
+  for (int k = 0; k < kvol; ++k) b.order[k] = (unsigned char)k;
+  if (kvol == 27 || kvol == 9) {
+    const int d = kvol == 27 ? 3 : 2;
+    auto norm = [d](int k) { int s = 0; for (int i = 0; i < d; ++i, k /= 3) s += (k % 3) != 1; return s; };
+    std::stable_sort(b.order, b.order + kvol, [&](unsigned char x, unsigned char y) { return norm(x) < norm(y); });
+  }
+  const dim3 grid(8 * cdiv(b.slices, 8) * kvol * b.tiles);
+  hipLaunchKernelGGL((wgrad_split3_kernel<WM, WN>), grid, dim3(64 * WM * WN), lds, stream, b);
+  return DF3D_OK;
+}
+
+static int launch_wgrad3_any(const WgradArgs &a, int kvol, hipStream_t stream) {
+  if (a.cin >= 128 && a.cout >= 128) return launch_wgrad3<2, 2>(a, kvol, stream);
+  if (a.cin >= 128) return launch_wgrad3<2, 1>(a, kvol, stream);
+  if (a.cout >= 128) return launch_wgrad3<1, 2>(a, kvol, stream);
+  return launch_wgrad3<1, 1>(a, kvol, stream);
+}
+
 template <int RT>
 static void launch_wgrad_ct(WgradArgs &a, int kvol, hipStream_t stream) {
   if (a.cout >= 64) a.tiles_n = cdiv(a.cout, 64), launch_wgrad<RT, 4>(a, kvol, stream);
@@ -339,8 +593,20 @@ extern "C" int df3d_sparse_conv_grad_filters(const float *features, int n_in, in
   DF3D_HIP(hipMemsetAsync(grad_filters, 0, (size_t)kvol * cin * cout * sizeof(float), stream));
   if (n_out == 0 || n_in == 0) return DF3D_OK;
   DF3D_CHECK_ARG(features && grad_out && nbr, "sparse_conv_grad_filters: null argument");
-  const char *env = getenv("DF3D_WGRAD");                    // read per call: tests switch between the two kernels
-  const int kernel_choice = env ? atoi(env) : 1;
+  const char *env = getenv("DF3D_WGRAD");                    // read per call: tests switch between the kernels
+  // 0 = grad_filters_kernel, 1 = wgrad_f32_kernel (exact fp32 products), 3 = wgrad_split3_kernel (three bf16 parts, six
+  // products: fp32-grade); default: 3 where it measured faster (tools/ubench/wgrad3_probe.py, MI355X: 128 -> 128 K = 27 230 ->
+  // 171 us, dense 3 x 3 128 -> 128 121 -> 112, 256 -> 256 118 -> 108, 256 -> 128 202 -> 179, the head's 64 -> 36 x 64 1257 -> 940;
+  // slower on 64 -> 64 K = 27 116 -> 138, 512 -> 64 198 -> 214 and on maps under 16 k rows), else 1
+  const bool wide = (cin >= 128 && cout >= 128 && n_out >= 16384) || cout >= 1024;
+  const int kernel_choice = env ? atoi(env) : (wide ? 3 : 1);
+  if (kernel_choice == 3 && cin % 4 == 0 && cout % 4 == 0) {
+    WgradArgs a{features, grad_out, nbr, grad_filters, n_out, cin, cout, 0, 1, 0, 0, 0, {0}};
+    int rc = launch_wgrad3_any(a, kvol, stream);
+    if (rc) return rc;
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+  }
   if (kernel_choice && cin % 4 == 0 && cout % 4 == 0) {
     WgradArgs a{features, grad_out, nbr, grad_filters, n_out, cin, cout, 0, 1, 0, 0, 0, {0}};
     // enough workgroups to fill the chip a few times over, slices of at least 1024 rows (the atomics of a slice are
@@ -363,6 +629,21 @@ extern "C" int df3d_sparse_conv_grad_filters(const float *features, int n_in, in
   else if (ct <= 2) hipLaunchKernelGGL(grad_filters_kernel<2>, grid, dim3(256), 0, stream, features, grad_out, nbr, n_out, cin, cout, grad_filters);
   else if (ct <= 4) hipLaunchKernelGGL(grad_filters_kernel<4>, grid, dim3(256), 0, stream, features, grad_out, nbr, n_out, cin, cout, grad_filters);
   else hipLaunchKernelGGL(grad_filters_kernel<8>, grid, dim3(256), 0, stream, features, grad_out, nbr, n_out, cin, cout, grad_filters);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_rows_grad_weights(const float *x, const float *grad_out, long long n, int cin, int cout, float *grad_weights,
+                                      void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(grad_weights && cin > 0 && cout > 0 && n >= 0 && n < (1ll << 31), "rows_grad_weights: bad sizes");
+  DF3D_CHECK_ARG(cin % 4 == 0 && cout % 4 == 0, "rows_grad_weights: channel counts must be multiples of 4 (got %d, %d)", cin, cout);
+  DF3D_HIP(hipMemsetAsync(grad_weights, 0, (size_t)cin * cout * sizeof(float), stream));
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(x && grad_out, "rows_grad_weights: null argument");
+  WgradArgs a{x, grad_out, nullptr, grad_weights, (int)n, cin, cout, 0, 1, 0, 0, 0, {0}};
+  int rc = launch_wgrad3_any(a, 1, stream);
+  if (rc) return rc;
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

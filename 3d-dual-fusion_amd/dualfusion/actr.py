@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import normal_
 
+from .linear_rows import Linear, linear as _linear
 from .msda import MSDeformAttn
 
 
@@ -39,8 +40,8 @@ class _Gate1D(nn.Module):
 
     def _maps(self, x1, x2):
         """sigmoid(conv1x1) on [N, Q, C] inputs without the permutes: one GEMV each."""
-        m1 = torch.sigmoid(F.linear(x1, self.b_conv1d.weight[:, :, 0], self.b_conv1d.bias))
-        m2 = torch.sigmoid(F.linear(x2, self.a_conv1d.weight[:, :, 0], self.a_conv1d.bias))
+        m1 = torch.sigmoid(_linear(x1, self.b_conv1d.weight[:, :, 0], self.b_conv1d.bias))
+        m2 = torch.sigmoid(_linear(x2, self.a_conv1d.weight[:, :, 0], self.a_conv1d.bias))
         return m1, m2
 
 
@@ -168,10 +169,10 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.self_attn = MSDeformAttn(d_model, q_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout2 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
 
@@ -207,15 +208,15 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
                                       q_rep_place=self.q_rep_place)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)      # image-query FFN
+        self.linear1 = Linear(d_model, d_ffn)      # image-query FFN
         self.activation = _get_activation_fn(activation)
         self.dropout2 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
-        self.linear3 = nn.Linear(d_model, d_ffn)      # LiDAR-query FFN
+        self.linear3 = Linear(d_model, d_ffn)      # LiDAR-query FFN
         self.dropout4 = nn.Dropout(dropout)
-        self.linear4 = nn.Linear(d_ffn, d_model)
+        self.linear4 = Linear(d_ffn, d_model)
         self.dropout5 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
         self.fusion_layer = attn_dict[self.attn_layer](q_model, q_model)
@@ -506,7 +507,7 @@ class ACTR(nn.Module):
                 and _ops.CONV_PRECISION != "fp32" and _ops.rows_linear_supported(conv.in_channels, conv.out_channels)):
             y = _ops.rows_linear(v_i_feat.contiguous(), _ops.rows_linear_pack(conv.weight, conv.bias))
         else:
-            y = F.linear(v_i_feat, conv.weight[:, :, 0], conv.bias)        # [N, Q, C]
+            y = _linear(v_i_feat, conv.weight[:, :, 0], conv.bias)        # [N, Q, C]
         if y.is_cuda and y.dtype == torch.float32 and not torch.is_grad_enabled() \
                 and (gn.num_channels // gn.num_groups) % 4 == 0 and y.shape[1] > 0:
             from . import ops as _ops

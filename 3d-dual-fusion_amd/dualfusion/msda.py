@@ -10,6 +10,7 @@ from torch import nn
 from torch.autograd import Function
 from torch.nn.init import xavier_uniform_
 
+from .linear_rows import Linear
 from . import ops as _ops
 from ._lib import Df3dError
 
@@ -58,10 +59,10 @@ class MSDeformAttn(nn.Module):
         self.n_levels = n_levels
         self.n_heads = n_heads
         self.n_points = n_points
-        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
-        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
-        self.value_proj = nn.Linear(d_model, d_model)
-        self.output_proj = nn.Linear(d_model, d_model)
+        self.sampling_offsets = Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = Linear(d_model, d_model)
+        self.output_proj = Linear(d_model, d_model)
         self.q_method = q_method
         self.q_rep_place = q_rep_place
         if q_method == 'gating':

@@ -672,6 +672,22 @@ def sparse_conv_grad_filters(features, grad_out, nbr):
     return gw
 
 
+def rows_grad_weights(x, grad_out):
+    """-> [cin, cout] = x^T grad_out over rows (df3d_rows_grad_weights: three bf16 parts per operand, six products, fp32
+    accumulate).  The weight gradient of y = x W^T is rows_grad_weights(grad_y, x)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    _chk(grad_out, torch.float32, "grad_out")
+    n, cin = x.shape
+    if grad_out.shape[0] != n:
+        raise _lib.Df3dError("rows_grad_weights: %d rows against %d" % (n, grad_out.shape[0]))
+    cout = grad_out.shape[1]
+    gw = torch.empty((cin, cout), dtype=torch.float32, device=x.device)
+    rc = lib.df3d_rows_grad_weights(_ptr(x), _ptr(grad_out), int(n), int(cin), int(cout), _ptr(gw), _stream())
+    _lib.check(rc, "df3d_rows_grad_weights")
+    return gw
+
+
 def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=False):
     """indice_conv backward from the kernel-facing rulebook: -> (grad_features [n_in, cin], grad_filters [K, cin, cout]).
     filters [K, cin, cout].  bf16: the input gradient on the bf16 kernel (mixed-precision training: gradient rows and

@@ -562,7 +562,10 @@ def cpu_baseline(wl, n_sweeps=20):
 
 
 # ------------------------------------------------------------------------------------------------ the other configs
-SIDE_CONFIGS = (("cp_lidar", "configs[0] shape", "split"), ("tf_fusion", "configs[2]", "bf16"), ("vr_fusion", "configs[4]", "split"))
+SIDE_CONFIGS = (("cp_lidar", "configs[0] shape", "split", "detect"), ("tf_fusion", "configs[2]", "bf16", "detect"),
+                ("vr_fusion", "configs[4]", "split", "detect"),
+                # (VERDICT r4 "next" 5: the training step where the driver's record sees it)
+                ("cp_fusion", "configs[1], training step: forward + losses + backward + optimizer", "split", "train"))
 
 
 def side_configs(args, steps=12):
@@ -574,23 +577,24 @@ def side_configs(args, steps=12):
     import subprocess
     out = {}
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
-    for name, cfg, prec in SIDE_CONFIGS:
-        if name == args.workload:
+    for name, cfg, prec, stage in SIDE_CONFIGS:
+        if name == args.workload and stage == "detect":
             continue
+        key = name if stage == "detect" else "%s_%s" % (name, stage)
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", "4",
                "--frames", "4", "--conv-precision", prec, "--no-cpu-baseline", "--no-extra-passes", "--no-kernel-timing",
-               "--no-side-configs", "--inflight", "1"]
+               "--no-side-configs", "--inflight", "1", "--stage", stage]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:
                 raise RuntimeError("rc %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1][:100] if r.stderr.strip() else ""))
             d = json.loads(line[-1])
-            out[name] = {"cfg": cfg, "ms_per_step": d["ms_per_step"], "bs": d["config"]["sweeps_per_gpu_per_step"],
+            out[key] = {"cfg": cfg, "ms_per_step": d["ms_per_step"], "bs": d["config"]["sweeps_per_gpu_per_step"],
                          "value": d["value"], "unit": d["unit"],
                          "dtype": {"split": "f32(fp16 hi+lo operands, 3 products)", "bf16": "bf16", "fp32": "f32"}[prec], "steps": steps}
         except Exception as ex:                                  # noqa: BLE001
-            out[name] = {"cfg": cfg, "error": repr(ex)[:120]}
+            out[key] = {"cfg": cfg, "error": repr(ex)[:120]}
     return out
 
 

@@ -263,10 +263,19 @@ int df3d_sparse_conv_bf16(const void *features_bf16, int n_in, int cin, const vo
  *   filter gradient = df3d_sparse_conv_grad_filters: grad_filters[k][ci][co] = sum_o features[nbr[k][o]][ci] *
  *       grad_out[o][co] ([K][Cin][Cout], zero-filled here; fp32 MFMA partial tiles are added with fp32 atomics, so
  *       the summation order varies between runs like the reference's cuBLAS split-K).  Channel counts that are multiples
- *       of 4 run on the LDS-staged pair-compacted kernel (any Cout); anything else on the direct kernel (Cout <= 128). */
+ *       of 4 run on the LDS-staged pair-compacted kernels (any Cout) -- from 64 channels on both sides on the 16-bit matrix
+ *       cores with both operands split into three bf16 parts (six products, fp32 accumulate: fp32-grade, ~1e-6 of scale;
+ *       round 5), below that with exact fp32 products; anything else on the direct kernel (Cout <= 128).
+ *   df3d_rows_grad_weights: the same contraction without a table -- grad_weights[ci][co] = sum_r x[r][ci] * grad_out[r][co]
+ *       ([Cin][Cout], zero-filled here): the weight gradient of a linear layer over rows (torch.nn.Linear.weight.grad =
+ *       this with the roles of x and grad_out exchanged; the adapter's query / value / feed-forward projections,
+ *       CP/det3d/models/fusion/actr_transformer.py:388-424), where the library GEMM runs a [Cin x rows] . [rows x Cout]
+ *       product with 32 k - 240 k rows at a fifth of its rate. */
 int df3d_invert_neighbors(const int32_t *nbr, int kvol, int n_out, int n_in, int32_t *inv, void *stream);
 int df3d_sparse_conv_grad_filters(const float *features, int n_in, int cin, const float *grad_out, int n_out, int cout,
                                   const int32_t *nbr, int kvol, float *grad_filters, void *stream);
+int df3d_rows_grad_weights(const float *x, const float *grad_out, long long n, int cin, int cout, float *grad_weights,
+                           void *stream);
 
 /* BatchNorm with batch statistics over channels-last rows [n][c] (training rows).  Replace
  * torch.nn.BatchNorm1d / BatchNorm2d in train() mode behind the convolutions of the sparse backbone, the BEV neck and the head

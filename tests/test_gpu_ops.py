@@ -975,15 +975,39 @@ def test_filter_gradient_kernels_against_float64(cin, cout, K, n_in, n_out, dens
         ref[k] = feats[nbr[k][o].long()].double().t() @ gout[o].double()
     scale = max(1.0, float(ref.abs().max()))
     outs = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "3"):
         if mode == "0" and cout > 128:
+            continue
+        if mode == "3" and (cin % 4 or cout % 4):
             continue
         os.environ["DF3D_WGRAD"] = mode
         try:
             outs[mode] = ops.sparse_conv_grad_filters(feats.to(dev), gout.to(dev), nbr.to(dev)).cpu().double()
         finally:
             os.environ.pop("DF3D_WGRAD", None)
-        assert float((outs[mode] - ref).abs().max()) <= 2e-5 * scale, mode
+        # (round 5) mode 3 = three bf16 parts per operand on the 16-bit matrix cores, forced here on every shape with channel
+        # counts that are multiples of 4 (by default it takes the layers with >= 64 channels on both sides): fp32-grade
+        assert float((outs[mode] - ref).abs().max()) <= (4e-6 if mode == "3" else 2e-5) * scale, mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cin,cout,gscale", [(32034, 128, 1024, 1e-6), (31254, 1024, 128, 3.0), (5000, 256, 128, 1e-3),
+                                               (70, 64, 64, 1.0), (1, 128, 128, 1.0), (4099, 132, 64, 1e-9), (40050, 4, 256, 1.0)])
+def test_rows_grad_weights_against_float64(n, cin, cout, gscale):
+    """df3d_rows_grad_weights (the filter-gradient kernel without a table) = x^T grad over rows, the weight gradient of the
+    adapter's linear layers: against float64 at the feed-forward / projection shapes of the training step, with gradients of
+    very different magnitudes (the three-part bf16 split has fp32's exponent range: no scaling anywhere) and a row block whose
+    gradient is 2^40 times larger than the rest."""
+    from dualfusion import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(n + cin)
+    x = torch.randn((n, cin), generator=gen) * 2.0
+    g = torch.randn((n, cout), generator=gen) * gscale
+    if n > 1000:
+        g[100:132] *= 2.0 ** 40
+    ref = x.double().t() @ g.double()
+    got = ops.rows_grad_weights(x.to(dev), g.to(dev)).cpu().double()
+    assert float((got - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
 @pytest.mark.gpu
