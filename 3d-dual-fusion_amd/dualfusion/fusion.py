@@ -118,7 +118,7 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
                 f = _linear_rows(f, cv.weight[:, :, 0, 0], cv.bias)
             pt = f if pt is None else pt + f
         pt = _linear_rows(pt, self.reduced_dim2.weight[:, :, 0, 0], self.reduced_dim2.bias)          # [NI, HW, last]
-        summary = torch.matmul(self.reduced_dim3.weight[:, :, 0, 0], img_feat.reshape(NI, Ci, H * W))   # [NI, 1, HW]
+        summary = _ops.channel_first_linear(img_feat.reshape(NI, Ci, H * W), self.reduced_dim3.weight[:, :, 0, 0])   # [NI, 1, HW]
         fused = pt + (summary.transpose(1, 2) + self.reduced_dim3.bias)
         taps = _linear_rows(fused, self.spatial_basic.weight[0].permute(1, 2, 0).reshape(9, -1))     # [NI, HW, 9]
         taps = F.pad(taps.view(NI, H, W, 9), (0, 0, 1, 1, 1, 1))                                     # zero padding of the 3x3

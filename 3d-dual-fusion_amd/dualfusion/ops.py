@@ -2184,7 +2184,14 @@ class _LinearRows(torch.autograd.Function):
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
         gx = (g2 @ weight).view(x.shape) if ctx.needs_input_grad[0] else None
         n, d = g2.shape[0], _row_split(g2.shape[0])
-        if d and n // d >= 8:
+        if (g2.is_cuda and g2.dtype == torch.float32 and x2.dtype == torch.float32 and x2.shape[1] % 4 == 0 and n >= 2048
+                and os.environ.get("DF3D_LINEAR_WGRAD", "1") != "0"):
+            # (round 5) the contraction over rows on the matrix cores: df3d_rows_grad_weights (three bf16 parts per operand);
+            # gradient columns padded to the kernel's 4-channel pieces (the gates have one output)
+            pad = (-g2.shape[1]) % 4
+            gp = torch.nn.functional.pad(g2, (0, pad)) if pad else g2.contiguous()
+            gw = rows_grad_weights(gp, x2.contiguous())[:g2.shape[1]]
+        elif d and n // d >= 8:
             gw = torch.bmm(g2.view(n // d, d, -1).transpose(1, 2), x2.view(n // d, d, -1)).sum(0)
         else:
             gw = g2.t() @ x2
@@ -2213,7 +2220,18 @@ class _ChannelFirstLinear(torch.autograd.Function):
         gx = torch.matmul(weight.t(), g) if ctx.needs_input_grad[0] else None
         N, Cin, S = x.shape
         d = _row_split(S)
-        if d and S // d >= 8 and g.is_contiguous() and x.is_contiguous():
+        if weight.shape[0] <= 4:
+            # a gate with one output map: g x^T is a matrix-vector product per map over the contiguous pixel axis (the library's
+            # own backward transposes x to pixel-major rows -- a 246 MB copy -- for a [1, N S] x [N S, Cin] product: 850 us)
+            if weight.shape[0] == 1 and x.dtype == torch.float32 and x.is_contiguous() and g.is_contiguous():
+                lib = _lib.load()
+                part = torch.empty((N, Cin), dtype=torch.float32, device=x.device)
+                _lib.check(lib.df3d_chanfirst_dot(_ptr(x), _ptr(g), int(N), int(Cin), int(S), _ptr(part), _stream()),
+                           "df3d_chanfirst_dot")
+                gw = part.sum(0, keepdim=True)
+            else:
+                gw = torch.bmm(x, g.transpose(1, 2)).sum(0).t()
+        elif d and S // d >= 8 and g.is_contiguous() and x.is_contiguous():
             nc = S // d
             gw = None
             for n in range(N):

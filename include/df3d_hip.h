@@ -276,6 +276,10 @@ int df3d_sparse_conv_grad_filters(const float *features, int n_in, int cin, cons
                                   const int32_t *nbr, int kvol, float *grad_filters, void *stream);
 int df3d_rows_grad_weights(const float *x, const float *grad_out, long long n, int cin, int cout, float *grad_weights,
                            void *stream);
+/* out[n][c] = sum_s x[n][c][s] * g[n][s] over channel-first maps x [nmaps][channels][S], g [nmaps][S]: the weight gradient of a
+ * one-output 1 x 1 convolution (the image gate's `reduced_dim3`, CP/det3d/models/fusion/point_to_image_projection.py:34-61) is the
+ * sum of out over the maps. */
+int df3d_chanfirst_dot(const float *x, const float *g, int nmaps, int channels, long long S, float *out, void *stream);
 
 /* BatchNorm with batch statistics over channels-last rows [n][c] (training rows).  Replace
  * torch.nn.BatchNorm1d / BatchNorm2d in train() mode behind the convolutions of the sparse backbone, the BEV neck and the head

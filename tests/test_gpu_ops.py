@@ -1011,6 +1011,41 @@ def test_rows_grad_weights_against_float64(n, cin, cout, gscale):
 
 
 @pytest.mark.gpu
+def test_linear_module_and_gate_weight_gradients_on_native_kernels():
+    """dualfusion.linear_rows.Linear (forward = F.linear; weight gradient on df3d_rows_grad_weights) and the one-output
+    channel-first gate (`ops.channel_first_linear`, weight gradient on df3d_chanfirst_dot) against torch's autograd in float64:
+    3-D inputs, a bias, an output count that is not a multiple of 4, a pixel count that is not a multiple of 4."""
+    from dualfusion import ops
+    from dualfusion.linear_rows import Linear
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)
+    for shape, cout in (((6, 5339, 128), 1024), ((3, 4000, 256), 131), ((40050, 128), 1)):
+        x = torch.randn(shape, generator=gen)
+        lin = Linear(shape[-1], cout)
+        ref = torch.nn.Linear(shape[-1], cout).double()
+        ref.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+        g = torch.randn(shape[:-1] + (cout,), generator=gen) * 1e-4
+        xr = x.double().requires_grad_(True)
+        ref(xr).backward(g.double())
+        lin = lin.to(dev)
+        xd = x.to(dev).requires_grad_(True)
+        y = lin(xd)
+        assert type(y.grad_fn).__name__ == "_LinearFunctionBackward"
+        y.backward(g.to(dev))
+        for got, want in ((lin.weight.grad, ref.weight.grad), (lin.bias.grad, ref.bias.grad), (xd.grad, xr.grad)):
+            assert float((got.cpu().double() - want).abs().max()) <= 4e-6 * float(want.abs().max())
+    for S in (40050, 40051):
+        x = torch.randn((6, 256, S), generator=gen)
+        w = torch.randn((1, 256), generator=gen)
+        g = torch.randn((6, 1, S), generator=gen) * 1e-3
+        wr = w.double().requires_grad_(True)
+        torch.matmul(wr, x.double()).backward(g.double())
+        wd = w.to(dev).requires_grad_(True)
+        ops.channel_first_linear(x.to(dev), wd).backward(g.to(dev))
+        assert float((wd.grad.cpu().double() - wr.grad).abs().max()) <= 4e-6 * float(wr.grad.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,c,relu", [(37001, 16, True), (9000, 32, False), (5003, 64, True), (3000, 128, True),
                                       (2048, 256, False), (777, 512, True), (400, 2304, True), (2, 64, False)])
 def test_batch_norm_rows_kernels_vs_float64(n, c, relu):
