@@ -133,3 +133,26 @@ def test_chunked_nms_host_loop_matches_the_dense_matrix_loop():
             assert k == len(want) and keep[:k].tolist() == want
     finally:
         iou3d_cuda._NMS_ROWS = old
+
+
+def test_linear_rows_module_is_a_drop_in_linear_on_the_host():
+    """dualfusion.linear_rows.Linear (the weight gradient of the adapter's linear layers on a native kernel, GPU only): on the
+    host it IS torch.nn.Linear -- same parameter names, same values, same gradients, state dicts interchangeable; the modules
+    that used nn.Linear before round 5 still load the same checkpoints."""
+    from dualfusion.linear_rows import Linear, linear
+    from dualfusion.msda import MSDeformAttn
+    torch.manual_seed(0)
+    a, b = Linear(12, 7), torch.nn.Linear(12, 7)
+    b.load_state_dict(a.state_dict())
+    assert list(a.state_dict()) == list(b.state_dict()) == ["weight", "bias"]
+    x = torch.randn(5, 3, 12, requires_grad=True)
+    y = a(x)
+    assert y.grad_fn is not None and "LinearFunction" not in type(y.grad_fn).__name__      # plain autograd on the host
+    y.sum().backward()
+    xb = x.detach().clone().requires_grad_(True)
+    b(xb).sum().backward()
+    assert torch.equal(y, b(xb)) and torch.equal(a.weight.grad, b.weight.grad) and torch.equal(x.grad, xb.grad)
+    assert torch.equal(linear(x, a.weight, None), torch.nn.functional.linear(x, a.weight))
+    m = MSDeformAttn(d_model=64, q_model=64, n_levels=1, n_heads=4, n_points=4)
+    assert {"sampling_offsets.weight", "attention_weights.bias", "value_proj.weight", "output_proj.bias"} <= set(m.state_dict())
+    assert all(isinstance(getattr(m, k), torch.nn.Linear) for k in ("sampling_offsets", "attention_weights", "value_proj", "output_proj"))
