@@ -393,7 +393,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
     w3_split_pair(v[2], v[3], h1, m1, l1);
     unsigned char *d = im + pair * rb + (pair >> 3) * 128 + ((c4 * 8) ^ ((pair & 3) * 32));
     *(w3_u32x2 *)d = (w3_u32x2){h0, h1};
-    if (a.dbg & 16) return;                                        // (experiment: one part only)
     *(w3_u32x2 *)(d + imb) = (w3_u32x2){m0, m1};
     *(w3_u32x2 *)(d + 2 * imb) = (w3_u32x2){l0, l1};
   };
@@ -424,15 +423,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
   const unsigned char *gbase = imG + (g * 8 + (li16 >> 2)) * RBG + g * 128 + wn * 128 + (li16 & 3) * 8;
 #define W3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
   auto compute = [&]() {
-    if (a.dbg & 8) {                                               // (experiment: the hi x hi product only)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const w3_bf16x8 b0 = frag(gbase, RBG, IMG, nt, 0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W3_MFMA(frag(abase, RBA, IMA, mt, 0), b0, acc[mt][nt]);
-      }
-      return;
-    }
     w3_bf16x8 af[4][3];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)

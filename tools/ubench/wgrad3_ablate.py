@@ -41,7 +41,7 @@ for stage, x in (("conv4", x4), ("conv3", x3)):
     f = x.features.contiguous()
     g = torch.randn_like(f) * 1e-3
     out = []
-    for dbg in (0, 1, 2, 4, 6, 7, 8, 16, 24):
+    for dbg in (0, 1, 2, 4, 6, 7):
         os.environ["DF3D_W3_DBG"] = str(dbg)
         out.append("dbg %d: %.0f" % (dbg, timeit(lambda: ops.sparse_conv_grad_filters(f, g, rb.nbr))))
     os.environ["DF3D_W3_DBG"] = "0"
