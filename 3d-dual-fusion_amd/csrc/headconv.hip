@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
   const int b = tile / (a.tiles_x * a.tiles_y), t2 = tile - b * (a.tiles_x * a.tiles_y);
   const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
   const int y0 = ty * HF_TILE - 1, x0 = tx * HF_TILE - 1;
-  // ---- halo -> LDS: item = (halo pixel, 8-channel block): 32 B of split row = hi 8 x bf16 | lo 8 x bf16.  All loads of a
+  // ---- halo -> LDS: item = (halo pixel, 8-channel block): 32 B of split row = hi 8 x fp16 | lo 8 x fp16 (round 5; bf16 pairs before).  All loads of a
   //      thread are issued before the first conversion (independent addresses: one memory round trip, not four) ----
   constexpr int ITEMS = HF_HP * 8, PER = (ITEMS + 255) / 256;
   u32x4 hi[PER], lo[PER];
@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
 
 // ---- round 3: the same convolutions on the matrix cores, "multiply, then shift" ---------------------------------------------
 // head_final_kernel is bound by its vector ALU, not by memory (tools/ubench/head_final.py: 150 us with the loads, 122 us
-// without them): unpacking the bf16 halves costs as many instructions as the 576 FMAs per pixel, all of them at one wave64
-// instruction per 4 clocks.  The split rows ARE matrix-core operands, though: 16 bytes of a row = 8 bf16 channels = what one
-// lane of v_mfma_f32_16x16x32_bf16 holds of its A operand.  Contracting over the 576 = 9 taps x 64 channels directly would
+// without them): unpacking the 16-bit halves costs as many instructions as the 576 FMAs per pixel, all of them at one wave64
+// instruction per 4 clocks.  The split rows ARE matrix-core operands, though: 16 bytes of a row = 8 fp16 channels = what one
+// lane of v_mfma_f32_16x16x32_f16 holds of its A operand.  Contracting over the 576 = 9 taps x 64 channels directly would
 // make every activation an operand nine times (and the k <= 4 output maps fill 4 of the 16 columns).  Instead the taps go
 // into the COLUMNS: for every pixel q of a 16 x 16 halo tile
 //     D[q][tap * 4 + j] = sum_c M[q][c] * W[tap][c][j]          (256 x 64 times 64 x 36: each activation is an operand ONCE,

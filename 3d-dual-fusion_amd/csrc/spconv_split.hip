@@ -24,6 +24,7 @@
 // name, the item list is built by 32 lanes instead of one, and the epilogue can emit the split rows of its
 // output for the next convolution.
 #include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 
 #include "common.h"
@@ -113,6 +114,66 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nblk) return;
   f32x4 a = ((const f32x4 *)x)[2 * i], b = ((const f32x4 *)x)[2 * i + 1];
+  u32x4 ho, lo;
+  split_pair(a[0], a[1], ho[0], lo[0]);
+  split_pair(a[2], a[3], ho[1], lo[1]);
+  split_pair(b[0], b[1], ho[2], lo[2]);
+  split_pair(b[2], b[3], ho[3], lo[3]);
+  out[2 * i] = ho;
+  out[2 * i + 1] = lo;
+}
+
+// ---- gradient rows -> split rows under a per-tensor power-of-two scale (round 5, training) -----------------------------------
+// The fp16 pair format holds activations (|x| < 2047 at the fixed scale 2^5) but not gradients, whose magnitude is set by the loss:
+// rounds 4-5 ran the input-gradient convolutions on three bf16 parts (six products, ~3x the two-part kernel's time on the
+// 64-channel layers).  A gradient TENSOR has a narrow range relative to its own largest value, though: scaled by the power of two
+// that puts its largest |value| into [512, 1024), every entry >= 2^-19 of that maximum keeps its 22 bits and smaller ones are
+// off by <= 2^-40 of the maximum -- fp32-grade "of scale", which is what the parity bounds measure.  rows_absmax_kernel reduces
+// |x| into one word (fp32 bit patterns of non-negative values order like unsigned integers), pow2_scale_kernel turns it into
+// s = 2^k and a [channels] vector of 1 / s for the convolution's epilogue, split_rows_scaled_kernel splits s * x.
+// inf / NaN: the scale stays 1 and the checked split raises the range flag.
+__global__ __launch_bounds__(256) void rows_absmax_kernel(const float *__restrict__ x, size_t n4, size_t n, unsigned *__restrict__ out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4 *)x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    if (!(v[0] == v[0]) || !(v[1] == v[1]) || !(v[2] == v[2]) || !(v[3] == v[3])) m = __builtin_inff();   // NaN must not hide
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, __builtin_fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (m > 0.f) atomicMax(out, __float_as_uint(m));            // one atomic per workgroup
+  }
+}
+
+__global__ __launch_bounds__(256) void pow2_scale_kernel(const unsigned *__restrict__ amax_bits, int channels, float *__restrict__ scale,
+                                                         float *__restrict__ inv) {
+  const float amax = __uint_as_float(*amax_bits);
+  float s = 1.f;
+  if (amax > 0.f && amax < __builtin_inff()) {
+    // exponent e of amax (amax in [2^e, 2^(e+1))): s = 2^(9 - e) puts it into [512, 1024); clamped to fp32's normal range
+    int e = (int)((*amax_bits >> 23) & 0xffu) - 127;
+    int k = 9 - e;
+    k = k > 120 ? 120 : (k < -120 ? -120 : k);
+    s = __uint_as_float((unsigned)(k + 127) << 23);
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *scale = s;
+  if (i < channels) inv[i] = 1.f / s;
+}
+
+__global__ __launch_bounds__(256) void split_rows_scaled_kernel(const float *__restrict__ x, size_t nblk, const float *__restrict__ scale,
+                                                                u32x4 *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblk) return;
+  const float s = *scale;
+  f32x4 a = ((const f32x4 *)x)[2 * i] * s, b = ((const f32x4 *)x)[2 * i + 1] * s;
   u32x4 ho, lo;
   split_pair(a[0], a[1], ho[0], lo[0]);
   split_pair(a[2], a[3], ho[1], lo[1]);
@@ -1909,6 +1970,28 @@ extern "C" int df3d_conv_pack_weights_groups(const float *filters, int groups, i
   size_t total = (size_t)groups * kvol * cin * cout / 4;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, stream, filters, groups * kvol,
                      cin, cout, split_layout(cin, cout), (u32x4 *)packed);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_split_rows_scaled(const float *features, long long n, int c, void *split, float *scale, float *inv_scale,
+                                      int inv_channels, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(features && split && scale && inv_scale, "split_rows_scaled: null argument");
+  DF3D_CHECK_ARG(c > 0 && c % 8 == 0 && n >= 0 && inv_channels >= 1, "split_rows_scaled: channels must be a multiple of 8 (got %d)", c);
+  DF3D_CHECK_ARG((size_t)features % 16 == 0, "split_rows_scaled: rows must be 16-byte aligned");
+  const size_t ne = (size_t)n * c, nblk = ne / 8;
+  // scale[1] is the reduction word (bit pattern of the largest |value|)
+  DF3D_HIP(hipMemsetAsync(scale + 1, 0, sizeof(float), stream));
+  if (ne) {
+    const int wgs = (int)std::min<size_t>(512, cdiv((long long)(ne / 4), 256 * 4) + 1);
+    hipLaunchKernelGGL(rows_absmax_kernel, dim3(wgs), dim3(256), 0, stream, features, ne / 4, ne, (unsigned *)(scale + 1));
+  }
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(cdiv(inv_channels, 256)), dim3(256), 0, stream, (const unsigned *)(scale + 1),
+                     inv_channels, scale, inv_scale);
+  if (nblk)
+    hipLaunchKernelGGL(split_rows_scaled_kernel, dim3(cdiv((long long)nblk, 256)), dim3(256), 0, stream, features, nblk, scale,
+                       (u32x4 *)split);
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

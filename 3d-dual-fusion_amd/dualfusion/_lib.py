@@ -120,6 +120,7 @@ SIGNATURES = {
     "df3d_bn_rows_backward": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
     "df3d_conv_pack_weights_groups": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_split_rows_scaled": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "df3d_split_rows": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p]),
     "df3d_sparse_conv_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,

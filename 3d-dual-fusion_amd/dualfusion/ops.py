@@ -547,6 +547,21 @@ def split_rows(features):
     return out
 
 
+def split_rows_scaled(features, inv_channels):
+    """Gradient rows -> (two-part split rows of s * features, inv [inv_channels] = 1 / s each, scale [2]) with s the power of two
+    that puts the largest |value| of the tensor into [512, 1024) (df3d_split_rows_scaled).  A convolution over these rows with
+    `scale=inv` returns the unscaled result."""
+    lib = _lib.load()
+    _chk(features, torch.float32, "features")
+    n, c = features.shape
+    out = torch.empty((n, 4 * c), dtype=torch.uint8, device=features.device)
+    scale = torch.empty((2,), dtype=torch.float32, device=features.device)
+    inv = torch.empty((int(inv_channels),), dtype=torch.float32, device=features.device)
+    rc = lib.df3d_split_rows_scaled(_ptr(features), n, c, _ptr(out), _ptr(scale), _ptr(inv), int(inv_channels), _stream())
+    _lib.check(rc, "df3d_split_rows_scaled")
+    return out, inv, scale
+
+
 def sparse_conv_split(features_split, packed, nbr, n_out, cin, cout, bias=None, scale=None, shift=None,
                       residual=None, relu=False, tiles=None, emit_split=True, order=None):
     """Split-precision twin of sparse_conv_fused.  Returns (out fp32 [n_out, cout], split rows of out or None).
@@ -705,6 +720,14 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=
             inv = invert_neighbors(nbr, n_in)
     wt = filters.transpose(1, 2).contiguous()                     # [K, cout, cin]
     cout, cin = wt.shape[1], wt.shape[2]
+    if (CONV_PRECISION == "split" and not bf16 and cout % 8 == 0 and conv_split_supported(K, cout, cin)
+            and os.environ.get("DF3D_GRAD_SCALED", "1") != "0"):
+        # (round 5, second half) two-part rows of the gradient under ITS OWN power-of-two scale instead of three bf16 parts: a
+        # gradient tensor is narrow relative to its largest value, whatever that is; the convolution's epilogue multiplies by
+        # 1 / s.  DF3D_GRAD_SCALED=0: the three-part path below
+        gs, inv_s, _ = split_rows_scaled(grad_out, cin)
+        g_in, _ = sparse_conv_split(gs, conv_pack_weights(wt), inv, n_in, cout, cin, scale=inv_s, emit_split=False)
+        return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr)
     with grad_precision():
         if bf16 and conv_bf16_supported(K, cout, cin):
             g_in, _ = sparse_conv_bf16(rows_to_bf16(grad_out), conv_pack_weights_bf16(wt), inv, n_in, cout, cin, want_f32=True,

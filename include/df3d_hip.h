@@ -739,6 +739,13 @@ int df3d_conv_pack_weights(const float *filters, int kvol, int cin, int cout, vo
 int df3d_conv_pack_weights_groups(const float *filters, int groups, int kvol, int cin, int cout, void *packed,
                                  void *stream);
 int df3d_split_rows(const float *features, long long n, int c, void *split, void *stream);
+/* Gradient rows (training): features [n][c] fp32 -> split rows of s * features, s = the power of two that puts the tensor's largest
+ * |value| into [512, 1024) (a per-tensor block scale: the fixed-scale fp16 pair format holds activations, not gradients of arbitrary
+ * magnitude).  scale [2] receives s in its first entry (the second is the reduction's workspace), inv_scale [inv_channels] receives 1 / s in every entry -- the per-channel `scale` vector of the
+ * convolution that consumes the rows (its epilogue multiplies by it: exact, a power of two).  Replaces the three-bf16-part rows of
+ * the input-gradient convolutions (indice_conv_backward's data gradient, spconv_ops.h:363-456). */
+int df3d_split_rows_scaled(const float *features, long long n, int c, void *split, float *scale, float *inv_scale, int inv_channels,
+                           void *stream);
 int df3d_sparse_conv_split(const void *features_split, int n_in, int cin, const void *packed_filters, int kvol,
                            int cout, const int32_t *nbr, int n_out, const float *bias, const float *scale,
                            const float *shift, const float *residual, int relu, float *out, void *out_split,

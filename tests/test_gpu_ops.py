@@ -1011,6 +1011,56 @@ def test_rows_grad_weights_against_float64(n, cin, cout, gscale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gscale", [1.0, 1e-9, 3e+7])
+def test_input_gradient_on_block_scaled_two_part_rows(gscale):
+    """ops.sparse_conv_backward in the "split" mode: the gradient rows are split into fp16 pairs under their own power-of-two
+    scale (df3d_split_rows_scaled) and the convolution's epilogue undoes it -- against float64, for gradient tensors of very
+    different magnitudes (the fixed-scale split would underflow at 1e-9 and overflow at 3e+7), with entries spread over twelve
+    decades inside one tensor, and against the three-bf16-part path (DF3D_GRAD_SCALED=0); the range flag stays clear."""
+    import os
+    from dualfusion import ops
+    if ops.CONV_PRECISION != "split":
+        pytest.skip("the block scale replaces the three-part rows of the split mode")
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    K, cin, cout, n = 27, 64, 128, 6000
+    # (a rulebook pairs an input with at most one output per offset: a permutation per offset, thinned)
+    nbr = torch.stack([torch.randperm(n, generator=gen) for _ in range(K)]).to(torch.int32)
+    nbr[torch.rand((K, n), generator=gen) >= 0.4] = -1
+    feats = torch.randn((n, cin), generator=gen)
+    filt = torch.randn((K, cin, cout), generator=gen) * 0.1
+    g = torch.randn((n, cout), generator=gen) * gscale
+    g[::3] *= 1e-6                                               # a third of the rows a million times smaller
+    g[1::7] *= 1e-12
+    inv = ops.invert_neighbors(nbr.to(dev), n)
+    ref = torch.zeros((n, cin), dtype=torch.float64)
+    for k in range(K):
+        o = (nbr[k] >= 0).nonzero(as_tuple=True)[0]
+        ref.index_add_(0, nbr[k][o].long(), g[o].double() @ filt[k].double().t())
+    got, _ = ops.sparse_conv_backward(feats.to(dev), filt.to(dev), g.to(dev), nbr.to(dev), subm=False, inv=inv)
+    scale = float(ref.abs().max())
+    assert float((got.cpu().double() - ref).abs().max()) <= 4e-6 * scale
+    old = os.environ.get("DF3D_GRAD_SCALED")
+    os.environ["DF3D_GRAD_SCALED"] = "0"
+    try:
+        three, _ = ops.sparse_conv_backward(feats.to(dev), filt.to(dev), g.to(dev), nbr.to(dev), subm=False, inv=inv)
+    finally:
+        if old is None:
+            os.environ.pop("DF3D_GRAD_SCALED", None)
+        else:
+            os.environ["DF3D_GRAD_SCALED"] = old
+    assert float((three.cpu().double() - ref).abs().max()) <= 4e-6 * scale
+    assert not ops.split_overflow(reset=True)[0]
+    # an all-zero gradient and one with an infinity: scale 1; the infinity is reported, not swallowed
+    z, _ = ops.sparse_conv_backward(feats.to(dev), filt.to(dev), torch.zeros_like(g).to(dev), nbr.to(dev), subm=False, inv=inv)
+    assert float(z.abs().max()) == 0.0
+    g2 = g.clone()
+    g2[5, 3] = float("inf")
+    ops.sparse_conv_backward(feats.to(dev), filt.to(dev), g2.to(dev), nbr.to(dev), subm=False, inv=inv)
+    assert ops.split_overflow(reset=True)[0]
+
+
+@pytest.mark.gpu
 def test_linear_module_and_gate_weight_gradients_on_native_kernels():
     """dualfusion.linear_rows.Linear (forward = F.linear; weight gradient on df3d_rows_grad_weights) and the one-output
     channel-first gate (`ops.channel_first_linear`, weight gradient on df3d_chanfirst_dot) against torch's autograd in float64:
