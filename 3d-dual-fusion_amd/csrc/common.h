@@ -118,6 +118,11 @@ __device__ __forceinline__ void split_pair_f16_ref(float x0, float x1, float s, 
   do {                                                                                        \
     if (__builtin_expect(!((AMAX) * DF3D_SA_SCALE <= 65504.f), 0)) atomicOr(&df3d::g_split_overflow_tu, 1u); \
   } while (0)
+// (AMAX already carries the operand's scale)
+#define split_range_flag_scaled(AMAX)                                                         \
+  do {                                                                                        \
+    if (__builtin_expect(!((AMAX) <= 65504.f), 0)) atomicOr(&df3d::g_split_overflow_tu, 1u);  \
+  } while (0)
 // weights / filters (packed once per parameter version)
 #define split_pair_w(x0, x1, HI, LO) DF3D_SPLIT_PAIR_(x0, x1, DF3D_SW_SCALE, true, HI, LO)
 #define split_pair_bf16(x0, x1, HI, LO)                  \

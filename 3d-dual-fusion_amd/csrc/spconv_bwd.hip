@@ -24,6 +24,8 @@ namespace df3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+DF3D_SPLIT_OVERFLOW_TU(spconv_bwd)
+
 __global__ __launch_bounds__(256) void invert_fill_kernel(int32_t *__restrict__ inv, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) inv[i] = -1;
@@ -115,6 +117,7 @@ struct WgradArgs {
   int n_out, cin, cout, slice, tiles_n, tiles, kvol, slices;
   unsigned char order[DF3D_MAX_KVOL];   // offsets, the ones with the most pairs first
   int dbg;                              // wgrad_split3_kernel tuning experiments (DF3D_W3_DBG): 1 no atomics, 2 no MFMAs, 4 no split + LDS stores
+  const float *sa, *sg;                 // two-part form: device scales of `feat` / `gout` (NULL: the fixed activation scale 2^5)
 };
 
 constexpr int WG_STAGE = 16, WG_BATCH = 256, WG_LIST = WG_BATCH + 64;
@@ -334,7 +337,11 @@ __device__ __forceinline__ void w3_split_pair(float x0, float x1, unsigned &hi, 
   hi = h, mid = m, lo = l;
 }
 
-template <int WM, int WN>
+// NP = 2 (second half of round 5): fp16 PAIRS instead of three bf16 parts -- three products, two stored parts.  Activations
+// carry the fixed scale 2^5 of every split kernel; a gradient operand carries the power-of-two block scale of its tensor
+// (df3d_split_rows_scaled computes it for the input-gradient convolution of the same layer: a.sa / a.sg point at it), and the
+// accumulators are multiplied by 1 / (sa sg) on their way out.  Same staging, same transposing reads, half the MFMAs.
+template <int WM, int WN, int NP>
 __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs a) {
   constexpr int NT = 64 * WM * WN, NWV = WM * WN, TM = 64 * WM, TN = 64 * WN, ST = W3_STAGE;
   // LDS image of one part: row `r` (a pair) at r * RB + (r >> 3) * 128, its 32-byte slots XOR-ed with (r & 3): a
@@ -344,11 +351,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
   constexpr int PA = ST * (TM / 4) / NT, PG = ST * (TN / 4) / NT;  // 4-channel pieces per thread and stage
   static_assert(ST * (TM / 4) % NT == 0 && ST * (TN / 4) % NT == 0, "pieces divide over the workgroup");
   extern __shared__ __align__(16) unsigned char w3_smem[];
-  unsigned char *imA = w3_smem, *imG = imA + 3 * IMA;
-  int *li = (int *)(imG + 3 * IMG), *lo = li + W3_LIST;
+  unsigned char *imA = w3_smem, *imG = imA + NP * IMA;
+  int *li = (int *)(imG + NP * IMG), *lo = li + W3_LIST;
   int *s_pop = lo + W3_LIST;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float sca = (NP == 2) ? (a.sa ? *a.sa : DF3D_SA_SCALE) : 1.f, scg = (NP == 2) ? (a.sg ? *a.sg : DF3D_SA_SCALE) : 1.f;
+  float amax = 0.f;                                              // largest |scaled value| split here (two-part form: range flag)
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int slices_x = (a.slices + 7) >> 3, per_k = slices_x * a.tiles;
   const int kr = j / per_k, rest = j - kr * per_k;
@@ -387,25 +396,35 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
       okm |= (ia >= 0 && c < a.cout) ? 1u << (16 + q) : 0u;
     }
   };
-  auto put = [&](unsigned char *im, int rb, int imb, int pair, int c4, f32x4 v) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    w3_split_pair(v[0], v[1], h0, m0, l0);
-    w3_split_pair(v[2], v[3], h1, m1, l1);
+  auto put = [&](unsigned char *im, int rb, int imb, int pair, int c4, f32x4 v, float sc) {
     unsigned char *d = im + pair * rb + (pair >> 3) * 128 + ((c4 * 8) ^ ((pair & 3) * 32));
-    *(w3_u32x2 *)d = (w3_u32x2){h0, h1};
-    *(w3_u32x2 *)(d + imb) = (w3_u32x2){m0, m1};
-    *(w3_u32x2 *)(d + 2 * imb) = (w3_u32x2){l0, l1};
+    if constexpr (NP == 2) {
+      unsigned h0, l0, h1, l1;
+      v *= sc;
+      amax = fmaxf(amax, fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+      split_pair_f16_ref<false>(v[0], v[1], 1.f, h0, l0);
+      split_pair_f16_ref<false>(v[2], v[3], 1.f, h1, l1);
+      *(w3_u32x2 *)d = (w3_u32x2){h0, h1};
+      *(w3_u32x2 *)(d + imb) = (w3_u32x2){l0, l1};
+    } else {
+      unsigned h0, m0, l0, h1, m1, l1;
+      w3_split_pair(v[0], v[1], h0, m0, l0);
+      w3_split_pair(v[2], v[3], h1, m1, l1);
+      *(w3_u32x2 *)d = (w3_u32x2){h0, h1};
+      *(w3_u32x2 *)(d + imb) = (w3_u32x2){m0, m1};
+      *(w3_u32x2 *)(d + 2 * imb) = (w3_u32x2){l0, l1};
+    }
   };
   auto stash = [&]() {
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int p = tid + NT * q, pair = p / (TM / 4);
-      put(imA, RBA, IMA, pair, p - pair * (TM / 4), (okm >> q & 1u) ? ra[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+      put(imA, RBA, IMA, pair, p - pair * (TM / 4), (okm >> q & 1u) ? ra[q] : (f32x4){0.f, 0.f, 0.f, 0.f}, sca);
     }
 #pragma unroll
     for (int q = 0; q < PG; ++q) {
       const int p = tid + NT * q, pair = p / (TN / 4);
-      put(imG, RBG, IMG, pair, p - pair * (TN / 4), (okm >> (16 + q) & 1u) ? rg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+      put(imG, RBG, IMG, pair, p - pair * (TN / 4), (okm >> (16 + q) & 1u) ? rg[q] : (f32x4){0.f, 0.f, 0.f, 0.f}, scg);
     }
   };
   typedef __attribute__((address_space(3))) w3_s16x4 *lds_tr_ptr;
@@ -422,7 +441,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
   const unsigned char *abase = imA + (g * 8 + (li16 >> 2)) * RBA + g * 128 + wm * 128 + (li16 & 3) * 8;
   const unsigned char *gbase = imG + (g * 8 + (li16 >> 2)) * RBG + g * 128 + wn * 128 + (li16 & 3) * 8;
 #define W3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+#define W2_MFMA(A, B, C) DF3D_MFMA_F16(A, B, C)
   auto compute = [&]() {
+    if constexpr (NP == 2) {
+      w3_bf16x8 af[4][2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) af[mt][p] = frag(abase, RBA, IMA, mt, p);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const w3_bf16x8 b0 = frag(gbase, RBG, IMG, nt, 0), b1 = frag(gbase, RBG, IMG, nt, 1);
+        // lo*hi, hi*lo, hi*hi: the summation order of every two-part kernel
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W2_MFMA(af[mt][1], b0, acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W2_MFMA(af[mt][0], b1, acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W2_MFMA(af[mt][0], b0, acc[mt][nt]);
+      }
+      return;
+    }
     w3_bf16x8 af[4][3];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -447,6 +486,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
       for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W3_MFMA(af[mt][0], b0, acc[mt][nt]);
     }
   };
+#undef W2_MFMA
 #undef W3_MFMA
 
   int cnt = 0, next = r0;
@@ -502,7 +542,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
     cnt = rem;
     __syncthreads();
   }
+  if (NP == 2) split_range_flag_scaled(amax);
   if (!had || (a.dbg & 1)) return;
+  const float unscale = NP == 2 ? 1.f / (sca * scg) : 1.f;
   // every wave owns its 64 x 64 block: one atomic add per element and workgroup
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
@@ -511,18 +553,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ci = ci0 + wm * 64 + mt * 16 + 4 * g + r, co = co0 + wn * 64 + nt * 16 + li16;
-        const float v = acc[mt][nt][r];
+        const float v = acc[mt][nt][r] * unscale;
         if (v != 0.f && ci < a.cin && co < a.cout) unsafeAtomicAdd(a.gw + ((size_t)k * a.cin + ci) * a.cout + co, v);
       }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int NP>
 static int launch_wgrad3(const WgradArgs &a, int kvol, hipStream_t stream) {
   constexpr int TM = 64 * WM, TN = 64 * WN;
-  constexpr size_t lds = (size_t)3 * (W3_STAGE * (TM * 2 + TN * 2) + 1024) + (size_t)(2 * W3_LIST + 8) * sizeof(int);
+  constexpr size_t lds = (size_t)NP * (W3_STAGE * (TM * 2 + TN * 2) + 1024) + (size_t)(2 * W3_LIST + 8) * sizeof(int);
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void *)wgrad_split3_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)wgrad_split3_kernel<WM, WN, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("wgrad_split3: cannot raise the dynamic LDS limit");
       return DF3D_EHIP;
     }
@@ -545,15 +587,20 @@ static int launch_wgrad3(const WgradArgs &a, int kvol, hipStream_t stream) {
     std::stable_sort(b.order, b.order + kvol, [&](unsigned char x, unsigned char y) { return norm(x) < norm(y); });
   }
   const dim3 grid(8 * cdiv(b.slices, 8) * kvol * b.tiles);
-  hipLaunchKernelGGL((wgrad_split3_kernel<WM, WN>), grid, dim3(64 * WM * WN), lds, stream, b);
+  hipLaunchKernelGGL((wgrad_split3_kernel<WM, WN, NP>), grid, dim3(64 * WM * WN), lds, stream, b);
   return DF3D_OK;
 }
 
-static int launch_wgrad3_any(const WgradArgs &a, int kvol, hipStream_t stream) {
-  if (a.cin >= 128 && a.cout >= 128) return launch_wgrad3<2, 2>(a, kvol, stream);
-  if (a.cin >= 128) return launch_wgrad3<2, 1>(a, kvol, stream);
-  if (a.cout >= 128) return launch_wgrad3<1, 2>(a, kvol, stream);
-  return launch_wgrad3<1, 1>(a, kvol, stream);
+template <int NP>
+static int launch_wgrad3_np(const WgradArgs &a, int kvol, hipStream_t stream) {
+  if (a.cin >= 128 && a.cout >= 128) return launch_wgrad3<2, 2, NP>(a, kvol, stream);
+  if (a.cin >= 128) return launch_wgrad3<2, 1, NP>(a, kvol, stream);
+  if (a.cout >= 128) return launch_wgrad3<1, 2, NP>(a, kvol, stream);
+  return launch_wgrad3<1, 1, NP>(a, kvol, stream);
+}
+// parts = 2: fp16 pairs (a.sa / a.sg = device scales or NULL); 3: bf16 triples
+static int launch_wgrad3_any(const WgradArgs &a, int kvol, hipStream_t stream, int parts = 3) {
+  return parts == 2 ? launch_wgrad3_np<2>(a, kvol, stream) : launch_wgrad3_np<3>(a, kvol, stream);
 }
 
 template <int RT>
@@ -643,6 +690,49 @@ extern "C" int df3d_rows_grad_weights(const float *x, const float *grad_out, lon
   DF3D_CHECK_ARG(x && grad_out, "rows_grad_weights: null argument");
   WgradArgs a{x, grad_out, nullptr, grad_weights, (int)n, cin, cout, 0, 1, 0, 0, 0, {0}};
   int rc = launch_wgrad3_any(a, 1, stream);
+  if (rc) return rc;
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+// Two-part forms (second half of round 5): fp16 pairs, three products.  grad_scale / x_scale / g_scale point at the power-of-two
+// block scale of a GRADIENT operand (df3d_split_rows_scaled / df3d_rows_pow2_scale write it); NULL = an activation operand at
+// the fixed scale 2^5 of every split kernel.
+extern "C" int df3d_sparse_conv_grad_filters_scaled(const float *features, int n_in, int cin, const float *grad_out, int n_out,
+                                                    int cout, const int32_t *nbr, int kvol, const float *grad_scale,
+                                                    float *grad_filters, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const char *env = getenv("DF3D_WGRAD");                    // (a forced kernel choice: the unscaled entry decides)
+  // measured (tools/ubench/wgrad3_probe.py, us: exact-fp32 kernel / three bf16 parts / this): conv4 128 -> 128 K = 27 226 / 167 /
+  // 117, conv3 64 -> 64 116 / 147 / 96, dense 3 x 3 256 -> 128 202 / 175 / 127, 512 -> 64 202 / 208 / 146, the head's 64 -> 36 x 64
+  // 1254 / 918 / 582; 32 -> 32 K = 27 40 / 149 / 107: the 64-wide blocks are half empty there -- the fp32 kernel keeps < 64 channels
+  const bool fits = cin % 4 == 0 && cout % 4 == 0 && cin >= 64 && cout >= 64 && grad_scale;
+  if (env || !fits)
+    return df3d_sparse_conv_grad_filters(features, n_in, cin, grad_out, n_out, cout, nbr, kvol, grad_filters, stream_);
+  DF3D_CHECK_ARG(kvol > 0 && kvol <= DF3D_MAX_KVOL && n_in >= 0 && n_out >= 0, "sparse_conv_grad_filters_scaled: bad sizes");
+  DF3D_CHECK_ARG(grad_filters, "sparse_conv_grad_filters_scaled: null output");
+  DF3D_HIP(hipMemsetAsync(grad_filters, 0, (size_t)kvol * cin * cout * sizeof(float), stream));
+  if (n_out == 0 || n_in == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(features && grad_out && nbr, "sparse_conv_grad_filters_scaled: null argument");
+  WgradArgs a{features, grad_out, nbr, grad_filters, n_out, cin, cout, 0, 1, 0, 0, 0, {0}};
+  a.sa = nullptr, a.sg = grad_scale;
+  int rc = launch_wgrad3_any(a, kvol, stream, 2);
+  if (rc) return rc;
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_rows_grad_weights_scaled(const float *x, const float *grad_out, long long n, int cin, int cout,
+                                             const float *x_scale, const float *g_scale, float *grad_weights, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(grad_weights && cin > 0 && cout > 0 && n >= 0 && n < (1ll << 31), "rows_grad_weights_scaled: bad sizes");
+  DF3D_CHECK_ARG(cin % 4 == 0 && cout % 4 == 0, "rows_grad_weights_scaled: channel counts must be multiples of 4 (got %d, %d)", cin, cout);
+  DF3D_HIP(hipMemsetAsync(grad_weights, 0, (size_t)cin * cout * sizeof(float), stream));
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(x && grad_out, "rows_grad_weights_scaled: null argument");
+  WgradArgs a{x, grad_out, nullptr, grad_weights, (int)n, cin, cout, 0, 1, 0, 0, 0, {0}};
+  a.sa = x_scale, a.sg = g_scale;
+  int rc = launch_wgrad3_any(a, 1, stream, 2);
   if (rc) return rc;
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;

@@ -1996,6 +1996,21 @@ extern "C" int df3d_split_rows_scaled(const float *features, long long n, int c,
   return DF3D_OK;
 }
 
+extern "C" int df3d_rows_pow2_scale(const float *x, long long n_elems, float *scale, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(x && scale && n_elems >= 0, "rows_pow2_scale: bad argument");
+  DF3D_CHECK_ARG((size_t)x % 16 == 0, "rows_pow2_scale: rows must be 16-byte aligned");
+  const size_t ne = (size_t)n_elems;
+  DF3D_HIP(hipMemsetAsync(scale + 1, 0, sizeof(float), stream));
+  if (ne) {
+    const int wgs = (int)std::min<size_t>(512, cdiv((long long)(ne / 4), 256 * 4) + 1);
+    hipLaunchKernelGGL(rows_absmax_kernel, dim3(wgs), dim3(256), 0, stream, x, ne / 4, ne, (unsigned *)(scale + 1));
+  }
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(256), 0, stream, (const unsigned *)(scale + 1), 0, scale, scale);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
 extern "C" int df3d_split_rows(const float *features, long long n, int c, void *split, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(features && split, "split_rows: null argument");

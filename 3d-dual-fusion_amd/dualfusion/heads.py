@@ -81,15 +81,16 @@ class _BranchConvFunction(torch.autograd.Function):
         if _ops.CONV_PRECISION == "split" and os.environ.get("DF3D_GRAD_SCALED", "1") != "0":
             # (round 5) the gradient rows as fp16 pairs under their own power-of-two scale; the epilogue multiplies by 1 / s
             packed_t = _ops.conv_pack_weights_groups(w.detach().float().transpose(2, 3).contiguous())
-            gs, inv_s, _ = _ops.split_rows_scaled(go, G * cin)
+            gs, inv_s, g_sc = _ops.split_rows_scaled(go, G * cin)
             part, _ = _ops.conv_rows_split(gs, cout, cout, packed_t, cin, G, nbr_mirror, P, None, inv_s, None, relu=False)
         else:
+            g_sc = None
             with _ops.grad_precision():       # (gradient rows: three bf16 parts in the fp16-split mode)
                 packed_t = _ops.conv_pack_weights_groups(w.detach().float().transpose(2, 3).contiguous())
                 part, _ = _ops.conv_rows_split(_ops.split_rows(go), cout, cout, packed_t, cin, G, nbr_mirror, P, None, None, None,
                                                relu=False)
         g_rows = part.view(P, G, cin).sum(1)
-        g_w = _ops.sparse_conv_grad_filters(rows.contiguous(), go, nbr)            # [K, cin, G * cout]
+        g_w = _ops.sparse_conv_grad_filters(rows.contiguous(), go, nbr, grad_scale=g_sc)            # [K, cin, G * cout]
         g_w = g_w.view(K, cin, G, cout).permute(2, 0, 1, 3)
         g_b = go.sum(0) if ctx.has_bias else None
         return g_rows, g_w, g_b, None, None

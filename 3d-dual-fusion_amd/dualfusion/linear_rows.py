@@ -5,8 +5,8 @@ layer; ms_deform_attn.py:60-64: sampling offsets, attention weights, value and o
 weight gradient grad^T x is a [C_out x rows] . [rows x C_in] product -- a contraction over the ROWS, where the library's fp32
 GEMM runs at a fifth of its rate (and, for inputs with a batch dimension, as a batched product plus a sum over the batch).
 `Linear` is a drop-in subclass (same parameters, same state_dict keys, same forward values -- the forward IS F.linear); only
-the backward differs: grad_input = grad W (library GEMM), grad_weight = df3d_rows_grad_weights(grad, x) -- three bf16 parts per
-operand, six products, fp32 accumulate: fp32-grade at fp32's exponent range (tests/test_gpu_ops.py::test_rows_grad_weights…),
+the backward differs: grad_input = grad W (library GEMM), grad_weight = df3d_rows_grad_weights_scaled(grad, x) -- fp16 pairs, the
+gradient under its own power-of-two block scale, three products, fp32 accumulate: fp32-grade of scale (tests/test_gpu_ops.py),
 grad_bias = column sums.  DF3D_LINEAR_WGRAD=0 keeps autograd's own backward (A/B switch, read per call)."""
 import os
 
@@ -34,10 +34,9 @@ class _LinearFunction(torch.autograd.Function):
             x2 = x.reshape(-1, x.shape[-1])
             g2c, x2c = g2.contiguous(), x2.contiguous()
             if g2c.shape[1] % 4:                      # (a gate with one output: columns padded to the kernel's 4-channel pieces)
-                pad = (-g2c.shape[1]) % 4
-                gw = _ops.rows_grad_weights(torch.nn.functional.pad(g2c, (0, pad)), x2c)[:g2c.shape[1]]
-            else:
-                gw = _ops.rows_grad_weights(g2c, x2c)
+                g2c = torch.nn.functional.pad(g2c, (0, (-g2c.shape[1]) % 4))
+            # two-part operands: the gradient under its own power-of-two block scale, the activation at the fixed scale
+            gw = _ops.rows_grad_weights(g2c, x2c, x_scale=_ops.rows_pow2_scale(g2c))[:g2.shape[1]]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb

@@ -670,8 +670,20 @@ def invert_neighbors(nbr, n_in):
     return inv
 
 
-def sparse_conv_grad_filters(features, grad_out, nbr):
-    """-> grad_filters [K, cin, cout] = sum over rulebook pairs of features[in]^T grad_out[out]."""
+def rows_pow2_scale(x):
+    """-> float32 [2] on the device: [0] = the power of two s with max |x| * s in [512, 1024) (1 for an all-zero or non-finite
+    tensor), [1] = workspace (df3d_rows_pow2_scale).  The block scale of a gradient operand of the two-part kernels."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    scale = torch.empty((2,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.df3d_rows_pow2_scale(_ptr(x), int(x.numel()), _ptr(scale), _stream()), "df3d_rows_pow2_scale")
+    return scale
+
+
+def sparse_conv_grad_filters(features, grad_out, nbr, grad_scale=None):
+    """-> grad_filters [K, cin, cout] = sum over rulebook pairs of features[in]^T grad_out[out].
+    grad_scale: device scale of grad_out (`split_rows_scaled(...)[2]` / `rows_pow2_scale`): the two-part kernel
+    (df3d_sparse_conv_grad_filters_scaled) where it applies."""
     lib = _lib.load()
     _chk(features, torch.float32, "features")
     _chk(grad_out, torch.float32, "grad_out")
@@ -681,15 +693,24 @@ def sparse_conv_grad_filters(features, grad_out, nbr):
         raise ValueError("grad_out rows do not match the neighbour table")
     cin, cout = features.shape[1], grad_out.shape[1]
     gw = torch.empty((K, cin, cout), dtype=torch.float32, device=features.device)
+    if (grad_scale is not None and os.environ.get("DF3D_GRAD_SCALED", "1") != "0"
+            and os.environ.get("DF3D_WGRAD_SCALED", "1") != "0"):        # (A/B switch of the two-part filter gradient alone)
+        _chk(grad_scale, torch.float32, "grad_scale")
+        rc = lib.df3d_sparse_conv_grad_filters_scaled(_ptr(features), features.shape[0], cin, _ptr(grad_out), n_out, cout,
+                                                      _ptr(nbr), K, _ptr(grad_scale), _ptr(gw), _stream())
+        _lib.check(rc, "df3d_sparse_conv_grad_filters_scaled")
+        return gw
     rc = lib.df3d_sparse_conv_grad_filters(_ptr(features), features.shape[0], cin, _ptr(grad_out), n_out, cout, _ptr(nbr),
                                            K, _ptr(gw), _stream())
     _lib.check(rc, "df3d_sparse_conv_grad_filters")
     return gw
 
 
-def rows_grad_weights(x, grad_out):
+def rows_grad_weights(x, grad_out, x_scale=None, g_scale=None, two_part=False):
     """-> [cin, cout] = x^T grad_out over rows (df3d_rows_grad_weights: three bf16 parts per operand, six products, fp32
-    accumulate).  The weight gradient of y = x W^T is rows_grad_weights(grad_y, x)."""
+    accumulate).  The weight gradient of y = x W^T is rows_grad_weights(grad_y, x).
+    two_part (or a scale given): fp16 pairs, three products (df3d_rows_grad_weights_scaled): `x_scale` / `g_scale` = device block
+    scale of a gradient operand (`rows_pow2_scale`), None = an activation operand at the fixed scale."""
     lib = _lib.load()
     _chk(x, torch.float32, "x")
     _chk(grad_out, torch.float32, "grad_out")
@@ -698,6 +719,11 @@ def rows_grad_weights(x, grad_out):
         raise _lib.Df3dError("rows_grad_weights: %d rows against %d" % (n, grad_out.shape[0]))
     cout = grad_out.shape[1]
     gw = torch.empty((cin, cout), dtype=torch.float32, device=x.device)
+    if (two_part or x_scale is not None or g_scale is not None) and os.environ.get("DF3D_GRAD_SCALED", "1") != "0":
+        rc = lib.df3d_rows_grad_weights_scaled(_ptr(x), _ptr(grad_out), int(n), int(cin), int(cout), _ptr(x_scale), _ptr(g_scale),
+                                               _ptr(gw), _stream())
+        _lib.check(rc, "df3d_rows_grad_weights_scaled")
+        return gw
     rc = lib.df3d_rows_grad_weights(_ptr(x), _ptr(grad_out), int(n), int(cin), int(cout), _ptr(gw), _stream())
     _lib.check(rc, "df3d_rows_grad_weights")
     return gw
@@ -725,9 +751,9 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=
         # (round 5, second half) two-part rows of the gradient under ITS OWN power-of-two scale instead of three bf16 parts: a
         # gradient tensor is narrow relative to its largest value, whatever that is; the convolution's epilogue multiplies by
         # 1 / s.  DF3D_GRAD_SCALED=0: the three-part path below
-        gs, inv_s, _ = split_rows_scaled(grad_out, cin)
+        gs, inv_s, sc = split_rows_scaled(grad_out, cin)
         g_in, _ = sparse_conv_split(gs, conv_pack_weights(wt), inv, n_in, cout, cin, scale=inv_s, emit_split=False)
-        return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr)
+        return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr, grad_scale=sc)
     with grad_precision():
         if bf16 and conv_bf16_supported(K, cout, cin):
             g_in, _ = sparse_conv_bf16(rows_to_bf16(grad_out), conv_pack_weights_bf16(wt), inv, n_in, cout, cin, want_f32=True,
@@ -2213,7 +2239,7 @@ class _LinearRows(torch.autograd.Function):
             # gradient columns padded to the kernel's 4-channel pieces (the gates have one output)
             pad = (-g2.shape[1]) % 4
             gp = torch.nn.functional.pad(g2, (0, pad)) if pad else g2.contiguous()
-            gw = rows_grad_weights(gp, x2.contiguous())[:g2.shape[1]]
+            gw = rows_grad_weights(gp, x2.contiguous(), x_scale=rows_pow2_scale(gp))[:g2.shape[1]]
         elif d and n // d >= 8:
             gw = torch.bmm(g2.view(n // d, d, -1).transpose(1, 2), x2.view(n // d, d, -1)).sum(0)
         else:

@@ -276,6 +276,15 @@ int df3d_sparse_conv_grad_filters(const float *features, int n_in, int cin, cons
                                   const int32_t *nbr, int kvol, float *grad_filters, void *stream);
 int df3d_rows_grad_weights(const float *x, const float *grad_out, long long n, int cin, int cout, float *grad_weights,
                            void *stream);
+/* Two-part forms of the two gradients above (fp16 pairs, three products instead of six): an ACTIVATION operand carries the fixed
+ * scale of every split kernel, a GRADIENT operand the power-of-two block scale of its tensor -- `grad_scale` / `x_scale` /
+ * `g_scale` point at it on the device (scale[0] of df3d_split_rows_scaled or df3d_rows_pow2_scale; NULL = an activation operand).
+ * df3d_rows_pow2_scale: scale [2] <- (2^k with max |x| * 2^k in [512, 1024), workspace). */
+int df3d_sparse_conv_grad_filters_scaled(const float *features, int n_in, int cin, const float *grad_out, int n_out, int cout,
+                                         const int32_t *nbr, int kvol, const float *grad_scale, float *grad_filters, void *stream);
+int df3d_rows_grad_weights_scaled(const float *x, const float *grad_out, long long n, int cin, int cout, const float *x_scale,
+                                  const float *g_scale, float *grad_weights, void *stream);
+int df3d_rows_pow2_scale(const float *x, long long n_elems, float *scale, void *stream);
 /* out[n][c] = sum_s x[n][c][s] * g[n][s] over channel-first maps x [nmaps][channels][S], g [nmaps][S]: the weight gradient of a
  * one-output 1 x 1 convolution (the image gate's `reduced_dim3`, CP/det3d/models/fusion/point_to_image_projection.py:34-61) is the
  * sum of out over the maps. */

@@ -988,6 +988,12 @@ def test_filter_gradient_kernels_against_float64(cin, cout, K, n_in, n_out, dens
         # (round 5) mode 3 = three bf16 parts per operand on the 16-bit matrix cores, forced here on every shape with channel
         # counts that are multiples of 4 (by default it takes the layers with >= 64 channels on both sides): fp32-grade
         assert float((outs[mode] - ref).abs().max()) <= (4e-6 if mode == "3" else 2e-5) * scale, mode
+    if cin % 4 == 0 and cout % 4 == 0 and cin >= 32 and cout >= 32:
+        # second half of round 5: fp16 pairs, the gradient under its power-of-two block scale (three products)
+        for gs in (1.0, 1e-7, 1e+6):
+            gd = (gout * gs).to(dev)
+            got = ops.sparse_conv_grad_filters(feats.to(dev), gd, nbr.to(dev), grad_scale=ops.rows_pow2_scale(gd)).cpu().double()
+            assert float((got - ref * gs).abs().max()) <= 4e-6 * scale * gs, gs
 
 
 @pytest.mark.gpu
@@ -1008,6 +1014,12 @@ def test_rows_grad_weights_against_float64(n, cin, cout, gscale):
     ref = x.double().t() @ g.double()
     got = ops.rows_grad_weights(x.to(dev), g.to(dev)).cpu().double()
     assert float((got - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+    if n <= 1000 or gscale == 1.0 or True:
+        # two-part form: the gradient operand under its block scale (rows a factor 2^40 apart exceed 22 bits of ONE scale: the
+        # small rows then count for nothing against the large ones, in float64 as well -- the bound is of the result's scale)
+        gd = g.to(dev)
+        got2 = ops.rows_grad_weights(x.to(dev), gd, g_scale=ops.rows_pow2_scale(gd)).cpu().double()
+        assert float((got2 - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
 @pytest.mark.gpu

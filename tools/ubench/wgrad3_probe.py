@@ -44,6 +44,10 @@ for stage, x in (("conv4", x4), ("conv3", x3), ("conv2", x2)):
         os.environ["DF3D_WGRAD"] = mode
         res[mode] = timeit(lambda: ops.sparse_conv_grad_filters(f, g, rb.nbr))
     os.environ.pop("DF3D_WGRAD")
+    sc = ops.rows_pow2_scale(g)
+    t2, y2 = timeit(lambda: ops.sparse_conv_grad_filters(f, g, rb.nbr, grad_scale=sc))
+    print("   two-part kernel (fp16 pairs, block-scaled gradient) %.0f us, max diff %.1e of scale" % (
+        t2, float((y2.double() - res["1"][1].double()).abs().max() / res["1"][1].abs().max())), flush=True)
     R = int((rb.nbr >= 0).sum())
     ref = torch.zeros_like(res["1"][1], dtype=torch.float64)
     d = float((res["3"][1].double() - res["1"][1].double()).abs().max() / res["1"][1].abs().max())
@@ -54,8 +58,11 @@ for n, cin, cout in ((32034, 128, 1024), (32034, 1024, 128), (240300, 256, 128),
     g = torch.randn(n, cout, device=dev) * 1e-3
     t_t, ref = timeit(lambda: x.t() @ g)
     t_k, got = timeit(lambda: ops.rows_grad_weights(x, g))
-    print("x^T g, %d rows, %d x %d: torch %.0f us, df3d_rows_grad_weights %.0f us, max diff %.1e of scale"
-          % (n, cin, cout, t_t, t_k, float((got - ref).abs().max() / ref.abs().max())), flush=True)
+    sc = ops.rows_pow2_scale(g)
+    t_2, got2 = timeit(lambda: ops.rows_grad_weights(x, g, g_scale=sc))
+    print("x^T g, %d rows, %d x %d: torch %.0f us, df3d_rows_grad_weights %.0f us, two-part %.0f us, max diff %.1e / %.1e of scale"
+          % (n, cin, cout, t_t, t_k, t_2, float((got - ref).abs().max() / ref.abs().max()),
+             float((got2 - ref).abs().max() / ref.abs().max())), flush=True)
 for cin, cout, H in ((128, 128, 180), (256, 256, 90), (256, 128, 180), (512, 64, 180), (64, 2304, 180), (128, 256, 90)):
     nbr, _, _ = ops.conv2d_neighbors(1, H, H, 3, 3, 1, 1, False, dev)
     n = nbr.shape[1]
@@ -66,5 +73,8 @@ for cin, cout, H in ((128, 128, 180), (256, 256, 90), (256, 128, 180), (512, 64,
         os.environ["DF3D_WGRAD"] = mode
         res[mode] = timeit(lambda: ops.sparse_conv_grad_filters(f, g, nbr), iters=5)
     os.environ.pop("DF3D_WGRAD")
-    print("dense 3x3 %d -> %d on %d x %d: fp32 kernel %.0f us, three-part kernel %.0f us, max diff %.1e of scale"
-          % (cin, cout, H, H, res["1"][0], res["3"][0], float((res["3"][1] - res["1"][1]).abs().max() / res["1"][1].abs().max())), flush=True)
+    sc = ops.rows_pow2_scale(g)
+    t2, y2 = timeit(lambda: ops.sparse_conv_grad_filters(f, g, nbr, grad_scale=sc), iters=5)
+    print("dense 3x3 %d -> %d on %d x %d: fp32 kernel %.0f us, three-part kernel %.0f us, two-part %.0f us, max diff %.1e / %.1e of scale"
+          % (cin, cout, H, H, res["1"][0], res["3"][0], t2, float((res["3"][1] - res["1"][1]).abs().max() / res["1"][1].abs().max()),
+             float((y2 - res["1"][1]).abs().max() / res["1"][1].abs().max())), flush=True)
