@@ -132,39 +132,53 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
 // |x| into one word (fp32 bit patterns of non-negative values order like unsigned integers), pow2_scale_kernel turns it into
 // s = 2^k and a [channels] vector of 1 / s for the convolution's epilogue, split_rows_scaled_kernel splits s * x.
 // inf / NaN: the scale stays 1 and the checked split raises the range flag.
-__global__ __launch_bounds__(256) void rows_absmax_kernel(const float *__restrict__ x, size_t n4, size_t n, unsigned *__restrict__ out) {
+// per-workgroup maxima (no atomics, nothing to clear): part[blockIdx.x] = max |x| over the workgroup's strided share
+__global__ __launch_bounds__(256) void rows_absmax_kernel(const float *__restrict__ x, size_t n4, size_t n, float *__restrict__ part) {
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const f32x4 v = ((const f32x4 *)x)[i];
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  auto upd = [&](f32x4 v) {
     m = fmaxf(fmaxf(m, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
     if (!(v[0] == v[0]) || !(v[1] == v[1]) || !(v[2] == v[2]) || !(v[3] == v[3])) m = __builtin_inff();   // NaN must not hide
+  };
+  for (; i + 3 * stride < n4; i += 4 * stride) {                 // four loads in flight
+    const f32x4 v0 = ((const f32x4 *)x)[i], v1 = ((const f32x4 *)x)[i + stride], v2 = ((const f32x4 *)x)[i + 2 * stride],
+                v3 = ((const f32x4 *)x)[i + 3 * stride];
+    upd(v0), upd(v1), upd(v2), upd(v3);
   }
+  for (; i < n4; i += stride) upd(((const f32x4 *)x)[i]);
   if (blockIdx.x == 0)
-    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, __builtin_fabsf(x[i]));
+    for (size_t t = n4 * 4 + threadIdx.x; t < n; t += 256) m = fmaxf(m, __builtin_fabsf(x[t]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   __shared__ float wm[4];
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    if (m > 0.f) atomicMax(out, __float_as_uint(m));            // one atomic per workgroup
-  }
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
 }
 
-__global__ __launch_bounds__(256) void pow2_scale_kernel(const unsigned *__restrict__ amax_bits, int channels, float *__restrict__ scale,
-                                                         float *__restrict__ inv) {
-  const float amax = __uint_as_float(*amax_bits);
+// s = 2^k from the per-workgroup maxima (every workgroup of this launch reduces them itself: at most POW2_PARTS values), and the
+// [channels] vector of 1 / s
+constexpr int POW2_PARTS = 1024;
+__global__ __launch_bounds__(256) void pow2_scale_kernel(const float *__restrict__ part, int nparts, int channels,
+                                                         float *__restrict__ scale, float *__restrict__ inv) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const float amax = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
   float s = 1.f;
   if (amax > 0.f && amax < __builtin_inff()) {
     // exponent e of amax (amax in [2^e, 2^(e+1))): s = 2^(9 - e) puts it into [512, 1024); clamped to fp32's normal range
-    int e = (int)((*amax_bits >> 23) & 0xffu) - 127;
-    int k = 9 - e;
+    int k = 9 - ((int)((__float_as_uint(amax) >> 23) & 0xffu) - 127);
     k = k > 120 ? 120 : (k < -120 ? -120 : k);
     s = __uint_as_float((unsigned)(k + 127) << 23);
   }
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) *scale = s;
+  if (i == 0) scale[0] = s, scale[1] = amax;
   if (i < channels) inv[i] = 1.f / s;
 }
 
@@ -1974,6 +1988,22 @@ extern "C" int df3d_conv_pack_weights_groups(const float *filters, int groups, i
   return DF3D_OK;
 }
 
+// scale: DF3D_POW2_SCALE_FLOATS floats -- [0] = s, [1] = the largest |value|, the rest the reduction's per-workgroup maxima
+static int pow2_scale(const float *x, size_t ne, float *scale, float *inv, int inv_channels, hipStream_t stream) {
+  int wgs = 1;
+  if (ne) {
+    wgs = (int)std::min<size_t>(POW2_PARTS, cdiv((long long)(ne / 4), 256 * 4) + 1);
+    hipLaunchKernelGGL(rows_absmax_kernel, dim3(wgs), dim3(256), 0, stream, x, ne / 4, ne, scale + 2);
+  } else {
+    DF3D_HIP(hipMemsetAsync(scale + 2, 0, sizeof(float), stream));
+  }
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(std::max(1, cdiv(inv_channels, 256))), dim3(256), 0, stream, scale + 2, wgs,
+                     inv_channels, scale, inv ? inv : scale);
+  return DF3D_OK;
+}
+
+extern "C" int df3d_pow2_scale_floats(void) { return 2 + POW2_PARTS; }
+
 extern "C" int df3d_split_rows_scaled(const float *features, long long n, int c, void *split, float *scale, float *inv_scale,
                                       int inv_channels, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -1981,14 +2011,8 @@ extern "C" int df3d_split_rows_scaled(const float *features, long long n, int c,
   DF3D_CHECK_ARG(c > 0 && c % 8 == 0 && n >= 0 && inv_channels >= 1, "split_rows_scaled: channels must be a multiple of 8 (got %d)", c);
   DF3D_CHECK_ARG((size_t)features % 16 == 0, "split_rows_scaled: rows must be 16-byte aligned");
   const size_t ne = (size_t)n * c, nblk = ne / 8;
-  // scale[1] is the reduction word (bit pattern of the largest |value|)
-  DF3D_HIP(hipMemsetAsync(scale + 1, 0, sizeof(float), stream));
-  if (ne) {
-    const int wgs = (int)std::min<size_t>(512, cdiv((long long)(ne / 4), 256 * 4) + 1);
-    hipLaunchKernelGGL(rows_absmax_kernel, dim3(wgs), dim3(256), 0, stream, features, ne / 4, ne, (unsigned *)(scale + 1));
-  }
-  hipLaunchKernelGGL(pow2_scale_kernel, dim3(cdiv(inv_channels, 256)), dim3(256), 0, stream, (const unsigned *)(scale + 1),
-                     inv_channels, scale, inv_scale);
+  int rc = pow2_scale(features, ne, scale, inv_scale, inv_channels, stream);
+  if (rc) return rc;
   if (nblk)
     hipLaunchKernelGGL(split_rows_scaled_kernel, dim3(cdiv((long long)nblk, 256)), dim3(256), 0, stream, features, nblk, scale,
                        (u32x4 *)split);
@@ -2000,13 +2024,8 @@ extern "C" int df3d_rows_pow2_scale(const float *x, long long n_elems, float *sc
   hipStream_t stream = (hipStream_t)stream_;
   DF3D_CHECK_ARG(x && scale && n_elems >= 0, "rows_pow2_scale: bad argument");
   DF3D_CHECK_ARG((size_t)x % 16 == 0, "rows_pow2_scale: rows must be 16-byte aligned");
-  const size_t ne = (size_t)n_elems;
-  DF3D_HIP(hipMemsetAsync(scale + 1, 0, sizeof(float), stream));
-  if (ne) {
-    const int wgs = (int)std::min<size_t>(512, cdiv((long long)(ne / 4), 256 * 4) + 1);
-    hipLaunchKernelGGL(rows_absmax_kernel, dim3(wgs), dim3(256), 0, stream, x, ne / 4, ne, (unsigned *)(scale + 1));
-  }
-  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(256), 0, stream, (const unsigned *)(scale + 1), 0, scale, scale);
+  int rc = pow2_scale(x, (size_t)n_elems, scale, nullptr, 0, stream);
+  if (rc) return rc;
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;
 }

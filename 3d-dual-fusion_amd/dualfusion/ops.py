@@ -555,7 +555,7 @@ def split_rows_scaled(features, inv_channels):
     _chk(features, torch.float32, "features")
     n, c = features.shape
     out = torch.empty((n, 4 * c), dtype=torch.uint8, device=features.device)
-    scale = torch.empty((2,), dtype=torch.float32, device=features.device)
+    scale = torch.empty((int(lib.df3d_pow2_scale_floats()),), dtype=torch.float32, device=features.device)
     inv = torch.empty((int(inv_channels),), dtype=torch.float32, device=features.device)
     rc = lib.df3d_split_rows_scaled(_ptr(features), n, c, _ptr(out), _ptr(scale), _ptr(inv), int(inv_channels), _stream())
     _lib.check(rc, "df3d_split_rows_scaled")
@@ -671,11 +671,11 @@ def invert_neighbors(nbr, n_in):
 
 
 def rows_pow2_scale(x):
-    """-> float32 [2] on the device: [0] = the power of two s with max |x| * s in [512, 1024) (1 for an all-zero or non-finite
-    tensor), [1] = workspace (df3d_rows_pow2_scale).  The block scale of a gradient operand of the two-part kernels."""
+    """-> float32 [df3d_pow2_scale_floats()] on the device: [0] = the power of two s with max |x| * s in [512, 1024) (1 for an all-zero or non-finite
+    tensor), [1] = max |x|, then workspace (df3d_rows_pow2_scale).  The block scale of a gradient operand of the two-part kernels."""
     lib = _lib.load()
     _chk(x, torch.float32, "x")
-    scale = torch.empty((2,), dtype=torch.float32, device=x.device)
+    scale = torch.empty((int(lib.df3d_pow2_scale_floats()),), dtype=torch.float32, device=x.device)
     _lib.check(lib.df3d_rows_pow2_scale(_ptr(x), int(x.numel()), _ptr(scale), _stream()), "df3d_rows_pow2_scale")
     return scale
 

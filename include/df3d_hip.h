@@ -279,12 +279,13 @@ int df3d_rows_grad_weights(const float *x, const float *grad_out, long long n, i
 /* Two-part forms of the two gradients above (fp16 pairs, three products instead of six): an ACTIVATION operand carries the fixed
  * scale of every split kernel, a GRADIENT operand the power-of-two block scale of its tensor -- `grad_scale` / `x_scale` /
  * `g_scale` point at it on the device (scale[0] of df3d_split_rows_scaled or df3d_rows_pow2_scale; NULL = an activation operand).
- * df3d_rows_pow2_scale: scale [2] <- (2^k with max |x| * 2^k in [512, 1024), workspace). */
+ * df3d_rows_pow2_scale: scale [df3d_pow2_scale_floats()] <- (2^k with max |x| * 2^k in [512, 1024), max |x|, workspace). */
 int df3d_sparse_conv_grad_filters_scaled(const float *features, int n_in, int cin, const float *grad_out, int n_out, int cout,
                                          const int32_t *nbr, int kvol, const float *grad_scale, float *grad_filters, void *stream);
 int df3d_rows_grad_weights_scaled(const float *x, const float *grad_out, long long n, int cin, int cout, const float *x_scale,
                                   const float *g_scale, float *grad_weights, void *stream);
 int df3d_rows_pow2_scale(const float *x, long long n_elems, float *scale, void *stream);
+int df3d_pow2_scale_floats(void);
 /* out[n][c] = sum_s x[n][c][s] * g[n][s] over channel-first maps x [nmaps][channels][S], g [nmaps][S]: the weight gradient of a
  * one-output 1 x 1 convolution (the image gate's `reduced_dim3`, CP/det3d/models/fusion/point_to_image_projection.py:34-61) is the
  * sum of out over the maps. */
@@ -750,7 +751,7 @@ int df3d_conv_pack_weights_groups(const float *filters, int groups, int kvol, in
 int df3d_split_rows(const float *features, long long n, int c, void *split, void *stream);
 /* Gradient rows (training): features [n][c] fp32 -> split rows of s * features, s = the power of two that puts the tensor's largest
  * |value| into [512, 1024) (a per-tensor block scale: the fixed-scale fp16 pair format holds activations, not gradients of arbitrary
- * magnitude).  scale [2] receives s in its first entry (the second is the reduction's workspace), inv_scale [inv_channels] receives 1 / s in every entry -- the per-channel `scale` vector of the
+ * magnitude).  scale [df3d_pow2_scale_floats()] receives s in its first entry (then the largest |value| and the reduction's workspace), inv_scale [inv_channels] receives 1 / s in every entry -- the per-channel `scale` vector of the
  * convolution that consumes the rows (its epilogue multiplies by it: exact, a power of two).  Replaces the three-bf16-part rows of
  * the input-gradient convolutions (indice_conv_backward's data gradient, spconv_ops.h:363-456). */
 int df3d_split_rows_scaled(const float *features, long long n, int c, void *split, float *scale, float *inv_scale, int inv_channels,
