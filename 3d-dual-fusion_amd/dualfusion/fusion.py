@@ -129,6 +129,21 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
         return torch.sigmoid(y)
 
 
+def _stack_views(maps):
+    """torch.stack(maps, 0) -- without the copy when the maps are equally spaced contiguous views of ONE storage (the camera
+    network runs the cameras as one batch: the per-camera dict entries are slices of its output; 246 MB per step otherwise)."""
+    m0 = maps[0]
+    if len(maps) > 1 and m0.is_contiguous():
+        step = (maps[1].data_ptr() - m0.data_ptr()) // m0.element_size()
+        if (step >= m0.numel() and all(m.is_contiguous() and m.shape == m0.shape and m.dtype == m0.dtype and m.device == m0.device
+                                       and m.untyped_storage().data_ptr() == m0.untyped_storage().data_ptr()
+                                       and (m.data_ptr() - m0.data_ptr()) // m0.element_size() == i * step
+                                       for i, m in enumerate(maps))
+                and not any(m.requires_grad for m in maps)):
+            return torch.as_strided(m0, (len(maps),) + tuple(m0.shape), (step,) + tuple(m0.stride()))
+    return torch.stack(maps, 0)
+
+
 # (the row-linear autograd Function and its two-stage column sum live in ops.py: the ACTR modules use them too)
 _col_sum = _ops.col_sum_rows
 _linear_rows = _ops.linear_rows_autograd
@@ -568,7 +583,7 @@ class VoxelWithPointProjection(nn.Module):
             main.wait_stream(geo)
             for t in made:
                 t.record_stream(main)
-        imgs = torch.stack(inp['imgs'], 0)                                          # [NI, Ci, H, W]
+        imgs = _stack_views(inp['imgs'])                                            # [NI, Ci, H, W]
         if img_conv_func is not None:
             imgs = img_conv_func(imgs)
         gated = imgs

@@ -156,3 +156,20 @@ def test_linear_rows_module_is_a_drop_in_linear_on_the_host():
     m = MSDeformAttn(d_model=64, q_model=64, n_levels=1, n_heads=4, n_points=4)
     assert {"sampling_offsets.weight", "attention_weights.bias", "value_proj.weight", "output_proj.bias"} <= set(m.state_dict())
     assert all(isinstance(getattr(m, k), torch.nn.Linear) for k in ("sampling_offsets", "attention_weights", "value_proj", "output_proj"))
+
+
+def test_stack_views_returns_a_view_of_equally_spaced_maps_and_a_copy_otherwise():
+    """fusion._stack_views (training path of the adapter): per-camera maps that are slices of one tensor come back as one strided
+    view (no 246 MB copy per step), anything else as torch.stack's copy; values identical either way."""
+    from dualfusion.fusion import _stack_views
+    base = torch.arange(6 * 4 * 3 * 5, dtype=torch.float32).view(6, 4, 3, 5)
+    maps = [base[i] for i in range(6)]
+    v = _stack_views(maps)
+    assert v.data_ptr() == base.data_ptr() and torch.equal(v, base)
+    assert torch.equal(_stack_views(maps[::2]), base[::2]) and _stack_views(maps[::2]).data_ptr() == base.data_ptr()
+    other = [m.clone() for m in maps]
+    c = _stack_views(other)
+    assert torch.equal(c, base) and c.data_ptr() != other[0].data_ptr()
+    mixed = [maps[0], maps[2], maps[3]]
+    assert torch.equal(_stack_views(mixed), torch.stack(mixed, 0))
+    assert torch.equal(_stack_views([base.permute(0, 1, 3, 2)[i] for i in range(6)]), base.permute(0, 1, 3, 2))

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Which Python frames make the big layout copies of a training step: a TorchDispatchMode that prints the stack of every
+aten::copy_ / clone / contiguous whose output has one of the shapes given on the command line (e.g. 6,40050,256)."""
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-dual-fusion_amd")]
+import torch  # noqa: E402
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
+
+import bench  # noqa: E402
+
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(6, 40050, 256)]
+sys.argv = [sys.argv[0], "--stage", "train", "--workload", "cp_fusion", "--no-cpu-baseline"]
+args = bench.parse()
+dev = torch.device("cuda:0")
+wl = bench.make_workload(args, 0, 1, dev)
+for i in range(2):
+    wl.step(i, "train")
+torch.cuda.synchronize()
+
+
+class Spy(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = str(func)
+        if isinstance(out, torch.Tensor) and tuple(out.shape) in shapes and any(k in name for k in ("copy_", "clone", "contiguous", "_to_copy", "transpose", "permute", "mul", "add")):
+            if "copy_" in name or "clone" in name or "contiguous" in name:
+                fr = [f for f in traceback.format_stack() if "dualfusion" in f or "bench.py" in f]
+                print("==", name, tuple(out.shape), "strides in:", [tuple(a.stride()) for a in args if isinstance(a, torch.Tensor)][:2])
+                print("".join(fr[-4:]))
+        return out
+
+
+with Spy():
+    wl.step(2, "train")
+torch.cuda.synchronize()
+if hasattr(wl, "close"):
+    wl.close()
