@@ -493,7 +493,12 @@ class ACTR(nn.Module):
         conv, gn = self.input_proj[l][0], self.input_proj[l][1]
         if src.is_cuda and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1) and conv.groups == 1:
             N, C, H, W = src.shape
-            y = torch.matmul(conv.weight[:, :, 0, 0], src.reshape(N, C, H * W))
+            if torch.is_grad_enabled():
+                y = torch.matmul(conv.weight[:, :, 0, 0], src.reshape(N, C, H * W))
+            else:
+                # (inference: bmm, not torch.matmul -- matmul of a 2-D weight with a 3-D map clones the map transposed and
+                # transposes the result back: 0.4 ms per step at the Voxel-RCNN size)
+                y = torch.bmm(conv.weight[:, :, 0, 0].unsqueeze(0).expand(N, -1, -1), src.reshape(N, C, H * W))
             if conv.bias is not None:
                 y = y + conv.bias[None, :, None]
             return gn(y.view(N, -1, H, W))

@@ -329,7 +329,7 @@ class VoxelWithPointProjection(nn.Module):
                 f.untyped_storage().data_ptr() == store and f.data_ptr() == p0 + i * step
                 for i, f in enumerate(imgs)):
             stacked = torch.as_strided(imgs[0], (len(imgs), Ci, S_pix), (step // 4, S_pix, 1))
-            return torch.matmul(wcat, stacked)
+            return torch.bmm(wcat.unsqueeze(0).expand(stacked.shape[0], -1, -1), stacked)     # (matmul would transpose-copy the maps)
         both = torch.empty((len(imgs), wcat.shape[0], S_pix), dtype=torch.float32, device=imgs[0].device)
         for i, f in enumerate(imgs):
             torch.matmul(wcat, f.view(Ci, S_pix), out=both[i])

@@ -2299,7 +2299,7 @@ def channel_first_linear(x, weight):
     """weight [Cout, Cin] times x [N, Cin, S] -> [N, Cout, S], differentiable (see _ChannelFirstLinear)."""
     if x.is_cuda and (x.requires_grad or weight.requires_grad) and torch.is_grad_enabled():
         return _ChannelFirstLinear.apply(x, weight)
-    return torch.matmul(weight, x)
+    return torch.bmm(weight.unsqueeze(0).expand(x.shape[0], -1, -1), x)       # (not matmul: see _ChannelFirstLinear.forward)
 
 
 def linear_rows(x, lin, min_rows=16384):
