@@ -373,6 +373,13 @@ class SparseEncoder(nn.Module):
 
     def _dense_out(self, x):
         out = self.conv_out(x)
+        if (not torch.is_grad_enabled() and out.features.is_cuda and out.features.dtype == torch.float32
+                and os.environ.get("DF3D_DENSE_ROWS", "1") != "0"):
+            # inference: the same map as channels-last pixel rows behind an NCHW VIEW (necks._as_nchw) -- the row-kernel neck
+            # that follows reads the rows in place instead of transposing the NCHW volume (0.17 ms per step at bs = 4)
+            from .necks import _as_nchw
+            D, H, W = [int(v) for v in out.spatial_shape]
+            return _as_nchw(out.dense_rows(), None, out.batch_size, H, W)
         spatial_features = out.dense()
         N, C, D, H, W = spatial_features.shape
         return spatial_features.view(N, C * D, H, W)

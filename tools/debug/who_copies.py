@@ -12,13 +12,16 @@ from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
 import bench  # noqa: E402
 
-shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(6, 40050, 256)]
-sys.argv = [sys.argv[0], "--stage", "train", "--workload", "cp_fusion", "--no-cpu-baseline"]
+# usage: who_copies.py [workload=cp_fusion] [stage=train] [precision=split] shape...   (shape = 6,40050,256)
+words = [a for a in sys.argv[1:] if "," not in a]
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if "," in a] or [(6, 40050, 256)]
+wlname, stage, prec = (words + ["cp_fusion", "train", "split"][len(words):])[:3]
+sys.argv = [sys.argv[0], "--stage", stage, "--workload", wlname, "--no-cpu-baseline", "--conv-precision", prec, "--frames", "4", "--inflight", "1"]
 args = bench.parse()
 dev = torch.device("cuda:0")
 wl = bench.make_workload(args, 0, 1, dev)
 for i in range(2):
-    wl.step(i, "train")
+    wl.step(i, stage)
 torch.cuda.synchronize()
 
 
@@ -26,8 +29,8 @@ class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         name = str(func)
-        if isinstance(out, torch.Tensor) and tuple(out.shape) in shapes and any(k in name for k in ("copy_", "clone", "contiguous", "_to_copy", "transpose", "permute", "mul", "add")):
-            if "copy_" in name or "clone" in name or "contiguous" in name:
+        if isinstance(out, torch.Tensor) and tuple(out.shape) in shapes and any(k in name for k in ("copy_", "clone", "contiguous", "_to_copy", "addmm", "cat")):
+            if True:
                 fr = [f for f in traceback.format_stack() if "dualfusion" in f or "bench.py" in f]
                 print("==", name, tuple(out.shape), "strides in:", [tuple(a.stride()) for a in args if isinstance(a, torch.Tensor)][:2])
                 print("".join(fr[-4:]))
@@ -35,7 +38,7 @@ class Spy(TorchDispatchMode):
 
 
 with Spy():
-    wl.step(2, "train")
+    wl.step(2, stage)
 torch.cuda.synchronize()
 if hasattr(wl, "close"):
     wl.close()
