@@ -36,7 +36,7 @@ configure_runtime()
 from ._lib import Df3dError, LIB_PATH, load as require  # noqa: E402,F401
 
 __all__ = ["require", "Df3dError", "LIB_PATH", "spconv", "ops", "voxel", "msda", "actr", "fusion", "backbones",
-           "pipeline", "registry", "synth", "necks", "executor", "fusion_tf", "iou3d_nms", "heads", "transfusion_head"]
+           "pipeline", "registry", "synth", "necks", "executor", "fusion_tf", "iou3d_nms", "heads", "transfusion_head", "transfusion"]
 
 
 def __getattr__(name):

@@ -281,9 +281,9 @@ class TFSparseBasicBlock(spconv.SparseModule):
             return _fused_basic_block(x, self.conv1, self.bn1, self.conv2, self.bn2, None)
         identity = x.features
         out = self.conv1(x)
-        out.features = self.relu(self.bn1(out.features))
+        out.features = _ops.batch_norm_rows(self.bn1, out.features, relu=True)      # train(): csrc/bnrows.hip
         out = self.conv2(out)
-        out.features = self.bn2(out.features)
+        out.features = _ops.batch_norm_rows(self.bn2, out.features)
         if self.downsample is not None:
             identity = self.downsample(x)
         out.features = self.relu(out.features + identity)

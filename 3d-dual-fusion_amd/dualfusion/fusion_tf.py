@@ -201,6 +201,54 @@ class ACTRFusionLayer(nn.Module):
                                              _ops._stream()), "df3d_fusion_writeback")
         return out
 
+    def _forward_autograd(self, img_feats, pts, pts_feats, cam_id, norm, pix, batch_size):
+        """Training formulation of `_forward_native` (the per-rank body of BASELINE configs[3]): the integer work -- one-hot
+        (sample, camera) lists, query slots (df3d_query_slots), the image-feature / point gathers of the assembly kernel --
+        runs on the same native kernels without gradients (none of it depends on a learnable value); the floating-point
+        stages are differentiable: the LiDAR rows enter their slots by index_put (gradient = a gather), ACTR runs its
+        module path (input projection as chunked batched products, GroupNorm, dual-query layers with the deformable
+        sampling and its backward on csrc/msda.hip), the additive write-back reads every voxel's one slot.  Same values as
+        `_forward_native` up to summation order."""
+        import ctypes
+        from . import _lib
+        from . import ops as _ops
+        lib = _lib.load()
+        P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)   # noqa: E731
+        dev = pts.device
+        n, C = pts_feats.shape
+        ncam = self.num_cams
+        f0 = img_feats[0].contiguous()
+        NI, Ci, H, W = f0.shape
+        N6 = batch_size * ncam
+        with torch.no_grad():
+            cams = torch.arange(ncam, device=dev, dtype=cam_id.dtype)
+            mask = (cam_id[None, :] == cams[:, None]).to(torch.uint8).contiguous()
+            ic = (pix.to(torch.long) // 4).to(torch.int32)
+            grid = ic[None].expand(ncam, n, 2).contiguous()
+            ind = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+            ind[:, 0] = pts[:, 0].to(torch.int32)
+            pinv = pts[:, 1:4].contiguous()
+            pos = torch.empty((ncam, n), dtype=torch.int32, device=dev)
+            counts = torch.empty((N6,), dtype=torch.int32, device=dev)
+            _lib.check(lib.df3d_query_slots(P(mask), P(ind), n, batch_size, ncam, P(pos), P(counts), _ops._stream()),
+                       "df3d_query_slots")
+            max_ne = int(counts.max().item()) if n > 0 else 0                                  # the one host sync
+            rows_nograd = pts_feats.detach().contiguous()
+            v_feat0 = torch.empty((N6, max_ne, C), dtype=torch.float32, device=dev)
+            v_i_feat = torch.empty((N6, max_ne, Ci), dtype=torch.float32, device=dev)
+            qgrid = torch.empty((N6, max_ne, 2), dtype=torch.float32, device=dev)
+            qpts = torch.empty((N6, max_ne, 3), dtype=torch.float32, device=dev)
+            _lib.check(lib.df3d_assemble_queries2(P(rows_nograd), P(pinv), P(ind), P(grid), P(mask), P(pos), P(f0), None, None,
+                                                  n, C, Ci, batch_size, ncam, H, W, max_ne, P(v_feat0), P(v_i_feat), P(qgrid),
+                                                  P(qpts), None, P(counts), _ops._stream()), "df3d_assemble_queries2")
+            seg = pts[:, 0].long() * ncam + cam_id
+            slot = pos[cam_id, torch.arange(n, device=dev)].long()
+            qgrid[seg, slot] = norm                    # the un-truncated image coordinates (see _forward_native)
+        # the LiDAR rows with their gradient path: zeros + index_put (every (seg, slot) pair is distinct)
+        v_feat = torch.zeros_like(v_feat0).index_put((seg, slot), pts_feats)
+        enh = self._actr(v_feat, qgrid, [f0], qpts, v_i_feat)
+        return pts_feats + enh[seg, slot]
+
     def _actr(self, v_feat, grid, img_feats, qpts, v_i_feat, q_pos=None):
         """ACTR on the assembled queries.  Inference with the 3D-DF configuration (one 256-channel level, two dual-query
         layers) takes the fold-through path of the CenterPoint adapter: the input projection runs on the matrix cores
@@ -246,6 +294,10 @@ class ACTRFusionLayer(nn.Module):
                 and not torch.is_grad_enabled() and len(img_feats) == 1 and img_feats[0].dtype == torch.float32
                 and os.environ.get("DF3D_TF_NATIVE_ASSEMBLE", "1") == "1"):
             return self._forward_native(img_feats, pts, pts_feats.contiguous(), cam_id, norm, pix, batch_size)
+        if (pts_feats.is_cuda and pts_feats.dtype == torch.float32 and self.fusion_method == 'sum' and not self.activate_out
+                and torch.is_grad_enabled() and len(img_feats) == 1 and img_feats[0].dtype == torch.float32
+                and not img_feats[0].requires_grad and os.environ.get("DF3D_TF_NATIVE_ASSEMBLE", "1") == "1"):
+            return self._forward_autograd(img_feats, pts, pts_feats.contiguous(), cam_id, norm, pix, batch_size)
         v_feat, v_i_feat, grid, qpts, seg, slot = self.assemble(img_feats, pts, pts_feats, cam_id, norm, pix, batch_size)
         enh = self._actr(v_feat, grid, img_feats, qpts, v_i_feat)
         enh_cat = enh[seg, slot]

@@ -80,6 +80,7 @@ CONV_LAYERS = Registry("conv layer")
 MM_BACKBONES = Registry("mmdet backbone")      # 2-D BEV backbone / neck of the TransFusion tree (SECOND, SECONDFPN)
 MM_NECKS = Registry("mmdet neck")
 MM_HEADS = Registry("mmdet head")              # TransFusionHead (mmdet3d HEADS is mmdet's HEADS registry)
+MM_DETECTORS = Registry("mmdet detector")      # TransFusionDetector (mmdet3d registers detectors into mmdet's DETECTORS)
 BACKBONES_3D = Registry("pcdet backbone_3d")   # pcdet uses a plain dict `__all__`; same lookup by NAME
 
 
@@ -87,7 +88,7 @@ def late_register():
     """Register our classes into the real frameworks' registries when those are importable, so the
     reference configs resolve `type=` / `NAME:` strings to the MI355X modules unchanged."""
     import importlib
-    for m in ("spconv", "voxel", "backbones", "fusion", "fusion_tf", "necks", "heads", "transfusion_head"):
+    for m in ("spconv", "voxel", "backbones", "fusion", "fusion_tf", "necks", "heads", "transfusion_head", "transfusion"):
         importlib.import_module("." + m, __package__)          # every module that registers classes (some import lazily)
     done = []
     try:
@@ -109,8 +110,8 @@ def late_register():
     except Exception:
         pass
     try:
-        from mmdet.models import BACKBONES as MB, HEADS as MH, NECKS as MN
-        for src, dst in ((MM_BACKBONES, MB), (MM_NECKS, MN), (MM_HEADS, MH)):
+        from mmdet.models import BACKBONES as MB, DETECTORS as MD, HEADS as MH, NECKS as MN
+        for src, dst in ((MM_BACKBONES, MB), (MM_NECKS, MN), (MM_HEADS, MH), (MM_DETECTORS, MD)):
             for k, v in src.module_dict.items():
                 dst.register_module(name=k, module=v, force=True)
         done.append("mmdet")

@@ -73,6 +73,16 @@ class TransFusionWorkload(object):
                            code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2], point_cloud_range=synth.NUSC_RANGE),
             test_cfg=dict(dataset='nuScenes', grid_size=[1440, 1440, 40], out_size_factor=8, pc_range=[-54.0, -54.0],
                           voxel_size=[0.075, 0.075], nms_type=None)).to(dev).eval()
+        from .transfusion import TransFusionDetector
+        from .voxel import HardSimpleVFE, Voxelization
+        # the detector the reference composes from the same config (TF/mmdet3d/models/detectors/transfusion.py): the training
+        # step (`--stage train`, BASELINE configs[3]'s per-rank body) goes through it; the inference stages above call the
+        # same sub-modules directly (with the frame head a batch ahead)
+        self.detector = TransFusionDetector(
+            pts_voxel_layer=Voxelization(synth.NUSC_VOXEL, synth.NUSC_RANGE, 10, (120000, 160000)),
+            pts_voxel_encoder=HardSimpleVFE(num_features=5), pts_middle_encoder=self.enc, pts_backbone=self.second,
+            pts_neck=self.fpn, pts_bbox_head=self.head).to(dev).eval()
+        self.detector.resident_inputs = os.environ.get("DF3D_VOXEL_STREAM", "1") == "1"
         ori_hw, in_hw, fh, fw = (900, 1600), (448, 800), 112, 200          # stride-4 level (the layer indexes pix // 4)
         sf = [in_hw[1] / ori_hw[1], in_hw[0] / ori_hw[0]]
         self.frames = []
@@ -97,8 +107,33 @@ class TransFusionWorkload(object):
     def close(self):
         self.enc.close()
 
-    @torch.no_grad()
+    def _train_setup(self):
+        from . import dist as D
+        self.detector.train()
+        params = [p for p in self.detector.parameters() if p.requires_grad]
+        self.reducer = D.GradBucketReducer(params)
+        # TF/configs/transfusion_nusc_voxel_F.py:302-303
+        self.optimizer = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+        self.grad_clip = dict(max_norm=0.1, norm_type=2)
+        self.n_params = sum(p.numel() for p in params)
+
+    def train_step(self, i):
+        """One data-parallel training iteration on this rank's `batch` sweeps (TransFusionDetector.training_step)."""
+        if getattr(self, "reducer", None) is None:
+            self._train_setup()
+        fr = self.frames[i % len(self.frames)]
+        metas = [dict(m) for m in fr["metas"]]
+        loss, logs = self.detector.training_step(fr["points"], [fr["img"]], metas, fr["gt_boxes"], fr["gt_labels"],
+                                                 reducer=self.reducer, optimizer=self.optimizer, grad_clip=self.grad_clip)
+        return {k: v.reshape(1).float() for k, v in logs.items()}
+
     def step(self, i, stage):
+        if stage == "train":
+            return self.train_step(i)
+        with torch.no_grad():
+            return self._infer_step(i, stage)
+
+    def _infer_step(self, i, stage):
         fr = self.frames[i % len(self.frames)]
         head = self.enc.take_head(fr["points"]) if self.prefetch else None
         if self.prefetch:
@@ -125,6 +160,9 @@ class TransFusionWorkload(object):
             assert out.shape[0] == self.batch and out.shape[-2:] == (180, 180), out.shape
         elif stage == "boxes":
             assert out[0].shape[0] == self.batch and bool(torch.isfinite(out[1]).all())
+        elif stage == "train":
+            assert {"loss", "loss_heatmap", "layer_-1_loss_cls", "layer_-1_loss_bbox", "grad_norm"} <= set(out), sorted(out)
+            assert all(bool(torch.isfinite(v).all()) for v in out.values()), out
         else:
             assert set(out) == {"loss_heatmap", "layer_-1_loss_cls", "layer_-1_loss_bbox", "matched_ious"}, sorted(out)
             assert all(bool(torch.isfinite(v).all()) for v in out.values()), out

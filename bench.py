@@ -64,7 +64,7 @@ def parse():
                          "KITTI, bs=8); protocol = launcher / barrier / reduce protocol only, no GPU work (CPU tests)")
     ap.add_argument("--stage", default="detect", choices=["detect", "hot_path", "train", "boxes"],
                     help="detect (default): ... -> neck -> head -> losses -> reduce_dict; hot_path: stop at the dense BEV; "
-                         "train (cp_lidar, cp_fusion): forward + backward + bucketed gradient all-reduce overlapped with backward "
+                         "train (cp_lidar, cp_fusion, tf_fusion): forward + backward + bucketed gradient all-reduce overlapped with backward "
                          "+ AdamW step + reduce_dict of the losses -- a real data-parallel training step; boxes (tf_fusion): "
                          "... -> head -> decoded boxes instead of the losses")
     ap.add_argument("--batch", type=int, default=0, help="sweeps per GPU per step (0 = the workload's BASELINE batch)")
@@ -823,7 +823,7 @@ def main():
     wl.check(out, stage)
     extra = {}
     if stage == "train":
-        assert args.workload in ("cp_lidar", "cp_fusion"), "--stage train: the CenterPoint detectors"
+        assert args.workload in ("cp_lidar", "cp_fusion", "tf_fusion"), "--stage train: the CenterPoint / TransFusion detectors"
     if not (args.no_extra_passes or protocol or stage == "train"):
         # the same K steps ending at the dense BEV tensor (round 1's step), and both stages on the exact-fp32 kernels
         skip = set(x for x in args.skip_passes.split(",") if x)
