@@ -346,7 +346,7 @@ class TransFusionHead(nn.Module):
         B = inputs.shape[0]
         lidar_feat = self.shared_conv(inputs)
         flat = lidar_feat.view(B, lidar_feat.shape[1], -1)
-        bev_pos = self.bev_pos.repeat(B, 1, 1).to(lidar_feat.device)
+        bev_pos = self.bev_pos.repeat(B, 1, 1).to(lidar_feat)
         if self.initialize_by_heatmap:
             dense_heatmap = self.heatmap_head(lidar_feat)
             heatmap = dense_heatmap.detach().sigmoid()

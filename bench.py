@@ -565,7 +565,10 @@ def cpu_baseline(wl, n_sweeps=20):
 SIDE_CONFIGS = (("cp_lidar", "configs[0] shape", "split", "detect"), ("tf_fusion", "configs[2]", "bf16", "detect"),
                 ("vr_fusion", "configs[4]", "split", "detect"),
                 # (VERDICT r4 "next" 5: the training step where the driver's record sees it)
-                ("cp_fusion", "configs[1], training step: forward + losses + backward + optimizer", "split", "train"))
+                ("cp_fusion", "configs[1], training step: forward + losses + backward + optimizer", "split", "train"),
+                # (VERDICT r5 "next" 1: configs[3]'s per-rank body -- TransFusion-L + 3D-DF bs 4 as a training step)
+                ("tf_fusion", "configs[3] per rank, training step: forward + Hungarian losses + backward + grad clip + AdamW", "bf16",
+                 "train"))
 
 
 def side_configs(args, steps=12):
@@ -936,7 +939,15 @@ def main():
                                       "scalars%s)" % (world, ", RCCL" if use_gpu and world > 1 else "")},
             "collective_backend": (torch.distributed.get_backend() if D.is_dist() else None), "world_size": world,
         }
-        if stage == "train":
+        if stage == "train" and args.workload == "tf_fusion":
+            res["config"]["training"] = {"trainable_parameters": getattr(wl, "n_params", None),
+                                         "optimizer": "AdamW (fused) lr 1e-4 wd 0.01, grad_clip max_norm 0.1 (TF/configs/"
+                                                      "transfusion_nusc_voxel_F.py:302-303)",
+                                         "loss_logging": "device scalars (loss terms, grad_norm) reduced over the ranks; no host copy "
+                                                         "inside the step",
+                                         "gradient_reduction": "GradBucketReducer: %d bucket(s) of <= 16 MB, all-reduces launched in "
+                                                               "bucket order from post-accumulate-grad hooks during backward" % len(wl.reducer.buckets)}
+        elif stage == "train":
             async_log = os.environ.get("DF3D_TRAIN_ASYNC_LOG", "1") == "1"
             res["config"]["training"] = {"trainable_parameters": getattr(wl, "n_params", None), "optimizer": "AdamW (fused)",
                                          "loss_logging": ("async: hm_loss / loc_loss_elem go to pinned host memory without a host "
