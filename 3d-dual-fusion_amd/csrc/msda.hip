@@ -171,6 +171,14 @@ __global__ __launch_bounds__(256) void msda_bwd_vec4_kernel(MsdaBwdArgs a) {
   const int qstride = a.M * a.D;
   f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (live) g = *(const f32x4 *)(a.gout + (size_t)qm * a.D + sub * 4);
+  // A (query, head) whose upstream gradient is all zero contributes nothing: every product below carries g.  The padded
+  // rows of the zero-padded per-camera query lists are exactly that (nobody reads their outputs), and they all sample around
+  // reference point (0, 0): ~8 k rows per image adding zeros to the same few cache lines of grad_value (the atomics of one line
+  // serialise in the L2: 3.4 ms per call at the TransFusion training shape, 0.12 ms for the forward).
+  int nz = (g[0] != 0.f) | (g[1] != 0.f) | (g[2] != 0.f) | (g[3] != 0.f);
+#pragma unroll
+  for (int d = 1; d < LPG; d <<= 1) nz |= __shfl_xor(nz, d, 64);
+  const bool work = live && nz;
   for (int lp0 = 0; lp0 < LP; lp0 += LPG) {
     float mx = 0.f, my = 0.f, mw = 0.f;
     const int lp = lp0 + sub;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256) void msda_bwd_vec4_kernel(MsdaBwdArgs a) {
       const size_t off = ((size_t)b * a.S + (size_t)a.lstart[l]) * qstride + m * a.D + sub * 4;
       const float h_im = ly * (float)H - 0.5f, w_im = lx * (float)W - 0.5f;
       float px = 0.f, py = 0.f, pw = 0.f;
-      if (live && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+      if (work && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
         const int h_high = h_low + 1, w_high = w_low + 1;
         const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;

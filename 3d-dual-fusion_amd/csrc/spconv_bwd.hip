@@ -398,7 +398,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
   };
   auto put = [&](unsigned char *im, int rb, int imb, int pair, int c4, f32x4 v, float sc) {
     unsigned char *d = im + pair * rb + (pair >> 3) * 128 + ((c4 * 8) ^ ((pair & 3) * 32));
-    if constexpr (NP == 2) {
+    if constexpr (NP == 1) {                                   // bf16 mixed precision: one rounded part per operand
+      unsigned h0, h1, unused;
+      split_pair_bf16_ref(v[0], v[1], h0, unused);
+      split_pair_bf16_ref(v[2], v[3], h1, unused);
+      *(w3_u32x2 *)d = (w3_u32x2){h0, h1};
+    } else if constexpr (NP == 2) {
       unsigned h0, l0, h1, l1;
       v *= sc;
       amax = fmaxf(amax, fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
@@ -443,6 +448,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
 #define W3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
 #define W2_MFMA(A, B, C) DF3D_MFMA_F16(A, B, C)
   auto compute = [&]() {
+    if constexpr (NP == 1) {
+      w3_bf16x8 af[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt] = frag(abase, RBA, IMA, mt, 0);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const w3_bf16x8 b0 = frag(gbase, RBG, IMG, nt, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = W3_MFMA(af[mt], b0, acc[mt][nt]);
+      }
+      return;
+    }
     if constexpr (NP == 2) {
       w3_bf16x8 af[4][2];
 #pragma unroll
@@ -598,8 +615,10 @@ static int launch_wgrad3_np(const WgradArgs &a, int kvol, hipStream_t stream) {
   if (a.cout >= 128) return launch_wgrad3<1, 2, NP>(a, kvol, stream);
   return launch_wgrad3<1, 1, NP>(a, kvol, stream);
 }
-// parts = 2: fp16 pairs (a.sa / a.sg = device scales or NULL); 3: bf16 triples
+// parts = 1: one bf16 part per operand (bf16 mixed-precision training: the operands the forward rounded the same way); 2: fp16
+// pairs (a.sa / a.sg = device scales or NULL); 3: bf16 triples
 static int launch_wgrad3_any(const WgradArgs &a, int kvol, hipStream_t stream, int parts = 3) {
+  if (parts == 1) return launch_wgrad3_np<1>(a, kvol, stream);
   return parts == 2 ? launch_wgrad3_np<2>(a, kvol, stream) : launch_wgrad3_np<3>(a, kvol, stream);
 }
 
@@ -690,6 +709,26 @@ extern "C" int df3d_rows_grad_weights(const float *x, const float *grad_out, lon
   DF3D_CHECK_ARG(x && grad_out, "rows_grad_weights: null argument");
   WgradArgs a{x, grad_out, nullptr, grad_weights, (int)n, cin, cout, 0, 1, 0, 0, 0, {0}};
   int rc = launch_wgrad3_any(a, 1, stream);
+  if (rc) return rc;
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+// bf16 mixed-precision training (round 6; BASELINE configs[2] / [3] are bf16 configurations): both operands rounded to ONE bf16
+// part where they are staged, one product, fp32 accumulate -- what an fp16-AMP reference does for its filter gradients
+// (spconv_ops.h:363-456 under autocast), at a third of the two-part kernel's matrix work and half of its staging.
+extern "C" int df3d_sparse_conv_grad_filters_bf16(const float *features, int n_in, int cin, const float *grad_out, int n_out,
+                                                  int cout, const int32_t *nbr, int kvol, float *grad_filters, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (cin % 4 || cout % 4 || cin < 64 || cout < 64)             // narrow layers: the fp32 kernels (the 64-wide blocks would be half empty)
+    return df3d_sparse_conv_grad_filters(features, n_in, cin, grad_out, n_out, cout, nbr, kvol, grad_filters, stream_);
+  DF3D_CHECK_ARG(kvol > 0 && kvol <= DF3D_MAX_KVOL && n_in >= 0 && n_out >= 0, "sparse_conv_grad_filters_bf16: bad sizes");
+  DF3D_CHECK_ARG(grad_filters, "sparse_conv_grad_filters_bf16: null output");
+  DF3D_HIP(hipMemsetAsync(grad_filters, 0, (size_t)kvol * cin * cout * sizeof(float), stream));
+  if (n_out == 0 || n_in == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(features && grad_out && nbr, "sparse_conv_grad_filters_bf16: null argument");
+  WgradArgs a{features, grad_out, nbr, grad_filters, n_out, cin, cout, 0, 1, 0, 0, 0, {0}};
+  int rc = launch_wgrad3_any(a, kvol, stream, 1);
   if (rc) return rc;
   DF3D_LAUNCH_CHECK();
   return DF3D_OK;

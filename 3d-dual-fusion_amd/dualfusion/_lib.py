@@ -147,6 +147,7 @@ SIGNATURES = {
     "df3d_chanfirst_dot": (c_int, [c_void_p, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p]),
     "df3d_sparse_conv_grad_filters_scaled": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                                     c_void_p, c_void_p]),
+    "df3d_sparse_conv_grad_filters_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "df3d_rows_grad_weights_scaled": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_pow2_scale_floats": (c_int, []),
     "df3d_rows_pow2_scale": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p]),

@@ -455,6 +455,24 @@ def sparse_conv_fused(features, filters, nbr, n_out, bias=None, scale=None, shif
 CONV_PRECISION = os.environ.get("DF3D_CONV_PRECISION", "split")
 
 
+class precision(object):
+    """`with precision("split"): ...` -- the convolution arithmetic of the calls inside (the TransFusion head keeps its own
+    convolutions fp32-grade while backbone and neck run bf16: BASELINE configs[2] / [3])."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        global CONV_PRECISION
+        self.old, CONV_PRECISION = CONV_PRECISION, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_PRECISION
+        CONV_PRECISION = self.old
+        return False
+
+
 class grad_precision(object):
     """Context of a backward pass: gradient rows have no fixed scale (1e-8 .. 1e+2 within one step), which the fp16 parts of
     the "split" mode cannot hold -- input-gradient convolutions run in the three-part mode (bf16 parts: fp32's exponent range)."""
@@ -680,7 +698,7 @@ def rows_pow2_scale(x):
     return scale
 
 
-def sparse_conv_grad_filters(features, grad_out, nbr, grad_scale=None):
+def sparse_conv_grad_filters(features, grad_out, nbr, grad_scale=None, bf16=False):
     """-> grad_filters [K, cin, cout] = sum over rulebook pairs of features[in]^T grad_out[out].
     grad_scale: device scale of grad_out (`split_rows_scaled(...)[2]` / `rows_pow2_scale`): the two-part kernel
     (df3d_sparse_conv_grad_filters_scaled) where it applies."""
@@ -693,6 +711,12 @@ def sparse_conv_grad_filters(features, grad_out, nbr, grad_scale=None):
         raise ValueError("grad_out rows do not match the neighbour table")
     cin, cout = features.shape[1], grad_out.shape[1]
     gw = torch.empty((K, cin, cout), dtype=torch.float32, device=features.device)
+    if bf16 and os.environ.get("DF3D_WGRAD_BF16", "1") != "0":
+        # bf16 mixed-precision training: one rounded part per operand, one product (df3d_sparse_conv_grad_filters_bf16)
+        rc = lib.df3d_sparse_conv_grad_filters_bf16(_ptr(features), features.shape[0], cin, _ptr(grad_out), n_out, cout, _ptr(nbr),
+                                                    K, _ptr(gw), _stream())
+        _lib.check(rc, "df3d_sparse_conv_grad_filters_bf16")
+        return gw
     if (grad_scale is not None and os.environ.get("DF3D_GRAD_SCALED", "1") != "0"
             and os.environ.get("DF3D_WGRAD_SCALED", "1") != "0"):        # (A/B switch of the two-part filter gradient alone)
         _chk(grad_scale, torch.float32, "grad_scale")
@@ -732,7 +756,8 @@ def rows_grad_weights(x, grad_out, x_scale=None, g_scale=None, two_part=False):
 def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=False):
     """indice_conv backward from the kernel-facing rulebook: -> (grad_features [n_in, cin], grad_filters [K, cin, cout]).
     filters [K, cin, cout].  bf16: the input gradient on the bf16 kernel (mixed-precision training: gradient rows and
-    transposed filters rounded to bf16, fp32 accumulate, fp32 rows out); the filter gradient stays on the fp32 matrix cores."""
+    transposed filters rounded to bf16, fp32 accumulate, fp32 rows out), and the filter gradient on single bf16 parts
+    (df3d_sparse_conv_grad_filters_bf16)."""
     K = nbr.shape[0]
     n_in = features.shape[0]
     grad_out = grad_out.contiguous()
@@ -767,7 +792,7 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=
                                       n_in)
         else:
             g_in = sparse_conv_fused(grad_out, wt, inv, n_in)
-    return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr)
+    return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr, bf16=bf16)
 
 
 def conv_rows_split(in_split, cin, in_group_stride, packed, cout, groups, nbr, n_out, bias=None, scale=None, shift=None,

@@ -44,6 +44,7 @@ class SparseConvFunction(torch.autograd.Function):
         ctx.mirror, ctx.has_bias, ctx.inv = mirror, bias is not None, inv
         w = filters.detach().contiguous().view(K, cin, cout)
         b = bias.detach() if bias is not None else None
+        ctx.mode = _ops.CONV_PRECISION                     # the backward runs in the arithmetic the forward was called in
         ctx.amp = _ops.CONV_PRECISION == "bf16" and _ops.conv_bf16_supported(K, cin, cout)
         if ctx.amp:
             # bf16 mixed-precision training (the reference's fp16-AMP configurations): operands rounded to
@@ -54,6 +55,10 @@ class SparseConvFunction(torch.autograd.Function):
         if _ops.conv_split_supported(K, cin, cout):            # same split-precision kernel as inference (~1e-5 rel.)
             return _ops.sparse_conv_split(_ops.split_rows(features), _ops.conv_pack_weights(w), nbr, n_out, cin, cout,
                                           bias=b, emit_split=False)[0]
+        if _ops.CONV_PRECISION == "split" and cin > 128 and cin % 128 == 0 and cout % 8 == 0 and cout <= 128:
+            # many input channels (a head's shared convolution 512 -> 128 over the BEV rows): the row kernel that walks the
+            # input channels in 128-column blocks (the inference path's launch, csrc/spconv_split.hip loader / consumer)
+            return _ops.conv_rows_split(_ops.split_rows(features), cin, 0, _ops.conv_pack_weights(w), cout, 1, nbr, n_out, b)[0]
         return _ops.sparse_conv_fused(features, w, nbr, n_out, bias=b)
 
     @staticmethod
@@ -62,8 +67,9 @@ class SparseConvFunction(torch.autograd.Function):
         features, filters, nbr = ctx.saved_tensors
         K = nbr.shape[0]
         cin, cout = features.shape[1], filters.shape[-1]
-        g_in, g_w = _ops.sparse_conv_backward(features, filters.detach().contiguous().view(K, cin, cout),
-                                              grad_out.contiguous().float(), nbr, ctx.mirror, inv=ctx.inv, bf16=ctx.amp)
+        with _ops.precision(ctx.mode):
+            g_in, g_w = _ops.sparse_conv_backward(features, filters.detach().contiguous().view(K, cin, cout),
+                                                  grad_out.contiguous().float(), nbr, ctx.mirror, inv=ctx.inv, bf16=ctx.amp)
         g_b = grad_out.sum(0) if ctx.has_bias else None
         return g_in, g_w.view_as(filters), g_b, None, None, None, None
 

@@ -20,6 +20,7 @@ losses.  Plain torch formulation (`loss`, autograd) from dualfusion/tf_losses.py
 (incl. the rotated 3-D IoU), the Gaussian heat-map targets and the three losses with their gradients are csrc/tfloss.hip
 kernels (`loss_device`), the assignment itself `scipy.optimize.linear_sum_assignment` on the host as in the reference."""
 import copy
+import os
 
 import torch
 import torch.nn.functional as F
@@ -87,8 +88,19 @@ class MultiheadAttention(nn.Module):
 
     def attend(self, q, k, v):
         """q [N, L, E], k / v [N, S, E] already projected -> out_proj(softmax(q k^T / sqrt(d)) v)."""
-        o = F.scaled_dot_product_attention(self._heads(q), self._heads(k), self._heads(v),
-                                           dropout_p=self.dropout if self.training else 0.0)
+        qh, kh, vh = self._heads(q), self._heads(k), self._heads(v)
+        if (torch.is_grad_enabled() and q.is_cuda and q.shape[1] * 16 <= k.shape[1]
+                and os.environ.get("DF3D_TFHEAD_MATH_ATTN", "1") == "1"):
+            # training, a few hundred queries against a BEV map of keys: the library's fused attention parallelises its
+            # backward over QUERY blocks (200 queries = a handful of workgroups: 2.4 ms for d(query) + 0.8 ms forward per call at
+            # 200 x 32 400 x 8 heads x 4 samples); the explicit softmax(q k^T / sqrt(d)) v is batched GEMMs + one softmax over
+            # [N, heads, L, S] and differentiates through the same
+            p = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)) * (self.head_dim ** -0.5), -1)
+            if self.training and self.dropout > 0:
+                p = F.dropout(p, self.dropout)
+            o = torch.matmul(p, vh)
+        else:
+            o = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=self.dropout if self.training else 0.0)
         return self.out_proj(o.transpose(1, 2).reshape(q.shape[0], q.shape[1], self.embed_dim))
 
     def forward(self, query, key, value):
@@ -341,14 +353,20 @@ class TransFusionHead(nn.Module):
         return super(TransFusionHead, self).train(mode)
 
     # ------------------------------------------------------------------ plain torch path (training / CPU)
-    def forward_reference(self, inputs):
-        """forward_single (transfusion_head.py:797-1030), LiDAR-only statements."""
+    def forward_reference(self, inputs, convs=None):
+        """forward_single (transfusion_head.py:797-1030), LiDAR-only statements.  convs: callable that produces (shared-conv
+        map, dense heat map) -- the training forward on the row kernels (`_train_convs_rows`); None = the torch modules."""
         B = inputs.shape[0]
-        lidar_feat = self.shared_conv(inputs)
-        flat = lidar_feat.view(B, lidar_feat.shape[1], -1)
+        if convs is not None:
+            lidar_feat, dense_heatmap = convs(inputs)
+            flat = lidar_feat.flatten(2)                            # a view of the channels-last rows ([B, C, HW] strided)
+        else:
+            lidar_feat = self.shared_conv(inputs)
+            flat = lidar_feat.view(B, lidar_feat.shape[1], -1)
         bev_pos = self.bev_pos.repeat(B, 1, 1).to(lidar_feat)
         if self.initialize_by_heatmap:
-            dense_heatmap = self.heatmap_head(lidar_feat)
+            if convs is None:
+                dense_heatmap = self.heatmap_head(lidar_feat)
             heatmap = dense_heatmap.detach().sigmoid()
             pad = self.nms_kernel_size // 2
             local_max = torch.zeros_like(heatmap)
@@ -392,9 +410,42 @@ class TransFusionHead(nn.Module):
                 new_res[key] = ret_dicts[0][key]
         return [new_res]
 
+    def _train_convs_rows(self, inputs):
+        """shared_conv and the heat-map branch of a TRAINING forward on the row kernels (the neck's `_train_stack`: every 3 x 3
+        convolution is `SparseConvFunction` over the full neighbour table of the BEV grid -- forward, input gradient and filter
+        gradient on csrc/spconv_split.hip / spconv_bwd.hip --, BatchNorm over the pixel rows on csrc/bnrows.hip) instead of
+        MIOpen's fp32 convolutions (5.2 ms of the 68 ms TransFusion training step at bs 4).  -> (lidar_feat [B, C, H, W] as a
+        view of channels-last rows, dense_heatmap [B, classes, H, W])."""
+        from .necks import RPN, _rows_of, _train_stack
+        from .spconv.conv import SparseConvFunction
+        B, _, H, W = inputs.shape
+        tables = self.__dict__.setdefault("_train_tables", {})
+        rows, _ = _rows_of(inputs)
+        key = (B, H, W)
+        if key not in tables:
+            tables[key] = _ops.conv2d_neighbors(B, H, W, 3, 3, 1, 1, False, rows.device)[0]
+        nbr = tables[key]
+        sc = self.shared_conv
+        hm0, hm1 = self.heatmap_head[0], self.heatmap_head[1]
+        C = hm1.out_channels
+        with _ops.precision("split"):          # (the head's own convolutions stay fp32-grade in the bf16 mode, as in inference)
+            feat = SparseConvFunction.apply(rows.contiguous(), sc.weight.permute(2, 3, 1, 0), sc.bias, nbr, nbr.shape[1], True, None)
+            mid, _, _ = _train_stack([(hm0.conv, hm0.bn, True, 1)], feat, B, H, W,
+                                     self.__dict__.setdefault("_train_stack_tables", {}))
+            # the class maps as 32 output columns (zero filters behind the real ones: the narrowest block of the row kernel;
+            # autograd slices the gradient of the padding away)
+            w = F.pad(hm1.weight.permute(2, 3, 1, 0), (0, 32 - C))
+            b = F.pad(hm1.bias, (0, 32 - C)) if hm1.bias is not None else None
+            heat = SparseConvFunction.apply(mid.contiguous(), w, b, nbr, nbr.shape[1], True, None)[:, :C]
+        to_map = lambda r: r.reshape(B, H, W, -1).permute(0, 3, 1, 2)                       # noqa: E731
+        return to_map(feat), to_map(heat)
+
     def forward_single(self, inputs, img_inputs=None, img_metas=None):
         if (self.training or torch.is_grad_enabled() or not inputs.is_cuda or inputs.dtype != torch.float32
                 or _ops.CONV_PRECISION == "fp32" or not self._row_kernels_fit(inputs)):
+            if (torch.is_grad_enabled() and inputs.is_cuda and inputs.dtype == torch.float32 and self._row_kernels_fit(inputs)
+                    and os.environ.get("DF3D_TFHEAD_TRAIN_ROWS", "1") == "1"):
+                return self.forward_reference(inputs, convs=self._train_convs_rows)
             return self.forward_reference(inputs)
         # the head's own convolutions stay split precision (fp32-grade) in the bf16 mode of the backbone / neck
         return self.forward_rows(inputs)

@@ -284,6 +284,12 @@ int df3d_sparse_conv_grad_filters_scaled(const float *features, int n_in, int ci
                                          const int32_t *nbr, int kvol, const float *grad_scale, float *grad_filters, void *stream);
 int df3d_rows_grad_weights_scaled(const float *x, const float *grad_out, long long n, int cin, int cout, const float *x_scale,
                                   const float *g_scale, float *grad_weights, void *stream);
+/* round 6 -- the filter gradient of bf16 mixed-precision training (BASELINE configs[2] / [3]): both operands rounded to one bf16
+ * part where they are staged, one matrix-core product per pair block, fp32 accumulate (what the reference's fp16-AMP runs give
+ * `indice_conv_backward`'s filtersGrad, TF/mmdet3d/ops/spconv/include/spconv/spconv_ops.h:363-456); layers under 64 channels
+ * take df3d_sparse_conv_grad_filters. */
+int df3d_sparse_conv_grad_filters_bf16(const float *features, int n_in, int cin, const float *grad_out, int n_out, int cout,
+                                       const int32_t *nbr, int kvol, float *grad_filters, void *stream);
 int df3d_rows_pow2_scale(const float *x, long long n_elems, float *scale, void *stream);
 int df3d_pow2_scale_floats(void);
 /* out[n][c] = sum_s x[n][c][s] * g[n][s] over channel-first maps x [nmaps][channels][S], g [nmaps][S]: the weight gradient of a

@@ -994,6 +994,19 @@ def test_filter_gradient_kernels_against_float64(cin, cout, K, n_in, n_out, dens
             gd = (gout * gs).to(dev)
             got = ops.sparse_conv_grad_filters(feats.to(dev), gd, nbr.to(dev), grad_scale=ops.rows_pow2_scale(gd)).cpu().double()
             assert float((got - ref * gs).abs().max()) <= 4e-6 * scale * gs, gs
+        # round 6: bf16 mixed-precision training -- ONE bf16 part per operand, one product: exact (fp32 accumulate) for operands
+        # that are bf16 values already, bf16-grade (2^-8 per operand, averaging over the pairs) for fp32 operands
+        fb, gb = feats.bfloat16().float(), gout.bfloat16().float()
+        refb = torch.zeros((K, cin, cout), dtype=torch.float64)
+        for k in range(K):
+            o = (nbr[k] >= 0).nonzero(as_tuple=True)[0]
+            refb[k] = fb[nbr[k][o].long()].double().t() @ gb[o].double()
+        got = ops.sparse_conv_grad_filters(fb.to(dev), gb.to(dev), nbr.to(dev), bf16=True).cpu().double()
+        assert float((got - refb).abs().max()) <= 4e-6 * scale
+        got = ops.sparse_conv_grad_filters(feats.to(dev), gout.to(dev), nbr.to(dev), bf16=True).cpu().double()
+        if cin >= 64 and cout >= 64:                                           # (narrower layers stay on the fp32 kernel)
+            assert float((got - refb).abs().max()) <= 4e-6 * scale            # round-to-nearest-even, as torch's .bfloat16()
+        assert float((got - ref).abs().max()) <= 1e-2 * scale
 
 
 @pytest.mark.gpu
