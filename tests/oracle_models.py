@@ -360,6 +360,236 @@ def centerpoint_fusion(sd, levels, img_feats, calib, image_hw, cams, voxel_size,
     return out
 
 
+# ------------------------------------------------------------------------- TransFusion fusion layer (round 6)
+def _undo_3d_augmentation(p, m):
+    """`apply_3d_transformation(points, 'LIDAR', img_meta, reverse=True)` (TF/mmdet3d/models/fusion_layers/
+    coord_transform.py:6-94 over core/points/base_points.py:77-141,199-205): the recorded flow undone in reverse order."""
+    flow = list(m.get('transformation_3d_flow', []))
+    if not flow:
+        return p
+    p = np.array(p, np.float32, copy=True)
+    rot = np.asarray(m['pcd_rotation'], np.float32) if 'pcd_rotation' in m else np.eye(3, dtype=np.float32)
+    trans = np.asarray(m['pcd_trans'], np.float32) if 'pcd_trans' in m else np.zeros(3, np.float32)
+    scale = np.float32(m.get('pcd_scale_factor', 1.0))
+    for op in flow[::-1]:
+        if op == 'T':
+            p = p + (-trans)
+        elif op == 'S':
+            p = p * np.float32(1.0 / scale)
+        elif op == 'R':
+            p = p @ np.linalg.inv(rot).astype(np.float32)
+        elif op == 'HF':
+            if m.get('pcd_horizontal_flip', False):
+                p = p * np.array([1, -1, 1], np.float32)
+        elif op == 'VF':
+            if m.get('pcd_vertical_flip', False):
+                p = p * np.array([-1, 1, 1], np.float32)
+        else:
+            raise ValueError(op)
+    return p
+
+
+def transfusion_project(pts, m):
+    """`get_2d_coor_multi` + `projection` (TF/mmdet3d/models/fusion_layers/point_fusion.py:509-643) for one sample with the
+    lidar -> camera chain of the nuScenes records composed into `m['lidar2cam']` [6, 4, 4] / `m['cam_intrinsic']` [6, 3, 3]:
+    float64 numpy like the devkit arithmetic, cameras in order (a later camera overwrites), visibility on the ORIGINAL image,
+    -> (coor_2d [n, 3] = (camera, x / w_pad, y / h_pad), coor_2d_o [n, 3] = (camera, x, y) in input-image pixels), zeros for
+    points no camera sees."""
+    p = _undo_3d_augmentation(np.asarray(pts, np.float32)[:, :3], m).astype(np.float64)
+    n = len(p)
+    c2, c2o = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    H, W = m['ori_shape'][:2]
+    sf = np.asarray(m.get('scale_factor', [1.0, 1.0]), np.float32)[:2]
+    off = np.float32(m.get('img_crop_offset', 0))
+    hp, wp = m['input_shape'][:2]
+    for idx in range(len(m['lidar2cam'])):
+        T = np.asarray(m['lidar2cam'][idx], np.float64)
+        K = np.asarray(m['cam_intrinsic'][idx], np.float64)
+        pc = p @ T[:3, :3].T + T[:3, 3]
+        depth = pc[:, 2]
+        uvw = pc @ K.T
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u, v = uvw[:, 0] / uvw[:, 2], uvw[:, 1] / uvw[:, 2]
+        mask = (depth > 1.0) & (u > 1) & (u < W - 1) & (v > 1) & (v < H - 1)
+        uv = np.stack([u[mask], v[mask]], 1).astype(np.float32)                 # points.new_tensor(...): fp32 from here on
+        xy = uv * sf - off
+        if m.get('flip', False):
+            xy[:, 0] = np.float32(m['img_shape'][1]) - xy[:, 0]
+        c2[mask, 0], c2o[mask, 0] = idx, idx
+        c2o[mask, 1:] = xy
+        c2[mask, 1:] = xy / np.array([wp, hp], np.float32)
+    return c2, c2o
+
+
+def transfusion_fusion(sd, pts_list, pts_feats, img, metas, prefix="actr.", num_cams=6):
+    """`point_fusion.ACTR.forward` with fusion_method 'sum' (point_fusion.py:342-394 split_param, :396-408 agg_param,
+    :410-507 forward): per-sample projection, zero-padded per-(sample, camera) query lists in row order, the image feature of
+    a query = level-0 map at (pixel // 4), ACTR on the padded lists, additive write-back.
+    pts_list: per sample [n_b, 3] voxel centres (augmented frame); pts_feats [sum n_b, C]; img [B * 6, 256, h, w]."""
+    B = len(pts_list)
+    C, IC = pts_feats.shape[1], img.shape[1]
+    proj = [transfusion_project(p, m) for p, m in zip(pts_list, metas)]
+    lists = []
+    for b in range(B):
+        cam = proj[b][0][:, 0].astype(np.int64)
+        lists += [np.nonzero(cam == n)[0] for n in range(num_cams)]
+    max_pts = max(len(l) for l in lists)
+    v_feat = np.zeros((B * num_cams, max_pts, C), np.float32)
+    v_i = np.zeros((B * num_cams, max_pts, IC), np.float32)
+    grid = np.zeros((B * num_cams, max_pts, 2), np.float32)
+    qpts = np.zeros((B * num_cams, max_pts, 3), np.float32)
+    starts = np.cumsum([0] + [len(p) for p in pts_list])
+    for i, rows in enumerate(lists):
+        b = i // num_cams
+        k = len(rows)
+        v_feat[i, :k] = pts_feats[starts[b]:starts[b + 1]][rows]
+        grid[i, :k] = proj[b][0][rows, 1:3]
+        qpts[i, :k] = np.asarray(pts_list[b], np.float32)[rows, :3]
+        px = proj[b][1][rows, 1:].astype(np.int64) // 4                          # .to(torch.long) // 4
+        v_i[i, :k] = img[i][:, px[:, 1], px[:, 0]].T
+    enh = actr_forward(sd, v_feat, grid, img, qpts, v_i, prefix=prefix)
+    out = np.array(pts_feats, np.float32, copy=True)
+    for i, rows in enumerate(lists):
+        b = i // num_cams
+        out[starts[b] + rows] += enh[i, :len(rows)]
+    return out
+
+
+# ------------------------------------------------------------------------- Voxel-RCNN fusion glue (round 6)
+def _kitti_lidar_to_img(p, l2i):
+    """`Calibration.lidar_to_img` (VR/pcdet/utils/calibration_kitti.py:64-86) through the composed chain `l2i` [3, 4] whose
+    third row is the rectified-camera depth row (make_golden.gen_vr_fusion composes it): float64 like the devkit's numpy."""
+    ph = np.concatenate([p.astype(np.float64), np.ones((len(p), 1))], 1) @ np.asarray(l2i, np.float64).T
+    return ph[:, :2] / ph[:, 2:3]
+
+
+def _vr_voxel_points(ind_b, b, voxel_stride, aug):
+    """Voxel corner (z, y, x) * stride * voxel_size + range minimum in fp32, then the augmentation records undone
+    (spconv_backbone.py:671-705): scale, rotation about z, flip -- columns stay (z, y, x)."""
+    vs = np.array([0.1, 0.05, 0.05], np.float32)
+    lo = np.array([-3.0, -40.0, 0.0], np.float32)
+    v = (ind_b[:, 1:] * voxel_stride).astype(np.float32) * vs + lo                 # (z, y, x)
+    if aug is not None:
+        if "noise_scale" in aug:
+            v = v / np.float32(aug["noise_scale"][b])
+        if "noise_rot" in aug:
+            a = -np.float32(aug["noise_rot"][b])
+            c, s_ = np.float32(np.cos(a)), np.float32(np.sin(a))
+            xyz = v[:, ::-1]
+            rot = np.array([[c, s_, 0], [-s_, c, 0], [0, 0, 1]], np.float32)          # common_utils.rotate_points_along_z
+            v = (xyz @ rot)[:, ::-1]
+        if "flip_x" in aug and aug["flip_x"][b]:
+            v = v * np.array([1, -1, 1], np.float32)
+        if "flip_y" in aug and aug["flip_y"][b]:
+            v = v * np.array([1, 1, -1], np.float32)
+    return np.ascontiguousarray(v, np.float32)
+
+
+def _interp_bilinear(fmap, hw):
+    import torch
+    import torch.nn.functional as F
+    return F.interpolate(_t(fmap), tuple(hw), mode="bilinear").numpy()
+
+
+def voxel_rcnn_mvx(indices, features, fmap, lidar2img, image_hw, voxel_stride=1, aug=None):
+    """`point_fusion(..., 'MVX')` with fuse_sum (spconv_backbone.py:650-760): the image feature at the truncated pixel of every
+    voxel inside the image, bilinearly up-sampled map, added to the LiDAR row."""
+    H, W = image_hw
+    up = _interp_bilinear(fmap, (H, W))
+    out = np.array(features, np.float32, copy=True)
+    for b in range(fmap.shape[0]):
+        rows = np.nonzero(indices[:, 0] == b)[0]
+        v = _vr_voxel_points(indices[rows], b, voxel_stride, aug)
+        uv = _kitti_lidar_to_img(v[:, ::-1], lidar2img[b])
+        px = uv.astype(np.float32).astype(np.int64)                                 # torch.Tensor(voxels_2d).long()
+        ok = (px[:, 1] >= 0) & (px[:, 1] < H) & (px[:, 0] >= 0) & (px[:, 0] < W)
+        out[rows[ok]] += up[b][:, px[ok, 1], px[ok, 0]].T
+    return out
+
+
+def voxel_rcnn_actr_fusion(sd, indices, features, fmap, lidar2img, image_hw, lt_cfg, voxel_stride=8, aug=None, num_layers=4,
+                           prefix=""):
+    """`point_fusion(..., 'ACTRv2')` with fuse_sum (spconv_backbone.py:650-820): one zero-padded query list per sample (ALL its
+    voxels, in row order), normalised un-truncated image coordinates, image features at the truncated pixel of the up-sampled
+    map (zero outside the image), ACTRv2 = LocalTransformer + dual-query layer with the gate BEFORE the feed-forward blocks
+    (VR/pcdet/models/model_utils/actr_transformer.py:496-512), added to the LiDAR rows."""
+    import torch
+    import torch.nn.functional as F
+    H, W = image_hw
+    B = fmap.shape[0]
+    up = _interp_bilinear(fmap, (H, W))
+    rows_b = [np.nonzero(indices[:, 0] == b)[0] for b in range(B)]
+    n_max = max(len(r) for r in rows_b)
+    C, IC = features.shape[1], fmap.shape[1]
+    v_feat = np.zeros((B, n_max, C), np.float32)
+    v_i = np.zeros((B, n_max, IC), np.float32)
+    grid = np.zeros((B, n_max, 2), np.float32)
+    qpts = np.zeros((B, n_max, 3), np.float32)
+    for b, rows in enumerate(rows_b):
+        v = _vr_voxel_points(indices[rows], b, voxel_stride, aug)
+        uv = _kitti_lidar_to_img(v[:, ::-1], lidar2img[b])
+        px = uv.astype(np.float32).astype(np.int64)
+        ok = (px[:, 1] >= 0) & (px[:, 1] < H) & (px[:, 0] >= 0) & (px[:, 0] < W)
+        k = len(rows)
+        v_feat[b, :k] = features[rows]
+        v_i[b, :k][ok] = up[b][:, px[ok, 1], px[ok, 0]].T
+        grid[b, :k] = (uv / np.array([W, H])).astype(np.float32)
+        qpts[b, :k] = v[:, ::-1]                                                    # pts_b[..., inv_idx] = (x, y, z)
+    enh = actr_v2_forward(sd, v_feat, grid, fmap, qpts, v_i, lt_cfg, num_layers=num_layers, prefix=prefix)
+    out = np.array(features, np.float32, copy=True)
+    for b, rows in enumerate(rows_b):
+        out[rows] += enh[b, :len(rows)]
+    return out
+
+
+def actr_v2_forward(sd, v_feat, grid, i_feat, lidar_grid, v_i_feat, lt_cfg, num_layers=4, n_heads=8, n_points=4, prefix=""):
+    """ACTRv2 of the Voxel-RCNN tree (VR/pcdet/models/model_utils/actr.py:131-187, actr_transformer.py:473-512): as
+    `actr_forward`, with a LocalTransformer over the LiDAR queries in front of every dual-query layer (:496-498) and the
+    bidirectional gate right after the attention, the two feed-forward blocks on the gated streams (:503-512)."""
+    import torch
+    import torch.nn.functional as F
+    P = lambda k: _t(sd[prefix + k])
+    v_feat, grid, i_feat, lidar_grid, v_i_feat = [_t(np.asarray(a, np.float32)) for a in
+                                                  (v_feat, grid, i_feat, lidar_grid, v_i_feat)]
+    N, Q, C = v_feat.shape
+    H, W = i_feat.shape[2:]
+    qi = F.conv1d(v_i_feat.transpose(1, 2), P("i_input_proj.0.weight"), P("i_input_proj.0.bias"))
+    qi = F.group_norm(qi, 32, P("i_input_proj.1.weight"), P("i_input_proj.1.bias"), 1e-5).transpose(1, 2)
+    d = lidar_grid[..., 0] / 60.0 * (2 * np.pi)
+    dim_t = torch.arange(C, dtype=torch.float32)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / C)
+    pd = d[:, :, None] / dim_t
+    q_pos = torch.stack((pd[:, :, 0::2].sin(), pd[:, :, 1::2].cos()), dim=3).flatten(2)
+    src = F.group_norm(F.conv2d(i_feat, P("input_proj.0.0.weight"), P("input_proj.0.0.bias")), 32,
+                       P("input_proj.0.1.weight"), P("input_proj.0.1.bias"), 1e-5)
+    src = src.flatten(2).transpose(1, 2)
+    q = v_feat
+    D = C // n_heads
+    lin = lambda x, k: F.linear(x, P(k + ".weight"), P(k + ".bias"))                 # noqa: E731
+    for i in range(num_layers):
+        lt_sd = {k[len(prefix + "transformer.encoder.lidar_attns.%d." % i):]: v for k, v in sd.items()
+                 if k.startswith(prefix + "transformer.encoder.lidar_attns.%d." % i)}
+        q = _t(local_transformer(lt_sd, lidar_grid.numpy(), q.permute(0, 2, 1).contiguous().numpy(), lt_cfg["npoint"],
+                                 lt_cfg["radius"], lt_cfg["nsample"], num_layers=lt_cfg["num_layers"]))
+        L = "transformer.encoder.layers.%d." % i
+        value = lin(src, L + "self_attn.value_proj")
+        query, iq = q + q_pos, qi + q_pos
+        off = lin(query, L + "self_attn.sampling_offsets")
+        aw = lin(query + iq, L + "self_attn.attention_weights")
+        aw = torch.softmax(aw.view(N, Q, n_heads, n_points), -1).view(N, Q, n_heads, 1, n_points)
+        off = off.view(N, Q, n_heads, 1, n_points, 2)
+        loc = grid[:, :, None, None, None, :] + off / torch.tensor([W, H], dtype=torch.float32)
+        att = orc.ms_deform_attn(value.view(N, H * W, n_heads, D).numpy(), [(H, W)], loc.numpy(), aw.numpy())
+        qi = F.layer_norm(qi + lin(_t(att), L + "self_attn.output_proj"), (C,), P(L + "norm1.weight"), P(L + "norm1.bias"))
+        fuse = (q + qi).transpose(1, 2)
+        s1 = torch.sigmoid(F.conv1d(fuse, P(L + "fusion_layer.b_conv1d.weight"), P(L + "fusion_layer.b_conv1d.bias"))).transpose(1, 2)
+        s2 = torch.sigmoid(F.conv1d(fuse, P(L + "fusion_layer.a_conv1d.weight"), P(L + "fusion_layer.a_conv1d.bias"))).transpose(1, 2)
+        q, qi = q + qi * s1, qi + q * s2
+        qi = F.layer_norm(qi + lin(F.relu(lin(qi, L + "linear1")), L + "linear2"), (C,), P(L + "norm2.weight"), P(L + "norm2.bias"))
+        q = F.layer_norm(q + lin(F.relu(lin(q, L + "linear3")), L + "linear4"), (C,), P(L + "norm3.weight"), P(L + "norm3.bias"))
+    return q.numpy()
+
+
 # ------------------------------------------------------------------------- TransFusion head (section 8f row 3)
 def transfusion_head(sd, x, num_proposals, num_classes=10, num_heads=8, nms_kernel_size=3, dataset="nuScenes",
                      num_decoder_layers=1, heads=("center", "height", "dim", "rot", "vel", "heatmap"), bn_eps=1e-5):

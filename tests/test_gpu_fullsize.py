@@ -336,9 +336,9 @@ def test_bf16_mixed_precision_training_step_vs_fp32_grade():
     """bf16 mixed-precision training (the reference trains its fp16-AMP configurations with
     torch.cuda.amp): with DF3D_CONV_PRECISION=bf16 every sparse / dense convolution of backbone, neck and head that has a
     bf16 kernel runs forward AND input-gradient on it (operands rounded to bf16, fp32 accumulate, fp32 rows out), filter
-    gradients on the fp32 matrix cores, BatchNorm / losses / master weights fp32.
+    gradients of the >= 64-channel layers on single bf16 parts as well (round 6), BatchNorm / losses / master weights fp32.
     (1) one convolution layer against float64: forward and input gradient within bf16 rounding (3e-3 of the scale), the
-        filter gradient -- fp32 products of the SAME fp32 operands -- within 1e-5;
+        filter gradient within bf16 rounding too (fp32 products of the fp32 operands, DF3D_WGRAD_BF16=0: within 1e-5);
     (2) one training step of the LiDAR detector at BASELINE size against the same step on the fp32-grade kernels: losses
         within 2 %, gradient norms within 15 %, direction cos > 0.99 at the head and > 0.6 everywhere.  (This randomly
         initialised 40-layer net with batch-statistics BatchNorm amplifies perturbations ~10^3 x on the way back: the
@@ -370,7 +370,20 @@ def test_bf16_mixed_precision_training_step_vs_fp32_grade():
         ops.CONV_PRECISION = old
     rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())   # noqa: E731
     assert rel(y.detach(), ref.detach()) < 3e-3 and rel(xg.grad, xd.grad) < 3e-3, (rel(y.detach(), ref.detach()), rel(xg.grad, xd.grad))
-    assert rel(wg.grad, wd.grad) < 1e-5, rel(wg.grad, wd.grad)
+    # round 6: the filter gradient of the bf16 mode is a bf16 product too (one rounded part per operand, fp32 accumulate:
+    # df3d_sparse_conv_grad_filters_bf16 -- what an fp16-AMP reference gives its filtersGrad); DF3D_WGRAD_BF16=0 keeps it on
+    # fp32 products of the fp32 operands (1e-5)
+    assert rel(wg.grad, wd.grad) < 5e-3, rel(wg.grad, wd.grad)
+    import os
+    os.environ["DF3D_WGRAD_BF16"] = "0"
+    try:
+        ops.CONV_PRECISION = "bf16"
+        xg2, wg2 = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        SparseConvFunction.apply(xg2, wg2, None, nbr.to(DEV), n, False).backward(go.to(DEV))
+    finally:
+        ops.CONV_PRECISION = old
+        os.environ.pop("DF3D_WGRAD_BF16", None)
+    assert rel(wg2.grad, wd.grad) < 1e-5, rel(wg2.grad, wd.grad)
 
     pts = [torch.from_numpy(synth.nusc_sweep(seed=12)).to(DEV)]
     tg = synth.centerhead_targets(1, [t["num_class"] for t in NUSC_TASKS], seed=5)

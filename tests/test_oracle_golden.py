@@ -496,3 +496,61 @@ def test_transfusion_projection_vs_reference_golden(golden):
         assert len(set(want[:, 0].astype(int))) == 6 and (want_o[:, 1:] == 0).all(1).sum() > 5      # all cameras, some unseen
         np.testing.assert_allclose(pix.numpy(), want_o[:, 1:], atol=5e-3, rtol=0)
         np.testing.assert_allclose(norm.numpy(), want[:, 1:], atol=5e-5, rtol=0)
+
+
+# ---- round 6: the fusion adapters of the other two trees as oracle compositions (the full-size parity tests of configs[2] / [4]
+#      use them instead of the device layer)
+@pytest.mark.parametrize("tag,aug", [("plain", False), ("aug", True)])
+def test_transfusion_fusion_oracle_vs_reference_golden(golden, tag, aug):
+    """tests/oracle_models.transfusion_fusion (projection through the composed nuScenes chain in float64, last visible camera
+    wins, zero-padded per-camera lists, image feature at pixel // 4, ACTR, additive write-back) against the output of the
+    reference's own point_fusion.ACTR.forward (golden tf_fusion.npz; TF/mmdet3d/models/fusion_layers/point_fusion.py:342-643)."""
+    import oracle_models as om
+    from make_golden import ACTR_CFG, tff_inputs, tff_metas    # noqa: F401
+    g = golden("tf_fusion.npz")
+    from dualfusion.fusion_tf import ACTRFusionLayer
+    shapes = {k: tuple(v.shape) for k, v in ACTRFusionLayer(pfat_cfg=dict(ACTR_CFG)).state_dict().items()}
+    assert sorted(shapes) == list(g["param_names"])
+    sd = detgen.det_state_dict(shapes)
+    pts, feats, img = tff_inputs()
+    metas, _, _, _ = tff_metas(aug)
+    ours = []
+    for b, m in enumerate(metas):
+        mm = {k: v for k, v in m.items() if k not in ("sample_idx", "filename")}
+        mm["lidar2cam"], mm["cam_intrinsic"] = g[tag + "_lidar2cam"][b], g[tag + "_intrinsic"][b]
+        ours.append(mm)
+    c2 = np.concatenate([om.transfusion_project(p, m)[0] for p, m in zip(pts, ours)])
+    c2o = np.concatenate([om.transfusion_project(p, m)[1] for p, m in zip(pts, ours)])
+    assert np.array_equal(c2[:, 0], g[tag + "_coor_2d"][:, 0])                       # camera assignment: exact
+    # (the reference walks five frames with its points held in a float32 array -- the global frame's ~1 km coordinates cost it
+    # ~1e-4 m --, the composition goes through the composed matrix in float64: a few 1e-3 px)
+    np.testing.assert_allclose(c2o[:, 1:], g[tag + "_coor_2d_o"][:, 1:], atol=5e-3, rtol=0)
+    assert np.array_equal(c2o[:, 1:].astype(np.int64) // 4, g[tag + "_coor_2d_o"][:, 1:].astype(np.int64) // 4)   # same feature pixels
+    out = om.transfusion_fusion(sd, pts, feats, img, ours)
+    want = g[tag + "_fused"]
+    assert np.abs(out - want).max() <= 2e-4 * np.abs(want).max(), np.abs(out - want).max()
+
+
+@pytest.mark.parametrize("tag,with_aug", [("plain", False), ("aug", True)])
+def test_voxel_rcnn_fusion_oracle_vs_reference_golden(golden, tag, with_aug):
+    """tests/oracle_models.voxel_rcnn_mvx / voxel_rcnn_actr_fusion against the reference's own VoxelBackBone8xFusion.
+    point_fusion (golden vr_fusion.npz; VR/pcdet/models/backbones_3d/spconv_backbone.py:650-827): the MVX nearest-pixel sum at
+    stride 1 and the ACTRv2 dual-query fusion at stride 8 (LocalTransformer per layer, gate before the feed-forward blocks)."""
+    import oracle_models as om
+    from make_golden import VRF, vrf_inputs
+    g = golden("vr_fusion.npz")
+    from dualfusion import actr as actr_mod
+    model = actr_mod.build(dict(VRF["actr"]), model_name="ACTRv2", lt_cfg=dict(VRF["lt"]),
+                           hybrid_cfg=dict(VRF["hybrid"], gate_before_ffn=True))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert sorted(shapes) == list(g["param_names"])
+    sd = detgen.det_state_dict(shapes)
+    ind1, f1, ind4, f4, mvx, img, aug = vrf_inputs()
+    aug = aug if with_aug else None
+    l2i = g["lidar2img"]
+    y1 = om.voxel_rcnn_mvx(ind1, f1, mvx, l2i, VRF["hw"], 1, aug)
+    want1 = g[tag + "_mvx"]
+    assert np.abs(y1 - want1).max() <= 1e-5 * max(1.0, np.abs(want1).max()), np.abs(y1 - want1).max()
+    y4 = om.voxel_rcnn_actr_fusion(sd, ind4, f4, img, l2i, VRF["hw"], VRF["lt"], 8, aug, num_layers=VRF["actr"]["num_enc_layers"])
+    want4 = g[tag + "_actr"]
+    assert np.abs(y4 - want4).max() <= 2e-4 * np.abs(want4).max(), np.abs(y4 - want4).max()
