@@ -17,6 +17,15 @@ namespace df3d {
 
 DF3D_SPLIT_OVERFLOW_TU(pointops)
 
+// Squared distance as the reference computes it ON ITS GPU: nvcc contracts `dx * dx + dy * dy + dz * dz` (--fmad=true, the
+// default) into fma(dz, dz, fma(dy, dy, dx * dx)).  Voxel centres sit on a lattice, so exact ties between candidates are common
+// and the LAST BIT of this sum decides which point furthest point sampling picks (found at the full KITTI size in round 6: the
+// oracle, compiled without contraction, left the device's sequence at pick 79 of 2048).  Written out so that neither compiler
+// chooses: the kernels here and oracle/df3d_oracle.c evaluate the same three roundings.
+__device__ __forceinline__ float dist2_fma(float dx, float dy, float dz) {
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
 constexpr int FPS_MAXPT = 32;  // points per thread kept in registers (N <= 32 * 1024)
 
 struct Best {
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
         int k = tid + i * bs;
         if (k < N) {
           float x2 = XYZ ? px[i] : p[k * 3], y2 = XYZ ? py[i] : p[k * 3 + 1], z2 = XYZ ? pz[i] : p[k * 3 + 2];
-          float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+          float d = dist2_fma(x2 - x1, y2 - y1, z2 - z1);
           float d2 = fminf(d, temp[i]);
           temp[i] = d2;
           if (d2 > me.v) {
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
     } else {
       for (int k = tid; k < N; k += bs) {
         float x2 = p[k * 3], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
-        float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+        float d = dist2_fma(x2 - x1, y2 - y1, z2 - z1);
         float d2 = fminf(d, tg[k]);
         tg[k] = d2;
         if (d2 > me.v) {
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(const float *
       bool hit = false;
       if (k < tn) {
         const float x = tile[k * 3], y = tile[k * 3 + 1], z = tile[k * 3 + 2];
-        const float d2 = (nx - x) * (nx - x) + (ny - y) * (ny - y) + (nz - z) * (nz - z);
+        const float d2 = dist2_fma(nx - x, ny - y, nz - z);
         hit = d2 == 0.f || (d2 >= min_r2 && d2 < max_r2);
       }
       const unsigned long long mask = __ballot(hit);
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(512) void fps_kernel_half(const float *__restrict__
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const f2 dx = px[e][q] - x1, dy = py[e][q] - y1, dz = pz[e][q] - z1;
-        const f2 d = dx * dx + dy * dy + dz * dz;
+        const f2 d = (f2){dist2_fma(dx[0], dy[0], dz[0]), dist2_fma(dx[1], dy[1], dz[1])};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const float d2 = fminf(d[h], temp[e][q][h]);

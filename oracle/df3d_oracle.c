@@ -318,6 +318,12 @@ int orc_get_indice_pairs(const int32_t *indices, int N, int batch, const int *ou
  * the LOWEST k of its strided sequence (strict '>', :66-67) and the tree reduction
  * keeps the LOWER tid on ties (__update :17-24), i.e. among maxima the winner has
  * the smallest (k mod block, k).  xyz [B,N,3]; idx out [B,m]. */
+/* The squared distance of both kernels as the reference's GPU build evaluates it: nvcc contracts dx*dx + dy*dy + dz*dz
+ * (--fmad=true by default) into fma(dz, dz, fma(dy, dy, dx*dx)).  On lattice points (voxel centres) exact ties between
+ * candidates are common, and the last bit of this sum decides the pick; this file is compiled with -ffp-contract=off, so
+ * the contraction is written out (csrc/pointops.hip does the same). */
+static float orc_dist2(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+
 int orc_fps_block(int n) {
   int pow_2 = (int)(log((double)n) / log(2.0));
   int t = 1 << pow_2;
@@ -341,7 +347,7 @@ void orc_fps(const float *xyz, int B, int N, int m, int32_t *idx) {
       int besti = 0;
       for (int k = 0; k < N; ++k) {
         float x2 = p[k * 3], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
-        float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+        float d = orc_dist2(x2 - x1, y2 - y1, z2 - z1);
         float d2 = d < temp[k] ? d : temp[k];
         temp[k] = d2;
         if (d2 > best || (d2 == best && (k % bs) < (besti % bs))) { best = d2; besti = k; }
@@ -368,7 +374,7 @@ void orc_ball_query(const float *new_xyz, const float *xyz, int B, int N, int m,
       for (int k = 0; k < N && cnt < nsample; ++k) {
         const float *p = xyz + ((size_t)b * N + k) * 3;
         float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
-        float d2 = dx * dx + dy * dy + dz * dz;
+        float d2 = orc_dist2(dx, dy, dz);
         if (d2 == 0 || (d2 >= min_r2 && d2 < max_r2)) {
           if (cnt == 0)
             for (int l = 0; l < nsample; ++l) o[l] = k;

@@ -421,14 +421,17 @@ def transfusion_project(pts, m):
     return c2, c2o
 
 
-def transfusion_fusion(sd, pts_list, pts_feats, img, metas, prefix="actr.", num_cams=6):
+def transfusion_fusion(sd, pts_list, pts_feats, img, metas, prefix="actr.", num_cams=6, projection=None):
     """`point_fusion.ACTR.forward` with fusion_method 'sum' (point_fusion.py:342-394 split_param, :396-408 agg_param,
     :410-507 forward): per-sample projection, zero-padded per-(sample, camera) query lists in row order, the image feature of
     a query = level-0 map at (pixel // 4), ACTR on the padded lists, additive write-back.
     pts_list: per sample [n_b, 3] voxel centres (augmented frame); pts_feats [sum n_b, C]; img [B * 6, 256, h, w]."""
     B = len(pts_list)
     C, IC = pts_feats.shape[1], img.shape[1]
-    proj = [transfusion_project(p, m) for p, m in zip(pts_list, metas)]
+    # projection: per sample (coor_2d, coor_2d_o) to use instead of this composition's own -- the full-size parity tests hand
+    # over the DEVICE's projection (after checking it against `transfusion_project`), so that a voxel whose pixel sits within
+    # fp32 rounding of a boundary (camera border, multiple of 4) takes the same branch on both sides
+    proj = projection if projection is not None else [transfusion_project(p, m) for p, m in zip(pts_list, metas)]
     lists = []
     for b in range(B):
         cam = proj[b][0][:, 0].astype(np.int64)
@@ -491,7 +494,7 @@ def _interp_bilinear(fmap, hw):
     return F.interpolate(_t(fmap), tuple(hw), mode="bilinear").numpy()
 
 
-def voxel_rcnn_mvx(indices, features, fmap, lidar2img, image_hw, voxel_stride=1, aug=None):
+def voxel_rcnn_mvx(indices, features, fmap, lidar2img, image_hw, voxel_stride=1, aug=None, uv_rows=None):
     """`point_fusion(..., 'MVX')` with fuse_sum (spconv_backbone.py:650-760): the image feature at the truncated pixel of every
     voxel inside the image, bilinearly up-sampled map, added to the LiDAR row."""
     H, W = image_hw
@@ -500,15 +503,25 @@ def voxel_rcnn_mvx(indices, features, fmap, lidar2img, image_hw, voxel_stride=1,
     for b in range(fmap.shape[0]):
         rows = np.nonzero(indices[:, 0] == b)[0]
         v = _vr_voxel_points(indices[rows], b, voxel_stride, aug)
-        uv = _kitti_lidar_to_img(v[:, ::-1], lidar2img[b])
+        # uv_rows [n, 2]: pixel coordinates to use instead of this composition's own (see transfusion_fusion: `projection`)
+        uv = _kitti_lidar_to_img(v[:, ::-1], lidar2img[b]) if uv_rows is None else np.asarray(uv_rows)[rows]
         px = uv.astype(np.float32).astype(np.int64)                                 # torch.Tensor(voxels_2d).long()
         ok = (px[:, 1] >= 0) & (px[:, 1] < H) & (px[:, 0] >= 0) & (px[:, 0] < W)
         out[rows[ok]] += up[b][:, px[ok, 1], px[ok, 0]].T
     return out
 
 
+def voxel_rcnn_pixels(indices, lidar2img, voxel_stride, aug=None):
+    """Pixel coordinates [n, 2] (float64) of every voxel row: the projection of the two fusion points on its own."""
+    uv = np.zeros((len(indices), 2))
+    for b in np.unique(indices[:, 0]):
+        rows = np.nonzero(indices[:, 0] == b)[0]
+        uv[rows] = _kitti_lidar_to_img(_vr_voxel_points(indices[rows], int(b), voxel_stride, aug)[:, ::-1], lidar2img[int(b)])
+    return uv
+
+
 def voxel_rcnn_actr_fusion(sd, indices, features, fmap, lidar2img, image_hw, lt_cfg, voxel_stride=8, aug=None, num_layers=4,
-                           prefix=""):
+                           prefix="", uv_rows=None):
     """`point_fusion(..., 'ACTRv2')` with fuse_sum (spconv_backbone.py:650-820): one zero-padded query list per sample (ALL its
     voxels, in row order), normalised un-truncated image coordinates, image features at the truncated pixel of the up-sampled
     map (zero outside the image), ACTRv2 = LocalTransformer + dual-query layer with the gate BEFORE the feed-forward blocks
@@ -527,7 +540,7 @@ def voxel_rcnn_actr_fusion(sd, indices, features, fmap, lidar2img, image_hw, lt_
     qpts = np.zeros((B, n_max, 3), np.float32)
     for b, rows in enumerate(rows_b):
         v = _vr_voxel_points(indices[rows], b, voxel_stride, aug)
-        uv = _kitti_lidar_to_img(v[:, ::-1], lidar2img[b])
+        uv = _kitti_lidar_to_img(v[:, ::-1], lidar2img[b]) if uv_rows is None else np.asarray(uv_rows, np.float64)[rows]
         px = uv.astype(np.float32).astype(np.int64)
         ok = (px[:, 1] >= 0) & (px[:, 1] < H) & (px[:, 0] >= 0) & (px[:, 0] < W)
         k = len(rows)

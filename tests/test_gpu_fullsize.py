@@ -9,6 +9,8 @@ near their range, the native executor's arena.  Here the HIP path is compared, a
     the real stage index sets (N = 28-85 k rows) for every channel shape of the backbone and both arithmetic modes
     (split precision and exact fp32): rulebooks bit-exact in canonical order, features <= 1e-3 (measured ~1e-5 / 1e-6).
 """
+import types
+
 import numpy as np
 import pytest
 
@@ -439,9 +441,11 @@ def test_full_grid_transfusion_encoder_fusion_bs4_vs_oracle():
     against the oracle composition on the reference's own compiled CPU ops where they are built: voxel tensors and every
     stage's index set bit-exact, every stage's rows and the dense map <= 1e-3 of their scale in the split-precision
     mode; in the bf16 mode (what configs[2] asks for) the same index sets and the dense map inside the stated bf16 bound
-    against the ORACLE.  The fusion layer itself is pinned to the reference module by tests/golden/tf_fusion.npz
-    (test_gpu_trees.py); here the oracle hands ITS stage rows to the device layer, so the comparison covers the full-size
-    encoder on both sides of it."""
+    against the ORACLE.  Round 6: the fusion layer at this size is the ORACLE's too (oracle_models.transfusion_fusion, pinned to
+    the reference module by tests/golden/tf_fusion.npz): the device layer's by-slot assembly, longest-list padding, folded image
+    projection and multi-tile dual-query kernels are compared with an independent composition on ~110 k voxels x 24 camera maps;
+    the integer decisions of the projection (camera, feature pixel) come from the device after a check against the
+    composition's float64 projection."""
     from dualfusion import ops, spconv, synth
     from dualfusion.backbones import SparseEncoderFusion
     from dualfusion.workloads import TF_ACTR_CFG
@@ -473,16 +477,51 @@ def test_full_grid_transfusion_encoder_fusion_bs4_vs_oracle():
         stages = enc._runner([4]).run(spconv.SparseConvTensor(f, c, shape, B))           # every stage before the fusion
     o_stages = []
 
+    proj_stats = {}
+
     def fuse(x):
         o_stages.append((x.indices.copy(), x.features.copy()))
         if len(o_stages) < 4:
             return x
-        # the oracle's rows of the last stage (in spconv's GPU order) through the DEVICE fusion layer
+        # round 6: the oracle's rows of the last stage through the ORACLE composition of the fusion layer
+        # (oracle_models.transfusion_fusion, pinned to the reference module by tf_fusion.npz in test_oracle_golden.py) -- at the
+        # size where the by-slot assembly, the longest-list padding and the multi-tile kernels of the device layer are live
         oi, ofe = om.sort_rows(x.indices, x.features)
+        # voxel centres (sparse_encoder.py:309-319): (index + 0.5) * voxel * ratio + range minimum, fp32
+        ratio = np.float32(shape[1] / x.shape[1])
+        zyx = (oi[:, 1:].astype(np.float32) + np.float32(0.5)) * np.array(synth.NUSC_VOXEL[::-1], np.float32) * ratio \
+            + np.array(synth.NUSC_RANGE[:3][::-1], np.float32)
+        pts = np.ascontiguousarray(zyx[:, ::-1])
         xt = spconv.SparseConvTensor(T(ofe), T(oi), x.shape, B)
         with torch.no_grad():
-            out = enc.fusion_layer([img], enc.coor2pts(xt, 0.5), xt.features, [dict(m) for m in metas], None)
-        x.indices, x.features, x.rulebooks = np.ascontiguousarray(oi), out.cpu().numpy(), {}
+            dpts = enc.coor2pts(xt, 0.5)
+            cam_id, norm, pix = enc.fusion_layer.project(dpts, [dict(m) for m in metas])
+        assert np.abs(dpts[:, 1:].cpu().numpy() - pts).max() <= 1e-5
+        cam_id, norm, pix = cam_id.cpu().numpy(), norm.cpu().numpy(), pix.cpu().numpy()
+        # the DEVICE's projection (fp32 through the composed matrices) against the composition's float64 one: same camera and
+        # same feature pixel everywhere except where the float64 coordinate sits within 2e-2 px of the deciding boundary
+        pts_b = [pts[oi[:, 0] == b] for b in range(B)]
+        dev_proj, off = [], 0
+        n_cam = n_pix = 0
+        for b in range(B):
+            k = len(pts_b[b])
+            c2, c2o = om.transfusion_project(pts_b[b], metas[b])
+            d2 = np.concatenate([cam_id[off:off + k, None].astype(np.float32), norm[off:off + k]], 1)
+            d2o = np.concatenate([cam_id[off:off + k, None].astype(np.float32), pix[off:off + k]], 1)
+            same = c2[:, 0] == d2[:, 0]
+            n_cam += int((~same).sum())
+            assert np.abs(c2o[same, 1:] - d2o[same, 1:]).max() <= 1e-2
+            cell = c2o[same, 1:].astype(np.int64) // 4 != d2o[same, 1:].astype(np.int64) // 4
+            near = np.abs(c2o[same, 1:] / 4 - np.round(c2o[same, 1:] / 4)) * 4 <= 2e-2
+            assert not (cell & ~near).any()
+            n_pix += int(cell.any(1).sum())
+            dev_proj.append((d2, d2o))
+            off += k
+        proj_stats.update(rows=len(pts), other_camera=n_cam, other_pixel=n_pix)
+        assert n_cam <= 2e-4 * len(pts) + 2 and n_pix <= 2e-3 * len(pts), proj_stats
+        fsd = {k_[len("fusion_layer."):]: v for k_, v in sd.items() if k_.startswith("fusion_layer.")}
+        out = om.transfusion_fusion(fsd, pts_b, ofe, img.cpu().numpy(), metas, projection=dev_proj)
+        x.indices, x.features, x.rulebooks = np.ascontiguousarray(oi), out, {}
         return x
     with om.using(_impl()):
         o_y, _ = om.transfusion_encoder(sd, of, oc, B, shape, TF_CH, TF_PAD, fuse=fuse, fusion_pos=[0, 1, 2, 3])
@@ -580,28 +619,47 @@ def test_full_grid_voxel_rcnn_backbone_bs8_vs_oracle():
         assert np.array_equal(a, b_), name
         assert bool(torch.isfinite(ms[name].features).all()), name
     assert bool(torch.isfinite(out["encoded_spconv_tensor"].features).all())
-    # ---- round 5: the fusion variant's OUTPUT against the oracle composition.  Both fusion layers are pinned to the reference
-    # module at small size (tests/golden/vr_fusion.npz, test_gpu_trees.py); here the oracle backbone (the reference's compiled
-    # CPU ops where built) hands ITS rows to the device layers at the two fusion points -- x_conv1 rows through the MVX
-    # sampling, x_conv4 rows (in spconv's GPU order: furthest point sampling starts at row 0 of every sample) through
-    # ACTRv2 with its LocalTransformer -- and goes on from their results, so the comparison covers the full-size encoder on
-    # both sides of the fusion, as the TransFusion test above does.
+    # ---- the fusion variant's OUTPUT against the oracle composition, fusion layers included (round 6: oracle_models.
+    # voxel_rcnn_mvx / voxel_rcnn_actr_fusion, pinned to the reference module by tests/golden/vr_fusion.npz): the oracle backbone
+    # (the reference's compiled CPU ops where built) runs its own MVX sum on the x_conv1 rows and its own ACTRv2 (furthest point
+    # sampling of 2048 of ~20 k points per sample, ball query, LocalTransformer, four dual-query layers) on the x_conv4 rows and
+    # goes on from their results; the device's pixel coordinates are used after a check against the float64 projection.
     sdf = {k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}
     SCT = __import__("dualfusion").spconv.SparseConvTensor
 
-    def fuse1(x):
+    l2i_np = np.stack([K @ Tr] * B)
+    fmaps = {k_: v.cpu().numpy() for k_, v in bdf["img_dict"].items()}
+    pix_stats = {}
+
+    def device_pixels(indices, stride, tag):
+        """The device's own pixel coordinates of these voxel rows (the sampling kernel's), checked against the composition's
+        float64 projection: <= 1e-2 px apart, the same truncated pixel except within 2e-2 px of an integer."""
         with torch.no_grad():
-            y = mf._fuse1(SCT(T(x.features), T(x.indices), mf.sparse_shape, B), dict(bdf))
-        x.features = y.features.cpu().numpy()
+            _, uv = mf._project(types.SimpleNamespace(indices=T(indices)), stride, dict(bdf))
+        uv = uv.cpu().numpy()
+        want = om.voxel_rcnn_pixels(indices, l2i_np, stride)
+        assert np.abs(uv - want).max() <= 1e-2, np.abs(uv - want).max()
+        other = uv.astype(np.int64) != want.astype(np.float32).astype(np.int64)
+        assert not (other & (np.abs(want - np.round(want)) > 2e-2)).any()
+        pix_stats[tag] = (len(indices), int(other.any(1).sum()))
+        assert other.any(1).sum() <= 2e-3 * len(indices), pix_stats
+        return uv
+
+    def fuse1(x):
+        # round 6: the MVX sum at stride 1 by the ORACLE composition (oracle_models.voxel_rcnn_mvx, pinned by vr_fusion.npz)
+        x.features = om.voxel_rcnn_mvx(x.indices, x.features, fmaps["mvx_layer1_feat2d"], l2i_np, (H, W), 1,
+                                       uv_rows=device_pixels(x.indices, 1, "stride1"))
         return x
 
     def fuse4(c2, c3, c4):
+        # round 6: ACTRv2 at stride 8 by the ORACLE composition (oracle_models.voxel_rcnn_actr_fusion, pinned by vr_fusion.npz);
+        # rows in spconv's GPU order: furthest point sampling starts at row 0 of every sample
         oi, ofe = om.sort_rows(c4.indices, c4.features)
-        mf.__dict__.pop("_fuse4_pre", None)                   # (the in-line path: positions and slots from these rows)
         assert mf.ifat is None
-        with torch.no_grad():
-            y = mf._fuse4(None, None, SCT(T(ofe), T(oi), c4.shape, B), dict(bdf))
-        c4.indices, c4.features, c4.rulebooks = np.ascontiguousarray(oi), y.features.cpu().numpy(), {}
+        asd = {k_[len("actr."):]: v for k_, v in sdf.items() if k_.startswith("actr.")}
+        out = om.voxel_rcnn_actr_fusion(asd, oi, ofe, fmaps["layer1_feat2d"], l2i_np, (H, W), cfg["LT_CFG"], 8,
+                                        num_layers=cfg["ACTR_CFG"]["num_enc_layers"], uv_rows=device_pixels(oi, 8, "stride8"))
+        c4.indices, c4.features, c4.rulebooks = np.ascontiguousarray(oi), out, {}
         return c4
     with om.using(_impl()):
         o_out_f, o_ms_f = om.voxel_backbone8x(sdf, of, oc, B, [41, 1600, 1408], fuse1=fuse1, fuse4=fuse4)
