@@ -653,6 +653,38 @@ class VoxelBackBone8x(nn.Module):
         return batch_dict
 
 
+class KittiCalibration(object):
+    """The three matrices of a KITTI calibration file and the devkit's `lidar_to_img` (VR/pcdet/utils/calibration_kitti.py:
+    25-93): P2 [3, 4], R0 [3, 3], Tr_velo2cam [3, 4], kept in the dtype they were read in (the devkit reads float32).
+    `batch_dict['calib']` of the reference holds one such object per sample; `VoxelBackBone8xFusion` accepts them (or the
+    reference's own objects: anything with P2 / R0 / V2C attributes) when no composed `lidar2img` is given and then projects
+    the way the reference does -- on the host, in numpy, with the devkit's three separate products and their float32
+    roundings -- so that every voxel lands in the pixel the reference puts it in (the composed fp32 matrix on the device
+    agrees to ~1e-4 px, which moves a voxel across a pixel boundary about once in 10^4 voxels)."""
+
+    def __init__(self, P2, R0, V2C):
+        import numpy as np
+        self.P2, self.R0, self.V2C = np.asarray(P2), np.asarray(R0), np.asarray(V2C)
+
+    @staticmethod
+    def of(obj):
+        if isinstance(obj, KittiCalibration):
+            return obj
+        if isinstance(obj, dict):
+            return KittiCalibration(obj['P2'], obj['R0'], obj['Tr_velo2cam'] if 'Tr_velo2cam' in obj else obj['V2C'])
+        return KittiCalibration(obj.P2, obj.R0, obj.V2C)
+
+    def lidar_to_img(self, pts_lidar):
+        """[n, 3] LiDAR points -> ([n, 2] pixels, [n] depth in the rectified camera): homogeneous points times
+        (V2C^T R0^T), then times P2^T, pixel numerators over the RECTIFIED depth (not over the homogeneous coordinate)."""
+        import numpy as np
+        one = np.ones((pts_lidar.shape[0], 1), dtype=np.float32)
+        rect = np.dot(np.hstack((pts_lidar, one)), np.dot(self.V2C.T, self.R0.T))
+        rect_h = np.hstack((rect, one))
+        img_h = np.dot(rect_h, self.P2.T)
+        return (img_h[:, 0:2].T / rect_h[:, 2]).T, img_h[:, 2] - self.P2.T[3, 2]
+
+
 class BasicGate(nn.Module):
     """VR/pcdet/models/model_utils/attention.py:88-177 -- the image gate of the Voxel-RCNN tree (`I_FUSION_METHOD: BasicGate`,
     called at spconv_backbone.py:797-800 right before ACTR): per image level s, the voxels of `x_list[s]` are projected into the
@@ -726,7 +758,9 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
     frozen DeepLabV3) is out of scope, so its outputs are read from `batch_dict['img_dict']`
     ({'mvx_layer1_feat2d' | 'layer1_feat2d': [B,C,h,w]}); the KITTI calibration objects, whose
     `lidar_to_img` runs in numpy on the CPU (:717-718), are replaced by `batch_dict['lidar2img']`
-    [B,3,4] on the device (`lidar2img_from_kitti` composes it from P2 / R0 / Tr the way the devkit projects).  `I_FUSION_METHOD:
+    [B,3,4] on the device (`lidar2img_from_kitti` composes it from P2 / R0 / Tr the way the devkit projects); a batch_dict that
+    carries the reference's `calib` objects and no `lidar2img` is projected on the host exactly as the reference does
+    (`KittiCalibration`: slower, pixel for pixel the reference's).  `I_FUSION_METHOD:
     BasicGate` (the image gate in front of ACTR, `BasicGate` above) is mirrored since round 4; the shipped `_ifat` yaml cannot be
     constructed by the reference itself (no `pts_idx`) -- the default [0, 2] of the PV-RCNN yaml is taken."""
 
@@ -799,7 +833,18 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
 
     @staticmethod
     def _pixels(xyz, bi, batch_dict):
-        """LiDAR xyz -> image pixel (float) through lidar2img [B,3,4]."""
+        """LiDAR xyz -> image pixel (float) through lidar2img [B,3,4]; without it, through the KITTI calibration objects of
+        `batch_dict['calib']` on the host, as the reference does (`KittiCalibration`)."""
+        if "lidar2img" not in batch_dict:
+            import numpy as np
+            calibs = [KittiCalibration.of(c) for c in batch_dict["calib"]]
+            host, bh = xyz.detach().cpu().numpy(), bi.cpu().numpy()           # (the reference's own host round trip, :717-718)
+            uv = np.zeros((host.shape[0], 2), np.float64)
+            for b, cal in enumerate(calibs):
+                sel = bh == b
+                if sel.any():
+                    uv[sel] = cal.lidar_to_img(host[sel])[0]
+            return torch.from_numpy(uv.astype(np.float32)).to(xyz.device)      # torch.Tensor(voxels_2d): fp32 from here on
         P = batch_dict["lidar2img"].float()[bi]                                                      # [N,3,4]
         # broadcast multiply-adds: einsum lowers to a batched GEMM over N tiny 3x4 matrices (2.4 ms per call at 200k voxels)
         h = P[:, :, 0] * xyz[:, 0:1] + P[:, :, 1] * xyz[:, 1:2] + P[:, :, 2] * xyz[:, 2:3] + P[:, :, 3]
@@ -893,7 +938,8 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         """`prepared`: the frame head's PreparedGeometry of the whole chain (`take_head`): conv4's index set is in it already."""
         previous = None
         if (4 not in self.fusion_pos or "ACTR" not in self.fusion_method or torch.is_grad_enabled()
-                or os.environ.get("DF3D_VR_PREFETCH", "1") != "1" or not coords.is_cuda or coords.shape[0] == 0):
+                or os.environ.get("DF3D_VR_PREFETCH", "1") != "1" or not coords.is_cuda or coords.shape[0] == 0
+                or "lidar2img" not in batch_dict):
             return None
         lts = getattr(getattr(self.actr.transformer, "encoder", None), "lidar_attns", None)
         if lts is None or len(lts) == 0:
@@ -999,6 +1045,7 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
 
     def _sample_native(self, x, batch_dict, fmap):
         return (x.features.is_cuda and not torch.is_grad_enabled() and x.features.dtype == torch.float32
+                and "lidar2img" in batch_dict               # (the sampling kernel projects through the composed matrix)
                 and fmap.dtype == torch.float32 and fmap.is_contiguous() and fmap.shape[1] % 4 == 0
                 and x.indices.dtype == torch.int32 and os.environ.get("DF3D_VR_SAMPLE", "1") == "1")
 
