@@ -473,6 +473,26 @@ class precision(object):
         return False
 
 
+# True inside `reference_arithmetic()`: every matrix product of the hot path in plain fp32 -- the convolutions on the exact-fp32
+# MFMA kernels (CONV_PRECISION "fp32"), the feed-forward blocks / query linears / image projection / value GEMM on the library's
+# fp32 GEMMs (the `*_supported` predicates of the fp16 hi + lo kernels answer False).  Slow; the yardstick of bench.py's
+# `precision_evidence`, never the measured path.
+ALL_FP32 = False
+
+
+class reference_arithmetic(object):
+    def __enter__(self):
+        global CONV_PRECISION, ALL_FP32
+        self.old = (CONV_PRECISION, ALL_FP32)
+        CONV_PRECISION, ALL_FP32 = "fp32", True
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_PRECISION, ALL_FP32
+        CONV_PRECISION, ALL_FP32 = self.old
+        return False
+
+
 class grad_precision(object):
     """Context of a backward pass: gradient rows have no fixed scale (1e-8 .. 1e+2 within one step), which the fp16 parts of
     the "split" mode cannot hold -- input-gradient convolutions run in the three-part mode (bf16 parts: fp32's exponent range)."""
@@ -1210,7 +1230,7 @@ def split_weights_fp16(w, what="weights"):
 
 def rows_linear_supported(cin, cout):
     """DF3D_ROWS_LINEAR=0 keeps the library GEMMs (A/B switch, read per call)."""
-    if os.environ.get("DF3D_ROWS_LINEAR", "1") == "0":
+    if os.environ.get("DF3D_ROWS_LINEAR", "1") == "0" or ALL_FP32:
         return False
     return _lib.load().df3d_rows_linear_packed_bytes(int(cin), int(cout)) > 0
 
@@ -1683,7 +1703,7 @@ def groupnorm_fold(u, gate, conv_bias, gn, weight, bias):
 
 
 def ffn_supported(d_model, d_ffn):
-    return _lib.load().df3d_ffn_packed_bytes(int(d_model), int(d_ffn)) > 0
+    return not ALL_FP32 and _lib.load().df3d_ffn_packed_bytes(int(d_model), int(d_ffn)) > 0
 
 
 def ffn_pack(w1, w2):
@@ -1754,7 +1774,7 @@ def ffn_fused_jobs(jobs, d_ffn):
 
 
 def imgproj_supported(rows, cin, c_model):
-    return c_model == 128 and _lib.load().df3d_imgproj_packed_bytes(int(rows), int(cin)) > 0
+    return not ALL_FP32 and c_model == 128 and _lib.load().df3d_imgproj_packed_bytes(int(rows), int(cin)) > 0
 
 
 def imgproj_pack(wcat):

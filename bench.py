@@ -611,13 +611,16 @@ def precision_probe(wl, ops, frames=2):
     import torch
     old = ops.CONV_PRECISION
     res = {"what": "max |x - x_fp32| / max |x_fp32| over the dense BEV map [B, 256, 180, 180] and over the detection head's "
-                   "output maps of %d frame(s), x = a precision mode's result, x_fp32 = the result with every convolution on "
-                   "v_mfma_f32_16x16x4_f32 (exact fp32 products); all modes run the FFN / query linears / image projection on "
-                   "the fp16 hi + lo kernels" % frames}
+                   "output maps of %d frame(s), x = a precision mode's result, x_fp32 = the ALL-fp32 result (round 6, "
+                   "ops.reference_arithmetic): every convolution on v_mfma_f32_16x16x4_f32 (exact fp32 products) AND the "
+                   "feed-forward blocks / query linears / image projection / value GEMM on the library's fp32 GEMMs; "
+                   "'fp32_convs' = the exact-fp32 convolutions with the other GEMMs on the fp16 hi + lo kernels (round 5's "
+                   "yardstick)" % frames}
     bev, heads = {}, {}
     try:
-        for mode in ("fp32", "split", "split3"):
-            ops.CONV_PRECISION = mode
+        for mode in ("fp32", "fp32_convs", "split", "split3"):
+            ops.CONV_PRECISION = "fp32" if mode == "fp32_convs" else mode
+            ops.ALL_FP32 = mode == "fp32"
             bev[mode], heads[mode] = [], []
             for k in range(frames):
                 fr = wl.frames[k % len(wl.frames)]
@@ -629,9 +632,9 @@ def precision_probe(wl, ops, frames=2):
                     preds = wl.model.bbox_head(x)
                 heads[mode].append(torch.cat([v.float().reshape(-1) for d in preds for _, v in sorted(d.items())]).clone())
     finally:
-        ops.CONV_PRECISION = old
+        ops.CONV_PRECISION, ops.ALL_FP32 = old, False
     torch.cuda.synchronize()
-    for mode in ("split", "split3"):
+    for mode in ("split", "split3", "fp32_convs"):
         worst, hworst = 0.0, 0.0
         for a, b, ha, hb in zip(bev[mode], bev["fp32"], heads[mode], heads["fp32"]):
             worst = max(worst, float((a - b).abs().max() / b.abs().max()))
