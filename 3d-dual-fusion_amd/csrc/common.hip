@@ -20,8 +20,40 @@ void set_error(const char *fmt, ...) {
 // constructors (a plain array: no initialisation order to get wrong) and resolved to device addresses at the first poll.
 static const void *g_ovf_sym[64];
 static const char *g_ovf_tu[64];
-static unsigned *g_ovf_dev[64];
+static constexpr int OVF_MAXDEV = 16;
+static unsigned *g_ovf_dev[OVF_MAXDEV][64];       // device addresses of the flags, per device (they differ between GPUs)
+static unsigned **g_ovf_table[OVF_MAXDEV];         // the same addresses as a device array (df3d_split_overflow_collect)
+static int g_ovf_table_n[OVF_MAXDEV];
 static int g_ovf_n = 0;
+
+// the flags' addresses on the CURRENT device (resolved once per device); -> device index or -1
+static int ovf_resolve() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OVF_MAXDEV) return -1;
+  for (int i = 0; i < g_ovf_n; ++i) {
+    if (g_ovf_dev[dev][i]) continue;
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, g_ovf_sym[i]) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      continue;                                     // (no device code of that unit was loaded)
+    }
+    g_ovf_dev[dev][i] = (unsigned *)p;
+  }
+  return dev;
+}
+
+__global__ void ovf_collect_kernel(unsigned *const *flags, int n, unsigned *out, int reset) {
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    unsigned *f = flags[i];
+    if (f && *f) {
+      m |= 1u << (i & 31);
+      if (reset) *f = 0u;
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d, 64);
+  if (threadIdx.x == 0) *out = m;
+}
 void split_overflow_register(const void *symbol, const char *tu) {
   if (g_ovf_n < 64) g_ovf_sym[g_ovf_n] = symbol, g_ovf_tu[g_ovf_n] = tu, ++g_ovf_n;
 }
@@ -179,34 +211,71 @@ extern "C" {
 int df3d_version(void) { return 100; }
 
 int df3d_split_overflow(int reset, char *where, int where_len) {
-  // synchronous on purpose (a poll at a frame / test boundary): waits for the device
+  // synchronous on purpose (a poll at a frame / test boundary): waits for the CURRENT device
   unsigned any = 0;
   if (where && where_len > 0) where[0] = 0;
   if (hipDeviceSynchronize() != hipSuccess) {
     df3d::set_error("df3d_split_overflow: hipDeviceSynchronize failed");
     return DF3D_EHIP;
   }
+  const int dev = df3d::ovf_resolve();
+  if (dev < 0) {
+    df3d::set_error("df3d_split_overflow: no current device");
+    return DF3D_EHIP;
+  }
   for (int i = 0; i < df3d::g_ovf_n; ++i) {
-    if (!df3d::g_ovf_dev[i]) {
-      void *p = nullptr;
-      if (hipGetSymbolAddress(&p, df3d::g_ovf_sym[i]) != hipSuccess || !p) {
-        (void)hipGetLastError();
-        continue;                                   // (no device code of that unit was loaded)
-      }
-      df3d::g_ovf_dev[i] = (unsigned *)p;
-    }
+    unsigned *f = df3d::g_ovf_dev[dev][i];
+    if (!f) continue;
     unsigned v = 0;
-    DF3D_HIP(hipMemcpy(&v, df3d::g_ovf_dev[i], sizeof(v), hipMemcpyDeviceToHost));
+    DF3D_HIP(hipMemcpy(&v, f, sizeof(v), hipMemcpyDeviceToHost));
     if (v) {
       any |= v;
       if (where && where_len > 0) {
         size_t used = strlen(where);
         snprintf(where + used, (size_t)where_len - used, "%s%s", used ? "," : "", df3d::g_ovf_tu[i]);
       }
-      if (reset) DF3D_HIP(hipMemset(df3d::g_ovf_dev[i], 0, sizeof(v)));
+      if (reset) DF3D_HIP(hipMemset(f, 0, sizeof(v)));
     }
   }
   return any ? 1 : 0;
+}
+
+// The same poll WITHOUT a host wait (round 6): one tiny launch on `stream` ORs every unit's flag into *out (a device word of the
+// caller; bit i & 31 = unit i of df3d_split_overflow_units) and clears the flags when `reset`.  The caller reads the word with a
+// device -> host copy it makes anyway (a detector's box counts, a trainer's logged losses): the flag then covers every kernel
+// queued on `stream` before this call.
+int df3d_split_overflow_collect(uint32_t *out, int reset, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(out, "split_overflow_collect: null output");
+  const int dev = df3d::ovf_resolve();
+  if (dev < 0) {
+    df3d::set_error("df3d_split_overflow_collect: no current device");
+    return DF3D_EHIP;
+  }
+  // (a unit's flag has an address once its code object is loaded -- HIP loads them lazily, at the unit's first launch: the
+  // device-side table is refreshed whenever more of them have resolved)
+  int resolved = 0;
+  for (int i = 0; i < df3d::g_ovf_n; ++i) resolved += df3d::g_ovf_dev[dev][i] != nullptr;
+  if (!df3d::g_ovf_table[dev] || df3d::g_ovf_table_n[dev] != resolved) {
+    if (!df3d::g_ovf_table[dev]) DF3D_HIP(hipMalloc((void **)&df3d::g_ovf_table[dev], sizeof(unsigned *) * 64));
+    DF3D_HIP(hipMemcpyAsync(df3d::g_ovf_table[dev], df3d::g_ovf_dev[dev], sizeof(unsigned *) * 64, hipMemcpyHostToDevice, stream));
+    DF3D_HIP(hipStreamSynchronize(stream));         // (the host array may change before an asynchronous copy has read it; rare)
+    df3d::g_ovf_table_n[dev] = resolved;
+  }
+  hipLaunchKernelGGL(df3d::ovf_collect_kernel, dim3(1), dim3(64), 0, stream, df3d::g_ovf_table[dev], df3d::g_ovf_n, out, reset);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+// names of the units behind the bits of df3d_split_overflow_collect, comma separated in registration order
+int df3d_split_overflow_units(char *buf, int buflen) {
+  if (!buf || buflen <= 0) return df3d::g_ovf_n;
+  buf[0] = 0;
+  for (int i = 0; i < df3d::g_ovf_n; ++i) {
+    size_t used = strlen(buf);
+    snprintf(buf + used, (size_t)buflen - used, "%s%s", used ? "," : "", df3d::g_ovf_tu[i]);
+  }
+  return df3d::g_ovf_n;
 }
 const char *df3d_last_error(void) { return df3d::g_err; }
 

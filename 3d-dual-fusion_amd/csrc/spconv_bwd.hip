@@ -407,6 +407,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wgrad_split3_kernel(WgradArgs
       unsigned h0, l0, h1, l1;
       v *= sc;
       amax = fmaxf(amax, fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+      const float nan_probe = (v[0] + v[1]) + (v[2] + v[3]);     // fmaxf drops a NaN operand: a NaN (or inf - inf)
+      if (nan_probe != nan_probe) amax = __builtin_inff();       // anywhere in the piece raises the flag like an overflow
       split_pair_f16_ref<false>(v[0], v[1], 1.f, h0, l0);
       split_pair_f16_ref<false>(v[2], v[3], 1.f, h1, l1);
       *(w3_u32x2 *)d = (w3_u32x2){h0, h1};

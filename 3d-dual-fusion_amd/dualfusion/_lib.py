@@ -25,6 +25,8 @@ SIGNATURES = {
     "df3d_device_count": (c_int, []),
     "df3d_device_arch": (c_int, [c_char_p, c_int]),
     "df3d_split_overflow": (c_int, [c_int, c_char_p, c_int]),
+    "df3d_split_overflow_collect": (c_int, [c_void_p, c_int, c_void_p]),
+    "df3d_split_overflow_units": (c_int, [c_char_p, c_int]),
     "df3d_hard_voxelize_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "df3d_hard_voxelize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

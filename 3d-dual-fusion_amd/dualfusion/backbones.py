@@ -860,7 +860,8 @@ class VoxelBackBone8xFusion(VoxelBackBone8x):
         """Rows (batch-sorted) -> (sample, slot inside the sample's padded query list, longest list).  One host read."""
         b = ind[:, 0].long()
         counts = torch.bincount(b, minlength=B)
-        n_max = int(counts.max().item())                      # host sync (the reference pads to max_num_nev then slices)
+        # host sync (the reference pads to max_num_nev then slices); the range flag of the fp16 operand format rides on it
+        n_max = int(_ops.read_with_range_flag(counts.max().view(1))[0])
         starts = torch.cumsum(counts, 0) - counts
         slot = torch.arange(ind.shape[0], device=ind.device) - starts[b]       # rows are batch-sorted
         return b, slot, n_max

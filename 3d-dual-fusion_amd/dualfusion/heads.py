@@ -649,7 +649,8 @@ class CenterHead(nn.Module):
         boxes, scores, labels, counts = self.predict_device(preds_dicts, test_cfg)
         T = len(preds_dicts)
         B = boxes.shape[0] // T
-        cnt = counts.view(T, B).cpu().tolist()
+        # (the range flag of the fp16 operand format rides on this copy: ops.read_with_range_flag raises SplitRangeError)
+        cnt = _ops.read_with_range_flag(counts.view(T, B))
         metas = example.get("metadata", None) if isinstance(example, dict) else None
         if not metas:
             metas = [None] * B

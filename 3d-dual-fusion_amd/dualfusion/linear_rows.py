@@ -26,6 +26,8 @@ class _LinearFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         x, weight = ctx.saved_tensors
+        if grad.dtype != torch.float32:               # (a caller that casts the output: the kernels take fp32 rows)
+            grad = grad.float()
         g2 = grad.reshape(-1, grad.shape[-1])
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
@@ -45,7 +47,10 @@ class _LinearFunction(torch.autograd.Function):
 def linear(x, weight, bias=None):
     """F.linear with the weight gradient on the row kernel where it applies (CUDA fp32, >= 2048 rows, input channels a multiple
     of 4), else F.linear."""
+    # (under torch.autocast -- the reference trains these layers with AMP -- F.linear returns half precision and hands the
+    # backward half-precision gradients, which the fp32 row kernels do not take: autocast keeps nn.Linear's own path, ADVICE r5)
     if (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and not torch.is_autocast_enabled()
             and weight.requires_grad and x.shape[-1] % 4 == 0 and x.numel() // max(x.shape[-1], 1) >= 2048
             and os.environ.get("DF3D_LINEAR_WGRAD", "1") != "0"):
         return _LinearFunction.apply(x, weight, bias)

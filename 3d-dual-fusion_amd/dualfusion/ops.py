@@ -1210,6 +1210,77 @@ def check_split_overflow():
                              % (65504.0 / SPLIT_ACT_SCALE, 65504.0 / SPLIT_W_SCALE, where))
 
 
+class SplitRangeError(_lib.Df3dError):
+    """A value left the range of the fp16 operand split (found by a read the host makes anyway: `read_with_range_flag`)."""
+
+
+RANGE_STATS = {"range_fallbacks": 0, "range_checks": 0}
+_OVF_UNITS = []
+_RANGE_WARNED = [False]
+
+
+def overflow_word(reset=True):
+    """Device int32 [1]: bit (i & 31) set when unit i of the library has met a value outside the fp16 operand range since the
+    last reset (df3d_split_overflow_collect: one small launch on the current stream, NO host wait).  Read it with a device ->
+    host copy you make anyway -- `read_with_range_flag` does that for the usual case of a few integers."""
+    lib = _lib.load()
+    word = torch.zeros((1,), dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    _lib.check(lib.df3d_split_overflow_collect(_ptr(word), int(bool(reset)), _stream()), "df3d_split_overflow_collect")
+    return word
+
+
+def overflow_units(mask):
+    if not _OVF_UNITS:
+        buf = ctypes.create_string_buffer(1024)
+        _lib.load().df3d_split_overflow_units(buf, 1024)
+        _OVF_UNITS.extend(u for u in buf.value.decode().split(",") if u)
+    return ",".join(u for i, u in enumerate(_OVF_UNITS) if mask >> (i & 31) & 1) or "?"
+
+
+def read_with_range_flag(ints):
+    """`ints.cpu().tolist()` of a small integer tensor, with the overflow word riding on the same copy (the host reads that
+    tensor anyway: a detector's box counts, a longest-list length).  Raises SplitRangeError when a kernel queued on this
+    stream before the call has met a value the fp16 operand format cannot hold -- "reported, never silent" holds for hosts that
+    never call `check_split_overflow` themselves.  Only the fp16-pair mode has a range to check."""
+    if not ints.is_cuda or CONV_PRECISION != "split":
+        return ints.cpu().tolist()
+    flat = ints.reshape(-1)
+    both = torch.cat([flat.to(torch.int32), overflow_word()]).cpu().tolist()
+    RANGE_STATS["range_checks"] += 1
+    raise_if_range_flag(both[-1])
+    vals = both[:-1]
+    return vals if ints.dim() <= 1 else torch.tensor(vals).view(ints.shape).tolist()
+
+
+def raise_if_range_flag(mask):
+    if mask:
+        raise SplitRangeError("a value left the range of the fp16 operand split (|activation| < %g, |weight| < %g, or NaN / inf; "
+                              "raised in: %s): the results computed since the last check are invalid in this arithmetic.  "
+                              "`ops.with_range_fallback` / the detectors' `simple_test` rerun such a frame on three bf16 parts "
+                              "(fp32's exponent range); DF3D_CONV_PRECISION=split3 selects that mode for all frames."
+                              % (65504.0 / SPLIT_ACT_SCALE, 65504.0 / SPLIT_W_SCALE, overflow_units(int(mask) & 0xffffffff)))
+
+
+def with_range_fallback(fn, *args, **kwargs):
+    """fn(*args, **kwargs); when it raises SplitRangeError (a read inside it found the range flag) the SAME call again with
+    every convolution / GEMM on three bf16 parts ("split3": 24 significand bits, fp32's exponent range, twice the matrix work),
+    a warning the first time, RANGE_STATS['range_fallbacks'] += 1.  fn must be repeatable (an inference frame)."""
+    try:
+        return fn(*args, **kwargs)
+    except SplitRangeError as e:
+        if CONV_PRECISION != "split":
+            raise
+        RANGE_STATS["range_fallbacks"] += 1
+        if not _RANGE_WARNED[0]:
+            _RANGE_WARNED[0] = True
+            import warnings
+            warnings.warn("dualfusion: %s  Rerunning the frame in the three-part mode (this warning appears once)." % (e,),
+                          RuntimeWarning, stacklevel=2)
+        split_overflow(reset=True)                       # (flags raised by kernels queued behind the read)
+        with precision("split3"):
+            return fn(*args, **kwargs)
+
+
 def unsplit_rows(split, n, c):
     """Two-part split rows (uint8 [n, 4 c]: per 8 channels 8 x fp16 hi | 8 x fp16 lo of 2^5 x) -> fp32 [n, c] (exact)."""
     h = split.reshape(-1).view(torch.float16).view(n, c // 8, 2, 8).float()
@@ -2280,8 +2351,10 @@ class _LinearRows(torch.autograd.Function):
         n, d = g2.shape[0], _row_split(g2.shape[0])
         if (g2.is_cuda and g2.dtype == torch.float32 and x2.dtype == torch.float32 and x2.shape[1] % 4 == 0 and n >= 2048
                 and os.environ.get("DF3D_LINEAR_WGRAD", "1") != "0"):
-            # (round 5) the contraction over rows on the matrix cores: df3d_rows_grad_weights (three bf16 parts per operand);
-            # gradient columns padded to the kernel's 4-channel pieces (the gates have one output)
+            # (round 5) the contraction over rows on the matrix cores: df3d_rows_grad_weights_scaled -- fp16 PAIRS, the gradient
+            # operand under its own power-of-two block scale (any magnitude), the activation operand at the fixed scale 2^5
+            # (|x| < 2047: range-checked like every split operand); gradient columns padded to the kernel's 4-channel pieces
+            # (the gates have one output)
             pad = (-g2.shape[1]) % 4
             gp = torch.nn.functional.pad(g2, (0, pad)) if pad else g2.contiguous()
             gw = rows_grad_weights(gp, x2.contiguous(), x_scale=rows_pow2_scale(gp))[:g2.shape[1]]

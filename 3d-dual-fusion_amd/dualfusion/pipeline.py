@@ -221,7 +221,13 @@ class CenterPointDetector(nn.Module):
                 sum(rets["loss"]).backward()
         finally:
             hp.backbone.dense_layout = layout
+        from . import ops as _ops
+        flag = _ops.overflow_word() if (_ops.CONV_PRECISION == "split" and points_list[0].is_cuda) else None
         if host_copies == "async":
+            if flag is not None:
+                # the range flag of the fp16 operand format, valid with the other logging copies (nonzero: ops.raise_if_range_flag)
+                rets["range_flag"] = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+                rets["range_flag"].copy_(flag, non_blocking=True)
             # (the device tensors stay available for a loss reduction over the ranks: reading them back from the pinned copies
             # would be a blocking H2D copy queued behind the whole step)
             rets["on_device"] = {key: list(rets[key]) for key in ("hm_loss", "loc_loss_elem", "loc_loss") if key in rets}
@@ -236,6 +242,9 @@ class CenterPointDetector(nn.Module):
             return rets
         for key in ("hm_loss", "loc_loss_elem"):            # the reference's host copies, once the backward is queued
             rets[key] = [v.cpu() for v in rets[key]]
+        if flag is not None:                                 # (the host has just waited for the step: the flag costs no wait)
+            _ops.RANGE_STATS["range_checks"] += 1
+            _ops.raise_if_range_flag(int(flag.cpu()[0]))      # raised BEFORE the caller's optimizer step
         return rets
 
     def prefetch(self, points_list, batch_dict=None):
@@ -284,6 +293,31 @@ class CenterPointDetector(nn.Module):
         key = (nb, c, h, w, tuple(inp.shape), inp.dtype, _ops.CONV_PRECISION, self._tail_versions(),
                os.environ.get("DF3D_HEAD_FINAL"), os.environ.get("DF3D_HEADFINAL"))
         return tape.run(key, lambda: self._neck_head(bev), [inp], _ops._stream())
+
+    @torch.no_grad()
+    def simple_test(self, points_list, batch_dict=None, example=None):
+        """Detections on the host, the reference's `VoxelNet.forward(..., return_loss=False)` -> `bbox_head.predict`
+        (CP/det3d/models/detectors/voxelnet.py:150-188): per sample {'box3d_lidar', 'scores', 'label_preds', 'metadata'}.
+        The one device -> host copy of the tail (the box counts) also carries the range flag of the fp16 operand format: a
+        frame with a value that format cannot hold (|activation| >= 2047 after a checkpoint with unusual BatchNorm scales,
+        say) is rerun on three bf16 parts by itself (`ops.with_range_fallback`; `ops.RANGE_STATS` counts them)."""
+        from . import ops as _ops
+
+        def run():
+            preds = self._predictions(points_list, batch_dict, example)
+            return self.bbox_head.predict(example if example is not None else {}, preds, self.test_cfg)
+        return _ops.with_range_fallback(run)
+
+    def _predictions(self, points_list, batch_dict=None, example=None):
+        hp = self.hot_path
+        taped = (self.launch_tape and not self.training and hp.neck is not None and hasattr(hp.neck, "forward_rows")
+                 and getattr(hp.backbone, "dense_layout", "nchw") == "rows")
+        hp.defer_neck = taped
+        try:
+            x, _ = hp(points_list, batch_dict=batch_dict, example=example)
+        finally:
+            hp.defer_neck = False
+        return self._taped_tail(x) if taped else self.bbox_head(x)
 
     @torch.no_grad()
     def forward(self, points_list, batch_dict=None, example=None, return_loss=True):

@@ -1,6 +1,8 @@
 """SparseConvTensor: same container API as the reference's spconv
 (TF/mmdet3d/ops/spconv/structure.py:21-69; spconv 2.x `replace_feature` as probed by
 CP/det3d/models/backbones/scn.py:17-23), backed by the MI355X kernels."""
+import os
+
 import numpy as np
 import torch
 
@@ -173,6 +175,8 @@ class SparseConvTensor(object):
         if len(self.spatial_shape) != 3 or self.indices.shape[1] != 4:
             raise Df3dError("dense(): 2-D or 3-D tensors with [N, 1 + ndim] indices only")
         feats = self.features.contiguous()
+        if feats.is_cuda and os.environ.get("DF3D_STRICT", "0") == "1":
+            _ops.check_split_overflow()                       # strict mode: synchronise and raise on a raised range flag
         if feats.requires_grad and torch.is_grad_enabled():
             out = _DenseFunction.apply(feats, self.indices.contiguous(), self.batch_size, tuple(self.spatial_shape))
         else:

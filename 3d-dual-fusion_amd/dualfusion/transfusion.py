@@ -181,13 +181,16 @@ class TransFusionDetector(nn.Module):
             reducer.zero_grad()
         elif optimizer is not None:
             optimizer.zero_grad(set_to_none=True)
-        with torch.enable_grad():
+        def forward_losses():
             if voxels is None:
-                losses = self.forward_train(points=points, img_metas=img_metas, gt_bboxes_3d=gt_bboxes_3d,
-                                            gt_labels_3d=gt_labels_3d, img_feats=img_feats)
-            else:
-                losses = self.forward_train_voxels(voxels[0], voxels[1], len(img_metas), img_feats, img_metas, gt_bboxes_3d,
-                                                   gt_labels_3d)
+                return self.forward_train(points=points, img_metas=img_metas, gt_bboxes_3d=gt_bboxes_3d,
+                                          gt_labels_3d=gt_labels_3d, img_feats=img_feats)
+            return self.forward_train_voxels(voxels[0], voxels[1], len(img_metas), img_feats, img_metas, gt_bboxes_3d,
+                                             gt_labels_3d)
+        with torch.enable_grad():
+            # (`loss_device` reads the range flag of the fp16 operand format with its matching costs, BEFORE anything is
+            # back-propagated: a forward that met a value the format cannot hold is repeated on three bf16 parts)
+            losses = _ops.with_range_fallback(forward_losses)
             loss, log_vars = parse_losses(losses)
             loss.backward()
         if reducer is not None:
@@ -209,12 +212,16 @@ class TransFusionDetector(nn.Module):
 
     @torch.no_grad()
     def simple_test(self, points, img_metas, img=None, rescale=False, img_feats=None):
-        img_feats, pts_feats = self.extract_feat(points, img, img_metas, img_feats)
-        bbox_list = [dict() for _ in range(len(img_metas))]
-        if pts_feats and self.with_pts_bbox:
-            for result, pts_bbox in zip(bbox_list, self.simple_test_pts(pts_feats, img_feats, img_metas, rescale=rescale)):
-                result['pts_bbox'] = pts_bbox
-        return bbox_list
+        def run():
+            feats2d, pts_feats = self.extract_feat(points, img, img_metas, img_feats)
+            bbox_list = [dict() for _ in range(len(img_metas))]
+            if pts_feats and self.with_pts_bbox:
+                for result, pts_bbox in zip(bbox_list, self.simple_test_pts(pts_feats, feats2d, img_metas, rescale=rescale)):
+                    result['pts_bbox'] = pts_bbox
+            return bbox_list
+        # (`get_bboxes` reads the range flag of the fp16 operand format with the box counts: ops.with_range_fallback reruns a
+        # frame that left the format's range on three bf16 parts)
+        return _ops.with_range_fallback(run)
 
     def forward(self, return_loss=True, **kwargs):
         """mmdet `BaseDetector.forward`: forward_train(**kwargs) or simple_test(**kwargs)."""

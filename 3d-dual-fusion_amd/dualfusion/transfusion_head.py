@@ -797,6 +797,12 @@ class TransFusionHead(nn.Module):
         cost, iou, _ = _ops.tf_match_cost(rows.detach(), code, C, gt, lab, off, gmax, **self._match_cfg())
         host = torch.empty(cost.shape, dtype=torch.float32, pin_memory=True)
         host.copy_(cost, non_blocking=True)
+        flag = None
+        if _ops.CONV_PRECISION == "split":
+            # the range flag of the fp16 operand format rides on the cost matrix's copy (no extra host wait): every kernel of
+            # this forward is in front of it
+            flag = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+            flag.copy_(_ops.overflow_word(), non_blocking=True)
         copied = torch.cuda.Event()
         copied.record()
         losses = dict()
@@ -808,6 +814,9 @@ class TransFusionHead(nn.Module):
             losses['loss_heatmap'] = _GaussianFocalFunction.apply(p['dense_heatmap'], target, lh.alpha, lh.gamma, lh.loss_weight,
                                                                  want_grad)
         copied.synchronize()
+        if flag is not None:
+            _ops.RANGE_STATS["range_checks"] += 1
+            _ops.raise_if_range_flag(int(flag[0]))
         cost_np = host.numpy()
         assigned = np.full((B, P_all), -1, np.int32)
         start = 0
@@ -856,7 +865,7 @@ class TransFusionHead(nn.Module):
             raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range is not None for now!')
         if p['heatmap'].is_cuda:
             boxes, scores, labels, counts = self.get_bboxes_device(preds_dicts)
-            counts = counts.tolist()
+            counts = _ops.read_with_range_flag(counts)          # (+ the range flag of the fp16 operand format)
             dets = [(boxes[b, :n], scores[b, :n], labels[b, :n].long()) for b, n in enumerate(counts)]
         else:
             K = self.num_proposals

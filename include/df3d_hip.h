@@ -50,6 +50,11 @@ int df3d_device_arch(char *buf, int buflen);
  * receives the comma-separated source units that raised it.  SYNCHRONISES the device.  The reference has no counterpart
  * (its fp32 GEMMs have fp32's range, spconv_ops.h:302,338); data beyond the range belongs on the three-part mode. */
 int df3d_split_overflow(int reset, char *where, int where_len);
+/* round 6 -- the same poll without a host wait: one small launch on `stream` ORs every unit's flag into *out (device word; bit
+ * i & 31 = unit i of df3d_split_overflow_units) and clears them when `reset`; the caller reads the word with a device -> host
+ * copy it makes anyway.  df3d_split_overflow_units: the units' names, comma separated, -> their number. */
+int df3d_split_overflow_collect(uint32_t *out, int reset, void *stream);
+int df3d_split_overflow_units(char *buf, int buflen);
 
 /* ------------------------------------------------------------------------------------
  * Voxelisation + fused mean VFE.

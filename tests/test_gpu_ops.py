@@ -1086,6 +1086,34 @@ def test_input_gradient_on_block_scaled_two_part_rows(gscale):
 
 
 @pytest.mark.gpu
+def test_linear_module_under_autocast_trains_like_nn_linear():
+    """`dualfusion.linear_rows.Linear` replaces nn.Linear throughout ACTR / MSDeformAttn, and the reference trains
+    those layers with AMP.  Under torch.autocast the module must behave like nn.Linear (half-precision forward, gradients in
+    the parameters' dtype) instead of handing half-precision gradients to the fp32 row kernels."""
+    from dualfusion.linear_rows import Linear
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn((4, 3000, 128), generator=gen).to(dev).requires_grad_(True)
+    lin = Linear(128, 256).to(dev)
+    ref = torch.nn.Linear(128, 256).to(dev)
+    ref.load_state_dict(lin.state_dict())
+    xr = x.detach().clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = lin(x)
+        yr = ref(xr)
+    assert y.dtype == yr.dtype == torch.bfloat16
+    y.float().square().sum().backward()
+    yr.float().square().sum().backward()
+    for a, b in ((lin.weight.grad, ref.weight.grad), (lin.bias.grad, ref.bias.grad), (x.grad, xr.grad)):
+        assert a.dtype == torch.float32 and torch.equal(a, b)
+    # a caller that casts the OUTPUT of the fp32 path itself: half-precision gradients reach the Function and are accepted
+    lin.zero_grad()
+    y2 = lin(x.detach()).to(torch.bfloat16)
+    y2.float().sum().backward()
+    assert lin.weight.grad is not None and bool(torch.isfinite(lin.weight.grad).all())
+
+
+@pytest.mark.gpu
 def test_linear_module_and_gate_weight_gradients_on_native_kernels():
     """dualfusion.linear_rows.Linear (forward = F.linear; weight gradient on df3d_rows_grad_weights) and the one-output
     channel-first gate (`ops.channel_first_linear`, weight gradient on df3d_chanfirst_dot) against torch's autograd in float64:
