@@ -49,7 +49,7 @@ import torch  # noqa: E402
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_MFMA_TF = 157.3   # dense fp32 MFMA (= vector) peak
 PEAK_BF16_MFMA_TF = 2500.0  # dense bf16 / fp16 MFMA peak; the split-precision kernels spend 3 products per fp32 product
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_spconv_split.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_spconv_split.json")
 
 
 def parse():
