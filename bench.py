@@ -270,6 +270,12 @@ def conv_algorithmic(rec, pairs):
     block writes split rows only)."""
     cin, cout, K, n_out = rec["cin"], rec["cout"], rec["kvol"], rec["n_out"]
     s = 2 if rec["split"] == 2 else 4
+    if K in (1, 4, 9) and pairs >= 0.9 * K * n_out:
+        # a DENSE 2-D map (BEV neck, detection heads: the sparse kernel over a full neighbour table).  The sparse formula would
+        # count every pixel K times; a dense convolution's algorithmic traffic is every input pixel once, every output pixel
+        # once and the filters (VERDICT r5 weak 5) -- with it these launches fall under the matrix roof, where they belong
+        by = (pairs // K) * cin * s + n_out * cout * s + K * cin * cout * s
+        return by, 2 * pairs * cin * cout, n_out * cout * 4 if rec.get("both") else 0
     by = pairs * cin * s + n_out * cout * s + 8 * pairs + K * cin * cout * s
     extra = n_out * cout * 4 if rec.get("both") else 0
     return by, 2 * pairs * cin * cout, extra
