@@ -110,8 +110,10 @@ def late_register():
     except Exception:
         pass
     try:
-        from mmdet.models import BACKBONES as MB, DETECTORS as MD, HEADS as MH, NECKS as MN
-        for src, dst in ((MM_BACKBONES, MB), (MM_NECKS, MN), (MM_HEADS, MH), (MM_DETECTORS, MD)):
+        import mmdet.models as _mm
+        from mmdet.models import BACKBONES as MB, HEADS as MH, NECKS as MN
+        MD = getattr(_mm, "DETECTORS", None)                    # (absent from some mmdet builds: the detector is optional)
+        for src, dst in ((MM_BACKBONES, MB), (MM_NECKS, MN), (MM_HEADS, MH)) + (((MM_DETECTORS, MD),) if MD is not None else ()):
             for k, v in src.module_dict.items():
                 dst.register_module(name=k, module=v, force=True)
         done.append("mmdet")

@@ -143,6 +143,8 @@ def test_late_register_fills_the_frameworks_registries():
         sys.modules["mmdet"] = types.ModuleType("mmdet")
         m = types.ModuleType("mmdet.models")
         m.BACKBONES, m.HEADS, m.NECKS = mb, mh, mn
+        md = _MMRegistry()
+        m.DETECTORS = md
         sys.modules["mmdet.models"] = m
         d3 = types.ModuleType("det3d.models.registry")
         for n in ("READERS", "BACKBONES", "FUSION", "NECKS", "HEADS"):
@@ -165,6 +167,7 @@ def test_late_register_fills_the_frameworks_registries():
         assert "HardSimpleVFE" in ve.module_dict and "ACTR" in fl.module_dict
         assert mh.module_dict["TransFusionHead"] is dualfusion.transfusion_head.TransFusionHead
         assert "SECOND" in mb.module_dict and "SECONDFPN" in mn.module_dict
+        assert md.module_dict["TransFusionDetector"] is dualfusion.transfusion.TransFusionDetector      # round 6
         assert d3.BACKBONES._module_dict["SpMiddleResNetFHDFusion"] is dualfusion.backbones.SpMiddleResNetFHDFusion
         assert d3.HEADS._module_dict["CenterHead"] is dualfusion.heads.CenterHead and "RPN" in d3.NECKS._module_dict
         assert "VoxelFeatureExtractorV3" in d3.READERS._module_dict and len(d3.FUSION._module_dict) > 0
