@@ -70,6 +70,9 @@ SIGNATURES = {
                                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_ms_deform_attn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                              c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_ms_deform_attn_backward_binned_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "df3d_ms_deform_attn_backward_binned_slab_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "df3d_ms_deform_attn_backward_binned": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 4 + [c_size_t, c_void_p, c_void_p]),
     "df3d_furthest_point_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_pe_gather_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int,
                                    c_void_p, c_void_p]),

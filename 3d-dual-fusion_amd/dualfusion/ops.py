@@ -1694,6 +1694,22 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+_LEVEL_SHAPES = {}
+
+
+def level_shapes_on_host(spatial_shapes):
+    """[(H, W)] of a device `spatial_shapes` tensor as Python ints, cached by the tensor's storage and version: the modules
+    keep ONE such tensor per shape set (`_level_cache` / `_shape_cache` in actr.py), so the copy to the host happens once."""
+    key = (spatial_shapes.data_ptr(), spatial_shapes._version, tuple(spatial_shapes.shape), str(spatial_shapes.device))
+    hit = _LEVEL_SHAPES.get(key)
+    if hit is None:
+        if len(_LEVEL_SHAPES) >= 64:
+            _LEVEL_SHAPES.clear()
+        # (the entry keeps the tensor alive: its address cannot be handed to another shapes tensor while it is cached)
+        hit = _LEVEL_SHAPES[key] = ([(int(h), int(w)) for h, w in spatial_shapes.cpu().tolist()], spatial_shapes)
+    return hit[0]
+
+
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, grad_output):
     """-> (grad_value [N,S,M,D], grad_sampling_loc [N,Lq,M,L,P,2], grad_attn_weight [N,Lq,M,L,P])."""
     lib = _lib.load()
@@ -1709,6 +1725,21 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     gv = torch.empty_like(value)
     gl = torch.empty_like(sampling_locations)
     ga = torch.empty_like(attention_weights)
+    if L == 1 and D == 16 and P <= 16 and Lq < (1 << 28) and os.environ.get("DF3D_MSDA_BWD", "binned") != "atomic":
+        H, W = level_shapes_on_host(spatial_shapes)[0]
+        if H * W == S and ((H + 7) // 8) * ((W + 7) // 8) * M <= 7680 and N <= 65535:
+            # one single-level map, 16-channel heads: the value gradient as tile-wise matrix products, no global atomics
+            # (df3d_ms_deform_attn_backward_binned)
+            nbytes = int(lib.df3d_ms_deform_attn_backward_binned_workspace_bytes(N, M, Lq, P, H, W))
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=value.device)
+            slabs = torch.empty((int(lib.df3d_ms_deform_attn_backward_binned_slab_bytes(N, M, D, Lq, P, H, W)) // 4,),
+                                dtype=torch.float32, device=value.device)
+            rc = lib.df3d_ms_deform_attn_backward_binned(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index),
+                                                         _ptr(sampling_locations), _ptr(attention_weights), _ptr(grad_output), N, M,
+                                                         D, Lq, P, H, W, _ptr(gv), _ptr(gl), _ptr(ga), _ptr(ws), nbytes, _ptr(slabs),
+                                                         _stream())
+            _lib.check(rc, "df3d_ms_deform_attn_backward_binned")
+            return gv, gl, ga
     rc = lib.df3d_ms_deform_attn_backward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index),
                                           _ptr(sampling_locations), _ptr(attention_weights), _ptr(grad_output), N, S, M,
                                           D, Lq, L, P, _ptr(gv), _ptr(gl), _ptr(ga), _stream())

@@ -572,6 +572,20 @@ int df3d_ms_deform_attn_backward(const float *value, const int64_t *spatial_shap
                                  const float *sampling_loc, const float *attn_weight, const float *grad_output, int N,
                                  int S, int M, int D, int Lq, int L, int P, float *grad_value,
                                  float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+/* round 6 -- the same gradients for ONE single-level map [N, H * W, M, 16] WITHOUT global atomics (csrc/msda.hip msda_bin_*): the
+ * sampling points are counting-sorted by (map, 8 x 8 pixel tile, head); a wave per <= 512 points of a bin evaluates the col2im of
+ * its 9 x 9 pixel footprint as a matrix product on v_mfma_f32_16x16x4_f32 (bilinear weights x gradient rows, exact fp32 products)
+ * and stores it as a slab; a gather kernel adds the slabs and the neighbours' halos up -- every element of grad_value is written
+ * once (no zero fill).  Same contract as df3d_ms_deform_attn_backward (which the reference's
+ * ms_deform_attn_backward, CP/det3d/models/model_utils/ops/src/vision.cpp:13-16 -> ms_deform_attn_cuda.cu:93-153, maps to);
+ * H, W: the map's size on the host; workspace of ..._workspace_bytes(N, M, Lq, P, H, W) bytes, `slabs` of ..._slab_bytes(...).
+ * Served: D == 16, P <= 16, ceil(H / 8) * ceil(W / 8) * M <= 7680 (the LDS histogram), N <= 65535. */
+size_t df3d_ms_deform_attn_backward_binned_workspace_bytes(int N, int M, int Lq, int P, int H, int W);
+size_t df3d_ms_deform_attn_backward_binned_slab_bytes(int N, int M, int D, int Lq, int P, int H, int W);   /* `slabs` scratch */
+int df3d_ms_deform_attn_backward_binned(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                        const float *sampling_loc, const float *attn_weight, const float *grad_output, int N,
+                                        int M, int D, int Lq, int P, int H, int W, float *grad_value, float *grad_sampling_loc,
+                                        float *grad_attn_weight, void *workspace, size_t workspace_bytes, float *slabs, void *stream);
 
 /* Self-attention inside small token groups: nn.MultiheadAttention's scaled-dot-product core for the LocalTransformer of
  * ACTRv2 (VR/pcdet/models/backbones_3d/.../pointformer.py:10-44, 232-262): qkv [tokens*groups][3*heads*16] fp32 rows in

@@ -1086,6 +1086,49 @@ def test_input_gradient_on_block_scaled_two_part_rows(gscale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,Lq,M,D,P,H,W", [(3, 700, 8, 16, 4, 37, 61), (2, 300, 4, 16, 4, 8, 8), (1, 9000, 8, 16, 4, 112, 200),
+                                            (2, 64, 2, 16, 2, 5, 19), (1, 40, 1, 16, 16, 3, 2)])
+def test_msda_backward_binned_against_the_atomic_kernel_and_the_oracle(N, Lq, M, D, P, H, W):
+    """Round 6: the value gradient without global atomics (df3d_ms_deform_attn_backward_binned: sampling points counting-sorted
+    by (8 x 8 pixel tile, head), a 9 x 9 pixel footprint per wave as a matrix product on the fp32 MFMA, slabs gathered) against
+    the one-atomic-per-contribution kernel and the oracle's col2im: maps that are not multiples of the tile, points outside / on
+    the border, a third of the queries on one pixel (the unseen voxels' reference point: several work items per bin at the
+    largest case), rows without an upstream gradient (the padded rows)."""
+    import os
+    from dualfusion import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(N * 1000 + Lq)
+    value = torch.randn(N, H * W, M, D, generator=gen)
+    ref = torch.rand(N, Lq, 1, 1, 1, 2, generator=gen) * 1.2 - 0.1
+    ref[:, Lq * 2 // 3:] = 0.0
+    loc = (ref + torch.randn(N, Lq, M, 1, P, 2, generator=gen) * 0.03).contiguous()
+    aw = torch.softmax(torch.randn(N, Lq, M, P, generator=gen), -1).view(N, Lq, M, 1, P).contiguous()
+    go = torch.randn(N, Lq, M * D, generator=gen)
+    go[:, Lq * 5 // 6:] = 0.0
+    shp = torch.tensor([[H, W]], dtype=torch.long, device=dev)
+    ls = torch.zeros(1, dtype=torch.long, device=dev)
+    args = [t.to(dev) for t in (value,)] + [shp, ls] + [t.to(dev) for t in (loc, aw, go)]
+    from dualfusion import _lib
+    real = _lib.load().df3d_ms_deform_attn_backward_binned
+    got = [t.cpu() for t in ops.ms_deform_attn_backward(*args)]
+    again = [t.cpu() for t in ops.ms_deform_attn_backward(*args)]
+    assert torch.equal(got[1], again[1]) and torch.equal(got[2], again[2])
+    assert float((got[0] - again[0]).abs().max()) <= 2e-5 * max(1.0, float(got[0].abs().max()))   # (order of the points in a bin)
+    assert int(_lib.load().df3d_ms_deform_attn_backward_binned_slab_bytes(N, M, D, Lq, P, H, W)) > 0 and real is not None
+    os.environ["DF3D_MSDA_BWD"] = "atomic"
+    try:
+        old = [t.cpu() for t in ops.ms_deform_attn_backward(*args)]
+    finally:
+        os.environ.pop("DF3D_MSDA_BWD", None)
+    want = orc.ms_deform_attn_backward(value.numpy(), [(H, W)], loc.numpy(), aw.numpy(), go.numpy())
+    for a, b, w, name in zip(got, old, want, ("value", "loc", "weight")):
+        scale = max(1.0, float(np.abs(w).max()))
+        assert float((a - b).abs().max()) <= 2e-5 * scale, name                   # (summation order of the atomics)
+        assert np.abs(a.numpy() - w).max() <= 1e-4 * scale, name
+    assert torch.equal(got[1], old[1]) and torch.equal(got[2], old[2])            # the gather half is the same code
+
+
+@pytest.mark.gpu
 def test_linear_module_under_autocast_trains_like_nn_linear():
     """`dualfusion.linear_rows.Linear` replaces nn.Linear throughout ACTR / MSDeformAttn, and the reference trains
     those layers with AMP.  Under torch.autocast the module must behave like nn.Linear (half-precision forward, gradients in
