@@ -457,6 +457,74 @@ extern "C" int df3d_add_layernorm_split(const float *x, const float *y, const fl
   return add_layernorm_impl(x, y, gamma, beta, eps, rows, C, out, (unsigned *)out_split, stream_);
 }
 
+// ---- training: ReLU + dropout of the feed-forward hidden rows in one pass, in place ------------------------------------------------
+// forward_ffn (CP/det3d/models/model_utils/actr_transformer.py:309-311, 388-395) runs linear2(dropout(relu(linear1(src)))): on the
+// [rows x 1024] hidden tensor of a training step (150 k - 240 k rows: 0.6 - 1 GB) the library's relu + dropout read and write it
+// twice and keep a mask, their backward twice more.  Here h <- relu(h) . keep / (1 - p) in ONE in-place pass; the kept-and-active
+// elements are exactly the non-zeros of the result, so the backward (g <- g / (1 - p) where h != 0) needs no mask tensor.
+// keep = a counter-based hash of (element index, the call's 64-bit seed): the same mask whatever the launch shape.
+__device__ __forceinline__ unsigned rd_mix(unsigned x) {
+  x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool rd_keep(unsigned long long i, unsigned s0, unsigned s1, unsigned thr) {
+  const unsigned h = rd_mix(rd_mix((unsigned)i ^ s0) + (unsigned)(i >> 32) * 0x9E3779B9u + s1);
+  return (h >> 8) >= thr;                                      // 24 uniform bits against p * 2^24
+}
+__global__ __launch_bounds__(256) void relu_dropout_kernel(float *__restrict__ h, unsigned long long n, unsigned thr, float scale,
+                                                           unsigned s0, unsigned s1) {
+  const unsigned long long i4 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    f32x4 v = *(f32x4 *)(h + i4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f && (thr == 0u || rd_keep(i4 + j, s0, s1, thr)) ? v[j] * scale : 0.f;
+    *(f32x4 *)(h + i4) = v;
+  } else {
+    for (unsigned long long i = i4; i < n; ++i) {
+      const float v = h[i];
+      h[i] = v > 0.f && (thr == 0u || rd_keep(i, s0, s1, thr)) ? v * scale : 0.f;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float *__restrict__ h, const float *__restrict__ g,
+                                                               unsigned long long n, float scale, float *__restrict__ out) {
+  const unsigned long long i4 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    const f32x4 hv = *(const f32x4 *)(h + i4), gv = *(const f32x4 *)(g + i4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = hv[j] != 0.f ? gv[j] * scale : 0.f;
+    *(f32x4 *)(out + i4) = o;
+  } else {
+    for (unsigned long long i = i4; i < n; ++i) out[i] = h[i] != 0.f ? g[i] * scale : 0.f;
+  }
+}
+
+extern "C" int df3d_relu_dropout(float *h, long long n, float p, unsigned long long seed, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(n >= 0 && p >= 0.f && p < 1.f, "relu_dropout: p must be in [0, 1) (got %g)", (double)p);
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(h && ((uintptr_t)h & 15) == 0, "relu_dropout: null or unaligned rows");
+  const unsigned thr = (unsigned)((double)p * 16777216.0);
+  hipLaunchKernelGGL(relu_dropout_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, stream, h, (unsigned long long)n, thr,
+                     thr ? (float)(1.0 / (1.0 - (double)thr / 16777216.0)) : 1.f, (unsigned)seed, (unsigned)(seed >> 32));
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_relu_dropout_backward(const float *h, const float *grad, long long n, float p, float *grad_in, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(n >= 0 && p >= 0.f && p < 1.f, "relu_dropout_backward: p must be in [0, 1) (got %g)", (double)p);
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(h && grad && grad_in && (((uintptr_t)h | (uintptr_t)grad | (uintptr_t)grad_in) & 15) == 0,
+                 "relu_dropout_backward: null or unaligned rows");
+  const unsigned thr = (unsigned)((double)p * 16777216.0);
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, stream, h, grad, (unsigned long long)n,
+                     thr ? (float)(1.0 / (1.0 - (double)thr / 16777216.0)) : 1.f, grad_in);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
 extern "C" int df3d_bigate_sum(const float *q, const float *qi, const float *wb, const float *bb, const float *wa,
                                const float *ba, long long rows, int C, float *q_out, float *qi_out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -16,6 +16,7 @@ c_longlong = ctypes.c_longlong
 c_size_t = ctypes.c_size_t
 c_float = ctypes.c_float
 c_void_p = ctypes.c_void_p
+c_ulonglong = ctypes.c_ulonglong
 c_char_p = ctypes.c_char_p
 
 # name -> (restype, argtypes); mirrors include/df3d_hip.h one to one
@@ -249,6 +250,8 @@ SIGNATURES = {
     "df3d_frame_head_wait": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_backbone_release": (c_int, [c_void_p]),
     "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_relu_dropout": (c_int, [c_void_p, c_longlong, c_float, c_ulonglong, c_void_p]),
+    "df3d_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p]),
     "df3d_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,
                                    c_void_p]),
     "df3d_add_layernorm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,

@@ -1987,6 +1987,51 @@ def add_layernorm(x, y, weight, bias, eps, want_split=False):
     return out
 
 
+_DROPOUT_CALLS = [None, 0]                     # (torch.initial_seed() the counter belongs to, calls since)
+
+
+def _dropout_seed():
+    """A 64-bit seed per call from torch's seed and a call counter: the masks of a run repeat under torch.manual_seed."""
+    base = torch.initial_seed()
+    if _DROPOUT_CALLS[0] != base:
+        _DROPOUT_CALLS[0], _DROPOUT_CALLS[1] = base, 0
+    _DROPOUT_CALLS[1] += 1
+    return (base * 0x9E3779B97F4A7C15 + _DROPOUT_CALLS[1] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+class _ReluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, p, seed):
+        rc = _lib.load().df3d_relu_dropout(_ptr(h), h.numel(), float(p), int(seed), _stream())
+        _lib.check(rc, "df3d_relu_dropout")
+        ctx.mark_dirty(h)
+        ctx.save_for_backward(h)
+        ctx.p = float(p)
+        return h
+
+    @staticmethod
+    def backward(ctx, grad):
+        (h,) = ctx.saved_tensors
+        grad = grad.contiguous()
+        out = torch.empty_like(grad)
+        rc = _lib.load().df3d_relu_dropout_backward(_ptr(h), _ptr(grad), h.numel(), ctx.p, _ptr(out), _stream())
+        _lib.check(rc, "df3d_relu_dropout_backward")
+        return out, None, None
+
+
+def relu_dropout_(h, p=0.0, seed=None):
+    """h <- dropout(relu(h), p) IN PLACE (h: a fresh contiguous fp32 CUDA tensor nobody else needs, e.g. a linear layer's
+    output), one pass forward, one pass backward, no mask tensor (df3d_relu_dropout).  p = 0: ReLU."""
+    _chk(h, torch.float32, "h")
+    return _ReluDropout.apply(h, float(p), _dropout_seed() if seed is None else int(seed))
+
+
+def relu_dropout_supported(h):
+    """DF3D_RELU_DROPOUT=0 keeps torch's relu + dropout (A/B switch, read per call)."""
+    return (h.is_cuda and h.dtype == torch.float32 and h.is_contiguous() and not torch.is_autocast_enabled()
+            and os.environ.get("DF3D_RELU_DROPOUT", "1") != "0")
+
+
 def bigate_sum(q, qi, wb, bb, wa, ba):
     """BiGateSum1D_2 on [.., C] rows: returns (q + qi*s1, qi + q*s2)."""
     lib = _lib.load()

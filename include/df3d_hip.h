@@ -801,6 +801,13 @@ int df3d_sparse_conv_split(const void *features_split, int n_in, int cin, const 
  * ---------------------------------------------------------------------------------- */
 int df3d_actr_prep(const float *q, const float *qi, const float *pos, long long rows, int C, float *A, float *Bw,
                    void *stream);
+/* training (round 6): h <- relu(h) . keep / (1 - p) over n floats IN PLACE -- the activation + dropout between the two linears of
+ * forward_ffn (CP/det3d/models/model_utils/actr_transformer.py:309-311, 388-395: linear2(dropout(activation(linear1(src))))) as
+ * one pass over the [rows x d_ffn] hidden tensor.  keep(i) = hash(i, seed) >= p (24 uniform bits; p = 0: plain ReLU); the
+ * kept-and-active elements are the non-zeros of the result, so ..._backward (grad_in = grad / (1 - p) where h != 0, else 0;
+ * h = the forward's result) takes no mask.  16-byte aligned pointers. */
+int df3d_relu_dropout(float *h, long long n, float p, unsigned long long seed, void *stream);
+int df3d_relu_dropout_backward(const float *h, const float *grad, long long n, float p, float *grad_in, void *stream);
 int df3d_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, float eps,
                        long long rows, int C, float *out, void *stream);
 /* df3d_add_layernorm that also writes the split rows of its output (C % 8 == 0) for a following split-precision layer. */

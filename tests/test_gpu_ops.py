@@ -1863,3 +1863,49 @@ def test_small_channel_conv_from_row_lists(cin, cout, strided):
                                                     ops._stream()))
         assert torch.equal(got2, want) and torch.equal(gsplit2, gsplit)
     assert float(want.abs().max()) > 0.1
+
+
+@pytest.mark.gpu
+def test_relu_dropout_in_place_forward_and_maskless_backward():
+    """df3d_relu_dropout: h <- relu(h) . keep / (1 - p) in place (the hidden rows of forward_ffn, actr_transformer.py:309-311 /
+    388-395, in a training step).  p = 0 is torch's relu bit for bit, forward and backward; p = 0.1 keeps 90 % of the active
+    elements (binomial bounds), scales them by 1 / 0.9, repeats under the same seed and differs under another; the backward passes
+    grad / (1 - p) exactly where the forward kept a positive value -- checked against the mask read off the forward's result."""
+    from dualfusion import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn((3001, 1024), generator=gen)
+    x[5, :7] = 0.0
+    g = torch.randn(x.shape, generator=gen).to(dev)
+    a = x.to(dev).requires_grad_(True)
+    y = ops.relu_dropout_(a * 1.0, 0.0)
+    y.backward(g)
+    b = x.to(dev).requires_grad_(True)
+    yr = torch.relu(b)
+    yr.backward(g)
+    assert torch.equal(y, yr) and torch.equal(a.grad, b.grad)
+    p = 0.1
+    outs = []
+    for seed in (11, 11, 12):
+        h = x.to(dev).requires_grad_(True)
+        y = ops.relu_dropout_(h * 1.0, p, seed=seed)
+        y.backward(g)
+        outs.append((y.detach().cpu(), h.grad.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][0], outs[2][0])
+    y, gx = outs[0]
+    active = x > 0
+    kept = y != 0
+    assert not bool((kept & ~active).any())
+    n, k = int(active.sum()), int(kept.sum())
+    assert abs(k - (1 - p) * n) <= 5 * (n * p * (1 - p)) ** 0.5, (k, n)                 # five sigma of the binomial
+    scale = np.float32(1.0 / (1.0 - np.floor(p * 16777216.0) / 16777216.0))
+    assert torch.equal(y[kept], x[kept] * float(scale))
+    assert torch.equal(gx, torch.where(kept, g.cpu() * float(scale), torch.zeros(())))
+    # the mask does not depend on the launch shape: the first 1001 elements of a longer call = a call on 1001 elements
+    h1, h2 = x.reshape(-1)[:1001].clone().to(dev), x.reshape(-1)[:4004].clone().to(dev)
+    y1, y2 = ops.relu_dropout_(h1, 0.3, seed=5), ops.relu_dropout_(h2, 0.3, seed=5)
+    assert torch.equal(y1, y2[:1001])
+    # per-row independence: no column of a [rows, 1024] tensor is dropped much more often than p
+    col = (outs[0][0] != 0).float().sum(0) / active.float().sum(0).clamp_min(1)
+    assert float(col.min()) > 0.8 and float(col.max()) <= 1.0

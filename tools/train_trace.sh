@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel statistics of the training step (bench.py --stage train): top kernels by total time, grouped
 R=$(pwd); OUT=$R/gpurun_out/train_trace; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python $R/bench.py --stage train --steps 4 --warmup 2 --no-cpu-baseline --no-extra-passes --no-side-configs --no-kernel-timing > $OUT/log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python $R/bench.py --workload ${WL:-centerpoint} --stage train --steps 4 --warmup 2 --no-cpu-baseline --no-extra-passes --no-side-configs --no-kernel-timing > $OUT/log 2>&1
 grep -h "^{" $OUT/log | python -c "
 import json,sys
 for l in sys.stdin:
