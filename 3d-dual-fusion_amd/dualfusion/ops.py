@@ -1987,16 +1987,13 @@ def add_layernorm(x, y, weight, bias, eps, want_split=False):
     return out
 
 
-_DROPOUT_CALLS = [None, 0]                     # (torch.initial_seed() the counter belongs to, calls since)
-
-
-def _dropout_seed():
-    """A 64-bit seed per call from torch's seed and a call counter: the masks of a run repeat under torch.manual_seed."""
-    base = torch.initial_seed()
-    if _DROPOUT_CALLS[0] != base:
-        _DROPOUT_CALLS[0], _DROPOUT_CALLS[1] = base, 0
-    _DROPOUT_CALLS[1] += 1
-    return (base * 0x9E3779B97F4A7C15 + _DROPOUT_CALLS[1] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+def _dropout_seed(device):
+    """A 63-bit seed per call from the device generator's (seed, Philox offset), which the call advances like a dropout kernel
+    would: the masks of a run repeat under torch.manual_seed, host side only (no launch)."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    return (gen.initial_seed() * 0x9E3779B97F4A7C15 + (off // 4 + 1) * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF   # (int64 for autograd)
 
 
 class _ReluDropout(torch.autograd.Function):
@@ -2023,7 +2020,7 @@ def relu_dropout_(h, p=0.0, seed=None):
     """h <- dropout(relu(h), p) IN PLACE (h: a fresh contiguous fp32 CUDA tensor nobody else needs, e.g. a linear layer's
     output), one pass forward, one pass backward, no mask tensor (df3d_relu_dropout).  p = 0: ReLU."""
     _chk(h, torch.float32, "h")
-    return _ReluDropout.apply(h, float(p), _dropout_seed() if seed is None else int(seed))
+    return _ReluDropout.apply(h, float(p), _dropout_seed(h.device) if seed is None else int(seed))
 
 
 def relu_dropout_supported(h):

@@ -1906,6 +1906,12 @@ def test_relu_dropout_in_place_forward_and_maskless_backward():
     h1, h2 = x.reshape(-1)[:1001].clone().to(dev), x.reshape(-1)[:4004].clone().to(dev)
     y1, y2 = ops.relu_dropout_(h1, 0.3, seed=5), ops.relu_dropout_(h2, 0.3, seed=5)
     assert torch.equal(y1, y2[:1001])
+    # without an explicit seed the mask follows torch's device generator: repeats under manual_seed, moves from call to call
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(123)
+        runs.append([ops.relu_dropout_(x.to(dev), 0.1).cpu() for _ in range(2)])
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and not torch.equal(runs[0][0], runs[0][1])
     # per-row independence: no column of a [rows, 1024] tensor is dropped much more often than p
     col = (outs[0][0] != 0).float().sum(0) / active.float().sum(0).clamp_min(1)
     assert float(col.min()) > 0.8 and float(col.max()) <= 1.0
