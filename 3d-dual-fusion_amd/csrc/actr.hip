@@ -525,6 +525,183 @@ extern "C" int df3d_relu_dropout_backward(const float *h, const float *grad, lon
   return DF3D_OK;
 }
 
+// ---- training: LayerNorm(x + dropout(y)) and its backward as one row kernel each way ------------------------------------------
+// The residual steps of the encoder layers (actr_transformer.py:311-312, 330-331, 389-390, 395-396, 416-417: src = norm(src +
+// dropout(src2))) ran as dropout (+ mask) + add + LayerNorm (7 passes over the rows) and, backwards, LayerNorm's two kernels +
+// masked scale + the residual's gradient sum (8 passes).  Forward here: out and the normalised rows xhat (what the backward
+// needs instead of the input) + 1 / sigma per row; backward: dx = (g gamma - mean(g gamma) - xhat mean(g gamma xhat)) / sigma for
+// the residual branch, dy = dx . keep / (1 - p) with the mask recomputed from the hash, d gamma / d beta as per-workgroup
+// column sums added once per workgroup.
+template <int LPR>
+__global__ __launch_bounds__(256) void dropout_add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                    float eps, long long rows, int C, unsigned thr, float scale,
+                                                                    unsigned s0, unsigned s1, float *__restrict__ out,
+                                                                    float *__restrict__ xhat, float *__restrict__ rstd_out) {
+  constexpr int RPW = 64 / LPR, NK = LPR == 64 ? 4 : 1;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const long long row = wave * RPW + lane / LPR;
+  const bool live = row < rows;
+  const int nv = C / 4;
+  f32x4 v[NK];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int c4 = sub + LPR * k;
+    v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (live && c4 < nv) {
+      f32x4 a = ((const f32x4 *)(x + row * C))[c4];
+      f32x4 b = ((const f32x4 *)(y + row * C))[c4];
+      if (thr) {
+        const unsigned long long i0 = (unsigned long long)row * C + c4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = rd_keep(i0 + j, s0, s1, thr) ? b[j] * scale : 0.f;
+      }
+      a += b;
+      v[k] = a;
+      s += a[0] + a[1] + a[2] + a[3];
+    }
+  }
+  const float mean = group_sum<LPR>(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int c4 = sub + LPR * k;
+    if (c4 < nv) {
+      const f32x4 d = v[k] - mean;
+      ss += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    }
+  }
+  const float rstd = rsqrtf(group_sum<LPR>(ss) / (float)C + eps);
+  if (live && sub == 0) rstd_out[row] = rstd;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int c4 = sub + LPR * k;
+    if (live && c4 < nv) {
+      const f32x4 g = ((const f32x4 *)gamma)[c4], b = ((const f32x4 *)beta)[c4];
+      const f32x4 xh = (v[k] - mean) * rstd;
+      ((f32x4 *)(xhat + row * C))[c4] = xh;
+      ((f32x4 *)(out + row * C))[c4] = xh * g + b;
+    }
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void dropout_add_layernorm_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ xhat,
+                                                                        const float *__restrict__ rstd,
+                                                                        const float *__restrict__ gamma, long long rows, int C,
+                                                                        unsigned thr, float scale, unsigned s0, unsigned s1,
+                                                                        float *__restrict__ dx, float *__restrict__ dy,
+                                                                        float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  constexpr int RPW = 64 / LPR, NK = LPR == 64 ? 4 : 1;
+  __shared__ float sdg[1024], sdb[1024];
+  for (int c = threadIdx.x; c < C; c += 256) sdg[c] = 0.f, sdb[c] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const int nv = C / 4;
+  const long long wave0 = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (long long)gridDim.x * 4;
+  f32x4 gam[NK], ag[NK], ab[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int c4 = sub + LPR * k;
+    gam[k] = c4 < nv ? ((const f32x4 *)gamma)[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    ag[k] = ab[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (long long wave = wave0; wave * RPW < rows; wave += nwaves) {
+    const long long row = wave * RPW + lane / LPR;
+    const bool live = row < rows;
+    f32x4 g[NK], xh[NK];
+    float s1v = 0.f, s2v = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int c4 = sub + LPR * k;
+      g[k] = xh[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (live && c4 < nv) {
+        g[k] = ((const f32x4 *)(grad + row * C))[c4];
+        xh[k] = ((const f32x4 *)(xhat + row * C))[c4];
+        ab[k] += g[k];
+        ag[k] += g[k] * xh[k];
+        const f32x4 a = g[k] * gam[k];
+        s1v += a[0] + a[1] + a[2] + a[3];
+        s2v += a[0] * xh[k][0] + a[1] * xh[k][1] + a[2] * xh[k][2] + a[3] * xh[k][3];
+      }
+    }
+    const float m1 = group_sum<LPR>(s1v) / (float)C, m2 = group_sum<LPR>(s2v) / (float)C;
+    const float rs = live ? rstd[row] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int c4 = sub + LPR * k;
+      if (live && c4 < nv) {
+        const f32x4 d = (g[k] * gam[k] - m1 - xh[k] * m2) * rs;
+        ((f32x4 *)(dx + row * C))[c4] = d;
+        if (thr) {
+          const unsigned long long i0 = (unsigned long long)row * C + c4 * 4;
+          f32x4 e;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = rd_keep(i0 + j, s0, s1, thr) ? d[j] * scale : 0.f;
+          ((f32x4 *)(dy + row * C))[c4] = e;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int c4 = sub + LPR * k;
+    if (c4 < nv)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(&sdg[c4 * 4 + j], ag[k][j]), atomicAdd(&sdb[c4 * 4 + j], ab[k][j]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) unsafeAtomicAdd(dgamma + c, sdg[c]), unsafeAtomicAdd(dbeta + c, sdb[c]);
+}
+
+static unsigned dropout_threshold(float p) { return (unsigned)((double)p * 16777216.0); }
+static float dropout_scale(unsigned thr) { return thr ? (float)(1.0 / (1.0 - (double)thr / 16777216.0)) : 1.f; }
+
+extern "C" int df3d_dropout_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, float eps, float p,
+                                          unsigned long long seed, long long rows, int C, float *out, float *xhat, float *rstd,
+                                          void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(rows >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "dropout_add_layernorm: C must be a multiple of 4 and <= 1024 (got %d)", C);
+  DF3D_CHECK_ARG(p >= 0.f && p < 1.f, "dropout_add_layernorm: p must be in [0, 1) (got %g)", (double)p);
+  if (rows == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(x && y && gamma && beta && out && xhat && rstd, "dropout_add_layernorm: null argument");
+  const unsigned thr = dropout_threshold(p), s0 = (unsigned)seed, s1 = (unsigned)(seed >> 32);
+  const float sc = dropout_scale(thr);
+#define DF3D_DAL(LPR, RPWV)                                                                                                   \
+  hipLaunchKernelGGL(dropout_add_layernorm_kernel<LPR>, dim3(cdiv(cdiv(rows, RPWV) * 64, 256)), dim3(256), 0, stream, x, y, gamma, \
+                     beta, eps, rows, C, thr, sc, s0, s1, out, xhat, rstd)
+  if (C <= 64) DF3D_DAL(16, 4);
+  else if (C <= 128) DF3D_DAL(32, 2);
+  else DF3D_DAL(64, 1);
+#undef DF3D_DAL
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+/* dgamma / dbeta [C] are ADDED to (zero them first) */
+extern "C" int df3d_dropout_add_layernorm_backward(const float *grad, const float *xhat, const float *rstd, const float *gamma,
+                                                   float p, unsigned long long seed, long long rows, int C, float *dx, float *dy,
+                                                   float *dgamma, float *dbeta, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(rows >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "dropout_add_layernorm_backward: C must be a multiple of 4 and <= 1024 (got %d)", C);
+  DF3D_CHECK_ARG(p >= 0.f && p < 1.f, "dropout_add_layernorm_backward: p must be in [0, 1) (got %g)", (double)p);
+  if (rows == 0) return DF3D_OK;
+  const unsigned thr = dropout_threshold(p), s0 = (unsigned)seed, s1 = (unsigned)(seed >> 32);
+  DF3D_CHECK_ARG(grad && xhat && rstd && gamma && dx && dgamma && dbeta && (dy || !thr), "dropout_add_layernorm_backward: null argument");
+  const float sc = dropout_scale(thr);
+#define DF3D_DALB(LPR, RPWV)                                                                                                       \
+  hipLaunchKernelGGL(dropout_add_layernorm_bwd_kernel<LPR>, dim3((unsigned)std::min<long long>(2048, cdiv(cdiv(rows, RPWV), 4))), dim3(256), \
+                     0, stream, grad, xhat, rstd, gamma, rows, C, thr, sc, s0, s1, dx, dy, dgamma, dbeta)
+  if (C <= 64) DF3D_DALB(16, 4);
+  else if (C <= 128) DF3D_DALB(32, 2);
+  else DF3D_DALB(64, 1);
+#undef DF3D_DALB
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
 extern "C" int df3d_bigate_sum(const float *q, const float *qi, const float *wb, const float *bb, const float *wa,
                                const float *ba, long long rows, int C, float *q_out, float *qi_out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -252,6 +252,10 @@ SIGNATURES = {
     "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_relu_dropout": (c_int, [c_void_p, c_longlong, c_float, c_ulonglong, c_void_p]),
     "df3d_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p]),
+    "df3d_dropout_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_ulonglong, c_longlong, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    "df3d_dropout_add_layernorm_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_ulonglong, c_longlong, c_int,
+                                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,
                                    c_void_p]),
     "df3d_add_layernorm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p,

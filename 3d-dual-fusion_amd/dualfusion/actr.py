@@ -163,6 +163,12 @@ def _ffn_hidden(lin, x, activation, drop):
     return drop(activation(lin(x)))
 
 
+def _residual_norm(x, y, norm, drop):
+    """norm(x + drop(y)): one row kernel each way under grad (ops.dropout_add_layernorm), the modules otherwise."""
+    from . import ops as _ops
+    return _ops.dropout_add_layernorm(x, y, norm, drop)
+
+
 def _get_activation_fn(activation):
     if activation == "relu":
         return F.relu
@@ -194,9 +200,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
                 q_feat=None, q_i_feat=None):
         query = q_feat if q_pos is None else q_feat + q_pos
         att = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
-        q_feat = self.norm1(q_feat + self.dropout1(att))
+        q_feat = _residual_norm(q_feat, att, self.norm1, self.dropout1)
         ffn = self.linear2(_ffn_hidden(self.linear1, q_feat, self.activation, self.dropout2))
-        q_feat = self.norm2(q_feat + self.dropout3(ffn))
+        q_feat = _residual_norm(q_feat, ffn, self.norm2, self.dropout3)
         return q_feat, q_i_feat
 
 
@@ -243,13 +249,13 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         lq = q_feat if q_pos is None else q_feat + q_pos
         iq = q_i_feat if q_pos is None else q_i_feat + q_pos
         att = self.self_attn(lq, reference_points, src, spatial_shapes, level_start_index, padding_mask, i_query=iq)
-        q_i_feat = self.norm1(q_i_feat + self.dropout1(att))
+        q_i_feat = _residual_norm(q_i_feat, att, self.norm1, self.dropout1)
         if self.gate_before_ffn:
             q_feat, q_i_feat = self.fusion_layer(q_feat, q_i_feat)
-        q_i_feat = self.norm2(q_i_feat + self.dropout3(
-            self.linear2(_ffn_hidden(self.linear1, q_i_feat, self.activation, self.dropout2))))
-        q_feat = self.norm3(q_feat + self.dropout5(
-            self.linear4(_ffn_hidden(self.linear3, q_feat, self.activation, self.dropout4))))
+        q_i_feat = _residual_norm(q_i_feat, self.linear2(_ffn_hidden(self.linear1, q_i_feat, self.activation, self.dropout2)),
+                                  self.norm2, self.dropout3)
+        q_feat = _residual_norm(q_feat, self.linear4(_ffn_hidden(self.linear3, q_feat, self.activation, self.dropout4)),
+                                self.norm3, self.dropout5)
         if self.gate_before_ffn:
             return q_feat, q_i_feat
         return self.fusion_layer(q_feat, q_i_feat)

@@ -2029,6 +2029,49 @@ def relu_dropout_supported(h):
             and os.environ.get("DF3D_RELU_DROPOUT", "1") != "0")
 
 
+class _DropoutAddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, weight, bias, eps, p, seed):
+        C = x.shape[-1]
+        rows = x.numel() // C
+        out, xhat = torch.empty_like(x), torch.empty_like(x)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rc = _lib.load().df3d_dropout_add_layernorm(_ptr(x), _ptr(y), _ptr(weight), _ptr(bias), float(eps), float(p), int(seed),
+                                                    rows, C, _ptr(out), _ptr(xhat), _ptr(rstd), _stream())
+        _lib.check(rc, "df3d_dropout_add_layernorm")
+        ctx.save_for_backward(xhat, rstd, weight)
+        ctx.p, ctx.seed = float(p), int(seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        xhat, rstd, weight = ctx.saved_tensors
+        grad = grad.contiguous()
+        C = xhat.shape[-1]
+        dx = torch.empty_like(xhat)
+        dy = torch.empty_like(xhat) if ctx.p > 0 else None
+        dwb = torch.zeros((2, C), dtype=torch.float32, device=xhat.device)
+        rc = _lib.load().df3d_dropout_add_layernorm_backward(_ptr(grad), _ptr(xhat), _ptr(rstd), _ptr(weight), ctx.p, ctx.seed,
+                                                             xhat.numel() // C, C, _ptr(dx), _ptr(dy), _ptr(dwb[0]),
+                                                             _ptr(dwb[1]), _stream())
+        _lib.check(rc, "df3d_dropout_add_layernorm_backward")
+        return dx, (dy if dy is not None else dx), dwb[0], dwb[1], None, None, None
+
+
+def dropout_add_layernorm(x, y, norm, drop):
+    """norm(x + drop(y)) for an nn.LayerNorm over the last dimension and an nn.Dropout: under grad on fp32 CUDA rows one kernel
+    forward and one backward (df3d_dropout_add_layernorm); otherwise the modules."""
+    p = drop.p if drop.training else 0.0
+    C = x.shape[-1]
+    if (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape == y.shape
+            and not torch.is_autocast_enabled() and C % 4 == 0 and C <= 1024 and tuple(norm.normalized_shape) == (C,)
+            and norm.weight is not None and norm.bias is not None and p < 1.0
+            and os.environ.get("DF3D_DROPOUT_ADD_LN", "1") != "0"):
+        return _DropoutAddLayerNorm.apply(x.contiguous(), y.contiguous(), norm.weight, norm.bias, norm.eps, p,
+                                          _dropout_seed(x.device) if p > 0 else 0)
+    return norm(x + drop(y))
+
+
 def bigate_sum(q, qi, wb, bb, wa, ba):
     """BiGateSum1D_2 on [.., C] rows: returns (q + qi*s1, qi + q*s2)."""
     lib = _lib.load()

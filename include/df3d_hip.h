@@ -808,6 +808,16 @@ int df3d_actr_prep(const float *q, const float *qi, const float *pos, long long 
  * h = the forward's result) takes no mask.  16-byte aligned pointers. */
 int df3d_relu_dropout(float *h, long long n, float p, unsigned long long seed, void *stream);
 int df3d_relu_dropout_backward(const float *h, const float *grad, long long n, float p, float *grad_in, void *stream);
+/* training (round 6): out = LayerNorm(x + dropout(y, p)) over [rows, C] fp32 rows -- the residual steps of the encoder layers
+ * (CP/det3d/models/model_utils/actr_transformer.py:311-312, 330-331, 389-390, 395-396, 416-417) -- in one kernel; also writes the
+ * normalised rows `xhat` [rows, C] and `rstd` [rows] for the backward.  keep(i) = the hash of df3d_relu_dropout over the element
+ * index row * C + c (p = 0: no dropout).  ..._backward: dx = d out / d x [rows, C]; dy = dx . keep / (1 - p) (may be NULL when
+ * p = 0: dy = dx); dgamma / dbeta [C] are ADDED to (zero them first).  C % 4 == 0, C <= 1024. */
+int df3d_dropout_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, float eps, float p,
+                               unsigned long long seed, long long rows, int C, float *out, float *xhat, float *rstd, void *stream);
+int df3d_dropout_add_layernorm_backward(const float *grad, const float *xhat, const float *rstd, const float *gamma, float p,
+                                        unsigned long long seed, long long rows, int C, float *dx, float *dy, float *dgamma,
+                                        float *dbeta, void *stream);
 int df3d_add_layernorm(const float *x, const float *y, const float *gamma, const float *beta, float eps,
                        long long rows, int C, float *out, void *stream);
 /* df3d_add_layernorm that also writes the split rows of its output (C % 8 == 0) for a following split-precision layer. */

@@ -4,6 +4,8 @@ Bit-exact for voxel indices / rulebooks (canonical order); fp32 
 1e-3 (north_star), in practice ~1e-5.  Run with -m gpu on a MI355X."""
 import os
 
+import copy
+
 import numpy as np
 import pytest
 
@@ -1915,3 +1917,44 @@ def test_relu_dropout_in_place_forward_and_maskless_backward():
     # per-row independence: no column of a [rows, 1024] tensor is dropped much more often than p
     col = (outs[0][0] != 0).float().sum(0) / active.float().sum(0).clamp_min(1)
     assert float(col.min()) > 0.8 and float(col.max()) <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C", [(5003, 128), (777, 64), (300, 256), (1030, 32)])
+def test_dropout_add_layernorm_forward_and_backward(rows, C):
+    """df3d_dropout_add_layernorm: norm(x + dropout(y)) of the encoder layers' residual steps (actr_transformer.py:311-312,
+    389-396, 416-417) as one kernel each way.  p = 0 against nn.LayerNorm in float64 (output, d x = d y, d gamma, d beta);
+    p = 0.2 against the torch composition with the SAME mask (the hash of df3d_relu_dropout over the element index, read off a
+    relu_dropout_ call with that seed)."""
+    from dualfusion import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(rows + C)
+    x, y = torch.randn((3, rows, C), generator=gen), torch.randn((3, rows, C), generator=gen) * 2 + 0.3
+    g = torch.randn((3, rows, C), generator=gen)
+    norm = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(C, generator=gen) + 0.5)
+        norm.bias.copy_(torch.randn(C, generator=gen))
+    for p in (0.0, 0.2):
+        drop = torch.nn.Dropout(p)
+        nd = copy.deepcopy(norm).to(dev)
+        xa, ya = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+        torch.manual_seed(99)
+        seed = ops._dropout_seed(dev) if p else 0
+        torch.manual_seed(99)
+        out = ops.dropout_add_layernorm(xa, ya, nd, drop)
+        assert type(out.grad_fn).__name__ == "_DropoutAddLayerNormBackward"
+        out.backward(g.to(dev))
+        mask = torch.ones_like(x, dtype=torch.float64)
+        if p:
+            kept = ops.relu_dropout_(torch.ones(x.numel(), device=dev), p, seed=seed).cpu().view(x.shape)
+            assert 0.7 < float((kept != 0).double().mean()) < 0.9
+            mask = kept.double()                                    # 0 or 1 / (1 - p)
+        n64 = copy.deepcopy(norm).double()
+        xr, yr = x.double().requires_grad_(True), y.double().requires_grad_(True)
+        ref = n64(xr + yr * mask)
+        ref.backward(g.double())
+        for a, b, name in ((out, ref, "out"), (xa.grad, xr.grad, "dx"), (ya.grad, yr.grad, "dy"),
+                           (nd.weight.grad, n64.weight.grad, "dgamma"), (nd.bias.grad, n64.bias.grad, "dbeta")):
+            err = float((a.detach().cpu().double() - b.detach()).abs().max()) / max(1.0, float(b.detach().abs().max()))
+            assert err <= (2e-5 if name in ("dgamma", "dbeta") else 5e-6), (name, p, err)
