@@ -19,6 +19,8 @@ What differs is the execution plan (results identical in eval mode):
 import copy
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -149,18 +151,28 @@ class PositionEmbeddingLearnedDepth(nn.Module):
 
 
 # ----------------------------------------------------------------------------- encoder layers
-def _ffn_hidden(lin, x, activation, drop):
-    """drop(activation(lin(x))): the hidden rows of a feed-forward block.  Under grad with ReLU: one in-place pass forward and
-    one pass backward without a mask tensor (ops.relu_dropout_) instead of the library's four + four over a 0.6 - 1 GB tensor.
-    (The linear runs on the flattened rows: its result is then a fresh tensor, not a view, and may be written in place.)"""
+def _ffn_branch(lin_a, lin_b, x, activation, drop):
+    """lin_b(drop(activation(lin_a(x)))): the two linears of a feed-forward block around its [rows x d_ffn] hidden tensor
+    (0.5 - 1 GB in a training step).  Under grad:
+      * bf16 mixed precision (ops.CONV_PRECISION == "bf16": BASELINE configs[2] / [3]): the branch under torch.autocast -- hidden
+        rows, their activation / dropout and both products in bfloat16 (half the bytes of every pass, 16-bit matrix rate), the
+        result back in fp32 for the residual LayerNorm; DF3D_FFN_AUTOCAST=0 keeps fp32;
+      * otherwise with ReLU: activation + dropout as one in-place pass forward and one pass backward without a mask tensor
+        (ops.relu_dropout_); the first linear runs on the flattened rows so that its result is a fresh tensor, not a view."""
     from . import ops as _ops
-    if activation is F.relu and torch.is_grad_enabled() and _ops.relu_dropout_supported(x):
-        h = lin(x.reshape(-1, x.shape[-1]))
-        if h.requires_grad and h.is_contiguous() and h._base is None:
-            h = _ops.relu_dropout_(h, drop.p if drop.training else 0.0)
-            return h.view(x.shape[:-1] + (h.shape[-1],))
-        return drop(activation(h)).view(x.shape[:-1] + (h.shape[-1],))
-    return drop(activation(lin(x)))
+    if torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+        if _ops.CONV_PRECISION == "bf16" and os.environ.get("DF3D_FFN_AUTOCAST", "1") != "0":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = lin_b(drop(activation(lin_a(x))))
+            return y.float()
+        if activation is F.relu and _ops.relu_dropout_supported(x):
+            h = lin_a(x.reshape(-1, x.shape[-1]))
+            if h.requires_grad and h.is_contiguous() and h._base is None:
+                h = _ops.relu_dropout_(h, drop.p if drop.training else 0.0)
+            else:
+                h = drop(activation(h))
+            return lin_b(h.view(x.shape[:-1] + (h.shape[-1],)))
+    return lin_b(drop(activation(lin_a(x))))
 
 
 def _residual_norm(x, y, norm, drop):
@@ -201,7 +213,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         query = q_feat if q_pos is None else q_feat + q_pos
         att = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         q_feat = _residual_norm(q_feat, att, self.norm1, self.dropout1)
-        ffn = self.linear2(_ffn_hidden(self.linear1, q_feat, self.activation, self.dropout2))
+        ffn = _ffn_branch(self.linear1, self.linear2, q_feat, self.activation, self.dropout2)
         q_feat = _residual_norm(q_feat, ffn, self.norm2, self.dropout3)
         return q_feat, q_i_feat
 
@@ -252,9 +264,9 @@ class DeformableTransformerFusionEncoderLayer(nn.Module):
         q_i_feat = _residual_norm(q_i_feat, att, self.norm1, self.dropout1)
         if self.gate_before_ffn:
             q_feat, q_i_feat = self.fusion_layer(q_feat, q_i_feat)
-        q_i_feat = _residual_norm(q_i_feat, self.linear2(_ffn_hidden(self.linear1, q_i_feat, self.activation, self.dropout2)),
+        q_i_feat = _residual_norm(q_i_feat, _ffn_branch(self.linear1, self.linear2, q_i_feat, self.activation, self.dropout2),
                                   self.norm2, self.dropout3)
-        q_feat = _residual_norm(q_feat, self.linear4(_ffn_hidden(self.linear3, q_feat, self.activation, self.dropout4)),
+        q_feat = _residual_norm(q_feat, _ffn_branch(self.linear3, self.linear4, q_feat, self.activation, self.dropout4),
                                 self.norm3, self.dropout5)
         if self.gate_before_ffn:
             return q_feat, q_i_feat
