@@ -463,14 +463,7 @@ extern "C" int df3d_add_layernorm_split(const float *x, const float *y, const fl
 // twice and keep a mask, their backward twice more.  Here h <- relu(h) . keep / (1 - p) in ONE in-place pass; the kept-and-active
 // elements are exactly the non-zeros of the result, so the backward (g <- g / (1 - p) where h != 0) needs no mask tensor.
 // keep = a counter-based hash of (element index, the call's 64-bit seed): the same mask whatever the launch shape.
-__device__ __forceinline__ unsigned rd_mix(unsigned x) {
-  x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ bool rd_keep(unsigned long long i, unsigned s0, unsigned s1, unsigned thr) {
-  const unsigned h = rd_mix(rd_mix((unsigned)i ^ s0) + (unsigned)(i >> 32) * 0x9E3779B9u + s1);
-  return (h >> 8) >= thr;                                      // 24 uniform bits against p * 2^24
-}
+// (rd_keep: common.h)
 __global__ __launch_bounds__(256) void relu_dropout_kernel(float *__restrict__ h, unsigned long long n, unsigned thr, float scale,
                                                            unsigned s0, unsigned s1) {
   const unsigned long long i4 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4;

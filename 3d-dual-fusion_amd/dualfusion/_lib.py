@@ -227,6 +227,11 @@ SIGNATURES = {
     "df3d_topk_keys_workspace_bytes": (c_size_t, [c_int, c_longlong, c_int]),
     "df3d_topk_keys": (c_int, [c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_cross_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "df3d_cross_attention_train": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_float, c_float, c_ulonglong, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_cross_attention_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                              c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_ulonglong,
+                                              c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "df3d_cross_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_float, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "df3d_imgproj_packed_bytes": (c_size_t, [c_int, c_int]),

@@ -1677,6 +1677,58 @@ def cross_attention(q, k, v, batch, heads, scale=None):
     return out
 
 
+class _CrossAttention(torch.autograd.Function):
+    """softmax(scale q k^T) (with dropout) v for [B, n, heads * 16] operands on csrc/xattn.hip, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, p, seed):
+        lib = _lib.load()
+        B, nq, E = q.shape
+        nk = k.shape[1]
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = torch.empty((B, nq, E), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B, heads, nq), dtype=torch.float32, device=q.device)
+        nbytes = int(lib.df3d_cross_attention_workspace_bytes(B, heads, nq, nk))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        rc = lib.df3d_cross_attention_train(_ptr(q), E, _ptr(k), E, _ptr(v), E, B, nq, nk, heads, 16, float(scale), float(p),
+                                            int(seed), _ptr(out), E, _ptr(lse), _ptr(ws), nbytes, _stream())
+        _lib.check(rc, "df3d_cross_attention_train")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.cfg = (heads, float(scale), float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        q, k, v, out, lse = ctx.saved_tensors
+        heads, scale, p, seed = ctx.cfg
+        B, nq, E = q.shape
+        nk = k.shape[1]
+        grad = grad.contiguous()
+        delta = (grad * out).view(B, nq, heads, 16).sum(-1).transpose(1, 2).contiguous()       # [B, heads, nq]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        rc = _lib.load().df3d_cross_attention_backward(_ptr(q), E, _ptr(k), E, _ptr(v), E, _ptr(grad), E, _ptr(lse), _ptr(delta),
+                                                       B, nq, nk, heads, 16, scale, p, seed, _ptr(dq), E, _ptr(dk), E,
+                                                       _ptr(dv), E, _stream())
+        _lib.check(rc, "df3d_cross_attention_backward")
+        return dq, dk, dv, None, None, None, None
+
+
+def cross_attention_train_supported(q, k, v, heads):
+    """DF3D_XATTN_TRAIN=0 keeps the torch composition (A/B switch, read per call)."""
+    return (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.float32 and q.dim() == 3 and q.shape[-1] == heads * 16
+            and q.shape[1] <= 256 and k.shape == v.shape and not torch.is_autocast_enabled()
+            and _lib.load().df3d_cross_attention_workspace_bytes(q.shape[0], heads, q.shape[1], k.shape[1]) > 0
+            and os.environ.get("DF3D_XATTN_TRAIN", "1") != "0")
+
+
+def cross_attention_train(q, k, v, heads, scale, p=0.0, seed=None):
+    """softmax(scale q k^T, over the keys) -> dropout(p) -> . v per head, q [B, nq, heads * 16], k / v [B, nk, heads * 16]
+    projected operands, differentiable (df3d_cross_attention_train / _backward): the [B * heads, nq, nk] tensors never exist."""
+    if seed is None:
+        seed = _dropout_seed(q.device) if p > 0 else 0
+    return _CrossAttention.apply(q, k, v, int(heads), float(scale), float(p), int(seed))
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
     lib = _lib.load()
     _chk(value, torch.float32, "value")

@@ -88,6 +88,13 @@ class MultiheadAttention(nn.Module):
 
     def attend(self, q, k, v):
         """q [N, L, E], k / v [N, S, E] already projected -> out_proj(softmax(q k^T / sqrt(d)) v)."""
+        if (torch.is_grad_enabled() and self.head_dim == 16 and q.shape[1] * 16 <= k.shape[1]
+                and _ops.cross_attention_train_supported(q, k, v, self.num_heads)):
+            # training, a few hundred queries against a BEV map of keys: keys split over waves, probabilities recomputed in the
+            # backward (csrc/xattn.hip) -- the [N, heads, L, S] tensors of the composition below are never written
+            o = _ops.cross_attention_train(q, k, v, self.num_heads, self.head_dim ** -0.5,
+                                          self.dropout if self.training else 0.0)
+            return self.out_proj(o)
         qh, kh, vh = self._heads(q), self._heads(k), self._heads(v)
         if (torch.is_grad_enabled() and q.is_cuda and q.shape[1] * 16 <= k.shape[1]
                 and os.environ.get("DF3D_TFHEAD_MATH_ATTN", "1") == "1"):

@@ -547,6 +547,20 @@ size_t df3d_cross_attention_workspace_bytes(int batch, int heads, int nq, int nk
 int df3d_cross_attention(const float *q, int ld_q, const float *k, int ld_k, const float *v, int ld_v, int batch, int nq,
                          int nk, int heads, int head_dim, float scale, float *out, int ld_out, void *workspace,
                          size_t workspace_bytes, void *stream);
+/* training (round 6).  ..._train: the same product with dropout of the probabilities (F.dropout(attn_output_weights, p) of
+ * multi_head_attention_forward, transfusion_head.py:489-490; keep(e) = the hash of df3d_relu_dropout over the element index
+ * e = ((b * heads + h) * nq + q) * nk + key; p = 0: none) and the base-2 log-sum-exp of the scaled scores lse [B, heads, nq] for
+ * the backward; same workspace.  ..._backward: dq [B*nq, ld_dq], dk / dv [B*nk, ld_dk / ld_dv] (first heads*16 columns written;
+ * dq is zeroed by the call) from grad_out [B*nq, ld_do], lse and delta [B, heads, nq] = <grad_out, out> per head; the
+ * probabilities are recomputed tile by tile on the fp32 matrix cores, the [B*heads, nq, nk] tensors never exist.  nq <= 256,
+ * head_dim 16, strides multiples of 4 floats, 16-byte aligned operands. */
+int df3d_cross_attention_train(const float *q, int ld_q, const float *k, int ld_k, const float *v, int ld_v, int batch, int nq,
+                               int nk, int heads, int head_dim, float scale, float p, unsigned long long seed, float *out,
+                               int ld_out, float *lse, void *workspace, size_t workspace_bytes, void *stream);
+int df3d_cross_attention_backward(const float *q, int ld_q, const float *k, int ld_k, const float *v, int ld_v,
+                                  const float *grad_out, int ld_do, const float *lse, const float *delta, int batch, int nq,
+                                  int nk, int heads, int head_dim, float scale, float p, unsigned long long seed, float *dq,
+                                  int ld_dq, float *dk, int ld_dk, float *dv, int ld_dv, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-scale deformable attention, forward.  Replaces

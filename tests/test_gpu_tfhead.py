@@ -284,3 +284,42 @@ def test_multi_layer_decoder_device_path_vs_torch_path(layers, aux):
         assert l0.cpu().numpy().tolist() == l1.cpu().numpy().tolist()
         np.testing.assert_allclose(s0.cpu().numpy(), s1.cpu().numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(b0.cpu().numpy(), b1.cpu().numpy(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,nq,nk,H", [(2, 200, 3000, 8), (1, 37, 1001, 2), (3, 256, 517, 4)])
+def test_cross_attention_training_kernels(B, nq, nk, H):
+    """df3d_cross_attention_train / _backward (the decoder layer's cross-attention of a training step: multi_head_attention_forward,
+    transfusion_head.py:478-495) against the float64 composition softmax(scale q k^T) -> dropout -> . v and its autograd
+    gradients: ragged query / key tiles, keys over several chunks; with p = 0.1 the composition uses the SAME mask (the hash over
+    ((b h) q) key, read off a relu_dropout_ call on ones with that seed) and the mask keeps ~90 %."""
+    from dualfusion import ops
+    dev = torch.device("cuda:0")
+    E = H * 16
+    gen = torch.Generator().manual_seed(B * 1000 + nq)
+    q, k, v = (torch.randn((B, n, E), generator=gen) for n in (nq, nk, nk))
+    q = q * 1.5
+    go = torch.randn((B, nq, E), generator=gen)
+    for p in (0.0, 0.1):
+        seed = 4242
+        qa, ka, va = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+        out = ops.cross_attention_train(qa, ka, va, H, 0.25, p, seed=seed)
+        out.backward(go.to(dev))
+        mask = torch.ones((B, H, nq, nk), dtype=torch.float64)
+        if p:
+            kept = ops.relu_dropout_(torch.ones(B * H * nq * nk, device=dev), p, seed=seed).cpu().view(B, H, nq, nk)
+            assert abs(float((kept != 0).double().mean()) - (1 - p)) < 0.01
+            mask = kept.double()
+        qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+        heads = lambda t: t.view(B, t.shape[1], H, 16).transpose(1, 2)
+        pr = torch.softmax(heads(qr) @ heads(kr).transpose(-1, -2) * 0.25, -1) * mask
+        ref = (pr @ heads(vr)).transpose(1, 2).reshape(B, nq, E)
+        ref.backward(go.double())
+        for a, b, name in ((out, ref, "out"), (qa.grad, qr.grad, "dq"), (ka.grad, kr.grad, "dk"), (va.grad, vr.grad, "dv")):
+            err = float((a.detach().cpu().double() - b.detach()).abs().max()) / float(b.detach().abs().max())
+            assert err <= 2e-5, (name, p, err)
+    # the inference entry gives the same output as the training entry without dropout
+    plain = ops.cross_attention(q.to(dev).view(B * nq, E), k.to(dev).view(B * nk, E), v.to(dev).view(B * nk, E), B, H, scale=0.25)
+    with torch.no_grad():
+        again = ops.cross_attention_train(q.to(dev), k.to(dev), v.to(dev), H, 0.25, 0.0)
+    assert torch.equal(plain.view(B, nq, E), again)
