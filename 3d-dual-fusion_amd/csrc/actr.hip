@@ -18,6 +18,7 @@ namespace df3d {
 DF3D_SPLIT_OVERFLOW_TU(actr)
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -491,6 +492,68 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float *__re
   } else {
     for (unsigned long long i = i4; i < n; ++i) out[i] = h[i] != 0.f ? g[i] * scale : 0.f;
   }
+}
+
+// bfloat16 rows (the bf16 mixed-precision mode): eight elements per lane
+__device__ __forceinline__ float rd_bf16_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ unsigned short rd_f32_to_bf16(float f) {       // round to nearest even (finite inputs)
+  const unsigned u = __float_as_uint(f);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void relu_dropout_bf16_kernel(unsigned short *__restrict__ h, const unsigned short *__restrict__ g,
+                                                                unsigned short *__restrict__ out, unsigned long long n,
+                                                                unsigned thr, float scale, unsigned s0, unsigned s1) {
+  const unsigned long long i8 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i8 >= n) return;
+  const int cnt = (int)min((unsigned long long)8, n - i8);
+  unsigned short hv[8], gv[8], ov[8];
+  if (cnt == 8) {
+    *(u32x4 *)hv = *(const u32x4 *)(h + i8);
+    if (BWD) *(u32x4 *)gv = *(const u32x4 *)(g + i8);
+  } else {
+    for (int j = 0; j < cnt; ++j) hv[j] = h[i8 + j], gv[j] = BWD ? g[i8 + j] : (unsigned short)0;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (BWD) {
+      ov[j] = (hv[j] & 0x7fffu) ? rd_f32_to_bf16(rd_bf16_to_f32(gv[j]) * scale) : (unsigned short)0;
+    } else {
+      const float v = rd_bf16_to_f32(hv[j]);
+      ov[j] = v > 0.f && (thr == 0u || rd_keep(i8 + j, s0, s1, thr)) ? rd_f32_to_bf16(v * scale) : (unsigned short)0;
+    }
+  }
+  unsigned short *dst = BWD ? out : h;
+  if (cnt == 8) *(u32x4 *)(dst + i8) = *(const u32x4 *)ov;
+  else
+    for (int j = 0; j < cnt; ++j) dst[i8 + j] = ov[j];
+}
+
+extern "C" int df3d_relu_dropout_bf16(void *h, long long n, float p, unsigned long long seed, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(n >= 0 && p >= 0.f && p < 1.f, "relu_dropout_bf16: p must be in [0, 1) (got %g)", (double)p);
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(h && ((uintptr_t)h & 15) == 0, "relu_dropout_bf16: null or unaligned rows");
+  const unsigned thr = (unsigned)((double)p * 16777216.0);
+  hipLaunchKernelGGL(relu_dropout_bf16_kernel<false>, dim3(cdiv(cdiv(n, 8), 256)), dim3(256), 0, stream, (unsigned short *)h, nullptr,
+                     nullptr, (unsigned long long)n, thr, thr ? (float)(1.0 / (1.0 - (double)thr / 16777216.0)) : 1.f, (unsigned)seed,
+                     (unsigned)(seed >> 32));
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
+}
+
+extern "C" int df3d_relu_dropout_backward_bf16(const void *h, const void *grad, long long n, float p, void *grad_in, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DF3D_CHECK_ARG(n >= 0 && p >= 0.f && p < 1.f, "relu_dropout_backward_bf16: p must be in [0, 1) (got %g)", (double)p);
+  if (n == 0) return DF3D_OK;
+  DF3D_CHECK_ARG(h && grad && grad_in && (((uintptr_t)h | (uintptr_t)grad | (uintptr_t)grad_in) & 15) == 0,
+                 "relu_dropout_backward_bf16: null or unaligned rows");
+  const unsigned thr = (unsigned)((double)p * 16777216.0);
+  hipLaunchKernelGGL(relu_dropout_bf16_kernel<true>, dim3(cdiv(cdiv(n, 8), 256)), dim3(256), 0, stream, (unsigned short *)h,
+                     (const unsigned short *)grad, (unsigned short *)grad_in, (unsigned long long)n, thr,
+                     thr ? (float)(1.0 / (1.0 - (double)thr / 16777216.0)) : 1.f, 0u, 0u);
+  DF3D_LAUNCH_CHECK();
+  return DF3D_OK;
 }
 
 extern "C" int df3d_relu_dropout(float *h, long long n, float p, unsigned long long seed, void *stream_) {

@@ -255,6 +255,8 @@ SIGNATURES = {
     "df3d_frame_head_wait": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_backbone_release": (c_int, [c_void_p]),
     "df3d_actr_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_relu_dropout_bf16": (c_int, [c_void_p, c_longlong, c_float, c_ulonglong, c_void_p]),
+    "df3d_relu_dropout_backward_bf16": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p]),
     "df3d_relu_dropout": (c_int, [c_void_p, c_longlong, c_float, c_ulonglong, c_void_p]),
     "df3d_relu_dropout_backward": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p]),
     "df3d_dropout_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_ulonglong, c_longlong, c_int,

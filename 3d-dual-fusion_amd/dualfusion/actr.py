@@ -154,17 +154,22 @@ class PositionEmbeddingLearnedDepth(nn.Module):
 def _ffn_branch(lin_a, lin_b, x, activation, drop):
     """lin_b(drop(activation(lin_a(x)))): the two linears of a feed-forward block around its [rows x d_ffn] hidden tensor
     (0.5 - 1 GB in a training step).  Under grad:
-      * bf16 mixed precision (ops.CONV_PRECISION == "bf16": BASELINE configs[2] / [3]): the branch under torch.autocast -- hidden
-        rows, their activation / dropout and both products in bfloat16 (half the bytes of every pass, 16-bit matrix rate), the
-        result back in fp32 for the residual LayerNorm; DF3D_FFN_AUTOCAST=0 keeps fp32;
+      * bf16 mixed precision (ops.CONV_PRECISION == "bf16": BASELINE configs[2] / [3]): hidden rows, their activation / dropout
+        and both products in bfloat16 (linear_rows.linear_bf16: half the bytes of every pass, 16-bit matrix rate, the weight
+        gradients as per-sample batched products), the result back in fp32 for the residual LayerNorm; DF3D_FFN_AUTOCAST=0
+        keeps fp32;
       * otherwise with ReLU: activation + dropout as one in-place pass forward and one pass backward without a mask tensor
         (ops.relu_dropout_); the first linear runs on the flattened rows so that its result is a fresh tensor, not a view."""
     from . import ops as _ops
     if torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
         if _ops.CONV_PRECISION == "bf16" and os.environ.get("DF3D_FFN_AUTOCAST", "1") != "0":
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = lin_b(drop(activation(lin_a(x))))
-            return y.float()
+            from .linear_rows import linear_bf16
+            h = linear_bf16(x.reshape(-1, x.shape[-1]), lin_a.weight, lin_a.bias)          # (flattened: a fresh tensor)
+            if activation is F.relu and h.requires_grad and h._base is None and _ops.relu_dropout_supported(h):
+                h = _ops.relu_dropout_(h, drop.p if drop.training else 0.0)
+            else:
+                h = drop(activation(h))
+            return linear_bf16(h.view(x.shape[:-1] + (h.shape[-1],)), lin_b.weight, lin_b.bias).float()
         if activation is F.relu and _ops.relu_dropout_supported(x):
             h = lin_a(x.reshape(-1, x.shape[-1]))
             if h.requires_grad and h.is_contiguous() and h._base is None:

@@ -44,6 +44,44 @@ class _LinearFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _LinearBf16Function(torch.autograd.Function):
+    """Linear layer of the bf16 mixed-precision training mode (BASELINE configs[2] / [3]): operands rounded to bfloat16 (the
+    result stays bfloat16 for the next layer of the feed-forward branch), fp32 accumulation in the library's products.  The
+    weight gradient grad^T x contracts over the ROWS (131 k at the TransFusion shape): as ONE product the library runs it at a
+    few per cent of its rate (442 us for 128 x 1024 outputs), so it is taken per sample -- a batched product over the leading
+    dimension (or over 16 row chunks) -- and the partial results are summed in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x16, w16 = x.to(torch.bfloat16), weight.to(torch.bfloat16)
+        ctx.save_for_backward(x16, w16)
+        ctx.xdtype, ctx.has_bias = x.dtype, bias is not None
+        return torch.nn.functional.linear(x16, w16, None if bias is None else bias.to(torch.bfloat16))
+
+    @staticmethod
+    def backward(ctx, grad):
+        x16, w16 = ctx.saved_tensors
+        g16 = grad.to(torch.bfloat16)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (g16 @ w16).to(ctx.xdtype)
+        if ctx.needs_input_grad[1]:
+            g3, x3 = g16, x16
+            if g3.dim() != 3:
+                g2, x2 = g3.reshape(-1, g3.shape[-1]), x3.reshape(-1, x3.shape[-1])
+                parts = 16 if g2.shape[0] % 16 == 0 and g2.shape[0] >= 16 * 1024 else 1
+                g3, x3 = g2.view(parts, -1, g2.shape[1]), x2.view(parts, -1, x2.shape[1])
+            gw = torch.bmm(g3.transpose(1, 2), x3).sum(0, dtype=torch.float32)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g16.reshape(-1, g16.shape[-1]).sum(0, dtype=torch.float32)
+        return gx, gw, gb
+
+
+def linear_bf16(x, weight, bias=None):
+    """x W^T + b with bfloat16 operands and a bfloat16 result, differentiable (fp32 parameter gradients)."""
+    return _LinearBf16Function.apply(x, weight, bias)
+
+
 def linear(x, weight, bias=None):
     """F.linear with the weight gradient on the row kernel where it applies (CUDA fp32, >= 2048 rows, input channels a multiple
     of 4), else F.linear."""

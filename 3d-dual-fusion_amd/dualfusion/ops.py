@@ -2051,8 +2051,9 @@ def _dropout_seed(device):
 class _ReluDropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, p, seed):
-        rc = _lib.load().df3d_relu_dropout(_ptr(h), h.numel(), float(p), int(seed), _stream())
-        _lib.check(rc, "df3d_relu_dropout")
+        lib = _lib.load()
+        fn = lib.df3d_relu_dropout_bf16 if h.dtype == torch.bfloat16 else lib.df3d_relu_dropout
+        _lib.check(fn(_ptr(h), h.numel(), float(p), int(seed), _stream()), "df3d_relu_dropout")
         ctx.mark_dirty(h)
         ctx.save_for_backward(h)
         ctx.p = float(p)
@@ -2061,23 +2062,25 @@ class _ReluDropout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         (h,) = ctx.saved_tensors
-        grad = grad.contiguous()
+        grad = grad.to(h.dtype).contiguous()
         out = torch.empty_like(grad)
-        rc = _lib.load().df3d_relu_dropout_backward(_ptr(h), _ptr(grad), h.numel(), ctx.p, _ptr(out), _stream())
-        _lib.check(rc, "df3d_relu_dropout_backward")
+        lib = _lib.load()
+        fn = lib.df3d_relu_dropout_backward_bf16 if h.dtype == torch.bfloat16 else lib.df3d_relu_dropout_backward
+        _lib.check(fn(_ptr(h), _ptr(grad), h.numel(), ctx.p, _ptr(out), _stream()), "df3d_relu_dropout_backward")
         return out, None, None
 
 
 def relu_dropout_(h, p=0.0, seed=None):
     """h <- dropout(relu(h), p) IN PLACE (h: a fresh contiguous fp32 CUDA tensor nobody else needs, e.g. a linear layer's
     output), one pass forward, one pass backward, no mask tensor (df3d_relu_dropout).  p = 0: ReLU."""
-    _chk(h, torch.float32, "h")
+    if not (h.is_cuda and h.is_contiguous() and h.dtype in (torch.float32, torch.bfloat16)):
+        raise _lib.Df3dError("relu_dropout_: a contiguous float32 / bfloat16 GPU tensor is required")
     return _ReluDropout.apply(h, float(p), _dropout_seed(h.device) if seed is None else int(seed))
 
 
 def relu_dropout_supported(h):
     """DF3D_RELU_DROPOUT=0 keeps torch's relu + dropout (A/B switch, read per call)."""
-    return (h.is_cuda and h.dtype == torch.float32 and h.is_contiguous() and not torch.is_autocast_enabled()
+    return (h.is_cuda and h.dtype in (torch.float32, torch.bfloat16) and h.is_contiguous() and not torch.is_autocast_enabled()
             and os.environ.get("DF3D_RELU_DROPOUT", "1") != "0")
 
 

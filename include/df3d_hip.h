@@ -822,6 +822,9 @@ int df3d_actr_prep(const float *q, const float *qi, const float *pos, long long 
  * h = the forward's result) takes no mask.  16-byte aligned pointers. */
 int df3d_relu_dropout(float *h, long long n, float p, unsigned long long seed, void *stream);
 int df3d_relu_dropout_backward(const float *h, const float *grad, long long n, float p, float *grad_in, void *stream);
+/* the same over bfloat16 elements (the bf16 mixed-precision mode: hidden rows produced by a bfloat16 product) */
+int df3d_relu_dropout_bf16(void *h, long long n, float p, unsigned long long seed, void *stream);
+int df3d_relu_dropout_backward_bf16(const void *h, const void *grad, long long n, float p, void *grad_in, void *stream);
 /* training (round 6): out = LayerNorm(x + dropout(y, p)) over [rows, C] fp32 rows -- the residual steps of the encoder layers
  * (CP/det3d/models/model_utils/actr_transformer.py:311-312, 330-331, 389-390, 395-396, 416-417) -- in one kernel; also writes the
  * normalised rows `xhat` [rows, C] and `rstd` [rows] for the backward.  keep(i) = the hash of df3d_relu_dropout over the element

@@ -1958,3 +1958,42 @@ def test_dropout_add_layernorm_forward_and_backward(rows, C):
                            (nd.weight.grad, n64.weight.grad, "dgamma"), (nd.bias.grad, n64.bias.grad, "dbeta")):
             err = float((a.detach().cpu().double() - b.detach()).abs().max()) / max(1.0, float(b.detach().abs().max()))
             assert err <= (2e-5 if name in ("dgamma", "dbeta") else 5e-6), (name, p, err)
+
+
+@pytest.mark.gpu
+def test_bf16_feed_forward_branch_pieces():
+    """The bf16 mixed-precision feed-forward branch of a training step (BASELINE configs[2] / [3]): `linear_bf16` (bfloat16
+    operands, fp32 accumulation, the weight gradient as per-sample batched products) against float64 within bfloat16's rounding,
+    and df3d_relu_dropout_bf16 (in place on bfloat16 rows) with the same mask as the fp32 kernel under the same seed."""
+    from dualfusion import ops
+    from dualfusion.linear_rows import linear_bf16
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(17)
+    for shape in ((6, 3001, 128), (32768, 128)):
+        x = torch.randn(shape, generator=gen)
+        w, b = torch.randn((256, 128), generator=gen) * 0.1, torch.randn(256, generator=gen)
+        g = torch.randn(shape[:-1] + (256,), generator=gen)
+        xa, wa, ba = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+        y = linear_bf16(xa, wa, ba)
+        assert y.dtype == torch.bfloat16
+        y.backward(g.to(dev).to(torch.bfloat16))
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+        yr = torch.nn.functional.linear(xr, wr, br)
+        yr.backward(g.double())
+        for a, r, name in ((y, yr, "y"), (xa.grad, xr.grad, "dx"), (wa.grad, wr.grad, "dw"), (ba.grad, br.grad, "db")):
+            assert a.dtype == (torch.bfloat16 if name == "y" else torch.float32)
+            err = float((a.detach().cpu().double() - r.detach()).abs().max()) / float(r.detach().abs().max())
+            assert err <= 2e-2, (name, shape, err)                                     # 8 significant bits per operand
+    h = torch.randn((4099, 1024), generator=gen)
+    h16 = h.to(dev).to(torch.bfloat16)
+    want = ops.relu_dropout_(h16.float(), 0.1, seed=77)                                # fp32 kernel on the rounded values
+    got = ops.relu_dropout_((h16.clone().requires_grad_(True)) * 1, 0.1, seed=77)
+    assert got.dtype == torch.bfloat16 and torch.equal(got.detach().float() != 0, want != 0)
+    assert float((got.detach().float() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
+    gg = torch.randn(h.shape, generator=gen).to(dev).to(torch.bfloat16)
+    leaf = h16.clone().requires_grad_(True)
+    out = ops.relu_dropout_(leaf * 1, 0.1, seed=77)
+    out.backward(gg)
+    scale = 1.0 / (1.0 - np.floor(0.1 * 16777216.0) / 16777216.0)
+    ref = torch.where(out.detach() != 0, gg.float() * scale, torch.zeros((), device=dev))
+    assert leaf.grad.dtype == torch.bfloat16 and float((leaf.grad.float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
