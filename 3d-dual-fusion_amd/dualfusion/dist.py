@@ -362,3 +362,52 @@ class GradBucketReducer(object):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+class BucketAdamW(object):
+    """AdamW (TF/configs/transfusion_nusc_voxel_F.py:302: `optimizer = dict(type='AdamW', lr=..., weight_decay=0.01)`) over the
+    buckets of a `GradBucketReducer` instead of over ~400 parameter tensors: every parameter is re-seated as a view of ONE flat
+    buffer per bucket (same offsets as its gradient view), the optimizer state is two flat buffers per bucket, and a step is one
+    fused launch per bucket on contiguous memory (the multi-tensor kernel over the individual tensors took 0.8 ms of the
+    27 ms cp_fusion step: 28 chunked launches).  Same arithmetic as `torch.optim.AdamW` element by element.
+    Parameters without a gradient in a step see the zeros the reducer keeps for them (what DistributedDataParallel hands the
+    optimizer for unused parameters): their moments decay and weight decay applies.
+    The views keep their own version counters, which an in-place update of the flat buffer does not move; `step()` bumps them
+    (host side) so that every (data_ptr, _version)-keyed weight pack of the library sees the update.
+    Re-seating happens once, here: move / cast the model BEFORE building the reducer and this optimizer."""
+
+    def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.reducer = reducer
+        self.flat = []
+        with torch.no_grad():
+            for b in reducer.buckets:
+                fp = torch.empty_like(b["flat"])
+                for p in b["params"]:
+                    off = b["offsets"][id(p)]
+                    v = fp[off:off + p.numel()].view(p.shape)
+                    v.copy_(p.detach())
+                    p.data = v
+                P = torch.nn.Parameter(fp, requires_grad=True)
+                P.grad = b["flat"]
+                self.flat.append(P)
+        on_gpu = bool(self.flat) and self.flat[0].is_cuda
+        self.inner = torch.optim.AdamW(self.flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=on_gpu or None)
+
+    @property
+    def param_groups(self):
+        return self.inner.param_groups
+
+    def clip_grad_norm(self, max_norm, norm_type=2):
+        """mmcv `OptimizerHook.clip_grads` over the flat gradient buffers (after `reducer.finish()`): one norm per bucket."""
+        return torch.nn.utils.clip_grad_norm_(self.flat, max_norm=max_norm, norm_type=norm_type,
+                                              foreach=(bool(self.flat) and self.flat[0].is_cuda) or None)
+
+    def step(self):
+        for P, b in zip(self.flat, self.reducer.buckets):
+            P.grad = b["flat"]
+        self.inner.step()
+        torch.autograd.graph.increment_version(self.reducer.params)
+
+    def zero_grad(self, set_to_none=True):
+        self.reducer.zero_grad()
+

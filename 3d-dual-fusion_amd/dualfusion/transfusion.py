@@ -196,8 +196,11 @@ class TransFusionDetector(nn.Module):
         if reducer is not None:
             reducer.finish()
         if grad_clip is not None:
-            params = reducer.params if reducer is not None else [p for p in self.parameters() if p.requires_grad]
-            log_vars['grad_norm'] = clip_grads(params, **grad_clip)
+            if hasattr(optimizer, "clip_grad_norm"):            # dist.BucketAdamW: over its flat gradient buffers
+                log_vars['grad_norm'] = optimizer.clip_grad_norm(**grad_clip)
+            else:
+                params = reducer.params if reducer is not None else [p for p in self.parameters() if p.requires_grad]
+                log_vars['grad_norm'] = clip_grads(params, **grad_clip)
         if optimizer is not None:
             optimizer.step()
         return loss.detach(), {k: v.detach() for k, v in log_vars.items()}

@@ -113,7 +113,10 @@ class TransFusionWorkload(object):
         params = [p for p in self.detector.parameters() if p.requires_grad]
         self.reducer = D.GradBucketReducer(params)
         # TF/configs/transfusion_nusc_voxel_F.py:302-303
-        self.optimizer = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+        if os.environ.get("DF3D_BUCKET_ADAMW", "1") == "1":
+            self.optimizer = D.BucketAdamW(self.reducer, lr=1e-4, weight_decay=0.01)   # one fused launch per 16 MB bucket
+        else:
+            self.optimizer = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
         self.grad_clip = dict(max_norm=0.1, norm_type=2)
         self.n_params = sum(p.numel() for p in params)
 

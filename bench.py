@@ -200,7 +200,10 @@ class CenterPointWorkload(object):
         self.model.train()
         params = [p for p in self.model.parameters() if p.requires_grad]
         self.reducer = D.GradBucketReducer(params)      # 16 MB buckets: three for this detector
-        self.optimizer = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+        if os.environ.get("DF3D_BUCKET_ADAMW", "1") == "1":
+            self.optimizer = D.BucketAdamW(self.reducer, lr=1e-4, weight_decay=0.01)   # one fused launch per 16 MB bucket
+        else:
+            self.optimizer = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
         self.n_params = sum(p.numel() for p in params)
 
     def close(self):

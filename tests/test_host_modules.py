@@ -257,3 +257,39 @@ def test_voxel_rcnn_basic_gate_module_contract():
     assert torch.equal(c[1, :, 0, 0], feats[3]) and torch.equal(c[1, :, 3, 7], feats[4])
     out = gate([torch.ones(2, 256, 4, 8)], [x], dict(batch_size=2, image_hw=(40, 80)), project=lambda t, s: (None, uv))
     assert tuple(out[0].shape) == (2, 256, 4, 8) and bool(((out[0] > 0) & (out[0] < 1)).all())
+
+
+def test_bucket_adamw_equals_torch_adamw():
+    """dist.BucketAdamW (one flat parameter / state buffer per gradient bucket) against torch.optim.AdamW on the same toy model:
+    same parameters after three steps incl. gradient clipping; the re-seated parameters' version counters move with every step
+    (the library's weight packs are keyed by them); a parameter without a gradient sees zeros."""
+    import copy
+    from dualfusion import dist as D
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 4), torch.nn.LayerNorm(4))
+    ref = copy.deepcopy(net)
+    red = D.GradBucketReducer(list(net.parameters()), bucket_mb=0.0002)          # several buckets
+    assert len(red.buckets) > 1
+    opt = D.BucketAdamW(red, lr=1e-2, weight_decay=0.05)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.05)
+    for step in range(3):
+        x = torch.randn(5, 6)
+        red.zero_grad()
+        ropt.zero_grad(set_to_none=True)
+        net(x).square().sum().backward()
+        ref(x).square().sum().backward()
+        red.finish()
+        n1 = opt.clip_grad_norm(max_norm=0.5)
+        n0 = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=0.5)
+        assert abs(float(n1) - float(n0)) <= 1e-5 * float(n0)
+        before = [p._version for p in net.parameters()]
+        opt.step()
+        ropt.step()
+        assert all(p._version > v for p, v in zip(net.parameters(), before))
+        for a, b in zip(net.parameters(), ref.parameters()):
+            assert float((a - b).abs().max()) <= 2e-5, step            # (lr 1e-2; the clip factor differs in its last bits)
+    # the parameters ARE views of the optimizer's flat buffers
+    for P, b in zip(opt.flat, red.buckets):
+        for p in b["params"]:
+            off = b["offsets"][id(p)]
+            assert p.data_ptr() == P.data_ptr() + off * P.element_size()
