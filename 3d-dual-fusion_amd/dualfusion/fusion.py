@@ -107,6 +107,43 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
         20-160 ms per call forward / backward."""
         return img_feat * self.attention_rows(img_feat, canvases).unsqueeze(1)
 
+    def attention_sparse(self, img_feat, rows, winners):
+        """attention_rows WITHOUT the dense canvases (training, round 6).  The gate is linear up to its sigmoid (see `folded`):
+        the tap responses of (point term + image summary) at a pixel are
+          taps[pixel, t] = sum_idx T_idx[t] . (winner row of scale idx at the pixel)  +  g[t] . summary(pixel)  +  k[t],
+        T_idx = Wsb (R2 R_idx) [9, C_idx + 3], g = row sums of Wsb, k = Wsb . (folded biases), and the 3 x 3 convolution is the
+        sum of the nine shifted tap maps (zero padding: as attention_rows).  So per scale ONE product [n_idx, C_idx + 3] x
+        [C_idx + 3, 9] on the voxel rows, a gather of the winners and a write of their nine responses at their pixels (a pixel
+        has one winner per scale: no accumulation, the same bits in every run) replace the [NI, H W, 131] canvases, four
+        products over 240 k pixel rows and their backward.
+        rows: {idx: [n_idx, C_idx + 3] voxel rows + inverse points}; winners: {idx: (image, pixel, row) of every occupied pixel}.
+        Same function of the parameters and rows as attention_rows (summation order aside); differentiable in both."""
+        NI, Ci, H, W = img_feat.shape
+        last = self.voxel_idx[-1]
+        R2 = self.reduced_dim2.weight[:, :, 0, 0]
+        Wsb = self.spatial_basic.weight[0].permute(1, 2, 0).reshape(9, -1)                      # [tap = ty * 3 + tx, channel]
+        const = self.reduced_dim2.bias
+        summary = _ops.channel_first_linear(img_feat.reshape(NI, Ci, H * W), self.reduced_dim3.weight[:, :, 0, 0])   # [NI, 1, HW]
+        taps = None
+        for idx in self.voxel_idx:
+            if len(self.voxel_idx) > 1 and idx != last:
+                cv = self.reduced_dim[idx]
+                T = Wsb @ (R2 @ cv.weight[:, :, 0, 0])
+                const = const + R2 @ cv.bias
+            else:
+                T = Wsb @ R2
+            img_w, pix_w, row_w = winners[idx]
+            resp = rows[idx] @ T.t()                                                             # [n_idx, 9]
+            t_idx = resp.new_zeros((NI * H * W, 9)).index_put((img_w * (H * W) + pix_w,), resp[row_w])
+            taps = t_idx if taps is None else taps + t_idx
+        dense = (summary.reshape(-1, 1) + self.reduced_dim3.bias) * Wsb.sum(1) + Wsb @ const   # [NI H W, 9]
+        taps = F.pad((taps + dense).view(NI, H, W, 9), (0, 0, 1, 1, 1, 1))                       # zero padding of the 3x3
+        y = self.spatial_basic.bias.view(1, 1, 1)
+        for ty in range(3):
+            for tx in range(3):
+                y = y + taps[:, ty:ty + H, tx:tx + W, ty * 3 + tx]
+        return torch.sigmoid(y)
+
     def attention_rows(self, img_feat, canvases):
         """The gate itself, [NI, H, W] (forward_rows without the product with the image)."""
         NI, Ci, H, W = img_feat.shape
@@ -597,7 +634,11 @@ class VoxelWithPointProjection(nn.Module):
         factored = (self.ifat_cfg is not None and os.environ.get("DF3D_TRAIN_GATED", "0") != "1" and not imgs.requires_grad
                     and tuple(in_conv.kernel_size) == (1, 1) and tuple(in_conv.stride) == (1, 1) and in_conv.groups == 1
                     and len(self.pfat.input_proj) == 1 and self.pfat.feature_modal in ('image', 'hybrid'))
-        if self.ifat_cfg is not None:
+        if self.ifat_cfg is not None and factored and os.environ.get("DF3D_TRAIN_GATE_SPARSE", "1") == "1":
+            # the gate from the voxel rows themselves (no [NI, H W, C + 3] canvases: Basicgate...attention_sparse)
+            rows = {sidx: torch.cat([encoded_voxel_list[sidx].features, proj[sidx][2]], 1) for sidx in self.ifat.voxel_idx}
+            att = self.ifat.attention_sparse(imgs, rows, winners)
+        elif self.ifat_cfg is not None:
             canvases = {}
             for sidx in self.ifat.voxel_idx:
                 x = encoded_voxel_list[sidx]
