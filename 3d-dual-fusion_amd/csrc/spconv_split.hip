@@ -1819,15 +1819,19 @@ static int launch_os_bf16(const SplitConvArgs &a, hipStream_t stream) {
 }
 
 static bool bf16_shape_ok(int cin, int cout) {
-  return (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 64 || cout == 128)) ||
-         (cin == 128 && (cout == 128 || cout == 256)) || (cin == 256 && (cout == 128 || cout == 256));
+  // (128 -> 64 and 64 -> 32: the input gradients of the strided 64 -> 128 / 32 -> 64 layers -- round 6: they fell back to the
+  // exact-fp32 kernel, 649 us of the TransFusion training step)
+  return (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 32 || cout == 64 || cout == 128)) ||
+         (cin == 128 && (cout == 64 || cout == 128 || cout == 256)) || (cin == 256 && (cout == 128 || cout == 256));
 }
 
 static int launch_os_bf16_any(int cin, int cout, const SplitConvArgs &a, hipStream_t stream) {
   if (cin == 32 && cout == 32) return launch_os_bf16<32, 32>(a, stream);
   if (cin == 32 && cout == 64) return launch_os_bf16<32, 64>(a, stream);
+  if (cin == 64 && cout == 32) return launch_os_bf16<64, 32>(a, stream);
   if (cin == 64 && cout == 64) return launch_os_bf16<64, 64>(a, stream);
   if (cin == 64 && cout == 128) return launch_os_bf16<64, 128>(a, stream);
+  if (cin == 128 && cout == 64) return launch_os_bf16<128, 64>(a, stream);
   if (cin == 128 && cout == 128) return launch_os_bf16<128, 128>(a, stream);
   if (cin == 128 && cout == 256) return launch_os_bf16<128, 256>(a, stream);
   if (cin == 256 && cout == 128) return launch_os_bf16<256, 128>(a, stream);

@@ -760,7 +760,8 @@ def test_msda_backward_full_size_properties(dev):
 
 # ------------------------------------------------------------------------- bf16 convolution (BASELINE configs[2])
 @pytest.mark.parametrize("cin,cout,n_seeds,ks,st,subm", [(128, 128, 14, 3, 1, 1), (64, 64, 9, 3, 1, 1), (32, 64, 9, 3, 2, 0),
-                                                        (64, 128, 6, 3, 2, 0), (32, 32, 4, 3, 1, 1)])
+                                                        (64, 128, 6, 3, 2, 0), (32, 32, 4, 3, 1, 1), (128, 64, 6, 3, 1, 1),
+                                                        (64, 32, 9, 3, 1, 1)])
 def test_conv_bf16_equals_fp32_kernel_on_rounded_operands(dev, cin, cout, n_seeds, ks, st, subm):
     """df3d_sparse_conv_bf16 (bf16 rows, bf16 weights, fp32 accumulate, fused BN / residual / ReLU) against the exact
     fp32 kernel fed the SAME bf16-rounded operands: products of bf16 numbers are exact in fp32, so only the
