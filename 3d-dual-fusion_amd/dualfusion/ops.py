@@ -799,6 +799,14 @@ def sparse_conv_backward(features, filters, grad_out, nbr, subm, inv=None, bf16=
         gs, inv_s, sc = split_rows_scaled(grad_out, cin)
         g_in, _ = sparse_conv_split(gs, conv_pack_weights(wt), inv, n_in, cout, cin, scale=inv_s, emit_split=False)
         return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr, grad_scale=sc)
+    if (CONV_PRECISION == "split" and not bf16 and cout % 8 == 0 and cin > 128 and cin % 128 == 0
+            and conv_split_supported(K, cout, 128) and os.environ.get("DF3D_GRAD_SCALED", "1") != "0"):
+        # the same for many input channels (the head's shared conv 512 -> 128, transposed): 128-column blocks of one grouped launch
+        # over the scaled two-part gradient rows (round 6: the three-part forms were 1.8 ms of the TransFusion training step)
+        gs, inv_s, sc = split_rows_scaled(grad_out, cin)
+        blocks = wt.view(K, cout, cin // 128, 128).permute(2, 0, 1, 3).contiguous()
+        g_in, _ = conv_rows_split(gs, cout, 0, conv_pack_weights_groups(blocks), 128, cin // 128, inv, n_in, scale=inv_s)
+        return g_in, sparse_conv_grad_filters(features.contiguous(), grad_out, nbr, grad_scale=sc)
     with grad_precision():
         if bf16 and conv_bf16_supported(K, cout, cin):
             g_in, _ = sparse_conv_bf16(rows_to_bf16(grad_out), conv_pack_weights_bf16(wt), inv, n_in, cout, cin, want_f32=True,
