@@ -66,7 +66,6 @@ typedef _Float16 df3d_f16x8 __attribute__((ext_vector_type(8)));
 
 static __device__ unsigned g_split_overflow_tu;    // one per translation unit (no relocatable device code): see split_overflow_*
 
-// a pair of fp32 values -> packed bf16 (round to nearest even, x0 in the low 16 bits): the operand format of the bf16 mode
 // dropout keep decision of element i under a call's 64-bit seed (s0 = low, s1 = high word): a counter-based hash, the same mask
 // whatever the launch shape; thr = p * 2^24 against 24 uniform bits (df3d_relu_dropout, df3d_dropout_add_layernorm,
 // df3d_cross_attention_train)
@@ -79,6 +78,7 @@ __device__ __forceinline__ bool rd_keep(unsigned long long i, unsigned s0, unsig
   return (h >> 8) >= thr;
 }
 
+// a pair of fp32 values -> packed bf16 (round to nearest even, x0 in the low 16 bits): the operand format of the bf16 mode
 __device__ __forceinline__ unsigned bf16_pair(float x0, float x1) {
   df3d_f32x2 v = {x0, x1};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, df3d_bf16x2));
