@@ -33,6 +33,29 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+class _TallMatmul(torch.autograd.Function):
+    """a [rows, k] @ b [k, n] for a few columns and ~10^5 rows.  The gradient of b contracts over the rows: as one library product
+    ([2, 240300] x [240300, 9]: 0.56 ms) or as autograd's column reductions (0.2 ms each) it costs more than the layer it belongs
+    to; here per chunk of rows (a batched product) and a sum over the chunks."""
+
+    @staticmethod
+    def forward(ctx, a, b, chunks):
+        ctx.save_for_backward(a, b)
+        ctx.chunks = chunks if a.shape[0] % max(chunks, 1) == 0 else 1
+        return a @ b
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = g @ b.t()
+        if ctx.needs_input_grad[1]:
+            P = ctx.chunks
+            gb = torch.bmm(a.view(P, -1, a.shape[1]).transpose(1, 2), g.reshape(P, -1, g.shape[1])).sum(0)
+        return ga, gb, None
+
+
 class Basicgate_patch_iv_multivoxel(nn.Module):
     """Image-side gate (attention.py:8-61): voxel features of the scales in `voxel_idx` are dropped
     on the image plane, mixed by 1x1 convs, added to a 1-channel image summary and turned into a
@@ -136,7 +159,10 @@ class Basicgate_patch_iv_multivoxel(nn.Module):
             resp = rows[idx] @ T.t()                                                             # [n_idx, 9]
             t_idx = resp.new_zeros((NI * H * W, 9)).index_put((img_w * (H * W) + pix_w,), resp[row_w])
             taps = t_idx if taps is None else taps + t_idx
-        dense = (summary.reshape(-1, 1) + self.reduced_dim3.bias) * Wsb.sum(1) + Wsb @ const   # [NI H W, 9]
+        # g[t] . summary(pixel) + k[t] as ONE product [NI H W, 2] x [2, 9]: its backward w.r.t. g and k is then a product over the
+        # 240 k pixel rows too (autograd's broadcast form reduced three [240300, 9] tensors column-wise: 0.2 ms each)
+        s1 = torch.cat([summary.reshape(-1, 1) + self.reduced_dim3.bias, summary.new_ones((NI * H * W, 1))], 1)
+        dense = _TallMatmul.apply(s1, torch.stack([Wsb.sum(1), Wsb @ const], 0), NI * H)        # [NI H W, 9]
         taps = F.pad((taps + dense).view(NI, H, W, 9), (0, 0, 1, 1, 1, 1))                       # zero padding of the 3x3
         y = self.spatial_basic.bias.view(1, 1, 1)
         for ty in range(3):

@@ -2565,6 +2565,8 @@ class _ChannelFirstLinear(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
+        if weight.shape[0] == 1 and os.environ.get("DF3D_GATE_DOT", "1") == "1":
+            g = g.contiguous()                                 # (one map per image: 1 MB; the dot kernel below wants it dense)
         gx = torch.bmm(weight.t().unsqueeze(0).expand(g.shape[0], -1, -1), g) if ctx.needs_input_grad[0] else None
         N, Cin, S = x.shape
         d = _row_split(S)
