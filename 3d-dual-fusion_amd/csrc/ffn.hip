@@ -457,13 +457,14 @@ extern "C" int df3d_ffn_fused_jobs(const df3d_ffn_job *j, int njobs, int d_model
   FfnJobs jobs;
   memset(&jobs, 0, sizeof(jobs));
   long long max_rows = 0;
+  static const int dbg = getenv("DF3D_FFN_DBG") ? atoi(getenv("DF3D_FFN_DBG")) : 0;      // tuning aid (see FfnArgs::dbg)
   for (int i = 0; i < njobs; ++i) {
     DF3D_CHECK_ARG(j[i].rows <= 0 || (j[i].x && j[i].packed && j[i].b1 && j[i].b2 && j[i].out),
                    "ffn_fused_jobs: job %d has a null argument", i);
     DF3D_CHECK_ARG((j[i].ln_weight == nullptr) == (j[i].ln_bias == nullptr),
                    "ffn_fused_jobs: LayerNorm needs weight and bias");
     jobs.s[i] = {j[i].x, (const u32x4 *)j[i].packed, j[i].b1, j[i].b2, j[i].residual, j[i].ln_weight, j[i].ln_bias,
-                 j[i].eps, j[i].out, j[i].rows > 0 ? j[i].rows : 0, d_ffn, 0, g_ffn_bf16};
+                 j[i].eps, j[i].out, j[i].rows > 0 ? j[i].rows : 0, d_ffn, dbg, g_ffn_bf16};
     if (j[i].rows > max_rows) max_rows = j[i].rows;
   }
   if (max_rows <= 0) return DF3D_OK;
