@@ -209,6 +209,56 @@ def test_gradient_reduction_two_ranks(tmp_path):
         assert res["buckets"] >= 2 and res["unused_zero"] and res["views"], res
 
 
+def test_bucket_adamw_two_ranks_equals_one_rank_on_the_union_batch(tmp_path):
+    """GradBucketReducer + BucketAdamW (parameters and AdamW state as one flat buffer per bucket) over two ranks, each with half
+    of a batch: after three steps (with gradient clipping over the flat buffers) both ranks hold the SAME parameters, equal to
+    those of one process that ran torch.optim.AdamW on the whole batch (mean loss)."""
+    worker = textwrap.dedent("""
+        import os, sys, json, copy
+        sys.path.insert(0, os.path.join(%r, "3d-dual-fusion_amd"))
+        import torch
+        from dualfusion import dist as D
+        rank, local, world = D.init_from_env("gloo")
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 4), torch.nn.LayerNorm(4))
+        ref = copy.deepcopy(net)
+        red = D.GradBucketReducer(list(net.parameters()), bucket_mb=0.0002)
+        opt = D.BucketAdamW(red, lr=1e-2, weight_decay=0.05)
+        ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.05)
+        gen = torch.Generator().manual_seed(1)
+        for step in range(3):
+            x = torch.randn((8, 6), generator=gen)                 # the same on both ranks; rank r takes rows [4 r, 4 r + 4)
+            red.zero_grad()
+            net(x[4 * rank:4 * rank + 4]).square().mean().backward()
+            red.finish()
+            opt.clip_grad_norm(max_norm=0.5)
+            opt.step()
+            ropt.zero_grad(set_to_none=True)
+            ref(x).square().mean().backward()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=0.5)
+            ropt.step()
+        err = max(float((a - b).abs().max()) for a, b in zip(net.parameters(), ref.parameters()))
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        torch.distributed.all_gather(both, flat)
+        with open(os.path.join(os.environ["DF3D_TEST_OUT"], "a%%d.json" %% rank), "w") as f:
+            json.dump({"err": err, "same": bool(torch.equal(both[0], both[1])), "buckets": len(red.buckets)}, f)
+        D.barrier()
+        torch.distributed.destroy_process_group()
+    """) % ROOT
+    script = tmp_path / "w.py"
+    script.write_text(worker)
+    sys.path.insert(0, os.path.join(ROOT, "3d-dual-fusion_amd"))
+    from dualfusion import dist as D
+    rc = D.launch_ranks(2, str(script), [], env=dict(os.environ, OMP_NUM_THREADS="1", DF3D_TEST_OUT=str(tmp_path)),
+                        timeout=300)
+    assert rc == 0
+    import json
+    for r in (0, 1):
+        res = json.load(open(os.path.join(str(tmp_path), "a%d.json" % r)))
+        assert res["err"] < 2e-5 and res["same"] and res["buckets"] >= 2, res
+
+
 def test_gradient_buckets_rank_dependent_unused_parameters(tmp_path):
     """the set of parameters without a gradient differs between the ranks (a data-dependent branch: rank 0
     skips the LAST layer's bucket, rank 1 the FIRST layer's).  Buckets are launched strictly in index order, so both ranks
