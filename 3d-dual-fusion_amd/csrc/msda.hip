@@ -624,7 +624,7 @@ extern "C" int df3d_ms_deform_attn_backward_binned(const float *value, const int
   DF3D_CHECK_ARG(D == MB_D && P <= 16 && Lq < (1 << 28), "ms_deform_attn_backward_binned: head width %d / %d points not served", D, P);
   const int S = H * W, C = M * D, tx = cdiv(W, MB_T), ty = cdiv(H, MB_T), tiles = tx * ty;
   DF3D_CHECK_ARG((size_t)tiles * M <= 7680, "ms_deform_attn_backward_binned: %d tiles x %d heads exceed the LDS budget", tiles, M);
-  DF3D_CHECK_ARG(N <= 65535, "ms_deform_attn_backward_binned: %d maps", N);
+  DF3D_CHECK_ARG(N <= 65535 && (long long)Lq * M * P < (1LL << 31), "ms_deform_attn_backward_binned: %d maps x %d queries", N, Lq);
   if (N == 0) return DF3D_OK;
   DF3D_CHECK_ARG(value && spatial_shapes && level_start_index && grad_value, "ms_deform_attn_backward_binned: null argument");
   if (Lq == 0) {

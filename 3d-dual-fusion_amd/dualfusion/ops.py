@@ -1785,7 +1785,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     gv = torch.empty_like(value)
     gl = torch.empty_like(sampling_locations)
     ga = torch.empty_like(attention_weights)
-    if L == 1 and D == 16 and P <= 16 and Lq < (1 << 28) and os.environ.get("DF3D_MSDA_BWD", "binned") != "atomic":
+    if (L == 1 and D == 16 and P <= 16 and Lq < (1 << 28) and Lq * M * P < (1 << 31)
+            and os.environ.get("DF3D_MSDA_BWD", "binned") != "atomic"):
         H, W = level_shapes_on_host(spatial_shapes)[0]
         if H * W == S and ((H + 7) // 8) * ((W + 7) // 8) * M <= 7680 and N <= 65535:
             # one single-level map, 16-channel heads: the value gradient as tile-wise matrix products, no global atomics
