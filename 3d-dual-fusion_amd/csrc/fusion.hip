@@ -410,13 +410,23 @@ __global__ __launch_bounds__(256) void gate_scatter_rows_kernel(const float *__r
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.f;
   const float *f = feat + (size_t)i * C;
-  for (int c = 0; c < C; c += 4) {
-    const float4 v = *(const float4 *)(f + c);
-    const float x[4] = {v.x, v.y, v.z, v.w};
+  // (round 6: eight 16-byte loads of the row in flight per pass -- with one load per pass the few winner lanes of a wave walked
+  // 32 dependent L2 round trips per 128-channel row: 55 us for 20 k rows; same summation order)
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    float4 v[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int u = 0; u < 8; ++u) v[u] = c0 + 4 * u < C ? *(const float4 *)(f + c0 + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) acc[k] = fmaf(x[j], Tl[(c + j) * 9 + k], acc[k]);
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + 4 * u;
+      if (c < C) {
+        const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc[k] = fmaf(x[j], Tl[(c + j) * 9 + k], acc[k]);
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
