@@ -114,7 +114,10 @@ class MultiheadAttention(nn.Module):
         E = self.embed_dim
         w, b = self.in_proj_weight, self.in_proj_bias
         bs = (None, None, None) if b is None else (b[:E], b[E:2 * E], b[2 * E:])
-        return self.attend(F.linear(query, w[:E], bs[0]), F.linear(key, w[E:2 * E], bs[1]), F.linear(value, w[2 * E:], bs[2]))
+        # (the key / value projections see the whole BEV map: under grad their weight gradients contract over B * H * W rows,
+        # which the row kernel of linear_rows takes; otherwise this is F.linear)
+        from .linear_rows import linear as _lin
+        return self.attend(F.linear(query, w[:E], bs[0]), _lin(key, w[E:2 * E], bs[1]), _lin(value, w[2 * E:], bs[2]))
 
 
 class TransformerDecoderLayer(nn.Module):
