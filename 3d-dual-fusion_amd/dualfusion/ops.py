@@ -2584,12 +2584,12 @@ class _ChannelFirstLinear(torch.autograd.Function):
                 gw = torch.bmm(x, g.transpose(1, 2)).sum(0).t()
         elif d and S // d >= 8 and g.is_contiguous() and x.is_contiguous():
             nc = S // d
-            gw = None
-            for n in range(N):
+            parts = torch.empty((N * nc, g.shape[1], Cin), dtype=g.dtype, device=g.device)
+            for n in range(N):                                             # (one product per map into its slice, ONE sum at the end)
                 gc = g[n].view(-1, nc, d).permute(1, 0, 2)                 # [chunks, Cout, d], strides (d, S, 1)
                 xc = x[n].view(Cin, nc, d).permute(1, 2, 0)                # [chunks, d, Cin]
-                part = torch.bmm(gc, xc).sum(0)
-                gw = part if gw is None else gw + part
+                torch.bmm(gc, xc, out=parts[n * nc:(n + 1) * nc])
+            gw = parts.sum(0)
         else:
             gw = torch.matmul(g, x.transpose(1, 2)).sum(0)
         return gx, gw
